@@ -1,0 +1,232 @@
+/*
+ * shc_batch.h — C ABI of the MI355X batched leg-control engine (libshc_batch.so).
+ *
+ * The reference (csiro-robotics/syropod_highlevel_controller, OpenSHC v0.5.11) has NO plugin / FFI
+ * boundary: it is one executable whose per-cycle work is the C++ call sequence
+ *     PoseController::updateCurrentPose   (src/state_controller.cpp:167)
+ *     AdmittanceController::updateStiffness / updateAdmittance   (:177, :179)
+ *     WalkController::updateWalk          (:429)
+ *     PoseController::updateStance        (:442)
+ *     Model::updateModel                  (:445)
+ * on ONE robot.  This header is the boundary a maintainer would bind instead: the same
+ * quantities, batched over `n_instances` independent robots, plain pointers and sizes only.
+ * Each entry point cites the reference interface it replaces.
+ *
+ * All floating point is IEEE double (the reference is `double` throughout).  All arrays passed
+ * through this ABI are HOST or DEVICE pointers as stated per call; layouts are instance-major
+ * ("AoS over instances"): element (i, leg, k) of an array with per-leg width K lives at
+ * [(i * leg_count + leg) * K + k].  Internally the engine keeps structure-of-arrays state in HBM
+ *  and transposes at this boundary.
+ */
+#ifndef SHC_BATCH_H
+#define SHC_BATCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHC_MAX_LEGS 8      /* reference bound: parameters_and_states.h:298 (joint_parameters[8][6]) */
+#define SHC_MAX_JOINTS 6    /* reference bound: parameters_and_states.h:298 */
+#define SHC_MAX_LINKS 7     /* reference bound: parameters_and_states.h:299 (base link + one per joint) */
+#define SHC_MAX_AUTO_POSERS 8
+#define SHC_N_BEARINGS 9    /* 0..360 step 45 (model.h:22 BEARING_STEP) */
+
+/* Status codes (the reference has no error returns: ROS_FATAL + shutdown). */
+enum {
+  SHC_OK = 0,
+  SHC_ERR_INVALID_ARG = 1,
+  SHC_ERR_NO_DEVICE = 2,      /* no HIP device / kernel image: the product path never falls back to CPU */
+  SHC_ERR_HIP = 3,
+  SHC_ERR_UNSUPPORTED = 4,    /* feature of the reference outside the accelerated path (rough terrain, manual legs) */
+  SHC_ERR_UNSTABLE = 5        /* pose_controller.cpp:1230 "IMU rotation compensation became unstable" */
+};
+
+/* parameters_and_states.h:99 */
+enum { SHC_WALK_STARTING = 0, SHC_WALK_MOVING = 1, SHC_WALK_STOPPING = 2, SHC_WALK_STOPPED = 3 };
+/* parameters_and_states.h:111 */
+enum { SHC_STEP_SWING = 0, SHC_STEP_STANCE = 1, SHC_STEP_FORCE_STANCE = 2, SHC_STEP_FORCE_STOP = 3 };
+/* parameters_and_states.h:123 */
+enum { SHC_POSING = 0, SHC_STOP_POSING = 1, SHC_POSING_COMPLETE = 2 };
+/* parameters_and_states.h:150 PoseResetMode */
+enum {
+  SHC_NO_RESET = 0, SHC_Z_AND_YAW_RESET = 1, SHC_X_AND_Y_RESET = 2, SHC_PITCH_AND_ROLL_RESET = 3,
+  SHC_ALL_RESET = 4, SHC_IMMEDIATE_ALL_RESET = 5
+};
+enum { SHC_VEL_THROTTLE = 0, SHC_VEL_REAL = 1 }; /* default.yaml:89 velocity_input_mode */
+
+/* One joint: config/default.yaml:31 "<LEG>_<joint>_joint_parameters" (model.cpp:1032-1036). */
+typedef struct shc_joint_params {
+  double min, max, offset, unpacked, max_vel;
+} shc_joint_params;
+
+/* One link: config/default.yaml:51 "<LEG>_<link>_link_parameters" (model.cpp:998-1001). */
+typedef struct shc_link_params {
+  double d, theta, r, alpha;
+} shc_link_params;
+
+/*
+ * The subset of `struct Parameters` (parameters_and_states.h:271-381) + gait.yaml + auto_pose.yaml
+ * that the accelerated path reads.  One morphology + one gait for the whole batch (mixed
+ * batches = several engines / bins).
+ */
+typedef struct shc_params {
+  /* control parameters (default.yaml:9-15) */
+  double time_delta;
+  int32_t manual_posing, auto_posing, rough_terrain_mode, admittance_control, inclination_posing, imu_posing;
+  /* model (default.yaml:25-78) */
+  int32_t leg_count;
+  int32_t leg_dof[SHC_MAX_LEGS];
+  shc_joint_params joint[SHC_MAX_LEGS][SHC_MAX_JOINTS];
+  shc_link_params link[SHC_MAX_LEGS][SHC_MAX_LINKS]; /* link[l][0] = base link */
+  int32_t clamp_joint_positions, clamp_joint_velocities;
+  /* walker (default.yaml:82-106) */
+  double body_clearance, step_frequency, swing_height, swing_width, step_depth, stance_span_modifier;
+  int32_t velocity_input_mode;
+  double stance_position[SHC_MAX_LEGS][2];
+  int32_t overlapping_walkspaces, force_normal_touchdown, gravity_aligned_tips;
+  /* poser (default.yaml:110-118) */
+  double time_to_start;
+  double rotation_pid_gains[3];  /* p, i, d */
+  double max_translation[3];     /* x, y, z */
+  double max_rotation[3];        /* roll, pitch, yaw */
+  double max_translation_velocity, max_rotation_velocity;
+  /* admittance (default.yaml:122-130) */
+  int32_t dynamic_stiffness, use_joint_effort;
+  double integrator_step_time, virtual_mass, virtual_stiffness, virtual_damping_ratio, force_gain;
+  double load_stiffness_scaler, swing_stiffness_scaler;
+  /* gait (gait.yaml) */
+  int32_t stance_phase, swing_phase, phase_offset;
+  int32_t offset_multiplier[SHC_MAX_LEGS];
+  /* auto pose (auto_pose.yaml) */
+  double pose_frequency;
+  int32_t pose_phase_length;
+  int32_t n_auto_posers;
+  int32_t pose_phase_starts[SHC_MAX_AUTO_POSERS], pose_phase_ends[SHC_MAX_AUTO_POSERS];
+  int32_t pose_negation_phase_starts[SHC_MAX_LEGS], pose_negation_phase_ends[SHC_MAX_LEGS];
+  double negation_transition_ratio[SHC_MAX_LEGS];
+  double roll_amplitudes[SHC_MAX_AUTO_POSERS], pitch_amplitudes[SHC_MAX_AUTO_POSERS],
+      yaw_amplitudes[SHC_MAX_AUTO_POSERS];
+  double x_amplitudes[SHC_MAX_AUTO_POSERS], y_amplitudes[SHC_MAX_AUTO_POSERS], z_amplitudes[SHC_MAX_AUTO_POSERS],
+      gravity_amplitudes[SHC_MAX_AUTO_POSERS];
+} shc_params;
+
+/* walk_controller.h:23-33 StepCycle */
+typedef struct shc_step_cycle {
+  double frequency;
+  int32_t period, swing_period, stance_period, stance_end, swing_start, swing_end, stance_start;
+} shc_step_cycle;
+
+/*
+ * Per-(morphology, gait) tables produced once by the init chain
+ * (state_controller.cpp:263-272: directStartup -> updateDefaultConfiguration ->
+ *  Model::generateWorkspaces -> WalkController::generateWalkspace -> generateLimits)
+ * and consumed every cycle by WalkController::getLimit (walk_controller.cpp:414).
+ */
+typedef struct shc_tables {
+  shc_step_cycle step;
+  int32_t phase_offset[SHC_MAX_LEGS];                      /* walk_controller.cpp:277 */
+  double default_joint_position[SHC_MAX_LEGS][SHC_MAX_JOINTS]; /* model.cpp:593 after direct start-up */
+  double walkspace[SHC_N_BEARINGS];                        /* walk_controller.cpp:57 */
+  double max_linear_speed[SHC_N_BEARINGS];                 /* walk_controller.cpp:344-359 */
+  double max_angular_speed[SHC_N_BEARINGS];
+  double max_linear_acceleration[SHC_N_BEARINGS];
+  double max_angular_acceleration[SHC_N_BEARINGS];
+  double workspace_radius[SHC_MAX_LEGS][SHC_N_BEARINGS];   /* model.cpp:309 (simple workspace, plane z = 0) */
+  int32_t pose_phase_length, pose_normaliser;              /* pose_controller.cpp:62-63 */
+  int32_t auto_pose_reference_leg;                         /* pose_controller.cpp:75-78 */
+} shc_tables;
+
+typedef struct shc_engine shc_engine; /* opaque */
+
+/* Feature bits of the fused cycle kernel (compile-time specialisations are picked from these). */
+enum {
+  SHC_FEAT_TIP_FORCE = 1 << 0, /* Leg::calculateTipForce every cycle (model.cpp:938); needs joint_effort input */
+  SHC_FEAT_ALL = 0x7fffffff
+};
+
+/*
+ * Library/device introspection.  shc_device_count() returns the number of visible HIP devices
+ * (0 when none; never an error) so a caller can fail loudly before creating an engine.
+ */
+int shc_abi_version(void);
+int shc_device_count(void);
+const char *shc_last_error(void);
+
+/*
+ * Host-side init chain = StateController::init + initModel + direct start-up + workspace /
+ * walkspace / limit generation (state_controller.cpp:127-153, 263-272).  Pure host function
+ * (no device needed); fills `out`.  Product code (shares the device math headers), NOT the oracle.
+ */
+int shc_generate_tables(const shc_params *params, shc_tables *out);
+
+/*
+ * Create an engine for `n_instances` robots on HIP device `device` (replaces
+ * StateController::StateController + init(), state_controller.cpp:13-153, for a batch).
+ * Every instance starts in the post-start-up RUNNING state: joints at the default
+ * configuration, walk state STOPPED.  `stream` is a hipStream_t (0 = default stream).
+ */
+int shc_engine_create(const shc_params *params, int64_t n_instances, int device, void *stream, shc_engine **out);
+int shc_engine_destroy(shc_engine *e);
+int shc_engine_set_stream(shc_engine *e, void *stream);
+int shc_engine_set_features(shc_engine *e, uint32_t features);
+int shc_engine_get_tables(const shc_engine *e, shc_tables *out);
+int64_t shc_engine_instances(const shc_engine *e);
+
+/*
+ * Inputs that arrive between cycles in the reference (ROS callbacks, state_controller.cpp).
+ * `on_device` != 0: pointers are device pointers in the same layouts (no host round trip).
+ * NULL pointer = leave that input unchanged.
+ */
+/* StateController::bodyVelocityInputCallback (state_controller.cpp:1127): lin [n][2], ang [n]. */
+int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, const double *angular, int on_device);
+/* imuCallback -> Model::setImuData (state_controller.cpp:1552, model.h:146): quat [n][4] (w,x,y,z), gyro [n][3]. */
+int shc_engine_set_imu(shc_engine *e, const double *orientation_wxyz, const double *angular_velocity, int on_device);
+/* tipStatesCallback -> Leg::setTipForceMeasured (state_controller.cpp:1618): [n][legs][3]. */
+int shc_engine_set_tip_force(shc_engine *e, const double *tip_force, int on_device);
+/* jointStatesCallback -> Joint::current_effort_ (state_controller.cpp:1590): [n][legs][dof]. */
+int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int on_device);
+/* bodyPoseInputCallback (state_controller.cpp:1142): translation / rotation velocity inputs [n][3] each. */
+int shc_engine_set_pose_input(shc_engine *e, const double *translation_velocity, const double *rotation_velocity,
+                              int on_device);
+
+/*
+ * Advance every instance by `n_cycles` control cycles (StateController::loop with robot_state
+ * RUNNING, state_controller.cpp:162-193 + runningState :379-447).  Inputs are held for all
+ * n_cycles.  Asynchronous on the engine's stream.
+ */
+int shc_engine_step(shc_engine *e, int n_cycles);
+int shc_engine_synchronize(shc_engine *e);
+
+/*
+ * Outputs read after the cycle (state_controller.cpp:777-805 publishDesiredJointState).
+ * q/qd: [n][legs][dof] desired joint position / velocity.  Either may be NULL.
+ */
+int shc_engine_get_joint_state(shc_engine *e, double *q, double *qd, int on_device);
+/*
+ * Device view of the engine's own joint-position buffer (structure-of-arrays):
+ * the buffer a multi-GPU caller all-gathers.  `*n_doubles` = dof * n_slots.
+ */
+int shc_engine_joint_buffer(shc_engine *e, double **device_ptr, int64_t *n_doubles);
+/* Map instance-major (i, leg, j) to an index into the buffer above. */
+int64_t shc_engine_joint_index(const shc_engine *e, int64_t instance, int leg, int joint);
+
+/* LegState-style per-leg outputs (state_controller.cpp:809-893): any pointer may be NULL.
+ *   walker_tip   [n][legs][3]  LegStepper::current_tip_pose_.position_
+ *   poser_tip    [n][legs][3]  LegPoser::current_tip_pose_.position_ (posed, body frame)
+ *   model_tip    [n][legs][3]  Leg::current_tip_pose_.position_ (FK)
+ *   tip_force    [n][legs][3]  Leg::tip_force_calculated_
+ *   admittance   [n][legs][3]  Leg::admittance_delta_
+ *   leg_status   [n][legs]     packed: bits 0-1 step state, bit 2 ik failure (model.cpp:921), bits 8.. phase
+ */
+int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, double *poser_tip, double *model_tip,
+                             double *tip_force, double *admittance, int32_t *leg_status, int on_device);
+/* Per-robot outputs: body pose [n][7] (x,y,z,qw,qx,qy,qz) = Model::current_pose_ (state_controller.cpp:911),
+ * desired velocity [n][3] (vx,vy,omega), walk_state [n]. */
+int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHC_BATCH_H */

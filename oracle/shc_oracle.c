@@ -1,0 +1,2436 @@
+/*
+ * shc_oracle.c — TEST INFRASTRUCTURE: CPU oracle (see shc_oracle.h for the contract and the
+ * "PARITY UNPINNED" statement).  Every function cites the reference file:line it restates;
+ * paths are relative to /root/reference.  Reference = OpenSHC v0.5.11.
+ *
+ * Scope restated here: model.cpp FK / DLS IK / joint update / tip force / workspace
+ * search; walk_controller.cpp step cycle, walkspace, limits, updateWalk, LegStepper; pose_controller.cpp
+ * updateCurrentPose (walk-plane, manual, inclination, IMU, auto), updateStance, direct start-up;
+ * admittance_controller.cpp; call order of state_controller.cpp loop()/runningState().
+ * Not restated (out of the accelerated path): rough_terrain_mode branches, manual leg manipulation,
+ * start-up/shut-down sequences, tip-align pose (experimental), ROS I/O.
+ */
+#include "shc_oracle.h"
+#include "oracle_math.h"
+
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <time.h>
+
+/* model.h:17-25 */
+#define IK_TOLERANCE 0.005
+#define DLS_COEFFICIENT 0.02
+#define JOINT_LIMIT_COST_WEIGHT 0.1
+#define BEARING_STEP 45
+#define MAX_POSITION_DELTA 0.002
+#define MAX_WORKSPACE_RADIUS 1.0
+#define WORKSPACE_LAYERS 10
+/* pose_controller.h:18-25 */
+#define JOINT_TOLERANCE 0.01
+#define TIP_TOLERANCE 0.01
+#define STABILITY_THRESHOLD 100
+#define IMU_POSING_DEADBAND 0.0
+/* admittance_controller.h:18 */
+#define ADMITTANCE_DEADBAND 0.0
+#define PROGRESS_COMPLETE 100 /* standard_includes.h:53 */
+
+enum { WALKING = 0 };                                             /* parameters_and_states.h:87 */
+enum { STARTING = 0, MOVING = 1, STOPPING = 2, STOPPED = 3 };     /* :99 */
+enum { SWING = 0, STANCE = 1, FORCE_STANCE = 2, FORCE_STOP = 3 }; /* :111 */
+enum { POSING = 0, STOP_POSING = 1, POSING_COMPLETE = 2 };        /* :123 */
+enum { RS_PACKED = 0, RS_READY = 1, RS_RUNNING = 2, RS_UNKNOWN = -1 }; /* :25 */
+
+typedef struct
+{ /* class Joint, model.h:558-646 (index j = id_number_ - 1) */
+  double min_position, max_position, offset, unpacked_position, max_angular_speed;
+  double desired_position, desired_velocity, desired_effort, prev_desired_position;
+  double current_position, current_velocity, current_effort;
+  double default_position, default_velocity, default_effort;
+  orc_m4 current_transform, identity_transform;
+} joint_t;
+
+typedef struct { double d, theta, r, alpha; } link_t; /* class Link, model.h:541-553 */
+
+typedef struct
+{ /* class LegStepper, walk_controller.h:486-535 */
+  int at_correct_phase, completed_first_step;
+  int phase, phase_offset;
+  double step_progress, swing_progress, stance_progress;
+  int step_state;
+  orc_v3 swing_1_nodes[5], swing_2_nodes[5], stance_nodes[5];
+  orc_v3 walk_plane, walk_plane_normal, stride_vector, swing_clearance;
+  double swing_delta_t, stance_delta_t;
+  orc_pose identity_tip_pose, default_tip_pose, current_tip_pose, origin_tip_pose, target_tip_pose;
+  orc_v3 current_tip_velocity;
+  orc_v3 swing_origin_tip_position, swing_origin_tip_velocity, stance_origin_tip_position;
+} stepper_t;
+
+typedef struct
+{ /* class LegPoser, pose_controller.h:429-597 (members used on the path) */
+  orc_pose auto_pose, current_tip_pose, origin_tip_pose, target_tip_pose;
+  int pose_negation_phase_start, pose_negation_phase_end;
+  double negation_transition_ratio;
+  int negate_auto_pose;
+  int first_iteration, master_iteration_count;
+  int has_desired_configuration;
+  double desired_configuration[SHC_MAX_JOINTS], origin_configuration[SHC_MAX_JOINTS];
+} leg_poser_t;
+
+typedef struct
+{ /* class Leg, model.h:202-536 */
+  int id_number, joint_count, leg_state;
+  joint_t joint[SHC_MAX_JOINTS];
+  link_t link[SHC_MAX_LINKS];
+  orc_m4 tip_current_transform, tip_identity_transform; /* class Tip, model.h:652-703 */
+  orc_v3 admittance_delta;
+  double admittance_state[2];
+  double virtual_stiffness;
+  orc_pose desired_tip_pose, current_tip_pose;
+  orc_v3 desired_tip_velocity, current_tip_velocity;
+  orc_v3 tip_force_calculated, tip_force_measured;
+  orc_pose step_plane_pose;
+  double workspace[SHC_N_BEARINGS]; /* Workspace with the single plane 0.0 (simple workspace, model.cpp:355-358) */
+  int workspace_zero;               /* model.cpp:349-353 */
+  int ik_failed;                    /* model.cpp:921 this cycle */
+  stepper_t stepper;
+  leg_poser_t poser;
+} leg_t;
+
+typedef struct
+{ /* class AutoPoser, pose_controller.h:333-421 */
+  int start_phase, end_phase;
+  int start_check, end_check_first, end_check_second, allow_posing;
+  double x_amplitude, y_amplitude, z_amplitude, gravity_amplitude, roll_amplitude, pitch_amplitude, yaw_amplitude;
+} auto_poser_t;
+
+struct orc_robot
+{
+  shc_params params;
+  /* Model (model.h:57-200) */
+  int leg_count;
+  double time_delta;
+  orc_pose current_pose, default_pose;
+  orc_quat imu_orientation;
+  orc_v3 imu_angular_velocity;
+  leg_t leg[SHC_MAX_LEGS];
+  /* WalkController (walk_controller.h:240-275) */
+  int walk_state, pose_state;
+  shc_step_cycle step;
+  double walkspace[SHC_N_BEARINGS];
+  orc_v3 walk_plane, walk_plane_normal;
+  double desired_linear_velocity[2], desired_angular_velocity;
+  orc_pose odometry_ideal;
+  double max_linear_speed[SHC_N_BEARINGS], max_angular_speed[SHC_N_BEARINGS];
+  double max_linear_acceleration[SHC_N_BEARINGS], max_angular_acceleration[SHC_N_BEARINGS];
+  int legs_at_correct_phase, legs_completed_first_step, return_to_default_attempted;
+  /* PoseController (pose_controller.h:262-322) */
+  int pose_reset_mode;
+  orc_v3 translation_velocity_input, rotation_velocity_input;
+  orc_pose manual_pose, auto_pose, imu_pose, inclination_pose, pc_default_pose, walk_plane_pose, origin_walk_plane_pose;
+  int executing_transition;
+  auto_poser_t auto_poser[SHC_MAX_AUTO_POSERS];
+  int n_auto_posers;
+  int auto_posing_state, pose_phase;
+  double pose_frequency;
+  int pose_phase_length, normaliser, auto_pose_reference_leg;
+  orc_v3 rotation_absement_error, rotation_position_error, rotation_velocity_error;
+  /* StateController (state_controller.h) */
+  int robot_state, new_robot_state, transition_state_flag;
+  double linear_velocity_input[2], angular_velocity_input;
+  int unstable;
+};
+
+/* ==================================================================================== Model / Leg */
+
+/* Joint::getTransformFromJoint / Tip::getTransformFromJoint (model.h:594-599, 674-679).
+ * element e: 1..joint_count = joint id, joint_count + 1 = tip.  target: joint id the product stops at (0 = origin). */
+static orc_m4 transform_from_joint(const leg_t *leg, int e, int target)
+{
+  const orc_m4 *cur = (e == leg->joint_count + 1) ? &leg->tip_current_transform : &leg->joint[e - 1].current_transform;
+  int next_joint_id = e - 1; /* reference_link_->actuating_joint_->id_number_ */
+  if (target == next_joint_id) return *cur;
+  orc_m4 up = transform_from_joint(leg, next_joint_id, target);
+  return orc_m4_mul(&up, cur);
+}
+
+static orc_m4 m4_inverse_lu(const orc_m4 *t) /* MatrixXd(transform).inverse(), model.h:615-616 */
+{
+  orc_m4 r;
+  orc_lu_inverse(&t->m[0][0], 4, &r.m[0][0]);
+  return r;
+}
+
+/* Joint::getPoseJointFrame (model.h:613-617) for joint id e */
+static orc_pose joint_pose_joint_frame(const leg_t *leg, int e, orc_pose robot_frame_pose)
+{
+  orc_m4 t = transform_from_joint(leg, e, 0);
+  orc_m4 inv = m4_inverse_lu(&t);
+  return orc_pose_transform_m4(robot_frame_pose, &inv);
+}
+
+/* Leg::applyFK (model.cpp:945-988), set_current = true, use_actual = false */
+static orc_pose leg_apply_fk(orc_robot *r, leg_t *leg)
+{
+  for (int e = 2; e <= leg->joint_count; ++e)
+  { /* joint e: reference link e-1, actuated by joint e-1 */
+    const link_t *rl = &leg->link[e - 1];
+    double joint_angle = leg->joint[e - 2].desired_position;
+    leg->joint[e - 1].current_transform = orc_create_dh_matrix(rl->d, rl->theta + joint_angle, rl->r, rl->alpha);
+  }
+  {
+    const link_t *rl = &leg->link[leg->joint_count];
+    double joint_angle = leg->joint[leg->joint_count - 1].desired_position;
+    leg->tip_current_transform = orc_create_dh_matrix(rl->d, rl->theta + joint_angle, rl->r, rl->alpha);
+  }
+  orc_m4 t = transform_from_joint(leg, leg->joint_count + 1, 0);
+  orc_pose tip_pose = orc_pose_transform_m4(orc_pose_identity(), &t); /* Tip::getPoseRobotFrame model.h:684 */
+  if (orc_pose_ne(leg->current_tip_pose, orc_pose_undefined()))
+  {
+    /* reference: (a - b) / dt, element-wise division */
+    leg->current_tip_velocity.x = (tip_pose.p.x - leg->current_tip_pose.p.x) / r->time_delta;
+    leg->current_tip_velocity.y = (tip_pose.p.y - leg->current_tip_pose.p.y) / r->time_delta;
+    leg->current_tip_velocity.z = (tip_pose.p.z - leg->current_tip_pose.p.z) / r->time_delta;
+  }
+  leg->current_tip_pose = tip_pose;
+  return tip_pose;
+}
+
+/* Leg::init (model.cpp:286-305) */
+static void leg_init(orc_robot *r, leg_t *leg, int use_default_joint_positions)
+{
+  for (int j = 0; j < leg->joint_count; ++j)
+  {
+    joint_t *jt = &leg->joint[j];
+    if (use_default_joint_positions)
+    {
+      jt->current_position = jt->default_position;
+      jt->current_velocity = jt->default_velocity;
+      jt->current_effort = jt->default_effort;
+    }
+    jt->desired_position = jt->current_position;
+    jt->desired_velocity = jt->current_velocity;
+    jt->desired_effort = jt->current_effort;
+    jt->prev_desired_position = jt->desired_position;
+  }
+  leg_apply_fk(r, leg);
+  leg->desired_tip_pose = leg->current_tip_pose;
+}
+
+/* Leg::updateDefaultConfiguration (model.cpp:593-601) */
+static void leg_update_default_configuration(leg_t *leg)
+{
+  for (int j = 0; j < leg->joint_count; ++j) leg->joint[j].default_position = leg->joint[j].desired_position;
+}
+
+/* Leg::setDesiredTipPose (model.cpp:653-663) */
+static void leg_set_desired_tip_pose(leg_t *leg, orc_pose tip_pose, int apply_delta)
+{
+  int use_poser_tip_pose = orc_pose_eq(orc_pose_undefined(), tip_pose);
+  leg->desired_tip_pose = use_poser_tip_pose ? leg->poser.current_tip_pose : tip_pose;
+  if (apply_delta) leg->desired_tip_pose.p = orc_v3_add(leg->desired_tip_pose.p, leg->admittance_delta);
+}
+
+/* Leg::setAdmittanceDelta (model.h:365-368) */
+static void leg_set_admittance_delta(leg_t *leg, orc_v3 delta)
+{
+  leg->admittance_delta = orc_get_projection(delta, orc_quat_rotate(leg->current_tip_pose.r, orc_v3_make(1, 0, 0)));
+}
+
+/* Geometric Jacobian columns shared by solveIK (model.cpp:731-747) and calculateTipForce (:671-692).
+ * lin[i], ang[i] = linear / angular column of joint i (0-based). */
+static void leg_jacobian(const leg_t *leg, orc_v3 *lin, orc_v3 *ang)
+{
+  orc_m4 te = transform_from_joint(leg, leg->joint_count + 1, 1);
+  orc_v3 pe = orc_v3_make(te.m[0][3], te.m[1][3], te.m[2][3]);
+  orc_v3 z0 = orc_v3_make(0, 0, 1), p0 = orc_v3_make(0, 0, 0);
+  lin[0] = orc_v3_cross(z0, orc_v3_sub(pe, p0));
+  ang[0] = z0;
+  for (int i = 1; i < leg->joint_count; ++i)
+  {
+    orc_m4 t = transform_from_joint(leg, i + 1, 1);
+    orc_v3 zi = orc_v3_make(t.m[0][2], t.m[1][2], t.m[2][2]);
+    orc_v3 pi = orc_v3_make(t.m[0][3], t.m[1][3], t.m[2][3]);
+    lin[i] = orc_v3_cross(zi, orc_v3_sub(pe, pi));
+    ang[i] = zi;
+  }
+}
+
+/* Leg::calculateTipForce (model.cpp:667-708) */
+static void leg_calculate_tip_force(orc_robot *r, leg_t *leg)
+{
+  int n = leg->joint_count;
+  orc_v3 lin[SHC_MAX_JOINTS], ang[SHC_MAX_JOINTS];
+  leg_jacobian(leg, lin, ang);
+  double jac[6][SHC_MAX_JOINTS];
+  for (int i = 0; i < n; ++i)
+  {
+    jac[0][i] = lin[i].x; jac[1][i] = lin[i].y; jac[2][i] = lin[i].z;
+    jac[3][i] = ang[i].x; jac[4][i] = ang[i].y; jac[5][i] = ang[i].z;
+  }
+  double a[SHC_MAX_JOINTS * SHC_MAX_JOINTS], ainv[SHC_MAX_JOINTS * SHC_MAX_JOINTS];
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+    {
+      double s = 0.0;
+      for (int k = 0; k < 6; ++k) s += jac[k][i] * jac[k][j];
+      a[i * n + j] = s + orc_sqr(DLS_COEFFICIENT) * (i == j ? 1.0 : 0.0);
+    }
+  orc_lu_inverse(a, n, ainv);
+  /* transformation = J * inv ; raw = transformation * torques */
+  double transformation[6][SHC_MAX_JOINTS];
+  for (int k = 0; k < 6; ++k)
+    for (int j = 0; j < n; ++j)
+    {
+      double s = 0.0;
+      for (int i = 0; i < n; ++i) s += jac[k][i] * ainv[i * n + j];
+      transformation[k][j] = s;
+    }
+  double raw[3];
+  for (int k = 0; k < 3; ++k)
+  {
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += transformation[k][j] * leg->joint[j].current_effort;
+    raw[k] = s;
+  }
+  orc_quat rotation = joint_pose_joint_frame(leg, 1, orc_pose_identity()).r;
+  orc_v3 raw_tip_force = orc_quat_rotate(rotation, orc_v3_make(raw[0], raw[1], raw[2]));
+  double s = 0.15;
+  double fg = r->params.force_gain;
+  leg->tip_force_calculated.x = s * raw_tip_force.x * fg + (1 - s) * leg->tip_force_calculated.x;
+  leg->tip_force_calculated.y = s * raw_tip_force.y * fg + (1 - s) * leg->tip_force_calculated.y;
+  leg->tip_force_calculated.z = s * raw_tip_force.z * fg + (1 - s) * leg->tip_force_calculated.z;
+}
+
+/* Leg::solveIK (model.cpp:726-795).  delta[6]; out dq[n] */
+static void leg_solve_ik(const leg_t *leg, const double delta[6], int solve_rotation, double *dq)
+{
+  int n = leg->joint_count;
+  orc_v3 lin[SHC_MAX_JOINTS], ang[SHC_MAX_JOINTS];
+  leg_jacobian(leg, lin, ang);
+  double j[6][SHC_MAX_JOINTS];
+  for (int i = 0; i < n; ++i)
+  {
+    j[0][i] = lin[i].x; j[1][i] = lin[i].y; j[2][i] = lin[i].z;
+    j[3][i] = solve_rotation ? ang[i].x : 0.0;
+    j[4][i] = solve_rotation ? ang[i].y : 0.0;
+    j[5][i] = solve_rotation ? ang[i].z : 0.0;
+  }
+  /* jacobian_inverse = J^T * (J J^T + lambda^2 I6)^-1  (:755) */
+  double jjt[36], jjt_inv[36];
+  for (int a = 0; a < 6; ++a)
+    for (int b = 0; b < 6; ++b)
+    {
+      double s = 0.0;
+      for (int k = 0; k < n; ++k) s += j[a][k] * j[b][k];
+      jjt[a * 6 + b] = s + orc_sqr(DLS_COEFFICIENT) * (a == b ? 1.0 : 0.0);
+    }
+  orc_lu_inverse(jjt, 6, jjt_inv);
+  double jinv[SHC_MAX_JOINTS][6];
+  for (int i = 0; i < n; ++i)
+    for (int b = 0; b < 6; ++b)
+    {
+      double s = 0.0;
+      for (int a = 0; a < 6; ++a) s += j[a][i] * jjt_inv[a * 6 + b];
+      jinv[i][b] = s;
+    }
+  /* joint limit cost function and gradient (:759-790) */
+  double position_limit_cost = 0.0, velocity_limit_cost = 0.0;
+  double pg[SHC_MAX_JOINTS], vg[SHC_MAX_JOINTS], cg[SHC_MAX_JOINTS];
+  for (int i = 0; i < n; ++i)
+  {
+    const joint_t *jt = &leg->joint[i];
+    pg[i] = 0.0;
+    double joint_position_range = jt->max_position - jt->min_position;
+    double position_range_centre = jt->min_position + joint_position_range / 2.0;
+    if (joint_position_range != 0.0)
+    {
+      position_limit_cost +=
+          orc_sqr(fabs(JOINT_LIMIT_COST_WEIGHT * (jt->desired_position - position_range_centre) / joint_position_range));
+      pg[i] = -orc_sqr(JOINT_LIMIT_COST_WEIGHT) * (jt->desired_position - position_range_centre) /
+              orc_sqr(joint_position_range);
+    }
+    double joint_velocity_range = 2 * jt->max_angular_speed;
+    double velocity_range_centre = 0.0;
+    velocity_limit_cost +=
+        orc_sqr(fabs(JOINT_LIMIT_COST_WEIGHT * (jt->desired_velocity - velocity_range_centre) / joint_velocity_range));
+    vg[i] = -orc_sqr(JOINT_LIMIT_COST_WEIGHT) * (jt->desired_velocity - velocity_range_centre) /
+            orc_sqr(joint_velocity_range);
+  }
+  double ps = (position_limit_cost == 0.0 ? 0.0 : 1.0 / sqrt(position_limit_cost));
+  double vs = (velocity_limit_cost == 0.0 ? 0.0 : 1.0 / sqrt(velocity_limit_cost));
+  for (int i = 0; i < n; ++i)
+  {
+    pg[i] *= ps;
+    vg[i] *= vs;
+    cg[i] = (1.0 - 0.75) * pg[i] + 0.75 * vg[i]; /* interpolate(pg, vg, 0.75) */
+  }
+  /* return jinv * delta + (I - jinv * J) * cg  (:793-794) */
+  for (int i = 0; i < n; ++i)
+  {
+    double s = 0.0;
+    for (int b = 0; b < 6; ++b) s += jinv[i][b] * delta[b];
+    double t = 0.0;
+    for (int k = 0; k < n; ++k)
+    {
+      double jj = 0.0;
+      for (int b = 0; b < 6; ++b) jj += jinv[i][b] * j[b][k];
+      t += ((i == k ? 1.0 : 0.0) - jj) * cg[k];
+    }
+    dq[i] = s + t;
+  }
+}
+
+/* Leg::updateJointPositions (model.cpp:799-857) */
+static double leg_update_joint_positions(orc_robot *r, leg_t *leg, const double *delta, int simulation)
+{
+  double min_limit_proximity = 1.0;
+  for (int i = 0; i < leg->joint_count; ++i)
+  {
+    joint_t *jt = &leg->joint[i];
+    jt->desired_velocity = delta[i] / r->time_delta;
+    if (r->params.clamp_joint_velocities && !simulation)
+    {
+      if (fabs(jt->desired_velocity) > jt->max_angular_speed)
+      {
+        double max_velocity = jt->max_angular_speed;
+        jt->desired_velocity = orc_clamped(jt->desired_velocity, -max_velocity, max_velocity);
+      }
+    }
+    jt->prev_desired_position = jt->desired_position;
+    jt->desired_position = jt->prev_desired_position + jt->desired_velocity * r->time_delta;
+    if (r->params.clamp_joint_positions)
+    {
+      if (jt->desired_position < jt->min_position) jt->desired_position = jt->min_position;
+      else if (jt->desired_position > jt->max_position) jt->desired_position = jt->max_position;
+    }
+    double min_diff = fabs(jt->min_position - jt->desired_position);
+    double max_diff = fabs(jt->max_position - jt->desired_position);
+    double half_joint_range = (jt->max_position - jt->min_position) / 2.0;
+    double limit_proximity = half_joint_range != 0 ? fmin(min_diff, max_diff) / half_joint_range : 1.0;
+    min_limit_proximity = fmin(limit_proximity, min_limit_proximity);
+  }
+  return min_limit_proximity;
+}
+
+/* Leg::applyIK (model.cpp:861-941) */
+static double leg_apply_ik(orc_robot *r, leg_t *leg, int simulation)
+{
+  orc_pose leg_frame_desired_tip_pose = joint_pose_joint_frame(leg, 1, leg->desired_tip_pose);
+  orc_pose leg_frame_current_tip_pose = joint_pose_joint_frame(leg, 1, leg->current_tip_pose);
+  orc_v3 position_delta = orc_v3_sub(leg_frame_desired_tip_pose.p, leg_frame_current_tip_pose.p);
+
+  double delta[6] = { position_delta.x, position_delta.y, position_delta.z, 0, 0, 0 };
+  double joint_position_delta[SHC_MAX_JOINTS];
+  leg_solve_ik(leg, delta, 0, joint_position_delta);
+
+  int rotation_constrained = !orc_quat_is_approx(leg->desired_tip_pose.r, ORC_UNDEFINED_ROTATION);
+  if (rotation_constrained)
+  {
+    leg_update_joint_positions(r, leg, joint_position_delta, 1);
+    leg_apply_fk(r, leg);
+    orc_v3 desired_tip_direction = orc_quat_rotate(leg_frame_desired_tip_pose.r, orc_v3_make(1, 0, 0));
+    orc_v3 current_tip_direction = orc_quat_rotate(leg_frame_current_tip_pose.r, orc_v3_make(1, 0, 0));
+    orc_quat difference = orc_quat_from_two_vectors(current_tip_direction, desired_tip_direction);
+    orc_v3 axis;
+    double angle = orc_angle_axis_from_quat(orc_quat_normalized(difference), &axis);
+    orc_v3 rotation_delta = orc_v3_scale(axis, angle);
+    double delta2[6] = { 0, 0, 0, rotation_delta.x, rotation_delta.y, rotation_delta.z };
+    leg_solve_ik(leg, delta2, 1, joint_position_delta);
+  }
+
+  double ik_success = leg_update_joint_positions(r, leg, joint_position_delta, simulation);
+  leg_apply_fk(r, leg);
+
+  for (int i = 0; i < 3; ++i)
+  {
+    orc_v3 position_error = orc_v3_sub(leg->current_tip_pose.p, leg->desired_tip_pose.p);
+    double pe = i == 0 ? position_error.x : (i == 1 ? position_error.y : position_error.z);
+    if (fabs(pe) > IK_TOLERANCE)
+    {
+      ik_success = 0.0;
+      if (!simulation) leg->ik_failed = 1;
+    }
+  }
+
+  if (rotation_constrained && !ik_success)
+  {
+    leg->desired_tip_pose.r = ORC_UNDEFINED_ROTATION;
+    ik_success = leg_apply_ik(r, leg, simulation);
+  }
+
+  leg_calculate_tip_force(r, leg);
+  return ik_success;
+}
+
+/* Model::estimateGravity (model.cpp:156-165) */
+static orc_v3 model_estimate_gravity(const orc_robot *r)
+{
+  orc_v3 euler = orc_quat_to_euler(r->imu_orientation, 0); /* raw imu_data_.orientation (may be the zero sentinel) */
+  orc_v3 gravity = orc_v3_make(0, 0, ORC_GRAVITY_ACCELERATION);
+  gravity = orc_angle_axis_rotate(-euler.y, orc_v3_make(0, 1, 0), gravity);
+  gravity = orc_angle_axis_rotate(-euler.x, orc_v3_make(1, 0, 0), gravity);
+  return gravity;
+}
+
+/* Model::getImuData (model.h:132-140) */
+static orc_quat model_imu_orientation(const orc_robot *r)
+{
+  if (orc_quat_is_approx(r->imu_orientation, ORC_UNDEFINED_ROTATION)) return orc_quat_identity();
+  return r->imu_orientation;
+}
+
+/* Leg::generateWorkspace (model.cpp:309-510), simple workspace (rough_terrain_mode == false) only */
+static void leg_generate_workspace(orc_robot *r, leg_t *leg)
+{
+  double max_workplane[SHC_N_BEARINGS];
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) max_workplane[b] = MAX_WORKSPACE_RADIUS;
+  orc_pose current_pose = r->current_pose;
+  orc_v3 identity_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.identity_tip_pose.p);
+  leg->workspace_zero = 0;
+  if (orc_v3_norm(orc_v3_sub(identity_tip_position, leg->current_tip_pose.p)) > IK_TOLERANCE)
+  {
+    for (int b = 0; b < SHC_N_BEARINGS; ++b) leg->workspace[b] = 0.0;
+    leg->workspace_zero = 1;
+    return;
+  }
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) leg->workspace[b] = max_workplane[b];
+
+  double min_plane_height = 0.0;
+  double search_height_delta = MAX_WORKSPACE_RADIUS / WORKSPACE_LAYERS;
+  double search_height = 0.0;
+  int search_bearing = 0;
+  int within_limits = 1;
+  int iteration = 1;
+  orc_v3 origin_tip_position = orc_v3_make(0, 0, 0), target_tip_position = orc_v3_make(0, 0, 0);
+  double distance_from_origin;
+  int number_iterations = 1;
+  int workspace_generation_complete = 0;
+
+  while (1)
+  {
+    current_pose = r->current_pose;
+    identity_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.identity_tip_pose.p);
+    identity_tip_position.z += search_height;
+
+    if (iteration == 1)
+    {
+      within_limits = 1;
+      leg_init(r, leg, 1);
+      if (search_bearing == 0)
+      {
+        number_iterations = orc_round_to_int(search_height_delta / MAX_POSITION_DELTA);
+        number_iterations = number_iterations > 1 ? number_iterations : 1;
+        origin_tip_position = leg->current_tip_pose.p;
+        target_tip_position = identity_tip_position;
+      }
+      else
+      {
+        number_iterations = orc_round_to_int(MAX_WORKSPACE_RADIUS / MAX_POSITION_DELTA);
+        origin_tip_position = identity_tip_position;
+        target_tip_position = origin_tip_position;
+        target_tip_position.x += MAX_WORKSPACE_RADIUS * cos(orc_deg2rad(search_bearing));
+        target_tip_position.y += MAX_WORKSPACE_RADIUS * sin(orc_deg2rad(search_bearing));
+      }
+    }
+
+    double i = (double)iteration / number_iterations;
+    orc_v3 desired_tip_position = orc_v3_add(orc_v3_scale(origin_tip_position, 1.0 - i), orc_v3_scale(target_tip_position, i));
+    leg_set_desired_tip_pose(leg, orc_pose_make(desired_tip_position, ORC_UNDEFINED_ROTATION), 1);
+    double ik_result = leg_apply_ik(r, leg, 1);
+    distance_from_origin = orc_v3_norm(orc_v3_sub(leg->current_tip_pose.p, identity_tip_position));
+    within_limits = within_limits && ik_result != 0.0;
+
+    if (within_limits && iteration < number_iterations)
+    {
+      iteration++;
+    }
+    else
+    {
+      iteration = 1;
+      if (search_bearing == 0) leg_update_default_configuration(leg);
+      else leg->workspace[search_bearing / BEARING_STEP] = distance_from_origin;
+
+      if (search_bearing + BEARING_STEP <= 360)
+      {
+        search_bearing += BEARING_STEP;
+      }
+      else
+      {
+        search_bearing = 0;
+        leg->workspace[0] = leg->workspace[360 / BEARING_STEP];
+        search_height -= search_height_delta;
+        if (search_height >= min_plane_height) { /* unreachable in simple mode */ }
+        else workspace_generation_complete = 1;
+      }
+    }
+    if (workspace_generation_complete) return;
+  }
+}
+
+/* ==================================================================================== WalkController */
+
+/* WalkController::generateStepCycle (walk_controller.cpp:365-410) */
+static shc_step_cycle generate_step_cycle(const shc_params *p)
+{
+  shc_step_cycle step;
+  step.stance_end = (int)(p->stance_phase * 0.5);
+  step.swing_start = step.stance_end;
+  step.swing_end = step.swing_start + p->swing_phase;
+  step.stance_start = step.swing_end;
+  int base_step_period = p->stance_phase + p->swing_phase;
+  double swing_ratio = (double)p->swing_phase / (double)base_step_period;
+  double raw_step_period = ((1.0 / p->step_frequency) / p->time_delta) / swing_ratio;
+  step.period = orc_round_to_even_int(raw_step_period / base_step_period) * base_step_period;
+  step.frequency = 1.0 / (step.period * p->time_delta);
+  int normaliser = step.period / base_step_period;
+  step.stance_end *= normaliser;
+  step.swing_start *= normaliser;
+  step.swing_end *= normaliser;
+  step.stance_start *= normaliser;
+  step.stance_period = orc_mod(step.stance_end - step.stance_start, step.period);
+  step.swing_period = step.swing_end - step.swing_start;
+  return step;
+}
+
+/* LegStepper::LegStepper (walk_controller.cpp:795-819) */
+static void stepper_construct(orc_robot *r, stepper_t *s, orc_pose identity_tip_pose)
+{
+  memset(s, 0, sizeof *s);
+  s->identity_tip_pose = identity_tip_pose;
+  s->default_tip_pose = identity_tip_pose;
+  s->current_tip_pose = s->default_tip_pose;
+  s->origin_tip_pose = s->current_tip_pose;
+  s->target_tip_pose = s->default_tip_pose;
+  s->walk_plane = orc_v3_make(0, 0, 0);
+  s->walk_plane_normal = orc_v3_make(0, 0, 1);
+  s->stride_vector = orc_v3_make(0, 0, 0);
+  s->current_tip_velocity = orc_v3_make(0, 0, 0);
+  s->swing_origin_tip_position = s->default_tip_pose.p;
+  s->stance_origin_tip_position = s->default_tip_pose.p;
+  s->swing_clearance = orc_v3_make(0.0, 0.0, r->params.swing_height);
+  s->at_correct_phase = 0; s->completed_first_step = 0;
+  s->phase = 0; s->phase_offset = 0;
+  s->step_progress = 0.0; s->swing_progress = -1.0; s->stance_progress = -1.0; /* walk_controller.h:497-499 */
+  s->step_state = STANCE;
+  s->swing_origin_tip_velocity = orc_v3_make(0, 0, 0); /* uninitialised in the reference until first swing */
+}
+
+/* WalkController::init (walk_controller.cpp:22-53) */
+static void walker_init(orc_robot *r)
+{
+  r->walk_state = STOPPED;
+  r->pose_state = POSING_COMPLETE;
+  r->walk_plane = orc_v3_make(0, 0, 0);
+  r->walk_plane_normal = orc_v3_make(0, 0, 1);
+  r->odometry_ideal = orc_pose_identity();
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    double x_position = r->params.stance_position[l][0];
+    double y_position = r->params.stance_position[l][1];
+    orc_quat identity_tip_rotation = ORC_UNDEFINED_ROTATION;
+    if (leg->joint_count > 3 && r->params.gravity_aligned_tips)
+    {
+      identity_tip_rotation = orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), orc_v3_make(-0.0, -0.0, -1));
+      identity_tip_rotation = orc_correct_rotation(identity_tip_rotation, orc_quat_identity());
+    }
+    stepper_construct(r, &leg->stepper, orc_pose_make(orc_v3_make(x_position, y_position, 0.0), identity_tip_rotation));
+  }
+  r->desired_linear_velocity[0] = r->desired_linear_velocity[1] = 0;
+  r->desired_angular_velocity = 0;
+  r->legs_at_correct_phase = 0;
+  r->legs_completed_first_step = 0;
+  r->return_to_default_attempted = 0;
+  r->step = generate_step_cycle(&r->params);
+}
+
+/* WalkController::generateLimits (walk_controller.cpp:231-361), set_limits path */
+static void walker_generate_limits(orc_robot *r)
+{
+  const shc_params *p = &r->params;
+  shc_step_cycle step = r->step;
+  int base_step_period = p->stance_phase + p->swing_phase;
+  int normaliser = step.period / base_step_period;
+  int base_step_offset = (int)(p->phase_offset * normaliser);
+
+  int max_stance_extension = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    int multiplier = p->offset_multiplier[l];
+    int step_offset = (base_step_offset * multiplier) % step.period;
+    r->leg[l].stepper.phase_offset = step_offset;
+    if (step_offset > step.swing_start && step_offset < step.swing_end)
+    {
+      int ext = step.swing_end - step_offset;
+      max_stance_extension = max_stance_extension > ext ? max_stance_extension : ext;
+    }
+  }
+  double time_to_max_stride = (max_stance_extension + step.stance_period + step.swing_period) * r->time_delta;
+
+  for (int b = 0; b < SHC_N_BEARINGS; ++b)
+  {
+    double walkspace_radius = r->walkspace[b];
+    double on_ground_ratio = (double)step.stance_period / step.period;
+    double max_speed = (walkspace_radius * 2.0) / (on_ground_ratio / step.frequency);
+    double max_acceleration = max_speed / time_to_max_stride;
+
+    double stance_overshoot = 0;
+    for (int l = 0; l < r->leg_count; ++l)
+    {
+      double step_offset = r->leg[l].stepper.phase_offset;
+      double t = step_offset * r->time_delta;
+      double time_to_swing_end = time_to_max_stride - t;
+      double v0 = max_acceleration * time_to_swing_end;
+      double stride_length = v0 * (on_ground_ratio / step.frequency);
+      double d0 = -stride_length / 2.0;
+      double d1 = d0 + v0 * t + 0.5 * max_acceleration * orc_sqr(t);
+      double d2 = max_speed * (step.stance_period * r->time_delta - t);
+      stance_overshoot = fmax(stance_overshoot, d1 + d2 - walkspace_radius);
+    }
+    double swing_overshoot = 0.5 * max_speed * step.swing_period / (2.0 * step.period * step.frequency);
+    double scaled_walkspace_radius =
+        (walkspace_radius / (walkspace_radius + stance_overshoot + swing_overshoot)) * walkspace_radius;
+
+    double x_position = r->leg[0].stepper.default_tip_pose.p.x;
+    double y_position = r->leg[0].stepper.default_tip_pose.p.y;
+    double stance_radius = sqrt(x_position * x_position + y_position * y_position);
+
+    double max_linear_speed = (scaled_walkspace_radius * 2.0) / (on_ground_ratio / step.frequency);
+    double max_linear_acceleration = max_linear_speed / time_to_max_stride;
+    double max_angular_speed = max_linear_speed / stance_radius;
+    double max_angular_acceleration = max_angular_speed / time_to_max_stride;
+    if (walkspace_radius == 0.0)
+    {
+      max_linear_speed = 0.0;
+      max_linear_acceleration = ORC_UNASSIGNED_VALUE;
+      max_angular_speed = 0.0;
+      max_angular_acceleration = ORC_UNASSIGNED_VALUE;
+    }
+    r->max_linear_speed[b] = max_linear_speed;
+    r->max_linear_acceleration[b] = max_linear_acceleration;
+    r->max_angular_speed[b] = max_angular_speed;
+    r->max_angular_acceleration[b] = max_angular_acceleration;
+  }
+}
+
+/* WalkController::generateWalkspace (walk_controller.cpp:57-227) */
+static void walker_generate_walkspace(orc_robot *r)
+{
+  int have[SHC_N_BEARINGS];
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) have[b] = 0;
+  int leg_count = r->leg_count;
+  for (int l = 0; l < leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    leg_t *adj1 = &r->leg[orc_mod(l + 1, leg_count)];
+    leg_t *adj2 = &r->leg[orc_mod(l - 1, leg_count)];
+    orc_v3 dtp = leg->stepper.default_tip_pose.p;
+    orc_v3 a1 = adj1->stepper.default_tip_pose.p;
+    orc_v3 a2 = adj2->stepper.default_tip_pose.p;
+    double distance_to_adjacent_leg_1 = orc_v3_norm(orc_v3_sub(dtp, a1)) / 2.0;
+    double distance_to_adjacent_leg_2 = orc_v3_norm(orc_v3_sub(dtp, a2)) / 2.0;
+    double bearing_to_adjacent_leg_1 = orc_rad2deg(atan2(a1.y - dtp.y, a1.x - dtp.x));
+    double bearing_to_adjacent_leg_2 = orc_rad2deg(atan2(a2.y - dtp.y, a2.x - dtp.x));
+    for (int bearing = 0; bearing <= 360; bearing += BEARING_STEP)
+    {
+      int bearing_diff_1 = abs(orc_mod((int)bearing_to_adjacent_leg_1, 360) - bearing);
+      int bearing_diff_2 = abs(orc_mod((int)bearing_to_adjacent_leg_2, 360) - bearing);
+      double distance_to_overlap_1 = ORC_UNASSIGNED_VALUE;
+      double distance_to_overlap_2 = ORC_UNASSIGNED_VALUE;
+      if ((bearing_diff_1 < 90 || bearing_diff_1 > 270) && distance_to_adjacent_leg_1 > 0.0)
+        distance_to_overlap_1 = distance_to_adjacent_leg_1 / cos(orc_deg2rad(bearing_diff_1));
+      if ((bearing_diff_2 < 90 || bearing_diff_2 > 270) && distance_to_adjacent_leg_2 > 0.0)
+        distance_to_overlap_2 = distance_to_adjacent_leg_2 / cos(orc_deg2rad(bearing_diff_2));
+      int overlapping = r->params.overlapping_walkspaces;
+      double min_distance = overlapping ? MAX_WORKSPACE_RADIUS : fmin(distance_to_overlap_1, distance_to_overlap_2);
+      min_distance = fmin(min_distance, MAX_WORKSPACE_RADIUS);
+      int bi = bearing / BEARING_STEP;
+      if (have[bi] && min_distance < r->walkspace[bi]) r->walkspace[bi] = min_distance;
+      else if (!have[bi]) { r->walkspace[bi] = min_distance; have[bi] = 1; }
+    }
+  }
+
+  for (int l = 0; l < leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    orc_pose current_pose = r->current_pose;
+    orc_v3 identity_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.identity_tip_pose.p);
+    orc_v3 default_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.default_tip_pose.p);
+    orc_v3 default_shift = orc_v3_sub(default_tip_position, identity_tip_position);
+    double target_workplane_height = default_shift.z;
+    /* Leg::getWorkplane (model.cpp:514-550) with the single plane at height 0.0 */
+    if (!(target_workplane_height >= 0.0 && target_workplane_height <= 0.0)) continue; /* "undefined" workplane -> empty */
+    const double *workplane = leg->workspace;
+
+    for (int bi = 0; bi < SHC_N_BEARINGS; ++bi)
+    {
+      int bearing = bi * BEARING_STEP;
+      double radius = r->walkspace[bi];
+      if (orc_v3_norm(default_shift) == 0.0)
+      {
+        radius = workplane[bi];
+      }
+      else
+      {
+        /* AngleAxisd::_transformVector == toRotationMatrix() * v */
+        orc_v3 new_point = orc_angle_axis_rotate(orc_deg2rad(bearing), orc_v3_make(0, 0, 1), orc_v3_make(MAX_WORKSPACE_RADIUS, 0, 0));
+        new_point = orc_v3_set_precision(new_point, 3);
+        for (int wi = 0; wi < SHC_N_BEARINGS; ++wi)
+        {
+          int bearing_1 = wi * BEARING_STEP;
+          double radius_1 = workplane[wi];
+          orc_v3 point_1 = orc_angle_axis_rotate(orc_deg2rad(bearing_1), orc_v3_make(0, 0, 1), orc_v3_make(radius_1, 0, 0));
+          point_1 = orc_v3_sub(point_1, default_shift);
+          point_1.z = 0.0;
+          point_1 = orc_v3_set_precision(point_1, 3);
+          if (bearing_1 == 360) { radius = 0.0; break; }
+          int bearing_2 = (wi + 1) * BEARING_STEP;
+          double radius_2 = workplane[wi + 1];
+          orc_v3 point_2 = orc_angle_axis_rotate(orc_deg2rad(bearing_2), orc_v3_make(0, 0, 1), orc_v3_make(radius_2, 0, 0));
+          point_2 = orc_v3_sub(point_2, default_shift);
+          point_2.z = 0.0;
+          point_2 = orc_v3_set_precision(point_2, 3);
+          if (orc_v3_norm(orc_v3_cross(point_1, new_point)) == 0.0) { radius = orc_v3_norm(point_1); break; }
+          else if (orc_v3_norm(orc_v3_cross(point_2, new_point)) == 0.0) { radius = orc_v3_norm(point_2); break; }
+          else if (orc_v3_dot(orc_v3_cross(point_1, new_point), orc_v3_cross(point_1, point_2)) >= 0.0 &&
+                   orc_v3_dot(orc_v3_cross(point_2, new_point), orc_v3_cross(point_2, point_1)) >= 0.0)
+          {
+            double dx = point_2.x - point_1.x;
+            double dy = point_2.y - point_1.y;
+            orc_v3 normal_1 = orc_v3_normalized(orc_v3_make(dy, -dx, 0.0));
+            orc_v3 normal_2 = orc_v3_normalized(orc_v3_make(-dy, dx, 0.0));
+            int same_direction_as_new_point = orc_v3_dot(orc_get_projection(new_point, normal_1), normal_1) >= 0.0;
+            orc_v3 normal = same_direction_as_new_point ? normal_1 : normal_2;
+            orc_v3 new_point_projection = orc_get_projection(new_point, normal);
+            orc_v3 point_1_projection = orc_get_projection(point_1, normal);
+            double ratio = orc_v3_norm(point_1_projection) / orc_v3_norm(new_point_projection);
+            radius = ratio * MAX_WORKSPACE_RADIUS;
+            break;
+          }
+        }
+      }
+      int opposite_bearing = orc_mod(bearing + 180, 360);
+      if (radius < r->walkspace[bi])
+      {
+        r->walkspace[bi] = radius;
+        r->walkspace[opposite_bearing / BEARING_STEP] = radius;
+      }
+    }
+  }
+  r->walkspace[360 / BEARING_STEP] = r->walkspace[0];
+  walker_generate_limits(r);
+}
+
+/* WalkController::getLimit (walk_controller.cpp:414-436) */
+static double walker_get_limit(const orc_robot *r, const double lin[2], double ang, const double *limit)
+{
+  double min_limit = ORC_UNASSIGNED_VALUE;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    orc_v3 tip_position = r->leg[l].stepper.current_tip_pose.p;
+    double rn0 = -tip_position.y, rn1 = tip_position.x;
+    double sv0 = lin[0] + ang * rn0, sv1 = lin[1] + ang * rn1;
+    int bearing = orc_mod(orc_round_to_int(orc_rad2deg(atan2(sv1, sv0))), 360);
+    int upper_bound = ((bearing + BEARING_STEP - 1) / BEARING_STEP) * BEARING_STEP; /* map::lower_bound(bearing)->first */
+    int lower_bound = orc_mod(upper_bound - BEARING_STEP, 360);
+    bearing += (bearing < lower_bound) ? 360 : 0;
+    upper_bound += (upper_bound < lower_bound) ? 360 : 0;
+    double control_input = (bearing - lower_bound) / (upper_bound - lower_bound); /* int / int (quirk 4) */
+    double limit_interpolation =
+        orc_interpolate(limit[lower_bound / BEARING_STEP], limit[orc_mod(upper_bound, 360) / BEARING_STEP], control_input);
+    min_limit = fmin(min_limit, limit_interpolation);
+  }
+  return min_limit;
+}
+
+/* LegStepper::updateStepState (walk_controller.cpp:901-917) */
+static void stepper_update_step_state(const orc_robot *r, stepper_t *s)
+{
+  const shc_step_cycle *step = &r->step;
+  if (s->step_state == FORCE_STOP) return;
+  else if (s->phase >= step->swing_start && s->phase < step->swing_end && s->step_state != FORCE_STANCE) s->step_state = SWING;
+  else if (s->phase < step->stance_end || s->phase >= step->stance_start) s->step_state = STANCE;
+}
+
+/* LegStepper::iteratePhase (walk_controller.cpp:871-897) */
+static void stepper_iterate_phase(const orc_robot *r, stepper_t *s)
+{
+  const shc_step_cycle *step = &r->step;
+  s->phase = (s->phase + 1) % (step->period);
+  stepper_update_step_state(r, s);
+  s->step_progress = (double)s->phase / step->period;
+  if (s->step_state == SWING)
+  {
+    s->swing_progress = (double)(s->phase - step->swing_start + 1) / (double)(step->swing_end - step->swing_start);
+    s->swing_progress = orc_clamped(s->swing_progress, 0.0, 1.0);
+    s->stance_progress = -1.0;
+  }
+  else if (s->step_state == STANCE)
+  {
+    s->stance_progress = (double)(orc_mod(s->phase + (step->period - step->stance_start), step->period) + 1) /
+                         (double)(orc_mod(step->stance_end - step->stance_start, step->period));
+    s->stance_progress = orc_clamped(s->stance_progress, 0.0, 1.0);
+    s->swing_progress = -1.0;
+  }
+  else if (s->step_state == FORCE_STOP)
+  {
+    s->stance_progress = 0.0;
+    s->swing_progress = -1.0;
+  }
+}
+
+/* LegStepper::updateStride (walk_controller.cpp:921-945) */
+static void stepper_update_stride(const orc_robot *r, stepper_t *s)
+{
+  s->walk_plane = r->walk_plane;
+  s->walk_plane_normal = r->walk_plane_normal;
+  orc_v3 stride_vector_linear = orc_v3_make(r->desired_linear_velocity[0], r->desired_linear_velocity[1], 0.0);
+  orc_v3 radius = orc_get_rejection(s->current_tip_pose.p, orc_v3_make(0, 0, 1));
+  orc_v3 angular_velocity = orc_v3_scale(orc_v3_make(0, 0, 1), r->desired_angular_velocity);
+  orc_v3 stride_vector_angular = orc_v3_cross(angular_velocity, radius);
+  s->stride_vector = orc_v3_add(stride_vector_linear, stride_vector_angular);
+  double on_ground_ratio = (double)r->step.stance_period / r->step.period;
+  s->stride_vector = orc_v3_scale(s->stride_vector, (on_ground_ratio / r->step.frequency));
+  s->swing_clearance = orc_v3_scale(orc_v3_normalized(s->walk_plane_normal), r->params.swing_height);
+}
+
+/* LegStepper::calculateStanceSpanChange (walk_controller.cpp:949-980), single-plane workspace */
+static orc_v3 stepper_calculate_stance_span_change(const orc_robot *r, const leg_t *leg)
+{
+  const stepper_t *s = &leg->stepper;
+  double stance_span_modifier = r->params.stance_span_modifier;
+  int positive_y_axis = (s->identity_tip_pose.p.y > 0.0); /* UnitY.dot(identity) > 0 */
+  int bearing = (positive_y_axis ^ (stance_span_modifier > 0.0)) ? 270 : 90;
+  stance_span_modifier *= (positive_y_axis ? 1.0 : -1.0);
+  double radius = leg->workspace[bearing / BEARING_STEP]; /* workspace.size() == 1 -> workspace.at(0.0).at(bearing) */
+  return orc_v3_make(0.0, radius * stance_span_modifier, 0.0);
+}
+
+/* LegStepper::updateDefaultTipPosition (walk_controller.cpp:984-1014), no external default */
+static void stepper_update_default_tip_position(const orc_robot *r, leg_t *leg)
+{
+  stepper_t *s = &leg->stepper;
+  orc_v3 identity_tip_position = s->identity_tip_pose.p;
+  identity_tip_position = orc_v3_add(identity_tip_position, stepper_calculate_stance_span_change(r, leg));
+  identity_tip_position = orc_pose_transform_vector(r->default_pose, identity_tip_position); /* leg_->getDefaultBodyPose() */
+  orc_v3 identity_to_stance_origin = orc_v3_sub(s->stance_origin_tip_position, identity_tip_position);
+  orc_v3 projection_to_walk_plane = orc_get_projection(identity_to_stance_origin, s->walk_plane_normal);
+  s->default_tip_pose = orc_pose_make(orc_v3_add(identity_tip_position, projection_to_walk_plane), ORC_UNDEFINED_ROTATION);
+}
+
+/* control node generators (walk_controller.cpp:1238-1329) */
+static void stepper_generate_primary_swing_control_nodes(const orc_robot *r, stepper_t *s)
+{
+  orc_v3 mid_tip_position;
+  mid_tip_position.x = (s->swing_origin_tip_position.x + s->target_tip_pose.p.x) / 2.0;
+  mid_tip_position.y = (s->swing_origin_tip_position.y + s->target_tip_pose.p.y) / 2.0;
+  mid_tip_position.z = fmax(s->swing_origin_tip_position.z, s->target_tip_pose.p.z);
+  mid_tip_position = orc_v3_add(mid_tip_position, s->swing_clearance);
+  double mid_lateral_shift = r->params.swing_width;
+  int positive_y_axis = (s->identity_tip_pose.p.y > 0.0);
+  mid_tip_position.y += positive_y_axis ? mid_lateral_shift : -mid_lateral_shift;
+  orc_v3 stance_node_seperation = orc_v3_scale(orc_v3_scale(s->swing_origin_tip_velocity, 0.25), (r->time_delta / s->swing_delta_t));
+  s->swing_1_nodes[0] = s->swing_origin_tip_position;
+  s->swing_1_nodes[1] = orc_v3_add(s->swing_origin_tip_position, stance_node_seperation);
+  s->swing_1_nodes[2] = orc_v3_add(s->swing_origin_tip_position, orc_v3_scale(stance_node_seperation, 2.0));
+  s->swing_1_nodes[3] = orc_v3_make((mid_tip_position.x + s->swing_1_nodes[2].x) / 2.0,
+                                    (mid_tip_position.y + s->swing_1_nodes[2].y) / 2.0,
+                                    (mid_tip_position.z + s->swing_1_nodes[2].z) / 2.0);
+  s->swing_1_nodes[3].z = mid_tip_position.z;
+  s->swing_1_nodes[4] = mid_tip_position;
+}
+
+static void stepper_generate_secondary_swing_control_nodes(const orc_robot *r, stepper_t *s, int ground_contact)
+{
+  orc_v3 final_tip_velocity = orc_v3_scale(orc_v3_neg(s->stride_vector), (s->stance_delta_t / r->time_delta));
+  orc_v3 stance_node_seperation = orc_v3_scale(orc_v3_scale(final_tip_velocity, 0.25), (r->time_delta / s->swing_delta_t));
+  s->swing_2_nodes[0] = s->swing_1_nodes[4];
+  s->swing_2_nodes[1] = orc_v3_sub(s->swing_1_nodes[4], orc_v3_sub(s->swing_1_nodes[3], s->swing_1_nodes[4]));
+  s->swing_2_nodes[2] = orc_v3_sub(s->target_tip_pose.p, orc_v3_scale(stance_node_seperation, 2.0));
+  s->swing_2_nodes[3] = orc_v3_sub(s->target_tip_pose.p, stance_node_seperation);
+  s->swing_2_nodes[4] = s->target_tip_pose.p;
+  if (ground_contact)
+  {
+    for (int k = 0; k < 5; ++k)
+      s->swing_2_nodes[k] = orc_v3_add(s->current_tip_pose.p, orc_v3_scale(stance_node_seperation, (double)k));
+  }
+}
+
+static void stepper_generate_stance_control_nodes(stepper_t *s, double stride_scaler)
+{
+  orc_v3 stance_node_seperation = orc_v3_scale(orc_v3_scale(orc_v3_neg(s->stride_vector), stride_scaler), 0.25);
+  for (int k = 0; k < 5; ++k)
+    s->stance_nodes[k] = orc_v3_add(s->stance_origin_tip_position, orc_v3_scale(stance_node_seperation, (double)k));
+}
+
+static void stepper_force_normal_touchdown(const orc_robot *r, stepper_t *s)
+{
+  orc_v3 final_tip_velocity = orc_v3_scale(orc_v3_neg(s->stride_vector), (s->stance_delta_t / r->time_delta));
+  orc_v3 stance_node_seperation = orc_v3_scale(orc_v3_scale(final_tip_velocity, 0.25), (r->time_delta / s->swing_delta_t));
+  orc_v3 bezier_target = s->target_tip_pose.p;
+  orc_v3 bezier_origin = orc_v3_sub(s->target_tip_pose.p, orc_v3_scale(stance_node_seperation, 4.0));
+  bezier_origin.z = fmax(s->swing_origin_tip_position.z, s->target_tip_pose.p.z);
+  bezier_origin = orc_v3_add(bezier_origin, s->swing_clearance);
+  s->swing_1_nodes[4] = bezier_origin;
+  s->swing_2_nodes[0] = bezier_origin;
+  s->swing_2_nodes[2] = orc_v3_sub(bezier_target, orc_v3_scale(stance_node_seperation, 2.0));
+  orc_v3 half = orc_v3_make((s->swing_2_nodes[2].x - bezier_origin.x) / 2.0, (s->swing_2_nodes[2].y - bezier_origin.y) / 2.0,
+                     (s->swing_2_nodes[2].z - bezier_origin.z) / 2.0);
+  s->swing_1_nodes[3] = orc_v3_sub(s->swing_2_nodes[0], half);
+  s->swing_2_nodes[1] = orc_v3_add(s->swing_2_nodes[0], half);
+}
+
+/* LegStepper::updateTipPosition (walk_controller.cpp:1018-1189), rough_terrain_mode == false */
+static void stepper_update_tip_position(const orc_robot *r, leg_t *leg)
+{
+  stepper_t *s = &leg->stepper;
+  double time_delta = r->time_delta;
+  const shc_step_cycle *step = &r->step;
+
+  int standard_stance_period = (s->step_state == SWING || s->completed_first_step);
+  int modified_stance_start = standard_stance_period ? step->stance_start : s->phase_offset;
+  int modified_stance_period = orc_mod(step->stance_end - modified_stance_start, step->period);
+  if (step->stance_end == modified_stance_start) modified_stance_period = step->period;
+
+  int swing_iterations = (int)(((double)step->swing_period / step->period) / (step->frequency * time_delta));
+  swing_iterations = orc_round_to_even_int(swing_iterations);
+  s->swing_delta_t = 1.0 / (swing_iterations / 2.0);
+
+  int stance_iterations = (int)(((double)modified_stance_period / step->period) / (step->frequency * time_delta));
+  s->stance_delta_t = 1.0 / stance_iterations;
+
+  s->target_tip_pose.p = orc_v3_add(s->default_tip_pose.p, orc_v3_scale(s->stride_vector, 0.5));
+
+  if (s->step_state == SWING)
+  {
+    stepper_update_stride(r, s);
+    int iteration = s->phase - step->swing_start + 1;
+    int first_half = iteration <= swing_iterations / 2;
+    if (iteration == 1)
+    {
+      s->swing_origin_tip_position = s->current_tip_pose.p;
+      s->swing_origin_tip_velocity = s->current_tip_velocity;
+    }
+    int ground_contact = 0; /* rough_terrain_mode false */
+    stepper_generate_primary_swing_control_nodes(r, s);
+    stepper_generate_secondary_swing_control_nodes(r, s, !first_half && ground_contact);
+    if (r->params.force_normal_touchdown && !ground_contact) stepper_force_normal_touchdown(r, s);
+
+    orc_v3 delta_pos;
+    double time_input;
+    if (first_half)
+    {
+      time_input = s->swing_delta_t * iteration;
+      delta_pos = orc_v3_scale(orc_quartic_bezier_dot(s->swing_1_nodes, time_input), s->swing_delta_t);
+    }
+    else
+    {
+      time_input = s->swing_delta_t * (iteration - swing_iterations / 2);
+      delta_pos = orc_v3_scale(orc_quartic_bezier_dot(s->swing_2_nodes, time_input), s->swing_delta_t);
+    }
+    s->current_tip_pose.p = orc_v3_add(s->current_tip_pose.p, delta_pos);
+    s->current_tip_velocity = orc_v3_make(delta_pos.x / time_delta, delta_pos.y / time_delta, delta_pos.z / time_delta);
+  }
+  else if (s->step_state == STANCE || s->step_state == FORCE_STANCE)
+  {
+    stepper_update_stride(r, s);
+    int iteration = orc_mod(s->phase + (step->period - modified_stance_start), step->period) + 1;
+    if (iteration == 1) s->stance_origin_tip_position = s->current_tip_pose.p;
+    double stride_scaler = (double)modified_stance_period / (orc_mod(step->stance_end - step->stance_start, step->period));
+    stepper_generate_stance_control_nodes(s, stride_scaler);
+    double time_input = iteration * s->stance_delta_t;
+    orc_v3 delta_pos = orc_v3_scale(orc_quartic_bezier_dot(s->stance_nodes, time_input), s->stance_delta_t);
+    s->current_tip_pose.p = orc_v3_add(s->current_tip_pose.p, delta_pos);
+    s->current_tip_velocity = orc_v3_make(delta_pos.x / time_delta, delta_pos.y / time_delta, delta_pos.z / time_delta);
+  }
+}
+
+/* LegStepper::updateTipRotation (walk_controller.cpp:1193-1234) */
+static void stepper_update_tip_rotation(const orc_robot *r, leg_t *leg)
+{
+  stepper_t *s = &leg->stepper;
+  if (leg->joint_count > 3 && (s->stance_progress >= 0.0 || s->swing_progress >= 0.5))
+  {
+    if (r->params.gravity_aligned_tips && orc_quat_is_undefined(s->target_tip_pose.r))
+      s->target_tip_pose.r = orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), model_estimate_gravity(r));
+    if (orc_quat_is_undefined(s->target_tip_pose.r))
+    {
+      s->current_tip_pose.r = s->target_tip_pose.r;
+    }
+    else
+    {
+      s->current_tip_pose.r = orc_correct_rotation(s->target_tip_pose.r, s->origin_tip_pose.r);
+      if (s->swing_progress >= 0.5)
+      {
+        double c = orc_smooth_step(fmin(1.0, 2.0 * (s->swing_progress - 0.5)));
+        orc_v3 origin_tip_direction = orc_quat_rotate(s->origin_tip_pose.r, orc_v3_make(1, 0, 0));
+        orc_v3 target_tip_direction = orc_quat_rotate(s->target_tip_pose.r, orc_v3_make(1, 0, 0));
+        orc_v3 new_tip_direction = orc_v3_lerp(origin_tip_direction, target_tip_direction, c);
+        orc_quat new_tip_rotation = orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), orc_v3_normalized(new_tip_direction));
+        s->current_tip_pose.r = orc_correct_rotation(new_tip_rotation, s->current_tip_pose.r);
+      }
+    }
+  }
+  else
+  {
+    s->origin_tip_pose.r = leg->current_tip_pose.r;
+    s->current_tip_pose.r = ORC_UNDEFINED_ROTATION;
+  }
+}
+
+/* WalkController::updateWalkPlane (walk_controller.cpp:748-779) */
+static void walker_update_walk_plane(orc_robot *r)
+{
+  int n = r->leg_count;
+  if (n >= 3)
+  {
+    double ata[9] = { 0 }, atb[3] = { 0 };
+    double A[SHC_MAX_LEGS][3], B[SHC_MAX_LEGS];
+    for (int l = 0; l < n; ++l)
+    {
+      A[l][0] = r->leg[l].stepper.default_tip_pose.p.x;
+      A[l][1] = r->leg[l].stepper.default_tip_pose.p.y;
+      A[l][2] = 1.0;
+      B[l] = r->leg[l].stepper.default_tip_pose.p.z;
+    }
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+      {
+        double s = 0.0;
+        for (int l = 0; l < n; ++l) s += A[l][i] * A[l][j];
+        ata[i * 3 + j] = s;
+      }
+    double inv[9];
+    orc_lu_inverse(ata, 3, inv);
+    /* pseudo_inverse_A = (AtA)^-1 * At ; walk_plane = pinv * B */
+    double pinv[3][SHC_MAX_LEGS];
+    for (int i = 0; i < 3; ++i)
+      for (int l = 0; l < n; ++l)
+      {
+        double s = 0.0;
+        for (int k = 0; k < 3; ++k) s += inv[i * 3 + k] * A[l][k];
+        pinv[i][l] = s;
+      }
+    for (int i = 0; i < 3; ++i)
+    {
+      double s = 0.0;
+      for (int l = 0; l < n; ++l) s += pinv[i][l] * B[l];
+      atb[i] = s;
+    }
+    r->walk_plane = orc_v3_make(atb[0], atb[1], atb[2]);
+    r->walk_plane_normal = orc_v3_normalized(orc_v3_make(-r->walk_plane.x, -r->walk_plane.y, 1.0));
+  }
+  else
+  {
+    r->walk_plane = orc_v3_make(0, 0, 0);
+    r->walk_plane_normal = orc_v3_make(0, 0, 1);
+  }
+}
+
+/* WalkController::calculateOdometry (walk_controller.cpp:783-791) */
+static orc_pose walker_calculate_odometry(const orc_robot *r, double time_period)
+{
+  orc_v3 position_delta = orc_v3_scale(orc_v3_make(r->desired_linear_velocity[0], r->desired_linear_velocity[1], 0), time_period);
+  orc_quat rotation_delta = orc_quat_from_angle_axis(r->desired_angular_velocity * time_period, orc_v3_make(0, 0, 1));
+  return orc_pose_make(position_delta, rotation_delta);
+}
+
+/* WalkController::updateWalk (walk_controller.cpp:440-648) */
+static void walker_update_walk(orc_robot *r, const double lin_in[2], double ang_in)
+{
+  double new_linear_velocity[2];
+  double new_angular_velocity;
+  double max_linear_speed = walker_get_limit(r, lin_in, ang_in, r->max_linear_speed);
+  double max_angular_speed = walker_get_limit(r, lin_in, ang_in, r->max_angular_speed);
+  double max_linear_acceleration = walker_get_limit(r, lin_in, ang_in, r->max_linear_acceleration);
+  double max_angular_acceleration = walker_get_limit(r, lin_in, ang_in, r->max_angular_acceleration);
+  double lin_norm = sqrt(lin_in[0] * lin_in[0] + lin_in[1] * lin_in[1]);
+
+  if (r->walk_state != STOPPING)
+  {
+    if (r->params.velocity_input_mode == SHC_VEL_THROTTLE)
+    {
+      double cl[2] = { lin_in[0], lin_in[1] };
+      if (lin_norm > 1.0) { cl[0] = lin_in[0] * (1.0 / lin_norm); cl[1] = lin_in[1] * (1.0 / lin_norm); }
+      new_linear_velocity[0] = cl[0] * max_linear_speed;
+      new_linear_velocity[1] = cl[1] * max_linear_speed;
+      new_angular_velocity = orc_clamped(ang_in, -1.0, 1.0) * max_angular_speed;
+      new_linear_velocity[0] *= (1.0 - fabs(ang_in));
+      new_linear_velocity[1] *= (1.0 - fabs(ang_in));
+    }
+    else
+    {
+      double cl[2] = { lin_in[0], lin_in[1] };
+      if (lin_norm > max_linear_speed) { cl[0] = lin_in[0] * (max_linear_speed / lin_norm); cl[1] = lin_in[1] * (max_linear_speed / lin_norm); }
+      new_linear_velocity[0] = cl[0];
+      new_linear_velocity[1] = cl[1];
+      new_angular_velocity = orc_clamped(ang_in, -max_angular_speed, max_angular_speed);
+      double sc = (max_angular_speed != 0.0 ? (1.0 - fabs(new_angular_velocity / max_angular_speed)) : 0.0);
+      new_linear_velocity[0] *= sc;
+      new_linear_velocity[1] *= sc;
+    }
+  }
+  else
+  {
+    new_linear_velocity[0] = new_linear_velocity[1] = 0.0;
+    new_angular_velocity = 0.0;
+  }
+
+  int has_velocity_command = (lin_norm != 0.0) || (ang_in != 0.0);
+
+  /* all legs WALKING on this path (:492-505) */
+
+  double la[2] = { new_linear_velocity[0] - r->desired_linear_velocity[0], new_linear_velocity[1] - r->desired_linear_velocity[1] };
+  double la_norm = sqrt(la[0] * la[0] + la[1] * la[1]);
+  if (la_norm < max_linear_acceleration * r->time_delta)
+  {
+    r->desired_linear_velocity[0] += la[0];
+    r->desired_linear_velocity[1] += la[1];
+  }
+  else
+  {
+    double z = la[0] * la[0] + la[1] * la[1];
+    double n0 = la[0], n1 = la[1];
+    if (z > 0.0) { n0 = la[0] / sqrt(z); n1 = la[1] / sqrt(z); }
+    r->desired_linear_velocity[0] += n0 * max_linear_acceleration * r->time_delta;
+    r->desired_linear_velocity[1] += n1 * max_linear_acceleration * r->time_delta;
+  }
+  double angular_acceleration = new_angular_velocity - r->desired_angular_velocity;
+  if (fabs(angular_acceleration) < max_angular_acceleration * r->time_delta)
+    r->desired_angular_velocity += angular_acceleration;
+  else
+    r->desired_angular_velocity += orc_sign(angular_acceleration) * max_angular_acceleration * r->time_delta;
+
+  int leg_count = r->leg_count;
+  if (r->walk_state == STOPPED && has_velocity_command)
+  {
+    r->walk_state = STARTING;
+    for (int l = 0; l < leg_count; ++l)
+    {
+      stepper_t *s = &r->leg[l].stepper;
+      s->at_correct_phase = 0;
+      s->completed_first_step = 0;
+      s->step_state = STANCE;
+      s->phase = s->phase_offset;
+      stepper_update_step_state(r, s);
+    }
+    return;
+  }
+  else if (r->walk_state == STARTING && r->legs_at_correct_phase == leg_count && r->legs_completed_first_step == leg_count)
+  {
+    r->legs_at_correct_phase = 0;
+    r->legs_completed_first_step = 0;
+    r->walk_state = MOVING;
+  }
+  else if (r->walk_state == MOVING && !has_velocity_command)
+  {
+    r->walk_state = STOPPING;
+  }
+  else if (r->walk_state == STOPPING && r->legs_at_correct_phase == leg_count && r->pose_state == POSING_COMPLETE)
+  {
+    r->legs_at_correct_phase = 0;
+    r->walk_state = STOPPED;
+  }
+
+  for (int l = 0; l < leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    stepper_t *s = &leg->stepper;
+    if (r->walk_state == STARTING)
+    {
+      if (r->legs_at_correct_phase == leg_count)
+      {
+        if (s->phase == r->step.swing_end && !s->completed_first_step)
+        {
+          s->completed_first_step = 1;
+          r->legs_completed_first_step++;
+        }
+      }
+      if (!s->at_correct_phase)
+      {
+        if (s->phase_offset > r->step.swing_start && s->phase_offset < r->step.swing_end && s->phase != r->step.swing_end)
+        {
+          s->step_state = FORCE_STANCE;
+        }
+        else
+        {
+          r->legs_at_correct_phase++;
+          s->at_correct_phase = 1;
+        }
+      }
+    }
+    else if (r->walk_state == MOVING)
+    {
+      s->at_correct_phase = 0;
+    }
+    else if (r->walk_state == STOPPING)
+    {
+      int zero_body_velocity = orc_v3_norm(s->stride_vector) == 0;
+      orc_v3 error = orc_v3_sub(s->current_tip_pose.p, s->target_tip_pose.p);
+      error = orc_get_rejection(error, s->walk_plane_normal);
+      int at_target_tip_position = (orc_v3_norm(error) < TIP_TOLERANCE);
+      if (zero_body_velocity && !s->at_correct_phase && s->phase == r->step.swing_end)
+      {
+        if (at_target_tip_position || r->return_to_default_attempted)
+        {
+          r->return_to_default_attempted = 0;
+          stepper_update_default_tip_position(r, leg);
+          s->step_state = FORCE_STOP;
+          s->at_correct_phase = 1;
+          r->legs_at_correct_phase++;
+        }
+        else
+        {
+          r->return_to_default_attempted = 1;
+        }
+      }
+    }
+    else if (r->walk_state == STOPPED)
+    {
+      s->step_state = FORCE_STOP;
+      s->phase = 0;
+    }
+    /* leg state WALKING */
+    stepper_update_tip_position(r, leg);
+    stepper_update_tip_rotation(r, leg);
+    stepper_iterate_phase(r, s);
+  }
+  walker_update_walk_plane(r);
+  r->odometry_ideal = orc_pose_add(r->odometry_ideal, walker_calculate_odometry(r, r->time_delta));
+}
+
+/* ==================================================================================== PoseController */
+
+/* PoseController::setAutoPoseParams (pose_controller.cpp:44-106) */
+static void poser_set_auto_pose_params(orc_robot *r)
+{
+  const shc_params *p = &r->params;
+  double raw_phase_length;
+  int base_phase_length;
+  r->pose_frequency = p->pose_frequency;
+  if (r->pose_frequency == -1.0)
+  {
+    base_phase_length = p->stance_phase + p->swing_phase;
+    double swing_ratio = (double)p->swing_phase / base_phase_length;
+    raw_phase_length = ((1.0 / p->step_frequency) / p->time_delta) / swing_ratio;
+  }
+  else
+  {
+    base_phase_length = p->pose_phase_length;
+    raw_phase_length = ((1.0 / r->pose_frequency) / p->time_delta);
+  }
+  r->pose_phase_length = orc_round_to_even_int(raw_phase_length / base_phase_length) * base_phase_length;
+  r->normaliser = r->pose_phase_length / base_phase_length;
+  r->auto_pose_reference_leg = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_poser_t *lp = &r->leg[l].poser;
+    lp->pose_negation_phase_start = p->pose_negation_phase_starts[l];
+    lp->pose_negation_phase_end = p->pose_negation_phase_ends[l];
+    lp->negation_transition_ratio = p->negation_transition_ratio[l];
+    if (p->offset_multiplier[l] == 0) r->auto_pose_reference_leg = l;
+  }
+  r->n_auto_posers = p->n_auto_posers;
+  for (int i = 0; i < r->n_auto_posers; ++i)
+  {
+    auto_poser_t *ap = &r->auto_poser[i];
+    memset(ap, 0, sizeof *ap);
+    ap->start_phase = p->pose_phase_starts[i];
+    ap->end_phase = p->pose_phase_ends[i];
+    ap->x_amplitude = p->x_amplitudes[i];
+    ap->y_amplitude = p->y_amplitudes[i];
+    ap->z_amplitude = p->z_amplitudes[i];
+    ap->gravity_amplitude = p->gravity_amplitudes[i];
+    ap->roll_amplitude = p->roll_amplitudes[i];
+    ap->pitch_amplitude = p->pitch_amplitudes[i];
+    ap->yaw_amplitude = p->yaw_amplitudes[i];
+    ap->start_check = 0; ap->end_check_first = 0; ap->end_check_second = 0; ap->allow_posing = 0;
+  }
+}
+
+/* PoseController ctor + init (pose_controller.cpp:14-41) */
+static void poser_init(orc_robot *r)
+{
+  r->manual_pose = r->auto_pose = r->imu_pose = r->inclination_pose = r->pc_default_pose = orc_pose_identity();
+  r->walk_plane_pose = r->origin_walk_plane_pose = orc_pose_identity();
+  r->rotation_absement_error = r->rotation_position_error = r->rotation_velocity_error = orc_v3_make(0, 0, 0);
+  r->translation_velocity_input = r->rotation_velocity_input = orc_v3_make(0, 0, 0);
+  r->pose_reset_mode = SHC_NO_RESET;
+  r->executing_transition = 0;
+  r->auto_posing_state = POSING_COMPLETE;
+  r->pose_phase = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_poser_t *lp = &r->leg[l].poser;
+    memset(lp, 0, sizeof *lp);
+    lp->auto_pose = orc_pose_identity();
+    lp->current_tip_pose = orc_pose_undefined();
+    lp->target_tip_pose = orc_pose_undefined();
+    lp->origin_tip_pose = orc_pose_identity(); /* default-constructed (unset) in the reference */
+    lp->negate_auto_pose = 0;
+    lp->first_iteration = 1;
+    lp->master_iteration_count = 0;
+    lp->has_desired_configuration = 0;
+  }
+  poser_set_auto_pose_params(r);
+  r->walk_plane_pose.p = orc_v3_make(0.0, 0.0, r->params.body_clearance);
+  r->origin_walk_plane_pose = r->walk_plane_pose;
+}
+
+/* PoseController::updateWalkPlanePose (pose_controller.cpp:1092-1130) */
+static void poser_update_walk_plane_pose(orc_robot *r)
+{
+  orc_v3 walk_plane = orc_v3_make(0, 0, 0);
+  orc_v3 walk_plane_normal = orc_v3_make(0, 0, 1);
+  double c = 0.0;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    const stepper_t *s = &r->leg[l].stepper;
+    double swing_progress_scaler = fmax(1.0, (double)r->params.swing_phase / r->params.phase_offset);
+    double swing_progress = s->swing_progress * swing_progress_scaler;
+    if (swing_progress >= 0 && swing_progress <= 1.0)
+    {
+      c = orc_smooth_step(swing_progress);
+      walk_plane = s->walk_plane;
+      walk_plane_normal = s->walk_plane_normal;
+    }
+  }
+  orc_pose new_walk_plane_pose;
+  new_walk_plane_pose.r = orc_quat_from_two_vectors(orc_v3_make(0, 0, 1), walk_plane_normal);
+  new_walk_plane_pose.r = orc_correct_rotation(new_walk_plane_pose.r, orc_quat_identity());
+  orc_v3 body_clearance = orc_v3_make(0, 0, r->params.body_clearance);
+  new_walk_plane_pose.p = orc_quat_rotate(new_walk_plane_pose.r, body_clearance);
+  new_walk_plane_pose.p.z += walk_plane.z;
+  r->walk_plane_pose = orc_pose_interpolate(r->origin_walk_plane_pose, c, new_walk_plane_pose);
+  if (c == 1.0) r->origin_walk_plane_pose = r->walk_plane_pose;
+}
+
+/* PoseController::updateManualPose (pose_controller.cpp:863-1003) */
+static void poser_update_manual_pose(orc_robot *r)
+{
+  const shc_params *p = &r->params;
+  double time_delta = p->time_delta;
+  double current_position[3] = { r->manual_pose.p.x, r->manual_pose.p.y, r->manual_pose.p.z };
+  orc_v3 cr = orc_quat_to_euler(r->manual_pose.r, 1);
+  double current_rotation[3] = { cr.x, cr.y, cr.z };
+  double default_position[3] = { r->pc_default_pose.p.x, r->pc_default_pose.p.y, r->pc_default_pose.p.z };
+  orc_v3 dr = orc_quat_to_euler(r->pc_default_pose.r, 1);
+  double default_rotation[3] = { dr.x, dr.y, dr.z };
+  const double *max_position = p->max_translation;
+  const double *max_rotation = p->max_rotation;
+  double translation_limit[3] = { 0, 0, 0 }, rotation_limit[3] = { 0, 0, 0 };
+  double translation_velocity[3] = { 0, 0, 0 }, rotation_velocity[3] = { 0, 0, 0 };
+  double desired_position[3] = { 0, 0, 0 }, desired_rotation[3] = { 0, 0, 0 };
+  double tvi[3] = { r->translation_velocity_input.x, r->translation_velocity_input.y, r->translation_velocity_input.z };
+  double rvi[3] = { r->rotation_velocity_input.x, r->rotation_velocity_input.y, r->rotation_velocity_input.z };
+
+  int reset_translation[3] = { 0, 0, 0 }, reset_rotation[3] = { 0, 0, 0 };
+  switch (r->pose_reset_mode)
+  {
+    case SHC_Z_AND_YAW_RESET: reset_translation[2] = 1; reset_rotation[2] = 1; break;
+    case SHC_X_AND_Y_RESET: reset_translation[0] = 1; reset_translation[1] = 1; break;
+    case SHC_PITCH_AND_ROLL_RESET: reset_rotation[0] = 1; reset_rotation[1] = 1; break;
+    case SHC_ALL_RESET:
+      reset_translation[0] = reset_translation[1] = reset_translation[2] = 1;
+      reset_rotation[0] = reset_rotation[1] = reset_rotation[2] = 1;
+      break;
+    case SHC_IMMEDIATE_ALL_RESET: r->manual_pose = r->pc_default_pose; return;
+    default: break;
+  }
+  for (int i = 0; i < 3; i++)
+  {
+    if (reset_translation[i])
+    {
+      double diff = current_position[i] - default_position[i];
+      if (diff < 0) tvi[i] = 1.0; else if (diff > 0) tvi[i] = -1.0;
+    }
+    if (reset_rotation[i])
+    {
+      double diff = current_rotation[i] - default_rotation[i];
+      if (diff < 0) rvi[i] = 1.0; else if (diff > 0) rvi[i] = -1.0;
+    }
+    translation_velocity[i] = tvi[i] * p->max_translation_velocity;
+    rotation_velocity[i] = rvi[i] * p->max_rotation_velocity;
+    desired_position[i] = current_position[i] + translation_velocity[i] * time_delta;
+    desired_rotation[i] = current_rotation[i] + rotation_velocity[i] * time_delta;
+
+    translation_limit[i] = orc_sign(translation_velocity[i]) * max_position[i];
+    if (reset_translation[i] && default_position[i] < max_position[i] && default_position[i] > -max_position[i])
+      translation_limit[i] = default_position[i];
+    int positive_translation_velocity = orc_sign(translation_velocity[i]) > 0;
+    int exceeds_positive_translation_limit = positive_translation_velocity && desired_position[i] > translation_limit[i];
+    int exceeds_negative_translation_limit = !positive_translation_velocity && desired_position[i] < translation_limit[i];
+    if (exceeds_positive_translation_limit || exceeds_negative_translation_limit)
+      translation_velocity[i] = (translation_limit[i] - current_position[i]) / time_delta;
+
+    rotation_limit[i] = orc_sign(rotation_velocity[i]) * max_rotation[i];
+    if (reset_rotation[i] && default_rotation[i] < max_rotation[i] && default_rotation[i] > -max_rotation[i])
+      rotation_limit[i] = default_rotation[i];
+    int positive_rotation_velocity = orc_sign(rotation_velocity[i]) > 0;
+    int exceeds_positive_rotation_limit = positive_rotation_velocity && desired_rotation[i] > rotation_limit[i];
+    int exceeds_negative_rotation_limit = !positive_rotation_velocity && desired_rotation[i] < rotation_limit[i];
+    if (exceeds_positive_rotation_limit || exceeds_negative_rotation_limit)
+      rotation_velocity[i] = (rotation_limit[i] - current_rotation[i]) / time_delta;
+
+    desired_position[i] = current_position[i] + translation_velocity[i] * time_delta;
+    desired_rotation[i] = current_rotation[i] + rotation_velocity[i] * time_delta;
+  }
+  /* the reset modes write back into the member inputs (translation_velocity_input_[i] = ...) */
+  r->translation_velocity_input = orc_v3_make(tvi[0], tvi[1], tvi[2]);
+  r->rotation_velocity_input = orc_v3_make(rvi[0], rvi[1], rvi[2]);
+  r->manual_pose.p = orc_v3_make(desired_position[0], desired_position[1], desired_position[2]);
+  r->manual_pose.r = orc_correct_rotation(
+      orc_euler_to_quat(orc_v3_make(desired_rotation[0], desired_rotation[1], desired_rotation[2]), 1), orc_quat_identity());
+}
+
+/* PoseController::updateInclinationPose (pose_controller.cpp:1240-1259) */
+static void poser_update_inclination_pose(orc_robot *r)
+{
+  orc_quat compensation_combined = orc_quat_normalized(orc_quat_mul(r->manual_pose.r, r->auto_pose.r));
+  orc_quat compensation_removed =
+      orc_quat_normalized(orc_quat_mul(model_imu_orientation(r), orc_quat_inverse(compensation_combined)));
+  orc_v3 euler = orc_quat_to_euler(compensation_removed, 0);
+  double body_height = r->params.body_clearance;
+  double longitudinal_correction = -body_height * tan(euler.y);
+  double lateral_correction = body_height * tan(euler.x);
+  double max_translation_x = r->params.max_translation[0];
+  double max_translation_y = r->params.max_translation[1];
+  longitudinal_correction = orc_clamped(longitudinal_correction, -max_translation_x, max_translation_x);
+  lateral_correction = orc_clamped(lateral_correction, -max_translation_y, max_translation_y);
+  r->inclination_pose.p.x = longitudinal_correction;
+  r->inclination_pose.p.y = lateral_correction;
+}
+
+/* PoseController::updateIMUPose (pose_controller.cpp:1191-1236) */
+static void poser_update_imu_pose(orc_robot *r)
+{
+  orc_quat current_rotation = orc_correct_rotation(model_imu_orientation(r), orc_quat_identity());
+  orc_quat target_rotation = orc_correct_rotation(r->manual_pose.r, orc_quat_identity());
+  orc_quat rotation_error = orc_quat_normalized(orc_quat_mul(current_rotation, orc_quat_inverse(target_rotation)));
+  double kp = r->params.rotation_pid_gains[0];
+  double ki = r->params.rotation_pid_gains[1];
+  double kd = r->params.rotation_pid_gains[2];
+  r->rotation_position_error = orc_quat_to_euler(rotation_error, 0);
+  r->rotation_position_error.z = 0.0;
+  if (orc_v3_norm(r->rotation_position_error) < IMU_POSING_DEADBAND) return;
+  r->rotation_absement_error = orc_v3_add(r->rotation_absement_error, orc_v3_scale(r->rotation_position_error, r->params.time_delta));
+  double smoothing_factor = 0.15;
+  r->rotation_velocity_error = orc_v3_add(orc_v3_scale(orc_v3_neg(r->imu_angular_velocity), smoothing_factor),
+                                          orc_v3_scale(r->rotation_velocity_error, (1 - smoothing_factor)));
+  orc_v3 rotation_correction = orc_v3_neg(orc_v3_add(orc_v3_add(orc_v3_scale(r->rotation_velocity_error, kd),
+                                                                orc_v3_scale(r->rotation_position_error, kp)),
+                                                     orc_v3_scale(r->rotation_absement_error, ki)));
+  double max_roll = r->params.max_rotation[0];
+  double max_pitch = r->params.max_rotation[1];
+  rotation_correction.x = orc_clamped(rotation_correction.x, -max_roll, max_roll);
+  rotation_correction.y = orc_clamped(rotation_correction.y, -max_pitch, max_pitch);
+  rotation_correction.z = orc_quat_to_euler(target_rotation, 0).z;
+  if (orc_v3_norm(rotation_correction) > STABILITY_THRESHOLD) r->unstable = 1;
+  r->imu_pose.r = orc_euler_to_quat(rotation_correction, 0);
+  r->imu_pose.r = orc_correct_rotation(r->imu_pose.r, target_rotation);
+}
+
+/* AutoPoser::updatePose (pose_controller.cpp:1338-1439) */
+static orc_pose auto_poser_update_pose(orc_robot *r, auto_poser_t *ap, int phase)
+{
+  orc_pose return_pose = orc_pose_identity();
+  int start_phase = ap->start_phase * r->normaliser;
+  int end_phase = ap->end_phase * r->normaliser;
+  if (start_phase > end_phase)
+  {
+    end_phase += r->pose_phase_length;
+    if (phase < start_phase) phase += r->pose_phase_length;
+  }
+  int state = r->auto_posing_state;
+  int sync_with_step_cycle = (r->pose_frequency == -1.0);
+  ap->start_check = !sync_with_step_cycle || (!ap->start_check && state == POSING && phase == start_phase);
+  ap->end_check_first = (ap->end_check_first || (state == STOP_POSING && phase == start_phase));
+  ap->end_check_second = (ap->end_check_second || (state == STOP_POSING && phase == end_phase && ap->end_check_first));
+  if (!ap->allow_posing && ap->start_check)
+  {
+    ap->allow_posing = 1;
+    ap->end_check_first = 0; ap->end_check_second = 0;
+  }
+  else if (ap->allow_posing && sync_with_step_cycle && ap->end_check_first && ap->end_check_second)
+  {
+    ap->allow_posing = 0;
+    ap->start_check = 0;
+  }
+  if (phase >= start_phase && phase < end_phase && ap->allow_posing)
+  {
+    int iteration = phase - start_phase + 1;
+    int num_iterations = end_phase - start_phase;
+    orc_v3 zero = orc_v3_make(0, 0, 0);
+    orc_v3 position_control_nodes[5] = { zero, zero, zero, zero, zero };
+    orc_v3 rotation_control_nodes[5] = { zero, zero, zero, zero, zero };
+    int first_half = iteration <= num_iterations / 2;
+    orc_v3 gravity_direction = orc_v3_normalized(model_estimate_gravity(r));
+    orc_v3 rot_amp = orc_v3_make(ap->roll_amplitude, ap->pitch_amplitude, ap->yaw_amplitude);
+    orc_v3 pos_amp = (ap->gravity_amplitude != 0.0) ? orc_v3_scale(gravity_direction, ap->gravity_amplitude)
+                                                    : orc_v3_make(ap->x_amplitude, ap->y_amplitude, ap->z_amplitude);
+    if (first_half)
+    {
+      rotation_control_nodes[3] = rot_amp; rotation_control_nodes[4] = rot_amp;
+      position_control_nodes[3] = pos_amp; position_control_nodes[4] = pos_amp;
+    }
+    else
+    {
+      rotation_control_nodes[0] = rot_amp; rotation_control_nodes[1] = rot_amp;
+      position_control_nodes[0] = pos_amp; position_control_nodes[1] = pos_amp;
+    }
+    double delta_t = 1.0 / (num_iterations / 2.0);
+    int offset = (int)((first_half ? 0 : num_iterations / 2.0));
+    double time_input = (iteration - offset) * delta_t;
+    orc_v3 position = orc_quartic_bezier(position_control_nodes, time_input);
+    orc_v3 rotation = orc_quartic_bezier(rotation_control_nodes, time_input);
+    return_pose = orc_pose_make(position, orc_euler_to_quat(rotation, 0));
+  }
+  return return_pose;
+}
+
+/* LegPoser::updateAutoPose (pose_controller.cpp:1716-1778) */
+static void leg_poser_update_auto_pose(orc_robot *r, leg_t *leg, int phase)
+{
+  leg_poser_t *lp = &leg->poser;
+  int start_phase = lp->pose_negation_phase_start * r->normaliser;
+  int end_phase = lp->pose_negation_phase_end * r->normaliser;
+  int negation_phase = phase;
+  if (start_phase == 0) start_phase = r->pose_phase_length;
+  if (end_phase == 0) end_phase = r->pose_phase_length;
+  if (start_phase > end_phase)
+  {
+    end_phase += r->pose_phase_length;
+    if (negation_phase < start_phase) negation_phase += r->pose_phase_length;
+  }
+  int step_state = leg->stepper.step_state;
+  if (step_state != FORCE_STANCE && step_state != FORCE_STOP && negation_phase == start_phase) lp->negate_auto_pose = 1;
+  if (negation_phase < start_phase || negation_phase > end_phase) lp->negate_auto_pose = 0;
+  lp->auto_pose = r->auto_pose;
+  if (lp->negate_auto_pose)
+  {
+    int iteration = negation_phase - start_phase + 1;
+    int num_iterations = end_phase - start_phase;
+    int first_half = iteration <= num_iterations / 2;
+    double control_input = 1.0;
+    if (lp->negation_transition_ratio > 0.0)
+    {
+      if (first_half) control_input = fmin(1.0, iteration / (num_iterations * lp->negation_transition_ratio));
+      else control_input = fmin(1.0, (num_iterations - iteration) / (num_iterations * lp->negation_transition_ratio));
+    }
+    control_input = orc_smooth_step(control_input);
+    orc_pose negation = orc_pose_interpolate(orc_pose_identity(), control_input, lp->auto_pose);
+    lp->auto_pose = orc_pose_remove(lp->auto_pose, negation);
+  }
+}
+
+/* PoseController::updateAutoPose (pose_controller.cpp:1134-1187) */
+static void poser_update_auto_pose(orc_robot *r)
+{
+  const stepper_t *ls = &r->leg[r->auto_pose_reference_leg].stepper;
+  r->auto_pose = orc_pose_identity();
+  int zero_body_velocity = orc_v3_norm(ls->stride_vector) == 0;
+  if (r->walk_state == STARTING || r->walk_state == MOVING) r->auto_posing_state = POSING;
+  else if ((zero_body_velocity && r->walk_state == STOPPING) || r->walk_state == STOPPED) r->auto_posing_state = STOP_POSING;
+  int master_phase;
+  int sync_with_step_cycle = (r->pose_frequency == -1.0);
+  if (sync_with_step_cycle) master_phase = ls->phase;
+  else
+  {
+    master_phase = r->pose_phase;
+    r->pose_phase = (r->pose_phase + 1) % r->pose_phase_length;
+  }
+  int auto_posers_complete = 0;
+  for (int i = 0; i < r->n_auto_posers; ++i)
+  {
+    orc_pose updated_pose = auto_poser_update_pose(r, &r->auto_poser[i], master_phase);
+    auto_posers_complete += (int)(!r->auto_poser[i].allow_posing);
+    r->auto_pose = orc_pose_add(r->auto_pose, updated_pose);
+  }
+  if (auto_posers_complete == r->n_auto_posers) r->auto_posing_state = POSING_COMPLETE;
+  for (int l = 0; l < r->leg_count; ++l) leg_poser_update_auto_pose(r, &r->leg[l], master_phase);
+}
+
+/* PoseController::updateCurrentPose (pose_controller.cpp:811-859) */
+static void poser_update_current_pose(orc_robot *r, int robot_state)
+{
+  orc_pose new_pose = orc_pose_identity();
+  poser_update_walk_plane_pose(r);
+  new_pose = orc_pose_add(new_pose, r->walk_plane_pose);
+  r->default_pose = r->walk_plane_pose; /* model_->setDefaultPose */
+  if (r->params.manual_posing)
+  {
+    poser_update_manual_pose(r);
+    new_pose = orc_pose_add(new_pose, r->manual_pose);
+  }
+  if (r->params.inclination_posing)
+  {
+    poser_update_inclination_pose(r);
+    new_pose = orc_pose_add(new_pose, r->inclination_pose);
+  }
+  if (r->params.imu_posing && robot_state == RS_RUNNING)
+  {
+    poser_update_imu_pose(r);
+    new_pose = orc_pose_add(new_pose, r->imu_pose);
+  }
+  else if (r->params.auto_posing)
+  {
+    poser_update_auto_pose(r);
+    new_pose = orc_pose_add(new_pose, r->auto_pose);
+  }
+  /* gravity_aligned_tips && DOF <= 3 (updateTipAlignPose, "TODO EXPERIMENTAL") is outside the restated path */
+  r->current_pose = new_pose;
+}
+
+/* PoseController::updateStance (pose_controller.cpp:110-141) */
+static void poser_update_stance(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    orc_pose current_pose = r->current_pose;
+    current_pose = orc_pose_remove(current_pose, r->auto_pose);
+    current_pose = orc_pose_add(current_pose, leg->poser.auto_pose);
+    orc_v3 new_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.current_tip_pose.p);
+    orc_quat new_tip_rotation = orc_quat_mul(orc_quat_inverse(current_pose.r), leg->stepper.current_tip_pose.r);
+    leg->poser.current_tip_pose = orc_pose_make(new_tip_position, new_tip_rotation);
+  }
+}
+
+/* LegPoser::stepToPosition (pose_controller.cpp:1571-1712) */
+static int leg_poser_step_to_position(orc_robot *r, leg_t *leg, orc_pose target_tip_pose, orc_pose target_pose,
+                                      double lift_height, double time_to_step, int apply_delta)
+{
+  leg_poser_t *lp = &leg->poser;
+  if (lp->first_iteration)
+  {
+    lp->origin_tip_pose = leg->current_tip_pose;
+    lp->master_iteration_count = 0;
+    lp->first_iteration = 0;
+  }
+  orc_pose desired_tip_pose = target_tip_pose;
+  if (orc_pose_eq(desired_tip_pose, orc_pose_undefined()))
+  {
+    desired_tip_pose = lp->origin_tip_pose;
+    desired_tip_pose.r = ORC_UNDEFINED_ROTATION;
+  }
+  orc_v3 position_delta = orc_v3_sub(lp->origin_tip_pose.p, orc_pose_inverse_transform_vector(target_pose, desired_tip_pose.p));
+  int transition_position = orc_v3_norm(position_delta) > TIP_TOLERANCE;
+  int transition_rotation = 0;
+  if (!orc_quat_is_undefined(desired_tip_pose.r))
+  {
+    orc_v3 origin_tip_direction = orc_quat_rotate(lp->origin_tip_pose.r, orc_v3_make(1, 0, 0));
+    orc_v3 desired_tip_direction = orc_quat_rotate(desired_tip_pose.r, orc_v3_make(1, 0, 0));
+    orc_v3 ax;
+    double ang = orc_angle_axis_from_quat(orc_quat_from_two_vectors(origin_tip_direction, desired_tip_direction), &ax);
+    transition_rotation = ang > JOINT_TOLERANCE;
+  }
+  if (!transition_position && !transition_rotation && lift_height == 0.0)
+  {
+    lp->first_iteration = 1;
+    lp->current_tip_pose = lp->origin_tip_pose;
+    return PROGRESS_COMPLETE;
+  }
+  if (apply_delta) desired_tip_pose.p = orc_v3_add(desired_tip_pose.p, leg->admittance_delta);
+  lp->master_iteration_count++;
+  int num_iterations = orc_round_to_int(time_to_step / r->params.time_delta);
+  num_iterations = num_iterations > 1 ? num_iterations : 1;
+  double delta_t = 1.0 / num_iterations;
+  double completion_ratio = ((double)(lp->master_iteration_count - 1) / (double)num_iterations);
+  orc_pose desired_pose = orc_pose_interpolate(orc_pose_identity(), orc_smooth_step(completion_ratio), target_pose);
+  orc_quat new_tip_rotation = ORC_UNDEFINED_ROTATION;
+  if (!orc_quat_is_undefined(desired_tip_pose.r))
+  {
+    orc_v3 origin_tip_direction = orc_quat_rotate(lp->origin_tip_pose.r, orc_v3_make(1, 0, 0));
+    orc_v3 desired_tip_direction = orc_quat_rotate(desired_tip_pose.r, orc_v3_make(1, 0, 0));
+    orc_v3 new_tip_direction = orc_v3_lerp(origin_tip_direction, desired_tip_direction, orc_smooth_step(completion_ratio));
+    new_tip_rotation = orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), orc_v3_normalized(new_tip_direction));
+  }
+  double time_input;
+  orc_v3 new_tip_position = lp->origin_tip_pose.p;
+  if (!(desired_tip_pose.p.x == (double)INT_MAX && desired_tip_pose.p.y == (double)INT_MAX && desired_tip_pose.p.z == (double)INT_MAX))
+  {
+    int half_swing_iteration = num_iterations / 2;
+    orc_v3 cp[5], cs[5];
+    orc_v3 origin_to_target = orc_v3_sub(lp->origin_tip_pose.p, desired_tip_pose.p);
+    cp[0] = lp->origin_tip_pose.p;
+    cp[1] = lp->origin_tip_pose.p;
+    cp[2] = lp->origin_tip_pose.p;
+    cp[3] = orc_v3_add(desired_tip_pose.p, orc_v3_scale(origin_to_target, 0.75));
+    cp[4] = orc_v3_add(desired_tip_pose.p, orc_v3_scale(origin_to_target, 0.5));
+    cp[2].z += lift_height; cp[3].z += lift_height; cp[4].z += lift_height;
+    cs[0] = orc_v3_add(desired_tip_pose.p, orc_v3_scale(origin_to_target, 0.5));
+    cs[1] = orc_v3_add(desired_tip_pose.p, orc_v3_scale(origin_to_target, 0.25));
+    cs[2] = desired_tip_pose.p;
+    cs[3] = desired_tip_pose.p;
+    cs[4] = desired_tip_pose.p;
+    cs[0].z += lift_height; cs[1].z += lift_height; cs[2].z += lift_height;
+    int swing_iteration_count = (lp->master_iteration_count + (num_iterations - 1)) % (num_iterations) + 1;
+    if (swing_iteration_count <= half_swing_iteration)
+    {
+      time_input = swing_iteration_count * delta_t * 2.0;
+      new_tip_position = orc_quartic_bezier(cp, time_input);
+    }
+    else
+    {
+      time_input = (swing_iteration_count - half_swing_iteration) * delta_t * 2.0;
+      new_tip_position = orc_quartic_bezier(cs, time_input);
+    }
+  }
+  lp->current_tip_pose.p = orc_pose_inverse_transform_vector(desired_pose, new_tip_position);
+  lp->current_tip_pose.r = new_tip_rotation;
+  if (lp->master_iteration_count >= num_iterations)
+  {
+    lp->first_iteration = 1;
+    return PROGRESS_COMPLETE;
+  }
+  return (int)(completion_ratio * PROGRESS_COMPLETE);
+}
+
+/* LegPoser::transitionConfiguration (pose_controller.cpp:1476-1567) */
+static int leg_poser_transition_configuration(orc_robot *r, leg_t *leg, double transition_time)
+{
+  leg_poser_t *lp = &leg->poser;
+  if (!lp->has_desired_configuration) return PROGRESS_COMPLETE;
+  if (lp->first_iteration)
+  {
+    for (int i = 0; i < leg->joint_count; ++i) lp->origin_configuration[i] = leg->joint[i].desired_position;
+    lp->first_iteration = 0;
+    lp->master_iteration_count = 0;
+  }
+  int num_iterations = orc_round_to_int(transition_time / r->params.time_delta);
+  num_iterations = num_iterations > 1 ? num_iterations : 1;
+  double delta_t = 1.0 / num_iterations;
+  lp->master_iteration_count++;
+  for (int i = 0; i < leg->joint_count; ++i)
+  {
+    joint_t *jt = &leg->joint[i];
+    double control_nodes[4] = { lp->origin_configuration[i], lp->origin_configuration[i], lp->desired_configuration[i],
+                                lp->desired_configuration[i] };
+    jt->prev_desired_position = jt->desired_position;
+    jt->desired_position = orc_cubic_bezier_scalar(control_nodes, lp->master_iteration_count * delta_t);
+  }
+  leg_apply_fk(r, leg);
+  int progress = (int)(((double)(lp->master_iteration_count - 1) / (double)num_iterations) * PROGRESS_COMPLETE);
+  progress = progress < 1 ? 1 : (progress > PROGRESS_COMPLETE ? PROGRESS_COMPLETE : progress);
+  if (lp->master_iteration_count >= num_iterations)
+  {
+    lp->first_iteration = 1;
+    return PROGRESS_COMPLETE;
+  }
+  return progress;
+}
+
+/* PoseController::directStartup (pose_controller.cpp:463-517) */
+static int poser_direct_startup(orc_robot *r)
+{
+  int progress = 0;
+  double time_to_start = r->params.time_to_start;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    if (!r->executing_transition)
+    {
+      leg_t *test_leg = (leg_t *)malloc(sizeof(leg_t));
+      *test_leg = *leg; /* Leg(leg) + generate(leg): copies joints, tip, stepper, poser */
+      leg_init(r, test_leg, 1);
+      orc_pose default_tip_pose = leg->stepper.default_tip_pose;
+      int guard = 0;
+      while (progress != PROGRESS_COMPLETE && guard++ < 1000000)
+      {
+        progress = leg_poser_step_to_position(r, test_leg, default_tip_pose, r->current_pose, 0.0, time_to_start, 1);
+        leg_set_desired_tip_pose(test_leg, test_leg->poser.current_tip_pose, 1);
+        leg_apply_ik(r, test_leg, 1);
+      }
+      for (int j = 0; j < leg->joint_count; ++j) leg->poser.desired_configuration[j] = test_leg->joint[j].desired_position;
+      leg->poser.has_desired_configuration = 1;
+      free(test_leg);
+    }
+    progress = leg_poser_transition_configuration(r, leg, time_to_start);
+  }
+  r->executing_transition = (progress != 0 && progress != PROGRESS_COMPLETE);
+  return progress;
+}
+
+/* ==================================================================================== AdmittanceController */
+
+/* AdmittanceController::updateAdmittance (admittance_controller.cpp:22-63) for one leg.
+ * boost::numeric::odeint::runge_kutta4 + integrate_const(0, step_time, step_time / 30): 30 fixed steps. */
+static void admittance_leg(const shc_params *p, double state[2], orc_v3 tip_force_in, double delta_out[3])
+{
+  double tip_force[3] = { tip_force_in.x * p->force_gain, tip_force_in.y * p->force_gain, tip_force_in.z * p->force_gain };
+  for (int i = 0; i < 3; ++i)
+  {
+    delta_out[i] = 0.0;
+    double force_input = fmax(tip_force[i], 0.0);
+    double damping = p->virtual_damping_ratio;
+    double stiffness = p->virtual_stiffness;
+    double mass = p->virtual_mass;
+    double step_time = p->integrator_step_time;
+    double virtual_damping = damping * 2 * sqrt(mass * stiffness);
+    double dt = step_time / 30;
+    /* integrate_const: while (less_eq_with_sign(time + dt, end, dt)) { do_step; ++step; time = start + step * dt; } */
+    double time = 0.0;
+    int step = 0;
+    const double eps = 2.220446049250313e-16;
+    while ((time + dt) - step_time <= eps)
+    {
+      double x0 = state[0], x1 = state[1];
+      /* k1 */
+      double k1_0 = x1;
+      double k1_1 = -force_input / mass - virtual_damping / mass * x1 - stiffness / mass * x0;
+      /* k2 at x + dt*0.5*k1 */
+      double a0 = x0 + (0.5 * dt) * k1_0, a1 = x1 + (0.5 * dt) * k1_1;
+      double k2_0 = a1;
+      double k2_1 = -force_input / mass - virtual_damping / mass * a1 - stiffness / mass * a0;
+      /* k3 at x + dt*(0*k1 + 0.5*k2) */
+      double b0 = x0 + (0.0 * dt) * k1_0 + (0.5 * dt) * k2_0, b1 = x1 + (0.0 * dt) * k1_1 + (0.5 * dt) * k2_1;
+      double k3_0 = b1;
+      double k3_1 = -force_input / mass - virtual_damping / mass * b1 - stiffness / mass * b0;
+      /* k4 at x + dt*(0*k1 + 0*k2 + 1*k3) */
+      double c0 = x0 + (0.0 * dt) * k1_0 + (0.0 * dt) * k2_0 + (1.0 * dt) * k3_0;
+      double c1 = x1 + (0.0 * dt) * k1_1 + (0.0 * dt) * k2_1 + (1.0 * dt) * k3_1;
+      double k4_0 = c1;
+      double k4_1 = -force_input / mass - virtual_damping / mass * c1 - stiffness / mass * c0;
+      state[0] = x0 + (dt / 6.0) * k1_0 + (dt / 3.0) * k2_0 + (dt / 3.0) * k3_0 + (dt / 6.0) * k4_0;
+      state[1] = x1 + (dt / 6.0) * k1_1 + (dt / 3.0) * k2_1 + (dt / 3.0) * k3_1 + (dt / 6.0) * k4_1;
+      ++step;
+      time = 0.0 + (double)step * dt;
+    }
+    double delta = orc_clamped(-state[0], -0.2, 0.2);
+    double delta_direction = delta / fabs(delta);
+    if (fabs(delta) > ADMITTANCE_DEADBAND)
+      delta_out[i] = delta_direction * (fabs(delta) - ADMITTANCE_DEADBAND) / (1 - ADMITTANCE_DEADBAND);
+  }
+}
+
+static void admittance_update_admittance(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    orc_v3 tip_force = r->params.use_joint_effort ? leg->tip_force_calculated : leg->tip_force_measured;
+    double d[3];
+    admittance_leg(&r->params, leg->admittance_state, tip_force, d);
+    leg_set_admittance_delta(leg, orc_v3_make(d[0], d[1], d[2]));
+  }
+}
+
+/* AdmittanceController::updateStiffness(walker) (admittance_controller.cpp:96-134) */
+static void admittance_update_stiffness(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l) r->leg[l].virtual_stiffness = r->params.virtual_stiffness;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    if (leg->stepper.step_state == SWING)
+    {
+      double z_diff = leg->stepper.current_tip_pose.p.z - leg->stepper.default_tip_pose.p.z;
+      double step_reference = 0;
+      step_reference += fabs(z_diff / r->params.swing_height);
+      leg_t *adj1 = &r->leg[orc_mod(l - 1, r->leg_count)];
+      leg_t *adj2 = &r->leg[orc_mod(l + 1, r->leg_count)];
+      double virtual_stiffness = r->params.virtual_stiffness;
+      double swing_stiffness = virtual_stiffness * (step_reference * (r->params.swing_stiffness_scaler - 1) + 1);
+      double load_stiffness = virtual_stiffness * (step_reference * (r->params.load_stiffness_scaler - 1));
+      double current_stiffness_1 = adj1->virtual_stiffness;
+      double current_stiffness_2 = adj2->virtual_stiffness;
+      leg->virtual_stiffness = swing_stiffness;
+      adj1->virtual_stiffness = current_stiffness_1 + load_stiffness;
+      adj2->virtual_stiffness = current_stiffness_2 + load_stiffness;
+    }
+  }
+}
+
+/* ==================================================================================== StateController */
+
+/* Model::updateModel (model.cpp:142-152) */
+static void model_update_model(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    leg->ik_failed = 0;
+    leg_set_desired_tip_pose(leg, orc_pose_undefined(), 1);
+    leg_apply_ik(r, leg, 0);
+  }
+}
+
+/* Model::generateWorkspaces (model.cpp:120-138) */
+static void model_generate_workspaces(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *search_leg = (leg_t *)malloc(sizeof(leg_t));
+    *search_leg = r->leg[l];
+    leg_init(r, search_leg, 1); /* search_model->initLegs(true) */
+    leg_generate_workspace(r, search_leg);
+    memcpy(r->leg[l].workspace, search_leg->workspace, sizeof search_leg->workspace);
+    r->leg[l].workspace_zero = search_leg->workspace_zero;
+    free(search_leg);
+  }
+}
+
+/* StateController::runningState (state_controller.cpp:379-447), no transitions / gait change / manual legs */
+static void state_running_state(orc_robot *r)
+{
+  walker_update_walk(r, r->linear_velocity_input, r->angular_velocity_input);
+  poser_update_stance(r);
+  model_update_model(r);
+}
+
+/* StateController::transitionRobotState (state_controller.cpp:197-375), direct start-up path only */
+static void state_transition_robot_state(orc_robot *r)
+{
+  if (r->robot_state == RS_UNKNOWN)
+  {
+    r->robot_state = RS_PACKED; /* joints at defaults are neither packed nor "unpacked": "state undefined" branch */
+    r->new_robot_state = r->robot_state;
+  }
+  else if (r->robot_state == RS_PACKED && r->new_robot_state == RS_READY)
+  {
+    int progress = poser_direct_startup(r);
+    if (progress == PROGRESS_COMPLETE)
+    {
+      r->robot_state = RS_READY;
+      for (int l = 0; l < r->leg_count; ++l) leg_update_default_configuration(&r->leg[l]);
+      model_generate_workspaces(r);
+      walker_generate_walkspace(r);
+    }
+  }
+  else if (r->robot_state == RS_READY && r->new_robot_state == RS_RUNNING)
+  {
+    r->robot_state = RS_RUNNING;
+  }
+  if (r->robot_state == r->new_robot_state) r->transition_state_flag = 0;
+}
+
+/* StateController::loop (state_controller.cpp:162-193) */
+static void state_loop(orc_robot *r)
+{
+  if (r->robot_state != RS_UNKNOWN)
+  {
+    poser_update_current_pose(r, r->robot_state);
+    r->pose_state = r->auto_posing_state;
+    if (r->params.admittance_control)
+    {
+      if (r->walk_state != STOPPED && r->params.dynamic_stiffness) admittance_update_stiffness(r);
+      admittance_update_admittance(r);
+    }
+  }
+  if (r->transition_state_flag) state_transition_robot_state(r);
+  if (r->robot_state == RS_RUNNING) state_running_state(r);
+}
+
+/* ==================================================================================== public API */
+
+size_t orc_sizeof_robot(void) { return sizeof(orc_robot); }
+
+orc_robot *orc_create(const shc_params *params)
+{
+  if (!params || params->leg_count < 1 || params->leg_count > SHC_MAX_LEGS) return NULL;
+  if (params->rough_terrain_mode) return NULL;
+  for (int l = 0; l < params->leg_count; ++l)
+    if (params->leg_dof[l] < 1 || params->leg_dof[l] > SHC_MAX_JOINTS) return NULL;
+  orc_robot *r = (orc_robot *)calloc(1, sizeof(orc_robot));
+  r->params = *params;
+  /* Model::Model (model.cpp:16-27) */
+  r->leg_count = params->leg_count;
+  r->time_delta = params->time_delta;
+  r->current_pose = orc_pose_identity();
+  r->default_pose = orc_pose_identity();
+  r->imu_orientation = ORC_UNDEFINED_ROTATION;
+  r->imu_angular_velocity = orc_v3_make(0, 0, 0);
+  /* Model::generate -> Leg::Leg + Leg::generate (model.cpp:44-62, 169-239) */
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    leg->id_number = l;
+    leg->joint_count = params->leg_dof[l];
+    leg->leg_state = WALKING;
+    leg->admittance_delta = orc_v3_make(0, 0, 0);
+    leg->admittance_state[0] = leg->admittance_state[1] = 0.0;
+    leg->desired_tip_pose = orc_pose_undefined();
+    leg->current_tip_pose = orc_pose_undefined();
+    leg->step_plane_pose = orc_pose_undefined();
+    for (int k = 0; k <= leg->joint_count; ++k)
+    {
+      leg->link[k].d = params->link[l][k].d;
+      leg->link[k].theta = params->link[l][k].theta;
+      leg->link[k].r = params->link[l][k].r;
+      leg->link[k].alpha = params->link[l][k].alpha;
+    }
+    for (int j = 0; j < leg->joint_count; ++j)
+    { /* Joint::Joint (model.cpp:1026-1073); reference link = link[j] */
+      joint_t *jt = &leg->joint[j];
+      jt->min_position = params->joint[l][j].min;
+      jt->max_position = params->joint[l][j].max;
+      jt->offset = params->joint[l][j].offset;
+      jt->unpacked_position = params->joint[l][j].unpacked;
+      jt->max_angular_speed = params->joint[l][j].max_vel;
+      jt->default_position = orc_clamped(0.0, jt->min_position, jt->max_position);
+      jt->current_position = ORC_UNASSIGNED_VALUE;
+      jt->identity_transform = orc_create_dh_matrix(leg->link[j].d, leg->link[j].theta, leg->link[j].r, leg->link[j].alpha);
+      jt->current_transform = jt->identity_transform;
+    }
+    { /* Tip::Tip (model.cpp:1119-1127) */
+      const link_t *rl = &leg->link[leg->joint_count];
+      leg->tip_identity_transform = orc_create_dh_matrix(rl->d, rl->theta, rl->r, rl->alpha);
+      leg->tip_current_transform = leg->tip_identity_transform;
+    }
+  }
+  /* StateController::init (state_controller.cpp:127-153) */
+  walker_init(r);
+  poser_init(r);
+  r->robot_state = RS_UNKNOWN;
+  r->new_robot_state = RS_UNKNOWN;
+  r->transition_state_flag = 0;
+  /* initModel(true) (main.cpp:101) */
+  for (int l = 0; l < r->leg_count; ++l) leg_init(r, &r->leg[l], 1);
+  return r;
+}
+
+void orc_destroy(orc_robot *r) { free(r); }
+
+orc_robot *orc_clone(const orc_robot *r)
+{
+  orc_robot *c = (orc_robot *)malloc(sizeof(orc_robot));
+  memcpy(c, r, sizeof(orc_robot));
+  return c;
+}
+
+int orc_startup(orc_robot *r)
+{
+  int loops = 0;
+  /* first loop: UNKNOWN -> PACKED (transition_state_flag_ is raised by the start button callback) */
+  r->transition_state_flag = 1;
+  state_loop(r);
+  ++loops;
+  /* START pressed: PACKED -> READY (direct start-up) */
+  r->new_robot_state = RS_READY;
+  r->transition_state_flag = 1;
+  while (r->robot_state != RS_READY)
+  {
+    state_loop(r);
+    if (++loops > 100000) return -1;
+  }
+  /* START pressed again: READY -> RUNNING */
+  r->new_robot_state = RS_RUNNING;
+  r->transition_state_flag = 1;
+  state_loop(r);
+  ++loops;
+  return r->robot_state == RS_RUNNING ? loops : -1;
+}
+
+void orc_get_tables(const orc_robot *r, shc_tables *out)
+{
+  memset(out, 0, sizeof *out);
+  out->step = r->step;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    out->phase_offset[l] = r->leg[l].stepper.phase_offset;
+    for (int j = 0; j < r->leg[l].joint_count; ++j) out->default_joint_position[l][j] = r->leg[l].joint[j].default_position;
+    for (int b = 0; b < SHC_N_BEARINGS; ++b) out->workspace_radius[l][b] = r->leg[l].workspace[b];
+  }
+  for (int b = 0; b < SHC_N_BEARINGS; ++b)
+  {
+    out->walkspace[b] = r->walkspace[b];
+    out->max_linear_speed[b] = r->max_linear_speed[b];
+    out->max_angular_speed[b] = r->max_angular_speed[b];
+    out->max_linear_acceleration[b] = r->max_linear_acceleration[b];
+    out->max_angular_acceleration[b] = r->max_angular_acceleration[b];
+  }
+  out->pose_phase_length = r->pose_phase_length;
+  out->pose_normaliser = r->normaliser;
+  out->auto_pose_reference_leg = r->auto_pose_reference_leg;
+}
+
+void orc_set_velocity(orc_robot *r, double vx, double vy, double omega)
+{
+  r->linear_velocity_input[0] = vx;
+  r->linear_velocity_input[1] = vy;
+  r->angular_velocity_input = omega;
+}
+
+void orc_set_imu(orc_robot *r, const double q[4], const double gyro[3])
+{ /* Model::setImuData (model.h:146-153): orientation.normalized() */
+  r->imu_orientation = orc_quat_normalized(orc_quat_make(q[0], q[1], q[2], q[3]));
+  r->imu_angular_velocity = orc_v3_make(gyro[0], gyro[1], gyro[2]);
+}
+
+void orc_set_tip_force(orc_robot *r, const double *force)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+    r->leg[l].tip_force_measured = orc_v3_make(force[l * 3 + 0], force[l * 3 + 1], force[l * 3 + 2]);
+}
+
+void orc_set_joint_effort(orc_robot *r, const double *effort)
+{
+  int k = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+    for (int j = 0; j < r->leg[l].joint_count; ++j) r->leg[l].joint[j].current_effort = effort[k++];
+}
+
+void orc_set_pose_input(orc_robot *r, const double tv[3], const double rv[3])
+{
+  r->translation_velocity_input = orc_v3_make(tv[0], tv[1], tv[2]);
+  r->rotation_velocity_input = orc_v3_make(rv[0], rv[1], rv[2]);
+}
+
+void orc_set_pose_reset_mode(orc_robot *r, int mode) { r->pose_reset_mode = mode; }
+
+void orc_cycle(orc_robot *r) { state_loop(r); }
+
+void orc_get_joint_state(const orc_robot *r, double *q, double *qd)
+{
+  int k = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+    for (int j = 0; j < r->leg[l].joint_count; ++j, ++k)
+    {
+      if (q) q[k] = r->leg[l].joint[j].desired_position;
+      if (qd) qd[k] = r->leg[l].joint[j].desired_velocity;
+    }
+}
+
+static void put3(double *dst, orc_v3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+
+void orc_get_leg_state(const orc_robot *r, double *walker_tip, double *poser_tip, double *model_tip, double *tip_force,
+                       double *admittance, int32_t *leg_status)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    const leg_t *leg = &r->leg[l];
+    if (walker_tip) put3(walker_tip + 3 * l, leg->stepper.current_tip_pose.p);
+    if (poser_tip) put3(poser_tip + 3 * l, leg->poser.current_tip_pose.p);
+    if (model_tip) put3(model_tip + 3 * l, leg->current_tip_pose.p);
+    if (tip_force) put3(tip_force + 3 * l, leg->tip_force_calculated);
+    if (admittance) put3(admittance + 3 * l, leg->admittance_delta);
+    if (leg_status) leg_status[l] = (leg->stepper.step_state & 3) | (leg->ik_failed ? 4 : 0) | (leg->stepper.phase << 8);
+  }
+}
+
+void orc_get_body_state(const orc_robot *r, double pose[7], double velocity[3], int32_t *walk_state)
+{
+  if (pose)
+  {
+    pose[0] = r->current_pose.p.x; pose[1] = r->current_pose.p.y; pose[2] = r->current_pose.p.z;
+    pose[3] = r->current_pose.r.w; pose[4] = r->current_pose.r.x; pose[5] = r->current_pose.r.y; pose[6] = r->current_pose.r.z;
+  }
+  if (velocity)
+  {
+    velocity[0] = r->desired_linear_velocity[0];
+    velocity[1] = r->desired_linear_velocity[1];
+    velocity[2] = r->desired_angular_velocity;
+  }
+  if (walk_state) *walk_state = r->walk_state;
+}
+
+int orc_get_ik_failures(const orc_robot *r)
+{
+  int n = 0;
+  for (int l = 0; l < r->leg_count; ++l) n += r->leg[l].ik_failed;
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------ batch driver */
+
+struct orc_batch
+{
+  int64_t n;
+  orc_robot *robots; /* contiguous */
+  int dof_total;
+};
+
+orc_batch *orc_batch_create(const shc_params *params, int64_t n)
+{
+  orc_robot *proto = orc_create(params);
+  if (!proto) return NULL;
+  if (orc_startup(proto) < 0) { orc_destroy(proto); return NULL; }
+  orc_batch *b = (orc_batch *)calloc(1, sizeof(orc_batch));
+  b->n = n;
+  b->robots = (orc_robot *)malloc(sizeof(orc_robot) * (size_t)n);
+  for (int64_t i = 0; i < n; ++i) memcpy(&b->robots[i], proto, sizeof(orc_robot));
+  b->dof_total = 0;
+  for (int l = 0; l < proto->leg_count; ++l) b->dof_total += proto->leg[l].joint_count;
+  orc_destroy(proto);
+  return b;
+}
+
+void orc_batch_destroy(orc_batch *b)
+{
+  if (!b) return;
+  free(b->robots);
+  free(b);
+}
+
+orc_robot *orc_batch_robot(orc_batch *b, int64_t i) { return &b->robots[i]; }
+
+void orc_batch_set_velocity(orc_batch *b, const double *lin_xy, const double *ang)
+{
+  for (int64_t i = 0; i < b->n; ++i)
+    orc_set_velocity(&b->robots[i], lin_xy ? lin_xy[2 * i] : 0.0, lin_xy ? lin_xy[2 * i + 1] : 0.0, ang ? ang[i] : 0.0);
+}
+void orc_batch_set_imu(orc_batch *b, const double *quat, const double *gyro)
+{
+  static const double zero3[3] = { 0, 0, 0 };
+  for (int64_t i = 0; i < b->n; ++i) orc_set_imu(&b->robots[i], quat + 4 * i, gyro ? gyro + 3 * i : zero3);
+}
+void orc_batch_set_tip_force(orc_batch *b, const double *force)
+{
+  for (int64_t i = 0; i < b->n; ++i) orc_set_tip_force(&b->robots[i], force + (size_t)i * b->robots[i].leg_count * 3);
+}
+void orc_batch_set_joint_effort(orc_batch *b, const double *effort)
+{
+  for (int64_t i = 0; i < b->n; ++i) orc_set_joint_effort(&b->robots[i], effort + (size_t)i * b->dof_total);
+}
+void orc_batch_set_pose_input(orc_batch *b, const double *tv, const double *rv)
+{
+  for (int64_t i = 0; i < b->n; ++i) orc_set_pose_input(&b->robots[i], tv + 3 * i, rv + 3 * i);
+}
+
+typedef struct { orc_batch *b; int64_t lo, hi; int n_cycles; } batch_job;
+
+static void *batch_worker(void *arg)
+{
+  batch_job *j = (batch_job *)arg;
+  /* robot-major: each robot runs all its cycles (the reference's one-robot loop), robots are independent */
+  for (int64_t i = j->lo; i < j->hi; ++i)
+    for (int c = 0; c < j->n_cycles; ++c) state_loop(&j->b->robots[i]);
+  return NULL;
+}
+
+double orc_batch_step(orc_batch *b, int n_cycles, int n_threads)
+{
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > 256) n_threads = 256;
+  if ((int64_t)n_threads > b->n) n_threads = (int)b->n;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  if (n_threads == 1)
+  {
+    batch_job j = { b, 0, b->n, n_cycles };
+    batch_worker(&j);
+  }
+  else
+  {
+    pthread_t th[256];
+    batch_job jobs[256];
+    for (int t = 0; t < n_threads; ++t)
+    {
+      jobs[t].b = b;
+      jobs[t].lo = b->n * t / n_threads;
+      jobs[t].hi = b->n * (t + 1) / n_threads;
+      jobs[t].n_cycles = n_cycles;
+      pthread_create(&th[t], NULL, batch_worker, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+void orc_batch_get_joint_state(orc_batch *b, double *q, double *qd)
+{
+  for (int64_t i = 0; i < b->n; ++i)
+    orc_get_joint_state(&b->robots[i], q ? q + (size_t)i * b->dof_total : NULL, qd ? qd + (size_t)i * b->dof_total : NULL);
+}
+
+void orc_batch_get_leg_state(orc_batch *b, double *walker_tip, double *poser_tip, double *model_tip, double *tip_force,
+                             double *admittance, int32_t *leg_status)
+{
+  for (int64_t i = 0; i < b->n; ++i)
+  {
+    size_t L = (size_t)b->robots[i].leg_count;
+    orc_get_leg_state(&b->robots[i], walker_tip ? walker_tip + i * L * 3 : NULL, poser_tip ? poser_tip + i * L * 3 : NULL,
+                      model_tip ? model_tip + i * L * 3 : NULL, tip_force ? tip_force + i * L * 3 : NULL,
+                      admittance ? admittance + i * L * 3 : NULL, leg_status ? leg_status + i * L : NULL);
+  }
+}
+
+void orc_batch_get_body_state(orc_batch *b, double *pose, double *velocity, int32_t *walk_state)
+{
+  for (int64_t i = 0; i < b->n; ++i)
+    orc_get_body_state(&b->robots[i], pose ? pose + 7 * i : NULL, velocity ? velocity + 3 * i : NULL,
+                       walk_state ? walk_state + i : NULL);
+}
+
+/* ------------------------------------------------------------------------------------ unit-level test hooks */
+
+void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out) { *out = generate_step_cycle(p); }
+void orc_test_quat_to_euler(const double q[4], int intrinsic, double out[3])
+{
+  orc_v3 e = orc_quat_to_euler(orc_quat_make(q[0], q[1], q[2], q[3]), intrinsic);
+  out[0] = e.x; out[1] = e.y; out[2] = e.z;
+}
+void orc_test_euler_to_quat(const double e[3], int intrinsic, double out[4])
+{
+  orc_quat q = orc_euler_to_quat(orc_v3_make(e[0], e[1], e[2]), intrinsic);
+  out[0] = q.w; out[1] = q.x; out[2] = q.y; out[3] = q.z;
+}
+void orc_test_from_two_vectors(const double a[3], const double b[3], double out[4])
+{
+  orc_quat q = orc_quat_from_two_vectors(orc_v3_make(a[0], a[1], a[2]), orc_v3_make(b[0], b[1], b[2]));
+  out[0] = q.w; out[1] = q.x; out[2] = q.y; out[3] = q.z;
+}
+void orc_test_slerp(const double a[4], double t, const double b[4], double out[4])
+{
+  orc_quat q = orc_quat_slerp(orc_quat_make(a[0], a[1], a[2], a[3]), t, orc_quat_make(b[0], b[1], b[2], b[3]));
+  out[0] = q.w; out[1] = q.x; out[2] = q.y; out[3] = q.z;
+}
+void orc_test_quat_from_matrix(const double m[9], double out[4])
+{
+  orc_m3 mm;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) mm.m[i][j] = m[i * 3 + j];
+  orc_quat q = orc_quat_from_matrix(&mm);
+  out[0] = q.w; out[1] = q.x; out[2] = q.y; out[3] = q.z;
+}
+int orc_test_lu_inverse(const double *a, int n, double *inv) { return orc_lu_inverse(a, n, inv); }
+void orc_test_dh_matrix(double d, double theta, double r, double alpha, double out[16])
+{
+  orc_m4 m = orc_create_dh_matrix(d, theta, r, alpha);
+  memcpy(out, &m.m[0][0], sizeof(double) * 16);
+}
+void orc_test_quartic_bezier(const double nodes[15], double t, double out[3], double out_dot[3])
+{
+  orc_v3 p[5];
+  for (int k = 0; k < 5; ++k) p[k] = orc_v3_make(nodes[3 * k], nodes[3 * k + 1], nodes[3 * k + 2]);
+  orc_v3 a = orc_quartic_bezier(p, t), b = orc_quartic_bezier_dot(p, t);
+  out[0] = a.x; out[1] = a.y; out[2] = a.z;
+  out_dot[0] = b.x; out_dot[1] = b.y; out_dot[2] = b.z;
+}
+void orc_test_leg_fk(const shc_params *p, int l, const double *q, double tip_pos[3], double tip_quat[4])
+{
+  orc_robot *r = orc_create(p);
+  leg_t *leg = &r->leg[l];
+  for (int j = 0; j < leg->joint_count; ++j) leg->joint[j].desired_position = q[j];
+  orc_pose t = leg_apply_fk(r, leg);
+  put3(tip_pos, t.p);
+  tip_quat[0] = t.r.w; tip_quat[1] = t.r.x; tip_quat[2] = t.r.y; tip_quat[3] = t.r.z;
+  orc_destroy(r);
+}
+double orc_test_leg_ik_step(const shc_params *p, int l, const double *q, const double *qd, const double desired[3],
+                            int simulation, double *q_out, double *qd_out, double tip_out[3])
+{
+  orc_robot *r = orc_create(p);
+  leg_t *leg = &r->leg[l];
+  for (int j = 0; j < leg->joint_count; ++j)
+  {
+    leg->joint[j].desired_position = q[j];
+    leg->joint[j].desired_velocity = qd ? qd[j] : 0.0;
+  }
+  leg_apply_fk(r, leg);
+  leg_set_desired_tip_pose(leg, orc_pose_make(orc_v3_make(desired[0], desired[1], desired[2]), ORC_UNDEFINED_ROTATION), 0);
+  double res = leg_apply_ik(r, leg, simulation);
+  for (int j = 0; j < leg->joint_count; ++j)
+  {
+    q_out[j] = leg->joint[j].desired_position;
+    if (qd_out) qd_out[j] = leg->joint[j].desired_velocity;
+  }
+  if (tip_out) put3(tip_out, leg->current_tip_pose.p);
+  orc_destroy(r);
+  return res;
+}
+void orc_test_admittance(const shc_params *p, double state[2], const double force[3], double delta_out[3])
+{
+  admittance_leg(p, state, orc_v3_make(force[0], force[1], force[2]), delta_out);
+}

@@ -1,0 +1,104 @@
+/*
+ * shc_oracle.h — TEST INFRASTRUCTURE: CPU oracle for the batched leg-control engine.
+ *
+ * A scalar, one-robot-at-a-time C restatement of the reference's per-cycle hot path
+ * (OpenSHC v0.5.11; file:line citations in shc_oracle.c are relative to /root/reference) and of the
+ * host init chain the hot path's tables come from.  It keeps the reference's structure on purpose
+ * (per robot -> per leg loops, full 6x6 partial-pivot LU DLS inverse, 30-step RK4 admittance, O(N^2)
+ * chain products), so it doubles as the "port" CPU baseline of bench.py.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
+ *  and cannot be compiled in this image (needs ROS-1, Eigen3, Boost.odeint; none
+ * installed, no network), so this oracle is pinned only by (1) hand-derived known answers from the
+ * reference formulae (tests/test_oracle_kat.py), (2) independent numpy/scipy cross-checks generated in the
+ * build container (tests/golden/), (3) the reference's own runtime invariants (FK(IK(x)) within
+ * IK_TOLERANCE, C0/C1 continuity of the swing/stance Beziers, finite outputs).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import, call, link or execute
+ * anything under oracle/.  The product (libshc_batch.so) never links this.
+ */
+#ifndef SHC_ORACLE_H
+#define SHC_ORACLE_H
+
+#include <stddef.h>
+#include "../include/shc_batch.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_robot orc_robot;
+
+/* StateController ctor + init() + initModel(use_default_joint_positions = true)
+ * (state_controller.cpp:13-153, main.cpp:100-101).  Returns NULL on unsupported parameters. */
+orc_robot *orc_create(const shc_params *params);
+void orc_destroy(orc_robot *r);
+orc_robot *orc_clone(const orc_robot *r);
+size_t orc_sizeof_robot(void);
+
+/* Run StateController::loop() from UNKNOWN through PACKED -> (direct start-up) -> READY -> RUNNING
+ * (state_controller.cpp:197-272).  Returns the number of loop iterations taken, < 0 on failure. */
+int orc_startup(orc_robot *r);
+void orc_get_tables(const orc_robot *r, shc_tables *out);
+
+/* Inputs (ROS callbacks in the reference). */
+void orc_set_velocity(orc_robot *r, double vx, double vy, double omega);       /* state_controller.cpp:1127 */
+void orc_set_imu(orc_robot *r, const double quat_wxyz[4], const double gyro[3]); /* :1552, model.h:146 */
+void orc_set_tip_force(orc_robot *r, const double *force /* [legs][3] */);      /* :1618 */
+void orc_set_joint_effort(orc_robot *r, const double *effort /* [legs][dof] */); /* :1590 */
+void orc_set_pose_input(orc_robot *r, const double tv[3], const double rv[3]);  /* :1142 */
+void orc_set_pose_reset_mode(orc_robot *r, int mode);
+
+/* One StateController::loop() with robot_state == RUNNING (state_controller.cpp:162-193, 379-447). */
+void orc_cycle(orc_robot *r);
+
+/* Outputs. */
+void orc_get_joint_state(const orc_robot *r, double *q, double *qd);            /* [legs][dof] */
+void orc_get_leg_state(const orc_robot *r, double *walker_tip, double *poser_tip, double *model_tip,
+                       double *tip_force, double *admittance, int32_t *leg_status);
+void orc_get_body_state(const orc_robot *r, double pose[7], double velocity[3], int32_t *walk_state);
+int orc_get_ik_failures(const orc_robot *r);
+
+/*
+ * Batch driver used by tests and by bench.py's cpu_baseline leg: `n` independent robots cloned from
+ * one started-up robot, per-instance inputs in the C-ABI's instance-major layouts (NULL = zeros),
+ * `n_cycles` cycles each, split over `n_threads` pthreads.  Outputs q/qd [n][legs][dof] (may be NULL).
+ * Returns wall seconds spent in the cycle loop (excluding start-up and cloning), < 0 on failure.
+ */
+typedef struct orc_batch orc_batch;
+orc_batch *orc_batch_create(const shc_params *params, int64_t n);
+void orc_batch_destroy(orc_batch *b);
+orc_robot *orc_batch_robot(orc_batch *b, int64_t i);
+void orc_batch_set_velocity(orc_batch *b, const double *lin_xy, const double *ang);
+void orc_batch_set_imu(orc_batch *b, const double *quat, const double *gyro);
+void orc_batch_set_tip_force(orc_batch *b, const double *force);
+void orc_batch_set_joint_effort(orc_batch *b, const double *effort);
+void orc_batch_set_pose_input(orc_batch *b, const double *tv, const double *rv);
+double orc_batch_step(orc_batch *b, int n_cycles, int n_threads);
+void orc_batch_get_joint_state(orc_batch *b, double *q, double *qd);
+void orc_batch_get_leg_state(orc_batch *b, double *walker_tip, double *poser_tip, double *model_tip,
+                             double *tip_force, double *admittance, int32_t *leg_status);
+void orc_batch_get_body_state(orc_batch *b, double *pose, double *velocity, int32_t *walk_state);
+
+/* ---- unit-level entry points for the KAT / cross-check tests (thin wrappers over the static code) ---- */
+void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out);
+void orc_test_quat_to_euler(const double q_wxyz[4], int intrinsic, double out[3]);
+void orc_test_euler_to_quat(const double e[3], int intrinsic, double out_wxyz[4]);
+void orc_test_from_two_vectors(const double a[3], const double b[3], double out_wxyz[4]);
+void orc_test_slerp(const double a[4], double t, const double b[4], double out[4]);
+void orc_test_quat_from_matrix(const double m[9], double out_wxyz[4]);
+int orc_test_lu_inverse(const double *a, int n, double *inv);
+void orc_test_dh_matrix(double d, double theta, double r, double alpha, double out[16]);
+void orc_test_quartic_bezier(const double nodes[15], double t, double out[3], double out_dot[3]);
+/* Leg-level: FK of leg `leg` at joint angles q -> tip pose (robot frame) */
+void orc_test_leg_fk(const shc_params *p, int leg, const double *q, double tip_pos[3], double tip_quat[4]);
+/* One applyIK(simulation) from joint state (q, qd) towards desired tip position; returns ik result. */
+double orc_test_leg_ik_step(const shc_params *p, int leg, const double *q, const double *qd, const double desired[3],
+                            int simulation, double *q_out, double *qd_out, double tip_out[3]);
+/* Admittance: one updateAdmittance for a single leg state (x, xdot) and force (3) */
+void orc_test_admittance(const shc_params *p, double state[2], const double force[3], double delta_out[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
