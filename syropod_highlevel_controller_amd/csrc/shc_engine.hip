@@ -1,0 +1,836 @@
+// shc_engine.hip — libshc_batch.so: C ABI (include/shc_batch.h), host init chain and HIP kernels (gfx950).
+//
+// Product code.  Nothing here links, includes or calls anything under oracle/.  There is no CPU fallback for
+// the cycle: without a HIP device shc_engine_create fails with SHC_ERR_NO_DEVICE.
+#include "../../include/shc_batch.h"
+#include "shc_cycle.hpp"
+#include "shc_host_init.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace shc;
+
+static thread_local std::string g_last_error;
+static int fail(int code, const std::string &msg) {
+  g_last_error = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) return fail(SHC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+// ================================================================================================= kernels
+
+template <int L, int NJ>
+__device__ __forceinline__ void load_lane(Lane<L, NJ> &s, const DevState &st, const CycleParams &P, int64_t slot, int64_t rob) {
+  using F = Fields<NJ>;
+  using R = RobotFields;
+  const double *ld = st.legd + slot;
+  const int64_t ns = st.n_slots;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    s.q[i] = ld[(F::Q + i) * ns];
+    s.qd[i] = ld[(F::QD + i) * ns];
+  }
+  s.tip = ldv3(ld + F::TIP * ns, ns);
+  s.tvel = ldv3(ld + F::TVEL * ns, ns);
+  s.sorg = ldv3(ld + F::SORG * ns, ns);
+  s.svel = ldv3(ld + F::SVEL * ns, ns);
+  s.torg = ldv3(ld + F::TORG * ns, ns);
+  s.dflt = ldv3(ld + F::DFLT * ns, ns);
+  s.targ = ldv3(ld + F::TARG * ns, ns);
+  s.strd = ldv3(ld + F::STRD * ns, ns);
+  s.adm0 = s.adm1 = 0.0;
+  s.tf = V3{0, 0, 0};
+  s.force_in = V3{0, 0, 0};
+  if (P.admittance_control) {
+    s.adm0 = ld[(F::ADM + 0) * ns];
+    s.adm1 = ld[(F::ADM + 1) * ns];
+    s.force_in = ldv3(ld + F::FORCE_IN * ns, ns);
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) s.effort[i] = 0.0;
+  if (P.tip_force) {
+    s.tf = ldv3(ld + F::TF * ns, ns);
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) s.effort[i] = ld[(F::EFFORT_IN + i) * ns];
+  }
+  s.word = st.legi[slot];
+
+  const double *rd = st.robd + rob;
+  const int64_t nr = st.n_rob_pad;
+  s.vx = rd[(R::VLIN + 0) * nr];
+  s.vy = rd[(R::VLIN + 1) * nr];
+  s.vw = rd[R::VANG * nr];
+  s.plane = ldv3(rd + R::PLANE * nr, nr);
+  s.pnorm = ldv3(rd + R::PNORM * nr, nr);
+  s.plane_prev = ldv3(rd + R::PLANE_PREV * nr, nr);
+  s.pnorm_prev = ldv3(rd + R::PNORM_PREV * nr, nr);
+  s.owpp.p = ldv3(rd + R::OWPP * nr, nr);
+  s.owpp.r = Quat{rd[(R::OWPP + 3) * nr], rd[(R::OWPP + 4) * nr], rd[(R::OWPP + 5) * nr], rd[(R::OWPP + 6) * nr]};
+  s.mpose = pose_identity();
+  s.tvi = s.rvi = V3{0, 0, 0};
+  s.reset_mode = 0;
+  if (P.manual_posing) {
+    s.mpose.p = ldv3(rd + R::MPOSE * nr, nr);
+    s.mpose.r = Quat{rd[(R::MPOSE + 3) * nr], rd[(R::MPOSE + 4) * nr], rd[(R::MPOSE + 5) * nr], rd[(R::MPOSE + 6) * nr]};
+    s.tvi = ldv3(rd + R::TVI * nr, nr);
+    s.rvi = ldv3(rd + R::RVI * nr, nr);
+    s.reset_mode = st.robi[R::I_RESET_MODE * nr + rob];
+  }
+  s.abse = s.verr = s.gyro = V3{0, 0, 0};
+  s.imuq = quat_identity();
+  s.aprev = quat_identity();
+  if (P.imu_posing) {
+    s.abse = ldv3(rd + R::ABSE * nr, nr);
+    s.verr = ldv3(rd + R::VERR * nr, nr);
+    s.gyro = ldv3(rd + R::GYRO * nr, nr);
+  }
+  if (P.imu_posing || P.inclination_posing || P.auto_posing)
+    s.imuq = Quat{rd[(R::IMUQ + 0) * nr], rd[(R::IMUQ + 1) * nr], rd[(R::IMUQ + 2) * nr], rd[(R::IMUQ + 3) * nr]};
+  if (P.inclination_posing && P.auto_posing)
+    s.aprev = Quat{rd[(R::APREV + 0) * nr], rd[(R::APREV + 1) * nr], rd[(R::APREV + 2) * nr], rd[(R::APREV + 3) * nr]};
+  s.vin_x = rd[(R::VIN + 0) * nr];
+  s.vin_y = rd[(R::VIN + 1) * nr];
+  s.win = rd[R::WIN * nr];
+  s.rword = st.robi[R::I_WORD * nr + rob];
+  s.aposer = 0;
+  s.pose_phase = 0;
+  if (P.auto_posing) {
+    s.aposer = st.robi[R::I_APOSER * nr + rob];
+    s.pose_phase = st.robi[R::I_POSE_PHASE * nr + rob];
+  }
+}
+
+template <int L, int NJ>
+__device__ __forceinline__ void store_lane(const Lane<L, NJ> &s, const DevState &st, const CycleParams &P, int64_t slot, int64_t rob,
+                                           bool leader) {
+  using F = Fields<NJ>;
+  using R = RobotFields;
+  double *ld = st.legd + slot;
+  const int64_t ns = st.n_slots;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    ld[(F::Q + i) * ns] = s.q[i];
+    ld[(F::QD + i) * ns] = s.qd[i];
+  }
+  stv3(ld + F::TIP * ns, ns, s.tip);
+  stv3(ld + F::TVEL * ns, ns, s.tvel);
+  stv3(ld + F::SORG * ns, ns, s.sorg);
+  stv3(ld + F::SVEL * ns, ns, s.svel);
+  stv3(ld + F::TORG * ns, ns, s.torg);
+  stv3(ld + F::DFLT * ns, ns, s.dflt);
+  stv3(ld + F::TARG * ns, ns, s.targ);
+  stv3(ld + F::STRD * ns, ns, s.strd);
+  if (P.admittance_control) {
+    ld[(F::ADM + 0) * ns] = s.adm0;
+    ld[(F::ADM + 1) * ns] = s.adm1;
+    stv3(ld + F::ADM_DELTA * ns, ns, s.adm_delta);
+  }
+  if (P.tip_force) stv3(ld + F::TF * ns, ns, s.tf);
+  stv3(ld + F::POSER_TIP * ns, ns, s.poser_tip);
+  stv3(ld + F::MODEL_TIP * ns, ns, s.model_tip);
+  st.legi[slot] = s.word;
+  if (leader) {
+    double *rd = st.robd + rob;
+    const int64_t nr = st.n_rob_pad;
+    rd[(R::VLIN + 0) * nr] = s.vx;
+    rd[(R::VLIN + 1) * nr] = s.vy;
+    rd[R::VANG * nr] = s.vw;
+    stv3(rd + R::PLANE * nr, nr, s.plane);
+    stv3(rd + R::PNORM * nr, nr, s.pnorm);
+    stv3(rd + R::PLANE_PREV * nr, nr, s.plane_prev);
+    stv3(rd + R::PNORM_PREV * nr, nr, s.pnorm_prev);
+    stv3(rd + R::OWPP * nr, nr, s.owpp.p);
+    rd[(R::OWPP + 3) * nr] = s.owpp.r.w;
+    rd[(R::OWPP + 4) * nr] = s.owpp.r.x;
+    rd[(R::OWPP + 5) * nr] = s.owpp.r.y;
+    rd[(R::OWPP + 6) * nr] = s.owpp.r.z;
+    if (P.manual_posing) {
+      stv3(rd + R::MPOSE * nr, nr, s.mpose.p);
+      rd[(R::MPOSE + 3) * nr] = s.mpose.r.w;
+      rd[(R::MPOSE + 4) * nr] = s.mpose.r.x;
+      rd[(R::MPOSE + 5) * nr] = s.mpose.r.y;
+      rd[(R::MPOSE + 6) * nr] = s.mpose.r.z;
+      stv3(rd + R::TVI * nr, nr, s.tvi);
+      stv3(rd + R::RVI * nr, nr, s.rvi);
+    }
+    if (P.imu_posing) {
+      stv3(rd + R::ABSE * nr, nr, s.abse);
+      stv3(rd + R::VERR * nr, nr, s.verr);
+    }
+    if (P.inclination_posing && P.auto_posing) {
+      rd[(R::APREV + 0) * nr] = s.aprev.w;
+      rd[(R::APREV + 1) * nr] = s.aprev.x;
+      rd[(R::APREV + 2) * nr] = s.aprev.y;
+      rd[(R::APREV + 3) * nr] = s.aprev.z;
+    }
+    stv3(rd + R::CPOSE * nr, nr, s.cpose.p);
+    rd[(R::CPOSE + 3) * nr] = s.cpose.r.w;
+    rd[(R::CPOSE + 4) * nr] = s.cpose.r.x;
+    rd[(R::CPOSE + 5) * nr] = s.cpose.r.y;
+    rd[(R::CPOSE + 6) * nr] = s.cpose.r.z;
+    st.robi[R::I_WORD * nr + rob] = s.rword;
+    if (P.auto_posing) {
+      st.robi[R::I_APOSER * nr + rob] = s.aposer;
+      st.robi[R::I_POSE_PHASE * nr + rob] = s.pose_phase;
+    }
+  }
+}
+
+// One launch = n_cycles control cycles of every robot; state lives in registers between cycles.
+template <int L, int NJ>
+__global__ void __launch_bounds__(256) shc_cycle_kernel(DevState st, CycleParams P, const SharedConsts<L, NJ> *gc, int n_cycles) {
+  __shared__ SharedConsts<L, NJ> C;
+  {
+    constexpr int n8 = sizeof(SharedConsts<L, NJ>) / 8;
+    static_assert(sizeof(SharedConsts<L, NJ>) % 8 == 0, "const block must be a whole number of 8-byte words");
+    const double *src = reinterpret_cast<const double *>(gc);
+    double *dst = reinterpret_cast<double *>(&C);
+    for (int i = threadIdx.x; i < n8; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  constexpr int RPW = 64 / L; // robots per wavefront
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  if (wave * RPW >= st.n_robots) return; // whole wave past the end (wave-uniform)
+  const int64_t left = st.n_robots - wave * RPW;
+  const int robots_here = left < RPW ? int(left) : RPW;
+  // Lanes without a robot of their own (the 64 % L tail lanes and the groups past the end of the batch) mirror a
+  // live lane of the same leg in this wave so that every shuffle stays well defined; they never store.
+  int grp = lane / L;
+  int leg = lane - grp * L;
+  const bool live = grp < robots_here;
+  if (grp >= robots_here) grp = robots_here - 1;
+  const int64_t rob = wave * RPW + grp;
+  const int64_t slot = wave * 64 + grp * L + leg;
+  Group<L> g{grp * L};
+  Lane<L, NJ> s;
+  load_lane<L, NJ>(s, st, P, slot, rob);
+  Chain<NJ> chain;
+  fk_chain<NJ>(C.leg[leg], s.q, chain);
+  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ>(s, P, C, g, leg, chain);
+  if (live) store_lane<L, NJ>(s, st, P, slot, rob, leg == 0);
+}
+
+// ---- layout conversion kernels (C ABI instance-major arrays <-> SoA fields)
+__device__ __forceinline__ int64_t slot_of(int64_t rob, int leg, int L) {
+  int rpw = 64 / L;
+  int64_t w = rob / rpw;
+  int gi = int(rob - w * rpw);
+  return w * 64 + gi * L + leg;
+}
+
+// AoS [n][L][K] -> leg fields f0..f0+K-1
+__global__ void scatter_leg_kernel(const double *src, double *legd, int64_t n_slots, int64_t n, int L, int K, int f0) {
+  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  int64_t rob = t / L;
+  int leg = int(t - rob * L);
+  int64_t slot = slot_of(rob, leg, L);
+  for (int k = 0; k < K; ++k) legd[(f0 + k) * n_slots + slot] = src[t * K + k];
+}
+__global__ void gather_leg_kernel(double *dst, const double *legd, int64_t n_slots, int64_t n, int L, int K, int f0) {
+  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  int64_t rob = t / L;
+  int leg = int(t - rob * L);
+  int64_t slot = slot_of(rob, leg, L);
+  for (int k = 0; k < K; ++k) dst[t * K + k] = legd[(f0 + k) * n_slots + slot];
+}
+__global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int64_t n, int L) {
+  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  int64_t rob = t / L;
+  int leg = int(t - rob * L);
+  int w = legi[slot_of(rob, leg, L)];
+  int phase = (w >> LW_PHASE_SHIFT) & LW_PHASE_MASK;
+  dst[t] = (w & 3) | ((w & LW_IKFAIL) ? 4 : 0) | (phase << 8);
+}
+// AoS [n][K] -> robot fields
+__global__ void scatter_rob_kernel(const double *src, double *robd, int64_t n_rob_pad, int64_t n, int K, int f0, int normalize_quat) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  if (normalize_quat) { // Model::setImuData normalises the orientation (model.h:150)
+    Quat q = normalized(Quat{src[r * 4], src[r * 4 + 1], src[r * 4 + 2], src[r * 4 + 3]});
+    robd[(f0 + 0) * n_rob_pad + r] = q.w;
+    robd[(f0 + 1) * n_rob_pad + r] = q.x;
+    robd[(f0 + 2) * n_rob_pad + r] = q.y;
+    robd[(f0 + 3) * n_rob_pad + r] = q.z;
+    return;
+  }
+  for (int k = 0; k < K; ++k) robd[(f0 + k) * n_rob_pad + r] = src[r * K + k];
+}
+__global__ void gather_rob_kernel(double *dst, const double *robd, int64_t n_rob_pad, int64_t n, int K, int f0) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int k = 0; k < K; ++k) dst[r * K + k] = robd[(f0 + k) * n_rob_pad + r];
+}
+__global__ void gather_walk_state_kernel(int32_t *dst, const int32_t *robi, int64_t n) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  dst[r] = robi[r] & 3;
+}
+// replicate the post-start-up state of one robot into every slot
+__global__ void init_state_kernel(DevState st, const double *leg_template /*[L][nf]*/, const int32_t *legw_template /*[L]*/,
+                                  const double *rob_template /*[nrf]*/, const int32_t *robi_template /*[nri]*/, int L, int nf,
+                                  int nrf, int nri) {
+  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  int64_t n = st.n_robots;
+  if (t < n * L) {
+    int64_t rob = t / L;
+    int leg = int(t - rob * L);
+    int64_t slot = slot_of(rob, leg, L);
+    for (int f = 0; f < nf; ++f) st.legd[f * st.n_slots + slot] = leg_template[leg * nf + f];
+    st.legi[slot] = legw_template[leg];
+  }
+  if (t < n) {
+    for (int f = 0; f < nrf; ++f) st.robd[f * st.n_rob_pad + t] = rob_template[f];
+    for (int f = 0; f < nri; ++f) st.robi[f * st.n_rob_pad + t] = robi_template[f];
+  }
+}
+
+// ================================================================================================= engine
+
+struct shc_engine {
+  shc_params params;
+  shc_tables tables;
+  CycleParams cp;
+  int L, NJ;
+  int device;
+  hipStream_t stream;
+  int64_t n, n_waves, n_slots, n_rob_pad;
+  int n_leg_fields;
+  DevState st;
+  void *d_consts;
+  double *d_stage;     // staging for host <-> device conversions
+  size_t stage_bytes;
+  uint32_t features;
+};
+
+template <int L, int NJ>
+static void build_shared_consts(const shc_params &p, const shc_tables &t, SharedConsts<L, NJ> &c) {
+  memset(&c, 0, sizeof c);
+  const shc_step_cycle &step = t.step;
+  for (int l = 0; l < L; ++l) {
+    hostinit::fill_leg_const<NJ>(p, l, c.leg[l]);
+    LegConst<NJ> &lc = c.leg[l];
+    lc.neg_ratio = p.negation_transition_ratio[l];
+    lc.phase_offset = t.phase_offset[l];
+    int ns = p.pose_negation_phase_starts[l] * t.pose_normaliser, ne = p.pose_negation_phase_ends[l] * t.pose_normaliser;
+    if (ns == 0) ns = t.pose_phase_length; // pose_controller.cpp:1723-1730
+    if (ne == 0) ne = t.pose_phase_length;
+    lc.neg_start = ns;
+    lc.neg_end = ne;
+    int msp = mod_i(step.stance_end - lc.phase_offset, step.period); // walk_controller.cpp:1026-1031
+    if (step.stance_end == lc.phase_offset) msp = step.period;
+    lc.first_stance_period = msp;
+    lc.first_stance_iterations = int((double(msp) / step.period) / (step.frequency * p.time_delta));
+    lc.starts_in_swing = (lc.phase_offset > step.swing_start && lc.phase_offset < step.swing_end) ? 1 : 0;
+  }
+  for (int b = 0; b < 9; ++b) {
+    c.limit[0][b] = t.max_linear_speed[b];
+    c.limit[1][b] = t.max_angular_speed[b];
+    c.limit[2][b] = t.max_linear_acceleration[b];
+    c.limit[3][b] = t.max_angular_acceleration[b];
+  }
+}
+
+static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_t features, CycleParams &c) {
+  memset(&c, 0, sizeof c);
+  const shc_step_cycle &s = t.step;
+  c.dt = p.time_delta;
+  c.period = s.period;
+  c.swing_period = s.swing_period;
+  c.stance_period = s.stance_period;
+  c.stance_end = s.stance_end;
+  c.swing_start = s.swing_start;
+  c.swing_end = s.swing_end;
+  c.stance_start = s.stance_start;
+  int swing_iterations = int((double(s.swing_period) / s.period) / (s.frequency * p.time_delta)); // walk_controller.cpp:1035
+  swing_iterations = round_to_even_int(swing_iterations);
+  c.swing_iterations = swing_iterations;
+  c.swing_delta_t = 1.0 / (swing_iterations / 2.0);
+  c.stance_iterations = int((double(s.stance_period) / s.period) / (s.frequency * p.time_delta)); // :1040
+  double on_ground_ratio = double(s.stance_period) / s.period;                                    // :940
+  c.stride_scale = on_ground_ratio / s.frequency;
+  c.swing_height = p.swing_height;
+  c.swing_width = p.swing_width;
+  c.body_clearance = p.body_clearance;
+  c.swing_progress_scaler = fmax(1.0, double(p.swing_phase) / p.phase_offset); // pose_controller.cpp:1103
+  c.velocity_input_mode = p.velocity_input_mode;
+  c.manual_posing = p.manual_posing;
+  c.auto_posing = p.auto_posing;
+  c.inclination_posing = p.inclination_posing;
+  c.imu_posing = p.imu_posing;
+  c.admittance_control = p.admittance_control;
+  c.dynamic_stiffness = p.dynamic_stiffness;
+  c.use_joint_effort = p.use_joint_effort;
+  c.clamp_joint_positions = p.clamp_joint_positions;
+  c.clamp_joint_velocities = p.clamp_joint_velocities;
+  c.force_normal_touchdown = p.force_normal_touchdown;
+  c.tip_force = (features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort ? 1 : 0;
+  for (int i = 0; i < 3; ++i) {
+    c.max_translation[i] = p.max_translation[i];
+    c.max_rotation[i] = p.max_rotation[i];
+  }
+  c.max_translation_velocity = p.max_translation_velocity;
+  c.max_rotation_velocity = p.max_rotation_velocity;
+  c.pid_p = p.rotation_pid_gains[0];
+  c.pid_i = p.rotation_pid_gains[1];
+  c.pid_d = p.rotation_pid_gains[2];
+  hostinit::admittance_map(p, c.adm_m00, c.adm_m01, c.adm_m10, c.adm_m11, c.adm_g0, c.adm_g1);
+  c.force_gain = p.force_gain;
+  c.virtual_stiffness = p.virtual_stiffness;
+  c.swing_stiffness_scaler = p.swing_stiffness_scaler;
+  c.load_stiffness_scaler = p.load_stiffness_scaler;
+  c.n_auto_posers = p.n_auto_posers;
+  c.pose_phase_length = t.pose_phase_length;
+  c.pose_sync = (p.pose_frequency == -1.0) ? 1 : 0;
+  c.auto_pose_reference_leg = t.auto_pose_reference_leg;
+  for (int i = 0; i < p.n_auto_posers && i < kMaxAutoPosers; ++i) {
+    c.ap_start[i] = p.pose_phase_starts[i] * t.pose_normaliser;
+    c.ap_end[i] = p.pose_phase_ends[i] * t.pose_normaliser;
+    c.ap_amp[i][0] = p.x_amplitudes[i];
+    c.ap_amp[i][1] = p.y_amplitudes[i];
+    c.ap_amp[i][2] = p.z_amplitudes[i];
+    c.ap_amp[i][3] = p.gravity_amplitudes[i];
+    c.ap_amp[i][4] = p.roll_amplitudes[i];
+    c.ap_amp[i][5] = p.pitch_amplitudes[i];
+    c.ap_amp[i][6] = p.yaw_amplitudes[i];
+  }
+}
+
+static int validate_params(const shc_params *p, int *L, int *NJ) {
+  if (!p) return fail(SHC_ERR_INVALID_ARG, "params is NULL");
+  if (p->leg_count < 3 || p->leg_count > SHC_MAX_LEGS) return fail(SHC_ERR_INVALID_ARG, "leg_count must be 3..8");
+  int nj = p->leg_dof[0];
+  for (int l = 0; l < p->leg_count; ++l)
+    if (p->leg_dof[l] != nj) return fail(SHC_ERR_UNSUPPORTED, "all legs of one engine must share one DOF (bin mixed morphologies)");
+  if (nj < 3 || nj > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
+  if (p->rough_terrain_mode) return fail(SHC_ERR_UNSUPPORTED, "rough_terrain_mode is outside the accelerated path");
+  if (p->gravity_aligned_tips) return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips (tip-rotation constrained IK) is outside the accelerated path");
+  if (p->stance_span_modifier != 0.0) return fail(SHC_ERR_UNSUPPORTED, "stance_span_modifier != 0 is outside the accelerated path");
+  if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
+  if (p->time_delta <= 0 || p->step_frequency <= 0) return fail(SHC_ERR_INVALID_ARG, "time_delta / step_frequency must be > 0");
+  *L = p->leg_count;
+  *NJ = nj;
+  return SHC_OK;
+}
+
+template <int NJ>
+static int generate_tables_nj(const shc_params *p, shc_tables *out) {
+  return hostinit::generate_tables<NJ>(*p, *out) ? SHC_OK : fail(SHC_ERR_INVALID_ARG, "init chain failed (unreachable stance?)");
+}
+
+extern "C" int shc_abi_version(void) { return 1; }
+
+extern "C" int shc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" const char *shc_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int shc_generate_tables(const shc_params *params, shc_tables *out) {
+  int L, NJ;
+  int rc = validate_params(params, &L, &NJ);
+  if (rc != SHC_OK) return rc;
+  if (!out) return fail(SHC_ERR_INVALID_ARG, "out is NULL");
+  switch (NJ) {
+    case 3: return generate_tables_nj<3>(params, out);
+    case 4: return generate_tables_nj<4>(params, out);
+    case 5: return generate_tables_nj<5>(params, out);
+  }
+  return fail(SHC_ERR_UNSUPPORTED, "dof");
+}
+
+#define SHC_DISPATCH(L_, NJ_, CALL)                                   \
+  do {                                                                \
+    if (L_ == 3 && NJ_ == 3) { CALL(3, 3); }                          \
+    else if (L_ == 4 && NJ_ == 3) { CALL(4, 3); }                     \
+    else if (L_ == 4 && NJ_ == 4) { CALL(4, 4); }                     \
+    else if (L_ == 4 && NJ_ == 5) { CALL(4, 5); }                     \
+    else if (L_ == 5 && NJ_ == 3) { CALL(5, 3); }                     \
+    else if (L_ == 6 && NJ_ == 3) { CALL(6, 3); }                     \
+    else if (L_ == 6 && NJ_ == 4) { CALL(6, 4); }                     \
+    else if (L_ == 6 && NJ_ == 5) { CALL(6, 5); }                     \
+    else if (L_ == 7 && NJ_ == 3) { CALL(7, 3); }                     \
+    else if (L_ == 8 && NJ_ == 3) { CALL(8, 3); }                     \
+    else if (L_ == 8 && NJ_ == 4) { CALL(8, 4); }                     \
+    else if (L_ == 8 && NJ_ == 5) { CALL(8, 5); }                     \
+    else return fail(SHC_ERR_UNSUPPORTED, "no kernel specialisation for this (legs, dof)"); \
+  } while (0)
+
+static int upload_consts(shc_engine *e) {
+#define CALL(L_, NJ_)                                                                                   \
+  {                                                                                                     \
+    SharedConsts<L_, NJ_> c;                                                                            \
+    build_shared_consts<L_, NJ_>(e->params, e->tables, c);                                              \
+    if (!e->d_consts) HIP_TRY(hipMalloc(&e->d_consts, sizeof c));                                       \
+    HIP_TRY(hipMemcpyAsync(e->d_consts, &c, sizeof c, hipMemcpyHostToDevice, e->stream));               \
+    HIP_TRY(hipStreamSynchronize(e->stream));                                                           \
+  }
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  return SHC_OK;
+}
+
+template <int NJ>
+static void build_templates(const shc_engine *e, std::vector<double> &legt, std::vector<int32_t> &legw, std::vector<double> &robt,
+                            std::vector<int32_t> &robi) {
+  using F = Fields<NJ>;
+  using R = RobotFields;
+  const int nf = F::COUNT;
+  legt.assign(size_t(e->L) * nf, 0.0);
+  legw.assign(e->L, 0);
+  for (int l = 0; l < e->L; ++l) {
+    double *t = &legt[size_t(l) * nf];
+    for (int j = 0; j < NJ; ++j) t[F::Q + j] = e->tables.default_joint_position[l][j];
+    double sx = e->params.stance_position[l][0], sy = e->params.stance_position[l][1];
+    // LegStepper constructor (walk_controller.cpp:795-819): everything at the identity tip pose
+    const int at_identity[] = {F::TIP, F::SORG, F::TORG, F::DFLT, F::TARG};
+    for (int f : at_identity) {
+      t[f] = sx;
+      t[f + 1] = sy;
+      t[f + 2] = 0.0;
+    }
+    // model tip of the start-up configuration (for getters before the first cycle)
+    LegConst<NJ> lc;
+    hostinit::fill_leg_const<NJ>(e->params, l, lc);
+    double q[NJ];
+    for (int j = 0; j < NJ; ++j) q[j] = t[F::Q + j];
+    Chain<NJ> ch;
+    fk_chain<NJ>(lc, q, ch);
+    V3 tip = tip_robot_frame(lc, ch.pe);
+    t[F::MODEL_TIP] = tip.x;
+    t[F::MODEL_TIP + 1] = tip.y;
+    t[F::MODEL_TIP + 2] = tip.z;
+    // step_state STANCE, phase 0, progress "none" (walk_controller.h:493-501)
+    legw[l] = SS_STANCE | (PM_NONE << LW_PM_SHIFT);
+  }
+  robt.assign(R::COUNT, 0.0);
+  robt[R::PNORM + 2] = 1.0;
+  robt[R::PNORM_PREV + 2] = 1.0;
+  robt[R::OWPP + 2] = e->params.body_clearance; // pose_controller.cpp:39-40
+  robt[R::OWPP + 3] = 1.0;
+  robt[R::MPOSE + 3] = 1.0;
+  robt[R::IMUQ + 0] = 1.0;
+  robt[R::APREV + 0] = 1.0;
+  robt[R::CPOSE + 2] = e->params.body_clearance;
+  robt[R::CPOSE + 3] = 1.0;
+  robi.assign(R::I_COUNT, 0);
+  robi[R::I_WORD] = WS_STOPPED | (PS_POSING_COMPLETE << RW_APS_SHIFT);
+}
+
+static int init_state(shc_engine *e) {
+  std::vector<double> legt, robt;
+  std::vector<int32_t> legw, robi;
+  switch (e->NJ) {
+    case 3: build_templates<3>(e, legt, legw, robt, robi); break;
+    case 4: build_templates<4>(e, legt, legw, robt, robi); break;
+    case 5: build_templates<5>(e, legt, legw, robt, robi); break;
+  }
+  double *d_legt, *d_robt;
+  int32_t *d_legw, *d_robi;
+  HIP_TRY(hipMalloc(&d_legt, legt.size() * 8));
+  HIP_TRY(hipMalloc(&d_robt, robt.size() * 8));
+  HIP_TRY(hipMalloc(&d_legw, legw.size() * 4));
+  HIP_TRY(hipMalloc(&d_robi, robi.size() * 4));
+  HIP_TRY(hipMemcpyAsync(d_legt, legt.data(), legt.size() * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(d_robt, robt.data(), robt.size() * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(d_legw, legw.data(), legw.size() * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(d_robi, robi.data(), robi.size() * 4, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemsetAsync(e->st.legd, 0, size_t(e->n_leg_fields) * e->n_slots * 8, e->stream));
+  HIP_TRY(hipMemsetAsync(e->st.legi, 0, size_t(e->n_slots) * 4, e->stream));
+  int64_t threads = e->n * e->L;
+  init_state_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(
+      e->st, d_legt, d_legw, d_robt, d_robi, e->L, e->n_leg_fields, RobotFields::COUNT, RobotFields::I_COUNT);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  (void)hipFree(d_legt);
+  (void)hipFree(d_robt);
+  (void)hipFree(d_legw);
+  (void)hipFree(d_robi);
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_create(const shc_params *params, int64_t n_instances, int device, void *stream, shc_engine **out) {
+  int L, NJ;
+  int rc = validate_params(params, &L, &NJ);
+  if (rc != SHC_OK) return rc;
+  if (!out || n_instances < 1) return fail(SHC_ERR_INVALID_ARG, "n_instances must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(SHC_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(SHC_ERR_INVALID_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  shc_engine *e = new shc_engine();
+  memset(static_cast<void *>(e), 0, sizeof *e);
+  e->params = *params;
+  e->L = L;
+  e->NJ = NJ;
+  e->device = device;
+  e->stream = (hipStream_t)stream;
+  e->n = n_instances;
+  e->features = SHC_FEAT_TIP_FORCE;
+  rc = shc_generate_tables(params, &e->tables);
+  if (rc != SHC_OK) {
+    delete e;
+    return rc;
+  }
+  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  const int rpw = 64 / L;
+  e->n_waves = (n_instances + rpw - 1) / rpw;
+  e->n_slots = e->n_waves * 64;
+  e->n_rob_pad = ((n_instances + 63) / 64) * 64;
+  e->n_leg_fields = NJ == 3 ? Fields<3>::COUNT : (NJ == 4 ? Fields<4>::COUNT : Fields<5>::COUNT);
+  e->st.n_slots = e->n_slots;
+  e->st.n_rob_pad = e->n_rob_pad;
+  e->st.n_robots = e->n;
+  HIP_TRY(hipMalloc(&e->st.legd, size_t(e->n_leg_fields) * e->n_slots * 8));
+  HIP_TRY(hipMalloc(&e->st.legi, size_t(e->n_slots) * 4));
+  HIP_TRY(hipMalloc(&e->st.robd, size_t(RobotFields::COUNT) * e->n_rob_pad * 8));
+  HIP_TRY(hipMalloc(&e->st.robi, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4));
+  e->stage_bytes = size_t(e->n) * L * (NJ > 3 ? NJ : 3) * 8 + size_t(e->n) * 8 * 8;
+  HIP_TRY(hipMalloc(&e->d_stage, e->stage_bytes));
+  rc = upload_consts(e);
+  if (rc == SHC_OK) rc = init_state(e);
+  // The reference's loop() that enters RUNNING also executes runningState() once with the (zero) inputs present at
+  // that moment (state_controller.cpp:277-281 then :189-192): the engine's initial state includes that cycle.
+  if (rc == SHC_OK) rc = shc_engine_step(e, 1);
+  if (rc == SHC_OK) rc = shc_engine_synchronize(e);
+  if (rc != SHC_OK) {
+    shc_engine_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_destroy(shc_engine *e) {
+  if (!e) return SHC_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipFree(e->st.legd);
+  (void)hipFree(e->st.legi);
+  (void)hipFree(e->st.robd);
+  (void)hipFree(e->st.robi);
+  (void)hipFree(e->d_consts);
+  (void)hipFree(e->d_stage);
+  delete e;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_set_stream(shc_engine *e, void *stream) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  e->stream = (hipStream_t)stream;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_set_features(shc_engine *e, uint32_t features) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  e->features = features;
+  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_get_tables(const shc_engine *e, shc_tables *out) {
+  if (!e || !out) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  *out = e->tables;
+  return SHC_OK;
+}
+
+extern "C" int64_t shc_engine_instances(const shc_engine *e) { return e ? e->n : 0; }
+
+// ---- input / output plumbing
+static int to_device(shc_engine *e, const double *src, size_t count, int on_device, const double **dptr) {
+  if (on_device) {
+    *dptr = src;
+    return SHC_OK;
+  }
+  if (count * 8 > e->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
+  HIP_TRY(hipMemcpyAsync(e->d_stage, src, count * 8, hipMemcpyHostToDevice, e->stream));
+  *dptr = e->d_stage;
+  return SHC_OK;
+}
+
+static int scatter_rob(shc_engine *e, const double *src, int K, int f0, int on_device, int normalize_quat = 0) {
+  if (!src) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const double *d;
+  int rc = to_device(e, src, size_t(e->n) * K, on_device, &d);
+  if (rc != SHC_OK) return rc;
+  scatter_rob_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robd, e->n_rob_pad, e->n, K, f0,
+                                                                                      normalize_quat);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) HIP_TRY(hipStreamSynchronize(e->stream)); // the staging buffer is reused by the next call
+  return SHC_OK;
+}
+
+static int scatter_leg(shc_engine *e, const double *src, int K, int f0, int on_device) {
+  if (!src) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const double *d;
+  int rc = to_device(e, src, size_t(e->n) * e->L * K, on_device, &d);
+  if (rc != SHC_OK) return rc;
+  int64_t threads = e->n * e->L;
+  scatter_leg_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.legd, e->n_slots, e->n, e->L, K, f0);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
+}
+
+static int gather_leg(shc_engine *e, double *dst, int K, int f0, int on_device) {
+  if (!dst) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  int64_t threads = e->n * e->L;
+  double *d = on_device ? dst : e->d_stage;
+  gather_leg_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.legd, e->n_slots, e->n, e->L, K, f0);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) {
+    HIP_TRY(hipMemcpyAsync(dst, d, size_t(threads) * K * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return SHC_OK;
+}
+
+static int gather_rob(shc_engine *e, double *dst, int K, int f0, int on_device) {
+  if (!dst) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  double *d = on_device ? dst : e->d_stage;
+  gather_rob_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robd, e->n_rob_pad, e->n, K, f0);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) {
+    HIP_TRY(hipMemcpyAsync(dst, d, size_t(e->n) * K * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return SHC_OK;
+}
+
+#define LEG_FIELD(e, NAME) ((e)->NJ == 3 ? Fields<3>::NAME : ((e)->NJ == 4 ? Fields<4>::NAME : Fields<5>::NAME))
+
+extern "C" int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, const double *angular, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc = scatter_rob(e, linear_xy, 2, RobotFields::VIN, on_device);
+  if (rc != SHC_OK) return rc;
+  return scatter_rob(e, angular, 1, RobotFields::WIN, on_device);
+}
+
+extern "C" int shc_engine_set_imu(shc_engine *e, const double *orientation_wxyz, const double *angular_velocity, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc = scatter_rob(e, orientation_wxyz, 4, RobotFields::IMUQ, on_device, 1);
+  if (rc != SHC_OK) return rc;
+  return scatter_rob(e, angular_velocity, 3, RobotFields::GYRO, on_device);
+}
+
+extern "C" int shc_engine_set_tip_force(shc_engine *e, const double *tip_force, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  return scatter_leg(e, tip_force, 3, LEG_FIELD(e, FORCE_IN), on_device);
+}
+
+extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  return scatter_leg(e, joint_effort, e->NJ, LEG_FIELD(e, EFFORT_IN), on_device);
+}
+
+extern "C" int shc_engine_set_pose_input(shc_engine *e, const double *translation_velocity, const double *rotation_velocity,
+                                         int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc = scatter_rob(e, translation_velocity, 3, RobotFields::TVI, on_device);
+  if (rc != SHC_OK) return rc;
+  return scatter_rob(e, rotation_velocity, 3, RobotFields::RVI, on_device);
+}
+
+extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (n_cycles < 1) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  // 256-thread workgroups (4 waves share one LDS copy of the tables); small batches use 64-thread groups to reach more CUs
+  const int block = (e->n_waves >= 1024) ? 256 : 64;
+  const int64_t waves_per_block = block / 64;
+  const unsigned grid = (unsigned)((e->n_waves + waves_per_block - 1) / waves_per_block);
+#define CALL(L_, NJ_)                                                                                                    \
+  shc_cycle_kernel<L_, NJ_><<<dim3(grid), dim3(block), 0, e->stream>>>(e->st, e->cp,                                     \
+                                                                       (const SharedConsts<L_, NJ_> *)e->d_consts, n_cycles)
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_synchronize(shc_engine *e) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_get_joint_state(shc_engine *e, double *q, double *qd, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc = gather_leg(e, q, e->NJ, LEG_FIELD(e, Q), on_device);
+  if (rc != SHC_OK) return rc;
+  return gather_leg(e, qd, e->NJ, LEG_FIELD(e, QD), on_device);
+}
+
+extern "C" int shc_engine_joint_buffer(shc_engine *e, double **device_ptr, int64_t *n_doubles) {
+  if (!e || !device_ptr || !n_doubles) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  *device_ptr = e->st.legd; // fields Q0..Q(NJ-1) are the first NJ planes of the leg state
+  *n_doubles = int64_t(e->NJ) * e->n_slots;
+  return SHC_OK;
+}
+
+extern "C" int64_t shc_engine_joint_index(const shc_engine *e, int64_t instance, int leg, int joint) {
+  if (!e) return -1;
+  int rpw = 64 / e->L;
+  int64_t w = instance / rpw;
+  int gi = int(instance - w * rpw);
+  return int64_t(joint) * e->n_slots + w * 64 + gi * e->L + leg;
+}
+
+extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, double *poser_tip, double *model_tip, double *tip_force,
+                                        double *admittance, int32_t *leg_status, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc;
+  if ((rc = gather_leg(e, walker_tip, 3, LEG_FIELD(e, TIP), on_device)) != SHC_OK) return rc;
+  if ((rc = gather_leg(e, poser_tip, 3, LEG_FIELD(e, POSER_TIP), on_device)) != SHC_OK) return rc;
+  if ((rc = gather_leg(e, model_tip, 3, LEG_FIELD(e, MODEL_TIP), on_device)) != SHC_OK) return rc;
+  if ((rc = gather_leg(e, tip_force, 3, LEG_FIELD(e, TF), on_device)) != SHC_OK) return rc;
+  if ((rc = gather_leg(e, admittance, 3, LEG_FIELD(e, ADM_DELTA), on_device)) != SHC_OK) return rc;
+  if (leg_status) {
+    HIP_TRY(hipSetDevice(e->device));
+    int64_t threads = e->n * e->L;
+    int32_t *d = on_device ? leg_status : reinterpret_cast<int32_t *>(e->d_stage);
+    gather_leg_status_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.legi, e->n, e->L);
+    HIP_TRY(hipGetLastError());
+    if (!on_device) {
+      HIP_TRY(hipMemcpyAsync(leg_status, d, size_t(threads) * 4, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+  }
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc;
+  if ((rc = gather_rob(e, pose, 7, RobotFields::CPOSE, on_device)) != SHC_OK) return rc;
+  if ((rc = gather_rob(e, velocity, 3, RobotFields::VLIN, on_device)) != SHC_OK) return rc;
+  if (walk_state) {
+    HIP_TRY(hipSetDevice(e->device));
+    int32_t *d = on_device ? walk_state : reinterpret_cast<int32_t *>(e->d_stage);
+    gather_walk_state_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robi, e->n);
+    HIP_TRY(hipGetLastError());
+    if (!on_device) {
+      HIP_TRY(hipMemcpyAsync(walk_state, d, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+  }
+  return SHC_OK;
+}

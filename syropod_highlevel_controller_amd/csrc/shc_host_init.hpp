@@ -1,0 +1,353 @@
+// shc_host_init.hpp — host-side init chain of the engine (product code; shares shc_leg.hpp with the HIP kernels;
+// the CPU oracle has its own, independent restatement).
+//
+// Produces the per-(morphology, gait) tables the cycle kernel consumes.  Reference chain restated
+// (OpenSHC v0.5.11):
+//   WalkController::generateStepCycle          src/walk_controller.cpp:365-410
+//   PoseController::directStartup              src/pose_controller.cpp:463-517  (LegPoser::stepToPosition :1571-1712)
+//   Model::updateDefaultConfiguration          src/model.cpp:108, :593
+//   Leg::generateWorkspace (simple workspace)  src/model.cpp:309-510
+//   WalkController::generateWalkspace          src/walk_controller.cpp:57-227
+//   WalkController::generateLimits             src/walk_controller.cpp:231-361
+//   PoseController::setAutoPoseParams          src/pose_controller.cpp:44-106
+//   AdmittanceController::updateAdmittance     src/admittance_controller.cpp:22-63 (collapsed to an affine map)
+#pragma once
+
+#include "../../include/shc_batch.h"
+#include "shc_leg.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace shc {
+namespace hostinit {
+
+constexpr int kBearingStep = 45;          // model.h:22
+constexpr double kMaxPositionDelta = 0.002; // model.h:23
+constexpr double kMaxWorkspaceRadius = 1.0; // model.h:24
+constexpr int kWorkspaceLayers = 10;      // model.h:25
+
+template <int NJ>
+inline void fill_leg_const(const shc_params &p, int l, LegConst<NJ> &lc) {
+  std::memset(&lc, 0, sizeof lc);
+  const shc_link_params &b = p.link[l][0];
+  // createDHMatrix (standard_includes.h:466) of the base link: joint 1's constant transform
+  double ct = cos(b.theta), st = sin(b.theta), ca = cos(b.alpha), sa = sin(b.alpha);
+  lc.r1[0] = ct; lc.r1[1] = -st * ca; lc.r1[2] = st * sa;
+  lc.r1[3] = st; lc.r1[4] = ct * ca;  lc.r1[5] = -ct * sa;
+  lc.r1[6] = 0;  lc.r1[7] = sa;       lc.r1[8] = ca;
+  lc.p1[0] = b.r * ct; lc.p1[1] = b.r * st; lc.p1[2] = b.d;
+  for (int k = 0; k < NJ; ++k) {
+    const shc_link_params &lk = p.link[l][k + 1];
+    lc.link_d[k] = lk.d;
+    lc.link_r[k] = lk.r;
+    lc.link_sa[k] = sin(lk.alpha);
+    lc.link_ca[k] = cos(lk.alpha);
+    lc.link_th[k] = lk.theta;
+    const shc_joint_params &j = p.joint[l][k];
+    lc.jmin[k] = j.min;
+    lc.jmax[k] = j.max;
+    lc.jvmax[k] = j.max_vel;
+    double range = j.max - j.min;
+    lc.jcentre[k] = j.min + range / 2.0;
+    lc.jw_range[k] = range != 0.0 ? kJointLimitCostWeight / range : 0.0;
+    lc.jw_vrange[k] = kJointLimitCostWeight / (2 * j.max_vel);
+  }
+  lc.stance_x = p.stance_position[l][0];
+  lc.stance_y = p.stance_position[l][1];
+}
+
+// 30 classical RK4 steps (h = integrator_step_time / 30) of  x' = A x + b u,  A = [[0,1],[-k/m,-c/m]], b = [0,-1/m]
+// are one affine map x <- M x + g u, because u is constant during the call (admittance_controller.cpp:33-52).
+inline void admittance_map(const shc_params &p, double &m00, double &m01, double &m10, double &m11, double &g0, double &g1) {
+  typedef long double ld;
+  ld mass = p.virtual_mass, k = p.virtual_stiffness;
+  ld c = (ld)p.virtual_damping_ratio * 2 * sqrtl(mass * k);
+  ld h = (ld)p.integrator_step_time / 30;
+  ld A[2][2] = {{0, 1}, {-k / mass, -c / mass}};
+  ld H[2][2] = {{h * A[0][0], h * A[0][1]}, {h * A[1][0], h * A[1][1]}};
+  auto mul = [](const ld (&x)[2][2], const ld (&y)[2][2], ld (&z)[2][2]) {
+    ld t[2][2];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) t[i][j] = x[i][0] * y[0][j] + x[i][1] * y[1][j];
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) z[i][j] = t[i][j];
+  };
+  ld H2[2][2], H3[2][2], H4[2][2];
+  mul(H, H, H2);
+  mul(H2, H, H3);
+  mul(H3, H, H4);
+  ld P[2][2], S[2][2]; // P = I + H + H^2/2 + H^3/6 + H^4/24 ; S = I + H/2 + H^2/6 + H^3/24
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j) {
+      ld I = i == j ? 1 : 0;
+      P[i][j] = I + H[i][j] + H2[i][j] / 2 + H3[i][j] / 6 + H4[i][j] / 24;
+      S[i][j] = I + H[i][j] / 2 + H2[i][j] / 6 + H3[i][j] / 24;
+    }
+  ld bvec[2] = {0, -1 / mass};
+  ld g1v[2] = {h * (S[0][0] * bvec[0] + S[0][1] * bvec[1]), h * (S[1][0] * bvec[0] + S[1][1] * bvec[1])};
+  ld M[2][2] = {{1, 0}, {0, 1}}, G[2] = {0, 0};
+  for (int s = 0; s < 30; ++s) { // x_{n+1} = P x_n + g1 u
+    ld ng0 = P[0][0] * G[0] + P[0][1] * G[1] + g1v[0], ng1 = P[1][0] * G[0] + P[1][1] * G[1] + g1v[1];
+    G[0] = ng0;
+    G[1] = ng1;
+    mul(P, M, M);
+  }
+  m00 = (double)M[0][0]; m01 = (double)M[0][1]; m10 = (double)M[1][0]; m11 = (double)M[1][1];
+  g0 = (double)G[0]; g1 = (double)G[1];
+}
+
+inline shc_step_cycle generate_step_cycle(const shc_params &p) {
+  shc_step_cycle s;
+  s.stance_end = int(p.stance_phase * 0.5);
+  s.swing_start = s.stance_end;
+  s.swing_end = s.swing_start + p.swing_phase;
+  s.stance_start = s.swing_end;
+  int base = p.stance_phase + p.swing_phase;
+  double swing_ratio = double(p.swing_phase) / double(base);
+  double raw = ((1.0 / p.step_frequency) / p.time_delta) / swing_ratio;
+  s.period = round_to_even_int(raw / base) * base;
+  s.frequency = 1.0 / (s.period * p.time_delta);
+  int normaliser = s.period / base;
+  s.stance_end *= normaliser;
+  s.swing_start *= normaliser;
+  s.swing_end *= normaliser;
+  s.stance_start *= normaliser;
+  s.stance_period = mod_i(s.stance_end - s.stance_start, s.period);
+  s.swing_period = s.swing_end - s.swing_start;
+  return s;
+}
+
+// A leg being driven by single DLS steps on the host (start-up solve and workspace search).
+template <int NJ>
+struct HostLeg {
+  LegConst<NJ> lc;
+  double q[NJ], qd[NJ], dflt[NJ];
+  Chain<NJ> ch;
+  V3 tip; // robot frame
+  void fk() {
+    fk_chain<NJ>(lc, q, ch);
+    tip = tip_robot_frame(lc, ch.pe);
+  }
+  void reset_to_default() { // Leg::init(true) (model.cpp:286-305)
+    for (int j = 0; j < NJ; ++j) {
+      q[j] = dflt[j];
+      qd[j] = 0.0;
+    }
+    fk();
+  }
+  // Leg::applyIK(simulation = true) towards `desired` (model.cpp:861-941); returns the ik result
+  double ik(V3 desired, const shc_params &p) {
+    double dq[NJ];
+    ik_step<NJ>(lc, ch, q, qd, desired, dq);
+    double prox = update_joints<NJ>(lc, dq, p.time_delta, false, p.clamp_joint_positions != 0, q, qd);
+    fk();
+    V3 e = tip - desired;
+    if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) return 0.0;
+    return prox;
+  }
+};
+
+// PoseController::directStartup's simulated solve for one leg: LegPoser::stepToPosition (lift 0, time_to_start)
+// towards the default tip pose with the body easing to `body` + one DLS step per iteration.
+template <int NJ>
+inline void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip, const Pose &body) {
+  leg.reset_to_default();
+  V3 origin = leg.tip;
+  V3 delta = origin - inverse_transform_vector(body, default_tip);
+  if (!(norm(delta) > kTipTolerance)) return; // already there (pose_controller.cpp:1603-1608)
+  int num = std::max(1, round_to_int(p.time_to_start / p.time_delta));
+  double dt = 1.0 / num;
+  int half = num / 2;
+  V3 o2t = origin - default_tip;
+  V3 prim[5] = {origin, origin, origin, default_tip + o2t * 0.75, default_tip + o2t * 0.5};
+  V3 sec[5] = {default_tip + o2t * 0.5, default_tip + o2t * 0.25, default_tip, default_tip, default_tip};
+  for (int it = 1; it <= num; ++it) {
+    double ratio = double(it - 1) / double(num);
+    Pose dp = interpolate_pose(pose_identity(), smooth_step(ratio), body);
+    int sic = (it + (num - 1)) % num + 1;
+    V3 np = sic <= half ? quartic_bezier(prim, sic * dt * 2.0) : quartic_bezier(sec, (sic - half) * dt * 2.0);
+    leg.ik(inverse_transform_vector(dp, np), p);
+  }
+}
+
+// Leg::generateWorkspace, simple (single plane z = 0) workspace.  radius[b], b = bearing / 45.
+template <int NJ>
+inline void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS]) {
+  leg.reset_to_default();
+  if (norm(identity_tip_body - leg.tip) > kIkTolerance) { // model.cpp:349-353
+    for (double &r : radius) r = 0.0;
+    return;
+  }
+  for (double &r : radius) r = kMaxWorkspaceRadius;
+  // track from the default-configuration tip to the identity tip position (model.cpp:397-404), then re-base defaults
+  {
+    int n = std::max(1, round_to_int((kMaxWorkspaceRadius / kWorkspaceLayers) / kMaxPositionDelta));
+    V3 o = leg.tip, t = identity_tip_body;
+    bool ok = true;
+    for (int it = 1; it <= n && ok; ++it) {
+      double i = double(it) / n;
+      ok = leg.ik(o * (1.0 - i) + t * i, p) != 0.0;
+    }
+    for (int j = 0; j < NJ; ++j) leg.dflt[j] = leg.q[j]; // updateDefaultConfiguration (model.cpp:465)
+  }
+  for (int bearing = kBearingStep; bearing <= 360; bearing += kBearingStep) {
+    leg.reset_to_default();
+    int n = round_to_int(kMaxWorkspaceRadius / kMaxPositionDelta);
+    V3 o = identity_tip_body, t = o;
+    t.x += kMaxWorkspaceRadius * cos(deg2rad(bearing));
+    t.y += kMaxWorkspaceRadius * sin(deg2rad(bearing));
+    for (int it = 1; it <= n; ++it) {
+      double i = double(it) / n;
+      if (leg.ik(o * (1.0 - i) + t * i, p) == 0.0) break;
+    }
+    radius[bearing / kBearingStep] = norm(leg.tip - identity_tip_body);
+  }
+  radius[0] = radius[360 / kBearingStep];
+}
+
+inline V3 rot_z(double ang, V3 v) { // Eigen::AngleAxisd(ang, UnitZ) * v
+  double s = sin(ang), c = cos(ang);
+  return V3{c * v.x - s * v.y, s * v.x + c * v.y, v.z};
+}
+inline V3 set_precision3(V3 v) { // setPrecision(vector, 3) (standard_includes.h:152)
+  return V3{round_to_int(v.x * pow(10, 3)) / pow(10, 3), round_to_int(v.y * pow(10, 3)) / pow(10, 3),
+            round_to_int(v.z * pow(10, 3)) / pow(10, 3)};
+}
+
+// WalkController::generateWalkspace with default tip == identity tip for every leg (true right after start-up)
+inline void generate_walkspace(const shc_params &p, const double (*workspace)[SHC_N_BEARINGS], double (&walkspace)[SHC_N_BEARINGS]) {
+  const int L = p.leg_count;
+  bool have[SHC_N_BEARINGS] = {false};
+  for (int l = 0; l < L; ++l) {
+    int l1 = mod_i(l + 1, L), l2 = mod_i(l - 1, L);
+    V3 d{p.stance_position[l][0], p.stance_position[l][1], 0.0};
+    V3 a1{p.stance_position[l1][0], p.stance_position[l1][1], 0.0}, a2{p.stance_position[l2][0], p.stance_position[l2][1], 0.0};
+    double dist1 = norm(d - a1) / 2.0, dist2 = norm(d - a2) / 2.0;
+    double b1 = rad2deg(atan2(a1.y - d.y, a1.x - d.x)), b2 = rad2deg(atan2(a2.y - d.y, a2.x - d.x));
+    for (int bearing = 0; bearing <= 360; bearing += kBearingStep) {
+      int diff1 = std::abs(mod_i(int(b1), 360) - bearing), diff2 = std::abs(mod_i(int(b2), 360) - bearing);
+      double o1 = kUnassigned, o2 = kUnassigned;
+      if ((diff1 < 90 || diff1 > 270) && dist1 > 0.0) o1 = dist1 / cos(deg2rad(diff1));
+      if ((diff2 < 90 || diff2 > 270) && dist2 > 0.0) o2 = dist2 / cos(deg2rad(diff2));
+      double md = p.overlapping_walkspaces ? kMaxWorkspaceRadius : std::min(o1, o2);
+      md = std::min(md, kMaxWorkspaceRadius);
+      int bi = bearing / kBearingStep;
+      if (!have[bi]) {
+        walkspace[bi] = md;
+        have[bi] = true;
+      } else if (md < walkspace[bi]) {
+        walkspace[bi] = md;
+      }
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    for (int bi = 0; bi < SHC_N_BEARINGS; ++bi) {
+      double radius = workspace[l][bi]; // default shift is zero: radius = workplane.at(bearing) (walk_controller.cpp:137-140)
+      int opposite = mod_i(bi * kBearingStep + 180, 360) / kBearingStep;
+      if (radius < walkspace[bi]) {
+        walkspace[bi] = radius;
+        walkspace[opposite] = radius;
+      }
+    }
+  }
+  walkspace[360 / kBearingStep] = walkspace[0];
+}
+
+inline void generate_limits(const shc_params &p, shc_tables &t) {
+  const shc_step_cycle &step = t.step;
+  const int L = p.leg_count;
+  int base = p.stance_phase + p.swing_phase;
+  int normaliser = step.period / base;
+  int base_offset = int(p.phase_offset * normaliser);
+  int max_ext = 0;
+  for (int l = 0; l < L; ++l) {
+    int off = (base_offset * p.offset_multiplier[l]) % step.period;
+    t.phase_offset[l] = off;
+    if (off > step.swing_start && off < step.swing_end) max_ext = std::max(max_ext, step.swing_end - off);
+  }
+  double time_to_max_stride = (max_ext + step.stance_period + step.swing_period) * p.time_delta;
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) {
+    double wr = t.walkspace[b];
+    double ogr = double(step.stance_period) / step.period;
+    double max_speed = (wr * 2.0) / (ogr / step.frequency);
+    double max_acc = max_speed / time_to_max_stride;
+    double overshoot = 0;
+    for (int l = 0; l < L; ++l) {
+      double off = t.phase_offset[l];
+      double tt = off * p.time_delta;
+      double tse = time_to_max_stride - tt;
+      double v0 = max_acc * tse;
+      double stride_length = v0 * (ogr / step.frequency);
+      double d0 = -stride_length / 2.0;
+      double d1 = d0 + v0 * tt + 0.5 * max_acc * (tt * tt);
+      double d2 = max_speed * (step.stance_period * p.time_delta - tt);
+      overshoot = std::max(overshoot, d1 + d2 - wr);
+    }
+    double swing_overshoot = 0.5 * max_speed * step.swing_period / (2.0 * step.period * step.frequency);
+    double scaled = (wr / (wr + overshoot + swing_overshoot)) * wr;
+    double sx = p.stance_position[0][0], sy = p.stance_position[0][1];
+    double stance_radius = sqrt(sx * sx + sy * sy);
+    double mls = (scaled * 2.0) / (ogr / step.frequency);
+    double mla = mls / time_to_max_stride;
+    double mas = mls / stance_radius;
+    double maa = mas / time_to_max_stride;
+    if (wr == 0.0) {
+      mls = 0.0;
+      mla = kUnassigned;
+      mas = 0.0;
+      maa = kUnassigned;
+    }
+    t.max_linear_speed[b] = mls;
+    t.max_linear_acceleration[b] = mla;
+    t.max_angular_speed[b] = mas;
+    t.max_angular_acceleration[b] = maa;
+  }
+}
+
+template <int NJ>
+inline bool generate_tables(const shc_params &p, shc_tables &t) {
+  std::memset(&t, 0, sizeof t);
+  t.step = generate_step_cycle(p);
+  if (t.step.period <= 0 || t.step.stance_period <= 0 || t.step.swing_period <= 0) return false;
+  // auto-pose phase length / normaliser (pose_controller.cpp:44-63) and reference leg (:75-78)
+  {
+    int base;
+    double raw;
+    if (p.pose_frequency == -1.0) {
+      base = p.stance_phase + p.swing_phase;
+      double swing_ratio = double(p.swing_phase) / base;
+      raw = ((1.0 / p.step_frequency) / p.time_delta) / swing_ratio;
+    } else {
+      base = p.pose_phase_length;
+      raw = ((1.0 / p.pose_frequency) / p.time_delta);
+    }
+    if (base <= 0) base = 1;
+    t.pose_phase_length = round_to_even_int(raw / base) * base;
+    t.pose_normaliser = t.pose_phase_length / base;
+    t.auto_pose_reference_leg = 0;
+    for (int l = 0; l < p.leg_count; ++l)
+      if (p.offset_multiplier[l] == 0) t.auto_pose_reference_leg = l;
+  }
+  // body pose during start-up and workspace generation: walk-plane pose (0, 0, body_clearance), no rotation
+  Pose body{V3{0, 0, p.body_clearance}, quat_identity()};
+  for (int l = 0; l < p.leg_count; ++l) {
+    HostLeg<NJ> leg;
+    fill_leg_const<NJ>(p, l, leg.lc);
+    for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, p.joint[l][j].min, p.joint[l][j].max); // model.cpp:1038
+    V3 default_tip{p.stance_position[l][0], p.stance_position[l][1], 0.0};
+    startup_solve<NJ>(p, leg, default_tip, body);
+    for (int j = 0; j < NJ; ++j) {
+      leg.dflt[j] = leg.q[j]; // Model::updateDefaultConfiguration
+      t.default_joint_position[l][j] = leg.q[j];
+    }
+    generate_workspace<NJ>(p, leg, inverse_transform_vector(body, default_tip), t.workspace_radius[l]);
+  }
+  generate_walkspace(p, t.workspace_radius, t.walkspace);
+  generate_limits(p, t);
+  return true;
+}
+
+} // namespace hostinit
+} // namespace shc

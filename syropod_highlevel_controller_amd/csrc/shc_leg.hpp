@@ -1,0 +1,171 @@
+// shc_leg.hpp — per-leg kinematics: DH forward kinematics, geometric Jacobian, one damped-least-squares IK
+// step, joint integration / clamping, tip-force estimate.  Host + device (the HIP cycle kernel and the host
+// init chain share this code; the CPU oracle does not).
+//
+// Reference behaviour restated (src/model.cpp of OpenSHC v0.5.11):
+//   Leg::applyFK :945-988, Leg::solveIK :726-795, Leg::updateJointPositions :799-857, Leg::applyIK :861-941,
+//   Leg::calculateTipForce :667-708; frames per model.h:594-617 (Jacobian and position delta live in the
+//   joint-1 frame; joint 1's transform is the constant base-link DH matrix).
+//
+// MI355X-first formulation (mathematically identical to the reference's, different arithmetic):
+//   reference:  dq = J^T (J J^T + l^2 I6)^-1 d  +  (I - J^+ J) g      with a dynamic 6x6 LU inverse
+//   here:       dq = (Jp^T Jp + l^2 I_N)^-1 (Jp^T d_p + l^2 g)         one N x N SPD solve in registers
+//   (push-through identity; in position-only mode the angular rows of J are zero, so J^T J = Jp^T Jp,
+//    and I - J^+ J = l^2 (J^T J + l^2 I)^-1.)  Differences are at rounding level (~1e-13 rad).
+#pragma once
+
+#include "shc_math.hpp"
+
+namespace shc {
+
+// Per-leg constant record.  Plain doubles/ints so it can be staged verbatim in LDS.
+template <int NJ>
+struct LegConst {
+  double r1[9];       // rotation of the base transform T1 = DH(base link)  (row-major)
+  double p1[3];       // translation of T1
+  double link_d[NJ], link_r[NJ], link_sa[NJ], link_ca[NJ], link_th[NJ]; // links 1..NJ (link k actuated by joint k)
+  double jmin[NJ], jmax[NJ], jvmax[NJ];
+  double jcentre[NJ];  // min + (max - min) / 2                       (model.cpp:771)
+  double jw_range[NJ]; // JOINT_LIMIT_COST_WEIGHT / (max - min), 0 if the range is 0   (model.cpp:772-778)
+  double jw_vrange[NJ]; // JOINT_LIMIT_COST_WEIGHT / (2 max_vel)      (model.cpp:781-786)
+  double stance_x, stance_y; // identity tip position (walk_controller.cpp:34-35)
+  double neg_ratio;          // negation_transition_ratio
+  int32_t phase_offset;      // walk_controller.cpp:277
+  int32_t neg_start, neg_end; // pose negation phases (already * normaliser, 0 -> phase length; pose_controller.cpp:1718-1731)
+  int32_t first_stance_period;     // modified stance period of the first step (walk_controller.cpp:1026-1031)
+  int32_t first_stance_iterations; // int((msp / period) / (frequency * dt))   (walk_controller.cpp:1040)
+  int32_t starts_in_swing;         // phase_offset strictly inside the swing window (walk_controller.cpp:587-588)
+};
+
+template <int NJ>
+struct Chain {
+  V3 z[NJ]; // joint axes in the joint-1 frame (z[0] = (0,0,1))
+  V3 p[NJ]; // joint origins in the joint-1 frame (p[0] = 0)
+  V3 pe;    // tip position in the joint-1 frame
+  V3 xe;    // tip x-axis in the joint-1 frame
+};
+
+// Leg::applyFK chain product in the joint-1 frame.
+template <int NJ, class LC>
+SHC_HD void fk_chain(const LC &lc, const double (&q)[NJ], Chain<NJ> &c) {
+  V3 X{1, 0, 0}, Y{0, 1, 0}, Z{0, 0, 1}, P{0, 0, 0};
+  c.z[0] = Z;
+  c.p[0] = P;
+#pragma unroll
+  for (int k = 0; k < NJ; ++k) {
+    double s, co;
+    sincos(lc.link_th[k] + q[k], &s, &co);
+    double sa = lc.link_sa[k], ca = lc.link_ca[k];
+    V3 Xn = X * co + Y * s;
+    V3 t = Y * co - X * s;
+    V3 Yn = t * ca + Z * sa;
+    V3 Zn = Z * ca - t * sa;
+    P = P + Xn * lc.link_r[k] + Z * lc.link_d[k];
+    X = Xn;
+    Y = Yn;
+    Z = Zn;
+    if (k + 1 < NJ) {
+      c.z[k + 1] = Z;
+      c.p[k + 1] = P;
+    }
+  }
+  c.pe = P;
+  c.xe = X;
+}
+
+template <class LC>
+SHC_HD V3 base_rotate(const LC &lc, V3 v) { // R1 * v
+  return V3{lc.r1[0] * v.x + lc.r1[1] * v.y + lc.r1[2] * v.z, lc.r1[3] * v.x + lc.r1[4] * v.y + lc.r1[5] * v.z,
+            lc.r1[6] * v.x + lc.r1[7] * v.y + lc.r1[8] * v.z};
+}
+template <class LC>
+SHC_HD V3 base_rotate_inv(const LC &lc, V3 v) { // R1^T * v
+  return V3{lc.r1[0] * v.x + lc.r1[3] * v.y + lc.r1[6] * v.z, lc.r1[1] * v.x + lc.r1[4] * v.y + lc.r1[7] * v.z,
+            lc.r1[2] * v.x + lc.r1[5] * v.y + lc.r1[8] * v.z};
+}
+template <class LC>
+SHC_HD V3 tip_robot_frame(const LC &lc, V3 pe) { // T1 * pe
+  return base_rotate(lc, pe) + V3{lc.p1[0], lc.p1[1], lc.p1[2]};
+}
+
+// One DLS step towards `desired` (robot frame): Leg::applyIK :864-877 + solveIK with solve_rotation = false.
+template <int NJ, class LC>
+SHC_HD void ik_step(const LC &lc, const Chain<NJ> &c, const double (&q)[NJ], const double (&qd)[NJ], V3 desired,
+                    double (&dq)[NJ]) {
+  // position delta in the joint-1 frame: T1^-1 desired - T1^-1 current
+  V3 delta = base_rotate_inv(lc, desired - V3{lc.p1[0], lc.p1[1], lc.p1[2]}) - c.pe;
+  V3 lin[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) lin[i] = cross(c.z[i], c.pe - c.p[i]);
+  // joint-limit cost gradient (model.cpp:759-790)
+  double pg[NJ], vg[NJ];
+  double pcost = 0.0, vcost = 0.0;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    double e = (q[i] - lc.jcentre[i]) * lc.jw_range[i];
+    pcost += e * e;
+    pg[i] = -e * lc.jw_range[i];
+    double v = qd[i] * lc.jw_vrange[i];
+    vcost += v * v;
+    vg[i] = -v * lc.jw_vrange[i];
+  }
+  double ps = pcost == 0.0 ? 0.0 : 1.0 / sqrt(pcost);
+  double vs = vcost == 0.0 ? 0.0 : 1.0 / sqrt(vcost);
+  const double l2 = kDls * kDls;
+  double a[NJ][NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]);
+    a[i][i] += l2;
+    double g = 0.25 * (pg[i] * ps) + 0.75 * (vg[i] * vs);
+    dq[i] = dot(lin[i], delta) + l2 * g;
+  }
+  spd_solve<NJ>(a, dq);
+}
+
+// Leg::updateJointPositions (model.cpp:799-857).  Returns the minimum limit proximity.
+template <int NJ, class LC>
+SHC_HD double update_joints(const LC &lc, const double (&dq)[NJ], double dt, bool clamp_vel, bool clamp_pos, double (&q)[NJ],
+                            double (&qd)[NJ]) {
+  double prox = 1.0;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    double v = dq[i] / dt;
+    if (clamp_vel && fabs(v) > lc.jvmax[i]) v = clampd(v, -lc.jvmax[i], lc.jvmax[i]);
+    double nq = q[i] + v * dt;
+    if (clamp_pos) {
+      if (nq < lc.jmin[i]) nq = lc.jmin[i];
+      else if (nq > lc.jmax[i]) nq = lc.jmax[i];
+    }
+    qd[i] = v;
+    q[i] = nq;
+    double half = (lc.jmax[i] - lc.jmin[i]) / 2.0;
+    double lp = half != 0 ? fmin(fabs(lc.jmin[i] - nq), fabs(lc.jmax[i] - nq)) / half : 1.0;
+    prox = fmin(lp, prox);
+  }
+  return prox;
+}
+
+// Leg::calculateTipForce (model.cpp:667-708): raw force in the robot frame (before the low-pass filter).
+template <int NJ, class LC>
+SHC_HD V3 tip_force_raw(const LC &lc, const Chain<NJ> &c, const double (&tau)[NJ]) {
+  V3 lin[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) lin[i] = cross(c.z[i], c.pe - c.p[i]);
+  double a[NJ][NJ], y[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + dot(c.z[i], c.z[j]);
+    a[i][i] += kDls * kDls;
+    y[i] = tau[i];
+  }
+  spd_solve<NJ>(a, y);
+  V3 f{0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) f = f + lin[i] * y[i];
+  return base_rotate_inv(lc, f);
+}
+
+} // namespace shc

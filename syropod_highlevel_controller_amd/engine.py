@@ -1,0 +1,219 @@
+"""ctypes binding of the C ABI (include/shc_batch.h, libshc_batch.so) — host-side mirror of the per-cycle call
+surface of the reference's StateController::loop for a batch of robots.
+
+Plumbing only: numpy arrays (host) or raw device pointers (e.g. ``torch.Tensor.data_ptr()``) go straight to the
+C entry points.  There is NO CPU fallback: creating an engine without a HIP device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import numpy as np
+
+from .params import Params, Tables
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libshc_batch.so")
+_SRC = os.path.join(_HERE, "csrc")
+_INC = os.path.join(os.path.dirname(_HERE), "include")
+
+SHC_OK, SHC_ERR_INVALID_ARG, SHC_ERR_NO_DEVICE, SHC_ERR_HIP, SHC_ERR_UNSUPPORTED, SHC_ERR_UNSTABLE = range(6)
+
+EXPORTED_SYMBOLS = [
+    "shc_abi_version", "shc_device_count", "shc_last_error", "shc_generate_tables", "shc_engine_create",
+    "shc_engine_destroy", "shc_engine_set_stream", "shc_engine_set_features", "shc_engine_get_tables",
+    "shc_engine_instances", "shc_engine_set_velocity", "shc_engine_set_imu", "shc_engine_set_tip_force",
+    "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_step", "shc_engine_synchronize",
+    "shc_engine_get_joint_state", "shc_engine_joint_buffer", "shc_engine_joint_index", "shc_engine_get_leg_state",
+    "shc_engine_get_body_state",
+]
+
+
+class ShcError(RuntimeError):
+    pass
+
+
+def _sources():
+    out = [os.path.join(_SRC, f) for f in sorted(os.listdir(_SRC)) if f.endswith((".hip", ".hpp"))]
+    out.append(os.path.join(_INC, "shc_batch.h"))
+    return out
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/shc_engine.hip for gfx950 into libshc_batch.so (in-tree).  hipcc cross-compiles without a GPU."""
+    if not force and os.path.exists(_SO) and all(os.path.getmtime(s) <= os.path.getmtime(_SO) for s in _sources()):
+        return _SO
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", _SO, os.path.join(_SRC, "shc_engine.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return _SO
+
+
+_lib = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def lib():
+    """Load libshc_batch.so (building it if the sources are newer)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build_library()
+        L = C.CDLL(_SO)
+        L.shc_last_error.restype = C.c_char_p
+        L.shc_generate_tables.argtypes = [C.POINTER(Params), C.POINTER(Tables)]
+        L.shc_engine_create.argtypes = [C.POINTER(Params), C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.shc_engine_destroy.argtypes = [C.c_void_p]
+        L.shc_engine_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.shc_engine_set_features.argtypes = [C.c_void_p, C.c_uint32]
+        L.shc_engine_get_tables.argtypes = [C.c_void_p, C.POINTER(Tables)]
+        L.shc_engine_instances.restype = C.c_int64
+        L.shc_engine_instances.argtypes = [C.c_void_p]
+        for name, n in (("shc_engine_set_velocity", 2), ("shc_engine_set_imu", 2), ("shc_engine_set_tip_force", 1),
+                        ("shc_engine_set_joint_effort", 1), ("shc_engine_set_pose_input", 2)):
+            getattr(L, name).argtypes = [C.c_void_p] + [C.c_void_p] * n + [C.c_int]
+        L.shc_engine_step.argtypes = [C.c_void_p, C.c_int]
+        L.shc_engine_synchronize.argtypes = [C.c_void_p]
+        L.shc_engine_get_joint_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_joint_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.shc_engine_joint_index.restype = C.c_int64
+        L.shc_engine_joint_index.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
+        L.shc_engine_get_leg_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int]
+        L.shc_engine_get_body_state.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != SHC_OK:
+        msg = lib().shc_last_error()
+        raise ShcError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def device_count() -> int:
+    return lib().shc_device_count()
+
+
+def generate_tables(params: Params) -> Tables:
+    """Host init chain of the product (start-up solve, workspace search, walkspace, limits)."""
+    t = Tables()
+    _check(lib().shc_generate_tables(C.byref(params), C.byref(t)), "shc_generate_tables")
+    return t
+
+
+def _host(a, dtype=np.float64):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchEngine:
+    """A batch of ``n`` robots of one morphology/gait advancing through control cycles on one MI355X."""
+
+    def __init__(self, params: Params, n: int, device: int = 0, stream: int = 0):
+        self.L = lib()
+        if self.L.shc_device_count() < 1:
+            raise ShcError("no HIP device visible: the batched engine has no CPU fallback")
+        self.params, self.n = params, int(n)
+        self.legs, self.dof = params.leg_count, params.leg_dof[0]
+        h = C.c_void_p()
+        _check(self.L.shc_engine_create(C.byref(params), self.n, device, C.c_void_p(stream), C.byref(h)), "shc_engine_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.shc_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration
+    def set_stream(self, stream: int):
+        _check(self.L.shc_engine_set_stream(self.h, C.c_void_p(stream)), "set_stream")
+
+    def set_features(self, features: int):
+        _check(self.L.shc_engine_set_features(self.h, features), "set_features")
+
+    def tables(self) -> Tables:
+        t = Tables()
+        _check(self.L.shc_engine_get_tables(self.h, C.byref(t)), "get_tables")
+        return t
+
+    # -- inputs (host numpy arrays)
+    def set_velocity(self, linear_xy=None, angular=None):
+        a, b = _host(linear_xy), _host(angular)
+        _check(self.L.shc_engine_set_velocity(self.h, _p(a), _p(b), 0), "set_velocity")
+
+    def set_imu(self, quat_wxyz=None, gyro=None):
+        a, b = _host(quat_wxyz), _host(gyro)
+        _check(self.L.shc_engine_set_imu(self.h, _p(a), _p(b), 0), "set_imu")
+
+    def set_tip_force(self, force):
+        a = _host(force)
+        _check(self.L.shc_engine_set_tip_force(self.h, _p(a), 0), "set_tip_force")
+
+    def set_joint_effort(self, effort):
+        a = _host(effort)
+        _check(self.L.shc_engine_set_joint_effort(self.h, _p(a), 0), "set_joint_effort")
+
+    def set_pose_input(self, translation_velocity=None, rotation_velocity=None):
+        a, b = _host(translation_velocity), _host(rotation_velocity)
+        _check(self.L.shc_engine_set_pose_input(self.h, _p(a), _p(b), 0), "set_pose_input")
+
+    # -- inputs (device pointers, e.g. torch tensors' data_ptr())
+    def set_velocity_device(self, linear_ptr: Optional[int], angular_ptr: Optional[int]):
+        _check(self.L.shc_engine_set_velocity(self.h, C.c_void_p(linear_ptr), C.c_void_p(angular_ptr), 1), "set_velocity")
+
+    # -- stepping
+    def step(self, n_cycles: int = 1):
+        _check(self.L.shc_engine_step(self.h, int(n_cycles)), "step")
+
+    def synchronize(self):
+        _check(self.L.shc_engine_synchronize(self.h), "synchronize")
+
+    # -- outputs
+    def joints(self):
+        q = np.zeros((self.n, self.legs * self.dof))
+        qd = np.zeros((self.n, self.legs * self.dof))
+        _check(self.L.shc_engine_get_joint_state(self.h, _p(q), _p(qd), 0), "get_joint_state")
+        return q, qd
+
+    def joints_device(self, q_ptr: Optional[int], qd_ptr: Optional[int]):
+        _check(self.L.shc_engine_get_joint_state(self.h, C.c_void_p(q_ptr), C.c_void_p(qd_ptr), 1), "get_joint_state")
+
+    def joint_buffer(self):
+        """(device pointer, n_doubles) of the engine's own SoA joint-position planes (the all-gather payload)."""
+        ptr, n = C.c_void_p(), C.c_int64()
+        _check(self.L.shc_engine_joint_buffer(self.h, C.byref(ptr), C.byref(n)), "joint_buffer")
+        return ptr.value, n.value
+
+    def joint_index(self, instance: int, leg: int, joint: int) -> int:
+        return self.L.shc_engine_joint_index(self.h, instance, leg, joint)
+
+    def leg_state(self):
+        out = {k: np.zeros((self.n, self.legs, 3)) for k in ("walker_tip", "poser_tip", "model_tip", "tip_force", "admittance")}
+        st = np.zeros((self.n, self.legs), dtype=np.int32)
+        _check(self.L.shc_engine_get_leg_state(self.h, _p(out["walker_tip"]), _p(out["poser_tip"]), _p(out["model_tip"]),
+                                               _p(out["tip_force"]), _p(out["admittance"]), _p(st), 0), "get_leg_state")
+        out["leg_status"] = st
+        return out
+
+    def body_state(self):
+        pose = np.zeros((self.n, 7))
+        vel = np.zeros((self.n, 3))
+        ws = np.zeros(self.n, dtype=np.int32)
+        _check(self.L.shc_engine_get_body_state(self.h, _p(pose), _p(vel), _p(ws), 0), "get_body_state")
+        return pose, vel, ws
