@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py — control-cycles/sec of the batched leg-control hot path on MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ...`` (one rank per GPU, RCCL).  Rank 0 prints ONE JSON line.
+
+* metric / unit: BASELINE.json's ``control-cycles/sec (all legs IK-solved)``.
+* workload (N = 1): BASELINE.json configs[1] — 4 096 default.yaml hexapods (6 legs x 3 DOF), tripod gait, the full
+  per-cycle path (velocity limiting + walk FSM + Bezier tip trajectory + body pose + per-leg DLS IK/FK + tip-force
+  estimate), synthetic seeded velocity commands, every instance MOVING and de-phased before the timed region.
+* a "step" = one launch of the fused cycle kernel = ``--cycles-per-step`` control cycles (default 1) of every
+  instance; inputs are resident in HBM (no host traffic inside the timed region).
+* N > 1: weak scaling — every rank owns ``--instances`` robots of its own (instance ranges are contiguous per rank),
+  no data-path collective while stepping; the final joint-state buffer is all-gathered over RCCL inside the timed
+  region (every ``--gather-every`` steps if given).
+* ``roofline``: HBM roofline of the cycle kernel — algorithmic bytes per launch (3 008 B per hexapod
+  cycle) / mean kernel duration measured with HIP events on the launch stream.
+* ``cpu_baseline``: the CPU oracle (a scalar restatement of the reference loop, "port") timed on this box's host
+  cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+ALG_BYTES_PER_CYCLE = {("hexapod", 2): 3008, ("hexapod", 3): 3560, ("octopod", 4): 4496}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
+
+
+def make_workload(name, n, seed):
+    from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
+    rng = np.random.default_rng(seed)
+    r = np.sqrt(rng.uniform(0.04, 1.0, size=n))
+    th = rng.uniform(0, 2 * np.pi, size=n)
+    lin = np.stack([r * np.cos(th), r * np.sin(th)], axis=1)  # uniform in the unit disc (|v| >= 0.2 so every robot walks)
+    ang = rng.uniform(-1.0, 1.0, size=n)
+    extra = {}
+    if name == "config2":
+        p = default_hexapod_params("tripod")
+        key, desc = ("hexapod", 2), "4096 hexapods (6x3 DOF, default.yaml), tripod gait, IK + Bezier tip trajectory"
+    elif name == "config3":
+        p = default_hexapod_params("wave")
+        p.admittance_control, p.imu_posing = 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+        key, desc = ("hexapod", 3), "hexapods, wave gait + admittance + IMU pose compensation"
+        from scipy.spatial.transform import Rotation as R
+        e = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-np.pi, np.pi, n)], axis=1)
+        q = R.from_euler("xyz", e).as_quat()
+        extra["imu_q"] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1)
+        extra["gyro"] = rng.normal(0, 0.05, size=(n, 3))
+        extra["force"] = np.stack([rng.normal(0, 1, (n, 6)), rng.normal(0, 1, (n, 6)), rng.uniform(0, 2, (n, 6))], axis=2)
+    elif name == "config4":
+        p = synthetic_octopod_params("ripple", 5, 8)
+        key, desc = ("octopod", 4), "synthetic octopods (8x5 DOF), ripple gait, IK + Bezier tip trajectory"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    extra["effort"] = rng.normal(0, 0.5, size=(n, p.leg_count * p.leg_dof[0]))
+    return p, lin, ang, extra, key, desc
+
+
+def apply_inputs(obj, lin, ang, extra):
+    obj.set_velocity(lin, ang)
+    if "imu_q" in extra:
+        obj.set_imu(extra["imu_q"], extra["gyro"])
+    if "force" in extra:
+        obj.set_tip_force(extra["force"])
+    obj.set_joint_effort(extra["effort"])
+
+
+def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
+    """Oracle ("port" of the reference loop) on the host cores, bounded sample of the same workload."""
+    from oracle_lib import OracleBatch
+    cores = os.cpu_count() or 1
+    n_s = min(len(ang), 64 * cores)
+    sub = {k: v[:n_s] for k, v in extra.items()}
+    ob = OracleBatch(p, n_s)
+    apply_inputs(ob, lin[:n_s], ang[:n_s], sub)
+    t = ob.step(20, cores)  # calibration + warm-up (walk start)
+    rate = n_s * 20 / max(t, 1e-9)
+    cycles = int(max(20, min(2000, target_seconds * rate / n_s)))
+    t = ob.step(cycles, cores)
+    multi = n_s * cycles / t
+    n1 = min(n_s, 64)
+    ob1 = OracleBatch(p, n1)
+    apply_inputs(ob1, lin[:n1], ang[:n1], {k: v[:n1] for k, v in extra.items()})
+    ob1.step(20, 1)
+    c1 = int(max(20, min(2000, 3.0 * (rate / cores) / n1)))
+    t1 = ob1.step(c1, 1)
+    return {"value": multi, "unit": "control-cycles/s", "cores": cores, "kind": "port",
+            "sample": f"{n_s} instances x {cycles} cycles on {cores} threads (pthreads over instances); "
+                      f"single thread: {n1 * c1 / t1:.0f} control-cycles/s ({n1} instances x {c1} cycles)",
+            "single_thread_value": n1 * c1 / t1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: 4096 for config2)")
+    ap.add_argument("--cycles-per-step", type=int, default=1)
+    ap.add_argument("--gather-every", type=int, default=0, help="all-gather the joint buffer every G steps (0 = once, at the end)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0xC0FFEE)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the batched engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+
+    n = args.instances or {"config2": 4096, "config3": 65536, "config4": 131072}[args.workload]
+    p, lin, ang, extra, key, desc = make_workload(args.workload, n, args.seed + rank)
+    stream = torch.cuda.current_stream()
+    eng = BatchEngine(p, n, device=local_rank, stream=stream.cuda_stream)
+    apply_inputs(eng, lin * 0.0, ang * 0.0, extra)
+
+    # ---- untimed preparation: de-phase the instances (instance i receives its command i mod period cycles late),
+    #      then walk until every instance is MOVING.
+    period = eng.tables().step.period
+    groups = 8
+    for gk in range(groups):
+        sel = (np.arange(n) % groups) <= gk
+        eng.set_velocity(lin * sel[:, None], ang * sel)
+        eng.step(max(1, period // groups))
+    eng.set_velocity(lin, ang)
+    eng.step(2 * period + 64)
+    eng.synchronize()
+    _, _, ws = eng.body_state()
+    moving_frac = float((ws == 1).mean())
+
+    cps = args.cycles_per_step
+    gathered = None
+    if world > 1:
+        gathered = torch.empty(world * n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda")
+
+    # joint-state shard of this rank in the C ABI's instance-major layout [n][legs][dof] (device resident)
+    qshard = torch.empty(n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def gather():
+        if world > 1:
+            eng.joints_device(qshard.data_ptr(), None)  # SoA planes -> [n][legs][dof] on the engine's stream
+            dist.all_gather_into_tensor(gathered, qshard)
+
+    for _ in range(args.warmup):
+        eng.step(cps)
+    if world > 1:
+        gather()
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.step(cps)
+        if args.gather_every and (i + 1) % args.gather_every == 0:
+            gather()
+    if not args.gather_every or args.steps % args.gather_every:
+        gather()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- kernel duration of the cycle kernel: HIP events on the launch stream, one pair per launch
+    m = min(args.steps, 200)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(m)]
+    for a, b in evs:
+        a.record(stream)
+        eng.step(cps)
+        b.record(stream)
+    torch.cuda.synchronize()
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    q, _ = eng.joints()
+    finite = bool(np.isfinite(q).all())
+
+    if rank == 0:
+        total_cycles = world * n * args.steps * cps
+        value = total_cycles / elapsed
+        alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}:{n}:{cps}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "control-cycles/sec (all legs IK-solved)", "value": value, "unit": "control-cycles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json {args.workload}: {desc}", "instances_per_gpu": n,
+                       "cycles_per_step": cps, "legs": p.leg_count, "dof": p.leg_dof[0],
+                       "gather": f"all-gather of the joint buffer every {args.gather_every} steps" if args.gather_every
+                       else "one all-gather of the final joint buffer (N > 1)",
+                       "moving_fraction": moving_frac, "finite": finite, "seed": args.seed},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(p, lin, ang, extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

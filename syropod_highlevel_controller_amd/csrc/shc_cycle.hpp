@@ -2,11 +2,13 @@
 //
 // Mapping: one leg per lane, one robot per L-lane group, floor(64 / L) robots per
 // wavefront (10 hexapods or 8 octopods per wave).  All per-leg linear algebra (<= 6x6) stays in that lane's
-// registers; per-robot scalars (velocity limiting, walk FSM, body pose) are wave-replicated inside the
-// group; the only cross-lane traffic is a handful of ds_bpermute shuffles (packed leg words, limit
-// brackets, walk-plane sums).  Per-leg DH / joint-limit tables and the 4 x 9 limit maps are staged in LDS
-// once per workgroup.  State is structure-of-arrays in HBM, one 8-byte slot per (field, lane) so that every
-// load/store of a wave is one fully coalesced 512-byte segment.
+// registers.  Per-robot state (velocity, walk FSM word, walk plane, body-pose components, PID state) lives in an
+// LDS tile owned by the wave — every lane of a group reads the same address (LDS broadcast), only lane 0 of the
+// group writes — so the replicated per-robot scalars cost no VGPRs between phases.  The launch-uniform parameter
+// block, the per-leg DH / joint-limit records and the 4 x 9 velocity-limit maps are staged in LDS once per
+// workgroup.  The only cross-lane traffic is a handful of ds_bpermute shuffles (packed leg words, limit brackets,
+// walk-plane sums).  HBM state is structure-of-arrays, one 8-byte slot per (field, lane): every load/store of a
+// wave is one fully coalesced 512-byte segment.
 //
 // Reference call order restated (OpenSHC v0.5.11, StateController::loop, src/state_controller.cpp:162-193,
 // runningState :379-447):
@@ -28,28 +30,33 @@ enum : int { PS_POSING = 0, PS_STOP_POSING = 1, PS_POSING_COMPLETE = 2 };       
 enum : int { PM_NONE = 0, PM_SWING = 1, PM_STANCE = 2, PM_STOP = 3 };
 
 // packed per-leg word
-constexpr int LW_STATE_SHIFT = 0, LW_ACP = 1 << 2, LW_CFS = 1 << 3, LW_PM_SHIFT = 4, LW_NEG = 1 << 6, LW_IKFAIL = 1 << 7,
-              LW_PHASE_SHIFT = 8, LW_PHASE_MASK = 0xFFFFF, LW_ZBV = 1 << 28, LW_ATT = 1 << 29;
+constexpr int LW_ACP = 1 << 2, LW_CFS = 1 << 3, LW_PM_SHIFT = 4, LW_NEG = 1 << 6, LW_IKFAIL = 1 << 7, LW_PHASE_SHIFT = 8,
+              LW_PHASE_MASK = 0xFFFFF, LW_ZBV = 1 << 28, LW_ATT = 1 << 29;
 // packed per-robot word: walk state [0:1], legs_at_correct_phase [2:5], legs_completed_first_step [6:9],
 // return_to_default_attempted [10], auto_posing_state [11:12]
 constexpr int RW_LACP_SHIFT = 2, RW_LCFS_SHIFT = 6, RW_RTDA = 1 << 10, RW_APS_SHIFT = 11;
 
 constexpr int kMaxAutoPosers = 8;
 
-// Uniform (per launch) parameters: passed by value in the kernarg segment -> scalar registers.
+// Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
+enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_DYN = 1u << 31 };
+
+// Launch-uniform parameters (staged in LDS).
 struct CycleParams {
   double dt;
   int32_t period, swing_period, stance_period, stance_end, swing_start, swing_end, stance_start;
-  int32_t swing_iterations;       // walk_controller.cpp:1035-1036
-  int32_t stance_iterations;      // :1040 with the standard stance period
-  double swing_delta_t;           // :1037
-  double stride_scale;            // (stance_period / period) / frequency   (:940-941)
+  int32_t swing_iterations;  // walk_controller.cpp:1035-1036
+  int32_t stance_iterations; // :1040 with the standard stance period
+  double swing_delta_t;      // :1037
+  double stride_scale;       // (stance_period / period) / frequency   (:940-941)
   double swing_height, swing_width, body_clearance;
-  double swing_progress_scaler;   // pose_controller.cpp:1103
+  double swing_progress_scaler; // pose_controller.cpp:1103
   int32_t velocity_input_mode;
   int32_t manual_posing, auto_posing, inclination_posing, imu_posing, admittance_control, dynamic_stiffness, use_joint_effort;
   int32_t clamp_joint_positions, clamp_joint_velocities, force_normal_touchdown;
-  int32_t tip_force; // SHC_FEAT_TIP_FORCE
+  int32_t tip_force;  // SHC_FEAT_TIP_FORCE
+  int32_t debug_skip; // development ablation mask (SHC_DEBUG_SKIP env): 1 pose, 2 limits, 4 stepper, 8 ik, 16 fk
+  int32_t pad0;
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
   double pid_p, pid_i, pid_d;
   // admittance: 30 RK4 steps of x'' = -F/m - c/m x' - k/m x collapsed into x <- M x + g F
@@ -63,29 +70,33 @@ struct CycleParams {
 
 template <int L, int NJ>
 struct SharedConsts { // staged in LDS
+  CycleParams P;
   LegConst<NJ> leg[L];
   double limit[4][9]; // max linear speed, max angular speed, max linear acceleration, max angular acceleration
 };
 
-// Device-side view of the SoA state.  Leg fields: legd[f * n_slots + slot]; robot fields: robd[f * n_rob + robot].
+// SoA planes in HBM.  Leg fields: legd[f * n_slots + slot]; robot fields: robd[f * n_rob_pad + robot].
 template <int NJ>
 struct Fields {
-  // per-leg double fields
   static constexpr int Q = 0, QD = NJ, TIP = 2 * NJ, TVEL = TIP + 3, SORG = TVEL + 3, SVEL = SORG + 3, TORG = SVEL + 3,
                        DFLT = TORG + 3, TARG = DFLT + 3, STRD = TARG + 3,
-                       CORE_END = STRD + 3,                    // always loaded / stored
-                       ADM = CORE_END, ADM_END = ADM + 2,      // admittance state   (admittance_control)
-                       TF = ADM_END, TF_END = TF + 3,          // tip_force_calculated_ filter state (tip_force)
+                       CORE_END = STRD + 3,                         // always loaded / stored
+                       ADM = CORE_END, ADM_END = ADM + 2,           // admittance state   (admittance_control)
+                       TF = ADM_END, TF_END = TF + 3,               // tip_force_calculated_ filter state (tip_force)
                        FORCE_IN = TF_END, EFFORT_IN = FORCE_IN + 3, // inputs
                        POSER_TIP = EFFORT_IN + NJ, MODEL_TIP = POSER_TIP + 3, ADM_DELTA = MODEL_TIP + 3, // outputs
                        COUNT = ADM_DELTA + 3;
 };
 struct RobotFields {
-  static constexpr int VLIN = 0, VANG = 2, PLANE = 3, PNORM = 6, PLANE_PREV = 9, PNORM_PREV = 12, CORE_END = 15,
-                       OWPP = 15, OWPP_END = 22, MPOSE = 22, MPOSE_END = 29, ABSE = 29, VERR = 32, IMU_END = 35,
-                       APREV = 35, APREV_END = 39, // auto_pose_.rotation_ of the previous cycle (read by updateInclinationPose)
-                       VIN = 39, WIN = 41, IMUQ = 42, GYRO = 46, TVI = 49, RVI = 52, // inputs
-                       CPOSE = 55, COUNT = 62;
+  // state + inputs that every specialisation touches
+  static constexpr int VLIN = 0, VANG = 2, PLANE = 3, PNORM = 6, PLANE_PREV = 9, PNORM_PREV = 12, OWPP = 15, VIN = 22, WIN = 24,
+                       CORE_END = 25;
+  static constexpr int MPOSE = 25, TVI = 32, RVI = 35, MANUAL_END = 38; // manual posing
+  static constexpr int ABSE = 38, VERR = 41, GYRO = 44, IMU_END = 47;   // IMU posing PID state + gyro input
+  static constexpr int IMUQ = 47, IMUQ_END = 51;                        // IMU orientation input
+  static constexpr int APREV = 51, APREV_END = 55;                      // previous cycle's auto_pose_.rotation_
+  static constexpr int CPOSE = 55, CPOSE_END = 62;                      // output: Model::current_pose_
+  static constexpr int WPP = 62, COUNT = 69;                            // output: walk_plane_pose_ (model default pose)
   static constexpr int I_WORD = 0, I_APOSER = 1, I_POSE_PHASE = 2, I_RESET_MODE = 3, I_COUNT = 4;
 };
 
@@ -98,6 +109,23 @@ struct DevState {
 };
 
 #if defined(__HIPCC__)
+
+// Phase fence: keeps the machine scheduler from hoisting the next phase's LDS/const loads above this point, which
+// bounds live ranges to one phase (the fused cycle is one huge basic block otherwise -> ~470 live VGPRs).
+#define SHC_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef SHC_DBG
+#define SHC_DBG(P) ((P).debug_skip)
+#endif
+
+template <unsigned F>
+struct Feat {
+  __device__ __forceinline__ static bool manual(const CycleParams &P) { return (F & F_DYN) ? P.manual_posing != 0 : (F & F_MANUAL) != 0; }
+  __device__ __forceinline__ static bool autop(const CycleParams &P) { return (F & F_DYN) ? P.auto_posing != 0 : (F & F_AUTO) != 0; }
+  __device__ __forceinline__ static bool incl(const CycleParams &P) { return (F & F_DYN) ? P.inclination_posing != 0 : (F & F_INCL) != 0; }
+  __device__ __forceinline__ static bool imu(const CycleParams &P) { return (F & F_DYN) ? P.imu_posing != 0 : (F & F_IMU) != 0; }
+  __device__ __forceinline__ static bool adm(const CycleParams &P) { return (F & F_DYN) ? P.admittance_control != 0 : (F & F_ADM) != 0; }
+  __device__ __forceinline__ static bool tipf(const CycleParams &P) { return (F & F_DYN) ? P.tip_force != 0 : (F & F_TIPF) != 0; }
+};
 
 template <int L>
 struct Group {
@@ -112,14 +140,78 @@ struct Group {
   }
 };
 
-__device__ __forceinline__ V3 ldv3(const double *p, int64_t stride) { return V3{p[0], p[stride], p[2 * stride]}; }
-__device__ __forceinline__ void stv3(double *p, int64_t stride, V3 v) {
-  p[0] = v.x;
-  p[stride] = v.y;
-  p[2 * stride] = v.z;
-}
+// The wave's robot tile in LDS: value of field f for this lane's robot is d[f * RPW + grp].
+template <int RPW>
+struct RobTile {
+  double *d;
+  int32_t *i;
+  int grp;
+  bool writer; // lane 0 of a live group
+  __device__ __forceinline__ double get(int f) const { return d[f * RPW + grp]; }
+  __device__ __forceinline__ V3 get3(int f) const { return V3{d[f * RPW + grp], d[(f + 1) * RPW + grp], d[(f + 2) * RPW + grp]}; }
+  __device__ __forceinline__ Quat getq(int f) const {
+    return Quat{d[f * RPW + grp], d[(f + 1) * RPW + grp], d[(f + 2) * RPW + grp], d[(f + 3) * RPW + grp]};
+  }
+  __device__ __forceinline__ Pose getpose(int f) const { return Pose{get3(f), getq(f + 3)}; }
+  __device__ __forceinline__ void put(int f, double v) const {
+    if (writer) d[f * RPW + grp] = v;
+  }
+  __device__ __forceinline__ void put3(int f, V3 v) const {
+    if (writer) {
+      d[f * RPW + grp] = v.x;
+      d[(f + 1) * RPW + grp] = v.y;
+      d[(f + 2) * RPW + grp] = v.z;
+    }
+  }
+  __device__ __forceinline__ void putq(int f, Quat q) const {
+    if (writer) {
+      d[f * RPW + grp] = q.w;
+      d[(f + 1) * RPW + grp] = q.x;
+      d[(f + 2) * RPW + grp] = q.y;
+      d[(f + 3) * RPW + grp] = q.z;
+    }
+  }
+  __device__ __forceinline__ void putpose(int f, const Pose &p) const {
+    put3(f, p.p);
+    putq(f + 3, p.r);
+  }
+  __device__ __forceinline__ int geti(int f) const { return i[f * RPW + grp]; }
+  __device__ __forceinline__ void puti(int f, int v) const {
+    if (writer) i[f * RPW + grp] = v;
+  }
+};
 
-// progress values as the reference's LegStepper holds them (walk_controller.cpp:878-896)
+// Per-leg state held in registers across the cycles of one launch.
+template <int NJ>
+struct LegRegs {
+  double q[NJ], qd[NJ];
+  double sn[NJ], cs[NJ]; // sin / cos of the DH joint angles at q: the chain (Jacobian, tip) is rebuilt from these
+  V3 tip, tvel, targ, strd;
+  double adm0, adm1;
+  V3 tf, tipx; // tip x axis (robot frame) of the current FK, kept only for Leg::setAdmittanceDelta
+  int word;
+};
+
+// Stepper state that only the swing / stance branch touches is parked in a per-lane LDS strip between uses
+// (swing origin position / velocity, stance origin, default tip): 12 doubles = 24 VGPRs off the persistent set.
+enum : int { PK_SORG = 0, PK_SVEL = 3, PK_TORG = 6, PK_DFLT = 9, PK_COUNT = 12 };
+struct Park {
+  double *d; // d[f * 64 + lane]
+  int lane;
+  __device__ __forceinline__ V3 get3(int f) const { return V3{d[f * 64 + lane], d[(f + 1) * 64 + lane], d[(f + 2) * 64 + lane]}; }
+  __device__ __forceinline__ void put3(int f, V3 v) const {
+    d[f * 64 + lane] = v.x;
+    d[(f + 1) * 64 + lane] = v.y;
+    d[(f + 2) * 64 + lane] = v.z;
+  }
+};
+
+// Per-cycle outputs (LegState topic fields); only the last cycle of a launch is written to HBM.
+struct LegOut {
+  V3 poser_tip, model_tip, adm_delta;
+};
+
+// progress value as the reference's LegStepper holds it (walk_controller.cpp:878-896)
 __device__ __forceinline__ double swing_progress_of(int word, const CycleParams &P) {
   int pm = (word >> LW_PM_SHIFT) & 3;
   if (pm != PM_SWING) return -1.0;
@@ -127,257 +219,278 @@ __device__ __forceinline__ double swing_progress_of(int word, const CycleParams 
   return clampd(double(phase - P.swing_start + 1) / double(P.swing_end - P.swing_start), 0.0, 1.0);
 }
 
-template <int L, int NJ>
-struct Lane {
-  // per-leg state
-  double q[NJ], qd[NJ];
-  V3 tip, tvel, sorg, svel, torg, dflt, targ, strd;
-  double adm0, adm1;
-  V3 tf, force_in;
-  double effort[NJ];
-  int word;
-  // per-robot state (replicated over the group's lanes)
-  double vx, vy, vw;
-  V3 plane, pnorm, plane_prev, pnorm_prev;
-  Pose owpp, mpose;
-  V3 abse, verr;
-  Quat aprev;
-  int rword, aposer, pose_phase, reset_mode;
-  // inputs
-  double vin_x, vin_y, win;
-  Quat imuq;
-  V3 gyro, tvi, rvi;
-  // per-cycle outputs
-  V3 poser_tip, model_tip, adm_delta;
-  Pose cpose;
-};
-
 // ------------------------------------------------------------------------------------------------- one control cycle
-template <int L, int NJ>
-__device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, const SharedConsts<L, NJ> &C, const Group<L> g, int leg,
-                                      Chain<NJ> &chain) {
-  const LegConst<NJ> &lc = C.leg[leg];
-  const V3 UX{1, 0, 0}, UZ{0, 0, 1};
+template <int L, int NJ, unsigned F>
+__device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
+                                      const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot) {
+  using R = RobotFields;
+  using FT = Feat<F>;
+  // The parameter block and the per-leg records are loop-invariant LDS data: without this opaque zero LICM hoists every
+  // one of their ~90 loads out of the n_cycles loop and pins ~180 VGPRs for the whole launch.
+  int zero = 0;
+  asm volatile("" : "+v"(zero));
+  const CycleParams &P = (&C.P)[zero];
+  const LegConst<NJ> &lc = C.leg[leg + zero];
+  const V3 UZ{0, 0, 1};
 
   // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611)
   {
     int w = s.word & ~(LW_ZBV | LW_ATT);
     if (dot(s.strd, s.strd) == 0.0) w |= LW_ZBV;
-    V3 err = rejection(s.tip - s.targ, s.pnorm_prev);
-    if (norm(err) < kTipTolerance) w |= LW_ATT;
+    V3 err = rejection(s.tip - s.targ, rb.get3(R::PNORM_PREV));
+    if (dot(err, err) < kTipTolerance * kTipTolerance) w |= LW_ATT;
     s.word = w;
   }
   int lw[L];
 #pragma unroll
   for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
 
-  int walk_state = s.rword & 3;
+  SHC_PHASE_FENCE();
+  int rword = rb.geti(R::I_WORD);
+  int walk_state = rword & 3;
 
   // =============================================================== PoseController::updateCurrentPose (:811-859)
-  // ---- updateWalkPlanePose (:1092-1130)
-  Pose wpp;
-  {
-    double c = 0.0;
-    bool sel = false;
-#pragma unroll
-    for (int j = 0; j < L; ++j) {
-      double sp = swing_progress_of(lw[j], P) * P.swing_progress_scaler;
-      if (sp >= 0 && sp <= 1.0) {
-        c = smooth_step(sp);
-        sel = true;
-      }
-    }
-    V3 wplane = sel ? s.plane_prev : V3{0, 0, 0};
-    V3 wnorm = sel ? s.pnorm_prev : UZ;
-    Pose np;
-    np.r = correct_rotation(from_two_vectors(UZ, wnorm), quat_identity());
-    np.p = rotate(np.r, V3{0, 0, P.body_clearance});
-    np.p.z += wplane.z;
-    wpp = interpolate_pose(s.owpp, c, np);
-    if (c == 1.0) s.owpp = wpp;
-  }
-  Pose cp = wpp; // Identity.addPose(walk_plane_pose_)
-  // ---- updateManualPose (:863-1003)
-  if (P.manual_posing) {
-    bool idle = s.reset_mode == 0 && s.tvi.x == 0.0 && s.tvi.y == 0.0 && s.tvi.z == 0.0 && s.rvi.x == 0.0 && s.rvi.y == 0.0 &&
-                s.rvi.z == 0.0;
-    // With zero inputs and NO_RESET the reference re-derives manual_pose_ from its own Euler angles (a no-op up to
-    // rounding); that Euler round trip is skipped here.
-    if (__any(!idle)) {
-      if (!idle) {
-        if (s.reset_mode == 5) { // IMMEDIATE_ALL_RESET (default_pose_ is identity on this path)
-          s.mpose = pose_identity();
-        } else {
-          double cpos[3] = {s.mpose.p.x, s.mpose.p.y, s.mpose.p.z};
-          V3 ce = quat_to_euler(s.mpose.r, true);
-          double crot[3] = {ce.x, ce.y, ce.z};
-          double tvi[3] = {s.tvi.x, s.tvi.y, s.tvi.z}, rvi[3] = {s.rvi.x, s.rvi.y, s.rvi.z};
-          bool rt[3] = {false, false, false}, rr[3] = {false, false, false};
-          switch (s.reset_mode) {
-            case 1: rt[2] = true; rr[2] = true; break;
-            case 2: rt[0] = true; rt[1] = true; break;
-            case 3: rr[0] = true; rr[1] = true; break;
-            case 4: rt[0] = rt[1] = rt[2] = true; rr[0] = rr[1] = rr[2] = true; break;
-            default: break;
-          }
-          double dpos[3], drot[3];
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            if (rt[i]) {
-              double diff = cpos[i] - 0.0;
-              if (diff < 0) tvi[i] = 1.0; else if (diff > 0) tvi[i] = -1.0;
-            }
-            if (rr[i]) {
-              double diff = crot[i] - 0.0;
-              if (diff < 0) rvi[i] = 1.0; else if (diff > 0) rvi[i] = -1.0;
-            }
-            double tv = tvi[i] * P.max_translation_velocity;
-            double rv = rvi[i] * P.max_rotation_velocity;
-            double dp = cpos[i] + tv * P.dt;
-            double dr = crot[i] + rv * P.dt;
-            double tl = signd(tv) * P.max_translation[i];
-            if (rt[i] && 0.0 < P.max_translation[i] && 0.0 > -P.max_translation[i]) tl = 0.0;
-            bool ptv = signd(tv) > 0;
-            if ((ptv && dp > tl) || (!ptv && dp < tl)) tv = (tl - cpos[i]) / P.dt;
-            double rl = signd(rv) * P.max_rotation[i];
-            if (rr[i] && 0.0 < P.max_rotation[i] && 0.0 > -P.max_rotation[i]) rl = 0.0;
-            bool prv = signd(rv) > 0;
-            if ((prv && dr > rl) || (!prv && dr < rl)) rv = (rl - crot[i]) / P.dt;
-            dpos[i] = cpos[i] + tv * P.dt;
-            drot[i] = crot[i] + rv * P.dt;
-          }
-          s.tvi = V3{tvi[0], tvi[1], tvi[2]};
-          s.rvi = V3{rvi[0], rvi[1], rvi[2]};
-          s.mpose.p = V3{dpos[0], dpos[1], dpos[2]};
-          s.mpose.r = correct_rotation(euler_to_quat(V3{drot[0], drot[1], drot[2]}, true), quat_identity());
-        }
-      }
-    }
-    cp = add_pose(cp, s.mpose);
-  }
-  // ---- auto pose of the previous cycle is needed by updateInclinationPose (auto_pose_ member); on this path
-  //      auto posing and IMU posing are exclusive (:836-846), and inclination reads auto_pose_ before it is updated.
+  Pose cp; // Model::current_pose_
   Pose auto_pose = pose_identity();
   Pose leg_auto = pose_identity();
-  if (P.inclination_posing) { // updateInclinationPose (:1240-1259) reads the auto_pose_ left by the previous cycle
-    Quat comb = normalized(s.mpose.r * s.aprev);
-    Quat removed = normalized(s.imuq * inverse(comb));
-    V3 e = quat_to_euler(removed, false);
-    double lon = clampd(-P.body_clearance * tan(e.y), -P.max_translation[0], P.max_translation[0]);
-    double lat = clampd(P.body_clearance * tan(e.x), -P.max_translation[1], P.max_translation[1]);
-    cp = add_pose(cp, Pose{V3{lon, lat, 0.0}, quat_identity()});
-  }
-  if (P.imu_posing) { // updateIMUPose (:1191-1236)
-    Quat cur = correct_rotation(s.imuq, quat_identity());
-    Quat tgt = correct_rotation(s.mpose.r, quat_identity());
-    Quat err = normalized(cur * inverse(tgt));
-    V3 pe = quat_to_euler(err, false);
-    pe.z = 0.0;
-    s.abse = s.abse + pe * P.dt;
-    s.verr = (-s.gyro) * 0.15 + s.verr * (1 - 0.15);
-    V3 corr = -(s.verr * P.pid_d + pe * P.pid_p + s.abse * P.pid_i);
-    corr.x = clampd(corr.x, -P.max_rotation[0], P.max_rotation[0]);
-    corr.y = clampd(corr.y, -P.max_rotation[1], P.max_rotation[1]);
-    corr.z = quat_to_euler(tgt, false).z;
-    Quat ir = correct_rotation(euler_to_quat(corr, false), tgt);
-    cp = add_pose(cp, Pose{V3{0, 0, 0}, ir});
-  } else if (P.auto_posing) { // updateAutoPose (:1134-1187)
-    int ref = lw[P.auto_pose_reference_leg];
-    bool zbv = (ref & LW_ZBV) != 0;
-    int aps = (s.rword >> RW_APS_SHIFT) & 3;
-    if (walk_state == WS_STARTING || walk_state == WS_MOVING) aps = PS_POSING;
-    else if ((zbv && walk_state == WS_STOPPING) || walk_state == WS_STOPPED) aps = PS_STOP_POSING;
-    int master_phase;
-    if (P.pose_sync) {
-      master_phase = (ref >> LW_PHASE_SHIFT) & LW_PHASE_MASK;
-    } else {
-      master_phase = s.pose_phase;
-      s.pose_phase = (s.pose_phase + 1) % P.pose_phase_length;
-    }
-    int complete = 0;
-    for (int i = 0; i < P.n_auto_posers; ++i) { // AutoPoser::updatePose (:1338-1439)
-      int fl = (s.aposer >> (4 * i)) & 15;
-      bool start_check = fl & 1, end1 = fl & 2, end2 = fl & 4, allow = fl & 8;
-      int phase = master_phase, sp = P.ap_start[i], ep = P.ap_end[i];
-      if (sp > ep) {
-        ep += P.pose_phase_length;
-        if (phase < sp) phase += P.pose_phase_length;
-      }
-      start_check = !P.pose_sync || (!start_check && aps == PS_POSING && phase == sp);
-      end1 = end1 || (aps == PS_STOP_POSING && phase == sp);
-      end2 = end2 || (aps == PS_STOP_POSING && phase == ep && end1);
-      if (!allow && start_check) {
-        allow = true;
-        end1 = end2 = false;
-      } else if (allow && P.pose_sync && end1 && end2) {
-        allow = false;
-        start_check = false;
-      }
-      s.aposer = (s.aposer & ~(15 << (4 * i))) | ((int(start_check) | int(end1) << 1 | int(end2) << 2 | int(allow) << 3) << (4 * i));
-      complete += allow ? 0 : 1;
-      if (phase >= sp && phase < ep && allow) {
-        int iteration = phase - sp + 1, num = ep - sp;
-        bool first_half = iteration <= num / 2;
-        double delta_t = 1.0 / (num / 2.0);
-        int offset = int(first_half ? 0 : num / 2.0);
-        double t = (iteration - offset) * delta_t;
-        double u = 1.0 - t;
-        // nodes {0,0,0,A,A} (first half) or {A,A,0,0,0} (second half): B(t) = A * weight
-        double wgt = first_half ? (4.0 * t * t * t * u + t * t * t * t) : (u * u * u * u + 4.0 * t * u * u * u);
-        V3 pos;
-        if (P.ap_amp[i][3] != 0.0) { // gravity amplitude: Model::estimateGravity (model.cpp:156-165)
-          V3 e = quat_to_euler(s.imuq, false);
-          V3 gv{0, 0, kGravity};
-          gv = rotate(angle_axis_y(-e.y), gv);
-          gv = rotate(angle_axis_x(-e.x), gv);
-          pos = normalized(gv) * (P.ap_amp[i][3] * wgt);
-        } else {
-          pos = V3{P.ap_amp[i][0] * wgt, P.ap_amp[i][1] * wgt, P.ap_amp[i][2] * wgt};
-        }
-        V3 rot{P.ap_amp[i][4] * wgt, P.ap_amp[i][5] * wgt, P.ap_amp[i][6] * wgt};
-        auto_pose = add_pose(auto_pose, Pose{pos, euler_to_quat(rot, false)});
-      }
-    }
-    if (complete == P.n_auto_posers) aps = PS_POSING_COMPLETE;
-    s.rword = (s.rword & ~(3 << RW_APS_SHIFT)) | (aps << RW_APS_SHIFT);
-    // LegPoser::updateAutoPose for this lane's leg (:1716-1778)
+  if (!(SHC_DBG(P) & 1)) {
+    // ---- updateWalkPlanePose (:1092-1130)
+    Pose wpp;
     {
-      int sp = lc.neg_start, ep = lc.neg_end, np = master_phase;
-      if (sp > ep) {
-        ep += P.pose_phase_length;
-        if (np < sp) np += P.pose_phase_length;
-      }
-      int st = s.word & 3;
-      bool neg = (s.word & LW_NEG) != 0;
-      if (st != SS_FORCE_STANCE && st != SS_FORCE_STOP && np == sp) neg = true;
-      if (np < sp || np > ep) neg = false;
-      s.word = neg ? (s.word | LW_NEG) : (s.word & ~LW_NEG);
-      leg_auto = auto_pose;
-      if (neg) {
-        int iteration = np - sp + 1, num = ep - sp;
-        bool first_half = iteration <= num / 2;
-        double ci = 1.0;
-        if (lc.neg_ratio > 0.0) {
-          if (first_half) ci = fmin(1.0, iteration / (num * lc.neg_ratio));
-          else ci = fmin(1.0, (num - iteration) / (num * lc.neg_ratio));
+      double c = 0.0;
+      bool sel = false;
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        double sp = swing_progress_of(lw[j], P) * P.swing_progress_scaler;
+        if (sp >= 0 && sp <= 1.0) {
+          c = smooth_step(sp);
+          sel = true;
         }
-        ci = smooth_step(ci);
-        Pose negation = interpolate_pose(pose_identity(), ci, auto_pose);
-        leg_auto = remove_pose(auto_pose, negation);
       }
+      V3 wplane = sel ? rb.get3(R::PLANE_PREV) : V3{0, 0, 0};
+      V3 wnorm = sel ? rb.get3(R::PNORM_PREV) : UZ;
+      Pose owpp = rb.getpose(R::OWPP);
+      // Flat ground (the walk-plane normal is exactly +z and the body is not tilted): FromTwoVectors(z, z) is exactly the
+      // identity and slerp(identity, c, identity) takes Eigen's linear branch, so the result below is bit-identical to the
+      // general path at a fraction of its cost.  The general path only runs after a default tip moved off the plane.
+      bool flat = wnorm.x == 0.0 && wnorm.y == 0.0 && wnorm.z == 1.0 && owpp.r.w == 1.0 && owpp.r.x == 0.0 && owpp.r.y == 0.0 &&
+                  owpp.r.z == 0.0;
+      if (__builtin_expect(__all(flat), 1)) {
+        double s0 = 1.0 - c;
+        V3 npp{0.0, 0.0, P.body_clearance + wplane.z};
+        wpp.p = npp * c + owpp.p * s0;
+        wpp.r = Quat{s0 * 1.0 + c * 1.0, s0 * 0.0 + c * 0.0, s0 * 0.0 + c * 0.0, s0 * 0.0 + c * 0.0};
+      } else {
+        Pose np;
+        np.r = correct_rotation(from_two_vectors(UZ, wnorm), quat_identity());
+        np.p = rotate(np.r, V3{0, 0, P.body_clearance});
+        np.p.z += wplane.z;
+        wpp = interpolate_pose(owpp, c, np);
+      }
+      if (c == 1.0) rb.putpose(R::OWPP, wpp);
+      rb.putpose(R::WPP, wpp);
     }
-    cp = add_pose(cp, auto_pose);
-    s.aprev = auto_pose.r;
+    cp = wpp; // Identity.addPose(walk_plane_pose_)
+    // ---- updateManualPose (:863-1003)
+    Quat manual_r = quat_identity();
+    if (FT::manual(P)) {
+      V3 tvi_in = rb.get3(R::TVI), rvi_in = rb.get3(R::RVI);
+      int reset_mode = rb.geti(R::I_RESET_MODE);
+      bool idle = reset_mode == 0 && tvi_in.x == 0.0 && tvi_in.y == 0.0 && tvi_in.z == 0.0 && rvi_in.x == 0.0 && rvi_in.y == 0.0 &&
+                  rvi_in.z == 0.0;
+      Pose mpose = rb.getpose(R::MPOSE);
+      // With zero inputs and NO_RESET the reference re-derives manual_pose_ from its own Euler angles (a no-op up to
+      // rounding); that Euler round trip is skipped here.
+      if (__any(!idle)) {
+        if (!idle) {
+          if (reset_mode == 5) { // IMMEDIATE_ALL_RESET (default_pose_ is identity on this path)
+            mpose = pose_identity();
+          } else {
+            double cpos[3] = {mpose.p.x, mpose.p.y, mpose.p.z};
+            V3 ce = quat_to_euler(mpose.r, true);
+            double crot[3] = {ce.x, ce.y, ce.z};
+            double tvi[3] = {tvi_in.x, tvi_in.y, tvi_in.z}, rvi[3] = {rvi_in.x, rvi_in.y, rvi_in.z};
+            bool rt[3] = {false, false, false}, rr[3] = {false, false, false};
+            switch (reset_mode) {
+              case 1: rt[2] = true; rr[2] = true; break;
+              case 2: rt[0] = true; rt[1] = true; break;
+              case 3: rr[0] = true; rr[1] = true; break;
+              case 4: rt[0] = rt[1] = rt[2] = true; rr[0] = rr[1] = rr[2] = true; break;
+              default: break;
+            }
+            double dpos[3], drot[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+              if (rt[i]) {
+                double diff = cpos[i] - 0.0;
+                if (diff < 0) tvi[i] = 1.0; else if (diff > 0) tvi[i] = -1.0;
+              }
+              if (rr[i]) {
+                double diff = crot[i] - 0.0;
+                if (diff < 0) rvi[i] = 1.0; else if (diff > 0) rvi[i] = -1.0;
+              }
+              double tv = tvi[i] * P.max_translation_velocity;
+              double rv = rvi[i] * P.max_rotation_velocity;
+              double dp = cpos[i] + tv * P.dt;
+              double dr = crot[i] + rv * P.dt;
+              double tl = signd(tv) * P.max_translation[i];
+              if (rt[i] && 0.0 < P.max_translation[i] && 0.0 > -P.max_translation[i]) tl = 0.0;
+              bool ptv = signd(tv) > 0;
+              if ((ptv && dp > tl) || (!ptv && dp < tl)) tv = (tl - cpos[i]) / P.dt;
+              double rl = signd(rv) * P.max_rotation[i];
+              if (rr[i] && 0.0 < P.max_rotation[i] && 0.0 > -P.max_rotation[i]) rl = 0.0;
+              bool prv = signd(rv) > 0;
+              if ((prv && dr > rl) || (!prv && dr < rl)) rv = (rl - crot[i]) / P.dt;
+              dpos[i] = cpos[i] + tv * P.dt;
+              drot[i] = crot[i] + rv * P.dt;
+            }
+            rb.put3(R::TVI, V3{tvi[0], tvi[1], tvi[2]});
+            rb.put3(R::RVI, V3{rvi[0], rvi[1], rvi[2]});
+            mpose.p = V3{dpos[0], dpos[1], dpos[2]};
+            mpose.r = correct_rotation(euler_to_quat(V3{drot[0], drot[1], drot[2]}, true), quat_identity());
+          }
+          rb.putpose(R::MPOSE, mpose);
+        }
+      }
+      manual_r = mpose.r;
+      cp = add_pose(cp, mpose);
+    }
+    if (FT::incl(P)) { // updateInclinationPose (:1240-1259) reads the auto_pose_ left by the previous cycle
+      Quat aprev = FT::autop(P) ? rb.getq(R::APREV) : quat_identity();
+      Quat comb = normalized(manual_r * aprev);
+      Quat removed = normalized(rb.getq(R::IMUQ) * inverse(comb));
+      V3 e = quat_to_euler(removed, false);
+      double lon = clampd(-P.body_clearance * tan(e.y), -P.max_translation[0], P.max_translation[0]);
+      double lat = clampd(P.body_clearance * tan(e.x), -P.max_translation[1], P.max_translation[1]);
+      cp = add_pose(cp, Pose{V3{lon, lat, 0.0}, quat_identity()});
+    }
+    if (FT::imu(P)) { // updateIMUPose (:1191-1236)
+      Quat cur = correct_rotation(rb.getq(R::IMUQ), quat_identity());
+      Quat tgt = correct_rotation(manual_r, quat_identity());
+      Quat err = normalized(cur * inverse(tgt));
+      V3 pe = quat_to_euler(err, false);
+      pe.z = 0.0;
+      V3 abse = rb.get3(R::ABSE) + pe * P.dt;
+      V3 verr = (-rb.get3(R::GYRO)) * 0.15 + rb.get3(R::VERR) * (1 - 0.15);
+      rb.put3(R::ABSE, abse);
+      rb.put3(R::VERR, verr);
+      V3 corr = -(verr * P.pid_d + pe * P.pid_p + abse * P.pid_i);
+      corr.x = clampd(corr.x, -P.max_rotation[0], P.max_rotation[0]);
+      corr.y = clampd(corr.y, -P.max_rotation[1], P.max_rotation[1]);
+      // yaw of the target rotation; the identity target (idle manual pose) has yaw +0 exactly
+      bool tgt_identity = tgt.w == 1.0 && tgt.x == 0.0 && tgt.y == 0.0 && tgt.z == 0.0;
+      corr.z = 0.0;
+      if (__any(!tgt_identity)) {
+        if (!tgt_identity) corr.z = quat_to_euler(tgt, false).z;
+      }
+      Quat ir = correct_rotation(euler_to_quat(corr, false), tgt);
+      cp = add_pose(cp, Pose{V3{0, 0, 0}, ir});
+    } else if (FT::autop(P)) { // updateAutoPose (:1134-1187)
+      int ref = lw[P.auto_pose_reference_leg];
+      bool zbv = (ref & LW_ZBV) != 0;
+      int aps = (rword >> RW_APS_SHIFT) & 3;
+      if (walk_state == WS_STARTING || walk_state == WS_MOVING) aps = PS_POSING;
+      else if ((zbv && walk_state == WS_STOPPING) || walk_state == WS_STOPPED) aps = PS_STOP_POSING;
+      int master_phase;
+      if (P.pose_sync) {
+        master_phase = (ref >> LW_PHASE_SHIFT) & LW_PHASE_MASK;
+      } else {
+        master_phase = rb.geti(R::I_POSE_PHASE);
+        rb.puti(R::I_POSE_PHASE, (master_phase + 1) % P.pose_phase_length);
+      }
+      int aposer = rb.geti(R::I_APOSER);
+      int complete = 0;
+      for (int i = 0; i < P.n_auto_posers; ++i) { // AutoPoser::updatePose (:1338-1439)
+        int fl = (aposer >> (4 * i)) & 15;
+        bool start_check = fl & 1, end1 = fl & 2, end2 = fl & 4, allow = fl & 8;
+        int phase = master_phase, sp = P.ap_start[i], ep = P.ap_end[i];
+        if (sp > ep) {
+          ep += P.pose_phase_length;
+          if (phase < sp) phase += P.pose_phase_length;
+        }
+        start_check = !P.pose_sync || (!start_check && aps == PS_POSING && phase == sp);
+        end1 = end1 || (aps == PS_STOP_POSING && phase == sp);
+        end2 = end2 || (aps == PS_STOP_POSING && phase == ep && end1);
+        if (!allow && start_check) {
+          allow = true;
+          end1 = end2 = false;
+        } else if (allow && P.pose_sync && end1 && end2) {
+          allow = false;
+          start_check = false;
+        }
+        aposer = (aposer & ~(15 << (4 * i))) | ((int(start_check) | int(end1) << 1 | int(end2) << 2 | int(allow) << 3) << (4 * i));
+        complete += allow ? 0 : 1;
+        if (phase >= sp && phase < ep && allow) {
+          int iteration = phase - sp + 1, num = ep - sp;
+          bool first_half = iteration <= num / 2;
+          double delta_t = 1.0 / (num / 2.0);
+          int offset = int(first_half ? 0 : num / 2.0);
+          double t = (iteration - offset) * delta_t;
+          double u = 1.0 - t;
+          // nodes {0,0,0,A,A} (first half) or {A,A,0,0,0} (second half): B(t) = A * weight
+          double wgt = first_half ? (4.0 * t * t * t * u + t * t * t * t) : (u * u * u * u + 4.0 * t * u * u * u);
+          V3 pos;
+          if (P.ap_amp[i][3] != 0.0) { // gravity amplitude: Model::estimateGravity (model.cpp:156-165)
+            V3 e = quat_to_euler(rb.getq(R::IMUQ), false);
+            V3 gv{0, 0, kGravity};
+            gv = rotate(angle_axis_y(-e.y), gv);
+            gv = rotate(angle_axis_x(-e.x), gv);
+            pos = normalized(gv) * (P.ap_amp[i][3] * wgt);
+          } else {
+            pos = V3{P.ap_amp[i][0] * wgt, P.ap_amp[i][1] * wgt, P.ap_amp[i][2] * wgt};
+          }
+          V3 rot{P.ap_amp[i][4] * wgt, P.ap_amp[i][5] * wgt, P.ap_amp[i][6] * wgt};
+          auto_pose = add_pose(auto_pose, Pose{pos, euler_to_quat(rot, false)});
+        }
+      }
+      rb.puti(R::I_APOSER, aposer);
+      if (complete == P.n_auto_posers) aps = PS_POSING_COMPLETE;
+      rword = (rword & ~(3 << RW_APS_SHIFT)) | (aps << RW_APS_SHIFT);
+      // LegPoser::updateAutoPose for this lane's leg (:1716-1778)
+      {
+        int sp = lc.neg_start, ep = lc.neg_end, np = master_phase;
+        if (sp > ep) {
+          ep += P.pose_phase_length;
+          if (np < sp) np += P.pose_phase_length;
+        }
+        int st = s.word & 3;
+        bool neg = (s.word & LW_NEG) != 0;
+        if (st != SS_FORCE_STANCE && st != SS_FORCE_STOP && np == sp) neg = true;
+        if (np < sp || np > ep) neg = false;
+        s.word = neg ? (s.word | LW_NEG) : (s.word & ~LW_NEG);
+        leg_auto = auto_pose;
+        if (neg) {
+          int iteration = np - sp + 1, num = ep - sp;
+          bool first_half = iteration <= num / 2;
+          double ci = 1.0;
+          if (lc.neg_ratio > 0.0) {
+            if (first_half) ci = fmin(1.0, iteration / (num * lc.neg_ratio));
+            else ci = fmin(1.0, (num - iteration) / (num * lc.neg_ratio));
+          }
+          ci = smooth_step(ci);
+          Pose negation = interpolate_pose(pose_identity(), ci, auto_pose);
+          leg_auto = remove_pose(auto_pose, negation);
+        }
+      }
+      cp = add_pose(cp, auto_pose);
+      if (FT::incl(P)) rb.putq(R::APREV, auto_pose.r);
+    }
+    rb.putpose(R::CPOSE, cp);
+  } else {
+    cp = rb.getpose(R::CPOSE);
   }
-  s.cpose = cp;
-  int pose_state = (s.rword >> RW_APS_SHIFT) & 3; // walker_->setPoseState (state_controller.cpp:168)
+  SHC_PHASE_FENCE();
+  int pose_state = (rword >> RW_APS_SHIFT) & 3; // walker_->setPoseState (state_controller.cpp:168)
 
   // =============================================================== AdmittanceController (:22-134)
-  s.adm_delta = V3{0, 0, 0};
-  if (P.admittance_control) {
+  out.adm_delta = V3{0, 0, 0};
+  if (FT::adm(P)) {
     // updateStiffness only feeds the published per-leg virtual_stiffness_ (state_controller.cpp:889); updateAdmittance
     // reads the global parameters (admittance_controller.cpp:35-37), so nothing of it reaches the joint path.
-    V3 f = (P.use_joint_effort ? s.tf : s.force_in) * P.force_gain;
+    // tip_force_measured_ is an input held in HBM (L2-resident across the cycles of one launch)
+    V3 force_in{(legd + (Fields<NJ>::FORCE_IN + 0) * ns)[slot], (legd + (Fields<NJ>::FORCE_IN + 1) * ns)[slot],
+                (legd + (Fields<NJ>::FORCE_IN + 2) * ns)[slot]};
+    V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
     double fi[3] = {f.x, f.y, f.z}, d[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -389,15 +502,16 @@ __device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, cons
       d[i] = clampd(-x0, -0.2, 0.2); // ADMITTANCE_DEADBAND == 0: delta passes through unchanged
     }
     // Leg::setAdmittanceDelta (model.h:365-368): projection on the tip's x axis (robot frame) of the current FK
-    V3 tipx = base_rotate(lc, chain.xe);
-    s.adm_delta = projection(V3{d[0], d[1], d[2]}, tipx);
+    out.adm_delta = projection(V3{d[0], d[1], d[2]}, s.tipx);
   }
 
+  SHC_PHASE_FENCE();
   // =============================================================== WalkController::updateWalk (:440-648)
+  const double vin_x = rb.get(R::VIN), vin_y = rb.get(R::VIN + 1), win = rb.get(R::WIN);
   // ---- getLimit x 4 (:414-436): bracket index per leg, min over the robot's legs
-  double lim[4];
-  {
-    double sx = s.vin_x + s.win * (-s.tip.y), sy = s.vin_y + s.win * s.tip.x;
+  double lim[4] = {0.05, 0.3, 0.02, 0.1};
+  if (!(SHC_DBG(P) & 2)) {
+    double sx = vin_x + win * (-s.tip.y), sy = vin_y + win * s.tip.x;
     int bearing = mod_i(round_to_int(rad2deg(atan2(sy, sx))), 360);
     int upper = ((bearing + 44) / 45) * 45;
     // control_input is an int / int division in the reference: 1 iff bearing == upper bound, else 0
@@ -411,63 +525,69 @@ __device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, cons
       for (int k = 0; k < 4; ++k) lim[k] = fmin(lim[k], C.limit[k][ij]);
     }
   }
-  double nvx, nvy, nw;
-  double lin_norm = sqrt(s.vin_x * s.vin_x + s.vin_y * s.vin_y);
-  if (walk_state != WS_STOPPING) {
-    if (P.velocity_input_mode == 0) { // throttle
-      double cx = s.vin_x, cy = s.vin_y;
-      if (lin_norm > 1.0) {
-        double k = 1.0 / lin_norm;
-        cx *= k;
-        cy *= k;
-      }
-      nvx = cx * lim[0];
-      nvy = cy * lim[0];
-      nw = clampd(s.win, -1.0, 1.0) * lim[1];
-      double sc = 1.0 - fabs(s.win);
-      nvx *= sc;
-      nvy *= sc;
-    } else {
-      double cx = s.vin_x, cy = s.vin_y;
-      if (lin_norm > lim[0]) {
-        double k = lim[0] / lin_norm;
-        cx *= k;
-        cy *= k;
-      }
-      nw = clampd(s.win, -lim[1], lim[1]);
-      double sc = lim[1] != 0.0 ? (1.0 - fabs(nw / lim[1])) : 0.0;
-      nvx = cx * sc;
-      nvy = cy * sc;
-    }
-  } else {
-    nvx = nvy = nw = 0.0;
-  }
-  bool has_cmd = (lin_norm != 0.0) || (s.win != 0.0);
+  SHC_PHASE_FENCE();
+  double vx = rb.get(R::VLIN), vy = rb.get(R::VLIN + 1), vw = rb.get(R::VANG);
+  const double lin_norm = sqrt(vin_x * vin_x + vin_y * vin_y);
   {
-    double ax = nvx - s.vx, ay = nvy - s.vy;
+    double nvx, nvy, nw;
+    if (walk_state != WS_STOPPING) {
+      if (P.velocity_input_mode == 0) { // throttle
+        double cx = vin_x, cy = vin_y;
+        if (lin_norm > 1.0) {
+          double k = 1.0 / lin_norm;
+          cx *= k;
+          cy *= k;
+        }
+        nvx = cx * lim[0];
+        nvy = cy * lim[0];
+        nw = clampd(win, -1.0, 1.0) * lim[1];
+        double sc = 1.0 - fabs(win);
+        nvx *= sc;
+        nvy *= sc;
+      } else {
+        double cx = vin_x, cy = vin_y;
+        if (lin_norm > lim[0]) {
+          double k = lim[0] / lin_norm;
+          cx *= k;
+          cy *= k;
+        }
+        nw = clampd(win, -lim[1], lim[1]);
+        double sc = lim[1] != 0.0 ? (1.0 - fabs(nw / lim[1])) : 0.0;
+        nvx = cx * sc;
+        nvy = cy * sc;
+      }
+    } else {
+      nvx = nvy = nw = 0.0;
+    }
+    double ax = nvx - vx, ay = nvy - vy;
     double an2 = ax * ax + ay * ay;
     double an = sqrt(an2);
     double cap = lim[2] * P.dt;
     if (an < cap) {
-      s.vx += ax;
-      s.vy += ay;
+      vx += ax;
+      vy += ay;
     } else {
       double nx = ax, ny = ay;
       if (an2 > 0.0) {
         nx = ax / an;
         ny = ay / an;
       }
-      s.vx += nx * lim[2] * P.dt;
-      s.vy += ny * lim[2] * P.dt;
+      vx += nx * lim[2] * P.dt;
+      vy += ny * lim[2] * P.dt;
     }
-    double aa = nw - s.vw;
-    if (fabs(aa) < lim[3] * P.dt) s.vw += aa;
-    else s.vw += signd(aa) * lim[3] * P.dt;
+    double aa = nw - vw;
+    if (fabs(aa) < lim[3] * P.dt) vw += aa;
+    else vw += signd(aa) * lim[3] * P.dt;
+    rb.put(R::VLIN, vx);
+    rb.put(R::VLIN + 1, vy);
+    rb.put(R::VANG, vw);
   }
+  const bool has_cmd = (lin_norm != 0.0) || (win != 0.0);
 
+  SHC_PHASE_FENCE();
   // ---- walk state machine (:529-564)
-  int lacp = (s.rword >> RW_LACP_SHIFT) & 15, lcfs = (s.rword >> RW_LCFS_SHIFT) & 15;
-  bool rtda = (s.rword & RW_RTDA) != 0;
+  int lacp = (rword >> RW_LACP_SHIFT) & 15, lcfs = (rword >> RW_LCFS_SHIFT) & 15;
+  bool rtda = (rword & RW_RTDA) != 0;
   bool early_return = false;
   int my_state = s.word & 3, my_phase = (s.word >> LW_PHASE_SHIFT) & LW_PHASE_MASK;
   bool my_acp = (s.word & LW_ACP) != 0, my_cfs = (s.word & LW_CFS) != 0;
@@ -541,19 +661,24 @@ __device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, cons
       }
     }
   }
-  s.rword = (s.rword & ~(3 | (15 << RW_LACP_SHIFT) | (15 << RW_LCFS_SHIFT) | RW_RTDA)) | walk_state | (lacp << RW_LACP_SHIFT) |
-            (lcfs << RW_LCFS_SHIFT) | (rtda ? RW_RTDA : 0);
+  rword = (rword & ~(3 | (15 << RW_LACP_SHIFT) | (15 << RW_LCFS_SHIFT) | RW_RTDA)) | walk_state | (lacp << RW_LACP_SHIFT) |
+          (lcfs << RW_LCFS_SHIFT) | (rtda ? RW_RTDA : 0);
+  rb.puti(R::I_WORD, rword);
   int my_pm = (s.word >> LW_PM_SHIFT) & 3;
+  SHC_PHASE_FENCE();
 
-  bool default_changed = false;
   if (!early_return) {
-    // ---- LegStepper::updateDefaultTipPosition (:984-1014) on the STOPPING -> FORCE_STOP edge
-    if (my_update_default) {
-      // stance_span_modifier is 0 on this path -> calculateStanceSpanChange() == 0 (:949-980)
-      V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y, 0.0}); // leg_->getDefaultBodyPose() == walk_plane_pose_
-      V3 proj = projection(s.torg - idp, s.pnorm_prev);
-      s.dflt = idp + proj;
-      default_changed = true;
+    bool default_changed = false;
+    // ---- LegStepper::updateDefaultTipPosition (:984-1014) on the STOPPING -> FORCE_STOP edge (rare)
+    if (__any(my_update_default)) {
+      if (my_update_default) {
+        // stance_span_modifier is 0 on this path -> calculateStanceSpanChange() == 0 (:949-980)
+        Pose wpp = rb.getpose(R::WPP); // leg_->getDefaultBodyPose() == walk_plane_pose_
+        V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y, 0.0});
+        V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM_PREV));
+        pk.put3(PK_DFLT, idp + proj);
+        default_changed = true;
+      }
     }
     // ---- LegStepper::updateTipPosition (:1018-1189)
     bool standard = (my_state == SS_SWING) || my_cfs;
@@ -561,28 +686,34 @@ __device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, cons
     int stance_iter = standard ? P.stance_iterations : lc.first_stance_iterations;
     int mss = standard ? P.stance_start : lc.phase_offset;
     double stance_dt = 1.0 / stance_iter;
-    s.targ = s.dflt + s.strd * 0.5; // uses last cycle's stride (:1044 precedes updateStride)
+    const V3 dflt = pk.get3(PK_DFLT);
+    s.targ = dflt + s.strd * 0.5; // uses last cycle's stride (:1044 precedes updateStride)
     bool stepping = my_state != SS_FORCE_STOP;
-    if (stepping) {
+    if (stepping && !(SHC_DBG(P) & 4)) {
       // updateStride (:921-945)
-      V3 radius{s.tip.x, s.tip.y, 0.0}; // rejection of the tip position from +z
-      V3 sv{s.vx - s.vw * radius.y, s.vy + s.vw * radius.x, 0.0};
+      V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0}; // v + w z^ x (tip rejected from z^)
       s.strd = sv * P.stride_scale;
-      V3 clearance = normalized(s.pnorm) * P.swing_height;
+      V3 clearance = normalized(rb.get3(R::PNORM)) * P.swing_height;
       V3 dpos;
       if (my_state == SS_SWING) {
         int iteration = my_phase - P.swing_start + 1;
         bool first_half = iteration <= P.swing_iterations / 2;
+        V3 sorg, svel;
         if (iteration == 1) {
-          s.sorg = s.tip;
-          s.svel = s.tvel;
+          sorg = s.tip;
+          svel = s.tvel;
+          pk.put3(PK_SORG, sorg);
+          pk.put3(PK_SVEL, svel);
+        } else {
+          sorg = pk.get3(PK_SORG);
+          svel = pk.get3(PK_SVEL);
         }
         // generatePrimarySwingControlNodes (:1238-1261)
-        V3 mid{(s.sorg.x + s.targ.x) / 2.0, (s.sorg.y + s.targ.y) / 2.0, fmax(s.sorg.z, s.targ.z)};
+        V3 mid{(sorg.x + s.targ.x) / 2.0, (sorg.y + s.targ.y) / 2.0, fmax(sorg.z, s.targ.z)};
         mid = mid + clearance;
         mid.y += (lc.stance_y > 0.0) ? P.swing_width : -P.swing_width;
-        V3 sep1 = (s.svel * 0.25) * (P.dt / P.swing_delta_t);
-        V3 n1_0 = s.sorg, n1_1 = s.sorg + sep1, n1_2 = s.sorg + sep1 * 2.0;
+        V3 sep1 = (svel * 0.25) * (P.dt / P.swing_delta_t);
+        V3 n1_0 = sorg, n1_1 = sorg + sep1, n1_2 = sorg + sep1 * 2.0;
         V3 n1_3{(mid.x + n1_2.x) / 2.0, (mid.y + n1_2.y) / 2.0, mid.z};
         V3 n1_4 = mid;
         // generateSecondarySwingControlNodes (:1265-1291)
@@ -591,7 +722,7 @@ __device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, cons
         V3 n2_0 = n1_4, n2_1 = n1_4 - (n1_3 - n1_4), n2_2 = s.targ - sep2 * 2.0, n2_3 = s.targ - sep2, n2_4 = s.targ;
         if (P.force_normal_touchdown) { // forceNormalTouchdown (:1314-1329)
           V3 bo = s.targ - sep2 * 4.0;
-          bo.z = fmax(s.sorg.z, s.targ.z);
+          bo.z = fmax(sorg.z, s.targ.z);
           bo = bo + clearance;
           n1_4 = bo;
           n2_0 = bo;
@@ -609,12 +740,18 @@ __device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, cons
         }
       } else { // STANCE / FORCE_STANCE
         int iteration = mod_i(my_phase + (P.period - mss), P.period) + 1;
-        if (iteration == 1) s.torg = s.tip;
+        V3 torg;
+        if (iteration == 1) {
+          torg = s.tip;
+          pk.put3(PK_TORG, torg);
+        } else {
+          torg = pk.get3(PK_TORG);
+        }
         double stride_scaler = double(msp) / double(P.stance_period);
         V3 sep = ((-s.strd) * stride_scaler) * 0.25;
         double t = iteration * stance_dt;
         // five collinear equispaced nodes (:1295-1310)
-        dpos = quartic_bezier_dot(s.torg, s.torg + sep, s.torg + sep * 2.0, s.torg + sep * 3.0, s.torg + sep * 4.0, t) * stance_dt;
+        dpos = quartic_bezier_dot(torg, torg + sep, torg + sep * 2.0, torg + sep * 3.0, torg + sep * 4.0, t) * stance_dt;
       }
       s.tip = s.tip + dpos;
       s.tvel = V3{dpos.x / P.dt, dpos.y / P.dt, dpos.z / P.dt};
@@ -632,52 +769,64 @@ __device__ __forceinline__ void cycle(Lane<L, NJ> &s, const CycleParams &P, cons
     // ---- updateWalkPlane (:748-779): least-squares plane through the default tip positions.  The fit only changes
     //      when a default tip changed, which is a rare event -> recompute under a wave-uniform guard (bit-identical).
     if (any_stepping) { // the stepping legs' saved copies (LegStepper::walk_plane_) now hold the pre-update walker plane
-      s.plane_prev = s.plane;
-      s.pnorm_prev = s.pnorm;
+      rb.put3(R::PLANE_PREV, rb.get3(R::PLANE));
+      rb.put3(R::PNORM_PREV, rb.get3(R::PNORM));
     }
     if (__any(default_changed)) {
-      double x = s.dflt.x, y = s.dflt.y, z = s.dflt.z;
+      const V3 nd = pk.get3(PK_DFLT);
+      double x = nd.x, y = nd.y, z = nd.z;
       double sxx = g.sum(x * x), sxy = g.sum(x * y), sx = g.sum(x), syy = g.sum(y * y), sy = g.sum(y);
       double sxz = g.sum(x * z), syz = g.sum(y * z), sz = g.sum(z);
-      if (L >= 3) {
-        // (A^T A)^-1 A^T b with A = [x y 1]
-        double a00 = sxx, a01 = sxy, a02 = sx, a11 = syy, a12 = sy, a22 = double(L);
-        double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
-        double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
-        double det = a00 * c00 + a01 * c01 + a02 * c02;
-        double pa = (c00 * sxz + c01 * syz + c02 * sz) / det;
-        double pb = (c01 * sxz + c11 * syz + c12 * sz) / det;
-        double pc = (c02 * sxz + c12 * syz + c22 * sz) / det;
-        s.plane = V3{pa, pb, pc};
-        s.pnorm = normalized(V3{-pa, -pb, 1.0});
-      }
+      // (A^T A)^-1 A^T b with A = [x y 1]
+      double a00 = sxx, a01 = sxy, a02 = sx, a11 = syy, a12 = sy, a22 = double(L);
+      double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+      double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+      double det = a00 * c00 + a01 * c01 + a02 * c02;
+      double pa = (c00 * sxz + c01 * syz + c02 * sz) / det;
+      double pb = (c01 * sxz + c11 * syz + c12 * sz) / det;
+      double pc = (c02 * sxz + c12 * syz + c22 * sz) / det;
+      rb.put3(R::PLANE, V3{pa, pb, pc});
+      rb.put3(R::PNORM, normalized(V3{-pa, -pb, 1.0}));
     }
   }
   s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL)) |
            my_state | (my_acp ? LW_ACP : 0) | (my_cfs ? LW_CFS : 0) | (my_pm << LW_PM_SHIFT) | (my_phase << LW_PHASE_SHIFT);
 
+  SHC_PHASE_FENCE();
   // =============================================================== PoseController::updateStance (:110-141)
   {
     Pose bp = cp;
-    if (P.auto_posing && !P.imu_posing) {
+    if (FT::autop(P) && !FT::imu(P)) {
       bp = remove_pose(bp, auto_pose);
       bp = add_pose(bp, leg_auto);
     }
-    s.poser_tip = inverse_transform_vector(bp, s.tip);
+    out.poser_tip = inverse_transform_vector(bp, s.tip);
   }
 
+  SHC_PHASE_FENCE();
   // =============================================================== Model::updateModel (model.cpp:142-152)
   {
-    V3 desired = s.poser_tip + s.adm_delta; // Leg::setDesiredTipPose (:653-663)
-    double dq[NJ];
-    ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
-    update_joints<NJ>(lc, dq, P.dt, P.clamp_joint_velocities != 0, P.clamp_joint_positions != 0, s.q, s.qd);
-    fk_chain<NJ>(lc, s.q, chain); // Leg::applyFK (:904): also next cycle's Jacobian configuration
-    s.model_tip = tip_robot_frame(lc, chain.pe);
-    V3 e = s.model_tip - desired;
+    V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
+    Chain<NJ> chain;
+    if (!(SHC_DBG(P) & 8)) {
+      chain_from_sincos<NJ>(lc, s.sn, s.cs, chain); // joint transforms left by the previous applyFK (model.cpp:731,744)
+      double dq[NJ];
+      ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
+      update_joints<NJ>(lc, dq, P.dt, P.clamp_joint_velocities != 0, P.clamp_joint_positions != 0, s.q, s.qd);
+    }
+    SHC_PHASE_FENCE();
+    if (!(SHC_DBG(P) & 16)) joint_sincos<NJ>(lc, s.q, s.sn, s.cs); // Leg::applyFK (:904)
+    chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
+    SHC_PHASE_FENCE();
+    out.model_tip = tip_robot_frame(lc, chain.pe);
+    if (FT::adm(P)) s.tipx = base_rotate(lc, chain.xe);
+    V3 e = out.model_tip - desired;
     if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) s.word |= LW_IKFAIL; // :916-929
-    if (P.tip_force) { // Leg::calculateTipForce (:667-708)
-      V3 raw = tip_force_raw<NJ>(lc, chain, s.effort);
+    if (FT::tipf(P)) { // Leg::calculateTipForce (:667-708)
+      double effort[NJ];
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) effort[i] = (legd + (Fields<NJ>::EFFORT_IN + i) * ns)[slot]; // Joint::current_effort_ input
+      V3 raw = tip_force_raw<NJ>(lc, chain, effort);
       s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
     }
   }

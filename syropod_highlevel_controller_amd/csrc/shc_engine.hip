@@ -14,6 +14,10 @@
 
 using namespace shc;
 
+#ifndef SHC_WAVES_PER_SIMD
+#define SHC_WAVES_PER_SIMD 2
+#endif
+
 static thread_local std::string g_last_error;
 static int fail(int code, const std::string &msg) {
   g_last_error = msg;
@@ -27,196 +31,180 @@ static int fail(int code, const std::string &msg) {
 
 // ================================================================================================= kernels
 
-template <int L, int NJ>
-__device__ __forceinline__ void load_lane(Lane<L, NJ> &s, const DevState &st, const CycleParams &P, int64_t slot, int64_t rob) {
-  using F = Fields<NJ>;
-  using R = RobotFields;
-  const double *ld = st.legd + slot;
-  const int64_t ns = st.n_slots;
+// Field plane f of the per-leg SoA state: wave-uniform base pointer + 32-bit lane offset.
+struct LegPlanes {
+  double *base;
+  int64_t ns;
+  uint32_t slot;
+  __device__ __forceinline__ double &operator()(int f) const { return (base + f * ns)[slot]; }
+  __device__ __forceinline__ void st3(int f, V3 v) const {
+    (*this)(f) = v.x;
+    (*this)(f + 1) = v.y;
+    (*this)(f + 2) = v.z;
+  }
+};
+
+template <int NJ, unsigned F>
+__device__ __forceinline__ void load_leg(LegRegs<NJ> &s, const Park &pk, const DevState &st, const CycleParams &P, uint32_t slot) {
+  using FD = Fields<NJ>;
+  using FT = Feat<F>;
+  // plane pointers are wave-uniform (SGPR base), the lane offset is 32-bit: global_load saddr + voffset addressing
+  const LegPlanes ld{st.legd, st.n_slots, slot};
+  s.word = st.legi[slot];
+  // swing origin / stance origin / default tip go straight to the per-lane LDS strip (SORG, SVEL, TORG, DFLT are contiguous planes)
+  static_assert(FD::SVEL == FD::SORG + 3 && FD::TORG == FD::SORG + 6 && FD::DFLT == FD::SORG + 9, "park layout");
+#pragma unroll
+  for (int k = 0; k < PK_COUNT; ++k) pk.d[k * 64 + pk.lane] = ld(FD::SORG + k);
+  s.tip = V3{ld(FD::TIP + 0), ld(FD::TIP + 1), ld(FD::TIP + 2)};
+  s.targ = V3{ld(FD::TARG + 0), ld(FD::TARG + 1), ld(FD::TARG + 2)};
+  s.strd = V3{ld(FD::STRD + 0), ld(FD::STRD + 1), ld(FD::STRD + 2)};
+  s.tvel = V3{ld(FD::TVEL + 0), ld(FD::TVEL + 1), ld(FD::TVEL + 2)};
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
-    s.q[i] = ld[(F::Q + i) * ns];
-    s.qd[i] = ld[(F::QD + i) * ns];
+    s.q[i] = ld(FD::Q + i);
+    s.qd[i] = ld(FD::QD + i);
   }
-  s.tip = ldv3(ld + F::TIP * ns, ns);
-  s.tvel = ldv3(ld + F::TVEL * ns, ns);
-  s.sorg = ldv3(ld + F::SORG * ns, ns);
-  s.svel = ldv3(ld + F::SVEL * ns, ns);
-  s.torg = ldv3(ld + F::TORG * ns, ns);
-  s.dflt = ldv3(ld + F::DFLT * ns, ns);
-  s.targ = ldv3(ld + F::TARG * ns, ns);
-  s.strd = ldv3(ld + F::STRD * ns, ns);
   s.adm0 = s.adm1 = 0.0;
   s.tf = V3{0, 0, 0};
-  s.force_in = V3{0, 0, 0};
-  if (P.admittance_control) {
-    s.adm0 = ld[(F::ADM + 0) * ns];
-    s.adm1 = ld[(F::ADM + 1) * ns];
-    s.force_in = ldv3(ld + F::FORCE_IN * ns, ns);
+  if (FT::adm(P)) {
+    s.adm0 = ld(FD::ADM + 0);
+    s.adm1 = ld(FD::ADM + 1);
   }
-#pragma unroll
-  for (int i = 0; i < NJ; ++i) s.effort[i] = 0.0;
-  if (P.tip_force) {
-    s.tf = ldv3(ld + F::TF * ns, ns);
-#pragma unroll
-    for (int i = 0; i < NJ; ++i) s.effort[i] = ld[(F::EFFORT_IN + i) * ns];
-  }
-  s.word = st.legi[slot];
-
-  const double *rd = st.robd + rob;
-  const int64_t nr = st.n_rob_pad;
-  s.vx = rd[(R::VLIN + 0) * nr];
-  s.vy = rd[(R::VLIN + 1) * nr];
-  s.vw = rd[R::VANG * nr];
-  s.plane = ldv3(rd + R::PLANE * nr, nr);
-  s.pnorm = ldv3(rd + R::PNORM * nr, nr);
-  s.plane_prev = ldv3(rd + R::PLANE_PREV * nr, nr);
-  s.pnorm_prev = ldv3(rd + R::PNORM_PREV * nr, nr);
-  s.owpp.p = ldv3(rd + R::OWPP * nr, nr);
-  s.owpp.r = Quat{rd[(R::OWPP + 3) * nr], rd[(R::OWPP + 4) * nr], rd[(R::OWPP + 5) * nr], rd[(R::OWPP + 6) * nr]};
-  s.mpose = pose_identity();
-  s.tvi = s.rvi = V3{0, 0, 0};
-  s.reset_mode = 0;
-  if (P.manual_posing) {
-    s.mpose.p = ldv3(rd + R::MPOSE * nr, nr);
-    s.mpose.r = Quat{rd[(R::MPOSE + 3) * nr], rd[(R::MPOSE + 4) * nr], rd[(R::MPOSE + 5) * nr], rd[(R::MPOSE + 6) * nr]};
-    s.tvi = ldv3(rd + R::TVI * nr, nr);
-    s.rvi = ldv3(rd + R::RVI * nr, nr);
-    s.reset_mode = st.robi[R::I_RESET_MODE * nr + rob];
-  }
-  s.abse = s.verr = s.gyro = V3{0, 0, 0};
-  s.imuq = quat_identity();
-  s.aprev = quat_identity();
-  if (P.imu_posing) {
-    s.abse = ldv3(rd + R::ABSE * nr, nr);
-    s.verr = ldv3(rd + R::VERR * nr, nr);
-    s.gyro = ldv3(rd + R::GYRO * nr, nr);
-  }
-  if (P.imu_posing || P.inclination_posing || P.auto_posing)
-    s.imuq = Quat{rd[(R::IMUQ + 0) * nr], rd[(R::IMUQ + 1) * nr], rd[(R::IMUQ + 2) * nr], rd[(R::IMUQ + 3) * nr]};
-  if (P.inclination_posing && P.auto_posing)
-    s.aprev = Quat{rd[(R::APREV + 0) * nr], rd[(R::APREV + 1) * nr], rd[(R::APREV + 2) * nr], rd[(R::APREV + 3) * nr]};
-  s.vin_x = rd[(R::VIN + 0) * nr];
-  s.vin_y = rd[(R::VIN + 1) * nr];
-  s.win = rd[R::WIN * nr];
-  s.rword = st.robi[R::I_WORD * nr + rob];
-  s.aposer = 0;
-  s.pose_phase = 0;
-  if (P.auto_posing) {
-    s.aposer = st.robi[R::I_APOSER * nr + rob];
-    s.pose_phase = st.robi[R::I_POSE_PHASE * nr + rob];
-  }
+  if (FT::tipf(P)) s.tf = V3{ld(FD::TF + 0), ld(FD::TF + 1), ld(FD::TF + 2)};
 }
 
-template <int L, int NJ>
-__device__ __forceinline__ void store_lane(const Lane<L, NJ> &s, const DevState &st, const CycleParams &P, int64_t slot, int64_t rob,
-                                           bool leader) {
-  using F = Fields<NJ>;
-  using R = RobotFields;
-  double *ld = st.legd + slot;
-  const int64_t ns = st.n_slots;
+template <int NJ, unsigned F>
+__device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &out, const Park &pk, const DevState &st, const CycleParams &P,
+                                          uint32_t slot) {
+  using FD = Fields<NJ>;
+  using FT = Feat<F>;
+  const LegPlanes ld{st.legd, st.n_slots, slot};
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
-    ld[(F::Q + i) * ns] = s.q[i];
-    ld[(F::QD + i) * ns] = s.qd[i];
+    ld(FD::Q + i) = s.q[i];
+    ld(FD::QD + i) = s.qd[i];
   }
-  stv3(ld + F::TIP * ns, ns, s.tip);
-  stv3(ld + F::TVEL * ns, ns, s.tvel);
-  stv3(ld + F::SORG * ns, ns, s.sorg);
-  stv3(ld + F::SVEL * ns, ns, s.svel);
-  stv3(ld + F::TORG * ns, ns, s.torg);
-  stv3(ld + F::DFLT * ns, ns, s.dflt);
-  stv3(ld + F::TARG * ns, ns, s.targ);
-  stv3(ld + F::STRD * ns, ns, s.strd);
-  if (P.admittance_control) {
-    ld[(F::ADM + 0) * ns] = s.adm0;
-    ld[(F::ADM + 1) * ns] = s.adm1;
-    stv3(ld + F::ADM_DELTA * ns, ns, s.adm_delta);
+  ld.st3(FD::TIP, s.tip);
+  ld.st3(FD::TVEL, s.tvel);
+#pragma unroll
+  for (int k = 0; k < PK_COUNT; ++k) ld(FD::SORG + k) = pk.d[k * 64 + pk.lane];
+  ld.st3(FD::TARG, s.targ);
+  ld.st3(FD::STRD, s.strd);
+  if (FT::adm(P)) {
+    ld(FD::ADM + 0) = s.adm0;
+    ld(FD::ADM + 1) = s.adm1;
+    ld.st3(FD::ADM_DELTA, out.adm_delta);
   }
-  if (P.tip_force) stv3(ld + F::TF * ns, ns, s.tf);
-  stv3(ld + F::POSER_TIP * ns, ns, s.poser_tip);
-  stv3(ld + F::MODEL_TIP * ns, ns, s.model_tip);
+  if (FT::tipf(P)) ld.st3(FD::TF, s.tf);
+  ld.st3(FD::POSER_TIP, out.poser_tip);
+  ld.st3(FD::MODEL_TIP, out.model_tip);
   st.legi[slot] = s.word;
-  if (leader) {
-    double *rd = st.robd + rob;
-    const int64_t nr = st.n_rob_pad;
-    rd[(R::VLIN + 0) * nr] = s.vx;
-    rd[(R::VLIN + 1) * nr] = s.vy;
-    rd[R::VANG * nr] = s.vw;
-    stv3(rd + R::PLANE * nr, nr, s.plane);
-    stv3(rd + R::PNORM * nr, nr, s.pnorm);
-    stv3(rd + R::PLANE_PREV * nr, nr, s.plane_prev);
-    stv3(rd + R::PNORM_PREV * nr, nr, s.pnorm_prev);
-    stv3(rd + R::OWPP * nr, nr, s.owpp.p);
-    rd[(R::OWPP + 3) * nr] = s.owpp.r.w;
-    rd[(R::OWPP + 4) * nr] = s.owpp.r.x;
-    rd[(R::OWPP + 5) * nr] = s.owpp.r.y;
-    rd[(R::OWPP + 6) * nr] = s.owpp.r.z;
-    if (P.manual_posing) {
-      stv3(rd + R::MPOSE * nr, nr, s.mpose.p);
-      rd[(R::MPOSE + 3) * nr] = s.mpose.r.w;
-      rd[(R::MPOSE + 4) * nr] = s.mpose.r.x;
-      rd[(R::MPOSE + 5) * nr] = s.mpose.r.y;
-      rd[(R::MPOSE + 6) * nr] = s.mpose.r.z;
-      stv3(rd + R::TVI * nr, nr, s.tvi);
-      stv3(rd + R::RVI * nr, nr, s.rvi);
-    }
-    if (P.imu_posing) {
-      stv3(rd + R::ABSE * nr, nr, s.abse);
-      stv3(rd + R::VERR * nr, nr, s.verr);
-    }
-    if (P.inclination_posing && P.auto_posing) {
-      rd[(R::APREV + 0) * nr] = s.aprev.w;
-      rd[(R::APREV + 1) * nr] = s.aprev.x;
-      rd[(R::APREV + 2) * nr] = s.aprev.y;
-      rd[(R::APREV + 3) * nr] = s.aprev.z;
-    }
-    stv3(rd + R::CPOSE * nr, nr, s.cpose.p);
-    rd[(R::CPOSE + 3) * nr] = s.cpose.r.w;
-    rd[(R::CPOSE + 4) * nr] = s.cpose.r.x;
-    rd[(R::CPOSE + 5) * nr] = s.cpose.r.y;
-    rd[(R::CPOSE + 6) * nr] = s.cpose.r.z;
-    st.robi[R::I_WORD * nr + rob] = s.rword;
-    if (P.auto_posing) {
-      st.robi[R::I_APOSER * nr + rob] = s.aposer;
-      st.robi[R::I_POSE_PHASE * nr + rob] = s.pose_phase;
+}
+
+// Copy robot-field planes [f0, f1) of this wave's robots between HBM and the wave's LDS tile (lane-parallel, unrolled).
+template <int RPW, int F0, int F1, bool TO_LDS>
+__device__ __forceinline__ void copy_rob_fields(double *tile, double *robd, int64_t nr, int64_t rob0, int robots_here, int lane) {
+  constexpr int total = (F1 - F0) * RPW;
+  constexpr int iters = (total + 63) / 64;
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
+    int idx = it * 64 + lane;
+    int f = F0 + idx / RPW;
+    int r = idx % RPW;
+    if (idx < total && r < robots_here) {
+      if (TO_LDS) tile[f * RPW + r] = robd[f * nr + rob0 + r];
+      else robd[f * nr + rob0 + r] = tile[f * RPW + r];
     }
   }
 }
 
-// One launch = n_cycles control cycles of every robot; state lives in registers between cycles.
-template <int L, int NJ>
-__global__ void __launch_bounds__(256) shc_cycle_kernel(DevState st, CycleParams P, const SharedConsts<L, NJ> *gc, int n_cycles) {
+// One launch = n_cycles control cycles of every robot; per-leg state stays in registers, per-robot state in LDS.
+template <int L, int NJ, unsigned F>
+__global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles) {
+  using R = RobotFields;
+  using FT = Feat<F>;
+  constexpr int RPW = 64 / L; // robots per wavefront
+  constexpr int WPB = 4;      // waves per workgroup (max)
   __shared__ SharedConsts<L, NJ> C;
+  __shared__ double rob_d[WPB][R::COUNT * RPW];
+  __shared__ int32_t rob_i[WPB][R::I_COUNT * RPW];
+  __shared__ double park_d[WPB][PK_COUNT * 64];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+  const int64_t rob0 = wave * RPW;
+  const int64_t left = st.n_robots - rob0;
+  const int robots_here = left < RPW ? (left < 0 ? 0 : int(left)) : RPW;
+  // Lanes without a robot of their own (the 64 % L tail lanes and the groups past the end of the batch) mirror a
+  // live lane of the same leg in this wave so that every shuffle stays well defined; they never store.
+  int grp = lane / L;
+  const int leg = lane - grp * L;
+  const bool live = grp < robots_here;
+  if (grp >= robots_here) grp = robots_here > 0 ? robots_here - 1 : 0;
+  const uint32_t slot = uint32_t(wave * 64 + grp * L + leg);
+  Park pk{park_d[wib], lane};
+  LegRegs<NJ> s;
+  const CycleParams &GP = gc->P; // feature flags of the generic specialisation: read from HBM before the LDS copy lands
+  // 1. per-leg state: global loads issued first, so their HBM latency overlaps the table / tile staging below
+  if (robots_here > 0) load_leg<NJ, F>(s, pk, st, GP, slot);
+  // 2. launch-uniform tables -> LDS (independent loads, fully unrolled)
   {
     constexpr int n8 = sizeof(SharedConsts<L, NJ>) / 8;
     static_assert(sizeof(SharedConsts<L, NJ>) % 8 == 0, "const block must be a whole number of 8-byte words");
     const double *src = reinterpret_cast<const double *>(gc);
     double *dst = reinterpret_cast<double *>(&C);
-    for (int i = threadIdx.x; i < n8; i += blockDim.x) dst[i] = src[i];
+    constexpr int iters = (n8 + 63) / 64; // enough for a 64-thread workgroup
+    const int nt = blockDim.x;
+#pragma unroll
+    for (int it = 0; it < iters; ++it) {
+      int i = it * nt + threadIdx.x;
+      if (i < n8) dst[i] = src[i];
+    }
+  }
+  // 3. this wave's robot tile -> LDS
+  double *tile = rob_d[wib];
+  int32_t *tile_i = rob_i[wib];
+  if (robots_here > 0) {
+    const int64_t nr = st.n_rob_pad;
+    copy_rob_fields<RPW, 0, R::CORE_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (FT::manual(GP)) copy_rob_fields<RPW, R::MPOSE, R::MANUAL_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (FT::imu(GP)) copy_rob_fields<RPW, R::ABSE, R::IMU_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP))
+      copy_rob_fields<RPW, R::IMUQ, R::IMUQ_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (FT::incl(GP) && FT::autop(GP)) copy_rob_fields<RPW, R::APREV, R::APREV_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (lane < R::I_COUNT * RPW) {
+      int f = lane / RPW, r = lane % RPW;
+      if (r < robots_here) tile_i[f * RPW + r] = st.robi[f * nr + rob0 + r];
+    }
   }
   __syncthreads();
-  constexpr int RPW = 64 / L; // robots per wavefront
-  const int lane = threadIdx.x & 63;
-  const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-  if (wave * RPW >= st.n_robots) return; // whole wave past the end (wave-uniform)
-  const int64_t left = st.n_robots - wave * RPW;
-  const int robots_here = left < RPW ? int(left) : RPW;
-  // Lanes without a robot of their own (the 64 % L tail lanes and the groups past the end of the batch) mirror a
-  // live lane of the same leg in this wave so that every shuffle stays well defined; they never store.
-  int grp = lane / L;
-  int leg = lane - grp * L;
-  const bool live = grp < robots_here;
-  if (grp >= robots_here) grp = robots_here - 1;
-  const int64_t rob = wave * RPW + grp;
-  const int64_t slot = wave * 64 + grp * L + leg;
+  if (robots_here == 0) return; // whole wave past the end (wave-uniform)
+  const CycleParams &P = C.P;
   Group<L> g{grp * L};
-  Lane<L, NJ> s;
-  load_lane<L, NJ>(s, st, P, slot, rob);
-  Chain<NJ> chain;
-  fk_chain<NJ>(C.leg[leg], s.q, chain);
-  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ>(s, P, C, g, leg, chain);
-  if (live) store_lane<L, NJ>(s, st, P, slot, rob, leg == 0);
+  RobTile<RPW> rb{tile, tile_i, grp, live && leg == 0};
+  joint_sincos<NJ>(C.leg[leg], s.q, s.sn, s.cs); // FK of the stored joint state (Leg::applyFK of the previous cycle)
+  s.tipx = V3{1, 0, 0};
+  if (FT::adm(P)) {
+    Chain<NJ> ch;
+    chain_from_sincos<NJ>(C.leg[leg], s.sn, s.cs, ch);
+    s.tipx = base_rotate(C.leg[leg], ch.xe);
+  }
+  LegOut out;
+  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot);
+  if (live) store_leg<NJ, F>(s, out, pk, st, P, slot);
+  __builtin_amdgcn_wave_barrier(); // LDS ops of one wave complete in order: the tile now holds the leaders' updates
+  {
+    const int64_t nr = st.n_rob_pad;
+    copy_rob_fields<RPW, 0, R::VIN, false>(tile, st.robd, nr, rob0, robots_here, lane); // state (inputs VIN/WIN are not written back)
+    if (FT::manual(P)) copy_rob_fields<RPW, R::MPOSE, R::MANUAL_END, false>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (FT::imu(P)) copy_rob_fields<RPW, R::ABSE, R::GYRO, false>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (FT::incl(P) && FT::autop(P)) copy_rob_fields<RPW, R::APREV, R::APREV_END, false>(tile, st.robd, nr, rob0, robots_here, lane);
+    copy_rob_fields<RPW, R::CPOSE, R::COUNT, false>(tile, st.robd, nr, rob0, robots_here, lane);
+    if (lane < (R::I_POSE_PHASE + 1) * RPW) {
+      int f = lane / RPW, r = lane % RPW;
+      if (r < robots_here) st.robi[f * nr + rob0 + r] = tile_i[f * RPW + r];
+    }
+  }
 }
 
 // ---- layout conversion kernels (C ABI instance-major arrays <-> SoA fields)
@@ -315,8 +303,9 @@ struct shc_engine {
 };
 
 template <int L, int NJ>
-static void build_shared_consts(const shc_params &p, const shc_tables &t, SharedConsts<L, NJ> &c) {
+static void build_shared_consts(const shc_params &p, const shc_tables &t, const CycleParams &cp, SharedConsts<L, NJ> &c) {
   memset(&c, 0, sizeof c);
+  c.P = cp;
   const shc_step_cycle &step = t.step;
   for (int l = 0; l < L; ++l) {
     hostinit::fill_leg_const<NJ>(p, l, c.leg[l]);
@@ -376,6 +365,7 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.clamp_joint_velocities = p.clamp_joint_velocities;
   c.force_normal_touchdown = p.force_normal_touchdown;
   c.tip_force = (features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort ? 1 : 0;
+  if (const char *dbg = getenv("SHC_DEBUG_SKIP")) c.debug_skip = atoi(dbg);
   for (int i = 0; i < 3; ++i) {
     c.max_translation[i] = p.max_translation[i];
     c.max_rotation[i] = p.max_rotation[i];
@@ -407,6 +397,7 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   }
 }
 
+static int upload_consts(shc_engine *e);
 static int validate_params(const shc_params *p, int *L, int *NJ) {
   if (!p) return fail(SHC_ERR_INVALID_ARG, "params is NULL");
   if (p->leg_count < 3 || p->leg_count > SHC_MAX_LEGS) return fail(SHC_ERR_INVALID_ARG, "leg_count must be 3..8");
@@ -473,7 +464,7 @@ static int upload_consts(shc_engine *e) {
 #define CALL(L_, NJ_)                                                                                   \
   {                                                                                                     \
     SharedConsts<L_, NJ_> c;                                                                            \
-    build_shared_consts<L_, NJ_>(e->params, e->tables, c);                                              \
+    build_shared_consts<L_, NJ_>(e->params, e->tables, e->cp, c);                                              \
     if (!e->d_consts) HIP_TRY(hipMalloc(&e->d_consts, sizeof c));                                       \
     HIP_TRY(hipMemcpyAsync(e->d_consts, &c, sizeof c, hipMemcpyHostToDevice, e->stream));               \
     HIP_TRY(hipStreamSynchronize(e->stream));                                                           \
@@ -526,6 +517,8 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
   robt[R::APREV + 0] = 1.0;
   robt[R::CPOSE + 2] = e->params.body_clearance;
   robt[R::CPOSE + 3] = 1.0;
+  robt[R::WPP + 2] = e->params.body_clearance;
+  robt[R::WPP + 3] = 1.0;
   robi.assign(R::I_COUNT, 0);
   robi[R::I_WORD] = WS_STOPPED | (PS_POSING_COMPLETE << RW_APS_SHIFT);
 }
@@ -638,7 +631,7 @@ extern "C" int shc_engine_set_features(shc_engine *e, uint32_t features) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   e->features = features;
   build_cycle_params(e->params, e->tables, e->features, e->cp);
-  return SHC_OK;
+  return upload_consts(e);
 }
 
 extern "C" int shc_engine_get_tables(const shc_engine *e, shc_tables *out) {
@@ -748,6 +741,30 @@ extern "C" int shc_engine_set_pose_input(shc_engine *e, const double *translatio
   return scatter_rob(e, rotation_velocity, 3, RobotFields::RVI, on_device);
 }
 
+template <int L, int NJ, unsigned F>
+static void launch_cycle(shc_engine *e, unsigned grid, int block, int n_cycles) {
+  shc_cycle_kernel<L, NJ, F><<<dim3(grid), dim3(block), 0, e->stream>>>(e->st, (const SharedConsts<L, NJ> *)e->d_consts, n_cycles);
+}
+
+// Pick the kernel specialisation: the BASELINE.json configurations get feature-exact kernels (dead features cost
+// neither registers nor HBM traffic); every other flag combination runs the generic kernel (F_DYN).
+template <int L, int NJ, bool SPEC>
+static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cycles, bool specialised) {
+  const CycleParams &c = e->cp;
+  unsigned f = (c.manual_posing ? F_MANUAL : 0) | (c.auto_posing ? F_AUTO : 0) | (c.inclination_posing ? F_INCL : 0) |
+               (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0);
+  if constexpr (SPEC) {
+    if (specialised) switch (f) {
+      case F_MANUAL | F_TIPF: launch_cycle<L, NJ, F_MANUAL | F_TIPF>(e, grid, block, n_cycles); return;
+      case F_MANUAL: launch_cycle<L, NJ, F_MANUAL>(e, grid, block, n_cycles); return;
+      case F_MANUAL | F_IMU | F_ADM | F_TIPF: launch_cycle<L, NJ, F_MANUAL | F_IMU | F_ADM | F_TIPF>(e, grid, block, n_cycles); return;
+      case F_MANUAL | F_IMU | F_ADM: launch_cycle<L, NJ, F_MANUAL | F_IMU | F_ADM>(e, grid, block, n_cycles); return;
+      default: break;
+    }
+  }
+  launch_cycle<L, NJ, F_DYN>(e, grid, block, n_cycles);
+}
+
 extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1) return SHC_OK;
@@ -756,11 +773,21 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   const int block = (e->n_waves >= 1024) ? 256 : 64;
   const int64_t waves_per_block = block / 64;
   const unsigned grid = (unsigned)((e->n_waves + waves_per_block - 1) / waves_per_block);
-#define CALL(L_, NJ_)                                                                                                    \
-  shc_cycle_kernel<L_, NJ_><<<dim3(grid), dim3(block), 0, e->stream>>>(e->st, e->cp,                                     \
-                                                                       (const SharedConsts<L_, NJ_> *)e->d_consts, n_cycles)
-  SHC_DISPATCH(e->L, e->NJ, CALL);
-#undef CALL
+  const bool dyn = getenv("SHC_FORCE_GENERIC") != nullptr;
+  const int L = e->L, NJ = e->NJ;
+  if (L == 6 && NJ == 3) launch_cycle_feat<6, 3, true>(e, grid, block, n_cycles, !dyn);
+  else if (L == 8 && NJ == 5) launch_cycle_feat<8, 5, true>(e, grid, block, n_cycles, !dyn);
+  else if (L == 3 && NJ == 3) launch_cycle_feat<3, 3, false>(e, grid, block, n_cycles, false);
+  else if (L == 4 && NJ == 3) launch_cycle_feat<4, 3, false>(e, grid, block, n_cycles, false);
+  else if (L == 4 && NJ == 4) launch_cycle_feat<4, 4, false>(e, grid, block, n_cycles, false);
+  else if (L == 4 && NJ == 5) launch_cycle_feat<4, 5, false>(e, grid, block, n_cycles, false);
+  else if (L == 5 && NJ == 3) launch_cycle_feat<5, 3, false>(e, grid, block, n_cycles, false);
+  else if (L == 6 && NJ == 4) launch_cycle_feat<6, 4, false>(e, grid, block, n_cycles, false);
+  else if (L == 6 && NJ == 5) launch_cycle_feat<6, 5, false>(e, grid, block, n_cycles, false);
+  else if (L == 7 && NJ == 3) launch_cycle_feat<7, 3, false>(e, grid, block, n_cycles, false);
+  else if (L == 8 && NJ == 3) launch_cycle_feat<8, 3, false>(e, grid, block, n_cycles, false);
+  else if (L == 8 && NJ == 4) launch_cycle_feat<8, 4, false>(e, grid, block, n_cycles, false);
+  else return fail(SHC_ERR_UNSUPPORTED, "no kernel specialisation for this (legs, dof)");
   HIP_TRY(hipGetLastError());
   return SHC_OK;
 }

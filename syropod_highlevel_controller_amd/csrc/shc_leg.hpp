@@ -45,16 +45,22 @@ struct Chain {
   V3 xe;    // tip x-axis in the joint-1 frame
 };
 
-// Leg::applyFK chain product in the joint-1 frame.
+// sin / cos of the DH joint angles theta_k + q_k: the only transcendental part of Leg::applyFK.
 template <int NJ, class LC>
-SHC_HD void fk_chain(const LC &lc, const double (&q)[NJ], Chain<NJ> &c) {
+SHC_HD void joint_sincos(const LC &lc, const double (&q)[NJ], double (&sn)[NJ], double (&cs)[NJ]) {
+#pragma unroll
+  for (int k = 0; k < NJ; ++k) sincos(lc.link_th[k] + q[k], &sn[k], &cs[k]);
+}
+
+// Leg::applyFK chain product in the joint-1 frame from the joint sines / cosines.
+template <int NJ, class LC>
+SHC_HD void chain_from_sincos(const LC &lc, const double (&sn)[NJ], const double (&cs)[NJ], Chain<NJ> &c) {
   V3 X{1, 0, 0}, Y{0, 1, 0}, Z{0, 0, 1}, P{0, 0, 0};
   c.z[0] = Z;
   c.p[0] = P;
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
-    double s, co;
-    sincos(lc.link_th[k] + q[k], &s, &co);
+    double s = sn[k], co = cs[k];
     double sa = lc.link_sa[k], ca = lc.link_ca[k];
     V3 Xn = X * co + Y * s;
     V3 t = Y * co - X * s;
@@ -71,6 +77,13 @@ SHC_HD void fk_chain(const LC &lc, const double (&q)[NJ], Chain<NJ> &c) {
   }
   c.pe = P;
   c.xe = X;
+}
+
+template <int NJ, class LC>
+SHC_HD void fk_chain(const LC &lc, const double (&q)[NJ], Chain<NJ> &c) {
+  double sn[NJ], cs[NJ];
+  joint_sincos<NJ>(lc, q, sn, cs);
+  chain_from_sincos<NJ>(lc, sn, cs, c);
 }
 
 template <class LC>

@@ -16,7 +16,7 @@ import numpy as np
 from .params import Params, Tables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libshc_batch.so")
+_SO = os.environ.get("SHC_LIB") or os.path.join(_HERE, "libshc_batch.so")
 _SRC = os.path.join(_HERE, "csrc")
 _INC = os.path.join(os.path.dirname(_HERE), "include")
 
