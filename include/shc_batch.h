@@ -151,6 +151,9 @@ enum {
  * (0 when none; never an error) so a caller can fail loudly before creating an engine.
  */
 int shc_abi_version(void);
+/* sizeof(shc_params) / sizeof(shc_tables) as compiled into the library: lets a foreign-language binding check its layout */
+int64_t shc_sizeof_params(void);
+int64_t shc_sizeof_tables(void);
 int shc_device_count(void);
 const char *shc_last_error(void);
 
@@ -190,6 +193,8 @@ int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int o
 /* bodyPoseInputCallback (state_controller.cpp:1142): translation / rotation velocity inputs [n][3] each. */
 int shc_engine_set_pose_input(shc_engine *e, const double *translation_velocity, const double *rotation_velocity,
                               int on_device);
+/* poseResetCallback -> PoseController::setPoseResetMode (pose_controller.h:105): mode [n], SHC_NO_RESET .. SHC_IMMEDIATE_ALL_RESET. */
+int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode, int on_device);
 
 /*
  * Advance every instance by `n_cycles` control cycles (StateController::loop with robot_state

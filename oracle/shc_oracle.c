@@ -2299,6 +2299,11 @@ static void *batch_worker(void *arg)
   return NULL;
 }
 
+void orc_batch_set_pose_reset_mode(orc_batch *b, const int32_t *mode)
+{
+  for (int64_t i = 0; i < b->n; ++i) orc_set_pose_reset_mode(&b->robots[i], mode[i]);
+}
+
 double orc_batch_step(orc_batch *b, int n_cycles, int n_threads)
 {
   if (n_threads < 1) n_threads = 1;

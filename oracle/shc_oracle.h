@@ -74,6 +74,7 @@ void orc_batch_set_imu(orc_batch *b, const double *quat, const double *gyro);
 void orc_batch_set_tip_force(orc_batch *b, const double *force);
 void orc_batch_set_joint_effort(orc_batch *b, const double *effort);
 void orc_batch_set_pose_input(orc_batch *b, const double *tv, const double *rv);
+void orc_batch_set_pose_reset_mode(orc_batch *b, const int32_t *mode);
 double orc_batch_step(orc_batch *b, int n_cycles, int n_threads);
 void orc_batch_get_joint_state(orc_batch *b, double *q, double *qd);
 void orc_batch_get_leg_state(orc_batch *b, double *walker_tip, double *poser_tip, double *model_tip,

@@ -260,6 +260,10 @@ __global__ void gather_rob_kernel(double *dst, const double *robd, int64_t n_rob
   if (r >= n) return;
   for (int k = 0; k < K; ++k) dst[r * K + k] = robd[(f0 + k) * n_rob_pad + r];
 }
+__global__ void scatter_robi_kernel(const int32_t *src, int32_t *robi, int64_t n_rob_pad, int64_t n, int f) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r < n) robi[f * n_rob_pad + r] = src[r];
+}
 __global__ void gather_walk_state_kernel(int32_t *dst, const int32_t *robi, int64_t n) {
   int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -421,6 +425,8 @@ static int generate_tables_nj(const shc_params *p, shc_tables *out) {
 }
 
 extern "C" int shc_abi_version(void) { return 1; }
+extern "C" int64_t shc_sizeof_params(void) { return (int64_t)sizeof(shc_params); }
+extern "C" int64_t shc_sizeof_tables(void) { return (int64_t)sizeof(shc_tables); }
 
 extern "C" int shc_device_count(void) {
   int n = 0;
@@ -763,6 +769,22 @@ static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cyc
     }
   }
   launch_cycle<L, NJ, F_DYN>(e, grid, block, n_cycles);
+}
+
+extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (!mode) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const int32_t *d = mode;
+  if (!on_device) {
+    HIP_TRY(hipMemcpyAsync(e->d_stage, mode, size_t(e->n) * 4, hipMemcpyHostToDevice, e->stream));
+    d = reinterpret_cast<const int32_t *>(e->d_stage);
+  }
+  scatter_robi_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robi, e->n_rob_pad, e->n,
+                                                                                       RobotFields::I_RESET_MODE);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
 }
 
 extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {

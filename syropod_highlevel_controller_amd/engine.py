@@ -23,10 +23,10 @@ _INC = os.path.join(os.path.dirname(_HERE), "include")
 SHC_OK, SHC_ERR_INVALID_ARG, SHC_ERR_NO_DEVICE, SHC_ERR_HIP, SHC_ERR_UNSUPPORTED, SHC_ERR_UNSTABLE = range(6)
 
 EXPORTED_SYMBOLS = [
-    "shc_abi_version", "shc_device_count", "shc_last_error", "shc_generate_tables", "shc_engine_create",
+    "shc_abi_version", "shc_sizeof_params", "shc_sizeof_tables", "shc_device_count", "shc_last_error", "shc_generate_tables", "shc_engine_create",
     "shc_engine_destroy", "shc_engine_set_stream", "shc_engine_set_features", "shc_engine_get_tables",
     "shc_engine_instances", "shc_engine_set_velocity", "shc_engine_set_imu", "shc_engine_set_tip_force",
-    "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_step", "shc_engine_synchronize",
+    "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_set_pose_reset_mode", "shc_engine_step", "shc_engine_synchronize",
     "shc_engine_get_joint_state", "shc_engine_joint_buffer", "shc_engine_joint_index", "shc_engine_get_leg_state",
     "shc_engine_get_body_state",
 ]
@@ -68,6 +68,8 @@ def lib():
             build_library()
         L = C.CDLL(_SO)
         L.shc_last_error.restype = C.c_char_p
+        L.shc_sizeof_params.restype = C.c_int64
+        L.shc_sizeof_tables.restype = C.c_int64
         L.shc_generate_tables.argtypes = [C.POINTER(Params), C.POINTER(Tables)]
         L.shc_engine_create.argtypes = [C.POINTER(Params), C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.shc_engine_destroy.argtypes = [C.c_void_p]
@@ -77,7 +79,7 @@ def lib():
         L.shc_engine_instances.restype = C.c_int64
         L.shc_engine_instances.argtypes = [C.c_void_p]
         for name, n in (("shc_engine_set_velocity", 2), ("shc_engine_set_imu", 2), ("shc_engine_set_tip_force", 1),
-                        ("shc_engine_set_joint_effort", 1), ("shc_engine_set_pose_input", 2)):
+                        ("shc_engine_set_joint_effort", 1), ("shc_engine_set_pose_input", 2), ("shc_engine_set_pose_reset_mode", 1)):
             getattr(L, name).argtypes = [C.c_void_p] + [C.c_void_p] * n + [C.c_int]
         L.shc_engine_step.argtypes = [C.c_void_p, C.c_int]
         L.shc_engine_synchronize.argtypes = [C.c_void_p]
@@ -172,6 +174,10 @@ class BatchEngine:
     def set_pose_input(self, translation_velocity=None, rotation_velocity=None):
         a, b = _host(translation_velocity), _host(rotation_velocity)
         _check(self.L.shc_engine_set_pose_input(self.h, _p(a), _p(b), 0), "set_pose_input")
+
+    def set_pose_reset_mode(self, mode):
+        a = _host(mode, np.int32)
+        _check(self.L.shc_engine_set_pose_reset_mode(self.h, _p(a), 0), "set_pose_reset_mode")
 
     # -- inputs (device pointers, e.g. torch tensors' data_ptr())
     def set_velocity_device(self, linear_ptr: Optional[int], angular_ptr: Optional[int]):

@@ -64,6 +64,7 @@ def lib():
         L.orc_batch_set_tip_force.argtypes = [C.c_void_p, _dp]
         L.orc_batch_set_joint_effort.argtypes = [C.c_void_p, _dp]
         L.orc_batch_set_pose_input.argtypes = [C.c_void_p, _dp, _dp]
+        L.orc_batch_set_pose_reset_mode.argtypes = [C.c_void_p, _ip]
         L.orc_batch_step.restype = C.c_double
         L.orc_batch_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_batch_get_joint_state.argtypes = [C.c_void_p, _dp, _dp]
@@ -203,6 +204,10 @@ class OracleBatch:
         tv = np.ascontiguousarray(tv, dtype=np.float64)
         rv = np.ascontiguousarray(rv, dtype=np.float64)
         self.L.orc_batch_set_pose_input(self.h, _ptr(tv), _ptr(rv))
+
+    def set_pose_reset_mode(self, mode):
+        mode = np.ascontiguousarray(mode, dtype=np.int32)
+        self.L.orc_batch_set_pose_reset_mode(self.h, _ptr(mode, _ip))
 
     def step(self, n_cycles=1, threads=1) -> float:
         return self.L.orc_batch_step(self.h, n_cycles, threads)

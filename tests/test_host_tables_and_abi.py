@@ -1,0 +1,86 @@
+"""CPU: the product's host init chain (libshc_batch.so, no GPU needed) against the oracle's, and the C ABI surface."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleRobot
+from syropod_highlevel_controller_amd import Params, Tables, default_hexapod_params, engine, synthetic_octopod_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def cases():
+    for g in ("tripod", "wave", "ripple", "amble"):
+        yield f"hexapod-{g}", default_hexapod_params(g)
+    yield "octopod-ripple-5dof", synthetic_octopod_params("ripple", 5, 8)
+    yield "quadruped-tripod-4dof", synthetic_octopod_params("tripod", 4, 4)
+
+
+@pytest.mark.parametrize("name,p", list(cases()), ids=[c[0] for c in cases()])
+def test_tables_match_oracle(name, p):
+    o = OracleRobot(p).tables()
+    t = engine.generate_tables(p)
+    L, NJ = p.leg_count, p.leg_dof[0]
+    for f in ("period", "swing_period", "stance_period", "stance_end", "swing_start", "swing_end", "stance_start"):
+        assert getattr(o.step, f) == getattr(t.step, f)                      # integers: bit-exact
+    assert o.step.frequency == t.step.frequency
+    assert list(o.phase_offset)[:L] == list(t.phase_offset)[:L]
+    assert (o.pose_phase_length, o.pose_normaliser, o.auto_pose_reference_leg) == (t.pose_phase_length, t.pose_normaliser, t.auto_pose_reference_leg)
+    dq = max(abs(o.default_joint_position[l][j] - t.default_joint_position[l][j]) for l in range(L) for j in range(NJ))
+    assert dq < 1e-6                                                          # start-up solve: 300 DLS steps each
+    for l in range(L):
+        np.testing.assert_allclose(list(t.workspace_radius[l]), list(o.workspace_radius[l]), atol=1e-9)
+    for f in ("walkspace", "max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration"):
+        np.testing.assert_allclose(list(getattr(t, f)), list(getattr(o, f)), rtol=1e-9, atol=1e-12)
+        assert all(v > 0 for v in getattr(t, f))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "shc_batch.h")).read()
+    declared = set(re.findall(r"\b(shc_[a-z_]+)\s*\(", hdr))
+    declared -= {"shc_engine"}
+    assert declared == set(engine.EXPORTED_SYMBOLS), declared ^ set(engine.EXPORTED_SYMBOLS)
+    lib = C.CDLL(engine.build_library())
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.shc_abi_version() == 1
+
+
+def test_struct_layouts_match_the_library():
+    lib = engine.lib()
+    assert lib.shc_sizeof_params() == C.sizeof(Params)
+    assert lib.shc_sizeof_tables() == C.sizeof(Tables)
+
+
+def test_unsupported_parameters_are_rejected():
+    p = default_hexapod_params("tripod")
+    p.rough_terrain_mode = 1
+    with pytest.raises(engine.ShcError):
+        engine.generate_tables(p)
+    p = default_hexapod_params("tripod")
+    p.leg_dof[2] = 4
+    with pytest.raises(engine.ShcError):
+        engine.generate_tables(p)
+
+
+def test_no_cpu_fallback_without_a_device():
+    """The product path must fail loudly when there is no HIP device (no silent CPU path)."""
+    if engine.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(engine.ShcError):
+        engine.BatchEngine(default_hexapod_params("tripod"), 8)
+    h = C.c_void_p()
+    p = default_hexapod_params("tripod")
+    rc = engine.lib().shc_engine_create(C.byref(p), 8, 0, None, C.byref(h))
+    assert rc == engine.SHC_ERR_NO_DEVICE and not h.value
+
+
+def test_product_does_not_reference_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "syropod_highlevel_controller_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "liboracle" not in src and "oracle_lib" not in src and "shc_oracle" not in src, f
