@@ -34,13 +34,12 @@ ALG_BYTES_PER_CYCLE = {("hexapod", 2): 3008, ("hexapod", 3): 3560, ("octopod", 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
 
 
-def make_workload(name, n, seed):
+def make_workload(name, n, seed, rank=0):
     from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
-    rng = np.random.default_rng(seed)
-    r = np.sqrt(rng.uniform(0.04, 1.0, size=n))
-    th = rng.uniform(0, 2 * np.pi, size=n)
-    lin = np.stack([r * np.cos(th), r * np.sin(th)], axis=1)  # uniform in the unit disc (|v| >= 0.2 so every robot walks)
-    ang = rng.uniform(-1.0, 1.0, size=n)
+    from syropod_highlevel_controller_amd.parallel import velocity_inputs
+    # instance ranges are contiguous per rank; inputs are keyed by the GLOBAL instance id (parallel.py)
+    lin, ang = velocity_inputs(seed, rank * n, (rank + 1) * n)  # uniform in the unit disc, |v| >= 0.2: every robot walks
+    rng = np.random.default_rng(seed + 7919 * rank)
     extra = {}
     if name == "config2":
         p = default_hexapod_params("tripod")
@@ -109,6 +108,7 @@ def main():
     ap.add_argument("--cycles-per-step", type=int, default=1)
     ap.add_argument("--gather-every", type=int, default=0, help="all-gather the joint buffer every G steps (0 = once, at the end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-probe", action="store_true", help="skip the secondary 16-cycles-per-launch figure (keeps rocprof stats to one launch shape)")
     ap.add_argument("--seed", type=int, default=0xC0FFEE)
     args = ap.parse_args()
 
@@ -130,7 +130,7 @@ def main():
     from syropod_highlevel_controller_amd.engine import BatchEngine
 
     n = args.instances or {"config2": 4096, "config3": 65536, "config4": 131072}[args.workload]
-    p, lin, ang, extra, key, desc = make_workload(args.workload, n, args.seed + rank)
+    p, lin, ang, extra, key, desc = make_workload(args.workload, n, args.seed, rank)
     stream = torch.cuda.current_stream()
     eng = BatchEngine(p, n, device=local_rank, stream=stream.cuda_stream)
     apply_inputs(eng, lin * 0.0, ang * 0.0, extra)
@@ -139,17 +139,22 @@ def main():
     #      then walk until every instance is MOVING.
     period = eng.tables().step.period
     groups = 8
+    cps = args.cycles_per_step
+
+    def advance(cycles):  # same launch shape as the timed region, so a profile of this process sees one kernel shape
+        for _ in range((cycles + cps - 1) // cps):
+            eng.step(cps)
+
     for gk in range(groups):
         sel = (np.arange(n) % groups) <= gk
         eng.set_velocity(lin * sel[:, None], ang * sel)
-        eng.step(max(1, period // groups))
+        advance(max(1, period // groups))
     eng.set_velocity(lin, ang)
-    eng.step(2 * period + 64)
+    advance(2 * period + 64)
     eng.synchronize()
     _, _, ws = eng.body_state()
     moving_frac = float((ws == 1).mean())
 
-    cps = args.cycles_per_step
     gathered = None
     if world > 1:
         gathered = torch.empty(world * n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda")
@@ -194,6 +199,18 @@ def main():
         b.record(stream)
     torch.cuda.synchronize()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # ---- secondary figure: 16 control cycles fused per launch (inputs held, state in registers between cycles)
+    fused_value = None
+    if cps == 1 and world == 1 and not args.no_fused_probe:
+        fc, reps = 16, max(4, args.steps // 16)
+        for _ in range(3):
+            eng.step(fc)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(reps):
+            eng.step(fc)
+        torch.cuda.synchronize()
+        fused_value = n * fc * reps / (time.perf_counter() - tf0)
     q, _ = eng.joints()
     finite = bool(np.isfinite(q).all())
 
@@ -217,7 +234,8 @@ def main():
                        "cycles_per_step": cps, "legs": p.leg_count, "dof": p.leg_dof[0],
                        "gather": f"all-gather of the joint buffer every {args.gather_every} steps" if args.gather_every
                        else "one all-gather of the final joint buffer (N > 1)",
-                       "moving_fraction": moving_frac, "finite": finite, "seed": args.seed},
+                       "moving_fraction": moving_frac, "finite": finite, "seed": args.seed,
+                       "fused_16_cycles_per_launch_value": fused_value},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},

@@ -207,6 +207,11 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   }
 }
 
+__global__ void shc_plane_copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
+  int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 // ---- layout conversion kernels (C ABI instance-major arrays <-> SoA fields)
 __device__ __forceinline__ int64_t slot_of(int64_t rob, int leg, int L) {
   int rpw = 64 / L;
@@ -435,6 +440,21 @@ extern "C" int shc_device_count(void) {
 }
 
 extern "C" const char *shc_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int shc_debug_plane_copy(int device, int64_t n_doubles, int reps) {
+  if (n_doubles < 1 || reps < 1) return fail(SHC_ERR_INVALID_ARG, "n_doubles and reps must be >= 1");
+  HIP_TRY(hipSetDevice(device));
+  double *a, *b;
+  HIP_TRY(hipMalloc(&a, size_t(n_doubles) * 8));
+  HIP_TRY(hipMalloc(&b, size_t(n_doubles) * 8));
+  HIP_TRY(hipMemset(a, 0, size_t(n_doubles) * 8));
+  for (int r = 0; r < reps; ++r)
+    shc_plane_copy_kernel<<<dim3((unsigned)((n_doubles + 255) / 256)), dim3(256)>>>(a, b, n_doubles);
+  HIP_TRY(hipDeviceSynchronize());
+  (void)hipFree(a);
+  (void)hipFree(b);
+  return SHC_OK;
+}
 
 extern "C" int shc_generate_tables(const shc_params *params, shc_tables *out) {
   int L, NJ;

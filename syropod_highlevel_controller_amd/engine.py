@@ -23,7 +23,7 @@ _INC = os.path.join(os.path.dirname(_HERE), "include")
 SHC_OK, SHC_ERR_INVALID_ARG, SHC_ERR_NO_DEVICE, SHC_ERR_HIP, SHC_ERR_UNSUPPORTED, SHC_ERR_UNSTABLE = range(6)
 
 EXPORTED_SYMBOLS = [
-    "shc_abi_version", "shc_sizeof_params", "shc_sizeof_tables", "shc_device_count", "shc_last_error", "shc_generate_tables", "shc_engine_create",
+    "shc_abi_version", "shc_sizeof_params", "shc_sizeof_tables", "shc_device_count", "shc_last_error", "shc_debug_plane_copy", "shc_generate_tables", "shc_engine_create",
     "shc_engine_destroy", "shc_engine_set_stream", "shc_engine_set_features", "shc_engine_get_tables",
     "shc_engine_instances", "shc_engine_set_velocity", "shc_engine_set_imu", "shc_engine_set_tip_force",
     "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_set_pose_reset_mode", "shc_engine_step", "shc_engine_synchronize",
@@ -69,6 +69,7 @@ def lib():
         L = C.CDLL(_SO)
         L.shc_last_error.restype = C.c_char_p
         L.shc_sizeof_params.restype = C.c_int64
+        L.shc_debug_plane_copy.argtypes = [C.c_int, C.c_int64, C.c_int]
         L.shc_sizeof_tables.restype = C.c_int64
         L.shc_generate_tables.argtypes = [C.POINTER(Params), C.POINTER(Tables)]
         L.shc_engine_create.argtypes = [C.POINTER(Params), C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
