@@ -112,7 +112,16 @@ struct DevState {
 
 // Phase fence: keeps the machine scheduler from hoisting the next phase's LDS/const loads above this point, which
 // bounds live ranges to one phase (the fused cycle is one huge basic block otherwise -> ~470 live VGPRs).
+#ifndef SHC_PHASE_FENCE
 #define SHC_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+// Development-only phase timestamps (build with -DSHC_TIMING): wave 0 / lane 0 stores s_memtime at phase boundaries.
+#ifdef SHC_TIMING
+__device__ long long *shc_tick_buf = nullptr;
+#define SHC_TICK(i) do { __builtin_amdgcn_sched_barrier(0); if (shc_tick_on) shc_tick_buf[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SHC_TICK(i) do {} while (0)
+#endif
 #ifndef SHC_DBG
 #define SHC_DBG(P) ((P).debug_skip)
 #endif
@@ -232,6 +241,10 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   const CycleParams &P = (&C.P)[zero];
   const LegConst<NJ> &lc = C.leg[leg + zero];
   const V3 UZ{0, 0, 1};
+#ifdef SHC_TIMING
+  const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
+#endif
+  SHC_TICK(2);
 
   // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611)
   {
@@ -246,6 +259,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
 
   SHC_PHASE_FENCE();
+  SHC_TICK(3);
   int rword = rb.geti(R::I_WORD);
   int walk_state = rword & 3;
 
@@ -480,6 +494,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     cp = rb.getpose(R::CPOSE);
   }
   SHC_PHASE_FENCE();
+  SHC_TICK(4);
   int pose_state = (rword >> RW_APS_SHIFT) & 3; // walker_->setPoseState (state_controller.cpp:168)
 
   // =============================================================== AdmittanceController (:22-134)
@@ -526,6 +541,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     }
   }
   SHC_PHASE_FENCE();
+  SHC_TICK(5);
   double vx = rb.get(R::VLIN), vy = rb.get(R::VLIN + 1), vw = rb.get(R::VANG);
   const double lin_norm = sqrt(vin_x * vin_x + vin_y * vin_y);
   {
@@ -585,6 +601,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   const bool has_cmd = (lin_norm != 0.0) || (win != 0.0);
 
   SHC_PHASE_FENCE();
+  SHC_TICK(6);
   // ---- walk state machine (:529-564)
   int lacp = (rword >> RW_LACP_SHIFT) & 15, lcfs = (rword >> RW_LCFS_SHIFT) & 15;
   bool rtda = (rword & RW_RTDA) != 0;
@@ -664,6 +681,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   rword = (rword & ~(3 | (15 << RW_LACP_SHIFT) | (15 << RW_LCFS_SHIFT) | RW_RTDA)) | walk_state | (lacp << RW_LACP_SHIFT) |
           (lcfs << RW_LCFS_SHIFT) | (rtda ? RW_RTDA : 0);
   rb.puti(R::I_WORD, rword);
+  SHC_TICK(7);
   int my_pm = (s.word >> LW_PM_SHIFT) & 3;
   SHC_PHASE_FENCE();
 
@@ -793,6 +811,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
            my_state | (my_acp ? LW_ACP : 0) | (my_cfs ? LW_CFS : 0) | (my_pm << LW_PM_SHIFT) | (my_phase << LW_PHASE_SHIFT);
 
   SHC_PHASE_FENCE();
+  SHC_TICK(8);
   // =============================================================== PoseController::updateStance (:110-141)
   {
     Pose bp = cp;
@@ -806,6 +825,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   SHC_PHASE_FENCE();
   // =============================================================== Model::updateModel (model.cpp:142-152)
   {
+    SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
     Chain<NJ> chain;
     if (!(SHC_DBG(P) & 8)) {
@@ -815,9 +835,11 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       update_joints<NJ>(lc, dq, P.dt, P.clamp_joint_velocities != 0, P.clamp_joint_positions != 0, s.q, s.qd);
     }
     SHC_PHASE_FENCE();
+    SHC_TICK(10);
     if (!(SHC_DBG(P) & 16)) joint_sincos<NJ>(lc, s.q, s.sn, s.cs); // Leg::applyFK (:904)
     chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
     SHC_PHASE_FENCE();
+    SHC_TICK(11);
     out.model_tip = tip_robot_frame(lc, chain.pe);
     if (FT::adm(P)) s.tipx = base_rotate(lc, chain.xe);
     V3 e = out.model_tip - desired;
@@ -830,6 +852,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
     }
   }
+  SHC_TICK(12);
 }
 
 #endif // __HIPCC__

@@ -101,20 +101,36 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   st.legi[slot] = s.word;
 }
 
-// Copy robot-field planes [f0, f1) of this wave's robots between HBM and the wave's LDS tile (lane-parallel, unrolled).
-template <int RPW, int F0, int F1, bool TO_LDS>
-__device__ __forceinline__ void copy_rob_fields(double *tile, double *robd, int64_t nr, int64_t rob0, int robots_here, int lane) {
+// Robot state lives in HBM as one contiguous tile per wave, [wave][field][RPW] (AoSoA): staging fields [F0, F1) of this
+// wave's robots to / from the LDS tile is a straight coalesced copy of (F1 - F0) * RPW doubles.
+template <int RPW, int F0, int F1>
+__device__ __forceinline__ void load_rob_fields(double (&reg)[((F1 - F0) * RPW + 63) / 64], const double *gtile, int lane) {
   constexpr int total = (F1 - F0) * RPW;
   constexpr int iters = (total + 63) / 64;
 #pragma unroll
   for (int it = 0; it < iters; ++it) {
     int idx = it * 64 + lane;
-    int f = F0 + idx / RPW;
-    int r = idx % RPW;
-    if (idx < total && r < robots_here) {
-      if (TO_LDS) tile[f * RPW + r] = robd[f * nr + rob0 + r];
-      else robd[f * nr + rob0 + r] = tile[f * RPW + r];
-    }
+    reg[it] = idx < total ? gtile[F0 * RPW + idx] : 0.0;
+  }
+}
+template <int RPW, int F0, int F1>
+__device__ __forceinline__ void put_rob_fields(const double (&reg)[((F1 - F0) * RPW + 63) / 64], double *tile, int lane) {
+  constexpr int total = (F1 - F0) * RPW;
+  constexpr int iters = (total + 63) / 64;
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
+    int idx = it * 64 + lane;
+    if (idx < total) tile[F0 * RPW + idx] = reg[it];
+  }
+}
+template <int RPW, int F0, int F1>
+__device__ __forceinline__ void store_rob_fields(const double *tile, double *gtile, int lane) {
+  constexpr int total = (F1 - F0) * RPW;
+  constexpr int iters = (total + 63) / 64;
+#pragma unroll
+  for (int it = 0; it < iters; ++it) {
+    int idx = it * 64 + lane;
+    if (idx < total) gtile[F0 * RPW + idx] = tile[F0 * RPW + idx];
   }
 }
 
@@ -129,6 +145,10 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   __shared__ double rob_d[WPB][R::COUNT * RPW];
   __shared__ int32_t rob_i[WPB][R::I_COUNT * RPW];
   __shared__ double park_d[WPB][PK_COUNT * 64];
+#ifdef SHC_TIMING
+  const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
+#endif
+  SHC_TICK(0);
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -145,39 +165,59 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   Park pk{park_d[wib], lane};
   LegRegs<NJ> s;
   const CycleParams &GP = gc->P; // feature flags of the generic specialisation: read from HBM before the LDS copy lands
-  // 1. per-leg state: global loads issued first, so their HBM latency overlaps the table / tile staging below
-  if (robots_here > 0) load_leg<NJ, F>(s, pk, st, GP, slot);
-  // 2. launch-uniform tables -> LDS (independent loads, fully unrolled)
-  {
-    constexpr int n8 = sizeof(SharedConsts<L, NJ>) / 8;
-    static_assert(sizeof(SharedConsts<L, NJ>) % 8 == 0, "const block must be a whole number of 8-byte words");
-    const double *src = reinterpret_cast<const double *>(gc);
-    double *dst = reinterpret_cast<double *>(&C);
-    constexpr int iters = (n8 + 63) / 64; // enough for a 64-thread workgroup
-    const int nt = blockDim.x;
-#pragma unroll
-    for (int it = 0; it < iters; ++it) {
-      int i = it * nt + threadIdx.x;
-      if (i < n8) dst[i] = src[i];
-    }
-  }
-  // 3. this wave's robot tile -> LDS
   double *tile = rob_d[wib];
   int32_t *tile_i = rob_i[wib];
-  if (robots_here > 0) {
-    const int64_t nr = st.n_rob_pad;
-    copy_rob_fields<RPW, 0, R::CORE_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (FT::manual(GP)) copy_rob_fields<RPW, R::MPOSE, R::MANUAL_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (FT::imu(GP)) copy_rob_fields<RPW, R::ABSE, R::IMU_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP))
-      copy_rob_fields<RPW, R::IMUQ, R::IMUQ_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (FT::incl(GP) && FT::autop(GP)) copy_rob_fields<RPW, R::APREV, R::APREV_END, true>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (lane < R::I_COUNT * RPW) {
-      int f = lane / RPW, r = lane % RPW;
-      if (r < robots_here) tile_i[f * RPW + r] = st.robi[f * nr + rob0 + r];
+  double *gtile = st.robd + wave * (R::COUNT * RPW);
+  int32_t *gtile_i = st.robi + wave * (R::I_COUNT * RPW);
+  // ---- prologue: every global load of this wave is issued before the first wait, so the HBM / L2 latencies overlap:
+  //      (1) launch-uniform tables, (2) this wave's robot tile, (3) per-leg state; then the LDS writes; then one barrier.
+  constexpr int n8 = sizeof(SharedConsts<L, NJ>) / 8;
+  static_assert(sizeof(SharedConsts<L, NJ>) % 8 == 0, "const block must be a whole number of 8-byte words");
+  constexpr int citers = (n8 + 63) / 64; // enough for a 64-thread workgroup
+  double creg[citers];
+  {
+    const double *src = reinterpret_cast<const double *>(gc);
+    const int nt = blockDim.x;
+#pragma unroll
+    for (int it = 0; it < citers; ++it) {
+      int i = it * nt + threadIdx.x;
+      creg[it] = i < n8 ? src[i] : 0.0;
     }
   }
+  double t_core[(R::CORE_END * RPW + 63) / 64], t_man[((R::MANUAL_END - R::MPOSE) * RPW + 63) / 64],
+      t_imu[((R::IMU_END - R::ABSE) * RPW + 63) / 64], t_imuq[((R::IMUQ_END - R::IMUQ) * RPW + 63) / 64],
+      t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64];
+  int32_t t_int = 0;
+  const bool any_robot = robots_here > 0;
+  if (any_robot) {
+    load_rob_fields<RPW, 0, R::CORE_END>(t_core, gtile, lane);
+    if (FT::manual(GP)) load_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, gtile, lane);
+    if (FT::imu(GP)) load_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, gtile, lane);
+    if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
+    if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
+    if (lane < R::I_COUNT * RPW) t_int = gtile_i[lane];
+    load_leg<NJ, F>(s, pk, st, GP, slot);
+  }
+  {
+    double *dst = reinterpret_cast<double *>(&C);
+    const int nt = blockDim.x;
+#pragma unroll
+    for (int it = 0; it < citers; ++it) {
+      int i = it * nt + threadIdx.x;
+      if (i < n8) dst[i] = creg[it];
+    }
+  }
+  if (any_robot) {
+    put_rob_fields<RPW, 0, R::CORE_END>(t_core, tile, lane);
+    if (FT::manual(GP)) put_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, tile, lane);
+    if (FT::imu(GP)) put_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, tile, lane);
+    if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
+    if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
+    if (lane < R::I_COUNT * RPW) tile_i[lane] = t_int;
+  }
+  SHC_TICK(18);
   __syncthreads();
+  SHC_TICK(19);
   if (robots_here == 0) return; // whole wave past the end (wave-uniform)
   const CycleParams &P = C.P;
   Group<L> g{grp * L};
@@ -190,21 +230,19 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
     s.tipx = base_rotate(C.leg[leg], ch.xe);
   }
   LegOut out;
+  SHC_TICK(1);
   for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot);
   if (live) store_leg<NJ, F>(s, out, pk, st, P, slot);
+  SHC_TICK(13);
   __builtin_amdgcn_wave_barrier(); // LDS ops of one wave complete in order: the tile now holds the leaders' updates
-  {
-    const int64_t nr = st.n_rob_pad;
-    copy_rob_fields<RPW, 0, R::VIN, false>(tile, st.robd, nr, rob0, robots_here, lane); // state (inputs VIN/WIN are not written back)
-    if (FT::manual(P)) copy_rob_fields<RPW, R::MPOSE, R::MANUAL_END, false>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (FT::imu(P)) copy_rob_fields<RPW, R::ABSE, R::GYRO, false>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (FT::incl(P) && FT::autop(P)) copy_rob_fields<RPW, R::APREV, R::APREV_END, false>(tile, st.robd, nr, rob0, robots_here, lane);
-    copy_rob_fields<RPW, R::CPOSE, R::COUNT, false>(tile, st.robd, nr, rob0, robots_here, lane);
-    if (lane < (R::I_POSE_PHASE + 1) * RPW) {
-      int f = lane / RPW, r = lane % RPW;
-      if (r < robots_here) st.robi[f * nr + rob0 + r] = tile_i[f * RPW + r];
-    }
-  }
+  // state planes back to this wave's HBM tile (the inputs VIN / WIN / GYRO / IMUQ are not written back)
+  store_rob_fields<RPW, 0, R::VIN>(tile, gtile, lane);
+  if (FT::manual(P)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
+  if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
+  if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
+  store_rob_fields<RPW, R::CPOSE, R::COUNT>(tile, gtile, lane);
+  if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
+  SHC_TICK(14);
 }
 
 __global__ void shc_plane_copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
@@ -247,32 +285,36 @@ __global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int6
   dst[t] = (w & 3) | ((w & LW_IKFAIL) ? 4 : 0) | (phase << 8);
 }
 // AoS [n][K] -> robot fields
-__global__ void scatter_rob_kernel(const double *src, double *robd, int64_t n_rob_pad, int64_t n, int K, int f0, int normalize_quat) {
+__device__ __forceinline__ int64_t rob_index(int64_t r, int f, int rpw, int nf) { return ((r / rpw) * nf + f) * rpw + (r % rpw); }
+
+__global__ void scatter_rob_kernel(const double *src, double *robd, int rpw, int64_t n, int K, int f0, int normalize_quat) {
+  constexpr int nf = RobotFields::COUNT;
   int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
   if (normalize_quat) { // Model::setImuData normalises the orientation (model.h:150)
     Quat q = normalized(Quat{src[r * 4], src[r * 4 + 1], src[r * 4 + 2], src[r * 4 + 3]});
-    robd[(f0 + 0) * n_rob_pad + r] = q.w;
-    robd[(f0 + 1) * n_rob_pad + r] = q.x;
-    robd[(f0 + 2) * n_rob_pad + r] = q.y;
-    robd[(f0 + 3) * n_rob_pad + r] = q.z;
+    robd[rob_index(r, f0 + 0, rpw, nf)] = q.w;
+    robd[rob_index(r, f0 + 1, rpw, nf)] = q.x;
+    robd[rob_index(r, f0 + 2, rpw, nf)] = q.y;
+    robd[rob_index(r, f0 + 3, rpw, nf)] = q.z;
     return;
   }
-  for (int k = 0; k < K; ++k) robd[(f0 + k) * n_rob_pad + r] = src[r * K + k];
+  for (int k = 0; k < K; ++k) robd[rob_index(r, f0 + k, rpw, nf)] = src[r * K + k];
 }
-__global__ void gather_rob_kernel(double *dst, const double *robd, int64_t n_rob_pad, int64_t n, int K, int f0) {
+__global__ void gather_rob_kernel(double *dst, const double *robd, int rpw, int64_t n, int K, int f0) {
+  constexpr int nf = RobotFields::COUNT;
   int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  for (int k = 0; k < K; ++k) dst[r * K + k] = robd[(f0 + k) * n_rob_pad + r];
+  for (int k = 0; k < K; ++k) dst[r * K + k] = robd[rob_index(r, f0 + k, rpw, nf)];
 }
-__global__ void scatter_robi_kernel(const int32_t *src, int32_t *robi, int64_t n_rob_pad, int64_t n, int f) {
+__global__ void scatter_robi_kernel(const int32_t *src, int32_t *robi, int rpw, int64_t n, int f) {
   int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (r < n) robi[f * n_rob_pad + r] = src[r];
+  if (r < n) robi[rob_index(r, f, rpw, RobotFields::I_COUNT)] = src[r];
 }
-__global__ void gather_walk_state_kernel(int32_t *dst, const int32_t *robi, int64_t n) {
+__global__ void gather_walk_state_kernel(int32_t *dst, const int32_t *robi, int rpw, int64_t n) {
   int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
-  dst[r] = robi[r] & 3;
+  dst[r] = robi[rob_index(r, RobotFields::I_WORD, rpw, RobotFields::I_COUNT)] & 3;
 }
 // replicate the post-start-up state of one robot into every slot
 __global__ void init_state_kernel(DevState st, const double *leg_template /*[L][nf]*/, const int32_t *legw_template /*[L]*/,
@@ -288,8 +330,9 @@ __global__ void init_state_kernel(DevState st, const double *leg_template /*[L][
     st.legi[slot] = legw_template[leg];
   }
   if (t < n) {
-    for (int f = 0; f < nrf; ++f) st.robd[f * st.n_rob_pad + t] = rob_template[f];
-    for (int f = 0; f < nri; ++f) st.robi[f * st.n_rob_pad + t] = robi_template[f];
+    const int rpw = 64 / L;
+    for (int f = 0; f < nrf; ++f) st.robd[rob_index(t, f, rpw, nrf)] = rob_template[f];
+    for (int f = 0; f < nri; ++f) st.robi[rob_index(t, f, rpw, nri)] = robi_template[f];
   }
 }
 
@@ -440,6 +483,20 @@ extern "C" int shc_device_count(void) {
 }
 
 extern "C" const char *shc_last_error(void) { return g_last_error.c_str(); }
+
+#ifdef SHC_TIMING
+extern "C" int shc_debug_ticks(long long *out16) {
+  static long long *d = nullptr;
+  if (!d) {
+    HIP_TRY(hipMalloc(&d, 32 * 8));
+    HIP_TRY(hipMemset(d, 0, 32 * 8));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(shc_tick_buf), &d, sizeof d));
+  }
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out16, d, 32 * 8, hipMemcpyDeviceToHost));
+  return SHC_OK;
+}
+#endif
 
 extern "C" int shc_debug_plane_copy(int device, int64_t n_doubles, int reps) {
   if (n_doubles < 1 || reps < 1) return fail(SHC_ERR_INVALID_ARG, "n_doubles and reps must be >= 1");
@@ -609,15 +666,18 @@ extern "C" int shc_engine_create(const shc_params *params, int64_t n_instances, 
   const int rpw = 64 / L;
   e->n_waves = (n_instances + rpw - 1) / rpw;
   e->n_slots = e->n_waves * 64;
-  e->n_rob_pad = ((n_instances + 63) / 64) * 64;
+  e->n_rob_pad = e->n_waves * rpw; // robots incl. the padding of the last wave's tile
   e->n_leg_fields = NJ == 3 ? Fields<3>::COUNT : (NJ == 4 ? Fields<4>::COUNT : Fields<5>::COUNT);
   e->st.n_slots = e->n_slots;
   e->st.n_rob_pad = e->n_rob_pad;
   e->st.n_robots = e->n;
   HIP_TRY(hipMalloc(&e->st.legd, size_t(e->n_leg_fields) * e->n_slots * 8));
   HIP_TRY(hipMalloc(&e->st.legi, size_t(e->n_slots) * 4));
+  // robot state: one contiguous [field][rpw] tile per wave
   HIP_TRY(hipMalloc(&e->st.robd, size_t(RobotFields::COUNT) * e->n_rob_pad * 8));
   HIP_TRY(hipMalloc(&e->st.robi, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4));
+  HIP_TRY(hipMemsetAsync(e->st.robd, 0, size_t(RobotFields::COUNT) * e->n_rob_pad * 8, e->stream));
+  HIP_TRY(hipMemsetAsync(e->st.robi, 0, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4, e->stream));
   e->stage_bytes = size_t(e->n) * L * (NJ > 3 ? NJ : 3) * 8 + size_t(e->n) * 8 * 8;
   HIP_TRY(hipMalloc(&e->d_stage, e->stage_bytes));
   rc = upload_consts(e);
@@ -686,7 +746,7 @@ static int scatter_rob(shc_engine *e, const double *src, int K, int f0, int on_d
   const double *d;
   int rc = to_device(e, src, size_t(e->n) * K, on_device, &d);
   if (rc != SHC_OK) return rc;
-  scatter_rob_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robd, e->n_rob_pad, e->n, K, f0,
+  scatter_rob_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robd, 64 / e->L, e->n, K, f0,
                                                                                       normalize_quat);
   HIP_TRY(hipGetLastError());
   if (!on_device) HIP_TRY(hipStreamSynchronize(e->stream)); // the staging buffer is reused by the next call
@@ -724,7 +784,7 @@ static int gather_rob(shc_engine *e, double *dst, int K, int f0, int on_device) 
   if (!dst) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
   double *d = on_device ? dst : e->d_stage;
-  gather_rob_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robd, e->n_rob_pad, e->n, K, f0);
+  gather_rob_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robd, 64 / e->L, e->n, K, f0);
   HIP_TRY(hipGetLastError());
   if (!on_device) {
     HIP_TRY(hipMemcpyAsync(dst, d, size_t(e->n) * K * 8, hipMemcpyDeviceToHost, e->stream));
@@ -800,7 +860,7 @@ extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode
     HIP_TRY(hipMemcpyAsync(e->d_stage, mode, size_t(e->n) * 4, hipMemcpyHostToDevice, e->stream));
     d = reinterpret_cast<const int32_t *>(e->d_stage);
   }
-  scatter_robi_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robi, e->n_rob_pad, e->n,
+  scatter_robi_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robi, 64 / e->L, e->n,
                                                                                        RobotFields::I_RESET_MODE);
   HIP_TRY(hipGetLastError());
   if (!on_device) HIP_TRY(hipStreamSynchronize(e->stream));
@@ -894,7 +954,7 @@ extern "C" int shc_engine_get_body_state(shc_engine *e, double *pose, double *ve
   if (walk_state) {
     HIP_TRY(hipSetDevice(e->device));
     int32_t *d = on_device ? walk_state : reinterpret_cast<int32_t *>(e->d_stage);
-    gather_walk_state_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robi, e->n);
+    gather_walk_state_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robi, 64 / e->L, e->n);
     HIP_TRY(hipGetLastError());
     if (!on_device) {
       HIP_TRY(hipMemcpyAsync(walk_state, d, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));

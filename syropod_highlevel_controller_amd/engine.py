@@ -47,8 +47,11 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(_SO) and all(os.path.getmtime(s) <= os.path.getmtime(_SO) for s in _sources()):
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -disable-machine-licm: MachineLICM hoists the materialisation of ~100 FP64 literals (polynomial coefficients of
+    # sincos / atan2, tolerances) out of the n_cycles loop and pins them in VGPRs for the whole launch (256 VGPRs + scratch
+    # spills); re-materialising them at use keeps the hexapod kernel at 192 VGPRs with no scratch.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-o", _SO, os.path.join(_SRC, "shc_engine.hip")]
+           "-mllvm", "-disable-machine-licm", "-o", _SO, os.path.join(_SRC, "shc_engine.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
