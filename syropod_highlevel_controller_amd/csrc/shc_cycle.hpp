@@ -48,6 +48,9 @@ struct CycleParams {
   int32_t swing_iterations;  // walk_controller.cpp:1035-1036
   int32_t stance_iterations; // :1040 with the standard stance period
   double swing_delta_t;      // :1037
+  double inv_dt;             // 1 / time_delta
+  double dt_over_swing_dt;   // time_delta / swing_delta_t   (:1247, :1268)
+  double stance_dt;          // 1 / stance_iterations (standard stance period, :1041)
   double stride_scale;       // (stance_period / period) / frequency   (:940-941)
   double swing_height, swing_width, body_clearance;
   double swing_progress_scaler; // pose_controller.cpp:1103
@@ -271,13 +274,20 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     // ---- updateWalkPlanePose (:1092-1130)
     Pose wpp;
     {
+      // control input of the last leg (in id order) whose scaled swing progress lies in [0, 1]: each lane evaluates its
+      // own leg once (one division + smoothStep), the group picks the last valid one
+      double c_own = -1.0;
+      {
+        double sp = swing_progress_of(s.word, P) * P.swing_progress_scaler;
+        if (sp >= 0 && sp <= 1.0) c_own = smooth_step(sp);
+      }
       double c = 0.0;
       bool sel = false;
 #pragma unroll
       for (int j = 0; j < L; ++j) {
-        double sp = swing_progress_of(lw[j], P) * P.swing_progress_scaler;
-        if (sp >= 0 && sp <= 1.0) {
-          c = smooth_step(sp);
+        double cj = g.get(c_own, j);
+        if (cj >= 0.0) {
+          c = cj;
           sel = true;
         }
       }
@@ -527,7 +537,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   double lim[4] = {0.05, 0.3, 0.02, 0.1};
   if (!(SHC_DBG(P) & 2)) {
     double sx = vin_x + win * (-s.tip.y), sy = vin_y + win * s.tip.x;
-    int bearing = mod_i(round_to_int(rad2deg(atan2(sy, sx))), 360);
+    int bearing = mod_i(round_to_int(atan2(sy, sx) * (180.0 / kPi)), 360); // radiansToDegrees (standard_includes.h:69)
     int upper = ((bearing + 44) / 45) * 45;
     // control_input is an int / int division in the reference: 1 iff bearing == upper bound, else 0
     int idx = (bearing == upper) ? (upper % 360) / 45 : mod_i(upper - 45, 360) / 45;
@@ -703,7 +713,8 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     int msp = standard ? P.stance_period : lc.first_stance_period;
     int stance_iter = standard ? P.stance_iterations : lc.first_stance_iterations;
     int mss = standard ? P.stance_start : lc.phase_offset;
-    double stance_dt = 1.0 / stance_iter;
+    double stance_dt = standard ? P.stance_dt : lc.first_stance_dt; // 1 / stance_iterations (:1041)
+    (void)stance_iter;
     const V3 dflt = pk.get3(PK_DFLT);
     s.targ = dflt + s.strd * 0.5; // uses last cycle's stride (:1044 precedes updateStride)
     bool stepping = my_state != SS_FORCE_STOP;
@@ -711,7 +722,11 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       // updateStride (:921-945)
       V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0}; // v + w z^ x (tip rejected from z^)
       s.strd = sv * P.stride_scale;
-      V3 clearance = normalized(rb.get3(R::PNORM)) * P.swing_height;
+      V3 pn = rb.get3(R::PNORM);
+      // normalized() of the exact unit vector (0,0,1) is itself: skip the sqrt + 3 divisions on flat ground (bit-identical)
+      bool flat_n = pn.x == 0.0 && pn.y == 0.0 && pn.z == 1.0;
+      if (!__all(flat_n)) pn = normalized(pn);
+      V3 clearance = pn * P.swing_height;
       V3 dpos;
       if (my_state == SS_SWING) {
         int iteration = my_phase - P.swing_start + 1;
@@ -730,13 +745,13 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         V3 mid{(sorg.x + s.targ.x) / 2.0, (sorg.y + s.targ.y) / 2.0, fmax(sorg.z, s.targ.z)};
         mid = mid + clearance;
         mid.y += (lc.stance_y > 0.0) ? P.swing_width : -P.swing_width;
-        V3 sep1 = (svel * 0.25) * (P.dt / P.swing_delta_t);
+        V3 sep1 = (svel * 0.25) * P.dt_over_swing_dt;
         V3 n1_0 = sorg, n1_1 = sorg + sep1, n1_2 = sorg + sep1 * 2.0;
         V3 n1_3{(mid.x + n1_2.x) / 2.0, (mid.y + n1_2.y) / 2.0, mid.z};
         V3 n1_4 = mid;
         // generateSecondarySwingControlNodes (:1265-1291)
-        V3 fv = (-s.strd) * (stance_dt / P.dt);
-        V3 sep2 = (fv * 0.25) * (P.dt / P.swing_delta_t);
+        V3 fv = (-s.strd) * (stance_dt * P.inv_dt);
+        V3 sep2 = (fv * 0.25) * P.dt_over_swing_dt;
         V3 n2_0 = n1_4, n2_1 = n1_4 - (n1_3 - n1_4), n2_2 = s.targ - sep2 * 2.0, n2_3 = s.targ - sep2, n2_4 = s.targ;
         if (P.force_normal_touchdown) { // forceNormalTouchdown (:1314-1329)
           V3 bo = s.targ - sep2 * 4.0;
@@ -765,14 +780,15 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         } else {
           torg = pk.get3(PK_TORG);
         }
-        double stride_scaler = double(msp) / double(P.stance_period);
+        double stride_scaler = standard ? 1.0 : lc.first_stride_scaler; // modified / standard stance period (:1167)
+        (void)msp;
         V3 sep = ((-s.strd) * stride_scaler) * 0.25;
         double t = iteration * stance_dt;
         // five collinear equispaced nodes (:1295-1310)
         dpos = quartic_bezier_dot(torg, torg + sep, torg + sep * 2.0, torg + sep * 3.0, torg + sep * 4.0, t) * stance_dt;
       }
       s.tip = s.tip + dpos;
-      s.tvel = V3{dpos.x / P.dt, dpos.y / P.dt, dpos.z / P.dt};
+      s.tvel = dpos * P.inv_dt; // delta_pos / time_delta (:1135, :1176)
     }
     // updateTipRotation (:1193-1234): tip rotations stay UNDEFINED on this path (<= 3 DOF, or gravity_aligned_tips off)
     // ---- iteratePhase (:871-897)
@@ -832,7 +848,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       chain_from_sincos<NJ>(lc, s.sn, s.cs, chain); // joint transforms left by the previous applyFK (model.cpp:731,744)
       double dq[NJ];
       ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
-      update_joints<NJ>(lc, dq, P.dt, P.clamp_joint_velocities != 0, P.clamp_joint_positions != 0, s.q, s.qd);
+      update_joints<NJ>(lc, dq, P.dt, P.inv_dt, P.clamp_joint_velocities != 0, P.clamp_joint_positions != 0, s.q, s.qd);
     }
     SHC_PHASE_FENCE();
     SHC_TICK(10);

@@ -373,6 +373,8 @@ static void build_shared_consts(const shc_params &p, const shc_tables &t, const 
     if (step.stance_end == lc.phase_offset) msp = step.period;
     lc.first_stance_period = msp;
     lc.first_stance_iterations = int((double(msp) / step.period) / (step.frequency * p.time_delta));
+    lc.first_stance_dt = 1.0 / lc.first_stance_iterations;
+    lc.first_stride_scaler = double(msp) / double(step.stance_period);
     lc.starts_in_swing = (lc.phase_offset > step.swing_start && lc.phase_offset < step.swing_end) ? 1 : 0;
   }
   for (int b = 0; b < 9; ++b) {
@@ -398,7 +400,10 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   swing_iterations = round_to_even_int(swing_iterations);
   c.swing_iterations = swing_iterations;
   c.swing_delta_t = 1.0 / (swing_iterations / 2.0);
+  c.inv_dt = 1.0 / p.time_delta;
+  c.dt_over_swing_dt = p.time_delta / c.swing_delta_t;
   c.stance_iterations = int((double(s.stance_period) / s.period) / (s.frequency * p.time_delta)); // :1040
+  c.stance_dt = 1.0 / c.stance_iterations;
   double on_ground_ratio = double(s.stance_period) / s.period;                                    // :940
   c.stride_scale = on_ground_ratio / s.frequency;
   c.swing_height = p.swing_height;

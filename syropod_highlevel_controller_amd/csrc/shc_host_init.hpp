@@ -141,7 +141,7 @@ struct HostLeg {
   double ik(V3 desired, const shc_params &p) {
     double dq[NJ];
     ik_step<NJ>(lc, ch, q, qd, desired, dq);
-    double prox = update_joints<NJ>(lc, dq, p.time_delta, false, p.clamp_joint_positions != 0, q, qd);
+    double prox = update_joints<NJ>(lc, dq, p.time_delta, 1.0 / p.time_delta, false, p.clamp_joint_positions != 0, q, qd);
     fk();
     V3 e = tip - desired;
     if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) return 0.0;

@@ -34,8 +34,12 @@ struct LegConst {
   int32_t neg_start, neg_end; // pose negation phases (already * normaliser, 0 -> phase length; pose_controller.cpp:1718-1731)
   int32_t first_stance_period;     // modified stance period of the first step (walk_controller.cpp:1026-1031)
   int32_t first_stance_iterations; // int((msp / period) / (frequency * dt))   (walk_controller.cpp:1040)
+  int32_t pad_;
+  double first_stance_dt;          // 1 / first_stance_iterations              (walk_controller.cpp:1041)
+  double first_stride_scaler;      // first_stance_period / stance_period      (walk_controller.cpp:1167)
   int32_t starts_in_swing;         // phase_offset strictly inside the swing window (walk_controller.cpp:587-588)
 };
+// (int32 members are kept in pairs so the record stays a whole number of 8-byte words for the LDS copy)
 
 template <int NJ>
 struct Chain {
@@ -49,7 +53,7 @@ struct Chain {
 template <int NJ, class LC>
 SHC_HD void joint_sincos(const LC &lc, const double (&q)[NJ], double (&sn)[NJ], double (&cs)[NJ]) {
 #pragma unroll
-  for (int k = 0; k < NJ; ++k) sincos(lc.link_th[k] + q[k], &sn[k], &cs[k]);
+  for (int k = 0; k < NJ; ++k) sincos_joint(lc.link_th[k] + q[k], &sn[k], &cs[k]);
 }
 
 // Leg::applyFK chain product in the joint-1 frame from the joint sines / cosines.
@@ -139,12 +143,12 @@ SHC_HD void ik_step(const LC &lc, const Chain<NJ> &c, const double (&q)[NJ], con
 
 // Leg::updateJointPositions (model.cpp:799-857).  Returns the minimum limit proximity.
 template <int NJ, class LC>
-SHC_HD double update_joints(const LC &lc, const double (&dq)[NJ], double dt, bool clamp_vel, bool clamp_pos, double (&q)[NJ],
-                            double (&qd)[NJ]) {
+SHC_HD double update_joints(const LC &lc, const double (&dq)[NJ], double dt, double inv_dt, bool clamp_vel, bool clamp_pos,
+                            double (&q)[NJ], double (&qd)[NJ]) {
   double prox = 1.0;
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
-    double v = dq[i] / dt;
+    double v = dq[i] * inv_dt; // delta / time_delta (model.cpp:808) with the reciprocal precomputed on the host
     if (clamp_vel && fabs(v) > lc.jvmax[i]) v = clampd(v, -lc.jvmax[i], lc.jvmax[i]);
     double nq = q[i] + v * dt;
     if (clamp_pos) {

@@ -76,6 +76,40 @@ SHC_HD double smooth_step(double c) {                                           
 SHC_HD double rad2deg(double r) { return (r / (2.0 * kPi)) * 360.0; } // :69
 SHC_HD double deg2rad(double d) { return d / 360.0 * 2.0 * kPi; }     // :64
 
+// sin and cos of a joint angle (|x| well below 2^20 * pi/2: DH offsets + joint limits are a few radians).
+// Cody-Waite reduction by pi/2 in two parts + the fdlibm kernel polynomials: < 1 ulp, ~45 FP64 instructions, no
+// large-argument path (ocml's sincos carries a Payne-Hanek branch and costs ~2x as many issue slots).
+SHC_HD void sincos_joint(double x, double *sn, double *cs) {
+  const double inv_pio2 = 6.36619772367581382433e-01;
+  const double pio2_1 = 1.57079632673412561417e+00;  // first 33 bits of pi/2
+  const double pio2_1t = 6.07710050650619224932e-11; // pi/2 - pio2_1
+  double fn = rint(x * inv_pio2);
+  double r = fma(-fn, pio2_1, x);
+  double w = fn * pio2_1t;
+  double y = r - w;
+  double yt = (r - y) - w; // tail of the reduced argument
+  int n = int(fn);
+  double z = y * y;
+  // __kernel_sin
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+               S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double v = z * y;
+  double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+  double s = y - ((z * (0.5 * yt - v * rs) - yt) - v * S1);
+  // __kernel_cos
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+               C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+  double hz = 0.5 * z;
+  double w1 = 1.0 - hz;
+  double c = w1 + (((1.0 - w1) - hz) + (z * rc - y * yt));
+  double ss = (n & 1) ? c : s, cc = (n & 1) ? s : c;
+  if (n & 2) ss = -ss;
+  if ((n + 1) & 2) cc = -cc;
+  *sn = ss;
+  *cs = cc;
+}
+
 // ---------------------------------------------------------------- quaternions (w, x, y, z)
 SHC_HD Quat quat(double w, double x, double y, double z) { return Quat{w, x, y, z}; }
 SHC_HD Quat quat_identity() { return Quat{1, 0, 0, 0}; }
@@ -113,9 +147,9 @@ SHC_HD Quat angle_axis_z(double a) { return Quat{cos(0.5 * a), 0, 0, sin(0.5 * a
 // eulerAnglesToQuaternion (standard_includes.h:227): e = (roll, pitch, yaw)
 SHC_HD Quat euler_to_quat(V3 e, bool intrinsic) {
   double sx, cx, sy, cy, sz, cz;
-  sincos(0.5 * e.x, &sx, &cx);
-  sincos(0.5 * e.y, &sy, &cy);
-  sincos(0.5 * e.z, &sz, &cz);
+  sincos_joint(0.5 * e.x, &sx, &cx);
+  sincos_joint(0.5 * e.y, &sy, &cy);
+  sincos_joint(0.5 * e.z, &sz, &cz);
   Quat qx{cx, sx, 0, 0}, qy{cy, 0, sy, 0}, qz{cz, 0, 0, sz};
   return intrinsic ? (qx * qy) * qz : (qz * qy) * qx;
 }
