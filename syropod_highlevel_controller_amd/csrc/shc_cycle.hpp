@@ -79,17 +79,24 @@ struct SharedConsts { // staged in LDS
 };
 
 // SoA planes in HBM.  Leg fields: legd[f * n_slots + slot]; robot fields: robd[f * n_rob_pad + robot].
+// Per-leg state fields.  Two consecutive fields share one 16-byte plane (plane p = fields 2p, 2p + 1, stored as a
+// double2 per slot) so that every load/store of a wave moves 16 B per lane = 1 KiB per instruction; every group starts on
+// an even index and has an even length (3-vectors are padded to 4).
 template <int NJ>
 struct Fields {
+  static constexpr int NJE = (NJ + 1) & ~1;
   static constexpr int Q = 0, QD = NJ, TIP = 2 * NJ, TVEL = TIP + 3, SORG = TVEL + 3, SVEL = SORG + 3, TORG = SVEL + 3,
                        DFLT = TORG + 3, TARG = DFLT + 3, STRD = TARG + 3,
-                       CORE_END = STRD + 3,                         // always loaded / stored
-                       ADM = CORE_END, ADM_END = ADM + 2,           // admittance state   (admittance_control)
-                       TF = ADM_END, TF_END = TF + 3,               // tip_force_calculated_ filter state (tip_force)
-                       FORCE_IN = TF_END, EFFORT_IN = FORCE_IN + 3, // inputs
-                       POSER_TIP = EFFORT_IN + NJ, MODEL_TIP = POSER_TIP + 3, ADM_DELTA = MODEL_TIP + 3, // outputs
-                       COUNT = ADM_DELTA + 3;
+                       CORE_END = STRD + 3,                            // always loaded / stored (2 NJ + 24: even)
+                       ADM = CORE_END, ADM_END = ADM + 2,              // admittance state   (admittance_control)
+                       TF = ADM_END, TF_END = TF + 4,                  // tip_force_calculated_ filter state (tip_force)
+                       FORCE_IN = TF_END, EFFORT_IN = FORCE_IN + 4,    // inputs
+                       POSER_TIP = EFFORT_IN + NJE, MODEL_TIP = POSER_TIP + 4, ADM_DELTA = MODEL_TIP + 4, // outputs
+                       COUNT = ADM_DELTA + 4;
+  static_assert(CORE_END % 2 == 0 && SORG % 2 == 0 && COUNT % 2 == 0, "field groups must align to 16-byte planes");
 };
+// element index of field f of slot `slot` in the plane array (n_slots slots per plane)
+SHC_HD int64_t leg_field_index(int f, int64_t slot, int64_t n_slots) { return (int64_t(f >> 1) * n_slots + slot) * 2 + (f & 1); }
 struct RobotFields {
   // state + inputs that every specialisation touches
   static constexpr int VLIN = 0, VANG = 2, PLANE = 3, PNORM = 6, PLANE_PREV = 9, PNORM_PREV = 12, OWPP = 15, VIN = 22, WIN = 24,
@@ -513,8 +520,9 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     // updateStiffness only feeds the published per-leg virtual_stiffness_ (state_controller.cpp:889); updateAdmittance
     // reads the global parameters (admittance_controller.cpp:35-37), so nothing of it reaches the joint path.
     // tip_force_measured_ is an input held in HBM (L2-resident across the cycles of one launch)
-    V3 force_in{(legd + (Fields<NJ>::FORCE_IN + 0) * ns)[slot], (legd + (Fields<NJ>::FORCE_IN + 1) * ns)[slot],
-                (legd + (Fields<NJ>::FORCE_IN + 2) * ns)[slot]};
+    const double2 f01 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2) * ns + slot];
+    const double2 f2_ = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2 + 1) * ns + slot];
+    V3 force_in{f01.x, f01.y, f2_.x};
     V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
     double fi[3] = {f.x, f.y, f.z}, d[3];
 #pragma unroll
@@ -863,7 +871,11 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     if (FT::tipf(P)) { // Leg::calculateTipForce (:667-708)
       double effort[NJ];
 #pragma unroll
-      for (int i = 0; i < NJ; ++i) effort[i] = (legd + (Fields<NJ>::EFFORT_IN + i) * ns)[slot]; // Joint::current_effort_ input
+      for (int i = 0; i < NJ; i += 2) { // Joint::current_effort_ input
+        const double2 e2 = reinterpret_cast<const double2 *>(legd)[((Fields<NJ>::EFFORT_IN + i) / 2) * ns + slot];
+        effort[i] = e2.x;
+        if (i + 1 < NJ) effort[i + 1] = e2.y;
+      }
       V3 raw = tip_force_raw<NJ>(lc, chain, effort);
       s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
     }

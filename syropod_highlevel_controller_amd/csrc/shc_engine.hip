@@ -31,46 +31,52 @@ static int fail(int code, const std::string &msg) {
 
 // ================================================================================================= kernels
 
-// Field plane f of the per-leg SoA state: wave-uniform base pointer + 32-bit lane offset.
+// Paired planes of the per-leg SoA state: plane p = fields (2p, 2p + 1) as one double2 per slot.
 struct LegPlanes {
-  double *base;
+  double2 *base;
   int64_t ns;
   uint32_t slot;
-  __device__ __forceinline__ double &operator()(int f) const { return (base + f * ns)[slot]; }
-  __device__ __forceinline__ void st3(int f, V3 v) const {
-    (*this)(f) = v.x;
-    (*this)(f + 1) = v.y;
-    (*this)(f + 2) = v.z;
-  }
+  __device__ __forceinline__ double2 load(int plane) const { return (base + plane * ns)[slot]; }
+  __device__ __forceinline__ void store(int plane, double2 v) const { (base + plane * ns)[slot] = v; }
 };
 
 template <int NJ, unsigned F>
 __device__ __forceinline__ void load_leg(LegRegs<NJ> &s, const Park &pk, const DevState &st, const CycleParams &P, uint32_t slot) {
   using FD = Fields<NJ>;
   using FT = Feat<F>;
-  // plane pointers are wave-uniform (SGPR base), the lane offset is 32-bit: global_load saddr + voffset addressing
-  const LegPlanes ld{st.legd, st.n_slots, slot};
+  const LegPlanes ld{reinterpret_cast<double2 *>(st.legd), st.n_slots, slot};
   s.word = st.legi[slot];
-  // swing origin / stance origin / default tip go straight to the per-lane LDS strip (SORG, SVEL, TORG, DFLT are contiguous planes)
+  double flat[FD::CORE_END];
+#pragma unroll
+  for (int p = 0; p < FD::CORE_END / 2; ++p) {
+    double2 v = ld.load(p);
+    flat[2 * p] = v.x;
+    flat[2 * p + 1] = v.y;
+  }
+  // swing origin / velocity, stance origin and default tip go straight to the per-lane LDS strip
   static_assert(FD::SVEL == FD::SORG + 3 && FD::TORG == FD::SORG + 6 && FD::DFLT == FD::SORG + 9, "park layout");
 #pragma unroll
-  for (int k = 0; k < PK_COUNT; ++k) pk.d[k * 64 + pk.lane] = ld(FD::SORG + k);
-  s.tip = V3{ld(FD::TIP + 0), ld(FD::TIP + 1), ld(FD::TIP + 2)};
-  s.targ = V3{ld(FD::TARG + 0), ld(FD::TARG + 1), ld(FD::TARG + 2)};
-  s.strd = V3{ld(FD::STRD + 0), ld(FD::STRD + 1), ld(FD::STRD + 2)};
-  s.tvel = V3{ld(FD::TVEL + 0), ld(FD::TVEL + 1), ld(FD::TVEL + 2)};
+  for (int k = 0; k < PK_COUNT; ++k) pk.d[k * 64 + pk.lane] = flat[FD::SORG + k];
+  s.tip = V3{flat[FD::TIP + 0], flat[FD::TIP + 1], flat[FD::TIP + 2]};
+  s.targ = V3{flat[FD::TARG + 0], flat[FD::TARG + 1], flat[FD::TARG + 2]};
+  s.strd = V3{flat[FD::STRD + 0], flat[FD::STRD + 1], flat[FD::STRD + 2]};
+  s.tvel = V3{flat[FD::TVEL + 0], flat[FD::TVEL + 1], flat[FD::TVEL + 2]};
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
-    s.q[i] = ld(FD::Q + i);
-    s.qd[i] = ld(FD::QD + i);
+    s.q[i] = flat[FD::Q + i];
+    s.qd[i] = flat[FD::QD + i];
   }
   s.adm0 = s.adm1 = 0.0;
   s.tf = V3{0, 0, 0};
   if (FT::adm(P)) {
-    s.adm0 = ld(FD::ADM + 0);
-    s.adm1 = ld(FD::ADM + 1);
+    double2 v = ld.load(FD::ADM / 2);
+    s.adm0 = v.x;
+    s.adm1 = v.y;
   }
-  if (FT::tipf(P)) s.tf = V3{ld(FD::TF + 0), ld(FD::TF + 1), ld(FD::TF + 2)};
+  if (FT::tipf(P)) {
+    double2 a = ld.load(FD::TF / 2), b = ld.load(FD::TF / 2 + 1);
+    s.tf = V3{a.x, a.y, b.x};
+  }
 }
 
 template <int NJ, unsigned F>
@@ -78,26 +84,34 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
                                           uint32_t slot) {
   using FD = Fields<NJ>;
   using FT = Feat<F>;
-  const LegPlanes ld{st.legd, st.n_slots, slot};
+  const LegPlanes ld{reinterpret_cast<double2 *>(st.legd), st.n_slots, slot};
+  double flat[FD::CORE_END];
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
-    ld(FD::Q + i) = s.q[i];
-    ld(FD::QD + i) = s.qd[i];
+    flat[FD::Q + i] = s.q[i];
+    flat[FD::QD + i] = s.qd[i];
   }
-  ld.st3(FD::TIP, s.tip);
-  ld.st3(FD::TVEL, s.tvel);
+  flat[FD::TIP] = s.tip.x, flat[FD::TIP + 1] = s.tip.y, flat[FD::TIP + 2] = s.tip.z;
+  flat[FD::TVEL] = s.tvel.x, flat[FD::TVEL + 1] = s.tvel.y, flat[FD::TVEL + 2] = s.tvel.z;
 #pragma unroll
-  for (int k = 0; k < PK_COUNT; ++k) ld(FD::SORG + k) = pk.d[k * 64 + pk.lane];
-  ld.st3(FD::TARG, s.targ);
-  ld.st3(FD::STRD, s.strd);
+  for (int k = 0; k < PK_COUNT; ++k) flat[FD::SORG + k] = pk.d[k * 64 + pk.lane];
+  flat[FD::TARG] = s.targ.x, flat[FD::TARG + 1] = s.targ.y, flat[FD::TARG + 2] = s.targ.z;
+  flat[FD::STRD] = s.strd.x, flat[FD::STRD + 1] = s.strd.y, flat[FD::STRD + 2] = s.strd.z;
+#pragma unroll
+  for (int p = 0; p < FD::CORE_END / 2; ++p) ld.store(p, double2{flat[2 * p], flat[2 * p + 1]});
   if (FT::adm(P)) {
-    ld(FD::ADM + 0) = s.adm0;
-    ld(FD::ADM + 1) = s.adm1;
-    ld.st3(FD::ADM_DELTA, out.adm_delta);
+    ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});
+    ld.store(FD::ADM_DELTA / 2, double2{out.adm_delta.x, out.adm_delta.y});
+    ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, 0.0});
   }
-  if (FT::tipf(P)) ld.st3(FD::TF, s.tf);
-  ld.st3(FD::POSER_TIP, out.poser_tip);
-  ld.st3(FD::MODEL_TIP, out.model_tip);
+  if (FT::tipf(P)) {
+    ld.store(FD::TF / 2, double2{s.tf.x, s.tf.y});
+    ld.store(FD::TF / 2 + 1, double2{s.tf.z, 0.0});
+  }
+  ld.store(FD::POSER_TIP / 2, double2{out.poser_tip.x, out.poser_tip.y});
+  ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
+  ld.store(FD::MODEL_TIP / 2, double2{out.model_tip.x, out.model_tip.y});
+  ld.store(FD::MODEL_TIP / 2 + 1, double2{out.model_tip.z, 0.0});
   st.legi[slot] = s.word;
 }
 
@@ -265,7 +279,7 @@ __global__ void scatter_leg_kernel(const double *src, double *legd, int64_t n_sl
   int64_t rob = t / L;
   int leg = int(t - rob * L);
   int64_t slot = slot_of(rob, leg, L);
-  for (int k = 0; k < K; ++k) legd[(f0 + k) * n_slots + slot] = src[t * K + k];
+  for (int k = 0; k < K; ++k) legd[leg_field_index(f0 + k, slot, n_slots)] = src[t * K + k];
 }
 __global__ void gather_leg_kernel(double *dst, const double *legd, int64_t n_slots, int64_t n, int L, int K, int f0) {
   int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -273,7 +287,7 @@ __global__ void gather_leg_kernel(double *dst, const double *legd, int64_t n_slo
   int64_t rob = t / L;
   int leg = int(t - rob * L);
   int64_t slot = slot_of(rob, leg, L);
-  for (int k = 0; k < K; ++k) dst[t * K + k] = legd[(f0 + k) * n_slots + slot];
+  for (int k = 0; k < K; ++k) dst[t * K + k] = legd[leg_field_index(f0 + k, slot, n_slots)];
 }
 __global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int64_t n, int L) {
   int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -326,7 +340,7 @@ __global__ void init_state_kernel(DevState st, const double *leg_template /*[L][
     int64_t rob = t / L;
     int leg = int(t - rob * L);
     int64_t slot = slot_of(rob, leg, L);
-    for (int f = 0; f < nf; ++f) st.legd[f * st.n_slots + slot] = leg_template[leg * nf + f];
+    for (int f = 0; f < nf; ++f) st.legd[leg_field_index(f, slot, st.n_slots)] = leg_template[leg * nf + f];
     st.legi[slot] = legw_template[leg];
   }
   if (t < n) {
@@ -915,8 +929,8 @@ extern "C" int shc_engine_get_joint_state(shc_engine *e, double *q, double *qd, 
 
 extern "C" int shc_engine_joint_buffer(shc_engine *e, double **device_ptr, int64_t *n_doubles) {
   if (!e || !device_ptr || !n_doubles) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
-  *device_ptr = e->st.legd; // fields Q0..Q(NJ-1) are the first NJ planes of the leg state
-  *n_doubles = int64_t(e->NJ) * e->n_slots;
+  *device_ptr = e->st.legd; // fields Q (and, for odd DOF, the first QD) occupy the first ceil(NJ / 2) paired planes of the leg state
+  *n_doubles = int64_t((e->NJ + 1) / 2) * e->n_slots * 2;
   return SHC_OK;
 }
 
@@ -925,7 +939,7 @@ extern "C" int64_t shc_engine_joint_index(const shc_engine *e, int64_t instance,
   int rpw = 64 / e->L;
   int64_t w = instance / rpw;
   int gi = int(instance - w * rpw);
-  return int64_t(joint) * e->n_slots + w * 64 + gi * e->L + leg;
+  return leg_field_index(joint, w * 64 + gi * e->L + leg, e->n_slots);
 }
 
 extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, double *poser_tip, double *model_tip, double *tip_force,

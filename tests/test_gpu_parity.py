@@ -356,5 +356,18 @@ def test_device_pointer_io_with_torch(Engine):
     b.synchronize()
     assert np.array_equal(qd.cpu().numpy().reshape(n, 18), b.joints()[0])
     ptr, nd = a.joint_buffer()
-    assert nd == 3 * ((n + 9) // 10) * 64
-    assert a.joint_index(13, 4, 2) == 2 * ((n + 9) // 10) * 64 + 1 * 64 + 3 * 6 + 4
+    n_slots = ((n + 9) // 10) * 64
+    assert nd == 2 * 2 * n_slots                       # ceil(3 / 2) paired planes of double2 per slot
+    slot = 1 * 64 + 3 * 6 + 4                          # instance 13 -> wave 1, group 3; leg 4
+    assert a.joint_index(13, 4, 2) == (1 * n_slots + slot) * 2 + 0
+    buf = torch.empty(nd, dtype=torch.float64, device="cuda")
+    import ctypes
+    assert ctypes.CDLL(None) is not None
+    q_host = b.joints()[0]
+    # the raw planes hold the same joint positions the transposing getter returns
+    raw = torch.empty(nd, dtype=torch.float64)
+    torch.cuda.synchronize()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy(ctypes.c_void_p(raw.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(nd * 8), 2)
+    for (i, l, j) in ((0, 0, 0), (13, 4, 2), (99, 5, 1)):
+        assert raw[a.joint_index(i, l, j)].item() == q_host[i, l * 3 + j]
