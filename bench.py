@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=0, help="all-gather the joint buffer every G steps (0 = once, at the end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-probe", action="store_true", help="skip the secondary 16-cycles-per-launch figure (keeps rocprof stats to one launch shape)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather path even with one rank")
     ap.add_argument("--seed", type=int, default=0xC0FFEE)
     args = ap.parse_args()
 
@@ -124,7 +125,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the batched engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from syropod_highlevel_controller_amd.engine import BatchEngine
@@ -156,20 +160,20 @@ def main():
     moving_frac = float((ws == 1).mean())
 
     gathered = None
-    if world > 1:
+    if use_dist:
         gathered = torch.empty(world * n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda")
 
     # joint-state shard of this rank in the C ABI's instance-major layout [n][legs][dof] (device resident)
-    qshard = torch.empty(n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda") if world > 1 else None
+    qshard = torch.empty(n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda") if use_dist else None
 
     def gather():
-        if world > 1:
+        if use_dist:
             eng.joints_device(qshard.data_ptr(), None)  # SoA planes -> [n][legs][dof] on the engine's stream
             dist.all_gather_into_tensor(gathered, qshard)
 
     for _ in range(args.warmup):
         eng.step(cps)
-    if world > 1:
+    if use_dist:
         gather()
         dist.barrier()
     torch.cuda.synchronize()
@@ -181,11 +185,14 @@ def main():
     if not args.gather_every or args.steps % args.gather_every:
         gather()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
+        # the gathered buffer must hold every rank's shard in rank order: check this rank's own slice
+        own = gathered[rank * qshard.numel():(rank + 1) * qshard.numel()]
+        assert torch.equal(own, qshard), "all-gather returned a different shard for this rank"
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -252,7 +259,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(p, lin, ang, extra)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

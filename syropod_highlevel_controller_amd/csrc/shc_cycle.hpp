@@ -238,6 +238,23 @@ __device__ __forceinline__ double swing_progress_of(int word, const CycleParams 
   return clampd(double(phase - P.swing_start + 1) / double(P.swing_end - P.swing_start), 0.0, 1.0);
 }
 
+// WalkController::getLimit's bracket lookup (walk_controller.cpp:414-436) without the atan2.
+// Reference: bearing = mod(roundToInt(degrees(atan2(y, x))), 360); upper = first multiple of 45 >= bearing; the
+// interpolation factor is an int / int division (1 iff bearing == upper, else 0), so the limit used is the map entry
+// at floor(bearing / 45) * 45.  floor(round(deg) / 45) only changes where deg crosses 45 k - 0.5, i.e. the entry is the
+// 45-degree sector of the direction rotated by +0.5 degrees; that sector follows from the signs of the rotated
+// components and one magnitude comparison.  Both forms can only disagree for a direction within one rounding error
+// of a sector edge (as the device atan2 and glibc's already could).
+__device__ __forceinline__ int bearing_bracket(double y, double x) {
+  if (x == 0.0 && y == 0.0) return 0; // atan2(0, 0) = 0
+  constexpr double kC = 0.99996192306417128874, kS = 0.0087265354983739347; // cos / sin of 0.5 degrees
+  double xr = kC * x - kS * y, yr = kS * x + kC * y;
+  double ax = fabs(xr), ay = fabs(yr);
+  bool upper = yr > 0.0 || (yr == 0.0 && xr > 0.0);
+  if (upper) return xr > 0.0 ? (ay < ax ? 0 : 1) : (ay > ax ? 2 : 3);
+  return xr < 0.0 ? (ay < ax ? 4 : 5) : (ay > ax ? 6 : 7);
+}
+
 // ------------------------------------------------------------------------------------------------- one control cycle
 template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
@@ -384,7 +401,10 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         }
       }
       manual_r = mpose.r;
-      cp = add_pose(cp, mpose);
+      // adding the identity pose returns cp unchanged (x + 0, q * 1): skip it while no robot of the wave is posed
+      bool unposed = mpose.p.x == 0.0 && mpose.p.y == 0.0 && mpose.p.z == 0.0 && mpose.r.w == 1.0 && mpose.r.x == 0.0 &&
+                     mpose.r.y == 0.0 && mpose.r.z == 0.0;
+      if (!__all(unposed)) cp = add_pose(cp, mpose);
     }
     if (FT::incl(P)) { // updateInclinationPose (:1240-1259) reads the auto_pose_ left by the previous cycle
       Quat aprev = FT::autop(P) ? rb.getq(R::APREV) : quat_identity();
@@ -545,10 +565,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   double lim[4] = {0.05, 0.3, 0.02, 0.1};
   if (!(SHC_DBG(P) & 2)) {
     double sx = vin_x + win * (-s.tip.y), sy = vin_y + win * s.tip.x;
-    int bearing = mod_i(round_to_int(atan2(sy, sx) * (180.0 / kPi)), 360); // radiansToDegrees (standard_includes.h:69)
-    int upper = ((bearing + 44) / 45) * 45;
-    // control_input is an int / int division in the reference: 1 iff bearing == upper bound, else 0
-    int idx = (bearing == upper) ? (upper % 360) / 45 : mod_i(upper - 45, 360) / 45;
+    int idx = bearing_bracket(sy, sx);
 #pragma unroll
     for (int k = 0; k < 4; ++k) lim[k] = kUnassigned;
 #pragma unroll
@@ -648,6 +665,12 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       walk_state = WS_STOPPED;
     }
     // per-leg bookkeeping in leg-id order: counters are shared and read by later legs in the same cycle (:567-632)
+    if (__all(walk_state == WS_MOVING)) {
+      // every robot of the wave is MOVING: the loop below reduces to "at_correct_phase = false" (:594-597)
+      my_acp = false;
+#pragma unroll
+      for (int j = 0; j < L; ++j) any_stepping = any_stepping || ((lw[j] & 3) != SS_FORCE_STOP);
+    } else
 #pragma unroll
     for (int j = 0; j < L; ++j) {
       int wj = lw[j];
@@ -780,7 +803,9 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           dpos = quartic_bezier_dot(n2_0, n2_1, n2_2, n2_3, n2_4, t) * P.swing_delta_t;
         }
       } else { // STANCE / FORCE_STANCE
-        int iteration = mod_i(my_phase + (P.period - mss), P.period) + 1;
+        int iteration = my_phase + (P.period - mss); // both terms lie in [0, period]: one conditional subtract is the modulo
+        if (iteration >= P.period) iteration -= P.period;
+        iteration += 1;
         V3 torg;
         if (iteration == 1) {
           torg = s.tip;
@@ -800,7 +825,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     }
     // updateTipRotation (:1193-1234): tip rotations stay UNDEFINED on this path (<= 3 DOF, or gravity_aligned_tips off)
     // ---- iteratePhase (:871-897)
-    my_phase = (my_phase + 1) % P.period;
+    my_phase = my_phase + 1 == P.period ? 0 : my_phase + 1; // (phase + 1) % period with phase in [0, period)
     if (my_state != SS_FORCE_STOP) {
       if (my_phase >= P.swing_start && my_phase < P.swing_end && my_state != SS_FORCE_STANCE) my_state = SS_SWING;
       else if (my_phase < P.stance_end || my_phase >= P.stance_start) my_state = SS_STANCE;
