@@ -143,6 +143,7 @@ typedef struct shc_engine shc_engine; /* opaque */
 /* Feature bits of the fused cycle kernel (compile-time specialisations are picked from these). */
 enum {
   SHC_FEAT_TIP_FORCE = 1 << 0, /* Leg::calculateTipForce every cycle (model.cpp:938); needs joint_effort input */
+  SHC_FEAT_ODOMETRY = 1 << 1,  /* WalkController::odometry_ideal_ integration (walk_controller.cpp:643, :783-791) */
   SHC_FEAT_ALL = 0x7fffffff
 };
 
@@ -234,6 +235,14 @@ int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, double *poser_ti
 /* Per-robot outputs: body pose [n][7] (x,y,z,qw,qx,qy,qz) = Model::current_pose_ (state_controller.cpp:911),
  * desired velocity [n][3] (vx,vy,omega), walk_state [n]. */
 int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device);
+/* WalkController::getOdometryIdeal() (walk_controller.h:112; integrated at walk_controller.cpp:643 from
+ * calculateOdometry :783-791): [n][7] (x,y,z,qw,qx,qy,qz).  Needs SHC_FEAT_ODOMETRY (on by default). */
+int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device);
+/* Leg::getVirtualStiffness() (model.h:264) as left by AdmittanceController::updateStiffness
+ * (admittance_controller.cpp:96-134; only published, state_controller.cpp:889): [n][legs].  Updated while
+ * admittance_control && dynamic_stiffness && walk state != STOPPED (state_controller.cpp:172-178); 0 before the
+ * first update (the reference leaves the member uninitialised).  SHC_ERR_UNSUPPORTED without admittance_control. */
+int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness, int on_device);
 
 #ifdef __cplusplus
 }

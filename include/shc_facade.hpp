@@ -59,6 +59,8 @@ public:
     leg_status_.resize(size_t(n) * legs);
     pose_.resize(size_t(n) * 7);
     velocity_.resize(size_t(n) * 3);
+    odometry_.resize(size_t(n) * 7);
+    stiffness_.resize(size_t(n) * legs);
     walk_state_.resize(size_t(n));
     refresh();
   }
@@ -80,8 +82,10 @@ public:
                                    leg_status_.data(), 0),
           "get_leg_state");
     check(shc_engine_get_body_state(e_, pose_.data(), velocity_.data(), walk_state_.data(), 0), "get_body_state");
+    check(shc_engine_get_odometry(e_, odometry_.data(), 0), "get_odometry");
+    if (params_.admittance_control) check(shc_engine_get_virtual_stiffness(e_, stiffness_.data(), 0), "get_virtual_stiffness");
   }
-  std::vector<double> q_, qd_, walker_tip_, poser_tip_, model_tip_, tip_force_, admittance_, pose_, velocity_;
+  std::vector<double> q_, qd_, walker_tip_, poser_tip_, model_tip_, tip_force_, admittance_, pose_, velocity_, odometry_, stiffness_;
   std::vector<int32_t> leg_status_, walk_state_;
 
 private:
@@ -117,6 +121,7 @@ public:
   Vector3 getWalkerTipPosition() const { return v3(eng_.walker_tip_); }    // LegStepper::getCurrentTipPose() (walk_controller.h:389)
   Vector3 getTipForceCalculated() const { return v3(eng_.tip_force_); }    // model.h:244
   Vector3 getAdmittanceDelta() const { return v3(eng_.admittance_); }      // model.h:256
+  double getVirtualStiffness() const { return eng_.stiffness_[size_t(index_) * eng_.params().leg_count + id_]; } // model.h:264
   int getStepState() const { return eng_.leg_status_[size_t(index_) * eng_.params().leg_count + id_] & 3; } // walk_controller.h:325
   int getPhase() const { return eng_.leg_status_[size_t(index_) * eng_.params().leg_count + id_] >> 8; }    // :317
   bool ikFailed() const { return (eng_.leg_status_[size_t(index_) * eng_.params().leg_count + id_] & 4) != 0; } // model.cpp:921
@@ -178,6 +183,10 @@ public:
     return {eng_->velocity_[size_t(index) * 3], eng_->velocity_[size_t(index) * 3 + 1]};
   }
   double getDesiredAngularVelocity(int64_t index = 0) const { return eng_->velocity_[size_t(index) * 3 + 2]; } // :104
+  Pose getOdometryIdeal(int64_t index = 0) const {                                                               // :112
+    const double *p = &eng_->odometry_[size_t(index) * 7];
+    return Pose{{{p[0], p[1], p[2]}}, {p[3], p[4], p[5], p[6]}};
+  }
 
 private:
   std::shared_ptr<Engine> eng_;

@@ -2359,6 +2359,29 @@ void orc_batch_get_body_state(orc_batch *b, double *pose, double *velocity, int3
                        walk_state ? walk_state + i : NULL);
 }
 
+/* WalkController::getOdometryIdeal (walk_controller.h) per robot: position xyz + rotation wxyz */
+void orc_batch_get_odometry(orc_batch *b, double *pose)
+{
+  for (int64_t i = 0; i < b->n; ++i)
+  {
+    const orc_robot *r = &b->robots[i];
+    double *o = pose + 7 * i;
+    o[0] = r->odometry_ideal.p.x; o[1] = r->odometry_ideal.p.y; o[2] = r->odometry_ideal.p.z;
+    o[3] = r->odometry_ideal.r.w; o[4] = r->odometry_ideal.r.x; o[5] = r->odometry_ideal.r.y; o[6] = r->odometry_ideal.r.z;
+  }
+}
+
+/* Leg::getVirtualStiffness (model.h:264) per leg; the reference leaves the member uninitialised until the first
+ * updateStiffness call - the restatement (calloc) and the engine both start it at 0 */
+void orc_batch_get_virtual_stiffness(orc_batch *b, double *stiffness)
+{
+  for (int64_t i = 0; i < b->n; ++i)
+  {
+    const orc_robot *r = &b->robots[i];
+    for (int l = 0; l < r->leg_count; ++l) stiffness[i * r->leg_count + l] = r->leg[l].virtual_stiffness;
+  }
+}
+
 /* ------------------------------------------------------------------------------------ unit-level test hooks */
 
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out) { *out = generate_step_cycle(p); }

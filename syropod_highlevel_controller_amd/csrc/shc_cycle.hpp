@@ -39,7 +39,7 @@ constexpr int RW_LACP_SHIFT = 2, RW_LCFS_SHIFT = 6, RW_RTDA = 1 << 10, RW_APS_SH
 constexpr int kMaxAutoPosers = 8;
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
-enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_DYN = 1u << 31 };
+enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31 };
 
 // Launch-uniform parameters (staged in LDS).
 struct CycleParams {
@@ -59,7 +59,7 @@ struct CycleParams {
   int32_t clamp_joint_positions, clamp_joint_velocities, force_normal_touchdown;
   int32_t tip_force;  // SHC_FEAT_TIP_FORCE
   int32_t debug_skip; // development ablation mask (SHC_DEBUG_SKIP env): 1 pose, 2 limits, 4 stepper, 8 ik, 16 fk
-  int32_t pad0;
+  int32_t odometry;   // SHC_FEAT_ODOMETRY
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
   double pid_p, pid_i, pid_d;
   // admittance: 30 RK4 steps of x'' = -F/m - c/m x' - k/m x collapsed into x <- M x + g F
@@ -106,7 +106,8 @@ struct RobotFields {
   static constexpr int IMUQ = 47, IMUQ_END = 51;                        // IMU orientation input
   static constexpr int APREV = 51, APREV_END = 55;                      // previous cycle's auto_pose_.rotation_
   static constexpr int CPOSE = 55, CPOSE_END = 62;                      // output: Model::current_pose_
-  static constexpr int WPP = 62, COUNT = 69;                            // output: walk_plane_pose_ (model default pose)
+  static constexpr int WPP = 62, WPP_END = 69;                          // output: walk_plane_pose_ (model default pose)
+  static constexpr int ODOM = 69, COUNT = 76;                           // WalkController::odometry_ideal_ (odometry feature)
   static constexpr int I_WORD = 0, I_APOSER = 1, I_POSE_PHASE = 2, I_RESET_MODE = 3, I_COUNT = 4;
 };
 
@@ -144,6 +145,7 @@ struct Feat {
   __device__ __forceinline__ static bool imu(const CycleParams &P) { return (F & F_DYN) ? P.imu_posing != 0 : (F & F_IMU) != 0; }
   __device__ __forceinline__ static bool adm(const CycleParams &P) { return (F & F_DYN) ? P.admittance_control != 0 : (F & F_ADM) != 0; }
   __device__ __forceinline__ static bool tipf(const CycleParams &P) { return (F & F_DYN) ? P.tip_force != 0 : (F & F_TIPF) != 0; }
+  __device__ __forceinline__ static bool odom(const CycleParams &P) { return (F & F_DYN) ? P.odometry != 0 : (F & F_ODOM) != 0; }
 };
 
 template <int L>
@@ -160,44 +162,38 @@ struct Group {
 };
 
 // The wave's robot tile in LDS: value of field f for this lane's robot is d[f * RPW + grp].
+// Robot-level quantities are computed redundantly by the L lanes of a group from the same tile values and the same
+// shuffles, so every lane of a group holds the same bits: put() is an unconditional store (L lanes write one value to
+// one address, no exec-mask branch per store; mirror lanes rewrite their live twin's value).
 template <int RPW>
 struct RobTile {
   double *d;
   int32_t *i;
   int grp;
-  bool writer; // lane 0 of a live group
   __device__ __forceinline__ double get(int f) const { return d[f * RPW + grp]; }
   __device__ __forceinline__ V3 get3(int f) const { return V3{d[f * RPW + grp], d[(f + 1) * RPW + grp], d[(f + 2) * RPW + grp]}; }
   __device__ __forceinline__ Quat getq(int f) const {
     return Quat{d[f * RPW + grp], d[(f + 1) * RPW + grp], d[(f + 2) * RPW + grp], d[(f + 3) * RPW + grp]};
   }
   __device__ __forceinline__ Pose getpose(int f) const { return Pose{get3(f), getq(f + 3)}; }
-  __device__ __forceinline__ void put(int f, double v) const {
-    if (writer) d[f * RPW + grp] = v;
-  }
+  __device__ __forceinline__ void put(int f, double v) const { d[f * RPW + grp] = v; }
   __device__ __forceinline__ void put3(int f, V3 v) const {
-    if (writer) {
-      d[f * RPW + grp] = v.x;
-      d[(f + 1) * RPW + grp] = v.y;
-      d[(f + 2) * RPW + grp] = v.z;
-    }
+    d[f * RPW + grp] = v.x;
+    d[(f + 1) * RPW + grp] = v.y;
+    d[(f + 2) * RPW + grp] = v.z;
   }
   __device__ __forceinline__ void putq(int f, Quat q) const {
-    if (writer) {
-      d[f * RPW + grp] = q.w;
-      d[(f + 1) * RPW + grp] = q.x;
-      d[(f + 2) * RPW + grp] = q.y;
-      d[(f + 3) * RPW + grp] = q.z;
-    }
+    d[f * RPW + grp] = q.w;
+    d[(f + 1) * RPW + grp] = q.x;
+    d[(f + 2) * RPW + grp] = q.y;
+    d[(f + 3) * RPW + grp] = q.z;
   }
   __device__ __forceinline__ void putpose(int f, const Pose &p) const {
     put3(f, p.p);
     putq(f + 3, p.r);
   }
   __device__ __forceinline__ int geti(int f) const { return i[f * RPW + grp]; }
-  __device__ __forceinline__ void puti(int f, int v) const {
-    if (writer) i[f * RPW + grp] = v;
-  }
+  __device__ __forceinline__ void puti(int f, int v) const { i[f * RPW + grp] = v; }
 };
 
 // Per-leg state held in registers across the cycles of one launch.
@@ -207,6 +203,7 @@ struct LegRegs {
   double sn[NJ], cs[NJ]; // sin / cos of the DH joint angles at q: the chain (Jacobian, tip) is rebuilt from these
   V3 tip, tvel, targ, strd;
   double adm0, adm1;
+  double stiff; // Leg::virtual_stiffness_ (published only; admittance feature)
   V3 tf, tipx; // tip x axis (robot frame) of the current FK, kept only for Leg::setAdmittanceDelta
   int word;
 };
@@ -537,8 +534,26 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   // =============================================================== AdmittanceController (:22-134)
   out.adm_delta = V3{0, 0, 0};
   if (FT::adm(P)) {
-    // updateStiffness only feeds the published per-leg virtual_stiffness_ (state_controller.cpp:889); updateAdmittance
-    // reads the global parameters (admittance_controller.cpp:35-37), so nothing of it reaches the joint path.
+    // updateStiffness (admittance_controller.cpp:96-134) only feeds the published per-leg virtual_stiffness_
+    // (state_controller.cpp:889); updateAdmittance reads the global parameters (:35-37), so nothing of it reaches the
+    // joint path.  The reference walks the legs in id order: a SWING leg overwrites its own value and adds its load term
+    // to both neighbours, so leg j ends with its base value plus the load terms of those SWING neighbours that are
+    // processed after leg j's own overwrite (all of them when leg j is not in SWING), added in id order.
+    if (P.dynamic_stiffness && walk_state != WS_STOPPED) { // state_controller.cpp:175 (walk state before updateWalk)
+      const bool swing = (s.word & 3) == SS_SWING;
+      const double k = P.virtual_stiffness;
+      const double ref = fabs((s.tip.z - pk.get3(PK_DFLT).z) / P.swing_height);
+      const double load = swing ? k * (ref * (P.load_stiffness_scaler - 1)) : 0.0;
+      double v = swing ? k * (ref * (P.swing_stiffness_scaler - 1) + 1) : k;
+      const int lo = leg == 0 ? L - 1 : leg - 1, hi = leg == L - 1 ? 0 : leg + 1;
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        const double li = g.get(load, i);
+        const bool si = (lw[i] & 3) == SS_SWING;
+        if (si && (i == lo || i == hi) && (!swing || i > leg)) v += li;
+      }
+      s.stiff = v;
+    }
     // tip_force_measured_ is an input held in HBM (L2-resident across the cycles of one launch)
     const double2 f01 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2) * ns + slot];
     const double2 f2_ = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2 + 1) * ns + slot];
@@ -854,6 +869,22 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       double pc = (c02 * sxz + c12 * syz + c22 * sz) / det;
       rb.put3(R::PLANE, V3{pa, pb, pc});
       rb.put3(R::PNORM, normalized(V3{-pa, -pb, 1.0}));
+    }
+    // ---- odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (:643, :783-791)
+    if (FT::odom(P)) {
+      // Both poses are pure yaw (rotation (w, 0, 0, z), z translation 0), so Pose::addPose reduces to its w / z and x / y
+      // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
+      double sh, ch;
+      sincos_joint(0.5 * (vw * P.dt), &sh, &ch); // Quaterniond(AngleAxisd(w dt, z^))
+      const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 3), oz = rb.get(R::ODOM + 6);
+      const double a = vx * P.dt, b = vy * P.dt;
+      double ux = -(oz * b), uy = oz * a; // u x v
+      ux = ux + ux;
+      uy = uy + uy;
+      rb.put(R::ODOM, ox + ((a + ux * ow) - oz * uy));
+      rb.put(R::ODOM + 1, oy + ((b + uy * ow) + oz * ux));
+      rb.put(R::ODOM + 3, ow * ch - oz * sh);
+      rb.put(R::ODOM + 6, ow * sh + oz * ch);
     }
   }
   s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL)) |

@@ -67,11 +67,13 @@ __device__ __forceinline__ void load_leg(LegRegs<NJ> &s, const Park &pk, const D
     s.qd[i] = flat[FD::QD + i];
   }
   s.adm0 = s.adm1 = 0.0;
+  s.stiff = 0.0;
   s.tf = V3{0, 0, 0};
   if (FT::adm(P)) {
     double2 v = ld.load(FD::ADM / 2);
     s.adm0 = v.x;
     s.adm1 = v.y;
+    if (P.dynamic_stiffness) s.stiff = ld.load(FD::ADM_DELTA / 2 + 1).y; // virtual_stiffness_ persists while STOPPED
   }
   if (FT::tipf(P)) {
     double2 a = ld.load(FD::TF / 2), b = ld.load(FD::TF / 2 + 1);
@@ -102,7 +104,7 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   if (FT::adm(P)) {
     ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});
     ld.store(FD::ADM_DELTA / 2, double2{out.adm_delta.x, out.adm_delta.y});
-    ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, 0.0});
+    ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, s.stiff});
   }
   if (FT::tipf(P)) {
     ld.store(FD::TF / 2, double2{s.tf.x, s.tf.y});
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   }
   double t_core[(R::CORE_END * RPW + 63) / 64], t_man[((R::MANUAL_END - R::MPOSE) * RPW + 63) / 64],
       t_imu[((R::IMU_END - R::ABSE) * RPW + 63) / 64], t_imuq[((R::IMUQ_END - R::IMUQ) * RPW + 63) / 64],
-      t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64];
+      t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_odom[((R::COUNT - R::ODOM) * RPW + 63) / 64];
   int32_t t_int = 0;
   const bool any_robot = robots_here > 0;
   if (any_robot) {
@@ -209,6 +211,7 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
     if (FT::imu(GP)) load_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, gtile, lane);
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
+    if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::COUNT>(t_odom, gtile, lane);
     if (lane < R::I_COUNT * RPW) t_int = gtile_i[lane];
     load_leg<NJ, F>(s, pk, st, GP, slot);
   }
@@ -227,6 +230,7 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
     if (FT::imu(GP)) put_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, tile, lane);
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
+    if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::COUNT>(t_odom, tile, lane);
     if (lane < R::I_COUNT * RPW) tile_i[lane] = t_int;
   }
   SHC_TICK(18);
@@ -235,7 +239,7 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   if (robots_here == 0) return; // whole wave past the end (wave-uniform)
   const CycleParams &P = C.P;
   Group<L> g{grp * L};
-  RobTile<RPW> rb{tile, tile_i, grp, live && leg == 0};
+  RobTile<RPW> rb{tile, tile_i, grp};
   joint_sincos<NJ>(C.leg[leg], s.q, s.sn, s.cs); // FK of the stored joint state (Leg::applyFK of the previous cycle)
   s.tipx = V3{1, 0, 0};
   if (FT::adm(P)) {
@@ -254,7 +258,8 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   if (FT::manual(P)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
   if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
-  store_rob_fields<RPW, R::CPOSE, R::COUNT>(tile, gtile, lane);
+  store_rob_fields<RPW, R::CPOSE, R::WPP_END>(tile, gtile, lane);
+  if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::COUNT>(tile, gtile, lane);
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
   SHC_TICK(14);
 }
@@ -436,6 +441,7 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.clamp_joint_velocities = p.clamp_joint_velocities;
   c.force_normal_touchdown = p.force_normal_touchdown;
   c.tip_force = (features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort ? 1 : 0;
+  c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
   if (const char *dbg = getenv("SHC_DEBUG_SKIP")) c.debug_skip = atoi(dbg);
   for (int i = 0; i < 3; ++i) {
     c.max_translation[i] = p.max_translation[i];
@@ -621,6 +627,7 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
   robt[R::CPOSE + 3] = 1.0;
   robt[R::WPP + 2] = e->params.body_clearance;
   robt[R::WPP + 3] = 1.0;
+  robt[R::ODOM + 3] = 1.0; // walk_controller.cpp:28
   robi.assign(R::I_COUNT, 0);
   robi[R::I_WORD] = WS_STOPPED | (PS_POSING_COMPLETE << RW_APS_SHIFT);
 }
@@ -675,7 +682,7 @@ extern "C" int shc_engine_create(const shc_params *params, int64_t n_instances, 
   e->device = device;
   e->stream = (hipStream_t)stream;
   e->n = n_instances;
-  e->features = SHC_FEAT_TIP_FORCE;
+  e->features = SHC_FEAT_TIP_FORCE | SHC_FEAT_ODOMETRY;
   rc = shc_generate_tables(params, &e->tables);
   if (rc != SHC_OK) {
     delete e;
@@ -857,13 +864,14 @@ template <int L, int NJ, bool SPEC>
 static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cycles, bool specialised) {
   const CycleParams &c = e->cp;
   unsigned f = (c.manual_posing ? F_MANUAL : 0) | (c.auto_posing ? F_AUTO : 0) | (c.inclination_posing ? F_INCL : 0) |
-               (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0);
+               (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0) | (c.odometry ? F_ODOM : 0);
   if constexpr (SPEC) {
+    constexpr unsigned C2 = F_MANUAL | F_ODOM, C3 = F_MANUAL | F_IMU | F_ADM | F_ODOM; // BASELINE.json configs 2/4 and 3
     if (specialised) switch (f) {
-      case F_MANUAL | F_TIPF: launch_cycle<L, NJ, F_MANUAL | F_TIPF>(e, grid, block, n_cycles); return;
-      case F_MANUAL: launch_cycle<L, NJ, F_MANUAL>(e, grid, block, n_cycles); return;
-      case F_MANUAL | F_IMU | F_ADM | F_TIPF: launch_cycle<L, NJ, F_MANUAL | F_IMU | F_ADM | F_TIPF>(e, grid, block, n_cycles); return;
-      case F_MANUAL | F_IMU | F_ADM: launch_cycle<L, NJ, F_MANUAL | F_IMU | F_ADM>(e, grid, block, n_cycles); return;
+      case C2 | F_TIPF: launch_cycle<L, NJ, C2 | F_TIPF>(e, grid, block, n_cycles); return;
+      case C2: launch_cycle<L, NJ, C2>(e, grid, block, n_cycles); return;
+      case C3 | F_TIPF: launch_cycle<L, NJ, C3 | F_TIPF>(e, grid, block, n_cycles); return;
+      case C3: launch_cycle<L, NJ, C3>(e, grid, block, n_cycles); return;
       default: break;
     }
   }
@@ -963,6 +971,18 @@ extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, doubl
     }
   }
   return SHC_OK;
+}
+
+extern "C" int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (!e->cp.odometry) return fail(SHC_ERR_UNSUPPORTED, "SHC_FEAT_ODOMETRY is off");
+  return gather_rob(e, pose, 7, RobotFields::ODOM, on_device);
+}
+
+extern "C" int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (!e->params.admittance_control) return fail(SHC_ERR_UNSUPPORTED, "admittance_control is off: updateStiffness never runs");
+  return gather_leg(e, stiffness, 1, LEG_FIELD(e, ADM_DELTA) + 3, on_device);
 }
 
 extern "C" int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device) {

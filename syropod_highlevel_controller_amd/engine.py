@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from .params import Params, Tables
+from .params import FEAT_DEFAULT, Params, Tables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("SHC_LIB") or os.path.join(_HERE, "libshc_batch.so")
@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_instances", "shc_engine_set_velocity", "shc_engine_set_imu", "shc_engine_set_tip_force",
     "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_set_pose_reset_mode", "shc_engine_step", "shc_engine_synchronize",
     "shc_engine_get_joint_state", "shc_engine_joint_buffer", "shc_engine_joint_index", "shc_engine_get_leg_state",
-    "shc_engine_get_body_state",
+    "shc_engine_get_body_state", "shc_engine_get_odometry", "shc_engine_get_virtual_stiffness",
 ]
 
 
@@ -93,6 +93,8 @@ def lib():
         L.shc_engine_joint_index.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
         L.shc_engine_get_leg_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int]
         L.shc_engine_get_body_state.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
+        L.shc_engine_get_odometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_get_virtual_stiffness.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -131,6 +133,7 @@ class BatchEngine:
             raise ShcError("no HIP device visible: the batched engine has no CPU fallback")
         self.params, self.n = params, int(n)
         self.legs, self.dof = params.leg_count, params.leg_dof[0]
+        self.features = FEAT_DEFAULT
         h = C.c_void_p()
         _check(self.L.shc_engine_create(C.byref(params), self.n, device, C.c_void_p(stream), C.byref(h)), "shc_engine_create")
         self.h = h
@@ -152,6 +155,7 @@ class BatchEngine:
 
     def set_features(self, features: int):
         _check(self.L.shc_engine_set_features(self.h, features), "set_features")
+        self.features = int(features)
 
     def tables(self) -> Tables:
         t = Tables()
@@ -227,3 +231,15 @@ class BatchEngine:
         ws = np.zeros(self.n, dtype=np.int32)
         _check(self.L.shc_engine_get_body_state(self.h, _p(pose), _p(vel), _p(ws), 0), "get_body_state")
         return pose, vel, ws
+
+    def odometry(self):
+        """WalkController::getOdometryIdeal per instance: [n][7] (x, y, z, qw, qx, qy, qz)."""
+        pose = np.zeros((self.n, 7))
+        _check(self.L.shc_engine_get_odometry(self.h, _p(pose), 0), "get_odometry")
+        return pose
+
+    def virtual_stiffness(self):
+        """Leg::getVirtualStiffness per leg (AdmittanceController::updateStiffness): [n][legs]."""
+        k = np.zeros((self.n, self.legs))
+        _check(self.L.shc_engine_get_virtual_stiffness(self.h, _p(k), 0), "get_virtual_stiffness")
+        return k

@@ -24,6 +24,8 @@ WALK_STARTING, WALK_MOVING, WALK_STOPPING, WALK_STOPPED = 0, 1, 2, 3
 STEP_SWING, STEP_STANCE, STEP_FORCE_STANCE, STEP_FORCE_STOP = 0, 1, 2, 3
 VEL_THROTTLE, VEL_REAL = 0, 1
 FEAT_TIP_FORCE = 1
+FEAT_ODOMETRY = 2
+FEAT_DEFAULT = FEAT_TIP_FORCE | FEAT_ODOMETRY  # what shc_engine_create enables
 
 
 class JointParams(C.Structure):

@@ -70,6 +70,8 @@ def lib():
         L.orc_batch_get_joint_state.argtypes = [C.c_void_p, _dp, _dp]
         L.orc_batch_get_leg_state.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _ip]
         L.orc_batch_get_body_state.argtypes = [C.c_void_p, _dp, _dp, _ip]
+        L.orc_batch_get_odometry.argtypes = [C.c_void_p, _dp]
+        L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
         L.orc_test_generate_step_cycle.argtypes = [C.POINTER(Params), C.POINTER(StepCycle)]
         L.orc_test_quat_to_euler.argtypes = [_dp, C.c_int, _dp]
         L.orc_test_euler_to_quat.argtypes = [_dp, C.c_int, _dp]
@@ -232,3 +234,13 @@ class OracleBatch:
         ws = np.zeros(self.n, dtype=np.int32)
         self.L.orc_batch_get_body_state(self.h, _ptr(pose), _ptr(vel), _ptr(ws, _ip))
         return pose, vel, ws
+
+    def odometry(self):
+        pose = np.zeros((self.n, 7))
+        self.L.orc_batch_get_odometry(self.h, _ptr(pose))
+        return pose
+
+    def virtual_stiffness(self):
+        k = np.zeros((self.n, self.p.leg_count))
+        self.L.orc_batch_get_virtual_stiffness(self.h, _ptr(k))
+        return k

@@ -17,7 +17,7 @@ import pytest
 
 from oracle_lib import OracleBatch
 from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
-from syropod_highlevel_controller_amd.params import FEAT_TIP_FORCE, VEL_REAL, WALK_MOVING, WALK_STOPPED
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_ODOMETRY, FEAT_TIP_FORCE, VEL_REAL, WALK_MOVING, WALK_STOPPED
 
 pytestmark = pytest.mark.gpu
 TOL_Q = 1e-6  # rad, BASELINE.json north_star
@@ -78,6 +78,10 @@ def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
     np.testing.assert_allclose(vg[m], vo[m], atol=1e-12)
     np.testing.assert_allclose(lg["poser_tip"][m], lo["poser_tip"][m], atol=1e-8)
     np.testing.assert_allclose(lg["model_tip"][m], lo["model_tip"][m], atol=tol_q)
+    if eng.features & FEAT_ODOMETRY:  # odometry_ideal_ integrates the desired velocities only: independent of the IK path
+        np.testing.assert_allclose(eng.odometry()[m], ob.odometry()[m], atol=1e-11)
+    if eng.params.admittance_control:  # published virtual stiffness: a function of step states and walker tips
+        np.testing.assert_allclose(eng.virtual_stiffness()[m], ob.virtual_stiffness()[m], rtol=1e-9, atol=1e-9)
     if ints:
         assert np.array_equal(wg[m], wo[m])                                   # walk state: bit-exact
         assert np.array_equal(lg["leg_status"][m] & ~4, lo["leg_status"][m] & ~4)  # step state + phase: bit-exact
@@ -86,7 +90,7 @@ def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
     return float(dq.max())
 
 
-def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_posed=0.8, features=FEAT_TIP_FORCE):
+def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_posed=0.8, features=FEAT_DEFAULT):
     eng = Engine(p, n)
     eng.set_features(features)
     ob = OracleBatch(p, n)
@@ -286,11 +290,14 @@ def test_generic_kernel_is_bit_identical_to_specialised(Engine):
         assert np.array_equal(x, y)
 
 
-def test_tip_force_feature_off_leaves_joints_unchanged(Engine):
+def test_optional_features_off_leave_joints_unchanged(Engine):
+    """Tip-force estimate and odometry are published-only quantities: switching them off must not move a joint."""
     p = default_hexapod_params("tripod")
     inp = make_inputs(p, 40, 41)
     a, b = Engine(p, 40), Engine(p, 40)
     b.set_features(0)
+    with pytest.raises(RuntimeError):
+        b.odometry()
     apply(a, inp)
     apply(b, inp)
     a.step(200)
