@@ -157,8 +157,8 @@ int64_t shc_sizeof_params(void);
 int64_t shc_sizeof_tables(void);
 int shc_device_count(void);
 const char *shc_last_error(void);
-/* Diagnostics: `reps` launches of a plain plane copy (8-byte loads and stores per lane, the cycle kernel's access shape) of
- * `n_doubles` doubles; the known byte count calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
+/* Diagnostics: `reps` launches of a plain plane copy (16-byte loads and stores per lane, the cycle kernel's access shape) of
+ * `n_doubles` (even) doubles; the known byte count calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
 int shc_debug_plane_copy(int device, int64_t n_doubles, int reps);
 
 /*

@@ -3,7 +3,7 @@
 #   kernel trace + stats of the default bench command, FETCH_SIZE / WRITE_SIZE / SQ PMC passes (each in its own run),
 #   and the same PMC passes on a plane copy of known size (calibration of the byte counters).
 set -u
-R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/prof; rm -rf $O; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${PROF_DIR:-prof}; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-fused-probe $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH > $O/trace.log 2>&1

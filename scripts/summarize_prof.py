@@ -1,19 +1,35 @@
-"""Turn rocprofv3 CSV output (kernel trace / stats / PMC passes) into the small text summaries committed under profiles/."""
+"""Turn the rocprofv3 CSV output of scripts/profile_round.sh (kernel trace / stats / PMC passes) into the text summary
+committed under profiles/ and the per-launch HBM traffic figure bench.py reports (profiles/traffic.json).
+
+usage: python scripts/summarize_prof.py gpurun_out/prof profiles/r01_config2_rocprofv3.txt [traffic key, default config2:4096:1]
+"""
 import collections
 import csv
 import glob
+import json
+import os
 import statistics as st
 import sys
 
+KERNEL = "shc_cycle_kernel"
+CAL_KERNEL = "shc_plane_copy_kernel"
+CAL_KIB = 64 * 1024 * 1024 * 8 / 1024.0  # scripts/profile_round.sh copies 64 Mi doubles per launch
+
+
+def newest(pattern):
+    f = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return f[-1] if f else None
+
 
 def kernel_stats(dirn, out):
-    f = glob.glob(f"{dirn}/**/*_kernel_stats.csv", recursive=True)
+    f = newest(f"{dirn}/**/*_kernel_stats.csv")
     if f:
         out.write("== rocprofv3 --kernel-trace --stats : kernel_stats.csv\n")
-        out.write(open(f[0]).read())
-    f = glob.glob(f"{dirn}/**/*_kernel_trace.csv", recursive=True)
+        out.write(open(f).read())
+    f = newest(f"{dirn}/**/*_kernel_trace.csv")
+    med = None
     if f:
-        rows = list(csv.DictReader(open(f[0])))
+        rows = list(csv.DictReader(open(f)))
         by = collections.defaultdict(list)
         meta = {}
         for r in rows:
@@ -25,26 +41,68 @@ def kernel_stats(dirn, out):
             d = sorted(d)
             out.write(f"{k[:90]:90s} {len(d):6d} {st.mean(d):10.0f} {st.median(d):10.0f} {d[0]:9d} {d[int(.9 * (len(d) - 1))]:9d} {d[-1]:10d} | "
                       + " ".join(meta[k]) + "\n")
+            if KERNEL in k:
+                med = (st.mean(d), st.median(d), len(d))
+    return med
 
 
-def pmc(dirn, out):
-    for f in glob.glob(f"{dirn}/**/*_counter_collection.csv", recursive=True):
-        rows = list(csv.DictReader(open(f)))
-        agg = collections.defaultdict(list)
-        for r in rows:
-            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
-        out.write(f"\n== rocprofv3 --pmc ({dirn}): per-dispatch counter values: kernel, counter, dispatches, mean, median\n")
-        for (k, c), v in sorted(agg.items()):
-            if "shc_cycle_kernel" in k:
-                out.write(f"{k[:70]:70s} {c:22s} {len(v):5d} {st.mean(v):16.1f} {st.median(v):16.1f}\n")
+def pmc(dirn, kernel, out, label):
+    """median per-dispatch value of every counter collected for `kernel` in the newest CSV under dirn"""
+    f = newest(f"{dirn}/**/*_counter_collection.csv")
+    res = {}
+    if not f:
+        return res
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kernel in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out.write(f"\n== rocprofv3 --pmc ({label}): kernel, counter, dispatches, mean, median\n")
+    for c, v in sorted(agg.items()):
+        out.write(f"{kernel:24s} {c:22s} {len(v):5d} {st.mean(v):16.1f} {st.median(v):16.1f}\n")
+        res[c] = st.median(v)
+    return res
 
 
 if __name__ == "__main__":
-    out = open(sys.argv[1], "w")
-    for d in sys.argv[2:]:
-        if "pmc" in d:
-            pmc(d, out)
-        else:
-            kernel_stats(d, out)
+    prof, dest = sys.argv[1], sys.argv[2]
+    key = sys.argv[3] if len(sys.argv) > 3 else "config2:4096:1"
+    out = open(dest, "w")
+    dur = kernel_stats(f"{prof}/trace", out)
+    fetch = pmc(f"{prof}/pmc_fetch", KERNEL, out, "FETCH_SIZE pass").get("FETCH_SIZE")
+    write = pmc(f"{prof}/pmc_write", KERNEL, out, "WRITE_SIZE pass").get("WRITE_SIZE")
+    sq = pmc(f"{prof}/pmc_sq", KERNEL, out, "SQ pass")
+    cf = pmc(f"{prof}/pmc_cal_fetch", CAL_KERNEL, out, "calibration, FETCH_SIZE").get("FETCH_SIZE")
+    cw = pmc(f"{prof}/pmc_cal_write", CAL_KERNEL, out, "calibration, WRITE_SIZE").get("WRITE_SIZE")
+    out.write("\n== PMC calibration on a plane copy of known size (shc_debug_plane_copy: 64 Mi doubles = %d KiB read + %d KiB written per "
+              "launch, 16 B per lane)\n" % (CAL_KIB, CAL_KIB))
+    kf = CAL_KIB / cf if cf else float("nan")
+    kw = CAL_KIB / cw if cw else float("nan")
+    out.write(f"FETCH_SIZE median {cf} KiB -> correction factor x{kf:.3f}\nWRITE_SIZE median {cw} KiB -> correction factor x{kw:.3f}\n")
+    traffic = None
+    if fetch and write and cf and cw:
+        kib = kf * fetch + kw * write
+        traffic = kib * 1024.0
+        out.write(f"\n== derived ({key})\nHBM traffic per launch = {kf:.3f} x FETCH_SIZE + {kw:.3f} x WRITE_SIZE = {kf:.3f} x {fetch:.1f} KiB + "
+                  f"{kw:.3f} x {write:.1f} KiB = {kib:.1f} KiB = {traffic / 1e6:.2f} MB\n")
+    if sq.get("SQ_WAVES"):
+        w = sq["SQ_WAVES"]
+        out.write(f"VALU instructions per wave per launch = SQ_INSTS_VALU / SQ_WAVES = {sq.get('SQ_INSTS_VALU', 0) / w:.0f}; SALU {sq.get('SQ_INSTS_SALU', 0) / w:.0f}; "
+                  f"LDS {sq.get('SQ_INSTS_LDS', 0) / w:.0f}\n")
+        if sq.get("SQ_WAVE_CYCLES"):
+            out.write(f"VALU issue share of wave lifetime = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {sq.get('SQ_ACTIVE_INST_VALU', 0) / sq['SQ_WAVE_CYCLES']:.3f}; "
+                      f"wave lifetime = 4 x SQ_WAVE_CYCLES / SQ_WAVES = {4 * sq['SQ_WAVE_CYCLES'] / w:.0f} cycles\n")
+    if dur:
+        out.write(f"kernel duration (kernel_trace): mean {dur[0]:.0f} ns, median {dur[1]:.0f} ns over {dur[2]} launches\n")
+    bl = f"{prof}/bench_line.json"
+    if os.path.exists(bl):
+        out.write("\n== bench.py line of the traced run (rocprofv3 --kernel-trace --stats -- python bench.py --steps 400 --warmup 40 "
+                  "--no-cpu-baseline --no-fused-probe)\n" + open(bl).read())
     out.close()
-    print(open(sys.argv[1]).read())
+    if traffic:
+        tj = os.path.join(os.path.dirname(dest), "traffic.json")
+        d = json.load(open(tj)) if os.path.exists(tj) else {}
+        d[key] = round(traffic)
+        d["_note"] = ("HBM bytes per launch of shc_cycle_kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in KiB, each scaled by the "
+                      "factor calibrated on shc_debug_plane_copy in the same run); written by scripts/summarize_prof.py from " + os.path.basename(dest))
+        json.dump(d, open(tj, "w"), indent=1)
+    print(open(dest).read())

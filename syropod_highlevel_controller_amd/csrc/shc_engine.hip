@@ -264,9 +264,9 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   SHC_TICK(14);
 }
 
-__global__ void shc_plane_copy_kernel(const double *__restrict__ src, double *__restrict__ dst, int64_t n) {
+__global__ void shc_plane_copy_kernel(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t n_pairs) {
   int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = src[i];
+  if (i < n_pairs) dst[i] = src[i];
 }
 
 // ---- layout conversion kernels (C ABI instance-major arrays <-> SoA fields)
@@ -524,14 +524,15 @@ extern "C" int shc_debug_ticks(long long *out16) {
 #endif
 
 extern "C" int shc_debug_plane_copy(int device, int64_t n_doubles, int reps) {
-  if (n_doubles < 1 || reps < 1) return fail(SHC_ERR_INVALID_ARG, "n_doubles and reps must be >= 1");
+  if (n_doubles < 2 || (n_doubles & 1) || reps < 1) return fail(SHC_ERR_INVALID_ARG, "n_doubles must be even and >= 2, reps >= 1");
   HIP_TRY(hipSetDevice(device));
   double *a, *b;
   HIP_TRY(hipMalloc(&a, size_t(n_doubles) * 8));
   HIP_TRY(hipMalloc(&b, size_t(n_doubles) * 8));
   HIP_TRY(hipMemset(a, 0, size_t(n_doubles) * 8));
+  const int64_t n_pairs = n_doubles / 2;
   for (int r = 0; r < reps; ++r)
-    shc_plane_copy_kernel<<<dim3((unsigned)((n_doubles + 255) / 256)), dim3(256)>>>(a, b, n_doubles);
+    shc_plane_copy_kernel<<<dim3((unsigned)((n_pairs + 255) / 256)), dim3(256)>>>((const double2 *)a, (double2 *)b, n_pairs);
   HIP_TRY(hipDeviceSynchronize());
   (void)hipFree(a);
   (void)hipFree(b);
