@@ -133,9 +133,15 @@ __device__ long long *shc_tick_buf = nullptr;
 #else
 #define SHC_TICK(i) do {} while (0)
 #endif
-#ifndef SHC_DBG
+// Development-only phase ablation (build with -DSHC_ABLATE, select with the SHC_DEBUG_SKIP environment variable)
+#ifdef SHC_ABLATE
 #define SHC_DBG(P) ((P).debug_skip)
+#else
+#define SHC_DBG(P) 0
 #endif
+// A launch-uniform parameter read from LDS is a vector value to the compiler: branching on it costs an exec-mask region.
+// uni() moves it to an SGPR so the branch is a scalar one.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 template <unsigned F>
 struct Feat {
@@ -274,7 +280,11 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   {
     int w = s.word & ~(LW_ZBV | LW_ATT);
     if (dot(s.strd, s.strd) == 0.0) w |= LW_ZBV;
-    V3 err = rejection(s.tip - s.targ, rb.get3(R::PNORM_PREV));
+    const V3 pnp = rb.get3(R::PNORM_PREV);
+    V3 err = s.tip - s.targ;
+    // rejection from the exact unit normal (0, 0, 1) is (x, y, z - z): skip the projection's division on flat ground
+    if (__all(pnp.x == 0.0 && pnp.y == 0.0 && pnp.z == 1.0)) err.z = 0.0;
+    else err = rejection(err, pnp);
     if (dot(err, err) < kTipTolerance * kTipTolerance) w |= LW_ATT;
     s.word = w;
   }
@@ -539,7 +549,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     // joint path.  The reference walks the legs in id order: a SWING leg overwrites its own value and adds its load term
     // to both neighbours, so leg j ends with its base value plus the load terms of those SWING neighbours that are
     // processed after leg j's own overwrite (all of them when leg j is not in SWING), added in id order.
-    if (P.dynamic_stiffness && walk_state != WS_STOPPED) { // state_controller.cpp:175 (walk state before updateWalk)
+    if (uni(P.dynamic_stiffness) && walk_state != WS_STOPPED) { // state_controller.cpp:175 (walk state before updateWalk)
       const bool swing = (s.word & 3) == SS_SWING;
       const double k = P.virtual_stiffness;
       const double ref = fabs((s.tip.z - pk.get3(PK_DFLT).z) / P.swing_height);
@@ -596,54 +606,39 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   const double lin_norm = sqrt(vin_x * vin_x + vin_y * vin_y);
   {
     double nvx, nvy, nw;
-    if (walk_state != WS_STOPPING) {
-      if (P.velocity_input_mode == 0) { // throttle
-        double cx = vin_x, cy = vin_y;
-        if (lin_norm > 1.0) {
-          double k = 1.0 / lin_norm;
-          cx *= k;
-          cy *= k;
-        }
-        nvx = cx * lim[0];
-        nvy = cy * lim[0];
-        nw = clampd(win, -1.0, 1.0) * lim[1];
-        double sc = 1.0 - fabs(win);
-        nvx *= sc;
-        nvy *= sc;
-      } else {
-        double cx = vin_x, cy = vin_y;
-        if (lin_norm > lim[0]) {
-          double k = lim[0] / lin_norm;
-          cx *= k;
-          cy *= k;
-        }
-        nw = clampd(win, -lim[1], lim[1]);
-        double sc = lim[1] != 0.0 ? (1.0 - fabs(nw / lim[1])) : 0.0;
-        nvx = cx * sc;
-        nvy = cy * sc;
-      }
-    } else {
-      nvx = nvy = nw = 0.0;
+    if (uni(P.velocity_input_mode) == 0) { // throttle (:451-466)
+      const double k = lin_norm > 1.0 ? 1.0 / lin_norm : 1.0; // clamped to the unit disc
+      const double cx = lin_norm > 1.0 ? vin_x * k : vin_x, cy = lin_norm > 1.0 ? vin_y * k : vin_y;
+      nw = clampd(win, -1.0, 1.0) * lim[1];
+      const double sc = 1.0 - fabs(win);
+      nvx = (cx * lim[0]) * sc;
+      nvy = (cy * lim[0]) * sc;
+    } else { // real (:467-481)
+      const bool over = lin_norm > lim[0];
+      const double k = lim[0] / lin_norm;
+      const double cx = over ? vin_x * k : vin_x, cy = over ? vin_y * k : vin_y;
+      nw = clampd(win, -lim[1], lim[1]);
+      const double sc = lim[1] != 0.0 ? (1.0 - fabs(nw / lim[1])) : 0.0;
+      nvx = cx * sc;
+      nvy = cy * sc;
     }
-    double ax = nvx - vx, ay = nvy - vy;
-    double an2 = ax * ax + ay * ay;
-    double an = sqrt(an2);
-    double cap = lim[2] * P.dt;
-    if (an < cap) {
+    if (walk_state == WS_STOPPING) nvx = nvy = nw = 0.0; // :483-487
+    // acceleration-limited approach (:508-527)
+    const double ax = nvx - vx, ay = nvy - vy;
+    const double an2 = ax * ax + ay * ay;
+    const double an = sqrt(an2);
+    const double cap = lim[2] * P.dt;
+    if (__all(an < cap)) { // every robot of the wave reaches its target this cycle (the steady state)
       vx += ax;
       vy += ay;
     } else {
-      double nx = ax, ny = ay;
-      if (an2 > 0.0) {
-        nx = ax / an;
-        ny = ay / an;
-      }
-      vx += nx * lim[2] * P.dt;
-      vy += ny * lim[2] * P.dt;
+      const double inv = an2 > 0.0 ? an : 1.0; // normalized() leaves the zero vector unchanged
+      const double sx_ = (ax / inv) * lim[2] * P.dt, sy_ = (ay / inv) * lim[2] * P.dt;
+      vx += an < cap ? ax : sx_;
+      vy += an < cap ? ay : sy_;
     }
-    double aa = nw - vw;
-    if (fabs(aa) < lim[3] * P.dt) vw += aa;
-    else vw += signd(aa) * lim[3] * P.dt;
+    const double aa = nw - vw;
+    vw += fabs(aa) < lim[3] * P.dt ? aa : signd(aa) * lim[3] * P.dt;
     rb.put(R::VLIN, vx);
     rb.put(R::VLIN + 1, vy);
     rb.put(R::VANG, vw);
@@ -799,7 +794,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         V3 fv = (-s.strd) * (stance_dt * P.inv_dt);
         V3 sep2 = (fv * 0.25) * P.dt_over_swing_dt;
         V3 n2_0 = n1_4, n2_1 = n1_4 - (n1_3 - n1_4), n2_2 = s.targ - sep2 * 2.0, n2_3 = s.targ - sep2, n2_4 = s.targ;
-        if (P.force_normal_touchdown) { // forceNormalTouchdown (:1314-1329)
+        if (uni(P.force_normal_touchdown)) { // forceNormalTouchdown (:1314-1329)
           V3 bo = s.targ - sep2 * 4.0;
           bo.z = fmax(sorg.z, s.targ.z);
           bo = bo + clearance;
@@ -912,7 +907,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       chain_from_sincos<NJ>(lc, s.sn, s.cs, chain); // joint transforms left by the previous applyFK (model.cpp:731,744)
       double dq[NJ];
       ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
-      update_joints<NJ>(lc, dq, P.dt, P.inv_dt, P.clamp_joint_velocities != 0, P.clamp_joint_positions != 0, s.q, s.qd);
+      update_joints<NJ>(lc, dq, P.dt, P.inv_dt, uni(P.clamp_joint_velocities) != 0, uni(P.clamp_joint_positions) != 0, s.q, s.qd);
     }
     SHC_PHASE_FENCE();
     SHC_TICK(10);

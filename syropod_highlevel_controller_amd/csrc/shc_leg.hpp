@@ -126,8 +126,10 @@ SHC_HD void ik_step(const LC &lc, const Chain<NJ> &c, const double (&q)[NJ], con
     vcost += v * v;
     vg[i] = -v * lc.jw_vrange[i];
   }
-  double ps = pcost == 0.0 ? 0.0 : 1.0 / sqrt(pcost);
-  double vs = vcost == 0.0 ? 0.0 : 1.0 / sqrt(vcost);
+  // evaluated unconditionally and selected afterwards: no exec-mask branch around the sqrt / division
+  double ps = 1.0 / sqrt(pcost), vs = 1.0 / sqrt(vcost);
+  ps = pcost == 0.0 ? 0.0 : ps;
+  vs = vcost == 0.0 ? 0.0 : vs;
   const double l2 = kDls * kDls;
   double a[NJ][NJ];
 #pragma unroll
@@ -149,12 +151,12 @@ SHC_HD double update_joints(const LC &lc, const double (&dq)[NJ], double dt, dou
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
     double v = dq[i] * inv_dt; // delta / time_delta (model.cpp:808) with the reciprocal precomputed on the host
-    if (clamp_vel && fabs(v) > lc.jvmax[i]) v = clampd(v, -lc.jvmax[i], lc.jvmax[i]);
+    // clamps as min / max against +-infinity when a clamp is disabled: branch-free, same values (model.cpp:812-841)
+    const double vm = clamp_vel ? lc.jvmax[i] : HUGE_VAL;
+    v = fmin(fmax(v, -vm), vm);
     double nq = q[i] + v * dt;
-    if (clamp_pos) {
-      if (nq < lc.jmin[i]) nq = lc.jmin[i];
-      else if (nq > lc.jmax[i]) nq = lc.jmax[i];
-    }
+    const double lo = clamp_pos ? lc.jmin[i] : -HUGE_VAL, hi = clamp_pos ? lc.jmax[i] : HUGE_VAL;
+    nq = fmin(fmax(nq, lo), hi);
     qd[i] = v;
     q[i] = nq;
     double half = (lc.jmax[i] - lc.jmin[i]) / 2.0;
