@@ -1,5 +1,5 @@
 """Development aid: wall-clock launch times of the cycle kernel for the three shapes that matter (config 2 at 4096 x 1 cycle,
-65536 x 1, 65536 x 16 fused).  SHC_LIB selects the library variant; `python scripts/timeit.py a.so b.so` compares variants."""
+65536 x 1, 65536 x 16 fused).  SHC_LIB selects the library variant; `python scripts/time_shapes.py a.so b.so` compares variants."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -37,6 +37,10 @@ constexpr int LW_ACP = 1 << 2, LW_CFS = 1 << 3, LW_PM_SHIFT = 4, LW_NEG = 1 << 6
 constexpr int RW_LACP_SHIFT = 2, RW_LCFS_SHIFT = 6, RW_RTDA = 1 << 10, RW_APS_SHIFT = 11;
 
 constexpr int kMaxAutoPosers = 8;
+// "this group of state fields changed during the launch" bits, kept per lane and OR-reduced over the wave before the
+// write-back: groups nobody changed are not stored (walk plane / manual pose of the robot tile; the parked stepper
+// origins of the per-leg planes, which change once per step period).
+enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31 };
@@ -107,7 +111,7 @@ struct RobotFields {
   static constexpr int APREV = 51, APREV_END = 55;                      // previous cycle's auto_pose_.rotation_
   static constexpr int CPOSE = 55, CPOSE_END = 62;                      // output: Model::current_pose_
   static constexpr int WPP = 62, WPP_END = 69;                          // output: walk_plane_pose_ (model default pose)
-  static constexpr int ODOM = 69, COUNT = 76;                           // WalkController::odometry_ideal_ (odometry feature)
+  static constexpr int ODOM = 69, COUNT = 73; // WalkController::odometry_ideal_ (odometry feature): x, y, qw, qz (pure yaw)
   static constexpr int I_WORD = 0, I_APOSER = 1, I_POSE_PHASE = 2, I_RESET_MODE = 3, I_COUNT = 4;
 };
 
@@ -261,7 +265,7 @@ __device__ __forceinline__ int bearing_bracket(double y, double x) {
 // ------------------------------------------------------------------------------------------------- one control cycle
 template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
-                                      const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot) {
+                                      const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: without this opaque zero LICM hoists every
@@ -342,7 +346,14 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         np.p.z += wplane.z;
         wpp = interpolate_pose(owpp, c, np);
       }
-      if (c == 1.0) rb.putpose(R::OWPP, wpp);
+      if (c == 1.0) {
+        const bool same = wpp.p.x == owpp.p.x && wpp.p.y == owpp.p.y && wpp.p.z == owpp.p.z && wpp.r.w == owpp.r.w && wpp.r.x == owpp.r.x &&
+                          wpp.r.y == owpp.r.y && wpp.r.z == owpp.r.z;
+        if (__any(!same)) {
+          rb.putpose(R::OWPP, wpp);
+          dirty |= DIRTY_WALK_PLANE;
+        }
+      }
       rb.putpose(R::WPP, wpp);
     }
     cp = wpp; // Identity.addPose(walk_plane_pose_)
@@ -406,6 +417,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           }
           rb.putpose(R::MPOSE, mpose);
         }
+        dirty |= DIRTY_MANUAL;
       }
       manual_r = mpose.r;
       // adding the identity pose returns cp unchanged (x + 0, q * 1): skip it while no robot of the wave is posed
@@ -747,6 +759,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM_PREV));
         pk.put3(PK_DFLT, idp + proj);
         default_changed = true;
+        dirty |= DIRTY_STANCE_ORG; // the default tip shares the stance-origin planes
       }
     }
     // ---- LegStepper::updateTipPosition (:1018-1189)
@@ -778,6 +791,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           svel = s.tvel;
           pk.put3(PK_SORG, sorg);
           pk.put3(PK_SVEL, svel);
+          dirty |= DIRTY_SWING_ORG;
         } else {
           sorg = pk.get3(PK_SORG);
           svel = pk.get3(PK_SVEL);
@@ -820,6 +834,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         if (iteration == 1) {
           torg = s.tip;
           pk.put3(PK_TORG, torg);
+          dirty |= DIRTY_STANCE_ORG;
         } else {
           torg = pk.get3(PK_TORG);
         }
@@ -846,10 +861,16 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     // ---- updateWalkPlane (:748-779): least-squares plane through the default tip positions.  The fit only changes
     //      when a default tip changed, which is a rare event -> recompute under a wave-uniform guard (bit-identical).
     if (any_stepping) { // the stepping legs' saved copies (LegStepper::walk_plane_) now hold the pre-update walker plane
-      rb.put3(R::PLANE_PREV, rb.get3(R::PLANE));
-      rb.put3(R::PNORM_PREV, rb.get3(R::PNORM));
+      const V3 pl = rb.get3(R::PLANE), pn_ = rb.get3(R::PNORM), plp = rb.get3(R::PLANE_PREV), pnp_ = rb.get3(R::PNORM_PREV);
+      const bool same = pl.x == plp.x && pl.y == plp.y && pl.z == plp.z && pn_.x == pnp_.x && pn_.y == pnp_.y && pn_.z == pnp_.z;
+      if (__any(!same)) {
+        rb.put3(R::PLANE_PREV, pl);
+        rb.put3(R::PNORM_PREV, pn_);
+        dirty |= DIRTY_WALK_PLANE;
+      }
     }
     if (__any(default_changed)) {
+      dirty |= DIRTY_WALK_PLANE;
       const V3 nd = pk.get3(PK_DFLT);
       double x = nd.x, y = nd.y, z = nd.z;
       double sxx = g.sum(x * x), sxy = g.sum(x * y), sx = g.sum(x), syy = g.sum(y * y), sy = g.sum(y);
@@ -871,15 +892,15 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
       double sh, ch;
       sincos_joint(0.5 * (vw * P.dt), &sh, &ch); // Quaterniond(AngleAxisd(w dt, z^))
-      const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 3), oz = rb.get(R::ODOM + 6);
+      const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 2), oz = rb.get(R::ODOM + 3);
       const double a = vx * P.dt, b = vy * P.dt;
       double ux = -(oz * b), uy = oz * a; // u x v
       ux = ux + ux;
       uy = uy + uy;
       rb.put(R::ODOM, ox + ((a + ux * ow) - oz * uy));
       rb.put(R::ODOM + 1, oy + ((b + uy * ow) + oz * ux));
-      rb.put(R::ODOM + 3, ow * ch - oz * sh);
-      rb.put(R::ODOM + 6, ow * sh + oz * ch);
+      rb.put(R::ODOM + 2, ow * ch - oz * sh);
+      rb.put(R::ODOM + 3, ow * sh + oz * ch);
     }
   }
   s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL)) |

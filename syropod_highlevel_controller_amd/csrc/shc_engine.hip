@@ -83,7 +83,7 @@ __device__ __forceinline__ void load_leg(LegRegs<NJ> &s, const Park &pk, const D
 
 template <int NJ, unsigned F>
 __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &out, const Park &pk, const DevState &st, const CycleParams &P,
-                                          uint32_t slot) {
+                                          uint32_t slot, unsigned dirty) {
   using FD = Fields<NJ>;
   using FT = Feat<F>;
   const LegPlanes ld{reinterpret_cast<double2 *>(st.legd), st.n_slots, slot};
@@ -99,8 +99,16 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   for (int k = 0; k < PK_COUNT; ++k) flat[FD::SORG + k] = pk.d[k * 64 + pk.lane];
   flat[FD::TARG] = s.targ.x, flat[FD::TARG + 1] = s.targ.y, flat[FD::TARG + 2] = s.targ.z;
   flat[FD::STRD] = s.strd.x, flat[FD::STRD + 1] = s.strd.y, flat[FD::STRD + 2] = s.strd.z;
+  // swing origin position / velocity and stance origin / default tip change once per step period: their planes are
+  // written back only when some lane of the wave changed them during this launch
+  static_assert(FD::SORG % 2 == 0 && FD::TORG % 2 == 0 && FD::TARG % 2 == 0, "park groups must cover whole planes");
 #pragma unroll
-  for (int p = 0; p < FD::CORE_END / 2; ++p) ld.store(p, double2{flat[2 * p], flat[2 * p + 1]});
+  for (int p = 0; p < FD::CORE_END / 2; ++p) {
+    const bool swing_org = 2 * p >= FD::SORG && 2 * p < FD::TORG, stance_org = 2 * p >= FD::TORG && 2 * p < FD::TARG;
+    if (swing_org && !(dirty & DIRTY_SWING_ORG)) continue;
+    if (stance_org && !(dirty & DIRTY_STANCE_ORG)) continue;
+    ld.store(p, double2{flat[2 * p], flat[2 * p + 1]});
+  }
   if (FT::adm(P)) {
     ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});
     ld.store(FD::ADM_DELTA / 2, double2{out.adm_delta.x, out.adm_delta.y});
@@ -110,10 +118,13 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     ld.store(FD::TF / 2, double2{s.tf.x, s.tf.y});
     ld.store(FD::TF / 2 + 1, double2{s.tf.z, 0.0});
   }
-  ld.store(FD::POSER_TIP / 2, double2{out.poser_tip.x, out.poser_tip.y});
-  ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
-  ld.store(FD::MODEL_TIP / 2, double2{out.model_tip.x, out.model_tip.y});
-  ld.store(FD::MODEL_TIP / 2 + 1, double2{out.model_tip.z, 0.0});
+  // LegState outputs: the model tip is FK(q) and, without per-leg auto poses, the poser tip is the walker tip seen from
+  // Model::current_pose_ - both are derived from the stored state when a getter asks (derive_tips_kernel), not written
+  // every launch.  Only the auto-pose path's per-leg pose is not recoverable, so it stores its poser tip.
+  if (FT::autop(P) && !FT::imu(P)) {
+    ld.store(FD::POSER_TIP / 2, double2{out.poser_tip.x, out.poser_tip.y});
+    ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
+  }
   st.legi[slot] = s.word;
 }
 
@@ -249,13 +260,22 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   }
   LegOut out;
   SHC_TICK(1);
-  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot);
-  if (live) store_leg<NJ, F>(s, out, pk, st, P, slot);
+  unsigned dirty = 0;
+  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty);
+  { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
+    unsigned d = 0;
+#pragma unroll
+    for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
+      if (__any((dirty & b) != 0)) d |= b;
+    dirty = d;
+  }
+  if (live) store_leg<NJ, F>(s, out, pk, st, P, slot, dirty);
   SHC_TICK(13);
   __builtin_amdgcn_wave_barrier(); // LDS ops of one wave complete in order: the tile now holds the leaders' updates
   // state planes back to this wave's HBM tile (the inputs VIN / WIN / GYRO / IMUQ are not written back)
-  store_rob_fields<RPW, 0, R::VIN>(tile, gtile, lane);
-  if (FT::manual(P)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
+  store_rob_fields<RPW, 0, R::PLANE>(tile, gtile, lane);
+  if (dirty & DIRTY_WALK_PLANE) store_rob_fields<RPW, R::PLANE, R::VIN>(tile, gtile, lane); // walk plane + origin walk-plane pose
+  if (FT::manual(P) && (dirty & DIRTY_MANUAL)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
   if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
   store_rob_fields<RPW, R::CPOSE, R::WPP_END>(tile, gtile, lane);
@@ -270,6 +290,8 @@ __global__ void shc_plane_copy_kernel(const double2 *__restrict__ src, double2 *
 }
 
 // ---- layout conversion kernels (C ABI instance-major arrays <-> SoA fields)
+// element index of field f of robot r in the AoSoA robot tiles ([wave][field][robots-per-wave])
+__device__ __forceinline__ int64_t rob_index(int64_t r, int f, int rpw, int nf) { return ((r / rpw) * nf + f) * rpw + (r % rpw); }
 __device__ __forceinline__ int64_t slot_of(int64_t rob, int leg, int L) {
   int rpw = 64 / L;
   int64_t w = rob / rpw;
@@ -294,6 +316,52 @@ __global__ void gather_leg_kernel(double *dst, const double *legd, int64_t n_slo
   int64_t slot = slot_of(rob, leg, L);
   for (int k = 0; k < K; ++k) dst[t * K + k] = legd[leg_field_index(f0 + k, slot, n_slots)];
 }
+// LegState tips derived from the stored state (see store_leg): model tip = FK(q) in the robot frame (Leg::applyFK,
+// model.cpp:975), poser tip = Model::current_pose_^-1 * walker tip (PoseController::updateStance, pose_controller.cpp:122-131).
+template <int L, int NJ>
+__global__ void derive_tips_kernel(DevState st, const SharedConsts<L, NJ> *gc, int derive_poser) {
+  using FD = Fields<NJ>;
+  using R = RobotFields;
+  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= st.n_robots * L) return;
+  int64_t rob = t / L;
+  int leg = int(t - rob * L);
+  int64_t slot = slot_of(rob, leg, L);
+  const LegConst<NJ> &lc = gc->leg[leg];
+  double q[NJ];
+  for (int j = 0; j < NJ; ++j) q[j] = st.legd[leg_field_index(FD::Q + j, slot, st.n_slots)];
+  Chain<NJ> ch;
+  fk_chain<NJ>(lc, q, ch);
+  V3 tip = tip_robot_frame(lc, ch.pe);
+  st.legd[leg_field_index(FD::MODEL_TIP, slot, st.n_slots)] = tip.x;
+  st.legd[leg_field_index(FD::MODEL_TIP + 1, slot, st.n_slots)] = tip.y;
+  st.legd[leg_field_index(FD::MODEL_TIP + 2, slot, st.n_slots)] = tip.z;
+  if (derive_poser) {
+    constexpr int rpw = 64 / L;
+    double c[7];
+    for (int k = 0; k < 7; ++k) c[k] = st.robd[rob_index(rob, R::CPOSE + k, rpw, R::COUNT)];
+    V3 w{st.legd[leg_field_index(FD::TIP, slot, st.n_slots)], st.legd[leg_field_index(FD::TIP + 1, slot, st.n_slots)],
+         st.legd[leg_field_index(FD::TIP + 2, slot, st.n_slots)]};
+    V3 pt = inverse_transform_vector(Pose{V3{c[0], c[1], c[2]}, Quat{c[3], c[4], c[5], c[6]}}, w);
+    st.legd[leg_field_index(FD::POSER_TIP, slot, st.n_slots)] = pt.x;
+    st.legd[leg_field_index(FD::POSER_TIP + 1, slot, st.n_slots)] = pt.y;
+    st.legd[leg_field_index(FD::POSER_TIP + 2, slot, st.n_slots)] = pt.z;
+  }
+}
+// odometry_ideal_ is stored as (x, y, qw, qz): expand to the pose layout of the ABI (x, y, z, qw, qx, qy, qz)
+__global__ void gather_odometry_kernel(double *dst, const double *robd, int rpw, int64_t n) {
+  constexpr int nf = RobotFields::COUNT;
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double *o = dst + r * 7;
+  o[0] = robd[rob_index(r, RobotFields::ODOM, rpw, nf)];
+  o[1] = robd[rob_index(r, RobotFields::ODOM + 1, rpw, nf)];
+  o[2] = 0.0;
+  o[3] = robd[rob_index(r, RobotFields::ODOM + 2, rpw, nf)];
+  o[4] = 0.0;
+  o[5] = 0.0;
+  o[6] = robd[rob_index(r, RobotFields::ODOM + 3, rpw, nf)];
+}
 __global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int64_t n, int L) {
   int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n * L) return;
@@ -304,7 +372,6 @@ __global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int6
   dst[t] = (w & 3) | ((w & LW_IKFAIL) ? 4 : 0) | (phase << 8);
 }
 // AoS [n][K] -> robot fields
-__device__ __forceinline__ int64_t rob_index(int64_t r, int f, int rpw, int nf) { return ((r / rpw) * nf + f) * rpw + (r % rpw); }
 
 __global__ void scatter_rob_kernel(const double *src, double *robd, int rpw, int64_t n, int K, int f0, int normalize_quat) {
   constexpr int nf = RobotFields::COUNT;
@@ -628,7 +695,7 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
   robt[R::CPOSE + 3] = 1.0;
   robt[R::WPP + 2] = e->params.body_clearance;
   robt[R::WPP + 3] = 1.0;
-  robt[R::ODOM + 3] = 1.0; // walk_controller.cpp:28
+  robt[R::ODOM + 2] = 1.0; // identity (walk_controller.cpp:28): x, y, qw, qz
   robi.assign(R::I_COUNT, 0);
   robi[R::I_WORD] = WS_STOPPED | (PS_POSING_COMPLETE << RW_APS_SHIFT);
 }
@@ -956,6 +1023,17 @@ extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, doubl
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc;
   if ((rc = gather_leg(e, walker_tip, 3, LEG_FIELD(e, TIP), on_device)) != SHC_OK) return rc;
+  if (poser_tip || model_tip) { // derived on demand from the stored joint state / walker tip / body pose
+    HIP_TRY(hipSetDevice(e->device));
+    const int64_t threads = e->n * e->L;
+    const int derive_poser = !(e->cp.auto_posing && !e->cp.imu_posing); // the auto-pose path stores its per-leg poser tip
+#define CALL(L_, NJ_)                                                                                             \
+  derive_tips_kernel<L_, NJ_><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(                \
+      e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, derive_poser)
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+    HIP_TRY(hipGetLastError());
+  }
   if ((rc = gather_leg(e, poser_tip, 3, LEG_FIELD(e, POSER_TIP), on_device)) != SHC_OK) return rc;
   if ((rc = gather_leg(e, model_tip, 3, LEG_FIELD(e, MODEL_TIP), on_device)) != SHC_OK) return rc;
   if ((rc = gather_leg(e, tip_force, 3, LEG_FIELD(e, TF), on_device)) != SHC_OK) return rc;
@@ -977,7 +1055,16 @@ extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, doubl
 extern "C" int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (!e->cp.odometry) return fail(SHC_ERR_UNSUPPORTED, "SHC_FEAT_ODOMETRY is off");
-  return gather_rob(e, pose, 7, RobotFields::ODOM, on_device);
+  if (!pose) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  double *d = on_device ? pose : e->d_stage;
+  gather_odometry_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.robd, 64 / e->L, e->n);
+  HIP_TRY(hipGetLastError());
+  if (!on_device) {
+    HIP_TRY(hipMemcpyAsync(pose, d, size_t(e->n) * 7 * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return SHC_OK;
 }
 
 extern "C" int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness, int on_device) {
