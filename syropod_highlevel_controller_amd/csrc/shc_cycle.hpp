@@ -37,6 +37,7 @@ constexpr int LW_ACP = 1 << 2, LW_CFS = 1 << 3, LW_PM_SHIFT = 4, LW_NEG = 1 << 6
 constexpr int RW_LACP_SHIFT = 2, RW_LCFS_SHIFT = 6, RW_RTDA = 1 << 10, RW_APS_SHIFT = 11;
 
 constexpr int kMaxAutoPosers = 8;
+constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input table (one per swing iteration)
 // "this group of state fields changed during the launch" bits, kept per lane and OR-reduced over the wave before the
 // write-back: groups nobody changed are not stored (walk plane / manual pose of the robot tile; the parked stepper
 // origins of the per-leg planes, which change once per step period).
@@ -58,6 +59,8 @@ struct CycleParams {
   double stride_scale;       // (stance_period / period) / frequency   (:940-941)
   double swing_height, swing_width, body_clearance;
   double swing_progress_scaler; // pose_controller.cpp:1103
+  int32_t swing_c_count;        // entries of SharedConsts::swing_c in use; 0 = swing period too long for the table
+  int32_t swing_c_valid;        // swing iterations (phase - swing_start) < this have a scaled progress within [0, 1]
   int32_t velocity_input_mode;
   int32_t manual_posing, auto_posing, inclination_posing, imu_posing, admittance_control, dynamic_stiffness, use_joint_effort;
   int32_t clamp_joint_positions, clamp_joint_velocities, force_normal_touchdown;
@@ -71,15 +74,20 @@ struct CycleParams {
   double force_gain, virtual_stiffness, swing_stiffness_scaler, load_stiffness_scaler;
   // auto pose (pose_controller.cpp:44-106)
   int32_t n_auto_posers, pose_phase_length, pose_sync, auto_pose_reference_leg;
-  int32_t ap_start[kMaxAutoPosers], ap_end[kMaxAutoPosers]; // already * normaliser
+  // ---- tail staged to LDS only by kernels with auto posing (16-byte aligned start)
+  alignas(16) int32_t ap_start[kMaxAutoPosers];
+  int32_t ap_end[kMaxAutoPosers]; // both already * normaliser
   double ap_amp[kMaxAutoPosers][7];                         // x y z gravity roll pitch yaw
 };
 
 template <int L, int NJ>
-struct SharedConsts { // staged in LDS
-  CycleParams P;
+struct alignas(16) SharedConsts { // staged in LDS; the parameter block comes last so that its auto-pose tail ends the record
   LegConst<NJ> leg[L];
   double limit[4][9]; // max linear speed, max angular speed, max linear acceleration, max angular acceleration
+  // smoothStep(swing_progress * scaler) per swing iteration (pose_controller.cpp:1100-1108): the only per-cycle use of the
+  // swing progress is this control input, a function of the integer phase alone
+  double swing_c[kSwingTable];
+  alignas(16) CycleParams P;
 };
 
 // SoA planes in HBM.  Leg fields: legd[f * n_slots + slot]; robot fields: robd[f * n_rob_pad + robot].
@@ -309,21 +317,34 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     // ---- updateWalkPlanePose (:1092-1130)
     Pose wpp;
     {
-      // control input of the last leg (in id order) whose scaled swing progress lies in [0, 1]: each lane evaluates its
-      // own leg once (one division + smoothStep), the group picks the last valid one
-      double c_own = -1.0;
-      {
-        double sp = swing_progress_of(s.word, P) * P.swing_progress_scaler;
-        if (sp >= 0 && sp <= 1.0) c_own = smooth_step(sp);
-      }
+      // control input of the last leg (in id order) whose scaled swing progress lies in [0, 1]
       double c = 0.0;
       bool sel = false;
+      if (uni(P.swing_c_count) > 0) {
+        // the legs' words are already in every lane: pick the leg with integer tests, then one table read
+        int it_sel = 0;
 #pragma unroll
-      for (int j = 0; j < L; ++j) {
-        double cj = g.get(c_own, j);
-        if (cj >= 0.0) {
-          c = cj;
-          sel = true;
+        for (int j = 0; j < L; ++j) {
+          // clamping the iteration is the clamp of the progress to [0, 1] (walk_controller.cpp:880)
+          const int it = min(max(((lw[j] >> LW_PHASE_SHIFT) & LW_PHASE_MASK) - P.swing_start, 0), P.swing_c_count - 1);
+          const bool ok = ((lw[j] >> LW_PM_SHIFT) & 3) == PM_SWING && it < P.swing_c_valid;
+          it_sel = ok ? it : it_sel;
+          sel = sel || ok;
+        }
+        if (__any(sel)) c = sel ? C.swing_c[it_sel] : 0.0;
+      } else { // each lane evaluates its own leg once (one division + smoothStep), the group picks the last valid one
+        double c_own = -1.0;
+        {
+          double sp = swing_progress_of(s.word, P) * P.swing_progress_scaler;
+          if (sp >= 0 && sp <= 1.0) c_own = smooth_step(sp);
+        }
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          double cj = g.get(c_own, j);
+          if (cj >= 0.0) {
+            c = cj;
+            sel = true;
+          }
         }
       }
       V3 wplane = sel ? rb.get3(R::PLANE_PREV) : V3{0, 0, 0};

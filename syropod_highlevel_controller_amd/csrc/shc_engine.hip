@@ -198,17 +198,20 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   int32_t *gtile_i = st.robi + wave * (R::I_COUNT * RPW);
   // ---- prologue: every global load of this wave is issued before the first wait, so the HBM / L2 latencies overlap:
   //      (1) launch-uniform tables, (2) this wave's robot tile, (3) per-leg state; then the LDS writes; then one barrier.
-  constexpr int n8 = sizeof(SharedConsts<L, NJ>) / 8;
-  static_assert(sizeof(SharedConsts<L, NJ>) % 8 == 0, "const block must be a whole number of 8-byte words");
-  constexpr int citers = (n8 + 63) / 64; // enough for a 64-thread workgroup
-  double creg[citers];
+  using SC = SharedConsts<L, NJ>;
+  static_assert(sizeof(SC) % 16 == 0 && (offsetof(SC, P) + offsetof(CycleParams, ap_start)) % 16 == 0, "const block is copied in 16-byte words");
+  constexpr int n16_all = sizeof(SC) / 16;
+  constexpr int n16_core = (offsetof(SC, P) + offsetof(CycleParams, ap_start)) / 16; // without the auto-pose tables
+  const int n16 = FT::autop(GP) ? n16_all : n16_core;
+  constexpr int citers = (n16_all + 63) / 64; // enough for a 64-thread workgroup
+  double2 creg[citers];
   {
-    const double *src = reinterpret_cast<const double *>(gc);
+    const double2 *src = reinterpret_cast<const double2 *>(gc);
     const int nt = blockDim.x;
 #pragma unroll
     for (int it = 0; it < citers; ++it) {
       int i = it * nt + threadIdx.x;
-      creg[it] = i < n8 ? src[i] : 0.0;
+      creg[it] = i < n16 ? src[i] : double2{0.0, 0.0};
     }
   }
   double t_core[(R::CORE_END * RPW + 63) / 64], t_man[((R::MANUAL_END - R::MPOSE) * RPW + 63) / 64],
@@ -227,12 +230,12 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
     load_leg<NJ, F>(s, pk, st, GP, slot);
   }
   {
-    double *dst = reinterpret_cast<double *>(&C);
+    double2 *dst = reinterpret_cast<double2 *>(&C);
     const int nt = blockDim.x;
 #pragma unroll
     for (int it = 0; it < citers; ++it) {
       int i = it * nt + threadIdx.x;
-      if (i < n8) dst[i] = creg[it];
+      if (i < n16) dst[i] = creg[it];
     }
   }
   if (any_robot) {
@@ -463,6 +466,10 @@ static void build_shared_consts(const shc_params &p, const shc_tables &t, const 
     lc.first_stride_scaler = double(msp) / double(step.stance_period);
     lc.starts_in_swing = (lc.phase_offset > step.swing_start && lc.phase_offset < step.swing_end) ? 1 : 0;
   }
+  for (int it = 0; it < cp.swing_c_count; ++it) { // LegStepper::updatePhase progress (walk_controller.cpp:878-880) -> control input
+    double sp = clampd(double(it + 1) / double(step.swing_end - step.swing_start), 0.0, 1.0) * cp.swing_progress_scaler;
+    c.swing_c[it] = smooth_step(sp);
+  }
   for (int b = 0; b < 9; ++b) {
     c.limit[0][b] = t.max_linear_speed[b];
     c.limit[1][b] = t.max_angular_speed[b];
@@ -496,6 +503,12 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.swing_width = p.swing_width;
   c.body_clearance = p.body_clearance;
   c.swing_progress_scaler = fmax(1.0, double(p.swing_phase) / p.phase_offset); // pose_controller.cpp:1103
+  c.swing_c_count = (s.swing_end - s.swing_start) <= kSwingTable ? (s.swing_end - s.swing_start) : 0;
+  c.swing_c_valid = 0;
+  for (int it = 0; it < c.swing_c_count; ++it) { // progress is non-decreasing in the iteration: the valid ones form a prefix
+    double sp = clampd(double(it + 1) / double(s.swing_end - s.swing_start), 0.0, 1.0) * c.swing_progress_scaler;
+    if (sp >= 0 && sp <= 1.0) c.swing_c_valid = it + 1;
+  }
   c.velocity_input_mode = p.velocity_input_mode;
   c.manual_posing = p.manual_posing;
   c.auto_posing = p.auto_posing;

@@ -127,7 +127,7 @@ SHC_HD void ik_step(const LC &lc, const Chain<NJ> &c, const double (&q)[NJ], con
     vg[i] = -v * lc.jw_vrange[i];
   }
   // evaluated unconditionally and selected afterwards: no exec-mask branch around the sqrt / division
-  double ps = 1.0 / sqrt(pcost), vs = 1.0 / sqrt(vcost);
+  double ps = fast_rsqrt(pcost), vs = fast_rsqrt(vcost);
   ps = pcost == 0.0 ? 0.0 : ps;
   vs = vcost == 0.0 ? 0.0 : vs;
   const double l2 = kDls * kDls;

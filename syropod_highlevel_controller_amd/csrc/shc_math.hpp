@@ -260,6 +260,31 @@ SHC_HD V3 quartic_bezier_dot(V3 p0, V3 p1, V3 p2, V3 p3, V3 p4, double t) {
 }
 
 // ---------------------------------------------------------------- small SPD solve  A x = b,  A = A^T > 0  (N <= 6)
+// Reciprocal / reciprocal square root for the DLS solve, whose arithmetic form is this engine's own (shc_leg.hpp): the
+// hardware estimate refined by two Newton steps (<= 1 ulp for the well-scaled positive arguments that occur: pivots
+// >= lambda^2, limit costs) - 5-6 dependent instructions instead of the ~12-20 of an IEEE division / sqrt + division.
+// The host build of the same templates (init chain) uses plain division.
+SHC_HD double fast_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+SHC_HD double fast_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double y = __builtin_amdgcn_rsq(x);
+  y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+  y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
+  return y;
+#else
+  return 1.0 / sqrt(x);
+#endif
+}
+
 // A is the damped normal matrix J^T J + lambda^2 I of the DLS step (always SPD), so an unpivoted
 // LDL^T in registers is exact enough and branch-free; fully unrolled for compile-time N.
 template <int N>
@@ -267,7 +292,7 @@ SHC_HD void spd_solve(double (&a)[N][N], double (&b)[N]) {
   double dinv[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    dinv[k] = 1.0 / a[k][k];
+    dinv[k] = fast_rcp(a[k][k]);
 #pragma unroll
     for (int i = k + 1; i < N; ++i) {
       double l = a[i][k] * dinv[k];
