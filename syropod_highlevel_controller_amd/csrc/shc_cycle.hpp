@@ -118,7 +118,7 @@ struct RobotFields {
   static constexpr int IMUQ = 47, IMUQ_END = 51;                        // IMU orientation input
   static constexpr int APREV = 51, APREV_END = 55;                      // previous cycle's auto_pose_.rotation_
   static constexpr int CPOSE = 55, CPOSE_END = 62;                      // output: Model::current_pose_
-  static constexpr int WPP = 62, WPP_END = 69;                          // output: walk_plane_pose_ (model default pose)
+  static constexpr int WPP = 62, WPP_END = 69;                          // walk_plane_pose_ of the current cycle (LDS tile only)
   static constexpr int ODOM = 69, COUNT = 73; // WalkController::odometry_ideal_ (odometry feature): x, y, qw, qz (pure yaw)
   static constexpr int I_WORD = 0, I_APOSER = 1, I_POSE_PHASE = 2, I_RESET_MODE = 3, I_COUNT = 4;
 };

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   if (FT::manual(P) && (dirty & DIRTY_MANUAL)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
   if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
-  store_rob_fields<RPW, R::CPOSE, R::WPP_END>(tile, gtile, lane);
+  store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
   if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::COUNT>(tile, gtile, lane);
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
   SHC_TICK(14);
