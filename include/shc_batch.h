@@ -235,6 +235,16 @@ int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, double *poser_ti
 /* Per-robot outputs: body pose [n][7] (x,y,z,qw,qx,qy,qz) = Model::current_pose_ (state_controller.cpp:911),
  * desired velocity [n][3] (vx,vy,omega), walk_state [n]. */
 int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device);
+/*
+ * StateController::changeGait (state_controller.cpp:513-538; gaitSelectionCallback :1206): the gait members of `new_gait`
+ * (stance_phase, swing_phase, phase_offset, offset_multiplier and, with auto_posing, the auto-pose tables) replace the
+ * engine's; step cycle, velocity / acceleration limits and auto-pose phases are regenerated as generateStepCycle +
+ * generateLimits + setAutoPoseParams do.  A batch shares one gait, so the change happens only when EVERY instance is
+ * STOPPED; otherwise the velocity inputs of all instances are zeroed (the reference "forces the Syropod to stop") and
+ * *still_walking receives the number of instances not yet STOPPED: step on and call again, as the reference retries on
+ * every loop while gait_change_flag_ is set.  Synchronises the engine's stream.
+ */
+int shc_engine_change_gait(shc_engine *e, const shc_params *new_gait, int64_t *still_walking);
 /* WalkController::getOdometryIdeal() (walk_controller.h:112; integrated at walk_controller.cpp:643 from
  * calculateOdometry :783-791): [n][7] (x,y,z,qw,qx,qy,qz).  Needs SHC_FEAT_ODOMETRY (on by default). */
 int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device);

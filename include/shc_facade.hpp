@@ -76,6 +76,13 @@ public:
     check(shc_engine_step(e_, n_cycles), "shc_engine_step");
     refresh();
   }
+  // StateController::changeGait (state_controller.cpp:513): true once the gait has changed, false while the robots are
+  // still being stopped (keep cycling and call again, as the reference does while gait_change_flag_ is set)
+  bool changeGait(const shc_params &new_gait) {
+    int64_t still = 0;
+    check(shc_engine_change_gait(e_, &new_gait, &still), "shc_engine_change_gait");
+    return still == 0;
+  }
   void refresh() {
     check(shc_engine_get_joint_state(e_, q_.data(), qd_.data(), 0), "get_joint_state");
     check(shc_engine_get_leg_state(e_, walker_tip_.data(), poser_tip_.data(), model_tip_.data(), tip_force_.data(), admittance_.data(),

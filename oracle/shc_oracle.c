@@ -2122,6 +2122,47 @@ int orc_startup(orc_robot *r)
   return r->robot_state == RS_RUNNING ? loops : -1;
 }
 
+/* StateController::changeGait (state_controller.cpp:513-538) with initGaitParameters (:1941-1969) and, for auto posing,
+ * initAutoPoseParameters + setAutoPoseParams (:1973-1999, pose_controller.cpp:44-106): the gait-dependent members of
+ * `np` replace the current ones.  Returns 1 when the gait was changed, 0 when the robot is still walking (the reference
+ * then zeroes the velocity inputs and retries on the next loop). */
+int orc_change_gait(orc_robot *r, const shc_params *np)
+{
+  if (r->walk_state != STOPPED)
+  {
+    r->linear_velocity_input[0] = r->linear_velocity_input[1] = 0.0;
+    r->angular_velocity_input = 0.0;
+    return 0;
+  }
+  shc_params *p = &r->params;
+  p->stance_phase = np->stance_phase;
+  p->swing_phase = np->swing_phase;
+  p->phase_offset = np->phase_offset;
+  memcpy(p->offset_multiplier, np->offset_multiplier, sizeof p->offset_multiplier);
+  r->step = generate_step_cycle(p); /* WalkController::generateStepCycle */
+  walker_generate_limits(r);
+  if (p->auto_posing)
+  {
+    p->pose_frequency = np->pose_frequency;
+    p->pose_phase_length = np->pose_phase_length;
+    p->n_auto_posers = np->n_auto_posers;
+    memcpy(p->pose_phase_starts, np->pose_phase_starts, sizeof p->pose_phase_starts);
+    memcpy(p->pose_phase_ends, np->pose_phase_ends, sizeof p->pose_phase_ends);
+    memcpy(p->pose_negation_phase_starts, np->pose_negation_phase_starts, sizeof p->pose_negation_phase_starts);
+    memcpy(p->pose_negation_phase_ends, np->pose_negation_phase_ends, sizeof p->pose_negation_phase_ends);
+    memcpy(p->negation_transition_ratio, np->negation_transition_ratio, sizeof p->negation_transition_ratio);
+    memcpy(p->x_amplitudes, np->x_amplitudes, sizeof p->x_amplitudes);
+    memcpy(p->y_amplitudes, np->y_amplitudes, sizeof p->y_amplitudes);
+    memcpy(p->z_amplitudes, np->z_amplitudes, sizeof p->z_amplitudes);
+    memcpy(p->gravity_amplitudes, np->gravity_amplitudes, sizeof p->gravity_amplitudes);
+    memcpy(p->roll_amplitudes, np->roll_amplitudes, sizeof p->roll_amplitudes);
+    memcpy(p->pitch_amplitudes, np->pitch_amplitudes, sizeof p->pitch_amplitudes);
+    memcpy(p->yaw_amplitudes, np->yaw_amplitudes, sizeof p->yaw_amplitudes);
+    poser_set_auto_pose_params(r);
+  }
+  return 1;
+}
+
 void orc_get_tables(const orc_robot *r, shc_tables *out)
 {
   memset(out, 0, sizeof *out);
@@ -2357,6 +2398,20 @@ void orc_batch_get_body_state(orc_batch *b, double *pose, double *velocity, int3
   for (int64_t i = 0; i < b->n; ++i)
     orc_get_body_state(&b->robots[i], pose ? pose + 7 * i : NULL, velocity ? velocity + 3 * i : NULL,
                        walk_state ? walk_state + i : NULL);
+}
+
+/* changeGait on every robot of the batch; returns how many were still walking (0 = the gait was changed everywhere) */
+int64_t orc_batch_change_gait(orc_batch *b, const shc_params *np)
+{
+  int64_t walking = 0;
+  for (int64_t i = 0; i < b->n; ++i) walking += b->robots[i].walk_state != STOPPED;
+  if (walking) /* a batch shares one gait: nobody changes until everybody has stopped */
+  {
+    for (int64_t i = 0; i < b->n; ++i) orc_set_velocity(&b->robots[i], 0.0, 0.0, 0.0);
+    return walking;
+  }
+  for (int64_t i = 0; i < b->n; ++i) orc_change_gait(&b->robots[i], np);
+  return 0;
 }
 
 /* WalkController::getOdometryIdeal (walk_controller.h) per robot: position xyz + rotation wxyz */

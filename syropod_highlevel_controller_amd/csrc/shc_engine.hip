@@ -400,6 +400,21 @@ __global__ void scatter_robi_kernel(const int32_t *src, int32_t *robi, int rpw, 
   int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r < n) robi[rob_index(r, f, rpw, RobotFields::I_COUNT)] = src[r];
 }
+__global__ void count_walking_kernel(int32_t *count, const int32_t *robi, int rpw, int64_t n) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  bool walking = r < n && (robi[rob_index(r, RobotFields::I_WORD, rpw, RobotFields::I_COUNT)] & 3) != WS_STOPPED;
+  unsigned long long m = __ballot(walking);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+__global__ void fill_rob_kernel(double *robd, int rpw, int64_t n, int f0, int K, double v) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  for (int k = 0; k < K; ++k) robd[rob_index(r, f0 + k, rpw, RobotFields::COUNT)] = v;
+}
+__global__ void fill_robi_kernel(int32_t *robi, int rpw, int64_t n, int f, int32_t v) {
+  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (r < n) robi[rob_index(r, f, rpw, RobotFields::I_COUNT)] = v;
+}
 __global__ void gather_walk_state_kernel(int32_t *dst, const int32_t *robi, int rpw, int64_t n) {
   int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (r >= n) return;
@@ -1063,6 +1078,62 @@ extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, doubl
     }
   }
   return SHC_OK;
+}
+
+extern "C" int shc_engine_change_gait(shc_engine *e, const shc_params *ng, int64_t *still_walking) {
+  if (!e || !ng) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  const unsigned grid = (unsigned)((e->n + 255) / 256);
+  const int rpw = 64 / e->L;
+  int32_t *d_count = reinterpret_cast<int32_t *>(e->d_stage);
+  int32_t walking = 0;
+  HIP_TRY(hipMemsetAsync(d_count, 0, 4, e->stream));
+  count_walking_kernel<<<dim3(grid), dim3(256), 0, e->stream>>>(d_count, e->st.robi, rpw, e->n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(&walking, d_count, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (still_walking) *still_walking = walking;
+  if (walking) { // state_controller.cpp:531-537
+    fill_rob_kernel<<<dim3(grid), dim3(256), 0, e->stream>>>(e->st.robd, rpw, e->n, RobotFields::VIN, 3, 0.0);
+    HIP_TRY(hipGetLastError());
+    return SHC_OK;
+  }
+  shc_params p = e->params; // initGaitParameters (state_controller.cpp:1941-1969)
+  p.stance_phase = ng->stance_phase;
+  p.swing_phase = ng->swing_phase;
+  p.phase_offset = ng->phase_offset;
+  memcpy(p.offset_multiplier, ng->offset_multiplier, sizeof p.offset_multiplier);
+  if (p.auto_posing) { // initAutoPoseParameters (:1973-1999)
+    p.pose_frequency = ng->pose_frequency;
+    p.pose_phase_length = ng->pose_phase_length;
+    p.n_auto_posers = ng->n_auto_posers;
+    memcpy(p.pose_phase_starts, ng->pose_phase_starts, sizeof p.pose_phase_starts);
+    memcpy(p.pose_phase_ends, ng->pose_phase_ends, sizeof p.pose_phase_ends);
+    memcpy(p.pose_negation_phase_starts, ng->pose_negation_phase_starts, sizeof p.pose_negation_phase_starts);
+    memcpy(p.pose_negation_phase_ends, ng->pose_negation_phase_ends, sizeof p.pose_negation_phase_ends);
+    memcpy(p.negation_transition_ratio, ng->negation_transition_ratio, sizeof p.negation_transition_ratio);
+    memcpy(p.x_amplitudes, ng->x_amplitudes, sizeof p.x_amplitudes);
+    memcpy(p.y_amplitudes, ng->y_amplitudes, sizeof p.y_amplitudes);
+    memcpy(p.z_amplitudes, ng->z_amplitudes, sizeof p.z_amplitudes);
+    memcpy(p.gravity_amplitudes, ng->gravity_amplitudes, sizeof p.gravity_amplitudes);
+    memcpy(p.roll_amplitudes, ng->roll_amplitudes, sizeof p.roll_amplitudes);
+    memcpy(p.pitch_amplitudes, ng->pitch_amplitudes, sizeof p.pitch_amplitudes);
+    memcpy(p.yaw_amplitudes, ng->yaw_amplitudes, sizeof p.yaw_amplitudes);
+  }
+  int L, NJ;
+  int rc = validate_params(&p, &L, &NJ);
+  if (rc != SHC_OK) return rc;
+  shc_tables t;
+  if ((rc = shc_generate_tables(&p, &t)) != SHC_OK) return rc; // generateStepCycle + generateLimits (morphology tables come out unchanged)
+  e->params = p;
+  e->tables = t;
+  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  if ((rc = upload_consts(e)) != SHC_OK) return rc;
+  if (p.auto_posing) { // setAutoPoseParams builds fresh AutoPosers: their start / end checks are reset (pose_controller.cpp:39-61)
+    fill_robi_kernel<<<dim3(grid), dim3(256), 0, e->stream>>>(e->st.robi, rpw, e->n, RobotFields::I_APOSER, 0);
+    HIP_TRY(hipGetLastError());
+  }
+  return shc_engine_synchronize(e);
 }
 
 extern "C" int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device) {

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_set_pose_reset_mode", "shc_engine_step", "shc_engine_synchronize",
     "shc_engine_get_joint_state", "shc_engine_joint_buffer", "shc_engine_joint_index", "shc_engine_get_leg_state",
     "shc_engine_get_body_state", "shc_engine_get_odometry", "shc_engine_get_virtual_stiffness",
+    "shc_engine_change_gait",
 ]
 
 
@@ -94,6 +95,7 @@ def lib():
         L.shc_engine_get_leg_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int]
         L.shc_engine_get_body_state.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
         L.shc_engine_get_odometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_change_gait.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
         L.shc_engine_get_virtual_stiffness.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -231,6 +233,15 @@ class BatchEngine:
         ws = np.zeros(self.n, dtype=np.int32)
         _check(self.L.shc_engine_get_body_state(self.h, _p(pose), _p(vel), _p(ws), 0), "get_body_state")
         return pose, vel, ws
+
+    def change_gait(self, new_gait: Params) -> int:
+        """StateController::changeGait for the whole batch.  Returns the number of instances still walking (their velocity
+        inputs have been zeroed; step on and call again); 0 means the gait was changed."""
+        still = C.c_int64(0)
+        _check(self.L.shc_engine_change_gait(self.h, C.byref(new_gait), C.byref(still)), "change_gait")
+        if still.value == 0:
+            self.params = new_gait
+        return int(still.value)
 
     def odometry(self):
         """WalkController::getOdometryIdeal per instance: [n][7] (x, y, z, qw, qx, qy, qz)."""

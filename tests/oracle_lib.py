@@ -71,6 +71,8 @@ def lib():
         L.orc_batch_get_leg_state.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _ip]
         L.orc_batch_get_body_state.argtypes = [C.c_void_p, _dp, _dp, _ip]
         L.orc_batch_get_odometry.argtypes = [C.c_void_p, _dp]
+        L.orc_batch_change_gait.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.orc_batch_change_gait.restype = C.c_int64
         L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
         L.orc_test_generate_step_cycle.argtypes = [C.POINTER(Params), C.POINTER(StepCycle)]
         L.orc_test_quat_to_euler.argtypes = [_dp, C.c_int, _dp]
@@ -234,6 +236,12 @@ class OracleBatch:
         ws = np.zeros(self.n, dtype=np.int32)
         self.L.orc_batch_get_body_state(self.h, _ptr(pose), _ptr(vel), _ptr(ws, _ip))
         return pose, vel, ws
+
+    def change_gait(self, new_gait):
+        still = int(self.L.orc_batch_change_gait(self.h, C.byref(new_gait)))
+        if still == 0:
+            self.p = new_gait
+        return still
 
     def odometry(self):
         pose = np.zeros((self.n, 7))

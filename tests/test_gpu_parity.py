@@ -239,6 +239,43 @@ def test_start_stop_start_sequence(Engine):
         compare(eng, ob)
 
 
+@pytest.mark.parametrize("auto", [False, True])
+def test_change_gait_while_walking(Engine, auto):
+    """StateController::changeGait (state_controller.cpp:513-538): requested while MOVING the robots are first forced to
+    stop, then step cycle / limits / auto-pose phases are regenerated for the new gait and the walk resumes."""
+    p = default_hexapod_params("tripod")
+    new = default_hexapod_params("ripple")
+    if auto:
+        p.auto_posing = new.auto_posing = 1
+    n = 40
+    inp = make_inputs(p, n, 61)
+    eng, ob, _ = run_pair(Engine, p, n, inp, [150])
+    assert eng.change_gait(new) == n and ob.change_gait(new) == n  # everybody is MOVING: inputs zeroed, no change yet
+    loops = 0
+    while True:  # the reference retries on every loop while gait_change_flag_ is set
+        eng.step(50)
+        eng.synchronize()
+        ob.step(50, 8)
+        compare(eng, ob)
+        a, b = eng.change_gait(new), ob.change_gait(new)
+        assert a == b
+        loops += 1
+        assert loops < 20
+        if a == 0:
+            break
+    t = eng.tables()
+    assert t.step.period == 156 and t.step.swing_start == 52  # ripple step cycle (SURVEY section 8c)
+    for o in (eng, ob):
+        o.set_velocity(inp["lin"], -inp["ang"])
+    for k in (1, 1, 98, 300):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        compare(eng, ob)
+    _, _, ws = eng.body_state()
+    assert (ws == WALK_MOVING).all()
+
+
 @pytest.mark.parametrize("n", [1, 9, 10, 11, 64, 65, 127])
 def test_ragged_batch_sizes(Engine, n):
     """Batches that do not fill a wavefront (10 hexapods per wave): tail groups and tail lanes mirror live lanes."""
