@@ -161,6 +161,12 @@ const char *shc_last_error(void);
  * `n_doubles` (even) doubles; the known byte count calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
 int shc_debug_plane_copy(int device, int64_t n_doubles, int reps);
 
+/* HIP stream helpers for hosts without their own HIP binding (the ctypes tests, a cgo / JNI host): a non-blocking
+ * stream on `device` to pass to shc_engine_create / shc_engine_set_stream.  Engines of different morphology bins run
+ * concurrently when each has its own stream (BASELINE.json configs[4]). */
+int shc_stream_create(int device, void **stream);
+int shc_stream_destroy(int device, void *stream);
+
 /*
  * Host-side init chain = StateController::init + initModel + direct start-up + workspace /
  * walkspace / limit generation (state_controller.cpp:127-153, 263-272).  Pure host function

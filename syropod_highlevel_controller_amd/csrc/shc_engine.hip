@@ -634,6 +634,20 @@ extern "C" int shc_debug_plane_copy(int device, int64_t n_doubles, int reps) {
   return SHC_OK;
 }
 
+extern "C" int shc_stream_create(int device, void **stream) {
+  if (!stream) return fail(SHC_ERR_INVALID_ARG, "stream is NULL");
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t s;
+  HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void *)s;
+  return SHC_OK;
+}
+extern "C" int shc_stream_destroy(int device, void *stream) {
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+  return SHC_OK;
+}
+
 extern "C" int shc_generate_tables(const shc_params *params, shc_tables *out) {
   int L, NJ;
   int rc = validate_params(params, &L, &NJ);

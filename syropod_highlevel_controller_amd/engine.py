@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_set_pose_reset_mode", "shc_engine_step", "shc_engine_synchronize",
     "shc_engine_get_joint_state", "shc_engine_joint_buffer", "shc_engine_joint_index", "shc_engine_get_leg_state",
     "shc_engine_get_body_state", "shc_engine_get_odometry", "shc_engine_get_virtual_stiffness",
-    "shc_engine_change_gait",
+    "shc_engine_change_gait", "shc_stream_create", "shc_stream_destroy",
 ]
 
 
@@ -95,6 +95,8 @@ def lib():
         L.shc_engine_get_leg_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int]
         L.shc_engine_get_body_state.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
         L.shc_engine_get_odometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.shc_stream_destroy.argtypes = [C.c_int, C.c_void_p]
         L.shc_engine_change_gait.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
         L.shc_engine_get_virtual_stiffness.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib = L

@@ -161,6 +161,42 @@ def test_config5_mixed_morphologies_binned(Engine):
         run_pair(Engine, p, 33, make_inputs(p, 33, legs * 10 + dof), [40, 80, 80], twin=True, min_well_posed=0.5)
 
 
+def test_config5_interleaved_fleet(Engine):
+    """configs[4], interleaved variant: morphology = instance id mod 5.  The fleet bins the instances (one engine and one
+    HIP stream per bin) and hands results back in the caller's instance order; every instance must match the oracle of
+    its own morphology."""
+    from syropod_highlevel_controller_amd.fleet import MixedFleet
+    morphs = [synthetic_octopod_params(g, d, l) for l, d, g in ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"),
+                                                                (6, 5, "tripod"))]
+    n = 85
+    mid = np.arange(n) % len(morphs)
+    rng = np.random.default_rng(77)
+    lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
+    effort = rng.normal(0, 0.5, size=(n, 8, 5))
+    fleet = MixedFleet(morphs, mid)
+    fleet.set_velocity(lin, ang)
+    fleet.set_joint_effort(effort)
+    oracles = []
+    for k, p in enumerate(morphs):
+        idx = np.nonzero(mid == k)[0]
+        ob = OracleBatch(p, len(idx))
+        ob.set_velocity(lin[idx], ang[idx])
+        ob.set_joint_effort(np.ascontiguousarray(effort[idx][:, :p.leg_count, :p.leg_dof[0]].reshape(len(idx), -1)))
+        oracles.append((idx, p, ob))
+    for cycles in (1, 59, 60):
+        fleet.step(cycles)
+        fleet.synchronize()
+        q, _ = fleet.joints()
+        ws = fleet.walk_state()
+        for idx, p, ob in oracles:
+            ob.step(cycles, 8)
+            qo = ob.joints()[0].reshape(len(idx), p.leg_count, p.leg_dof[0])
+            assert np.abs(q[idx, :p.leg_count, :p.leg_dof[0]] - qo).max() <= TOL_Q
+            assert np.isnan(q[idx, p.leg_count:, :]).all() and np.isnan(q[idx, :, p.leg_dof[0]:]).all()
+            assert np.array_equal(ws[idx], ob.body_state()[2])
+    fleet.close()
+
+
 # ------------------------------------------------------------------------------------------------ features
 def test_auto_posing(Engine):
     for gait in ("tripod", "ripple"):
