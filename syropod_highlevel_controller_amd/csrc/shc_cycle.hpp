@@ -133,10 +133,13 @@ struct DevState {
 
 #if defined(__HIPCC__)
 
-// Phase fence: keeps the machine scheduler from hoisting the next phase's LDS/const loads above this point, which
-// bounds live ranges to one phase (the fused cycle is one huge basic block otherwise -> ~470 live VGPRs).
-#ifndef SHC_PHASE_FENCE
+// Phase fences (-DSHC_FENCE): scheduling barriers between the phases of the cycle.  They bounded live ranges while the
+// kernel was register-starved; with MachineLICM off (see engine.py) the cycle fits without them, and the max-ILP
+// scheduler overlaps the LDS / division latencies of neighbouring phases (-6 % per launch), so they are off by default.
+#if defined(SHC_FENCE)
 #define SHC_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SHC_PHASE_FENCE() do {} while (0)
 #endif
 // Development-only phase timestamps (build with -DSHC_TIMING): wave 0 / lane 0 stores s_memtime at phase boundaries.
 #ifdef SHC_TIMING

@@ -51,8 +51,12 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     # -disable-machine-licm: MachineLICM hoists the materialisation of ~100 FP64 literals (polynomial coefficients of
     # sincos / atan2, tolerances) out of the n_cycles loop and pins them in VGPRs for the whole launch (256 VGPRs + scratch
     # spills); re-materialising them at use keeps the hexapod kernel at 192 VGPRs with no scratch.
+    # -amdgpu-sched-strategy=max-ilp: at one or two waves per SIMD the cycle is bound by dependent-issue latency (FP64
+    # dependent ops issue every 8 clocks, LDS reads return after ~60); the ILP-first scheduler spends the spare VGPRs
+    # (the occupancy target of 2 waves/SIMD allows 256) on overlapping independent chains.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-mllvm", "-disable-machine-licm", "-o", _SO, os.path.join(_SRC, "shc_engine.hip")]
+           "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-o", _SO,
+           os.path.join(_SRC, "shc_engine.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
