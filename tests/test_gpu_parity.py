@@ -275,6 +275,60 @@ def test_start_stop_start_sequence(Engine):
         compare(eng, ob)
 
 
+@pytest.mark.parametrize("gait,seed", [("tripod", 101), ("ripple", 102), ("amble", 103), ("tripod", 104), ("wave", 105), ("ripple", 106)])
+def test_soak_random_command_schedule(Engine, gait, seed):
+    """1 500 cycles with the commands changing every few dozen cycles: new velocities (a third of them zero, so robots
+    stop and restart at arbitrary phases), manual pose inputs and pose-reset modes, single-cycle and fused launches mixed.
+    Exercises every walk-state transition from arbitrary stepper states; the bar holds at every checkpoint for every
+    instance whose reference trajectory is well-posed: a saturated manual pose can put a tip out of reach, the reference
+    then reports an IK failure (model.cpp:921) and its clamped DLS iteration becomes chaotic (module docstring), so
+    an instance is dropped from the comparison once a twin oracle with inputs perturbed by 1e-13 has left it by 1e-9."""
+    p = default_hexapod_params(gait)
+    if seed == 104:
+        p.auto_posing = 1
+    if seed == 105:  # configs[2] features: admittance from measured tip forces + IMU posing, inputs changing too
+        p.admittance_control, p.imu_posing = 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    if seed == 106:  # configs[3] morphology
+        p = synthetic_octopod_params(gait, 5, 8)
+    n = 64
+    L, D = p.leg_count, p.leg_dof[0]
+    rng = np.random.default_rng(seed)
+    eng, ob, tw = Engine(p, n), OracleBatch(p, n), OracleBatch(p, n)
+    effort = rng.normal(0, 0.5, size=(n, L * D))
+    for o in (eng, ob, tw):
+        o.set_joint_effort(effort)
+    done = 0
+    well_posed = np.ones(n, dtype=bool)
+    while done < 1500:
+        lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
+        stop = rng.random(n) < 0.33
+        lin[stop], ang[stop] = 0.0, 0.0
+        tv, rv = rng.uniform(-1, 1, size=(n, 3)) * (rng.random((n, 1)) < 0.3), rng.uniform(-1, 1, size=(n, 3)) * (rng.random((n, 1)) < 0.3)
+        reset = rng.choice([0, 0, 0, 1, 2, 3, 4, 5], size=n).astype(np.int32)
+        for o in (eng, ob):
+            o.set_velocity(lin, ang)
+            o.set_pose_input(tv, rv)
+            o.set_pose_reset_mode(reset)
+        tw.set_velocity(lin * (1 + 1e-13), ang)
+        tw.set_pose_input(tv * (1 + 1e-13), rv * (1 + 1e-13))
+        tw.set_pose_reset_mode(reset)
+        if seed == 105:
+            extra = make_inputs(p, n, int(rng.integers(1 << 30)), imu=True, force=2.0)
+            for o in (eng, ob, tw):
+                o.set_imu(extra["imu_q"], extra["gyro"])
+                o.set_tip_force(extra["force"] * (1 + 1e-13 * (o is tw)))
+        for k in (1, int(rng.integers(2, 40)), int(rng.integers(20, 90))):
+            eng.step(k)
+            eng.synchronize()
+            ob.step(k, 8)
+            tw.step(k, 8)
+            well_posed &= np.abs(ob.joints()[0] - tw.joints()[0]).max(axis=1) <= 1e-9
+            compare(eng, ob, mask=well_posed)
+            done += k
+    assert well_posed.mean() >= 0.8
+
+
 @pytest.mark.parametrize("auto", [False, True])
 def test_change_gait_while_walking(Engine, auto):
     """StateController::changeGait (state_controller.cpp:513-538): requested while MOVING the robots are first forced to
@@ -413,6 +467,57 @@ def test_full_size_config2_properties(Engine):
     apply(ob, {k: v[:m] for k, v in inp.items()})
     ob.step(400, 8)
     assert np.abs(ob.joints()[0] - q[:m]).max() <= TOL_Q
+
+
+def test_large_batch_uses_256_thread_workgroups(Engine):
+    """>= 1 024 waves (10 240 hexapods) switch to 4-wave workgroups sharing one LDS copy of the tables: every instance of
+    such a batch against the oracle, single-cycle and fused launches."""
+    p = default_hexapod_params("ripple")
+    n = 10300
+    inp = make_inputs(p, n, 53)
+    eng = Engine(p, n)
+    ob = OracleBatch(p, n)
+    apply(eng, inp)
+    apply(ob, inp)
+    threads = os.cpu_count() or 8
+    for k in (1, 1, 58, 60):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, threads)
+        compare(eng, ob)
+
+
+def test_full_size_config3_and_config4_properties(Engine):
+    """configs[2] (65 536 hexapods, wave gait, admittance + IMU) and the per-GPU share of configs[3] (131 072 octopods,
+    8 x 5, ripple): size-independent properties at full size + parity of a slice (the bar itself is met at oracle-sized
+    batches in the tests above)."""
+    for name, p, n, horizon in (("config3", default_hexapod_params("wave"), 65536, 60),
+                                ("config4", synthetic_octopod_params("ripple", 5, 8), 131072, 60)):
+        if name == "config3":
+            p.admittance_control, p.imu_posing = 1, 1
+            p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+        inp = make_inputs(p, n, 59, imu=(name == "config3"), force=2.0 if name == "config3" else None)
+        for k in inp:  # identical inputs in two places of the batch must give bit-identical outputs
+            inp[k][-512:] = inp[k][:512]
+        eng = Engine(p, n)
+        apply(eng, inp)
+        eng.step(horizon)
+        eng.synchronize()
+        q, qd = eng.joints()
+        ls = eng.leg_state()
+        assert np.isfinite(q).all() and np.isfinite(qd).all()
+        assert np.array_equal(q[-512:], q[:512]) and np.array_equal(ls["leg_status"][-512:], ls["leg_status"][:512])
+        L, D = p.leg_count, p.leg_dof[0]
+        jmin = np.array([[p.joint[l][j].min for j in range(D)] for l in range(L)]).reshape(-1)
+        jmax = np.array([[p.joint[l][j].max for j in range(D)] for l in range(L)]).reshape(-1)
+        assert (q >= jmin - 1e-12).all() and (q <= jmax + 1e-12).all()
+        m = 64
+        ob = OracleBatch(p, m)
+        apply(ob, {k: v[:m] for k, v in inp.items()})
+        ob.step(horizon, 8)
+        assert np.abs(ob.joints()[0] - q[:m]).max() <= TOL_Q
+        assert np.array_equal(ob.body_state()[2], eng.body_state()[2][:m])
+        eng.close()
 
 
 def test_device_pointer_io_with_torch(Engine):
