@@ -260,6 +260,32 @@ int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device);
  * first update (the reference leaves the member uninitialised).  SHC_ERR_UNSUPPORTED without admittance_control. */
 int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness, int on_device);
 
+/*
+ * ROS message surface.  Numeric payload of syropod_highlevel_controller/LegState.msg as
+ * StateController::publishLegState fills it (msg/LegState.msg; state_controller.cpp:809-893), one record per leg of ONE
+ * instance: the node copies the fields into its message and adds stamps, frame ids and the leg name.
+ * Not provided (the node keeps computing them): actual_tip_pose (FK of the MEASURED joint positions, :839, an input the
+ * engine never sees), model_tip_velocity (:845-849) and the per-leg auto_pose (:877-880).  Tip orientations are the
+ * reference's UNDEFINED rotation (0,0,0,0) on the accelerated path (<= 3 DOF or gravity_aligned_tips off).
+ */
+typedef struct shc_leg_state_msg {
+  double walker_tip_position[3]; /* walker_tip_pose.pose.position   :822-824 (frame walk_plane) */
+  double target_tip_position[3]; /* target_tip_pose.pose.position   :826-828 */
+  double poser_tip_position[3];  /* poser_tip_pose.pose.position    :830-832 (frame base_link) */
+  double model_tip_position[3];  /* model_tip_pose.pose.position    :834-836 */
+  double joint_positions[SHC_MAX_JOINTS];  /* Joint::desired_position_ :854 */
+  double joint_velocities[SHC_MAX_JOINTS]; /* Joint::desired_velocity_ :855 */
+  double joint_efforts[SHC_MAX_JOINTS];    /* Joint::desired_effort_   :856 (never assigned on this path: 0) */
+  double stance_progress, swing_progress;  /* :860-861, -1 when not in that state (walk_controller.cpp:871-897) */
+  double time_to_swing_end;                /* :862-874 */
+  double pose_delta[7];                    /* calculateOdometry(time_to_swing_end) :875: x,y,z,qw,qx,qy,qz */
+  double tip_force[3];                     /* tip_force_calculated_ * force_gain :883-885 */
+  double admittance_delta[3];              /* :886-888 */
+  double virtual_stiffness;                /* :889 */
+} shc_leg_state_msg;
+/* Fills legs[0 .. leg_count) for `instance`.  Synchronises the engine's stream. */
+int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, shc_leg_state_msg *legs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2400,6 +2400,45 @@ void orc_batch_get_body_state(orc_batch *b, double *pose, double *velocity, int3
                        walk_state ? walk_state + i : NULL);
 }
 
+/* StateController::publishLegState (state_controller.cpp:809-893): numeric payload per leg */
+void orc_get_leg_state_msg(const orc_robot *r, shc_leg_state_msg *legs)
+{
+  const shc_step_cycle *step = &r->step;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    const leg_t *leg = &r->leg[l];
+    const stepper_t *ls = &leg->stepper;
+    shc_leg_state_msg *m = &legs[l];
+    memset(m, 0, sizeof *m);
+    put3(m->walker_tip_position, ls->current_tip_pose.p);
+    put3(m->target_tip_position, ls->target_tip_pose.p);
+    put3(m->poser_tip_position, leg->poser.current_tip_pose.p);
+    put3(m->model_tip_position, leg->current_tip_pose.p);
+    for (int j = 0; j < leg->joint_count; ++j)
+    {
+      m->joint_positions[j] = leg->joint[j].desired_position;
+      m->joint_velocities[j] = leg->joint[j].desired_velocity;
+      m->joint_efforts[j] = 0.0; /* Joint::desired_effort_ is never assigned on this path */
+    }
+    m->swing_progress = ls->swing_progress;
+    m->stance_progress = ls->stance_progress;
+    double swing_time = ((double)step->swing_period / step->period) / step->frequency;
+    double stance_time = ((double)step->stance_period / step->period) / step->frequency;
+    double time_to_swing_end;
+    if (ls->stance_progress >= 0.0) time_to_swing_end = stance_time * (1.0 - ls->stance_progress) + swing_time;
+    else time_to_swing_end = swing_time * (1.0 - ls->swing_progress);
+    m->time_to_swing_end = time_to_swing_end;
+    orc_pose d = walker_calculate_odometry(r, time_to_swing_end);
+    m->pose_delta[0] = d.p.x; m->pose_delta[1] = d.p.y; m->pose_delta[2] = d.p.z;
+    m->pose_delta[3] = d.r.w; m->pose_delta[4] = d.r.x; m->pose_delta[5] = d.r.y; m->pose_delta[6] = d.r.z;
+    m->tip_force[0] = leg->tip_force_calculated.x * r->params.force_gain;
+    m->tip_force[1] = leg->tip_force_calculated.y * r->params.force_gain;
+    m->tip_force[2] = leg->tip_force_calculated.z * r->params.force_gain;
+    put3(m->admittance_delta, leg->admittance_delta);
+    m->virtual_stiffness = leg->virtual_stiffness;
+  }
+}
+
 /* changeGait on every robot of the batch; returns how many were still walking (0 = the gait was changed everywhere) */
 int64_t orc_batch_change_gait(orc_batch *b, const shc_params *np)
 {

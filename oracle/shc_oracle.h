@@ -80,6 +80,7 @@ void orc_batch_get_joint_state(orc_batch *b, double *q, double *qd);
 void orc_batch_get_leg_state(orc_batch *b, double *walker_tip, double *poser_tip, double *model_tip,
                              double *tip_force, double *admittance, int32_t *leg_status);
 void orc_batch_get_body_state(orc_batch *b, double *pose, double *velocity, int32_t *walk_state);
+void orc_get_leg_state_msg(const orc_robot *r, shc_leg_state_msg *legs /* [leg_count] */);
 int orc_change_gait(orc_robot *r, const shc_params *new_gait);
 int64_t orc_batch_change_gait(orc_batch *b, const shc_params *new_gait);
 void orc_batch_get_odometry(orc_batch *b, double *pose /* [n][7]: xyz + wxyz */);

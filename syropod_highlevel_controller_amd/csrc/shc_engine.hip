@@ -365,6 +365,37 @@ __global__ void gather_odometry_kernel(double *dst, const double *robd, int rpw,
   o[5] = 0.0;
   o[6] = robd[rob_index(r, RobotFields::ODOM + 3, rpw, nf)];
 }
+// everything publishLegState needs of one instance, packed per leg: tip(3) targ(3) poser(3) model(3) q(NJ) qd(NJ) tf(3)
+// adm(3) stiff word | then vx vy w
+template <int NJ>
+__global__ void read_instance_kernel(double *dst, DevState st, int L, int64_t rob, int have_adm) {
+  using FD = Fields<NJ>;
+  const int leg = threadIdx.x;
+  constexpr int per_leg = 12 + 2 * NJ + 8;
+  if (leg < L) {
+    const int64_t slot = slot_of(rob, leg, L);
+    auto f = [&](int field) { return st.legd[leg_field_index(field, slot, st.n_slots)]; };
+    double *o = dst + leg * per_leg;
+    for (int k = 0; k < 3; ++k) {
+      o[k] = f(FD::TIP + k);
+      o[3 + k] = f(FD::TARG + k);
+      o[6 + k] = f(FD::POSER_TIP + k);
+      o[9 + k] = f(FD::MODEL_TIP + k);
+      o[12 + 2 * NJ + k] = f(FD::TF + k);
+      o[15 + 2 * NJ + k] = have_adm ? f(FD::ADM_DELTA + k) : 0.0;
+    }
+    for (int j = 0; j < NJ; ++j) {
+      o[12 + j] = f(FD::Q + j);
+      o[12 + NJ + j] = f(FD::QD + j);
+    }
+    o[18 + 2 * NJ] = have_adm ? f(FD::ADM_DELTA + 3) : 0.0;
+    o[19 + 2 * NJ] = double(st.legi[slot]);
+  }
+  if (leg == 0) {
+    const int rpw = 64 / L;
+    for (int k = 0; k < 3; ++k) dst[L * per_leg + k] = st.robd[rob_index(rob, RobotFields::VLIN + k, rpw, RobotFields::COUNT)];
+  }
+}
 __global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int64_t n, int L) {
   int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n * L) return;
@@ -929,6 +960,7 @@ static int gather_rob(shc_engine *e, double *dst, int K, int f0, int on_device) 
   return SHC_OK;
 }
 
+static int derive_tips(shc_engine *e);
 #define LEG_FIELD(e, NAME) ((e)->NJ == 3 ? Fields<3>::NAME : ((e)->NJ == 4 ? Fields<4>::NAME : Fields<5>::NAME))
 
 extern "C" int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, const double *angular, int on_device) {
@@ -1065,17 +1097,7 @@ extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, doubl
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc;
   if ((rc = gather_leg(e, walker_tip, 3, LEG_FIELD(e, TIP), on_device)) != SHC_OK) return rc;
-  if (poser_tip || model_tip) { // derived on demand from the stored joint state / walker tip / body pose
-    HIP_TRY(hipSetDevice(e->device));
-    const int64_t threads = e->n * e->L;
-    const int derive_poser = !(e->cp.auto_posing && !e->cp.imu_posing); // the auto-pose path stores its per-leg poser tip
-#define CALL(L_, NJ_)                                                                                             \
-  derive_tips_kernel<L_, NJ_><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(                \
-      e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, derive_poser)
-    SHC_DISPATCH(e->L, e->NJ, CALL);
-#undef CALL
-    HIP_TRY(hipGetLastError());
-  }
+  if ((poser_tip || model_tip) && (rc = derive_tips(e)) != SHC_OK) return rc; // derived on demand from q / walker tip / body pose
   if ((rc = gather_leg(e, poser_tip, 3, LEG_FIELD(e, POSER_TIP), on_device)) != SHC_OK) return rc;
   if ((rc = gather_leg(e, model_tip, 3, LEG_FIELD(e, MODEL_TIP), on_device)) != SHC_OK) return rc;
   if ((rc = gather_leg(e, tip_force, 3, LEG_FIELD(e, TF), on_device)) != SHC_OK) return rc;
@@ -1169,6 +1191,80 @@ extern "C" int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (!e->params.admittance_control) return fail(SHC_ERR_UNSUPPORTED, "admittance_control is off: updateStiffness never runs");
   return gather_leg(e, stiffness, 1, LEG_FIELD(e, ADM_DELTA) + 3, on_device);
+}
+
+static int derive_tips(shc_engine *e) {
+  HIP_TRY(hipSetDevice(e->device));
+  const int64_t threads = e->n * e->L;
+  const int derive_poser = !(e->cp.auto_posing && !e->cp.imu_posing); // the auto-pose path stores its per-leg poser tip
+#define CALL(L_, NJ_)                                                                                             \
+  derive_tips_kernel<L_, NJ_><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(                \
+      e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, derive_poser)
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, shc_leg_state_msg *legs) {
+  if (!e || !legs) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  if (instance < 0 || instance >= e->n) return fail(SHC_ERR_INVALID_ARG, "instance out of range");
+  int rc = derive_tips(e);
+  if (rc != SHC_OK) return rc;
+  const int L = e->L, NJ = e->NJ, per_leg = 12 + 2 * NJ + 8;
+  std::vector<double> h(size_t(L) * per_leg + 3);
+  switch (NJ) {
+    case 3: read_instance_kernel<3><<<dim3(1), dim3(64), 0, e->stream>>>(e->d_stage, e->st, L, instance, e->params.admittance_control); break;
+    case 4: read_instance_kernel<4><<<dim3(1), dim3(64), 0, e->stream>>>(e->d_stage, e->st, L, instance, e->params.admittance_control); break;
+    default: read_instance_kernel<5><<<dim3(1), dim3(64), 0, e->stream>>>(e->d_stage, e->st, L, instance, e->params.admittance_control); break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(h.data(), e->d_stage, h.size() * 8, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const shc_step_cycle &step = e->tables.step;
+  const double vx = h[size_t(L) * per_leg], vy = h[size_t(L) * per_leg + 1], vw = h[size_t(L) * per_leg + 2];
+  const double swing_time = (double(step.swing_period) / step.period) / step.frequency;   // state_controller.cpp:863
+  const double stance_time = (double(step.stance_period) / step.period) / step.frequency; // :864
+  for (int l = 0; l < L; ++l) {
+    const double *o = &h[size_t(l) * per_leg];
+    shc_leg_state_msg &m = legs[l];
+    memset(&m, 0, sizeof m);
+    for (int k = 0; k < 3; ++k) {
+      m.walker_tip_position[k] = o[k];
+      m.target_tip_position[k] = o[3 + k];
+      m.poser_tip_position[k] = o[6 + k];
+      m.model_tip_position[k] = o[9 + k];
+      m.tip_force[k] = o[12 + 2 * NJ + k] * e->params.force_gain;
+      m.admittance_delta[k] = o[15 + 2 * NJ + k];
+    }
+    for (int j = 0; j < NJ; ++j) {
+      m.joint_positions[j] = o[12 + j];
+      m.joint_velocities[j] = o[12 + NJ + j];
+    }
+    m.virtual_stiffness = o[18 + 2 * NJ];
+    // LegStepper::swing_progress_ / stance_progress_ as iteratePhase left them (walk_controller.cpp:871-897)
+    const int word = int(o[19 + 2 * NJ]);
+    const int pm = (word >> LW_PM_SHIFT) & 3, phase = (word >> LW_PHASE_SHIFT) & LW_PHASE_MASK;
+    m.swing_progress = m.stance_progress = -1.0; // walk_controller.h:498-499
+    if (pm == PM_SWING) {
+      m.swing_progress = clampd(double(phase - step.swing_start + 1) / double(step.swing_end - step.swing_start), 0.0, 1.0);
+    } else if (pm == PM_STANCE) {
+      m.stance_progress = clampd(double(mod_i(phase + (step.period - step.stance_start), step.period) + 1) /
+                                     double(mod_i(step.stance_end - step.stance_start, step.period)),
+                                 0.0, 1.0);
+    } else if (pm == PM_STOP) {
+      m.stance_progress = 0.0;
+    }
+    m.time_to_swing_end = m.stance_progress >= 0.0 ? stance_time * (1.0 - m.stance_progress) + swing_time
+                                                   : swing_time * (1.0 - m.swing_progress); // :866-873
+    const double t = m.time_to_swing_end; // WalkController::calculateOdometry (walk_controller.cpp:783-791)
+    m.pose_delta[0] = vx * t;
+    m.pose_delta[1] = vy * t;
+    m.pose_delta[2] = 0.0 * t;
+    m.pose_delta[3] = cos(0.5 * (vw * t));
+    m.pose_delta[6] = sin(0.5 * (vw * t));
+  }
+  return SHC_OK;
 }
 
 extern "C" int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device) {

@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from .params import FEAT_DEFAULT, Params, Tables
+from .params import FEAT_DEFAULT, LegStateMsg, Params, Tables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("SHC_LIB") or os.path.join(_HERE, "libshc_batch.so")
@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_set_joint_effort", "shc_engine_set_pose_input", "shc_engine_set_pose_reset_mode", "shc_engine_step", "shc_engine_synchronize",
     "shc_engine_get_joint_state", "shc_engine_joint_buffer", "shc_engine_joint_index", "shc_engine_get_leg_state",
     "shc_engine_get_body_state", "shc_engine_get_odometry", "shc_engine_get_virtual_stiffness",
-    "shc_engine_change_gait", "shc_stream_create", "shc_stream_destroy",
+    "shc_engine_change_gait", "shc_stream_create", "shc_stream_destroy", "shc_engine_read_leg_state_msg",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
         L.shc_engine_get_leg_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int]
         L.shc_engine_get_body_state.argtypes = [C.c_void_p] + [C.c_void_p] * 3 + [C.c_int]
         L.shc_engine_get_odometry.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_read_leg_state_msg.argtypes = [C.c_void_p, C.c_int64, C.POINTER(LegStateMsg)]
         L.shc_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.shc_stream_destroy.argtypes = [C.c_int, C.c_void_p]
         L.shc_engine_change_gait.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
@@ -248,6 +249,12 @@ class BatchEngine:
         if still.value == 0:
             self.params = new_gait
         return int(still.value)
+
+    def leg_state_msg(self, instance: int):
+        """Numeric payload of LegState.msg for every leg of one instance (StateController::publishLegState)."""
+        arr = (LegStateMsg * self.legs)()
+        _check(self.L.shc_engine_read_leg_state_msg(self.h, int(instance), arr), "read_leg_state_msg")
+        return list(arr)
 
     def odometry(self):
         """WalkController::getOdometryIdeal per instance: [n][7] (x, y, z, qw, qx, qy, qz)."""

@@ -7,7 +7,7 @@ import subprocess
 
 import numpy as np
 
-from syropod_highlevel_controller_amd.params import Params, StepCycle, Tables
+from syropod_highlevel_controller_amd.params import LegStateMsg, Params, StepCycle, Tables
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "liboracle.so")
@@ -71,6 +71,7 @@ def lib():
         L.orc_batch_get_leg_state.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _ip]
         L.orc_batch_get_body_state.argtypes = [C.c_void_p, _dp, _dp, _ip]
         L.orc_batch_get_odometry.argtypes = [C.c_void_p, _dp]
+        L.orc_get_leg_state_msg.argtypes = [C.c_void_p, C.POINTER(LegStateMsg)]
         L.orc_batch_change_gait.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.orc_batch_change_gait.restype = C.c_int64
         L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
@@ -236,6 +237,11 @@ class OracleBatch:
         ws = np.zeros(self.n, dtype=np.int32)
         self.L.orc_batch_get_body_state(self.h, _ptr(pose), _ptr(vel), _ptr(ws, _ip))
         return pose, vel, ws
+
+    def leg_state_msg(self, instance):
+        arr = (LegStateMsg * self.p.leg_count)()
+        self.L.orc_get_leg_state_msg(self.L.orc_batch_robot(self.h, int(instance)), arr)
+        return list(arr)
 
     def change_gait(self, new_gait):
         still = int(self.L.orc_batch_change_gait(self.h, C.byref(new_gait)))

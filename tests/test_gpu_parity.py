@@ -591,3 +591,29 @@ def test_cycle_captured_in_hip_graph(Engine):
     torch.cuda.synchronize()
     b.synchronize()
     assert np.array_equal(q.cpu().numpy().reshape(n, 18), b.joints()[0])
+
+
+def test_leg_state_message_payload(Engine):
+    """shc_engine_read_leg_state_msg: the numeric fields of LegState.msg as publishLegState computes them
+    (state_controller.cpp:809-893), for single instances of a walking batch with admittance + dynamic stiffness."""
+    p = default_hexapod_params("ripple")
+    p.admittance_control = 1
+    n = 24
+    inp = make_inputs(p, n, 83, force=2.0)
+    eng, ob = Engine(p, n), OracleBatch(p, n)
+    apply(eng, inp)
+    apply(ob, inp)
+    done = 0
+    for k in (1, 1, 37, 80, 33):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        done += k
+        for i in (0, 7, n - 1):
+            for g, o in zip(eng.leg_state_msg(i), ob.leg_state_msg(i)):
+                for name, _ in g._fields_:
+                    a, b = np.array(getattr(g, name)), np.array(getattr(o, name))
+                    if name in ("stance_progress", "swing_progress", "joint_efforts"):
+                        assert np.array_equal(a, b), name   # functions of the integer phase only
+                    else:
+                        np.testing.assert_allclose(a, b, rtol=0, atol=1e-8, err_msg=f"{name} cycle {done} instance {i}")
