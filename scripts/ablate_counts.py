@@ -4,7 +4,9 @@ Run under rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES with
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-LEVELS = [(0, 3, "full"), (0, 2, "no tipforce"), (1, 2, "-pose"), (3, 2, "-limits"), (7, 2, "-stepper"), (15, 2, "-ik"), (31, 2, "-fk sincos (floor)")]
+LEVELS = [(0, 3, "full"), (0, 2, "no tipforce"), (1, 2, "-pose"), (3, 2, "-limits"), (7, 2, "-stepper"), (15, 2, "-ik"), (31, 2, "-fk sincos"),
+          (31 + 512, 2, "-2nd chain + tip"), (31 + 512 + 256, 2, "-stance"), (31 + 512 + 256 + 1024, 2, "-odometry"),
+          (31 + 512 + 256 + 1024 + 32, 2, "-velocity"), (31 + 512 + 256 + 1024 + 32 + 128, 2, "-predicates (floor)")]
 SINGLES = 20
 
 if len(sys.argv) > 1 and sys.argv[1] == "parse":

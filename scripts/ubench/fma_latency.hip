@@ -18,6 +18,25 @@ __global__ void fma_chain(double *out, long long *ticks, int iters, double a, do
   out[threadIdx.x] = s;
   if (threadIdx.x == 0) ticks[0] = t1 - t0;
 }
+template <int CHAINS>
+__global__ void fma_chain_masked(double *out, long long *ticks, int iters, double a, double b, int active) {
+  double x[CHAINS];
+  for (int c = 0; c < CHAINS; ++c) x[c] = a + c + threadIdx.x;
+  long long t0 = __builtin_readcyclecounter();
+  if (int(threadIdx.x) < active) {
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) x[c] = __builtin_fma(x[c], b, a);
+    }
+  }
+  long long t1 = __builtin_readcyclecounter();
+  double s = 0;
+  for (int c = 0; c < CHAINS; ++c) s += x[c];
+  out[threadIdx.x] = s;
+  if (threadIdx.x == 0) ticks[0] = t1 - t0;
+}
 __global__ void div_chain(double *out, long long *ticks, int iters, double a, double b) {
   double x = a + threadIdx.x;
   long long t0 = __builtin_readcyclecounter();
@@ -55,6 +74,10 @@ int main() {
   RUN((fma_chain<1><<<1, 64>>>(out, t, iters, 0.5, 0.999)), "fma f64, 1 chain", 1)
   RUN((fma_chain<2><<<1, 64>>>(out, t, iters, 0.5, 0.999)), "fma f64, 2 chains", 2)
   RUN((fma_chain<4><<<1, 64>>>(out, t, iters, 0.5, 0.999)), "fma f64, 4 chains", 4)
+  RUN((fma_chain_masked<4><<<1, 64>>>(out, t, iters, 0.5, 0.999, 64)), "fma 4 chains, 64 lanes", 4)
+  RUN((fma_chain_masked<4><<<1, 64>>>(out, t, iters, 0.5, 0.999, 32)), "fma 4 chains, 32 lanes", 4)
+  RUN((fma_chain_masked<4><<<1, 64>>>(out, t, iters, 0.5, 0.999, 16)), "fma 4 chains, 16 lanes", 4)
+  RUN((fma_chain_masked<4><<<1, 64>>>(out, t, iters, 0.5, 0.999, 10)), "fma 4 chains, 10 lanes", 4)
   RUN((div_chain<<<1, 64>>>(out, t, iters, 0.5, 1.7)), "div f64 + add, 1 chain", 1)
   RUN((lds_chain<<<1, 64>>>(out, t, iters)), "dependent ds_read_b32", 1)
   RUN((shfl_chain<<<1, 64>>>(out, t, iters)), "dependent ds_bpermute", 1)

@@ -292,7 +292,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   SHC_TICK(2);
 
   // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611)
-  {
+  if (!(SHC_DBG(P) & 128)) {
     int w = s.word & ~(LW_ZBV | LW_ATT);
     if (dot(s.strd, s.strd) == 0.0) w |= LW_ZBV;
     const V3 pnp = rb.get3(R::PNORM_PREV);
@@ -640,7 +640,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   SHC_TICK(5);
   double vx = rb.get(R::VLIN), vy = rb.get(R::VLIN + 1), vw = rb.get(R::VANG);
   const double lin_norm = sqrt(vin_x * vin_x + vin_y * vin_y);
-  {
+  if (!(SHC_DBG(P) & 32)) {
     double nvx, nvy, nw;
     if (uni(P.velocity_input_mode) == 0) { // throttle (:451-466)
       const double k = lin_norm > 1.0 ? 1.0 / lin_norm : 1.0; // clamped to the unit disc
@@ -911,7 +911,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       rb.put3(R::PNORM, normalized(V3{-pa, -pb, 1.0}));
     }
     // ---- odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (:643, :783-791)
-    if (FT::odom(P)) {
+    if (FT::odom(P) && !(SHC_DBG(P) & 1024)) {
       // Both poses are pure yaw (rotation (w, 0, 0, z), z translation 0), so Pose::addPose reduces to its w / z and x / y
       // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
       double sh, ch;
@@ -939,7 +939,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       bp = remove_pose(bp, auto_pose);
       bp = add_pose(bp, leg_auto);
     }
-    out.poser_tip = inverse_transform_vector(bp, s.tip);
+    out.poser_tip = (SHC_DBG(P) & 256) ? s.tip : inverse_transform_vector(bp, s.tip);
   }
 
   SHC_PHASE_FENCE();
@@ -957,10 +957,10 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     SHC_PHASE_FENCE();
     SHC_TICK(10);
     if (!(SHC_DBG(P) & 16)) joint_sincos<NJ>(lc, s.q, s.sn, s.cs); // Leg::applyFK (:904)
-    chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
+    if (!(SHC_DBG(P) & 512)) chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
     SHC_PHASE_FENCE();
     SHC_TICK(11);
-    out.model_tip = tip_robot_frame(lc, chain.pe);
+    out.model_tip = (SHC_DBG(P) & 512) ? desired : tip_robot_frame(lc, chain.pe);
     if (FT::adm(P)) s.tipx = base_rotate(lc, chain.xe);
     V3 e = out.model_tip - desired;
     if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) s.word |= LW_IKFAIL; // :916-929

@@ -40,19 +40,41 @@ struct LegPlanes {
   __device__ __forceinline__ void store(int plane, double2 v) const { (base + plane * ns)[slot] = v; }
 };
 
+// Per-leg state load, in two steps so that the kernel prologue can issue every global load of the wave before the first
+// use: load_leg_issue() only issues the plane loads (joint planes first), load_leg_finish() unpacks them.
+template <int NJ>
+struct LegLoad {
+  double flat[Fields<NJ>::CORE_END];
+  double2 adm, tf0, tf1, stiff;
+  int word;
+};
 template <int NJ, unsigned F>
-__device__ __forceinline__ void load_leg(LegRegs<NJ> &s, const Park &pk, const DevState &st, const CycleParams &P, uint32_t slot) {
+__device__ __forceinline__ void load_leg_issue(LegLoad<NJ> &ll, const DevState &st, const CycleParams &P, uint32_t slot) {
   using FD = Fields<NJ>;
   using FT = Feat<F>;
   const LegPlanes ld{reinterpret_cast<double2 *>(st.legd), st.n_slots, slot};
-  s.word = st.legi[slot];
-  double flat[FD::CORE_END];
 #pragma unroll
   for (int p = 0; p < FD::CORE_END / 2; ++p) {
     double2 v = ld.load(p);
-    flat[2 * p] = v.x;
-    flat[2 * p + 1] = v.y;
+    ll.flat[2 * p] = v.x;
+    ll.flat[2 * p + 1] = v.y;
   }
+  ll.word = st.legi[slot];
+  ll.adm = ll.tf0 = ll.tf1 = ll.stiff = double2{0.0, 0.0};
+  if (FT::adm(P)) {
+    ll.adm = ld.load(FD::ADM / 2);
+    if (P.dynamic_stiffness) ll.stiff = ld.load(FD::ADM_DELTA / 2 + 1); // virtual_stiffness_ persists while STOPPED
+  }
+  if (FT::tipf(P)) {
+    ll.tf0 = ld.load(FD::TF / 2);
+    ll.tf1 = ld.load(FD::TF / 2 + 1);
+  }
+}
+template <int NJ>
+__device__ __forceinline__ void load_leg_finish(LegRegs<NJ> &s, const Park &pk, const LegLoad<NJ> &ll) {
+  using FD = Fields<NJ>;
+  const double(&flat)[FD::CORE_END] = ll.flat;
+  s.word = ll.word;
   // swing origin / velocity, stance origin and default tip go straight to the per-lane LDS strip
   static_assert(FD::SVEL == FD::SORG + 3 && FD::TORG == FD::SORG + 6 && FD::DFLT == FD::SORG + 9, "park layout");
 #pragma unroll
@@ -66,19 +88,10 @@ __device__ __forceinline__ void load_leg(LegRegs<NJ> &s, const Park &pk, const D
     s.q[i] = flat[FD::Q + i];
     s.qd[i] = flat[FD::QD + i];
   }
-  s.adm0 = s.adm1 = 0.0;
-  s.stiff = 0.0;
-  s.tf = V3{0, 0, 0};
-  if (FT::adm(P)) {
-    double2 v = ld.load(FD::ADM / 2);
-    s.adm0 = v.x;
-    s.adm1 = v.y;
-    if (P.dynamic_stiffness) s.stiff = ld.load(FD::ADM_DELTA / 2 + 1).y; // virtual_stiffness_ persists while STOPPED
-  }
-  if (FT::tipf(P)) {
-    double2 a = ld.load(FD::TF / 2), b = ld.load(FD::TF / 2 + 1);
-    s.tf = V3{a.x, a.y, b.x};
-  }
+  s.adm0 = ll.adm.x;
+  s.adm1 = ll.adm.y;
+  s.stiff = ll.stiff.y;
+  s.tf = V3{ll.tf0.x, ll.tf0.y, ll.tf1.x};
 }
 
 template <int NJ, unsigned F>
@@ -198,6 +211,15 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   int32_t *gtile_i = st.robi + wave * (R::I_COUNT * RPW);
   // ---- prologue: every global load of this wave is issued before the first wait, so the HBM / L2 latencies overlap:
   //      (1) launch-uniform tables, (2) this wave's robot tile, (3) per-leg state; then the LDS writes; then one barrier.
+  LegLoad<NJ> ll;
+  double th[NJ]; // DH joint offsets of this lane's leg straight from the table in HBM: the FK of the stored joint state
+                 // (sin / cos) then starts as soon as the joint planes arrive, under the latency of the remaining loads
+  const bool any_robot = robots_here > 0;
+  if (any_robot) {
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) th[k] = gc->leg[leg].link_th[k];
+    load_leg_issue<NJ, F>(ll, st, GP, slot);
+  }
   using SC = SharedConsts<L, NJ>;
   static_assert(sizeof(SC) % 16 == 0 && (offsetof(SC, P) + offsetof(CycleParams, ap_start)) % 16 == 0, "const block is copied in 16-byte words");
   constexpr int n16_all = sizeof(SC) / 16;
@@ -218,7 +240,6 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
       t_imu[((R::IMU_END - R::ABSE) * RPW + 63) / 64], t_imuq[((R::IMUQ_END - R::IMUQ) * RPW + 63) / 64],
       t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_odom[((R::COUNT - R::ODOM) * RPW + 63) / 64];
   int32_t t_int = 0;
-  const bool any_robot = robots_here > 0;
   if (any_robot) {
     load_rob_fields<RPW, 0, R::CORE_END>(t_core, gtile, lane);
     if (FT::manual(GP)) load_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, gtile, lane);
@@ -227,7 +248,10 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
     if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::COUNT>(t_odom, gtile, lane);
     if (lane < R::I_COUNT * RPW) t_int = gtile_i[lane];
-    load_leg<NJ, F>(s, pk, st, GP, slot);
+    // Leg::applyFK of the previous cycle: sin / cos of the stored joint angles
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) sincos_joint(th[k] + ll.flat[Fields<NJ>::Q + k], &s.sn[k], &s.cs[k]);
+    load_leg_finish<NJ>(s, pk, ll);
   }
   {
     double2 *dst = reinterpret_cast<double2 *>(&C);
@@ -254,7 +278,6 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   const CycleParams &P = C.P;
   Group<L> g{grp * L};
   RobTile<RPW> rb{tile, tile_i, grp};
-  joint_sincos<NJ>(C.leg[leg], s.q, s.sn, s.cs); // FK of the stored joint state (Leg::applyFK of the previous cycle)
   s.tipx = V3{1, 0, 0};
   if (FT::adm(P)) {
     Chain<NJ> ch;
