@@ -220,8 +220,13 @@ struct RobTile {
 // Per-leg state held in registers across the cycles of one launch.
 template <int NJ>
 struct LegRegs {
+  // What the next cycle's IK step needs of the FK at q (Leg::solveIK reads the joint transforms the previous applyFK left):
+  // short chains keep the linear Jacobian columns + tip position themselves (4 vectors for 3 joints), longer ones the
+  // sin / cos of the joint angles and rebuild the chain from them (fewer registers, one more chain product per cycle).
+  static constexpr bool kKeepJacobian = NJ <= 3;
   double q[NJ], qd[NJ];
-  double sn[NJ], cs[NJ]; // sin / cos of the DH joint angles at q: the chain (Jacobian, tip) is rebuilt from these
+  double sn[NJ], cs[NJ];
+  V3 lin[NJ], pe;
   V3 tip, tvel, targ, strd;
   double adm0, adm1;
   double stiff; // Leg::virtual_stiffness_ (published only; admittance feature)
@@ -915,7 +920,9 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       // Both poses are pure yaw (rotation (w, 0, 0, z), z translation 0), so Pose::addPose reduces to its w / z and x / y
       // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
       double sh, ch;
-      sincos_joint(0.5 * (vw * P.dt), &sh, &ch); // Quaterniond(AngleAxisd(w dt, z^))
+      const double ha = 0.5 * (vw * P.dt); // Quaterniond(AngleAxisd(w dt, z^)): half of one cycle's yaw, a few milliradians
+      if (__all(fabs(ha) <= 0.5)) sincos_joint<false>(ha, &sh, &ch);
+      else sincos_joint(ha, &sh, &ch);
       const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 2), oz = rb.get(R::ODOM + 3);
       const double a = vx * P.dt, b = vy * P.dt;
       double ux = -(oz * b), uy = oz * a; // u x v
@@ -949,15 +956,26 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
     Chain<NJ> chain;
     if (!(SHC_DBG(P) & 8)) {
-      chain_from_sincos<NJ>(lc, s.sn, s.cs, chain); // joint transforms left by the previous applyFK (model.cpp:731,744)
       double dq[NJ];
-      ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
+      if (LegRegs<NJ>::kKeepJacobian) {
+        ik_step_cols<NJ>(lc, s.lin, s.pe, s.q, s.qd, desired, dq);
+      } else {
+        chain_from_sincos<NJ>(lc, s.sn, s.cs, chain); // joint transforms left by the previous applyFK (model.cpp:731,744)
+        ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
+      }
       update_joints<NJ>(lc, dq, P.dt, P.inv_dt, uni(P.clamp_joint_velocities) != 0, uni(P.clamp_joint_positions) != 0, s.q, s.qd);
     }
     SHC_PHASE_FENCE();
     SHC_TICK(10);
     if (!(SHC_DBG(P) & 16)) joint_sincos<NJ>(lc, s.q, s.sn, s.cs); // Leg::applyFK (:904)
     if (!(SHC_DBG(P) & 512)) chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
+    V3 lin[NJ];
+    jacobian_columns<NJ>(chain, lin);
+    if (LegRegs<NJ>::kKeepJacobian) {
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) s.lin[i] = lin[i];
+      s.pe = chain.pe;
+    }
     SHC_PHASE_FENCE();
     SHC_TICK(11);
     out.model_tip = (SHC_DBG(P) & 512) ? desired : tip_robot_frame(lc, chain.pe);
@@ -972,7 +990,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         effort[i] = e2.x;
         if (i + 1 < NJ) effort[i + 1] = e2.y;
       }
-      V3 raw = tip_force_raw<NJ>(lc, chain, effort);
+      V3 raw = tip_force_cols<NJ>(lc, chain, lin, effort);
       s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
     }
   }

@@ -279,10 +279,14 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   Group<L> g{grp * L};
   RobTile<RPW> rb{tile, tile_i, grp};
   s.tipx = V3{1, 0, 0};
-  if (FT::adm(P)) {
+  if (FT::adm(P) || LegRegs<NJ>::kKeepJacobian) {
     Chain<NJ> ch;
     chain_from_sincos<NJ>(C.leg[leg], s.sn, s.cs, ch);
-    s.tipx = base_rotate(C.leg[leg], ch.xe);
+    if (LegRegs<NJ>::kKeepJacobian) {
+      jacobian_columns<NJ>(ch, s.lin);
+      s.pe = ch.pe;
+    }
+    if (FT::adm(P)) s.tipx = base_rotate(C.leg[leg], ch.xe);
   }
   LegOut out;
   SHC_TICK(1);

@@ -57,30 +57,37 @@ SHC_HD void joint_sincos(const LC &lc, const double (&q)[NJ], double (&sn)[NJ], 
 }
 
 // Leg::applyFK chain product in the joint-1 frame from the joint sines / cosines.
+// The chain and the Jacobian columns are evaluated both in the kernel prologue (state loaded from HBM) and inside the
+// cycle loop (state carried in registers); a launch of n cycles must reproduce n single-cycle launches bit for bit, so
+// these two functions fix their own rounding: contraction is off and every fused multiply-add is written out.
 template <int NJ, class LC>
 SHC_HD void chain_from_sincos(const LC &lc, const double (&sn)[NJ], const double (&cs)[NJ], Chain<NJ> &c) {
-  V3 X{1, 0, 0}, Y{0, 1, 0}, Z{0, 0, 1}, P{0, 0, 0};
-  c.z[0] = Z;
-  c.p[0] = P;
+#pragma clang fp contract(off)
+  double X[3] = {1, 0, 0}, Y[3] = {0, 1, 0}, Z[3] = {0, 0, 1}, P[3] = {0, 0, 0};
+  c.z[0] = V3{0, 0, 1};
+  c.p[0] = V3{0, 0, 0};
 #pragma unroll
   for (int k = 0; k < NJ; ++k) {
-    double s = sn[k], co = cs[k];
-    double sa = lc.link_sa[k], ca = lc.link_ca[k];
-    V3 Xn = X * co + Y * s;
-    V3 t = Y * co - X * s;
-    V3 Yn = t * ca + Z * sa;
-    V3 Zn = Z * ca - t * sa;
-    P = P + Xn * lc.link_r[k] + Z * lc.link_d[k];
-    X = Xn;
-    Y = Yn;
-    Z = Zn;
+    const double s = sn[k], co = cs[k];
+    const double sa = lc.link_sa[k], ca = lc.link_ca[k], r = lc.link_r[k], d = lc.link_d[k];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double xn = fma(X[a], co, Y[a] * s);   // X cos + Y sin
+      const double t = fma(Y[a], co, -(X[a] * s)); // Y cos - X sin
+      const double yn = fma(t, ca, Z[a] * sa);
+      const double zn = fma(Z[a], ca, -(t * sa));
+      P[a] = fma(Z[a], d, fma(xn, r, P[a]));       // P + Xn r + Z d (Z of the previous frame)
+      X[a] = xn;
+      Y[a] = yn;
+      Z[a] = zn;
+    }
     if (k + 1 < NJ) {
-      c.z[k + 1] = Z;
-      c.p[k + 1] = P;
+      c.z[k + 1] = V3{Z[0], Z[1], Z[2]};
+      c.p[k + 1] = V3{P[0], P[1], P[2]};
     }
   }
-  c.pe = P;
-  c.xe = X;
+  c.pe = V3{P[0], P[1], P[2]};
+  c.xe = V3{X[0], X[1], X[2]};
 }
 
 template <int NJ, class LC>
@@ -106,14 +113,35 @@ SHC_HD V3 tip_robot_frame(const LC &lc, V3 pe) { // T1 * pe
 }
 
 // One DLS step towards `desired` (robot frame): Leg::applyIK :864-877 + solveIK with solve_rotation = false.
+// linear Jacobian columns z_i x (p_e - p_i) in the joint-1 frame (model.cpp:735-747)
+template <int NJ>
+SHC_HD void jacobian_columns(const Chain<NJ> &c, V3 (&lin)[NJ]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    const double dx = c.pe.x - c.p[i].x, dy = c.pe.y - c.p[i].y, dz = c.pe.z - c.p[i].z;
+    const V3 z = c.z[i];
+    lin[i] = V3{fma(z.y, dz, -(z.z * dy)), fma(z.z, dx, -(z.x * dz)), fma(z.x, dy, -(z.y * dx))};
+  }
+}
+
+template <int NJ, class LC>
+SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double (&q)[NJ], const double (&qd)[NJ], V3 desired,
+                         double (&dq)[NJ]);
+
 template <int NJ, class LC>
 SHC_HD void ik_step(const LC &lc, const Chain<NJ> &c, const double (&q)[NJ], const double (&qd)[NJ], V3 desired,
                     double (&dq)[NJ]) {
-  // position delta in the joint-1 frame: T1^-1 desired - T1^-1 current
-  V3 delta = base_rotate_inv(lc, desired - V3{lc.p1[0], lc.p1[1], lc.p1[2]}) - c.pe;
   V3 lin[NJ];
-#pragma unroll
-  for (int i = 0; i < NJ; ++i) lin[i] = cross(c.z[i], c.pe - c.p[i]);
+  jacobian_columns<NJ>(c, lin);
+  ik_step_cols<NJ>(lc, lin, c.pe, q, qd, desired, dq);
+}
+
+template <int NJ, class LC>
+SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double (&q)[NJ], const double (&qd)[NJ], V3 desired,
+                         double (&dq)[NJ]) {
+  // position delta in the joint-1 frame: T1^-1 desired - T1^-1 current
+  V3 delta = base_rotate_inv(lc, desired - V3{lc.p1[0], lc.p1[1], lc.p1[2]}) - pe;
   // joint-limit cost gradient (model.cpp:759-790)
   double pg[NJ], vg[NJ];
   double pcost = 0.0, vcost = 0.0;
@@ -168,10 +196,17 @@ SHC_HD double update_joints(const LC &lc, const double (&dq)[NJ], double dt, dou
 
 // Leg::calculateTipForce (model.cpp:667-708): raw force in the robot frame (before the low-pass filter).
 template <int NJ, class LC>
+SHC_HD V3 tip_force_cols(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[NJ], const double (&tau)[NJ]);
+
+template <int NJ, class LC>
 SHC_HD V3 tip_force_raw(const LC &lc, const Chain<NJ> &c, const double (&tau)[NJ]) {
   V3 lin[NJ];
-#pragma unroll
-  for (int i = 0; i < NJ; ++i) lin[i] = cross(c.z[i], c.pe - c.p[i]);
+  jacobian_columns<NJ>(c, lin);
+  return tip_force_cols<NJ>(lc, c, lin, tau);
+}
+
+template <int NJ, class LC>
+SHC_HD V3 tip_force_cols(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[NJ], const double (&tau)[NJ]) {
   double a[NJ][NJ], y[NJ];
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {

@@ -79,7 +79,21 @@ SHC_HD double deg2rad(double d) { return d / 360.0 * 2.0 * kPi; }     // :64
 // sin and cos of a joint angle (|x| well below 2^20 * pi/2: DH offsets + joint limits are a few radians).
 // Cody-Waite reduction by pi/2 in two parts + the fdlibm kernel polynomials: < 1 ulp, ~45 FP64 instructions, no
 // large-argument path (ocml's sincos carries a Payne-Hanek branch and costs ~2x as many issue slots).
+template <bool REDUCE = true>
 SHC_HD void sincos_joint(double x, double *sn, double *cs) {
+  if (!REDUCE) { // caller guarantees |x| <= pi/4: the reduction below would return n = 0, y = x, tail 0
+    const double z = x * x, v = z * x;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    *sn = x - ((z * (-(v * rs))) - v * S1);
+    const double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double hz = 0.5 * z, w1 = 1.0 - hz;
+    *cs = w1 + (((1.0 - w1) - hz) + z * rc);
+    return;
+  }
   const double inv_pio2 = 6.36619772367581382433e-01;
   const double pio2_1 = 1.57079632673412561417e+00;  // first 33 bits of pi/2
   const double pio2_1t = 6.07710050650619224932e-11; // pi/2 - pio2_1
