@@ -83,7 +83,7 @@ struct CycleParams {
 template <int L, int NJ>
 struct alignas(16) SharedConsts { // staged in LDS; the parameter block comes last so that its auto-pose tail ends the record
   LegConst<NJ> leg[L];
-  double limit[4][9]; // max linear speed, max angular speed, max linear acceleration, max angular acceleration
+  alignas(16) double limit[9][4]; // per bearing: max linear speed, max angular speed, max linear / angular acceleration
   // smoothStep(swing_progress * scaler) per swing iteration (pose_controller.cpp:1100-1108): the only per-cycle use of the
   // swing progress is this control input, a function of the integer phase alone
   double swing_c[kSwingTable];
@@ -638,7 +638,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     for (int j = 0; j < L; ++j) {
       int ij = g.get(idx, j);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) lim[k] = fmin(lim[k], C.limit[k][ij]);
+      for (int k = 0; k < 4; ++k) lim[k] = fmin(lim[k], C.limit[ij][k]);
     }
   }
   SHC_PHASE_FENCE();
@@ -648,7 +648,8 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   if (!(SHC_DBG(P) & 32)) {
     double nvx, nvy, nw;
     if (uni(P.velocity_input_mode) == 0) { // throttle (:451-466)
-      const double k = lin_norm > 1.0 ? 1.0 / lin_norm : 1.0; // clamped to the unit disc
+      double k = 1.0; // clamped to the unit disc
+      if (__any(lin_norm > 1.0)) k = lin_norm > 1.0 ? 1.0 / lin_norm : 1.0;
       const double cx = lin_norm > 1.0 ? vin_x * k : vin_x, cy = lin_norm > 1.0 ? vin_y * k : vin_y;
       nw = clampd(win, -1.0, 1.0) * lim[1];
       const double sc = 1.0 - fabs(win);

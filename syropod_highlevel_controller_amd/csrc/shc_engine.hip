@@ -544,10 +544,10 @@ static void build_shared_consts(const shc_params &p, const shc_tables &t, const 
     c.swing_c[it] = smooth_step(sp);
   }
   for (int b = 0; b < 9; ++b) {
-    c.limit[0][b] = t.max_linear_speed[b];
-    c.limit[1][b] = t.max_angular_speed[b];
-    c.limit[2][b] = t.max_linear_acceleration[b];
-    c.limit[3][b] = t.max_angular_acceleration[b];
+    c.limit[b][0] = t.max_linear_speed[b];
+    c.limit[b][1] = t.max_angular_speed[b];
+    c.limit[b][2] = t.max_linear_acceleration[b];
+    c.limit[b][3] = t.max_angular_acceleration[b];
   }
 }
 
