@@ -1,0 +1,18 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from syropod_highlevel_controller_amd import default_hexapod_params
+from syropod_highlevel_controller_amd.engine import BatchEngine
+p = default_hexapod_params("tripod")
+for n in (10, 4096):
+    eng = BatchEngine(p, n)
+    rng = np.random.default_rng(0)
+    eng.set_velocity(rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n))
+    eng.step(300); eng.synchronize()
+    for reps in (200, 2000):
+        t0 = time.perf_counter()
+        for _ in range(reps): eng.step(1)
+        t1 = time.perf_counter()
+        eng.synchronize()
+        t2 = time.perf_counter()
+        print(f"n={n} reps={reps}: enqueue {1e6*(t1-t0)/reps:.2f} us/launch, total {1e6*(t2-t0)/reps:.2f} us/launch")
