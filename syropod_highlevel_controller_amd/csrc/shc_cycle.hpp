@@ -784,9 +784,8 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     // ---- LegStepper::updateDefaultTipPosition (:984-1014) on the STOPPING -> FORCE_STOP edge (rare)
     if (__any(my_update_default)) {
       if (my_update_default) {
-        // stance_span_modifier is 0 on this path -> calculateStanceSpanChange() == 0 (:949-980)
         Pose wpp = rb.getpose(R::WPP); // leg_->getDefaultBodyPose() == walk_plane_pose_
-        V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y, 0.0});
+        V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y + lc.span_shift, 0.0}); // identity + stance span change
         V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM_PREV));
         pk.put3(PK_DFLT, idp + proj);
         default_changed = true;

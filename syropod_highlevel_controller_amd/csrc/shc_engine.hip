@@ -525,6 +525,13 @@ static void build_shared_consts(const shc_params &p, const shc_tables &t, const 
     hostinit::fill_leg_const<NJ>(p, l, c.leg[l]);
     LegConst<NJ> &lc = c.leg[l];
     lc.neg_ratio = p.negation_transition_ratio[l];
+    { // calculateStanceSpanChange (walk_controller.cpp:949-980): workspace.size() == 1 -> radius = workspace.at(0.0).at(bearing)
+      double m = p.stance_span_modifier;
+      const bool positive_y = p.stance_position[l][1] > 0.0;
+      const int bearing = (positive_y ^ (m > 0.0)) ? 270 : 90;
+      m *= positive_y ? 1.0 : -1.0;
+      lc.span_shift = t.workspace_radius[l][bearing / 45] * m;
+    }
     lc.phase_offset = t.phase_offset[l];
     int ns = p.pose_negation_phase_starts[l] * t.pose_normaliser, ne = p.pose_negation_phase_ends[l] * t.pose_normaliser;
     if (ns == 0) ns = t.pose_phase_length; // pose_controller.cpp:1723-1730
@@ -637,7 +644,6 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
   if (nj < 3 || nj > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
   if (p->rough_terrain_mode) return fail(SHC_ERR_UNSUPPORTED, "rough_terrain_mode is outside the accelerated path");
   if (p->gravity_aligned_tips) return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips (tip-rotation constrained IK) is outside the accelerated path");
-  if (p->stance_span_modifier != 0.0) return fail(SHC_ERR_UNSUPPORTED, "stance_span_modifier != 0 is outside the accelerated path");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
   if (p->time_delta <= 0 || p->step_frequency <= 0) return fail(SHC_ERR_INVALID_ARG, "time_delta / step_frequency must be > 0");
   *L = p->leg_count;

@@ -29,6 +29,7 @@ struct LegConst {
   double jw_range[NJ]; // JOINT_LIMIT_COST_WEIGHT / (max - min), 0 if the range is 0   (model.cpp:772-778)
   double jw_vrange[NJ]; // JOINT_LIMIT_COST_WEIGHT / (2 max_vel)      (model.cpp:781-786)
   double stance_x, stance_y; // identity tip position (walk_controller.cpp:34-35)
+  double span_shift;         // LegStepper::calculateStanceSpanChange().y for the single-plane workspace (walk_controller.cpp:949-980)
   double neg_ratio;          // negation_transition_ratio
   int32_t phase_offset;      // walk_controller.cpp:277
   int32_t neg_start, neg_end; // pose negation phases (already * normaliser, 0 -> phase length; pose_controller.cpp:1718-1731)

@@ -247,10 +247,13 @@ def test_force_normal_touchdown_and_swing_width(Engine):
     run_pair(Engine, p, 40, make_inputs(p, 40, 19), [120, 180])
 
 
-def test_start_stop_start_sequence(Engine):
+@pytest.mark.parametrize("span", [0.0, 0.25, -0.2])
+def test_start_stop_start_sequence(Engine, span):
     """STOPPED -> STARTING -> MOVING -> STOPPING -> STOPPED -> ... : walk FSM counters, FORCE_STANCE / FORCE_STOP,
-    the default-tip update and the walk-plane refit (walk_controller.cpp:529-632, 748-779, 984-1014)."""
+    the default-tip update (with and without a stance-span change, walk_controller.cpp:949-980) and the walk-plane refit
+    (walk_controller.cpp:529-632, 748-779, 984-1014)."""
     p = default_hexapod_params("tripod")
+    p.stance_span_modifier = span
     n = 50
     inp = make_inputs(p, n, 23)
     eng, ob, _ = run_pair(Engine, p, n, inp, [1, 1, 98, 200])
