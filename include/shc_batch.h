@@ -161,6 +161,18 @@ const char *shc_last_error(void);
  * `n_doubles` (even) doubles; the known byte count calibrates rocprofv3's FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM). */
 int shc_debug_plane_copy(int device, int64_t n_doubles, int reps);
 
+/*
+ * The same init chain for `count` morphologies at once, ON THE GPU: one thread per
+ * (morphology, leg) runs the direct start-up solve and the workspace search (thousands of sequential DLS steps each,
+ * model.cpp:309-510, pose_controller.cpp:463-517), one thread per morphology the walkspace and limits
+ * (walk_controller.cpp:57-361).  params / out are host arrays; status[i] (may be NULL) receives SHC_OK or the reason
+ * morphology i was rejected (its tables are zeroed).  Results match shc_generate_tables up to FP contraction.
+ */
+int shc_generate_tables_batch(const shc_params *params, int64_t count, shc_tables *out, int32_t *status, int device);
+/* shc_engine_create with tables computed beforehand (shc_generate_tables / _batch) instead of running the init chain. */
+int shc_engine_create_with_tables(const shc_params *params, const shc_tables *tables, int64_t n_instances, int device,
+                                  void *stream, shc_engine **out);
+
 /* HIP stream helpers for hosts without their own HIP binding (the ctypes tests, a cgo / JNI host): a non-blocking
  * stream on `device` to pass to shc_engine_create / shc_engine_set_stream.  Engines of different morphology bins run
  * concurrently when each has its own stream (BASELINE.json configs[4]). */

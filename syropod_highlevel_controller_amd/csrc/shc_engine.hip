@@ -725,6 +725,67 @@ extern "C" int shc_generate_tables(const shc_params *params, shc_tables *out) {
   return fail(SHC_ERR_UNSUPPORTED, "dof");
 }
 
+// ---- init chain on the device: the same host + device functions as shc_generate_tables, fanned out over morphologies
+template <int NJ>
+__global__ void init_chain_legs_kernel(const shc_params *params, shc_tables *tables, const int32_t *status, int64_t count) {
+  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  int64_t m = t / SHC_MAX_LEGS;
+  int l = int(t - m * SHC_MAX_LEGS);
+  if (m >= count || status[m] != SHC_OK) return;
+  const shc_params &p = params[m];
+  if (p.leg_dof[0] != NJ || l >= p.leg_count) return;
+  hostinit::generate_tables_leg<NJ>(p, l, tables[m]);
+}
+__global__ void init_chain_head_kernel(const shc_params *params, shc_tables *tables, int32_t *status, int64_t count) {
+  int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (m >= count || status[m] != SHC_OK) return;
+  if (!hostinit::generate_tables_head(params[m], tables[m])) status[m] = SHC_ERR_INVALID_ARG;
+}
+__global__ void init_chain_tail_kernel(const shc_params *params, shc_tables *tables, const int32_t *status, int64_t count) {
+  int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (m >= count || status[m] != SHC_OK) return;
+  hostinit::generate_tables_tail(params[m], tables[m]);
+}
+
+extern "C" int shc_generate_tables_batch(const shc_params *params, int64_t count, shc_tables *out, int32_t *status, int device) {
+  if (!params || !out || count < 1) return fail(SHC_ERR_INVALID_ARG, "params / out NULL or count < 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SHC_ERR_NO_DEVICE, "no HIP device visible");
+  HIP_TRY(hipSetDevice(device));
+  std::vector<int32_t> st(count);
+  for (int64_t i = 0; i < count; ++i) { // parameter screening is host logic (same rules as shc_engine_create)
+    int L, NJ;
+    st[i] = validate_params(&params[i], &L, &NJ);
+  }
+  shc_params *d_p = nullptr;
+  shc_tables *d_t = nullptr;
+  int32_t *d_s = nullptr;
+  HIP_TRY(hipMalloc(&d_p, size_t(count) * sizeof(shc_params)));
+  HIP_TRY(hipMalloc(&d_t, size_t(count) * sizeof(shc_tables)));
+  HIP_TRY(hipMalloc(&d_s, size_t(count) * 4));
+  HIP_TRY(hipMemcpy(d_p, params, size_t(count) * sizeof(shc_params), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(d_s, st.data(), size_t(count) * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(d_t, 0, size_t(count) * sizeof(shc_tables)));
+  const unsigned gm = (unsigned)((count + 63) / 64), gl = (unsigned)((count * SHC_MAX_LEGS + 63) / 64);
+  init_chain_head_kernel<<<dim3(gm), dim3(64)>>>(d_p, d_t, d_s, count);
+  init_chain_legs_kernel<3><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);
+  init_chain_legs_kernel<4><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);
+  init_chain_legs_kernel<5><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);
+  init_chain_tail_kernel<<<dim3(gm), dim3(64)>>>(d_p, d_t, d_s, count);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, d_t, size_t(count) * sizeof(shc_tables), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(st.data(), d_s, size_t(count) * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_p);
+  (void)hipFree(d_t);
+  (void)hipFree(d_s);
+  for (int64_t i = 0; i < count; ++i) {
+    if (st[i] != SHC_OK) memset(static_cast<void *>(&out[i]), 0, sizeof(shc_tables));
+    if (status) status[i] = st[i];
+  }
+  return SHC_OK;
+}
+
 #define SHC_DISPATCH(L_, NJ_, CALL)                                   \
   do {                                                                \
     if (L_ == 3 && NJ_ == 3) { CALL(3, 3); }                          \
@@ -838,7 +899,19 @@ static int init_state(shc_engine *e) {
   return SHC_OK;
 }
 
+static int engine_create(const shc_params *params, const shc_tables *tables, int64_t n_instances, int device, void *stream,
+                         shc_engine **out);
 extern "C" int shc_engine_create(const shc_params *params, int64_t n_instances, int device, void *stream, shc_engine **out) {
+  return engine_create(params, nullptr, n_instances, device, stream, out);
+}
+extern "C" int shc_engine_create_with_tables(const shc_params *params, const shc_tables *tables, int64_t n_instances, int device,
+                                             void *stream, shc_engine **out) {
+  if (!tables) return fail(SHC_ERR_INVALID_ARG, "tables is NULL");
+  if (tables->step.period <= 0) return fail(SHC_ERR_INVALID_ARG, "tables were not generated (step period 0)");
+  return engine_create(params, tables, n_instances, device, stream, out);
+}
+static int engine_create(const shc_params *params, const shc_tables *tables, int64_t n_instances, int device, void *stream,
+                         shc_engine **out) {
   int L, NJ;
   int rc = validate_params(params, &L, &NJ);
   if (rc != SHC_OK) return rc;
@@ -857,10 +930,14 @@ extern "C" int shc_engine_create(const shc_params *params, int64_t n_instances, 
   e->stream = (hipStream_t)stream;
   e->n = n_instances;
   e->features = SHC_FEAT_TIP_FORCE | SHC_FEAT_ODOMETRY;
-  rc = shc_generate_tables(params, &e->tables);
-  if (rc != SHC_OK) {
-    delete e;
-    return rc;
+  if (tables) {
+    e->tables = *tables;
+  } else {
+    rc = shc_generate_tables(params, &e->tables);
+    if (rc != SHC_OK) {
+      delete e;
+      return rc;
+    }
   }
   build_cycle_params(e->params, e->tables, e->features, e->cp);
   const int rpw = 64 / L;

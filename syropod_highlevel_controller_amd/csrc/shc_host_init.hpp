@@ -1,5 +1,7 @@
-// shc_host_init.hpp — host-side init chain of the engine (product code; shares shc_leg.hpp with the HIP kernels;
-// the CPU oracle has its own, independent restatement).
+// shc_host_init.hpp — init chain of the engine (product code; shares shc_leg.hpp with the HIP kernels; the CPU oracle has
+// its own, independent restatement).  Every function except the long-double admittance map is host + device: one
+// morphology is initialised on the host (shc_generate_tables, ~1 ms), many at once by init_chain kernels
+// (shc_generate_tables_batch: one thread per (morphology, leg) for the start-up solve + workspace search).
 //
 // Produces the per-(morphology, gait) tables the cycle kernel consumes.  Reference chain restated
 // (OpenSHC v0.5.11):
@@ -16,12 +18,18 @@
 #include "../../include/shc_batch.h"
 #include "shc_leg.hpp"
 
-#include <algorithm>
 #include <cmath>
 #include <cstring>
 
+#define SHC_HDI __host__ __device__ inline
+
 namespace shc {
 namespace hostinit {
+
+SHC_HDI int imax(int a, int b) { return a > b ? a : b; }
+SHC_HDI int iabs(int a) { return a < 0 ? -a : a; }
+SHC_HDI double dmin(double a, double b) { return a < b ? a : b; }
+SHC_HDI double dmax(double a, double b) { return a > b ? a : b; }
 
 constexpr int kBearingStep = 45;          // model.h:22
 constexpr double kMaxPositionDelta = 0.002; // model.h:23
@@ -29,8 +37,8 @@ constexpr double kMaxWorkspaceRadius = 1.0; // model.h:24
 constexpr int kWorkspaceLayers = 10;      // model.h:25
 
 template <int NJ>
-inline void fill_leg_const(const shc_params &p, int l, LegConst<NJ> &lc) {
-  std::memset(&lc, 0, sizeof lc);
+SHC_HDI void fill_leg_const(const shc_params &p, int l, LegConst<NJ> &lc) {
+  __builtin_memset(&lc, 0, sizeof lc);
   const shc_link_params &b = p.link[l][0];
   // createDHMatrix (standard_includes.h:466) of the base link: joint 1's constant transform
   double ct = cos(b.theta), st = sin(b.theta), ca = cos(b.alpha), sa = sin(b.alpha);
@@ -98,7 +106,7 @@ inline void admittance_map(const shc_params &p, double &m00, double &m01, double
   g0 = (double)G[0]; g1 = (double)G[1];
 }
 
-inline shc_step_cycle generate_step_cycle(const shc_params &p) {
+SHC_HDI shc_step_cycle generate_step_cycle(const shc_params &p) {
   shc_step_cycle s;
   s.stance_end = int(p.stance_phase * 0.5);
   s.swing_start = s.stance_end;
@@ -126,11 +134,11 @@ struct HostLeg {
   double q[NJ], qd[NJ], dflt[NJ];
   Chain<NJ> ch;
   V3 tip; // robot frame
-  void fk() {
+  SHC_HDI void fk() {
     fk_chain<NJ>(lc, q, ch);
     tip = tip_robot_frame(lc, ch.pe);
   }
-  void reset_to_default() { // Leg::init(true) (model.cpp:286-305)
+  SHC_HDI void reset_to_default() { // Leg::init(true) (model.cpp:286-305)
     for (int j = 0; j < NJ; ++j) {
       q[j] = dflt[j];
       qd[j] = 0.0;
@@ -138,9 +146,9 @@ struct HostLeg {
     fk();
   }
   // Leg::applyIK(simulation = true) towards `desired` (model.cpp:861-941); returns the ik result
-  double ik(V3 desired, const shc_params &p) {
+  SHC_HDI double ik(V3 desired, const shc_params &p) {
     double dq[NJ];
-    ik_step<NJ>(lc, ch, q, qd, desired, dq);
+    ik_step<NJ, true>(lc, ch, q, qd, desired, dq); // IEEE division on host and device alike
     double prox = update_joints<NJ>(lc, dq, p.time_delta, 1.0 / p.time_delta, false, p.clamp_joint_positions != 0, q, qd);
     fk();
     V3 e = tip - desired;
@@ -152,12 +160,12 @@ struct HostLeg {
 // PoseController::directStartup's simulated solve for one leg: LegPoser::stepToPosition (lift 0, time_to_start)
 // towards the default tip pose with the body easing to `body` + one DLS step per iteration.
 template <int NJ>
-inline void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip, const Pose &body) {
+SHC_HDI void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip, const Pose &body) {
   leg.reset_to_default();
   V3 origin = leg.tip;
   V3 delta = origin - inverse_transform_vector(body, default_tip);
   if (!(norm(delta) > kTipTolerance)) return; // already there (pose_controller.cpp:1603-1608)
-  int num = std::max(1, round_to_int(p.time_to_start / p.time_delta));
+  int num = imax(1, round_to_int(p.time_to_start / p.time_delta));
   double dt = 1.0 / num;
   int half = num / 2;
   V3 o2t = origin - default_tip;
@@ -174,16 +182,16 @@ inline void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip,
 
 // Leg::generateWorkspace, simple (single plane z = 0) workspace.  radius[b], b = bearing / 45.
 template <int NJ>
-inline void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS]) {
+SHC_HDI void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS]) {
   leg.reset_to_default();
   if (norm(identity_tip_body - leg.tip) > kIkTolerance) { // model.cpp:349-353
-    for (double &r : radius) r = 0.0;
+    for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = 0.0;
     return;
   }
-  for (double &r : radius) r = kMaxWorkspaceRadius;
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = kMaxWorkspaceRadius;
   // track from the default-configuration tip to the identity tip position (model.cpp:397-404), then re-base defaults
   {
-    int n = std::max(1, round_to_int((kMaxWorkspaceRadius / kWorkspaceLayers) / kMaxPositionDelta));
+    int n = imax(1, round_to_int((kMaxWorkspaceRadius / kWorkspaceLayers) / kMaxPositionDelta));
     V3 o = leg.tip, t = identity_tip_body;
     bool ok = true;
     for (int it = 1; it <= n && ok; ++it) {
@@ -207,17 +215,17 @@ inline void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identit
   radius[0] = radius[360 / kBearingStep];
 }
 
-inline V3 rot_z(double ang, V3 v) { // Eigen::AngleAxisd(ang, UnitZ) * v
+SHC_HDI V3 rot_z(double ang, V3 v) { // Eigen::AngleAxisd(ang, UnitZ) * v
   double s = sin(ang), c = cos(ang);
   return V3{c * v.x - s * v.y, s * v.x + c * v.y, v.z};
 }
-inline V3 set_precision3(V3 v) { // setPrecision(vector, 3) (standard_includes.h:152)
+SHC_HDI V3 set_precision3(V3 v) { // setPrecision(vector, 3) (standard_includes.h:152)
   return V3{round_to_int(v.x * pow(10, 3)) / pow(10, 3), round_to_int(v.y * pow(10, 3)) / pow(10, 3),
             round_to_int(v.z * pow(10, 3)) / pow(10, 3)};
 }
 
 // WalkController::generateWalkspace with default tip == identity tip for every leg (true right after start-up)
-inline void generate_walkspace(const shc_params &p, const double (*workspace)[SHC_N_BEARINGS], double (&walkspace)[SHC_N_BEARINGS]) {
+SHC_HDI void generate_walkspace(const shc_params &p, const double (*workspace)[SHC_N_BEARINGS], double (&walkspace)[SHC_N_BEARINGS]) {
   const int L = p.leg_count;
   bool have[SHC_N_BEARINGS] = {false};
   for (int l = 0; l < L; ++l) {
@@ -227,12 +235,12 @@ inline void generate_walkspace(const shc_params &p, const double (*workspace)[SH
     double dist1 = norm(d - a1) / 2.0, dist2 = norm(d - a2) / 2.0;
     double b1 = rad2deg(atan2(a1.y - d.y, a1.x - d.x)), b2 = rad2deg(atan2(a2.y - d.y, a2.x - d.x));
     for (int bearing = 0; bearing <= 360; bearing += kBearingStep) {
-      int diff1 = std::abs(mod_i(int(b1), 360) - bearing), diff2 = std::abs(mod_i(int(b2), 360) - bearing);
+      int diff1 = iabs(mod_i(int(b1), 360) - bearing), diff2 = iabs(mod_i(int(b2), 360) - bearing);
       double o1 = kUnassigned, o2 = kUnassigned;
       if ((diff1 < 90 || diff1 > 270) && dist1 > 0.0) o1 = dist1 / cos(deg2rad(diff1));
       if ((diff2 < 90 || diff2 > 270) && dist2 > 0.0) o2 = dist2 / cos(deg2rad(diff2));
-      double md = p.overlapping_walkspaces ? kMaxWorkspaceRadius : std::min(o1, o2);
-      md = std::min(md, kMaxWorkspaceRadius);
+      double md = p.overlapping_walkspaces ? kMaxWorkspaceRadius : dmin(o1, o2);
+      md = dmin(md, kMaxWorkspaceRadius);
       int bi = bearing / kBearingStep;
       if (!have[bi]) {
         walkspace[bi] = md;
@@ -255,7 +263,7 @@ inline void generate_walkspace(const shc_params &p, const double (*workspace)[SH
   walkspace[360 / kBearingStep] = walkspace[0];
 }
 
-inline void generate_limits(const shc_params &p, shc_tables &t) {
+SHC_HDI void generate_limits(const shc_params &p, shc_tables &t) {
   const shc_step_cycle &step = t.step;
   const int L = p.leg_count;
   int base = p.stance_phase + p.swing_phase;
@@ -265,7 +273,7 @@ inline void generate_limits(const shc_params &p, shc_tables &t) {
   for (int l = 0; l < L; ++l) {
     int off = (base_offset * p.offset_multiplier[l]) % step.period;
     t.phase_offset[l] = off;
-    if (off > step.swing_start && off < step.swing_end) max_ext = std::max(max_ext, step.swing_end - off);
+    if (off > step.swing_start && off < step.swing_end) max_ext = imax(max_ext, step.swing_end - off);
   }
   double time_to_max_stride = (max_ext + step.stance_period + step.swing_period) * p.time_delta;
   for (int b = 0; b < SHC_N_BEARINGS; ++b) {
@@ -283,7 +291,7 @@ inline void generate_limits(const shc_params &p, shc_tables &t) {
       double d0 = -stride_length / 2.0;
       double d1 = d0 + v0 * tt + 0.5 * max_acc * (tt * tt);
       double d2 = max_speed * (step.stance_period * p.time_delta - tt);
-      overshoot = std::max(overshoot, d1 + d2 - wr);
+      overshoot = dmax(overshoot, d1 + d2 - wr);
     }
     double swing_overshoot = 0.5 * max_speed * step.swing_period / (2.0 * step.period * step.frequency);
     double scaled = (wr / (wr + overshoot + swing_overshoot)) * wr;
@@ -306,46 +314,59 @@ inline void generate_limits(const shc_params &p, shc_tables &t) {
   }
 }
 
-template <int NJ>
-inline bool generate_tables(const shc_params &p, shc_tables &t) {
-  std::memset(&t, 0, sizeof t);
+// Step cycle + auto-pose phase tables of one morphology (everything that needs no IK).  False for a degenerate gait.
+SHC_HDI bool generate_tables_head(const shc_params &p, shc_tables &t) {
+  __builtin_memset(&t, 0, sizeof t);
   t.step = generate_step_cycle(p);
   if (t.step.period <= 0 || t.step.stance_period <= 0 || t.step.swing_period <= 0) return false;
   // auto-pose phase length / normaliser (pose_controller.cpp:44-63) and reference leg (:75-78)
-  {
-    int base;
-    double raw;
-    if (p.pose_frequency == -1.0) {
-      base = p.stance_phase + p.swing_phase;
-      double swing_ratio = double(p.swing_phase) / base;
-      raw = ((1.0 / p.step_frequency) / p.time_delta) / swing_ratio;
-    } else {
-      base = p.pose_phase_length;
-      raw = ((1.0 / p.pose_frequency) / p.time_delta);
-    }
-    if (base <= 0) base = 1;
-    t.pose_phase_length = round_to_even_int(raw / base) * base;
-    t.pose_normaliser = t.pose_phase_length / base;
-    t.auto_pose_reference_leg = 0;
-    for (int l = 0; l < p.leg_count; ++l)
-      if (p.offset_multiplier[l] == 0) t.auto_pose_reference_leg = l;
+  int base;
+  double raw;
+  if (p.pose_frequency == -1.0) {
+    base = p.stance_phase + p.swing_phase;
+    double swing_ratio = double(p.swing_phase) / base;
+    raw = ((1.0 / p.step_frequency) / p.time_delta) / swing_ratio;
+  } else {
+    base = p.pose_phase_length;
+    raw = ((1.0 / p.pose_frequency) / p.time_delta);
   }
+  if (base <= 0) base = 1;
+  t.pose_phase_length = round_to_even_int(raw / base) * base;
+  t.pose_normaliser = t.pose_phase_length / base;
+  t.auto_pose_reference_leg = 0;
+  for (int l = 0; l < p.leg_count; ++l)
+    if (p.offset_multiplier[l] == 0) t.auto_pose_reference_leg = l;
+  return true;
+}
+
+// Direct start-up solve + workspace search of ONE leg: the sequential part (thousands of DLS steps), independent per leg.
+template <int NJ>
+SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t) {
   // body pose during start-up and workspace generation: walk-plane pose (0, 0, body_clearance), no rotation
   Pose body{V3{0, 0, p.body_clearance}, quat_identity()};
-  for (int l = 0; l < p.leg_count; ++l) {
-    HostLeg<NJ> leg;
-    fill_leg_const<NJ>(p, l, leg.lc);
-    for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, p.joint[l][j].min, p.joint[l][j].max); // model.cpp:1038
-    V3 default_tip{p.stance_position[l][0], p.stance_position[l][1], 0.0};
-    startup_solve<NJ>(p, leg, default_tip, body);
-    for (int j = 0; j < NJ; ++j) {
-      leg.dflt[j] = leg.q[j]; // Model::updateDefaultConfiguration
-      t.default_joint_position[l][j] = leg.q[j];
-    }
-    generate_workspace<NJ>(p, leg, inverse_transform_vector(body, default_tip), t.workspace_radius[l]);
+  HostLeg<NJ> leg;
+  fill_leg_const<NJ>(p, l, leg.lc);
+  for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, p.joint[l][j].min, p.joint[l][j].max); // model.cpp:1038
+  V3 default_tip{p.stance_position[l][0], p.stance_position[l][1], 0.0};
+  startup_solve<NJ>(p, leg, default_tip, body);
+  for (int j = 0; j < NJ; ++j) {
+    leg.dflt[j] = leg.q[j]; // Model::updateDefaultConfiguration
+    t.default_joint_position[l][j] = leg.q[j];
   }
+  generate_workspace<NJ>(p, leg, inverse_transform_vector(body, default_tip), t.workspace_radius[l]);
+}
+
+// Walkspace + velocity / acceleration limits from the legs' workspaces.
+SHC_HDI void generate_tables_tail(const shc_params &p, shc_tables &t) {
   generate_walkspace(p, t.workspace_radius, t.walkspace);
   generate_limits(p, t);
+}
+
+template <int NJ>
+SHC_HDI bool generate_tables(const shc_params &p, shc_tables &t) {
+  if (!generate_tables_head(p, t)) return false;
+  for (int l = 0; l < p.leg_count; ++l) generate_tables_leg<NJ>(p, l, t);
+  generate_tables_tail(p, t);
   return true;
 }
 

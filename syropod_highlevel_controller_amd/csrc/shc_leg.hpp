@@ -126,19 +126,19 @@ SHC_HD void jacobian_columns(const Chain<NJ> &c, V3 (&lin)[NJ]) {
   }
 }
 
-template <int NJ, class LC>
+template <int NJ, bool EXACT = false, class LC>
 SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double (&q)[NJ], const double (&qd)[NJ], V3 desired,
                          double (&dq)[NJ]);
 
-template <int NJ, class LC>
+template <int NJ, bool EXACT = false, class LC>
 SHC_HD void ik_step(const LC &lc, const Chain<NJ> &c, const double (&q)[NJ], const double (&qd)[NJ], V3 desired,
                     double (&dq)[NJ]) {
   V3 lin[NJ];
   jacobian_columns<NJ>(c, lin);
-  ik_step_cols<NJ>(lc, lin, c.pe, q, qd, desired, dq);
+  ik_step_cols<NJ, EXACT>(lc, lin, c.pe, q, qd, desired, dq);
 }
 
-template <int NJ, class LC>
+template <int NJ, bool EXACT, class LC>
 SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double (&q)[NJ], const double (&qd)[NJ], V3 desired,
                          double (&dq)[NJ]) {
   // position delta in the joint-1 frame: T1^-1 desired - T1^-1 current
@@ -156,7 +156,7 @@ SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double 
     vg[i] = -v * lc.jw_vrange[i];
   }
   // evaluated unconditionally and selected afterwards: no exec-mask branch around the sqrt / division
-  double ps = fast_rsqrt(pcost), vs = fast_rsqrt(vcost);
+  double ps = fast_rsqrt<EXACT>(pcost), vs = fast_rsqrt<EXACT>(vcost);
   ps = pcost == 0.0 ? 0.0 : ps;
   vs = vcost == 0.0 ? 0.0 : vs;
   const double l2 = kDls * kDls;
@@ -169,7 +169,7 @@ SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double 
     double g = 0.25 * (pg[i] * ps) + 0.75 * (vg[i] * vs);
     dq[i] = dot(lin[i], delta) + l2 * g;
   }
-  spd_solve<NJ>(a, dq);
+  spd_solve<NJ, EXACT>(a, dq);
 }
 
 // Leg::updateJointPositions (model.cpp:799-857).  Returns the minimum limit proximity.

@@ -278,7 +278,9 @@ SHC_HD V3 quartic_bezier_dot(V3 p0, V3 p1, V3 p2, V3 p3, V3 p4, double t) {
 // hardware estimate refined by two Newton steps (<= 1 ulp for the well-scaled positive arguments that occur: pivots
 // >= lambda^2, limit costs) - 5-6 dependent instructions instead of the ~12-20 of an IEEE division / sqrt + division.
 // The host build of the same templates (init chain) uses plain division.
+template <bool EXACT = false>
 SHC_HD double fast_rcp(double x) {
+  if (EXACT) return 1.0 / x; // the init chain keeps IEEE division on both sides so that host and device tables agree
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(x);
   r = fma(r, fma(-x, r, 1.0), r);
@@ -288,7 +290,9 @@ SHC_HD double fast_rcp(double x) {
   return 1.0 / x;
 #endif
 }
+template <bool EXACT = false>
 SHC_HD double fast_rsqrt(double x) {
+  if (EXACT) return 1.0 / sqrt(x);
 #if defined(__HIP_DEVICE_COMPILE__)
   double y = __builtin_amdgcn_rsq(x);
   y = fma(0.5 * y, fma(-x * y, y, 1.0), y);
@@ -301,12 +305,12 @@ SHC_HD double fast_rsqrt(double x) {
 
 // A is the damped normal matrix J^T J + lambda^2 I of the DLS step (always SPD), so an unpivoted
 // LDL^T in registers is exact enough and branch-free; fully unrolled for compile-time N.
-template <int N>
+template <int N, bool EXACT = false>
 SHC_HD void spd_solve(double (&a)[N][N], double (&b)[N]) {
   double dinv[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    dinv[k] = fast_rcp(a[k][k]);
+    dinv[k] = fast_rcp<EXACT>(a[k][k]);
 #pragma unroll
     for (int i = k + 1; i < N; ++i) {
       double l = a[i][k] * dinv[k];

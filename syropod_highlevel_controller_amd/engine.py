@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_get_joint_state", "shc_engine_joint_buffer", "shc_engine_joint_index", "shc_engine_get_leg_state",
     "shc_engine_get_body_state", "shc_engine_get_odometry", "shc_engine_get_virtual_stiffness",
     "shc_engine_change_gait", "shc_stream_create", "shc_stream_destroy", "shc_engine_read_leg_state_msg",
+    "shc_generate_tables_batch", "shc_engine_create_with_tables",
 ]
 
 
@@ -80,6 +81,9 @@ def lib():
         L.shc_debug_plane_copy.argtypes = [C.c_int, C.c_int64, C.c_int]
         L.shc_sizeof_tables.restype = C.c_int64
         L.shc_generate_tables.argtypes = [C.POINTER(Params), C.POINTER(Tables)]
+        L.shc_generate_tables_batch.argtypes = [C.POINTER(Params), C.c_int64, C.POINTER(Tables), C.POINTER(C.c_int32), C.c_int]
+        L.shc_engine_create_with_tables.argtypes = [C.POINTER(Params), C.POINTER(Tables), C.c_int64, C.c_int, C.c_void_p,
+                                                    C.POINTER(C.c_void_p)]
         L.shc_engine_create.argtypes = [C.POINTER(Params), C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.shc_engine_destroy.argtypes = [C.c_void_p]
         L.shc_engine_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -133,10 +137,20 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def generate_tables_batch(params_list, device: int = 0):
+    """Init chain of many morphologies in one go on the GPU.  Returns (list of Tables, status array)."""
+    n = len(params_list)
+    arr = (Params * n)(*params_list)
+    out = (Tables * n)()
+    status = (C.c_int32 * n)()
+    _check(lib().shc_generate_tables_batch(arr, n, out, status, device), "shc_generate_tables_batch")
+    return list(out), np.array(status[:], dtype=np.int32)
+
+
 class BatchEngine:
     """A batch of ``n`` robots of one morphology/gait advancing through control cycles on one MI355X."""
 
-    def __init__(self, params: Params, n: int, device: int = 0, stream: int = 0):
+    def __init__(self, params: Params, n: int, device: int = 0, stream: int = 0, tables: Optional[Tables] = None):
         self.L = lib()
         if self.L.shc_device_count() < 1:
             raise ShcError("no HIP device visible: the batched engine has no CPU fallback")
@@ -144,7 +158,11 @@ class BatchEngine:
         self.legs, self.dof = params.leg_count, params.leg_dof[0]
         self.features = FEAT_DEFAULT
         h = C.c_void_p()
-        _check(self.L.shc_engine_create(C.byref(params), self.n, device, C.c_void_p(stream), C.byref(h)), "shc_engine_create")
+        if tables is None:
+            _check(self.L.shc_engine_create(C.byref(params), self.n, device, C.c_void_p(stream), C.byref(h)), "shc_engine_create")
+        else:
+            _check(self.L.shc_engine_create_with_tables(C.byref(params), C.byref(tables), self.n, device, C.c_void_p(stream),
+                                                        C.byref(h)), "shc_engine_create_with_tables")
         self.h = h
 
     def close(self):

@@ -17,8 +17,12 @@ from .params import Params
 
 
 class MixedFleet:
-    def __init__(self, morphologies: Sequence[Params], morph_id, device: int = 0, own_streams: bool = True):
-        """morphologies[k] describes bin k; morph_id[i] in [0, len(morphologies)) assigns instance i to a bin."""
+    def __init__(self, morphologies: Sequence[Params], morph_id, device: int = 0, own_streams: bool = True,
+                 device_init: bool = False):
+        """morphologies[k] describes bin k; morph_id[i] in [0, len(morphologies)) assigns instance i to a bin.
+        device_init: run the init chain of all bins as one batch of HIP kernels (shc_generate_tables_batch) instead of
+        ~1 ms of host time per bin; the start-up joint configuration then agrees with the host's to ~1e-6 rad only (the
+        reference's start-up iteration amplifies rounding differences)."""
         self.morph_id = np.asarray(morph_id, dtype=np.int64)
         self.n = len(self.morph_id)
         if self.n == 0 or self.morph_id.min() < 0 or self.morph_id.max() >= len(morphologies):
@@ -28,6 +32,8 @@ class MixedFleet:
         self.params = list(morphologies)
         self.index = [np.nonzero(self.morph_id == k)[0] for k in range(len(morphologies))]  # instance ids of bin k, ascending
         self.streams, self.engines = [], []
+        # init chain (start-up solve, workspace search, walkspace, limits) of every bin at once on the GPU
+        tables, status = _engine.generate_tables_batch(self.params, device) if device_init else (None, None)
         for k, idx in enumerate(self.index):
             if len(idx) == 0:
                 self.streams.append(None)
@@ -37,7 +43,10 @@ class MixedFleet:
             if own_streams:
                 _engine._check(self.L.shc_stream_create(device, C.byref(s)), "shc_stream_create")
             self.streams.append(s)
-            self.engines.append(_engine.BatchEngine(morphologies[k], len(idx), device, s.value or 0))
+            if status is not None and status[k] != 0:
+                raise _engine.ShcError(f"morphology {k} rejected by the init chain (code {status[k]})")
+            self.engines.append(_engine.BatchEngine(morphologies[k], len(idx), device, s.value or 0,
+                                                    tables=None if tables is None else tables[k]))
         self.max_legs = max(p.leg_count for p in self.params)
         self.max_dof = max(p.leg_dof[0] for p in self.params)
 

@@ -173,7 +173,7 @@ def test_config5_interleaved_fleet(Engine):
     rng = np.random.default_rng(77)
     lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
     effort = rng.normal(0, 0.5, size=(n, 8, 5))
-    fleet = MixedFleet(morphs, mid)
+    fleet = MixedFleet(morphs, mid, device_init=True)  # tables of all five bins from one batch of init-chain kernels
     fleet.set_velocity(lin, ang)
     fleet.set_joint_effort(effort)
     oracles = []
@@ -620,3 +620,48 @@ def test_leg_state_message_payload(Engine):
                         assert np.array_equal(a, b), name   # functions of the integer phase only
                     else:
                         np.testing.assert_allclose(a, b, rtol=0, atol=1e-8, err_msg=f"{name} cycle {done} instance {i}")
+
+
+def test_init_chain_on_device_matches_host():
+    """shc_generate_tables_batch (start-up solve + workspace search + walkspace + limits as HIP kernels, one thread per
+    (morphology, leg)) against the host init chain for perturbed morphologies.  Integers are exact; workspace radii,
+    walkspace and limits agree to 1e-8 (measured 1e-16 .. 5e-10).  The start-up joint configuration is the state of the
+    reference's DLS iteration after a fixed 300 steps, which still chatters around the solution and amplifies rounding
+    differences (host libm / no FMA vs device ocml / FMA): most morphologies agree to 1e-6 rad, all to 1e-3.
+    A rejected parameter set is reported per morphology."""
+    from syropod_highlevel_controller_amd import engine
+    rng = np.random.default_rng(91)
+    plist = []
+    for k in range(48):
+        if k % 4 == 3:
+            p = synthetic_octopod_params(["ripple", "wave", "tripod"][k % 3], 3 + k % 3, [4, 6, 8][(k // 4) % 3])
+        else:
+            p = default_hexapod_params(["tripod", "wave", "ripple", "amble"][k % 4])
+        for l in range(p.leg_count):  # perturb link lengths, stance positions and body clearance
+            for j in range(1, p.leg_dof[l] + 1):
+                p.link[l][j].r *= 1.0 + rng.uniform(-0.08, 0.08)
+            p.stance_position[l][0] *= 1.0 + rng.uniform(-0.05, 0.05)
+            p.stance_position[l][1] *= 1.0 + rng.uniform(-0.05, 0.05)
+        p.body_clearance *= 1.0 + rng.uniform(-0.1, 0.1)
+        p.step_frequency = [1.0, 0.8, 1.25][k % 3]
+        plist.append(p)
+    bad = default_hexapod_params("tripod")
+    bad.rough_terrain_mode = 1
+    plist.append(bad)
+    tables, status = engine.generate_tables_batch(plist)
+    assert status[-1] != 0 and (status[:-1] == 0).all()
+    tight = []
+    for p, t in zip(plist[:-1], tables[:-1]):
+        h = engine.generate_tables(p)
+        for name in ("period", "swing_period", "stance_period", "stance_end", "swing_start", "swing_end", "stance_start"):
+            assert getattr(t.step, name) == getattr(h.step, name)
+        assert list(t.phase_offset) == list(h.phase_offset)
+        assert (t.pose_phase_length, t.pose_normaliser, t.auto_pose_reference_leg) == (h.pose_phase_length, h.pose_normaliser, h.auto_pose_reference_leg)
+        L, D = p.leg_count, p.leg_dof[0]
+        dq = np.abs(np.array(t.default_joint_position)[:L, :D] - np.array(h.default_joint_position)[:L, :D]).max()
+        assert dq < 1e-3
+        tight.append(dq <= 1e-6)
+        np.testing.assert_allclose(np.array(t.workspace_radius)[:L], np.array(h.workspace_radius)[:L], atol=1e-8)
+        for name in ("walkspace", "max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration"):
+            np.testing.assert_allclose(np.array(getattr(t, name)), np.array(getattr(h, name)), rtol=1e-8, atol=1e-8, err_msg=name)
+    assert np.mean(tight) > 0.8
