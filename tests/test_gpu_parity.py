@@ -78,6 +78,9 @@ def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
     np.testing.assert_allclose(vg[m], vo[m], atol=1e-12)
     np.testing.assert_allclose(lg["poser_tip"][m], lo["poser_tip"][m], atol=1e-8)
     np.testing.assert_allclose(lg["model_tip"][m], lo["model_tip"][m], atol=tol_q)
+    if eng.features & FEAT_TIP_FORCE:  # Leg::calculateTipForce low-pass state (N; forces here are O(1) N)
+        np.testing.assert_allclose(lg["tip_force"][m], lo["tip_force"][m], atol=1e-5)
+    np.testing.assert_allclose(lg["admittance"][m], lo["admittance"][m], atol=1e-8)
     if eng.features & FEAT_ODOMETRY:  # odometry_ideal_ integrates the desired velocities only: independent of the IK path
         np.testing.assert_allclose(eng.odometry()[m], ob.odometry()[m], atol=1e-11)
     if eng.params.admittance_control:  # published virtual stiffness: a function of step states and walker tips
