@@ -668,3 +668,60 @@ def test_init_chain_on_device_matches_host():
         for name in ("walkspace", "max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration"):
             np.testing.assert_allclose(np.array(getattr(t, name)), np.array(getattr(h, name)), rtol=1e-8, atol=1e-8, err_msg=name)
     assert np.mean(tight) > 0.8
+
+
+def test_every_device_pointer_entry_point(Engine):
+    """All setters and getters of the C ABI with on_device = 1 (torch tensors as the device buffers) against an engine fed
+    through the host-pointer forms: same bits out."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    p = default_hexapod_params("wave")
+    p.admittance_control, p.imu_posing = 1, 1
+    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    n = 70
+    inp = make_inputs(p, n, 97, imu=True, force=2.0)
+    rng = np.random.default_rng(97)
+    inp["tv"], inp["rv"] = rng.uniform(-1, 1, size=(n, 3)), rng.uniform(-1, 1, size=(n, 3))
+    inp["reset"] = rng.choice([0, 1, 2, 3, 4], size=n).astype(np.int32)
+    a = Engine(p, n, stream=torch.cuda.current_stream().cuda_stream)
+    b = Engine(p, n)
+    apply(b, inp)
+    L = a.L
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in inp.items()}
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    assert L.shc_engine_set_velocity(a.h, ptr(dev["lin"]), ptr(dev["ang"]), 1) == 0
+    assert L.shc_engine_set_imu(a.h, ptr(dev["imu_q"]), ptr(dev["gyro"]), 1) == 0
+    assert L.shc_engine_set_tip_force(a.h, ptr(dev["force"]), 1) == 0
+    assert L.shc_engine_set_joint_effort(a.h, ptr(dev["effort"]), 1) == 0
+    assert L.shc_engine_set_pose_input(a.h, ptr(dev["tv"]), ptr(dev["rv"]), 1) == 0
+    assert L.shc_engine_set_pose_reset_mode(a.h, ptr(dev["reset"]), 1) == 0
+    a.step(90)
+    b.step(90)
+    out = {k: torch.empty(n * 6 * 3, dtype=torch.float64, device="cuda") for k in ("walker", "poser", "model", "tf", "adm")}
+    status = torch.empty(n * 6, dtype=torch.int32, device="cuda")
+    pose = torch.empty(n * 7, dtype=torch.float64, device="cuda")
+    vel = torch.empty(n * 3, dtype=torch.float64, device="cuda")
+    ws = torch.empty(n, dtype=torch.int32, device="cuda")
+    q = torch.empty(n * 18, dtype=torch.float64, device="cuda")
+    qd = torch.empty(n * 18, dtype=torch.float64, device="cuda")
+    odo = torch.empty(n * 7, dtype=torch.float64, device="cuda")
+    stiff = torch.empty(n * 6, dtype=torch.float64, device="cuda")
+    assert L.shc_engine_get_joint_state(a.h, ptr(q), ptr(qd), 1) == 0
+    assert L.shc_engine_get_leg_state(a.h, ptr(out["walker"]), ptr(out["poser"]), ptr(out["model"]), ptr(out["tf"]), ptr(out["adm"]),
+                                      ptr(status), 1) == 0
+    assert L.shc_engine_get_body_state(a.h, ptr(pose), ptr(vel), ptr(ws), 1) == 0
+    assert L.shc_engine_get_odometry(a.h, ptr(odo), 1) == 0
+    assert L.shc_engine_get_virtual_stiffness(a.h, ptr(stiff), 1) == 0
+    torch.cuda.synchronize()
+    b.synchronize()
+    qb, qdb = b.joints()
+    lb = b.leg_state()
+    pb, vb, wb = b.body_state()
+    assert np.array_equal(q.cpu().numpy().reshape(n, 18), qb) and np.array_equal(qd.cpu().numpy().reshape(n, 18), qdb)
+    for k, name in (("walker", "walker_tip"), ("poser", "poser_tip"), ("model", "model_tip"), ("tf", "tip_force"), ("adm", "admittance")):
+        assert np.array_equal(out[k].cpu().numpy().reshape(n, 6, 3), lb[name]), name
+    assert np.array_equal(status.cpu().numpy().reshape(n, 6), lb["leg_status"])
+    assert np.array_equal(pose.cpu().numpy().reshape(n, 7), pb) and np.array_equal(vel.cpu().numpy().reshape(n, 3), vb)
+    assert np.array_equal(ws.cpu().numpy(), wb)
+    assert np.array_equal(odo.cpu().numpy().reshape(n, 7), b.odometry())
+    assert np.array_equal(stiff.cpu().numpy().reshape(n, 6), b.virtual_stiffness())
