@@ -725,3 +725,33 @@ def test_every_device_pointer_entry_point(Engine):
     assert np.array_equal(ws.cpu().numpy(), wb)
     assert np.array_equal(odo.cpu().numpy().reshape(n, 7), b.odometry())
     assert np.array_equal(stiff.cpu().numpy().reshape(n, 6), b.virtual_stiffness())
+
+
+def test_error_codes(Engine):
+    """The ABI reports misuse through status codes + shc_last_error (the reference has no error returns on this path)."""
+    import ctypes as C
+    from syropod_highlevel_controller_amd import engine
+    from syropod_highlevel_controller_amd.params import LegStateMsg
+    p = default_hexapod_params("tripod")
+    eng = Engine(p, 12)
+    L = eng.L
+    INVALID, UNSUPPORTED = 1, 4
+    assert L.shc_engine_step(None, 1) == INVALID
+    assert L.shc_engine_step(eng.h, 0) == 0                       # nothing to do is not an error
+    msgs = (LegStateMsg * 6)()
+    assert L.shc_engine_read_leg_state_msg(eng.h, 12, msgs) == INVALID and b"instance" in L.shc_last_error()
+    assert L.shc_engine_read_leg_state_msg(eng.h, -1, msgs) == INVALID
+    assert L.shc_engine_get_virtual_stiffness(eng.h, None, 0) == UNSUPPORTED   # admittance_control is off
+    bad = default_hexapod_params("tripod")
+    bad.leg_dof[3] = 4
+    h = C.c_void_p()
+    assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED and b"DOF" in L.shc_last_error()
+    bad = default_hexapod_params("tripod")
+    bad.gravity_aligned_tips = 1
+    assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED
+    assert L.shc_engine_create(C.byref(p), 0, 0, None, C.byref(h)) == INVALID
+    assert L.shc_engine_create(C.byref(p), 4, 99, None, C.byref(h)) == INVALID       # no such device
+    t = engine.Tables()
+    assert L.shc_engine_create_with_tables(C.byref(p), C.byref(t), 4, 0, None, C.byref(h)) == INVALID  # tables never generated
+    still = C.c_int64(-1)
+    assert L.shc_engine_change_gait(eng.h, None, C.byref(still)) == INVALID
