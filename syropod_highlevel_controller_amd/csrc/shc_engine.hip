@@ -643,7 +643,8 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
     if (p->leg_dof[l] != nj) return fail(SHC_ERR_UNSUPPORTED, "all legs of one engine must share one DOF (bin mixed morphologies)");
   if (nj < 3 || nj > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
   if (p->rough_terrain_mode) return fail(SHC_ERR_UNSUPPORTED, "rough_terrain_mode is outside the accelerated path");
-  if (p->gravity_aligned_tips) return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips (tip-rotation constrained IK) is outside the accelerated path");
+  if (p->gravity_aligned_tips && nj <= 3)
+    return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips with <= 3 DOF legs is the reference's experimental tip-align pose (outside the accelerated path)");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
   if (p->time_delta <= 0 || p->step_frequency <= 0) return fail(SHC_ERR_INVALID_ARG, "time_delta / step_frequency must be > 0");
   *L = p->leg_count;
@@ -915,6 +916,8 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   int L, NJ;
   int rc = validate_params(params, &L, &NJ);
   if (rc != SHC_OK) return rc;
+  if (params->gravity_aligned_tips) // the init chain handles it (rotation-constrained start-up); the cycle kernel does not yet
+    return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips: rotation-constrained IK is not in the cycle kernel yet");
   if (!out || n_instances < 1) return fail(SHC_ERR_INVALID_ARG, "n_instances must be >= 1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)

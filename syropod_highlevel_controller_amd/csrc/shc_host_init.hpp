@@ -145,26 +145,47 @@ struct HostLeg {
     }
     fk();
   }
-  // Leg::applyIK(simulation = true) towards `desired` (model.cpp:861-941); returns the ik result
-  SHC_HDI double ik(V3 desired, const shc_params &p) {
+  // Leg::applyIK(simulation = true) towards `desired` (model.cpp:861-941); returns the ik result.  `desired_dir` (robot
+  // frame, unit) is the x axis of the desired tip rotation when has_rotation (rotation-constrained IK, :880-900).
+  SHC_HDI double ik(V3 desired, const shc_params &p, bool has_rotation = false, V3 desired_dir = V3{1, 0, 0}) {
+    const V3 current_dir = ch.xe; // leg-frame direction of the tip BEFORE this call's updates (the reference reads it first, :866)
     double dq[NJ];
     ik_step<NJ, true>(lc, ch, q, qd, desired, dq); // IEEE division on host and device alike
+    if (has_rotation) {
+      update_joints<NJ>(lc, dq, p.time_delta, 1.0 / p.time_delta, false, p.clamp_joint_positions != 0, q, qd); // simulation = true (:883)
+      fk();
+      V3 lin[NJ];
+      jacobian_columns<NJ>(ch, lin);
+      ik_step_rotation<NJ, true>(lc, ch, lin, q, qd, tip_rotation_delta(current_dir, base_rotate_inv(lc, desired_dir)), dq);
+    }
     double prox = update_joints<NJ>(lc, dq, p.time_delta, 1.0 / p.time_delta, false, p.clamp_joint_positions != 0, q, qd);
     fk();
     V3 e = tip - desired;
-    if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) return 0.0;
-    return prox;
+    double result = prox;
+    if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) result = 0.0;
+    if (has_rotation && result == 0.0) return ik(desired, p); // retry with the rotation unconstrained (:932-936)
+    return result;
   }
 };
 
 // PoseController::directStartup's simulated solve for one leg: LegPoser::stepToPosition (lift 0, time_to_start)
 // towards the default tip pose with the body easing to `body` + one DLS step per iteration.
+// identity tip direction of a gravity-aligned leg: x axis of FromTwoVectors(x, -z) (walk_controller.cpp:37-41)
+SHC_HDI V3 gravity_aligned_direction() {
+  return rotate(correct_rotation(from_two_vectors(V3{1, 0, 0}, V3{-0.0, -0.0, -1.0}), quat_identity()), V3{1, 0, 0});
+}
+SHC_HDI bool tips_rotation_constrained(const shc_params &p, int nj) { return nj > 3 && p.gravity_aligned_tips != 0; }
+
 template <int NJ>
 SHC_HDI void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip, const Pose &body) {
   leg.reset_to_default();
   V3 origin = leg.tip;
   V3 delta = origin - inverse_transform_vector(body, default_tip);
-  if (!(norm(delta) > kTipTolerance)) return; // already there (pose_controller.cpp:1603-1608)
+  const bool rot = tips_rotation_constrained(p, NJ);
+  const V3 origin_dir = base_rotate(leg.lc, leg.ch.xe), target_dir = gravity_aligned_direction();
+  bool transition_rotation = false; // pose_controller.cpp:1594-1601
+  if (rot) transition_rotation = norm(angle_axis_vector(from_two_vectors(origin_dir, target_dir))) > kJointTolerance;
+  if (!(norm(delta) > kTipTolerance) && !transition_rotation) return; // already there (pose_controller.cpp:1603-1608)
   int num = imax(1, round_to_int(p.time_to_start / p.time_delta));
   double dt = 1.0 / num;
   int half = num / 2;
@@ -176,7 +197,9 @@ SHC_HDI void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip
     Pose dp = interpolate_pose(pose_identity(), smooth_step(ratio), body);
     int sic = (it + (num - 1)) % num + 1;
     V3 np = sic <= half ? quartic_bezier(prim, sic * dt * 2.0) : quartic_bezier(sec, (sic - half) * dt * 2.0);
-    leg.ik(inverse_transform_vector(dp, np), p);
+    // tip direction eased from the current one to the target (:1633-1640); the pose interpolation moves positions only
+    V3 dir = rot ? normalized(lerp3(origin_dir, target_dir, smooth_step(ratio))) : V3{1, 0, 0};
+    leg.ik(inverse_transform_vector(dp, np), p, rot, dir);
   }
 }
 

@@ -145,7 +145,7 @@ SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double 
   V3 delta = base_rotate_inv(lc, desired - V3{lc.p1[0], lc.p1[1], lc.p1[2]}) - pe;
   // joint-limit cost gradient (model.cpp:759-790)
   double pg[NJ], vg[NJ];
-  double pcost = 0.0, vcost = 0.0;
+  double pcost = 0.0, vcost = 0.0; // (the rotation solve below repeats this block on the intermediate joint state)
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
     double e = (q[i] - lc.jcentre[i]) * lc.jw_range[i];
@@ -171,6 +171,42 @@ SHC_HD void ik_step_cols(const LC &lc, const V3 (&lin)[NJ], V3 pe, const double 
   }
   spd_solve<NJ, EXACT>(a, dq);
 }
+
+// The second solve of a rotation-constrained Leg::applyIK (model.cpp:880-900): delta has only its angular rows set
+// (axis * angle from the current to the desired tip direction, joint-1 frame) and the Jacobian its angular rows too
+// (joint axes).  Same push-through form as ik_step: dq = (J^T J + l^2 I)^-1 (J_w^T d_w + l^2 g), J^T J = lin.lin + z.z.
+template <int NJ, bool EXACT = false, class LC>
+SHC_HD void ik_step_rotation(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[NJ], const double (&q)[NJ], const double (&qd)[NJ],
+                             V3 rot_delta, double (&dq)[NJ]) {
+  double pg[NJ], vg[NJ];
+  double pcost = 0.0, vcost = 0.0;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    double e = (q[i] - lc.jcentre[i]) * lc.jw_range[i];
+    pcost += e * e;
+    pg[i] = -e * lc.jw_range[i];
+    double v = qd[i] * lc.jw_vrange[i];
+    vcost += v * v;
+    vg[i] = -v * lc.jw_vrange[i];
+  }
+  double ps = fast_rsqrt<EXACT>(pcost), vs = fast_rsqrt<EXACT>(vcost);
+  ps = pcost == 0.0 ? 0.0 : ps;
+  vs = vcost == 0.0 ? 0.0 : vs;
+  const double l2 = kDls * kDls;
+  double a[NJ][NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + dot(c.z[i], c.z[j]);
+    a[i][i] += l2;
+    double g = 0.25 * (pg[i] * ps) + 0.75 * (vg[i] * vs);
+    dq[i] = dot(c.z[i], rot_delta) + l2 * g;
+  }
+  spd_solve<NJ, EXACT>(a, dq);
+}
+
+// axis * angle of the shortest rotation taking the current tip direction to the desired one (model.cpp:884-893)
+SHC_HD V3 tip_rotation_delta(V3 current_dir, V3 desired_dir) { return angle_axis_vector(normalized(from_two_vectors(current_dir, desired_dir))); }
 
 // Leg::updateJointPositions (model.cpp:799-857).  Returns the minimum limit proximity.
 template <int NJ, class LC>

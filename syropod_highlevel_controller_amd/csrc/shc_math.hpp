@@ -25,6 +25,7 @@ constexpr double kIkTolerance = 0.005;        // model.h:17
 constexpr double kDls = 0.02;                 // model.h:19
 constexpr double kJointLimitCostWeight = 0.1; // model.h:20
 constexpr double kTipTolerance = 0.01;        // pose_controller.h:19
+constexpr double kJointTolerance = 0.01;      // pose_controller.h:20
 constexpr double kGravity = -9.81;            // standard_includes.h:59
 
 struct V3 {
@@ -233,6 +234,17 @@ SHC_HD Quat from_two_vectors(V3 a, V3 b) {
   double invs = 1.0 / s;
   return Quat{s * 0.5, ax.x * invs, ax.y * invs, ax.z * invs};
 }
+// Eigen::AngleAxisd(q).axis() * angle() (AngleAxis = QuaternionBase; model.cpp:892-893)
+SHC_HD V3 angle_axis_vector(Quat q) {
+  double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+  if (n != 0.0) {
+    double angle = 2.0 * atan2(n, fabs(q.w));
+    if (q.w < 0.0) n = -n;
+    return V3{q.x / n * angle, q.y / n * angle, q.z / n * angle};
+  }
+  return V3{0, 0, 0}; // angle 0 about (1, 0, 0)
+}
+SHC_HD V3 lerp3(V3 a, V3 b, double c) { return b * c + a * (1.0 - c); } // interpolate() (standard_includes.h:143)
 SHC_HD Quat slerp(Quat a, double t, Quat b) { // QuaternionBase::slerp
   const double one = 1.0 - 2.220446049250313e-16;
   double d = dot(a, b);

@@ -17,6 +17,10 @@ def cases():
         yield f"hexapod-{g}", default_hexapod_params(g)
     yield "octopod-ripple-5dof", synthetic_octopod_params("ripple", 5, 8)
     yield "quadruped-tripod-4dof", synthetic_octopod_params("tripod", 4, 4)
+    for name, (dof, legs, gait) in (("octopod-5dof-gravity-aligned-tips", (5, 8, "ripple")), ("hexapod-4dof-gravity-aligned-tips", (4, 6, "tripod"))):
+        p = synthetic_octopod_params(gait, dof, legs)
+        p.gravity_aligned_tips = 1  # rotation-constrained start-up solve (model.cpp:880-900)
+        yield name, p
 
 
 @pytest.mark.parametrize("name,p", list(cases()), ids=[c[0] for c in cases()])
