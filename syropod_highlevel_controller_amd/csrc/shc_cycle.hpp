@@ -31,7 +31,7 @@ enum : int { PM_NONE = 0, PM_SWING = 1, PM_STANCE = 2, PM_STOP = 3 };
 
 // packed per-leg word
 constexpr int LW_ACP = 1 << 2, LW_CFS = 1 << 3, LW_PM_SHIFT = 4, LW_NEG = 1 << 6, LW_IKFAIL = 1 << 7, LW_PHASE_SHIFT = 8,
-              LW_PHASE_MASK = 0xFFFFF, LW_ZBV = 1 << 28, LW_ATT = 1 << 29;
+              LW_PHASE_MASK = 0xFFFFF, LW_ZBV = 1 << 28, LW_ATT = 1 << 29, LW_ROTDEF = 1 << 30; // ROTDEF: walker tip rotation defined
 // packed per-robot word: walk state [0:1], legs_at_correct_phase [2:5], legs_completed_first_step [6:9],
 // return_to_default_attempted [10], auto_posing_state [11:12]
 constexpr int RW_LACP_SHIFT = 2, RW_LCFS_SHIFT = 6, RW_RTDA = 1 << 10, RW_APS_SHIFT = 11;
@@ -44,7 +44,8 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
-enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31 };
+enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
+                  F_ROT = 1u << 30 }; // F_ROT (with F_DYN, > 3 DOF): gravity-aligned tips, rotation-constrained IK
 
 // Launch-uniform parameters (staged in LDS).
 struct CycleParams {
@@ -67,6 +68,8 @@ struct CycleParams {
   int32_t tip_force;  // SHC_FEAT_TIP_FORCE
   int32_t debug_skip; // development ablation mask (SHC_DEBUG_SKIP env): 1 pose, 2 limits, 4 stepper, 8 ik, 16 fk
   int32_t odometry;   // SHC_FEAT_ODOMETRY
+  int32_t gravity_aligned, pad1; // gravity_aligned_tips with > 3 DOF legs: rotation-constrained IK (model.cpp:880-900)
+  double target_dir[3];          // x axis of the identity tip rotation FromTwoVectors(x, -z) (walk_controller.cpp:37-41)
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
   double pid_p, pid_i, pid_d;
   // admittance: 30 RK4 steps of x'' = -F/m - c/m x' - k/m x collapsed into x <- M x + g F
@@ -104,7 +107,8 @@ struct Fields {
                        TF = ADM_END, TF_END = TF + 4,                  // tip_force_calculated_ filter state (tip_force)
                        FORCE_IN = TF_END, EFFORT_IN = FORCE_IN + 4,    // inputs
                        POSER_TIP = EFFORT_IN + NJE, MODEL_TIP = POSER_TIP + 4, ADM_DELTA = MODEL_TIP + 4, // outputs
-                       COUNT = ADM_DELTA + 4;
+                       // tip directions (x axis of LegStepper::origin_tip_pose_ / current_tip_pose_ rotations), gravity-aligned tips only
+                       ORG_DIR = ADM_DELTA + 4, CUR_DIR = ORG_DIR + 3, COUNT = CUR_DIR + 3;
   static_assert(CORE_END % 2 == 0 && SORG % 2 == 0 && COUNT % 2 == 0, "field groups must align to 16-byte planes");
 };
 // element index of field f of slot `slot` in the plane array (n_slots slots per plane)
@@ -230,7 +234,8 @@ struct LegRegs {
   V3 tip, tvel, targ, strd;
   double adm0, adm1;
   double stiff; // Leg::virtual_stiffness_ (published only; admittance feature)
-  V3 tf, tipx; // tip x axis (robot frame) of the current FK, kept only for Leg::setAdmittanceDelta
+  V3 tf, tipx; // tip x axis (robot frame) of the current FK: Leg::setAdmittanceDelta, origin of the tip-rotation blend
+  V3 org_dir, cur_dir; // tip directions of LegStepper::origin_tip_pose_ / current_tip_pose_ (gravity-aligned tips)
   int word;
 };
 
@@ -292,6 +297,10 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   const CycleParams &P = (&C.P)[zero];
   const LegConst<NJ> &lc = C.leg[leg + zero];
   const V3 UZ{0, 0, 1};
+  // gravity-aligned tips: only legs with more than 3 joints constrain the tip rotation (walk_controller.cpp:37, :1197);
+  // its own kernel specialisation (F_ROT), launched when the parameter is set
+  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
+  bool rot_def = (s.word & LW_ROTDEF) != 0;
 #ifdef SHC_TIMING
   const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
 #endif
@@ -878,7 +887,25 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       s.tip = s.tip + dpos;
       s.tvel = dpos * P.inv_dt; // delta_pos / time_delta (:1135, :1176)
     }
-    // updateTipRotation (:1193-1234): tip rotations stay UNDEFINED on this path (<= 3 DOF, or gravity_aligned_tips off)
+    // ---- updateTipRotation (:1193-1234).  Without gravity-aligned tips every tip rotation stays UNDEFINED.  With them the
+    //      target is the constant identity rotation (x axis along -z); only the x axes of the rotations are ever used
+    //      downstream (poser, applyIK), so the state is kept as directions + a "defined" bit.
+    if (rot_on) {
+      const int pm0 = (s.word >> LW_PM_SHIFT) & 3; // swing / stance progress as the previous iteratePhase left them
+      const double sp = swing_progress_of(s.word, P);
+      const V3 target{P.target_dir[0], P.target_dir[1], P.target_dir[2]};
+      if (pm0 == PM_STANCE || pm0 == PM_STOP || sp >= 0.5) {
+        s.cur_dir = target; // correctRotation only flips the quaternion's sign
+        if (sp >= 0.5) {
+          const double c = smooth_step(fmin(1.0, 2.0 * (sp - 0.5)));
+          s.cur_dir = normalized(lerp3(s.org_dir, target, c));
+        }
+        rot_def = true;
+      } else {
+        s.org_dir = s.tipx; // leg_->getCurrentTipPose().rotation_: the FK tip rotation of the previous cycle
+        rot_def = false;
+      }
+    }
     // ---- iteratePhase (:871-897)
     my_phase = my_phase + 1 == P.period ? 0 : my_phase + 1; // (phase + 1) % period with phase in [0, period)
     if (my_state != SS_FORCE_STOP) {
@@ -935,12 +962,14 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       rb.put(R::ODOM + 3, ow * sh + oz * ch);
     }
   }
-  s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL)) |
-           my_state | (my_acp ? LW_ACP : 0) | (my_cfs ? LW_CFS : 0) | (my_pm << LW_PM_SHIFT) | (my_phase << LW_PHASE_SHIFT);
+  s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL | LW_ROTDEF)) |
+           my_state | (my_acp ? LW_ACP : 0) | (my_cfs ? LW_CFS : 0) | (my_pm << LW_PM_SHIFT) | (my_phase << LW_PHASE_SHIFT) |
+           (rot_def ? LW_ROTDEF : 0);
 
   SHC_PHASE_FENCE();
   SHC_TICK(8);
   // =============================================================== PoseController::updateStance (:110-141)
+  V3 desired_dir{1, 0, 0}; // x axis of the desired tip rotation (body frame) when rot_def
   {
     Pose bp = cp;
     if (FT::autop(P) && !FT::imu(P)) {
@@ -948,6 +977,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       bp = add_pose(bp, leg_auto);
     }
     out.poser_tip = (SHC_DBG(P) & 256) ? s.tip : inverse_transform_vector(bp, s.tip);
+    if (rot_on && rot_def) desired_dir = rotate(inverse(bp.r), s.cur_dir); // pose.rotation^-1 * walker tip rotation (:129-130)
   }
 
   SHC_PHASE_FENCE();
@@ -956,7 +986,40 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
     Chain<NJ> chain;
-    if (!(SHC_DBG(P) & 8)) {
+    if (rot_on) {
+      // Leg::applyIK with a (possibly) defined desired tip rotation (model.cpp:861-941): position solve; if constrained,
+      // integrate it without the velocity clamp, FK, solve for the rotation delta between the tip direction the leg had
+      // BEFORE this call (:866 is evaluated first) and the desired one; integrate, FK, check; on failure (5 mm deviation or
+      // a joint on its limit: proximity 0) retry unconstrained from the state reached.
+      const bool cv = uni(P.clamp_joint_velocities) != 0, cp_ = uni(P.clamp_joint_positions) != 0;
+      chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
+      const V3 current_dir = chain.xe;
+      double dq[NJ];
+      ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
+      V3 lin[NJ];
+      if (rot_def) {
+        update_joints<NJ>(lc, dq, P.dt, P.inv_dt, false, cp_, s.q, s.qd);
+        joint_sincos<NJ>(lc, s.q, s.sn, s.cs);
+        chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
+        jacobian_columns<NJ>(chain, lin);
+        ik_step_rotation<NJ>(lc, chain, lin, s.q, s.qd, tip_rotation_delta(current_dir, base_rotate_inv(lc, desired_dir)), dq);
+      }
+      double success = update_joints<NJ>(lc, dq, P.dt, P.inv_dt, cv, cp_, s.q, s.qd);
+      joint_sincos<NJ>(lc, s.q, s.sn, s.cs);
+      chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
+      {
+        V3 e = tip_robot_frame(lc, chain.pe) - desired;
+        if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) {
+          success = 0.0;
+          s.word |= LW_IKFAIL;
+        }
+      }
+      if (rot_def && success == 0.0) { // desired_tip_pose_.rotation_ = UNDEFINED_ROTATION; applyIK again (:932-936)
+        ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
+        update_joints<NJ>(lc, dq, P.dt, P.inv_dt, cv, cp_, s.q, s.qd);
+        joint_sincos<NJ>(lc, s.q, s.sn, s.cs);
+      }
+    } else if (!(SHC_DBG(P) & 8)) {
       double dq[NJ];
       if (LegRegs<NJ>::kKeepJacobian) {
         ik_step_cols<NJ>(lc, s.lin, s.pe, s.q, s.qd, desired, dq);
@@ -968,7 +1031,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     }
     SHC_PHASE_FENCE();
     SHC_TICK(10);
-    if (!(SHC_DBG(P) & 16)) joint_sincos<NJ>(lc, s.q, s.sn, s.cs); // Leg::applyFK (:904)
+    if (!(SHC_DBG(P) & 16) && !rot_on) joint_sincos<NJ>(lc, s.q, s.sn, s.cs); // Leg::applyFK (:904); the rotation path left sn / cs current
     if (!(SHC_DBG(P) & 512)) chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
     V3 lin[NJ];
     jacobian_columns<NJ>(chain, lin);
@@ -980,7 +1043,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     SHC_PHASE_FENCE();
     SHC_TICK(11);
     out.model_tip = (SHC_DBG(P) & 512) ? desired : tip_robot_frame(lc, chain.pe);
-    if (FT::adm(P)) s.tipx = base_rotate(lc, chain.xe);
+    if (FT::adm(P) || rot_on) s.tipx = base_rotate(lc, chain.xe);
     V3 e = out.model_tip - desired;
     if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) s.word |= LW_IKFAIL; // :916-929
     if (FT::tipf(P)) { // Leg::calculateTipForce (:667-708)

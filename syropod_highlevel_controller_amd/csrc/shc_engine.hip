@@ -45,7 +45,7 @@ struct LegPlanes {
 template <int NJ>
 struct LegLoad {
   double flat[Fields<NJ>::CORE_END];
-  double2 adm, tf0, tf1, stiff;
+  double2 adm, tf0, tf1, stiff, rot0, rot1, rot2;
   int word;
 };
 template <int NJ, unsigned F>
@@ -60,7 +60,12 @@ __device__ __forceinline__ void load_leg_issue(LegLoad<NJ> &ll, const DevState &
     ll.flat[2 * p + 1] = v.y;
   }
   ll.word = st.legi[slot];
-  ll.adm = ll.tf0 = ll.tf1 = ll.stiff = double2{0.0, 0.0};
+  ll.adm = ll.tf0 = ll.tf1 = ll.stiff = ll.rot0 = ll.rot1 = ll.rot2 = double2{0.0, 0.0};
+  if (NJ > 3 && (F & F_ROT)) { // tip directions of the stepper's origin / current tip rotations
+    ll.rot0 = ld.load(FD::ORG_DIR / 2);
+    ll.rot1 = ld.load(FD::ORG_DIR / 2 + 1);
+    ll.rot2 = ld.load(FD::ORG_DIR / 2 + 2);
+  }
   if (FT::adm(P)) {
     ll.adm = ld.load(FD::ADM / 2);
     if (P.dynamic_stiffness) ll.stiff = ld.load(FD::ADM_DELTA / 2 + 1); // virtual_stiffness_ persists while STOPPED
@@ -92,6 +97,8 @@ __device__ __forceinline__ void load_leg_finish(LegRegs<NJ> &s, const Park &pk, 
   s.adm1 = ll.adm.y;
   s.stiff = ll.stiff.y;
   s.tf = V3{ll.tf0.x, ll.tf0.y, ll.tf1.x};
+  s.org_dir = V3{ll.rot0.x, ll.rot0.y, ll.rot1.x};
+  s.cur_dir = V3{ll.rot1.y, ll.rot2.x, ll.rot2.y};
 }
 
 template <int NJ, unsigned F>
@@ -137,6 +144,12 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   if (FT::autop(P) && !FT::imu(P)) {
     ld.store(FD::POSER_TIP / 2, double2{out.poser_tip.x, out.poser_tip.y});
     ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
+  }
+  if (NJ > 3 && (F & F_ROT)) {
+    static_assert(FD::ORG_DIR % 2 == 0 && FD::CUR_DIR == FD::ORG_DIR + 3, "tip direction planes");
+    ld.store(FD::ORG_DIR / 2, double2{s.org_dir.x, s.org_dir.y});
+    ld.store(FD::ORG_DIR / 2 + 1, double2{s.org_dir.z, s.cur_dir.x});
+    ld.store(FD::ORG_DIR / 2 + 2, double2{s.cur_dir.y, s.cur_dir.z});
   }
   st.legi[slot] = s.word;
 }
@@ -279,14 +292,15 @@ __global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevS
   Group<L> g{grp * L};
   RobTile<RPW> rb{tile, tile_i, grp};
   s.tipx = V3{1, 0, 0};
-  if (FT::adm(P) || LegRegs<NJ>::kKeepJacobian) {
+  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
+  if (FT::adm(P) || LegRegs<NJ>::kKeepJacobian || rot_on) {
     Chain<NJ> ch;
     chain_from_sincos<NJ>(C.leg[leg], s.sn, s.cs, ch);
     if (LegRegs<NJ>::kKeepJacobian) {
       jacobian_columns<NJ>(ch, s.lin);
       s.pe = ch.pe;
     }
-    if (FT::adm(P)) s.tipx = base_rotate(C.leg[leg], ch.xe);
+    if (FT::adm(P) || rot_on) s.tipx = base_rotate(C.leg[leg], ch.xe);
   }
   LegOut out;
   SHC_TICK(1);
@@ -602,6 +616,13 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.force_normal_touchdown = p.force_normal_touchdown;
   c.tip_force = (features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort ? 1 : 0;
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
+  c.gravity_aligned = hostinit::tips_rotation_constrained(p, p.leg_dof[0]) ? 1 : 0;
+  {
+    V3 d = hostinit::gravity_aligned_direction();
+    c.target_dir[0] = d.x;
+    c.target_dir[1] = d.y;
+    c.target_dir[2] = d.z;
+  }
   if (const char *dbg = getenv("SHC_DEBUG_SKIP")) c.debug_skip = atoi(dbg);
   for (int i = 0; i < 3; ++i) {
     c.max_translation[i] = p.max_translation[i];
@@ -850,6 +871,13 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
     t[F::MODEL_TIP + 2] = tip.z;
     // step_state STANCE, phase 0, progress "none" (walk_controller.h:493-501)
     legw[l] = SS_STANCE | (PM_NONE << LW_PM_SHIFT);
+    if (hostinit::tips_rotation_constrained(e->params, NJ)) { // current / origin tip poses start at the identity tip pose (:800-803)
+      V3 d = hostinit::gravity_aligned_direction();
+      t[F::ORG_DIR] = t[F::CUR_DIR] = d.x;
+      t[F::ORG_DIR + 1] = t[F::CUR_DIR + 1] = d.y;
+      t[F::ORG_DIR + 2] = t[F::CUR_DIR + 2] = d.z;
+      legw[l] |= LW_ROTDEF;
+    }
   }
   robt.assign(R::COUNT, 0.0);
   robt[R::PNORM + 2] = 1.0;
@@ -916,8 +944,6 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   int L, NJ;
   int rc = validate_params(params, &L, &NJ);
   if (rc != SHC_OK) return rc;
-  if (params->gravity_aligned_tips) // the init chain handles it (rotation-constrained start-up); the cycle kernel does not yet
-    return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips: rotation-constrained IK is not in the cycle kernel yet");
   if (!out || n_instances < 1) return fail(SHC_ERR_INVALID_ARG, "n_instances must be >= 1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -1120,6 +1146,12 @@ static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cyc
   const CycleParams &c = e->cp;
   unsigned f = (c.manual_posing ? F_MANUAL : 0) | (c.auto_posing ? F_AUTO : 0) | (c.inclination_posing ? F_INCL : 0) |
                (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0) | (c.odometry ? F_ODOM : 0);
+  if constexpr (NJ > 3) {
+    if (c.gravity_aligned) { // gravity-aligned tips: the generic kernel with the tip-rotation logic compiled in
+      launch_cycle<L, NJ, F_DYN | F_ROT>(e, grid, block, n_cycles);
+      return;
+    }
+  }
   if constexpr (SPEC) {
     constexpr unsigned C2 = F_MANUAL | F_ODOM, C3 = F_MANUAL | F_IMU | F_ADM | F_ODOM; // BASELINE.json configs 2/4 and 3
     if (specialised) switch (f) {

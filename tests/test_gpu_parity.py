@@ -200,6 +200,35 @@ def test_config5_interleaved_fleet(Engine):
     fleet.close()
 
 
+@pytest.mark.parametrize("dof,legs,gait", [(5, 8, "ripple"), (4, 6, "tripod"), (5, 4, "amble")])
+def test_gravity_aligned_tips_rotation_constrained_ik(Engine, dof, legs, gait):
+    """gravity_aligned_tips with > 3 DOF legs (SURVEY rows a7 / a18): LegStepper::updateTipRotation blends the tip's x axis
+    towards -z, PoseController::updateStance carries it into the body frame and Leg::applyIK solves position, then
+    rotation (two joint integrations per cycle), retrying unconstrained on failure.  The rotation constraint removes the
+    redundant chain's null-space chatter, so the bar holds for every instance without a twin."""
+    p = synthetic_octopod_params(gait, dof, legs)
+    p.gravity_aligned_tips = 1
+    n = 48
+    inp = make_inputs(p, n, 300 + dof * 10 + legs, zero_every=7)
+    eng, ob, worst = run_pair(Engine, p, n, inp, [1, 1, 1, 47, 100, 150, 200])
+    assert worst < 1e-9
+    zero = {"lin": np.zeros((n, 2)), "ang": np.zeros(n)}
+    for o in (eng, ob):  # stop and restart: FORCE_STOP / FORCE_STANCE legs keep stale progress values
+        o.set_velocity(zero["lin"], zero["ang"])
+    for k in (1, 150, 250):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        compare(eng, ob)
+    for o in (eng, ob):
+        o.set_velocity(-inp["lin"], inp["ang"])
+    for k in (1, 1, 200):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        compare(eng, ob)
+
+
 # ------------------------------------------------------------------------------------------------ features
 def test_auto_posing(Engine):
     for gait in ("tripod", "ripple"):
