@@ -986,6 +986,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
     Chain<NJ> chain;
+    bool retried = false; // the unconstrained retry is a nested applyIK: calculateTipForce then runs twice (:938 in both frames)
     if (rot_on) {
       // Leg::applyIK with a (possibly) defined desired tip rotation (model.cpp:861-941): position solve; if constrained,
       // integrate it without the velocity clamp, FK, solve for the rotation delta between the tip direction the leg had
@@ -1015,6 +1016,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         }
       }
       if (rot_def && success == 0.0) { // desired_tip_pose_.rotation_ = UNDEFINED_ROTATION; applyIK again (:932-936)
+        retried = true;
         ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
         update_joints<NJ>(lc, dq, P.dt, P.inv_dt, cv, cp_, s.q, s.qd);
         joint_sincos<NJ>(lc, s.q, s.sn, s.cs);
@@ -1056,6 +1058,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       }
       V3 raw = tip_force_cols<NJ>(lc, chain, lin, effort);
       s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
+      if (rot_on && retried) s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
     }
   }
   SHC_TICK(12);

@@ -310,7 +310,7 @@ def test_start_stop_start_sequence(Engine, span):
         compare(eng, ob)
 
 
-@pytest.mark.parametrize("gait,seed", [("tripod", 101), ("ripple", 102), ("amble", 103), ("tripod", 104), ("wave", 105), ("ripple", 106)])
+@pytest.mark.parametrize("gait,seed", [("tripod", 101), ("ripple", 102), ("amble", 103), ("tripod", 104), ("wave", 105), ("ripple", 106), ("ripple", 107)])
 def test_soak_random_command_schedule(Engine, gait, seed):
     """1 500 cycles with the commands changing every few dozen cycles: new velocities (a third of them zero, so robots
     stop and restart at arbitrary phases), manual pose inputs and pose-reset modes, single-cycle and fused launches mixed.
@@ -324,8 +324,9 @@ def test_soak_random_command_schedule(Engine, gait, seed):
     if seed == 105:  # configs[2] features: admittance from measured tip forces + IMU posing, inputs changing too
         p.admittance_control, p.imu_posing = 1, 1
         p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
-    if seed == 106:  # configs[3] morphology
+    if seed in (106, 107):  # configs[3] morphology; 107: with gravity-aligned tips (rotation-constrained IK under body posing)
         p = synthetic_octopod_params(gait, 5, 8)
+        p.gravity_aligned_tips = 1 if seed == 107 else 0
     n = 64
     L, D = p.leg_count, p.leg_dof[0]
     rng = np.random.default_rng(seed)
