@@ -189,7 +189,7 @@ __device__ __forceinline__ void store_rob_fields(const double *tile, double *gti
 
 // One launch = n_cycles control cycles of every robot; per-leg state stays in registers, per-robot state in LDS.
 template <int L, int NJ, unsigned F>
-__global__ void __launch_bounds__(256, SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles) {
+__global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles) {
   using R = RobotFields;
   using FT = Feat<F>;
   constexpr int RPW = 64 / L; // robots per wavefront
