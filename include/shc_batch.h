@@ -278,21 +278,26 @@ int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness, int on_de
  * ROS message surface.  Numeric payload of syropod_highlevel_controller/LegState.msg as
  * StateController::publishLegState fills it (msg/LegState.msg; state_controller.cpp:809-893), one record per leg of ONE
  * instance: the node copies the fields into its message and adds stamps, frame ids and the leg name.
- * Not provided (the node keeps computing them): actual_tip_pose (FK of the MEASURED joint positions, :839, an input the
- * engine never sees), model_tip_velocity (:845-849) and the per-leg auto_pose (:877-880).  Tip orientations are the
- * reference's UNDEFINED rotation (0,0,0,0) on the accelerated path (<= 3 DOF or gravity_aligned_tips off).
+ * Not provided (the node keeps computing it): actual_tip_pose (FK of the MEASURED joint positions, :839, an input the
+ * engine never sees).  Tip orientations are not part of the payload (UNDEFINED (0,0,0,0) unless gravity_aligned_tips).
  */
 typedef struct shc_leg_state_msg {
   double walker_tip_position[3]; /* walker_tip_pose.pose.position   :822-824 (frame walk_plane) */
   double target_tip_position[3]; /* target_tip_pose.pose.position   :826-828 */
   double poser_tip_position[3];  /* poser_tip_pose.pose.position    :830-832 (frame base_link) */
   double model_tip_position[3];  /* model_tip_pose.pose.position    :834-836 */
+  double model_tip_velocity[3];  /* model_tip_velocity.twist.linear :845-849: always 0 - publishLegState calls applyFK() on
+                                    unchanged joints just before (:840), which resets Leg::current_tip_velocity_ to
+                                    (tip - tip) / dt (model.cpp:980) */
   double joint_positions[SHC_MAX_JOINTS];  /* Joint::desired_position_ :854 */
   double joint_velocities[SHC_MAX_JOINTS]; /* Joint::desired_velocity_ :855 */
   double joint_efforts[SHC_MAX_JOINTS];    /* Joint::desired_effort_   :856 (never assigned on this path: 0) */
   double stance_progress, swing_progress;  /* :860-861, -1 when not in that state (walk_controller.cpp:871-897) */
   double time_to_swing_end;                /* :862-874 */
   double pose_delta[7];                    /* calculateOdometry(time_to_swing_end) :875: x,y,z,qw,qx,qy,qz */
+  double auto_pose[7];                     /* LegPoser::auto_pose_ :877-880 (x,y,z,qw,qx,qy,qz): the identity pose when
+                                              auto_posing is off (never assigned, pose_controller.cpp:1716); NaN with
+                                              auto_posing on (the per-leg pose is not kept after the cycle) */
   double tip_force[3];                     /* tip_force_calculated_ * force_gain :883-885 */
   double admittance_delta[3];              /* :886-888 */
   double virtual_stiffness;                /* :889 */

@@ -2431,6 +2431,11 @@ void orc_get_leg_state_msg(const orc_robot *r, shc_leg_state_msg *legs)
     orc_pose d = walker_calculate_odometry(r, time_to_swing_end);
     m->pose_delta[0] = d.p.x; m->pose_delta[1] = d.p.y; m->pose_delta[2] = d.p.z;
     m->pose_delta[3] = d.r.w; m->pose_delta[4] = d.r.x; m->pose_delta[5] = d.r.y; m->pose_delta[6] = d.r.z;
+    /* model_tip_velocity: publishLegState's own applyFK() on unchanged joints (:840) zeroes Leg::current_tip_velocity_ first */
+    m->model_tip_velocity[0] = m->model_tip_velocity[1] = m->model_tip_velocity[2] = 0.0;
+    m->auto_pose[0] = leg->poser.auto_pose.p.x; m->auto_pose[1] = leg->poser.auto_pose.p.y; m->auto_pose[2] = leg->poser.auto_pose.p.z;
+    m->auto_pose[3] = leg->poser.auto_pose.r.w; m->auto_pose[4] = leg->poser.auto_pose.r.x; m->auto_pose[5] = leg->poser.auto_pose.r.y;
+    m->auto_pose[6] = leg->poser.auto_pose.r.z;
     m->tip_force[0] = leg->tip_force_calculated.x * r->params.force_gain;
     m->tip_force[1] = leg->tip_force_calculated.y * r->params.force_gain;
     m->tip_force[2] = leg->tip_force_calculated.z * r->params.force_gain;

@@ -1408,6 +1408,8 @@ extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, sh
     m.pose_delta[2] = 0.0 * t;
     m.pose_delta[3] = cos(0.5 * (vw * t));
     m.pose_delta[6] = sin(0.5 * (vw * t));
+    // (model_tip_velocity stays 0: see the header.)  LegPoser::auto_pose_
+    for (int k = 0; k < 7; ++k) m.auto_pose[k] = e->params.auto_posing ? std::nan("") : (k == 3 ? 1.0 : 0.0);
   }
   return SHC_OK;
 }
