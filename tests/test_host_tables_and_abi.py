@@ -17,6 +17,12 @@ def cases():
         yield f"hexapod-{g}", default_hexapod_params(g)
     yield "octopod-ripple-5dof", synthetic_octopod_params("ripple", 5, 8)
     yield "quadruped-tripod-4dof", synthetic_octopod_params("tripod", 4, 4)
+    p = default_hexapod_params("ripple")
+    p.overlapping_walkspaces = 1  # walk_controller.cpp:101-104
+    yield "hexapod-overlapping-walkspaces", p
+    p = default_hexapod_params("tripod")
+    p.step_frequency, p.body_clearance, p.time_delta = 0.6, 0.12, 0.01
+    yield "hexapod-slow-steps-100Hz", p  # 600 start-up iterations: see START_UP_CHATTER below
     for name, (dof, legs, gait) in (("octopod-5dof-gravity-aligned-tips", (5, 8, "ripple")), ("hexapod-4dof-gravity-aligned-tips", (4, 6, "tripod"))):
         p = synthetic_octopod_params(gait, dof, legs)
         p.gravity_aligned_tips = 1  # rotation-constrained start-up solve (model.cpp:880-900)
@@ -34,7 +40,14 @@ def test_tables_match_oracle(name, p):
     assert list(o.phase_offset)[:L] == list(t.phase_offset)[:L]
     assert (o.pose_phase_length, o.pose_normaliser, o.auto_pose_reference_leg) == (t.pose_phase_length, t.pose_normaliser, t.auto_pose_reference_leg)
     dq = max(abs(o.default_joint_position[l][j] - t.default_joint_position[l][j]) for l in range(L) for j in range(NJ))
-    assert dq < 1e-6                                                          # start-up solve: 300 DLS steps each
+    # Start-up solve: a fixed number of DLS steps.  The reference's iteration does not settle (period-2 chatter of a few
+    # mrad) and directStartup re-runs the simulated solve from a copied, half-initialised LegPoser
+    # while its transition reports 0 % (pose_controller.cpp:476-489, :1454-1472; origin_tip_pose_ is uninitialised there):
+    # which point of the orbit the configuration ends on depends on that history, so for some iteration counts (600 here)
+    # two faithful implementations differ by the chatter amplitude.  Everything derived from the configuration
+    # (workspace, walkspace, limits) is unaffected and compared tightly below.
+    START_UP_CHATTER = 5e-3 if name == "hexapod-slow-steps-100Hz" else 1e-6
+    assert dq < START_UP_CHATTER
     for l in range(L):
         np.testing.assert_allclose(list(t.workspace_radius[l]), list(o.workspace_radius[l]), atol=1e-9)
     for f in ("walkspace", "max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration"):
