@@ -18,9 +18,13 @@ for k in range(48):
     p.step_frequency = [1.0, 0.8, 1.25][k % 3]
     plist.append(p)
 import time
+engine.generate_tables_batch(plist[:2])  # warm-up: code-object load
 t0 = time.perf_counter(); tables, status = engine.generate_tables_batch(plist); t1 = time.perf_counter()
 hs = [engine.generate_tables(p) for p in plist]; t2 = time.perf_counter()
 print(f"device batch {1e3*(t1-t0):.1f} ms, host {1e3*(t2-t1):.1f} ms for {len(plist)} morphologies")
+big = plist * 20
+t3 = time.perf_counter(); engine.generate_tables_batch(big); t4 = time.perf_counter()
+print(f"device batch of {len(big)}: {1e3*(t4-t3):.1f} ms ({1e3*(t4-t3)/len(big):.3f} ms each; host {1e3*(t2-t1)/len(plist):.3f} ms each)")
 for k, (p, t, h) in enumerate(zip(plist, tables, hs)):
     L, D = p.leg_count, p.leg_dof[0]
     dq = np.abs(np.array(t.default_joint_position)[:L, :D] - np.array(h.default_joint_position)[:L, :D]).max()

@@ -750,13 +750,14 @@ extern "C" int shc_generate_tables(const shc_params *params, shc_tables *out) {
 // ---- init chain on the device: the same host + device functions as shc_generate_tables, fanned out over morphologies
 template <int NJ>
 __global__ void init_chain_legs_kernel(const shc_params *params, shc_tables *tables, const int32_t *status, int64_t count) {
-  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  int64_t m = t / SHC_MAX_LEGS;
-  int l = int(t - m * SHC_MAX_LEGS);
+  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; // one thread per (morphology, leg, bearing)
+  int64_t m = t / (SHC_MAX_LEGS * 8);
+  int r = int(t - m * (SHC_MAX_LEGS * 8));
+  int l = r / 8, b = r % 8 + 1;
   if (m >= count || status[m] != SHC_OK) return;
   const shc_params &p = params[m];
   if (p.leg_dof[0] != NJ || l >= p.leg_count) return;
-  hostinit::generate_tables_leg<NJ>(p, l, tables[m]);
+  hostinit::generate_tables_leg<NJ>(p, l, tables[m], b, b);
 }
 __global__ void init_chain_head_kernel(const shc_params *params, shc_tables *tables, int32_t *status, int64_t count) {
   int64_t m = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -788,7 +789,7 @@ extern "C" int shc_generate_tables_batch(const shc_params *params, int64_t count
   HIP_TRY(hipMemcpy(d_p, params, size_t(count) * sizeof(shc_params), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(d_s, st.data(), size_t(count) * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(d_t, 0, size_t(count) * sizeof(shc_tables)));
-  const unsigned gm = (unsigned)((count + 63) / 64), gl = (unsigned)((count * SHC_MAX_LEGS + 63) / 64);
+  const unsigned gm = (unsigned)((count + 63) / 64), gl = (unsigned)((count * SHC_MAX_LEGS * 8 + 63) / 64);
   init_chain_head_kernel<<<dim3(gm), dim3(64)>>>(d_p, d_t, d_s, count);
   init_chain_legs_kernel<3><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);
   init_chain_legs_kernel<4><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);

@@ -205,13 +205,16 @@ SHC_HDI void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip
 
 // Leg::generateWorkspace, simple (single plane z = 0) workspace.  radius[b], b = bearing / 45.
 template <int NJ>
-SHC_HDI void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS]) {
+SHC_HDI void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS],
+                                int first_bearing = 1, int last_bearing = 8) { // bearing indices (x 45 degrees) searched by this call
   leg.reset_to_default();
   if (norm(identity_tip_body - leg.tip) > kIkTolerance) { // model.cpp:349-353
     for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = 0.0;
     return;
   }
-  for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = kMaxWorkspaceRadius;
+  const bool all = first_bearing == 1 && last_bearing == 8;
+  if (all)
+    for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = kMaxWorkspaceRadius;
   // track from the default-configuration tip to the identity tip position (model.cpp:397-404), then re-base defaults
   {
     int n = imax(1, round_to_int((kMaxWorkspaceRadius / kWorkspaceLayers) / kMaxPositionDelta));
@@ -223,7 +226,7 @@ SHC_HDI void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identi
     }
     for (int j = 0; j < NJ; ++j) leg.dflt[j] = leg.q[j]; // updateDefaultConfiguration (model.cpp:465)
   }
-  for (int bearing = kBearingStep; bearing <= 360; bearing += kBearingStep) {
+  for (int bearing = kBearingStep * first_bearing; bearing <= kBearingStep * last_bearing; bearing += kBearingStep) {
     leg.reset_to_default();
     int n = round_to_int(kMaxWorkspaceRadius / kMaxPositionDelta);
     V3 o = identity_tip_body, t = o;
@@ -235,7 +238,7 @@ SHC_HDI void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identi
     }
     radius[bearing / kBearingStep] = norm(leg.tip - identity_tip_body);
   }
-  radius[0] = radius[360 / kBearingStep];
+  if (last_bearing == 8) radius[0] = radius[360 / kBearingStep];
 }
 
 SHC_HDI V3 rot_z(double ang, V3 v) { // Eigen::AngleAxisd(ang, UnitZ) * v
@@ -363,8 +366,10 @@ SHC_HDI bool generate_tables_head(const shc_params &p, shc_tables &t) {
 }
 
 // Direct start-up solve + workspace search of ONE leg: the sequential part (thousands of DLS steps), independent per leg.
+// (the device batch splits the eight bearing searches of a leg over eight threads: each repeats the start-up solve and
+//  the re-basing prefix, ~350 steps, and searches one bearing, <= 500 steps)
 template <int NJ>
-SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t) {
+SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int first_bearing = 1, int last_bearing = 8) {
   // body pose during start-up and workspace generation: walk-plane pose (0, 0, body_clearance), no rotation
   Pose body{V3{0, 0, p.body_clearance}, quat_identity()};
   HostLeg<NJ> leg;
@@ -374,9 +379,9 @@ SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t) {
   startup_solve<NJ>(p, leg, default_tip, body);
   for (int j = 0; j < NJ; ++j) {
     leg.dflt[j] = leg.q[j]; // Model::updateDefaultConfiguration
-    t.default_joint_position[l][j] = leg.q[j];
+    if (first_bearing == 1) t.default_joint_position[l][j] = leg.q[j];
   }
-  generate_workspace<NJ>(p, leg, inverse_transform_vector(body, default_tip), t.workspace_radius[l]);
+  generate_workspace<NJ>(p, leg, inverse_transform_vector(body, default_tip), t.workspace_radius[l], first_bearing, last_bearing);
 }
 
 // Walkspace + velocity / acceleration limits from the legs' workspaces.
