@@ -240,6 +240,7 @@ def _variants():
             v("high-clearance-tall-steps", body_clearance=0.12, swing_height=0.04, swing_width=0.01),
             v("overlapping-walkspaces", overlapping_walkspaces=1),
             v("fast-steps", step_frequency=1.6),
+            v("no-posing-at-all", manual_posing=0),
             v("admittance-from-joint-efforts", admittance_control=1, use_joint_effort=1, force_gain=0.05),
             v("stiff-virtual-model", admittance_control=1, virtual_stiffness=30.0, virtual_mass=5.0, virtual_damping_ratio=1.2,
               force_gain=0.02, dynamic_stiffness=0)]
