@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH > $O/
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $BENCH > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq -- $BENCH > $O/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/pmc_lds -- $BENCH > $O/pmc_lds.log 2>&1
 CAL="python -c \"import sys; sys.path.insert(0,'$R'); from syropod_highlevel_controller_amd import engine; engine.lib().shc_debug_plane_copy(0, 64*1024*1024, 20)\""
 eval rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_cal_fetch -- $CAL > $O/cal_fetch.log 2>&1
 eval rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_cal_write -- $CAL > $O/cal_write.log 2>&1

@@ -71,6 +71,7 @@ if __name__ == "__main__":
     fetch = pmc(f"{prof}/pmc_fetch", KERNEL, out, "FETCH_SIZE pass").get("FETCH_SIZE")
     write = pmc(f"{prof}/pmc_write", KERNEL, out, "WRITE_SIZE pass").get("WRITE_SIZE")
     sq = pmc(f"{prof}/pmc_sq", KERNEL, out, "SQ pass")
+    lds = pmc(f"{prof}/pmc_lds", KERNEL, out, "LDS pass")
     cf = pmc(f"{prof}/pmc_cal_fetch", CAL_KERNEL, out, "calibration, FETCH_SIZE").get("FETCH_SIZE")
     cw = pmc(f"{prof}/pmc_cal_write", CAL_KERNEL, out, "calibration, WRITE_SIZE").get("WRITE_SIZE")
     out.write("\n== PMC calibration on a plane copy of known size (shc_debug_plane_copy: 64 Mi doubles = %d KiB read + %d KiB written per "
@@ -91,6 +92,10 @@ if __name__ == "__main__":
         if sq.get("SQ_WAVE_CYCLES"):
             out.write(f"VALU issue share of wave lifetime = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {sq.get('SQ_ACTIVE_INST_VALU', 0) / sq['SQ_WAVE_CYCLES']:.3f}; "
                       f"wave lifetime = 4 x SQ_WAVE_CYCLES / SQ_WAVES = {4 * sq['SQ_WAVE_CYCLES'] / w:.0f} cycles\n")
+    if lds.get("SQ_LDS_IDX_ACTIVE"):
+        out.write(f"LDS bank-conflict share of LDS-active cycles = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = "
+                  f"{lds.get('SQ_LDS_BANK_CONFLICT', 0) / lds['SQ_LDS_IDX_ACTIVE']:.3f}; LDS instructions per wave = "
+                  f"{lds.get('SQ_INSTS_LDS', 0) / max(lds.get('SQ_WAVES', 1), 1):.0f}\n")
     if dur:
         out.write(f"kernel duration (kernel_trace): mean {dur[0]:.0f} ns, median {dur[1]:.0f} ns over {dur[2]} launches\n")
     bl = f"{prof}/bench_line.json"
