@@ -78,8 +78,8 @@ def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
     np.testing.assert_allclose(vg[m], vo[m], atol=1e-12)
     np.testing.assert_allclose(lg["poser_tip"][m], lo["poser_tip"][m], atol=1e-8)
     np.testing.assert_allclose(lg["model_tip"][m], lo["model_tip"][m], atol=tol_q)
-    if eng.features & FEAT_TIP_FORCE:  # Leg::calculateTipForce low-pass state (N; forces here are O(1) N)
-        np.testing.assert_allclose(lg["tip_force"][m], lo["tip_force"][m], atol=1e-5)
+    if eng.features & FEAT_TIP_FORCE:  # Leg::calculateTipForce low-pass state (forces here are O(1) N)
+        np.testing.assert_allclose(lg["tip_force"][m], lo["tip_force"][m], atol=2e-4)  # ~100 N/rad x the 1e-6 rad joint bar
     np.testing.assert_allclose(lg["admittance"][m], lo["admittance"][m], atol=1e-8)
     if eng.features & FEAT_ODOMETRY:  # odometry_ideal_ integrates the desired velocities only: independent of the IK path
         np.testing.assert_allclose(eng.odometry()[m], ob.odometry()[m], atol=1e-11)
@@ -359,13 +359,22 @@ def test_soak_random_command_schedule(Engine, gait, seed):
     n = 64
     L, D = p.leg_count, p.leg_dof[0]
     rng = np.random.default_rng(seed)
-    eng, ob, tw = Engine(p, n), OracleBatch(p, n), OracleBatch(p, n)
+    # the twin is a robot whose link lengths differ by 1e-13 (relative): a perturbation that no input can switch off
+    # (a stopped robot whose manual pose was reset to exactly zero receives none through scaled commands)
+    import copy
+    p_twin = copy.deepcopy(p)
+    if seed != 106:  # (the redundant 8 x 5 chain without a rotation constraint already differs by ~5e-8 after its start-up
+        for l in range(L):  # solve for such a twin - DESIGN.md section 2 - so it keeps the command-scaling twin only)
+            for j in range(1, D + 1):
+                p_twin.link[l][j].r *= 1.0 + 1e-13
+    eng, ob, tw = Engine(p, n), OracleBatch(p, n), OracleBatch(p_twin, n)
     effort = rng.normal(0, 0.5, size=(n, L * D))
     for o in (eng, ob, tw):
         o.set_joint_effort(effort)
     done = 0
     well_posed = np.ones(n, dtype=bool)
-    while done < 1500:
+    total = int(os.environ.get("SHC_SOAK_CYCLES", "1500"))  # longer soaks on demand
+    while done < total:
         lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
         stop = rng.random(n) < 0.33
         lin[stop], ang[stop] = 0.0, 0.0
@@ -391,7 +400,7 @@ def test_soak_random_command_schedule(Engine, gait, seed):
             well_posed &= np.abs(ob.joints()[0] - tw.joints()[0]).max(axis=1) <= 1e-9
             compare(eng, ob, mask=well_posed)
             done += k
-    assert well_posed.mean() >= 0.8
+    assert well_posed.mean() >= (0.8 if total <= 1500 else 0.2)  # exclusion is sticky: long soaks lose more instances
 
 
 @pytest.mark.parametrize("auto", [False, True])
