@@ -258,6 +258,24 @@ def test_parameter_variants(Engine, kw):
     run_pair(Engine, p, n, inp, [1, 1, 58, 140, 200], twin=True, min_well_posed=0.7, oracle_tables=True)
 
 
+@pytest.mark.parametrize("mode", ["throttle", "real"])
+def test_out_of_range_velocity_commands(Engine, mode):
+    """Commands outside the unit disc / beyond +-1 (throttle) or beyond the walkspace limits (real): the clamps of
+    WalkController::updateWalk (walk_controller.cpp:451-487)."""
+    p = default_hexapod_params("tripod")
+    if mode == "real":
+        p.velocity_input_mode = VEL_REAL
+    n = 80
+    rng = np.random.default_rng(401)
+    inp = make_inputs(p, n, 401)
+    scale = 3.0 if mode == "throttle" else 0.5
+    inp["lin"] = rng.uniform(-1, 1, size=(n, 2)) * scale
+    inp["ang"] = rng.uniform(-1, 1, size=n) * scale
+    inp["lin"][::9] = 0.0  # pure rotation for some
+    inp["ang"][::7] = 0.0
+    run_pair(Engine, p, n, inp, [1, 1, 98, 150, 150], twin=True)
+
+
 # ------------------------------------------------------------------------------------------------ features
 def test_auto_posing(Engine):
     for gait in ("tripod", "ripple"):
