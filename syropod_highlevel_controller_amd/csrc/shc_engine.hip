@@ -895,6 +895,57 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
   robt[R::ODOM + 2] = 1.0; // identity (walk_controller.cpp:28): x, y, qw, qz
   robi.assign(R::I_COUNT, 0);
   robi[R::I_WORD] = WS_STOPPED | (PS_POSING_COMPLETE << RW_APS_SHIFT);
+  // Auto posing on its own clock (pose_frequency != -1): PoseController::updateCurrentPose already runs in every loop of
+  // the direct start-up (state_controller.cpp:165-167 with robot_state PACKED; one loop per transitionConfiguration step,
+  // pose_controller.cpp:1476-1567), and every call advances the pose phase counter and lets the posers latch on
+  // (start_check is unconditional without step-cycle sync, :1359-1371).  Replay those calls for the flags / counter the
+  // first RUNNING cycle starts from; the walk state is STOPPED throughout, hence auto_posing_state STOP_POSING.
+  if (e->params.auto_posing && e->params.pose_frequency != -1.0 && e->tables.pose_phase_length > 0) {
+    int calls = round_to_int(e->params.time_to_start / e->params.time_delta);
+    if (calls < 1) calls = 1;
+    const int len = e->tables.pose_phase_length, nrm = e->tables.pose_normaliser;
+    int phase_counter = 0, flags = 0;
+    for (int c = 0; c < calls; ++c) {
+      const int master_phase = phase_counter;
+      phase_counter = (phase_counter + 1) % len;
+      for (int i = 0; i < e->params.n_auto_posers && i < kMaxAutoPosers; ++i) {
+        int fl = (flags >> (4 * i)) & 15;
+        bool start_check = fl & 1, end1 = fl & 2, end2 = fl & 4, allow = fl & 8;
+        int phase = master_phase, sp = e->params.pose_phase_starts[i] * nrm, ep = e->params.pose_phase_ends[i] * nrm;
+        if (sp > ep) {
+          ep += len;
+          if (phase < sp) phase += len;
+        }
+        start_check = true;
+        end1 = end1 || phase == sp;          // auto_posing_state == STOP_POSING
+        end2 = end2 || (phase == ep && end1);
+        if (!allow && start_check) {
+          allow = true;
+          end1 = end2 = false;
+        }
+        flags = (flags & ~(15 << (4 * i))) | ((int(start_check) | int(end1) << 1 | int(end2) << 2 | int(allow) << 3) << (4 * i));
+      }
+    }
+    robi[R::I_POSE_PHASE] = phase_counter;
+    robi[R::I_APOSER] = flags;
+    // ... and each leg's negation latch (LegPoser::updateAutoPose :1716-1731; step state STANCE throughout the start-up)
+    for (int l = 0; l < e->L; ++l) {
+      int ns = e->params.pose_negation_phase_starts[l] * nrm, ne = e->params.pose_negation_phase_ends[l] * nrm;
+      if (ns == 0) ns = len;
+      if (ne == 0) ne = len;
+      bool neg = false;
+      for (int c = 0; c < calls; ++c) {
+        int sp = ns, ep = ne, np = c % len;
+        if (sp > ep) {
+          ep += len;
+          if (np < sp) np += len;
+        }
+        if (np == sp) neg = true;
+        if (np < sp || np > ep) neg = false;
+      }
+      if (neg) legw[l] |= LW_NEG;
+    }
+  }
 }
 
 static int init_state(shc_engine *e) {

@@ -276,6 +276,26 @@ def test_out_of_range_velocity_commands(Engine, mode):
     run_pair(Engine, p, n, inp, [1, 1, 98, 150, 150], twin=True)
 
 
+@pytest.mark.parametrize("gait", ["tripod", "wave"])
+def test_auto_posing_on_its_own_clock(Engine, gait):
+    """pose_frequency != -1: the auto-pose cycle runs on PoseController's own phase counter instead of the reference leg's
+    step phase (pose_controller.cpp:1150-1159), including start / stop handling of the posers."""
+    p = default_hexapod_params(gait)
+    p.auto_posing = 1
+    p.pose_frequency = 0.8
+    n = 50
+    inp = make_inputs(p, n, 433, zero_every=6)
+    eng, ob, _ = run_pair(Engine, p, n, inp, [1, 1, 98, 150], twin=True, oracle_tables=True)
+    zero = {"lin": np.zeros((n, 2)), "ang": np.zeros(n)}
+    for o in (eng, ob):
+        o.set_velocity(zero["lin"], zero["ang"])
+    for k in (1, 199, 200):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        compare(eng, ob)
+
+
 # ------------------------------------------------------------------------------------------------ features
 def test_auto_posing(Engine):
     for gait in ("tripod", "ripple"):
