@@ -310,6 +310,23 @@ def test_inclination_and_auto_posing_with_imu_input(Engine):
     run_pair(Engine, p, 40, make_inputs(p, 40, 11, imu=True), [100, 150], twin=True)
 
 
+@pytest.mark.parametrize("gait", ["tripod", "wave"])
+def test_auto_pose_amplitudes_negation_ratio_and_gravity(Engine, gait):
+    """Auto-pose parameters auto_pose.yaml leaves at zero: x / y / yaw amplitudes, the gravity amplitude (position along the
+    IMU-estimated gravity direction, Model::estimateGravity) and a non-zero negation transition ratio (smooth-stepped
+    per-leg negation, pose_controller.cpp:1740-1776)."""
+    p = default_hexapod_params(gait)
+    p.auto_posing = 1
+    for i in range(p.n_auto_posers):
+        p.x_amplitudes[i], p.y_amplitudes[i], p.yaw_amplitudes[i] = 0.004 * (-1) ** i, 0.003, 0.01 * (-1) ** i
+        if i % 2:
+            p.gravity_amplitudes[i] = 0.008
+    for l in range(6):
+        p.negation_transition_ratio[l] = 0.25
+    n = 40
+    run_pair(Engine, p, n, make_inputs(p, n, 449, imu=True, zero_every=9), [1, 1, 98, 150, 150], twin=True)
+
+
 def test_manual_pose_inputs_and_reset_modes(Engine):
     p = default_hexapod_params("tripod")
     n = 48
