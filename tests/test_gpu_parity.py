@@ -167,6 +167,17 @@ def test_config5_mixed_morphologies_binned(Engine):
         run_pair(Engine, p, 33, make_inputs(p, 33, legs * 10 + dof), [40, 80, 80], twin=True, min_well_posed=0.5)
 
 
+@pytest.mark.parametrize("legs,dof,gait", [(3, 3, "wave"), (5, 3, "ripple"), (7, 3, "wave"), (8, 4, "ripple"), (4, 5, "amble"),
+                                           (8, 3, "tripod"), (6, 5, "wave")])
+def test_every_other_kernel_instantiation(Engine, legs, dof, gait):
+    """The (legs, dof) kernels not covered by the BASELINE configurations: every instantiated specialisation runs against
+    the oracle (3 - 8 legs x 3 - 5 joints, lanes per group 3 ... 8, 21 ... 8 robots per wavefront)."""
+    p = synthetic_octopod_params(gait, dof, legs)
+    n = 45
+    run_pair(Engine, p, n, make_inputs(p, n, 500 + legs * 10 + dof, zero_every=8), [1, 1, 58, 120, 120], twin=True,
+             min_well_posed=0.5)
+
+
 def test_config5_interleaved_fleet(Engine):
     """configs[4], interleaved variant: morphology = instance id mod 5.  The fleet bins the instances (one engine and one
     HIP stream per bin) and hands results back in the caller's instance order; every instance must match the oracle of
