@@ -338,6 +338,29 @@ def test_auto_pose_amplitudes_negation_ratio_and_gravity(Engine, gait):
     run_pair(Engine, p, n, make_inputs(p, n, 449, imu=True, zero_every=9), [1, 1, 98, 150, 150], twin=True)
 
 
+def test_custom_gait_and_saturating_pose_limits(Engine):
+    """A gait that is not in gait.yaml (stance 5 / swing 3 / offset 2) together with tight manual-pose limits, slow pose
+    velocities, strong IMU PID gains and IMU tilts beyond max_rotation (the correction saturates at the clamp)."""
+    p = default_hexapod_params("ripple")
+    p.stance_phase, p.swing_phase, p.phase_offset = 5, 3, 2
+    for l, m in enumerate([1, 3, 0, 2, 0, 1]):
+        p.offset_multiplier[l] = m
+    p.imu_posing = 1
+    p.rotation_pid_gains[:] = [0.8, 0.1, 0.05]
+    p.max_translation[:] = [0.02, 0.015, 0.01]
+    p.max_rotation[:] = [0.05, 0.04, 0.06]
+    p.max_translation_velocity, p.max_rotation_velocity = 0.01, 0.05
+    n = 48
+    inp = make_inputs(p, n, 467, imu=True)
+    rng = np.random.default_rng(467)
+    from scipy.spatial.transform import Rotation as R
+    e = np.stack([rng.uniform(-0.4, 0.4, n), rng.uniform(-0.4, 0.4, n), rng.uniform(-3, 3, n)], axis=1)
+    q = R.from_euler("xyz", e).as_quat()
+    inp["imu_q"] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1)
+    inp["tv"], inp["rv"] = rng.uniform(-1, 1, size=(n, 3)), rng.uniform(-1, 1, size=(n, 3))
+    run_pair(Engine, p, n, inp, [1, 1, 98, 150, 150], twin=True, min_well_posed=0.5, oracle_tables=True)
+
+
 def test_manual_pose_inputs_and_reset_modes(Engine):
     p = default_hexapod_params("tripod")
     n = 48
