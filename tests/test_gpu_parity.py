@@ -253,6 +253,8 @@ def _variants():
             v("fast-steps", step_frequency=1.6),
             v("no-posing-at-all", manual_posing=0),
             v("admittance-from-joint-efforts", admittance_control=1, use_joint_effort=1, force_gain=0.05),
+            v("dynamic-stiffness-scalers", admittance_control=1, dynamic_stiffness=1, load_stiffness_scaler=3.0, swing_stiffness_scaler=0.2),
+            v("short-start-up", time_to_start=3.0),
             v("stiff-virtual-model", admittance_control=1, virtual_stiffness=30.0, virtual_mass=5.0, virtual_damping_ratio=1.2,
               force_gain=0.02, dynamic_stiffness=0)]
 
