@@ -146,7 +146,10 @@ typedef struct shc_engine shc_engine; /* opaque */
 enum {
   SHC_FEAT_TIP_FORCE = 1 << 0, /* Leg::calculateTipForce every cycle (model.cpp:938); needs joint_effort input */
   SHC_FEAT_ODOMETRY = 1 << 1,  /* WalkController::odometry_ideal_ integration (walk_controller.cpp:643, :783-791) */
-  SHC_FEAT_ALL = 0x7fffffff
+  /* Diagnostic: run the runtime-flag kernel (every feature compiled in, selected per launch) even where a compile-time
+   * specialisation for the parameter set exists.  Both produce identical bits (tests/test_gpu_parity.py). */
+  SHC_FEAT_GENERIC_KERNEL = 1 << 30,
+  SHC_FEAT_ALL = 0x3fffffff
 };
 
 /*
@@ -304,6 +307,69 @@ typedef struct shc_leg_state_msg {
 } shc_leg_state_msg;
 /* Fills legs[0 .. leg_count) for `instance`.  Synchronises the engine's stream. */
 int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, shc_leg_state_msg *legs);
+
+/*
+ * Full controller state of one instance (checkpoint / restore, state injection).  Everything the next control cycle reads
+ * that is not an input set through the shc_engine_set_* calls above: restoring a snapshot and replaying the same inputs
+ * reproduces the run bit for bit.  Members are named after the reference members they hold.
+ */
+typedef struct shc_leg_snapshot {
+  double joint_position[SHC_MAX_JOINTS];   /* Joint::desired_position_  (model.h:635) */
+  double joint_velocity[SHC_MAX_JOINTS];   /* Joint::desired_velocity_  (model.h:636) */
+  double walker_tip[3];                    /* LegStepper::current_tip_pose_.position_ (walk_controller.h:520) */
+  double walker_tip_velocity[3];           /* LegStepper::current_tip_velocity_       (:527) */
+  double swing_origin_tip[3];              /* swing_origin_tip_position_              (:529) */
+  double swing_origin_tip_velocity[3];     /* swing_origin_tip_velocity_              (:530) */
+  double stance_origin_tip[3];             /* stance_origin_tip_position_             (:531) */
+  double default_tip[3];                   /* default_tip_pose_.position_             (:519) */
+  double target_tip[3];                    /* target_tip_pose_.position_              (:522) */
+  double stride_vector[3];                 /* stride_vector_                          (:512) */
+  /* Tip rotations (gravity_aligned_tips, > 3 DOF): every consumer of LegStepper::current_tip_pose_.rotation_ /
+   * origin_tip_pose_.rotation_ reads only the rotated x axis (walk_controller.cpp:1217-1224, pose_controller.cpp:129-130,
+   * model.cpp:884-893), so the state is that unit vector + whether the current rotation is defined (!= UNDEFINED_ROTATION) */
+  double walker_tip_direction[3];
+  double origin_tip_direction[3];
+  double admittance_state[2];              /* Leg::admittance_state_    (model.h:518) */
+  double admittance_delta[3];              /* Leg::admittance_delta_    (model.h:365) */
+  double virtual_stiffness;                /* Leg::virtual_stiffness_   (model.h:264) */
+  double tip_force_calculated[3];          /* Leg::tip_force_calculated_ (model.cpp:706, low-pass filter state) */
+  double swing_progress, stance_progress;  /* LegStepper::swing_progress_ / stance_progress_ (walk_controller.h:498-499) */
+  int32_t step_state;                      /* SHC_STEP_* */
+  int32_t phase;                           /* LegStepper::phase_ */
+  int32_t at_correct_phase, completed_first_step; /* walk_controller.h:493-494 */
+  int32_t negate_auto_pose;                /* LegPoser::negate_auto_pose_ (pose_controller.h:575) */
+  int32_t ik_failed;                       /* the 5 mm deviation warning of the last applyIK (model.cpp:921) */
+  int32_t tip_rotation_defined;            /* current_tip_pose_.rotation_ != UNDEFINED_ROTATION */
+  int32_t pad_;
+} shc_leg_snapshot;
+
+typedef struct shc_instance_state {
+  double desired_linear_velocity[2], desired_angular_velocity; /* walk_controller.h:257-258 */
+  double walk_plane[3], walk_plane_normal[3];                   /* WalkController::walk_plane_ / walk_plane_normal_ (:255-256) */
+  double stepper_walk_plane[3], stepper_walk_plane_normal[3];   /* the copies the stepping LegSteppers took last cycle (:509-510) */
+  double origin_walk_plane_pose[7];   /* PoseController::origin_walk_plane_pose_ (x,y,z,qw,qx,qy,qz) */
+  double manual_pose[7];              /* PoseController::manual_pose_ */
+  double translation_velocity_input[3], rotation_velocity_input[3]; /* pose_controller.h:285-286 (rewritten by the reset modes) */
+  double rotation_absement_error[3], rotation_velocity_error[3];    /* IMU PID state (pose_controller.h:315-317) */
+  double auto_pose_rotation[4];       /* PoseController::auto_pose_.rotation_ of the last cycle (w,x,y,z) */
+  double current_pose[7];             /* Model::current_pose_ */
+  double odometry[7];                 /* WalkController::odometry_ideal_ */
+  int32_t walk_state;                 /* SHC_WALK_* */
+  int32_t legs_at_correct_phase, legs_completed_first_step, return_to_default_attempted; /* walk_controller.h:266-268 */
+  int32_t auto_posing_state;          /* SHC_POSING .. SHC_POSING_COMPLETE */
+  int32_t pose_phase;                 /* PoseController::pose_phase_ (auto posing on its own clock) */
+  /* AutoPoser latches, one word per poser: bit 0 start_check_, bit 1 end_check_.first, bit 2 end_check_.second, bit 3 allow_posing_ */
+  int32_t auto_poser_flags[SHC_MAX_AUTO_POSERS];
+  int32_t pad_;
+  shc_leg_snapshot leg[SHC_MAX_LEGS];
+} shc_instance_state;
+
+int64_t shc_sizeof_instance_state(void);
+/* Instances [first, first + count) -> states[0 .. count) (host array).  Synchronises the engine's stream. */
+int shc_engine_get_state(shc_engine *e, int64_t first, int64_t count, shc_instance_state *states);
+/* states[0 .. count) (host array) -> instances [first, first + count).  Inputs (velocity, IMU, forces, efforts, pose
+ * inputs' reset mode) are not part of the state and stay as set. */
+int shc_engine_set_state(shc_engine *e, int64_t first, int64_t count, const shc_instance_state *states);
 
 #ifdef __cplusplus
 }

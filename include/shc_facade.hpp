@@ -101,6 +101,12 @@ private:
   shc_engine *e_ = nullptr;
 };
 
+// The per-robot setters below take ONE robot's values, as the reference's callbacks do; the C ABI copies n instances' worth
+// from the pointer it is given, so they are only valid on a batch of one (larger batches set inputs through the C ABI arrays).
+inline void require_single(const Engine &e, const char *what) {
+  if (e.instances() != 1) throw std::logic_error(std::string(what) + ": per-robot setters need a batch of one; use the C ABI arrays");
+}
+
 // class Joint (model.h:558): the outputs the node publishes.
 struct Joint {
   double desired_position_ = 0.0; // state_controller.cpp:786
@@ -207,10 +213,12 @@ public:
   template <class V3>
   void setManualPoseInput(const V3 &translation, const V3 &rotation) {
     double t[3] = {translation[0], translation[1], translation[2]}, r[3] = {rotation[0], rotation[1], rotation[2]};
+    require_single(*eng_, "setManualPoseInput");
     check(shc_engine_set_pose_input(eng_->handle(), t, r, 0), "set_pose_input");
   }
   void setPoseResetMode(int mode) { // pose_controller.h:105
     int32_t m = mode;
+    require_single(*eng_, "setPoseResetMode");
     check(shc_engine_set_pose_reset_mode(eng_->handle(), &m, 0), "set_pose_reset_mode");
   }
   // updateCurrentPose / updateStance (pose_controller.h:216,157) are part of the fused cycle: nothing to do per call.
@@ -226,9 +234,15 @@ class AdmittanceController {
 public:
   explicit AdmittanceController(std::shared_ptr<Engine> eng) : eng_(std::move(eng)) {}
   // tipStatesCallback -> Leg::setTipForceMeasured (state_controller.cpp:1618): [legs][3]
-  void setTipForceMeasured(const double *force_legs_xyz) { check(shc_engine_set_tip_force(eng_->handle(), force_legs_xyz, 0), "set_tip_force"); }
+  void setTipForceMeasured(const double *force_legs_xyz) {
+    require_single(*eng_, "setTipForceMeasured");
+    check(shc_engine_set_tip_force(eng_->handle(), force_legs_xyz, 0), "set_tip_force");
+  }
   // jointStatesCallback -> Joint::current_effort_ (state_controller.cpp:1590): [legs][dof]
-  void setJointEffort(const double *effort) { check(shc_engine_set_joint_effort(eng_->handle(), effort, 0), "set_joint_effort"); }
+  void setJointEffort(const double *effort) {
+    require_single(*eng_, "setJointEffort");
+    check(shc_engine_set_joint_effort(eng_->handle(), effort, 0), "set_joint_effort");
+  }
   void updateStiffness(WalkController & /*walker*/) {} // fused (admittance_controller.cpp:96)
   void updateAdmittance() {}                           // fused (admittance_controller.cpp:22)
 

@@ -2483,6 +2483,180 @@ void orc_batch_get_virtual_stiffness(orc_batch *b, double *stiffness)
 
 /* ------------------------------------------------------------------------------------ unit-level test hooks */
 
+
+/* ------------------------------------------------------------------------------------ state snapshots
+ * shc_instance_state (include/shc_batch.h) speaks the reference's member names, so the oracle's side is a plain copy.
+ * Used by the teacher-forced one-step parity tests: the oracle's state is loaded into the engine before every cycle. */
+static void put_pose7(double *dst, orc_pose p)
+{
+  dst[0] = p.p.x; dst[1] = p.p.y; dst[2] = p.p.z; dst[3] = p.r.w; dst[4] = p.r.x; dst[5] = p.r.y; dst[6] = p.r.z;
+}
+static orc_pose get_pose7(const double *s) { return orc_pose_make(orc_v3_make(s[0], s[1], s[2]), orc_quat_make(s[3], s[4], s[5], s[6])); }
+static void put_quat4(double *dst, orc_quat q) { dst[0] = q.w; dst[1] = q.x; dst[2] = q.y; dst[3] = q.z; }
+static orc_v3 get3(const double *s) { return orc_v3_make(s[0], s[1], s[2]); }
+
+void orc_get_state(const orc_robot *r, shc_instance_state *o)
+{
+  memset(o, 0, sizeof *o);
+  o->desired_linear_velocity[0] = r->desired_linear_velocity[0];
+  o->desired_linear_velocity[1] = r->desired_linear_velocity[1];
+  o->desired_angular_velocity = r->desired_angular_velocity;
+  put3(o->walk_plane, r->walk_plane);
+  put3(o->walk_plane_normal, r->walk_plane_normal);
+  { /* LegStepper::walk_plane_ copies: every leg that stepped last cycle took the same one (updateStride, :924-925) */
+    int src = 0;
+    for (int l = r->leg_count - 1; l >= 0; --l)
+      if (r->leg[l].stepper.step_state != FORCE_STOP) src = l;
+    put3(o->stepper_walk_plane, r->leg[src].stepper.walk_plane);
+    put3(o->stepper_walk_plane_normal, r->leg[src].stepper.walk_plane_normal);
+  }
+  put_pose7(o->origin_walk_plane_pose, r->origin_walk_plane_pose);
+  put_pose7(o->manual_pose, r->manual_pose);
+  put3(o->translation_velocity_input, r->translation_velocity_input);
+  put3(o->rotation_velocity_input, r->rotation_velocity_input);
+  put3(o->rotation_absement_error, r->rotation_absement_error);
+  put3(o->rotation_velocity_error, r->rotation_velocity_error);
+  put_quat4(o->auto_pose_rotation, r->auto_pose.r);
+  put_pose7(o->current_pose, r->current_pose);
+  put_pose7(o->odometry, r->odometry_ideal);
+  o->walk_state = r->walk_state;
+  o->legs_at_correct_phase = r->legs_at_correct_phase;
+  o->legs_completed_first_step = r->legs_completed_first_step;
+  o->return_to_default_attempted = r->return_to_default_attempted;
+  o->auto_posing_state = r->auto_posing_state;
+  o->pose_phase = r->pose_phase;
+  for (int i = 0; i < r->n_auto_posers && i < SHC_MAX_AUTO_POSERS; ++i)
+  {
+    const auto_poser_t *ap = &r->auto_poser[i];
+    o->auto_poser_flags[i] = (ap->start_check ? 1 : 0) | (ap->end_check_first ? 2 : 0) | (ap->end_check_second ? 4 : 0) | (ap->allow_posing ? 8 : 0);
+  }
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    const leg_t *leg = &r->leg[l];
+    const stepper_t *s = &leg->stepper;
+    shc_leg_snapshot *g = &o->leg[l];
+    for (int j = 0; j < leg->joint_count; ++j)
+    {
+      g->joint_position[j] = leg->joint[j].desired_position;
+      g->joint_velocity[j] = leg->joint[j].desired_velocity;
+    }
+    put3(g->walker_tip, s->current_tip_pose.p);
+    put3(g->walker_tip_velocity, s->current_tip_velocity);
+    put3(g->swing_origin_tip, s->swing_origin_tip_position);
+    put3(g->swing_origin_tip_velocity, s->swing_origin_tip_velocity);
+    put3(g->stance_origin_tip, s->stance_origin_tip_position);
+    put3(g->default_tip, s->default_tip_pose.p);
+    put3(g->target_tip, s->target_tip_pose.p);
+    put3(g->stride_vector, s->stride_vector);
+    if (leg->joint_count > 3 && r->params.gravity_aligned_tips)
+    { /* otherwise the tip rotations are write-only on this path (updateTipRotation's else branch, :1230-1233) */
+      put3(g->walker_tip_direction, orc_quat_rotate(s->current_tip_pose.r, orc_v3_make(1, 0, 0)));
+      put3(g->origin_tip_direction, orc_quat_rotate(s->origin_tip_pose.r, orc_v3_make(1, 0, 0)));
+      g->tip_rotation_defined = !orc_quat_is_undefined(s->current_tip_pose.r);
+    }
+    g->admittance_state[0] = leg->admittance_state[0];
+    g->admittance_state[1] = leg->admittance_state[1];
+    put3(g->admittance_delta, leg->admittance_delta);
+    g->virtual_stiffness = leg->virtual_stiffness;
+    put3(g->tip_force_calculated, leg->tip_force_calculated);
+    g->swing_progress = s->swing_progress;
+    g->stance_progress = s->stance_progress;
+    g->step_state = s->step_state;
+    g->phase = s->phase;
+    g->at_correct_phase = s->at_correct_phase;
+    g->completed_first_step = s->completed_first_step;
+    g->negate_auto_pose = leg->poser.negate_auto_pose;
+    g->ik_failed = leg->ik_failed;
+  }
+}
+
+/* The reverse direction: a snapshot (e.g. taken from the engine) becomes the oracle's state.  Members the snapshot does
+ * not carry are derived the way the reference derives them (joint transforms and the model tip by Leg::applyFK). */
+void orc_set_state(orc_robot *r, const shc_instance_state *o)
+{
+  r->desired_linear_velocity[0] = o->desired_linear_velocity[0];
+  r->desired_linear_velocity[1] = o->desired_linear_velocity[1];
+  r->desired_angular_velocity = o->desired_angular_velocity;
+  r->walk_plane = get3(o->walk_plane);
+  r->walk_plane_normal = get3(o->walk_plane_normal);
+  r->origin_walk_plane_pose = get_pose7(o->origin_walk_plane_pose);
+  r->manual_pose = get_pose7(o->manual_pose);
+  r->translation_velocity_input = get3(o->translation_velocity_input);
+  r->rotation_velocity_input = get3(o->rotation_velocity_input);
+  r->rotation_absement_error = get3(o->rotation_absement_error);
+  r->rotation_velocity_error = get3(o->rotation_velocity_error);
+  r->auto_pose.r = orc_quat_make(o->auto_pose_rotation[0], o->auto_pose_rotation[1], o->auto_pose_rotation[2], o->auto_pose_rotation[3]);
+  r->current_pose = get_pose7(o->current_pose);
+  r->odometry_ideal = get_pose7(o->odometry);
+  r->walk_state = o->walk_state;
+  r->legs_at_correct_phase = o->legs_at_correct_phase;
+  r->legs_completed_first_step = o->legs_completed_first_step;
+  r->return_to_default_attempted = o->return_to_default_attempted;
+  r->auto_posing_state = o->auto_posing_state;
+  r->pose_state = o->auto_posing_state;
+  r->pose_phase = o->pose_phase;
+  for (int i = 0; i < r->n_auto_posers && i < SHC_MAX_AUTO_POSERS; ++i)
+  {
+    auto_poser_t *ap = &r->auto_poser[i];
+    ap->start_check = o->auto_poser_flags[i] & 1;
+    ap->end_check_first = (o->auto_poser_flags[i] >> 1) & 1;
+    ap->end_check_second = (o->auto_poser_flags[i] >> 2) & 1;
+    ap->allow_posing = (o->auto_poser_flags[i] >> 3) & 1;
+  }
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    stepper_t *s = &leg->stepper;
+    const shc_leg_snapshot *g = &o->leg[l];
+    for (int j = 0; j < leg->joint_count; ++j)
+    {
+      leg->joint[j].desired_position = g->joint_position[j];
+      leg->joint[j].prev_desired_position = g->joint_position[j];
+      leg->joint[j].desired_velocity = g->joint_velocity[j];
+    }
+    leg_apply_fk(r, leg);
+    s->current_tip_pose.p = get3(g->walker_tip);
+    s->current_tip_velocity = get3(g->walker_tip_velocity);
+    s->swing_origin_tip_position = get3(g->swing_origin_tip);
+    s->swing_origin_tip_velocity = get3(g->swing_origin_tip_velocity);
+    s->stance_origin_tip_position = get3(g->stance_origin_tip);
+    s->default_tip_pose.p = get3(g->default_tip);
+    s->target_tip_pose.p = get3(g->target_tip);
+    s->stride_vector = get3(g->stride_vector);
+    s->walk_plane = get3(o->stepper_walk_plane);
+    s->walk_plane_normal = get3(o->stepper_walk_plane_normal);
+    if (leg->joint_count > 3 && r->params.gravity_aligned_tips)
+    { /* rotations rebuilt from their x axes the way updateTipRotation builds them (walk_controller.cpp:1224) */
+      s->current_tip_pose.r = g->tip_rotation_defined ? orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), get3(g->walker_tip_direction))
+                                                      : ORC_UNDEFINED_ROTATION;
+      s->origin_tip_pose.r = orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), get3(g->origin_tip_direction));
+    }
+    leg->admittance_state[0] = g->admittance_state[0];
+    leg->admittance_state[1] = g->admittance_state[1];
+    leg->admittance_delta = get3(g->admittance_delta);
+    leg->virtual_stiffness = g->virtual_stiffness;
+    leg->tip_force_calculated = get3(g->tip_force_calculated);
+    s->swing_progress = g->swing_progress;
+    s->stance_progress = g->stance_progress;
+    s->step_state = g->step_state;
+    s->phase = g->phase;
+    s->at_correct_phase = g->at_correct_phase;
+    s->completed_first_step = g->completed_first_step;
+    leg->poser.negate_auto_pose = g->negate_auto_pose;
+    leg->ik_failed = g->ik_failed;
+  }
+}
+
+void orc_batch_get_state(orc_batch *b, shc_instance_state *states)
+{
+  for (int64_t i = 0; i < b->n; ++i) orc_get_state(&b->robots[i], &states[i]);
+}
+void orc_batch_set_state(orc_batch *b, const shc_instance_state *states)
+{
+  for (int64_t i = 0; i < b->n; ++i) orc_set_state(&b->robots[i], &states[i]);
+}
+
+/* ------------------------------------------------------------------------------------ unit-level entry points */
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out) { *out = generate_step_cycle(p); }
 void orc_test_quat_to_euler(const double q[4], int intrinsic, double out[3])
 {

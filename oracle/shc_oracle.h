@@ -86,6 +86,14 @@ int64_t orc_batch_change_gait(orc_batch *b, const shc_params *new_gait);
 void orc_batch_get_odometry(orc_batch *b, double *pose /* [n][7]: xyz + wxyz */);
 void orc_batch_get_virtual_stiffness(orc_batch *b, double *stiffness /* [n][legs] */);
 
+/* Full controller state <-> shc_instance_state (include/shc_batch.h): the teacher-forced parity tests load the oracle's
+ * state into the engine before every cycle (orc_get_state) and the checkpoint tests continue the oracle from an engine
+ * snapshot (orc_set_state). */
+void orc_get_state(const orc_robot *r, shc_instance_state *out);
+void orc_set_state(orc_robot *r, const shc_instance_state *in);
+void orc_batch_get_state(orc_batch *b, shc_instance_state *states /* [n] */);
+void orc_batch_set_state(orc_batch *b, const shc_instance_state *states /* [n] */);
+
 /* ---- unit-level entry points for the KAT / cross-check tests (thin wrappers over the static code) ---- */
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out);
 void orc_test_quat_to_euler(const double q_wxyz[4], int intrinsic, double out[3]);

@@ -29,6 +29,16 @@ static int fail(int code, const std::string &msg) {
     if (_e != hipSuccess) return fail(SHC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// as HIP_TRY, running `cleanup` before the early return (error paths must not leak device buffers)
+#define HIP_TRY_OR(expr, cleanup)                                                                       \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) {                                                                             \
+      cleanup;                                                                                          \
+      return fail(SHC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                     \
+    }                                                                                                   \
+  } while (0)
+
 // ================================================================================================= kernels
 
 // Paired planes of the per-leg SoA state: plane p = fields (2p, 2p + 1) as one double2 per slot.
@@ -252,7 +262,8 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   double t_core[(R::CORE_END * RPW + 63) / 64], t_man[((R::MANUAL_END - R::MPOSE) * RPW + 63) / 64],
       t_imu[((R::IMU_END - R::ABSE) * RPW + 63) / 64], t_imuq[((R::IMUQ_END - R::IMUQ) * RPW + 63) / 64],
       t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_odom[((R::COUNT - R::ODOM) * RPW + 63) / 64];
-  int32_t t_int = 0;
+  constexpr int int_iters = (R::I_COUNT * RPW + 63) / 64; // 3-legged robots: 21 per wave x 4 ints = 84 entries > one wave's width
+  int32_t t_int[int_iters];
   if (any_robot) {
     load_rob_fields<RPW, 0, R::CORE_END>(t_core, gtile, lane);
     if (FT::manual(GP)) load_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, gtile, lane);
@@ -260,7 +271,8 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
     if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::COUNT>(t_odom, gtile, lane);
-    if (lane < R::I_COUNT * RPW) t_int = gtile_i[lane];
+#pragma unroll
+    for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
     // Leg::applyFK of the previous cycle: sin / cos of the stored joint angles
 #pragma unroll
     for (int k = 0; k < NJ; ++k) sincos_joint(th[k] + ll.flat[Fields<NJ>::Q + k], &s.sn[k], &s.cs[k]);
@@ -282,7 +294,9 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
     if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::COUNT>(t_odom, tile, lane);
-    if (lane < R::I_COUNT * RPW) tile_i[lane] = t_int;
+#pragma unroll
+    for (int it = 0; it < int_iters; ++it)
+      if (it * 64 + lane < R::I_COUNT * RPW) tile_i[it * 64 + lane] = t_int[it];
   }
   SHC_TICK(18);
   __syncthreads();
@@ -324,6 +338,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
   store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
   if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::COUNT>(tile, gtile, lane);
+  static_assert((R::I_POSE_PHASE + 1) * RPW <= 64, "the written-back int fields (word, poser latches, pose phase) fit one wave-wide store");
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
   SHC_TICK(14);
 }
@@ -342,6 +357,8 @@ __device__ __forceinline__ int64_t slot_of(int64_t rob, int leg, int L) {
   int gi = int(rob - w * rpw);
   return w * 64 + gi * L + leg;
 }
+
+#include "shc_snapshot.hpp" // get_state / set_state kernels (use rob_index / slot_of)
 
 // AoS [n][L][K] -> leg fields f0..f0+K-1
 __global__ void scatter_leg_kernel(const double *src, double *legd, int64_t n_slots, int64_t n, int L, int K, int f0) {
@@ -623,7 +640,9 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
     c.target_dir[1] = d.y;
     c.target_dir[2] = d.z;
   }
+#ifdef SHC_ABLATE // development builds only (scripts/ablate.py): phase ablation mask
   if (const char *dbg = getenv("SHC_DEBUG_SKIP")) c.debug_skip = atoi(dbg);
+#endif
   for (int i = 0; i < 3; ++i) {
     c.max_translation[i] = p.max_translation[i];
     c.max_rotation[i] = p.max_rotation[i];
@@ -667,7 +686,22 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
   if (p->gravity_aligned_tips && nj <= 3)
     return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips with <= 3 DOF legs is the reference's experimental tip-align pose (outside the accelerated path)");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
-  if (p->time_delta <= 0 || p->step_frequency <= 0) return fail(SHC_ERR_INVALID_ARG, "time_delta / step_frequency must be > 0");
+  if (!(p->time_delta > 0) || !(p->step_frequency > 0)) return fail(SHC_ERR_INVALID_ARG, "time_delta / step_frequency must be > 0");
+  // gait integers feed integer divisions / modulos on the host (generateStepCycle) and on the device (phase arithmetic)
+  if (p->stance_phase <= 0 || p->swing_phase <= 0 || p->phase_offset <= 0 || p->stance_phase > 4096 || p->swing_phase > 4096)
+    return fail(SHC_ERR_INVALID_ARG, "gait: stance_phase, swing_phase and phase_offset must be positive (and <= 4096)");
+  for (int l = 0; l < p->leg_count; ++l)
+    if (p->offset_multiplier[l] < 0) return fail(SHC_ERR_INVALID_ARG, "gait: offset_multiplier must be >= 0");
+  {
+    const double raw = ((1.0 / p->step_frequency) / p->time_delta) / (double(p->swing_phase) / double(p->stance_phase + p->swing_phase));
+    const double periods = raw / double(p->stance_phase + p->swing_phase);
+    if (!(periods >= 0.0) || !(periods * (p->stance_phase + p->swing_phase) < double(LW_PHASE_MASK)))
+      return fail(SHC_ERR_INVALID_ARG, "gait: the step period (1 / (step_frequency * time_delta), rounded) does not fit the phase field");
+    if (int(periods) == 0) // roundToEvenInt(raw / base) == 0: period 0
+      return fail(SHC_ERR_INVALID_ARG, "gait: step period rounds to 0 iterations (step_frequency * time_delta too large)");
+  }
+  if (p->auto_posing && p->pose_frequency != -1.0 && (!(p->pose_frequency > 0) || p->pose_phase_length <= 0))
+    return fail(SHC_ERR_INVALID_ARG, "auto pose: pose_frequency must be -1 (step-cycle sync) or > 0 with pose_phase_length > 0");
   *L = p->leg_count;
   *NJ = nj;
   return SHC_OK;
@@ -783,25 +817,28 @@ extern "C" int shc_generate_tables_batch(const shc_params *params, int64_t count
   shc_params *d_p = nullptr;
   shc_tables *d_t = nullptr;
   int32_t *d_s = nullptr;
-  HIP_TRY(hipMalloc(&d_p, size_t(count) * sizeof(shc_params)));
-  HIP_TRY(hipMalloc(&d_t, size_t(count) * sizeof(shc_tables)));
-  HIP_TRY(hipMalloc(&d_s, size_t(count) * 4));
-  HIP_TRY(hipMemcpy(d_p, params, size_t(count) * sizeof(shc_params), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(d_s, st.data(), size_t(count) * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(d_t, 0, size_t(count) * sizeof(shc_tables)));
+  auto release = [&]() {
+    (void)hipFree(d_p);
+    (void)hipFree(d_t);
+    (void)hipFree(d_s);
+  };
+  HIP_TRY_OR(hipMalloc(&d_p, size_t(count) * sizeof(shc_params)), release());
+  HIP_TRY_OR(hipMalloc(&d_t, size_t(count) * sizeof(shc_tables)), release());
+  HIP_TRY_OR(hipMalloc(&d_s, size_t(count) * 4), release());
+  HIP_TRY_OR(hipMemcpy(d_p, params, size_t(count) * sizeof(shc_params), hipMemcpyHostToDevice), release());
+  HIP_TRY_OR(hipMemcpy(d_s, st.data(), size_t(count) * 4, hipMemcpyHostToDevice), release());
+  HIP_TRY_OR(hipMemset(d_t, 0, size_t(count) * sizeof(shc_tables)), release());
   const unsigned gm = (unsigned)((count + 63) / 64), gl = (unsigned)((count * SHC_MAX_LEGS * 8 + 63) / 64);
   init_chain_head_kernel<<<dim3(gm), dim3(64)>>>(d_p, d_t, d_s, count);
   init_chain_legs_kernel<3><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);
   init_chain_legs_kernel<4><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);
   init_chain_legs_kernel<5><<<dim3(gl), dim3(64)>>>(d_p, d_t, d_s, count);
   init_chain_tail_kernel<<<dim3(gm), dim3(64)>>>(d_p, d_t, d_s, count);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out, d_t, size_t(count) * sizeof(shc_tables), hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(st.data(), d_s, size_t(count) * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(d_p);
-  (void)hipFree(d_t);
-  (void)hipFree(d_s);
+  HIP_TRY_OR(hipGetLastError(), release());
+  HIP_TRY_OR(hipDeviceSynchronize(), release());
+  HIP_TRY_OR(hipMemcpy(out, d_t, size_t(count) * sizeof(shc_tables), hipMemcpyDeviceToHost), release());
+  HIP_TRY_OR(hipMemcpy(st.data(), d_s, size_t(count) * 4, hipMemcpyDeviceToHost), release());
+  release();
   for (int64_t i = 0; i < count; ++i) {
     if (st[i] != SHC_OK) memset(static_cast<void *>(&out[i]), 0, sizeof(shc_tables));
     if (status) status[i] = st[i];
@@ -956,27 +993,30 @@ static int init_state(shc_engine *e) {
     case 4: build_templates<4>(e, legt, legw, robt, robi); break;
     case 5: build_templates<5>(e, legt, legw, robt, robi); break;
   }
-  double *d_legt, *d_robt;
-  int32_t *d_legw, *d_robi;
-  HIP_TRY(hipMalloc(&d_legt, legt.size() * 8));
-  HIP_TRY(hipMalloc(&d_robt, robt.size() * 8));
-  HIP_TRY(hipMalloc(&d_legw, legw.size() * 4));
-  HIP_TRY(hipMalloc(&d_robi, robi.size() * 4));
-  HIP_TRY(hipMemcpyAsync(d_legt, legt.data(), legt.size() * 8, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(d_robt, robt.data(), robt.size() * 8, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(d_legw, legw.data(), legw.size() * 4, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(d_robi, robi.data(), robi.size() * 4, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemsetAsync(e->st.legd, 0, size_t(e->n_leg_fields) * e->n_slots * 8, e->stream));
-  HIP_TRY(hipMemsetAsync(e->st.legi, 0, size_t(e->n_slots) * 4, e->stream));
+  double *d_legt = nullptr, *d_robt = nullptr;
+  int32_t *d_legw = nullptr, *d_robi = nullptr;
+  auto release = [&]() {
+    (void)hipFree(d_legt);
+    (void)hipFree(d_robt);
+    (void)hipFree(d_legw);
+    (void)hipFree(d_robi);
+  };
+  HIP_TRY_OR(hipMalloc(&d_legt, legt.size() * 8), release());
+  HIP_TRY_OR(hipMalloc(&d_robt, robt.size() * 8), release());
+  HIP_TRY_OR(hipMalloc(&d_legw, legw.size() * 4), release());
+  HIP_TRY_OR(hipMalloc(&d_robi, robi.size() * 4), release());
+  HIP_TRY_OR(hipMemcpyAsync(d_legt, legt.data(), legt.size() * 8, hipMemcpyHostToDevice, e->stream), release());
+  HIP_TRY_OR(hipMemcpyAsync(d_robt, robt.data(), robt.size() * 8, hipMemcpyHostToDevice, e->stream), release());
+  HIP_TRY_OR(hipMemcpyAsync(d_legw, legw.data(), legw.size() * 4, hipMemcpyHostToDevice, e->stream), release());
+  HIP_TRY_OR(hipMemcpyAsync(d_robi, robi.data(), robi.size() * 4, hipMemcpyHostToDevice, e->stream), release());
+  HIP_TRY_OR(hipMemsetAsync(e->st.legd, 0, size_t(e->n_leg_fields) * e->n_slots * 8, e->stream), release());
+  HIP_TRY_OR(hipMemsetAsync(e->st.legi, 0, size_t(e->n_slots) * 4, e->stream), release());
   int64_t threads = e->n * e->L;
   init_state_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(
       e->st, d_legt, d_legw, d_robt, d_robi, e->L, e->n_leg_fields, RobotFields::COUNT, RobotFields::I_COUNT);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  (void)hipFree(d_legt);
-  (void)hipFree(d_robt);
-  (void)hipFree(d_legw);
-  (void)hipFree(d_robi);
+  HIP_TRY_OR(hipGetLastError(), release());
+  HIP_TRY_OR(hipStreamSynchronize(e->stream), release());
+  release();
   return SHC_OK;
 }
 
@@ -1029,15 +1069,15 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   e->st.n_slots = e->n_slots;
   e->st.n_rob_pad = e->n_rob_pad;
   e->st.n_robots = e->n;
-  HIP_TRY(hipMalloc(&e->st.legd, size_t(e->n_leg_fields) * e->n_slots * 8));
-  HIP_TRY(hipMalloc(&e->st.legi, size_t(e->n_slots) * 4));
+  HIP_TRY_OR(hipMalloc(&e->st.legd, size_t(e->n_leg_fields) * e->n_slots * 8), shc_engine_destroy(e));
+  HIP_TRY_OR(hipMalloc(&e->st.legi, size_t(e->n_slots) * 4), shc_engine_destroy(e));
   // robot state: one contiguous [field][rpw] tile per wave
-  HIP_TRY(hipMalloc(&e->st.robd, size_t(RobotFields::COUNT) * e->n_rob_pad * 8));
-  HIP_TRY(hipMalloc(&e->st.robi, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4));
-  HIP_TRY(hipMemsetAsync(e->st.robd, 0, size_t(RobotFields::COUNT) * e->n_rob_pad * 8, e->stream));
-  HIP_TRY(hipMemsetAsync(e->st.robi, 0, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4, e->stream));
+  HIP_TRY_OR(hipMalloc(&e->st.robd, size_t(RobotFields::COUNT) * e->n_rob_pad * 8), shc_engine_destroy(e));
+  HIP_TRY_OR(hipMalloc(&e->st.robi, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4), shc_engine_destroy(e));
+  HIP_TRY_OR(hipMemsetAsync(e->st.robd, 0, size_t(RobotFields::COUNT) * e->n_rob_pad * 8, e->stream), shc_engine_destroy(e));
+  HIP_TRY_OR(hipMemsetAsync(e->st.robi, 0, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4, e->stream), shc_engine_destroy(e));
   e->stage_bytes = size_t(e->n) * L * (NJ > 3 ? NJ : 3) * 8 + size_t(e->n) * 8 * 8;
-  HIP_TRY(hipMalloc(&e->d_stage, e->stage_bytes));
+  HIP_TRY_OR(hipMalloc(&e->d_stage, e->stage_bytes), shc_engine_destroy(e));
   rc = upload_consts(e);
   if (rc == SHC_OK) rc = init_state(e);
   // The reference's loop() that enters RUNNING also executes runningState() once with the (zero) inputs present at
@@ -1241,7 +1281,7 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   const int block = (e->n_waves >= 1024) ? 256 : 64;
   const int64_t waves_per_block = block / 64;
   const unsigned grid = (unsigned)((e->n_waves + waves_per_block - 1) / waves_per_block);
-  const bool dyn = getenv("SHC_FORCE_GENERIC") != nullptr;
+  const bool dyn = (e->features & SHC_FEAT_GENERIC_KERNEL) != 0;
   const int L = e->L, NJ = e->NJ;
   if (L == 6 && NJ == 3) launch_cycle_feat<6, 3, true>(e, grid, block, n_cycles, !dyn);
   else if (L == 8 && NJ == 5) launch_cycle_feat<8, 5, true>(e, grid, block, n_cycles, !dyn);
@@ -1464,6 +1504,49 @@ extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, sh
     for (int k = 0; k < 7; ++k) m.auto_pose[k] = e->params.auto_posing ? std::nan("") : (k == 3 ? 1.0 : 0.0);
   }
   return SHC_OK;
+}
+
+extern "C" int64_t shc_sizeof_instance_state(void) { return (int64_t)sizeof(shc_instance_state); }
+
+// Snapshot records travel through a temporary device buffer (checkpoint / injection are not per-cycle operations).
+static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_instance_state *out, const shc_instance_state *in) {
+  if (!e || (!out && !in)) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  if (first < 0 || count < 0 || first + count > e->n) return fail(SHC_ERR_INVALID_ARG, "instance range out of bounds");
+  if (count == 0) return SHC_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  shc_instance_state *d = nullptr;
+  const size_t bytes = size_t(count) * sizeof(shc_instance_state);
+  HIP_TRY(hipMalloc(&d, bytes));
+  hipError_t err = hipSuccess;
+  const dim3 grid((unsigned)((count + 63) / 64)), block(64);
+  if (in) err = hipMemcpyAsync(d, in, bytes, hipMemcpyHostToDevice, e->stream);
+  if (err == hipSuccess) {
+    switch (e->NJ) {
+      case 3: if (in) set_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+              else get_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+              break;
+      case 4: if (in) set_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+              else get_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+              break;
+      default: if (in) set_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+               else get_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+               break;
+    }
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess && out) err = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, e->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  (void)hipFree(d);
+  if (err != hipSuccess) return fail(SHC_ERR_HIP, std::string("state transfer: ") + hipGetErrorString(err));
+  return SHC_OK;
+}
+extern "C" int shc_engine_get_state(shc_engine *e, int64_t first, int64_t count, shc_instance_state *states) {
+  if (!states) return fail(SHC_ERR_INVALID_ARG, "states is NULL");
+  return state_transfer(e, first, count, states, nullptr);
+}
+extern "C" int shc_engine_set_state(shc_engine *e, int64_t first, int64_t count, const shc_instance_state *states) {
+  if (!states) return fail(SHC_ERR_INVALID_ARG, "states is NULL");
+  return state_transfer(e, first, count, nullptr, states);
 }
 
 extern "C" int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device) {

@@ -13,7 +13,7 @@ from typing import Optional
 
 import numpy as np
 
-from .params import FEAT_DEFAULT, LegStateMsg, Params, Tables
+from .params import FEAT_DEFAULT, InstanceState, LegStateMsg, Params, Tables
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("SHC_LIB") or os.path.join(_HERE, "libshc_batch.so")
@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_get_body_state", "shc_engine_get_odometry", "shc_engine_get_virtual_stiffness",
     "shc_engine_change_gait", "shc_stream_create", "shc_stream_destroy", "shc_engine_read_leg_state_msg",
     "shc_generate_tables_batch", "shc_engine_create_with_tables",
+    "shc_sizeof_instance_state", "shc_engine_get_state", "shc_engine_set_state",
 ]
 
 
@@ -44,23 +45,41 @@ def _sources():
     return out
 
 
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+          "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+
+
+def _source_hash() -> str:
+    """Content hash of everything the library is built from (sources, ABI header, flags).  A hash, not mtimes: the in-tree
+    .so travels to the GPU box in a snapshot that does not keep modification times."""
+    import hashlib
+    h = hashlib.sha256(" ".join(_FLAGS).encode())
+    for s in _sources():
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/shc_engine.hip for gfx950 into libshc_batch.so (in-tree).  hipcc cross-compiles without a GPU."""
-    if not force and os.path.exists(_SO) and all(os.path.getmtime(s) <= os.path.getmtime(_SO) for s in _sources()):
+    """Compile csrc/shc_engine.hip for gfx950 into libshc_batch.so (in-tree) unless the existing library was built from
+    exactly these sources.  hipcc cross-compiles without a GPU."""
+    stamp = _SO + ".srchash"
+    want = _source_hash()
+    if not force and os.path.exists(_SO) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -disable-machine-licm: MachineLICM hoists the materialisation of ~100 FP64 literals (polynomial coefficients of
     # sincos / atan2, tolerances) out of the n_cycles loop and pins them in VGPRs for the whole launch (256 VGPRs + scratch
-    # spills); re-materialising them at use keeps the hexapod kernel at 192 VGPRs with no scratch (DESIGN.md section 4.1).
+    # spills); re-materialising them at use keeps the hexapod kernel free of scratch (DESIGN.md section 4.1).
     # -amdgpu-sched-strategy=max-ilp: at one or two waves per SIMD the cycle is bound by dependent-issue latency (FP64
     # dependent ops issue every 8 clocks, LDS reads return after ~60); the ILP-first scheduler spends the spare VGPRs
     # (the occupancy target of 2 waves/SIMD allows 256) on overlapping independent chains.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-o", _SO,
-           os.path.join(_SRC, "shc_engine.hip")]
+    cmd = [hipcc] + _FLAGS + ["-o", _SO, os.path.join(_SRC, "shc_engine.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return _SO
 
 
@@ -70,12 +89,10 @@ _ip = C.POINTER(C.c_int32)
 
 
 def lib():
-    """Load libshc_batch.so (building it if the sources are newer)."""
+    """Load libshc_batch.so, (re)building it first when it is missing or was built from different sources."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO):
-            build_library()
-        L = C.CDLL(_SO)
+        L = C.CDLL(_SO if os.environ.get("SHC_LIB") else build_library())
         L.shc_last_error.restype = C.c_char_p
         L.shc_sizeof_params.restype = C.c_int64
         L.shc_debug_plane_copy.argtypes = [C.c_int, C.c_int64, C.c_int]
@@ -108,6 +125,13 @@ def lib():
         L.shc_stream_destroy.argtypes = [C.c_int, C.c_void_p]
         L.shc_engine_change_gait.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
         L.shc_engine_get_virtual_stiffness.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_sizeof_instance_state.restype = C.c_int64
+        L.shc_engine_get_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]
+        L.shc_engine_set_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]
+        # a binding whose struct layouts disagree with the library must not run
+        for name, typ in (("shc_sizeof_params", Params), ("shc_sizeof_tables", Tables), ("shc_sizeof_instance_state", InstanceState)):
+            if getattr(L, name)() != C.sizeof(typ):
+                raise ShcError(f"{name}() = {getattr(L, name)()} but the ctypes mirror has {C.sizeof(typ)} bytes")
         _lib = L
     return _lib
 
@@ -273,6 +297,17 @@ class BatchEngine:
         arr = (LegStateMsg * self.legs)()
         _check(self.L.shc_engine_read_leg_state_msg(self.h, int(instance), arr), "read_leg_state_msg")
         return list(arr)
+
+    def get_state(self, first: int = 0, count: Optional[int] = None):
+        """Full controller state of instances [first, first + count) as a ctypes array of InstanceState."""
+        count = self.n - first if count is None else count
+        arr = (InstanceState * count)()
+        _check(self.L.shc_engine_get_state(self.h, first, count, arr), "get_state")
+        return arr
+
+    def set_state(self, states, first: int = 0):
+        """Restore / inject the state of instances [first, first + len(states))."""
+        _check(self.L.shc_engine_set_state(self.h, first, len(states), states), "set_state")
 
     def odometry(self):
         """WalkController::getOdometryIdeal per instance: [n][7] (x, y, z, qw, qx, qy, qz)."""

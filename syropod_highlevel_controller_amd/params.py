@@ -25,6 +25,7 @@ STEP_SWING, STEP_STANCE, STEP_FORCE_STANCE, STEP_FORCE_STOP = 0, 1, 2, 3
 VEL_THROTTLE, VEL_REAL = 0, 1
 FEAT_TIP_FORCE = 1
 FEAT_ODOMETRY = 2
+FEAT_GENERIC_KERNEL = 1 << 30  # diagnostic: runtime-flag kernel instead of the compile-time specialisation
 FEAT_DEFAULT = FEAT_TIP_FORCE | FEAT_ODOMETRY  # what shc_engine_create enables
 
 
@@ -36,6 +37,32 @@ class LegStateMsg(C.Structure):
                 ("joint_efforts", C.c_double * SHC_MAX_JOINTS), ("stance_progress", C.c_double), ("swing_progress", C.c_double),
                 ("time_to_swing_end", C.c_double), ("pose_delta", C.c_double * 7), ("auto_pose", C.c_double * 7), ("tip_force", C.c_double * 3),
                 ("admittance_delta", C.c_double * 3), ("virtual_stiffness", C.c_double)]
+
+
+class LegSnapshot(C.Structure):
+    """shc_leg_snapshot of include/shc_batch.h."""
+    _fields_ = [("joint_position", C.c_double * SHC_MAX_JOINTS), ("joint_velocity", C.c_double * SHC_MAX_JOINTS),
+                ("walker_tip", C.c_double * 3), ("walker_tip_velocity", C.c_double * 3), ("swing_origin_tip", C.c_double * 3),
+                ("swing_origin_tip_velocity", C.c_double * 3), ("stance_origin_tip", C.c_double * 3), ("default_tip", C.c_double * 3),
+                ("target_tip", C.c_double * 3), ("stride_vector", C.c_double * 3), ("walker_tip_direction", C.c_double * 3),
+                ("origin_tip_direction", C.c_double * 3), ("admittance_state", C.c_double * 2), ("admittance_delta", C.c_double * 3),
+                ("virtual_stiffness", C.c_double), ("tip_force_calculated", C.c_double * 3), ("swing_progress", C.c_double),
+                ("stance_progress", C.c_double), ("step_state", C.c_int32), ("phase", C.c_int32), ("at_correct_phase", C.c_int32),
+                ("completed_first_step", C.c_int32), ("negate_auto_pose", C.c_int32), ("ik_failed", C.c_int32),
+                ("tip_rotation_defined", C.c_int32), ("pad_", C.c_int32)]
+
+
+class InstanceState(C.Structure):
+    """shc_instance_state of include/shc_batch.h: full controller state of one robot (checkpoint / state injection)."""
+    _fields_ = [("desired_linear_velocity", C.c_double * 2), ("desired_angular_velocity", C.c_double),
+                ("walk_plane", C.c_double * 3), ("walk_plane_normal", C.c_double * 3), ("stepper_walk_plane", C.c_double * 3),
+                ("stepper_walk_plane_normal", C.c_double * 3), ("origin_walk_plane_pose", C.c_double * 7), ("manual_pose", C.c_double * 7),
+                ("translation_velocity_input", C.c_double * 3), ("rotation_velocity_input", C.c_double * 3),
+                ("rotation_absement_error", C.c_double * 3), ("rotation_velocity_error", C.c_double * 3),
+                ("auto_pose_rotation", C.c_double * 4), ("current_pose", C.c_double * 7), ("odometry", C.c_double * 7),
+                ("walk_state", C.c_int32), ("legs_at_correct_phase", C.c_int32), ("legs_completed_first_step", C.c_int32),
+                ("return_to_default_attempted", C.c_int32), ("auto_posing_state", C.c_int32), ("pose_phase", C.c_int32),
+                ("auto_poser_flags", C.c_int32 * SHC_MAX_AUTO_POSERS), ("pad_", C.c_int32), ("leg", LegSnapshot * SHC_MAX_LEGS)]
 
 
 class JointParams(C.Structure):

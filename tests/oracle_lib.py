@@ -7,7 +7,7 @@ import subprocess
 
 import numpy as np
 
-from syropod_highlevel_controller_amd.params import LegStateMsg, Params, StepCycle, Tables
+from syropod_highlevel_controller_amd.params import InstanceState, LegStateMsg, Params, StepCycle, Tables
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _SO = os.path.join(_ROOT, "oracle", "liboracle.so")
@@ -75,6 +75,10 @@ def lib():
         L.orc_batch_change_gait.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.orc_batch_change_gait.restype = C.c_int64
         L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
+        L.orc_get_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
+        L.orc_set_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
+        L.orc_batch_get_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
+        L.orc_batch_set_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
         L.orc_test_generate_step_cycle.argtypes = [C.POINTER(Params), C.POINTER(StepCycle)]
         L.orc_test_quat_to_euler.argtypes = [_dp, C.c_int, _dp]
         L.orc_test_euler_to_quat.argtypes = [_dp, C.c_int, _dp]
@@ -237,6 +241,16 @@ class OracleBatch:
         ws = np.zeros(self.n, dtype=np.int32)
         self.L.orc_batch_get_body_state(self.h, _ptr(pose), _ptr(vel), _ptr(ws, _ip))
         return pose, vel, ws
+
+    def get_state(self):
+        """Full controller state of every robot as a ctypes array of InstanceState (shc_instance_state)."""
+        arr = (InstanceState * self.n)()
+        self.L.orc_batch_get_state(self.h, arr)
+        return arr
+
+    def set_state(self, states):
+        assert len(states) == self.n
+        self.L.orc_batch_set_state(self.h, states)
 
     def leg_state_msg(self, instance):
         arr = (LegStateMsg * self.p.leg_count)()

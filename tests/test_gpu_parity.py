@@ -17,7 +17,7 @@ import pytest
 
 from oracle_lib import OracleBatch, OracleRobot
 from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
-from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_ODOMETRY, FEAT_TIP_FORCE, VEL_REAL, WALK_MOVING, WALK_STOPPED
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_GENERIC_KERNEL, FEAT_ODOMETRY, FEAT_TIP_FORCE, VEL_REAL, WALK_MOVING, WALK_STOPPED
 
 pytestmark = pytest.mark.gpu
 TOL_Q = 1e-6  # rad, BASELINE.json north_star
@@ -572,12 +572,9 @@ def test_generic_kernel_is_bit_identical_to_specialised(Engine):
     apply(b, inp)
     a.step(150)
     a.synchronize()
-    os.environ["SHC_FORCE_GENERIC"] = "1"
-    try:
-        b.step(150)
-        b.synchronize()
-    finally:
-        del os.environ["SHC_FORCE_GENERIC"]
+    b.set_features(FEAT_DEFAULT | FEAT_GENERIC_KERNEL)
+    b.step(150)
+    b.synchronize()
     for x, y in zip(snapshot(a), snapshot(b)):
         assert np.array_equal(x, y)
 

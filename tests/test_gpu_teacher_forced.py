@@ -1,0 +1,347 @@
+"""GPU (-m gpu): TEACHER-FORCED one-step parity — the primary parity bar.
+
+Before every control cycle the oracle's complete controller state (shc_instance_state, include/shc_batch.h) is loaded
+into the engine through shc_engine_set_state; both then advance ONE cycle on the same inputs and the full state records
+are compared, field by field, for EVERY instance.  Differences cannot accumulate, so the comparison is immune to the
+expanding joint-limit term of the reference's Leg::solveIK (model.cpp:788-790) that forces the free-running tests
+(tests/test_gpu_parity.py) to mask ill-posed trajectories: here no instance is ever excluded and the bar is 1e-12 rad
+(BASELINE.json north_star asks for 1e-6).  tests/test_oracle_snapshot.py shows on the CPU that the record is complete.
+
+The oracle itself runs free (it is never corrected by the engine), so the visited states are the reference's own
+trajectory: walk-state transitions, swing / stance hand-overs, stops and restarts, saturated clamps.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle_lib import OracleBatch
+from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, InstanceState, VEL_REAL
+from test_gpu_parity import apply, make_inputs
+
+pytestmark = pytest.mark.gpu
+TOL_Q = 1e-12   # rad after one cycle from identical state (measured: 1e-16 ... 1e-14)
+TOL_X = 1e-12   # m / dimensionless state
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from syropod_highlevel_controller_amd import engine
+    if engine.device_count() < 1:
+        pytest.fail("no HIP device: the -m gpu tests must run the native HIP path")
+    return engine.BatchEngine
+
+
+def as_np(states):
+    return np.frombuffer(states, dtype=np.dtype(InstanceState))
+
+
+def compare_records(p, features, g, o, tol_q=TOL_Q):
+    """g: engine records, o: oracle records (numpy structured arrays).  Returns max |dq|."""
+    L, D = p.leg_count, p.leg_dof[0]
+    gl, ol = g["leg"][:, :L], o["leg"][:, :L]
+    dq = np.abs(gl["joint_position"][..., :D] - ol["joint_position"][..., :D])
+    assert np.isfinite(gl["joint_position"]).all()
+    assert dq.max() <= tol_q, f"max |dq| = {dq.max():.3e} rad after one cycle from identical state"
+    np.testing.assert_allclose(gl["joint_velocity"][..., :D], ol["joint_velocity"][..., :D], atol=tol_q / p.time_delta * 2)
+    for f in ("walker_tip", "swing_origin_tip", "stance_origin_tip", "default_tip", "target_tip", "stride_vector"):
+        np.testing.assert_allclose(gl[f], ol[f], atol=TOL_X, err_msg=f)
+    for f in ("walker_tip_velocity", "swing_origin_tip_velocity"):
+        np.testing.assert_allclose(gl[f], ol[f], atol=TOL_X / p.time_delta * 2, err_msg=f)
+    for f in ("step_state", "phase", "at_correct_phase", "completed_first_step", "ik_failed"):
+        assert np.array_equal(gl[f], ol[f]), f
+    for f in ("swing_progress", "stance_progress"):
+        np.testing.assert_allclose(gl[f], ol[f], atol=1e-15, err_msg=f)
+    if p.auto_posing and not p.imu_posing:
+        assert np.array_equal(gl["negate_auto_pose"], ol["negate_auto_pose"])
+    if p.admittance_control:
+        np.testing.assert_allclose(gl["admittance_state"], ol["admittance_state"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(gl["admittance_delta"], ol["admittance_delta"], atol=TOL_X)
+        if p.dynamic_stiffness:
+            np.testing.assert_allclose(gl["virtual_stiffness"], ol["virtual_stiffness"], rtol=1e-12)
+    if (features & 1) or p.use_joint_effort:
+        np.testing.assert_allclose(gl["tip_force_calculated"], ol["tip_force_calculated"], rtol=1e-9, atol=1e-9)
+    if p.gravity_aligned_tips and D > 3:
+        assert np.array_equal(gl["tip_rotation_defined"], ol["tip_rotation_defined"])
+        d = ol["tip_rotation_defined"] != 0
+        np.testing.assert_allclose(gl["walker_tip_direction"][d], ol["walker_tip_direction"][d], atol=1e-12)
+        np.testing.assert_allclose(gl["origin_tip_direction"], ol["origin_tip_direction"], atol=1e-12)
+    for f in ("desired_linear_velocity", "desired_angular_velocity", "walk_plane", "walk_plane_normal", "stepper_walk_plane",
+              "stepper_walk_plane_normal", "origin_walk_plane_pose", "current_pose"):
+        np.testing.assert_allclose(g[f], o[f], atol=TOL_X, err_msg=f)
+    for f in ("walk_state", "legs_at_correct_phase", "legs_completed_first_step", "return_to_default_attempted"):
+        assert np.array_equal(g[f], o[f]), f
+    if p.manual_posing:
+        for f in ("manual_pose", "translation_velocity_input", "rotation_velocity_input"):
+            np.testing.assert_allclose(g[f], o[f], atol=TOL_X, err_msg=f)
+    if p.imu_posing:
+        for f in ("rotation_absement_error", "rotation_velocity_error"):
+            np.testing.assert_allclose(g[f], o[f], atol=TOL_X, err_msg=f)
+    elif p.auto_posing:
+        assert np.array_equal(g["auto_posing_state"], o["auto_posing_state"])
+        assert np.array_equal(g["auto_poser_flags"][:, :p.n_auto_posers], o["auto_poser_flags"][:, :p.n_auto_posers])
+        if p.pose_frequency != -1.0:
+            assert np.array_equal(g["pose_phase"], o["pose_phase"])
+        if p.inclination_posing:
+            np.testing.assert_allclose(g["auto_pose_rotation"], o["auto_pose_rotation"], atol=TOL_X)
+    if features & 2:
+        np.testing.assert_allclose(g["odometry"], o["odometry"], atol=TOL_X)
+    return float(dq.max())
+
+
+class Schedule:
+    """Input changes applied identically to engine and oracle at given cycles."""
+
+    def __init__(self):
+        self.events = {}
+
+    def at(self, cycle, **inp):
+        self.events.setdefault(cycle, {}).update(inp)
+        return self
+
+    def fire(self, cycle, objs):
+        inp = self.events.get(cycle)
+        if not inp:
+            return
+        for o in objs:
+            if "lin" in inp:
+                o.set_velocity(inp["lin"], inp["ang"])
+            if "tv" in inp:
+                o.set_pose_input(inp["tv"], inp["rv"])
+            if "reset" in inp:
+                o.set_pose_reset_mode(inp["reset"])
+            if "force" in inp:
+                o.set_tip_force(inp["force"])
+            if "imu_q" in inp:
+                o.set_imu(inp["imu_q"], inp["gyro"])
+            if "effort" in inp:
+                o.set_joint_effort(inp["effort"])
+
+
+def teacher_forced(Engine, p, n, inp, cycles, schedule=None, features=FEAT_DEFAULT, label=""):
+    eng, ob = Engine(p, n), OracleBatch(p, n)
+    eng.set_features(features)
+    apply(eng, inp)
+    apply(ob, inp)
+    worst = 0.0
+    visited = set()
+    for c in range(cycles):
+        if schedule:
+            schedule.fire(c, (eng, ob))
+        eng.set_state(ob.get_state())          # teacher forcing: the oracle's state, every cycle, every instance
+        eng.step(1)
+        ob.step(1, 8)
+        g, o = as_np(eng.get_state()), as_np(ob.get_state())
+        worst = max(worst, compare_records(p, features, g, o))
+        visited.update(np.unique(o["walk_state"]).tolist())
+    print(f"[teacher-forced {label}] {n} instances x {cycles} cycles, all instances held: max |dq| = {worst:.3e} rad, "
+          f"walk states visited {sorted(visited)}")
+    return eng, ob, worst
+
+
+def stop_go_schedule(p, n, seed, cycles, every=60, pose=False):
+    rng = np.random.default_rng(seed)
+    s = Schedule()
+    for c in range(every, cycles, every):
+        lin, ang = rng.uniform(-0.7, 0.7, (n, 2)), rng.uniform(-1, 1, n)
+        stop = rng.random(n) < 0.4
+        lin[stop], ang[stop] = 0.0, 0.0
+        ev = dict(lin=lin, ang=ang)
+        if pose:
+            ev["tv"] = rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.4)
+            ev["rv"] = rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.4)
+            ev["reset"] = rng.choice([0, 0, 0, 1, 2, 3, 4, 5], size=n).astype(np.int32)
+        s.at(c, **ev)
+    return s
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs
+def test_config2_hexapod_tripod(Engine):
+    p = default_hexapod_params("tripod")
+    n, cycles = 256, 420
+    teacher_forced(Engine, p, n, make_inputs(p, n, 0, zero_every=11), cycles, stop_go_schedule(p, n, 1, cycles, every=130), label="config2")
+
+
+def config3_params():
+    p = default_hexapod_params("wave")
+    p.admittance_control, p.imu_posing = 1, 1
+    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    return p
+
+
+def test_config3_wave_admittance_imu_as_specified(Engine):
+    """configs[2] on SURVEY.md section 8(d)'s inputs: measured tip force z ~ U(0, 20) N, x, y ~ N(0, 1), resampled every 10
+    cycles; IMU roll / pitch ~ U(-0.15, 0.15) rad, yaw ~ U(-pi, pi), gyro ~ N(0, 0.05).  The admittance offsets drive legs
+    into their joint limits (position and velocity clamps saturate, IK-failure flags are raised) — all compared."""
+    p = config3_params()
+    n, cycles = 192, 600
+    inp = make_inputs(p, n, 5, imu=True, force=20.0)
+    rng = np.random.default_rng(0xADD1)
+    s = Schedule()
+    for c in range(10, cycles, 10):
+        s.at(c, force=np.stack([rng.normal(0, 1, (n, 6)), rng.normal(0, 1, (n, 6)), rng.uniform(0, 20, (n, 6))], axis=2))
+    eng, ob, _ = teacher_forced(Engine, p, n, inp, cycles, s, label="config3 U(0,20)N")
+    lo = ob.leg_state()
+    assert (lo["leg_status"] & 4).any(), "the specified forces are expected to raise IK-deviation flags somewhere"
+
+
+def test_config3_dynamic_stiffness_and_stops(Engine):
+    p = config3_params()
+    p.dynamic_stiffness = 1
+    n, cycles = 96, 500
+    inp = make_inputs(p, n, 6, imu=True, force=8.0)
+    teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 66, cycles, every=90, pose=True), label="config3 dyn-stiffness")
+
+
+def test_config4_octopod_ripple(Engine):
+    p = synthetic_octopod_params("ripple", 5, 8)
+    n, cycles = 128, 360
+    teacher_forced(Engine, p, n, make_inputs(p, n, 7, zero_every=9), cycles, stop_go_schedule(p, n, 77, cycles, every=110), label="config4")
+
+
+@pytest.mark.parametrize("legs,dof,gait", [(4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"),
+                                           (3, 3, "wave"), (5, 3, "ripple"), (7, 3, "wave"), (8, 4, "ripple"), (4, 5, "amble"),
+                                           (8, 3, "tripod"), (6, 5, "wave")])
+def test_config5_bins_and_every_kernel_instantiation(Engine, legs, dof, gait):
+    p = synthetic_octopod_params(gait, dof, legs)
+    n, cycles = 70, 330
+    teacher_forced(Engine, p, n, make_inputs(p, n, 500 + legs * 10 + dof, zero_every=8), cycles,
+                   stop_go_schedule(p, n, legs * 10 + dof, cycles, every=100, pose=True), label=f"{legs}x{dof} {gait}")
+
+
+# ------------------------------------------------------------------------------------------------ features
+@pytest.mark.parametrize("gait", ["tripod", "wave", "ripple", "amble"])
+def test_manual_pose_resets_stop_and_go(Engine, gait):
+    p = default_hexapod_params(gait)
+    n, cycles = 96, 520
+    inp = make_inputs(p, n, 13)
+    teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 131, cycles, every=45, pose=True), label=f"manual/{gait}")
+
+
+@pytest.mark.parametrize("own_clock", [False, True])
+@pytest.mark.parametrize("gait", ["tripod", "wave"])
+def test_auto_posing(Engine, gait, own_clock):
+    p = default_hexapod_params(gait)
+    p.auto_posing = 1
+    if own_clock:
+        p.pose_frequency = 0.8
+    for i in range(p.n_auto_posers):
+        p.x_amplitudes[i], p.y_amplitudes[i], p.yaw_amplitudes[i] = 0.004 * (-1) ** i, 0.003, 0.01 * (-1) ** i
+        if i % 2:
+            p.gravity_amplitudes[i] = 0.008
+    for l in range(6):
+        p.negation_transition_ratio[l] = 0.25
+    n, cycles = 64, 700
+    inp = make_inputs(p, n, 449, imu=True, zero_every=9)
+    teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 450, cycles, every=170), label=f"auto/{gait}/{own_clock}")
+
+
+def test_inclination_and_auto_posing(Engine):
+    p = default_hexapod_params("tripod")
+    p.inclination_posing, p.auto_posing = 1, 1
+    n, cycles = 64, 400
+    teacher_forced(Engine, p, n, make_inputs(p, n, 11, imu=True), cycles, stop_go_schedule(p, n, 12, cycles, every=150), label="incl+auto")
+
+
+@pytest.mark.parametrize("dof,legs,gait", [(5, 8, "ripple"), (4, 6, "tripod"), (5, 4, "amble")])
+def test_gravity_aligned_tips(Engine, dof, legs, gait):
+    p = synthetic_octopod_params(gait, dof, legs)
+    p.gravity_aligned_tips = 1
+    n, cycles = 64, 450
+    inp = make_inputs(p, n, 300 + dof * 10 + legs, zero_every=7)
+    teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 301, cycles, every=120, pose=True), label=f"gravity-aligned {legs}x{dof}")
+
+
+def _variants():
+    def v(name, **kw):
+        return pytest.param(kw, id=name)
+    return [v("no-clamps", clamp_joint_positions=0, clamp_joint_velocities=0),
+            v("100Hz-slow-steps", time_delta=0.01, step_frequency=0.6),
+            v("high-clearance-tall-steps", body_clearance=0.12, swing_height=0.04, swing_width=0.01),
+            v("overlapping-walkspaces", overlapping_walkspaces=1),
+            v("fast-steps", step_frequency=1.6),
+            v("no-posing-at-all", manual_posing=0),
+            v("real-velocity-mode", velocity_input_mode=VEL_REAL),
+            v("force-normal-touchdown", force_normal_touchdown=1, swing_width=0.01),
+            v("stance-span", stance_span_modifier=0.25),
+            v("admittance-from-joint-efforts", admittance_control=1, use_joint_effort=1, force_gain=0.05),
+            v("dynamic-stiffness-scalers", admittance_control=1, dynamic_stiffness=1, load_stiffness_scaler=3.0, swing_stiffness_scaler=0.2),
+            v("stiff-virtual-model", admittance_control=1, virtual_stiffness=30.0, virtual_mass=5.0, virtual_damping_ratio=1.2,
+              force_gain=0.02, dynamic_stiffness=0)]
+
+
+@pytest.mark.parametrize("kw", _variants())
+def test_parameter_variants(Engine, kw):
+    """One-step parity does not depend on where the start-up solve ended: the engine starts from its OWN init chain."""
+    p = default_hexapod_params("ripple")
+    for k, val in kw.items():
+        setattr(p, k, val)
+    n, cycles = 64, 380
+    inp = make_inputs(p, n, 211, force=6.0 if p.admittance_control else None)
+    if p.velocity_input_mode == VEL_REAL:
+        inp["lin"] *= 0.12
+        inp["ang"] *= 0.6
+    teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 212, cycles, every=120), label=str(kw))
+
+
+def test_optional_features_off(Engine):
+    p = default_hexapod_params("tripod")
+    n, cycles = 64, 200
+    teacher_forced(Engine, p, n, make_inputs(p, n, 3), cycles, features=0, label="features off")
+
+
+# ------------------------------------------------------------------------------------------------ checkpoint / restore
+@pytest.mark.parametrize("case", ["config2", "config3", "octopod-gravity"])
+def test_engine_snapshot_restores_bit_exactly(Engine, case):
+    """shc_engine_get_state -> a FRESH engine -> shc_engine_set_state continues bit for bit; the same snapshot loaded into
+    the oracle (orc_set_state) continues within the free-running tolerance."""
+    if case == "config2":
+        p, kw = default_hexapod_params("tripod"), {}
+    elif case == "config3":
+        p, kw = config3_params(), dict(imu=True, force=4.0)
+    else:
+        p, kw = synthetic_octopod_params("ripple", 5, 8), {}
+        p.gravity_aligned_tips = 1
+    n = 77
+    inp = make_inputs(p, n, 91, **kw)
+    a = Engine(p, n)
+    apply(a, inp)
+    a.step(173)
+    snap = a.get_state()
+    b = Engine(p, n)
+    apply(b, inp)
+    b.set_state(snap)
+    assert bytes(b.get_state()) == bytes(snap)          # the record survives the round trip unchanged
+    ob = OracleBatch(p, n)
+    apply(ob, inp)
+    ob.set_state(snap)
+    for k in (1, 1, 40):
+        a.step(k)
+        b.step(k)
+        ob.step(k, 8)
+        assert bytes(a.get_state()) == bytes(b.get_state())
+        qa, _ = a.joints()
+        qo, _ = ob.joints()
+        assert np.abs(qa - qo).max() <= 1e-9
+
+
+def test_partial_state_access(Engine):
+    p = default_hexapod_params("tripod")
+    n = 50
+    e = Engine(p, n)
+    inp = make_inputs(p, n, 5)
+    apply(e, inp)
+    e.step(60)
+    full = as_np(e.get_state()).copy()
+    part = as_np(e.get_state(17, 9))
+    assert part.tobytes() == full[17:26].tobytes()
+    # overwrite instances 3..5 with the state of instances 30..32: only those change
+    donor = e.get_state(30, 3)
+    e.set_state(donor, first=3)
+    after = as_np(e.get_state())
+    assert after[3:6].tobytes() == full[30:33].tobytes()
+    assert after[:3].tobytes() == full[:3].tobytes() and after[6:].tobytes() == full[6:].tobytes()
+    from syropod_highlevel_controller_amd.engine import ShcError
+    with pytest.raises(ShcError):
+        e.get_state(45, 10)
