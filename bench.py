@@ -34,6 +34,11 @@ ALG_BYTES_PER_CYCLE = {("hexapod", 2): 3008, ("hexapod", 3): 3560, ("octopod", 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
 
 
+def config3_forces(rng, n, legs):
+    """measured tip force z ~ U(0, 20) N, x, y ~ N(0, 1)."""
+    return np.stack([rng.normal(0, 1, (n, legs)), rng.normal(0, 1, (n, legs)), rng.uniform(0, 20, (n, legs))], axis=2)
+
+
 def make_workload(name, n, seed, rank=0):
     from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
     from syropod_highlevel_controller_amd.parallel import velocity_inputs
@@ -43,18 +48,22 @@ def make_workload(name, n, seed, rank=0):
     extra = {}
     if name == "config2":
         p = default_hexapod_params("tripod")
-        key, desc = ("hexapod", 2), "4096 hexapods (6x3 DOF, default.yaml), tripod gait, IK + Bezier tip trajectory"
+        key, desc = ("hexapod", 2), "hexapods (6x3 DOF, default.yaml), tripod gait, IK + Bezier tip trajectory"
     elif name == "config3":
         p = default_hexapod_params("wave")
         p.admittance_control, p.imu_posing = 1, 1
         p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
-        key, desc = ("hexapod", 3), "hexapods, wave gait + admittance + IMU pose compensation"
+        key = ("hexapod", 3)
+        desc = ("hexapods, wave gait + admittance (tip force z ~ U(0, 20) N, x, y ~ N(0, 1), resampled every 10 cycles from "
+                "device-resident sets) + IMU pose compensation (PID 0.2 / 0.02 / 0.01)")
         from scipy.spatial.transform import Rotation as R
         e = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-np.pi, np.pi, n)], axis=1)
         q = R.from_euler("xyz", e).as_quat()
         extra["imu_q"] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1)
         extra["gyro"] = rng.normal(0, 0.05, size=(n, 3))
-        extra["force"] = np.stack([rng.normal(0, 1, (n, 6)), rng.normal(0, 1, (n, 6)), rng.uniform(0, 2, (n, 6))], axis=2)
+        frng = np.random.default_rng(0xADD1 + rank)
+        extra["force"] = config3_forces(frng, n, 6)
+        extra["force_sets"] = [config3_forces(frng, n, 6) for _ in range(4)]  # rotated through every 10 cycles
     elif name == "config4":
         p = synthetic_octopod_params("ripple", 5, 8)
         key, desc = ("octopod", 4), "synthetic octopods (8x5 DOF), ripple gait, IK + Bezier tip trajectory"
@@ -78,7 +87,7 @@ def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
     from oracle_lib import OracleBatch
     cores = os.cpu_count() or 1
     n_s = min(len(ang), 64 * cores)
-    sub = {k: v[:n_s] for k, v in extra.items()}
+    sub = {k: v[:n_s] for k, v in extra.items() if k != "force_sets"}
     ob = OracleBatch(p, n_s)
     apply_inputs(ob, lin[:n_s], ang[:n_s], sub)
     t = ob.step(20, cores)  # calibration + warm-up (walk start)
@@ -88,7 +97,7 @@ def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
     multi = n_s * cycles / t
     n1 = min(n_s, 64)
     ob1 = OracleBatch(p, n1)
-    apply_inputs(ob1, lin[:n1], ang[:n1], {k: v[:n1] for k, v in extra.items()})
+    apply_inputs(ob1, lin[:n1], ang[:n1], {k: v[:n1] for k, v in sub.items()})
     ob1.step(20, 1)
     c1 = int(max(20, min(2000, 3.0 * (rate / cores) / n1)))
     t1 = ob1.step(c1, 1)
@@ -96,6 +105,156 @@ def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
             "sample": f"{n_s} instances x {cycles} cycles on {cores} threads (pthreads over instances); "
                       f"single thread: {n1 * c1 / t1:.0f} control-cycles/s ({n1} instances x {c1} cycles)",
             "single_thread_value": n1 * c1 / t1}
+
+
+def measured_traffic(workload, n, cps):
+    """HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel build (profiles/traffic.json, written by
+    scripts/summarize_prof.py); null when the committed figure belongs to different kernel sources."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        from syropod_highlevel_controller_amd.engine import _source_hash
+        t = json.load(open(tpath))
+        if t.get("_kernel_source_hash") != _source_hash():
+            return None
+        return t.get(f"{workload}:{n}:{cps}")
+    except Exception:
+        return None
+
+
+def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False):
+    """One workload on this rank's GPU: prepare (untimed), time `steps` steps, measure the kernel with HIP events.
+    dist_ctx = (world, rank, local_rank) when the RCCL path is active."""
+    import torch
+    import torch.distributed as dist
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+    from syropod_highlevel_controller_amd.parallel import all_gather_joints
+
+    world, rank, local_rank = dist_ctx or (1, 0, torch.cuda.current_device())
+    use_dist = dist_ctx is not None
+    p, lin, ang, extra, key, desc = make_workload(name, n, seed, rank)
+    stream = torch.cuda.current_stream()
+    eng = BatchEngine(p, n, device=local_rank, stream=stream.cuda_stream)
+    apply_inputs(eng, lin * 0.0, ang * 0.0, extra)
+    # config 3: the measured tip forces are resampled every 10 cycles (SURVEY.md section 8d) from sets resident in HBM
+    force_sets = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in extra.get("force_sets", [])]
+    state = {"cycle": 0}
+
+    def step_once():
+        if force_sets and state["cycle"] % 10 < cps and state["cycle"] > 0:
+            f = force_sets[(state["cycle"] // 10) % len(force_sets)]
+            eng.L.shc_engine_set_tip_force(eng.h, f.data_ptr(), 1)  # device pointer: a scatter kernel on the engine's stream
+        eng.step(cps)
+        state["cycle"] += cps
+
+    # ---- untimed preparation: de-phase the instances (instance i receives its command i mod period cycles late),
+    #      then walk until every instance is MOVING.
+    period = eng.tables().step.period
+    groups = 8
+
+    def advance(cycles):  # same launch shape as the timed region, so a profile of this process sees one kernel shape
+        for _ in range((cycles + cps - 1) // cps):
+            step_once()
+
+    for gk in range(groups):
+        sel = (np.arange(n) % groups) <= gk
+        eng.set_velocity(lin * sel[:, None], ang * sel)
+        advance(max(1, period // groups))
+    eng.set_velocity(lin, ang)
+    advance(2 * period + 64)
+    eng.synchronize()
+    _, _, ws = eng.body_state()
+    moving_frac = float((ws == 1).mean())
+
+    gathered = None
+    # joint-state shard of this rank in the C ABI's instance-major layout [n][legs][dof] (device resident)
+    qshard = torch.empty(n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda") if use_dist else None
+    if use_dist:
+        gathered = torch.empty(world * qshard.numel(), dtype=torch.float64, device="cuda")
+
+    def gather():
+        if use_dist:
+            eng.joints_device(qshard.data_ptr(), None)  # SoA planes -> [n][legs][dof] on the engine's stream
+            all_gather_joints(qshard, world, out=gathered)  # the helper tests/test_sharding_gloo.py runs over gloo
+
+    for _ in range(warmup):
+        step_once()
+    if use_dist:
+        gather()
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_once()
+        if gather_every and (i + 1) % gather_every == 0:
+            gather()
+    if not gather_every or steps % gather_every:
+        gather()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        # the gathered buffer must hold every rank's shard in rank order: check this rank's own slice
+        own = gathered[rank * qshard.numel():(rank + 1) * qshard.numel()]
+        assert torch.equal(own, qshard), "all-gather returned a different shard for this rank"
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- kernel duration of the cycle kernel, HIP events on the launch stream.  Two upper bounds on the true duration:
+    #      (a) one event pair per launch (adds the event-record latency), (b) one pair around m back-to-back launches
+    #      (adds the inter-kernel gaps).  The smaller one is reported; rocprofv3's kernel-trace average agrees with it.
+    m = min(steps, 200)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(m)]
+    for a, b in evs:
+        a.record(stream)
+        eng.step(cps)
+        b.record(stream)
+    torch.cuda.synchronize()
+    per_launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(m):
+        eng.step(cps)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    kern_ms = min(per_launch_ms, e0.elapsed_time(e1) / m)
+    # ---- secondary figure: 16 control cycles fused per launch (inputs held, state in registers between cycles)
+    fused_value = None
+    if cps == 1 and world == 1 and fused_probe:
+        fc, reps = 16, max(4, steps // 16)
+        for _ in range(3):
+            eng.step(fc)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(reps):
+            eng.step(fc)
+        torch.cuda.synchronize()
+        fused_value = n * fc * reps / (time.perf_counter() - tf0)
+    q, _ = eng.joints()
+    finite = bool(np.isfinite(q).all())
+    eng.close()
+
+    alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    res = {
+        "value": world * n * steps * cps / elapsed, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": f"BASELINE.json {name}: {n} {desc}", "instances_per_gpu": n, "cycles_per_step": cps,
+                   "legs": p.leg_count, "dof": p.leg_dof[0],
+                   "gather": f"all-gather of the joint buffer every {gather_every} steps" if gather_every
+                   else "one all-gather of the final joint buffer (N > 1)",
+                   "moving_fraction": moving_frac, "finite": finite, "seed": seed, "fused_16_cycles_per_launch_value": fused_value},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if want_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(p, lin, ang, extra)
+    return res
+
+
+DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072}
 
 
 def main():
@@ -109,6 +268,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=0, help="all-gather the joint buffer every G steps (0 = once, at the end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-probe", action="store_true", help="skip the secondary 16-cycles-per-launch figure (keeps rocprof stats to one launch shape)")
+    ap.add_argument("--no-also", action="store_true", help="skip the config 3 / config 4 measurements reported under config.also")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather path even with one rank")
     ap.add_argument("--seed", type=int, default=0xC0FFEE)
     args = ap.parse_args()
@@ -131,133 +291,34 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from syropod_highlevel_controller_amd.engine import BatchEngine
-
-    n = args.instances or {"config2": 4096, "config3": 65536, "config4": 131072}[args.workload]
-    p, lin, ang, extra, key, desc = make_workload(args.workload, n, args.seed, rank)
-    stream = torch.cuda.current_stream()
-    eng = BatchEngine(p, n, device=local_rank, stream=stream.cuda_stream)
-    apply_inputs(eng, lin * 0.0, ang * 0.0, extra)
-
-    # ---- untimed preparation: de-phase the instances (instance i receives its command i mod period cycles late),
-    #      then walk until every instance is MOVING.
-    period = eng.tables().step.period
-    groups = 8
-    cps = args.cycles_per_step
-
-    def advance(cycles):  # same launch shape as the timed region, so a profile of this process sees one kernel shape
-        for _ in range((cycles + cps - 1) // cps):
-            eng.step(cps)
-
-    for gk in range(groups):
-        sel = (np.arange(n) % groups) <= gk
-        eng.set_velocity(lin * sel[:, None], ang * sel)
-        advance(max(1, period // groups))
-    eng.set_velocity(lin, ang)
-    advance(2 * period + 64)
-    eng.synchronize()
-    _, _, ws = eng.body_state()
-    moving_frac = float((ws == 1).mean())
-
-    gathered = None
-    if use_dist:
-        gathered = torch.empty(world * n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda")
-
-    # joint-state shard of this rank in the C ABI's instance-major layout [n][legs][dof] (device resident)
-    qshard = torch.empty(n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda") if use_dist else None
-
-    def gather():
-        if use_dist:
-            eng.joints_device(qshard.data_ptr(), None)  # SoA planes -> [n][legs][dof] on the engine's stream
-            dist.all_gather_into_tensor(gathered, qshard)
-
-    for _ in range(args.warmup):
-        eng.step(cps)
-    if use_dist:
-        gather()
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.step(cps)
-        if args.gather_every and (i + 1) % args.gather_every == 0:
-            gather()
-    if not args.gather_every or args.steps % args.gather_every:
-        gather()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        # the gathered buffer must hold every rank's shard in rank order: check this rank's own slice
-        own = gathered[rank * qshard.numel():(rank + 1) * qshard.numel()]
-        assert torch.equal(own, qshard), "all-gather returned a different shard for this rank"
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- kernel duration of the cycle kernel, HIP events on the launch stream.  Two upper bounds on the true duration:
-    #      (a) one event pair per launch (adds the event-record latency), (b) one pair around m back-to-back launches
-    #      (adds the inter-kernel gaps).  The smaller one is reported; rocprofv3's kernel-trace average agrees with it.
-    m = min(args.steps, 200)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(m)]
-    for a, b in evs:
-        a.record(stream)
-        eng.step(cps)
-        b.record(stream)
-    torch.cuda.synchronize()
-    per_launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(m):
-        eng.step(cps)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    kern_ms = min(per_launch_ms, e0.elapsed_time(e1) / m)
-    # ---- secondary figure: 16 control cycles fused per launch (inputs held, state in registers between cycles)
-    fused_value = None
-    if cps == 1 and world == 1 and not args.no_fused_probe:
-        fc, reps = 16, max(4, args.steps // 16)
-        for _ in range(3):
-            eng.step(fc)
-        torch.cuda.synchronize()
-        tf0 = time.perf_counter()
-        for _ in range(reps):
-            eng.step(fc)
-        torch.cuda.synchronize()
-        fused_value = n * fc * reps / (time.perf_counter() - tf0)
-    q, _ = eng.joints()
-    finite = bool(np.isfinite(q).all())
-
+    n = args.instances or DEFAULT_INSTANCES[args.workload]
+    res = run_workload(args.workload, n, args.steps, args.warmup, args.cycles_per_step, args.seed,
+                       dist_ctx=(world, rank, local_rank) if use_dist else None, gather_every=args.gather_every,
+                       fused_probe=not args.no_fused_probe, want_cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+    # The other single-GPU BASELINE.json configurations, measured in the same process (N = 1 default run only):
+    # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
+    also = []
+    if world == 1 and not use_dist and args.workload == "config2" and not args.instances and not args.no_also:
+        for name in ("config3", "config4"):
+            k = max(50, min(args.steps, 300))
+            r = run_workload(name, DEFAULT_INSTANCES[name], k, max(10, min(args.warmup, 30)), args.cycles_per_step, args.seed,
+                             fused_probe=not args.no_fused_probe)
+            also.append({"workload": r["config"]["workload"], "value": r["value"], "unit": "control-cycles/s", "steps": k,
+                         "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"],
+                         "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],
+                         "roofline": r["roofline"]})
     if rank == 0:
-        total_cycles = world * n * args.steps * cps
-        value = total_cycles / elapsed
-        alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.workload}:{n}:{cps}")
-            except Exception:
-                traffic = None
+        cfg = res["config"]
+        if also:
+            cfg["also"] = also
         out = {
-            "metric": "control-cycles/sec (all legs IK-solved)", "value": value, "unit": "control-cycles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "control-cycles/sec (all legs IK-solved)", "value": res["value"], "unit": "control-cycles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json {args.workload}: {desc}", "instances_per_gpu": n,
-                       "cycles_per_step": cps, "legs": p.leg_count, "dof": p.leg_dof[0],
-                       "gather": f"all-gather of the joint buffer every {args.gather_every} steps" if args.gather_every
-                       else "one all-gather of the final joint buffer (N > 1)",
-                       "moving_fraction": moving_frac, "finite": finite, "seed": args.seed,
-                       "fused_16_cycles_per_launch_value": fused_value},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+            "config": cfg, "roofline": res["roofline"],
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(p, lin, ang, extra)
+        if "cpu_baseline" in res:
+            out["cpu_baseline"] = res["cpu_baseline"]
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -360,7 +360,7 @@ typedef struct shc_instance_state {
   int32_t pose_phase;                 /* PoseController::pose_phase_ (auto posing on its own clock) */
   /* AutoPoser latches, one word per poser: bit 0 start_check_, bit 1 end_check_.first, bit 2 end_check_.second, bit 3 allow_posing_ */
   int32_t auto_poser_flags[SHC_MAX_AUTO_POSERS];
-  int32_t pad_;
+  int32_t pad_[2];                    /* explicit: the record has no implicit padding (byte-comparable) */
   shc_leg_snapshot leg[SHC_MAX_LEGS];
 } shc_instance_state;
 

@@ -365,13 +365,52 @@ SHC_HDI bool generate_tables_head(const shc_params &p, shc_tables &t) {
   return true;
 }
 
+// Model::current_pose_ as PoseController::updateCurrentPose leaves it in loop `call` (0-based) of the direct start-up.
+// The loops before RUNNING already pose the body (state_controller.cpp:165-167 runs for every robot state): walk-plane pose
+// (0, 0, body_clearance) + identity manual pose (no inputs yet) + - because the IMU branch needs RUNNING, pose_controller.cpp:836 -
+// the auto pose whenever auto posing runs on its own clock (pose_frequency != -1: every AutoPoser is allowed from the first
+// call on, :1359-1371, and the master phase is the call counter, :1150-1159).  Synchronised with the step cycle the posers
+// never start while the walk state is STOPPED, so the auto pose is the identity.  The simulated start-up solve targets the
+// pose of loop 0 (directStartup's first call, :483-489); the workspace search runs at the pose of the loop that reaches
+// READY (state_controller.cpp:263-272; Leg::generateWorkspace reads model_->getCurrentPose(), model.cpp:338).
+SHC_HDI Pose startup_body_pose(const shc_params &p, const shc_tables &t, int call) {
+  Pose cp{V3{0, 0, p.body_clearance}, quat_identity()};
+  if (!p.auto_posing || p.pose_frequency == -1.0 || t.pose_phase_length <= 0) return cp;
+  const int len = t.pose_phase_length, nrm = t.pose_normaliser;
+  const int master_phase = call % len;
+  Pose auto_pose = pose_identity();
+  for (int i = 0; i < p.n_auto_posers && i < SHC_MAX_AUTO_POSERS; ++i) { // AutoPoser::updatePose (:1338-1439)
+    int phase = master_phase, sp = p.pose_phase_starts[i] * nrm, ep = p.pose_phase_ends[i] * nrm;
+    if (sp > ep) {
+      ep += len;
+      if (phase < sp) phase += len;
+    }
+    if (phase >= sp && phase < ep) {
+      const int iteration = phase - sp + 1, num = ep - sp;
+      const bool first_half = iteration <= num / 2;
+      const double delta_t = 1.0 / (num / 2.0);
+      const int offset = int(first_half ? 0 : num / 2.0);
+      const double tt = (iteration - offset) * delta_t, u = 1.0 - tt;
+      // control nodes {0,0,0,A,A} / {A,A,0,0,0}: B(t) = A * weight
+      const double wgt = first_half ? (4.0 * tt * tt * tt * u + tt * tt * tt * tt) : (u * u * u * u + 4.0 * tt * u * u * u);
+      V3 pos;
+      if (p.gravity_amplitudes[i] != 0.0) pos = V3{0, 0, -1.0} * (p.gravity_amplitudes[i] * wgt); // estimateGravity with the IMU still at identity
+      else pos = V3{p.x_amplitudes[i] * wgt, p.y_amplitudes[i] * wgt, p.z_amplitudes[i] * wgt};
+      const V3 rot{p.roll_amplitudes[i] * wgt, p.pitch_amplitudes[i] * wgt, p.yaw_amplitudes[i] * wgt};
+      auto_pose = add_pose(auto_pose, Pose{pos, euler_to_quat(rot, false)});
+    }
+  }
+  return add_pose(cp, auto_pose);
+}
+SHC_HDI int startup_loops(const shc_params &p) { return imax(1, round_to_int(p.time_to_start / p.time_delta)); } // :1520
+
 // Direct start-up solve + workspace search of ONE leg: the sequential part (thousands of DLS steps), independent per leg.
 // (the device batch splits the eight bearing searches of a leg over eight threads: each repeats the start-up solve and
 //  the re-basing prefix, ~350 steps, and searches one bearing, <= 500 steps)
 template <int NJ>
 SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int first_bearing = 1, int last_bearing = 8) {
-  // body pose during start-up and workspace generation: walk-plane pose (0, 0, body_clearance), no rotation
-  Pose body{V3{0, 0, p.body_clearance}, quat_identity()};
+  // body pose the start-up solve eases to / the workspace search runs at (identical unless auto posing has its own clock)
+  const Pose body = startup_body_pose(p, t, 0), body_ws = startup_body_pose(p, t, startup_loops(p) - 1);
   HostLeg<NJ> leg;
   fill_leg_const<NJ>(p, l, leg.lc);
   for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, p.joint[l][j].min, p.joint[l][j].max); // model.cpp:1038
@@ -381,7 +420,7 @@ SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int 
     leg.dflt[j] = leg.q[j]; // Model::updateDefaultConfiguration
     if (first_bearing == 1) t.default_joint_position[l][j] = leg.q[j];
   }
-  generate_workspace<NJ>(p, leg, inverse_transform_vector(body, default_tip), t.workspace_radius[l], first_bearing, last_bearing);
+  generate_workspace<NJ>(p, leg, inverse_transform_vector(body_ws, default_tip), t.workspace_radius[l], first_bearing, last_bearing);
 }
 
 // Walkspace + velocity / acceleration limits from the legs' workspaces.

@@ -62,7 +62,7 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
   o.pose_phase = ri(R::I_POSE_PHASE);
   const int ap = ri(R::I_APOSER);
   for (int i = 0; i < SHC_MAX_AUTO_POSERS; ++i) o.auto_poser_flags[i] = (ap >> (4 * i)) & 15;
-  o.pad_ = 0;
+  o.pad_[0] = o.pad_[1] = 0;
   for (int l = 0; l < SHC_MAX_LEGS; ++l) {
     shc_leg_snapshot &g = o.leg[l];
     __builtin_memset(&g, 0, sizeof g);

@@ -44,13 +44,15 @@ def velocity_inputs(seed: int, lo: int, hi: int, min_speed: float = 0.2):
     return lin, ang
 
 
-def all_gather_joints(local, world: int):
-    """All-gather equally sized per-rank joint-state shards (torch tensors, any device) into one tensor ordered by rank.
-    Returns the gathered tensor (world * local.numel() elements)."""
+def all_gather_joints(local, world: int, out=None):
+    """All-gather equally sized per-rank joint-state shards (torch tensors, any device) into one tensor ordered by rank:
+    THE exchange step of the sharded path (bench.py on RCCL, tests/test_sharding_gloo.py on gloo).  `out` (optional) is a
+    preallocated world * local.numel() tensor, so that a timed loop does not allocate.  Returns the gathered tensor."""
     import torch
     import torch.distributed as dist
-    out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
-    if world == 1:
+    if out is None:
+        out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         out.copy_(local.reshape(-1))
         return out
     dist.all_gather_into_tensor(out, local.reshape(-1).contiguous())

@@ -93,11 +93,13 @@ def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
     return float(dq.max())
 
 
-def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_posed=0.8, features=FEAT_DEFAULT, oracle_tables=False):
-    # oracle_tables: start the engine from the oracle's init-chain tables (shc_engine_create_with_tables), so that the
-    # cycle is compared from an identical start-up configuration where the two start-up solves end on different points of
-    # the reference's chatter orbit (tests/test_host_tables_and_abi.py, START_UP_CHATTER)
-    eng = Engine(p, n, tables=OracleRobot(p).tables()) if oracle_tables else Engine(p, n)
+def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_posed=0.8, features=FEAT_DEFAULT):
+    # The engine always starts from its OWN init chain.  Parameter sets keep time_to_start / time_delta <= 300 start-up
+    # steps: beyond that the reference's start-up iteration is ill-conditioned (two builds of the oracle itself end mrad
+    # apart, tests/test_oracle_conditioning.py) and a free-running comparison has no common starting point; such parameter
+    # sets are covered by the teacher-forced tests (tests/test_gpu_teacher_forced.py), which need none.
+    assert round(p.time_to_start / p.time_delta) <= 300
+    eng = Engine(p, n)
     eng.set_features(features)
     ob = OracleBatch(p, n)
     apply(eng, inp)
@@ -247,7 +249,7 @@ def _variants():
     def v(name, **kw):
         return pytest.param(kw, id=name)
     return [v("no-clamps", clamp_joint_positions=0, clamp_joint_velocities=0),
-            v("100Hz-slow-steps", time_delta=0.01, step_frequency=0.6),
+            v("100Hz-slow-steps", time_delta=0.01, step_frequency=0.6, time_to_start=3.0),
             v("high-clearance-tall-steps", body_clearance=0.12, swing_height=0.04, swing_width=0.01),
             v("overlapping-walkspaces", overlapping_walkspaces=1),
             v("fast-steps", step_frequency=1.6),
@@ -268,7 +270,7 @@ def test_parameter_variants(Engine, kw):
         setattr(p, k, val)
     n = 60
     inp = make_inputs(p, n, 211, force=2.0 if p.admittance_control else None)
-    run_pair(Engine, p, n, inp, [1, 1, 58, 140, 200], twin=True, min_well_posed=0.7, oracle_tables=True)
+    run_pair(Engine, p, n, inp, [1, 1, 58, 140, 200], twin=True, min_well_posed=0.7)
 
 
 @pytest.mark.parametrize("mode", ["throttle", "real"])
@@ -296,9 +298,16 @@ def test_auto_posing_on_its_own_clock(Engine, gait):
     p = default_hexapod_params(gait)
     p.auto_posing = 1
     p.pose_frequency = 0.8
+    # the reference generates its workspace at the body pose of the loop that reaches READY (model.cpp:338): choose the
+    # start-up length so that this is pose phase 0 (identity pose) - otherwise the workspace is ZERO and nothing walks
+    # (tests/test_host_tables_and_abi.py::own_clock_auto_pose_params)
+    base = p.pose_phase_length
+    k = int((1.0 / p.pose_frequency) / p.time_delta / base)
+    length = (k if k % 2 == 0 else k + 1) * base
+    p.time_to_start = ((299 // length) * length + 1) * p.time_delta
     n = 50
     inp = make_inputs(p, n, 433, zero_every=6)
-    eng, ob, _ = run_pair(Engine, p, n, inp, [1, 1, 98, 150], twin=True, oracle_tables=True)
+    eng, ob, _ = run_pair(Engine, p, n, inp, [1, 1, 98, 150], twin=True)
     zero = {"lin": np.zeros((n, 2)), "ang": np.zeros(n)}
     for o in (eng, ob):
         o.set_velocity(zero["lin"], zero["ang"])
@@ -360,7 +369,7 @@ def test_custom_gait_and_saturating_pose_limits(Engine):
     q = R.from_euler("xyz", e).as_quat()
     inp["imu_q"] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1)
     inp["tv"], inp["rv"] = rng.uniform(-1, 1, size=(n, 3)), rng.uniform(-1, 1, size=(n, 3))
-    run_pair(Engine, p, n, inp, [1, 1, 98, 150, 150], twin=True, min_well_posed=0.5, oracle_tables=True)
+    run_pair(Engine, p, n, inp, [1, 1, 98, 150, 150], twin=True, min_well_posed=0.5)
 
 
 def test_manual_pose_inputs_and_reset_modes(Engine):
