@@ -107,7 +107,12 @@ if __name__ == "__main__":
         tj = os.path.join(os.path.dirname(dest), "traffic.json")
         d = json.load(open(tj)) if os.path.exists(tj) else {}
         d[key] = round(traffic)
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from syropod_highlevel_controller_amd.engine import _source_hash
+        if d.get("_kernel_source_hash") != _source_hash():  # figures of an older kernel build are dropped, not mixed in
+            d = {key: round(traffic)}
+        d["_kernel_source_hash"] = _source_hash()
         d["_note"] = ("HBM bytes per launch of shc_cycle_kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in KiB, each scaled by the "
                       "factor calibrated on shc_debug_plane_copy in the same run); written by scripts/summarize_prof.py from " + os.path.basename(dest))
         json.dump(d, open(tj, "w"), indent=1)
-    print(open(dest).read())
+    print(open(dest).read()[-2500:])

@@ -42,6 +42,8 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // write-back: groups nobody changed are not stored (walk plane / manual pose of the robot tile; the parked stepper
 // origins of the per-leg planes, which change once per step period).
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
+// launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
+enum : unsigned { RT_MANUAL_LIVE = 1 };
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
@@ -286,7 +288,8 @@ __device__ __forceinline__ int bearing_bracket(double y, double x) {
 // ------------------------------------------------------------------------------------------------- one control cycle
 template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
-                                      const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty) {
+                                      const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
+                                      const bool manual_live) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
@@ -398,7 +401,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     cp = wpp; // Identity.addPose(walk_plane_pose_)
     // ---- updateManualPose (:863-1003)
     Quat manual_r = quat_identity();
-    if (FT::manual(P)) {
+    if (FT::manual(P) && manual_live) {
       V3 tvi_in = rb.get3(R::TVI), rvi_in = rb.get3(R::RVI);
       int reset_mode = rb.geti(R::I_RESET_MODE);
       bool idle = reset_mode == 0 && tvi_in.x == 0.0 && tvi_in.y == 0.0 && tvi_in.z == 0.0 && rvi_in.x == 0.0 && rvi_in.y == 0.0 &&

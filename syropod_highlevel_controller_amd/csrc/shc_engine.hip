@@ -199,19 +199,25 @@ __device__ __forceinline__ void store_rob_fields(const double *tile, double *gti
 
 // One launch = n_cycles control cycles of every robot; per-leg state stays in registers, per-robot state in LDS.
 template <int L, int NJ, unsigned F>
-__global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles) {
+__global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles,
+                                                                                             unsigned rt_flags) {
   using R = RobotFields;
   using FT = Feat<F>;
   constexpr int RPW = 64 / L; // robots per wavefront
-  constexpr int WPB = 4;      // waves per workgroup (max)
   __shared__ SharedConsts<L, NJ> C;
-  __shared__ double rob_d[WPB][R::COUNT * RPW];
-  __shared__ int32_t rob_i[WPB][R::I_COUNT * RPW];
-  __shared__ double park_d[WPB][PK_COUNT * 64];
+  // per-wave LDS (robot tile, its int words, park strip) is dynamic: sized for the workgroup actually launched (1 wave per
+  // workgroup for small batches, 4 for large ones), cycle_lds_bytes_per_wave() each
+  extern __shared__ double wave_lds[];
+  constexpr int kWaveDoubles = R::COUNT * RPW + PK_COUNT * 64 + (R::I_COUNT * RPW + 1) / 2;
 #ifdef SHC_TIMING
   const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
 #endif
   SHC_TICK(0);
+  // Launch-uniform run-time facts the host knows (kernel argument = SGPR from the first instruction on, no load to wait for):
+  // RT_MANUAL_LIVE - some pose input / reset mode / injected state has ever been given to this engine.  Until then every
+  // robot's manual pose is the identity and stays it, so the manual-pose group of the robot tile is neither loaded nor
+  // evaluated nor stored.
+  const bool manual_live = (rt_flags & RT_MANUAL_LIVE) != 0;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -225,11 +231,12 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   const bool live = grp < robots_here;
   if (grp >= robots_here) grp = robots_here > 0 ? robots_here - 1 : 0;
   const uint32_t slot = uint32_t(wave * 64 + grp * L + leg);
-  Park pk{park_d[wib], lane};
+  double *const my_lds = wave_lds + wib * kWaveDoubles;
+  Park pk{my_lds + R::COUNT * RPW, lane};
   LegRegs<NJ> s;
   const CycleParams &GP = gc->P; // feature flags of the generic specialisation: read from HBM before the LDS copy lands
-  double *tile = rob_d[wib];
-  int32_t *tile_i = rob_i[wib];
+  double *tile = my_lds;
+  int32_t *tile_i = reinterpret_cast<int32_t *>(my_lds + R::COUNT * RPW + PK_COUNT * 64);
   double *gtile = st.robd + wave * (R::COUNT * RPW);
   int32_t *gtile_i = st.robi + wave * (R::I_COUNT * RPW);
   // ---- prologue: every global load of this wave is issued before the first wait, so the HBM / L2 latencies overlap:
@@ -266,7 +273,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   int32_t t_int[int_iters];
   if (any_robot) {
     load_rob_fields<RPW, 0, R::CORE_END>(t_core, gtile, lane);
-    if (FT::manual(GP)) load_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, gtile, lane);
+    if (FT::manual(GP) && manual_live) load_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, gtile, lane);
     if (FT::imu(GP)) load_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, gtile, lane);
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
@@ -289,7 +296,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   }
   if (any_robot) {
     put_rob_fields<RPW, 0, R::CORE_END>(t_core, tile, lane);
-    if (FT::manual(GP)) put_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, tile, lane);
+    if (FT::manual(GP) && manual_live) put_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, tile, lane);
     if (FT::imu(GP)) put_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, tile, lane);
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
@@ -319,7 +326,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   LegOut out;
   SHC_TICK(1);
   unsigned dirty = 0;
-  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty);
+  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live);
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
@@ -333,7 +340,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   // state planes back to this wave's HBM tile (the inputs VIN / WIN / GYRO / IMUQ are not written back)
   store_rob_fields<RPW, 0, R::PLANE>(tile, gtile, lane);
   if (dirty & DIRTY_WALK_PLANE) store_rob_fields<RPW, R::PLANE, R::VIN>(tile, gtile, lane); // walk plane + origin walk-plane pose
-  if (FT::manual(P) && (dirty & DIRTY_MANUAL)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
+  if (FT::manual(P) && manual_live && (dirty & DIRTY_MANUAL)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
   if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
   store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
@@ -545,6 +552,7 @@ struct shc_engine {
   double *d_stage;     // staging for host <-> device conversions
   size_t stage_bytes;
   uint32_t features;
+  uint32_t rt_flags; // RT_* facts passed to every launch
 };
 
 template <int L, int NJ>
@@ -1221,6 +1229,7 @@ extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_ef
 extern "C" int shc_engine_set_pose_input(shc_engine *e, const double *translation_velocity, const double *rotation_velocity,
                                          int on_device) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (translation_velocity || rotation_velocity) e->rt_flags |= RT_MANUAL_LIVE;
   int rc = scatter_rob(e, translation_velocity, 3, RobotFields::TVI, on_device);
   if (rc != SHC_OK) return rc;
   return scatter_rob(e, rotation_velocity, 3, RobotFields::RVI, on_device);
@@ -1228,7 +1237,10 @@ extern "C" int shc_engine_set_pose_input(shc_engine *e, const double *translatio
 
 template <int L, int NJ, unsigned F>
 static void launch_cycle(shc_engine *e, unsigned grid, int block, int n_cycles) {
-  shc_cycle_kernel<L, NJ, F><<<dim3(grid), dim3(block), 0, e->stream>>>(e->st, (const SharedConsts<L, NJ> *)e->d_consts, n_cycles);
+  constexpr int RPW = 64 / L;
+  constexpr size_t wave_bytes = size_t(RobotFields::COUNT * RPW + PK_COUNT * 64 + (RobotFields::I_COUNT * RPW + 1) / 2) * 8;
+  shc_cycle_kernel<L, NJ, F><<<dim3(grid), dim3(block), wave_bytes * (block / 64), e->stream>>>(e->st, (const SharedConsts<L, NJ> *)e->d_consts, n_cycles,
+                                                                                              e->rt_flags);
 }
 
 // Pick the kernel specialisation: the BASELINE.json configurations get feature-exact kernels (dead features cost
@@ -1260,6 +1272,7 @@ static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cyc
 extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode, int on_device) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (!mode) return SHC_OK;
+  e->rt_flags |= RT_MANUAL_LIVE;
   HIP_TRY(hipSetDevice(e->device));
   const int32_t *d = mode;
   if (!on_device) {
@@ -1513,6 +1526,7 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
   if (!e || (!out && !in)) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   if (first < 0 || count < 0 || first + count > e->n) return fail(SHC_ERR_INVALID_ARG, "instance range out of bounds");
   if (count == 0) return SHC_OK;
+  if (in) e->rt_flags |= RT_MANUAL_LIVE; // an injected state may carry any manual pose
   HIP_TRY(hipSetDevice(e->device));
   shc_instance_state *d = nullptr;
   const size_t bytes = size_t(count) * sizeof(shc_instance_state);

@@ -22,7 +22,6 @@ from test_gpu_parity import apply, make_inputs
 
 pytestmark = pytest.mark.gpu
 TOL_Q = 1e-12   # rad after one cycle from identical state (measured: 1e-16 ... 1e-14)
-TOL_X = 1e-12   # m / dimensionless state
 
 
 @pytest.fixture(scope="module")
@@ -40,6 +39,14 @@ def as_np(states):
 def compare_records(p, features, g, o, tol_q=TOL_Q):
     """g: engine records, o: oracle records (numpy structured arrays).  Returns max |dq|."""
     L, D = p.leg_count, p.leg_dof[0]
+    # Teacher forcing equalises the STATE; the launch constants (velocity / acceleration limit tables) still come from each
+    # side's own init chain and agree to 1e-9 relative (1e-10 for 3- and 4-joint legs: tests/test_host_tables_and_abi.py), so
+    # limited velocities - and the strides / tip targets scaled from them - inherit that relative difference.  The unconstrained
+    # redundant 5-joint chain's start-up configuration differs by 7e-8 rad between any two builds (test_oracle_conditioning.py),
+    # its workspace radii by 1e-10: 1e-12 m absolute elsewhere, 5e-11 m there.
+    TOL_X = 5e-11 if (D == 5 and not p.gravity_aligned_tips) else 1e-12
+    if TOL_X > 1e-12:
+        tol_q = max(tol_q, 2e-11)  # the IK target moves with the tip targets
     gl, ol = g["leg"][:, :L], o["leg"][:, :L]
     dq = np.abs(gl["joint_position"][..., :D] - ol["joint_position"][..., :D])
     assert np.isfinite(gl["joint_position"]).all()
