@@ -309,6 +309,35 @@ typedef struct shc_leg_state_msg {
 int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, shc_leg_state_msg *legs);
 
 /*
+ * Per-leg methods of class Leg (model.h:448-492), batched.  The reference's cold paths call them on their own - workspace
+ * search (model.cpp:309-510), start-up / shut-down sequences (pose_controller.cpp:145-805), leg manipulation
+ * (state_controller.cpp:590-700); the fused cycle runs the same arithmetic in registers.  They act on the engine's joint state:
+ * a cycle launched afterwards continues from the joints these calls left.
+ * Selection: instances [first, first + count), leg = -1 for every leg or one leg id.  Arrays hold one row per selected
+ * (instance, leg) in instance-major order: [count][legs or 1][K].  Host pointers unless on_device != 0.
+ */
+/* Leg::setDesiredTipPose(tip_pose, apply_delta) (model.h:448, model.cpp:653): tip_pose rows are (x,y,z,qw,qx,qy,qz), an
+ * all-zero quaternion = UNDEFINED_ROTATION (position-only IK); tip_pose == NULL = the default argument Pose::Undefined() =
+ * "take the poser's tip pose"; apply_delta adds Leg::admittance_delta_. */
+int shc_leg_set_desired_tip_pose(shc_engine *e, int64_t first, int64_t count, int leg, const double *tip_pose, int apply_delta, int on_device);
+/* Leg::solveIK(delta, solve_rotation) (model.h:470, model.cpp:726): delta rows are the 6-vector (position delta, rotation
+ * delta) in the leg (joint 1) frame; joint_delta rows [dof].  Reads the joint state, changes nothing. */
+int shc_leg_solve_ik(shc_engine *e, int64_t first, int64_t count, int leg, const double *delta, int solve_rotation, double *joint_delta,
+                     int on_device);
+/* Leg::updateJointPositions(delta, simulation) (model.h:477, model.cpp:799): integrates joint_delta (velocity clamp unless
+ * simulation, position clamp per parameters); limit_proximity rows [1] (may be NULL) receive the returned minimum proximity. */
+int shc_leg_update_joint_positions(shc_engine *e, int64_t first, int64_t count, int leg, const double *joint_delta, int simulation,
+                                   double *limit_proximity, int on_device);
+/* Leg::applyIK(simulation) (model.h:485, model.cpp:861) towards the stored desired tip pose: position solve, rotation solve
+ * when the desired rotation is defined, unconstrained retry, 5 mm deviation check, calculateTipForce.  ik_result rows [1]
+ * (may be NULL): limit proximity, 0 on failure. */
+int shc_leg_apply_ik(shc_engine *e, int64_t first, int64_t count, int leg, int simulation, double *ik_result, int on_device);
+/* Leg::applyFK(set_current, use_actual) (model.h:492, model.cpp:945): tip pose rows (x,y,z,qw,qx,qy,qz) in the robot frame from
+ * the desired joint positions, or from joint_position rows [dof] when given (use_actual: the measured positions of
+ * jointStatesCallback, which the engine does not store - this is what LegState.actual_tip_pose needs, state_controller.cpp:839). */
+int shc_leg_apply_fk(shc_engine *e, int64_t first, int64_t count, int leg, const double *joint_position, double *tip_pose, int on_device);
+
+/*
  * Full controller state of one instance (checkpoint / restore, state injection).  Everything the next control cycle reads
  * that is not an input set through the shc_engine_set_* calls above: restoring a snapshot and replaying the same inputs
  * reproduces the run bit for bit.  Members are named after the reference members they hold.

@@ -2656,6 +2656,40 @@ void orc_batch_set_state(orc_batch *b, const shc_instance_state *states)
   for (int64_t i = 0; i < b->n; ++i) orc_set_state(&b->robots[i], &states[i]);
 }
 
+/* ------------------------------------------------------------------------------------ per-leg Leg methods on a robot
+ * (model.h:448-492) - counterparts of the engine's shc_leg_* entry points */
+void orc_leg_set_desired_tip_pose(orc_robot *r, int l, const double *pose7, int apply_delta)
+{
+  leg_set_desired_tip_pose(&r->leg[l], pose7 ? get_pose7(pose7) : orc_pose_undefined(), apply_delta);
+}
+void orc_leg_solve_ik(orc_robot *r, int l, const double delta[6], int solve_rotation, double *dq)
+{
+  leg_solve_ik(&r->leg[l], delta, solve_rotation, dq);
+}
+double orc_leg_update_joint_positions(orc_robot *r, int l, const double *dq, int simulation)
+{
+  return leg_update_joint_positions(r, &r->leg[l], dq, simulation);
+}
+double orc_leg_apply_ik(orc_robot *r, int l, int simulation)
+{
+  if (!simulation) r->leg[l].ik_failed = 0;
+  return leg_apply_ik(r, &r->leg[l], simulation);
+}
+/* Leg::applyFK(set_current, use_actual) (model.cpp:945-988): joint_position != NULL is use_actual with set_current = false */
+void orc_leg_apply_fk(orc_robot *r, int l, const double *joint_position, double pose7[7])
+{
+  if (!joint_position)
+  {
+    put_pose7(pose7, leg_apply_fk(r, &r->leg[l]));
+    return;
+  }
+  leg_t *copy = (leg_t *)malloc(sizeof(leg_t));
+  *copy = r->leg[l];
+  for (int j = 0; j < copy->joint_count; ++j) copy->joint[j].desired_position = joint_position[j];
+  put_pose7(pose7, leg_apply_fk(r, copy));
+  free(copy);
+}
+
 /* ------------------------------------------------------------------------------------ unit-level entry points */
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out) { *out = generate_step_cycle(p); }
 void orc_test_quat_to_euler(const double q[4], int intrinsic, double out[3])

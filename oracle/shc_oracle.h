@@ -94,6 +94,13 @@ void orc_set_state(orc_robot *r, const shc_instance_state *in);
 void orc_batch_get_state(orc_batch *b, shc_instance_state *states /* [n] */);
 void orc_batch_set_state(orc_batch *b, const shc_instance_state *states /* [n] */);
 
+/* Per-leg Leg methods (model.h:448-492) on leg `leg` of a robot: what the engine's shc_leg_* entry points are checked against. */
+void orc_leg_set_desired_tip_pose(orc_robot *r, int leg, const double *pose7 /* NULL = Pose::Undefined() */, int apply_delta);
+void orc_leg_solve_ik(orc_robot *r, int leg, const double delta[6], int solve_rotation, double *joint_delta);
+double orc_leg_update_joint_positions(orc_robot *r, int leg, const double *joint_delta, int simulation);
+double orc_leg_apply_ik(orc_robot *r, int leg, int simulation);
+void orc_leg_apply_fk(orc_robot *r, int leg, const double *joint_position /* NULL = desired */, double pose7[7]);
+
 /* ---- unit-level entry points for the KAT / cross-check tests (thin wrappers over the static code) ---- */
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out);
 void orc_test_quat_to_euler(const double q_wxyz[4], int intrinsic, double out[3]);

@@ -110,7 +110,10 @@ struct Fields {
                        FORCE_IN = TF_END, EFFORT_IN = FORCE_IN + 4,    // inputs
                        POSER_TIP = EFFORT_IN + NJE, MODEL_TIP = POSER_TIP + 4, ADM_DELTA = MODEL_TIP + 4, // outputs
                        // tip directions (x axis of LegStepper::origin_tip_pose_ / current_tip_pose_ rotations), gravity-aligned tips only
-                       ORG_DIR = ADM_DELTA + 4, CUR_DIR = ORG_DIR + 3, COUNT = CUR_DIR + 3;
+                       ORG_DIR = ADM_DELTA + 4, CUR_DIR = ORG_DIR + 3,
+                       // Leg::desired_tip_pose_ as the per-leg API holds it between shc_leg_set_desired_tip_pose and shc_leg_apply_ik:
+                       // position (3) + "rotation defined" flag, x axis of the rotation (3) + pad.  The fused cycle never touches these.
+                       DES_TIP = CUR_DIR + 3, DES_DIR = DES_TIP + 4, COUNT = DES_DIR + 4;
   static_assert(CORE_END % 2 == 0 && SORG % 2 == 0 && COUNT % 2 == 0, "field groups must align to 16-byte planes");
 };
 // element index of field f of slot `slot` in the plane array (n_slots slots per plane)

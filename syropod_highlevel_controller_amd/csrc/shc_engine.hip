@@ -366,6 +366,7 @@ __device__ __forceinline__ int64_t slot_of(int64_t rob, int leg, int L) {
 }
 
 #include "shc_snapshot.hpp" // get_state / set_state kernels (use rob_index / slot_of)
+#include "shc_leg_api.hpp"  // per-leg Leg methods, batched
 
 // AoS [n][L][K] -> leg fields f0..f0+K-1
 __global__ void scatter_leg_kernel(const double *src, double *legd, int64_t n_slots, int64_t n, int L, int K, int f0) {
@@ -1517,6 +1518,131 @@ extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, sh
     for (int k = 0; k < 7; ++k) m.auto_pose[k] = e->params.auto_posing ? std::nan("") : (k == 3 ? 1.0 : 0.0);
   }
   return SHC_OK;
+}
+
+// ---- per-leg Leg API (include/shc_batch.h "Per-leg methods"): host arrays travel through temporary device buffers
+struct LegCall {
+  shc_engine *e;
+  LegSel sel;
+  int64_t rows; // count * selected legs
+  std::vector<void *> temps;
+  ~LegCall() {
+    for (void *p : temps) (void)hipFree(p);
+  }
+  int init(shc_engine *eng, int64_t first, int64_t count, int leg) {
+    e = eng;
+    if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+    if (first < 0 || count < 0 || first + count > e->n) return fail(SHC_ERR_INVALID_ARG, "instance range out of bounds");
+    if (leg < -1 || leg >= e->L) return fail(SHC_ERR_INVALID_ARG, "leg out of range (-1 = every leg)");
+    sel = LegSel{first, count, leg, e->L};
+    rows = count * (leg < 0 ? e->L : 1);
+    HIP_TRY(hipSetDevice(e->device));
+    return SHC_OK;
+  }
+  // device view of an input array of `width` doubles per row
+  int in(const double *src, int width, int on_device, const double **d) {
+    *d = src;
+    if (!src || on_device || rows == 0) return SHC_OK;
+    void *t = nullptr;
+    HIP_TRY(hipMalloc(&t, size_t(rows) * width * 8));
+    temps.push_back(t);
+    HIP_TRY(hipMemcpyAsync(t, src, size_t(rows) * width * 8, hipMemcpyHostToDevice, e->stream));
+    *d = static_cast<const double *>(t);
+    return SHC_OK;
+  }
+  int out(double *dst, int width, int on_device, double **d) {
+    *d = dst;
+    if (!dst || on_device || rows == 0) return SHC_OK;
+    void *t = nullptr;
+    HIP_TRY(hipMalloc(&t, size_t(rows) * width * 8));
+    temps.push_back(t);
+    *d = static_cast<double *>(t);
+    return SHC_OK;
+  }
+  int finish(double *dst, const double *d, int width, int on_device) {
+    HIP_TRY(hipGetLastError());
+    if (dst && !on_device && rows) HIP_TRY(hipMemcpyAsync(dst, d, size_t(rows) * width * 8, hipMemcpyDeviceToHost, e->stream));
+    if (!temps.empty()) HIP_TRY(hipStreamSynchronize(e->stream)); // the temporaries are freed on return
+    return SHC_OK;
+  }
+  dim3 grid() const { return dim3((unsigned)((rows + 63) / 64)); }
+};
+template <class Fn>
+static int leg_dispatch(shc_engine *e, Fn &&fn) {
+#define CALL(L_, NJ_) fn(std::integral_constant<int, L_>{}, std::integral_constant<int, NJ_>{})
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  return SHC_OK;
+}
+#define LEG_KERNEL(KERNEL, ...)                                                                                              \
+  leg_dispatch(e, [&](auto l_, auto nj_) {                                                                                   \
+    constexpr int L_ = decltype(l_)::value, NJ_ = decltype(nj_)::value;                                                      \
+    if (c.rows) KERNEL<L_, NJ_><<<c.grid(), dim3(64), 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, c.sel, __VA_ARGS__); \
+  })
+
+extern "C" int shc_leg_set_desired_tip_pose(shc_engine *e, int64_t first, int64_t count, int leg, const double *tip_pose, int apply_delta,
+                                            int on_device) {
+  LegCall c;
+  int rc = c.init(e, first, count, leg);
+  if (rc != SHC_OK) return rc;
+  if (!tip_pose && (rc = derive_tips(e)) != SHC_OK) return rc; // Pose::Undefined() = "the poser's tip pose" (model.cpp:657)
+  const double *d;
+  if ((rc = c.in(tip_pose, 7, on_device, &d)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_set_desired_kernel, d, apply_delta, e->params.admittance_control, e->cp.gravity_aligned)) != SHC_OK) return rc;
+  return c.finish(nullptr, nullptr, 0, on_device);
+}
+
+extern "C" int shc_leg_solve_ik(shc_engine *e, int64_t first, int64_t count, int leg, const double *delta, int solve_rotation,
+                                double *joint_delta, int on_device) {
+  if (!delta || !joint_delta) return fail(SHC_ERR_INVALID_ARG, "delta / joint_delta is NULL");
+  LegCall c;
+  int rc = c.init(e, first, count, leg);
+  if (rc != SHC_OK) return rc;
+  const double *d;
+  double *o;
+  if ((rc = c.in(delta, 6, on_device, &d)) != SHC_OK || (rc = c.out(joint_delta, e->NJ, on_device, &o)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_solve_ik_kernel, d, solve_rotation, o)) != SHC_OK) return rc;
+  return c.finish(joint_delta, o, e->NJ, on_device);
+}
+
+extern "C" int shc_leg_update_joint_positions(shc_engine *e, int64_t first, int64_t count, int leg, const double *joint_delta, int simulation,
+                                              double *limit_proximity, int on_device) {
+  if (!joint_delta) return fail(SHC_ERR_INVALID_ARG, "joint_delta is NULL");
+  LegCall c;
+  int rc = c.init(e, first, count, leg);
+  if (rc != SHC_OK) return rc;
+  const double *d;
+  double *o;
+  if ((rc = c.in(joint_delta, e->NJ, on_device, &d)) != SHC_OK || (rc = c.out(limit_proximity, 1, on_device, &o)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_update_joints_kernel, d, simulation, o, e->params.time_delta, e->params.clamp_joint_velocities,
+                       e->params.clamp_joint_positions)) != SHC_OK)
+    return rc;
+  return c.finish(limit_proximity, o, 1, on_device);
+}
+
+extern "C" int shc_leg_apply_ik(shc_engine *e, int64_t first, int64_t count, int leg, int simulation, double *ik_result, int on_device) {
+  LegCall c;
+  int rc = c.init(e, first, count, leg);
+  if (rc != SHC_OK) return rc;
+  double *o;
+  if ((rc = c.out(ik_result, 1, on_device, &o)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_apply_ik_kernel, simulation, o, e->params.time_delta, e->params.clamp_joint_velocities,
+                       e->params.clamp_joint_positions, e->cp.tip_force, e->params.force_gain)) != SHC_OK)
+    return rc;
+  return c.finish(ik_result, o, 1, on_device);
+}
+
+extern "C" int shc_leg_apply_fk(shc_engine *e, int64_t first, int64_t count, int leg, const double *joint_position, double *tip_pose,
+                                int on_device) {
+  if (!tip_pose) return fail(SHC_ERR_INVALID_ARG, "tip_pose is NULL");
+  LegCall c;
+  int rc = c.init(e, first, count, leg);
+  if (rc != SHC_OK) return rc;
+  const double *d;
+  double *o;
+  if ((rc = c.in(joint_position, e->NJ, on_device, &d)) != SHC_OK || (rc = c.out(tip_pose, 7, on_device, &o)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_apply_fk_kernel, d, o)) != SHC_OK) return rc;
+  return c.finish(tip_pose, o, 7, on_device);
 }
 
 extern "C" int64_t shc_sizeof_instance_state(void) { return (int64_t)sizeof(shc_instance_state); }

@@ -205,6 +205,64 @@ SHC_HD void ik_step_rotation(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[N
   spd_solve<NJ, EXACT>(a, dq);
 }
 
+// Leg::solveIK for an arbitrary 6-vector delta (model.cpp:726-795), the general form behind ik_step_cols / ik_step_rotation:
+// with solve_rotation the Jacobian keeps its angular rows (joint axes), without it they are zero and the angular part of
+// delta has no effect.  Push-through form dq = (J^T J + l^2 I)^-1 (J^T delta + l^2 g).
+template <int NJ, bool EXACT = false, class LC>
+SHC_HD void solve_ik_delta(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[NJ], const double (&q)[NJ], const double (&qd)[NJ], V3 dp, V3 dw,
+                           bool solve_rotation, double (&dq)[NJ]) {
+  double pg[NJ], vg[NJ];
+  double pcost = 0.0, vcost = 0.0;
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    double e = (q[i] - lc.jcentre[i]) * lc.jw_range[i];
+    pcost += e * e;
+    pg[i] = -e * lc.jw_range[i];
+    double v = qd[i] * lc.jw_vrange[i];
+    vcost += v * v;
+    vg[i] = -v * lc.jw_vrange[i];
+  }
+  double ps = fast_rsqrt<EXACT>(pcost), vs = fast_rsqrt<EXACT>(vcost);
+  ps = pcost == 0.0 ? 0.0 : ps;
+  vs = vcost == 0.0 ? 0.0 : vs;
+  const double l2 = kDls * kDls;
+  double a[NJ][NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + (solve_rotation ? dot(c.z[i], c.z[j]) : 0.0);
+    a[i][i] += l2;
+    double g = 0.25 * (pg[i] * ps) + 0.75 * (vg[i] * vs);
+    dq[i] = dot(lin[i], dp) + (solve_rotation ? dot(c.z[i], dw) : 0.0) + l2 * g;
+  }
+  spd_solve<NJ, EXACT>(a, dq);
+}
+
+// Tip::getPoseRobotFrame (model.h:684): full tip pose (robot frame) of the chain at joint angles q; the rotation is the
+// quaternion of R1 * R_chain as Pose::transform builds it (pose.h:144).
+template <int NJ, class LC>
+SHC_HD Pose fk_tip_pose(const LC &lc, const double (&q)[NJ]) {
+  double X[3] = {1, 0, 0}, Y[3] = {0, 1, 0}, Z[3] = {0, 0, 1}, P[3] = {0, 0, 0};
+  for (int k = 0; k < NJ; ++k) {
+    double s, co;
+    sincos_joint(lc.link_th[k] + q[k], &s, &co);
+    const double sa = lc.link_sa[k], ca = lc.link_ca[k], r = lc.link_r[k], d = lc.link_d[k];
+    for (int a = 0; a < 3; ++a) {
+      const double xn = X[a] * co + Y[a] * s, t = Y[a] * co - X[a] * s;
+      const double yn = t * ca + Z[a] * sa, zn = Z[a] * ca - t * sa;
+      P[a] = P[a] + xn * r + Z[a] * d;
+      X[a] = xn, Y[a] = yn, Z[a] = zn;
+    }
+  }
+  double m[9]; // R1 * [X Y Z]
+  for (int i = 0; i < 3; ++i) {
+    m[i * 3 + 0] = lc.r1[i * 3] * X[0] + lc.r1[i * 3 + 1] * X[1] + lc.r1[i * 3 + 2] * X[2];
+    m[i * 3 + 1] = lc.r1[i * 3] * Y[0] + lc.r1[i * 3 + 1] * Y[1] + lc.r1[i * 3 + 2] * Y[2];
+    m[i * 3 + 2] = lc.r1[i * 3] * Z[0] + lc.r1[i * 3 + 1] * Z[1] + lc.r1[i * 3 + 2] * Z[2];
+  }
+  return Pose{tip_robot_frame(lc, V3{P[0], P[1], P[2]}), normalized(quat_from_matrix(m))};
+}
+
 // axis * angle of the shortest rotation taking the current tip direction to the desired one (model.cpp:884-893)
 SHC_HD V3 tip_rotation_delta(V3 current_dir, V3 desired_dir) { return angle_axis_vector(normalized(from_two_vectors(current_dir, desired_dir))); }
 

@@ -1,0 +1,210 @@
+// shc_leg_api.hpp — the reference's per-leg Leg methods (model.h:448-492), batched over (instance, leg):
+//   Leg::setDesiredTipPose :448 (model.cpp:653)    Leg::solveIK :470 (model.cpp:726)    Leg::updateJointPositions :477 (model.cpp:799)
+//   Leg::applyIK :485 (model.cpp:861)              Leg::applyFK :492 (model.cpp:945)
+// The reference's cold paths call these on their own (workspace search model.cpp:309-510, sequences pose_controller.cpp:
+// 145-805, leg manipulation state_controller.cpp:590-700); inside the fused cycle kernel the same shc_leg.hpp functions run
+// in registers.  One thread per (instance, leg); state is read from / written to the engine's SoA planes, so a cycle launched
+// afterwards continues from the joints these calls left.
+#pragma once
+
+#include "shc_cycle.hpp"
+
+namespace shc {
+
+struct LegSel {
+  int64_t first, count; // instances [first, first + count)
+  int leg;              // -1: every leg, else this leg only
+  int L;
+  __device__ __forceinline__ int legs() const { return leg < 0 ? L : 1; }
+  // thread t -> (instance, leg); returns false past the end
+  __device__ __forceinline__ bool map(int64_t t, int64_t &rob, int &l) const {
+    const int nl = legs();
+    if (t >= count * nl) return false;
+    rob = first + t / nl;
+    l = leg < 0 ? int(t % nl) : leg;
+    return true;
+  }
+};
+
+template <int NJ>
+struct LegIO {
+  const DevState &st;
+  int64_t slot;
+  __device__ __forceinline__ double get(int f) const { return st.legd[leg_field_index(f, slot, st.n_slots)]; }
+  __device__ __forceinline__ void put(int f, double v) const { st.legd[leg_field_index(f, slot, st.n_slots)] = v; }
+  __device__ __forceinline__ V3 get3(int f) const { return V3{get(f), get(f + 1), get(f + 2)}; }
+  __device__ __forceinline__ void put3(int f, V3 v) const {
+    put(f, v.x);
+    put(f + 1, v.y);
+    put(f + 2, v.z);
+  }
+  __device__ __forceinline__ void joints(double (&q)[NJ], double (&qd)[NJ]) const {
+    for (int j = 0; j < NJ; ++j) {
+      q[j] = get(Fields<NJ>::Q + j);
+      qd[j] = get(Fields<NJ>::QD + j);
+    }
+  }
+  __device__ __forceinline__ void put_joints(const double (&q)[NJ], const double (&qd)[NJ]) const {
+    for (int j = 0; j < NJ; ++j) {
+      put(Fields<NJ>::Q + j, q[j]);
+      put(Fields<NJ>::QD + j, qd[j]);
+    }
+  }
+};
+
+// Leg::setDesiredTipPose(tip_pose, apply_delta): tip_pose == NULL is the reference's default argument Pose::Undefined(),
+// "use the poser's tip pose" (model.cpp:657-660; POSER_TIP must have been derived, see derive_tips_kernel).
+template <int L_, int NJ>
+__global__ void leg_set_desired_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *tip_pose, int apply_delta,
+                                       int have_adm, int gravity_aligned) {
+  using FD = Fields<NJ>;
+  using R = RobotFields;
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  V3 pos, dir{0, 0, 0};
+  bool defined = false;
+  if (tip_pose) {
+    const double *p = tip_pose + t * 7;
+    pos = V3{p[0], p[1], p[2]};
+    const Quat r{p[3], p[4], p[5], p[6]};
+    defined = !(r.w == 0.0 && r.x == 0.0 && r.y == 0.0 && r.z == 0.0); // != UNDEFINED_ROTATION (isApprox with the zero quaternion)
+    if (defined) dir = rotate(r, V3{1, 0, 0});
+  } else {
+    pos = io.get3(FD::POSER_TIP);
+    if (gravity_aligned && NJ > 3 && (st.legi[io.slot] & LW_ROTDEF)) { // pose.rotation^-1 * walker tip rotation (pose_controller.cpp:129-130)
+      const int rpw = 64 / sel.L;
+      const Quat cr{st.robd[rob_index(rob, R::CPOSE + 3, rpw, R::COUNT)], st.robd[rob_index(rob, R::CPOSE + 4, rpw, R::COUNT)],
+                    st.robd[rob_index(rob, R::CPOSE + 5, rpw, R::COUNT)], st.robd[rob_index(rob, R::CPOSE + 6, rpw, R::COUNT)]};
+      dir = rotate(inverse(cr), io.get3(FD::CUR_DIR));
+      defined = true;
+    }
+  }
+  if (apply_delta && have_adm) pos = pos + io.get3(FD::ADM_DELTA); // model.cpp:661
+  io.put3(FD::DES_TIP, pos);
+  io.put(FD::DES_TIP + 3, defined ? 1.0 : 0.0);
+  io.put3(FD::DES_DIR, dir);
+}
+
+template <int L_, int NJ>
+__global__ void leg_solve_ik_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *delta, int solve_rotation, double *out) {
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  const LegConst<NJ> &lc = gc->leg[l];
+  double q[NJ], qd[NJ], dq[NJ];
+  io.joints(q, qd);
+  Chain<NJ> ch;
+  fk_chain<NJ>(lc, q, ch); // the joint transforms the last applyFK left (model.cpp:731, :744)
+  V3 lin[NJ];
+  jacobian_columns<NJ>(ch, lin);
+  const double *d = delta + t * 6;
+  solve_ik_delta<NJ>(lc, ch, lin, q, qd, V3{d[0], d[1], d[2]}, V3{d[3], d[4], d[5]}, solve_rotation != 0, dq);
+  for (int j = 0; j < NJ; ++j) out[t * NJ + j] = dq[j];
+}
+
+template <int L_, int NJ>
+__global__ void leg_update_joints_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *delta, int simulation, double *prox_out,
+                                         double dt, int clamp_vel, int clamp_pos) {
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  const LegConst<NJ> &lc = gc->leg[l];
+  double q[NJ], qd[NJ], dq[NJ];
+  io.joints(q, qd);
+  for (int j = 0; j < NJ; ++j) dq[j] = delta[t * NJ + j];
+  const double prox = update_joints<NJ>(lc, dq, dt, 1.0 / dt, clamp_vel && !simulation, clamp_pos != 0, q, qd);
+  io.put_joints(q, qd);
+  if (prox_out) prox_out[t] = prox;
+}
+
+// Leg::applyIK(simulation) towards the stored desired tip pose, including the rotation-constrained pass, the unconstrained
+// retry and the closing calculateTipForce (model.cpp:861-941).
+template <int L_, int NJ>
+__global__ void leg_apply_ik_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, int simulation, double *result_out, double dt,
+                                    int clamp_vel, int clamp_pos, int tip_force, double force_gain) {
+  using FD = Fields<NJ>;
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  const LegConst<NJ> &lc = gc->leg[l];
+  double q[NJ], qd[NJ], dq[NJ];
+  io.joints(q, qd);
+  const V3 desired = io.get3(FD::DES_TIP);
+  bool constrained = io.get(FD::DES_TIP + 3) != 0.0;
+  const V3 desired_dir = io.get3(FD::DES_DIR);
+  const bool cv = clamp_vel && !simulation, cp = clamp_pos != 0;
+  const double inv_dt = 1.0 / dt;
+  Chain<NJ> ch;
+  V3 lin[NJ];
+  double success = 0.0;
+  bool failed = false;
+  V3 tf = io.get3(FD::TF);
+  for (int pass = 0; pass < 2; ++pass) { // second pass = the unconstrained retry (a nested applyIK, :932-936)
+    fk_chain<NJ>(lc, q, ch);
+    const V3 current_dir = ch.xe;
+    ik_step<NJ>(lc, ch, q, qd, desired, dq);
+    if (constrained) {
+      update_joints<NJ>(lc, dq, dt, inv_dt, false, cp, q, qd); // simulation = true (:883)
+      fk_chain<NJ>(lc, q, ch);
+      jacobian_columns<NJ>(ch, lin);
+      ik_step_rotation<NJ>(lc, ch, lin, q, qd, tip_rotation_delta(current_dir, base_rotate_inv(lc, desired_dir)), dq);
+    }
+    success = update_joints<NJ>(lc, dq, dt, inv_dt, cv, cp, q, qd);
+    fk_chain<NJ>(lc, q, ch);
+    const V3 e = tip_robot_frame(lc, ch.pe) - desired;
+    if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) {
+      success = 0.0;
+      failed = true;
+    }
+    const bool retry = constrained && success == 0.0;
+    if (!retry || pass == 1) {
+      if (tip_force) { // calculateTipForce closes every applyIK frame: once here, and once more for the outer frame after a retry
+        double effort[NJ];
+        for (int j = 0; j < NJ; ++j) effort[j] = io.get(FD::EFFORT_IN + j);
+        jacobian_columns<NJ>(ch, lin);
+        const V3 raw = tip_force_cols<NJ>(lc, ch, lin, effort);
+        tf = raw * (0.15 * force_gain) + tf * (1 - 0.15);
+        if (pass == 1) tf = raw * (0.15 * force_gain) + tf * (1 - 0.15);
+      }
+      break;
+    }
+    constrained = false; // desired_tip_pose_.rotation_ = UNDEFINED_ROTATION
+    io.put(FD::DES_TIP + 3, 0.0);
+  }
+  io.put_joints(q, qd);
+  if (tip_force) io.put3(FD::TF, tf);
+  if (!simulation) { // the deviation warning is the engine's IK-failure bit (model.cpp:921, not raised in simulation)
+    int w = st.legi[io.slot];
+    w = failed ? (w | LW_IKFAIL) : (w & ~LW_IKFAIL);
+    st.legi[io.slot] = w;
+  }
+  if (result_out) result_out[t] = success;
+}
+
+// Leg::applyFK: tip pose (robot frame) from the desired joint positions, or from `joint_position` when given (use_actual).
+template <int L_, int NJ>
+__global__ void leg_apply_fk_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *joint_position, double *tip_pose) {
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  double q[NJ], qd[NJ];
+  io.joints(q, qd);
+  if (joint_position)
+    for (int j = 0; j < NJ; ++j) q[j] = joint_position[t * NJ + j];
+  const Pose p = fk_tip_pose<NJ>(gc->leg[l], q);
+  double *o = tip_pose + t * 7;
+  o[0] = p.p.x, o[1] = p.p.y, o[2] = p.p.z, o[3] = p.r.w, o[4] = p.r.x, o[5] = p.r.y, o[6] = p.r.z;
+}
+
+} // namespace shc

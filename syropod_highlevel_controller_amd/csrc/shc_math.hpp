@@ -234,6 +234,31 @@ SHC_HD Quat from_two_vectors(V3 a, V3 b) {
   double invs = 1.0 / s;
   return Quat{s * 0.5, ax.x * invs, ax.y * invs, ax.z * invs};
 }
+// Quaterniond(Matrix3d) (Eigen 3.3: Shoemake's trace method), m row-major
+SHC_HD Quat quat_from_matrix(const double (&m)[9]) {
+  double q[3], w;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    w = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (m[7] - m[5]) * t;
+    q[1] = (m[2] - m[6]) * t;
+    q[2] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    w = (m[k * 3 + j] - m[j * 3 + k]) * t;
+    q[j] = (m[j * 3 + i] + m[i * 3 + j]) * t;
+    q[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+  }
+  return Quat{w, q[0], q[1], q[2]};
+}
 // Eigen::AngleAxisd(q).axis() * angle() (AngleAxis = QuaternionBase; model.cpp:892-893)
 SHC_HD V3 angle_axis_vector(Quat q) {
   double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);

@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_change_gait", "shc_stream_create", "shc_stream_destroy", "shc_engine_read_leg_state_msg",
     "shc_generate_tables_batch", "shc_engine_create_with_tables",
     "shc_sizeof_instance_state", "shc_engine_get_state", "shc_engine_set_state",
+    "shc_leg_set_desired_tip_pose", "shc_leg_solve_ik", "shc_leg_update_joint_positions", "shc_leg_apply_ik", "shc_leg_apply_fk",
 ]
 
 
@@ -126,6 +127,12 @@ def lib():
         L.shc_engine_change_gait.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
         L.shc_engine_get_virtual_stiffness.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.shc_sizeof_instance_state.restype = C.c_int64
+        sel = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+        L.shc_leg_set_desired_tip_pose.argtypes = sel + [C.c_void_p, C.c_int, C.c_int]
+        L.shc_leg_solve_ik.argtypes = sel + [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.shc_leg_update_joint_positions.argtypes = sel + [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.shc_leg_apply_ik.argtypes = sel + [C.c_int, C.c_void_p, C.c_int]
+        L.shc_leg_apply_fk.argtypes = sel + [C.c_void_p, C.c_void_p, C.c_int]
         L.shc_engine_get_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]
         L.shc_engine_set_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]
         # a binding whose struct layouts disagree with the library must not run
@@ -308,6 +315,46 @@ class BatchEngine:
     def set_state(self, states, first: int = 0):
         """Restore / inject the state of instances [first, first + len(states))."""
         _check(self.L.shc_engine_set_state(self.h, first, len(states), states), "set_state")
+
+    # -- per-leg Leg methods (model.h:448-492), batched: instances [first, first + count), leg = -1 for every leg
+    def _rows(self, first, count, leg):
+        count = self.n - first if count is None else count
+        return count, count * (self.legs if leg < 0 else 1)
+
+    def leg_set_desired_tip_pose(self, tip_pose=None, apply_delta=True, first=0, count=None, leg=-1):
+        count, rows = self._rows(first, count, leg)
+        a = _host(tip_pose)
+        assert a is None or a.size == rows * 7
+        _check(self.L.shc_leg_set_desired_tip_pose(self.h, first, count, leg, _p(a), int(apply_delta), 0), "leg_set_desired_tip_pose")
+
+    def leg_solve_ik(self, delta, solve_rotation=False, first=0, count=None, leg=-1):
+        count, rows = self._rows(first, count, leg)
+        a = _host(delta)
+        assert a.size == rows * 6
+        out = np.zeros((rows, self.dof))
+        _check(self.L.shc_leg_solve_ik(self.h, first, count, leg, _p(a), int(solve_rotation), _p(out), 0), "leg_solve_ik")
+        return out
+
+    def leg_update_joint_positions(self, joint_delta, simulation=False, first=0, count=None, leg=-1):
+        count, rows = self._rows(first, count, leg)
+        a = _host(joint_delta)
+        assert a.size == rows * self.dof
+        out = np.zeros(rows)
+        _check(self.L.shc_leg_update_joint_positions(self.h, first, count, leg, _p(a), int(simulation), _p(out), 0), "leg_update_joint_positions")
+        return out
+
+    def leg_apply_ik(self, simulation=False, first=0, count=None, leg=-1):
+        count, rows = self._rows(first, count, leg)
+        out = np.zeros(rows)
+        _check(self.L.shc_leg_apply_ik(self.h, first, count, leg, int(simulation), _p(out), 0), "leg_apply_ik")
+        return out
+
+    def leg_apply_fk(self, joint_position=None, first=0, count=None, leg=-1):
+        count, rows = self._rows(first, count, leg)
+        a = _host(joint_position)
+        out = np.zeros((rows, 7))
+        _check(self.L.shc_leg_apply_fk(self.h, first, count, leg, _p(a), _p(out), 0), "leg_apply_fk")
+        return out
 
     def odometry(self):
         """WalkController::getOdometryIdeal per instance: [n][7] (x, y, z, qw, qx, qy, qz)."""

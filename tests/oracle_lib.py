@@ -75,6 +75,13 @@ def lib():
         L.orc_batch_change_gait.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.orc_batch_change_gait.restype = C.c_int64
         L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
+        L.orc_leg_set_desired_tip_pose.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
+        L.orc_leg_solve_ik.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
+        L.orc_leg_update_joint_positions.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
+        L.orc_leg_update_joint_positions.restype = C.c_double
+        L.orc_leg_apply_ik.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_leg_apply_ik.restype = C.c_double
+        L.orc_leg_apply_fk.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
         L.orc_get_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
         L.orc_set_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
         L.orc_batch_get_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
@@ -241,6 +248,42 @@ class OracleBatch:
         ws = np.zeros(self.n, dtype=np.int32)
         self.L.orc_batch_get_body_state(self.h, _ptr(pose), _ptr(vel), _ptr(ws, _ip))
         return pose, vel, ws
+
+    # ---- per-leg Leg methods, every (robot, leg) in instance-major order like the engine's shc_leg_* calls
+    def _each(self):
+        for i in range(self.n):
+            r = self.L.orc_batch_robot(self.h, i)
+            for l in range(self.legs):
+                yield i * self.legs + l, r, l
+
+    def leg_set_desired_tip_pose(self, tip_pose=None, apply_delta=True):
+        a = None if tip_pose is None else np.ascontiguousarray(tip_pose, dtype=np.float64).reshape(-1, 7)
+        for k, r, l in self._each():
+            self.L.orc_leg_set_desired_tip_pose(r, l, None if a is None else _ptr(a[k]), int(apply_delta))
+
+    def leg_solve_ik(self, delta, solve_rotation=False):
+        a = np.ascontiguousarray(delta, dtype=np.float64).reshape(-1, 6)
+        D = self.dof // self.legs
+        out = np.zeros((self.n * self.legs, D))
+        for k, r, l in self._each():
+            self.L.orc_leg_solve_ik(r, l, _ptr(a[k]), int(solve_rotation), _ptr(out[k]))
+        return out
+
+    def leg_update_joint_positions(self, joint_delta, simulation=False):
+        D = self.dof // self.legs
+        a = np.ascontiguousarray(joint_delta, dtype=np.float64).reshape(-1, D)
+        return np.array([self.L.orc_leg_update_joint_positions(r, l, _ptr(a[k]), int(simulation)) for k, r, l in self._each()])
+
+    def leg_apply_ik(self, simulation=False):
+        return np.array([self.L.orc_leg_apply_ik(r, l, int(simulation)) for k, r, l in self._each()])
+
+    def leg_apply_fk(self, joint_position=None):
+        D = self.dof // self.legs
+        a = None if joint_position is None else np.ascontiguousarray(joint_position, dtype=np.float64).reshape(-1, D)
+        out = np.zeros((self.n * self.legs, 7))
+        for k, r, l in self._each():
+            self.L.orc_leg_apply_fk(r, l, None if a is None else _ptr(a[k]), _ptr(out[k]))
+        return out
 
     def get_state(self):
         """Full controller state of every robot as a ctypes array of InstanceState (shc_instance_state)."""
