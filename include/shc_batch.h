@@ -338,6 +338,34 @@ int shc_leg_apply_ik(shc_engine *e, int64_t first, int64_t count, int leg, int s
 int shc_leg_apply_fk(shc_engine *e, int64_t first, int64_t count, int leg, const double *joint_position, double *tip_pose, int on_device);
 
 /*
+ * Sequences: the LegPoser building blocks of PoseController's start-up / shut-down / stance-change
+ * procedures, batched with the same (first, count, leg) selection as the per-leg methods, and the direct start-up built on them.
+ */
+/* LegPoser::stepToPosition(target_tip_pose, target_pose, lift_height, time_to_step, apply_delta) (pose_controller.h:506,
+ * pose_controller.cpp:1571-1712), ONE iteration: the tip follows two quartic Bezier curves from where the leg stood when the
+ * sequence began to target_tip_pose (rows (x,y,z,qw,qx,qy,qz); NULL = Pose::Undefined() = stay, rotation undefined) while the
+ * body pose eases from the identity to target_pose ([count][7], one row per instance).  tip_pose rows receive
+ * LegPoser::current_tip_pose_ - hand them to shc_leg_set_desired_tip_pose + shc_leg_apply_ik as stepToNewStance (:521) and
+ * directStartup (:463) do; progress rows (int32, may be NULL) the returned percentage (100 = complete, the next call starts a
+ * new sequence). */
+int shc_leg_step_to_position(shc_engine *e, int64_t first, int64_t count, int leg, const double *target_tip_pose, const double *target_pose,
+                             double lift_height, double time_to_step, int apply_delta, double *tip_pose, int32_t *progress, int on_device);
+/* LegPoser::transitionConfiguration(transition_time) towards desired_configuration rows [dof] (pose_controller.h:498,
+ * pose_controller.cpp:1476-1567), ONE iteration: every joint follows a cubic Bezier from the configuration it had when the
+ * transition began. */
+int shc_leg_transition_configuration(shc_engine *e, int64_t first, int64_t count, int leg, const double *desired_configuration,
+                                     double transition_time, int32_t *progress, int on_device);
+/* PoseController::directStartup (pose_controller.cpp:463-517) for the batch.  shc_engine_begin_direct_startup puts every
+ * instance where StateController::init + initModel(true) leave a robot (joints at clamped(0, min, max), model.cpp:286-305,
+ * :1038; robot state PACKED "undefined", state_controller.cpp:213-222); each shc_engine_direct_startup call is one
+ * StateController::loop() of the PACKED -> READY transition: every joint advances along its transition to the default
+ * configuration (the joints the init chain's simulated start-up solve ended on).  *progress = 1..100; the call that returns
+ * 100 also runs the loop that enters RUNNING, after which the engine is exactly where shc_engine_create leaves it and the
+ * joints published on the way are the reference's start-up trajectory. */
+int shc_engine_begin_direct_startup(shc_engine *e);
+int shc_engine_direct_startup(shc_engine *e, int32_t *progress);
+
+/*
  * Full controller state of one instance (checkpoint / restore, state injection).  Everything the next control cycle reads
  * that is not an input set through the shc_engine_set_* calls above: restoring a snapshot and replaying the same inputs
  * reproduces the run bit for bit.  Members are named after the reference members they hold.

@@ -7,13 +7,18 @@
 //     poser_->updateStance();                                  pose_controller.h:157
 //     model_->updateModel();                                   model.h:163
 // and then reads Joint::desired_position_ / desired_velocity_ (state_controller.cpp:777-805) and the LegState fields
-// (:809-893).  This façade keeps those class and method names so the node's loop compiles against it unchanged in
-// shape: the five calls record their inputs and the LAST one of the cycle (Model::updateModel) launches the fused
-// HIP cycle kernel for a batch of one (or for instance `index` of a larger batch that the caller steps itself).
+// (:809-893); its cold paths call the per-leg methods Leg::setDesiredTipPose / solveIK / updateJointPositions / applyIK /
+// applyFK (model.h:448-492) directly.  This façade keeps those class names, method names, argument order and return
+// values so the node's code compiles against it unchanged in shape: the five per-cycle calls record their inputs and the
+// LAST one of the cycle (Model::updateModel) launches the fused HIP cycle kernel for a batch of one (a larger batch is
+// driven through the C ABI arrays; its instance `index` can still be read through these classes).
 //
-// Types: the reference's signatures use Eigen (Vector2d/Vector3d/Quaterniond) and its own Pose; neither Eigen nor ROS is
-// a dependency of this repository, so the façade is templated on "anything indexable" and ships tiny PODs.  A ROS
-// host passes its Eigen objects directly (Eigen vectors are indexable); see INTEGRATION.md.
+// Types: the reference's signatures use Eigen (Vector2d / Vector3d / VectorXd / MatrixXd / Quaterniond) and its own Pose;
+// neither Eigen nor ROS is a dependency of this repository, so vector arguments are templated on "anything indexable"
+// (Eigen objects qualify) and the header ships tiny PODs.  See INTEGRATION.md.
+//
+// Read-back is lazy: a cycle only marks the cached outputs stale; the first getter of a group (joints, leg state, body
+// state, odometry, stiffness) fetches that group once.
 #pragma once
 
 #include "shc_batch.h"
@@ -26,6 +31,9 @@
 
 namespace shc_facade {
 
+// parameters_and_states.h:25
+enum RobotState { PACKED, READY, RUNNING, ROBOT_STATE_COUNT, UNKNOWN = -1, OFF = -2 };
+
 struct Vector3 {
   double v[3];
   double &operator[](int i) { return v[i]; }
@@ -37,32 +45,24 @@ struct Quaternion {
 struct Pose { // include/syropod_highlevel_controller/pose.h:17
   Vector3 position_;
   Quaternion rotation_;
+  // pose.h:206: UNDEFINED_POSITION (UNASSIGNED_VALUE x 3, standard_includes.h:52,55) + UNDEFINED_ROTATION (0, 0, 0, 0)
+  static Pose Undefined() { return Pose{{{2147483647.0, 2147483647.0, 2147483647.0}}, {0, 0, 0, 0}}; }
+  bool isUndefined() const {
+    return position_[0] == 2147483647.0 && position_[1] == 2147483647.0 && position_[2] == 2147483647.0 && rotation_.w == 0 &&
+           rotation_.x == 0 && rotation_.y == 0 && rotation_.z == 0;
+  }
 };
 
 inline void check(int rc, const char *what) {
   if (rc != SHC_OK) throw std::runtime_error(std::string(what) + ": " + shc_last_error());
 }
 
-// Owns the engine (batch of `n`, default one robot) and the per-cycle input latch.
+// Owns the engine (batch of `n`, default one robot) and the lazily refreshed copies of what the node reads.
 class Engine {
 public:
   explicit Engine(const shc_params &params, int64_t n = 1, int device = 0, void *stream = nullptr) : params_(params), n_(n) {
     check(shc_engine_create(&params_, n, device, stream, &e_), "shc_engine_create");
-    const int dof = params_.leg_dof[0], legs = params_.leg_count;
-    q_.resize(size_t(n) * legs * dof);
-    qd_.resize(q_.size());
-    walker_tip_.resize(size_t(n) * legs * 3);
-    poser_tip_.resize(walker_tip_.size());
-    model_tip_.resize(walker_tip_.size());
-    tip_force_.resize(walker_tip_.size());
-    admittance_.resize(walker_tip_.size());
-    leg_status_.resize(size_t(n) * legs);
-    pose_.resize(size_t(n) * 7);
-    velocity_.resize(size_t(n) * 3);
-    odometry_.resize(size_t(n) * 7);
-    stiffness_.resize(size_t(n) * legs);
-    walk_state_.resize(size_t(n));
-    refresh();
+    measured_q_.assign(size_t(n) * params_.leg_count * params_.leg_dof[0], 0.0);
   }
   ~Engine() { shc_engine_destroy(e_); }
   Engine(const Engine &) = delete;
@@ -71,34 +71,84 @@ public:
   shc_engine *handle() { return e_; }
   const shc_params &params() const { return params_; }
   int64_t instances() const { return n_; }
-  // One control cycle for the whole batch + read-back of the published quantities.
+  int legs() const { return params_.leg_count; }
+  int dof() const { return params_.leg_dof[0]; }
+  // One control cycle for the whole batch (asynchronous; the next getter synchronises through its copy).
   void cycle(int n_cycles = 1) {
     check(shc_engine_step(e_, n_cycles), "shc_engine_step");
-    refresh();
+    invalidate();
   }
+  void invalidate() { have_ = 0; }
   // StateController::changeGait (state_controller.cpp:513): true once the gait has changed, false while the robots are
   // still being stopped (keep cycling and call again, as the reference does while gait_change_flag_ is set)
   bool changeGait(const shc_params &new_gait) {
     int64_t still = 0;
     check(shc_engine_change_gait(e_, &new_gait, &still), "shc_engine_change_gait");
+    invalidate();
     return still == 0;
   }
-  void refresh() {
+
+  // ---- cached outputs, one fetch per group and cycle
+  const std::vector<double> &q() { return joints_(), q_; }
+  const std::vector<double> &qd() { return joints_(), qd_; }
+  const std::vector<double> &walker_tip() { return leg_state_(), walker_tip_; }
+  const std::vector<double> &poser_tip() { return leg_state_(), poser_tip_; }
+  const std::vector<double> &model_tip() { return leg_state_(), model_tip_; }
+  const std::vector<double> &tip_force() { return leg_state_(), tip_force_; }
+  const std::vector<double> &admittance() { return leg_state_(), admittance_; }
+  const std::vector<int32_t> &leg_status() { return leg_state_(), leg_status_; }
+  const std::vector<double> &pose() { return body_(), pose_; }
+  const std::vector<double> &velocity() { return body_(), velocity_; }
+  const std::vector<int32_t> &walk_state() { return body_(), walk_state_; }
+  const std::vector<double> &odometry() {
+    if (!(have_ & 8)) {
+      odometry_.resize(size_t(n_) * 7);
+      check(shc_engine_get_odometry(e_, odometry_.data(), 0), "get_odometry");
+      have_ |= 8;
+    }
+    return odometry_;
+  }
+  const std::vector<double> &stiffness() {
+    if (!(have_ & 16)) {
+      stiffness_.assign(size_t(n_) * legs(), 0.0);
+      if (params_.admittance_control) check(shc_engine_get_virtual_stiffness(e_, stiffness_.data(), 0), "get_virtual_stiffness");
+      have_ |= 16;
+    }
+    return stiffness_;
+  }
+  // Joint::current_position_ as jointStatesCallback stores it (state_controller.cpp:1566-1594): only Leg::applyFK(.., use_actual)
+  std::vector<double> measured_q_;
+
+private:
+  void joints_() {
+    if (have_ & 1) return;
+    q_.resize(size_t(n_) * legs() * dof());
+    qd_.resize(q_.size());
     check(shc_engine_get_joint_state(e_, q_.data(), qd_.data(), 0), "get_joint_state");
+    have_ |= 1;
+  }
+  void leg_state_() {
+    if (have_ & 2) return;
+    const size_t n3 = size_t(n_) * legs() * 3;
+    walker_tip_.resize(n3), poser_tip_.resize(n3), model_tip_.resize(n3), tip_force_.resize(n3), admittance_.resize(n3);
+    leg_status_.resize(size_t(n_) * legs());
     check(shc_engine_get_leg_state(e_, walker_tip_.data(), poser_tip_.data(), model_tip_.data(), tip_force_.data(), admittance_.data(),
                                    leg_status_.data(), 0),
           "get_leg_state");
-    check(shc_engine_get_body_state(e_, pose_.data(), velocity_.data(), walk_state_.data(), 0), "get_body_state");
-    check(shc_engine_get_odometry(e_, odometry_.data(), 0), "get_odometry");
-    if (params_.admittance_control) check(shc_engine_get_virtual_stiffness(e_, stiffness_.data(), 0), "get_virtual_stiffness");
+    have_ |= 2;
   }
-  std::vector<double> q_, qd_, walker_tip_, poser_tip_, model_tip_, tip_force_, admittance_, pose_, velocity_, odometry_, stiffness_;
-  std::vector<int32_t> leg_status_, walk_state_;
-
-private:
+  void body_() {
+    if (have_ & 4) return;
+    pose_.resize(size_t(n_) * 7), velocity_.resize(size_t(n_) * 3), walk_state_.resize(size_t(n_));
+    check(shc_engine_get_body_state(e_, pose_.data(), velocity_.data(), walk_state_.data(), 0), "get_body_state");
+    have_ |= 4;
+  }
   shc_params params_;
   int64_t n_;
   shc_engine *e_ = nullptr;
+  unsigned have_ = 0;
+  std::vector<double> q_, qd_, walker_tip_, poser_tip_, model_tip_, tip_force_, admittance_, pose_, velocity_, odometry_, stiffness_;
+  std::vector<int32_t> leg_status_, walk_state_;
 };
 
 // The per-robot setters below take ONE robot's values, as the reference's callbacks do; the C ABI copies n instances' worth
@@ -114,36 +164,75 @@ struct Joint {
   double offset_ = 0.0;           // :798 (added when publishing the per-joint command)
 };
 
-// class Leg (model.h:202): read-only view of instance `index`'s leg after the cycle.
+// class Leg (model.h:202): leg `id` of instance `index`.
 class Leg {
 public:
   Leg(Engine &eng, int64_t index, int id) : eng_(eng), index_(index), id_(id) {}
   int getIDNumber() const { return id_; }
   int getJointCount() const { return eng_.params().leg_dof[id_]; }
   Joint getJointByIDNumber(int joint_id /* 1-based, model.h:294 */) const {
-    const int dof = eng_.params().leg_dof[0], legs = eng_.params().leg_count;
-    size_t k = (size_t(index_) * legs + id_) * dof + (joint_id - 1);
+    const size_t k = (size_t(index_) * eng_.legs() + id_) * eng_.dof() + (joint_id - 1);
     Joint j;
-    j.desired_position_ = eng_.q_[k];
-    j.desired_velocity_ = eng_.qd_[k];
+    j.desired_position_ = eng_.q()[k];
+    j.desired_velocity_ = eng_.qd()[k];
     j.offset_ = eng_.params().joint[id_][joint_id - 1].offset;
     return j;
   }
-  Vector3 getCurrentTipPosition() const { return v3(eng_.model_tip_); }    // Leg::getCurrentTipPose().position_ (model.h:304)
-  Vector3 getDesiredTipPosition() const { return v3(eng_.poser_tip_); }    // LegPoser::getCurrentTipPose() (pose_controller.h:449)
-  Vector3 getWalkerTipPosition() const { return v3(eng_.walker_tip_); }    // LegStepper::getCurrentTipPose() (walk_controller.h:389)
-  Vector3 getTipForceCalculated() const { return v3(eng_.tip_force_); }    // model.h:244
-  Vector3 getAdmittanceDelta() const { return v3(eng_.admittance_); }      // model.h:256
-  double getVirtualStiffness() const { return eng_.stiffness_[size_t(index_) * eng_.params().leg_count + id_]; } // model.h:264
-  int getStepState() const { return eng_.leg_status_[size_t(index_) * eng_.params().leg_count + id_] & 3; } // walk_controller.h:325
-  int getPhase() const { return eng_.leg_status_[size_t(index_) * eng_.params().leg_count + id_] >> 8; }    // :317
-  bool ikFailed() const { return (eng_.leg_status_[size_t(index_) * eng_.params().leg_count + id_] & 4) != 0; } // model.cpp:921
+  Vector3 getCurrentTipPosition() const { return v3(eng_.model_tip()); }    // Leg::getCurrentTipPose().position_ (model.h:304)
+  Vector3 getDesiredTipPosition() const { return v3(eng_.poser_tip()); }    // LegPoser::getCurrentTipPose() (pose_controller.h:449)
+  Vector3 getWalkerTipPosition() const { return v3(eng_.walker_tip()); }    // LegStepper::getCurrentTipPose() (walk_controller.h:389)
+  Vector3 getTipForceCalculated() const { return v3(eng_.tip_force()); }    // model.h:244
+  Vector3 getAdmittanceDelta() const { return v3(eng_.admittance()); }      // model.h:256
+  double getVirtualStiffness() const { return eng_.stiffness()[slot()]; }   // model.h:264
+  int getStepState() const { return eng_.leg_status()[slot()] & 3; }        // walk_controller.h:325
+  int getPhase() const { return eng_.leg_status()[slot()] >> 8; }           // :317
+  bool ikFailed() const { return (eng_.leg_status()[slot()] & 4) != 0; }    // model.cpp:921
+
+  // ---- the per-leg methods the reference's cold paths call (model.h:448-492), same argument order and return values
+  // void setDesiredTipPose(const Pose& tip_pose = Pose::Undefined(), bool apply_delta = true)          model.h:448
+  void setDesiredTipPose(const Pose &tip_pose = Pose::Undefined(), bool apply_delta = true) {
+    const double p[7] = {tip_pose.position_[0], tip_pose.position_[1], tip_pose.position_[2], tip_pose.rotation_.w, tip_pose.rotation_.x,
+                         tip_pose.rotation_.y,  tip_pose.rotation_.z};
+    check(shc_leg_set_desired_tip_pose(eng_.handle(), index_, 1, id_, tip_pose.isUndefined() ? nullptr : p, apply_delta ? 1 : 0, 0),
+          "shc_leg_set_desired_tip_pose");
+  }
+  // Eigen::VectorXd solveIK(const Eigen::MatrixXd& delta, const bool& solve_rotation)                  model.h:470
+  template <class Delta6>
+  std::vector<double> solveIK(const Delta6 &delta, const bool &solve_rotation) {
+    const double d[6] = {delta[0], delta[1], delta[2], delta[3], delta[4], delta[5]};
+    std::vector<double> out(size_t(eng_.dof()));
+    check(shc_leg_solve_ik(eng_.handle(), index_, 1, id_, d, solve_rotation ? 1 : 0, out.data(), 0), "shc_leg_solve_ik");
+    return out;
+  }
+  // double updateJointPositions(const Eigen::VectorXd& delta, const bool& simulation)                  model.h:477
+  template <class JointDelta>
+  double updateJointPositions(const JointDelta &delta, const bool &simulation) {
+    std::vector<double> d(size_t(eng_.dof()));
+    for (size_t j = 0; j < d.size(); ++j) d[j] = delta[j];
+    double prox = 0.0;
+    check(shc_leg_update_joint_positions(eng_.handle(), index_, 1, id_, d.data(), simulation ? 1 : 0, &prox, 0), "shc_leg_update_joint_positions");
+    eng_.invalidate();
+    return prox;
+  }
+  // double applyIK(const bool& simulation = false)                                                     model.h:485
+  double applyIK(const bool &simulation = false) {
+    double result = 0.0;
+    check(shc_leg_apply_ik(eng_.handle(), index_, 1, id_, simulation ? 1 : 0, &result, 0), "shc_leg_apply_ik");
+    eng_.invalidate();
+    return result;
+  }
+  // Pose applyFK(const bool& set_current = true, const bool& use_actual = false)                        model.h:492
+  // (set_current only refreshes cached members in the reference; the engine derives the model tip from the joints on demand)
+  Pose applyFK(const bool & /*set_current*/ = true, const bool &use_actual = false) {
+    double p[7];
+    const double *measured = use_actual ? &eng_.measured_q_[(size_t(index_) * eng_.legs() + id_) * eng_.dof()] : nullptr;
+    check(shc_leg_apply_fk(eng_.handle(), index_, 1, id_, measured, p, 0), "shc_leg_apply_fk");
+    return Pose{{{p[0], p[1], p[2]}}, {p[3], p[4], p[5], p[6]}};
+  }
 
 private:
-  Vector3 v3(const std::vector<double> &a) const {
-    size_t k = (size_t(index_) * eng_.params().leg_count + id_) * 3;
-    return Vector3{{a[k], a[k + 1], a[k + 2]}};
-  }
+  size_t slot() const { return size_t(index_) * eng_.legs() + id_; }
+  Vector3 v3(const std::vector<double> &a) const { return Vector3{{a[slot() * 3], a[slot() * 3 + 1], a[slot() * 3 + 2]}}; }
   Engine &eng_;
   int64_t index_;
   int id_;
@@ -153,10 +242,10 @@ private:
 class Model {
 public:
   Model(std::shared_ptr<Engine> eng, int64_t index = 0) : eng_(std::move(eng)), index_(index) {}
-  int getLegCount() const { return eng_->params().leg_count; }                     // model.h:80
-  Leg getLegByIDNumber(int leg_id) { return Leg(*eng_, index_, leg_id); }          // model.h:124
-  Pose getCurrentPose() const {                                                    // model.h:84
-    const double *p = &eng_->pose_[size_t(index_) * 7];
+  int getLegCount() const { return eng_->legs(); }                                // model.h:80
+  Leg getLegByIDNumber(int leg_id) { return Leg(*eng_, index_, leg_id); }         // model.h:124
+  Pose getCurrentPose() const {                                                   // model.h:84
+    const double *p = &eng_->pose()[size_t(index_) * 7];
     return Pose{{{p[0], p[1], p[2]}}, {p[3], p[4], p[5], p[6]}};
   }
   // Model::setImuData (model.h:146): orientation (w,x,y,z), angular velocity
@@ -164,40 +253,62 @@ public:
   void setImuData(const Q &orientation_wxyz, const V & /*linear_acceleration*/, const V &angular_velocity) {
     double q[4] = {orientation_wxyz[0], orientation_wxyz[1], orientation_wxyz[2], orientation_wxyz[3]};
     double g[3] = {angular_velocity[0], angular_velocity[1], angular_velocity[2]};
-    require_single("setImuData");
+    require_single(*eng_, "setImuData");
     check(shc_engine_set_imu(eng_->handle(), q, g, 0), "set_imu");
   }
+  // jointStatesCallback (state_controller.cpp:1566-1594): measured positions (Leg::applyFK(.., use_actual)) and efforts
+  void setJointState(int leg_id, int joint_id /* 1-based */, double position, double /*velocity*/, double effort) {
+    const size_t k = (size_t(index_) * eng_->legs() + leg_id) * eng_->dof() + (joint_id - 1);
+    eng_->measured_q_[k] = position;
+    if (efforts_.empty()) efforts_.assign(size_t(eng_->legs()) * eng_->dof(), 0.0);
+    efforts_[size_t(leg_id) * eng_->dof() + (joint_id - 1)] = effort;
+    efforts_dirty_ = true;
+  }
   // Model::updateModel (model.h:163, src/model.cpp:142): the last call of the reference's cycle -> launch the fused kernel.
-  void updateModel() { eng_->cycle(1); }
+  void updateModel() {
+    if (efforts_dirty_) {
+      require_single(*eng_, "setJointState");
+      check(shc_engine_set_joint_effort(eng_->handle(), efforts_.data(), 0), "set_joint_effort");
+      efforts_dirty_ = false;
+    }
+    eng_->cycle(1);
+  }
   Engine &engine() { return *eng_; }
 
 private:
-  void require_single(const char *what) const {
-    if (eng_->instances() != 1) throw std::logic_error(std::string(what) + ": per-robot setters need a batch of one; use the C ABI arrays");
-  }
   std::shared_ptr<Engine> eng_;
   int64_t index_;
+  std::vector<double> efforts_;
+  bool efforts_dirty_ = false;
 };
 
 // class WalkController (walk_controller.h:54)
 class WalkController {
 public:
   explicit WalkController(std::shared_ptr<Engine> eng) : eng_(std::move(eng)) {}
-  // WalkController::updateWalk (walk_controller.h:204, src/walk_controller.cpp:440): latches the velocity inputs of this cycle.
+  // void updateWalk(const Eigen::Vector2d& linear_velocity_input, const double& angular_velocity_input)   walk_controller.h:204
   template <class V2>
   void updateWalk(const V2 &linear_velocity_input, const double &angular_velocity_input) {
     double lin[2] = {linear_velocity_input[0], linear_velocity_input[1]};
     double ang = angular_velocity_input;
-    if (eng_->instances() != 1) throw std::logic_error("updateWalk: batch of one only; use shc_engine_set_velocity");
+    require_single(*eng_, "updateWalk");
     check(shc_engine_set_velocity(eng_->handle(), lin, &ang, 0), "set_velocity");
   }
-  int getWalkState(int64_t index = 0) const { return eng_->walk_state_[size_t(index)]; } // walk_controller.h:92
+  // void updateManual(primary_leg_selection_ID, primary_tip_velocity_input, secondary_leg_selection_ID, ...)   walk_controller.h:213
+  // void updateManual(primary_leg_selection_ID, primary_tip_pose_input, secondary_leg_selection_ID, ...)       walk_controller.h:223
+  // Manual leg manipulation needs legs in LegState MANUAL (toggled through PoseController::poseForLegManipulation, a
+  // sequence outside the accelerated path); the engine keeps every leg WALKING, for which both overloads are no-ops
+  // (walk_controller.cpp:661, :722: "if (leg->getLegState() == MANUAL)").
+  template <class V3>
+  void updateManual(const int & /*primary_leg_selection_ID*/, const V3 & /*primary_input*/, const int & /*secondary_leg_selection_ID*/,
+                    const V3 & /*secondary_input*/) {}
+  int getWalkState(int64_t index = 0) const { return eng_->walk_state()[size_t(index)]; } // walk_controller.h:92
   std::array<double, 2> getDesiredLinearVelocity(int64_t index = 0) const {               // :100
-    return {eng_->velocity_[size_t(index) * 3], eng_->velocity_[size_t(index) * 3 + 1]};
+    return {eng_->velocity()[size_t(index) * 3], eng_->velocity()[size_t(index) * 3 + 1]};
   }
-  double getDesiredAngularVelocity(int64_t index = 0) const { return eng_->velocity_[size_t(index) * 3 + 2]; } // :104
+  double getDesiredAngularVelocity(int64_t index = 0) const { return eng_->velocity()[size_t(index) * 3 + 2]; } // :104
   Pose getOdometryIdeal(int64_t index = 0) const {                                                               // :112
-    const double *p = &eng_->odometry_[size_t(index) * 7];
+    const double *p = &eng_->odometry()[size_t(index) * 7];
     return Pose{{{p[0], p[1], p[2]}}, {p[3], p[4], p[5], p[6]}};
   }
 
@@ -221,9 +332,10 @@ public:
     require_single(*eng_, "setPoseResetMode");
     check(shc_engine_set_pose_reset_mode(eng_->handle(), &m, 0), "set_pose_reset_mode");
   }
-  // updateCurrentPose / updateStance (pose_controller.h:216,157) are part of the fused cycle: nothing to do per call.
-  void updateCurrentPose(int /*robot_state*/) {}
-  void updateStance() {}
+  // void updateCurrentPose(const RobotState& robot_state) (pose_controller.h:216) / void updateStance(void) (:157): both are
+  // phases of the fused cycle; the engine runs them with robot_state RUNNING when Model::updateModel launches it.
+  void updateCurrentPose(const RobotState & /*robot_state*/) {}
+  void updateStance(void) {}
 
 private:
   std::shared_ptr<Engine> eng_;
@@ -243,8 +355,9 @@ public:
     require_single(*eng_, "setJointEffort");
     check(shc_engine_set_joint_effort(eng_->handle(), effort, 0), "set_joint_effort");
   }
-  void updateStiffness(WalkController & /*walker*/) {} // fused (admittance_controller.cpp:96)
-  void updateAdmittance() {}                           // fused (admittance_controller.cpp:22)
+  // void updateStiffness(std::shared_ptr<WalkController> walker) (admittance_controller.h:42) / void updateAdmittance(void) (:61)
+  void updateStiffness(std::shared_ptr<WalkController> /*walker*/) {} // fused (admittance_controller.cpp:96)
+  void updateAdmittance(void) {}                                      // fused (admittance_controller.cpp:22)
 
 private:
   std::shared_ptr<Engine> eng_;

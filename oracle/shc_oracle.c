@@ -139,6 +139,7 @@ struct orc_robot
   int robot_state, new_robot_state, transition_state_flag;
   double linear_velocity_input[2], angular_velocity_input;
   int unstable;
+  int startup_progress; /* last return value of directStartup (orc_startup_step) */
 };
 
 /* ==================================================================================== Model / Leg */
@@ -1990,6 +1991,7 @@ static void state_transition_robot_state(orc_robot *r)
   else if (r->robot_state == RS_PACKED && r->new_robot_state == RS_READY)
   {
     int progress = poser_direct_startup(r);
+    r->startup_progress = progress;
     if (progress == PROGRESS_COMPLETE)
     {
       r->robot_state = RS_READY;
@@ -2688,6 +2690,45 @@ void orc_leg_apply_fk(orc_robot *r, int l, const double *joint_position, double 
   for (int j = 0; j < copy->joint_count; ++j) copy->joint[j].desired_position = joint_position[j];
   put_pose7(pose7, leg_apply_fk(r, copy));
   free(copy);
+}
+
+/* LegPoser::stepToPosition / transitionConfiguration on leg l of a robot */
+int orc_leg_step_to_position(orc_robot *r, int l, const double *target_tip_pose7, const double *target_pose7, double lift_height,
+                             double time_to_step, int apply_delta, double tip_pose7[7])
+{
+  leg_t *leg = &r->leg[l];
+  int progress = leg_poser_step_to_position(r, leg, target_tip_pose7 ? get_pose7(target_tip_pose7) : orc_pose_undefined(), get_pose7(target_pose7),
+                                            lift_height, time_to_step, apply_delta);
+  put_pose7(tip_pose7, leg->poser.current_tip_pose);
+  return progress;
+}
+int orc_leg_transition_configuration(orc_robot *r, int l, const double *desired_configuration, double transition_time)
+{
+  leg_t *leg = &r->leg[l];
+  for (int j = 0; j < leg->joint_count; ++j) leg->poser.desired_configuration[j] = desired_configuration[j];
+  leg->poser.has_desired_configuration = 1;
+  return leg_poser_transition_configuration(r, leg, transition_time);
+}
+/* Direct start-up, loop by loop: orc_startup_begin = the UNKNOWN -> PACKED loop + the START request; every orc_startup_step is
+ * one StateController::loop() of the PACKED -> READY transition (returns PoseController::directStartup's progress);
+ * orc_startup_finish = the loop that enters RUNNING (and runs the first control cycle). */
+void orc_startup_begin(orc_robot *r)
+{
+  r->transition_state_flag = 1;
+  state_loop(r);
+  r->new_robot_state = RS_READY;
+  r->transition_state_flag = 1;
+}
+int orc_startup_step(orc_robot *r)
+{
+  state_loop(r);
+  return r->robot_state == RS_READY ? PROGRESS_COMPLETE : r->startup_progress;
+}
+void orc_startup_finish(orc_robot *r)
+{
+  r->new_robot_state = RS_RUNNING;
+  r->transition_state_flag = 1;
+  state_loop(r);
 }
 
 /* ------------------------------------------------------------------------------------ unit-level entry points */

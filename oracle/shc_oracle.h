@@ -101,6 +101,14 @@ double orc_leg_update_joint_positions(orc_robot *r, int leg, const double *joint
 double orc_leg_apply_ik(orc_robot *r, int leg, int simulation);
 void orc_leg_apply_fk(orc_robot *r, int leg, const double *joint_position /* NULL = desired */, double pose7[7]);
 
+int orc_leg_step_to_position(orc_robot *r, int leg, const double *target_tip_pose7 /* NULL = Pose::Undefined() */, const double *target_pose7,
+                             double lift_height, double time_to_step, int apply_delta, double tip_pose7[7]);
+int orc_leg_transition_configuration(orc_robot *r, int leg, const double *desired_configuration, double transition_time);
+/* The direct start-up of orc_startup, one StateController::loop() at a time. */
+void orc_startup_begin(orc_robot *r);
+int orc_startup_step(orc_robot *r);
+void orc_startup_finish(orc_robot *r);
+
 /* ---- unit-level entry points for the KAT / cross-check tests (thin wrappers over the static code) ---- */
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out);
 void orc_test_quat_to_euler(const double q_wxyz[4], int intrinsic, double out[3]);

@@ -113,7 +113,11 @@ struct Fields {
                        ORG_DIR = ADM_DELTA + 4, CUR_DIR = ORG_DIR + 3,
                        // Leg::desired_tip_pose_ as the per-leg API holds it between shc_leg_set_desired_tip_pose and shc_leg_apply_ik:
                        // position (3) + "rotation defined" flag, x axis of the rotation (3) + pad.  The fused cycle never touches these.
-                       DES_TIP = CUR_DIR + 3, DES_DIR = DES_TIP + 4, COUNT = DES_DIR + 4;
+                       DES_TIP = CUR_DIR + 3, DES_DIR = DES_TIP + 4,
+                       // LegPoser sequence state (pose_controller.h:560-590) for stepToPosition / transitionConfiguration:
+                       // origin_tip_pose_ position (3) + master_iteration_count_, x axis of its rotation (3) + "!first_iteration_",
+                       // origin_configuration_ (NJ, padded).  Only the sequence entry points touch these.
+                       SEQ_ORG = DES_DIR + 4, SEQ_DIR = SEQ_ORG + 4, SEQ_Q0 = SEQ_DIR + 4, COUNT = SEQ_Q0 + NJE;
   static_assert(CORE_END % 2 == 0 && SORG % 2 == 0 && COUNT % 2 == 0, "field groups must align to 16-byte planes");
 };
 // element index of field f of slot `slot` in the plane array (n_slots slots per plane)

@@ -554,6 +554,7 @@ struct shc_engine {
   size_t stage_bytes;
   uint32_t features;
   uint32_t rt_flags; // RT_* facts passed to every launch
+  int starting_up, startup_calls; // shc_engine_begin_direct_startup .. shc_engine_direct_startup
 };
 
 template <int L, int NJ>
@@ -1643,6 +1644,122 @@ extern "C" int shc_leg_apply_fk(shc_engine *e, int64_t first, int64_t count, int
   if ((rc = c.in(joint_position, e->NJ, on_device, &d)) != SHC_OK || (rc = c.out(tip_pose, 7, on_device, &o)) != SHC_OK) return rc;
   if ((rc = LEG_KERNEL(leg_apply_fk_kernel, d, o)) != SHC_OK) return rc;
   return c.finish(tip_pose, o, 7, on_device);
+}
+
+// ---- sequences
+extern "C" int shc_leg_step_to_position(shc_engine *e, int64_t first, int64_t count, int leg, const double *target_tip_pose, const double *target_pose,
+                                        double lift_height, double time_to_step, int apply_delta, double *tip_pose, int32_t *progress, int on_device) {
+  if (!target_pose || !tip_pose) return fail(SHC_ERR_INVALID_ARG, "target_pose / tip_pose is NULL");
+  if (!(time_to_step >= 0.0)) return fail(SHC_ERR_INVALID_ARG, "time_to_step must be >= 0");
+  LegCall c;
+  int rc = c.init(e, first, count, leg);
+  if (rc != SHC_OK) return rc;
+  const double *dt, *dp;
+  double *o, *prog;
+  if ((rc = c.in(target_tip_pose, 7, on_device, &dt)) != SHC_OK) return rc;
+  { // target_pose has one row per INSTANCE
+    const int64_t rows = c.rows;
+    c.rows = count;
+    rc = c.in(target_pose, 7, on_device, &dp);
+    c.rows = rows;
+    if (rc != SHC_OK) return rc;
+  }
+  if ((rc = c.out(tip_pose, 7, on_device, &o)) != SHC_OK) return rc;
+  // int32 progress rows ride in a double-width temporary (4 bytes used per row)
+  if ((rc = c.out(reinterpret_cast<double *>(progress), 1, on_device, &prog)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_step_to_position_kernel, dt, dp, lift_height, time_to_step, apply_delta, e->params.admittance_control,
+                       e->params.time_delta, o, reinterpret_cast<int32_t *>(prog))) != SHC_OK)
+    return rc;
+  HIP_TRY(hipGetLastError());
+  if (progress && !on_device && c.rows) HIP_TRY(hipMemcpyAsync(progress, prog, size_t(c.rows) * 4, hipMemcpyDeviceToHost, e->stream));
+  return c.finish(tip_pose, o, 7, on_device);
+}
+
+extern "C" int shc_leg_transition_configuration(shc_engine *e, int64_t first, int64_t count, int leg, const double *desired_configuration,
+                                                double transition_time, int32_t *progress, int on_device) {
+  if (!desired_configuration) return fail(SHC_ERR_INVALID_ARG, "desired_configuration is NULL");
+  LegCall c;
+  int rc = c.init(e, first, count, leg);
+  if (rc != SHC_OK) return rc;
+  const double *d;
+  double *prog;
+  if ((rc = c.in(desired_configuration, e->NJ, on_device, &d)) != SHC_OK) return rc;
+  if ((rc = c.out(reinterpret_cast<double *>(progress), 1, on_device, &prog)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_transition_configuration_kernel, d, 1, transition_time, e->params.time_delta, reinterpret_cast<int32_t *>(prog))) != SHC_OK)
+    return rc;
+  HIP_TRY(hipGetLastError());
+  if (progress && !on_device && c.rows) HIP_TRY(hipMemcpyAsync(progress, prog, size_t(c.rows) * 4, hipMemcpyDeviceToHost, e->stream));
+  return c.finish(nullptr, nullptr, 0, on_device);
+}
+
+// Joints of every instance to the configuration Leg::init(true) leaves (model.cpp:286-305: Joint::default_position_ =
+// clamped(0, min, max), :1038), everything else to the engine's post-start-up template.
+template <int NJ>
+__global__ void set_initial_joints_kernel(DevState st, const double *q0 /*[L][NJ]*/, int L) {
+  using FD = Fields<NJ>;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= st.n_robots * L) return;
+  const int64_t rob = t / L;
+  const int leg = int(t - rob * L);
+  const int64_t slot = slot_of(rob, leg, L);
+  for (int j = 0; j < NJ; ++j) {
+    st.legd[leg_field_index(FD::Q + j, slot, st.n_slots)] = q0[leg * NJ + j];
+    st.legd[leg_field_index(FD::QD + j, slot, st.n_slots)] = 0.0;
+  }
+}
+
+extern "C" int shc_engine_begin_direct_startup(shc_engine *e) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc = init_state(e);
+  if (rc != SHC_OK) return rc;
+  std::vector<double> q0(size_t(e->L) * e->NJ);
+  for (int l = 0; l < e->L; ++l)
+    for (int j = 0; j < e->NJ; ++j) q0[size_t(l) * e->NJ + j] = clampd(0.0, e->params.joint[l][j].min, e->params.joint[l][j].max);
+  HIP_TRY(hipMemcpyAsync(e->d_stage, q0.data(), q0.size() * 8, hipMemcpyHostToDevice, e->stream));
+  const int64_t threads = e->n * e->L;
+  const dim3 grid((unsigned)((threads + 255) / 256));
+  switch (e->NJ) {
+    case 3: set_initial_joints_kernel<3><<<grid, dim3(256), 0, e->stream>>>(e->st, e->d_stage, e->L); break;
+    case 4: set_initial_joints_kernel<4><<<grid, dim3(256), 0, e->stream>>>(e->st, e->d_stage, e->L); break;
+    default: set_initial_joints_kernel<5><<<grid, dim3(256), 0, e->stream>>>(e->st, e->d_stage, e->L); break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->startup_calls = 0;
+  e->starting_up = 1;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_direct_startup(shc_engine *e, int32_t *progress) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (!e->starting_up) return fail(SHC_ERR_INVALID_ARG, "call shc_engine_begin_direct_startup first");
+  HIP_TRY(hipSetDevice(e->device));
+  // desired_configuration_ of every leg = the joints the simulated start-up solve ended on (pose_controller.cpp:476-510):
+  // the init chain's default_joint_position, one row per leg shared by all instances
+  std::vector<double> target(size_t(e->L) * e->NJ);
+  for (int l = 0; l < e->L; ++l)
+    for (int j = 0; j < e->NJ; ++j) target[size_t(l) * e->NJ + j] = e->tables.default_joint_position[l][j];
+  HIP_TRY(hipMemcpyAsync(e->d_stage, target.data(), target.size() * 8, hipMemcpyHostToDevice, e->stream));
+  LegCall c;
+  int rc = c.init(e, 0, e->n, -1);
+  if (rc != SHC_OK) return rc;
+  const double *d = e->d_stage;
+  if ((rc = LEG_KERNEL(leg_transition_configuration_kernel, d, 0, e->params.time_to_start, e->params.time_delta, (int32_t *)nullptr)) != SHC_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream)); // the staging buffer is reused
+  // progress is a function of the call count alone (every leg runs the same number of iterations, :1546-1566)
+  const int num = hostinit::startup_loops(e->params);
+  e->startup_calls++;
+  int p = int((double(e->startup_calls - 1) / double(num)) * 100);
+  p = p < 1 ? 1 : (p > 100 ? 100 : p);
+  if (e->startup_calls >= num) {
+    p = 100;
+    e->starting_up = 0;
+    // READY reached; the loop that enters RUNNING also runs the first control cycle (state_controller.cpp:277-281, :189-192)
+    if ((rc = shc_engine_step(e, 1)) != SHC_OK) return rc;
+  }
+  if (progress) *progress = p;
+  return SHC_OK;
 }
 
 extern "C" int64_t shc_sizeof_instance_state(void) { return (int64_t)sizeof(shc_instance_state); }

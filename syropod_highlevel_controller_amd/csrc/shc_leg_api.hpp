@@ -207,4 +207,125 @@ __global__ void leg_apply_fk_kernel(DevState st, const SharedConsts<L_, NJ> *gc,
   o[0] = p.p.x, o[1] = p.p.y, o[2] = p.p.z, o[3] = p.r.w, o[4] = p.r.x, o[5] = p.r.y, o[6] = p.r.z;
 }
 
+// ------------------------------------------------------------------------------------------------- sequences
+// LegPoser::stepToPosition (pose_controller.cpp:1571-1712), one iteration per selected leg: the tip follows two quartic
+// Bezier curves from where the leg was when the sequence started (origin_tip_pose_) to the target (with an optional lift)
+// while the body pose eases from the identity to target_pose; the result is LegPoser::current_tip_pose_, which the callers
+// hand to Leg::setDesiredTipPose + applyIK (stepToNewStance :521, poseForLegManipulation :561, directStartup :463).
+template <int L_, int NJ>
+__global__ void leg_step_to_position_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *target_tip_pose,
+                                            const double *target_pose, double lift_height, double time_to_step, int apply_delta, int have_adm,
+                                            double dt, double *tip_pose_out, int32_t *progress_out) {
+  using FD = Fields<NJ>;
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  const LegConst<NJ> &lc = gc->leg[l];
+  V3 origin = io.get3(FD::SEQ_ORG), origin_dir = io.get3(FD::SEQ_DIR);
+  int count = int(io.get(FD::SEQ_ORG + 3));
+  if (io.get(FD::SEQ_DIR + 3) == 0.0) { // first_iteration_: origin_tip_pose_ = leg_->getCurrentTipPose() (FK of the current joints)
+    double q[NJ], qd[NJ];
+    io.joints(q, qd);
+    Chain<NJ> ch;
+    fk_chain<NJ>(lc, q, ch);
+    origin = tip_robot_frame(lc, ch.pe);
+    origin_dir = base_rotate(lc, ch.xe);
+    count = 0;
+  }
+  V3 desired = origin, desired_dir{0, 0, 0};
+  bool rot = false;
+  if (target_tip_pose) { // NULL = Pose::Undefined(): stay at the origin position, rotation undefined (:1583-1587)
+    const double *p = target_tip_pose + t * 7;
+    desired = V3{p[0], p[1], p[2]};
+    const Quat r{p[3], p[4], p[5], p[6]};
+    rot = !(r.w == 0.0 && r.x == 0.0 && r.y == 0.0 && r.z == 0.0);
+    if (rot) desired_dir = rotate(r, V3{1, 0, 0});
+  }
+  const double *tp = target_pose + (rob - sel.first) * 7;
+  const Pose body{V3{tp[0], tp[1], tp[2]}, Quat{tp[3], tp[4], tp[5], tp[6]}};
+  const bool move = norm(origin - inverse_transform_vector(body, desired)) > kTipTolerance;
+  bool turn = false;
+  if (rot) turn = norm(angle_axis_vector(from_two_vectors(origin_dir, desired_dir))) > kJointTolerance;
+  Pose out{origin, from_two_vectors(V3{1, 0, 0}, origin_dir)};
+  int progress = 100;
+  double running = 0.0;
+  if (move || turn || lift_height != 0.0) {
+    if (apply_delta && have_adm) desired = desired + io.get3(FD::ADM_DELTA);
+    ++count;
+    int num = round_to_int(time_to_step / dt);
+    num = num > 1 ? num : 1;
+    const double delta_t = 1.0 / num, ratio = double(count - 1) / double(num);
+    const Pose eased = interpolate_pose(pose_identity(), smooth_step(ratio), body);
+    out.r = Quat{0, 0, 0, 0};
+    if (rot) out.r = from_two_vectors(V3{1, 0, 0}, normalized(lerp3(origin_dir, desired_dir, smooth_step(ratio))));
+    const int half = num / 2;
+    const V3 o2t = origin - desired;
+    V3 prim[5] = {origin, origin, origin, desired + o2t * 0.75, desired + o2t * 0.5};
+    V3 sec[5] = {desired + o2t * 0.5, desired + o2t * 0.25, desired, desired, desired};
+    prim[2].z += lift_height, prim[3].z += lift_height, prim[4].z += lift_height;
+    sec[0].z += lift_height, sec[1].z += lift_height, sec[2].z += lift_height;
+    const int sic = (count + (num - 1)) % num + 1;
+    const V3 np = sic <= half ? quartic_bezier(prim, sic * delta_t * 2.0) : quartic_bezier(sec, (sic - half) * delta_t * 2.0);
+    out.p = inverse_transform_vector(eased, np);
+    if (count >= num) {
+      progress = 100; // first_iteration_ = true
+    } else {
+      progress = int(ratio * 100);
+      running = 1.0;
+    }
+  }
+  io.put3(FD::SEQ_ORG, origin);
+  io.put(FD::SEQ_ORG + 3, double(count));
+  io.put3(FD::SEQ_DIR, origin_dir);
+  io.put(FD::SEQ_DIR + 3, running);
+  double *o = tip_pose_out + t * 7;
+  o[0] = out.p.x, o[1] = out.p.y, o[2] = out.p.z, o[3] = out.r.w, o[4] = out.r.x, o[5] = out.r.y, o[6] = out.r.z;
+  if (progress_out) progress_out[t] = progress;
+}
+
+// LegPoser::transitionConfiguration (pose_controller.cpp:1476-1567), one iteration per selected leg: every joint follows a cubic
+// Bezier (nodes origin, origin, target, target) from the configuration the leg had when the transition started.
+template <int L_, int NJ>
+__global__ void leg_transition_configuration_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *desired_configuration,
+                                                    int per_leg_rows, double transition_time, double dt, int32_t *progress_out) {
+  using FD = Fields<NJ>;
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  double q[NJ], qd[NJ], q0[NJ];
+  io.joints(q, qd);
+  int count = int(io.get(FD::SEQ_ORG + 3));
+  if (io.get(FD::SEQ_DIR + 3) == 0.0) { // first_iteration_: origin_configuration_ = the current desired joint positions
+    for (int j = 0; j < NJ; ++j) q0[j] = q[j];
+    count = 0;
+  } else {
+    for (int j = 0; j < NJ; ++j) q0[j] = io.get(FD::SEQ_Q0 + j);
+  }
+  int num = round_to_int(transition_time / dt);
+  num = num > 1 ? num : 1;
+  const double delta_t = 1.0 / num;
+  ++count;
+  // per_leg_rows: one target row per selected (instance, leg), else one row per LEG shared by every instance ([legs][dof])
+  const double *d = desired_configuration + (per_leg_rows ? t : int64_t(l)) * NJ;
+  const double tt = count * delta_t, s = 1.0 - tt;
+  for (int j = 0; j < NJ; ++j) // cubicBezier (standard_includes.h:347)
+    q[j] = q0[j] * (s * s * s) + q0[j] * (3.0 * tt * s * s) + d[j] * (3.0 * tt * tt * s) + d[j] * (tt * tt * tt);
+  int progress = int((double(count - 1) / double(num)) * 100);
+  progress = progress < 1 ? 1 : (progress > 100 ? 100 : progress);
+  double running = 1.0;
+  if (count >= num) {
+    progress = 100;
+    running = 0.0;
+  }
+  io.put_joints(q, qd); // desired_velocity_ is not touched by the reference here
+  for (int j = 0; j < NJ; ++j) io.put(FD::SEQ_Q0 + j, q0[j]);
+  io.put(FD::SEQ_ORG + 3, double(count));
+  io.put(FD::SEQ_DIR + 3, running);
+  if (progress_out) progress_out[t] = progress;
+}
+
 } // namespace shc

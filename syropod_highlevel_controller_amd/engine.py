@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "shc_generate_tables_batch", "shc_engine_create_with_tables",
     "shc_sizeof_instance_state", "shc_engine_get_state", "shc_engine_set_state",
     "shc_leg_set_desired_tip_pose", "shc_leg_solve_ik", "shc_leg_update_joint_positions", "shc_leg_apply_ik", "shc_leg_apply_fk",
+    "shc_leg_step_to_position", "shc_leg_transition_configuration", "shc_engine_begin_direct_startup", "shc_engine_direct_startup",
 ]
 
 
@@ -133,6 +134,10 @@ def lib():
         L.shc_leg_update_joint_positions.argtypes = sel + [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.shc_leg_apply_ik.argtypes = sel + [C.c_int, C.c_void_p, C.c_int]
         L.shc_leg_apply_fk.argtypes = sel + [C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_leg_step_to_position.argtypes = sel + [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_leg_transition_configuration.argtypes = sel + [C.c_void_p, C.c_double, C.c_void_p, C.c_int]
+        L.shc_engine_begin_direct_startup.argtypes = [C.c_void_p]
+        L.shc_engine_direct_startup.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.shc_engine_get_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]
         L.shc_engine_set_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]
         # a binding whose struct layouts disagree with the library must not run
@@ -355,6 +360,34 @@ class BatchEngine:
         out = np.zeros((rows, 7))
         _check(self.L.shc_leg_apply_fk(self.h, first, count, leg, _p(a), _p(out), 0), "leg_apply_fk")
         return out
+
+    # -- sequences
+    def leg_step_to_position(self, target_tip_pose, target_pose, lift_height, time_to_step, apply_delta=True, first=0, count=None, leg=-1):
+        """One LegPoser::stepToPosition iteration; returns (poser tip pose rows [.., 7], progress rows)."""
+        count, rows = self._rows(first, count, leg)
+        a, b = _host(target_tip_pose), _host(target_pose)
+        assert (a is None or a.size == rows * 7) and b.size == count * 7
+        out, prog = np.zeros((rows, 7)), np.zeros(rows, dtype=np.int32)
+        _check(self.L.shc_leg_step_to_position(self.h, first, count, leg, _p(a), _p(b), float(lift_height), float(time_to_step), int(apply_delta),
+                                               _p(out), _p(prog), 0), "leg_step_to_position")
+        return out, prog
+
+    def leg_transition_configuration(self, desired_configuration, transition_time, first=0, count=None, leg=-1):
+        count, rows = self._rows(first, count, leg)
+        a = _host(desired_configuration)
+        assert a.size == rows * self.dof
+        prog = np.zeros(rows, dtype=np.int32)
+        _check(self.L.shc_leg_transition_configuration(self.h, first, count, leg, _p(a), float(transition_time), _p(prog), 0),
+               "leg_transition_configuration")
+        return prog
+
+    def begin_direct_startup(self):
+        _check(self.L.shc_engine_begin_direct_startup(self.h), "begin_direct_startup")
+
+    def direct_startup(self) -> int:
+        p = C.c_int32(0)
+        _check(self.L.shc_engine_direct_startup(self.h, C.byref(p)), "direct_startup")
+        return int(p.value)
 
     def odometry(self):
         """WalkController::getOdometryIdeal per instance: [n][7] (x, y, z, qw, qx, qy, qz)."""

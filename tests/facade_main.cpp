@@ -1,9 +1,12 @@
-// Compiled by tests/test_gpu_facade.py: drives one default.yaml hexapod through the façade (reference class names) and
-// prints the joint positions after N cycles.
+// Compiled by tests/test_gpu_facade.py: drives one default.yaml hexapod through the façade (reference class names, method
+// names and argument order) - first the reference's loop body, then the per-leg Leg methods its cold paths use - and prints
+// what the test compares with the oracle.
 #include "shc_facade.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+
+using namespace shc_facade;
 
 int main(int argc, char **argv) {
   if (argc < 6) return 2;
@@ -15,20 +18,36 @@ int main(int argc, char **argv) {
   int cycles = atoi(argv[2]);
   double v[2] = {atof(argv[3]), atof(argv[4])};
   double w = atof(argv[5]);
-  auto engine = std::make_shared<shc_facade::Engine>(p, 1, 0);
-  shc_facade::Model model(engine);
-  shc_facade::WalkController walker(engine);
-  shc_facade::PoseController poser(engine);
-  shc_facade::AdmittanceController admittance(engine);
-  for (int c = 0; c < cycles; ++c) { // the reference's loop body, same call names and order
-    poser.updateCurrentPose(2 /* RUNNING */);
-    admittance.updateAdmittance();
-    walker.updateWalk(v, w);
-    poser.updateStance();
-    model.updateModel();
+  auto engine = std::make_shared<Engine>(p, 1, 0);
+  auto model = std::make_shared<Model>(engine);
+  auto walker = std::make_shared<WalkController>(engine);
+  auto poser = std::make_shared<PoseController>(engine);
+  auto admittance = std::make_shared<AdmittanceController>(engine);
+  RobotState robot_state = RUNNING;
+  for (int c = 0; c < cycles; ++c) { // the reference's loop body (state_controller.cpp:162-193, 379-447), same names and order
+    poser->updateCurrentPose(robot_state);
+    admittance->updateStiffness(walker);
+    admittance->updateAdmittance();
+    walker->updateWalk(v, w);
+    poser->updateStance();
+    model->updateModel();
   }
-  for (int l = 0; l < model.getLegCount(); ++l)
-    for (int j = 1; j <= model.getLegByIDNumber(l).getJointCount(); ++j) printf("%.17g\n", model.getLegByIDNumber(l).getJointByIDNumber(j).desired_position_);
-  printf("walk_state %d\n", walker.getWalkState());
+  for (int l = 0; l < model->getLegCount(); ++l)
+    for (int j = 1; j <= model->getLegByIDNumber(l).getJointCount(); ++j) printf("%.17g\n", model->getLegByIDNumber(l).getJointByIDNumber(j).desired_position_);
+  printf("walk_state %d\n", walker->getWalkState());
+  // ---- per-leg methods (model.h:448-492) on leg 2: FK, one explicit DLS step = solveIK + updateJointPositions, then applyIK
+  Leg leg = model->getLegByIDNumber(2);
+  Pose tip = leg.applyFK();
+  printf("%.17g %.17g %.17g\n", tip.position_[0], tip.position_[1], tip.position_[2]);
+  double delta[6] = {0.001, -0.002, 0.0015, 0, 0, 0};
+  std::vector<double> dq = leg.solveIK(delta, false);
+  printf("%.17g %.17g %.17g\n", dq[0], dq[1], dq[2]);
+  printf("%.17g\n", leg.updateJointPositions(dq, true));
+  Pose target = leg.applyFK();
+  target.position_[2] += 0.003;
+  target.rotation_ = Quaternion{0, 0, 0, 0}; // UNDEFINED_ROTATION: position only
+  leg.setDesiredTipPose(target, false);
+  printf("%.17g\n", leg.applyIK(true));
+  for (int j = 1; j <= 3; ++j) printf("%.17g\n", leg.getJointByIDNumber(j).desired_position_);
   return 0;
 }

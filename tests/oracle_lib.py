@@ -82,6 +82,11 @@ def lib():
         L.orc_leg_apply_ik.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_leg_apply_ik.restype = C.c_double
         L.orc_leg_apply_fk.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.orc_leg_step_to_position.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_double, C.c_double, C.c_int, _dp]
+        L.orc_leg_transition_configuration.argtypes = [C.c_void_p, C.c_int, _dp, C.c_double]
+        L.orc_startup_begin.argtypes = [C.c_void_p]
+        L.orc_startup_step.argtypes = [C.c_void_p]
+        L.orc_startup_finish.argtypes = [C.c_void_p]
         L.orc_get_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
         L.orc_set_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
         L.orc_batch_get_state.argtypes = [C.c_void_p, C.POINTER(InstanceState)]
@@ -284,6 +289,20 @@ class OracleBatch:
         for k, r, l in self._each():
             self.L.orc_leg_apply_fk(r, l, None if a is None else _ptr(a[k]), _ptr(out[k]))
         return out
+
+    def leg_step_to_position(self, target_tip_pose, target_pose, lift_height, time_to_step, apply_delta=True):
+        a = None if target_tip_pose is None else np.ascontiguousarray(target_tip_pose, dtype=np.float64).reshape(-1, 7)
+        b = np.ascontiguousarray(target_pose, dtype=np.float64).reshape(-1, 7)
+        out, prog = np.zeros((self.n * self.legs, 7)), np.zeros(self.n * self.legs, dtype=np.int32)
+        for k, r, l in self._each():
+            prog[k] = self.L.orc_leg_step_to_position(r, l, None if a is None else _ptr(a[k]), _ptr(b[k // self.legs]), lift_height,
+                                                      time_to_step, int(apply_delta), _ptr(out[k]))
+        return out, prog
+
+    def leg_transition_configuration(self, desired_configuration, transition_time):
+        D = self.dof // self.legs
+        a = np.ascontiguousarray(desired_configuration, dtype=np.float64).reshape(-1, D)
+        return np.array([self.L.orc_leg_transition_configuration(r, l, _ptr(a[k]), transition_time) for k, r, l in self._each()], dtype=np.int32)
 
     def get_state(self):
         """Full controller state of every robot as a ctypes array of InstanceState (shc_instance_state)."""

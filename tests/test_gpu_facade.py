@@ -7,6 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import oracle_lib
 from oracle_lib import OracleRobot
 from syropod_highlevel_controller_amd import default_hexapod_params, engine
 
@@ -30,3 +31,24 @@ def test_facade_reproduces_oracle(tmp_path):
     r.set_velocity(*v)
     r.cycle(cycles)
     assert np.abs(r.joints()[0] - q_gpu).max() <= 1e-6
+    # per-leg methods on leg 2, replayed on the oracle's Leg
+    num = lambda line: np.array([float(x) for x in line.split()])
+    L = oracle_lib.lib()
+    _dp = C.POINTER(C.c_double)
+    ptr = lambda a: a.ctypes.data_as(_dp)
+    pose = np.zeros(7)
+    L.orc_leg_apply_fk(r.h, 2, None, ptr(pose))
+    assert np.abs(num(out[19]) - pose[:3]).max() <= 1e-6
+    delta, dq = np.array([0.001, -0.002, 0.0015, 0, 0, 0]), np.zeros(3)
+    L.orc_leg_solve_ik(r.h, 2, ptr(delta), 0, ptr(dq))
+    assert np.abs(num(out[20]) - dq).max() <= 1e-7
+    prox = L.orc_leg_update_joint_positions(r.h, 2, ptr(dq), 1)
+    assert abs(float(out[21]) - prox) <= 1e-6
+    L.orc_leg_apply_fk(r.h, 2, None, ptr(pose))
+    pose[2] += 0.003
+    pose[3:] = 0.0
+    L.orc_leg_set_desired_tip_pose(r.h, 2, ptr(pose), 0)
+    res = L.orc_leg_apply_ik(r.h, 2, 1)
+    assert abs(float(out[22]) - res) <= 1e-6
+    q_leg = r.joints()[0][6:9]
+    assert np.abs(np.array([float(x) for x in out[23:26]]) - q_leg).max() <= 1e-6
