@@ -428,6 +428,39 @@ int shc_engine_get_state(shc_engine *e, int64_t first, int64_t count, shc_instan
  * inputs' reset mode) are not part of the state and stay as set. */
 int shc_engine_set_state(shc_engine *e, int64_t first, int64_t count, const shc_instance_state *states);
 
+/*
+ * Fleets: mixed morphologies (BASELINE.json configs[4]) and several GPUs of one node (configs[3]) behind one handle, for hosts
+ * that drive all devices from ONE process (a one-process-per-GPU host creates one engine per rank and exchanges with RCCL, see
+ * bench.py).  morph_id[i] in [0, n_morphologies) assigns instance i to params[morph_id[i]] (NULL = all 0).  Instances are binned
+ * by morphology - the cycle kernel keeps one morphology's tables in LDS and maps one leg to one lane - and every bin is split
+ * into contiguous shards over device_ids[0 .. n_devices) (NULL / 0 = device 0); each (bin, device) part is an engine on its own
+ * HIP stream.  Nothing is exchanged while stepping.  All arrays are HOST arrays in the CALLER's instance order; per-leg arrays
+ * are padded to [n][max_legs][max_k] (shc_fleet_shape), outputs are NaN where a morphology has no such leg / joint.
+ */
+typedef struct shc_fleet shc_fleet;
+int shc_fleet_create(const shc_params *params, int n_morphologies, const int32_t *morph_id, int64_t n_instances, const int *device_ids,
+                     int n_devices, shc_fleet **out);
+int shc_fleet_destroy(shc_fleet *f);
+int64_t shc_fleet_instances(const shc_fleet *f);
+int shc_fleet_shape(const shc_fleet *f, int *max_legs, int *max_dof);
+/* The parts (one engine per (morphology bin, device)): for device-resident I/O through the shc_engine_* calls. */
+int shc_fleet_part_count(const shc_fleet *f);
+int shc_fleet_part(const shc_fleet *f, int k, shc_engine **engine, int *morphology, int *device, int64_t *n_instances);
+int shc_fleet_part_instances(const shc_fleet *f, int k, int64_t *ids /* [n_instances of part k]: caller's instance ids, ascending */);
+int shc_fleet_set_velocity(shc_fleet *f, const double *linear_xy /* [n][2] */, const double *angular /* [n] */);
+int shc_fleet_set_imu(shc_fleet *f, const double *orientation_wxyz /* [n][4] */, const double *angular_velocity /* [n][3] */);
+int shc_fleet_set_pose_input(shc_fleet *f, const double *translation_velocity /* [n][3] */, const double *rotation_velocity /* [n][3] */);
+int shc_fleet_set_tip_force(shc_fleet *f, const double *tip_force /* [n][max_legs][3] */);
+int shc_fleet_set_joint_effort(shc_fleet *f, const double *joint_effort /* [n][max_legs][max_dof] */);
+int shc_fleet_step(shc_fleet *f, int n_cycles);
+int shc_fleet_synchronize(shc_fleet *f);
+int shc_fleet_get_joint_state(shc_fleet *f, double *q, double *qd /* [n][max_legs][max_dof], either may be NULL */);
+int shc_fleet_get_walk_state(shc_fleet *f, int32_t *walk_state /* [n] */);
+/* The exchange step of a sharded batch: every device ends up with the desired joint positions of ALL instances
+ * ([n][max_legs][max_dof], caller's order, NaN padded) in its own HBM, copied device to device (hipMemcpyPeerAsync: xGMI on an
+ * MI355X node).  device_buffers[d] (may be NULL) receives device_ids[d]'s buffer; the buffers belong to the fleet. */
+int shc_fleet_all_gather_joints(shc_fleet *f, double **device_buffers);
+
 #ifdef __cplusplus
 }
 #endif

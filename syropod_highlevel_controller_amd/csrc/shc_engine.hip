@@ -1823,3 +1823,5 @@ extern "C" int shc_engine_get_body_state(shc_engine *e, double *pose, double *ve
   }
   return SHC_OK;
 }
+
+#include "shc_fleet.hpp" // shc_fleet_*: mixed morphologies + multi-device sharding (uses the entry points above)

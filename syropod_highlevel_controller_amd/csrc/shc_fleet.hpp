@@ -1,0 +1,353 @@
+// shc_fleet.hpp — shc_fleet_*: mixed-morphology batches and multi-device sharding behind one handle (C ABI, host side).
+//
+// BASELINE.json configs[3] / configs[4]: robots are independent (nothing in the reference couples two robots), so a batch
+// shards by contiguous instance ranges with no data-path exchange while stepping, and a mixed-morphology batch is binned by
+// morphology: the cycle kernel keeps ONE morphology's DH / limit tables in LDS and maps one leg to one lane, so every
+// (morphology bin, device) pair gets its own engine on its own HIP stream.  The fleet keeps the caller's instance order at
+// the boundary whatever the interleaving pattern.  The only exchange is the all-gather of the final joint-state buffer:
+// every device ends up with every instance's joints, copied device to device (hipMemcpyPeerAsync: xGMI on an MI355X node).
+// One-process-per-GPU hosts (bench.py under torch.distributed) do the same exchange with RCCL instead.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+struct FleetPart {
+  shc_engine *engine = nullptr;
+  int morph = 0, device = 0, device_slot = 0;
+  hipStream_t stream = nullptr;
+  std::vector<int64_t> ids; // caller's instance ids, ascending
+};
+
+struct shc_fleet {
+  std::vector<shc_params> params;
+  std::vector<FleetPart> parts;
+  std::vector<int> devices;
+  int64_t n = 0;
+  int max_legs = 0, max_dof = 0;
+  std::vector<double *> gather; // per device: [n][max_legs][max_dof], NaN padded
+  std::vector<double> host_a, host_b;
+  std::vector<int32_t> host_i;
+};
+
+static void fleet_free(shc_fleet *f) {
+  if (!f) return;
+  for (auto &p : f->parts) {
+    if (p.engine) shc_engine_destroy(p.engine);
+    if (p.stream) {
+      (void)hipSetDevice(p.device);
+      (void)hipStreamDestroy(p.stream);
+    }
+  }
+  for (size_t d = 0; d < f->gather.size(); ++d)
+    if (f->gather[d]) {
+      (void)hipSetDevice(f->devices[d]);
+      (void)hipFree(f->gather[d]);
+    }
+  delete f;
+}
+
+extern "C" int shc_fleet_create(const shc_params *params, int n_morphologies, const int32_t *morph_id, int64_t n_instances, const int *device_ids,
+                                int n_devices, shc_fleet **out) {
+  if (!params || !out || n_morphologies < 1 || n_instances < 1) return fail(SHC_ERR_INVALID_ARG, "params / out NULL, or no morphology / instance");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SHC_ERR_NO_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+  const int one = 0;
+  if (!device_ids || n_devices < 1) {
+    device_ids = &one;
+    n_devices = 1;
+  }
+  for (int d = 0; d < n_devices; ++d)
+    if (device_ids[d] < 0 || device_ids[d] >= ndev) return fail(SHC_ERR_INVALID_ARG, "device id out of range");
+  shc_fleet *f = new shc_fleet();
+  f->params.assign(params, params + n_morphologies);
+  f->devices.assign(device_ids, device_ids + n_devices);
+  f->n = n_instances;
+  std::vector<std::vector<int64_t>> bins(n_morphologies);
+  for (int64_t i = 0; i < n_instances; ++i) {
+    const int m = morph_id ? morph_id[i] : 0;
+    if (m < 0 || m >= n_morphologies) {
+      fleet_free(f);
+      return fail(SHC_ERR_INVALID_ARG, "morph_id out of range");
+    }
+    bins[m].push_back(i);
+  }
+  for (int m = 0; m < n_morphologies; ++m) {
+    if (bins[m].empty()) continue;
+    int L, NJ;
+    const int rc = validate_params(&params[m], &L, &NJ);
+    if (rc != SHC_OK) {
+      fleet_free(f);
+      return rc;
+    }
+    f->max_legs = std::max(f->max_legs, L);
+    f->max_dof = std::max(f->max_dof, NJ);
+  }
+  // one init chain per morphology, shared by its shards
+  for (int m = 0; m < n_morphologies; ++m) {
+    if (bins[m].empty()) continue;
+    shc_tables tables;
+    int rc = shc_generate_tables(&params[m], &tables);
+    const int64_t nb = int64_t(bins[m].size());
+    for (int d = 0; d < n_devices && rc == SHC_OK; ++d) { // contiguous shards of the bin, sizes differing by at most one
+      const int64_t base = nb / n_devices, rem = nb % n_devices;
+      const int64_t lo = d * base + std::min<int64_t>(d, rem), hi = lo + base + (d < rem ? 1 : 0);
+      if (hi == lo) continue;
+      FleetPart part;
+      part.morph = m;
+      part.device = device_ids[d];
+      part.device_slot = d;
+      part.ids.assign(bins[m].begin() + lo, bins[m].begin() + hi);
+      if (hipSetDevice(part.device) != hipSuccess || hipStreamCreateWithFlags(&part.stream, hipStreamNonBlocking) != hipSuccess) {
+        rc = fail(SHC_ERR_HIP, "stream creation failed");
+        break;
+      }
+      rc = shc_engine_create_with_tables(&params[m], &tables, hi - lo, part.device, part.stream, &part.engine);
+      f->parts.push_back(part); // (also on failure: fleet_free releases the stream)
+    }
+    if (rc != SHC_OK) {
+      fleet_free(f);
+      return rc;
+    }
+  }
+  f->gather.assign(n_devices, nullptr);
+  *out = f;
+  return SHC_OK;
+}
+
+extern "C" int shc_fleet_destroy(shc_fleet *f) {
+  fleet_free(f);
+  return SHC_OK;
+}
+extern "C" int64_t shc_fleet_instances(const shc_fleet *f) { return f ? f->n : 0; }
+extern "C" int shc_fleet_part_count(const shc_fleet *f) { return f ? int(f->parts.size()) : 0; }
+extern "C" int shc_fleet_part(const shc_fleet *f, int k, shc_engine **engine, int *morphology, int *device, int64_t *n_instances) {
+  if (!f || k < 0 || k >= int(f->parts.size())) return fail(SHC_ERR_INVALID_ARG, "part index out of range");
+  const FleetPart &p = f->parts[k];
+  if (engine) *engine = p.engine;
+  if (morphology) *morphology = p.morph;
+  if (device) *device = p.device;
+  if (n_instances) *n_instances = int64_t(p.ids.size());
+  return SHC_OK;
+}
+extern "C" int shc_fleet_part_instances(const shc_fleet *f, int k, int64_t *ids) {
+  if (!f || !ids || k < 0 || k >= int(f->parts.size())) return fail(SHC_ERR_INVALID_ARG, "part index out of range / ids NULL");
+  std::copy(f->parts[k].ids.begin(), f->parts[k].ids.end(), ids);
+  return SHC_OK;
+}
+
+// caller-order rows of `width` doubles -> the part's rows
+static const double *fleet_pick(shc_fleet *f, const FleetPart &p, const double *src, int width, std::vector<double> &buf) {
+  if (!src) return nullptr;
+  buf.resize(p.ids.size() * size_t(width));
+  for (size_t k = 0; k < p.ids.size(); ++k) std::copy(src + p.ids[k] * width, src + (p.ids[k] + 1) * width, buf.begin() + k * width);
+  return buf.data();
+}
+
+extern "C" int shc_fleet_set_velocity(shc_fleet *f, const double *linear_xy, const double *angular) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  for (auto &p : f->parts) {
+    const int rc = shc_engine_set_velocity(p.engine, fleet_pick(f, p, linear_xy, 2, f->host_a), fleet_pick(f, p, angular, 1, f->host_b), 0);
+    if (rc != SHC_OK) return rc;
+  }
+  return SHC_OK;
+}
+extern "C" int shc_fleet_set_imu(shc_fleet *f, const double *orientation_wxyz, const double *angular_velocity) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  for (auto &p : f->parts) {
+    const int rc = shc_engine_set_imu(p.engine, fleet_pick(f, p, orientation_wxyz, 4, f->host_a), fleet_pick(f, p, angular_velocity, 3, f->host_b), 0);
+    if (rc != SHC_OK) return rc;
+  }
+  return SHC_OK;
+}
+extern "C" int shc_fleet_set_pose_input(shc_fleet *f, const double *translation_velocity, const double *rotation_velocity) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  for (auto &p : f->parts) {
+    const int rc =
+        shc_engine_set_pose_input(p.engine, fleet_pick(f, p, translation_velocity, 3, f->host_a), fleet_pick(f, p, rotation_velocity, 3, f->host_b), 0);
+    if (rc != SHC_OK) return rc;
+  }
+  return SHC_OK;
+}
+// per-leg inputs arrive padded: [n][max_legs][max_k]; entries beyond a morphology's (legs, k) are ignored
+static int fleet_set_leg(shc_fleet *f, const double *src, int max_k, bool per_dof, int (*setter)(shc_engine *, const double *, int)) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  if (!src) return SHC_OK;
+  for (auto &p : f->parts) {
+    const shc_params &pp = f->params[p.morph];
+    const int L = pp.leg_count, K = per_dof ? pp.leg_dof[0] : max_k;
+    f->host_a.resize(p.ids.size() * size_t(L) * K);
+    for (size_t k = 0; k < p.ids.size(); ++k)
+      for (int l = 0; l < L; ++l)
+        for (int j = 0; j < K; ++j) f->host_a[(k * L + l) * K + j] = src[(size_t(p.ids[k]) * f->max_legs + l) * max_k + j];
+    const int rc = setter(p.engine, f->host_a.data(), 0);
+    if (rc != SHC_OK) return rc;
+  }
+  return SHC_OK;
+}
+extern "C" int shc_fleet_set_tip_force(shc_fleet *f, const double *tip_force) { return fleet_set_leg(f, tip_force, 3, false, shc_engine_set_tip_force); }
+extern "C" int shc_fleet_set_joint_effort(shc_fleet *f, const double *joint_effort) {
+  return fleet_set_leg(f, joint_effort, f ? f->max_dof : 0, true, shc_engine_set_joint_effort);
+}
+extern "C" int shc_fleet_shape(const shc_fleet *f, int *max_legs, int *max_dof) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  if (max_legs) *max_legs = f->max_legs;
+  if (max_dof) *max_dof = f->max_dof;
+  return SHC_OK;
+}
+
+// every part advances on its own stream; nothing orders one part against another
+extern "C" int shc_fleet_step(shc_fleet *f, int n_cycles) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  for (auto &p : f->parts) {
+    const int rc = shc_engine_step(p.engine, n_cycles);
+    if (rc != SHC_OK) return rc;
+  }
+  return SHC_OK;
+}
+extern "C" int shc_fleet_synchronize(shc_fleet *f) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  for (auto &p : f->parts) {
+    const int rc = shc_engine_synchronize(p.engine);
+    if (rc != SHC_OK) return rc;
+  }
+  return SHC_OK;
+}
+
+// q / qd: [n][max_legs][max_dof] in the caller's instance order, NaN where a morphology has no such leg / joint
+extern "C" int shc_fleet_get_joint_state(shc_fleet *f, double *q, double *qd) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  const size_t row = size_t(f->max_legs) * f->max_dof;
+  for (double *dst : {q, qd})
+    if (dst) std::fill(dst, dst + size_t(f->n) * row, std::nan(""));
+  for (auto &p : f->parts) {
+    const shc_params &pp = f->params[p.morph];
+    const int L = pp.leg_count, D = pp.leg_dof[0];
+    f->host_a.resize(p.ids.size() * size_t(L) * D);
+    f->host_b.resize(f->host_a.size());
+    const int rc = shc_engine_get_joint_state(p.engine, q ? f->host_a.data() : nullptr, qd ? f->host_b.data() : nullptr, 0);
+    if (rc != SHC_OK) return rc;
+    for (size_t k = 0; k < p.ids.size(); ++k)
+      for (int l = 0; l < L; ++l)
+        for (int j = 0; j < D; ++j) {
+          const size_t o = size_t(p.ids[k]) * row + size_t(l) * f->max_dof + j;
+          if (q) q[o] = f->host_a[(k * L + l) * D + j];
+          if (qd) qd[o] = f->host_b[(k * L + l) * D + j];
+        }
+  }
+  return SHC_OK;
+}
+extern "C" int shc_fleet_get_walk_state(shc_fleet *f, int32_t *walk_state) {
+  if (!f || !walk_state) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  for (auto &p : f->parts) {
+    f->host_i.resize(p.ids.size());
+    const int rc = shc_engine_get_body_state(p.engine, nullptr, nullptr, f->host_i.data(), 0);
+    if (rc != SHC_OK) return rc;
+    for (size_t k = 0; k < p.ids.size(); ++k) walk_state[p.ids[k]] = f->host_i[k];
+  }
+  return SHC_OK;
+}
+
+// Scatter of one part's joints ([rows][L][D], contiguous) into a gather buffer ([n][max_legs][max_dof]) at the caller's ids.
+__global__ void fleet_place_joints_kernel(double *gather, const double *part, const int64_t *ids, int64_t rows, int L, int D, int max_legs, int max_dof) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= rows * L * D) return;
+  const int64_t k = t / (L * D);
+  const int r = int(t - k * L * D), l = r / D, j = r - l * D;
+  gather[(ids[k] * max_legs + l) * max_dof + j] = part[t];
+}
+
+// The exchange step: every device ends up with the desired joint positions of ALL instances ([n][max_legs][max_dof], NaN
+// padded, caller's order) in its own HBM; device_buffers[d] receives device d's buffer (owned by the fleet).  Each part
+// gathers its joints on its own device and stream, places them in the local buffer and copies its rows to the other devices'
+// buffers peer to peer.
+extern "C" int shc_fleet_all_gather_joints(shc_fleet *f, double **device_buffers) {
+  if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
+  const size_t row = size_t(f->max_legs) * f->max_dof, total = size_t(f->n) * row;
+  const int nd = int(f->devices.size());
+  for (int d = 0; d < nd; ++d) {
+    HIP_TRY(hipSetDevice(f->devices[d]));
+    if (!f->gather[d]) HIP_TRY(hipMalloc(&f->gather[d], total * 8));
+    // NaN padding (0xFF bytes are a NaN pattern); parts overwrite their entries
+    HIP_TRY(hipMemsetAsync(f->gather[d], 0xFF, total * 8, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+  }
+  struct Tmp {
+    double *joints = nullptr;
+    int64_t *ids = nullptr;
+    double *placed = nullptr;
+  };
+  std::vector<Tmp> tmp(f->parts.size());
+  int rc = SHC_OK;
+  for (size_t k = 0; k < f->parts.size() && rc == SHC_OK; ++k) {
+    FleetPart &p = f->parts[k];
+    const shc_params &pp = f->params[p.morph];
+    const int L = pp.leg_count, D = pp.leg_dof[0];
+    const int64_t rows = int64_t(p.ids.size());
+    if (hipSetDevice(p.device) != hipSuccess || hipMalloc(&tmp[k].joints, size_t(rows) * L * D * 8) != hipSuccess ||
+        hipMalloc(&tmp[k].ids, size_t(rows) * 8) != hipSuccess) {
+      rc = fail(SHC_ERR_HIP, "fleet gather: allocation failed");
+      break;
+    }
+    if (hipMemcpyAsync(tmp[k].ids, p.ids.data(), size_t(rows) * 8, hipMemcpyHostToDevice, p.stream) != hipSuccess) rc = fail(SHC_ERR_HIP, "fleet gather: copy failed");
+    if (rc == SHC_OK) rc = shc_engine_get_joint_state(p.engine, tmp[k].joints, nullptr, 1);
+    if (rc != SHC_OK) break;
+    const int64_t threads = rows * L * D;
+    for (int d = 0; d < nd && rc == SHC_OK; ++d) {
+      if (f->devices[d] == p.device) { // local placement (also covers several shards sharing one device)
+        fleet_place_joints_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, p.stream>>>(f->gather[d], tmp[k].joints, tmp[k].ids, rows, L, D,
+                                                                                                   f->max_legs, f->max_dof);
+        if (hipGetLastError() != hipSuccess) rc = fail(SHC_ERR_HIP, "fleet gather: placement kernel failed");
+      }
+    }
+  }
+  // peer copies: a part's rows are scattered in the caller's order, so remote devices receive the part's contiguous joints and
+  // place them with the same kernel on their side
+  std::vector<std::pair<int, void *>> remote; // (device, buffer) to free
+  for (size_t k = 0; k < f->parts.size() && rc == SHC_OK; ++k) {
+    FleetPart &p = f->parts[k];
+    const shc_params &pp = f->params[p.morph];
+    const int L = pp.leg_count, D = pp.leg_dof[0];
+    const int64_t rows = int64_t(p.ids.size()), threads = rows * L * D;
+    if (hipSetDevice(p.device) != hipSuccess || hipStreamSynchronize(p.stream) != hipSuccess) {
+      rc = fail(SHC_ERR_HIP, "fleet gather: synchronisation failed");
+      break;
+    }
+    for (int d = 0; d < nd && rc == SHC_OK; ++d) {
+      if (f->devices[d] == p.device) continue;
+      double *rj = nullptr;
+      int64_t *ri = nullptr;
+      if (hipSetDevice(f->devices[d]) != hipSuccess || hipMalloc(&rj, size_t(threads) * 8) != hipSuccess || hipMalloc(&ri, size_t(rows) * 8) != hipSuccess) {
+        rc = fail(SHC_ERR_HIP, "fleet gather: remote allocation failed");
+        break;
+      }
+      remote.emplace_back(f->devices[d], rj);
+      remote.emplace_back(f->devices[d], ri);
+      if (hipMemcpyPeerAsync(rj, f->devices[d], tmp[k].joints, p.device, size_t(threads) * 8, nullptr) != hipSuccess ||
+          hipMemcpyPeerAsync(ri, f->devices[d], tmp[k].ids, p.device, size_t(rows) * 8, nullptr) != hipSuccess) {
+        rc = fail(SHC_ERR_HIP, "fleet gather: peer copy failed");
+        break;
+      }
+      fleet_place_joints_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr>>>(f->gather[d], rj, ri, rows, L, D, f->max_legs,
+                                                                                                 f->max_dof);
+      if (hipGetLastError() != hipSuccess) rc = fail(SHC_ERR_HIP, "fleet gather: remote placement failed");
+    }
+  }
+  for (int d = 0; d < nd; ++d) {
+    (void)hipSetDevice(f->devices[d]);
+    (void)hipDeviceSynchronize();
+  }
+  for (auto &r : remote) {
+    (void)hipSetDevice(r.first);
+    (void)hipFree(r.second);
+  }
+  for (size_t k = 0; k < tmp.size(); ++k) {
+    (void)hipSetDevice(f->parts[k].device);
+    (void)hipFree(tmp[k].joints);
+    (void)hipFree(tmp[k].ids);
+  }
+  if (rc == SHC_OK && device_buffers)
+    for (int d = 0; d < nd; ++d) device_buffers[d] = f->gather[d];
+  return rc;
+}

@@ -34,6 +34,10 @@ EXPORTED_SYMBOLS = [
     "shc_sizeof_instance_state", "shc_engine_get_state", "shc_engine_set_state",
     "shc_leg_set_desired_tip_pose", "shc_leg_solve_ik", "shc_leg_update_joint_positions", "shc_leg_apply_ik", "shc_leg_apply_fk",
     "shc_leg_step_to_position", "shc_leg_transition_configuration", "shc_engine_begin_direct_startup", "shc_engine_direct_startup",
+    "shc_fleet_create", "shc_fleet_destroy", "shc_fleet_instances", "shc_fleet_shape", "shc_fleet_part_count", "shc_fleet_part",
+    "shc_fleet_part_instances", "shc_fleet_set_velocity", "shc_fleet_set_imu", "shc_fleet_set_pose_input", "shc_fleet_set_tip_force",
+    "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
+    "shc_fleet_all_gather_joints",
 ]
 
 
@@ -137,6 +141,20 @@ def lib():
         L.shc_leg_step_to_position.argtypes = sel + [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.shc_leg_transition_configuration.argtypes = sel + [C.c_void_p, C.c_double, C.c_void_p, C.c_int]
         L.shc_engine_begin_direct_startup.argtypes = [C.c_void_p]
+        L.shc_fleet_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.shc_fleet_destroy.argtypes = [C.c_void_p]
+        L.shc_fleet_instances.argtypes = [C.c_void_p]
+        L.shc_fleet_instances.restype = C.c_int64
+        L.shc_fleet_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.shc_fleet_part_count.argtypes = [C.c_void_p]
+        L.shc_fleet_part.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]
+        L.shc_fleet_part_instances.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        for name, k in (("shc_fleet_set_velocity", 2), ("shc_fleet_set_imu", 2), ("shc_fleet_set_pose_input", 2), ("shc_fleet_set_tip_force", 1),
+                        ("shc_fleet_set_joint_effort", 1), ("shc_fleet_get_joint_state", 2), ("shc_fleet_get_walk_state", 1)):
+            getattr(L, name).argtypes = [C.c_void_p] + [C.c_void_p] * k
+        L.shc_fleet_step.argtypes = [C.c_void_p, C.c_int]
+        L.shc_fleet_synchronize.argtypes = [C.c_void_p]
+        L.shc_fleet_all_gather_joints.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.shc_engine_direct_startup.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.shc_engine_get_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]
         L.shc_engine_set_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(InstanceState)]

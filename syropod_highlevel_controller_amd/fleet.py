@@ -1,9 +1,8 @@
-"""Mixed-morphology batches (BASELINE.json configs[4]): instances that differ in leg count, joints per leg or gait.
+"""Mixed-morphology / multi-device batches: thin ctypes view of the C ABI's shc_fleet_* entry points (include/shc_batch.h).
 
-The cycle kernel keeps one morphology's DH / limit tables in LDS and maps one leg to one lane, so a batch is uniform per
-engine.  A fleet bins its instances by morphology id (the "sorted / binned variant" of SURVEY.md section 8d), runs one
-engine per bin, each on its own HIP stream so that small bins overlap on the GPU, and keeps the caller's instance order at
-the boundary: inputs arrive and outputs leave indexed by the caller's instance id, whatever the interleaving pattern.
+The binning (one engine and one HIP stream per (morphology bin, device)), the contiguous sharding over devices and the
+device-to-device all-gather of the joint buffer live in the library (csrc/shc_fleet.hpp); this class only converts numpy
+arrays.  Inputs arrive and outputs leave indexed by the caller's instance id, whatever the interleaving pattern.
 """
 from __future__ import annotations
 
@@ -17,47 +16,29 @@ from .params import Params
 
 
 class MixedFleet:
-    def __init__(self, morphologies: Sequence[Params], morph_id, device: int = 0, own_streams: bool = True,
-                 device_init: bool = False):
-        """morphologies[k] describes bin k; morph_id[i] in [0, len(morphologies)) assigns instance i to a bin.
-        device_init: run the init chain of all bins as one batch of HIP kernels (shc_generate_tables_batch) instead of
-        ~1 ms of host time per bin; the start-up joint configuration then agrees with the host's to ~1e-6 rad only (the
-        reference's start-up iteration amplifies rounding differences)."""
-        self.morph_id = np.asarray(morph_id, dtype=np.int64)
-        self.n = len(self.morph_id)
-        if self.n == 0 or self.morph_id.min() < 0 or self.morph_id.max() >= len(morphologies):
-            raise ValueError("morph_id out of range")
-        self.device = device
+    def __init__(self, morphologies: Sequence[Params], morph_id, devices: Sequence[int] = (0,)):
+        """morphologies[k] describes bin k; morph_id[i] in [0, len(morphologies)) assigns instance i to a bin; every bin is
+        sharded over `devices` (repeating a device id gives several shards on that device)."""
         self.L = _engine.lib()
+        if self.L.shc_device_count() < 1:
+            raise _engine.ShcError("no HIP device visible: the batched engine has no CPU fallback")
+        self.morph_id = np.ascontiguousarray(morph_id, dtype=np.int32)
+        self.n = len(self.morph_id)
         self.params = list(morphologies)
-        self.index = [np.nonzero(self.morph_id == k)[0] for k in range(len(morphologies))]  # instance ids of bin k, ascending
-        self.streams, self.engines = [], []
-        # init chain (start-up solve, workspace search, walkspace, limits) of every bin at once on the GPU
-        tables, status = _engine.generate_tables_batch(self.params, device) if device_init else (None, None)
-        for k, idx in enumerate(self.index):
-            if len(idx) == 0:
-                self.streams.append(None)
-                self.engines.append(None)
-                continue
-            s = C.c_void_p(0)
-            if own_streams:
-                _engine._check(self.L.shc_stream_create(device, C.byref(s)), "shc_stream_create")
-            self.streams.append(s)
-            if status is not None and status[k] != 0:
-                raise _engine.ShcError(f"morphology {k} rejected by the init chain (code {status[k]})")
-            self.engines.append(_engine.BatchEngine(morphologies[k], len(idx), device, s.value or 0,
-                                                    tables=None if tables is None else tables[k]))
-        self.max_legs = max(p.leg_count for p in self.params)
-        self.max_dof = max(p.leg_dof[0] for p in self.params)
+        arr = (Params * len(self.params))(*self.params)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        _engine._check(self.L.shc_fleet_create(arr, len(self.params), self.morph_id.ctypes.data_as(C.c_void_p), self.n,
+                                               dev.ctypes.data_as(C.c_void_p), len(dev), C.byref(h)), "shc_fleet_create")
+        self.h, self.n_devices = h, len(dev)
+        a, b = C.c_int(), C.c_int()
+        _engine._check(self.L.shc_fleet_shape(self.h, C.byref(a), C.byref(b)), "shc_fleet_shape")
+        self.max_legs, self.max_dof = a.value, b.value
 
     def close(self):
-        for e in self.engines:
-            if e is not None:
-                e.close()
-        for s in self.streams:
-            if s is not None and s.value:
-                self.L.shc_stream_destroy(self.device, s)
-        self.engines, self.streams = [], []
+        if getattr(self, "h", None):
+            self.L.shc_fleet_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         try:
@@ -65,42 +46,50 @@ class MixedFleet:
         except Exception:
             pass
 
-    def _bins(self):
-        return [(k, e, self.index[k]) for k, e in enumerate(self.engines) if e is not None]
+    def parts(self):
+        """[(engine handle, morphology, device, instance ids)] of every (bin, device) part."""
+        out = []
+        for k in range(self.L.shc_fleet_part_count(self.h)):
+            e, m, d, n = C.c_void_p(), C.c_int(), C.c_int(), C.c_int64()
+            _engine._check(self.L.shc_fleet_part(self.h, k, C.byref(e), C.byref(m), C.byref(d), C.byref(n)), "shc_fleet_part")
+            ids = np.zeros(n.value, dtype=np.int64)
+            _engine._check(self.L.shc_fleet_part_instances(self.h, k, ids.ctypes.data_as(C.c_void_p)), "shc_fleet_part_instances")
+            out.append((e.value, m.value, d.value, ids))
+        return out
 
-    # ---- inputs in the caller's instance order
+    @staticmethod
+    def _p(a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
     def set_velocity(self, linear_xy, angular):
-        for _, e, idx in self._bins():
-            e.set_velocity(np.ascontiguousarray(linear_xy[idx]), np.ascontiguousarray(angular[idx]))
+        a, b = np.ascontiguousarray(linear_xy, dtype=np.float64), np.ascontiguousarray(angular, dtype=np.float64)
+        _engine._check(self.L.shc_fleet_set_velocity(self.h, self._p(a), self._p(b)), "shc_fleet_set_velocity")
 
     def set_joint_effort(self, effort_padded):
         """effort_padded [n][max_legs][max_dof]; entries beyond a bin's (legs, dof) are ignored."""
-        for k, e, idx in self._bins():
-            p = self.params[k]
-            e.set_joint_effort(np.ascontiguousarray(effort_padded[idx][:, :p.leg_count, :p.leg_dof[0]].reshape(len(idx), -1)))
+        a = np.ascontiguousarray(effort_padded, dtype=np.float64)
+        assert a.shape == (self.n, self.max_legs, self.max_dof)
+        _engine._check(self.L.shc_fleet_set_joint_effort(self.h, self._p(a)), "shc_fleet_set_joint_effort")
 
-    # ---- stepping: every bin advances n_cycles on its own stream; nothing orders one bin against another
     def step(self, n_cycles: int = 1):
-        for _, e, _ in self._bins():
-            e.step(n_cycles)
+        _engine._check(self.L.shc_fleet_step(self.h, int(n_cycles)), "shc_fleet_step")
 
     def synchronize(self):
-        for _, e, _ in self._bins():
-            e.synchronize()
+        _engine._check(self.L.shc_fleet_synchronize(self.h), "shc_fleet_synchronize")
 
-    # ---- outputs in the caller's instance order, NaN-padded to [n][max_legs][max_dof]
     def joints(self):
-        q = np.full((self.n, self.max_legs, self.max_dof), np.nan)
-        qd = np.full_like(q, np.nan)
-        for k, e, idx in self._bins():
-            p = self.params[k]
-            a, b = e.joints()
-            q[idx, :p.leg_count, :p.leg_dof[0]] = a.reshape(len(idx), p.leg_count, p.leg_dof[0])
-            qd[idx, :p.leg_count, :p.leg_dof[0]] = b.reshape(len(idx), p.leg_count, p.leg_dof[0])
+        q = np.zeros((self.n, self.max_legs, self.max_dof))
+        qd = np.zeros_like(q)
+        _engine._check(self.L.shc_fleet_get_joint_state(self.h, self._p(q), self._p(qd)), "shc_fleet_get_joint_state")
         return q, qd
 
     def walk_state(self):
         ws = np.zeros(self.n, dtype=np.int32)
-        for _, e, idx in self._bins():
-            ws[idx] = e.body_state()[2]
+        _engine._check(self.L.shc_fleet_get_walk_state(self.h, self._p(ws)), "shc_fleet_get_walk_state")
         return ws
+
+    def all_gather_joints(self):
+        """Device pointers (one per device slot) of the gathered [n][max_legs][max_dof] joint buffers."""
+        bufs = (C.c_void_p * self.n_devices)()
+        _engine._check(self.L.shc_fleet_all_gather_joints(self.h, bufs), "shc_fleet_all_gather_joints")
+        return [b for b in bufs]

@@ -192,7 +192,7 @@ def test_config5_interleaved_fleet(Engine):
     rng = np.random.default_rng(77)
     lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
     effort = rng.normal(0, 0.5, size=(n, 8, 5))
-    fleet = MixedFleet(morphs, mid, device_init=True)  # tables of all five bins from one batch of init-chain kernels
+    fleet = MixedFleet(morphs, mid)  # shc_fleet_create: binning, one engine + stream per bin, all in the C ABI
     fleet.set_velocity(lin, ang)
     fleet.set_joint_effort(effort)
     oracles = []
@@ -213,6 +213,53 @@ def test_config5_interleaved_fleet(Engine):
             assert np.abs(q[idx, :p.leg_count, :p.leg_dof[0]] - qo).max() <= TOL_Q
             assert np.isnan(q[idx, p.leg_count:, :]).all() and np.isnan(q[idx, :, p.leg_dof[0]:]).all()
             assert np.array_equal(ws[idx], ob.body_state()[2])
+    fleet.close()
+
+
+def test_fleet_shards_and_all_gather(Engine):
+    """shc_fleet_* with every bin split into TWO shards (two device slots; on a one-GPU box both are device 0 - the code path
+    of a multi-GPU node, minus the peer copies): the sharded fleet reproduces single engines instance for instance and the
+    exchange step leaves the complete joint buffer in every slot's HBM."""
+    import ctypes as C
+    from syropod_highlevel_controller_amd.fleet import MixedFleet
+    morphs = [default_hexapod_params("tripod"), synthetic_octopod_params("ripple", 5, 8)]
+    n = 61
+    rng = np.random.default_rng(5)
+    mid = rng.integers(0, 2, n)
+    lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
+    fleet = MixedFleet(morphs, mid, devices=(0, 0))
+    parts = fleet.parts()
+    assert len(parts) == 4 and sorted(np.concatenate([ids for *_, ids in parts]).tolist()) == list(range(n))
+    for k, m in enumerate((0, 1)):  # contiguous shards of each bin, sizes differing by at most one
+        shard = [ids for _, mm, _, ids in parts if mm == m]
+        assert np.array_equal(np.concatenate(shard), np.nonzero(mid == m)[0]) and abs(len(shard[0]) - len(shard[1])) <= 1
+    fleet.set_velocity(lin, ang)
+    singles = []
+    for m, p in enumerate(morphs):
+        idx = np.nonzero(mid == m)[0]
+        e = Engine(p, len(idx))
+        e.set_features(FEAT_DEFAULT)
+        e.set_velocity(lin[idx], ang[idx])
+        singles.append((idx, p, e))
+    for cycles in (1, 80, 120):
+        fleet.step(cycles)
+        fleet.synchronize()
+        q, qd = fleet.joints()
+        for idx, p, e in singles:
+            e.step(cycles)
+            e.synchronize()
+            a, b = e.joints()
+            L, D = p.leg_count, p.leg_dof[0]
+            assert np.array_equal(q[idx, :L, :D], a.reshape(len(idx), L, D))      # same kernels, same inputs: bit-identical
+            assert np.array_equal(qd[idx, :L, :D], b.reshape(len(idx), L, D))
+            assert np.isnan(q[idx, L:, :]).all() and np.isnan(q[idx, :, D:]).all()
+    bufs = fleet.all_gather_joints()
+    assert len(bufs) == 2 and bufs[0] != bufs[1]
+    hip = C.CDLL("libamdhip64.so")
+    for b in bufs:  # every device slot holds every instance's joints
+        host = np.zeros((n, fleet.max_legs, fleet.max_dof))
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(b), host.nbytes, 2) == 0
+        assert np.array_equal(np.isnan(host), np.isnan(q)) and np.array_equal(np.nan_to_num(host), np.nan_to_num(q))
     fleet.close()
 
 
@@ -790,13 +837,14 @@ def test_leg_state_message_payload(Engine):
                         np.testing.assert_allclose(a, b, rtol=0, atol=1e-8, err_msg=f"{name} cycle {done} instance {i}")
 
 
-def test_init_chain_on_device_matches_host():
+def test_init_chain_on_device_matches_the_oracle():
     """shc_generate_tables_batch (start-up solve + workspace search + walkspace + limits as HIP kernels, one thread per
-    (morphology, leg)) against the host init chain for perturbed morphologies.  Integers are exact; workspace radii,
-    walkspace and limits agree to 1e-8 (measured 1e-16 .. 5e-10).  The start-up joint configuration is the state of the
-    reference's DLS iteration after a fixed 300 steps, which still chatters around the solution and amplifies rounding
-    differences (host libm / no FMA vs device ocml / FMA): most morphologies agree to 1e-6 rad, all to 1e-3.
-    A rejected parameter set is reported per morphology."""
+    (morphology, leg, bearing)) against the ORACLE's init chain for perturbed morphologies.  Integers are exact; workspace
+    radii, walkspace and limits agree to 1e-8 wherever the start-up configuration does.  The start-up joint configuration is the state of the reference's DLS iteration
+    after time_to_start / time_delta steps, which amplifies rounding differences by ~1.1x per step
+    (tests/test_oracle_conditioning.py): at 200 steps the device chain (FMA contraction, its own sin / cos) is within 1e-9 rad of
+    the oracle for every morphology, at the default 300 steps within 1e-5 with a median below 1e-7 - what the oracle's own
+    fast-math build shows against itself.  A rejected parameter set is reported per morphology."""
     from syropod_highlevel_controller_amd import engine
     rng = np.random.default_rng(91)
     plist = []
@@ -812,27 +860,40 @@ def test_init_chain_on_device_matches_host():
             p.stance_position[l][1] *= 1.0 + rng.uniform(-0.05, 0.05)
         p.body_clearance *= 1.0 + rng.uniform(-0.1, 0.1)
         p.step_frequency = [1.0, 0.8, 1.25][k % 3]
+        if k % 2:
+            p.time_to_start = 4.0  # 200 start-up steps
         plist.append(p)
     bad = default_hexapod_params("tripod")
-    bad.rough_terrain_mode = 1
+    bad.leg_dof[1] = 4
     plist.append(bad)
     tables, status = engine.generate_tables_batch(plist)
     assert status[-1] != 0 and (status[:-1] == 0).all()
-    tight = []
+    err = {200: [], 300: []}
     for p, t in zip(plist[:-1], tables[:-1]):
-        h = engine.generate_tables(p)
+        h = OracleRobot(p).tables()
         for name in ("period", "swing_period", "stance_period", "stance_end", "swing_start", "swing_end", "stance_start"):
             assert getattr(t.step, name) == getattr(h.step, name)
-        assert list(t.phase_offset) == list(h.phase_offset)
-        assert (t.pose_phase_length, t.pose_normaliser, t.auto_pose_reference_leg) == (h.pose_phase_length, h.pose_normaliser, h.auto_pose_reference_leg)
         L, D = p.leg_count, p.leg_dof[0]
+        assert list(t.phase_offset)[:L] == list(h.phase_offset)[:L]
+        assert (t.pose_phase_length, t.pose_normaliser, t.auto_pose_reference_leg) == (h.pose_phase_length, h.pose_normaliser, h.auto_pose_reference_leg)
         dq = np.abs(np.array(t.default_joint_position)[:L, :D] - np.array(h.default_joint_position)[:L, :D]).max()
-        assert dq < 1e-3
-        tight.append(dq <= 1e-6)
-        np.testing.assert_allclose(np.array(t.workspace_radius)[:L], np.array(h.workspace_radius)[:L], atol=1e-8)
+        redundant = D == 5  # unconstrained 5-joint chains: the oracle's twin build is already 2e-8 away (test_host_tables_and_abi.py)
+        steps = round(p.time_to_start / p.time_delta)
+        err[steps].append((dq, redundant))
+        # the workspace search starts from the start-up configuration and ends where an IK step first fails: its radii inherit
+        # the configuration's difference (1e-9 at 200 start-up steps, up to 1e-5 at 300)
+        tol = 1e-8 if steps == 200 and not redundant else 1e-5
+        np.testing.assert_allclose(np.array(t.workspace_radius)[:L], np.array(h.workspace_radius)[:L], atol=tol)
         for name in ("walkspace", "max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration"):
-            np.testing.assert_allclose(np.array(getattr(t, name)), np.array(getattr(h, name)), rtol=1e-8, atol=1e-8, err_msg=name)
-    assert np.mean(tight) > 0.8
+            np.testing.assert_allclose(np.array(getattr(t, name)), np.array(getattr(h, name)), rtol=tol * 100, atol=tol, err_msg=name)
+    e200 = np.array([d for d, r in err[200] if not r])
+    e300 = np.array([d for d, r in err[300] if not r])
+    red = np.array([d for k in err for d, r in err[k] if r])
+    print(f"device init chain vs oracle, start-up configuration: 200 steps max {e200.max():.2e}, 300 steps median {np.median(e300):.2e} "
+          f"max {e300.max():.2e}, redundant 5-joint chains max {red.max():.2e} rad")
+    assert e200.max() < 1e-9
+    assert np.median(e300) < 1e-7 and e300.max() < 1e-5
+    assert red.max() < 1e-4
 
 
 def test_every_device_pointer_entry_point(Engine):
