@@ -254,7 +254,57 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     return res
 
 
-DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072}
+DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config5": 1 << 20}
+CONFIG5_BINS = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"))  # (legs, dof, gait)
+
+
+def run_config5(n, steps, warmup, seed):
+    """BASELINE.json configs[4]: mixed morphologies (4 / 6 / 8 legs, 3 - 5 joints, all four gaits), instance i has morphology
+    i mod 5 - the worst interleaving for a one-kernel design.  shc_fleet_create bins the instances (one engine + one HIP stream
+    per morphology), so the device work is the same whatever the order; the interleaved and the sorted ("binned") order differ
+    only in the host-side permutation of the boundary arrays, reported separately."""
+    import torch
+    from syropod_highlevel_controller_amd import synthetic_octopod_params
+    from syropod_highlevel_controller_amd.fleet import MixedFleet
+    from syropod_highlevel_controller_amd.parallel import velocity_inputs
+    morphs = [synthetic_octopod_params(g, d, l) for l, d, g in CONFIG5_BINS]
+    lin, ang = velocity_inputs(seed ^ 0x5EED5, 0, n)
+    out = {}
+    alg = 0
+    for order in ("interleaved", "binned"):
+        mid = np.arange(n) % len(morphs) if order == "interleaved" else np.sort(np.arange(n) % len(morphs))
+        fleet = MixedFleet(morphs, mid)
+        t0 = time.perf_counter()
+        fleet.set_velocity(lin, ang)
+        t_in = time.perf_counter() - t0
+        for _ in range(45):        # walk until every instance is MOVING (longest period: wave, 8 legs)
+            fleet.step(16)
+        for _ in range(warmup):
+            fleet.step(1)
+        fleet.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fleet.step(1)
+        fleet.synchronize()
+        elapsed = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        q, _ = fleet.joints()
+        t_out = time.perf_counter() - t0
+        moving = float((fleet.walk_state() == 1).mean())
+        alg = sum(int((mid == k).sum()) * (2 * (l * ((2 * d + 24) * 8 + 4) + 28) + 24) for k, (l, d, g) in enumerate(CONFIG5_BINS))
+        out[order] = {"value": n * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "moving_fraction": moving,
+                      "finite": bool(np.isfinite(q[~np.isnan(q)]).all()), "host_set_velocity_s": t_in, "host_get_joints_s": t_out}
+        fleet.close()
+    r = out["interleaved"]
+    achieved = alg / (r["ms_per_step"] * 1e-3) / 1e9
+    return {"workload": f"BASELINE.json config5: {n} mixed-morphology robots (legs x dof, gait) = {list(CONFIG5_BINS)}, instance i -> bin i mod 5, "
+                        "binned by shc_fleet_create onto one engine + HIP stream per morphology", "value": r["value"], "unit": "control-cycles/s",
+            "steps": steps, "ms_per_step": r["ms_per_step"], "moving_fraction": r["moving_fraction"], "finite": r["finite"],
+            "interleaved_vs_binned": out,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "shc_cycle_kernel x 5 morphologies on concurrent streams (wall clock per fleet step, not a single launch)",
+                         "algorithmic_bytes_per_launch": alg}}
 
 
 def main():
@@ -292,6 +342,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     n = args.instances or DEFAULT_INSTANCES[args.workload]
+    if args.workload == "config5":
+        if world > 1:
+            raise SystemExit("config5 is a single-GPU workload here (the fleet shards in-process: shc_fleet_create device_ids)")
+        r = run_config5(n, args.steps, args.warmup, args.seed)
+        print(json.dumps({"metric": "control-cycles/sec (all legs IK-solved)", "value": r["value"], "unit": "control-cycles/s", "n_gpus": 1,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "config": {k: v for k, v in r.items() if k not in ("value", "roofline", "ms_per_step")}, "roofline": r["roofline"]}), flush=True)
+        return
     res = run_workload(args.workload, n, args.steps, args.warmup, args.cycles_per_step, args.seed,
                        dist_ctx=(world, rank, local_rank) if use_dist else None, gather_every=args.gather_every,
                        fused_probe=not args.no_fused_probe, want_cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline))
@@ -307,6 +366,7 @@ def main():
                          "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"],
                          "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],
                          "roofline": r["roofline"]})
+        also.append(run_config5(DEFAULT_INSTANCES["config5"], 100, 10, args.seed))
     if rank == 0:
         cfg = res["config"]
         if also:
