@@ -85,6 +85,7 @@ typedef struct shc_params {
   int32_t clamp_joint_positions, clamp_joint_velocities;
   /* walker (default.yaml:82-106) */
   double body_clearance, step_frequency, swing_height, swing_width, step_depth, stance_span_modifier;
+  double touchdown_threshold, liftoff_threshold; /* default.yaml:107-108 (rough_terrain_mode: Leg::touchdownDetection, model.cpp:712) */
   int32_t velocity_input_mode;
   double stance_position[SHC_MAX_LEGS][2];
   int32_t overlapping_walkspaces, force_normal_touchdown, gravity_aligned_tips;
@@ -397,7 +398,8 @@ typedef struct shc_leg_snapshot {
   int32_t negate_auto_pose;                /* LegPoser::negate_auto_pose_ (pose_controller.h:575) */
   int32_t ik_failed;                       /* the 5 mm deviation warning of the last applyIK (model.cpp:921) */
   int32_t tip_rotation_defined;            /* current_tip_pose_.rotation_ != UNDEFINED_ROTATION */
-  int32_t pad_;
+  int32_t step_plane_defined;              /* Leg::step_plane_pose_ != Pose::Undefined() (touchdown detection, model.cpp:712-722) */
+  double step_plane_position[3];           /* Leg::step_plane_pose_.position_ (robot frame; only its position is read, walk_controller.cpp:1088) */
 } shc_leg_snapshot;
 
 typedef struct shc_instance_state {
@@ -417,7 +419,8 @@ typedef struct shc_instance_state {
   int32_t pose_phase;                 /* PoseController::pose_phase_ (auto posing on its own clock) */
   /* AutoPoser latches, one word per poser: bit 0 start_check_, bit 1 end_check_.first, bit 2 end_check_.second, bit 3 allow_posing_ */
   int32_t auto_poser_flags[SHC_MAX_AUTO_POSERS];
-  int32_t pad_[2];                    /* explicit: the record has no implicit padding (byte-comparable) */
+  int32_t touchdown_detection;        /* LegStepper::touchdown_detection_ (walk_controller.h:495): tip-state messages have arrived */
+  int32_t pad_;                       /* explicit: the record has no implicit padding (byte-comparable) */
   shc_leg_snapshot leg[SHC_MAX_LEGS];
 } shc_instance_state;
 

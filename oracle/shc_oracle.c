@@ -7,7 +7,9 @@
  * search; walk_controller.cpp step cycle, walkspace, limits, updateWalk, LegStepper; pose_controller.cpp
  * updateCurrentPose (walk-plane, manual, inclination, IMU, auto), updateStance, direct start-up;
  * admittance_controller.cpp; call order of state_controller.cpp loop()/runningState().
- * Not restated (out of the accelerated path): rough_terrain_mode branches, manual leg manipulation,
+ * Restated with rough_terrain_mode: the layered workspace, touchdown detection, the step-surface target shift, default tip
+ * updates at every swing / stance start (walk_controller.cpp:1058-1107, :1160).
+ * Not restated (out of the accelerated path): external targets / defaults of a planner node, manual leg manipulation,
  * start-up/shut-down sequences, tip-align pose (experimental), ROS I/O.
  */
 #include "shc_oracle.h"
@@ -64,6 +66,7 @@ typedef struct
   orc_pose identity_tip_pose, default_tip_pose, current_tip_pose, origin_tip_pose, target_tip_pose;
   orc_v3 current_tip_velocity;
   orc_v3 swing_origin_tip_position, swing_origin_tip_velocity, stance_origin_tip_position;
+  int touchdown_detection; /* walk_controller.h:495, raised by tipStatesCallback */
 } stepper_t;
 
 typedef struct
@@ -76,6 +79,66 @@ typedef struct
   int has_desired_configuration;
   double desired_configuration[SHC_MAX_JOINTS], origin_configuration[SHC_MAX_JOINTS];
 } leg_poser_t;
+
+/* Workspace = std::map<double, Workplane>, Workplane = std::map<int, double> with the nine bearings 0..360 (model.h:27-32).
+ * Kept in insertion order; lookups go through the sorted view below (map semantics: insert never overwrites). */
+#define ORC_MAX_PLANES 32
+typedef struct
+{
+  int n;
+  double height[ORC_MAX_PLANES];
+  double radius[ORC_MAX_PLANES][SHC_N_BEARINGS];
+} workspace_t;
+
+static int ws_find(const workspace_t *w, double height)
+{
+  for (int i = 0; i < w->n; ++i)
+    if (w->height[i] == height) return i;
+  return -1;
+}
+static void ws_insert(workspace_t *w, double height, const double *plane)
+{
+  if (ws_find(w, height) >= 0 || w->n >= ORC_MAX_PLANES) return;
+  w->height[w->n] = height;
+  memcpy(w->radius[w->n], plane, sizeof w->radius[0]);
+  w->n++;
+}
+static double *ws_at(workspace_t *w, double height) { int i = ws_find(w, height); return i >= 0 ? w->radius[i] : NULL; }
+/* indices of the planes bounding `height`: upper = first key > height (map::upper_bound), lower = prev(upper); -1 if none */
+static void ws_bounds(const workspace_t *w, double height, int *lower, int *upper)
+{
+  *lower = *upper = -1;
+  for (int i = 0; i < w->n; ++i)
+  {
+    if (w->height[i] > height && (*upper < 0 || w->height[i] < w->height[*upper])) *upper = i;
+    if (w->height[i] <= height && (*lower < 0 || w->height[i] > w->height[*lower])) *lower = i;
+  }
+}
+/* Leg::getWorkplane (model.cpp:514-550); returns 0 for the "undefined" (empty) workplane */
+static int ws_get_workplane(const workspace_t *w, double height, double *out)
+{
+  double lo = 0, hi = 0;
+  for (int i = 0; i < w->n; ++i)
+  {
+    if (i == 0 || w->height[i] < lo) lo = w->height[i];
+    if (i == 0 || w->height[i] > hi) hi = w->height[i];
+  }
+  if (w->n == 0 || !(height >= lo && height <= hi)) return 0;
+  if (w->n == 1)
+  {
+    int i = ws_find(w, 0.0);
+    if (i < 0) return 0;
+    memcpy(out, w->radius[i], sizeof w->radius[0]);
+    return 1;
+  }
+  int lower, upper;
+  ws_bounds(w, height, &lower, &upper);
+  if (lower < 0 || upper < 0) return 0; /* (the reference dereferences end() here) */
+  double upper_h = orc_set_precision(w->height[upper], 3), lower_h = orc_set_precision(w->height[lower], 3);
+  double i = (height - lower_h) / (upper_h - lower_h);
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) out[b] = w->radius[lower][b] * (1.0 - i) + w->radius[upper][b] * i;
+  return 1;
+}
 
 typedef struct
 { /* class Leg, model.h:202-536 */
@@ -90,7 +153,7 @@ typedef struct
   orc_v3 desired_tip_velocity, current_tip_velocity;
   orc_v3 tip_force_calculated, tip_force_measured;
   orc_pose step_plane_pose;
-  double workspace[SHC_N_BEARINGS]; /* Workspace with the single plane 0.0 (simple workspace, model.cpp:355-358) */
+  workspace_t workspace;            /* typedef std::map<double, Workplane> Workspace (model.h:31-32): planes keyed by height */
   int workspace_zero;               /* model.cpp:349-353 */
   int ik_failed;                    /* model.cpp:921 this cycle */
   stepper_t stepper;
@@ -481,23 +544,29 @@ static orc_quat model_imu_orientation(const orc_robot *r)
   return r->imu_orientation;
 }
 
-/* Leg::generateWorkspace (model.cpp:309-510), simple workspace (rough_terrain_mode == false) only */
+/* Leg::generateWorkspace (model.cpp:309-510): the simple workspace (one plane at the stance height) or, in rough terrain mode,
+ * the layered workspace: lower / upper vertical limit, then WORKSPACE_LAYERS planes searched from the top down. */
 static void leg_generate_workspace(orc_robot *r, leg_t *leg)
 {
-  double max_workplane[SHC_N_BEARINGS];
-  for (int b = 0; b < SHC_N_BEARINGS; ++b) max_workplane[b] = MAX_WORKSPACE_RADIUS;
+  int simple_workspace = !r->params.rough_terrain_mode;
+  double max_workplane[SHC_N_BEARINGS], min_workplane[SHC_N_BEARINGS];
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) { max_workplane[b] = MAX_WORKSPACE_RADIUS; min_workplane[b] = 0.0; }
+  leg->workspace.n = 0;
   orc_pose current_pose = r->current_pose;
   orc_v3 identity_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.identity_tip_pose.p);
   leg->workspace_zero = 0;
   if (orc_v3_norm(orc_v3_sub(identity_tip_position, leg->current_tip_pose.p)) > IK_TOLERANCE)
   {
-    for (int b = 0; b < SHC_N_BEARINGS; ++b) leg->workspace[b] = 0.0;
+    ws_insert(&leg->workspace, 0.0, min_workplane);
     leg->workspace_zero = 1;
     return;
   }
-  for (int b = 0; b < SHC_N_BEARINGS; ++b) leg->workspace[b] = max_workplane[b];
+  if (simple_workspace) ws_insert(&leg->workspace, 0.0, max_workplane);
 
-  double min_plane_height = 0.0;
+  int found_lower_limit = simple_workspace ? 1 : 0;
+  int found_upper_limit = simple_workspace ? 1 : 0;
+  double max_plane_height = simple_workspace ? 0.0 : MAX_WORKSPACE_RADIUS;
+  double min_plane_height = simple_workspace ? 0.0 : -MAX_WORKSPACE_RADIUS;
   double search_height_delta = MAX_WORKSPACE_RADIUS / WORKSPACE_LAYERS;
   double search_height = 0.0;
   int search_bearing = 0;
@@ -507,6 +576,7 @@ static void leg_generate_workspace(orc_robot *r, leg_t *leg)
   double distance_from_origin;
   int number_iterations = 1;
   int workspace_generation_complete = 0;
+  (void)max_plane_height;
 
   while (1)
   {
@@ -518,7 +588,14 @@ static void leg_generate_workspace(orc_robot *r, leg_t *leg)
     {
       within_limits = 1;
       leg_init(r, leg, 1);
-      if (search_bearing == 0)
+      if (!found_lower_limit || !found_upper_limit)
+      { /* search for the lower, then the upper vertical limit of the workspace */
+        number_iterations = orc_round_to_int(MAX_WORKSPACE_RADIUS / MAX_POSITION_DELTA);
+        origin_tip_position = identity_tip_position;
+        target_tip_position = identity_tip_position;
+        target_tip_position.z += found_lower_limit ? MAX_WORKSPACE_RADIUS : -MAX_WORKSPACE_RADIUS;
+      }
+      else if (search_bearing == 0)
       {
         number_iterations = orc_round_to_int(search_height_delta / MAX_POSITION_DELTA);
         number_iterations = number_iterations > 1 ? number_iterations : 1;
@@ -549,8 +626,26 @@ static void leg_generate_workspace(orc_robot *r, leg_t *leg)
     else
     {
       iteration = 1;
-      if (search_bearing == 0) leg_update_default_configuration(leg);
-      else leg->workspace[search_bearing / BEARING_STEP] = distance_from_origin;
+      if (!found_lower_limit)
+      {
+        found_lower_limit = 1;
+        min_plane_height = -distance_from_origin;
+        ws_insert(&leg->workspace, min_plane_height, min_workplane);
+        continue;
+      }
+      else if (!found_upper_limit)
+      {
+        found_upper_limit = 1;
+        max_plane_height = distance_from_origin;
+        search_height_delta = (max_plane_height - min_plane_height) / WORKSPACE_LAYERS;
+        int upper_levels = (int)(fabs(max_plane_height) / search_height_delta);
+        search_height = upper_levels * search_height_delta;
+        ws_insert(&leg->workspace, max_plane_height, min_workplane);
+        ws_insert(&leg->workspace, search_height, max_workplane);
+        continue;
+      }
+      else if (search_bearing == 0) leg_update_default_configuration(leg);
+      else ws_at(&leg->workspace, search_height)[search_bearing / BEARING_STEP] = distance_from_origin;
 
       if (search_bearing + BEARING_STEP <= 360)
       {
@@ -559,9 +654,10 @@ static void leg_generate_workspace(orc_robot *r, leg_t *leg)
       else
       {
         search_bearing = 0;
-        leg->workspace[0] = leg->workspace[360 / BEARING_STEP];
+        double *plane = ws_at(&leg->workspace, search_height);
+        plane[0] = plane[360 / BEARING_STEP];
         search_height -= search_height_delta;
-        if (search_height >= min_plane_height) { /* unreachable in simple mode */ }
+        if (search_height >= min_plane_height) ws_insert(&leg->workspace, search_height, max_workplane);
         else workspace_generation_complete = 1;
       }
     }
@@ -760,9 +856,8 @@ static void walker_generate_walkspace(orc_robot *r)
     orc_v3 default_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.default_tip_pose.p);
     orc_v3 default_shift = orc_v3_sub(default_tip_position, identity_tip_position);
     double target_workplane_height = default_shift.z;
-    /* Leg::getWorkplane (model.cpp:514-550) with the single plane at height 0.0 */
-    if (!(target_workplane_height >= 0.0 && target_workplane_height <= 0.0)) continue; /* "undefined" workplane -> empty */
-    const double *workplane = leg->workspace;
+    double workplane[SHC_N_BEARINGS]; /* Leg::getWorkplane (model.cpp:514-550): interpolated between the bounding planes */
+    if (!ws_get_workplane(&leg->workspace, target_workplane_height, workplane)) continue; /* "undefined" workplane -> empty */
 
     for (int bi = 0; bi < SHC_N_BEARINGS; ++bi)
     {
@@ -904,7 +999,23 @@ static orc_v3 stepper_calculate_stance_span_change(const orc_robot *r, const leg
   int positive_y_axis = (s->identity_tip_pose.p.y > 0.0); /* UnitY.dot(identity) > 0 */
   int bearing = (positive_y_axis ^ (stance_span_modifier > 0.0)) ? 270 : 90;
   stance_span_modifier *= (positive_y_axis ? 1.0 : -1.0);
-  double radius = leg->workspace[bearing / BEARING_STEP]; /* workspace.size() == 1 -> workspace.at(0.0).at(bearing) */
+  double radius = 0.0;
+  if (leg->workspace.n == 1)
+  {
+    radius = leg->workspace.radius[0][bearing / BEARING_STEP]; /* workspace.at(0.0).at(bearing) */
+  }
+  else
+  { /* interpolated between the planes bounding the default tip's height shift (:951-967) */
+    double target_workplane_height = orc_set_precision(s->default_tip_pose.p.z - s->identity_tip_pose.p.z, 3);
+    int lower, upper;
+    ws_bounds(&leg->workspace, target_workplane_height, &lower, &upper);
+    if (lower >= 0 && upper >= 0)
+    {
+      double upper_h = orc_set_precision(leg->workspace.height[upper], 3), lower_h = orc_set_precision(leg->workspace.height[lower], 3);
+      double i = (target_workplane_height - lower_h) / (upper_h - lower_h);
+      radius = leg->workspace.radius[lower][bearing / BEARING_STEP] * (1.0 - i) + leg->workspace.radius[upper][bearing / BEARING_STEP] * i;
+    }
+  }
   return orc_v3_make(0.0, radius * stance_span_modifier, 0.0);
 }
 
@@ -982,7 +1093,7 @@ static void stepper_force_normal_touchdown(const orc_robot *r, stepper_t *s)
   s->swing_2_nodes[1] = orc_v3_add(s->swing_2_nodes[0], half);
 }
 
-/* LegStepper::updateTipPosition (walk_controller.cpp:1018-1189), rough_terrain_mode == false */
+/* LegStepper::updateTipPosition (walk_controller.cpp:1018-1189); external targets (:1068-1079) are a planner node's API: not restated */
 static void stepper_update_tip_position(const orc_robot *r, leg_t *leg)
 {
   stepper_t *s = &leg->stepper;
@@ -1008,12 +1119,29 @@ static void stepper_update_tip_position(const orc_robot *r, leg_t *leg)
     stepper_update_stride(r, s);
     int iteration = s->phase - step->swing_start + 1;
     int first_half = iteration <= swing_iterations / 2;
+    int rough_terrain_mode = r->params.rough_terrain_mode;
     if (iteration == 1)
     {
       s->swing_origin_tip_position = s->current_tip_pose.p;
       s->swing_origin_tip_velocity = s->current_tip_velocity;
+      if (rough_terrain_mode) stepper_update_default_tip_position(r, leg);
     }
-    int ground_contact = 0; /* rough_terrain_mode false */
+    if (rough_terrain_mode && s->touchdown_detection)
+    { /* update default target to meet the step surface proactively or reactively (:1081-1101) */
+      orc_pose step_plane_pose = leg->step_plane_pose;
+      if (orc_pose_ne(step_plane_pose, orc_pose_undefined()))
+      {
+        orc_v3 step_plane_position = orc_v3_sub(step_plane_pose.p, leg->current_tip_pose.p);
+        orc_v3 target_tip_position = orc_v3_add(s->current_tip_pose.p, step_plane_position);
+        orc_v3 difference = orc_v3_sub(target_tip_position, s->target_tip_pose.p);
+        s->target_tip_pose.p = orc_v3_add(s->target_tip_pose.p, orc_get_projection(difference, s->walk_plane_normal));
+      }
+      else
+      {
+        s->target_tip_pose.p.z -= r->params.step_depth;
+      }
+    }
+    int ground_contact = (orc_pose_ne(leg->step_plane_pose, orc_pose_undefined()) && rough_terrain_mode);
     stepper_generate_primary_swing_control_nodes(r, s);
     stepper_generate_secondary_swing_control_nodes(r, s, !first_half && ground_contact);
     if (r->params.force_normal_touchdown && !ground_contact) stepper_force_normal_touchdown(r, s);
@@ -1037,7 +1165,11 @@ static void stepper_update_tip_position(const orc_robot *r, leg_t *leg)
   {
     stepper_update_stride(r, s);
     int iteration = orc_mod(s->phase + (step->period - modified_stance_start), step->period) + 1;
-    if (iteration == 1) s->stance_origin_tip_position = s->current_tip_pose.p;
+    if (iteration == 1)
+    {
+      s->stance_origin_tip_position = s->current_tip_pose.p;
+      if (r->params.rough_terrain_mode) stepper_update_default_tip_position(r, leg);
+    }
     double stride_scaler = (double)modified_stance_period / (orc_mod(step->stance_end - step->stance_start, step->period));
     stepper_generate_stance_control_nodes(s, stride_scaler);
     double time_input = iteration * s->stance_delta_t;
@@ -1966,7 +2098,7 @@ static void model_generate_workspaces(orc_robot *r)
     *search_leg = r->leg[l];
     leg_init(r, search_leg, 1); /* search_model->initLegs(true) */
     leg_generate_workspace(r, search_leg);
-    memcpy(r->leg[l].workspace, search_leg->workspace, sizeof search_leg->workspace);
+    r->leg[l].workspace = search_leg->workspace;
     r->leg[l].workspace_zero = search_leg->workspace_zero;
     free(search_leg);
   }
@@ -2031,7 +2163,7 @@ size_t orc_sizeof_robot(void) { return sizeof(orc_robot); }
 orc_robot *orc_create(const shc_params *params)
 {
   if (!params || params->leg_count < 1 || params->leg_count > SHC_MAX_LEGS) return NULL;
-  if (params->rough_terrain_mode) return NULL;
+  if (params->rough_terrain_mode && params->stance_span_modifier != 0.0) return NULL; /* (the engine rejects this pair: shc_batch.h) */
   for (int l = 0; l < params->leg_count; ++l)
     if (params->leg_dof[l] < 1 || params->leg_dof[l] > SHC_MAX_JOINTS) return NULL;
   orc_robot *r = (orc_robot *)calloc(1, sizeof(orc_robot));
@@ -2173,7 +2305,11 @@ void orc_get_tables(const orc_robot *r, shc_tables *out)
   {
     out->phase_offset[l] = r->leg[l].stepper.phase_offset;
     for (int j = 0; j < r->leg[l].joint_count; ++j) out->default_joint_position[l][j] = r->leg[l].joint[j].default_position;
-    for (int b = 0; b < SHC_N_BEARINGS; ++b) out->workspace_radius[l][b] = r->leg[l].workspace[b];
+    { /* the plane the walkspace was generated from: height 0 (default tips at their identity positions) */
+      double plane[SHC_N_BEARINGS];
+      if (!ws_get_workplane(&r->leg[l].workspace, 0.0, plane)) memset(plane, 0, sizeof plane);
+      for (int b = 0; b < SHC_N_BEARINGS; ++b) out->workspace_radius[l][b] = plane[b];
+    }
   }
   for (int b = 0; b < SHC_N_BEARINGS; ++b)
   {
@@ -2201,10 +2337,20 @@ void orc_set_imu(orc_robot *r, const double q[4], const double gyro[3])
   r->imu_angular_velocity = orc_v3_make(gyro[0], gyro[1], gyro[2]);
 }
 
+/* tipStatesCallback with wrench values (state_controller.cpp:1617-1648): touchdown detection on, force stored,
+ * Leg::touchdownDetection (model.cpp:712-722) */
 void orc_set_tip_force(orc_robot *r, const double *force)
 {
   for (int l = 0; l < r->leg_count; ++l)
-    r->leg[l].tip_force_measured = orc_v3_make(force[l * 3 + 0], force[l * 3 + 1], force[l * 3 + 2]);
+  {
+    leg_t *leg = &r->leg[l];
+    leg->stepper.touchdown_detection = 1;
+    leg->tip_force_measured = orc_v3_make(force[l * 3 + 0], force[l * 3 + 1], force[l * 3 + 2]);
+    if (orc_v3_norm(leg->tip_force_measured) > r->params.touchdown_threshold && orc_pose_eq(leg->step_plane_pose, orc_pose_undefined()))
+      leg->step_plane_pose = leg->current_tip_pose;
+    else if (orc_v3_norm(leg->tip_force_measured) < r->params.liftoff_threshold)
+      leg->step_plane_pose = orc_pose_undefined();
+  }
 }
 
 void orc_set_joint_effort(orc_robot *r, const double *effort)
@@ -2569,7 +2715,10 @@ void orc_get_state(const orc_robot *r, shc_instance_state *o)
     g->completed_first_step = s->completed_first_step;
     g->negate_auto_pose = leg->poser.negate_auto_pose;
     g->ik_failed = leg->ik_failed;
+    g->step_plane_defined = orc_pose_ne(leg->step_plane_pose, orc_pose_undefined());
+    if (g->step_plane_defined) put3(g->step_plane_position, leg->step_plane_pose.p);
   }
+  o->touchdown_detection = r->leg[0].stepper.touchdown_detection;
 }
 
 /* The reverse direction: a snapshot (e.g. taken from the engine) becomes the oracle's state.  Members the snapshot does
@@ -2646,6 +2795,9 @@ void orc_set_state(orc_robot *r, const shc_instance_state *o)
     s->completed_first_step = g->completed_first_step;
     leg->poser.negate_auto_pose = g->negate_auto_pose;
     leg->ik_failed = g->ik_failed;
+    leg->step_plane_pose = orc_pose_undefined();
+    if (g->step_plane_defined) leg->step_plane_pose = orc_pose_make(get3(g->step_plane_position), orc_quat_identity());
+    s->touchdown_detection = o->touchdown_detection;
   }
 }
 

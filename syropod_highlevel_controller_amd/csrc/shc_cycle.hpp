@@ -43,7 +43,7 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // origins of the per-leg planes, which change once per step period).
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
-enum : unsigned { RT_MANUAL_LIVE = 1 };
+enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2 }; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
@@ -70,7 +70,9 @@ struct CycleParams {
   int32_t tip_force;  // SHC_FEAT_TIP_FORCE
   int32_t debug_skip; // development ablation mask (SHC_DEBUG_SKIP env): 1 pose, 2 limits, 4 stepper, 8 ik, 16 fk
   int32_t odometry;   // SHC_FEAT_ODOMETRY
-  int32_t gravity_aligned, pad1; // gravity_aligned_tips with > 3 DOF legs: rotation-constrained IK (model.cpp:880-900)
+  int32_t gravity_aligned;       // gravity_aligned_tips with > 3 DOF legs: rotation-constrained IK (model.cpp:880-900)
+  int32_t rough_terrain;         // rough_terrain_mode (generic kernel): default tips follow the terrain, targets meet the step surface
+  double step_depth;             // walk_controller.h:80
   double target_dir[3];          // x axis of the identity tip rotation FromTwoVectors(x, -z) (walk_controller.cpp:37-41)
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
   double pid_p, pid_i, pid_d;
@@ -117,7 +119,9 @@ struct Fields {
                        // LegPoser sequence state (pose_controller.h:560-590) for stepToPosition / transitionConfiguration:
                        // origin_tip_pose_ position (3) + master_iteration_count_, x axis of its rotation (3) + "!first_iteration_",
                        // origin_configuration_ (NJ, padded).  Only the sequence entry points touch these.
-                       SEQ_ORG = DES_DIR + 4, SEQ_DIR = SEQ_ORG + 4, SEQ_Q0 = SEQ_DIR + 4, COUNT = SEQ_Q0 + NJE;
+                       SEQ_ORG = DES_DIR + 4, SEQ_DIR = SEQ_ORG + 4, SEQ_Q0 = SEQ_DIR + 4,
+                       // Leg::step_plane_pose_.position_ (3) + "defined" (touchdown detection; read by the cycle in rough terrain mode only)
+                       STEP_PLANE = SEQ_Q0 + NJE, COUNT = STEP_PLANE + 4;
   static_assert(CORE_END % 2 == 0 && SORG % 2 == 0 && COUNT % 2 == 0, "field groups must align to 16-byte planes");
 };
 // element index of field f of slot `slot` in the plane array (n_slots slots per plane)
@@ -296,7 +300,7 @@ __device__ __forceinline__ int bearing_bracket(double y, double x) {
 template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                       const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
-                                      const bool manual_live) {
+                                      const bool manual_live, const bool touchdown_detection) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
@@ -821,6 +825,18 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     const V3 dflt = pk.get3(PK_DFLT);
     s.targ = dflt + s.strd * 0.5; // uses last cycle's stride (:1044 precedes updateStride)
     bool stepping = my_state != SS_FORCE_STOP;
+    const bool rough = (F & F_DYN) != 0 && uni(P.rough_terrain) != 0; // rough terrain mode runs on the generic kernel
+    bool rough_update_default = false;
+    V3 model_tip_prev{0, 0, 0};
+    if (rough) { // Leg::current_tip_pose_.position_ as the previous cycle's applyFK left it
+      if (LegRegs<NJ>::kKeepJacobian) {
+        model_tip_prev = tip_robot_frame(lc, s.pe);
+      } else {
+        Chain<NJ> ch0;
+        chain_from_sincos<NJ>(lc, s.sn, s.cs, ch0);
+        model_tip_prev = tip_robot_frame(lc, ch0.pe);
+      }
+    }
     if (stepping && !(SHC_DBG(P) & 4)) {
       // updateStride (:921-945)
       V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0}; // v + w z^ x (tip rejected from z^)
@@ -841,9 +857,25 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           pk.put3(PK_SORG, sorg);
           pk.put3(PK_SVEL, svel);
           dirty |= DIRTY_SWING_ORG;
+          rough_update_default = rough; // walk_controller.cpp:1058-1061
         } else {
           sorg = pk.get3(PK_SORG);
           svel = pk.get3(PK_SVEL);
+        }
+        bool ground_contact = false;
+        if (rough) { // update the default target to meet the step surface, proactively or reactively (:1081-1101)
+          const double2 sp01 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::STEP_PLANE / 2) * ns + slot];
+          const double2 sp23 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::STEP_PLANE / 2 + 1) * ns + slot];
+          ground_contact = sp23.y != 0.0; // leg_->getStepPlanePose() != Pose::Undefined() (:1110)
+          if (touchdown_detection) {
+            if (ground_contact) {
+              const V3 step_plane_position = V3{sp01.x, sp01.y, sp23.x} - model_tip_prev; // relative to Leg::current_tip_pose_ (last FK)
+              const V3 difference = (s.tip + step_plane_position) - s.targ;
+              s.targ = s.targ + projection(difference, rb.get3(R::PNORM));
+            } else {
+              s.targ.z -= P.step_depth;
+            }
+          }
         }
         // generatePrimarySwingControlNodes (:1238-1261)
         V3 mid{(sorg.x + s.targ.x) / 2.0, (sorg.y + s.targ.y) / 2.0, fmax(sorg.z, s.targ.z)};
@@ -857,7 +889,10 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         V3 fv = (-s.strd) * (stance_dt * P.inv_dt);
         V3 sep2 = (fv * 0.25) * P.dt_over_swing_dt;
         V3 n2_0 = n1_4, n2_1 = n1_4 - (n1_3 - n1_4), n2_2 = s.targ - sep2 * 2.0, n2_3 = s.targ - sep2, n2_4 = s.targ;
-        if (uni(P.force_normal_touchdown)) { // forceNormalTouchdown (:1314-1329)
+        if (rough && ground_contact && !first_half) { // ground contact in the second half: stance-like nodes from the current tip (:1286-1290)
+          n2_0 = s.tip, n2_1 = s.tip + sep2, n2_2 = s.tip + sep2 * 2.0, n2_3 = s.tip + sep2 * 3.0, n2_4 = s.tip + sep2 * 4.0;
+        }
+        if (uni(P.force_normal_touchdown) && !(rough && ground_contact)) { // forceNormalTouchdown (:1314-1329), unless in ground contact (:1114)
           V3 bo = s.targ - sep2 * 4.0;
           bo.z = fmax(sorg.z, s.targ.z);
           bo = bo + clearance;
@@ -884,6 +919,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           torg = s.tip;
           pk.put3(PK_TORG, torg);
           dirty |= DIRTY_STANCE_ORG;
+          rough_update_default = rough; // :1160-1163
         } else {
           torg = pk.get3(PK_TORG);
         }
@@ -896,6 +932,16 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       }
       s.tip = s.tip + dpos;
       s.tvel = dpos * P.inv_dt; // delta_pos / time_delta (:1135, :1176)
+      if (rough && __any(rough_update_default)) { // LegStepper::updateDefaultTipPosition at the start of a swing / stance period
+        if (rough_update_default) { // (the stepper's walk-plane copy was refreshed by updateStride just before: the current plane)
+          Pose wpp = rb.getpose(R::WPP);
+          V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y, 0.0}); // (stance span modifier 0 in rough terrain mode)
+          V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM));
+          pk.put3(PK_DFLT, idp + proj);
+          default_changed = true;
+          dirty |= DIRTY_STANCE_ORG;
+        }
+      }
     }
     // ---- updateTipRotation (:1193-1234).  Without gravity-aligned tips every tip rotation stays UNDEFINED.  With them the
     //      target is the constant identity rotation (x axis along -z); only the x axes of the rotations are ever used

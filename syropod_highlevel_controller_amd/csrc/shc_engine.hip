@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   // robot's manual pose is the identity and stays it, so the manual-pose group of the robot tile is neither loaded nor
   // evaluated nor stored.
   const bool manual_live = (rt_flags & RT_MANUAL_LIVE) != 0;
+  const bool touchdown_detection = (rt_flags & RT_TOUCHDOWN) != 0;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   LegOut out;
   SHC_TICK(1);
   unsigned dirty = 0;
-  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live);
+  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection);
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
@@ -644,6 +645,8 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.tip_force = (features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort ? 1 : 0;
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
   c.gravity_aligned = hostinit::tips_rotation_constrained(p, p.leg_dof[0]) ? 1 : 0;
+  c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
+  c.step_depth = p.step_depth;
   {
     V3 d = hostinit::gravity_aligned_direction();
     c.target_dir[0] = d.x;
@@ -692,7 +695,11 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
   for (int l = 0; l < p->leg_count; ++l)
     if (p->leg_dof[l] != nj) return fail(SHC_ERR_UNSUPPORTED, "all legs of one engine must share one DOF (bin mixed morphologies)");
   if (nj < 3 || nj > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
-  if (p->rough_terrain_mode) return fail(SHC_ERR_UNSUPPORTED, "rough_terrain_mode is outside the accelerated path");
+  if (p->rough_terrain_mode && p->stance_span_modifier != 0.0)
+    return fail(SHC_ERR_UNSUPPORTED, "rough_terrain_mode with a stance span modifier (default tips re-derived from the layered workspace every step) "
+                                     "is outside the accelerated path");
+  if (p->rough_terrain_mode && !(p->touchdown_threshold >= p->liftoff_threshold))
+    return fail(SHC_ERR_INVALID_ARG, "touchdown_threshold must be >= liftoff_threshold");
   if (p->gravity_aligned_tips && nj <= 3)
     return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips with <= 3 DOF legs is the reference's experimental tip-align pose (outside the accelerated path)");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
@@ -722,7 +729,7 @@ static int generate_tables_nj(const shc_params *p, shc_tables *out) {
   return hostinit::generate_tables<NJ>(*p, *out) ? SHC_OK : fail(SHC_ERR_INVALID_ARG, "init chain failed (unreachable stance?)");
 }
 
-extern "C" int shc_abi_version(void) { return 1; }
+extern "C" int shc_abi_version(void) { return 2; }
 extern "C" int64_t shc_sizeof_params(void) { return (int64_t)sizeof(shc_params); }
 extern "C" int64_t shc_sizeof_tables(void) { return (int64_t)sizeof(shc_tables); }
 
@@ -1218,9 +1225,45 @@ extern "C" int shc_engine_set_imu(shc_engine *e, const double *orientation_wxyz,
   return scatter_rob(e, angular_velocity, 3, RobotFields::GYRO, on_device);
 }
 
+// Leg::touchdownDetection (model.cpp:712-722), run by tipStatesCallback right after it stored the measured force
+// (state_controller.cpp:1644-1646): the step plane is where the tip is when the force first exceeds the touchdown threshold.
+template <int L, int NJ>
+__global__ void touchdown_detection_kernel(DevState st, const SharedConsts<L, NJ> *gc, double touchdown_threshold, double liftoff_threshold) {
+  using FD = Fields<NJ>;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= st.n_robots * L) return;
+  const int64_t rob = t / L;
+  const int leg = int(t - rob * L);
+  const int64_t slot = slot_of(rob, leg, L);
+  auto f = [&](int field) -> double & { return st.legd[leg_field_index(field, slot, st.n_slots)]; };
+  const double fn = norm(V3{f(FD::FORCE_IN), f(FD::FORCE_IN + 1), f(FD::FORCE_IN + 2)});
+  if (fn > touchdown_threshold && f(FD::STEP_PLANE + 3) == 0.0) {
+    double q[NJ];
+    for (int j = 0; j < NJ; ++j) q[j] = f(FD::Q + j);
+    Chain<NJ> ch;
+    fk_chain<NJ>(gc->leg[leg], q, ch);
+    const V3 tip = tip_robot_frame(gc->leg[leg], ch.pe); // step_plane_pose_ = current_tip_pose_
+    f(FD::STEP_PLANE) = tip.x, f(FD::STEP_PLANE + 1) = tip.y, f(FD::STEP_PLANE + 2) = tip.z, f(FD::STEP_PLANE + 3) = 1.0;
+  } else if (fn < liftoff_threshold) {
+    f(FD::STEP_PLANE + 3) = 0.0;
+  }
+}
+
 extern "C" int shc_engine_set_tip_force(shc_engine *e, const double *tip_force, int on_device) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
-  return scatter_leg(e, tip_force, 3, LEG_FIELD(e, FORCE_IN), on_device);
+  int rc = scatter_leg(e, tip_force, 3, LEG_FIELD(e, FORCE_IN), on_device);
+  if (rc != SHC_OK || !tip_force) return rc;
+  e->rt_flags |= RT_TOUCHDOWN; // LegStepper::setTouchdownDetection(true) (state_controller.cpp:1642)
+  if (e->params.rough_terrain_mode) { // the step plane is only read in rough terrain mode (walk_controller.cpp:1065, :1110)
+    const int64_t threads = e->n * e->L;
+#define CALL(L_, NJ_)                                                                                                           \
+  touchdown_detection_kernel<L_, NJ_><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(                      \
+      e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, e->params.touchdown_threshold, e->params.liftoff_threshold)
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+    HIP_TRY(hipGetLastError());
+  }
+  return SHC_OK;
 }
 
 extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int on_device) {
@@ -1260,7 +1303,7 @@ static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cyc
   }
   if constexpr (SPEC) {
     constexpr unsigned C2 = F_MANUAL | F_ODOM, C3 = F_MANUAL | F_IMU | F_ADM | F_ODOM; // BASELINE.json configs 2/4 and 3
-    if (specialised) switch (f) {
+    if (specialised && !c.rough_terrain) switch (f) {
       case C2 | F_TIPF: launch_cycle<L, NJ, C2 | F_TIPF>(e, grid, block, n_cycles); return;
       case C2: launch_cycle<L, NJ, C2>(e, grid, block, n_cycles); return;
       case C3 | F_TIPF: launch_cycle<L, NJ, C3 | F_TIPF>(e, grid, block, n_cycles); return;
@@ -1770,6 +1813,10 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
   if (first < 0 || count < 0 || first + count > e->n) return fail(SHC_ERR_INVALID_ARG, "instance range out of bounds");
   if (count == 0) return SHC_OK;
   if (in) e->rt_flags |= RT_MANUAL_LIVE; // an injected state may carry any manual pose
+  if (in) // touchdown detection is one flag per engine: on as soon as any injected record has it (tip-state messages arrive for a whole robot)
+    for (int64_t i = 0; i < count; ++i)
+      if (in[i].touchdown_detection) e->rt_flags |= RT_TOUCHDOWN;
+  const int touchdown = (e->rt_flags & RT_TOUCHDOWN) ? 1 : 0;
   HIP_TRY(hipSetDevice(e->device));
   shc_instance_state *d = nullptr;
   const size_t bytes = size_t(count) * sizeof(shc_instance_state);
@@ -1780,13 +1827,13 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
   if (err == hipSuccess) {
     switch (e->NJ) {
       case 3: if (in) set_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
-              else get_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+              else get_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown);
               break;
       case 4: if (in) set_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
-              else get_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+              else get_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown);
               break;
       default: if (in) set_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
-               else get_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+               else get_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown);
                break;
     }
     err = hipGetLastError();

@@ -241,6 +241,85 @@ SHC_HDI void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identi
   if (last_bearing == 8) radius[0] = radius[360 / kBearingStep];
 }
 
+// Leg::generateWorkspace in rough terrain mode (model.cpp:309-510, simple_workspace == false): the layered workspace.  The tip
+// is first driven straight down, then straight up from its identity position until a DLS step fails (lower / upper plane
+// heights); the span is cut into WORKSPACE_LAYERS layers and every plane from the top one down is searched like the simple
+// workspace, each starting from the configuration reached by tracking to that plane's origin.  What the rest of the init
+// chain consumes is Leg::getWorkplane(0) (model.cpp:514-550) - WalkController::generateWalkspace asks for the plane at the
+// default tips' height shift, which is zero right after start-up (walk_controller.cpp:117-121) - written to radius[].
+template <int NJ>
+SHC_HDI void generate_workspace_layered(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS]) {
+  constexpr int kMaxPlanes = kWorkspaceLayers + 4;
+  double height[kMaxPlanes], plane[kMaxPlanes][SHC_N_BEARINGS];
+  int planes = 0;
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = 0.0;
+  leg.reset_to_default();
+  if (norm(identity_tip_body - leg.tip) > kIkTolerance) return; // zero workspace (model.cpp:349-353)
+  auto add_plane = [&](double h, double fill) { // std::map::insert: an existing key is kept
+    for (int k = 0; k < planes; ++k)
+      if (height[k] == h) return k;
+    if (planes == kMaxPlanes) return planes - 1;
+    height[planes] = h;
+    for (int b = 0; b < SHC_N_BEARINGS; ++b) plane[planes][b] = fill;
+    return planes++;
+  };
+  const int n_line = round_to_int(kMaxWorkspaceRadius / kMaxPositionDelta);
+  auto vertical_limit = [&](double direction) { // distance the tip can be moved along +-z from the identity position
+    leg.reset_to_default();
+    const V3 o = identity_tip_body, t = o + V3{0, 0, direction * kMaxWorkspaceRadius};
+    for (int it = 1; it <= n_line; ++it) {
+      const double i = double(it) / n_line;
+      if (leg.ik(o * (1.0 - i) + t * i, p) == 0.0) break;
+    }
+    return norm(leg.tip - identity_tip_body);
+  };
+  const double min_h = -vertical_limit(-1.0);
+  add_plane(min_h, 0.0);
+  const double max_h = vertical_limit(1.0);
+  const double delta = (max_h - min_h) / kWorkspaceLayers;
+  double h = int(fabs(max_h) / delta) * delta;
+  add_plane(max_h, 0.0);
+  int cur = add_plane(h, kMaxWorkspaceRadius);
+  while (true) {
+    const V3 origin = identity_tip_body + V3{0, 0, h};
+    { // track from the (re-based) default configuration to this plane's origin, then re-base again (model.cpp:397-404, :465)
+      leg.reset_to_default();
+      const int n = imax(1, round_to_int(delta / kMaxPositionDelta));
+      const V3 o = leg.tip;
+      for (int it = 1; it <= n; ++it) {
+        const double i = double(it) / n;
+        if (leg.ik(o * (1.0 - i) + origin * i, p) == 0.0) break;
+      }
+      for (int j = 0; j < NJ; ++j) leg.dflt[j] = leg.q[j];
+    }
+    for (int bearing = kBearingStep; bearing <= 360; bearing += kBearingStep) {
+      leg.reset_to_default();
+      V3 t = origin;
+      t.x += kMaxWorkspaceRadius * cos(deg2rad(bearing));
+      t.y += kMaxWorkspaceRadius * sin(deg2rad(bearing));
+      for (int it = 1; it <= n_line; ++it) {
+        const double i = double(it) / n_line;
+        if (leg.ik(origin * (1.0 - i) + t * i, p) == 0.0) break;
+      }
+      plane[cur][bearing / kBearingStep] = norm(leg.tip - origin);
+    }
+    plane[cur][0] = plane[cur][360 / kBearingStep];
+    h -= delta;
+    if (!(h >= min_h)) break;
+    cur = add_plane(h, kMaxWorkspaceRadius);
+  }
+  // Leg::getWorkplane(0.0): interpolate between the planes bounding height 0 (heights rounded to 3 decimals, :532-533)
+  int lower = -1, upper = -1;
+  for (int k = 0; k < planes; ++k) {
+    if (height[k] > 0.0 && (upper < 0 || height[k] < height[upper])) upper = k;
+    if (height[k] <= 0.0 && (lower < 0 || height[k] > height[lower])) lower = k;
+  }
+  if (lower < 0 || upper < 0) return;
+  const double uh = round_to_int(height[upper] * pow(10, 3)) / pow(10, 3), lh = round_to_int(height[lower] * pow(10, 3)) / pow(10, 3);
+  const double i = (0.0 - lh) / (uh - lh);
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = plane[lower][b] * (1.0 - i) + plane[upper][b] * i;
+}
+
 SHC_HDI V3 rot_z(double ang, V3 v) { // Eigen::AngleAxisd(ang, UnitZ) * v
   double s = sin(ang), c = cos(ang);
   return V3{c * v.x - s * v.y, s * v.x + c * v.y, v.z};
@@ -419,6 +498,10 @@ SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int 
   for (int j = 0; j < NJ; ++j) {
     leg.dflt[j] = leg.q[j]; // Model::updateDefaultConfiguration
     if (first_bearing == 1) t.default_joint_position[l][j] = leg.q[j];
+  }
+  if (p.rough_terrain_mode) { // layered workspace: planes are searched one after the other, no split over bearings
+    if (first_bearing == 1) generate_workspace_layered<NJ>(p, leg, inverse_transform_vector(body_ws, default_tip), t.workspace_radius[l]);
+    return;
   }
   generate_workspace<NJ>(p, leg, inverse_transform_vector(body_ws, default_tip), t.workspace_radius[l], first_bearing, last_bearing);
 }

@@ -19,7 +19,7 @@ __device__ inline void snap_put3(double *dst, V3 v) {
 }
 
 template <int NJ>
-__global__ void get_state_kernel(shc_instance_state *out, DevState st, CycleParams P, int L, int64_t first, int64_t count) {
+__global__ void get_state_kernel(shc_instance_state *out, DevState st, CycleParams P, int L, int64_t first, int64_t count, int touchdown) {
   using FD = Fields<NJ>;
   using R = RobotFields;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -62,7 +62,8 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
   o.pose_phase = ri(R::I_POSE_PHASE);
   const int ap = ri(R::I_APOSER);
   for (int i = 0; i < SHC_MAX_AUTO_POSERS; ++i) o.auto_poser_flags[i] = (ap >> (4 * i)) & 15;
-  o.pad_[0] = o.pad_[1] = 0;
+  o.touchdown_detection = touchdown;
+  o.pad_ = 0;
   for (int l = 0; l < SHC_MAX_LEGS; ++l) {
     shc_leg_snapshot &g = o.leg[l];
     __builtin_memset(&g, 0, sizeof g);
@@ -95,6 +96,9 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
     g.completed_first_step = (w & LW_CFS) ? 1 : 0;
     g.negate_auto_pose = (w & LW_NEG) ? 1 : 0;
     g.ik_failed = (w & LW_IKFAIL) ? 1 : 0;
+    g.step_plane_defined = (P.rough_terrain && f(FD::STEP_PLANE + 3) != 0.0) ? 1 : 0;
+    if (g.step_plane_defined)
+      for (int k = 0; k < 3; ++k) g.step_plane_position[k] = f(FD::STEP_PLANE + k);
     // LegStepper::iteratePhase (walk_controller.cpp:871-897)
     const int pm = (w >> LW_PM_SHIFT) & 3;
     g.swing_progress = g.stance_progress = -1.0; // walk_controller.h:498-499
@@ -180,6 +184,8 @@ __global__ void set_state_kernel(const shc_instance_state *in, DevState st, Cycl
     f(FD::ADM, g.admittance_state[0]);
     f(FD::ADM + 1, g.admittance_state[1]);
     f(FD::ADM_DELTA + 3, g.virtual_stiffness);
+    for (int k = 0; k < 3; ++k) f(FD::STEP_PLANE + k, g.step_plane_defined ? g.step_plane_position[k] : 0.0);
+    f(FD::STEP_PLANE + 3, g.step_plane_defined ? 1.0 : 0.0);
     int pm = PM_NONE;
     if (g.swing_progress >= 0.0) pm = PM_SWING;
     else if (g.stance_progress > 0.0) pm = PM_STANCE;

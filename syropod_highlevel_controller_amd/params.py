@@ -49,7 +49,7 @@ class LegSnapshot(C.Structure):
                 ("virtual_stiffness", C.c_double), ("tip_force_calculated", C.c_double * 3), ("swing_progress", C.c_double),
                 ("stance_progress", C.c_double), ("step_state", C.c_int32), ("phase", C.c_int32), ("at_correct_phase", C.c_int32),
                 ("completed_first_step", C.c_int32), ("negate_auto_pose", C.c_int32), ("ik_failed", C.c_int32),
-                ("tip_rotation_defined", C.c_int32), ("pad_", C.c_int32)]
+                ("tip_rotation_defined", C.c_int32), ("step_plane_defined", C.c_int32), ("step_plane_position", C.c_double * 3)]
 
 
 class InstanceState(C.Structure):
@@ -62,7 +62,8 @@ class InstanceState(C.Structure):
                 ("auto_pose_rotation", C.c_double * 4), ("current_pose", C.c_double * 7), ("odometry", C.c_double * 7),
                 ("walk_state", C.c_int32), ("legs_at_correct_phase", C.c_int32), ("legs_completed_first_step", C.c_int32),
                 ("return_to_default_attempted", C.c_int32), ("auto_posing_state", C.c_int32), ("pose_phase", C.c_int32),
-                ("auto_poser_flags", C.c_int32 * SHC_MAX_AUTO_POSERS), ("pad_", C.c_int32 * 2), ("leg", LegSnapshot * SHC_MAX_LEGS)]
+                ("auto_poser_flags", C.c_int32 * SHC_MAX_AUTO_POSERS), ("touchdown_detection", C.c_int32), ("pad_", C.c_int32),
+                ("leg", LegSnapshot * SHC_MAX_LEGS)]
 
 
 class JointParams(C.Structure):
@@ -87,6 +88,7 @@ class Params(C.Structure):
         ("clamp_joint_positions", C.c_int32), ("clamp_joint_velocities", C.c_int32),
         ("body_clearance", C.c_double), ("step_frequency", C.c_double), ("swing_height", C.c_double),
         ("swing_width", C.c_double), ("step_depth", C.c_double), ("stance_span_modifier", C.c_double),
+        ("touchdown_threshold", C.c_double), ("liftoff_threshold", C.c_double),
         ("velocity_input_mode", C.c_int32),
         ("stance_position", (C.c_double * 2) * SHC_MAX_LEGS),
         ("overlapping_walkspaces", C.c_int32), ("force_normal_touchdown", C.c_int32),
@@ -235,6 +237,7 @@ def _common(p: Params) -> None:
     p.swing_height = 0.020
     p.swing_width = 0.000
     p.step_depth = 0.000
+    p.touchdown_threshold, p.liftoff_threshold = 0.9, 0.1  # default.yaml:107-108
     p.stance_span_modifier = 0.000
     p.velocity_input_mode = VEL_THROTTLE
     p.overlapping_walkspaces, p.force_normal_touchdown, p.gravity_aligned_tips = 0, 0, 0

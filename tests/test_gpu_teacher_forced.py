@@ -69,6 +69,11 @@ def compare_records(p, features, g, o, tol_q=TOL_Q):
             np.testing.assert_allclose(gl["virtual_stiffness"], ol["virtual_stiffness"], rtol=1e-12)
     if (features & 1) or p.use_joint_effort:
         np.testing.assert_allclose(gl["tip_force_calculated"], ol["tip_force_calculated"], rtol=1e-9, atol=1e-9)
+    if p.rough_terrain_mode:
+        assert np.array_equal(gl["step_plane_defined"], ol["step_plane_defined"])
+        d = ol["step_plane_defined"] != 0
+        np.testing.assert_allclose(gl["step_plane_position"][d], ol["step_plane_position"][d], atol=TOL_X)
+        assert np.array_equal(g["touchdown_detection"], o["touchdown_detection"])
     if p.gravity_aligned_tips and D > 3:
         assert np.array_equal(gl["tip_rotation_defined"], ol["tip_rotation_defined"])
         d = ol["tip_rotation_defined"] != 0
@@ -284,6 +289,62 @@ def test_gravity_aligned_tips(Engine, dof, legs, gait):
     n, cycles = 64, 450
     inp = make_inputs(p, n, 300 + dof * 10 + legs, zero_every=7)
     teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 301, cycles, every=120, pose=True), label=f"gravity-aligned {legs}x{dof}")
+
+
+@pytest.mark.parametrize("case", ["hexapod-tripod", "hexapod-wave-force-normal-touchdown", "6x4-ripple", "no-tip-state-messages"])
+def test_rough_terrain_mode(Engine, case):
+    """rough_terrain_mode (SURVEY.md section 8f rank 4): the layered workspace behind the limits, Leg::touchdownDetection on every
+    tip-state message (model.cpp:712-722), default tip positions re-derived at every swing / stance start, swing targets
+    shifted onto the detected step surface (proactive) or pushed down by step_depth (reactive), stance-like secondary swing
+    nodes once in ground contact (walk_controller.cpp:1058-1114, :1160), and the walk plane re-fitted as the defaults move."""
+    if case == "6x4-ripple":
+        p = synthetic_octopod_params("ripple", 4, 6)
+    else:
+        p = default_hexapod_params("wave" if "wave" in case else "tripod")
+    p.rough_terrain_mode = 1
+    p.step_depth = 0.012
+    if "normal" in case:
+        p.force_normal_touchdown = 1
+    n, cycles = 96, 520
+    L = p.leg_count
+    inp = make_inputs(p, n, 601, zero_every=10)
+    sched = stop_go_schedule(p, n, 602, cycles, every=170)
+    if case != "no-tip-state-messages":
+        rng = np.random.default_rng(603)
+        for c in range(0, cycles, 6):  # a new tip-state message every 6 cycles: contact forces come and go
+            f = rng.normal(0, 0.25, (n, L, 3))
+            f[..., 2] += rng.choice([0.0, 0.05, 0.6, 1.5], size=(n, L), p=[0.3, 0.2, 0.2, 0.3])
+            sched.at(c, force=f)
+    eng, ob, _ = teacher_forced(Engine, p, n, inp, cycles, sched, label=f"rough terrain / {case}")
+    st = as_np(ob.get_state())
+    if case != "no-tip-state-messages":
+        assert st["leg"]["step_plane_defined"][:, :L].any() and not st["leg"]["step_plane_defined"][:, :L].all()
+        # the default tips have left their identity positions and the walk plane has tilted with them
+        ident = np.array([[p.stance_position[l][0], p.stance_position[l][1], 0.0] for l in range(L)])
+        assert np.abs(st["leg"]["default_tip"][:, :L] - ident).max() > 1e-3
+        assert np.abs(st["walk_plane"]).max() > 1e-4
+
+
+def test_rough_terrain_mode_free_running(Engine):
+    """... and free-running from the engine's own init chain (layered workspace on the host), against the oracle."""
+    from test_gpu_parity import compare
+    p = default_hexapod_params("tripod")
+    p.rough_terrain_mode, p.step_depth = 1, 0.01
+    n = 60
+    inp = make_inputs(p, n, 611, zero_every=9)
+    rng = np.random.default_rng(612)
+    eng, ob = Engine(p, n), OracleBatch(p, n)
+    apply(eng, inp)
+    apply(ob, inp)
+    for k in range(40):
+        f = rng.normal(0, 0.25, (n, 6, 3))
+        f[..., 2] += rng.choice([0.0, 0.6, 1.5], size=(n, 6))
+        for o in (eng, ob):
+            o.set_tip_force(f)
+        eng.step(7)
+        eng.synchronize()
+        ob.step(7, 8)
+        compare(eng, ob, tol_q=1e-6)
 
 
 def _variants():

@@ -53,6 +53,10 @@ def cases():
         for aligned in (False, True):
             p = own_clock_auto_pose_params(g, aligned)
             yield f"hexapod-{g}-auto-pose-own-clock" + ("-ready-at-phase-0" if aligned else ""), p
+    for g, legs, dof in (("tripod", 6, 3), ("ripple", 6, 4)):  # rough terrain mode: the layered workspace (model.cpp:309-510)
+        p = default_hexapod_params(g) if dof == 3 else synthetic_octopod_params(g, dof, legs)
+        p.rough_terrain_mode = 1
+        yield f"rough-terrain-{legs}x{dof}-{g}", p
     for name, (dof, legs, gait) in (("octopod-5dof-gravity-aligned-tips", (5, 8, "ripple")), ("hexapod-4dof-gravity-aligned-tips", (4, 6, "tripod"))):
         p = synthetic_octopod_params(gait, dof, legs)
         p.gravity_aligned_tips = 1  # rotation-constrained start-up solve (model.cpp:880-900)
@@ -100,7 +104,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(engine.build_library())
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.shc_abi_version() == 1
+    assert lib.shc_abi_version() == 2
 
 
 def test_struct_layouts_match_the_library():
@@ -111,7 +115,7 @@ def test_struct_layouts_match_the_library():
 
 def test_unsupported_parameters_are_rejected():
     p = default_hexapod_params("tripod")
-    p.rough_terrain_mode = 1
+    p.rough_terrain_mode, p.stance_span_modifier = 1, 0.2
     with pytest.raises(engine.ShcError):
         engine.generate_tables(p)
     p = default_hexapod_params("tripod")
