@@ -413,6 +413,7 @@ typedef struct shc_instance_state {
   double auto_pose_rotation[4];       /* PoseController::auto_pose_.rotation_ of the last cycle (w,x,y,z) */
   double current_pose[7];             /* Model::current_pose_ */
   double odometry[7];                 /* WalkController::odometry_ideal_ */
+  double tip_align_pose[7], origin_tip_align_pose[7]; /* PoseController::tip_align_pose_ / origin_tip_align_pose_ (pose_controller.h:286-287) */
   int32_t walk_state;                 /* SHC_WALK_* */
   int32_t legs_at_correct_phase, legs_completed_first_step, return_to_default_attempted; /* walk_controller.h:266-268 */
   int32_t auto_posing_state;          /* SHC_POSING .. SHC_POSING_COMPLETE */

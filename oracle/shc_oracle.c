@@ -191,6 +191,7 @@ struct orc_robot
   int pose_reset_mode;
   orc_v3 translation_velocity_input, rotation_velocity_input;
   orc_pose manual_pose, auto_pose, imu_pose, inclination_pose, pc_default_pose, walk_plane_pose, origin_walk_plane_pose;
+  orc_pose tip_align_pose, origin_tip_align_pose; /* pose_controller.h:286-287 */
   int executing_transition;
   auto_poser_t auto_poser[SHC_MAX_AUTO_POSERS];
   int n_auto_posers;
@@ -1487,6 +1488,7 @@ static void poser_init(orc_robot *r)
 {
   r->manual_pose = r->auto_pose = r->imu_pose = r->inclination_pose = r->pc_default_pose = orc_pose_identity();
   r->walk_plane_pose = r->origin_walk_plane_pose = orc_pose_identity();
+  r->tip_align_pose = r->origin_tip_align_pose = orc_pose_identity();
   r->rotation_absement_error = r->rotation_position_error = r->rotation_velocity_error = orc_v3_make(0, 0, 0);
   r->translation_velocity_input = r->rotation_velocity_input = orc_v3_make(0, 0, 0);
   r->pose_reset_mode = SHC_NO_RESET;
@@ -1784,6 +1786,55 @@ static void poser_update_auto_pose(orc_robot *r)
   for (int l = 0; l < r->leg_count; ++l) leg_poser_update_auto_pose(r, &r->leg[l], master_phase);
 }
 
+/* PoseController::updateTipAlignPose (pose_controller.cpp:1024-1088) */
+static void poser_update_tip_align_pose(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    const stepper_t *ls = &leg->stepper;
+    double swing_progress = ls->swing_progress;
+    if (swing_progress != -1.0)
+    {
+      orc_v3 walk_plane_normal = ls->walk_plane_normal;
+      orc_quat walk_plane_rotation = orc_quat_from_two_vectors(orc_v3_make(0, 0, 1), walk_plane_normal);
+      /* vector from the tip to the last joint, robot frame (Tip / Joint::getPoseRobotFrame, model.h:603-617, 684-697) */
+      orc_m4 tt = transform_from_joint(leg, leg->joint_count + 1, 0);
+      orc_m4 tj = transform_from_joint(leg, leg->joint_count, 0);
+      orc_v3 tip_position = orc_v3_make(tt.m[0][3], tt.m[1][3], tt.m[2][3]);
+      orc_v3 joint_position = orc_v3_make(tj.m[0][3], tj.m[1][3], tj.m[2][3]);
+      orc_v3 tip_to_joint = orc_v3_sub(joint_position, tip_position);
+      double link_length = orc_v3_norm(orc_v3_sub(tip_position, joint_position));
+      /* body translation that puts the joint in line with the tip along the walk-plane normal */
+      orc_v3 a = orc_quat_rotate(walk_plane_rotation, tip_to_joint);
+      orc_v3 b = orc_v3_scale(walk_plane_normal, link_length);
+      orc_v3 rejection = orc_v3_sub(a, orc_v3_scale(b, orc_v3_dot(a, b) / orc_v3_dot(b, b)));
+      orc_v3 translation_to_alignment = orc_v3_neg(rejection);
+      a = r->tip_align_pose.p;
+      b = walk_plane_normal;
+      rejection = orc_v3_sub(a, orc_v3_scale(b, orc_v3_dot(a, b) / orc_v3_dot(b, b)));
+      orc_v3 target_translation = orc_v3_add(rejection, translation_to_alignment);
+      /* clamped(value, limit): every upper bound is limit[1] (standard_includes.h:134) */
+      const double *lim = r->params.max_translation;
+      target_translation.x = orc_clamped(target_translation.x, -lim[0], lim[1]);
+      target_translation.y = orc_clamped(target_translation.y, -lim[1], lim[1]);
+      target_translation.z = orc_clamped(target_translation.z, -lim[2], lim[1]);
+      double c = orc_smooth_step(swing_progress);
+      if (swing_progress < 0.5)
+      {
+        c = orc_smooth_step(c * 2.0);
+        r->tip_align_pose = orc_pose_interpolate(r->origin_tip_align_pose, c, orc_pose_identity());
+      }
+      else if (swing_progress >= 0.5)
+      {
+        c = orc_smooth_step((c - 0.5) * 2.0);
+        r->tip_align_pose = orc_pose_interpolate(orc_pose_identity(), c, orc_pose_make(target_translation, orc_quat_identity()));
+      }
+      if (swing_progress == 1.0) r->origin_tip_align_pose = r->tip_align_pose;
+    }
+  }
+}
+
 /* PoseController::updateCurrentPose (pose_controller.cpp:811-859) */
 static void poser_update_current_pose(orc_robot *r, int robot_state)
 {
@@ -1811,7 +1862,12 @@ static void poser_update_current_pose(orc_robot *r, int robot_state)
     poser_update_auto_pose(r);
     new_pose = orc_pose_add(new_pose, r->auto_pose);
   }
-  /* gravity_aligned_tips && DOF <= 3 (updateTipAlignPose, "TODO EXPERIMENTAL") is outside the restated path */
+  /* automatic body posing to align tips orthogonal to the walk plane during the 2nd half of swing ("TODO EXPERIMENTAL", :849-855) */
+  if (r->params.gravity_aligned_tips && r->leg[0].joint_count <= 3)
+  {
+    poser_update_tip_align_pose(r);
+    new_pose = orc_pose_add(new_pose, r->tip_align_pose);
+  }
   r->current_pose = new_pose;
 }
 
@@ -2667,6 +2723,8 @@ void orc_get_state(const orc_robot *r, shc_instance_state *o)
   put_quat4(o->auto_pose_rotation, r->auto_pose.r);
   put_pose7(o->current_pose, r->current_pose);
   put_pose7(o->odometry, r->odometry_ideal);
+  put_pose7(o->tip_align_pose, r->tip_align_pose);
+  put_pose7(o->origin_tip_align_pose, r->origin_tip_align_pose);
   o->walk_state = r->walk_state;
   o->legs_at_correct_phase = r->legs_at_correct_phase;
   o->legs_completed_first_step = r->legs_completed_first_step;
@@ -2739,6 +2797,8 @@ void orc_set_state(orc_robot *r, const shc_instance_state *o)
   r->auto_pose.r = orc_quat_make(o->auto_pose_rotation[0], o->auto_pose_rotation[1], o->auto_pose_rotation[2], o->auto_pose_rotation[3]);
   r->current_pose = get_pose7(o->current_pose);
   r->odometry_ideal = get_pose7(o->odometry);
+  r->tip_align_pose = get_pose7(o->tip_align_pose);
+  r->origin_tip_align_pose = get_pose7(o->origin_tip_align_pose);
   r->walk_state = o->walk_state;
   r->legs_at_correct_phase = o->legs_at_correct_phase;
   r->legs_completed_first_step = o->legs_completed_first_step;

@@ -72,6 +72,7 @@ struct CycleParams {
   int32_t odometry;   // SHC_FEAT_ODOMETRY
   int32_t gravity_aligned;       // gravity_aligned_tips with > 3 DOF legs: rotation-constrained IK (model.cpp:880-900)
   int32_t rough_terrain;         // rough_terrain_mode (generic kernel): default tips follow the terrain, targets meet the step surface
+  int32_t tip_align, pad1;       // gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose (generic kernel)
   double step_depth;             // walk_controller.h:80
   double target_dir[3];          // x axis of the identity tip rotation FromTwoVectors(x, -z) (walk_controller.cpp:37-41)
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
@@ -136,7 +137,9 @@ struct RobotFields {
   static constexpr int APREV = 51, APREV_END = 55;                      // previous cycle's auto_pose_.rotation_
   static constexpr int CPOSE = 55, CPOSE_END = 62;                      // output: Model::current_pose_
   static constexpr int WPP = 62, WPP_END = 69;                          // walk_plane_pose_ of the current cycle (LDS tile only)
-  static constexpr int ODOM = 69, COUNT = 73; // WalkController::odometry_ideal_ (odometry feature): x, y, qw, qz (pure yaw)
+  static constexpr int ODOM = 69, ODOM_END = 73; // WalkController::odometry_ideal_ (odometry feature): x, y, qw, qz (pure yaw)
+  // PoseController::tip_align_pose_ / origin_tip_align_pose_ (gravity_aligned_tips with <= 3 DOF legs, generic kernel only)
+  static constexpr int TALIGN = 73, OTALIGN = 80, COUNT = 87;
   static constexpr int I_WORD = 0, I_APOSER = 1, I_POSE_PHASE = 2, I_RESET_MODE = 3, I_COUNT = 4;
 };
 
@@ -597,6 +600,44 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       }
       cp = add_pose(cp, auto_pose);
       if (FT::incl(P)) rb.putq(R::APREV, auto_pose.r);
+    }
+    // ---- updateTipAlignPose (:1024-1088): the legs are visited in id order and each swinging leg overwrites the pose, reading the
+    //      translation its predecessor left - re-simulated identically in every lane from L shuffled tip-to-joint vectors
+    if ((F & F_DYN) != 0 && NJ <= 3 && uni(P.tip_align)) {
+      Chain<NJ> ch0;
+      chain_from_sincos<NJ>(lc, s.sn, s.cs, ch0); // the last applyFK: tip and last joint in the robot frame
+      const V3 t2j_own = base_rotate(lc, ch0.p[NJ - 1] - ch0.pe);
+      Pose ta = rb.getpose(R::TALIGN), ota = rb.getpose(R::OTALIGN);
+      const V3 n = rb.get3(R::PNORM_PREV); // leg_stepper->getWalkPlaneNormal(): the copy taken by last cycle's updateStride
+      const Quat wrot = from_two_vectors(UZ, n);
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        const V3 t2j{g.get(t2j_own.x, j), g.get(t2j_own.y, j), g.get(t2j_own.z, j)};
+        const double sp = swing_progress_of(lw[j], P);
+        if (sp != -1.0) {
+          const double link_length = norm(-t2j);
+          V3 a = rotate(wrot, t2j), b = n * link_length;
+          const V3 to_alignment = -(a - b * (dot(a, b) / dot(b, b)));
+          a = ta.p;
+          b = n;
+          V3 target = (a - b * (dot(a, b) / dot(b, b))) + to_alignment;
+          target.x = clampd(target.x, -P.max_translation[0], P.max_translation[1]); // clamped(value, limit): every upper bound is
+          target.y = clampd(target.y, -P.max_translation[1], P.max_translation[1]); // limit[1] (standard_includes.h:134)
+          target.z = clampd(target.z, -P.max_translation[2], P.max_translation[1]);
+          double c = smooth_step(sp);
+          if (sp < 0.5) {
+            c = smooth_step(c * 2.0);
+            ta = interpolate_pose(ota, c, pose_identity());
+          } else {
+            c = smooth_step((c - 0.5) * 2.0);
+            ta = interpolate_pose(pose_identity(), c, Pose{target, quat_identity()});
+          }
+          if (sp == 1.0) ota = ta;
+        }
+      }
+      rb.putpose(R::TALIGN, ta);
+      rb.putpose(R::OTALIGN, ota);
+      cp = add_pose(cp, ta);
     }
     rb.putpose(R::CPOSE, cp);
   } else {

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   }
   double t_core[(R::CORE_END * RPW + 63) / 64], t_man[((R::MANUAL_END - R::MPOSE) * RPW + 63) / 64],
       t_imu[((R::IMU_END - R::ABSE) * RPW + 63) / 64], t_imuq[((R::IMUQ_END - R::IMUQ) * RPW + 63) / 64],
-      t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_odom[((R::COUNT - R::ODOM) * RPW + 63) / 64];
+      t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_align[((R::COUNT - R::TALIGN) * RPW + 63) / 64], t_odom[((R::ODOM_END - R::ODOM) * RPW + 63) / 64];
   constexpr int int_iters = (R::I_COUNT * RPW + 63) / 64; // 3-legged robots: 21 per wave x 4 ints = 84 entries > one wave's width
   int32_t t_int[int_iters];
   if (any_robot) {
@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP)) load_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, gtile, lane);
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
-    if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::COUNT>(t_odom, gtile, lane);
+    if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, gtile, lane);
+    if ((F & F_DYN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
     // Leg::applyFK of the previous cycle: sin / cos of the stored joint angles
@@ -301,7 +302,8 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP)) put_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, tile, lane);
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
-    if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::COUNT>(t_odom, tile, lane);
+    if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, tile, lane);
+    if ((F & F_DYN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it)
       if (it * 64 + lane < R::I_COUNT * RPW) tile_i[it * 64 + lane] = t_int[it];
@@ -345,7 +347,8 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
   store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
-  if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::COUNT>(tile, gtile, lane);
+  if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::ODOM_END>(tile, gtile, lane);
+  if ((F & F_DYN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
   static_assert((R::I_POSE_PHASE + 1) * RPW <= 64, "the written-back int fields (word, poser latches, pose phase) fit one wave-wide store");
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
   SHC_TICK(14);
@@ -646,6 +649,7 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
   c.gravity_aligned = hostinit::tips_rotation_constrained(p, p.leg_dof[0]) ? 1 : 0;
   c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
+  c.tip_align = (p.gravity_aligned_tips && p.leg_dof[0] <= 3) ? 1 : 0; // pose_controller.cpp:849
   c.step_depth = p.step_depth;
   {
     V3 d = hostinit::gravity_aligned_direction();
@@ -700,8 +704,6 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
                                      "is outside the accelerated path");
   if (p->rough_terrain_mode && !(p->touchdown_threshold >= p->liftoff_threshold))
     return fail(SHC_ERR_INVALID_ARG, "touchdown_threshold must be >= liftoff_threshold");
-  if (p->gravity_aligned_tips && nj <= 3)
-    return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips with <= 3 DOF legs is the reference's experimental tip-align pose (outside the accelerated path)");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
   if (!(p->time_delta > 0) || !(p->step_frequency > 0)) return fail(SHC_ERR_INVALID_ARG, "time_delta / step_frequency must be > 0");
   // gait integers feed integer divisions / modulos on the host (generateStepCycle) and on the device (phase arithmetic)
@@ -947,6 +949,7 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
   robt[R::WPP + 2] = e->params.body_clearance;
   robt[R::WPP + 3] = 1.0;
   robt[R::ODOM + 2] = 1.0; // identity (walk_controller.cpp:28): x, y, qw, qz
+  robt[R::TALIGN + 3] = robt[R::OTALIGN + 3] = 1.0; // identity (pose_controller.h:132-133)
   robi.assign(R::I_COUNT, 0);
   robi[R::I_WORD] = WS_STOPPED | (PS_POSING_COMPLETE << RW_APS_SHIFT);
   // Auto posing on its own clock (pose_frequency != -1): PoseController::updateCurrentPose already runs in every loop of
@@ -1303,7 +1306,7 @@ static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cyc
   }
   if constexpr (SPEC) {
     constexpr unsigned C2 = F_MANUAL | F_ODOM, C3 = F_MANUAL | F_IMU | F_ADM | F_ODOM; // BASELINE.json configs 2/4 and 3
-    if (specialised && !c.rough_terrain) switch (f) {
+    if (specialised && !c.rough_terrain && !c.tip_align) switch (f) {
       case C2 | F_TIPF: launch_cycle<L, NJ, C2 | F_TIPF>(e, grid, block, n_cycles); return;
       case C2: launch_cycle<L, NJ, C2>(e, grid, block, n_cycles); return;
       case C3 | F_TIPF: launch_cycle<L, NJ, C3 | F_TIPF>(e, grid, block, n_cycles); return;

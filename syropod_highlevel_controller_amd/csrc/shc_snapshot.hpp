@@ -47,6 +47,8 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
     o.manual_pose[k] = rd(R::MPOSE + k);
     o.current_pose[k] = rd(R::CPOSE + k);
     o.odometry[k] = 0.0;
+    o.tip_align_pose[k] = rd(R::TALIGN + k);
+    o.origin_tip_align_pose[k] = rd(R::OTALIGN + k);
   }
   for (int k = 0; k < 4; ++k) o.auto_pose_rotation[k] = rd(R::APREV + k);
   o.odometry[0] = rd(R::ODOM); // stored as (x, y, qw, qz): pure yaw
@@ -149,6 +151,8 @@ __global__ void set_state_kernel(const shc_instance_state *in, DevState st, Cycl
     wr(R::OWPP + k, o.origin_walk_plane_pose[k]);
     wr(R::MPOSE + k, o.manual_pose[k]);
     wr(R::CPOSE + k, o.current_pose[k]);
+    wr(R::TALIGN + k, o.tip_align_pose[k]);
+    wr(R::OTALIGN + k, o.origin_tip_align_pose[k]);
   }
   for (int k = 0; k < 4; ++k) wr(R::APREV + k, o.auto_pose_rotation[k]);
   wr(R::ODOM, o.odometry[0]);

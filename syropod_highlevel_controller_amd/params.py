@@ -60,6 +60,7 @@ class InstanceState(C.Structure):
                 ("translation_velocity_input", C.c_double * 3), ("rotation_velocity_input", C.c_double * 3),
                 ("rotation_absement_error", C.c_double * 3), ("rotation_velocity_error", C.c_double * 3),
                 ("auto_pose_rotation", C.c_double * 4), ("current_pose", C.c_double * 7), ("odometry", C.c_double * 7),
+                ("tip_align_pose", C.c_double * 7), ("origin_tip_align_pose", C.c_double * 7),
                 ("walk_state", C.c_int32), ("legs_at_correct_phase", C.c_int32), ("legs_completed_first_step", C.c_int32),
                 ("return_to_default_attempted", C.c_int32), ("auto_posing_state", C.c_int32), ("pose_phase", C.c_int32),
                 ("auto_poser_flags", C.c_int32 * SHC_MAX_AUTO_POSERS), ("touchdown_detection", C.c_int32), ("pad_", C.c_int32),

@@ -111,6 +111,9 @@ def compare_records(p, features, g, o, tol_q=TOL_Q):
             np.testing.assert_allclose(g["auto_pose_rotation"], o["auto_pose_rotation"], atol=TOL_X)
     if features & 2:
         np.testing.assert_allclose(g["odometry"], o["odometry"], atol=TOL_X)
+    if p.gravity_aligned_tips and D <= 3:
+        for f in ("tip_align_pose", "origin_tip_align_pose"):
+            np.testing.assert_allclose(g[f], o[f], atol=TOL_X, err_msg=f)
     return float(dq.max())
 
 
@@ -345,6 +348,29 @@ def test_rough_terrain_mode_free_running(Engine):
         eng.synchronize()
         ob.step(7, 8)
         compare(eng, ob, tol_q=1e-6)
+
+
+@pytest.mark.parametrize("gait,legs", [("tripod", 6), ("wave", 6), ("ripple", 8), ("amble", 4)])
+def test_tip_align_pose(Engine, gait, legs):
+    """gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose (pose_controller.cpp:1024-1088) shifts the body
+    so that the last link of a swinging leg lines up with the walk-plane normal - the legs are visited in id order, each
+    overwriting the pose its predecessor left (row a25 of SURVEY.md section 8)."""
+    p = default_hexapod_params(gait) if legs == 6 else synthetic_octopod_params(gait, 3, legs)
+    p.gravity_aligned_tips = 1
+    p.max_translation[:] = [0.03, 0.02, 0.025]  # distinct limits: the reference clamps every axis against limit[1] above
+    n, cycles = 80, 460
+    inp = make_inputs(p, n, 701, zero_every=9)
+    eng, ob, _ = teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 702, cycles, every=150, pose=True), label=f"tip-align {legs}x3 {gait}")
+    st = as_np(ob.get_state())
+    assert np.abs(st["tip_align_pose"][:, :3]).max() > 1e-3   # the pose is doing something
+
+
+def test_tip_align_pose_free_running(Engine):
+    from test_gpu_parity import run_pair
+    p = default_hexapod_params("tripod")
+    p.gravity_aligned_tips = 1
+    n = 60
+    run_pair(Engine, p, n, make_inputs(p, n, 711, zero_every=8), [1, 1, 98, 150, 200], twin=True)
 
 
 def _variants():
