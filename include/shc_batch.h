@@ -282,32 +282,55 @@ int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness, int on_de
  * ROS message surface.  Numeric payload of syropod_highlevel_controller/LegState.msg as
  * StateController::publishLegState fills it (msg/LegState.msg; state_controller.cpp:809-893), one record per leg of ONE
  * instance: the node copies the fields into its message and adds stamps, frame ids and the leg name.
- * Not provided (the node keeps computing it): actual_tip_pose (FK of the MEASURED joint positions, :839, an input the
- * engine never sees).  Tip orientations are not part of the payload (UNDEFINED (0,0,0,0) unless gravity_aligned_tips).
+ * Tip orientations of the walker / poser tips are not part of the payload (UNDEFINED (0,0,0,0) unless gravity_aligned_tips).
  */
 typedef struct shc_leg_state_msg {
   double walker_tip_position[3]; /* walker_tip_pose.pose.position   :822-824 (frame walk_plane) */
   double target_tip_position[3]; /* target_tip_pose.pose.position   :826-828 */
   double poser_tip_position[3];  /* poser_tip_pose.pose.position    :830-832 (frame base_link) */
   double model_tip_position[3];  /* model_tip_pose.pose.position    :834-836 */
+  double actual_tip_pose[7];     /* actual_tip_pose.pose :837-839 = Leg::applyFK(false, true): FK of the MEASURED joint positions
+                                    (x,y,z,qw,qx,qy,qz); until shc_engine_set_joint_states_msg supplies them these are the initial default
+                                    positions Leg::init(true) copied (model.cpp:292-296) */
   double model_tip_velocity[3];  /* model_tip_velocity.twist.linear :845-849: always 0 - publishLegState calls applyFK() on
                                     unchanged joints just before (:840), which resets Leg::current_tip_velocity_ to
                                     (tip - tip) / dt (model.cpp:980) */
   double joint_positions[SHC_MAX_JOINTS];  /* Joint::desired_position_ :854 */
   double joint_velocities[SHC_MAX_JOINTS]; /* Joint::desired_velocity_ :855 */
-  double joint_efforts[SHC_MAX_JOINTS];    /* Joint::desired_effort_   :856 (never assigned on this path: 0) */
+  double joint_efforts[SHC_MAX_JOINTS];    /* Joint::desired_effort_   :856 = the last measured effort (jointStatesCallback :1590) */
   double stance_progress, swing_progress;  /* :860-861, -1 when not in that state (walk_controller.cpp:871-897) */
   double time_to_swing_end;                /* :862-874 */
   double pose_delta[7];                    /* calculateOdometry(time_to_swing_end) :875: x,y,z,qw,qx,qy,qz */
   double auto_pose[7];                     /* LegPoser::auto_pose_ :877-880 (x,y,z,qw,qx,qy,qz): the identity pose when
-                                              auto_posing is off (never assigned, pose_controller.cpp:1716); NaN with
-                                              auto_posing on (the per-leg pose is not kept after the cycle) */
+                                              auto_posing is off (never assigned, pose_controller.cpp:1716); with auto posing
+                                              the per-leg pose of the last cycle (negation applied), re-derived from the
+                                              stored poser latches and master phase */
   double tip_force[3];                     /* tip_force_calculated_ * force_gain :883-885 */
   double admittance_delta[3];              /* :886-888 */
   double virtual_stiffness;                /* :889 */
 } shc_leg_state_msg;
 /* Fills legs[0 .. leg_count) for `instance`.  Synchronises the engine's stream. */
 int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, shc_leg_state_msg *legs);
+
+/*
+ * The other ROS messages of the path, batched: payloads in, payloads out; the node adds names,
+ * stamps and frame ids.
+ */
+/* jointStatesCallback (state_controller.cpp:1566-1594), sensor_msgs/JointState as the motors report it: position rows
+ * [n][legs][dof] are RAW motor positions - the callback stores position - Joint::offset_ as Joint::current_position_ (:1581; used by
+ * Leg::applyFK(.., use_actual) for LegState.actual_tip_pose) - and effort rows [n][legs][dof] become Joint::current_effort_ /
+ * desired_effort_ (:1589-1590, what Leg::calculateTipForce and LegState.joint_efforts read).  velocity is stored by the
+ * reference but never read on this path: accepted for symmetry, ignored.  Any pointer may be NULL. */
+int shc_engine_set_joint_states_msg(shc_engine *e, const double *position, const double *velocity, const double *effort, int on_device);
+/* tipStatesCallback (state_controller.cpp:1617-1679), syropod_highlevel_controller/TipState: wrench force rows [n][legs][3]
+ * (= shc_engine_set_tip_force: stores the force, switches touchdown detection on, runs Leg::touchdownDetection) and / or the
+ * range sensors' step_plane rows [n][legs][3] = (x, y, z): z = distance to the step surface along the tip's x axis, or
+ * UNASSIGNED_VALUE (2147483647) when the sensor lost contact -> Leg::step_plane_pose_ (:1661-1672).  Either may be NULL. */
+int shc_engine_set_tip_states_msg(shc_engine *e, const double *wrench_force, const double *step_plane, int on_device);
+/* publishDesiredJointState (state_controller.cpp:777-805): the combined sensor_msgs/JointState payload (Leg::
+ * generateDesiredJointStateMsg, model.cpp:605-617: desired_position_, desired_velocity_, desired_effort_) and the per-joint
+ * std_msgs/Float64 position commands desired_position_ + offset_ (:798).  All [n][legs][dof]; any pointer may be NULL. */
+int shc_engine_get_joint_commands(shc_engine *e, double *position, double *velocity, double *effort, double *position_command, int on_device);
 
 /*
  * Per-leg methods of class Leg (model.h:448-492), batched.  The reference's cold paths call them on their own - workspace

@@ -2413,7 +2413,63 @@ void orc_set_joint_effort(orc_robot *r, const double *effort)
 {
   int k = 0;
   for (int l = 0; l < r->leg_count; ++l)
-    for (int j = 0; j < r->leg[l].joint_count; ++j) r->leg[l].joint[j].current_effort = effort[k++];
+    for (int j = 0; j < r->leg[l].joint_count; ++j)
+    {
+      r->leg[l].joint[j].current_effort = effort[k];
+      r->leg[l].joint[j].desired_effort = effort[k++]; /* "HACK" (state_controller.cpp:1590) */
+    }
+}
+
+/* jointStatesCallback (state_controller.cpp:1566-1594): raw motor positions [legs][dof] (offset removed, :1581), efforts */
+void orc_set_joint_states_msg(orc_robot *r, const double *position, const double *velocity, const double *effort)
+{
+  int k = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+    for (int j = 0; j < r->leg[l].joint_count; ++j, ++k)
+    {
+      joint_t *jt = &r->leg[l].joint[j];
+      if (position) jt->current_position = position[k] - jt->offset;
+      if (velocity) jt->current_velocity = velocity[k];
+      if (effort) { jt->current_effort = effort[k]; jt->desired_effort = effort[k]; }
+    }
+}
+
+/* tipStatesCallback, step_plane values of the tip range sensors (state_controller.cpp:1651-1672): [legs][3] */
+void orc_set_step_plane(orc_robot *r, const double *step_plane)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    leg->stepper.touchdown_detection = 1;
+    const double *sp = step_plane + 3 * l;
+    if (sp[2] != ORC_UNASSIGNED_VALUE)
+    {
+      orc_v3 step_plane_position = orc_v3_make(sp[2], 0.0, 0.0);
+      orc_v3 step_plane_normal = orc_v3_make(sp[0], sp[1], -1.0);
+      orc_quat step_plane_orientation = orc_quat_from_two_vectors(orc_v3_make(0, 0, 1.0), orc_v3_neg(step_plane_normal));
+      orc_m4 t = transform_from_joint(leg, leg->joint_count + 1, 0); /* Tip::getPoseRobotFrame (model.h:684-688) */
+      leg->step_plane_pose = orc_pose_transform_m4(orc_pose_make(step_plane_position, step_plane_orientation), &t);
+    }
+    else
+    {
+      leg->step_plane_pose = orc_pose_undefined();
+    }
+  }
+}
+
+/* publishDesiredJointState (state_controller.cpp:777-805): [legs][dof] each */
+void orc_get_joint_commands(const orc_robot *r, double *position, double *velocity, double *effort, double *position_command)
+{
+  int k = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+    for (int j = 0; j < r->leg[l].joint_count; ++j, ++k)
+    {
+      const joint_t *jt = &r->leg[l].joint[j];
+      if (position) position[k] = jt->desired_position;
+      if (velocity) velocity[k] = jt->desired_velocity;
+      if (effort) effort[k] = jt->desired_effort;
+      if (position_command) position_command[k] = jt->desired_position + jt->offset;
+    }
 }
 
 void orc_set_pose_input(orc_robot *r, const double tv[3], const double rv[3])
@@ -2438,6 +2494,7 @@ void orc_get_joint_state(const orc_robot *r, double *q, double *qd)
 }
 
 static void put3(double *dst, orc_v3 v) { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; }
+static void put_pose7(double *dst, orc_pose p);
 
 void orc_get_leg_state(const orc_robot *r, double *walker_tip, double *poser_tip, double *model_tip, double *tip_force,
                        double *admittance, int32_t *leg_status)
@@ -2618,11 +2675,19 @@ void orc_get_leg_state_msg(const orc_robot *r, shc_leg_state_msg *legs)
     put3(m->target_tip_position, ls->target_tip_pose.p);
     put3(m->poser_tip_position, leg->poser.current_tip_pose.p);
     put3(m->model_tip_position, leg->current_tip_pose.p);
+    { /* actual_tip_pose = leg->applyFK(false, true): FK of Joint::current_position_ (:837-839), which Leg::init(true) set to the
+       * initial default positions (model.cpp:292-296) and only jointStatesCallback writes afterwards */
+      leg_t *copy = (leg_t *)malloc(sizeof(leg_t));
+      *copy = *leg;
+      for (int j = 0; j < copy->joint_count; ++j) copy->joint[j].desired_position = copy->joint[j].current_position;
+      put_pose7(m->actual_tip_pose, leg_apply_fk((orc_robot *)r, copy));
+      free(copy);
+    }
     for (int j = 0; j < leg->joint_count; ++j)
     {
       m->joint_positions[j] = leg->joint[j].desired_position;
       m->joint_velocities[j] = leg->joint[j].desired_velocity;
-      m->joint_efforts[j] = 0.0; /* Joint::desired_effort_ is never assigned on this path */
+      m->joint_efforts[j] = leg->joint[j].desired_effort; /* = the last measured effort (state_controller.cpp:1590) */
     }
     m->swing_progress = ls->swing_progress;
     m->stance_progress = ls->stance_progress;

@@ -94,6 +94,10 @@ void orc_set_state(orc_robot *r, const shc_instance_state *in);
 void orc_batch_get_state(orc_batch *b, shc_instance_state *states /* [n] */);
 void orc_batch_set_state(orc_batch *b, const shc_instance_state *states /* [n] */);
 
+void orc_set_joint_states_msg(orc_robot *r, const double *position, const double *velocity, const double *effort); /* :1566 */
+void orc_set_step_plane(orc_robot *r, const double *step_plane /* [legs][3] */);                                   /* :1651 */
+void orc_get_joint_commands(const orc_robot *r, double *position, double *velocity, double *effort, double *position_command); /* :777 */
+
 /* Per-leg Leg methods (model.h:448-492) on leg `leg` of a robot: what the engine's shc_leg_* entry points are checked against. */
 void orc_leg_set_desired_tip_pose(orc_robot *r, int leg, const double *pose7 /* NULL = Pose::Undefined() */, int apply_delta);
 void orc_leg_solve_ik(orc_robot *r, int leg, const double delta[6], int solve_rotation, double *joint_delta);

@@ -122,7 +122,9 @@ struct Fields {
                        // origin_configuration_ (NJ, padded).  Only the sequence entry points touch these.
                        SEQ_ORG = DES_DIR + 4, SEQ_DIR = SEQ_ORG + 4, SEQ_Q0 = SEQ_DIR + 4,
                        // Leg::step_plane_pose_.position_ (3) + "defined" (touchdown detection; read by the cycle in rough terrain mode only)
-                       STEP_PLANE = SEQ_Q0 + NJE, COUNT = STEP_PLANE + 4;
+                       STEP_PLANE = SEQ_Q0 + NJE,
+                       // Joint::current_position_ (measured, offset removed) as jointStatesCallback stores it: LegState.actual_tip_pose
+                       MEAS_Q = STEP_PLANE + 4, COUNT = MEAS_Q + NJE;
   static_assert(CORE_END % 2 == 0 && SORG % 2 == 0 && COUNT % 2 == 0, "field groups must align to 16-byte planes");
 };
 // element index of field f of slot `slot` in the plane array (n_slots slots per plane)
@@ -520,6 +522,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       int master_phase;
       if (P.pose_sync) {
         master_phase = (ref >> LW_PHASE_SHIFT) & LW_PHASE_MASK;
+        rb.puti(R::I_POSE_PHASE, master_phase); // kept for LegState.auto_pose (shc_engine_read_leg_state_msg); unused otherwise
       } else {
         master_phase = rb.geti(R::I_POSE_PHASE);
         rb.puti(R::I_POSE_PHASE, (master_phase + 1) % P.pose_phase_length);

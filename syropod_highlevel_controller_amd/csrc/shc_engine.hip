@@ -436,12 +436,13 @@ __global__ void gather_odometry_kernel(double *dst, const double *robd, int rpw,
   o[6] = robd[rob_index(r, RobotFields::ODOM + 3, rpw, nf)];
 }
 // everything publishLegState needs of one instance, packed per leg: tip(3) targ(3) poser(3) model(3) q(NJ) qd(NJ) tf(3)
-// adm(3) stiff word | then vx vy w
+// adm(3) stiff word effort(NJ) measured q(NJ) | then vx vy w, robot word, poser latches, pose phase, IMU orientation (4)
 template <int NJ>
 __global__ void read_instance_kernel(double *dst, DevState st, int L, int64_t rob, int have_adm) {
   using FD = Fields<NJ>;
+  using R = RobotFields;
   const int leg = threadIdx.x;
-  constexpr int per_leg = 12 + 2 * NJ + 8;
+  constexpr int per_leg = 12 + 4 * NJ + 8;
   if (leg < L) {
     const int64_t slot = slot_of(rob, leg, L);
     auto f = [&](int field) { return st.legd[leg_field_index(field, slot, st.n_slots)]; };
@@ -457,13 +458,20 @@ __global__ void read_instance_kernel(double *dst, DevState st, int L, int64_t ro
     for (int j = 0; j < NJ; ++j) {
       o[12 + j] = f(FD::Q + j);
       o[12 + NJ + j] = f(FD::QD + j);
+      o[20 + 2 * NJ + j] = f(FD::EFFORT_IN + j);
+      o[20 + 3 * NJ + j] = f(FD::MEAS_Q + j);
     }
     o[18 + 2 * NJ] = have_adm ? f(FD::ADM_DELTA + 3) : 0.0;
     o[19 + 2 * NJ] = double(st.legi[slot]);
   }
   if (leg == 0) {
     const int rpw = 64 / L;
-    for (int k = 0; k < 3; ++k) dst[L * per_leg + k] = st.robd[rob_index(rob, RobotFields::VLIN + k, rpw, RobotFields::COUNT)];
+    double *o = dst + L * per_leg;
+    for (int k = 0; k < 3; ++k) o[k] = st.robd[rob_index(rob, R::VLIN + k, rpw, R::COUNT)];
+    o[3] = double(st.robi[rob_index(rob, R::I_WORD, rpw, R::I_COUNT)]);
+    o[4] = double(st.robi[rob_index(rob, R::I_APOSER, rpw, R::I_COUNT)]);
+    o[5] = double(st.robi[rob_index(rob, R::I_POSE_PHASE, rpw, R::I_COUNT)]);
+    for (int k = 0; k < 4; ++k) o[6 + k] = st.robd[rob_index(rob, R::IMUQ + k, rpw, R::COUNT)];
   }
 }
 __global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int64_t n, int L) {
@@ -906,7 +914,12 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
   legw.assign(e->L, 0);
   for (int l = 0; l < e->L; ++l) {
     double *t = &legt[size_t(l) * nf];
-    for (int j = 0; j < NJ; ++j) t[F::Q + j] = e->tables.default_joint_position[l][j];
+    for (int j = 0; j < NJ; ++j) {
+      t[F::Q + j] = e->tables.default_joint_position[l][j];
+      // Joint::current_position_ until a joint state message arrives: Leg::init(true) copied the initial default positions
+      // (model.cpp:292-296, :1038) and nothing on this path writes it again
+      t[F::MEAS_Q + j] = clampd(0.0, e->params.joint[l][j].min, e->params.joint[l][j].max);
+    }
     double sx = e->params.stance_position[l][0], sy = e->params.stance_position[l][1];
     // LegStepper constructor (walk_controller.cpp:795-819): everything at the identity tip pose
     const int at_identity[] = {F::TIP, F::SORG, F::TORG, F::DFLT, F::TARG};
@@ -1096,7 +1109,7 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   HIP_TRY_OR(hipMalloc(&e->st.robi, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4), shc_engine_destroy(e));
   HIP_TRY_OR(hipMemsetAsync(e->st.robd, 0, size_t(RobotFields::COUNT) * e->n_rob_pad * 8, e->stream), shc_engine_destroy(e));
   HIP_TRY_OR(hipMemsetAsync(e->st.robi, 0, size_t(RobotFields::I_COUNT) * e->n_rob_pad * 4, e->stream), shc_engine_destroy(e));
-  e->stage_bytes = size_t(e->n) * L * (NJ > 3 ? NJ : 3) * 8 + size_t(e->n) * 8 * 8;
+  e->stage_bytes = size_t(e->n) * L * (NJ > 3 ? NJ : 3) * 8 + size_t(e->n) * 8 * 8 + size_t(SHC_MAX_LEGS) * SHC_MAX_JOINTS * 8 + 4096;
   HIP_TRY_OR(hipMalloc(&e->d_stage, e->stage_bytes), shc_engine_destroy(e));
   rc = upload_consts(e);
   if (rc == SHC_OK) rc = init_state(e);
@@ -1504,13 +1517,76 @@ static int derive_tips(shc_engine *e) {
   return SHC_OK;
 }
 
+// PoseController::auto_pose_ of the cycle whose master phase and (post-update) poser latches are given: the sum the cycle
+// kernel forms (AutoPoser::updatePose, pose_controller.cpp:1338-1439), re-derived on the host for LegState.auto_pose.
+static Pose host_auto_pose(const shc_params &p, const shc_tables &t, int master_phase, int flags, Quat imu) {
+  Pose auto_pose = pose_identity();
+  const int len = t.pose_phase_length, nrm = t.pose_normaliser;
+  for (int i = 0; i < p.n_auto_posers && i < kMaxAutoPosers; ++i) {
+    const bool allow = ((flags >> (4 * i)) & 8) != 0;
+    int phase = master_phase, sp = p.pose_phase_starts[i] * nrm, ep = p.pose_phase_ends[i] * nrm;
+    if (sp > ep) {
+      ep += len;
+      if (phase < sp) phase += len;
+    }
+    if (!(phase >= sp && phase < ep && allow)) continue;
+    const int iteration = phase - sp + 1, num = ep - sp;
+    const bool first_half = iteration <= num / 2;
+    const double delta_t = 1.0 / (num / 2.0);
+    const int offset = int(first_half ? 0 : num / 2.0);
+    const double tt = (iteration - offset) * delta_t, u = 1.0 - tt;
+    const double wgt = first_half ? (4.0 * tt * tt * tt * u + tt * tt * tt * tt) : (u * u * u * u + 4.0 * tt * u * u * u);
+    V3 pos;
+    if (p.gravity_amplitudes[i] != 0.0) { // Model::estimateGravity (model.cpp:156-165)
+      const V3 e = quat_to_euler(imu, false);
+      V3 gv{0, 0, kGravity};
+      gv = rotate(angle_axis_y(-e.y), gv);
+      gv = rotate(angle_axis_x(-e.x), gv);
+      pos = normalized(gv) * (p.gravity_amplitudes[i] * wgt);
+    } else {
+      pos = V3{p.x_amplitudes[i] * wgt, p.y_amplitudes[i] * wgt, p.z_amplitudes[i] * wgt};
+    }
+    const V3 rot{p.roll_amplitudes[i] * wgt, p.pitch_amplitudes[i] * wgt, p.yaw_amplitudes[i] * wgt};
+    auto_pose = add_pose(auto_pose, Pose{pos, euler_to_quat(rot, false)});
+  }
+  return auto_pose;
+}
+// LegPoser::updateAutoPose's negation (pose_controller.cpp:1740-1776) for a leg whose negate flag is set
+static Pose host_leg_auto_pose(const shc_params &p, const shc_tables &t, int leg, int master_phase, bool negate, const Pose &auto_pose) {
+  if (!negate) return auto_pose;
+  const int len = t.pose_phase_length, nrm = t.pose_normaliser;
+  int sp = p.pose_negation_phase_starts[leg] * nrm, ep = p.pose_negation_phase_ends[leg] * nrm, np = master_phase;
+  if (sp == 0) sp = len;
+  if (ep == 0) ep = len;
+  if (sp > ep) {
+    ep += len;
+    if (np < sp) np += len;
+  }
+  const int iteration = np - sp + 1, num = ep - sp;
+  const bool first_half = iteration <= num / 2;
+  double ci = 1.0;
+  const double ratio = p.negation_transition_ratio[leg];
+  if (ratio > 0.0) ci = first_half ? fmin(1.0, iteration / (num * ratio)) : fmin(1.0, (num - iteration) / (num * ratio));
+  ci = smooth_step(ci);
+  return remove_pose(auto_pose, interpolate_pose(pose_identity(), ci, auto_pose));
+}
+
+template <int NJ>
+static Pose host_fk_tip_pose(const shc_params &p, int leg, const double *q) {
+  LegConst<NJ> lc;
+  hostinit::fill_leg_const<NJ>(p, leg, lc);
+  double qq[NJ];
+  for (int j = 0; j < NJ; ++j) qq[j] = q[j];
+  return fk_tip_pose<NJ>(lc, qq);
+}
+
 extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, shc_leg_state_msg *legs) {
   if (!e || !legs) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   if (instance < 0 || instance >= e->n) return fail(SHC_ERR_INVALID_ARG, "instance out of range");
   int rc = derive_tips(e);
   if (rc != SHC_OK) return rc;
-  const int L = e->L, NJ = e->NJ, per_leg = 12 + 2 * NJ + 8;
-  std::vector<double> h(size_t(L) * per_leg + 3);
+  const int L = e->L, NJ = e->NJ, per_leg = 12 + 4 * NJ + 8;
+  std::vector<double> h(size_t(L) * per_leg + 10);
   switch (NJ) {
     case 3: read_instance_kernel<3><<<dim3(1), dim3(64), 0, e->stream>>>(e->d_stage, e->st, L, instance, e->params.admittance_control); break;
     case 4: read_instance_kernel<4><<<dim3(1), dim3(64), 0, e->stream>>>(e->d_stage, e->st, L, instance, e->params.admittance_control); break;
@@ -1520,9 +1596,15 @@ extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, sh
   HIP_TRY(hipMemcpyAsync(h.data(), e->d_stage, h.size() * 8, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const shc_step_cycle &step = e->tables.step;
-  const double vx = h[size_t(L) * per_leg], vy = h[size_t(L) * per_leg + 1], vw = h[size_t(L) * per_leg + 2];
+  const double *rb = &h[size_t(L) * per_leg];
+  const double vx = rb[0], vy = rb[1], vw = rb[2];
   const double swing_time = (double(step.swing_period) / step.period) / step.frequency;   // state_controller.cpp:863
   const double stance_time = (double(step.stance_period) / step.period) / step.frequency; // :864
+  // PoseController::auto_pose_ of the last cycle (auto posing runs only where IMU posing does not, pose_controller.cpp:836-846)
+  const bool auto_live = e->params.auto_posing && !e->params.imu_posing && e->tables.pose_phase_length > 0;
+  int master_phase = int(rb[5]);
+  if (auto_live && e->params.pose_frequency != -1.0) master_phase = mod_i(master_phase - 1, e->tables.pose_phase_length); // the counter has advanced
+  const Pose auto_pose = auto_live ? host_auto_pose(e->params, e->tables, master_phase, int(rb[4]), Quat{rb[6], rb[7], rb[8], rb[9]}) : pose_identity();
   for (int l = 0; l < L; ++l) {
     const double *o = &h[size_t(l) * per_leg];
     shc_leg_state_msg &m = legs[l];
@@ -1538,6 +1620,13 @@ extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, sh
     for (int j = 0; j < NJ; ++j) {
       m.joint_positions[j] = o[12 + j];
       m.joint_velocities[j] = o[12 + NJ + j];
+      m.joint_efforts[j] = o[20 + 2 * NJ + j]; // desired_effort_ = current_effort_ (state_controller.cpp:1590)
+    }
+    { // actual_tip_pose: Leg::applyFK(false, true) on the measured joint positions (:839)
+      const double *qm = &o[20 + 3 * NJ];
+      const Pose tp = NJ == 3 ? host_fk_tip_pose<3>(e->params, l, qm) : (NJ == 4 ? host_fk_tip_pose<4>(e->params, l, qm) : host_fk_tip_pose<5>(e->params, l, qm));
+      m.actual_tip_pose[0] = tp.p.x, m.actual_tip_pose[1] = tp.p.y, m.actual_tip_pose[2] = tp.p.z;
+      m.actual_tip_pose[3] = tp.r.w, m.actual_tip_pose[4] = tp.r.x, m.actual_tip_pose[5] = tp.r.y, m.actual_tip_pose[6] = tp.r.z;
     }
     m.virtual_stiffness = o[18 + 2 * NJ];
     // LegStepper::swing_progress_ / stance_progress_ as iteratePhase left them (walk_controller.cpp:871-897)
@@ -1561,9 +1650,145 @@ extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, sh
     m.pose_delta[2] = 0.0 * t;
     m.pose_delta[3] = cos(0.5 * (vw * t));
     m.pose_delta[6] = sin(0.5 * (vw * t));
-    // (model_tip_velocity stays 0: see the header.)  LegPoser::auto_pose_
-    for (int k = 0; k < 7; ++k) m.auto_pose[k] = e->params.auto_posing ? std::nan("") : (k == 3 ? 1.0 : 0.0);
+    // (model_tip_velocity stays 0: see the header.)  LegPoser::auto_pose_ :877-880
+    const Pose la = auto_live ? host_leg_auto_pose(e->params, e->tables, l, master_phase, (word & LW_NEG) != 0, auto_pose) : pose_identity();
+    m.auto_pose[0] = la.p.x, m.auto_pose[1] = la.p.y, m.auto_pose[2] = la.p.z;
+    m.auto_pose[3] = la.r.w, m.auto_pose[4] = la.r.x, m.auto_pose[5] = la.r.y, m.auto_pose[6] = la.r.z;
   }
+  return SHC_OK;
+}
+
+// ---- the other messages of the path (include/shc_batch.h)
+// raw motor positions - Joint::offset_ -> measured joint positions (jointStatesCallback, state_controller.cpp:1581)
+__global__ void store_measured_q_kernel(const double *src, double *legd, int64_t n_slots, int64_t n, int L, int NJ, int f0, const double *offset /*[L][NJ]*/) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  const int64_t rob = t / L;
+  const int leg = int(t - rob * L);
+  const int64_t slot = slot_of(rob, leg, L);
+  for (int j = 0; j < NJ; ++j) legd[leg_field_index(f0 + j, slot, n_slots)] = src[t * NJ + j] - offset[leg * NJ + j];
+}
+// desired joint state + per-joint position commands (publishDesiredJointState, state_controller.cpp:777-805)
+__global__ void joint_commands_kernel(double *pos, double *vel, double *eff, double *cmd, const double *legd, int64_t n_slots, int64_t n, int L, int NJ,
+                                      int fq, int fqd, int feff, const double *offset) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  const int64_t rob = t / L;
+  const int leg = int(t - rob * L);
+  const int64_t slot = slot_of(rob, leg, L);
+  for (int j = 0; j < NJ; ++j) {
+    const double q = legd[leg_field_index(fq + j, slot, n_slots)];
+    if (pos) pos[t * NJ + j] = q;
+    if (vel) vel[t * NJ + j] = legd[leg_field_index(fqd + j, slot, n_slots)];
+    if (eff) eff[t * NJ + j] = legd[leg_field_index(feff + j, slot, n_slots)];
+    if (cmd) cmd[t * NJ + j] = q + offset[leg * NJ + j];
+  }
+}
+// range-sensor step plane (tipStatesCallback, state_controller.cpp:1657-1672): the surface lies `z` along the tip's x axis
+template <int L, int NJ>
+__global__ void step_plane_range_kernel(DevState st, const SharedConsts<L, NJ> *gc, const double *step_plane /*[n][L][3]*/) {
+  using FD = Fields<NJ>;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= st.n_robots * L) return;
+  const int64_t rob = t / L;
+  const int leg = int(t - rob * L);
+  const int64_t slot = slot_of(rob, leg, L);
+  auto f = [&](int field) -> double & { return st.legd[leg_field_index(field, slot, st.n_slots)]; };
+  const double z = step_plane[t * 3 + 2];
+  if (z != kUnassigned) {
+    double q[NJ];
+    for (int j = 0; j < NJ; ++j) q[j] = f(FD::Q + j);
+    Chain<NJ> ch;
+    fk_chain<NJ>(gc->leg[leg], q, ch);
+    const V3 p = tip_robot_frame(gc->leg[leg], ch.pe) + base_rotate(gc->leg[leg], ch.xe) * z; // Tip::getPoseRobotFrame(Pose((z, 0, 0), ..))
+    f(FD::STEP_PLANE) = p.x, f(FD::STEP_PLANE + 1) = p.y, f(FD::STEP_PLANE + 2) = p.z, f(FD::STEP_PLANE + 3) = 1.0;
+  } else {
+    f(FD::STEP_PLANE + 3) = 0.0; // lost contact with the range sensor: Pose::Undefined()
+  }
+}
+
+static int upload_offsets(shc_engine *e, const double **d_off) {
+  std::vector<double> off(size_t(e->L) * e->NJ);
+  for (int l = 0; l < e->L; ++l)
+    for (int j = 0; j < e->NJ; ++j) off[size_t(l) * e->NJ + j] = e->params.joint[l][j].offset;
+  // the tail of the staging buffer (the scatter / gather helpers use its head)
+  double *dst = e->d_stage + (e->stage_bytes / 8 - off.size());
+  HIP_TRY(hipMemcpyAsync(dst, off.data(), off.size() * 8, hipMemcpyHostToDevice, e->stream));
+  *d_off = dst;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_set_joint_states_msg(shc_engine *e, const double *position, const double * /*velocity*/, const double *effort, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = SHC_OK;
+  if (position) {
+    const double *d_off, *d;
+    if ((rc = upload_offsets(e, &d_off)) != SHC_OK) return rc;
+    if ((rc = to_device(e, position, size_t(e->n) * e->L * e->NJ, on_device, &d)) != SHC_OK) return rc;
+    const int64_t threads = e->n * e->L;
+    store_measured_q_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(d, e->st.legd, e->n_slots, e->n, e->L, e->NJ,
+                                                                                              LEG_FIELD(e, MEAS_Q), d_off);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  if (effort) rc = shc_engine_set_joint_effort(e, effort, on_device);
+  return rc;
+}
+
+extern "C" int shc_engine_set_tip_states_msg(shc_engine *e, const double *wrench_force, const double *step_plane, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc = SHC_OK;
+  if (wrench_force && (rc = shc_engine_set_tip_force(e, wrench_force, on_device)) != SHC_OK) return rc;
+  if (step_plane) {
+    HIP_TRY(hipSetDevice(e->device));
+    e->rt_flags |= RT_TOUCHDOWN; // setTouchdownDetection(true) (:1655)
+    const double *d;
+    if ((rc = to_device(e, step_plane, size_t(e->n) * e->L * 3, on_device, &d)) != SHC_OK) return rc;
+    const int64_t threads = e->n * e->L;
+#define CALL(L_, NJ_) \
+  step_plane_range_kernel<L_, NJ_><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, d)
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+    HIP_TRY(hipGetLastError());
+    if (!on_device) HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return rc;
+}
+
+extern "C" int shc_engine_get_joint_commands(shc_engine *e, double *position, double *velocity, double *effort, double *position_command, int on_device) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  const double *d_off;
+  int rc = upload_offsets(e, &d_off);
+  if (rc != SHC_OK) return rc;
+  const size_t rows = size_t(e->n) * e->L * e->NJ;
+  double *out[4] = {position, velocity, effort, position_command}, *dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<void *> temps;
+  auto release = [&]() {
+    for (void *t : temps) (void)hipFree(t);
+  };
+  for (int k = 0; k < 4; ++k) {
+    if (!out[k]) continue;
+    if (on_device) {
+      dev[k] = out[k];
+      continue;
+    }
+    void *t = nullptr;
+    HIP_TRY_OR(hipMalloc(&t, rows * 8), release());
+    temps.push_back(t);
+    dev[k] = static_cast<double *>(t);
+  }
+  const int64_t threads = e->n * e->L;
+  joint_commands_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(dev[0], dev[1], dev[2], dev[3], e->st.legd, e->n_slots, e->n,
+                                                                                           e->L, e->NJ, LEG_FIELD(e, Q), LEG_FIELD(e, QD),
+                                                                                           LEG_FIELD(e, EFFORT_IN), d_off);
+  HIP_TRY_OR(hipGetLastError(), release());
+  if (!on_device)
+    for (int k = 0; k < 4; ++k)
+      if (out[k]) HIP_TRY_OR(hipMemcpyAsync(out[k], dev[k], rows * 8, hipMemcpyDeviceToHost, e->stream), release());
+  HIP_TRY_OR(hipStreamSynchronize(e->stream), release());
+  release();
   return SHC_OK;
 }
 

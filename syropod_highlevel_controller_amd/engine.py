@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_change_gait", "shc_stream_create", "shc_stream_destroy", "shc_engine_read_leg_state_msg",
     "shc_generate_tables_batch", "shc_engine_create_with_tables",
     "shc_sizeof_instance_state", "shc_engine_get_state", "shc_engine_set_state",
+    "shc_engine_set_joint_states_msg", "shc_engine_set_tip_states_msg", "shc_engine_get_joint_commands",
     "shc_leg_set_desired_tip_pose", "shc_leg_solve_ik", "shc_leg_update_joint_positions", "shc_leg_apply_ik", "shc_leg_apply_fk",
     "shc_leg_step_to_position", "shc_leg_transition_configuration", "shc_engine_begin_direct_startup", "shc_engine_direct_startup",
     "shc_fleet_create", "shc_fleet_destroy", "shc_fleet_instances", "shc_fleet_shape", "shc_fleet_part_count", "shc_fleet_part",
@@ -132,6 +133,9 @@ def lib():
         L.shc_engine_change_gait.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
         L.shc_engine_get_virtual_stiffness.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.shc_sizeof_instance_state.restype = C.c_int64
+        L.shc_engine_set_joint_states_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_set_tip_states_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_get_joint_commands.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int]
         sel = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
         L.shc_leg_set_desired_tip_pose.argtypes = sel + [C.c_void_p, C.c_int, C.c_int]
         L.shc_leg_solve_ik.argtypes = sel + [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
@@ -377,6 +381,21 @@ class BatchEngine:
         a = _host(joint_position)
         out = np.zeros((rows, 7))
         _check(self.L.shc_leg_apply_fk(self.h, first, count, leg, _p(a), _p(out), 0), "leg_apply_fk")
+        return out
+
+    # -- ROS message payloads
+    def set_joint_states_msg(self, position=None, velocity=None, effort=None):
+        a, b, c = _host(position), _host(velocity), _host(effort)
+        _check(self.L.shc_engine_set_joint_states_msg(self.h, _p(a), _p(b), _p(c), 0), "set_joint_states_msg")
+
+    def set_tip_states_msg(self, wrench_force=None, step_plane=None):
+        a, b = _host(wrench_force), _host(step_plane)
+        _check(self.L.shc_engine_set_tip_states_msg(self.h, _p(a), _p(b), 0), "set_tip_states_msg")
+
+    def joint_commands(self):
+        """(position, velocity, effort, position_command) of publishDesiredJointState, each [n][legs * dof]."""
+        out = [np.zeros((self.n, self.legs * self.dof)) for _ in range(4)]
+        _check(self.L.shc_engine_get_joint_commands(self.h, *[_p(o) for o in out], 0), "get_joint_commands")
         return out
 
     # -- sequences

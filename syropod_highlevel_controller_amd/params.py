@@ -33,7 +33,7 @@ class LegStateMsg(C.Structure):
     """shc_leg_state_msg of include/shc_batch.h (numeric payload of LegState.msg)."""
     _fields_ = [("walker_tip_position", C.c_double * 3), ("target_tip_position", C.c_double * 3),
                 ("poser_tip_position", C.c_double * 3), ("model_tip_position", C.c_double * 3),
-                ("model_tip_velocity", C.c_double * 3), ("joint_positions", C.c_double * SHC_MAX_JOINTS), ("joint_velocities", C.c_double * SHC_MAX_JOINTS),
+                ("actual_tip_pose", C.c_double * 7), ("model_tip_velocity", C.c_double * 3), ("joint_positions", C.c_double * SHC_MAX_JOINTS), ("joint_velocities", C.c_double * SHC_MAX_JOINTS),
                 ("joint_efforts", C.c_double * SHC_MAX_JOINTS), ("stance_progress", C.c_double), ("swing_progress", C.c_double),
                 ("time_to_swing_end", C.c_double), ("pose_delta", C.c_double * 7), ("auto_pose", C.c_double * 7), ("tip_force", C.c_double * 3),
                 ("admittance_delta", C.c_double * 3), ("virtual_stiffness", C.c_double)]

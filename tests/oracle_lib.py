@@ -75,6 +75,9 @@ def lib():
         L.orc_batch_change_gait.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.orc_batch_change_gait.restype = C.c_int64
         L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
+        L.orc_set_joint_states_msg.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_set_step_plane.argtypes = [C.c_void_p, _dp]
+        L.orc_get_joint_commands.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
         L.orc_leg_set_desired_tip_pose.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
         L.orc_leg_solve_ik.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
         L.orc_leg_update_joint_positions.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
@@ -253,6 +256,26 @@ class OracleBatch:
         ws = np.zeros(self.n, dtype=np.int32)
         self.L.orc_batch_get_body_state(self.h, _ptr(pose), _ptr(vel), _ptr(ws, _ip))
         return pose, vel, ws
+
+    # ---- ROS message payloads
+    def set_joint_states_msg(self, position=None, velocity=None, effort=None):
+        a = [None if x is None else np.ascontiguousarray(x, dtype=np.float64).reshape(self.n, -1) for x in (position, velocity, effort)]
+        for i in range(self.n):
+            self.L.orc_set_joint_states_msg(self.L.orc_batch_robot(self.h, i), *[None if x is None else _ptr(x[i]) for x in a])
+
+    def set_tip_states_msg(self, wrench_force=None, step_plane=None):
+        if wrench_force is not None:
+            self.set_tip_force(wrench_force)
+        if step_plane is not None:
+            sp = np.ascontiguousarray(step_plane, dtype=np.float64).reshape(self.n, -1)
+            for i in range(self.n):
+                self.L.orc_set_step_plane(self.L.orc_batch_robot(self.h, i), _ptr(sp[i]))
+
+    def joint_commands(self):
+        out = [np.zeros((self.n, self.dof)) for _ in range(4)]
+        for i in range(self.n):
+            self.L.orc_get_joint_commands(self.L.orc_batch_robot(self.h, i), *[_ptr(o[i]) for o in out])
+        return out
 
     # ---- per-leg Leg methods, every (robot, leg) in instance-major order like the engine's shc_leg_* calls
     def _each(self):

@@ -822,11 +822,17 @@ def test_leg_state_message_payload(Engine):
     apply(eng, inp)
     apply(ob, inp)
     done = 0
+    rng = np.random.default_rng(84)
     for k in (1, 1, 37, 80, 33):
         eng.step(k)
         eng.synchronize()
         ob.step(k, 8)
         done += k
+        if done > 2:  # jointStatesCallback: raw motor positions (offset still in) and efforts -> actual_tip_pose, joint_efforts
+            raw = eng.joints()[0] + rng.normal(0, 0.02, (n, 18)) + 0.1
+            eff = rng.normal(0, 0.5, (n, 18))
+            for o in (eng, ob):
+                o.set_joint_states_msg(raw, None, eff)
         for i in (0, 7, n - 1):
             for g, o in zip(eng.leg_state_msg(i), ob.leg_state_msg(i)):
                 for name, _ in g._fields_:
@@ -835,6 +841,71 @@ def test_leg_state_message_payload(Engine):
                         assert np.array_equal(a, b), name   # functions of the integer phase only
                     else:
                         np.testing.assert_allclose(a, b, rtol=0, atol=1e-8, err_msg=f"{name} cycle {done} instance {i}")
+
+
+@pytest.mark.parametrize("own_clock", [False, True])
+def test_leg_state_message_auto_pose(Engine, own_clock):
+    """LegState.auto_pose with auto posing on (state_controller.cpp:877-880): the per-leg pose of the last cycle, negation
+    included, re-derived by shc_engine_read_leg_state_msg from the stored poser latches and master phase."""
+    p = default_hexapod_params("tripod")
+    p.auto_posing = 1
+    for l in range(6):
+        p.negation_transition_ratio[l] = 0.25
+    for i in range(p.n_auto_posers):
+        p.x_amplitudes[i], p.yaw_amplitudes[i] = 0.004 * (-1) ** i, 0.01
+        if i % 2:
+            p.gravity_amplitudes[i] = 0.008
+    if own_clock:
+        p.pose_frequency = 0.8
+        base = p.pose_phase_length
+        k = int((1.0 / p.pose_frequency) / p.time_delta / base)
+        length = (k if k % 2 == 0 else k + 1) * base
+        p.time_to_start = ((299 // length) * length + 1) * p.time_delta
+    n = 16
+    inp = make_inputs(p, n, 85, imu=True, zero_every=5)
+    eng, ob = Engine(p, n), OracleBatch(p, n)
+    apply(eng, inp)
+    apply(ob, inp)
+    seen = 0.0
+    for k in (1, 1, 30, 17, 23, 41, 60, 9):
+        eng.step(k)
+        eng.synchronize()
+        ob.step(k, 8)
+        for i in (0, 3, n - 1):
+            for g, o in zip(eng.leg_state_msg(i), ob.leg_state_msg(i)):
+                np.testing.assert_allclose(np.array(g.auto_pose), np.array(o.auto_pose), rtol=0, atol=1e-12)
+                seen = max(seen, np.abs(np.array(o.auto_pose)[:3]).max())
+    assert seen > 1e-3
+
+
+def test_joint_command_and_tip_state_messages(Engine):
+    """publishDesiredJointState's payload (positions, velocities, efforts, per-joint commands with Joint::offset_) and the
+    range-sensor half of tipStatesCallback (step_plane values -> Leg::step_plane_pose_)."""
+    p = default_hexapod_params("tripod")
+    p.rough_terrain_mode = 1
+    for l in range(6):
+        for j in range(3):
+            p.joint[l][j].offset = 0.01 * (l + 1) - 0.02 * j
+    n = 20
+    inp = make_inputs(p, n, 87)
+    eng, ob = Engine(p, n), OracleBatch(p, n)
+    apply(eng, inp)
+    apply(ob, inp)
+    rng = np.random.default_rng(88)
+    for k in range(12):
+        sp = np.stack([rng.normal(0, 0.1, (n, 6)), rng.normal(0, 0.1, (n, 6)), rng.uniform(0.0, 0.03, (n, 6))], axis=2)
+        sp[rng.random((n, 6)) < 0.3, 2] = 2147483647.0  # sensor lost contact
+        for o in (eng, ob):
+            o.set_tip_states_msg(None, sp)
+        eng.step(11)
+        eng.synchronize()
+        ob.step(11, 8)
+        for a, b in zip(eng.joint_commands(), ob.joint_commands()):
+            np.testing.assert_allclose(a, b, rtol=0, atol=1e-9)
+    pos, _, eff, cmd = eng.joint_commands()
+    off = np.array([[p.joint[l][j].offset for j in range(3)] for l in range(6)]).reshape(-1)
+    np.testing.assert_allclose(cmd - pos, np.tile(off, (n, 1)), atol=1e-15)
+    np.testing.assert_allclose(eff, inp["effort"], atol=0)
 
 
 def test_init_chain_on_device_matches_the_oracle():
