@@ -140,3 +140,59 @@ def test_step_cycle_known_answers(gait):
     assert sc.stance_period % 2 == 0 and sc.swing_period % 2 == 0      # ROS_ASSERTs at walk_controller.cpp:392-393
     r = OracleRobot(p)
     assert list(r.tables().phase_offset)[:6] == k["phase_offset"]
+
+
+# ------------------------------------------------------------------------------------------------ multi-cycle trajectories
+def _walk_scenarios():
+    import json
+    import os
+    meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "walk_golden_meta.json")))
+    return sorted(meta.items())
+
+
+@pytest.mark.parametrize("name,meta", _walk_scenarios(), ids=[n for n, _ in _walk_scenarios()])
+def test_walk_trajectories(name, meta):
+    """Hundreds of cycles of walking from an INDEPENDENT numpy restatement of WalkController::updateWalk / getLimit / LegStepper
+    / updateWalkPlane and PoseController's walk-plane, auto and IMU poses (tests/golden/make_walk_golden.py, written from the
+    reference sources alone): velocity limiting, every walk-state transition, first-step handling of legs that start mid swing,
+    swing / stance Bezier tips, default-tip updates on stopping, auto-poser latches, the IMU PID.  The oracle must reproduce the
+    walker tips to 1e-9 m, the body pose to 1e-9 and every integer exactly."""
+    import os
+    from oracle_lib import OracleRobot
+    from syropod_highlevel_controller_amd import default_hexapod_params
+    from syropod_highlevel_controller_amd.params import VEL_REAL
+    data = np.load(os.path.join(os.path.dirname(__file__), "golden", "walk_golden.npz"))
+    g = {k.split("/", 1)[1]: data[k] for k in data.files if k.startswith(name + "/")}
+    p = default_hexapod_params(meta["gait"])
+    for k, v in meta["overrides"].items():
+        if k == "velocity_input_mode":
+            p.velocity_input_mode = VEL_REAL if v == "real" else 0
+        elif k == "n_auto_posers":
+            pass  # (default_hexapod_params already carries auto_pose.yaml)
+        else:
+            setattr(p, k, v)
+    if p.imu_posing:
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    r = OracleRobot(p)
+    t = r.tables()
+    for k, table in meta["limits"].items():  # the fixture's limit tables are the ones this oracle derives too
+        np.testing.assert_allclose(list(getattr(t, k)), table, rtol=1e-9)
+    worst_tip = worst_pose = 0.0
+    for c in range(meta["cycles"]):
+        r.set_velocity(float(g["lin"][c][0]), float(g["lin"][c][1]), float(g["ang"][c]))
+        if p.imu_posing:
+            r.set_imu(g["imu_q"][c], g["gyro"][c])
+        r.cycle(1)
+        ls = r.leg_state()
+        pose, vel, ws = r.body_state()
+        assert ws == g["walk_state"][c], (name, c)
+        assert np.array_equal(ls["leg_status"] & 3, g["state"][c]), (name, c)
+        assert np.array_equal(ls["leg_status"] >> 8, g["phase"][c]), (name, c)
+        np.testing.assert_allclose(vel, g["velocity"][c], atol=1e-12, err_msg=f"{name} cycle {c}")
+        worst_tip = max(worst_tip, np.abs(ls["walker_tip"] - g["tips"][c]).max())
+        q = np.array(pose)
+        if q[3] < 0:
+            q[3:] = -q[3:]
+        worst_pose = max(worst_pose, np.abs(q - g["pose"][c]).max())
+        assert worst_tip < 1e-9 and worst_pose < 1e-9, (name, c, worst_tip, worst_pose)
+    print(f"{name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, max |pose diff| {worst_pose:.2e}")
