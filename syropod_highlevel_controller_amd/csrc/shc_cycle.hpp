@@ -884,12 +884,12 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     if (stepping && !(SHC_DBG(P) & 4)) {
       // updateStride (:921-945)
       V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0}; // v + w z^ x (tip rejected from z^)
-      s.strd = sv * P.stride_scale;
+      s.strd = scaled(sv, P.stride_scale);
       V3 pn = rb.get3(R::PNORM);
       // normalized() of the exact unit vector (0,0,1) is itself: skip the sqrt + 3 divisions on flat ground (bit-identical)
       bool flat_n = pn.x == 0.0 && pn.y == 0.0 && pn.z == 1.0;
       if (!__all(flat_n)) pn = normalized(pn);
-      V3 clearance = pn * P.swing_height;
+      V3 clearance = scaled(pn, P.swing_height);
       V3 dpos;
       if (my_state == SS_SWING) {
         int iteration = my_phase - P.swing_start + 1;
@@ -925,34 +925,34 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         V3 mid{(sorg.x + s.targ.x) / 2.0, (sorg.y + s.targ.y) / 2.0, fmax(sorg.z, s.targ.z)};
         mid = mid + clearance;
         mid.y += (lc.stance_y > 0.0) ? P.swing_width : -P.swing_width;
-        V3 sep1 = (svel * 0.25) * P.dt_over_swing_dt;
-        V3 n1_0 = sorg, n1_1 = sorg + sep1, n1_2 = sorg + sep1 * 2.0;
+        V3 sep1 = scaled(svel * 0.25, P.dt_over_swing_dt);
+        V3 n1_0 = sorg, n1_1 = sorg + sep1, n1_2 = sorg + scaled(sep1, 2.0);
         V3 n1_3{(mid.x + n1_2.x) / 2.0, (mid.y + n1_2.y) / 2.0, mid.z};
         V3 n1_4 = mid;
         // generateSecondarySwingControlNodes (:1265-1291)
-        V3 fv = (-s.strd) * (stance_dt * P.inv_dt);
-        V3 sep2 = (fv * 0.25) * P.dt_over_swing_dt;
-        V3 n2_0 = n1_4, n2_1 = n1_4 - (n1_3 - n1_4), n2_2 = s.targ - sep2 * 2.0, n2_3 = s.targ - sep2, n2_4 = s.targ;
+        V3 fv = scaled(-s.strd, stance_dt * P.inv_dt);
+        V3 sep2 = scaled(fv * 0.25, P.dt_over_swing_dt);
+        V3 n2_0 = n1_4, n2_1 = n1_4 - (n1_3 - n1_4), n2_2 = s.targ - scaled(sep2, 2.0), n2_3 = s.targ - sep2, n2_4 = s.targ;
         if (rough && ground_contact && !first_half) { // ground contact in the second half: stance-like nodes from the current tip (:1286-1290)
-          n2_0 = s.tip, n2_1 = s.tip + sep2, n2_2 = s.tip + sep2 * 2.0, n2_3 = s.tip + sep2 * 3.0, n2_4 = s.tip + sep2 * 4.0;
+          n2_0 = s.tip, n2_1 = s.tip + sep2, n2_2 = s.tip + scaled(sep2, 2.0), n2_3 = s.tip + scaled(sep2, 3.0), n2_4 = s.tip + scaled(sep2, 4.0);
         }
         if (uni(P.force_normal_touchdown) && !(rough && ground_contact)) { // forceNormalTouchdown (:1314-1329), unless in ground contact (:1114)
-          V3 bo = s.targ - sep2 * 4.0;
+          V3 bo = s.targ - scaled(sep2, 4.0);
           bo.z = fmax(sorg.z, s.targ.z);
           bo = bo + clearance;
           n1_4 = bo;
           n2_0 = bo;
-          n2_2 = s.targ - sep2 * 2.0;
-          V3 half = (n2_2 - bo) * 0.5;
+          n2_2 = s.targ - scaled(sep2, 2.0);
+          V3 half = scaled(n2_2 - bo, 0.5);
           n1_3 = n2_0 - half;
           n2_1 = n2_0 + half;
         }
         if (first_half) {
           double t = P.swing_delta_t * iteration;
-          dpos = quartic_bezier_dot(n1_0, n1_1, n1_2, n1_3, n1_4, t) * P.swing_delta_t;
+          dpos = scaled(quartic_bezier_dot(n1_0, n1_1, n1_2, n1_3, n1_4, t), P.swing_delta_t);
         } else {
           double t = P.swing_delta_t * (iteration - P.swing_iterations / 2);
-          dpos = quartic_bezier_dot(n2_0, n2_1, n2_2, n2_3, n2_4, t) * P.swing_delta_t;
+          dpos = scaled(quartic_bezier_dot(n2_0, n2_1, n2_2, n2_3, n2_4, t), P.swing_delta_t);
         }
       } else { // STANCE / FORCE_STANCE
         int iteration = my_phase + (P.period - mss); // both terms lie in [0, period]: one conditional subtract is the modulo
@@ -969,10 +969,10 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         }
         double stride_scaler = standard ? 1.0 : lc.first_stride_scaler; // modified / standard stance period (:1167)
         (void)msp;
-        V3 sep = ((-s.strd) * stride_scaler) * 0.25;
+        V3 sep = scaled((-s.strd) * stride_scaler, 0.25);
         double t = iteration * stance_dt;
         // five collinear equispaced nodes (:1295-1310)
-        dpos = quartic_bezier_dot(torg, torg + sep, torg + sep * 2.0, torg + sep * 3.0, torg + sep * 4.0, t) * stance_dt;
+        dpos = scaled(quartic_bezier_dot(torg, torg + sep, torg + scaled(sep, 2.0), torg + scaled(sep, 3.0), torg + scaled(sep, 4.0), t), stance_dt);
       }
       s.tip = s.tip + dpos;
       s.tvel = dpos * P.inv_dt; // delta_pos / time_delta (:1135, :1176)

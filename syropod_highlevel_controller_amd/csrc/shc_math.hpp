@@ -45,6 +45,13 @@ SHC_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 SHC_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 SHC_HD V3 operator*(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
 SHC_HD V3 operator*(double s, V3 a) { return V3{a.x * s, a.y * s, a.z * s}; }
+// a * s rounded on its own: never contracted into a neighbouring addition (HIP honours the pragma under its default
+// -ffp-contract=fast-honor-pragmas).  Used where the compiler's choice of what to fuse would otherwise depend on the surrounding
+// code, i.e. differ between two instantiations of the same template (LegStepper control nodes).
+SHC_HD V3 scaled(V3 a, double s) {
+#pragma clang fp contract(off)
+  return V3{a.x * s, a.y * s, a.z * s};
+}
 SHC_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 SHC_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 SHC_HD double norm(V3 a) { return sqrt(dot(a, a)); }
@@ -304,10 +311,16 @@ SHC_HD V3 quartic_bezier(const V3 *p, double t) {
   double b0 = s * s * s * s, b1 = 4.0 * t * s * s * s, b2 = 6.0 * t * t * s * s, b3 = 4.0 * t * t * t * s, b4 = t * t * t * t;
   return p[0] * b0 + p[1] * b1 + p[2] * b2 + p[3] * b3 + p[4] * b4;
 }
+// The four-term sum is written as an explicit fma chain: with the compiler left to contract `a*b + c*d + ...` on its own, the
+// choice of which product is rounded depends on the surrounding code, and two instantiations of the cycle kernel (compile-time
+// and runtime feature flags) would differ in the last bit of the tip velocity.
+SHC_HD V3 fma3(V3 a, double s, V3 c) { return V3{fma(a.x, s, c.x), fma(a.y, s, c.y), fma(a.z, s, c.z)}; }
 SHC_HD V3 quartic_bezier_dot(V3 p0, V3 p1, V3 p2, V3 p3, V3 p4, double t) {
   double s = 1.0 - t;
-  return (p1 - p0) * (4.0 * s * s * s) + (p2 - p1) * (12.0 * s * s * t) + (p3 - p2) * (12.0 * s * t * t) +
-         (p4 - p3) * (4.0 * t * t * t);
+  V3 r = (p1 - p0) * (4.0 * s * s * s);
+  r = fma3(p2 - p1, 12.0 * s * s * t, r);
+  r = fma3(p3 - p2, 12.0 * s * t * t, r);
+  return fma3(p4 - p3, 4.0 * t * t * t, r);
 }
 
 // ---------------------------------------------------------------- small SPD solve  A x = b,  A = A^T > 0  (N <= 6)

@@ -618,19 +618,32 @@ def test_fused_launch_is_bit_identical_to_single_cycle_launches(Engine):
         assert np.array_equal(x, y)
 
 
-def test_generic_kernel_is_bit_identical_to_specialised(Engine):
-    p = default_hexapod_params("wave")
-    p.admittance_control, p.imu_posing = 1, 1
-    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
-    inp = make_inputs(p, 33, 37, imu=True, force=2.0)
-    a, b = Engine(p, 33), Engine(p, 33)
+@pytest.mark.parametrize("config", ["config2", "config3", "config4"])
+def test_generic_kernel_is_bit_identical_to_specialised(Engine, config):
+    """The compile-time specialisations (BASELINE.json configs 2-4) and the runtime-flag kernel execute the same arithmetic: the
+    full state record of every instance is byte-identical after a free run (the products the compiler could contract either
+    way are pinned in the source, shc_math.hpp::scaled / fma3)."""
+    kw = {}
+    if config == "config2":
+        p, n, cycles = default_hexapod_params("tripod"), 40, 260
+    elif config == "config3":
+        p, n, cycles = default_hexapod_params("wave"), 33, 420
+        p.admittance_control, p.imu_posing = 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+        kw = dict(imu=True, force=20.0)
+    else:
+        p, n, cycles = synthetic_octopod_params("ripple"), 24, 260
+    inp = make_inputs(p, n, 37, **kw)
+    a, b = Engine(p, n), Engine(p, n)
+    b.set_features(FEAT_DEFAULT | FEAT_GENERIC_KERNEL)
     apply(a, inp)
     apply(b, inp)
-    a.step(150)
-    a.synchronize()
-    b.set_features(FEAT_DEFAULT | FEAT_GENERIC_KERNEL)
-    b.step(150)
-    b.synchronize()
+    for chunk in (1, cycles // 2, cycles - cycles // 2 - 1):
+        a.step(chunk)
+        b.step(chunk)
+        a.synchronize()
+        b.synchronize()
+        assert bytes(a.get_state()) == bytes(b.get_state())
     for x, y in zip(snapshot(a), snapshot(b)):
         assert np.array_equal(x, y)
 
@@ -911,11 +924,12 @@ def test_joint_command_and_tip_state_messages(Engine):
 def test_init_chain_on_device_matches_the_oracle():
     """shc_generate_tables_batch (start-up solve + workspace search + walkspace + limits as HIP kernels, one thread per
     (morphology, leg, bearing)) against the ORACLE's init chain for perturbed morphologies.  Integers are exact; workspace
-    radii, walkspace and limits agree to 1e-8 wherever the start-up configuration does.  The start-up joint configuration is the state of the reference's DLS iteration
-    after time_to_start / time_delta steps, which amplifies rounding differences by ~1.1x per step
-    (tests/test_oracle_conditioning.py): at 200 steps the device chain (FMA contraction, its own sin / cos) is within 1e-9 rad of
-    the oracle for every morphology, at the default 300 steps within 1e-5 with a median below 1e-7 - what the oracle's own
-    fast-math build shows against itself.  A rejected parameter set is reported per morphology."""
+    radii, walkspace and limits agree to 1e-5.  The start-up joint configuration is the state of the reference's DLS iteration
+    after time_to_start / time_delta steps, which amplifies rounding differences by ~1.1x per step and, for chains with more
+    than three joints, drifts along the null space (tests/test_oracle_conditioning.py): the yardstick for every morphology is
+    how far the oracle's own fast-math build ends from the oracle (x20, floor 1e-9 rad) - 1e-14...1e-12 rad for 3-joint legs at
+    200 steps, 1e-9...1e-6 at the default 300, up to the chatter amplitude (mrad) for an occasional 4-joint chain.  A rejected
+    parameter set is reported per morphology."""
     from syropod_highlevel_controller_amd import engine
     rng = np.random.default_rng(91)
     plist = []
@@ -939,7 +953,9 @@ def test_init_chain_on_device_matches_the_oracle():
     plist.append(bad)
     tables, status = engine.generate_tables_batch(plist)
     assert status[-1] != 0 and (status[:-1] == 0).all()
+    from test_oracle_conditioning import dq as dq_of, twin_tables
     err = {200: [], 300: []}
+    worst = 0.0
     for p, t in zip(plist[:-1], tables[:-1]):
         h = OracleRobot(p).tables()
         for name in ("period", "swing_period", "stance_period", "stance_end", "swing_start", "swing_end", "stance_start"):
@@ -948,9 +964,12 @@ def test_init_chain_on_device_matches_the_oracle():
         assert list(t.phase_offset)[:L] == list(h.phase_offset)[:L]
         assert (t.pose_phase_length, t.pose_normaliser, t.auto_pose_reference_leg) == (h.pose_phase_length, h.pose_normaliser, h.auto_pose_reference_leg)
         dq = np.abs(np.array(t.default_joint_position)[:L, :D] - np.array(h.default_joint_position)[:L, :D]).max()
-        redundant = D == 5  # unconstrained 5-joint chains: the oracle's twin build is already 2e-8 away (test_host_tables_and_abi.py)
+        redundant = D > 3  # position-only IK of a 4- / 5-joint chain: a null space on top of the rounding amplification
         steps = round(p.time_to_start / p.time_delta)
         err[steps].append((dq, redundant))
+        bound = max(20 * dq_of(h, twin_tables(p), L, D), 1e-9)
+        worst = max(worst, dq / bound)
+        assert dq < bound, f"start-up configuration {dq:.2e} rad from the oracle, twin-build bound {bound:.2e}"
         # the workspace search is another several hundred DLS steps of the same ill-conditioned iteration (model.cpp:397-460), ending
         # where a step first fails: the device chain's radii (FMA contraction, its own sin / cos) are within a few micrometres of
         # the oracle's (the host chain, plain IEEE arithmetic like the oracle, within 1e-9: tests/test_host_tables_and_abi.py)
@@ -962,10 +981,10 @@ def test_init_chain_on_device_matches_the_oracle():
     e300 = np.array([d for d, r in err[300] if not r])
     red = np.array([d for k in err for d, r in err[k] if r])
     print(f"device init chain vs oracle, start-up configuration: 200 steps max {e200.max():.2e}, 300 steps median {np.median(e300):.2e} "
-          f"max {e300.max():.2e}, redundant 5-joint chains max {red.max():.2e} rad")
-    assert e200.max() < 1e-9
-    assert np.median(e300) < 1e-7 and e300.max() < 1e-5
-    assert red.max() < 1e-4
+          f"max {e300.max():.2e}, 4- / 5-joint chains median {np.median(red):.2e} max {red.max():.2e} rad; worst ratio to the twin-build bound {worst:.2f}")
+    assert e200.max() < 1e-9                                   # 3-joint legs, 200 steps: well-posed
+    assert np.median(e300) < 1e-7 and e300.max() < 1e-5        # default 300 steps
+    assert np.median(red) < 1e-5
 
 
 def test_every_device_pointer_entry_point(Engine):
@@ -1045,8 +1064,8 @@ def test_error_codes(Engine):
     h = C.c_void_p()
     assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED and b"DOF" in L.shc_last_error()
     bad = default_hexapod_params("tripod")
-    bad.gravity_aligned_tips = 1
-    assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED
+    bad.rough_terrain_mode, bad.stance_span_modifier = 1, 0.3   # default tips re-derived from the layered workspace: not accelerated
+    assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED and b"stance span" in L.shc_last_error()
     assert L.shc_engine_create(C.byref(p), 0, 0, None, C.byref(h)) == INVALID
     assert L.shc_engine_create(C.byref(p), 4, 99, None, C.byref(h)) == INVALID       # no such device
     t = engine.Tables()
