@@ -17,3 +17,20 @@ def pytest_configure(config):
 def shc_lib():
     from syropod_highlevel_controller_amd import engine
     return engine.lib()
+
+
+# Parity figures (max |dq|, well-posed fractions, ...) the GPU tests measured, printed after the run even with -q / captured
+# output so that the driver's log tail carries numbers, not only "passed".
+PARITY_REPORT = []
+
+
+def parity_report(line):
+    PARITY_REPORT.append(line)
+    print(line)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if PARITY_REPORT:
+        terminalreporter.section("parity report (HIP engine vs oracle)")
+        for line in PARITY_REPORT:
+            terminalreporter.write_line(line)

@@ -113,7 +113,7 @@ def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_pose
             inp2["force"] = inp["force"] * (1 + 1e-13)
         inp2["lin"] = inp["lin"] * (1 + 1e-13)
         apply(tw, inp2)
-    worst = 0.0
+    worst, frac = 0.0, 1.0
     for k in schedule:
         eng.step(k)
         eng.synchronize()
@@ -126,7 +126,12 @@ def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_pose
             well = np.abs(qo - qt).max(axis=1) <= 1e-9
             assert well.mean() >= min_well_posed, f"only {well.mean():.2f} of the reference trajectories are well-posed"
             mask = well
+            frac = min(frac, float(well.mean()))
         worst = max(worst, compare(eng, ob, tol_q, mask, ints=(mask is None)))
+    from conftest import parity_report
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    parity_report(f"[free-running {test}] {n} instances x {sum(schedule)} cycles: max |dq| = {worst:.2e} rad over "
+                  f"{'all instances' if tw is None else f'the {frac:.0%} of instances whose reference trajectory is well-posed'}")
     return eng, ob, worst
 
 
@@ -547,6 +552,9 @@ def test_soak_random_command_schedule(Engine, gait, seed):
             well_posed &= np.abs(ob.joints()[0] - tw.joints()[0]).max(axis=1) <= 1e-9
             compare(eng, ob, mask=well_posed)
             done += k
+    from conftest import parity_report
+    parity_report(f"[soak {os.environ.get('PYTEST_CURRENT_TEST', '').split('::')[-1].split(' ')[0]}] {n} instances x {total} cycles: "
+                  f"{well_posed.mean():.0%} of the reference trajectories well-posed to the end, all of them held to 1e-6 rad")
     assert well_posed.mean() >= (0.8 if total <= 1500 else 0.2)  # exclusion is sticky: long soaks lose more instances
 
 
@@ -980,7 +988,8 @@ def test_init_chain_on_device_matches_the_oracle():
     e200 = np.array([d for d, r in err[200] if not r])
     e300 = np.array([d for d, r in err[300] if not r])
     red = np.array([d for k in err for d, r in err[k] if r])
-    print(f"device init chain vs oracle, start-up configuration: 200 steps max {e200.max():.2e}, 300 steps median {np.median(e300):.2e} "
+    from conftest import parity_report
+    parity_report(f"device init chain vs oracle, start-up configuration: 200 steps max {e200.max():.2e}, 300 steps median {np.median(e300):.2e} "
           f"max {e300.max():.2e}, 4- / 5-joint chains median {np.median(red):.2e} max {red.max():.2e} rad; worst ratio to the twin-build bound {worst:.2f}")
     assert e200.max() < 1e-9                                   # 3-joint legs, 200 steps: well-posed
     assert np.median(e300) < 1e-7 and e300.max() < 1e-5        # default 300 steps

@@ -172,7 +172,8 @@ def teacher_forced(Engine, p, n, inp, cycles, schedule=None, features=FEAT_DEFAU
                   f"step states {o['leg']['step_state'][i, :L_]}, phases {o['leg']['phase'][i, :L_]}")
             raise
         visited.update(np.unique(o["walk_state"]).tolist())
-    print(f"[teacher-forced {label}] {n} instances x {cycles} cycles, all instances held: max |dq| = {worst:.3e} rad, "
+    from conftest import parity_report
+    parity_report(f"[teacher-forced {label}] {n} instances x {cycles} cycles, all instances held: max |dq| = {worst:.3e} rad, "
           f"walk states visited {sorted(visited)}")
     return eng, ob, worst
 
