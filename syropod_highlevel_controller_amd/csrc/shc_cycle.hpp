@@ -47,7 +47,8 @@ enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2 }; // RT_TOUCHDOWN: tip-s
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
-                  F_ROT = 1u << 30 }; // F_ROT (with F_DYN, > 3 DOF): gravity-aligned tips, rotation-constrained IK
+                  F_ROT = 1u << 30, // F_ROT (with F_DYN, > 3 DOF): gravity-aligned tips, rotation-constrained IK
+                  F_TERRAIN = 1u << 29 }; // F_TERRAIN (with F_DYN): rough terrain mode and the tip-align pose compiled in
 
 // Launch-uniform parameters (staged in LDS).
 struct CycleParams {
@@ -606,7 +607,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     }
     // ---- updateTipAlignPose (:1024-1088): the legs are visited in id order and each swinging leg overwrites the pose, reading the
     //      translation its predecessor left - re-simulated identically in every lane from L shuffled tip-to-joint vectors
-    if ((F & F_DYN) != 0 && NJ <= 3 && uni(P.tip_align)) {
+    if ((F & F_TERRAIN) != 0 && NJ <= 3 && uni(P.tip_align)) {
       Chain<NJ> ch0;
       chain_from_sincos<NJ>(lc, s.sn, s.cs, ch0); // the last applyFK: tip and last joint in the robot frame
       const V3 t2j_own = base_rotate(lc, ch0.p[NJ - 1] - ch0.pe);
@@ -869,7 +870,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     const V3 dflt = pk.get3(PK_DFLT);
     s.targ = dflt + s.strd * 0.5; // uses last cycle's stride (:1044 precedes updateStride)
     bool stepping = my_state != SS_FORCE_STOP;
-    const bool rough = (F & F_DYN) != 0 && uni(P.rough_terrain) != 0; // rough terrain mode runs on the generic kernel
+    const bool rough = (F & F_TERRAIN) != 0 && uni(P.rough_terrain) != 0; // rough terrain mode runs on the F_TERRAIN kernels
     bool rough_update_default = false;
     V3 model_tip_prev{0, 0, 0};
     if (rough) { // Leg::current_tip_pose_.position_ as the previous cycle's applyFK left it

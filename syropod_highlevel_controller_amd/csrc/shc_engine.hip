@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
     if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, gtile, lane);
-    if ((F & F_DYN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
+    if ((F & F_TERRAIN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
     // Leg::applyFK of the previous cycle: sin / cos of the stored joint angles
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
     if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, tile, lane);
-    if ((F & F_DYN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
+    if ((F & F_TERRAIN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it)
       if (it * 64 + lane < R::I_COUNT * RPW) tile_i[it * 64 + lane] = t_int[it];
@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
   store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
   if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::ODOM_END>(tile, gtile, lane);
-  if ((F & F_DYN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
+  if ((F & F_TERRAIN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
   static_assert((R::I_POSE_PHASE + 1) * RPW <= 64, "the written-back int fields (word, poser latches, pose phase) fit one wave-wide store");
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
   SHC_TICK(14);
@@ -1311,15 +1311,23 @@ static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cyc
   const CycleParams &c = e->cp;
   unsigned f = (c.manual_posing ? F_MANUAL : 0) | (c.auto_posing ? F_AUTO : 0) | (c.inclination_posing ? F_INCL : 0) |
                (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0) | (c.odometry ? F_ODOM : 0);
+  // rough terrain mode / the tip-align pose: generic kernels with that logic compiled in (kept out of the plain generic
+  // kernel, which would otherwise spill)
+  const bool terrain = c.rough_terrain || c.tip_align;
   if constexpr (NJ > 3) {
     if (c.gravity_aligned) { // gravity-aligned tips: the generic kernel with the tip-rotation logic compiled in
-      launch_cycle<L, NJ, F_DYN | F_ROT>(e, grid, block, n_cycles);
+      if (terrain) launch_cycle<L, NJ, F_DYN | F_ROT | F_TERRAIN>(e, grid, block, n_cycles);
+      else launch_cycle<L, NJ, F_DYN | F_ROT>(e, grid, block, n_cycles);
       return;
     }
   }
+  if (terrain) {
+    launch_cycle<L, NJ, F_DYN | F_TERRAIN>(e, grid, block, n_cycles);
+    return;
+  }
   if constexpr (SPEC) {
     constexpr unsigned C2 = F_MANUAL | F_ODOM, C3 = F_MANUAL | F_IMU | F_ADM | F_ODOM; // BASELINE.json configs 2/4 and 3
-    if (specialised && !c.rough_terrain && !c.tip_align) switch (f) {
+    if (specialised) switch (f) {
       case C2 | F_TIPF: launch_cycle<L, NJ, C2 | F_TIPF>(e, grid, block, n_cycles); return;
       case C2: launch_cycle<L, NJ, C2>(e, grid, block, n_cycles); return;
       case C3 | F_TIPF: launch_cycle<L, NJ, C3 | F_TIPF>(e, grid, block, n_cycles); return;
