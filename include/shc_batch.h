@@ -448,6 +448,36 @@ typedef struct shc_instance_state {
   shc_leg_snapshot leg[SHC_MAX_LEGS];
 } shc_instance_state;
 
+/*
+ * Externally requested tip targets / default stance poses of rough terrain mode: struct ExternalTarget (walk_controller.h:38-46)
+ * as targetTipPoseCallback (state_controller.cpp:1706-1767) fills it from syropod_highlevel_controller/TargetTipPose and
+ * generateExternalTargetTransforms (:703-773) refreshes its transform_ from the tf tree every loop.  While a leg swings, a
+ * defined target replaces the stepper's default target: target_tip_pose_ = pose_.removePose(transform_), the swing clearance
+ * takes the requested height, and a target given in the "odom_ideal" frame is led by the body's ideal odometry over the rest
+ * of the swing (walk_controller.cpp:1068-1079); the request is dropped at the start of the next stance period (:1159).  A
+ * defined default replaces the terrain-following default tip pose at every swing / stance start (:988-990) until another one
+ * arrives.  Only rough_terrain_mode reads either.  The tf lookup itself stays with the node.
+ */
+typedef struct shc_external_target {
+  double pose[7];          /* ExternalTarget::pose_ (x,y,z,qw,qx,qy,qz); an all-zero quaternion = UNDEFINED_ROTATION */
+  double transform[7];     /* ExternalTarget::transform_; the callback stores the identity (:1732), the tf refresh updates it */
+  double swing_clearance;  /* ExternalTarget::swing_clearance_ (0 for a default pose) */
+  int32_t frame_is_odom_ideal; /* frame_id_ == "odom_ideal" (:1073) */
+  int32_t defined;         /* ExternalTarget::defined_; 0 withdraws the request */
+} shc_external_target;
+enum { SHC_EXTERNAL_TARGET = 0, SHC_EXTERNAL_DEFAULT = 1 };
+/* LegStepper::setExternalTarget / setExternalDefault for legs `leg` (-1 = all, rows [count][legs]) of instances [first, first +
+ * count); rows is a HOST array.  As in the callback, a request reaches the stepper only while its robot is not STOPPED (a
+ * stopped robot hands targets to the planner-mode LegPoser, which is outside this engine): such rows are ignored and counted in
+ * *ignored (may be NULL).  The stepper keeps only the x axis of tip rotations (see shc_leg_snapshot), and legs with <= 3
+ * joints none at all: a defined target rotation on > 3-DOF legs is SHC_ERR_UNSUPPORTED. */
+int shc_engine_set_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, const shc_external_target *rows,
+                                   int64_t *ignored);
+/* generateExternalTargetTransforms: new transform_ rows (x,y,z,qw,qx,qy,qz) for requests that are currently defined. */
+int shc_engine_set_external_transform(shc_engine *e, int which, int64_t first, int64_t count, int leg, const double *transform);
+/* The requests as the steppers hold them now (defined_ cleared where a swing has consumed the target). */
+int shc_engine_get_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, shc_external_target *rows);
+
 int64_t shc_sizeof_instance_state(void);
 /* Instances [first, first + count) -> states[0 .. count) (host array).  Synchronises the engine's stream. */
 int shc_engine_get_state(shc_engine *e, int64_t first, int64_t count, shc_instance_state *states);

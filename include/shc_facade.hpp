@@ -164,6 +164,7 @@ struct Joint {
   double offset_ = 0.0;           // :798 (added when publishing the per-joint command)
 };
 
+class LegStepper;
 // class Leg (model.h:202): leg `id` of instance `index`.
 class Leg {
 public:
@@ -178,6 +179,7 @@ public:
     j.offset_ = eng_.params().joint[id_][joint_id - 1].offset;
     return j;
   }
+  LegStepper getLegStepper() const;                                         // model.h:288
   Vector3 getCurrentTipPosition() const { return v3(eng_.model_tip()); }    // Leg::getCurrentTipPose().position_ (model.h:304)
   Vector3 getDesiredTipPosition() const { return v3(eng_.poser_tip()); }    // LegPoser::getCurrentTipPose() (pose_controller.h:449)
   Vector3 getWalkerTipPosition() const { return v3(eng_.walker_tip()); }    // LegStepper::getCurrentTipPose() (walk_controller.h:389)
@@ -237,6 +239,57 @@ private:
   int64_t index_;
   int id_;
 };
+
+// struct ExternalTarget (walk_controller.h:38-46); frame_id_ is reduced to what the stepper asks of it (== "odom_ideal").
+struct ExternalTarget {
+  Pose pose_;
+  double swing_clearance_ = 0.0;
+  bool frame_is_odom_ideal_ = false;
+  Pose transform_ = Pose{{{0.0, 0.0, 0.0}}, {1.0, 0.0, 0.0, 0.0}};
+  bool defined_ = false;
+};
+
+// class LegStepper (walk_controller.h:304): the external target / default interface of leg `id` of instance `index`
+// (rough terrain mode; targetTipPoseCallback and generateExternalTargetTransforms, state_controller.cpp:1706-1767, :703-773).
+class LegStepper {
+public:
+  LegStepper(Engine &eng, int64_t index, int id) : eng_(eng), index_(index), id_(id) {}
+  void setExternalTarget(const ExternalTarget &t) { set(SHC_EXTERNAL_TARGET, t); }   // walk_controller.h:437
+  void setExternalDefault(const ExternalTarget &t) { set(SHC_EXTERNAL_DEFAULT, t); } // :441
+  ExternalTarget getExternalTarget() const { return get(SHC_EXTERNAL_TARGET); }      // :385
+  ExternalTarget getExternalDefault() const { return get(SHC_EXTERNAL_DEFAULT); }    // :389
+
+private:
+  static void pack(const Pose &p, double *o) {
+    o[0] = p.position_[0], o[1] = p.position_[1], o[2] = p.position_[2];
+    o[3] = p.rotation_.w, o[4] = p.rotation_.x, o[5] = p.rotation_.y, o[6] = p.rotation_.z;
+  }
+  void set(int which, const ExternalTarget &t) {
+    shc_external_target r{};
+    pack(t.pose_, r.pose);
+    pack(t.transform_, r.transform);
+    r.swing_clearance = t.swing_clearance_;
+    r.frame_is_odom_ideal = t.frame_is_odom_ideal_ ? 1 : 0;
+    r.defined = t.defined_ ? 1 : 0;
+    check(shc_engine_set_external_target(eng_.handle(), which, index_, 1, id_, &r, nullptr), "shc_engine_set_external_target");
+  }
+  ExternalTarget get(int which) const {
+    shc_external_target r{};
+    check(shc_engine_get_external_target(eng_.handle(), which, index_, 1, id_, &r), "shc_engine_get_external_target");
+    ExternalTarget t;
+    t.pose_ = Pose{{{r.pose[0], r.pose[1], r.pose[2]}}, {r.pose[3], r.pose[4], r.pose[5], r.pose[6]}};
+    t.transform_ = Pose{{{r.transform[0], r.transform[1], r.transform[2]}}, {r.transform[3], r.transform[4], r.transform[5], r.transform[6]}};
+    t.swing_clearance_ = r.swing_clearance;
+    t.frame_is_odom_ideal_ = r.frame_is_odom_ideal != 0;
+    t.defined_ = r.defined != 0;
+    return t;
+  }
+  Engine &eng_;
+  int64_t index_;
+  int id_;
+};
+
+inline LegStepper Leg::getLegStepper() const { return LegStepper(eng_, index_, id_); }
 
 // class Model (model.h:57)
 class Model {

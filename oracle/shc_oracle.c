@@ -67,6 +67,7 @@ typedef struct
   orc_v3 current_tip_velocity;
   orc_v3 swing_origin_tip_position, swing_origin_tip_velocity, stance_origin_tip_position;
   int touchdown_detection; /* walk_controller.h:495, raised by tipStatesCallback */
+  shc_external_target external_target, external_default; /* struct ExternalTarget (walk_controller.h:38-46, :533-534) */
 } stepper_t;
 
 typedef struct
@@ -1020,10 +1021,23 @@ static orc_v3 stepper_calculate_stance_span_change(const orc_robot *r, const leg
   return orc_v3_make(0.0, radius * stance_span_modifier, 0.0);
 }
 
-/* LegStepper::updateDefaultTipPosition (walk_controller.cpp:984-1014), no external default */
+static orc_pose pose_from7(const double *v)
+{
+  orc_pose o;
+  o.p = orc_v3_make(v[0], v[1], v[2]);
+  o.r.w = v[3], o.r.x = v[4], o.r.y = v[5], o.r.z = v[6];
+  return o;
+}
+
+/* LegStepper::updateDefaultTipPosition (walk_controller.cpp:984-1014) */
 static void stepper_update_default_tip_position(const orc_robot *r, leg_t *leg)
 {
   stepper_t *s = &leg->stepper;
+  if (s->external_default.defined)
+  { /* new default from the external request, transformed by the robot's movement since the request (:988-990) */
+    s->default_tip_pose = orc_pose_remove(pose_from7(s->external_default.pose), pose_from7(s->external_default.transform));
+    return;
+  }
   orc_v3 identity_tip_position = s->identity_tip_pose.p;
   identity_tip_position = orc_v3_add(identity_tip_position, stepper_calculate_stance_span_change(r, leg));
   identity_tip_position = orc_pose_transform_vector(r->default_pose, identity_tip_position); /* leg_->getDefaultBodyPose() */
@@ -1127,7 +1141,18 @@ static void stepper_update_tip_position(const orc_robot *r, leg_t *leg)
       s->swing_origin_tip_velocity = s->current_tip_velocity;
       if (rough_terrain_mode) stepper_update_default_tip_position(r, leg);
     }
-    if (rough_terrain_mode && s->touchdown_detection)
+    if (rough_terrain_mode && s->external_target.defined)
+    { /* externally requested target, transformed by the movement since the request (:1068-1079) */
+      s->target_tip_pose = orc_pose_remove(pose_from7(s->external_target.pose), pose_from7(s->external_target.transform));
+      s->swing_clearance = orc_v3_scale(orc_v3_normalized(s->swing_clearance), s->external_target.swing_clearance);
+      if (s->external_target.frame_is_odom_ideal)
+      { /* lead to compensate for the moving target: WalkController::calculateOdometry(time_to_swing_end).position_ (:783-791) */
+        double time_to_swing_end = (swing_iterations - iteration) * time_delta;
+        orc_v3 desired_linear_velocity = orc_v3_make(r->desired_linear_velocity[0], r->desired_linear_velocity[1], 0);
+        s->target_tip_pose.p = orc_v3_sub(s->target_tip_pose.p, orc_v3_scale(desired_linear_velocity, time_to_swing_end));
+      }
+    }
+    else if (rough_terrain_mode && s->touchdown_detection)
     { /* update default target to meet the step surface proactively or reactively (:1081-1101) */
       orc_pose step_plane_pose = leg->step_plane_pose;
       if (orc_pose_ne(step_plane_pose, orc_pose_undefined()))
@@ -1169,6 +1194,7 @@ static void stepper_update_tip_position(const orc_robot *r, leg_t *leg)
     if (iteration == 1)
     {
       s->stance_origin_tip_position = s->current_tip_pose.p;
+      s->external_target.defined = 0; /* reset external target after every swing period (:1159) */
       if (r->params.rough_terrain_mode) stepper_update_default_tip_position(r, leg);
     }
     double stride_scaler = (double)modified_stance_period / (orc_mod(step->stance_end - step->stance_start, step->period));
@@ -2435,6 +2461,35 @@ void orc_set_joint_states_msg(orc_robot *r, const double *position, const double
 }
 
 /* tipStatesCallback, step_plane values of the tip range sensors (state_controller.cpp:1651-1672): [legs][3] */
+/* targetTipPoseCallback (state_controller.cpp:1706-1767): robot RUNNING; a target reaches the LegStepper only while the robot
+ * is not STOPPED (else the planner-mode LegPoser takes it, not restated), a default likewise (:1746).  Returns 1 if taken. */
+int orc_set_external_target(orc_robot *r, int which, int leg, const shc_external_target *t)
+{
+  stepper_t *s = &r->leg[leg].stepper;
+  if (!t->defined)
+  {
+    (which ? &s->external_default : &s->external_target)->defined = 0;
+    return 1;
+  }
+  if (r->walk_state == STOPPED) return 0;
+  *(which ? &s->external_default : &s->external_target) = *t;
+  return 1;
+}
+
+/* generateExternalTargetTransforms (state_controller.cpp:703-773): refreshed transform_ of a defined request */
+void orc_set_external_transform(orc_robot *r, int which, int leg, const double *transform)
+{
+  stepper_t *s = &r->leg[leg].stepper;
+  shc_external_target *t = which ? &s->external_default : &s->external_target;
+  if (t->defined) memcpy(t->transform, transform, sizeof t->transform);
+}
+
+void orc_get_external_target(const orc_robot *r, int which, int leg, shc_external_target *out)
+{
+  const stepper_t *s = &r->leg[leg].stepper;
+  *out = which ? s->external_default : s->external_target;
+}
+
 void orc_set_step_plane(orc_robot *r, const double *step_plane)
 {
   for (int l = 0; l < r->leg_count; ++l)

@@ -95,6 +95,9 @@ void orc_batch_get_state(orc_batch *b, shc_instance_state *states /* [n] */);
 void orc_batch_set_state(orc_batch *b, const shc_instance_state *states /* [n] */);
 
 void orc_set_joint_states_msg(orc_robot *r, const double *position, const double *velocity, const double *effort); /* :1566 */
+int orc_set_external_target(orc_robot *r, int which, int leg, const shc_external_target *t);   /* state_controller.cpp:1706 */
+void orc_set_external_transform(orc_robot *r, int which, int leg, const double *transform);   /* :703-773 */
+void orc_get_external_target(const orc_robot *r, int which, int leg, shc_external_target *out);
 void orc_set_step_plane(orc_robot *r, const double *step_plane /* [legs][3] */);                                   /* :1651 */
 void orc_get_joint_commands(const orc_robot *r, double *position, double *velocity, double *effort, double *position_command); /* :777 */
 

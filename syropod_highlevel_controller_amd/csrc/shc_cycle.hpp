@@ -43,7 +43,7 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // origins of the per-leg planes, which change once per step period).
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
-enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2 }; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
+enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4 }; // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
@@ -146,12 +146,21 @@ struct RobotFields {
   static constexpr int I_WORD = 0, I_APOSER = 1, I_POSE_PHASE = 2, I_RESET_MODE = 3, I_COUNT = 4;
 };
 
+// Externally requested tip targets / default poses of rough terrain mode (struct ExternalTarget, walk_controller.h:38-46), one
+// record per leg slot in its own lazily allocated plane array (DevState::ext, paired planes like legd): only engines that were
+// ever given a request carry it.  flags: bit 0 defined_, bit 1 frame_id_ == "odom_ideal".
+struct ExtFields {
+  static constexpr int T_POSE = 0, T_TRANSFORM = 7, T_CLEARANCE = 14, T_FLAGS = 15, // external_target_
+                       D_POSE = 16, D_TRANSFORM = 23, D_FLAGS = 30, COUNT = 32;     // external_default_
+};
+
 struct DevState {
   double *legd;
   int32_t *legi;
   double *robd;
   int32_t *robi;
   int64_t n_slots, n_rob_pad, n_robots;
+  double *ext; // ExtFields planes, nullptr until the first external request
 };
 
 #if defined(__HIPCC__)
@@ -272,6 +281,21 @@ struct Park {
   }
 };
 
+// LegStepper::updateDefaultTipPosition with external_default_.defined_ (walk_controller.cpp:988-990): the requested stance pose,
+// moved with the robot since the request (pose_.removePose(transform_), pose.h:178-184), replaces the terrain-following default.
+__device__ __forceinline__ V3 external_default(const double *ext, int64_t ns, uint32_t slot, V3 terrain_following) {
+  if (ext == nullptr) return terrain_following;
+  const double2 *X = reinterpret_cast<const double2 *>(ext);
+  if ((int(X[(ExtFields::D_FLAGS / 2) * ns + slot].x) & 1) == 0) return terrain_following;
+  double v[14];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const double2 d = X[(ExtFields::D_POSE / 2 + k) * ns + slot];
+    v[2 * k] = d.x, v[2 * k + 1] = d.y;
+  }
+  return V3{v[0], v[1], v[2]} + rotate(Quat{v[3], v[4], v[5], v[6]}, -V3{v[7], v[8], v[9]});
+}
+
 // Per-cycle outputs (LegState topic fields); only the last cycle of a launch is written to HBM.
 struct LegOut {
   V3 poser_tip, model_tip, adm_delta;
@@ -306,7 +330,7 @@ __device__ __forceinline__ int bearing_bracket(double y, double x) {
 template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                       const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
-                                      const bool manual_live, const bool touchdown_detection) {
+                                      const bool manual_live, const bool touchdown_detection, double *ext) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
@@ -855,7 +879,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
         Pose wpp = rb.getpose(R::WPP); // leg_->getDefaultBodyPose() == walk_plane_pose_
         V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y + lc.span_shift, 0.0}); // identity + stance span change
         V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM_PREV));
-        pk.put3(PK_DFLT, idp + proj);
+        pk.put3(PK_DFLT, external_default(ext, ns, slot, idp + proj));
         default_changed = true;
         dirty |= DIRTY_STANCE_ORG; // the default tip shares the stance-origin planes
       }
@@ -912,7 +936,30 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           const double2 sp01 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::STEP_PLANE / 2) * ns + slot];
           const double2 sp23 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::STEP_PLANE / 2 + 1) * ns + slot];
           ground_contact = sp23.y != 0.0; // leg_->getStepPlanePose() != Pose::Undefined() (:1110)
-          if (touchdown_detection) {
+          bool external = false;
+          if (ext != nullptr) { // externally requested target (:1068-1079): ExtFields record of this leg, see shc_engine.hip
+            const double2 *X = reinterpret_cast<const double2 *>(ext);
+            const double2 cf = X[(ExtFields::T_CLEARANCE / 2) * ns + slot];
+            const int flags = int(cf.y);
+            external = (flags & 1) != 0;
+            if (external) {
+              double v[14];
+#pragma unroll
+              for (int k = 0; k < 7; ++k) {
+                const double2 d = X[(ExtFields::T_POSE / 2 + k) * ns + slot];
+                v[2 * k] = d.x, v[2 * k + 1] = d.y;
+              }
+              // target_tip_pose_ = pose_.removePose(transform_): position = pose_.transformVector(-transform_.position_) (pose.h:178-184)
+              s.targ = V3{v[0], v[1], v[2]} + rotate(Quat{v[3], v[4], v[5], v[6]}, -V3{v[7], v[8], v[9]});
+              clearance = normalized(clearance) * cf.x;
+              if (flags & 2) { // "odom_ideal" frame: lead by calculateOdometry(time_to_swing_end).position_ (:1073-1078, :783-791)
+                const double time_to_swing_end = (P.swing_iterations - iteration) * P.dt;
+                s.targ = s.targ - V3{vx, vy, 0.0} * time_to_swing_end;
+              }
+            }
+          }
+          if (external) {
+          } else if (touchdown_detection) {
             if (ground_contact) {
               const V3 step_plane_position = V3{sp01.x, sp01.y, sp23.x} - model_tip_prev; // relative to Leg::current_tip_pose_ (last FK)
               const V3 difference = (s.tip + step_plane_position) - s.targ;
@@ -965,6 +1012,10 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           pk.put3(PK_TORG, torg);
           dirty |= DIRTY_STANCE_ORG;
           rough_update_default = rough; // :1160-1163
+          if (ext != nullptr) { // external_target_.defined_ = false (:1159)
+            double &flags = ext[((ExtFields::T_CLEARANCE / 2) * ns + slot) * 2 + 1];
+            flags = double(int(flags) & ~1);
+          }
         } else {
           torg = pk.get3(PK_TORG);
         }
@@ -982,7 +1033,8 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
           Pose wpp = rb.getpose(R::WPP);
           V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y, 0.0}); // (stance span modifier 0 in rough terrain mode)
           V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM));
-          pk.put3(PK_DFLT, idp + proj);
+          V3 new_default = external_default(ext, ns, slot, idp + proj);
+          pk.put3(PK_DFLT, new_default);
           default_changed = true;
           dirty |= DIRTY_STANCE_ORG;
         }

@@ -329,7 +329,8 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   LegOut out;
   SHC_TICK(1);
   unsigned dirty = 0;
-  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection);
+  double *const ext = ((F & F_TERRAIN) != 0 && (rt_flags & RT_EXTERNAL) != 0) ? st.ext : nullptr; // external targets (rough terrain mode)
+  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext);
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
@@ -1132,6 +1133,7 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->st.legi);
   (void)hipFree(e->st.robd);
   (void)hipFree(e->st.robi);
+  (void)hipFree(e->st.ext);
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
   delete e;
@@ -1762,6 +1764,149 @@ extern "C" int shc_engine_set_tip_states_msg(shc_engine *e, const double *wrench
     if (!on_device) HIP_TRY(hipStreamSynchronize(e->stream));
   }
   return rc;
+}
+
+// ---- externally requested tip targets / default poses (rough terrain mode; struct ExternalTarget, walk_controller.h:38-46)
+struct ExtRow { // shc_external_target as doubles (staged on the device)
+  double pose[7], transform[7], swing_clearance, flags /* bit 0 defined, bit 1 odom_ideal */;
+};
+__global__ void set_external_kernel(DevState st, int L, int64_t first, int64_t count, int leg_sel, int which, const ExtRow *rows, int transform_only,
+                                    unsigned long long *ignored) {
+  const int legs = leg_sel < 0 ? L : 1;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= count * legs) return;
+  const int64_t rob = first + t / legs;
+  const int leg = leg_sel < 0 ? int(t % legs) : leg_sel;
+  const int64_t slot = slot_of(rob, leg, L);
+  const int base = which ? ExtFields::D_POSE : ExtFields::T_POSE;
+  const int flags_at = which ? ExtFields::D_FLAGS : ExtFields::T_FLAGS;
+  auto f = [&](int field) -> double & { return st.ext[leg_field_index(field, slot, st.n_slots)]; };
+  const ExtRow &r = rows[t];
+  if (transform_only) { // generateExternalTargetTransforms (state_controller.cpp:703-773): only defined requests are refreshed
+    if ((int(f(flags_at)) & 1) != 0)
+      for (int k = 0; k < 7; ++k) f(base + 7 + k) = r.transform[k];
+    return;
+  }
+  const int defined = int(r.flags) & 1;
+  if (!defined) { // withdrawn: defined_ = false, the rest of the record stays
+    f(flags_at) = double(int(f(flags_at)) & ~1);
+    return;
+  }
+  // targetTipPoseCallback (:1736, :1746): the LegStepper takes the request only while its robot is not STOPPED
+  const int walk_state = st.robi[rob_index(rob, RobotFields::I_WORD, 64 / L, RobotFields::I_COUNT)] & 3;
+  if (walk_state == WS_STOPPED) {
+    atomicAdd(ignored, 1ull);
+    return;
+  }
+  for (int k = 0; k < 7; ++k) f(base + k) = r.pose[k], f(base + 7 + k) = r.transform[k];
+  if (!which) f(ExtFields::T_CLEARANCE) = r.swing_clearance;
+  f(flags_at) = r.flags;
+}
+__global__ void get_external_kernel(DevState st, int L, int64_t first, int64_t count, int leg_sel, int which, ExtRow *rows) {
+  const int legs = leg_sel < 0 ? L : 1;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= count * legs) return;
+  const int64_t slot = slot_of(first + t / legs, leg_sel < 0 ? int(t % legs) : leg_sel, L);
+  const int base = which ? ExtFields::D_POSE : ExtFields::T_POSE;
+  auto f = [&](int field) { return st.ext[leg_field_index(field, slot, st.n_slots)]; };
+  ExtRow &r = rows[t];
+  for (int k = 0; k < 7; ++k) r.pose[k] = f(base + k), r.transform[k] = f(base + 7 + k);
+  r.swing_clearance = which ? 0.0 : f(ExtFields::T_CLEARANCE);
+  r.flags = f(which ? ExtFields::D_FLAGS : ExtFields::T_FLAGS);
+}
+
+static int external_select(shc_engine *e, int which, int64_t first, int64_t count, int leg, int64_t *rows_out) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (which != SHC_EXTERNAL_TARGET && which != SHC_EXTERNAL_DEFAULT) return fail(SHC_ERR_INVALID_ARG, "which must be SHC_EXTERNAL_TARGET or SHC_EXTERNAL_DEFAULT");
+  if (first < 0 || count < 0 || first + count > e->n || leg >= e->L) return fail(SHC_ERR_INVALID_ARG, "instance range / leg out of bounds");
+  if (!e->params.rough_terrain_mode) return fail(SHC_ERR_UNSUPPORTED, "external targets / defaults are read in rough_terrain_mode only (walk_controller.cpp:1065)");
+  *rows_out = count * (leg < 0 ? e->L : 1);
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->st.ext) { // first request: allocate the records (all undefined)
+    const size_t bytes = size_t(ExtFields::COUNT) * e->n_slots * 8;
+    HIP_TRY(hipMalloc(&e->st.ext, bytes));
+    HIP_TRY(hipMemsetAsync(e->st.ext, 0, bytes, e->stream));
+  }
+  return SHC_OK;
+}
+
+static int external_write(shc_engine *e, int which, int64_t first, int64_t count, int leg, const std::vector<ExtRow> &host, int transform_only,
+                          int64_t *ignored) {
+  ExtRow *d_rows = nullptr;
+  unsigned long long *d_ignored = nullptr, h_ignored = 0;
+  HIP_TRY(hipMalloc(&d_rows, host.size() * sizeof(ExtRow) + 8));
+  d_ignored = reinterpret_cast<unsigned long long *>(d_rows + host.size());
+  hipError_t err = hipMemcpyAsync(d_rows, host.data(), host.size() * sizeof(ExtRow), hipMemcpyHostToDevice, e->stream);
+  if (err == hipSuccess) err = hipMemsetAsync(d_ignored, 0, 8, e->stream);
+  if (err == hipSuccess) {
+    set_external_kernel<<<dim3((unsigned)((host.size() + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->L, first, count, leg, which, d_rows, transform_only, d_ignored);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipMemcpyAsync(&h_ignored, d_ignored, 8, hipMemcpyDeviceToHost, e->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  (void)hipFree(d_rows);
+  if (err != hipSuccess) return fail(SHC_ERR_HIP, hipGetErrorString(err));
+  if (ignored) *ignored = int64_t(h_ignored);
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_set_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, const shc_external_target *rows,
+                                              int64_t *ignored) {
+  int64_t n_rows = 0;
+  int rc = external_select(e, which, first, count, leg, &n_rows);
+  if (rc != SHC_OK) return rc;
+  if (!rows) return fail(SHC_ERR_INVALID_ARG, "rows is NULL");
+  if (ignored) *ignored = 0;
+  if (n_rows == 0) return SHC_OK;
+  std::vector<ExtRow> host((size_t)n_rows);
+  for (int64_t i = 0; i < n_rows; ++i) {
+    const shc_external_target &t = rows[i];
+    // LegStepper keeps tip rotations as their x axis, for > 3-DOF legs only; a requested target rotation would have to drive
+    // updateTipRotation / the rotation-constrained IK (walk_controller.cpp:1209-1230), which the engine runs for gravity-aligned tips only
+    if (t.defined && e->NJ > 3 && which == SHC_EXTERNAL_TARGET && (t.pose[3] != 0.0 || t.pose[4] != 0.0 || t.pose[5] != 0.0 || t.pose[6] != 0.0))
+      return fail(SHC_ERR_UNSUPPORTED, "external target with a defined tip rotation on legs with more than 3 joints");
+    for (int k = 0; k < 7; ++k) host[i].pose[k] = t.pose[k], host[i].transform[k] = t.transform[k];
+    host[i].swing_clearance = t.swing_clearance;
+    host[i].flags = double((t.defined ? 1 : 0) | (t.frame_is_odom_ideal ? 2 : 0));
+  }
+  e->rt_flags |= RT_EXTERNAL;
+  return external_write(e, which, first, count, leg, host, 0, ignored);
+}
+
+extern "C" int shc_engine_set_external_transform(shc_engine *e, int which, int64_t first, int64_t count, int leg, const double *transform) {
+  int64_t n_rows = 0;
+  int rc = external_select(e, which, first, count, leg, &n_rows);
+  if (rc != SHC_OK) return rc;
+  if (!transform) return fail(SHC_ERR_INVALID_ARG, "transform is NULL");
+  if (n_rows == 0) return SHC_OK;
+  std::vector<ExtRow> host((size_t)n_rows);
+  for (int64_t i = 0; i < n_rows; ++i)
+    for (int k = 0; k < 7; ++k) host[i].transform[k] = transform[i * 7 + k];
+  return external_write(e, which, first, count, leg, host, 1, nullptr);
+}
+
+extern "C" int shc_engine_get_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, shc_external_target *rows) {
+  int64_t n_rows = 0;
+  int rc = external_select(e, which, first, count, leg, &n_rows);
+  if (rc != SHC_OK) return rc;
+  if (!rows) return fail(SHC_ERR_INVALID_ARG, "rows is NULL");
+  if (n_rows == 0) return SHC_OK;
+  ExtRow *d_rows = nullptr;
+  HIP_TRY(hipMalloc(&d_rows, size_t(n_rows) * sizeof(ExtRow)));
+  get_external_kernel<<<dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->L, first, count, leg, which, d_rows);
+  std::vector<ExtRow> host((size_t)n_rows);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipMemcpyAsync(host.data(), d_rows, size_t(n_rows) * sizeof(ExtRow), hipMemcpyDeviceToHost, e->stream);
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  (void)hipFree(d_rows);
+  if (err != hipSuccess) return fail(SHC_ERR_HIP, hipGetErrorString(err));
+  for (int64_t i = 0; i < n_rows; ++i) {
+    for (int k = 0; k < 7; ++k) rows[i].pose[k] = host[i].pose[k], rows[i].transform[k] = host[i].transform[k];
+    rows[i].swing_clearance = host[i].swing_clearance;
+    rows[i].defined = int(host[i].flags) & 1;
+    rows[i].frame_is_odom_ideal = (int(host[i].flags) >> 1) & 1;
+  }
+  return SHC_OK;
 }
 
 extern "C" int shc_engine_get_joint_commands(shc_engine *e, double *position, double *velocity, double *effort, double *position_command, int on_device) {

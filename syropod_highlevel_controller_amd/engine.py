@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = [
     "shc_generate_tables_batch", "shc_engine_create_with_tables",
     "shc_sizeof_instance_state", "shc_engine_get_state", "shc_engine_set_state",
     "shc_engine_set_joint_states_msg", "shc_engine_set_tip_states_msg", "shc_engine_get_joint_commands",
+    "shc_engine_set_external_target", "shc_engine_set_external_transform", "shc_engine_get_external_target",
     "shc_leg_set_desired_tip_pose", "shc_leg_solve_ik", "shc_leg_update_joint_positions", "shc_leg_apply_ik", "shc_leg_apply_fk",
     "shc_leg_step_to_position", "shc_leg_transition_configuration", "shc_engine_begin_direct_startup", "shc_engine_direct_startup",
     "shc_fleet_create", "shc_fleet_destroy", "shc_fleet_instances", "shc_fleet_shape", "shc_fleet_part_count", "shc_fleet_part",
@@ -135,6 +136,9 @@ def lib():
         L.shc_sizeof_instance_state.restype = C.c_int64
         L.shc_engine_set_joint_states_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.shc_engine_set_tip_states_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
+        L.shc_engine_set_external_transform.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
+        L.shc_engine_get_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
         L.shc_engine_get_joint_commands.argtypes = [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int]
         sel = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
         L.shc_leg_set_desired_tip_pose.argtypes = sel + [C.c_void_p, C.c_int, C.c_int]
@@ -391,6 +395,29 @@ class BatchEngine:
     def set_tip_states_msg(self, wrench_force=None, step_plane=None):
         a, b = _host(wrench_force), _host(step_plane)
         _check(self.L.shc_engine_set_tip_states_msg(self.h, _p(a), _p(b), 0), "set_tip_states_msg")
+
+    # -- external targets / defaults of rough terrain mode (targetTipPoseCallback, generateExternalTargetTransforms)
+    def set_external_target(self, rows, which=0, first=0, count=None, leg=-1):
+        """rows: ctypes array of ExternalTarget, one per selected (instance, leg).  Returns how many requests were ignored
+        because their robot was STOPPED."""
+        count, n_rows = self._rows(first, count, leg)
+        assert len(rows) == n_rows
+        ignored = C.c_int64(0)
+        _check(self.L.shc_engine_set_external_target(self.h, which, first, count, leg, rows, C.byref(ignored)), "set_external_target")
+        return ignored.value
+
+    def set_external_transform(self, transform, which=0, first=0, count=None, leg=-1):
+        count, n_rows = self._rows(first, count, leg)
+        a = _host(transform)
+        assert a.size == n_rows * 7
+        _check(self.L.shc_engine_set_external_transform(self.h, which, first, count, leg, _p(a)), "set_external_transform")
+
+    def get_external_target(self, which=0, first=0, count=None, leg=-1):
+        from .params import ExternalTarget
+        count, n_rows = self._rows(first, count, leg)
+        rows = (ExternalTarget * n_rows)()
+        _check(self.L.shc_engine_get_external_target(self.h, which, first, count, leg, rows), "get_external_target")
+        return rows
 
     def joint_commands(self):
         """(position, velocity, effort, position_command) of publishDesiredJointState, each [n][legs * dof]."""

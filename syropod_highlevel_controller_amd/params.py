@@ -39,6 +39,15 @@ class LegStateMsg(C.Structure):
                 ("admittance_delta", C.c_double * 3), ("virtual_stiffness", C.c_double)]
 
 
+class ExternalTarget(C.Structure):
+    """shc_external_target of include/shc_batch.h (struct ExternalTarget, walk_controller.h:38-46)."""
+    _fields_ = [("pose", C.c_double * 7), ("transform", C.c_double * 7), ("swing_clearance", C.c_double),
+                ("frame_is_odom_ideal", C.c_int32), ("defined", C.c_int32)]
+
+
+EXTERNAL_TARGET, EXTERNAL_DEFAULT = 0, 1
+
+
 class LegSnapshot(C.Structure):
     """shc_leg_snapshot of include/shc_batch.h."""
     _fields_ = [("joint_position", C.c_double * SHC_MAX_JOINTS), ("joint_velocity", C.c_double * SHC_MAX_JOINTS),

@@ -122,6 +122,7 @@ class Schedule:
 
     def __init__(self):
         self.events = {}
+        self.ignored = {}
 
     def at(self, cycle, **inp):
         self.events.setdefault(cycle, {}).update(inp)
@@ -144,6 +145,11 @@ class Schedule:
                 o.set_imu(inp["imu_q"], inp["gyro"])
             if "effort" in inp:
                 o.set_joint_effort(inp["effort"])
+            for key, which in (("ext_target", 0), ("ext_default", 1)):
+                if key in inp:      # TargetTipPose message: both sides must take / ignore (robot STOPPED) the same requests
+                    self.ignored.setdefault(key, []).append(o.set_external_target(inp[key], which))
+                if key + "_transform" in inp:
+                    o.set_external_transform(inp[key + "_transform"], which)
 
 
 def teacher_forced(Engine, p, n, inp, cycles, schedule=None, features=FEAT_DEFAULT, label=""):
@@ -327,6 +333,110 @@ def test_rough_terrain_mode(Engine, case):
         ident = np.array([[p.stance_position[l][0], p.stance_position[l][1], 0.0] for l in range(L)])
         assert np.abs(st["leg"]["default_tip"][:, :L] - ident).max() > 1e-3
         assert np.abs(st["walk_plane"]).max() > 1e-4
+
+
+def external_rows(rng, p, n, frac, z_shift=0.0, rotation="identity", odom_frac=0.5, clearance=True):
+    """TargetTipPose rows for every (instance, leg): a fraction `frac` defined, poses around the legs' stance positions."""
+    from syropod_highlevel_controller_amd.params import ExternalTarget
+    L = p.leg_count
+    rows = (ExternalTarget * (n * L))()
+    for i in range(n):
+        for l in range(L):
+            r = rows[i * L + l]
+            if rng.random() >= frac:
+                continue
+            r.defined = 1
+            r.pose[0] = p.stance_position[l][0] + rng.uniform(-0.03, 0.03)
+            r.pose[1] = p.stance_position[l][1] + rng.uniform(-0.03, 0.03)
+            r.pose[2] = z_shift + rng.uniform(-0.015, 0.015)
+            if rotation == "random":
+                q = rng.normal(size=4)
+                q /= np.linalg.norm(q)
+            elif rotation == "identity":
+                q = np.array([1.0, 0, 0, 0])
+            else:
+                q = np.zeros(4)          # UNDEFINED_ROTATION
+            r.pose[3:7] = list(q)
+            r.transform[:] = [0, 0, 0, 1, 0, 0, 0]   # the callback stores the identity (state_controller.cpp:1732)
+            r.swing_clearance = rng.uniform(0.01, 0.05) if clearance else 0.0
+            r.frame_is_odom_ideal = int(rng.random() < odom_frac)
+    return rows
+
+
+def random_transforms(rng, n, L, scale=0.02):
+    """generateExternalTargetTransforms: the tf tree's walk-plane motion since the request (small translation + yaw / tilt)."""
+    from scipy.spatial.transform import Rotation as R
+    t = np.zeros((n, L, 7))
+    t[..., :3] = rng.normal(0, scale, (n, L, 3))
+    q = R.from_euler("xyz", rng.normal(0, 0.05, (n * L, 3))).as_quat()
+    t[..., 3] = q[:, 3].reshape(n, L)
+    t[..., 4:7] = q[:, :3].reshape(n, L, 3)
+    return t
+
+
+@pytest.mark.parametrize("case", ["6x3-tripod", "6x3-wave-forces", "8x3-ripple", "6x4-ripple-undefined-rotation"])
+def test_rough_terrain_external_targets(Engine, case):
+    """Externally requested tip targets and default stance poses (TargetTipPose messages, walk_controller.cpp:988-990,
+    :1068-1079, :1159): the swing lands on pose_.removePose(transform_) with the requested clearance, targets in the
+    odom_ideal frame are led by the ideal odometry, the request is dropped when the next stance begins, a requested default
+    replaces the terrain-following default tip until the next one; requests to STOPPED robots never reach the stepper
+    (state_controller.cpp:1736, :1746); the transforms are refreshed as the tf tree would (state_controller.cpp:703-773)."""
+    if case.startswith("6x4"):
+        p = synthetic_octopod_params("ripple", 4, 6)
+    elif case.startswith("8x3"):
+        p = synthetic_octopod_params("ripple", 3, 8)
+    else:
+        p = default_hexapod_params("wave" if "wave" in case else "tripod")
+    p.rough_terrain_mode, p.step_depth = 1, 0.01
+    n, cycles = 72, 560
+    L = p.leg_count
+    rng = np.random.default_rng(811)
+    inp = make_inputs(p, n, 801, zero_every=7)
+    sched = stop_go_schedule(p, n, 802, cycles, every=190)
+    rot = "undefined" if case.startswith("6x4") else "random"
+    for c in range(30, cycles, 45):      # a TargetTipPose message every 45 cycles, for half of the legs
+        sched.at(c, ext_target=external_rows(rng, p, n, 0.5, rotation=rot))
+    for c in range(100, cycles, 160):    # requested stance poses now and then, a fifth of the legs (some withdrawn again)
+        sched.at(c, ext_default=external_rows(rng, p, n, 0.2, rotation=rot, clearance=False))
+    for c in range(33, cycles, 3):       # tf refresh
+        sched.at(c, ext_target_transform=random_transforms(rng, n, L), ext_default_transform=random_transforms(rng, n, L, 0.01))
+    if "forces" in case:
+        for c in range(0, cycles, 6):
+            f = rng.normal(0, 0.25, (n, L, 3))
+            f[..., 2] += rng.choice([0.0, 0.05, 0.6, 1.5], size=(n, L), p=[0.3, 0.2, 0.2, 0.3])
+            sched.at(c, force=f)
+    eng, ob, _ = teacher_forced(Engine, p, n, inp, cycles, sched, label=f"rough terrain + external targets / {case}")
+    for key in ("ext_target", "ext_default"):
+        ig = sched.ignored[key]
+        assert ig[0::2] == ig[1::2], "engine and oracle ignored different requests"     # (engine, oracle) pairs
+        assert sum(ig) > 0                                                                # some robots were STOPPED
+    for which in (0, 1):                 # the records as the steppers hold them now
+        a, b = eng.get_external_target(which), ob.get_external_target(which)
+        assert bytes(a) == bytes(b)
+    assert any(r.defined for r in ob.get_external_target(1))
+    st = as_np(ob.get_state())
+    ident = np.array([[p.stance_position[l][0], p.stance_position[l][1], 0.0] for l in range(L)])
+    assert np.abs(st["leg"]["default_tip"][:, :L] - ident).max() > 5e-3
+
+
+def test_external_target_errors(Engine):
+    from syropod_highlevel_controller_amd.params import ExternalTarget
+    p = default_hexapod_params("tripod")
+    eng = Engine(p, 4)
+    rows = (ExternalTarget * 24)()
+    with pytest.raises(RuntimeError):                      # read in rough terrain mode only
+        eng.set_external_target(rows)
+    p = synthetic_octopod_params("ripple", 4, 6)
+    p.rough_terrain_mode = 1
+    eng = Engine(p, 4)
+    rows = (ExternalTarget * 24)()
+    assert eng.set_external_target(rows) == 0              # all undefined: withdraws nothing, ignores nothing
+    rows[3].defined = 1
+    rows[3].pose[3] = 1.0
+    with pytest.raises(RuntimeError):                      # a tip rotation request on 4-DOF legs
+        eng.set_external_target(rows)
+    rows[3].pose[3] = 0.0
+    assert eng.set_external_target(rows) == 1              # the robot is STOPPED: the planner-mode LegPoser would take it
 
 
 def test_rough_terrain_mode_free_running(Engine):
