@@ -388,6 +388,34 @@ int shc_leg_transition_configuration(shc_engine *e, int64_t first, int64_t count
  * joints published on the way are the reference's start-up trajectory. */
 int shc_engine_begin_direct_startup(shc_engine *e);
 int shc_engine_direct_startup(shc_engine *e, int32_t *progress);
+/*
+ * Start-up / shut-down SEQUENCES (start_up_sequence: true): PoseController::executeSequence (pose_controller.cpp:145-459) and
+ * PoseController::stepToNewStance (:521-557) for the batch, every instance with its own PoseController state (transition step,
+ * leg group, the transition poses its first START_UP learns, pose_controller.h:273-304, :591-593).
+ *   shc_engine_begin_sequence_startup  StateController::init() + initModel(false) (main.cpp:99-100, model.cpp:286-305): fresh
+ *       walker / poser state, every joint where the motors report it.  joint_positions: [legs][dof] rows shared by all instances,
+ *       or [n][legs][dof] with per_instance = 1 (host array, offsets removed); NULL = the READY configuration (every joint at its
+ *       `unpacked` position, state_controller.cpp:217).
+ *   shc_engine_execute_sequence        ONE call of executeSequence(sequence) per instance.  progress rows [n] (host, may be NULL):
+ *       -1 while a first START_UP is still generating its sequence, 0..99, 100 = complete, -2 = gave up (more than
+ *       TRANSITION_STEP_THRESHOLD transitions: the reference shuts down).  An instance that has completed `sequence` is left
+ *       alone by further calls with the same `sequence` (robots that learnt different sequences finish after different numbers
+ *       of calls; the caller loops until every row reads 100).  The node calls it where
+ *       transitionRobotState does (:301, :334: once per loop for START_UP, twice per loop for SHUT_DOWN through runningState :384-388).
+ *       The body pose is Model::current_pose_ as the last control cycle left it (the sequences run with the robot stopped).
+ *   shc_engine_finish_sequence_startup what follows a completed START_UP (:305-313): walker_->init(), the configuration the
+ *       sequence ended on becomes the default configuration, workspaces / walkspace / limits are regenerated from it (instance 0
+ *       stands for the batch: the tables belong to the engine), robot state RUNNING and the first control cycle of the same loop.
+ *   shc_engine_step_to_new_stance      ONE call of stepToNewStance per instance (progress as the reference returns it).
+ * packLegs / unpackLegs (:615-700) are LegPoser::transitionConfiguration towards the packed / unpacked joint positions:
+ * shc_leg_transition_configuration with those rows.  poseForLegManipulation (:561) needs manually controlled legs, which the
+ * batched engine does not model.
+ */
+enum { SHC_SEQUENCE_START_UP = 0, SHC_SEQUENCE_SHUT_DOWN = 1 }; /* enum SequenceSelection (parameters_and_states.h:183-188) */
+int shc_engine_begin_sequence_startup(shc_engine *e, const double *joint_positions, int per_instance);
+int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t *progress);
+int shc_engine_finish_sequence_startup(shc_engine *e);
+int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress);
 
 /*
  * Full controller state of one instance (checkpoint / restore, state injection).  Everything the next control cycle reads

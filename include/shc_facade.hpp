@@ -240,6 +240,8 @@ private:
   int id_;
 };
 
+enum SequenceSelection { START_UP, SHUT_DOWN, SEQUENCE_UNKNOWN }; // parameters_and_states.h:183-188
+
 // struct ExternalTarget (walk_controller.h:38-46); frame_id_ is reduced to what the stepper asks of it (== "odom_ideal").
 struct ExternalTarget {
   Pose pose_;
@@ -389,6 +391,23 @@ public:
   // phases of the fused cycle; the engine runs them with robot_state RUNNING when Model::updateModel launches it.
   void updateCurrentPose(const RobotState & /*robot_state*/) {}
   void updateStance(void) {}
+  // int executeSequence(const SequenceSelection& sequence) (pose_controller.h:166, pose_controller.cpp:145): one call of the
+  // start-up / shut-down choreography; -1 while the first START_UP generates its sequence, 100 = complete
+  int executeSequence(const SequenceSelection &sequence) {
+    require_single(*eng_, "executeSequence");
+    int32_t progress = 0;
+    check(shc_engine_execute_sequence(eng_->handle(), sequence == START_UP ? SHC_SEQUENCE_START_UP : SHC_SEQUENCE_SHUT_DOWN, &progress), "shc_engine_execute_sequence");
+    eng_->invalidate();
+    return progress;
+  }
+  // int stepToNewStance(void) (pose_controller.h:180, pose_controller.cpp:521)
+  int stepToNewStance(void) {
+    require_single(*eng_, "stepToNewStance");
+    int32_t progress = 0;
+    check(shc_engine_step_to_new_stance(eng_->handle(), &progress), "shc_engine_step_to_new_stance");
+    eng_->invalidate();
+    return progress;
+  }
 
 private:
   std::shared_ptr<Engine> eng_;

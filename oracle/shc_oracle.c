@@ -36,6 +36,12 @@
 /* admittance_controller.h:18 */
 #define ADMITTANCE_DEADBAND 0.0
 #define PROGRESS_COMPLETE 100 /* standard_includes.h:53 */
+#define SAFETY_FACTOR 0.15             /* pose_controller.h:20 */
+#define HORIZONTAL_TRANSITION_TIME 1.0 /* :21 */
+#define VERTICAL_TRANSITION_TIME 3.0   /* :22 */
+#define TRANSITION_STEP_THRESHOLD 20   /* :24 */
+#define HALF_BODY_DEPTH 0.05           /* model.h:18 */
+enum { SEQ_START_UP = 0, SEQ_SHUT_DOWN = 1 }; /* enum SequenceSelection, parameters_and_states.h:183-188 */
 
 enum { WALKING = 0 };                                             /* parameters_and_states.h:87 */
 enum { STARTING = 0, MOVING = 1, STOPPING = 2, STOPPED = 3 };     /* :99 */
@@ -70,6 +76,7 @@ typedef struct
   shc_external_target external_target, external_default; /* struct ExternalTarget (walk_controller.h:38-46, :533-534) */
 } stepper_t;
 
+#define ORC_MAX_TRANSITION_POSES 32 /* executeSequence gives up beyond TRANSITION_STEP_THRESHOLD = 20 steps (pose_controller.h:24) */
 typedef struct
 { /* class LegPoser, pose_controller.h:429-597 (members used on the path) */
   orc_pose auto_pose, current_tip_pose, origin_tip_pose, target_tip_pose;
@@ -79,6 +86,10 @@ typedef struct
   int first_iteration, master_iteration_count;
   int has_desired_configuration;
   double desired_configuration[SHC_MAX_JOINTS], origin_configuration[SHC_MAX_JOINTS];
+  /* start-up / shut-down sequences (pose_controller.h:591-593) */
+  orc_pose transition_poses[ORC_MAX_TRANSITION_POSES]; /* std::vector<Pose> transition_poses_ */
+  int n_transition_poses;
+  int leg_completed_step;
 } leg_poser_t;
 
 /* Workspace = std::map<double, Workplane>, Workplane = std::map<int, double> with the nine bearings 0..360 (model.h:27-32).
@@ -194,6 +205,10 @@ struct orc_robot
   orc_pose manual_pose, auto_pose, imu_pose, inclination_pose, pc_default_pose, walk_plane_pose, origin_walk_plane_pose;
   orc_pose tip_align_pose, origin_tip_align_pose; /* pose_controller.h:286-287 */
   int executing_transition;
+  /* sequence members (pose_controller.h:273-274, :296-304) */
+  int legs_completed_step, current_group, transition_step, transition_step_count;
+  int set_target, proximity_alert, horizontal_transition_complete, vertical_transition_complete;
+  int first_sequence_execution, reset_transition_sequence, sequence_failed;
   auto_poser_t auto_poser[SHC_MAX_AUTO_POSERS];
   int n_auto_posers;
   int auto_posing_state, pose_phase;
@@ -2067,6 +2082,247 @@ static int poser_direct_startup(orc_robot *r)
   return progress;
 }
 
+/* Model::legsBearingLoad (model.cpp:78-88) */
+static int model_legs_bearing_load(const orc_robot *r)
+{
+  double body_height_estimate = 0.0;
+  for (int l = 0; l < r->leg_count; ++l) body_height_estimate += r->leg[l].current_tip_pose.p.z;
+  return -(body_height_estimate / r->leg_count) > HALF_BODY_DEPTH;
+}
+
+static void leg_poser_add_transition_pose(leg_poser_t *lp, orc_pose pose)
+{
+  if (lp->n_transition_poses < ORC_MAX_TRANSITION_POSES) lp->transition_poses[lp->n_transition_poses++] = pose;
+}
+
+/* PoseController::executeSequence (pose_controller.cpp:145-459).  sequence: SEQ_START_UP / SEQ_SHUT_DOWN.  Returns the
+ * reference's progress (-1 while the first START_UP execution is generating the sequence, 100 = complete). */
+static int poser_execute_sequence(orc_robot *r, int sequence)
+{
+  /* Initialise / reset any saved transition sequence (:149-162) */
+  if (r->reset_transition_sequence && sequence == SEQ_START_UP)
+  {
+    r->reset_transition_sequence = 0;
+    r->first_sequence_execution = 1;
+    r->transition_step = 0;
+    for (int l = 0; l < r->leg_count; ++l)
+    {
+      leg_t *leg = &r->leg[l];
+      leg->poser.n_transition_poses = 0;                               /* resetTransitionSequence */
+      leg_poser_add_transition_pose(&leg->poser, leg->current_tip_pose); /* initial transition position */
+    }
+  }
+  int progress = 0;
+  int normalised_progress = 0;
+  int next_transition_step = 0, transition_step_target = 0, execute_horizontal_transition = 0, execute_vertical_transition = 0, total_progress = 0;
+  int count_or_one = r->transition_step_count > 1 ? r->transition_step_count : 1; /* std::max(transition_step_count_, 1) */
+  if (sequence == SEQ_START_UP)
+  {
+    execute_horizontal_transition = !(r->transition_step % 2);
+    execute_vertical_transition = r->transition_step % 2;
+    next_transition_step = r->transition_step + 1;
+    transition_step_target = r->transition_step_count;
+    total_progress = r->transition_step * 100 / count_or_one;
+  }
+  else
+  {
+    execute_horizontal_transition = r->transition_step % 2;
+    execute_vertical_transition = !(r->transition_step % 2);
+    next_transition_step = r->transition_step - 1;
+    transition_step_target = 0;
+    total_progress = 100 - r->transition_step * 100 / count_or_one;
+  }
+  int final_transition;
+  int sequence_complete = 0;
+  if (r->first_sequence_execution) final_transition = (r->horizontal_transition_complete || r->vertical_transition_complete);
+  else final_transition = (next_transition_step == transition_step_target);
+
+  double safety_factor = (r->first_sequence_execution ? SAFETY_FACTOR / (r->transition_step + 1) : 0.0);
+  double step_frequency = r->params.step_frequency;
+
+  if (execute_horizontal_transition)
+  {
+    if (r->set_target)
+    {
+      r->set_target = 0;
+      for (int l = 0; l < r->leg_count; ++l)
+      {
+        leg_t *leg = &r->leg[l];
+        leg->poser.leg_completed_step = 0;
+        orc_v3 target_tip_position;
+        if (next_transition_step >= 0 && leg->poser.n_transition_poses > next_transition_step) /* hasTransitionPose (a negative index - SHUT_DOWN before any START_UP - is undefined behaviour in the reference) */
+          target_tip_position = leg->poser.transition_poses[next_transition_step].p;
+        else
+          target_tip_position = orc_pose_inverse_transform_vector(r->current_pose, leg->stepper.default_tip_pose.p);
+        target_tip_position.z = leg->current_tip_pose.p.z; /* maintain horizontal position */
+        leg->poser.target_tip_pose = orc_pose_make(target_tip_position, leg->stepper.target_tip_pose.r);
+      }
+    }
+    int direct_step = !model_legs_bearing_load(r);
+    for (int l = 0; l < r->leg_count; ++l)
+    {
+      leg_t *leg = &r->leg[l];
+      leg_poser_t *lp = &leg->poser;
+      if (!lp->leg_completed_step)
+      {
+        if ((leg->id_number % 2) == r->current_group || direct_step) /* Leg::group_ = id_number % 2 (model.cpp:187) */
+        {
+          orc_pose target_tip_pose = lp->target_tip_pose;
+          int apply_delta = (sequence == SEQ_START_UP && final_transition);
+          double step_height = direct_step ? 0.0 : r->params.swing_height;
+          double time_to_step = HORIZONTAL_TRANSITION_TIME / step_frequency;
+          time_to_step *= (r->first_sequence_execution ? 2.0 : 1.0);
+          progress = leg_poser_step_to_position(r, leg, target_tip_pose, orc_pose_identity(), step_height, time_to_step, apply_delta);
+          leg_set_desired_tip_pose(leg, lp->current_tip_pose, 1);
+          double limit_proximity = leg_apply_ik(r, leg, 0);
+          int exceeded_workspace = limit_proximity < safety_factor;
+          if (r->first_sequence_execution && exceeded_workspace)
+          {
+            lp->target_tip_pose = lp->current_tip_pose;
+            lp->first_iteration = 1; /* resetStepToPosition */
+            progress = PROGRESS_COMPLETE;
+            r->proximity_alert = 1;
+          }
+          if (progress == PROGRESS_COMPLETE)
+          {
+            lp->leg_completed_step = 1;
+            r->legs_completed_step++;
+            if (r->first_sequence_execution)
+            {
+              int reached_target = !exceeded_workspace;
+              leg_poser_add_transition_pose(lp, reached_target ? lp->target_tip_pose : lp->current_tip_pose);
+            }
+          }
+        }
+        else
+        {
+          r->legs_completed_step++;
+          lp->leg_completed_step = 1;
+        }
+      }
+    }
+    count_or_one = r->transition_step_count > 1 ? r->transition_step_count : 1;
+    if (direct_step) normalised_progress = progress / count_or_one;
+    else normalised_progress = (progress / 2 + (r->current_group == 0 ? 0 : 50)) / count_or_one;
+    if (r->legs_completed_step == r->leg_count)
+    {
+      r->set_target = 1;
+      r->legs_completed_step = 0;
+      if (r->current_group == 1 || direct_step)
+      {
+        r->current_group = 0;
+        r->transition_step = next_transition_step;
+        r->horizontal_transition_complete = !r->proximity_alert;
+        sequence_complete = final_transition;
+        r->proximity_alert = 0;
+      }
+      else if (r->current_group == 0)
+      {
+        r->current_group = 1;
+      }
+    }
+  }
+
+  if (execute_vertical_transition)
+  {
+    if (r->set_target)
+    {
+      r->set_target = 0;
+      for (int l = 0; l < r->leg_count; ++l)
+      {
+        leg_t *leg = &r->leg[l];
+        orc_v3 target_tip_position;
+        if (next_transition_step >= 0 && leg->poser.n_transition_poses > next_transition_step)
+          target_tip_position = leg->poser.transition_poses[next_transition_step].p;
+        else
+          target_tip_position = orc_pose_inverse_transform_vector(r->current_pose, leg->stepper.default_tip_pose.p);
+        target_tip_position.x = leg->current_tip_pose.p.x; /* maintain horizontal position */
+        target_tip_position.y = leg->current_tip_pose.p.y;
+        leg->poser.target_tip_pose = orc_pose_make(target_tip_position, leg->stepper.target_tip_pose.r);
+      }
+    }
+    int all_legs_within_workspace = 1;
+    for (int l = 0; l < r->leg_count; ++l)
+    {
+      leg_t *leg = &r->leg[l];
+      leg_poser_t *lp = &leg->poser;
+      int apply_delta = (sequence == SEQ_START_UP && final_transition);
+      double time_to_step = VERTICAL_TRANSITION_TIME / step_frequency;
+      time_to_step *= (r->first_sequence_execution ? 2.0 : 1.0);
+      progress = leg_poser_step_to_position(r, leg, lp->target_tip_pose, orc_pose_identity(), 0.0, time_to_step, apply_delta);
+      leg_set_desired_tip_pose(leg, lp->current_tip_pose, 0);
+      double limit_proximity = leg_apply_ik(r, leg, 0);
+      all_legs_within_workspace = all_legs_within_workspace && !(limit_proximity < safety_factor);
+    }
+    if ((!all_legs_within_workspace && r->first_sequence_execution) || progress == PROGRESS_COMPLETE)
+    {
+      for (int l = 0; l < r->leg_count; ++l)
+      {
+        leg_poser_t *lp = &r->leg[l].poser;
+        lp->first_iteration = 1; /* resetStepToPosition */
+        progress = PROGRESS_COMPLETE;
+        if (r->first_sequence_execution)
+          leg_poser_add_transition_pose(lp, all_legs_within_workspace ? lp->target_tip_pose : lp->current_tip_pose);
+      }
+      r->vertical_transition_complete = all_legs_within_workspace;
+      r->transition_step = next_transition_step;
+      sequence_complete = final_transition;
+      r->set_target = 1;
+    }
+    count_or_one = r->transition_step_count > 1 ? r->transition_step_count : 1;
+    normalised_progress = progress / count_or_one;
+  }
+
+  if (r->first_sequence_execution)
+  {
+    r->transition_step_count = r->transition_step;
+    transition_step_target = r->transition_step;
+  }
+  if (r->transition_step > TRANSITION_STEP_THRESHOLD) r->sequence_failed = 1; /* ROS_FATAL + ros::shutdown() (:436-440) */
+
+  if (sequence_complete)
+  {
+    r->set_target = 1;
+    r->vertical_transition_complete = 0;
+    r->horizontal_transition_complete = 0;
+    r->first_sequence_execution = 0;
+    return PROGRESS_COMPLETE;
+  }
+  total_progress = total_progress + normalised_progress;
+  if (total_progress > PROGRESS_COMPLETE - 1) total_progress = PROGRESS_COMPLETE - 1;
+  return r->first_sequence_execution ? -1 : total_progress;
+}
+
+/* PoseController::stepToNewStance (pose_controller.cpp:521-557), tripod leg coordination */
+static int poser_step_to_new_stance(orc_robot *r)
+{
+  int progress = 0;
+  int leg_count = r->leg_count;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    if ((leg->id_number % 2) == r->current_group)
+    {
+      double step_height = r->params.swing_height;
+      double step_time = 1.0 / r->params.step_frequency;
+      orc_pose target_tip_pose = leg->stepper.default_tip_pose;
+      progress = leg_poser_step_to_position(r, leg, target_tip_pose, r->current_pose, step_height, step_time, 1);
+      leg_set_desired_tip_pose(leg, leg->poser.current_tip_pose, 1);
+      leg_apply_ik(r, leg, 0);
+      r->legs_completed_step += (progress == PROGRESS_COMPLETE);
+    }
+  }
+  progress = progress / 2 + r->current_group * 50;
+  r->current_group = r->legs_completed_step / (leg_count / 2);
+  if (r->legs_completed_step == leg_count)
+  {
+    r->legs_completed_step = 0;
+    r->current_group = 0;
+  }
+  r->reset_transition_sequence = 1;
+  return progress;
+}
+
 /* ==================================================================================== AdmittanceController */
 
 /* AdmittanceController::updateAdmittance (admittance_controller.cpp:22-63) for one leg.
@@ -2257,6 +2513,9 @@ orc_robot *orc_create(const shc_params *params)
   r->default_pose = orc_pose_identity();
   r->imu_orientation = ORC_UNDEFINED_ROTATION;
   r->imu_angular_velocity = orc_v3_make(0, 0, 0);
+  r->set_target = 1; /* pose_controller.h:299-304 */
+  r->first_sequence_execution = 1;
+  r->reset_transition_sequence = 1;
   /* Model::generate -> Leg::Leg + Leg::generate (model.cpp:44-62, 169-239) */
   for (int l = 0; l < r->leg_count; ++l)
   {
@@ -3062,6 +3321,58 @@ void orc_startup_finish(orc_robot *r)
   r->transition_state_flag = 1;
   state_loop(r);
 }
+
+/* ---- start-up / shut-down sequences (start_up_sequence: true).  orc_sequence_begin = state.init() + initModel(false) with the
+ * joint states `q` ([legs][dof], offsets removed) the motors reported (main.cpp:99-100, model.cpp:286-305) and the UNKNOWN ->
+ * READY estimate (state_controller.cpp:236-251).  orc_sequence_prologue = the posing / admittance part of one
+ * StateController::loop() (:165-181); orc_execute_sequence / orc_step_to_new_stance = one call of the PoseController method
+ * (transitionRobotState calls executeSequence once per loop for START_UP and - through runningState - twice per loop for
+ * SHUT_DOWN, :186-192, :384-388).  orc_sequence_finish_startup = what follows a completed START_UP (:305-313) and the
+ * runningState() of the same loop. */
+void orc_sequence_begin(orc_robot *r, const double *q)
+{
+  { /* a robot as the constructors leave it (the batch helpers hand out robots that already ran the direct start-up) */
+    shc_params params = r->params;
+    orc_robot *fresh = orc_create(&params);
+    memcpy(r, fresh, sizeof(orc_robot));
+    orc_destroy(fresh);
+  }
+  int k = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    for (int j = 0; j < leg->joint_count; ++j) leg->joint[j].current_position = q[k++];
+    leg->current_tip_pose = orc_pose_undefined();
+    leg_init(r, leg, 0);
+  }
+  r->robot_state = RS_READY;
+  r->new_robot_state = RS_RUNNING;
+  r->transition_state_flag = 1;
+}
+void orc_sequence_prologue(orc_robot *r)
+{
+  poser_update_current_pose(r, r->robot_state);
+  r->pose_state = r->auto_posing_state;
+  if (r->params.admittance_control)
+  {
+    if (r->walk_state != STOPPED && r->params.dynamic_stiffness) admittance_update_stiffness(r);
+    admittance_update_admittance(r);
+  }
+}
+int orc_execute_sequence(orc_robot *r, int sequence) { return poser_execute_sequence(r, sequence); }
+int orc_step_to_new_stance(orc_robot *r) { return poser_step_to_new_stance(r); }
+int orc_sequence_failed(const orc_robot *r) { return r->sequence_failed; }
+void orc_sequence_finish_startup(orc_robot *r)
+{
+  walker_init(r);
+  for (int l = 0; l < r->leg_count; ++l) leg_update_default_configuration(&r->leg[l]);
+  model_generate_workspaces(r);
+  walker_generate_walkspace(r);
+  r->robot_state = RS_RUNNING;
+  r->transition_state_flag = 0;
+  state_running_state(r);
+}
+void orc_sequence_finish_shutdown(orc_robot *r) { r->robot_state = RS_READY; r->new_robot_state = RS_RUNNING; }
 
 /* ------------------------------------------------------------------------------------ unit-level entry points */
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out) { *out = generate_step_cycle(p); }

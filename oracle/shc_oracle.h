@@ -95,6 +95,13 @@ void orc_batch_get_state(orc_batch *b, shc_instance_state *states /* [n] */);
 void orc_batch_set_state(orc_batch *b, const shc_instance_state *states /* [n] */);
 
 void orc_set_joint_states_msg(orc_robot *r, const double *position, const double *velocity, const double *effort); /* :1566 */
+void orc_sequence_begin(orc_robot *r, const double *q /* [legs][dof] */);   /* main.cpp:99-100 */
+void orc_sequence_prologue(orc_robot *r);                                    /* state_controller.cpp:165-181 */
+int orc_execute_sequence(orc_robot *r, int sequence /* 0 START_UP, 1 SHUT_DOWN */); /* pose_controller.cpp:145 */
+int orc_step_to_new_stance(orc_robot *r);                                    /* pose_controller.cpp:521 */
+int orc_sequence_failed(const orc_robot *r);
+void orc_sequence_finish_startup(orc_robot *r);                              /* state_controller.cpp:305-313 */
+void orc_sequence_finish_shutdown(orc_robot *r);
 int orc_set_external_target(orc_robot *r, int which, int leg, const shc_external_target *t);   /* state_controller.cpp:1706 */
 void orc_set_external_transform(orc_robot *r, int which, int leg, const double *transform);   /* :703-773 */
 void orc_get_external_target(const orc_robot *r, int which, int leg, shc_external_target *out);

@@ -372,6 +372,7 @@ __device__ __forceinline__ int64_t slot_of(int64_t rob, int leg, int L) {
 
 #include "shc_snapshot.hpp" // get_state / set_state kernels (use rob_index / slot_of)
 #include "shc_leg_api.hpp"  // per-leg Leg methods, batched
+#include "shc_sequence.hpp" // executeSequence / stepToNewStance: per-robot state machines over the per-leg primitives
 
 // AoS [n][L][K] -> leg fields f0..f0+K-1
 __global__ void scatter_leg_kernel(const double *src, double *legd, int64_t n_slots, int64_t n, int L, int K, int f0) {
@@ -568,6 +569,7 @@ struct shc_engine {
   uint32_t features;
   uint32_t rt_flags; // RT_* facts passed to every launch
   int starting_up, startup_calls; // shc_engine_begin_direct_startup .. shc_engine_direct_startup
+  SeqRobotState *d_seq;           // start-up / shut-down sequence state (shc_sequence.hpp), allocated by the first sequence call
 };
 
 template <int L, int NJ>
@@ -1134,6 +1136,7 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->st.robd);
   (void)hipFree(e->st.robi);
   (void)hipFree(e->st.ext);
+  (void)hipFree(e->d_seq);
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
   delete e;
@@ -2132,6 +2135,19 @@ __global__ void set_initial_joints_kernel(DevState st, const double *q0 /*[L][NJ
   }
 }
 
+// Q / QD of every leg slot from a saved copy of the joint planes (the TIP fields sharing the last plane keep their new values)
+__global__ void restore_joints_kernel(DevState st, const double2 *saved_planes, int L, int NJ) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= st.n_robots * L) return;
+  const int64_t rob = t / L;
+  const int64_t slot = slot_of(rob, int(t - rob * L), L);
+  const double *saved = reinterpret_cast<const double *>(saved_planes);
+  for (int f = 0; f < 2 * NJ; ++f) {
+    const int64_t i = leg_field_index(f, slot, st.n_slots);
+    st.legd[i] = saved[i];
+  }
+}
+
 extern "C" int shc_engine_begin_direct_startup(shc_engine *e) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = init_state(e);
@@ -2184,6 +2200,136 @@ extern "C" int shc_engine_direct_startup(shc_engine *e, int32_t *progress) {
   }
   if (progress) *progress = p;
   return SHC_OK;
+}
+
+// ---- start-up / shut-down sequences (start_up_sequence: true; shc_sequence.hpp)
+__global__ void set_joint_positions_kernel(DevState st, const double *q, int per_instance, int L, int NJ, int f_q, int f_qd, int f_meas) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= st.n_robots * L) return;
+  const int64_t rob = t / L;
+  const int leg = int(t - rob * L);
+  const int64_t slot = slot_of(rob, leg, L);
+  const double *row = q + (per_instance ? t : leg) * NJ;
+  for (int j = 0; j < NJ; ++j) { // Leg::init(false) (model.cpp:286-305): desired = current = the reported positions, velocities 0
+    st.legd[leg_field_index(f_q + j, slot, st.n_slots)] = row[j];
+    st.legd[leg_field_index(f_qd + j, slot, st.n_slots)] = 0.0;
+    st.legd[leg_field_index(f_meas + j, slot, st.n_slots)] = row[j];
+  }
+}
+
+extern "C" int shc_engine_begin_sequence_startup(shc_engine *e, const double *joint_positions, int per_instance) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (e->params.auto_posing && e->params.pose_frequency != -1.0)
+    return fail(SHC_ERR_UNSUPPORTED, "sequences with auto posing on its own clock (the body pose would move during the sequence)");
+  int rc = init_state(e); // StateController::init(): fresh walker / poser state
+  if (rc != SHC_OK) return rc;
+  const size_t rows = per_instance ? size_t(e->n) * e->L : size_t(e->L);
+  std::vector<double> q(rows * e->NJ);
+  if (joint_positions) {
+    memcpy(q.data(), joint_positions, q.size() * 8);
+  } else { // READY: every joint at its `unpacked` position (state_controller.cpp:217, :236)
+    if (per_instance) return fail(SHC_ERR_INVALID_ARG, "per_instance needs joint_positions");
+    for (int l = 0; l < e->L; ++l)
+      for (int j = 0; j < e->NJ; ++j) q[size_t(l) * e->NJ + j] = e->params.joint[l][j].unpacked;
+  }
+  if (q.size() * 8 > e->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
+  HIP_TRY(hipMemcpyAsync(e->d_stage, q.data(), q.size() * 8, hipMemcpyHostToDevice, e->stream));
+  const int64_t threads = e->n * e->L;
+  set_joint_positions_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->d_stage, per_instance, e->L, e->NJ, LEG_FIELD(e, Q),
+                                                                                                 LEG_FIELD(e, QD), LEG_FIELD(e, MEAS_Q));
+  HIP_TRY(hipGetLastError());
+  if (e->d_seq) HIP_TRY(hipMemsetAsync(e->d_seq, 0, sizeof(SeqRobotState) * size_t(e->n), e->stream)); // fresh PoseController
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->starting_up = 0;
+  return SHC_OK;
+}
+
+static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(START_UP / SHUT_DOWN), 2: stepToNewStance */, int32_t *progress) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->d_seq) {
+    HIP_TRY(hipMalloc(&e->d_seq, sizeof(SeqRobotState) * size_t(e->n)));
+    HIP_TRY(hipMemsetAsync(e->d_seq, 0, sizeof(SeqRobotState) * size_t(e->n), e->stream));
+  }
+  SeqParams P{};
+  P.step_frequency = e->params.step_frequency;
+  P.swing_height = e->params.swing_height;
+  P.dt = e->params.time_delta;
+  P.force_gain = e->params.force_gain;
+  P.clamp_vel = e->params.clamp_joint_velocities;
+  P.clamp_pos = e->params.clamp_joint_positions;
+  P.tip_force = e->cp.tip_force;
+  P.have_adm = e->params.admittance_control;
+  P.gravity_aligned = e->cp.gravity_aligned;
+  if (e->cp.gravity_aligned) { // identity tip rotation of gravity-aligned tips (walk_controller.cpp:37-41)
+    const Quat r = from_two_vectors(V3{1, 0, 0}, V3{e->cp.target_dir[0], e->cp.target_dir[1], e->cp.target_dir[2]});
+    P.target_rotation[0] = r.w, P.target_rotation[1] = r.x, P.target_rotation[2] = r.y, P.target_rotation[3] = r.z;
+  }
+  int32_t *d_progress = reinterpret_cast<int32_t *>(e->d_stage); // [n] ints fit the staging buffer (>= n * 8 * 8 bytes)
+  const dim3 grid((unsigned)((e->n + 63) / 64)), block(64);
+#define CALL(L_, NJ_)                                                                                                                        \
+  if (which == 2) step_to_new_stance_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, e->d_seq, P, d_progress); \
+  else execute_sequence_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, e->d_seq, which, P, d_progress)
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  if (progress) HIP_TRY(hipMemcpyAsync(progress, d_progress, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t *progress) {
+  if (sequence != SHC_SEQUENCE_START_UP && sequence != SHC_SEQUENCE_SHUT_DOWN) return fail(SHC_ERR_INVALID_ARG, "sequence must be SHC_SEQUENCE_START_UP or SHC_SEQUENCE_SHUT_DOWN");
+  return sequence_launch(e, sequence, progress);
+}
+
+extern "C" int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress) { return sequence_launch(e, 2, progress); }
+
+__global__ void copy_joint_planes_kernel(double2 *dst, const double2 *src, int64_t count) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t < count) dst[t] = src[t];
+}
+
+extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  HIP_TRY(hipSetDevice(e->device));
+  // Model::updateDefaultConfiguration + generateWorkspaces + generateWalkspace (state_controller.cpp:307-310): the tables of an
+  // engine belong to its morphology, so the configuration of instance 0 stands for the batch (identical robots that ran the
+  // same sequence end on the same joints)
+  std::vector<double> q(size_t(e->n) * e->L * e->NJ);
+  int rc = shc_engine_get_joint_state(e, q.data(), nullptr, 0);
+  if (rc != SHC_OK) return rc;
+  shc_tables t;
+  bool ok = false;
+  switch (e->NJ) {
+    case 3: ok = hostinit::generate_tables<3>(e->params, t, q.data()); break;
+    case 4: ok = hostinit::generate_tables<4>(e->params, t, q.data()); break;
+    default: ok = hostinit::generate_tables<5>(e->params, t, q.data()); break;
+  }
+  if (!ok) return fail(SHC_ERR_INVALID_ARG, "init chain failed for the configuration the sequence ended on");
+  e->tables = t;
+  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  if ((rc = upload_consts(e)) != SHC_OK) return rc;
+  // walker_->init() (:306): fresh LegSteppers / walk state; the joints stay where the sequence left them
+  const int n_joint_planes = (2 * e->NJ + 1) / 2 + 1; // planes holding Q and QD (Fields: Q = 0, QD = NJ, TIP = 2 NJ)
+  const int64_t count = int64_t(n_joint_planes) * e->n_slots;
+  double2 *keep = nullptr;
+  HIP_TRY(hipMalloc(&keep, size_t(count) * 16));
+  const dim3 grid((unsigned)((count + 255) / 256));
+  copy_joint_planes_kernel<<<grid, dim3(256), 0, e->stream>>>(keep, reinterpret_cast<const double2 *>(e->st.legd), count);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  if (err == hipSuccess && (rc = init_state(e)) == SHC_OK) {
+    restore_joints_kernel<<<dim3((unsigned)((e->n * e->L + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, keep, e->L, e->NJ);
+    err = hipGetLastError();
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  }
+  (void)hipFree(keep);
+  if (err != hipSuccess) return fail(SHC_ERR_HIP, hipGetErrorString(err));
+  if (rc != SHC_OK) return rc;
+  // robot_state_ = RUNNING, and the runningState() of the same loop (:189-192)
+  if ((rc = shc_engine_step(e, 1)) != SHC_OK) return rc;
+  return shc_engine_synchronize(e);
 }
 
 extern "C" int64_t shc_sizeof_instance_state(void) { return (int64_t)sizeof(shc_instance_state); }

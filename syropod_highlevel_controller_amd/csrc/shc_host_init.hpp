@@ -487,14 +487,20 @@ SHC_HDI int startup_loops(const shc_params &p) { return imax(1, round_to_int(p.t
 // (the device batch splits the eight bearing searches of a leg over eight threads: each repeats the start-up solve and
 //  the re-basing prefix, ~350 steps, and searches one bearing, <= 500 steps)
 template <int NJ>
-SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int first_bearing = 1, int last_bearing = 8) {
+SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int first_bearing = 1, int last_bearing = 8,
+                                 const double *preset_configuration = nullptr) {
   // body pose the start-up solve eases to / the workspace search runs at (identical unless auto posing has its own clock)
   const Pose body = startup_body_pose(p, t, 0), body_ws = startup_body_pose(p, t, startup_loops(p) - 1);
   HostLeg<NJ> leg;
   fill_leg_const<NJ>(p, l, leg.lc);
   for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, p.joint[l][j].min, p.joint[l][j].max); // model.cpp:1038
   V3 default_tip{p.stance_position[l][0], p.stance_position[l][1], 0.0};
-  startup_solve<NJ>(p, leg, default_tip, body);
+  if (preset_configuration) { // the default configuration is given (the joints a start-up SEQUENCE ended on, state_controller.cpp:307-310)
+    for (int j = 0; j < NJ; ++j) leg.q[j] = preset_configuration[j], leg.qd[j] = 0.0;
+    leg.fk();
+  } else {
+    startup_solve<NJ>(p, leg, default_tip, body);
+  }
   for (int j = 0; j < NJ; ++j) {
     leg.dflt[j] = leg.q[j]; // Model::updateDefaultConfiguration
     if (first_bearing == 1) t.default_joint_position[l][j] = leg.q[j];
@@ -513,9 +519,9 @@ SHC_HDI void generate_tables_tail(const shc_params &p, shc_tables &t) {
 }
 
 template <int NJ>
-SHC_HDI bool generate_tables(const shc_params &p, shc_tables &t) {
+SHC_HDI bool generate_tables(const shc_params &p, shc_tables &t, const double *preset_configuration /* [legs][NJ] or nullptr */ = nullptr) {
   if (!generate_tables_head(p, t)) return false;
-  for (int l = 0; l < p.leg_count; ++l) generate_tables_leg<NJ>(p, l, t);
+  for (int l = 0; l < p.leg_count; ++l) generate_tables_leg<NJ>(p, l, t, 1, 8, preset_configuration ? preset_configuration + l * NJ : nullptr);
   generate_tables_tail(p, t);
   return true;
 }

@@ -54,20 +54,15 @@ struct LegIO {
 
 // Leg::setDesiredTipPose(tip_pose, apply_delta): tip_pose == NULL is the reference's default argument Pose::Undefined(),
 // "use the poser's tip pose" (model.cpp:657-660; POSER_TIP must have been derived, see derive_tips_kernel).
-template <int L_, int NJ>
-__global__ void leg_set_desired_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *tip_pose, int apply_delta,
-                                       int have_adm, int gravity_aligned) {
+template <int NJ>
+__device__ __forceinline__ void set_desired_dev(const DevState &st, const LegIO<NJ> &io, int L, int64_t rob, const double *pose7, int apply_delta,
+                                                int have_adm, int gravity_aligned) {
   using FD = Fields<NJ>;
   using R = RobotFields;
-  int64_t rob;
-  int l;
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (!sel.map(t, rob, l)) return;
-  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
   V3 pos, dir{0, 0, 0};
   bool defined = false;
-  if (tip_pose) {
-    const double *p = tip_pose + t * 7;
+  if (pose7) {
+    const double *p = pose7;
     pos = V3{p[0], p[1], p[2]};
     const Quat r{p[3], p[4], p[5], p[6]};
     defined = !(r.w == 0.0 && r.x == 0.0 && r.y == 0.0 && r.z == 0.0); // != UNDEFINED_ROTATION (isApprox with the zero quaternion)
@@ -75,7 +70,7 @@ __global__ void leg_set_desired_kernel(DevState st, const SharedConsts<L_, NJ> *
   } else {
     pos = io.get3(FD::POSER_TIP);
     if (gravity_aligned && NJ > 3 && (st.legi[io.slot] & LW_ROTDEF)) { // pose.rotation^-1 * walker tip rotation (pose_controller.cpp:129-130)
-      const int rpw = 64 / sel.L;
+      const int rpw = 64 / L;
       const Quat cr{st.robd[rob_index(rob, R::CPOSE + 3, rpw, R::COUNT)], st.robd[rob_index(rob, R::CPOSE + 4, rpw, R::COUNT)],
                     st.robd[rob_index(rob, R::CPOSE + 5, rpw, R::COUNT)], st.robd[rob_index(rob, R::CPOSE + 6, rpw, R::COUNT)]};
       dir = rotate(inverse(cr), io.get3(FD::CUR_DIR));
@@ -86,6 +81,16 @@ __global__ void leg_set_desired_kernel(DevState st, const SharedConsts<L_, NJ> *
   io.put3(FD::DES_TIP, pos);
   io.put(FD::DES_TIP + 3, defined ? 1.0 : 0.0);
   io.put3(FD::DES_DIR, dir);
+}
+template <int L_, int NJ>
+__global__ void leg_set_desired_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *tip_pose, int apply_delta,
+                                       int have_adm, int gravity_aligned) {
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  set_desired_dev<NJ>(st, io, sel.L, rob, tip_pose ? tip_pose + t * 7 : nullptr, apply_delta, have_adm, gravity_aligned);
 }
 
 template <int L_, int NJ>
@@ -126,16 +131,10 @@ __global__ void leg_update_joints_kernel(DevState st, const SharedConsts<L_, NJ>
 
 // Leg::applyIK(simulation) towards the stored desired tip pose, including the rotation-constrained pass, the unconstrained
 // retry and the closing calculateTipForce (model.cpp:861-941).
-template <int L_, int NJ>
-__global__ void leg_apply_ik_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, int simulation, double *result_out, double dt,
-                                    int clamp_vel, int clamp_pos, int tip_force, double force_gain) {
+template <int NJ>
+__device__ __forceinline__ double apply_ik_dev(const DevState &st, const LegIO<NJ> &io, const LegConst<NJ> &lc, int simulation, double dt, int clamp_vel,
+                                               int clamp_pos, int tip_force, double force_gain) {
   using FD = Fields<NJ>;
-  int64_t rob;
-  int l;
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (!sel.map(t, rob, l)) return;
-  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
-  const LegConst<NJ> &lc = gc->leg[l];
   double q[NJ], qd[NJ], dq[NJ];
   io.joints(q, qd);
   const V3 desired = io.get3(FD::DES_TIP);
@@ -187,6 +186,17 @@ __global__ void leg_apply_ik_kernel(DevState st, const SharedConsts<L_, NJ> *gc,
     w = failed ? (w | LW_IKFAIL) : (w & ~LW_IKFAIL);
     st.legi[io.slot] = w;
   }
+  return success;
+}
+template <int L_, int NJ>
+__global__ void leg_apply_ik_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, int simulation, double *result_out, double dt,
+                                    int clamp_vel, int clamp_pos, int tip_force, double force_gain) {
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  const double success = apply_ik_dev<NJ>(st, io, gc->leg[l], simulation, dt, clamp_vel, clamp_pos, tip_force, force_gain);
   if (result_out) result_out[t] = success;
 }
 
@@ -212,17 +222,10 @@ __global__ void leg_apply_fk_kernel(DevState st, const SharedConsts<L_, NJ> *gc,
 // Bezier curves from where the leg was when the sequence started (origin_tip_pose_) to the target (with an optional lift)
 // while the body pose eases from the identity to target_pose; the result is LegPoser::current_tip_pose_, which the callers
 // hand to Leg::setDesiredTipPose + applyIK (stepToNewStance :521, poseForLegManipulation :561, directStartup :463).
-template <int L_, int NJ>
-__global__ void leg_step_to_position_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *target_tip_pose,
-                                            const double *target_pose, double lift_height, double time_to_step, int apply_delta, int have_adm,
-                                            double dt, double *tip_pose_out, int32_t *progress_out) {
+template <int NJ>
+__device__ __forceinline__ int step_to_position_dev(const DevState &st, const LegIO<NJ> &io, const LegConst<NJ> &lc, const double *target7, const Pose &body,
+                                                    double lift_height, double time_to_step, int apply_delta, int have_adm, double dt, Pose &out_pose) {
   using FD = Fields<NJ>;
-  int64_t rob;
-  int l;
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (!sel.map(t, rob, l)) return;
-  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
-  const LegConst<NJ> &lc = gc->leg[l];
   V3 origin = io.get3(FD::SEQ_ORG), origin_dir = io.get3(FD::SEQ_DIR);
   int count = int(io.get(FD::SEQ_ORG + 3));
   if (io.get(FD::SEQ_DIR + 3) == 0.0) { // first_iteration_: origin_tip_pose_ = leg_->getCurrentTipPose() (FK of the current joints)
@@ -236,15 +239,13 @@ __global__ void leg_step_to_position_kernel(DevState st, const SharedConsts<L_, 
   }
   V3 desired = origin, desired_dir{0, 0, 0};
   bool rot = false;
-  if (target_tip_pose) { // NULL = Pose::Undefined(): stay at the origin position, rotation undefined (:1583-1587)
-    const double *p = target_tip_pose + t * 7;
+  if (target7) { // NULL = Pose::Undefined(): stay at the origin position, rotation undefined (:1583-1587)
+    const double *p = target7;
     desired = V3{p[0], p[1], p[2]};
     const Quat r{p[3], p[4], p[5], p[6]};
     rot = !(r.w == 0.0 && r.x == 0.0 && r.y == 0.0 && r.z == 0.0);
     if (rot) desired_dir = rotate(r, V3{1, 0, 0});
   }
-  const double *tp = target_pose + (rob - sel.first) * 7;
-  const Pose body{V3{tp[0], tp[1], tp[2]}, Quat{tp[3], tp[4], tp[5], tp[6]}};
   const bool move = norm(origin - inverse_transform_vector(body, desired)) > kTipTolerance;
   bool turn = false;
   if (rot) turn = norm(angle_axis_vector(from_two_vectors(origin_dir, desired_dir))) > kJointTolerance;
@@ -280,6 +281,23 @@ __global__ void leg_step_to_position_kernel(DevState st, const SharedConsts<L_, 
   io.put(FD::SEQ_ORG + 3, double(count));
   io.put3(FD::SEQ_DIR, origin_dir);
   io.put(FD::SEQ_DIR + 3, running);
+  out_pose = out;
+  return progress;
+}
+template <int L_, int NJ>
+__global__ void leg_step_to_position_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *target_tip_pose,
+                                            const double *target_pose, double lift_height, double time_to_step, int apply_delta, int have_adm,
+                                            double dt, double *tip_pose_out, int32_t *progress_out) {
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  const double *tp = target_pose + (rob - sel.first) * 7;
+  const Pose body{V3{tp[0], tp[1], tp[2]}, Quat{tp[3], tp[4], tp[5], tp[6]}};
+  Pose out;
+  const int progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target_tip_pose ? target_tip_pose + t * 7 : nullptr, body, lift_height, time_to_step,
+                                                apply_delta, have_adm, dt, out);
   double *o = tip_pose_out + t * 7;
   o[0] = out.p.x, o[1] = out.p.y, o[2] = out.p.z, o[3] = out.r.w, o[4] = out.r.x, o[5] = out.r.y, o[6] = out.r.z;
   if (progress_out) progress_out[t] = progress;

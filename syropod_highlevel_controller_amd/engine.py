@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_set_external_target", "shc_engine_set_external_transform", "shc_engine_get_external_target",
     "shc_leg_set_desired_tip_pose", "shc_leg_solve_ik", "shc_leg_update_joint_positions", "shc_leg_apply_ik", "shc_leg_apply_fk",
     "shc_leg_step_to_position", "shc_leg_transition_configuration", "shc_engine_begin_direct_startup", "shc_engine_direct_startup",
+    "shc_engine_begin_sequence_startup", "shc_engine_execute_sequence", "shc_engine_finish_sequence_startup", "shc_engine_step_to_new_stance",
     "shc_fleet_create", "shc_fleet_destroy", "shc_fleet_instances", "shc_fleet_shape", "shc_fleet_part_count", "shc_fleet_part",
     "shc_fleet_part_instances", "shc_fleet_set_velocity", "shc_fleet_set_imu", "shc_fleet_set_pose_input", "shc_fleet_set_tip_force",
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
@@ -136,6 +137,10 @@ def lib():
         L.shc_sizeof_instance_state.restype = C.c_int64
         L.shc_engine_set_joint_states_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.shc_engine_set_tip_states_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_begin_sequence_startup.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_execute_sequence.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.shc_engine_finish_sequence_startup.argtypes = [C.c_void_p]
+        L.shc_engine_step_to_new_stance.argtypes = [C.c_void_p, C.c_void_p]
         L.shc_engine_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
         L.shc_engine_set_external_transform.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
         L.shc_engine_get_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
@@ -395,6 +400,25 @@ class BatchEngine:
     def set_tip_states_msg(self, wrench_force=None, step_plane=None):
         a, b = _host(wrench_force), _host(step_plane)
         _check(self.L.shc_engine_set_tip_states_msg(self.h, _p(a), _p(b), 0), "set_tip_states_msg")
+
+    # -- start-up / shut-down sequences (PoseController::executeSequence, stepToNewStance)
+    def begin_sequence_startup(self, joint_positions=None, per_instance=False):
+        a = _host(joint_positions)
+        _check(self.L.shc_engine_begin_sequence_startup(self.h, _p(a), 1 if per_instance else 0), "begin_sequence_startup")
+
+    def execute_sequence(self, sequence):
+        """One executeSequence call per instance; returns the progress rows (-1 generating, 0..99, 100 complete)."""
+        pr = np.zeros(self.n, dtype=np.int32)
+        _check(self.L.shc_engine_execute_sequence(self.h, int(sequence), _p(pr)), "execute_sequence")
+        return pr
+
+    def finish_sequence_startup(self):
+        _check(self.L.shc_engine_finish_sequence_startup(self.h), "finish_sequence_startup")
+
+    def step_to_new_stance(self):
+        pr = np.zeros(self.n, dtype=np.int32)
+        _check(self.L.shc_engine_step_to_new_stance(self.h, _p(pr)), "step_to_new_stance")
+        return pr
 
     # -- external targets / defaults of rough terrain mode (targetTipPoseCallback, generateExternalTargetTransforms)
     def set_external_target(self, rows, which=0, first=0, count=None, leg=-1):

@@ -77,6 +77,12 @@ def lib():
         L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
         L.orc_set_joint_states_msg.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.orc_set_step_plane.argtypes = [C.c_void_p, _dp]
+        L.orc_sequence_begin.argtypes = [C.c_void_p, _dp]
+        for f in ("orc_sequence_prologue", "orc_sequence_finish_startup", "orc_sequence_finish_shutdown"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.orc_execute_sequence.argtypes = [C.c_void_p, C.c_int]
+        L.orc_step_to_new_stance.argtypes = [C.c_void_p]
+        L.orc_sequence_failed.argtypes = [C.c_void_p]
         L.orc_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_set_external_target.restype = C.c_int
         L.orc_set_external_transform.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
@@ -274,6 +280,54 @@ class OracleBatch:
             sp = np.ascontiguousarray(step_plane, dtype=np.float64).reshape(self.n, -1)
             for i in range(self.n):
                 self.L.orc_set_step_plane(self.L.orc_batch_robot(self.h, i), _ptr(sp[i]))
+
+    # ---- start-up / shut-down sequences, one call per robot like the engine's batched entry points
+    def begin_sequence_startup(self, joint_positions=None, per_instance=False):
+        p = self.p
+        nl, nd = p.leg_count, p.leg_dof[0]
+        if joint_positions is None:
+            q = np.array([[p.joint[l][j].unpacked for j in range(nd)] for l in range(nl)], dtype=np.float64).ravel()
+            rows = [q] * self.n
+        else:
+            a = np.ascontiguousarray(joint_positions, dtype=np.float64)
+            rows = list(a.reshape(self.n, -1)) if per_instance else [a.ravel()] * self.n
+        for i in range(self.n):
+            self.L.orc_sequence_begin(self.L.orc_batch_robot(self.h, i), _ptr(np.ascontiguousarray(rows[i])))
+
+    def execute_sequence(self, sequence):
+        """One call per robot; a robot that has completed `sequence` is left alone until the other one is requested (its node
+        would have left transitionRobotState) - the engine's batched call does the same."""
+        if not hasattr(self, "_seq_done"):
+            self._seq_done = np.full(self.n, -1)
+        out = np.zeros(self.n, dtype=np.int32)
+        for i in range(self.n):
+            if self._seq_done[i] == sequence:
+                out[i] = 100
+                continue
+            self._seq_done[i] = -1
+            r = self.L.orc_batch_robot(self.h, i)
+            self.L.orc_sequence_prologue(r)          # the posing part of the loop the call sits in
+            out[i] = self.L.orc_execute_sequence(r, int(sequence))
+            assert not self.L.orc_sequence_failed(r)
+            if out[i] == 100:
+                self._seq_done[i] = sequence
+        return out
+
+    def finish_sequence_startup(self):
+        for i in range(self.n):
+            self.L.orc_sequence_finish_startup(self.L.orc_batch_robot(self.h, i))
+
+    def finish_sequence_shutdown(self):
+        for i in range(self.n):
+            self.L.orc_sequence_finish_shutdown(self.L.orc_batch_robot(self.h, i))
+
+    def step_to_new_stance(self):
+        out = np.zeros(self.n, dtype=np.int32)
+        for i in range(self.n):
+            r = self.L.orc_batch_robot(self.h, i)
+            self.L.orc_sequence_prologue(r)
+            out[i] = self.L.orc_step_to_new_stance(r)
+        return out
 
     # ---- external targets / defaults, rows in instance-major (instance, leg) order like the engine's call
     def set_external_target(self, rows, which=0):

