@@ -407,15 +407,21 @@ int shc_engine_direct_startup(shc_engine *e, int32_t *progress);
  *       sequence ended on becomes the default configuration, workspaces / walkspace / limits are regenerated from it (instance 0
  *       stands for the batch: the tables belong to the engine), robot state RUNNING and the first control cycle of the same loop.
  *   shc_engine_step_to_new_stance      ONE call of stepToNewStance per instance (progress as the reference returns it).
- * packLegs / unpackLegs (:615-700) are LegPoser::transitionConfiguration towards the packed / unpacked joint positions:
- * shc_leg_transition_configuration with those rows.  poseForLegManipulation (:561) needs manually controlled legs, which the
- * batched engine does not model.
+ *   shc_engine_pack_legs / unpack_legs PoseController::packLegs / unpackLegs (:615-707), ONE call per loop: every joint follows its
+ *       cubic Bezier (LegPoser::transitionConfiguration) to the packed positions of the current pack step / back to the previous
+ *       step's and finally the `unpacked` positions.  packed_positions = Joint::packed_positions_ as [n_pack_steps][legs][dof]
+ *       (default.yaml "packed" may list several steps per joint).  *progress as the reference returns it (0 between pack steps,
+ *       100 when done); the pack step and "transition executing" flag are PoseController members, kept per engine (every
+ *       instance runs the same number of iterations).
+ * poseForLegManipulation (:561) needs manually controlled legs, which the batched engine does not model.
  */
 enum { SHC_SEQUENCE_START_UP = 0, SHC_SEQUENCE_SHUT_DOWN = 1 }; /* enum SequenceSelection (parameters_and_states.h:183-188) */
 int shc_engine_begin_sequence_startup(shc_engine *e, const double *joint_positions, int per_instance);
 int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t *progress);
 int shc_engine_finish_sequence_startup(shc_engine *e);
 int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress);
+int shc_engine_pack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_pack, int32_t *progress);
+int shc_engine_unpack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_unpack, int32_t *progress);
 
 /*
  * Full controller state of one instance (checkpoint / restore, state injection).  Everything the next control cycle reads

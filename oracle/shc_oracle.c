@@ -209,6 +209,7 @@ struct orc_robot
   int legs_completed_step, current_group, transition_step, transition_step_count;
   int set_target, proximity_alert, horizontal_transition_complete, vertical_transition_complete;
   int first_sequence_execution, reset_transition_sequence, sequence_failed;
+  int pack_step; /* pose_controller.h:298 */
   auto_poser_t auto_poser[SHC_MAX_AUTO_POSERS];
   int n_auto_posers;
   int auto_posing_state, pose_phase;
@@ -2323,6 +2324,50 @@ static int poser_step_to_new_stance(orc_robot *r)
   return progress;
 }
 
+/* PoseController::packLegs / unpackLegs (pose_controller.cpp:615-707), simultaneous leg coordination.  packed_positions =
+ * Joint::packed_positions_ ([number_pack_steps][legs][dof] flattened; default.yaml "packed" is a list per joint). */
+static int poser_pack_legs(orc_robot *r, const double *packed_positions, int number_pack_steps, double time_to_pack, int unpack)
+{
+  int progress = 0;
+  if (!unpack) r->transition_step = 0; /* reset for the start-up / shut-down sequences (:618) */
+  int k = 0, dof_total = 0;
+  for (int l = 0; l < r->leg_count; ++l) dof_total += r->leg[l].joint_count;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    if (!r->executing_transition)
+    {
+      for (int j = 0; j < leg->joint_count; ++j)
+      {
+        double target;
+        if (!unpack) target = packed_positions[(size_t)r->pack_step * dof_total + k + j];
+        else target = (r->pack_step > 0) ? packed_positions[(size_t)(r->pack_step - 1) * dof_total + k + j] : leg->joint[j].unpacked_position;
+        leg->poser.desired_configuration[j] = target;
+      }
+      leg->poser.has_desired_configuration = 1;
+    }
+    k += leg->joint_count;
+    progress = leg_poser_transition_configuration(r, leg, time_to_pack);
+  }
+  r->executing_transition = (progress != 0 && progress != PROGRESS_COMPLETE);
+  if (!unpack)
+  {
+    if (progress == PROGRESS_COMPLETE && r->pack_step < number_pack_steps - 1)
+    {
+      r->executing_transition = 0;
+      r->pack_step++;
+      progress = 0;
+    }
+  }
+  else if (progress == PROGRESS_COMPLETE && r->pack_step != 0)
+  {
+    r->executing_transition = 0;
+    r->pack_step--;
+    progress = 0;
+  }
+  return progress;
+}
+
 /* ==================================================================================== AdmittanceController */
 
 /* AdmittanceController::updateAdmittance (admittance_controller.cpp:22-63) for one leg.
@@ -3362,6 +3407,14 @@ void orc_sequence_prologue(orc_robot *r)
 int orc_execute_sequence(orc_robot *r, int sequence) { return poser_execute_sequence(r, sequence); }
 int orc_step_to_new_stance(orc_robot *r) { return poser_step_to_new_stance(r); }
 int orc_sequence_failed(const orc_robot *r) { return r->sequence_failed; }
+int orc_pack_legs(orc_robot *r, const double *packed_positions, int number_pack_steps, double time_to_pack)
+{
+  return poser_pack_legs(r, packed_positions, number_pack_steps, time_to_pack, 0);
+}
+int orc_unpack_legs(orc_robot *r, const double *packed_positions, int number_pack_steps, double time_to_unpack)
+{
+  return poser_pack_legs(r, packed_positions, number_pack_steps, time_to_unpack, 1);
+}
 void orc_sequence_finish_startup(orc_robot *r)
 {
   walker_init(r);

@@ -100,6 +100,8 @@ void orc_sequence_prologue(orc_robot *r);                                    /* 
 int orc_execute_sequence(orc_robot *r, int sequence /* 0 START_UP, 1 SHUT_DOWN */); /* pose_controller.cpp:145 */
 int orc_step_to_new_stance(orc_robot *r);                                    /* pose_controller.cpp:521 */
 int orc_sequence_failed(const orc_robot *r);
+int orc_pack_legs(orc_robot *r, const double *packed_positions /* [steps][legs][dof] */, int number_pack_steps, double time_to_pack);     /* pose_controller.cpp:615 */
+int orc_unpack_legs(orc_robot *r, const double *packed_positions, int number_pack_steps, double time_to_unpack);                        /* :662 */
 void orc_sequence_finish_startup(orc_robot *r);                              /* state_controller.cpp:305-313 */
 void orc_sequence_finish_shutdown(orc_robot *r);
 int orc_set_external_target(orc_robot *r, int which, int leg, const shc_external_target *t);   /* state_controller.cpp:1706 */

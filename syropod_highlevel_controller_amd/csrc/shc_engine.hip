@@ -570,6 +570,7 @@ struct shc_engine {
   uint32_t rt_flags; // RT_* facts passed to every launch
   int starting_up, startup_calls; // shc_engine_begin_direct_startup .. shc_engine_direct_startup
   SeqRobotState *d_seq;           // start-up / shut-down sequence state (shc_sequence.hpp), allocated by the first sequence call
+  int pack_step, executing_transition, transition_calls; // PoseController::pack_step_ / executing_transition_ (pose_controller.h:294, :298)
 };
 
 template <int L, int NJ>
@@ -2241,6 +2242,7 @@ extern "C" int shc_engine_begin_sequence_startup(shc_engine *e, const double *jo
   if (e->d_seq) HIP_TRY(hipMemsetAsync(e->d_seq, 0, sizeof(SeqRobotState) * size_t(e->n), e->stream)); // fresh PoseController
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->starting_up = 0;
+  e->pack_step = e->executing_transition = e->transition_calls = 0;
   return SHC_OK;
 }
 
@@ -2284,6 +2286,63 @@ extern "C" int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t 
 }
 
 extern "C" int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress) { return sequence_launch(e, 2, progress); }
+
+// PoseController::packLegs / unpackLegs (pose_controller.cpp:615-707)
+static int pack_transition(shc_engine *e, const double *packed_positions, int n_pack_steps, double transition_time, bool unpack, int32_t *progress) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (!packed_positions || n_pack_steps < 1) return fail(SHC_ERR_INVALID_ARG, "packed_positions / n_pack_steps");
+  if (!(transition_time > 0)) return fail(SHC_ERR_INVALID_ARG, "transition time must be > 0");
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->pack_step >= n_pack_steps) e->pack_step = n_pack_steps - 1;
+  const size_t per_step = size_t(e->L) * e->NJ;
+  std::vector<double> target(per_step);
+  for (int l = 0; l < e->L; ++l) // desired_configuration_ of every leg (:628-642, :676-693); the kernel latches it when a transition begins
+    for (int j = 0; j < e->NJ; ++j) {
+      const size_t k = size_t(l) * e->NJ + j;
+      if (!unpack) target[k] = packed_positions[size_t(e->pack_step) * per_step + k];
+      else target[k] = e->pack_step > 0 ? packed_positions[size_t(e->pack_step - 1) * per_step + k] : e->params.joint[l][j].unpacked;
+    }
+  HIP_TRY(hipMemcpyAsync(e->d_stage, target.data(), target.size() * 8, hipMemcpyHostToDevice, e->stream));
+  LegCall c;
+  int rc = c.init(e, 0, e->n, -1);
+  if (rc != SHC_OK) return rc;
+  const double *d = e->d_stage;
+  if ((rc = LEG_KERNEL(leg_transition_configuration_kernel, d, 0, transition_time, e->params.time_delta, (int32_t *)nullptr)) != SHC_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream)); // the staging buffer is reused
+  // LegPoser::transitionConfiguration's progress is a function of its iteration count alone (:1546-1566)
+  int num = round_to_int(transition_time / e->params.time_delta);
+  num = num > 1 ? num : 1;
+  e->transition_calls++;
+  int p = int((double(e->transition_calls - 1) / double(num)) * 100);
+  p = p < 1 ? 1 : (p > 100 ? 100 : p);
+  if (e->transition_calls >= num) {
+    p = 100;
+    e->transition_calls = 0;
+  }
+  e->executing_transition = (p != 0 && p != 100);
+  if (!unpack) {
+    if (p == 100 && e->pack_step < n_pack_steps - 1) {
+      e->executing_transition = 0;
+      e->pack_step++;
+      p = 0;
+    }
+  } else if (p == 100 && e->pack_step != 0) {
+    e->executing_transition = 0;
+    e->pack_step--;
+    p = 0;
+  }
+  if (progress) *progress = p;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_pack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_pack, int32_t *progress) {
+  return pack_transition(e, packed_positions, n_pack_steps, time_to_pack, false, progress);
+}
+
+extern "C" int shc_engine_unpack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_unpack, int32_t *progress) {
+  return pack_transition(e, packed_positions, n_pack_steps, time_to_unpack, true, progress);
+}
 
 __global__ void copy_joint_planes_kernel(double2 *dst, const double2 *src, int64_t count) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;

@@ -37,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "shc_leg_set_desired_tip_pose", "shc_leg_solve_ik", "shc_leg_update_joint_positions", "shc_leg_apply_ik", "shc_leg_apply_fk",
     "shc_leg_step_to_position", "shc_leg_transition_configuration", "shc_engine_begin_direct_startup", "shc_engine_direct_startup",
     "shc_engine_begin_sequence_startup", "shc_engine_execute_sequence", "shc_engine_finish_sequence_startup", "shc_engine_step_to_new_stance",
+    "shc_engine_pack_legs", "shc_engine_unpack_legs",
     "shc_fleet_create", "shc_fleet_destroy", "shc_fleet_instances", "shc_fleet_shape", "shc_fleet_part_count", "shc_fleet_part",
     "shc_fleet_part_instances", "shc_fleet_set_velocity", "shc_fleet_set_imu", "shc_fleet_set_pose_input", "shc_fleet_set_tip_force",
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
@@ -141,6 +142,8 @@ def lib():
         L.shc_engine_execute_sequence.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.shc_engine_finish_sequence_startup.argtypes = [C.c_void_p]
         L.shc_engine_step_to_new_stance.argtypes = [C.c_void_p, C.c_void_p]
+        L.shc_engine_pack_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int32)]
+        L.shc_engine_unpack_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int32)]
         L.shc_engine_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
         L.shc_engine_set_external_transform.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
         L.shc_engine_get_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p]
@@ -414,6 +417,15 @@ class BatchEngine:
 
     def finish_sequence_startup(self):
         _check(self.L.shc_engine_finish_sequence_startup(self.h), "finish_sequence_startup")
+
+    def pack_legs(self, packed_positions, time_to_pack, unpack=False):
+        """One PoseController::packLegs / unpackLegs call; packed_positions [n_pack_steps][legs][dof]."""
+        a = np.ascontiguousarray(packed_positions, dtype=np.float64)
+        steps = a.size // (self.legs * self.dof)
+        pr = C.c_int32(0)
+        f = self.L.shc_engine_unpack_legs if unpack else self.L.shc_engine_pack_legs
+        _check(f(self.h, _p(a), steps, float(time_to_pack), C.byref(pr)), "pack_legs")
+        return pr.value
 
     def step_to_new_stance(self):
         pr = np.zeros(self.n, dtype=np.int32)

@@ -83,6 +83,8 @@ def lib():
         L.orc_execute_sequence.argtypes = [C.c_void_p, C.c_int]
         L.orc_step_to_new_stance.argtypes = [C.c_void_p]
         L.orc_sequence_failed.argtypes = [C.c_void_p]
+        L.orc_pack_legs.argtypes = [C.c_void_p, _dp, C.c_int, C.c_double]
+        L.orc_unpack_legs.argtypes = [C.c_void_p, _dp, C.c_int, C.c_double]
         L.orc_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_set_external_target.restype = C.c_int
         L.orc_set_external_transform.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
@@ -320,6 +322,14 @@ class OracleBatch:
     def finish_sequence_shutdown(self):
         for i in range(self.n):
             self.L.orc_sequence_finish_shutdown(self.L.orc_batch_robot(self.h, i))
+
+    def pack_legs(self, packed_positions, time_to_pack, unpack=False):
+        a = np.ascontiguousarray(packed_positions, dtype=np.float64)
+        steps = a.size // self.dof
+        f = self.L.orc_unpack_legs if unpack else self.L.orc_pack_legs
+        out = [f(self.L.orc_batch_robot(self.h, i), _ptr(a), steps, float(time_to_pack)) for i in range(self.n)]
+        assert len(set(out)) == 1
+        return out[0]
 
     def step_to_new_stance(self):
         out = np.zeros(self.n, dtype=np.int32)

@@ -245,3 +245,40 @@ def test_step_to_new_stance_sequence():
         assert np.abs(eng.joints()[0] - ob.joints()[0]).max() < 1e-8
         history.append(int(pe[0]))
     assert max(history) >= 98 and 50 in history          # both groups stepped: progress ran through the second half
+
+
+@pytest.mark.parametrize("case", ["hexapod", "8x5"])
+def test_pack_and_unpack_legs(case):
+    """PoseController::packLegs / unpackLegs (pose_controller.cpp:615-707) with a two-step pack list: READY -> pack step 0 ->
+    pack step 1 (PACKED) -> back through step 0 to the unpacked positions, progress and joints compared in every call."""
+    from oracle_lib import OracleBatch
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+    p = default_hexapod_params("tripod") if case == "hexapod" else synthetic_octopod_params("ripple", 5, 8)
+    n = 4
+    L, D = p.leg_count, p.leg_dof[0]
+    rng = np.random.default_rng(17)
+    ready = np.array([[p.joint[l][j].unpacked for j in range(D)] for l in range(L)])
+    lo = np.array([[p.joint[l][j].min for j in range(D)] for l in range(L)])
+    hi = np.array([[p.joint[l][j].max for j in range(D)] for l in range(L)])
+    packed = np.stack([ready + 0.5 * (rng.uniform(lo, hi) - ready), rng.uniform(lo, hi)])       # [2][legs][dof]
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    for o in (eng, ob):
+        o.begin_sequence_startup(None, False)
+    time_to_pack = 2.0 / p.step_frequency          # PACK_TIME / step_frequency (state_controller.h:27, state_controller.cpp:285)
+    worst = 0.0
+    for unpack in (False, True):
+        zeros = 0
+        for calls in range(1, 1000):
+            pe, po = eng.pack_legs(packed, time_to_pack, unpack), ob.pack_legs(packed, time_to_pack, unpack)
+            assert pe == po, (unpack, calls, pe, po)
+            d = float(np.abs(eng.joints()[0] - ob.joints()[0]).max())
+            worst = max(worst, d)
+            assert d < 1e-12
+            zeros += pe == 0
+            if pe == 100:
+                break
+        assert pe == 100 and zeros == 1            # one intermediate pack step was passed
+        target = packed[1] if not unpack else ready
+        assert np.abs(eng.joints()[0] - target.ravel()).max() < 1e-9
+    from conftest import parity_report
+    parity_report(f"[pack / unpack {case}] two pack steps each way, progress identical in every call, max |dq| = {worst:.2e} rad")
