@@ -77,9 +77,13 @@ def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
     np.testing.assert_allclose(pg[m], po[m], atol=1e-9)
     np.testing.assert_allclose(vg[m], vo[m], atol=1e-12)
     np.testing.assert_allclose(lg["poser_tip"][m], lo["poser_tip"][m], atol=1e-8)
-    np.testing.assert_allclose(lg["model_tip"][m], lo["model_tip"][m], atol=tol_q)
-    if eng.features & FEAT_TIP_FORCE:  # Leg::calculateTipForce low-pass state (forces here are O(1) N)
-        np.testing.assert_allclose(lg["tip_force"][m], lo["tip_force"][m], atol=2e-4)  # ~100 N/rad x the 1e-6 rad joint bar
+    # the model tip is a function of the joints alone: held as tightly as the measured joint difference allows (< 1 m / rad of
+    # lever arm), 1e-12 m when the joints agree to rounding
+    np.testing.assert_allclose(lg["model_tip"][m], lo["model_tip"][m], atol=max(1e-12, 2.0 * float(dq.max())))
+    if eng.features & FEAT_TIP_FORCE:  # Leg::calculateTipForce low-pass state (forces here are O(1) N): ~100 N / rad x the 1e-6 rad
+        # joint bar; the filter remembers earlier joint differences, so the bound cannot follow the current one (the
+        # teacher-forced tests hold it to 1e-9 N per cycle)
+        np.testing.assert_allclose(lg["tip_force"][m], lo["tip_force"][m], atol=2e-4)
     np.testing.assert_allclose(lg["admittance"][m], lo["admittance"][m], atol=1e-8)
     if eng.features & FEAT_ODOMETRY:  # odometry_ideal_ integrates the desired velocities only: independent of the IK path
         np.testing.assert_allclose(eng.odometry()[m], ob.odometry()[m], atol=1e-11)
