@@ -39,7 +39,8 @@ enum {
   SHC_ERR_INVALID_ARG = 1,
   SHC_ERR_NO_DEVICE = 2,      /* no HIP device / kernel image: the product path never falls back to CPU */
   SHC_ERR_HIP = 3,
-  SHC_ERR_UNSUPPORTED = 4,    /* feature of the reference outside the accelerated path (rough terrain, manual legs) */
+  SHC_ERR_UNSUPPORTED = 4,    /* outside the accelerated path: legs of different DOF in one engine, rough terrain with a stance
+                                 span modifier, a requested tip rotation on > 3-DOF legs, sequences with own-clock auto posing */
   SHC_ERR_UNSTABLE = 5        /* reserved: the reference aborts when the IMU correction's norm exceeds 100 rad
                                  (pose_controller.cpp:1228-1232); after its own clamps (:1222-1226) that needs
                                  max_rotation > 100 rad, so no entry point returns this code today */
