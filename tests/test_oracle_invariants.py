@@ -69,3 +69,54 @@ def test_octopod_walks():
     assert sum(h[7] for h in hist) == 0
     assert hist[-1][6] == WALK_MOVING
     assert any((h[3] & 3 == STEP_SWING).any() for h in hist)
+
+
+@pytest.mark.parametrize("legs,dof,gait", [(6, 3, "tripod"), (6, 4, "ripple"), (8, 5, "ripple"), (4, 3, "amble")])
+def test_sequences_reach_their_goals(legs, dof, gait):
+    """Invariants of the start-up / shut-down choreography (pose_controller.cpp:145-459, :615-707) that hold whatever the
+    implementation: a first START_UP from the READY (unpacked) configuration reports -1 while it generates its sequence and
+    ends with every tip on its default stance position under the body (inside the 5 mm IK tolerance) with no joint at a
+    limit; SHUT_DOWN brings the joints back to the unpacked configuration; the second START_UP replays the stored transition
+    poses in fewer calls, reporting a monotonically non-decreasing progress, and ends where the first one did; packing and
+    unpacking through a two-step pack list returns to the unpacked positions exactly."""
+    from oracle_lib import OracleBatch
+    p = default_hexapod_params(gait) if (legs, dof) == (6, 3) else synthetic_octopod_params(gait, dof, legs)
+    ob = OracleBatch(p, 1)
+    ob.begin_sequence_startup(None, False)
+    ready = np.array([[p.joint[l][j].unpacked for j in range(dof)] for l in range(legs)]).ravel()
+    lo = np.array([[p.joint[l][j].min for j in range(dof)] for l in range(legs)]).ravel()
+    hi = np.array([[p.joint[l][j].max for j in range(dof)] for l in range(legs)]).ravel()
+
+    def run(sequence):
+        hist = []
+        while not hist or hist[-1] != 100:
+            hist.append(int(ob.execute_sequence(sequence)[0]))
+            assert len(hist) < 5000
+        return hist
+
+    h1 = run(0)
+    assert set(h1[:-1]) == {-1}
+    q1 = ob.joints()[0][0].copy()
+    tips = ob.leg_state()["model_tip"][0]
+    want = np.array([[p.stance_position[l][0], p.stance_position[l][1], -p.body_clearance] for l in range(legs)])
+    assert np.abs(tips - want).max() < 5e-3                       # default stance under a body at its clearance height
+    assert (q1 > lo + 1e-6).all() and (q1 < hi - 1e-6).all()
+    ob.finish_sequence_startup()
+    h2 = run(1)
+    assert h2 == sorted(h2) and h2[0] >= 0
+    assert np.abs(ob.joints()[0][0] - ready).max() < 2e-2          # back in the READY configuration (IK tracking error)
+    ob.finish_sequence_shutdown()
+    h3 = run(0)
+    assert h3 == sorted(h3) and h3[0] >= 0 and len(h3) < len(h1)
+    assert np.abs(ob.joints()[0][0] - q1).max() < 2e-2
+    # pack / unpack
+    rng = np.random.default_rng(3)
+    ob.begin_sequence_startup(None, False)
+    packed = np.stack([ready + 0.4 * (rng.uniform(lo, hi) - ready), rng.uniform(lo, hi)])
+    for unpack in (False, True):
+        hist = []
+        while not hist or hist[-1] != 100:
+            hist.append(ob.pack_legs(packed, 2.0 / p.step_frequency, unpack))
+            assert len(hist) < 2000
+        assert hist.count(0) == 1
+        assert np.abs(ob.joints()[0][0] - (ready if unpack else packed[1])).max() < 1e-12
