@@ -79,6 +79,17 @@ public:
     invalidate();
   }
   void invalidate() { have_ = 0; }
+  // state.init() + state.initModel(false) (main.cpp:99-100): fresh controllers, joints where the motors report them (NULL =
+  // the READY / unpacked configuration) - the starting point of PoseController::executeSequence(START_UP)
+  void initModel(const double *joint_positions = nullptr) {
+    check(shc_engine_begin_sequence_startup(e_, joint_positions, 0), "shc_engine_begin_sequence_startup");
+    invalidate();
+  }
+  // what transitionRobotState does once executeSequence(START_UP) has completed (state_controller.cpp:305-313)
+  void finishStartUpSequence() {
+    check(shc_engine_finish_sequence_startup(e_), "shc_engine_finish_sequence_startup");
+    invalidate();
+  }
   // StateController::changeGait (state_controller.cpp:513): true once the gait has changed, false while the robots are
   // still being stopped (keep cycling and call again, as the reference does while gait_change_flag_ is set)
   bool changeGait(const shc_params &new_gait) {

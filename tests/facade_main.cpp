@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 using namespace shc_facade;
 
@@ -19,6 +20,40 @@ int main(int argc, char **argv) {
   double v[2] = {atof(argv[3]), atof(argv[4])};
   double w = atof(argv[5]);
   auto engine = std::make_shared<Engine>(p, 1, 0);
+  if (argc > 6 && std::string(argv[6]) == "sequence") {
+    // start_up_sequence: true - READY -> RUNNING through PoseController::executeSequence(START_UP) (state_controller.cpp:298-313),
+    // a short walk, then the LegStepper external-target interface; prints calls, joints after the sequence, joints after the walk
+    auto model = std::make_shared<Model>(engine);
+    auto walker = std::make_shared<WalkController>(engine);
+    auto poser = std::make_shared<PoseController>(engine);
+    engine->initModel();
+    int calls = 0, progress = 0;
+    while (progress != 100 && calls < 5000) {
+      progress = poser->executeSequence(START_UP);
+      ++calls;
+    }
+    printf("calls %d\n", calls);
+    for (int l = 0; l < model->getLegCount(); ++l)
+      for (int j = 1; j <= model->getLegByIDNumber(l).getJointCount(); ++j) printf("%.17g\n", model->getLegByIDNumber(l).getJointByIDNumber(j).desired_position_);
+    engine->finishStartUpSequence();
+    for (int c = 0; c < cycles; ++c) {
+      walker->updateWalk(v, w);
+      model->updateModel();
+    }
+    for (int l = 0; l < model->getLegCount(); ++l)
+      for (int j = 1; j <= model->getLegByIDNumber(l).getJointCount(); ++j) printf("%.17g\n", model->getLegByIDNumber(l).getJointByIDNumber(j).desired_position_);
+    if (p.rough_terrain_mode) { // LegStepper::setExternalTarget / getExternalTarget (walk_controller.h:385, :437)
+      ExternalTarget t;
+      t.pose_ = Pose{{{0.2, -0.1, -0.02}}, {1.0, 0.0, 0.0, 0.0}};
+      t.swing_clearance_ = 0.03;
+      t.defined_ = true;
+      LegStepper stepper = model->getLegByIDNumber(1).getLegStepper();
+      stepper.setExternalTarget(t);
+      ExternalTarget back = stepper.getExternalTarget();
+      printf("external %d %.17g %.17g\n", back.defined_ ? 1 : 0, back.pose_.position_[0], back.swing_clearance_);
+    }
+    return 0;
+  }
   auto model = std::make_shared<Model>(engine);
   auto walker = std::make_shared<WalkController>(engine);
   auto poser = std::make_shared<PoseController>(engine);

@@ -52,3 +52,36 @@ def test_facade_reproduces_oracle(tmp_path):
     assert abs(float(out[22]) - res) <= 1e-6
     q_leg = r.joints()[0][6:9]
     assert np.abs(np.array([float(x) for x in out[23:26]]) - q_leg).max() <= 1e-6
+
+
+def test_facade_sequence_start_up_and_external_target(tmp_path):
+    """The facade's start_up_sequence path: Engine::initModel + PoseController::executeSequence(START_UP) until complete +
+    finishStartUpSequence, then a walk in rough terrain mode and the LegStepper external-target accessors."""
+    from oracle_lib import OracleBatch
+    so = engine.build_library()
+    exe = str(tmp_path / "facade_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "facade_main.cpp"),
+                           so, "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    p = default_hexapod_params("tripod")
+    p.rough_terrain_mode = 1
+    pfile = str(tmp_path / "params.bin")
+    open(pfile, "wb").write(bytes(p))
+    cycles, v = 120, (0.4, 0.1, -0.3)
+    out = subprocess.check_output([exe, pfile, str(cycles), *map(str, v), "sequence"], text=True).split("\n")
+    ob = OracleBatch(p, 1)
+    ob.begin_sequence_startup(None, False)
+    calls = 0
+    while True:
+        calls += 1
+        if ob.execute_sequence(0)[0] == 100:
+            break
+    assert out[0] == f"calls {calls}"
+    q_seq = np.array([float(x) for x in out[1:19]])
+    assert np.abs(q_seq - ob.joints()[0][0]).max() <= 1e-6
+    ob.finish_sequence_startup()
+    ob.set_velocity(np.array([[v[0], v[1]]]), np.array([v[2]]))
+    ob.step(cycles, 1)
+    q_walk = np.array([float(x) for x in out[19:37]])
+    assert np.abs(q_walk - ob.joints()[0][0]).max() <= 1e-6
+    tag, defined, x, clearance = out[37].split()
+    assert (tag, defined) == ("external", "1") and float(x) == 0.2 and float(clearance) == 0.03
