@@ -1085,3 +1085,22 @@ def test_error_codes(Engine):
     assert L.shc_engine_create_with_tables(C.byref(p), C.byref(t), 4, 0, None, C.byref(h)) == INVALID  # tables never generated
     still = C.c_int64(-1)
     assert L.shc_engine_change_gait(eng.h, None, C.byref(still)) == INVALID
+    # entry points added in ABI version 2
+    from syropod_highlevel_controller_amd.params import ExternalTarget, InstanceState
+    st = (InstanceState * 2)()
+    assert L.shc_engine_get_state(eng.h, 11, 2, st) == INVALID and L.shc_engine_get_state(eng.h, -1, 1, st) == INVALID
+    assert L.shc_engine_set_state(eng.h, 0, 1, None) == INVALID
+    rows = (ExternalTarget * 6)()
+    assert L.shc_engine_set_external_target(eng.h, 0, 0, 1, -1, rows, None) == UNSUPPORTED       # not in rough terrain mode
+    assert L.shc_engine_execute_sequence(eng.h, 7, None) == INVALID                              # no such sequence
+    assert L.shc_engine_execute_sequence(None, 0, None) == INVALID
+    pr = C.c_int32(0)
+    assert L.shc_engine_pack_legs(eng.h, None, 1, 1.0, C.byref(pr)) == INVALID
+    q = (C.c_double * 18)()
+    assert L.shc_engine_pack_legs(eng.h, q, 1, 0.0, C.byref(pr)) == INVALID                      # no time to pack in
+    assert L.shc_engine_direct_startup(eng.h, C.byref(pr)) == INVALID                            # begin_direct_startup first
+    assert L.shc_leg_apply_ik(eng.h, 0, 1, 6, 0, None, 0) == INVALID                             # leg 6 of a hexapod
+    own = default_hexapod_params("tripod")
+    own.auto_posing, own.pose_frequency = 1, 0.8
+    e2 = Engine(own, 2)
+    assert L.shc_engine_begin_sequence_startup(e2.h, None, 0) == UNSUPPORTED and b"own clock" in L.shc_last_error()
