@@ -190,10 +190,10 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     if not gather_every or steps % gather_every:
         gather()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # this rank's K steps + its part of the gather; the MAX over ranks below is the job's time
     if use_dist:
-        dist.barrier()
+        dist.barrier()  # closing bracket (the all-gather inside the region already needed every rank's shard)
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
     if use_dist:
         # the gathered buffer must hold every rank's shard in rank order: check this rank's own slice
         own = gathered[rank * qshard.numel():(rank + 1) * qshard.numel()]
