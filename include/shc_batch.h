@@ -240,7 +240,8 @@ int shc_engine_synchronize(shc_engine *e);
 int shc_engine_get_joint_state(shc_engine *e, double *q, double *qd, int on_device);
 /*
  * Device view of the engine's own joint-position planes (paired structure-of-arrays):
- * the raw buffer a multi-GPU caller may all-gather without a transpose.  `*n_doubles` = 2 * ceil(dof / 2) * n_slots
+ * the raw buffer a multi-GPU caller may all-gather without a transpose.  `*n_doubles` = 2 * ceil(dof / 2) * n_slots, n_slots =
+ * 64 per wavefront of ⌊64 / legs⌋ robots + 192 slots of plane-stride padding
  * (for an odd DOF the last plane also carries the first joint velocity); use shc_engine_joint_index to address it.
  */
 int shc_engine_joint_buffer(shc_engine *e, double **device_ptr, int64_t *n_doubles);

@@ -784,7 +784,7 @@ def test_device_pointer_io_with_torch(Engine):
     b.synchronize()
     assert np.array_equal(qd.cpu().numpy().reshape(n, 18), b.joints()[0])
     ptr, nd = a.joint_buffer()
-    n_slots = ((n + 9) // 10) * 64
+    n_slots = ((n + 9) // 10) * 64 + 192               # 64 slots per wave + the plane-stride padding
     assert nd == 2 * 2 * n_slots                       # ceil(3 / 2) paired planes of double2 per slot
     slot = 1 * 64 + 3 * 6 + 4                          # instance 13 -> wave 1, group 3; leg 4
     assert a.joint_index(13, 4, 2) == (1 * n_slots + slot) * 2 + 0
