@@ -712,9 +712,9 @@ def test_full_size_config2_properties(Engine):
     assert np.abs(ob.joints()[0] - q[:m]).max() <= TOL_Q
 
 
-def test_large_batch_uses_256_thread_workgroups(Engine):
-    """>= 1 024 waves (10 240 hexapods) switch to 4-wave workgroups sharing one LDS copy of the tables: every instance of
-    such a batch against the oracle, single-cycle and fused launches."""
+def test_large_batch_every_instance(Engine):
+    """More than a thousand waves (10 300 hexapods; an odd number of waves, so the last two-wave workgroup is half empty):
+    every instance of such a batch against the oracle, single-cycle and fused launches."""
     p = default_hexapod_params("ripple")
     n = 10300
     inp = make_inputs(p, n, 53)
