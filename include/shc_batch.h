@@ -90,6 +90,7 @@ typedef struct shc_params {
   int32_t velocity_input_mode;
   double stance_position[SHC_MAX_LEGS][2];
   int32_t overlapping_walkspaces, force_normal_touchdown, gravity_aligned_tips;
+  int32_t leg_manipulation_mode; /* default.yaml:120: SHC_MANIPULATION_TIP_CONTROL / _JOINT_CONTROL (WalkController::updateManual) */
   /* poser (default.yaml:110-118) */
   double time_to_start;
   double rotation_pid_gains[3];  /* p, i, d */
@@ -415,13 +416,35 @@ int shc_engine_direct_startup(shc_engine *e, int32_t *progress);
  *       (default.yaml "packed" may list several steps per joint).  *progress as the reference returns it (0 between pack steps,
  *       100 when done); the pack step and "transition executing" flag are PoseController members, kept per engine (every
  *       instance runs the same number of iterations).
- * poseForLegManipulation (:561) needs manually controlled legs, which the batched engine does not model.
  */
+enum { SHC_MANIPULATION_TIP_CONTROL = 0, SHC_MANIPULATION_JOINT_CONTROL = 1 };
 enum { SHC_SEQUENCE_START_UP = 0, SHC_SEQUENCE_SHUT_DOWN = 1 }; /* enum SequenceSelection (parameters_and_states.h:183-188) */
 int shc_engine_begin_sequence_startup(shc_engine *e, const double *joint_positions, int per_instance);
 int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t *progress);
 int shc_engine_finish_sequence_startup(shc_engine *e);
 int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress);
+/*
+ * Manual leg manipulation: StateController::legStateToggle (state_controller.cpp:541-646) with PoseController::
+ * poseForLegManipulation (pose_controller.cpp:561-611), and WalkController::updateManual (walk_controller.cpp:652-744, both overloads)
+ * inside the control cycle.
+ *   shc_engine_toggle_leg_state   ONE legStateToggle call per instance for the leg its request designates: leg_selection [n]
+ *       (host; -1 = no request).  result rows [n]: 1 = transition complete (WALKING <-> MANUAL: the node clears its toggle flag),
+ *       0 = in progress, 2 = refused (MAX_MANUAL_LEGS = 2 already manual), -1 = the robot is still walking (the node zeroes its
+ *       velocity inputs and keeps cycling, :641-645), -3 = no request.  While a robot has a leg that is not WALKING its walker
+ *       is frozen (updateWalk returns at walk_controller.cpp:503); MANUAL / WALKING_TO_MANUAL legs are not posed (updateStance).
+ *       Supported while the body pose is walk-plane pose + manual pose (no IMU / auto / inclination posing, no tip-align pose):
+ *       SHC_ERR_UNSUPPORTED otherwise.
+ *   shc_engine_set_manual_inputs  primary / secondary leg selection [n] (-1 = LEG_UNDESIGNATED) with their tip velocity inputs
+ *       [n][3] (updateManual(.., tip_velocity_input, ..): tip_control moves the tip, joint_control the coxa / tibia joints of
+ *       3-DOF legs, params.leg_manipulation_mode) and tip position inputs [n][3] (updateManual(.., Pose, ..); a zero vector
+ *       = none).  Host arrays, any may be NULL.
+ *   shc_engine_get_leg_manipulation_state  enum LegState per (instance, leg): 0 WALKING, 1 MANUAL, -1 WALKING_TO_MANUAL,
+ *       -2 MANUAL_TO_WALKING.
+ */
+int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_selection, int32_t *result);
+int shc_engine_set_manual_inputs(shc_engine *e, const int32_t *primary_leg, const double *primary_tip_velocity, const double *primary_tip_position,
+                                 const int32_t *secondary_leg, const double *secondary_tip_velocity, const double *secondary_tip_position);
+int shc_engine_get_leg_manipulation_state(shc_engine *e, int32_t *states);
 int shc_engine_pack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_pack, int32_t *progress);
 int shc_engine_unpack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_unpack, int32_t *progress);
 

@@ -90,6 +90,19 @@ public:
     check(shc_engine_finish_sequence_startup(e_), "shc_engine_finish_sequence_startup");
     invalidate();
   }
+  // StateController::legStateToggle (state_controller.cpp:541-646) for leg `leg_id`, one call per loop while the node's toggle flag is
+  // set: 1 = transition complete, 0 = in progress, 2 = refused (MAX_MANUAL_LEGS), -1 = the robot is still walking (keep cycling
+  // with zero velocity inputs)
+  int legStateToggle(int leg_id) {
+    if (n_ != 1) throw std::runtime_error("shc_facade: legStateToggle takes one leg of one robot: use shc_engine_toggle_leg_state for a batch");
+    const int32_t sel = leg_id;
+    int32_t result = 0;
+    check(shc_engine_toggle_leg_state(e_, &sel, &result), "shc_engine_toggle_leg_state");
+    manual_legs_ = true;
+    invalidate();
+    return result;
+  }
+  bool manual_legs_ = false;
   // StateController::changeGait (state_controller.cpp:513): true once the gait has changed, false while the robots are
   // still being stopped (keep cycling and call again, as the reference does while gait_change_flag_ is set)
   bool changeGait(const shc_params &new_gait) {
@@ -360,14 +373,25 @@ public:
     require_single(*eng_, "updateWalk");
     check(shc_engine_set_velocity(eng_->handle(), lin, &ang, 0), "set_velocity");
   }
-  // void updateManual(primary_leg_selection_ID, primary_tip_velocity_input, secondary_leg_selection_ID, ...)   walk_controller.h:213
-  // void updateManual(primary_leg_selection_ID, primary_tip_pose_input, secondary_leg_selection_ID, ...)       walk_controller.h:223
-  // Manual leg manipulation needs legs in LegState MANUAL (toggled through PoseController::poseForLegManipulation, a
-  // sequence outside the accelerated path); the engine keeps every leg WALKING, for which both overloads are no-ops
-  // (walk_controller.cpp:661, :722: "if (leg->getLegState() == MANUAL)").
-  template <class V3>
-  void updateManual(const int & /*primary_leg_selection_ID*/, const V3 & /*primary_input*/, const int & /*secondary_leg_selection_ID*/,
-                    const V3 & /*secondary_input*/) {}
+  // void updateManual(primary_leg_selection_ID, primary_tip_velocity_input, secondary_leg_selection_ID, secondary_tip_velocity_input)
+  //                                                                                                     walk_controller.h:213
+  // The inputs are latched for the next control cycle, whose fused kernel moves the tips of MANUAL legs (walk_controller.cpp:652-708).
+  void updateManual(const int &primary_leg_selection_ID, const Vector3 &primary_tip_velocity_input, const int &secondary_leg_selection_ID,
+                    const Vector3 &secondary_tip_velocity_input) {
+    require_single(*eng_, "updateManual");
+    primary_ = primary_leg_selection_ID, secondary_ = secondary_leg_selection_ID;
+    pvel_ = primary_tip_velocity_input, svel_ = secondary_tip_velocity_input;
+    push_manual();
+  }
+  // void updateManual(primary_leg_selection_ID, primary_tip_pose_input, secondary_leg_selection_ID, secondary_tip_pose_input)
+  //                                                                                                     walk_controller.h:223
+  void updateManual(const int &primary_leg_selection_ID, const Pose &primary_tip_pose_input, const int &secondary_leg_selection_ID,
+                    const Pose &secondary_tip_pose_input) {
+    require_single(*eng_, "updateManual");
+    primary_ = primary_leg_selection_ID, secondary_ = secondary_leg_selection_ID;
+    ppos_ = primary_tip_pose_input.position_, spos_ = secondary_tip_pose_input.position_;
+    push_manual();
+  }
   int getWalkState(int64_t index = 0) const { return eng_->walk_state()[size_t(index)]; } // walk_controller.h:92
   std::array<double, 2> getDesiredLinearVelocity(int64_t index = 0) const {               // :100
     return {eng_->velocity()[size_t(index) * 3], eng_->velocity()[size_t(index) * 3 + 1]};
@@ -379,7 +403,14 @@ public:
   }
 
 private:
+  void push_manual() {
+    const int32_t p = primary_, q = secondary_;
+    if (!eng_->manual_legs_) return; // every leg is WALKING: both overloads do nothing (walk_controller.cpp:661, :722)
+    check(shc_engine_set_manual_inputs(eng_->handle(), &p, pvel_.v, ppos_.v, &q, svel_.v, spos_.v), "shc_engine_set_manual_inputs");
+  }
   std::shared_ptr<Engine> eng_;
+  int primary_ = -1, secondary_ = -1; // LEG_UNDESIGNATED
+  Vector3 pvel_{{0, 0, 0}}, svel_{{0, 0, 0}}, ppos_{{0, 0, 0}}, spos_{{0, 0, 0}};
 };
 
 // class PoseController (pose_controller.h:36)

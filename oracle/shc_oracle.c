@@ -43,7 +43,9 @@
 #define HALF_BODY_DEPTH 0.05           /* model.h:18 */
 enum { SEQ_START_UP = 0, SEQ_SHUT_DOWN = 1 }; /* enum SequenceSelection, parameters_and_states.h:183-188 */
 
-enum { WALKING = 0 };                                             /* parameters_and_states.h:87 */
+enum { WALKING = 0, MANUAL = 1, WALKING_TO_MANUAL = -1, MANUAL_TO_WALKING = -2 }; /* enum LegState, parameters_and_states.h:87-94 */
+#define MAX_MANUAL_LEGS 2 /* state_controller.h:26 */
+#define LEG_UNDESIGNATED (-1) /* parameters_and_states.h:159 */
 enum { STARTING = 0, MOVING = 1, STOPPING = 2, STOPPED = 3 };     /* :99 */
 enum { SWING = 0, STANCE = 1, FORCE_STANCE = 2, FORCE_STOP = 3 }; /* :111 */
 enum { POSING = 0, STOP_POSING = 1, POSING_COMPLETE = 2 };        /* :123 */
@@ -210,6 +212,10 @@ struct orc_robot
   int set_target, proximity_alert, horizontal_transition_complete, vertical_transition_complete;
   int first_sequence_execution, reset_transition_sequence, sequence_failed;
   int pack_step; /* pose_controller.h:298 */
+  /* manual leg manipulation: StateController members (state_controller.h:330-360) */
+  int manual_leg_count, primary_leg_selection, secondary_leg_selection;
+  orc_v3 primary_tip_velocity_input, secondary_tip_velocity_input;
+  orc_pose primary_pose_input, secondary_pose_input;
   auto_poser_t auto_poser[SHC_MAX_AUTO_POSERS];
   int n_auto_posers;
   int auto_posing_state, pose_phase;
@@ -1355,7 +1361,9 @@ static void walker_update_walk(orc_robot *r, const double lin_in[2], double ang_
 
   int has_velocity_command = (lin_norm != 0.0) || (ang_in != 0.0);
 
-  /* all legs WALKING on this path (:492-505) */
+  /* check that all legs are in WALKING state (:492-505) */
+  for (int l = 0; l < r->leg_count; ++l)
+    if (r->leg[l].leg_state != WALKING) return;
 
   double la[2] = { new_linear_velocity[0] - r->desired_linear_velocity[0], new_linear_velocity[1] - r->desired_linear_velocity[1] };
   double la_norm = sqrt(la[0] * la[0] + la[1] * la[1]);
@@ -1920,6 +1928,11 @@ static void poser_update_stance(orc_robot *r)
   {
     leg_t *leg = &r->leg[l];
     orc_pose current_pose = r->current_pose;
+    if (leg->leg_state == MANUAL || leg->leg_state == WALKING_TO_MANUAL)
+    { /* do not apply any posing to manually manipulated legs (:135-139) */
+      leg->poser.current_tip_pose = leg->stepper.current_tip_pose;
+      continue;
+    }
     current_pose = orc_pose_remove(current_pose, r->auto_pose);
     current_pose = orc_pose_add(current_pose, leg->poser.auto_pose);
     orc_v3 new_tip_position = orc_pose_inverse_transform_vector(current_pose, leg->stepper.current_tip_pose.p);
@@ -2368,6 +2381,167 @@ static int poser_pack_legs(orc_robot *r, const double *packed_positions, int num
   return progress;
 }
 
+/* ==================================================================================== manual leg manipulation */
+
+/* WalkController::updateManual, tip-velocity overload (walk_controller.cpp:652-708).  A MANUAL leg that is neither the primary
+ * nor the secondary selection reads an uninitialised Eigen vector in the reference; here its input is zero. */
+static void walker_update_manual_velocity(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    if (leg->leg_state != MANUAL) continue;
+    orc_v3 tip_velocity_input = orc_v3_make(0, 0, 0);
+    if (leg->id_number == r->primary_leg_selection) tip_velocity_input = r->primary_tip_velocity_input;
+    else if (leg->id_number == r->secondary_leg_selection) tip_velocity_input = r->secondary_tip_velocity_input;
+    if (orc_v3_norm(tip_velocity_input) == 0.0) continue;
+    if (r->params.leg_manipulation_mode == SHC_MANIPULATION_JOINT_CONTROL && leg->joint_count == 3)
+    { /* x / y velocity inputs move the tibia / coxa joints (:677-690) */
+      double coxa_joint_velocity = tip_velocity_input.y * r->params.max_rotation_velocity * r->time_delta;
+      double tibia_joint_velocity = tip_velocity_input.x * r->params.max_rotation_velocity * r->time_delta;
+      leg->joint[0].prev_desired_position = leg->joint[0].desired_position;
+      leg->joint[2].prev_desired_position = leg->joint[2].desired_position;
+      leg->joint[0].desired_position += coxa_joint_velocity;
+      leg->joint[2].desired_position += tibia_joint_velocity;
+      /* Leg::applyFK(false) (model.cpp:945-988): the joint transforms follow the new joint positions, current_tip_pose_ /
+       * current_tip_velocity_ are left alone */
+      orc_pose keep_pose = leg->current_tip_pose;
+      orc_v3 keep_velocity = leg->current_tip_velocity;
+      leg->stepper.current_tip_pose = leg_apply_fk(r, leg);
+      leg->current_tip_pose = keep_pose;
+      leg->current_tip_velocity = keep_velocity;
+    }
+    else if (r->params.leg_manipulation_mode == SHC_MANIPULATION_TIP_CONTROL)
+    {
+      orc_v3 ik_error = orc_v3_sub(leg->desired_tip_pose.p, leg->current_tip_pose.p);
+      orc_v3 tip_position_change = orc_v3_scale(tip_velocity_input, r->params.max_translation_velocity * r->time_delta);
+      if (orc_v3_norm(ik_error) >= IK_TOLERANCE)
+        tip_position_change = orc_v3_scale(orc_v3_neg(orc_v3_normalized(ik_error)), orc_v3_norm(tip_position_change));
+      leg->stepper.current_tip_pose = orc_pose_make(orc_v3_add(leg->stepper.current_tip_pose.p, tip_position_change), ORC_UNDEFINED_ROTATION);
+    }
+  }
+}
+
+/* WalkController::updateManual, tip-pose overload (walk_controller.cpp:712-744) */
+static void walker_update_manual_pose(orc_robot *r)
+{
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    if (leg->leg_state != MANUAL) continue;
+    orc_v3 tip_position_input = orc_v3_make(0, 0, 0);
+    if (leg->id_number == r->primary_leg_selection) tip_position_input = r->primary_pose_input.p;
+    else if (leg->id_number == r->secondary_leg_selection) tip_position_input = r->secondary_pose_input.p;
+    if (orc_v3_norm(tip_position_input) != 0.0 && r->params.leg_manipulation_mode == SHC_MANIPULATION_TIP_CONTROL)
+      leg->stepper.current_tip_pose = orc_pose_make(tip_position_input, ORC_UNDEFINED_ROTATION);
+  }
+}
+
+/* PoseController::poseForLegManipulation (pose_controller.cpp:561-611), simultaneous leg coordination */
+static int poser_pose_for_leg_manipulation(orc_robot *r)
+{
+  int min_progress = INT_MAX; /* UNASSIGNED_VALUE */
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    stepper_t *st = &leg->stepper;
+    double step_height = r->params.swing_height;
+    double step_time = 1.0 / r->params.step_frequency;
+    orc_pose target_pose;
+    if (leg->leg_state == WALKING_TO_MANUAL)
+    {
+      target_pose = orc_pose_identity();
+      target_pose.p = orc_v3_add(target_pose.p, r->inclination_pose.p); /* inclination control for the lifted leg */
+      target_pose.p.z -= step_height;                                    /* pose the leg at step height */
+    }
+    else
+    {
+      target_pose = r->current_pose;
+      target_pose.p = orc_v3_sub(target_pose.p, r->manual_pose.p);
+      target_pose.p = orc_v3_add(target_pose.p, r->pc_default_pose.p); /* (calculateDefaultPose is never called: identity) */
+    }
+    orc_pose target_tip_pose = orc_pose_undefined();
+    target_tip_pose.p = orc_pose_inverse_transform_vector(target_pose, st->default_tip_pose.p);
+    if (leg->leg_state == WALKING_TO_MANUAL)
+    {
+      st->current_tip_pose = target_tip_pose;
+      step_height = 0.0;
+    }
+    else if (leg->leg_state == MANUAL_TO_WALKING)
+    {
+      st->current_tip_pose = st->default_tip_pose;
+    }
+    int progress = leg_poser_step_to_position(r, leg, target_tip_pose, orc_pose_identity(), step_height, step_time, 1);
+    if (progress < min_progress) min_progress = progress;
+    if (progress != PROGRESS_COMPLETE)
+    {
+      leg_set_desired_tip_pose(leg, leg->poser.current_tip_pose, 1);
+      leg_apply_ik(r, leg, 0);
+    }
+  }
+  return min_progress;
+}
+
+/* AdmittanceController::updateStiffness(leg, scale_reference) (admittance_controller.cpp:66-92) */
+static void admittance_update_stiffness_leg(orc_robot *r, leg_t *leg, double scale_reference)
+{
+  leg_t *adj1 = &r->leg[orc_mod(leg->id_number - 1, r->leg_count)];
+  leg_t *adj2 = &r->leg[orc_mod(leg->id_number + 1, r->leg_count)];
+  double virtual_stiffness = r->params.virtual_stiffness;
+  double swing_stiffness = virtual_stiffness * (scale_reference * (r->params.swing_stiffness_scaler - 1) + 1);
+  double load_stiffness = virtual_stiffness * (scale_reference * (r->params.load_stiffness_scaler - 1) + 1);
+  leg->virtual_stiffness = swing_stiffness;
+  if (adj1->leg_state != MANUAL) adj1->virtual_stiffness = load_stiffness;
+  if (adj2->leg_state != MANUAL) adj2->virtual_stiffness = load_stiffness;
+}
+
+/* StateController::legStateToggle (state_controller.cpp:541-646) for the leg the toggle request designates.
+ * Returns 1 when the transition has completed (the request flag is cleared), 2 when the request was refused (MAX_MANUAL_LEGS),
+ * 0 while it is in progress, -1 while the robot still has to stop walking (velocity inputs zeroed). */
+static int state_leg_state_toggle(orc_robot *r, int leg_id)
+{
+  if (r->walk_state != STOPPED)
+  {
+    r->linear_velocity_input[0] = r->linear_velocity_input[1] = 0.0;
+    r->angular_velocity_input = 0.0;
+    return -1;
+  }
+  leg_t *leg = &r->leg[leg_id];
+  if (leg->leg_state == WALKING)
+  {
+    if (r->manual_leg_count < MAX_MANUAL_LEGS)
+    {
+      leg->leg_state = WALKING_TO_MANUAL;
+      leg->stepper.swing_progress = -1.0;
+      leg->stepper.stance_progress = -1.0;
+      return 0;
+    }
+    return 2;
+  }
+  if (leg->leg_state == MANUAL)
+  {
+    leg->leg_state = MANUAL_TO_WALKING;
+    return 0;
+  }
+  int to_manual = (leg->leg_state == WALKING_TO_MANUAL);
+  r->pose_reset_mode = SHC_IMMEDIATE_ALL_RESET; /* force the pose to the new default pose */
+  int progress = poser_pose_for_leg_manipulation(r);
+  if (r->params.dynamic_stiffness)
+  {
+    double scale_reference = (double)progress / PROGRESS_COMPLETE;
+    if (!to_manual) scale_reference = fabs(scale_reference - 1.0);
+    admittance_update_stiffness_leg(r, leg, scale_reference);
+  }
+  if (progress == PROGRESS_COMPLETE)
+  {
+    leg->leg_state = to_manual ? MANUAL : WALKING;
+    r->pose_reset_mode = SHC_NO_RESET;
+    r->manual_leg_count += to_manual ? 1 : -1;
+    return 1;
+  }
+  return 0;
+}
+
 /* ==================================================================================== AdmittanceController */
 
 /* AdmittanceController::updateAdmittance (admittance_controller.cpp:22-63) for one leg.
@@ -2488,9 +2662,13 @@ static void model_generate_workspaces(orc_robot *r)
 }
 
 /* StateController::runningState (state_controller.cpp:379-447), no transitions / gait change / manual legs */
+static void walker_update_manual_velocity(orc_robot *r);
+static void walker_update_manual_pose(orc_robot *r);
 static void state_running_state(orc_robot *r)
 {
   walker_update_walk(r, r->linear_velocity_input, r->angular_velocity_input);
+  walker_update_manual_velocity(r); /* :433-434 */
+  walker_update_manual_pose(r);     /* :439-440 */
   poser_update_stance(r);
   model_update_model(r);
 }
@@ -2558,6 +2736,7 @@ orc_robot *orc_create(const shc_params *params)
   r->default_pose = orc_pose_identity();
   r->imu_orientation = ORC_UNDEFINED_ROTATION;
   r->imu_angular_velocity = orc_v3_make(0, 0, 0);
+  r->primary_leg_selection = r->secondary_leg_selection = LEG_UNDESIGNATED;
   r->set_target = 1; /* pose_controller.h:299-304 */
   r->first_sequence_execution = 1;
   r->reset_transition_sequence = 1;
@@ -3426,6 +3605,31 @@ void orc_sequence_finish_startup(orc_robot *r)
   state_running_state(r);
 }
 void orc_sequence_finish_shutdown(orc_robot *r) { r->robot_state = RS_READY; r->new_robot_state = RS_RUNNING; }
+
+/* ---- manual leg manipulation.  orc_leg_state_toggle = one StateController::loop() with the toggle request for `leg` pending:
+ * the posing part (:165-181), then runningState -> legStateToggle (:396-400; no tip update while the robot is STOPPED); while
+ * the robot is still walking the request only zeroes the velocity inputs and the loop runs its normal cycle (:641-645, :421-446). */
+int orc_leg_state_toggle(orc_robot *r, int leg)
+{
+  orc_sequence_prologue(r);
+  int result = state_leg_state_toggle(r, leg);
+  if (result == -1) state_running_state(r);
+  return result;
+}
+int orc_get_leg_manipulation_state(const orc_robot *r, int leg) { return r->leg[leg].leg_state; }
+/* primaryLegSelectionCallback / primaryTipVelocityInputCallback / primaryPoseInput ... (state_controller.cpp:1247-1330) */
+void orc_set_manual_inputs(orc_robot *r, int primary_leg, const double *primary_tip_velocity, const double *primary_tip_position,
+                           int secondary_leg, const double *secondary_tip_velocity, const double *secondary_tip_position)
+{
+  r->primary_leg_selection = primary_leg;
+  r->secondary_leg_selection = secondary_leg;
+  r->primary_tip_velocity_input = primary_tip_velocity ? orc_v3_make(primary_tip_velocity[0], primary_tip_velocity[1], primary_tip_velocity[2]) : orc_v3_make(0, 0, 0);
+  r->secondary_tip_velocity_input = secondary_tip_velocity ? orc_v3_make(secondary_tip_velocity[0], secondary_tip_velocity[1], secondary_tip_velocity[2]) : orc_v3_make(0, 0, 0);
+  r->primary_pose_input = orc_pose_identity();
+  r->secondary_pose_input = orc_pose_identity();
+  r->primary_pose_input.p = primary_tip_position ? orc_v3_make(primary_tip_position[0], primary_tip_position[1], primary_tip_position[2]) : orc_v3_make(0, 0, 0);
+  r->secondary_pose_input.p = secondary_tip_position ? orc_v3_make(secondary_tip_position[0], secondary_tip_position[1], secondary_tip_position[2]) : orc_v3_make(0, 0, 0);
+}
 
 /* ------------------------------------------------------------------------------------ unit-level entry points */
 void orc_test_generate_step_cycle(const shc_params *p, shc_step_cycle *out) { *out = generate_step_cycle(p); }

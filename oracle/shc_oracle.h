@@ -104,6 +104,10 @@ int orc_pack_legs(orc_robot *r, const double *packed_positions /* [steps][legs][
 int orc_unpack_legs(orc_robot *r, const double *packed_positions, int number_pack_steps, double time_to_unpack);                        /* :662 */
 void orc_sequence_finish_startup(orc_robot *r);                              /* state_controller.cpp:305-313 */
 void orc_sequence_finish_shutdown(orc_robot *r);
+int orc_leg_state_toggle(orc_robot *r, int leg);                            /* state_controller.cpp:541-646 */
+int orc_get_leg_manipulation_state(const orc_robot *r, int leg);
+void orc_set_manual_inputs(orc_robot *r, int primary_leg, const double *primary_tip_velocity, const double *primary_tip_position,
+                           int secondary_leg, const double *secondary_tip_velocity, const double *secondary_tip_position); /* :1247-1330 */
 int orc_set_external_target(orc_robot *r, int which, int leg, const shc_external_target *t);   /* state_controller.cpp:1706 */
 void orc_set_external_transform(orc_robot *r, int which, int leg, const double *transform);   /* :703-773 */
 void orc_get_external_target(const orc_robot *r, int which, int leg, shc_external_target *out);

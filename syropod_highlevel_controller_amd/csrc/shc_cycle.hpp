@@ -43,7 +43,7 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // origins of the per-leg planes, which change once per step period).
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
-enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4 }; // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
+enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8 }; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
@@ -154,6 +154,16 @@ struct ExtFields {
                        D_POSE = 16, D_TRANSFORM = 23, D_FLAGS = 30, COUNT = 32;     // external_default_
 };
 
+// Manual leg manipulation (WalkController::updateManual, StateController::legStateToggle): per-robot record in a lazily allocated
+// array - only engines that ever toggled a leg carry it, and only the F_TERRAIN kernels read it.
+enum : int { LS_WALKING = 0, LS_MANUAL = 1, LS_WALKING_TO_MANUAL = -1, LS_MANUAL_TO_WALKING = -2 }; // enum LegState (parameters_and_states.h:87-94)
+struct ManualRobot {
+  int32_t leg_state[SHC_MAX_LEGS];
+  int32_t manual_leg_count, primary_leg, secondary_leg, pad_; // StateController::manual_leg_count_, primary / secondary_leg_selection_
+  double primary_velocity[3], secondary_velocity[3];         // primary / secondary_tip_velocity_input_
+  double primary_position[3], secondary_position[3];         // primary / secondary_pose_input_.position_
+};
+
 struct DevState {
   double *legd;
   int32_t *legi;
@@ -161,6 +171,7 @@ struct DevState {
   int32_t *robi;
   int64_t n_slots, n_rob_pad, n_robots;
   double *ext; // ExtFields planes, nullptr until the first external request
+  ManualRobot *manual; // nullptr until a leg is toggled
 };
 
 #if defined(__HIPCC__)
@@ -330,7 +341,7 @@ __device__ __forceinline__ int bearing_bracket(double y, double x) {
 template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                       const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
-                                      const bool manual_live, const bool touchdown_detection, double *ext) {
+                                      const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
@@ -370,6 +381,15 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   SHC_TICK(3);
   int rword = rb.geti(R::I_WORD);
   int walk_state = rword & 3;
+  // Manual leg manipulation: while any leg of the robot is not WALKING, updateWalk returns before it touches velocities, walk
+  // state or steppers (walk_controller.cpp:492-505)
+  int my_leg_state = LS_WALKING;
+  bool frozen = false;
+  if ((F & F_TERRAIN) != 0 && mr != nullptr) {
+    my_leg_state = mr->leg_state[leg];
+#pragma unroll
+    for (int j = 0; j < L; ++j) frozen = frozen || g.get(my_leg_state, j) != LS_WALKING;
+  }
 
   // =============================================================== PoseController::updateCurrentPose (:811-859)
   Pose cp; // Model::current_pose_
@@ -758,6 +778,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       nvy = cy * sc;
     }
     if (walk_state == WS_STOPPING) nvx = nvy = nw = 0.0; // :483-487
+    if (frozen) nvx = vx, nvy = vy, nw = vw; // (a robot with a manual leg keeps its desired velocities: zero acceleration below)
     // acceleration-limited approach (:508-527)
     const double ax = nvx - vx, ay = nvy - vy;
     const double an2 = ax * ax + ay * ay;
@@ -790,7 +811,9 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   bool my_acp = (s.word & LW_ACP) != 0, my_cfs = (s.word & LW_CFS) != 0;
   bool my_update_default = false;
   bool any_stepping = false;
-  if (walk_state == WS_STOPPED && has_cmd) {
+  if (frozen) {
+    early_return = true; // updateWalk returned at :503
+  } else if (walk_state == WS_STOPPED && has_cmd) {
     walk_state = WS_STARTING;
     my_acp = false;
     my_cfs = false;
@@ -1115,6 +1138,37 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       rb.put(R::ODOM + 3, ow * sh + oz * ch);
     }
   }
+  // =============================================================== WalkController::updateManual x 2 (walk_controller.cpp:652-744)
+  if ((F & F_TERRAIN) != 0 && mr != nullptr && my_leg_state == LS_MANUAL) {
+    const bool primary = leg == mr->primary_leg, secondary = !primary && leg == mr->secondary_leg;
+    // (a MANUAL leg that is neither selection reads an uninitialised vector in the reference: its inputs are zero here)
+    V3 vin{0, 0, 0}, pin{0, 0, 0};
+    if (primary) {
+      vin = V3{mr->primary_velocity[0], mr->primary_velocity[1], mr->primary_velocity[2]};
+      pin = V3{mr->primary_position[0], mr->primary_position[1], mr->primary_position[2]};
+    } else if (secondary) {
+      vin = V3{mr->secondary_velocity[0], mr->secondary_velocity[1], mr->secondary_velocity[2]};
+      pin = V3{mr->secondary_position[0], mr->secondary_position[1], mr->secondary_position[2]};
+    }
+    if (norm(vin) != 0.0) { // tip_control (:690-704); joint_control (:677-690) is rejected by the host
+      // ik_error = desired - current tip of the last updateModel: a leg that could not follow is pushed back towards its tip
+      V3 prev_tip;
+      if (LegRegs<NJ>::kKeepJacobian) {
+        prev_tip = tip_robot_frame(lc, s.pe);
+      } else {
+        Chain<NJ> ch0;
+        chain_from_sincos<NJ>(lc, s.sn, s.cs, ch0);
+        prev_tip = tip_robot_frame(lc, ch0.pe);
+      }
+      const double2 d01 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::DES_TIP / 2) * ns + slot];
+      const double2 d23 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::DES_TIP / 2 + 1) * ns + slot];
+      const V3 ik_error = V3{d01.x, d01.y, d23.x} - prev_tip;
+      V3 change = vin * (P.max_translation_velocity * P.dt);
+      if (norm(ik_error) >= kIkTolerance) change = (-normalized(ik_error)) * norm(change);
+      s.tip = s.tip + change;
+    }
+    if (norm(pin) != 0.0) s.tip = pin; // tip-pose overload (:712-744): the requested position, rotation undefined
+  }
   s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL | LW_ROTDEF)) |
            my_state | (my_acp ? LW_ACP : 0) | (my_cfs ? LW_CFS : 0) | (my_pm << LW_PM_SHIFT) | (my_phase << LW_PHASE_SHIFT) |
            (rot_def ? LW_ROTDEF : 0);
@@ -1130,6 +1184,8 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       bp = add_pose(bp, leg_auto);
     }
     out.poser_tip = (SHC_DBG(P) & 256) ? s.tip : inverse_transform_vector(bp, s.tip);
+    // no posing for manually manipulated legs (:135-139)
+    if ((F & F_TERRAIN) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL)) out.poser_tip = s.tip;
     if (rot_on && rot_def) desired_dir = rotate(inverse(bp.r), s.cur_dir); // pose.rotation^-1 * walker tip rotation (:129-130)
   }
 
@@ -1138,6 +1194,11 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   {
     SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
+    if ((F & F_TERRAIN) != 0 && mr != nullptr) { // Leg::desired_tip_pose_.position_ is read back by the next updateManual (:692)
+      double *dd = const_cast<double *>(legd);
+      reinterpret_cast<double2 *>(dd)[(Fields<NJ>::DES_TIP / 2) * ns + slot] = double2{desired.x, desired.y};
+      dd[((Fields<NJ>::DES_TIP / 2 + 1) * ns + slot) * 2] = desired.z;
+    }
     Chain<NJ> chain;
     bool retried = false; // the unconstrained retry is a nested applyIK: calculateTipForce then runs twice (:938 in both frames)
     if (rot_on) {

@@ -338,7 +338,9 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   SHC_TICK(1);
   unsigned dirty = 0;
   double *const ext = ((F & F_TERRAIN) != 0 && (rt_flags & RT_EXTERNAL) != 0) ? st.ext : nullptr; // external targets (rough terrain mode)
-  for (int c = 0; c < n_cycles; ++c) cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext);
+  const ManualRobot *const mr = ((F & F_TERRAIN) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0 && any_robot) ? st.manual + (rob0 + grp) : nullptr;
+  for (int c = 0; c < n_cycles; ++c)
+    cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr);
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
@@ -1151,6 +1153,7 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->st.robd);
   (void)hipFree(e->st.robi);
   (void)hipFree(e->st.ext);
+  (void)hipFree(e->st.manual);
   (void)hipFree(e->d_seq);
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
@@ -1333,7 +1336,7 @@ static void launch_cycle_feat(shc_engine *e, unsigned grid, int block, int n_cyc
                (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0) | (c.odometry ? F_ODOM : 0);
   // rough terrain mode / the tip-align pose: generic kernels with that logic compiled in (kept out of the plain generic
   // kernel, which would otherwise spill)
-  const bool terrain = c.rough_terrain || c.tip_align;
+  const bool terrain = c.rough_terrain || c.tip_align || (e->rt_flags & RT_MANUAL_LEGS) != 0;
   if constexpr (NJ > 3) {
     if (c.gravity_aligned) { // gravity-aligned tips: the generic kernel with the tip-rotation logic compiled in
       if (terrain) launch_cycle<L, NJ, F_DYN | F_ROT | F_TERRAIN>(e, grid, block, n_cycles);
@@ -2304,6 +2307,96 @@ extern "C" int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t 
 }
 
 extern "C" int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress) { return sequence_launch(e, 2, progress); }
+
+// ---- manual leg manipulation (shc_sequence.hpp)
+static int ensure_manual(shc_engine *e) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  const shc_params &p = e->params;
+  if (p.imu_posing || p.auto_posing || p.inclination_posing || e->cp.tip_align)
+    return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation with IMU / auto / inclination posing or the tip-align pose (the toggle's pose reset assumes "
+                                     "walk-plane + manual posing only)");
+  // joint_control hands the FK tip pose WITH its rotation to the stepper (walk_controller.cpp:688-689), which makes the following
+  // applyIK rotation-constrained on 3-DOF legs: outside the accelerated path
+  if (p.leg_manipulation_mode != SHC_MANIPULATION_TIP_CONTROL) return fail(SHC_ERR_UNSUPPORTED, "leg_manipulation_mode joint_control");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!e->st.manual) {
+    HIP_TRY(hipMalloc(&e->st.manual, sizeof(ManualRobot) * size_t(e->n_rob_pad)));
+    HIP_TRY(hipMemsetAsync(e->st.manual, 0, sizeof(ManualRobot) * size_t(e->n_rob_pad), e->stream)); // all WALKING
+    std::vector<int32_t> none(size_t(e->n), -1);
+    HIP_TRY(hipMemcpyAsync(e->d_stage, none.data(), none.size() * 4, hipMemcpyHostToDevice, e->stream));
+    set_manual_inputs_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(e->st.manual, e->n, reinterpret_cast<const int32_t *>(e->d_stage), nullptr,
+                                                                                          nullptr, reinterpret_cast<const int32_t *>(e->d_stage), nullptr, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  e->rt_flags |= RT_MANUAL_LEGS | RT_MANUAL_LIVE; // (the toggle resets the manual pose: its group of the robot tile is live from now on)
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_selection, int32_t *result) {
+  int rc = ensure_manual(e);
+  if (rc != SHC_OK) return rc;
+  if (!leg_selection) return fail(SHC_ERR_INVALID_ARG, "leg_selection is NULL");
+  int32_t *d_sel = reinterpret_cast<int32_t *>(e->d_stage), *d_res = d_sel + e->n;
+  HIP_TRY(hipMemcpyAsync(d_sel, leg_selection, size_t(e->n) * 4, hipMemcpyHostToDevice, e->stream));
+  SeqParams P{};
+  P.step_frequency = e->params.step_frequency;
+  P.swing_height = e->params.swing_height;
+  P.dt = e->params.time_delta;
+  P.force_gain = e->params.force_gain;
+  P.clamp_vel = e->params.clamp_joint_velocities;
+  P.clamp_pos = e->params.clamp_joint_positions;
+  P.tip_force = e->cp.tip_force;
+  P.have_adm = e->params.admittance_control;
+  P.gravity_aligned = e->cp.gravity_aligned;
+  const dim3 grid((unsigned)((e->n + 63) / 64)), block(64);
+#define CALL(L_, NJ_)                                                                                                                              \
+  leg_state_toggle_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, d_sel, P, e->params.virtual_stiffness, \
+                                                                  e->params.swing_stiffness_scaler, e->params.load_stiffness_scaler,                \
+                                                                  e->params.admittance_control && e->params.dynamic_stiffness, d_res)
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  if (result) HIP_TRY(hipMemcpyAsync(result, d_res, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_set_manual_inputs(shc_engine *e, const int32_t *primary_leg, const double *primary_tip_velocity, const double *primary_tip_position,
+                                            const int32_t *secondary_leg, const double *secondary_tip_velocity, const double *secondary_tip_position) {
+  int rc = ensure_manual(e);
+  if (rc != SHC_OK) return rc;
+  // staging layout: [primary leg | secondary leg] ints, then four [n][3] double blocks
+  const size_t n = size_t(e->n);
+  if (n * 8 + 4 * n * 24 > e->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
+  char *base = reinterpret_cast<char *>(e->d_stage);
+  int32_t *d_p = reinterpret_cast<int32_t *>(base), *d_s = d_p + n;
+  double *d_v[4];
+  for (int k = 0; k < 4; ++k) d_v[k] = reinterpret_cast<double *>(base + n * 8) + size_t(k) * n * 3;
+  const double *src[4] = {primary_tip_velocity, primary_tip_position, secondary_tip_velocity, secondary_tip_position};
+  if (primary_leg) HIP_TRY(hipMemcpyAsync(d_p, primary_leg, n * 4, hipMemcpyHostToDevice, e->stream));
+  if (secondary_leg) HIP_TRY(hipMemcpyAsync(d_s, secondary_leg, n * 4, hipMemcpyHostToDevice, e->stream));
+  for (int k = 0; k < 4; ++k)
+    if (src[k]) HIP_TRY(hipMemcpyAsync(d_v[k], src[k], n * 24, hipMemcpyHostToDevice, e->stream));
+  set_manual_inputs_kernel<<<dim3((unsigned)((e->n + 255) / 256)), dim3(256), 0, e->stream>>>(e->st.manual, e->n, primary_leg ? d_p : nullptr, src[0] ? d_v[0] : nullptr,
+                                                                                        src[1] ? d_v[1] : nullptr, secondary_leg ? d_s : nullptr,
+                                                                                        src[2] ? d_v[2] : nullptr, src[3] ? d_v[3] : nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_get_leg_manipulation_state(shc_engine *e, int32_t *states) {
+  if (!e || !states) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(e->device));
+  int32_t *d = reinterpret_cast<int32_t *>(e->d_stage);
+  const int64_t rows = e->n * e->L;
+  get_leg_manipulation_state_kernel<<<dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, e->stream>>>(e->st.manual, e->n, e->L, d);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(states, d, size_t(rows) * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
+}
 
 // PoseController::packLegs / unpackLegs (pose_controller.cpp:615-707)
 static int pack_transition(shc_engine *e, const double *packed_positions, int n_pack_steps, double transition_time, bool unpack, int32_t *progress) {

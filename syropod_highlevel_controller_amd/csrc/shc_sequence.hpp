@@ -62,6 +62,34 @@ __device__ __forceinline__ void seq_defaults(SeqRobotState &s) { // member initi
   s.initialised = 1;
 }
 
+// AdmittanceController::updateAdmittance for one leg (admittance_controller.cpp:22-63) as the posing part of a StateController
+// loop runs it before transitionRobotState / legStateToggle (state_controller.cpp:172-180); the robot is STOPPED on these paths,
+// so the dynamic stiffness update (:175) does not run.  Same arithmetic as the admittance block of the fused cycle.
+template <int NJ>
+__device__ __forceinline__ void admittance_prologue_dev(const LegIO<NJ> &io, const LegConst<NJ> &lc, const CycleParams &P) {
+  using FD = Fields<NJ>;
+  if (!P.admittance_control) return;
+  const V3 f = (P.use_joint_effort ? io.get3(FD::TF) : io.get3(FD::FORCE_IN)) * P.force_gain;
+  double a0 = io.get(FD::ADM), a1 = io.get(FD::ADM + 1);
+  const double fi[3] = {f.x, f.y, f.z};
+  double d[3];
+  for (int i = 0; i < 3; ++i) {
+    const double u = fmax(fi[i], 0.0);
+    const double x0 = P.adm_m00 * a0 + P.adm_m01 * a1 + P.adm_g0 * u;
+    const double x1 = P.adm_m10 * a0 + P.adm_m11 * a1 + P.adm_g1 * u;
+    a0 = x0;
+    a1 = x1;
+    d[i] = clampd(-x0, -0.2, 0.2);
+  }
+  double q[NJ], qd[NJ];
+  io.joints(q, qd);
+  Chain<NJ> ch;
+  fk_chain<NJ>(lc, q, ch);
+  io.put(FD::ADM, a0);
+  io.put(FD::ADM + 1, a1);
+  io.put3(FD::ADM_DELTA, projection(V3{d[0], d[1], d[2]}, base_rotate(lc, ch.xe))); // Leg::setAdmittanceDelta (model.h:365-368)
+}
+
 template <int L, int NJ>
 __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *gc, SeqRobotState *seq, int sequence /* 0 START_UP, 1 SHUT_DOWN */,
                                         SeqParams P, int32_t *progress_out) {
@@ -77,6 +105,7 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
     return;
   }
   s.completed_sequence = 0;
+  for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
   const bool start_up = sequence == 0;
   // Initialise / reset any saved transition sequence (:149-162)
   if (s.reset_transition_sequence && start_up) {
@@ -261,6 +290,7 @@ __global__ void step_to_new_stance_kernel(DevState st, const SharedConsts<L, NJ>
   const Pose current_pose = robot_current_pose<L>(st, rob);
   const Quat target_rotation{P.target_rotation[0], P.target_rotation[1], P.target_rotation[2], P.target_rotation[3]};
   int progress = 0;
+  for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
   for (int l = 0; l < L; ++l) {
     if ((l % 2) != s.current_group) continue;
     const LegIO<NJ> io{st, slot_of(rob, l, L)};
@@ -281,6 +311,132 @@ __global__ void step_to_new_stance_kernel(DevState st, const SharedConsts<L, NJ>
   }
   s.reset_transition_sequence = 1; // a new stance needs a new start-up sequence
   if (progress_out) progress_out[rob] = progress;
+}
+
+// ---------------------------------------------------------------------------------------------------- manual leg manipulation
+// StateController::legStateToggle (state_controller.cpp:541-646) for the leg each instance's request designates (leg_selection[rob],
+// -1 = no request), with PoseController::poseForLegManipulation (pose_controller.cpp:561-611) and AdmittanceController::
+// updateStiffness(leg, scale) (admittance_controller.cpp:66-92).  result: 1 transition complete (the node clears its toggle
+// flag), 0 in progress, 2 refused (MAX_MANUAL_LEGS), -1 the robot is still walking (the node keeps cycling with zero velocity
+// inputs, :641-645), -3 no request.  Supported while the body pose is walk-plane pose + manual pose only (the reset to the
+// default pose the toggle forces, :597, is then the walk-plane pose itself).
+constexpr int kMaxManualLegs = 2; // MAX_MANUAL_LEGS (state_controller.h:26)
+
+template <int L, int NJ>
+__global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *gc, const int32_t *leg_selection, SeqParams P, double virtual_stiffness,
+                                        double swing_stiffness_scaler, double load_stiffness_scaler, int dynamic_stiffness, int32_t *result_out) {
+  using FD = Fields<NJ>;
+  using R = RobotFields;
+  const int64_t rob = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (rob >= st.n_robots) return;
+  const int sel = leg_selection[rob];
+  int result = -3;
+  if (sel >= 0 && sel < L) {
+    ManualRobot &m = st.manual[rob];
+    constexpr int rpw = 64 / L;
+    const int walk_state = st.robi[rob_index(rob, R::I_WORD, rpw, R::I_COUNT)] & 3;
+    if (walk_state == WS_STOPPED) // the posing part of this loop (a robot that is still walking runs its whole loop in the cycle kernel)
+      for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P);
+    if (walk_state != WS_STOPPED) {
+      result = -1;
+    } else if (m.leg_state[sel] == LS_WALKING) {
+      if (m.manual_leg_count < kMaxManualLegs) {
+        m.leg_state[sel] = LS_WALKING_TO_MANUAL;
+        int &w = st.legi[slot_of(rob, sel, L)]; // leg_stepper->setSwingProgress(-1) / setStanceProgress(-1) (:573-574)
+        w = (w & ~(3 << LW_PM_SHIFT)) | (PM_NONE << LW_PM_SHIFT);
+        result = 0;
+      } else {
+        result = 2;
+      }
+    } else if (m.leg_state[sel] == LS_MANUAL) {
+      m.leg_state[sel] = LS_MANUAL_TO_WALKING;
+      result = 0;
+    } else {
+      const bool to_manual = m.leg_state[sel] == LS_WALKING_TO_MANUAL;
+      // poser_->setPoseResetMode(IMMEDIATE_ALL_RESET): the next pose update puts manual_pose_ on default_pose_ (identity: calculateDefaultPose
+      // is never called), and with walk-plane + manual posing only Model::current_pose_ becomes the walk-plane pose of a standing robot
+      // (the reset takes effect in the pose update of the NEXT loop: this call still sees the poses of the last update)
+      auto rd = [&](int f) -> double & { return st.robd[rob_index(rob, f, rpw, R::COUNT)]; };
+      Pose current_pose = robot_current_pose<L>(st, rob);
+      const V3 manual_position{rd(R::MPOSE), rd(R::MPOSE + 1), rd(R::MPOSE + 2)};
+      // ---- poseForLegManipulation
+      int min_progress = 2147483647;
+      for (int l = 0; l < L; ++l) {
+        const LegIO<NJ> io{st, slot_of(rob, l, L)};
+        const int ls = m.leg_state[l];
+        double step_height = P.swing_height;
+        const double step_time = 1.0 / P.step_frequency;
+        Pose target_pose;
+        if (ls == LS_WALKING_TO_MANUAL) {
+          target_pose = pose_identity(); // (+ inclination_pose_: inclination posing is outside the supported envelope)
+          target_pose.p.z -= step_height;
+        } else {
+          target_pose = current_pose;    // remove the manual pose, add the default pose (identity: calculateDefaultPose is never called)
+          target_pose.p = target_pose.p - manual_position;
+        }
+        double target[7];
+        put_pose7(target, inverse_transform_vector(target_pose, io.get3(FD::DFLT)), Quat{0, 0, 0, 0});
+        if (ls == LS_WALKING_TO_MANUAL) {
+          io.put3(FD::TIP, V3{target[0], target[1], target[2]}); // leg_stepper->setCurrentTipPose(target_tip_pose)
+          step_height = 0.0;
+        } else if (ls == LS_MANUAL_TO_WALKING) {
+          io.put3(FD::TIP, io.get3(FD::DFLT));                   // leg_stepper->setCurrentTipPose(default tip pose)
+        }
+        Pose tip;
+        const int progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target, pose_identity(), step_height, step_time, 1, P.have_adm, P.dt, tip);
+        min_progress = progress < min_progress ? progress : min_progress;
+        if (progress != 100) {
+          double cur[7];
+          put_pose7(cur, tip);
+          set_desired_dev<NJ>(st, io, L, rob, cur, 1, P.have_adm, P.gravity_aligned);
+          apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
+        }
+      }
+      if (dynamic_stiffness) { // admittance_->updateStiffness(leg, scale_reference) (:601-605, :622-626)
+        double scale = double(min_progress) / 100.0;
+        if (!to_manual) scale = fabs(scale - 1.0);
+        const double swing = virtual_stiffness * (scale * (swing_stiffness_scaler - 1) + 1), load = virtual_stiffness * (scale * (load_stiffness_scaler - 1) + 1);
+        auto stiff = [&](int l) -> double & { return st.legd[leg_field_index(FD::ADM_DELTA + 3, slot_of(rob, l, L), st.n_slots)]; };
+        const int a1 = (sel + L - 1) % L, a2 = (sel + 1) % L;
+        stiff(sel) = swing;
+        if (m.leg_state[a1] != LS_MANUAL) stiff(a1) = load;
+        if (m.leg_state[a2] != LS_MANUAL) stiff(a2) = load;
+      }
+      for (int k = 0; k < 7; ++k) rd(R::MPOSE + k) = (k == 3) ? 1.0 : 0.0; // the next pose update: manual_pose_ = default_pose_ ...
+      for (int k = 0; k < 7; ++k) rd(R::CPOSE + k) = rd(R::OWPP + k);      // ... and current_pose_ = the standing walk-plane pose
+      st.robi[rob_index(rob, R::I_RESET_MODE, rpw, R::I_COUNT)] = 5; // IMMEDIATE_ALL_RESET while the transition runs
+      result = 0;
+      if (min_progress == 100) {
+        m.leg_state[sel] = to_manual ? LS_MANUAL : LS_WALKING;
+        m.manual_leg_count += to_manual ? 1 : -1;
+        st.robi[rob_index(rob, R::I_RESET_MODE, rpw, R::I_COUNT)] = 0; // NO_RESET
+        result = 1;
+      }
+    }
+  }
+  if (result_out) result_out[rob] = result;
+}
+
+// primary / secondary leg selection and tip inputs of every instance (primaryLegSelectionCallback ... :1247-1330)
+__global__ void set_manual_inputs_kernel(ManualRobot *manual, int64_t n, const int32_t *primary_leg, const double *primary_velocity,
+                                         const double *primary_position, const int32_t *secondary_leg, const double *secondary_velocity,
+                                         const double *secondary_position) {
+  const int64_t rob = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (rob >= n) return;
+  ManualRobot &m = manual[rob];
+  m.primary_leg = primary_leg ? primary_leg[rob] : -1;
+  m.secondary_leg = secondary_leg ? secondary_leg[rob] : -1;
+  for (int k = 0; k < 3; ++k) {
+    m.primary_velocity[k] = primary_velocity ? primary_velocity[rob * 3 + k] : 0.0;
+    m.primary_position[k] = primary_position ? primary_position[rob * 3 + k] : 0.0;
+    m.secondary_velocity[k] = secondary_velocity ? secondary_velocity[rob * 3 + k] : 0.0;
+    m.secondary_position[k] = secondary_position ? secondary_position[rob * 3 + k] : 0.0;
+  }
+}
+__global__ void get_leg_manipulation_state_kernel(const ManualRobot *manual, int64_t n, int L, int32_t *out) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  out[t] = manual ? manual[t / L].leg_state[t % L] : LS_WALKING;
 }
 
 } // namespace shc

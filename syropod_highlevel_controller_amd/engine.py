@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "shc_leg_step_to_position", "shc_leg_transition_configuration", "shc_engine_begin_direct_startup", "shc_engine_direct_startup",
     "shc_engine_begin_sequence_startup", "shc_engine_execute_sequence", "shc_engine_finish_sequence_startup", "shc_engine_step_to_new_stance",
     "shc_engine_pack_legs", "shc_engine_unpack_legs",
+    "shc_engine_toggle_leg_state", "shc_engine_set_manual_inputs", "shc_engine_get_leg_manipulation_state",
     "shc_fleet_create", "shc_fleet_destroy", "shc_fleet_instances", "shc_fleet_shape", "shc_fleet_part_count", "shc_fleet_part",
     "shc_fleet_part_instances", "shc_fleet_set_velocity", "shc_fleet_set_imu", "shc_fleet_set_pose_input", "shc_fleet_set_tip_force",
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
@@ -142,6 +143,9 @@ def lib():
         L.shc_engine_execute_sequence.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.shc_engine_finish_sequence_startup.argtypes = [C.c_void_p]
         L.shc_engine_step_to_new_stance.argtypes = [C.c_void_p, C.c_void_p]
+        L.shc_engine_toggle_leg_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.shc_engine_set_manual_inputs.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.shc_engine_get_leg_manipulation_state.argtypes = [C.c_void_p, C.c_void_p]
         L.shc_engine_pack_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int32)]
         L.shc_engine_unpack_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int32)]
         L.shc_engine_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
@@ -417,6 +421,25 @@ class BatchEngine:
 
     def finish_sequence_startup(self):
         _check(self.L.shc_engine_finish_sequence_startup(self.h), "finish_sequence_startup")
+
+    # -- manual leg manipulation (legStateToggle, updateManual)
+    def toggle_leg_state(self, leg_selection):
+        """One legStateToggle call per instance (leg_selection[i] = -1: no request).  Returns the result rows."""
+        sel = np.ascontiguousarray(leg_selection, dtype=np.int32)
+        res = np.zeros(self.n, dtype=np.int32)
+        _check(self.L.shc_engine_toggle_leg_state(self.h, _p(sel), _p(res)), "toggle_leg_state")
+        return res
+
+    def set_manual_inputs(self, primary_leg=None, primary_velocity=None, primary_position=None, secondary_leg=None, secondary_velocity=None,
+                          secondary_position=None):
+        i32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+        a = [i32(primary_leg), _host(primary_velocity), _host(primary_position), i32(secondary_leg), _host(secondary_velocity), _host(secondary_position)]
+        _check(self.L.shc_engine_set_manual_inputs(self.h, *[_p(x) for x in a]), "set_manual_inputs")
+
+    def leg_manipulation_state(self):
+        out = np.zeros((self.n, self.legs), dtype=np.int32)
+        _check(self.L.shc_engine_get_leg_manipulation_state(self.h, _p(out)), "get_leg_manipulation_state")
+        return out
 
     def pack_legs(self, packed_positions, time_to_pack, unpack=False):
         """One PoseController::packLegs / unpackLegs call; packed_positions [n_pack_steps][legs][dof]."""

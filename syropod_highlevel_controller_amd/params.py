@@ -102,7 +102,7 @@ class Params(C.Structure):
         ("velocity_input_mode", C.c_int32),
         ("stance_position", (C.c_double * 2) * SHC_MAX_LEGS),
         ("overlapping_walkspaces", C.c_int32), ("force_normal_touchdown", C.c_int32),
-        ("gravity_aligned_tips", C.c_int32),
+        ("gravity_aligned_tips", C.c_int32), ("leg_manipulation_mode", C.c_int32),
         ("time_to_start", C.c_double),
         ("rotation_pid_gains", C.c_double * 3),
         ("max_translation", C.c_double * 3),

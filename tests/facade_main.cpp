@@ -52,6 +52,27 @@ int main(int argc, char **argv) {
       ExternalTarget back = stepper.getExternalTarget();
       printf("external %d %.17g %.17g\n", back.defined_ ? 1 : 0, back.pose_.position_[0], back.swing_clearance_);
     }
+    { // manual leg manipulation: stop, toggle leg 3 to MANUAL (legStateToggle), place its tip with updateManual's pose overload
+      double zero2[2] = {0.0, 0.0};
+      int result = -1, calls = 0;
+      while (result != 1 && calls < 4000) {
+        result = engine->legStateToggle(3);
+        if (result == -1) { // still walking: zero the velocity inputs and run the normal cycle of this loop (state_controller.cpp:641-645)
+          walker->updateWalk(zero2, 0.0);
+          model->updateModel();
+        }
+        ++calls;
+      }
+      const Pose none{{{0.0, 0.0, 0.0}}, {0.0, 0.0, 0.0, 0.0}};
+      const Pose where{{{p.stance_position[3][0] * 0.9, p.stance_position[3][1] * 0.9, -0.07}}, {0.0, 0.0, 0.0, 0.0}};
+      for (int c = 0; c < 30; ++c) {
+        walker->updateWalk(v, w); // ignored: the walker is frozen while a leg is MANUAL
+        walker->updateManual(3, where, -1, none);
+        model->updateModel();
+      }
+      Vector3 tip = model->getLegByIDNumber(3).getCurrentTipPosition();
+      printf("manual %d %.17g %.17g %.17g walk_state %d\n", result, tip[0], tip[1], tip[2], walker->getWalkState());
+    }
     return 0;
   }
   auto model = std::make_shared<Model>(engine);

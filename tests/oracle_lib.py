@@ -83,6 +83,9 @@ def lib():
         L.orc_execute_sequence.argtypes = [C.c_void_p, C.c_int]
         L.orc_step_to_new_stance.argtypes = [C.c_void_p]
         L.orc_sequence_failed.argtypes = [C.c_void_p]
+        L.orc_leg_state_toggle.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_leg_manipulation_state.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_manual_inputs.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
         L.orc_pack_legs.argtypes = [C.c_void_p, _dp, C.c_int, C.c_double]
         L.orc_unpack_legs.argtypes = [C.c_void_p, _dp, C.c_int, C.c_double]
         L.orc_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -322,6 +325,26 @@ class OracleBatch:
     def finish_sequence_shutdown(self):
         for i in range(self.n):
             self.L.orc_sequence_finish_shutdown(self.L.orc_batch_robot(self.h, i))
+
+    # ---- manual leg manipulation
+    def toggle_leg_state(self, leg_selection):
+        """One StateController loop with the toggle request pending, per robot (-1 = no request: result -3, nothing runs)."""
+        out = np.full(self.n, -3, dtype=np.int32)
+        for i in range(self.n):
+            if leg_selection[i] >= 0:
+                out[i] = self.L.orc_leg_state_toggle(self.L.orc_batch_robot(self.h, i), int(leg_selection[i]))
+        return out
+
+    def set_manual_inputs(self, primary_leg=None, primary_velocity=None, primary_position=None, secondary_leg=None, secondary_velocity=None,
+                          secondary_position=None):
+        f = lambda a, i: None if a is None else _ptr(np.ascontiguousarray(a[i], dtype=np.float64))
+        for i in range(self.n):
+            self.L.orc_set_manual_inputs(self.L.orc_batch_robot(self.h, i), -1 if primary_leg is None else int(primary_leg[i]), f(primary_velocity, i),
+                                         f(primary_position, i), -1 if secondary_leg is None else int(secondary_leg[i]), f(secondary_velocity, i),
+                                         f(secondary_position, i))
+
+    def leg_manipulation_state(self):
+        return np.array([[self.L.orc_get_leg_manipulation_state(self.L.orc_batch_robot(self.h, i), l) for l in range(self.legs)] for i in range(self.n)], dtype=np.int32)
 
     def pack_legs(self, packed_positions, time_to_pack, unpack=False):
         a = np.ascontiguousarray(packed_positions, dtype=np.float64)

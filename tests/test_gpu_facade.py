@@ -83,5 +83,16 @@ def test_facade_sequence_start_up_and_external_target(tmp_path):
     ob.step(cycles, 1)
     q_walk = np.array([float(x) for x in out[19:37]])
     assert np.abs(q_walk - ob.joints()[0][0]).max() <= 1e-6
-    tag, defined, x, clearance = out[37].split()
+    tag, defined, x, clearance = out[37].split()     # requested while the robot walks (a STOPPED robot's request goes to the planner)
     assert (tag, defined) == ("external", "1") and float(x) == 0.2 and float(clearance) == 0.03
+    # manual leg manipulation through the facade: the same requests on the oracle
+    sel = np.array([3], dtype=np.int32)
+    while ob.toggle_leg_state(sel)[0] != 1:
+        pass
+    where = np.array([[p.stance_position[3][0] * 0.9, p.stance_position[3][1] * 0.9, -0.07]])
+    ob.set_velocity(np.array([[v[0], v[1]]]), np.array([v[2]]))
+    ob.set_manual_inputs(sel, None, where, None, None, None)
+    ob.step(30, 1)
+    m = out[38].split()
+    assert m[0] == "manual" and m[1] == "1" and m[6] == "3"                      # toggled, robot STOPPED
+    assert np.abs(np.array([float(x) for x in m[2:5]]) - ob.leg_state()["model_tip"][0, 3]).max() <= 1e-6

@@ -120,3 +120,40 @@ def test_sequences_reach_their_goals(legs, dof, gait):
             assert len(hist) < 2000
         assert hist.count(0) == 1
         assert np.abs(ob.joints()[0][0] - (ready if unpack else packed[1])).max() < 1e-12
+
+
+def test_manual_leg_manipulation_invariants():
+    """Leg toggling and manual manipulation (state_controller.cpp:541-646, walk_controller.cpp:652-744) whatever the
+    implementation: a toggle request first stops a walking robot (-1), then takes exactly step-period-many posing calls
+    (1 / step_frequency / time_delta) plus the state change call; with a MANUAL leg the walker is frozen (velocity commands do
+    not start a walk, the other legs' joints only follow the IK chatter); the manual leg's tip follows a position input; at
+    most two legs can be MANUAL; toggling back restores an all-WALKING robot that walks again."""
+    from oracle_lib import OracleBatch
+    p = default_hexapod_params("tripod")
+    ob = OracleBatch(p, 1)
+    ob.set_velocity(np.array([[0.3, 0.0]]), np.array([0.1]))
+    ob.step(100, 1)
+    res = []
+    while not res or res[-1] != 1:
+        res.append(int(ob.toggle_leg_state(np.array([2], dtype=np.int32))[0]))
+        assert len(res) < 2000
+    posing = round(1.0 / p.step_frequency / p.time_delta)
+    assert res.count(-1) > 0 and res.count(0) == posing and res[-1] == 1      # state change call + (posing - 1) calls in progress + the completing one
+    assert ob.leg_manipulation_state()[0].tolist() == [0, 0, 1, 0, 0, 0]
+    target = np.array([[p.stance_position[2][0] * 0.9, p.stance_position[2][1] * 0.9, -0.07]])
+    ob.set_velocity(np.array([[0.4, 0.0]]), np.array([0.0]))
+    ob.set_manual_inputs(np.array([2], dtype=np.int32), None, target, None, None, None)
+    ob.step(40, 1)
+    assert ob.body_state()[2][0] == WALK_STOPPED
+    assert np.abs(ob.leg_state()["model_tip"][0, 2] - target[0]).max() < 5e-3   # the tip went where it was told (IK tolerance)
+    assert ob.toggle_leg_state(np.array([4], dtype=np.int32))[0] == 0           # a second leg may follow ...
+    while ob.toggle_leg_state(np.array([4], dtype=np.int32))[0] != 1:
+        pass
+    assert ob.toggle_leg_state(np.array([0], dtype=np.int32))[0] == 2           # ... a third may not (MAX_MANUAL_LEGS)
+    ob.set_manual_inputs(None, None, None, None, None, None)
+    for leg in (4, 2):
+        while ob.toggle_leg_state(np.array([leg], dtype=np.int32))[0] != 1:
+            pass
+    assert (ob.leg_manipulation_state() == 0).all()
+    ob.step(150, 1)
+    assert ob.body_state()[2][0] == WALK_MOVING
