@@ -6,8 +6,11 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 
 
 * metric / unit: BASELINE.json's ``control-cycles/sec (all legs IK-solved)``.
 * workload (N = 1): BASELINE.json configs[1] — 4 096 default.yaml hexapods (6 legs x 3 DOF), tripod gait, the full
-  per-cycle path (velocity limiting + walk FSM + Bezier tip trajectory + body pose + per-leg DLS IK/FK + tip-force
-  estimate), synthetic seeded velocity commands, every instance MOVING and de-phased before the timed region.
+  per-cycle path (velocity limiting + walk FSM + Bezier tip trajectory + body pose + per-leg DLS IK/FK), synthetic
+  seeded velocity commands, every instance MOVING and de-phased before the timed region.  "IK + Bezier tip-traj only":
+  no measured joint torques are supplied, so Leg::calculateTipForce filters zeros into a zero state and the engine runs
+  the kernels without the estimate (identical results); ``--joint-efforts`` supplies torques (estimate evaluated every
+  cycle) and the default run reports that variant under ``config.also``.
 * a "step" = one launch of the fused cycle kernel = ``--cycles-per-step`` control cycles (default 1) of every
   instance; inputs are resident in HBM (no host traffic inside the timed region).
 * N > 1: weak scaling — every rank owns ``--instances`` robots of its own (instance ranges are contiguous per rank),
@@ -39,7 +42,7 @@ def config3_forces(rng, n, legs):
     return np.stack([rng.normal(0, 1, (n, legs)), rng.normal(0, 1, (n, legs)), rng.uniform(0, 20, (n, legs))], axis=2)
 
 
-def make_workload(name, n, seed, rank=0):
+def make_workload(name, n, seed, rank=0, joint_efforts=False):
     from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
     from syropod_highlevel_controller_amd.parallel import velocity_inputs
     # instance ranges are contiguous per rank; inputs are keyed by the GLOBAL instance id (parallel.py)
@@ -69,7 +72,10 @@ def make_workload(name, n, seed, rank=0):
         key, desc = ("octopod", 4), "synthetic octopods (8x5 DOF), ripple gait, IK + Bezier tip trajectory"
     else:
         raise SystemExit(f"unknown workload {name}")
-    extra["effort"] = rng.normal(0, 0.5, size=(n, p.leg_count * p.leg_dof[0]))
+    effort = rng.normal(0, 0.5, size=(n, p.leg_count * p.leg_dof[0]))
+    if joint_efforts:  # measured joint torques (jointStatesCallback): Leg::calculateTipForce has something to filter
+        extra["effort"] = effort
+        desc += " + joint-effort input (tip-force estimate evaluated every cycle)"
     return p, lin, ang, extra, key, desc
 
 
@@ -79,7 +85,8 @@ def apply_inputs(obj, lin, ang, extra):
         obj.set_imu(extra["imu_q"], extra["gyro"])
     if "force" in extra:
         obj.set_tip_force(extra["force"])
-    obj.set_joint_effort(extra["effort"])
+    if "effort" in extra:
+        obj.set_joint_effort(extra["effort"])
 
 
 def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
@@ -121,7 +128,7 @@ def measured_traffic(workload, n, cps):
         return None
 
 
-def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False):
+def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False, joint_efforts=False):
     """One workload on this rank's GPU: prepare (untimed), time `steps` steps, measure the kernel with HIP events.
     dist_ctx = (world, rank, local_rank) when the RCCL path is active."""
     import torch
@@ -131,7 +138,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
 
     world, rank, local_rank = dist_ctx or (1, 0, torch.cuda.current_device())
     use_dist = dist_ctx is not None
-    p, lin, ang, extra, key, desc = make_workload(name, n, seed, rank)
+    p, lin, ang, extra, key, desc = make_workload(name, n, seed, rank, joint_efforts)
     stream = torch.cuda.current_stream()
     eng = BatchEngine(p, n, device=local_rank, stream=stream.cuda_stream)
     apply_inputs(eng, lin * 0.0, ang * 0.0, extra)
@@ -246,7 +253,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                    else "one all-gather of the final joint buffer (N > 1)",
                    "moving_fraction": moving_frac, "finite": finite, "seed": seed, "fused_16_cycles_per_launch_value": fused_value},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
+                     "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
     }
     if want_cpu_baseline:
@@ -320,6 +327,8 @@ def main():
     ap.add_argument("--no-fused-probe", action="store_true", help="skip the secondary 16-cycles-per-launch figure (keeps rocprof stats to one launch shape)")
     ap.add_argument("--no-also", action="store_true", help="skip the config 3 / config 4 measurements reported under config.also")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather path even with one rank")
+    ap.add_argument("--joint-efforts", action="store_true", help="supply measured joint torques: the tip-force estimate (Leg::calculateTipForce) "
+                    "is then evaluated every cycle; without them it is identically zero and the engine runs the kernels without it")
     ap.add_argument("--seed", type=int, default=0xC0FFEE)
     args = ap.parse_args()
 
@@ -353,15 +362,18 @@ def main():
         return
     res = run_workload(args.workload, n, args.steps, args.warmup, args.cycles_per_step, args.seed,
                        dist_ctx=(world, rank, local_rank) if use_dist else None, gather_every=args.gather_every,
-                       fused_probe=not args.no_fused_probe, want_cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+                       fused_probe=not args.no_fused_probe, want_cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline),
+                       joint_efforts=args.joint_efforts)
     # The other single-GPU BASELINE.json configurations, measured in the same process (N = 1 default run only):
     # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
     also = []
     if world == 1 and not use_dist and args.workload == "config2" and not args.instances and not args.no_also:
-        for name in ("config3", "config4"):
+        for name, efforts in (("config3", False), ("config4", False), ("config2", True), ("config4", True)):
+            if efforts == args.joint_efforts and name == "config2":
+                continue
             k = max(50, min(args.steps, 300))
             r = run_workload(name, DEFAULT_INSTANCES[name], k, max(10, min(args.warmup, 30)), args.cycles_per_step, args.seed,
-                             fused_probe=not args.no_fused_probe)
+                             fused_probe=not args.no_fused_probe and not efforts, joint_efforts=efforts)
             also.append({"workload": r["config"]["workload"], "value": r["value"], "unit": "control-cycles/s", "steps": k,
                          "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"],
                          "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],

@@ -218,7 +218,10 @@ int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, const double
 int shc_engine_set_imu(shc_engine *e, const double *orientation_wxyz, const double *angular_velocity, int on_device);
 /* tipStatesCallback -> Leg::setTipForceMeasured (state_controller.cpp:1618): [n][legs][3]. */
 int shc_engine_set_tip_force(shc_engine *e, const double *tip_force, int on_device);
-/* jointStatesCallback -> Joint::current_effort_ (state_controller.cpp:1590): [n][legs][dof]. */
+/* jointStatesCallback -> Joint::current_effort_ (state_controller.cpp:1590): [n][legs][dof].
+ * Until the first effort arrives Leg::calculateTipForce filters zero torques into a zero state (model.cpp:680-707), so the
+ * engine runs the kernels without the estimate; the FIRST call (or the injection of a non-zero filter state) switches to the
+ * kernels that evaluate it and synchronises the stream once - make it before capturing the per-cycle path in a hipGraph. */
 int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int on_device);
 /* bodyPoseInputCallback (state_controller.cpp:1142): translation / rotation velocity inputs [n][3] each. */
 int shc_engine_set_pose_input(shc_engine *e, const double *translation_velocity, const double *rotation_velocity,

@@ -43,7 +43,7 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // origins of the per-leg planes, which change once per step period).
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
-enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8 }; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
+enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8, RT_EFFORT_LIVE = 16 }; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,

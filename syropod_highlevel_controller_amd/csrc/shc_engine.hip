@@ -627,7 +627,7 @@ static void build_shared_consts(const shc_params &p, const shc_tables &t, const 
   }
 }
 
-static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_t features, CycleParams &c) {
+static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_t features, unsigned rt_flags, CycleParams &c) {
   memset(&c, 0, sizeof c);
   const shc_step_cycle &s = t.step;
   c.dt = p.time_delta;
@@ -669,7 +669,10 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.clamp_joint_positions = p.clamp_joint_positions;
   c.clamp_joint_velocities = p.clamp_joint_velocities;
   c.force_normal_touchdown = p.force_normal_touchdown;
-  c.tip_force = (features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort ? 1 : 0;
+  // Leg::calculateTipForce (model.cpp:667-708) filters the force of the measured joint torques into tip_force_calculated_.
+  // Until a torque has been supplied (RT_EFFORT_LIVE) it filters zeros into a zero state: the estimate is exactly zero and
+  // stays it, so the kernels without the estimate run (its planes are neither loaded nor stored).
+  c.tip_force = (((features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort) && (rt_flags & RT_EFFORT_LIVE)) ? 1 : 0;
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
   c.gravity_aligned = hostinit::tips_rotation_constrained(p, p.leg_dof[0]) ? 1 : 0;
   c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
@@ -1109,7 +1112,7 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
       return rc;
     }
   }
-  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   const int rpw = 64 / L;
   e->n_waves = (n_instances + rpw - 1) / rpw;
   // Plane stride: 64 slots per wave + 3 KiB of padding.  A wave touches the same 1 KiB offset of ~30 planes; with a stride that
@@ -1170,7 +1173,7 @@ extern "C" int shc_engine_set_stream(shc_engine *e, void *stream) {
 extern "C" int shc_engine_set_features(shc_engine *e, uint32_t features) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   e->features = features;
-  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   return upload_consts(e);
 }
 
@@ -1305,8 +1308,20 @@ extern "C" int shc_engine_set_tip_force(shc_engine *e, const double *tip_force, 
   return SHC_OK;
 }
 
+// First joint effort (or non-zero filter state): switch to the kernels that evaluate the tip-force estimate.
+static int effort_live(shc_engine *e) {
+  if (e->rt_flags & RT_EFFORT_LIVE) return SHC_OK;
+  e->rt_flags |= RT_EFFORT_LIVE;
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
+  return upload_consts(e);
+}
+
 extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int on_device) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (joint_effort) { // Leg::calculateTipForce has something to filter from now on
+    const int rc = effort_live(e);
+    if (rc != SHC_OK) return rc;
+  }
   return scatter_leg(e, joint_effort, e->NJ, LEG_FIELD(e, EFFORT_IN), on_device);
 }
 
@@ -1509,7 +1524,7 @@ extern "C" int shc_engine_change_gait(shc_engine *e, const shc_params *ng, int64
   if ((rc = shc_generate_tables(&p, &t)) != SHC_OK) return rc; // generateStepCycle + generateLimits (morphology tables come out unchanged)
   e->params = p;
   e->tables = t;
-  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   if ((rc = upload_consts(e)) != SHC_OK) return rc;
   if (p.auto_posing) { // setAutoPoseParams builds fresh AutoPosers: their start / end checks are reset (pose_controller.cpp:39-61)
     fill_robi_kernel<<<dim3(grid), dim3(256), 0, e->stream>>>(e->st.robi, rpw, e->n, RobotFields::I_APOSER, 0);
@@ -2478,7 +2493,7 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   }
   if (!ok) return fail(SHC_ERR_INVALID_ARG, "init chain failed for the configuration the sequence ended on");
   e->tables = t;
-  build_cycle_params(e->params, e->tables, e->features, e->cp);
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   if ((rc = upload_consts(e)) != SHC_OK) return rc;
   // walker_->init() (:306): fresh LegSteppers / walk state; the joints stay where the sequence left them
   const int n_joint_planes = (2 * e->NJ + 1) / 2 + 1; // planes holding Q and QD (Fields: Q = 0, QD = NJ, TIP = 2 NJ)
@@ -2513,6 +2528,16 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
   if (in) // touchdown detection is one flag per engine: on as soon as any injected record has it (tip-state messages arrive for a whole robot)
     for (int64_t i = 0; i < count; ++i)
       if (in[i].touchdown_detection) e->rt_flags |= RT_TOUCHDOWN;
+  if (in && !(e->rt_flags & RT_EFFORT_LIVE)) { // a non-zero tip-force filter state decays over the following cycles: evaluate it
+    bool any = false;
+    for (int64_t i = 0; i < count && !any; ++i)
+      for (int l = 0; l < e->L; ++l)
+        for (int k = 0; k < 3; ++k) any |= in[i].leg[l].tip_force_calculated[k] != 0.0;
+    if (any) {
+      const int rc = effort_live(e);
+      if (rc != SHC_OK) return rc;
+    }
+  }
   const int touchdown = (e->rt_flags & RT_TOUCHDOWN) ? 1 : 0;
   HIP_TRY(hipSetDevice(e->device));
   shc_instance_state *d = nullptr;

@@ -678,6 +678,37 @@ def test_optional_features_off_leave_joints_unchanged(Engine):
     assert np.abs(a.leg_state()["tip_force"]).max() > 0 and np.abs(b.leg_state()["tip_force"]).max() == 0
 
 
+def test_tip_force_estimate_waits_for_the_first_effort(Engine):
+    """Until a joint effort has been supplied Leg::calculateTipForce (model.cpp:667-708) filters zero torques into a zero
+    state; the engine then neither loads, evaluates nor stores the estimate.  The full state record must be byte-identical
+    to an engine that was handed explicit zeros (which evaluates it), match the oracle, and pick the estimate up from the
+    cycle the first effort arrives in."""
+    p = default_hexapod_params("tripod")
+    n = 40
+    inp = make_inputs(p, n, 59)
+    zeros = np.zeros_like(inp["effort"])
+    a, b = Engine(p, n), Engine(p, n)
+    ob = OracleBatch(p, n)
+    for o in (a, b, ob):
+        o.set_velocity(inp["lin"], inp["ang"])
+    b.set_joint_effort(zeros)
+    for o in (a, b, ob):
+        o.step(150) if o is not ob else o.step(150, 1)
+    a.synchronize(), b.synchronize()
+    assert bytes(a.get_state()) == bytes(b.get_state())
+    assert np.abs(a.leg_state()["tip_force"]).max() == 0
+    assert np.abs(a.joints()[0] - ob.joints()[0]).max() <= TOL_Q
+    for o in (a, b, ob):
+        o.set_joint_effort(inp["effort"])
+        o.step(60) if o is not ob else o.step(60, 1)
+    a.synchronize(), b.synchronize()
+    assert bytes(a.get_state()) == bytes(b.get_state())
+    tf = a.leg_state()["tip_force"]
+    assert np.abs(tf).max() > 0 and np.abs(tf - ob.leg_state()["tip_force"]).max() <= 2e-4
+    from conftest import parity_report
+    parity_report(f"[tip force waits for the first effort] {n} instances, 150 + 60 cycles: state byte-identical to the always-evaluating engine")
+
+
 # ------------------------------------------------------------------------------------------------ full size
 def test_full_size_config2_properties(Engine):
     """BASELINE.json configs[1] at full size (4 096 hexapods): size-independent properties + parity on a slice."""
