@@ -430,10 +430,11 @@ int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress);
  * Manual leg manipulation: StateController::legStateToggle (state_controller.cpp:541-646) with PoseController::
  * poseForLegManipulation (pose_controller.cpp:561-611), and WalkController::updateManual (walk_controller.cpp:652-744, both overloads)
  * inside the control cycle.
- *   shc_engine_toggle_leg_state   ONE legStateToggle call per instance for the leg its request designates: leg_selection [n]
- *       (host; -1 = no request).  result rows [n]: 1 = transition complete (WALKING <-> MANUAL: the node clears its toggle flag),
- *       0 = in progress, 2 = refused (MAX_MANUAL_LEGS = 2 already manual), -1 = the robot is still walking (the node zeroes its
- *       velocity inputs and keeps cycling, :641-645), -3 = no request.  While a robot has a leg that is not WALKING its walker
+ *   shc_engine_toggle_leg_state   ONE StateController::loop() for EVERY instance, with a toggle request pending for the leg
+ *       leg_selection[i] designates (host [n]; -1 = no request).  result rows [n]: 1 = transition complete (WALKING <-> MANUAL:
+ *       the node clears its toggle flag), 0 = in progress, 2 = refused (MAX_MANUAL_LEGS = 2 already manual), -1 = the robot is
+ *       still walking: its velocity inputs are zeroed (:641-645) and its loop is one ordinary control cycle, -3 = no request: one
+ *       ordinary control cycle (the call launches the cycle kernel for those two groups only).  While a robot has a leg that is not WALKING its walker
  *       is frozen (updateWalk returns at walk_controller.cpp:503); MANUAL / WALKING_TO_MANUAL legs are not posed (updateStance).
  *       Supported while the body pose is walk-plane pose + manual pose (no IMU / auto / inclination posing, no tip-align pose):
  *       SHC_ERR_UNSUPPORTED otherwise.
@@ -527,18 +528,47 @@ typedef struct shc_external_target {
   int32_t frame_is_odom_ideal; /* frame_id_ == "odom_ideal" (:1073) */
   int32_t defined;         /* ExternalTarget::defined_; 0 withdraws the request */
 } shc_external_target;
-enum { SHC_EXTERNAL_TARGET = 0, SHC_EXTERNAL_DEFAULT = 1 };
+enum { SHC_EXTERNAL_TARGET = 0, SHC_EXTERNAL_DEFAULT = 1, SHC_EXTERNAL_PLANNER_TARGET = 2 /* LegPoser::external_target_, see planner mode */ };
 /* LegStepper::setExternalTarget / setExternalDefault for legs `leg` (-1 = all, rows [count][legs]) of instances [first, first +
- * count); rows is a HOST array.  As in the callback, a request reaches the stepper only while its robot is not STOPPED (a
- * stopped robot hands targets to the planner-mode LegPoser, which is outside this engine): such rows are ignored and counted in
- * *ignored (may be NULL).  The stepper keeps only the x axis of tip rotations (see shc_leg_snapshot), and legs with <= 3
- * joints none at all: a defined target rotation on > 3-DOF legs is SHC_ERR_UNSUPPORTED. */
+ * count); rows is a HOST array.  As in the callback (:1734-1757), a LegStepper takes a request only while its robot is not
+ * STOPPED; the TARGET of a robot that stands goes to its LegPoser for planner mode (and raises target_tip_pose_acquired_, see
+ * shc_engine_execute_plan), a DEFAULT for it is dropped.  Dropped rows are counted in *ignored (may be NULL): defaults for
+ * standing robots, stepper requests without rough_terrain_mode (no stepper reads them), and targets with a tip rotation that would
+ * go to the LegPoser of a robot with <= 3 joints per leg.  The stepper keeps only the x axis of tip rotations (see
+ * shc_leg_snapshot), and legs with <= 3 joints none at all: a defined target rotation on > 3-DOF legs is SHC_ERR_UNSUPPORTED.
+ * which = SHC_EXTERNAL_PLANNER_TARGET addresses the LegPoser's record directly (set: whatever the walk state). */
 int shc_engine_set_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, const shc_external_target *rows,
                                    int64_t *ignored);
 /* generateExternalTargetTransforms: new transform_ rows (x,y,z,qw,qx,qy,qz) for requests that are currently defined. */
 int shc_engine_set_external_transform(shc_engine *e, int which, int64_t first, int64_t count, int leg, const double *transform);
 /* The requests as the steppers hold them now (defined_ cleared where a swing has consumed the target). */
 int shc_engine_get_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, shc_external_target *rows);
+
+/*
+ * Planner mode: StateController::executePlan (state_controller.cpp:653-698), the branch of runningState (:401-405) that replaces
+ * the walking cycle while planner_mode_ is on.  The planner answers the node's request for plan step N with either a joint
+ * configuration (target_configuration -> PoseController::transitionConfiguration(5.0), pose_controller.cpp:710-763: every named
+ * leg moves on LegPoser::transitionConfiguration's cubic Bezier) or tip targets and / or a body pose (TargetTipPose for a robot that
+ * stands, target_body_pose -> PoseController::transitionStance(5.0), :767-807: LegPoser::stepToPosition to the target while the
+ * body eases to the pose, Leg::setDesiredTipPose + applyIK every iteration).  Requires what manual leg manipulation requires of
+ * the posing modes; gravity_aligned_tips is SHC_ERR_UNSUPPORTED.
+ */
+enum { SHC_PLAN_WALKING = -1, SHC_PLAN_WAITING = -2 };
+/* plannerModeCallback (:1262-1281): switching it on resets plan_step_ of every instance. */
+int shc_engine_set_planner_mode(shc_engine *e, int on);
+/* targetConfigurationCallback (:1683-1687) for instances [first, first + count): rows [count][legs][dof] (HOST); a leg whose first
+ * entry is NaN is not named in the message and stays where it is.  (A leg the message names partly takes UNASSIGNED_VALUE for the
+ * joints it omits in the reference; name whole legs.) */
+int shc_engine_set_target_configuration(shc_engine *e, int64_t first, int64_t count, const double *configuration);
+/* targetBodyPoseCallback (:1691-1702): rows [count][7] (x,y,z,qw,qx,qy,qz), HOST.  (The reference leaves target_body_pose_
+ * uninitialised until the first plan step has completed; here it starts as the identity.) */
+int shc_engine_set_target_body_pose(shc_engine *e, int64_t first, int64_t count, const double *pose);
+/* One StateController::loop() in planner mode for EVERY instance.  A robot that stands runs executePlan: progress[i] = 0 .. 100 of
+ * the plan step being executed (100: plan_step_ advances, the acquired flags and the target body pose are reset), or
+ * SHC_PLAN_WAITING when nothing has been acquired (the node republishes its request for plan_step[i]; Model::updateModel runs,
+ * :666).  A robot that is still walking gets SHC_PLAN_WALKING, its velocity inputs are zeroed (:691-697) and its loop is one
+ * ordinary control cycle, launched by this call for those robots only.  progress / plan_step: HOST [n], may be NULL. */
+int shc_engine_execute_plan(shc_engine *e, int32_t *progress, int32_t *plan_step);
 
 int64_t shc_sizeof_instance_state(void);
 /* Instances [first, first + count) -> states[0 .. count) (host array).  Synchronises the engine's stream. */

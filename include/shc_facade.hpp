@@ -103,6 +103,21 @@ public:
     return result;
   }
   bool manual_legs_ = false;
+  // plannerModeCallback (state_controller.cpp:1262-1281) and StateController::executePlan (:653-698), one call per loop while planner
+  // mode is on: 0 .. 100 = progress of the plan step being executed (PoseController::transitionConfiguration / transitionStance with
+  // the 5 s the node gives them), SHC_PLAN_WAITING = nothing acquired (republish the request for planStep()), SHC_PLAN_WALKING =
+  // the robot was still walking: velocity inputs zeroed, this loop was an ordinary control cycle
+  void setPlannerMode(bool on) { check(shc_engine_set_planner_mode(e_, on ? 1 : 0), "shc_engine_set_planner_mode"); }
+  int executePlan() {
+    if (n_ != 1) throw std::runtime_error("shc_facade: executePlan runs one robot's loop: use shc_engine_execute_plan for a batch");
+    int32_t progress = 0;
+    check(shc_engine_execute_plan(e_, &progress, &plan_step_), "shc_engine_execute_plan");
+    manual_legs_ = true; // (the planner shares the per-robot records of the loop-level kernels)
+    invalidate();
+    return progress;
+  }
+  int planStep() const { return plan_step_; } // StateController::plan_step_
+  int32_t plan_step_ = 0;
   // StateController::changeGait (state_controller.cpp:513): true once the gait has changed, false while the robots are
   // still being stopped (keep cycling and call again, as the reference does while gait_change_flag_ is set)
   bool changeGait(const shc_params &new_gait) {
@@ -284,6 +299,10 @@ public:
   void setExternalDefault(const ExternalTarget &t) { set(SHC_EXTERNAL_DEFAULT, t); } // :441
   ExternalTarget getExternalTarget() const { return get(SHC_EXTERNAL_TARGET); }      // :385
   ExternalTarget getExternalDefault() const { return get(SHC_EXTERNAL_DEFAULT); }    // :389
+  // LegPoser::setExternalTarget / getExternalTarget (pose_controller.h:489, :457): the planner-mode tip target, which
+  // targetTipPoseCallback hands to the LegPoser of a robot that stands (state_controller.cpp:1738-1742)
+  void setPoserExternalTarget(const ExternalTarget &t) { set(SHC_EXTERNAL_PLANNER_TARGET, t); }
+  ExternalTarget getPoserExternalTarget() const { return get(SHC_EXTERNAL_PLANNER_TARGET); }
 
 private:
   static void pack(const Pose &p, double *o) {
@@ -441,6 +460,18 @@ public:
     check(shc_engine_execute_sequence(eng_->handle(), sequence == START_UP ? SHC_SEQUENCE_START_UP : SHC_SEQUENCE_SHUT_DOWN, &progress), "shc_engine_execute_sequence");
     eng_->invalidate();
     return progress;
+  }
+  // setTargetConfiguration (pose_controller.h:141; targetConfigurationCallback): positions [legs][dof], a leg the message does not
+  // name = NaN in its first joint.  setTargetBodyPose (pose_controller.h:109; targetBodyPoseCallback).  Engine::executePlan runs
+  // transitionConfiguration(5.0) / transitionStance(5.0) (pose_controller.cpp:710, :767) on what was acquired.
+  void setTargetConfiguration(const double *positions_legs_dof) {
+    require_single(*eng_, "setTargetConfiguration");
+    check(shc_engine_set_target_configuration(eng_->handle(), 0, 1, positions_legs_dof), "shc_engine_set_target_configuration");
+  }
+  void setTargetBodyPose(const Pose &pose) {
+    require_single(*eng_, "setTargetBodyPose");
+    const double p[7] = {pose.position_[0], pose.position_[1], pose.position_[2], pose.rotation_.w, pose.rotation_.x, pose.rotation_.y, pose.rotation_.z};
+    check(shc_engine_set_target_body_pose(eng_->handle(), 0, 1, p), "shc_engine_set_target_body_pose");
   }
   // int stepToNewStance(void) (pose_controller.h:180, pose_controller.cpp:521)
   int stepToNewStance(void) {

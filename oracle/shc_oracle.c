@@ -92,6 +92,7 @@ typedef struct
   orc_pose transition_poses[ORC_MAX_TRANSITION_POSES]; /* std::vector<Pose> transition_poses_ */
   int n_transition_poses;
   int leg_completed_step;
+  shc_external_target external_target; /* LegPoser::external_target_ (pose_controller.h:589): planner-mode tip target */
 } leg_poser_t;
 
 /* Workspace = std::map<double, Workplane>, Workplane = std::map<int, double> with the nine bearings 0..360 (model.h:27-32).
@@ -212,6 +213,12 @@ struct orc_robot
   int set_target, proximity_alert, horizontal_transition_complete, vertical_transition_complete;
   int first_sequence_execution, reset_transition_sequence, sequence_failed;
   int pack_step; /* pose_controller.h:298 */
+  /* planner mode: PoseController::target_configuration_ / target_body_pose_ (pose_controller.h:291-292; per leg, "named in the
+   * message" flag + positions) and the StateController flags (state_controller.h:337, :360-363) */
+  double target_configuration[SHC_MAX_LEGS][SHC_MAX_JOINTS];
+  int target_configuration_named[SHC_MAX_LEGS];
+  orc_pose target_body_pose;
+  int planner_mode, target_configuration_acquired, target_tip_pose_acquired, target_body_pose_acquired, plan_step;
   /* manual leg manipulation: StateController members (state_controller.h:330-360) */
   int manual_leg_count, primary_leg_selection, secondary_leg_selection;
   orc_v3 primary_tip_velocity_input, secondary_tip_velocity_input;
@@ -2381,6 +2388,84 @@ static int poser_pack_legs(orc_robot *r, const double *packed_positions, int num
   return progress;
 }
 
+/* ==================================================================================== planner mode */
+
+/* PoseController::transitionConfiguration (pose_controller.cpp:710-763): every leg the target_configuration message names moves
+ * to its joint positions on LegPoser::transitionConfiguration's cubic Bezier; a leg it does not name gets an empty desired
+ * configuration and reports completion at once (:1479-1482). */
+static int poser_transition_configuration(orc_robot *r, double transition_time)
+{
+  int min_progress = INT_MAX;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    if (!r->executing_transition)
+    {
+      leg->poser.has_desired_configuration = r->target_configuration_named[l];
+      for (int j = 0; j < leg->joint_count; ++j) leg->poser.desired_configuration[j] = r->target_configuration[l][j];
+    }
+    int progress = leg_poser_transition_configuration(r, leg, transition_time);
+    min_progress = progress < min_progress ? progress : min_progress;
+  }
+  r->executing_transition = (min_progress != 0 && min_progress != PROGRESS_COMPLETE);
+  return min_progress;
+}
+
+/* PoseController::transitionStance (pose_controller.cpp:767-807): every leg steps (no lift unless the request carries a swing
+ * clearance) to the planner's tip target - or stays where it is - while the body eases to target_body_pose_. */
+static int poser_transition_stance(orc_robot *r, double transition_time)
+{
+  int min_progress = INT_MAX;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    leg_t *leg = &r->leg[l];
+    shc_external_target *target = &leg->poser.external_target;
+    orc_pose target_tip_pose = orc_pose_undefined();
+    double swing_clearance = 0.0;
+    if (target->defined)
+    {
+      target_tip_pose = orc_pose_add(pose_from7(target->transform), pose_from7(target->pose));
+      swing_clearance = target->swing_clearance;
+    }
+    if (orc_quat_is_undefined(target_tip_pose.r) && r->params.gravity_aligned_tips)
+      target_tip_pose.r = orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), model_estimate_gravity(r));
+    int progress = leg_poser_step_to_position(r, leg, target_tip_pose, r->target_body_pose, swing_clearance, transition_time, 1);
+    leg_set_desired_tip_pose(leg, leg->poser.current_tip_pose, 1);
+    leg_apply_ik(r, leg, 0);
+    min_progress = progress < min_progress ? progress : min_progress;
+    if (target->defined && progress == PROGRESS_COMPLETE) target->defined = 0;
+  }
+  return min_progress;
+}
+
+static void model_update_model(orc_robot *r);
+
+/* StateController::executePlan (state_controller.cpp:653-698).  Returns the progress of the plan step being executed, -2 while
+ * it waits for the planner to publish one (the node then republishes its request for step plan_step_), -1 while the robot is
+ * still walking (velocity inputs forced to zero; the loop goes on with its normal cycle). */
+static int state_execute_plan(orc_robot *r)
+{
+  if (r->walk_state != STOPPED)
+  {
+    r->linear_velocity_input[0] = r->linear_velocity_input[1] = 0.0;
+    r->angular_velocity_input = 0.0;
+    return -1;
+  }
+  if (!r->target_configuration_acquired && !r->target_tip_pose_acquired && !r->target_body_pose_acquired)
+  {
+    model_update_model(r);
+    return -2;
+  }
+  int progress = r->target_configuration_acquired ? poser_transition_configuration(r, 5.0) : poser_transition_stance(r, 5.0);
+  if (progress == PROGRESS_COMPLETE)
+  {
+    r->plan_step++;
+    r->target_body_pose = orc_pose_identity();
+    r->target_configuration_acquired = r->target_tip_pose_acquired = r->target_body_pose_acquired = 0;
+  }
+  return progress;
+}
+
 /* ==================================================================================== manual leg manipulation */
 
 /* WalkController::updateManual, tip-velocity overload (walk_controller.cpp:652-708).  A MANUAL leg that is neither the primary
@@ -2737,6 +2822,7 @@ orc_robot *orc_create(const shc_params *params)
   r->imu_orientation = ORC_UNDEFINED_ROTATION;
   r->imu_angular_velocity = orc_v3_make(0, 0, 0);
   r->primary_leg_selection = r->secondary_leg_selection = LEG_UNDESIGNATED;
+  r->target_body_pose = orc_pose_identity(); /* (left uninitialised by the reference until the first plan step completes, :685) */
   r->set_target = 1; /* pose_controller.h:299-304 */
   r->first_sequence_execution = 1;
   r->reset_transition_sequence = 1;
@@ -2946,31 +3032,43 @@ void orc_set_joint_states_msg(orc_robot *r, const double *position, const double
 /* tipStatesCallback, step_plane values of the tip range sensors (state_controller.cpp:1651-1672): [legs][3] */
 /* targetTipPoseCallback (state_controller.cpp:1706-1767): robot RUNNING; a target reaches the LegStepper only while the robot
  * is not STOPPED (else the planner-mode LegPoser takes it, not restated), a default likewise (:1746).  Returns 1 if taken. */
+static shc_external_target *external_record(orc_robot *r, int which, int leg)
+{
+  if (which == SHC_EXTERNAL_PLANNER_TARGET) return &r->leg[leg].poser.external_target;
+  stepper_t *s = &r->leg[leg].stepper;
+  return which ? &s->external_default : &s->external_target;
+}
+
+/* targetTipPoseCallback (state_controller.cpp:1706-1767).  Returns 1 when a LegStepper took the request, 2 when the robot is
+ * STOPPED and the LegPoser took the target for planner mode (:1738-1742), 0 when it was dropped (a default for a STOPPED robot). */
 int orc_set_external_target(orc_robot *r, int which, int leg, const shc_external_target *t)
 {
-  stepper_t *s = &r->leg[leg].stepper;
   if (!t->defined)
   {
-    (which ? &s->external_default : &s->external_target)->defined = 0;
+    external_record(r, which, leg)->defined = 0;
     return 1;
   }
+  if (which == SHC_EXTERNAL_PLANNER_TARGET || (which == SHC_EXTERNAL_TARGET && r->walk_state == STOPPED))
+  {
+    r->leg[leg].poser.external_target = *t;
+    r->target_tip_pose_acquired = 1;
+    return 2;
+  }
   if (r->walk_state == STOPPED) return 0;
-  *(which ? &s->external_default : &s->external_target) = *t;
+  *external_record(r, which, leg) = *t;
   return 1;
 }
 
 /* generateExternalTargetTransforms (state_controller.cpp:703-773): refreshed transform_ of a defined request */
 void orc_set_external_transform(orc_robot *r, int which, int leg, const double *transform)
 {
-  stepper_t *s = &r->leg[leg].stepper;
-  shc_external_target *t = which ? &s->external_default : &s->external_target;
+  shc_external_target *t = external_record(r, which, leg);
   if (t->defined) memcpy(t->transform, transform, sizeof t->transform);
 }
 
 void orc_get_external_target(const orc_robot *r, int which, int leg, shc_external_target *out)
 {
-  const stepper_t *s = &r->leg[leg].stepper;
-  *out = which ? s->external_default : s->external_target;
+  *out = *external_record((orc_robot *)r, which, leg);
 }
 
 void orc_set_step_plane(orc_robot *r, const double *step_plane)
@@ -3605,6 +3703,40 @@ void orc_sequence_finish_startup(orc_robot *r)
   state_running_state(r);
 }
 void orc_sequence_finish_shutdown(orc_robot *r) { r->robot_state = RS_READY; r->new_robot_state = RS_RUNNING; }
+
+/* ---- planner mode.  plannerModeCallback (state_controller.cpp:1262-1281), targetConfigurationCallback (:1683-1687; rows [legs][dof],
+ * a leg whose first entry is NaN is not named in the message), targetBodyPoseCallback (:1691-1702); orc_execute_plan = one
+ * StateController::loop() in planner mode: the posing part (:165-181), then runningState -> executePlan (:401-405; a robot that
+ * is still walking goes on with its normal cycle, velocity inputs zeroed, :691-697). */
+void orc_set_planner_mode(orc_robot *r, int on)
+{
+  if (r->robot_state != RS_RUNNING || on == r->planner_mode) return;
+  r->planner_mode = on;
+  if (on) r->plan_step = 0;
+}
+void orc_set_target_configuration(orc_robot *r, const double *configuration)
+{
+  int k = 0;
+  for (int l = 0; l < r->leg_count; ++l)
+  {
+    r->target_configuration_named[l] = !isnan(configuration[k]);
+    for (int j = 0; j < r->leg[l].joint_count; ++j) r->target_configuration[l][j] = configuration[k++];
+  }
+  r->target_configuration_acquired = 1;
+}
+void orc_set_target_body_pose(orc_robot *r, const double *pose7)
+{
+  r->target_body_pose = pose_from7(pose7);
+  r->target_body_pose_acquired = 1;
+}
+int orc_execute_plan(orc_robot *r)
+{
+  orc_sequence_prologue(r);
+  int result = state_execute_plan(r);
+  if (result == -1) state_running_state(r);
+  return result;
+}
+int orc_get_plan_step(const orc_robot *r) { return r->plan_step; }
 
 /* ---- manual leg manipulation.  orc_leg_state_toggle = one StateController::loop() with the toggle request for `leg` pending:
  * the posing part (:165-181), then runningState -> legStateToggle (:396-400; no tip update while the robot is STOPPED); while

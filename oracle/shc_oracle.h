@@ -104,6 +104,11 @@ int orc_pack_legs(orc_robot *r, const double *packed_positions /* [steps][legs][
 int orc_unpack_legs(orc_robot *r, const double *packed_positions, int number_pack_steps, double time_to_unpack);                        /* :662 */
 void orc_sequence_finish_startup(orc_robot *r);                              /* state_controller.cpp:305-313 */
 void orc_sequence_finish_shutdown(orc_robot *r);
+void orc_set_planner_mode(orc_robot *r, int on);                            /* state_controller.cpp:1262-1281 */
+void orc_set_target_configuration(orc_robot *r, const double *configuration); /* :1683-1687; [legs][dof], NaN = leg not named */
+void orc_set_target_body_pose(orc_robot *r, const double *pose7);           /* :1691-1702 */
+int orc_execute_plan(orc_robot *r);                                         /* :653-698 inside one loop() */
+int orc_get_plan_step(const orc_robot *r);
 int orc_leg_state_toggle(orc_robot *r, int leg);                            /* state_controller.cpp:541-646 */
 int orc_get_leg_manipulation_state(const orc_robot *r, int leg);
 void orc_set_manual_inputs(orc_robot *r, int primary_leg, const double *primary_tip_velocity, const double *primary_tip_position,

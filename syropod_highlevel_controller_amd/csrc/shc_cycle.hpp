@@ -43,7 +43,7 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // origins of the per-leg planes, which change once per step period).
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
-enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8, RT_EFFORT_LIVE = 16 }; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
+enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8, RT_EFFORT_LIVE = 16, RT_SKIP_MARKED = 32 }; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
@@ -151,7 +151,8 @@ struct RobotFields {
 // ever given a request carry it.  flags: bit 0 defined_, bit 1 frame_id_ == "odom_ideal".
 struct ExtFields {
   static constexpr int T_POSE = 0, T_TRANSFORM = 7, T_CLEARANCE = 14, T_FLAGS = 15, // external_target_
-                       D_POSE = 16, D_TRANSFORM = 23, D_FLAGS = 30, COUNT = 32;     // external_default_
+                       D_POSE = 16, D_TRANSFORM = 23, D_FLAGS = 30,                  // external_default_
+                       P_POSE = 32, P_TRANSFORM = 39, P_CLEARANCE = 46, P_FLAGS = 47, COUNT = 48; // LegPoser::external_target_ (planner mode)
 };
 
 // Manual leg manipulation (WalkController::updateManual, StateController::legStateToggle): per-robot record in a lazily allocated
@@ -159,7 +160,9 @@ struct ExtFields {
 enum : int { LS_WALKING = 0, LS_MANUAL = 1, LS_WALKING_TO_MANUAL = -1, LS_MANUAL_TO_WALKING = -2 }; // enum LegState (parameters_and_states.h:87-94)
 struct ManualRobot {
   int32_t leg_state[SHC_MAX_LEGS];
-  int32_t manual_leg_count, primary_leg, secondary_leg, pad_; // StateController::manual_leg_count_, primary / secondary_leg_selection_
+  int32_t manual_leg_count, primary_leg, secondary_leg; // StateController::manual_leg_count_, primary / secondary_leg_selection_
+  int32_t skip_cycle; // set by the loop-level kernels (legStateToggle, executePlan) for a robot whose loop they have run: the cycle
+                      // launch that follows for the robots still walking (RT_SKIP_MARKED) leaves this robot untouched
   double primary_velocity[3], secondary_velocity[3];         // primary / secondary_tip_velocity_input_
   double primary_position[3], secondary_position[3];         // primary / secondary_pose_input_.position_
 };

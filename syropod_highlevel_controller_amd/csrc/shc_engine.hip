@@ -277,7 +277,12 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   }
   double t_core[(R::CORE_END * RPW + 63) / 64], t_man[((R::MANUAL_END - R::MPOSE) * RPW + 63) / 64],
       t_imu[((R::IMU_END - R::ABSE) * RPW + 63) / 64], t_imuq[((R::IMUQ_END - R::IMUQ) * RPW + 63) / 64],
-      t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_align[((R::COUNT - R::TALIGN) * RPW + 63) / 64], t_odom[((R::ODOM_END - R::ODOM) * RPW + 63) / 64];
+      t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_align[((R::COUNT - R::TALIGN) * RPW + 63) / 64], t_odom[((R::ODOM_END - R::ODOM) * RPW + 63) / 64],
+      t_cpose[((R::CPOSE_END - R::CPOSE) * RPW + 63) / 64];
+  // RT_SKIP_MARKED - this launch follows a loop-level kernel (leg toggle, plan execution) that has already run the loop of the robots it
+  // marked (ManualRobot::skip_cycle): they are left exactly as they are.  Model::current_pose_ is otherwise output only; here it
+  // is loaded too so that the tile write-back is the identity for a skipped robot.
+  const bool skip_marked = (F & F_TERRAIN) != 0 && (rt_flags & RT_SKIP_MARKED) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0;
   constexpr int int_iters = (R::I_COUNT * RPW + 63) / 64; // 3-legged robots: 21 per wave x 4 ints = 84 entries > one wave's width
   int32_t t_int[int_iters];
   if (any_robot) {
@@ -287,6 +292,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
     if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, gtile, lane);
+    if (skip_marked) load_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, gtile, lane);
     if ((F & F_TERRAIN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
@@ -311,6 +317,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
     if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, tile, lane);
+    if (skip_marked) put_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, tile, lane);
     if ((F & F_TERRAIN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it)
@@ -339,8 +346,10 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   unsigned dirty = 0;
   double *const ext = ((F & F_TERRAIN) != 0 && (rt_flags & RT_EXTERNAL) != 0) ? st.ext : nullptr; // external targets (rough terrain mode)
   const ManualRobot *const mr = ((F & F_TERRAIN) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0 && any_robot) ? st.manual + (rob0 + grp) : nullptr;
-  for (int c = 0; c < n_cycles; ++c)
-    cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr);
+  const bool skip = skip_marked && mr != nullptr && mr->skip_cycle != 0; // (uniform over the lanes of a robot)
+  if (!skip)
+    for (int c = 0; c < n_cycles; ++c)
+      cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr);
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
@@ -348,7 +357,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
       if (__any((dirty & b) != 0)) d |= b;
     dirty = d;
   }
-  if (live) store_leg<NJ, F>(s, out, pk, st, P, slot, dirty);
+  if (live && !skip) store_leg<NJ, F>(s, out, pk, st, P, slot, dirty);
   SHC_TICK(13);
   __builtin_amdgcn_wave_barrier(); // LDS ops of one wave complete in order: the tile now holds the leaders' updates
   // state planes back to this wave's HBM tile (the inputs VIN / WIN / GYRO / IMUQ are not written back)
@@ -583,6 +592,8 @@ struct shc_engine {
   int starting_up, startup_calls; // shc_engine_begin_direct_startup .. shc_engine_direct_startup
   SeqRobotState *d_seq;           // start-up / shut-down sequence state (shc_sequence.hpp), allocated by the first sequence call
   int pack_step, executing_transition, transition_calls; // PoseController::pack_step_ / executing_transition_ (pose_controller.h:294, :298)
+  bool planner_mode = false;            // StateController::planner_mode_ (state_controller.h:337)
+  bool plan_poser_tips_current = false; // no control cycle has run since the last shc_engine_execute_plan (SeqRobotState::poser_tip_from_plan holds)
 };
 
 template <int L, int NJ>
@@ -1397,6 +1408,7 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
+  if (!(e->rt_flags & RT_SKIP_MARKED)) e->plan_poser_tips_current = false; // PoseController::updateStance rewrites every LegPoser's tip pose
   // One wave per workgroup while the batch has about as many waves as the chip has SIMDs (1 024): the dispatcher then spreads
   // them one per SIMD (two-wave groups put pairs on the same SIMDs: 12.9 instead of 9.4 us at 768 waves, 12.2 instead of 10.2 at
   // 1 024; equal at 1 536).  Above that, 128-thread groups
@@ -1810,16 +1822,19 @@ extern "C" int shc_engine_set_tip_states_msg(shc_engine *e, const double *wrench
 struct ExtRow { // shc_external_target as doubles (staged on the device)
   double pose[7], transform[7], swing_clearance, flags /* bit 0 defined, bit 1 odom_ideal */;
 };
+struct ExtAt { int base, flags; };
+__host__ __device__ inline ExtAt ext_record(int which) { // 0 LegStepper::external_target_, 1 external_default_, 2 LegPoser::external_target_
+  return which == 0 ? ExtAt{ExtFields::T_POSE, ExtFields::T_FLAGS} : which == 1 ? ExtAt{ExtFields::D_POSE, ExtFields::D_FLAGS} : ExtAt{ExtFields::P_POSE, ExtFields::P_FLAGS};
+}
 __global__ void set_external_kernel(DevState st, int L, int64_t first, int64_t count, int leg_sel, int which, const ExtRow *rows, int transform_only,
-                                    unsigned long long *ignored) {
+                                    unsigned long long *ignored, SeqRobotState *seq, int rough_terrain, int NJ) {
   const int legs = leg_sel < 0 ? L : 1;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= count * legs) return;
   const int64_t rob = first + t / legs;
   const int leg = leg_sel < 0 ? int(t % legs) : leg_sel;
   const int64_t slot = slot_of(rob, leg, L);
-  const int base = which ? ExtFields::D_POSE : ExtFields::T_POSE;
-  const int flags_at = which ? ExtFields::D_FLAGS : ExtFields::T_FLAGS;
+  int base = ext_record(which).base, flags_at = ext_record(which).flags;
   auto f = [&](int field) -> double & { return st.ext[leg_field_index(field, slot, st.n_slots)]; };
   const ExtRow &r = rows[t];
   if (transform_only) { // generateExternalTargetTransforms (state_controller.cpp:703-773): only defined requests are refreshed
@@ -1832,14 +1847,25 @@ __global__ void set_external_kernel(DevState st, int L, int64_t first, int64_t c
     f(flags_at) = double(int(f(flags_at)) & ~1);
     return;
   }
-  // targetTipPoseCallback (:1736, :1746): the LegStepper takes the request only while its robot is not STOPPED
+  // targetTipPoseCallback (:1734-1757): the LegStepper takes a request only while its robot is not STOPPED; the target of a robot
+  // that stands goes to its LegPoser for planner mode (target_tip_pose_acquired_, :1738-1742), a default for it is dropped
   const int walk_state = st.robi[rob_index(rob, RobotFields::I_WORD, 64 / L, RobotFields::I_COUNT)] & 3;
-  if (walk_state == WS_STOPPED) {
+  const bool rotation_defined = r.pose[3] != 0.0 || r.pose[4] != 0.0 || r.pose[5] != 0.0 || r.pose[6] != 0.0;
+  if (which == 0 && walk_state == WS_STOPPED && NJ <= 3 && rotation_defined) { // (a planner target with a rotation needs the rotation-
+    atomicAdd(ignored, 1ull);                                                  //  constrained IK: legs with more than 3 joints only)
+    return;
+  }
+  if (which == 2 || (which == 0 && walk_state == WS_STOPPED)) {
+    which = 2;
+    base = ext_record(2).base, flags_at = ext_record(2).flags;
+    seq[rob].tip_pose_acquired = 1;
+  } else if (walk_state == WS_STOPPED || !rough_terrain) { // (without rough_terrain_mode no stepper ever reads its requests)
     atomicAdd(ignored, 1ull);
     return;
   }
   for (int k = 0; k < 7; ++k) f(base + k) = r.pose[k], f(base + 7 + k) = r.transform[k];
-  if (!which) f(ExtFields::T_CLEARANCE) = r.swing_clearance;
+  if (which == 0) f(ExtFields::T_CLEARANCE) = r.swing_clearance;
+  if (which == 2) f(ExtFields::P_CLEARANCE) = r.swing_clearance;
   f(flags_at) = r.flags;
 }
 __global__ void get_external_kernel(DevState st, int L, int64_t first, int64_t count, int leg_sel, int which, ExtRow *rows) {
@@ -1847,21 +1873,28 @@ __global__ void get_external_kernel(DevState st, int L, int64_t first, int64_t c
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= count * legs) return;
   const int64_t slot = slot_of(first + t / legs, leg_sel < 0 ? int(t % legs) : leg_sel, L);
-  const int base = which ? ExtFields::D_POSE : ExtFields::T_POSE;
+  const int base = ext_record(which).base;
   auto f = [&](int field) { return st.ext[leg_field_index(field, slot, st.n_slots)]; };
   ExtRow &r = rows[t];
   for (int k = 0; k < 7; ++k) r.pose[k] = f(base + k), r.transform[k] = f(base + 7 + k);
-  r.swing_clearance = which ? 0.0 : f(ExtFields::T_CLEARANCE);
-  r.flags = f(which ? ExtFields::D_FLAGS : ExtFields::T_FLAGS);
+  r.swing_clearance = which == 0 ? f(ExtFields::T_CLEARANCE) : which == 2 ? f(ExtFields::P_CLEARANCE) : 0.0;
+  r.flags = f(ext_record(which).flags);
 }
 
+static int ensure_seq(shc_engine *e);
 static int external_select(shc_engine *e, int which, int64_t first, int64_t count, int leg, int64_t *rows_out) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
-  if (which != SHC_EXTERNAL_TARGET && which != SHC_EXTERNAL_DEFAULT) return fail(SHC_ERR_INVALID_ARG, "which must be SHC_EXTERNAL_TARGET or SHC_EXTERNAL_DEFAULT");
+  if (which != SHC_EXTERNAL_TARGET && which != SHC_EXTERNAL_DEFAULT && which != SHC_EXTERNAL_PLANNER_TARGET)
+    return fail(SHC_ERR_INVALID_ARG, "which must be SHC_EXTERNAL_TARGET, SHC_EXTERNAL_DEFAULT or SHC_EXTERNAL_PLANNER_TARGET");
   if (first < 0 || count < 0 || first + count > e->n || leg >= e->L) return fail(SHC_ERR_INVALID_ARG, "instance range / leg out of bounds");
-  if (!e->params.rough_terrain_mode) return fail(SHC_ERR_UNSUPPORTED, "external targets / defaults are read in rough_terrain_mode only (walk_controller.cpp:1065)");
+  if (which == SHC_EXTERNAL_DEFAULT && !e->params.rough_terrain_mode)
+    return fail(SHC_ERR_UNSUPPORTED, "external default poses are read in rough_terrain_mode only (walk_controller.cpp:988)");
   *rows_out = count * (leg < 0 ? e->L : 1);
   HIP_TRY(hipSetDevice(e->device));
+  if (which != SHC_EXTERNAL_DEFAULT) { // a target may end up with the planner-mode LegPoser of a robot that stands
+    const int rc = ensure_seq(e);
+    if (rc != SHC_OK) return rc;
+  }
   if (!e->st.ext) { // first request: allocate the records (all undefined)
     const size_t bytes = size_t(ExtFields::COUNT) * e->n_slots * 8;
     HIP_TRY(hipMalloc(&e->st.ext, bytes));
@@ -1879,7 +1912,7 @@ static int external_write(shc_engine *e, int which, int64_t first, int64_t count
   hipError_t err = hipMemcpyAsync(d_rows, host.data(), host.size() * sizeof(ExtRow), hipMemcpyHostToDevice, e->stream);
   if (err == hipSuccess) err = hipMemsetAsync(d_ignored, 0, 8, e->stream);
   if (err == hipSuccess) {
-    set_external_kernel<<<dim3((unsigned)((host.size() + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->L, first, count, leg, which, d_rows, transform_only, d_ignored);
+    set_external_kernel<<<dim3((unsigned)((host.size() + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->L, first, count, leg, which, d_rows, transform_only, d_ignored, e->d_seq, e->params.rough_terrain_mode, e->NJ);
     err = hipGetLastError();
   }
   if (err == hipSuccess) err = hipMemcpyAsync(&h_ignored, d_ignored, 8, hipMemcpyDeviceToHost, e->stream);
@@ -1903,8 +1936,13 @@ extern "C" int shc_engine_set_external_target(shc_engine *e, int which, int64_t 
     const shc_external_target &t = rows[i];
     // LegStepper keeps tip rotations as their x axis, for > 3-DOF legs only; a requested target rotation would have to drive
     // updateTipRotation / the rotation-constrained IK (walk_controller.cpp:1209-1230), which the engine runs for gravity-aligned tips only
-    if (t.defined && e->NJ > 3 && which == SHC_EXTERNAL_TARGET && (t.pose[3] != 0.0 || t.pose[4] != 0.0 || t.pose[5] != 0.0 || t.pose[6] != 0.0))
+    const bool rotation_defined = t.pose[3] != 0.0 || t.pose[4] != 0.0 || t.pose[5] != 0.0 || t.pose[6] != 0.0;
+    if (t.defined && e->NJ > 3 && which == SHC_EXTERNAL_TARGET && rotation_defined)
       return fail(SHC_ERR_UNSUPPORTED, "external target with a defined tip rotation on legs with more than 3 joints");
+    // planner mode hands the target to Leg::applyIK as it is: with a rotation the solve is rotation-constrained, which the engine
+    // runs on legs with more than 3 joints only (the same limit as leg_manipulation_mode joint_control)
+    if (t.defined && e->NJ <= 3 && which == SHC_EXTERNAL_PLANNER_TARGET && rotation_defined)
+      return fail(SHC_ERR_UNSUPPORTED, "planner target with a defined tip rotation on legs with at most 3 joints");
     for (int k = 0; k < 7; ++k) host[i].pose[k] = t.pose[k], host[i].transform[k] = t.transform[k];
     host[i].swing_clearance = t.swing_clearance;
     host[i].flags = double((t.defined ? 1 : 0) | (t.frame_is_odom_ideal ? 2 : 0));
@@ -2282,13 +2320,15 @@ extern "C" int shc_engine_begin_sequence_startup(shc_engine *e, const double *jo
   return SHC_OK;
 }
 
-static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(START_UP / SHUT_DOWN), 2: stepToNewStance */, int32_t *progress) {
-  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+static int ensure_seq(shc_engine *e) { // the per-robot PoseController records of the sequence / planner kernels, on first use
   HIP_TRY(hipSetDevice(e->device));
   if (!e->d_seq) {
     HIP_TRY(hipMalloc(&e->d_seq, sizeof(SeqRobotState) * size_t(e->n)));
     HIP_TRY(hipMemsetAsync(e->d_seq, 0, sizeof(SeqRobotState) * size_t(e->n), e->stream));
   }
+  return SHC_OK;
+}
+static SeqParams seq_params(const shc_engine *e) {
   SeqParams P{};
   P.step_frequency = e->params.step_frequency;
   P.swing_height = e->params.swing_height;
@@ -2299,6 +2339,14 @@ static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(ST
   P.tip_force = e->cp.tip_force;
   P.have_adm = e->params.admittance_control;
   P.gravity_aligned = e->cp.gravity_aligned;
+  return P;
+}
+
+static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(START_UP / SHUT_DOWN), 2: stepToNewStance */, int32_t *progress) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  int rc = ensure_seq(e);
+  if (rc != SHC_OK) return rc;
+  SeqParams P = seq_params(e);
   if (e->cp.gravity_aligned) { // identity tip rotation of gravity-aligned tips (walk_controller.cpp:37-41)
     const Quat r = from_two_vectors(V3{1, 0, 0}, V3{e->cp.target_dir[0], e->cp.target_dir[1], e->cp.target_dir[2]});
     P.target_rotation[0] = r.w, P.target_rotation[1] = r.x, P.target_rotation[2] = r.y, P.target_rotation[3] = r.z;
@@ -2324,15 +2372,19 @@ extern "C" int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t 
 extern "C" int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress) { return sequence_launch(e, 2, progress); }
 
 // ---- manual leg manipulation (shc_sequence.hpp)
-static int ensure_manual(shc_engine *e) {
+static int ensure_manual(shc_engine *e, bool planner = false) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   const shc_params &p = e->params;
   if (p.imu_posing || p.auto_posing || p.inclination_posing || e->cp.tip_align)
-    return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation with IMU / auto / inclination posing or the tip-align pose (the toggle's pose reset assumes "
-                                     "walk-plane + manual posing only)");
-  // joint_control hands the FK tip pose WITH its rotation to the stepper (walk_controller.cpp:688-689), which makes the following
-  // applyIK rotation-constrained on 3-DOF legs: outside the accelerated path
-  if (p.leg_manipulation_mode != SHC_MANIPULATION_TIP_CONTROL) return fail(SHC_ERR_UNSUPPORTED, "leg_manipulation_mode joint_control");
+    return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with IMU / auto / inclination posing or the tip-align pose (the loop-level "
+                                     "kernels run the posing part of a loop for walk-plane + manual posing only)");
+  if (planner) { // (transitionStance would read Model::estimateGravity for the target rotation, pose_controller.cpp:786-790)
+    if (p.gravity_aligned_tips) return fail(SHC_ERR_UNSUPPORTED, "planner mode with gravity_aligned_tips");
+  } else if (p.leg_manipulation_mode != SHC_MANIPULATION_TIP_CONTROL) {
+    // joint_control hands the FK tip pose WITH its rotation to the stepper (walk_controller.cpp:688-689), which makes the following
+    // applyIK rotation-constrained on 3-DOF legs: outside the accelerated path
+    return fail(SHC_ERR_UNSUPPORTED, "leg_manipulation_mode joint_control");
+  }
   HIP_TRY(hipSetDevice(e->device));
   if (!e->st.manual) {
     HIP_TRY(hipMalloc(&e->st.manual, sizeof(ManualRobot) * size_t(e->n_rob_pad)));
@@ -2352,28 +2404,29 @@ extern "C" int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_sel
   int rc = ensure_manual(e);
   if (rc != SHC_OK) return rc;
   if (!leg_selection) return fail(SHC_ERR_INVALID_ARG, "leg_selection is NULL");
-  int32_t *d_sel = reinterpret_cast<int32_t *>(e->d_stage), *d_res = d_sel + e->n;
+  int32_t *d_sel = reinterpret_cast<int32_t *>(e->d_stage), *d_res = d_sel + e->n, *d_cycle = d_res + e->n;
   HIP_TRY(hipMemcpyAsync(d_sel, leg_selection, size_t(e->n) * 4, hipMemcpyHostToDevice, e->stream));
-  SeqParams P{};
-  P.step_frequency = e->params.step_frequency;
-  P.swing_height = e->params.swing_height;
-  P.dt = e->params.time_delta;
-  P.force_gain = e->params.force_gain;
-  P.clamp_vel = e->params.clamp_joint_velocities;
-  P.clamp_pos = e->params.clamp_joint_positions;
-  P.tip_force = e->cp.tip_force;
-  P.have_adm = e->params.admittance_control;
-  P.gravity_aligned = e->cp.gravity_aligned;
+  HIP_TRY(hipMemsetAsync(d_cycle, 0, 4, e->stream));
+  const SeqParams P = seq_params(e);
   const dim3 grid((unsigned)((e->n + 63) / 64)), block(64);
 #define CALL(L_, NJ_)                                                                                                                              \
   leg_state_toggle_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, d_sel, P, e->params.virtual_stiffness, \
                                                                   e->params.swing_stiffness_scaler, e->params.load_stiffness_scaler,                \
-                                                                  e->params.admittance_control && e->params.dynamic_stiffness, d_res)
+                                                                  e->params.admittance_control && e->params.dynamic_stiffness, d_res, d_cycle)
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
   HIP_TRY(hipGetLastError());
+  int32_t cycle = 0;
   if (result) HIP_TRY(hipMemcpyAsync(result, d_res, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(&cycle, d_cycle, 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (cycle) { // robots without a request, or asked to stop first: their loop is one ordinary control cycle; the others keep out of it
+    e->rt_flags |= RT_SKIP_MARKED;
+    rc = shc_engine_step(e, 1);
+    e->rt_flags &= ~RT_SKIP_MARKED;
+    if (rc != SHC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   return SHC_OK;
 }
 
@@ -2410,6 +2463,83 @@ extern "C" int shc_engine_get_leg_manipulation_state(shc_engine *e, int32_t *sta
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(states, d, size_t(rows) * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  return SHC_OK;
+}
+
+// ---- planner mode (shc_sequence.hpp: execute_plan_kernel)
+static int ensure_planner(shc_engine *e) {
+  int rc = ensure_manual(e, true); // the ManualRobot records carry the skip marks of the loop-level kernels
+  if (rc != SHC_OK) return rc;
+  return ensure_seq(e);
+}
+static int plan_inputs(shc_engine *e, int64_t first, int64_t count, int reset_plan_step, const double *configuration, const double *body_pose) {
+  int rc = ensure_planner(e);
+  if (rc != SHC_OK) return rc;
+  if (first < 0 || count < 0 || first + count > e->n) return fail(SHC_ERR_INVALID_ARG, "instance range out of bounds");
+  if (count == 0) return SHC_OK;
+  const size_t cfg_doubles = configuration ? size_t(count) * e->L * e->NJ : 0, pose_doubles = body_pose ? size_t(count) * 7 : 0;
+  double *d = nullptr;
+  if (cfg_doubles + pose_doubles) {
+    HIP_TRY(hipMalloc(&d, (cfg_doubles + pose_doubles) * 8));
+    hipError_t err = hipSuccess;
+    if (configuration) err = hipMemcpyAsync(d, configuration, cfg_doubles * 8, hipMemcpyHostToDevice, e->stream);
+    if (err == hipSuccess && body_pose) err = hipMemcpyAsync(d + cfg_doubles, body_pose, pose_doubles * 8, hipMemcpyHostToDevice, e->stream);
+    if (err != hipSuccess) {
+      (void)hipFree(d);
+      return fail(SHC_ERR_HIP, hipGetErrorString(err));
+    }
+  }
+  plan_inputs_kernel<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, e->stream>>>(e->d_seq, first, count, e->L, e->NJ, reset_plan_step,
+                                                                                 configuration ? d : nullptr, body_pose ? d + cfg_doubles : nullptr);
+  hipError_t err = hipGetLastError();
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+  (void)hipFree(d);
+  if (err != hipSuccess) return fail(SHC_ERR_HIP, hipGetErrorString(err));
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_set_planner_mode(shc_engine *e, int on) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if ((on != 0) == e->planner_mode) return SHC_OK; // plannerModeCallback acts on a change only (state_controller.cpp:1267)
+  e->planner_mode = on != 0;
+  return on ? plan_inputs(e, 0, e->n, 1, nullptr, nullptr) : SHC_OK; // plan_step_ = 0 (:1273)
+}
+extern "C" int shc_engine_set_target_configuration(shc_engine *e, int64_t first, int64_t count, const double *configuration) {
+  if (!e || !configuration) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  return plan_inputs(e, first, count, 0, configuration, nullptr);
+}
+extern "C" int shc_engine_set_target_body_pose(shc_engine *e, int64_t first, int64_t count, const double *pose) {
+  if (!e || !pose) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
+  return plan_inputs(e, first, count, 0, nullptr, pose);
+}
+
+extern "C" int shc_engine_execute_plan(shc_engine *e, int32_t *progress, int32_t *plan_step) {
+  int rc = ensure_planner(e);
+  if (rc != SHC_OK) return rc;
+  int32_t *d_progress = reinterpret_cast<int32_t *>(e->d_stage), *d_step = d_progress + e->n, *d_walking = d_step + e->n;
+  HIP_TRY(hipMemsetAsync(d_walking, 0, 4, e->stream));
+  const SeqParams P = seq_params(e);
+  const int reset_poser_tips = e->plan_poser_tips_current ? 0 : 1;
+  const dim3 grid((unsigned)((e->n + 63) / 64)), block(64);
+#define CALL(L_, NJ_)                                                                                                                             \
+  execute_plan_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, e->d_seq, P, reset_poser_tips, d_progress, \
+                                                              d_step, d_walking)
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  e->plan_poser_tips_current = true;
+  int32_t walking = 0;
+  if (progress) HIP_TRY(hipMemcpyAsync(progress, d_progress, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
+  if (plan_step) HIP_TRY(hipMemcpyAsync(plan_step, d_step, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipMemcpyAsync(&walking, d_walking, 4, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (walking) { // the loop of the robots that are still walking is the normal control cycle (inputs zeroed); the others keep out of it
+    e->rt_flags |= RT_SKIP_MARKED;
+    rc = shc_engine_step(e, 1);
+    e->rt_flags &= ~RT_SKIP_MARKED;
+    if (rc != SHC_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   return SHC_OK;
 }
 

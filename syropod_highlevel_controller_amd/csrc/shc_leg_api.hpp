@@ -303,17 +303,11 @@ __global__ void leg_step_to_position_kernel(DevState st, const SharedConsts<L_, 
   if (progress_out) progress_out[t] = progress;
 }
 
-// LegPoser::transitionConfiguration (pose_controller.cpp:1476-1567), one iteration per selected leg: every joint follows a cubic
+// LegPoser::transitionConfiguration (pose_controller.cpp:1476-1567), one iteration for one leg: every joint follows a cubic
 // Bezier (nodes origin, origin, target, target) from the configuration the leg had when the transition started.
-template <int L_, int NJ>
-__global__ void leg_transition_configuration_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *desired_configuration,
-                                                    int per_leg_rows, double transition_time, double dt, int32_t *progress_out) {
+template <int NJ>
+__device__ __forceinline__ int transition_configuration_dev(const LegIO<NJ> &io, const double *d, double transition_time, double dt) {
   using FD = Fields<NJ>;
-  int64_t rob;
-  int l;
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (!sel.map(t, rob, l)) return;
-  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
   double q[NJ], qd[NJ], q0[NJ];
   io.joints(q, qd);
   int count = int(io.get(FD::SEQ_ORG + 3));
@@ -327,8 +321,6 @@ __global__ void leg_transition_configuration_kernel(DevState st, const SharedCon
   num = num > 1 ? num : 1;
   const double delta_t = 1.0 / num;
   ++count;
-  // per_leg_rows: one target row per selected (instance, leg), else one row per LEG shared by every instance ([legs][dof])
-  const double *d = desired_configuration + (per_leg_rows ? t : int64_t(l)) * NJ;
   const double tt = count * delta_t, s = 1.0 - tt;
   for (int j = 0; j < NJ; ++j) // cubicBezier (standard_includes.h:347)
     q[j] = q0[j] * (s * s * s) + q0[j] * (3.0 * tt * s * s) + d[j] * (3.0 * tt * tt * s) + d[j] * (tt * tt * tt);
@@ -343,6 +335,18 @@ __global__ void leg_transition_configuration_kernel(DevState st, const SharedCon
   for (int j = 0; j < NJ; ++j) io.put(FD::SEQ_Q0 + j, q0[j]);
   io.put(FD::SEQ_ORG + 3, double(count));
   io.put(FD::SEQ_DIR + 3, running);
+  return progress;
+}
+template <int L_, int NJ>
+__global__ void leg_transition_configuration_kernel(DevState st, const SharedConsts<L_, NJ> *gc, LegSel sel, const double *desired_configuration,
+                                                    int per_leg_rows, double transition_time, double dt, int32_t *progress_out) {
+  int64_t rob;
+  int l;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (!sel.map(t, rob, l)) return;
+  const LegIO<NJ> io{st, slot_of(rob, l, sel.L)};
+  // per_leg_rows: one target row per selected (instance, leg), else one row per LEG shared by every instance ([legs][dof])
+  const int progress = transition_configuration_dev<NJ>(io, desired_configuration + (per_leg_rows ? t : int64_t(l)) * NJ, transition_time, dt);
   if (progress_out) progress_out[t] = progress;
 }
 

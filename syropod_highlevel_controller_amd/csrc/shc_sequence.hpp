@@ -23,12 +23,20 @@ struct SeqLegState {                        // class LegPoser
   double target[7];                          // target_tip_pose_
   double current[7];                         // current_tip_pose_ as the last stepToPosition left it
   int32_t n_poses, completed;                // transition_poses_.size(), leg_completed_step_
+  double plan_configuration[SHC_MAX_JOINTS]; // PoseController::target_configuration_, this leg's joints (planner mode)
+  double plan_desired[SHC_MAX_JOINTS];       // LegPoser::desired_configuration_ as latched when the transition began
+  int32_t plan_named, plan_latched;          // ... whether the message names the leg at all; LegPoser::desired_configuration_ defined (latched when a transition begins)
 };
 struct SeqRobotState {                       // class PoseController (pose_controller.h:273-274, :296-304)
   int32_t legs_completed_step, current_group, transition_step, transition_step_count;
   int32_t set_target, proximity_alert, horizontal_transition_complete, vertical_transition_complete;
   int32_t first_sequence_execution, reset_transition_sequence, failed, initialised;
   int32_t completed_sequence, pad_; // 1 + the sequence this robot has completed and not left since (see execute_sequence_kernel)
+  // planner mode: StateController::plan_step_ / target_*_acquired_ (state_controller.h:360-363), PoseController::executing_transition_
+  // and target_body_pose_ (pose_controller.h:292); poser_tip_from_plan: LegPoser::current_tip_pose_ is what transitionStance left
+  // in leg[].current (else it is what the last control cycle's updateStance derives from the walker tips)
+  int32_t plan_step, configuration_acquired, tip_pose_acquired, body_pose_acquired, executing_transition, poser_tip_from_plan;
+  double target_body_pose[7];
   SeqLegState leg[SHC_MAX_LEGS];
 };
 
@@ -59,6 +67,7 @@ __device__ __forceinline__ void seq_defaults(SeqRobotState &s) { // member initi
   s.set_target = 1;
   s.first_sequence_execution = 1;
   s.reset_transition_sequence = 1;
+  s.target_body_pose[3] = 1.0; // identity (the reference leaves it uninitialised until the first plan step completes, state_controller.cpp:685)
   s.initialised = 1;
 }
 
@@ -313,6 +322,128 @@ __global__ void step_to_new_stance_kernel(DevState st, const SharedConsts<L, NJ>
   if (progress_out) progress_out[rob] = progress;
 }
 
+// ---------------------------------------------------------------------------------------------------- planner mode
+// One StateController::loop() in planner mode for every robot that stands (state_controller.cpp:401-405 -> executePlan :653-698):
+//   nothing acquired        -> the node republishes its request for plan step plan_step_; Model::updateModel (:666)          result -2
+//   configuration acquired  -> PoseController::transitionConfiguration(5.0) (pose_controller.cpp:710-763)                     0 .. 100
+//   tip / body pose acquired-> PoseController::transitionStance(5.0) (:767-807)                                               0 .. 100
+// A robot that is still walking gets its velocity inputs zeroed (:691-697) and result -1; its loop is the normal control cycle,
+// which the host launches next with this kernel's skip marks (the robots handled here are left alone by it).
+constexpr double kPlanTransitionTime = 5.0;
+
+template <int L, int NJ>
+__global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, SeqRobotState *seq, SeqParams P, int reset_poser_tips, int32_t *progress_out,
+                                    int32_t *plan_step_out, int32_t *walking_out) {
+  using FD = Fields<NJ>;
+  using R = RobotFields;
+  using X = ExtFields;
+  const int64_t rob = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (rob >= st.n_robots) return;
+  SeqRobotState &s = seq[rob];
+  seq_defaults(s);
+  if (reset_poser_tips) s.poser_tip_from_plan = 0; // control cycles ran since the last plan call: updateStance rewrote the poser tips
+  constexpr int rpw = 64 / L;
+  const int walk_state = st.robi[rob_index(rob, R::I_WORD, rpw, R::I_COUNT)] & 3;
+  int progress;
+  if (walk_state != WS_STOPPED) {
+    st.robd[rob_index(rob, R::VIN, rpw, R::COUNT)] = 0.0;
+    st.robd[rob_index(rob, R::VIN + 1, rpw, R::COUNT)] = 0.0;
+    st.robd[rob_index(rob, R::WIN, rpw, R::COUNT)] = 0.0;
+    st.manual[rob].skip_cycle = 0;
+    *walking_out = 1;
+    progress = -1;
+  } else {
+    st.manual[rob].skip_cycle = 1;
+    for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
+    if (!s.configuration_acquired && !s.tip_pose_acquired && !s.body_pose_acquired) {
+      const Pose current_pose = robot_current_pose<L>(st, rob);
+      for (int l = 0; l < L; ++l) { // Model::updateModel: setDesiredTipPose() = the poser's tip pose + admittance delta, applyIK
+        const LegIO<NJ> io{st, slot_of(rob, l, L)};
+        double tip[7];
+        if (s.poser_tip_from_plan) {
+          for (int k = 0; k < 7; ++k) tip[k] = s.leg[l].current[k];
+        } else {
+          put_pose7(tip, inverse_transform_vector(current_pose, io.get3(FD::TIP)), Quat{0, 0, 0, 0}); // updateStance (pose_controller.cpp:122-131)
+        }
+        set_desired_dev<NJ>(st, io, L, rob, tip, 1, P.have_adm, 0);
+        apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
+      }
+      progress = -2;
+    } else {
+      progress = 0x7fffffff;
+      if (s.configuration_acquired) {
+        for (int l = 0; l < L; ++l) {
+          SeqLegState &sl = s.leg[l];
+          const LegIO<NJ> io{st, slot_of(rob, l, L)};
+          if (!s.executing_transition) { // setDesiredConfiguration (:750-757)
+            sl.plan_latched = sl.plan_named;
+            for (int j = 0; j < NJ; ++j) sl.plan_desired[j] = sl.plan_configuration[j];
+          }
+          int p = 100; // a leg the message does not name has no desired configuration (:1479-1482)
+          if (sl.plan_latched) p = transition_configuration_dev<NJ>(io, sl.plan_desired, kPlanTransitionTime, P.dt);
+          progress = p < progress ? p : progress;
+        }
+        s.executing_transition = (progress != 0 && progress != 100);
+      } else {
+        const double *b = s.target_body_pose;
+        const Pose body{V3{b[0], b[1], b[2]}, Quat{b[3], b[4], b[5], b[6]}};
+        for (int l = 0; l < L; ++l) {
+          const LegIO<NJ> io{st, slot_of(rob, l, L)};
+          auto xf = [&](int field) -> double & { return st.ext[leg_field_index(field, io.slot, st.n_slots)]; };
+          const bool defined = st.ext != nullptr && (int(xf(X::P_FLAGS)) & 1) != 0;
+          double target[7], clearance = 0.0;
+          if (defined) { // target.transform_.addPose(target.pose_) (:781)
+            const Pose tr{V3{xf(X::P_TRANSFORM), xf(X::P_TRANSFORM + 1), xf(X::P_TRANSFORM + 2)},
+                          Quat{xf(X::P_TRANSFORM + 3), xf(X::P_TRANSFORM + 4), xf(X::P_TRANSFORM + 5), xf(X::P_TRANSFORM + 6)}};
+            const Quat pr{xf(X::P_POSE + 3), xf(X::P_POSE + 4), xf(X::P_POSE + 5), xf(X::P_POSE + 6)};
+            put_pose7(target, transform_vector(tr, V3{xf(X::P_POSE), xf(X::P_POSE + 1), xf(X::P_POSE + 2)}), tr.r * pr);
+            clearance = xf(X::P_CLEARANCE);
+          }
+          Pose tip;
+          const int p = step_to_position_dev<NJ>(st, io, gc->leg[l], defined ? target : nullptr, body, clearance, kPlanTransitionTime, 1, P.have_adm, P.dt, tip);
+          put_pose7(s.leg[l].current, tip);
+          set_desired_dev<NJ>(st, io, L, rob, s.leg[l].current, 1, P.have_adm, 0);
+          apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
+          progress = p < progress ? p : progress;
+          if (defined && p == 100) xf(X::P_FLAGS) = double(int(xf(X::P_FLAGS)) & ~1); // target achieved (:801-805)
+        }
+        s.poser_tip_from_plan = 1;
+      }
+      if (progress == 100) {
+        s.plan_step++;
+        s.target_body_pose[0] = s.target_body_pose[1] = s.target_body_pose[2] = 0.0; // poser_->setTargetBodyPose(Pose::Identity())
+        s.target_body_pose[3] = 1.0;
+        s.target_body_pose[4] = s.target_body_pose[5] = s.target_body_pose[6] = 0.0;
+        s.configuration_acquired = s.tip_pose_acquired = s.body_pose_acquired = 0;
+      }
+    }
+  }
+  if (progress_out) progress_out[rob] = progress;
+  if (plan_step_out) plan_step_out[rob] = s.plan_step;
+}
+
+// plannerModeCallback / targetConfigurationCallback / targetBodyPoseCallback (state_controller.cpp:1262-1281, :1683-1702)
+__global__ void plan_inputs_kernel(SeqRobotState *seq, int64_t first, int64_t count, int L, int NJ, int reset_plan_step, const double *configuration,
+                                   const double *body_pose) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  SeqRobotState &s = seq[first + t];
+  seq_defaults(s);
+  if (reset_plan_step) s.plan_step = 0;
+  if (configuration) {
+    for (int l = 0; l < L; ++l) {
+      const double *row = configuration + (t * L + l) * NJ;
+      s.leg[l].plan_named = !isnan(row[0]);
+      for (int j = 0; j < NJ; ++j) s.leg[l].plan_configuration[j] = row[j];
+    }
+    s.configuration_acquired = 1;
+  }
+  if (body_pose) {
+    for (int k = 0; k < 7; ++k) s.target_body_pose[k] = body_pose[t * 7 + k];
+    s.body_pose_acquired = 1;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------- manual leg manipulation
 // StateController::legStateToggle (state_controller.cpp:541-646) for the leg each instance's request designates (leg_selection[rob],
 // -1 = no request), with PoseController::poseForLegManipulation (pose_controller.cpp:561-611) and AdmittanceController::
@@ -324,21 +455,28 @@ constexpr int kMaxManualLegs = 2; // MAX_MANUAL_LEGS (state_controller.h:26)
 
 template <int L, int NJ>
 __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *gc, const int32_t *leg_selection, SeqParams P, double virtual_stiffness,
-                                        double swing_stiffness_scaler, double load_stiffness_scaler, int dynamic_stiffness, int32_t *result_out) {
+                                        double swing_stiffness_scaler, double load_stiffness_scaler, int dynamic_stiffness, int32_t *result_out,
+                                        int32_t *cycle_out) {
   using FD = Fields<NJ>;
   using R = RobotFields;
   const int64_t rob = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (rob >= st.n_robots) return;
   const int sel = leg_selection[rob];
   int result = -3;
+  st.manual[rob].skip_cycle = 0; // no request, or still walking: this robot's loop is the ordinary control cycle (launched next)
   if (sel >= 0 && sel < L) {
     ManualRobot &m = st.manual[rob];
     constexpr int rpw = 64 / L;
     const int walk_state = st.robi[rob_index(rob, R::I_WORD, rpw, R::I_COUNT)] & 3;
-    if (walk_state == WS_STOPPED) // the posing part of this loop (a robot that is still walking runs its whole loop in the cycle kernel)
+    if (walk_state == WS_STOPPED) { // the posing part of this loop (a robot that is still walking runs its whole loop in the cycle kernel)
       for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P);
+      m.skip_cycle = 1;
+    }
     if (walk_state != WS_STOPPED) {
-      result = -1;
+      result = -1; // "Stopping Syropod to transition leg state": the velocity inputs are forced to zero (:641-645)
+      st.robd[rob_index(rob, R::VIN, rpw, R::COUNT)] = 0.0;
+      st.robd[rob_index(rob, R::VIN + 1, rpw, R::COUNT)] = 0.0;
+      st.robd[rob_index(rob, R::WIN, rpw, R::COUNT)] = 0.0;
     } else if (m.leg_state[sel] == LS_WALKING) {
       if (m.manual_leg_count < kMaxManualLegs) {
         m.leg_state[sel] = LS_WALKING_TO_MANUAL;
@@ -414,6 +552,7 @@ __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *
       }
     }
   }
+  if (result == -1 || result == -3) *cycle_out = 1;
   if (result_out) result_out[rob] = result;
 }
 

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_begin_sequence_startup", "shc_engine_execute_sequence", "shc_engine_finish_sequence_startup", "shc_engine_step_to_new_stance",
     "shc_engine_pack_legs", "shc_engine_unpack_legs",
     "shc_engine_toggle_leg_state", "shc_engine_set_manual_inputs", "shc_engine_get_leg_manipulation_state",
+    "shc_engine_set_planner_mode", "shc_engine_set_target_configuration", "shc_engine_set_target_body_pose", "shc_engine_execute_plan",
     "shc_fleet_create", "shc_fleet_destroy", "shc_fleet_instances", "shc_fleet_shape", "shc_fleet_part_count", "shc_fleet_part",
     "shc_fleet_part_instances", "shc_fleet_set_velocity", "shc_fleet_set_imu", "shc_fleet_set_pose_input", "shc_fleet_set_tip_force",
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
@@ -144,6 +145,10 @@ def lib():
         L.shc_engine_finish_sequence_startup.argtypes = [C.c_void_p]
         L.shc_engine_step_to_new_stance.argtypes = [C.c_void_p, C.c_void_p]
         L.shc_engine_toggle_leg_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.shc_engine_set_planner_mode.argtypes = [C.c_void_p, C.c_int]
+        L.shc_engine_set_target_configuration.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.shc_engine_set_target_body_pose.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.shc_engine_execute_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.shc_engine_set_manual_inputs.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.shc_engine_get_leg_manipulation_state.argtypes = [C.c_void_p, C.c_void_p]
         L.shc_engine_pack_legs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int32)]
@@ -440,6 +445,25 @@ class BatchEngine:
         out = np.zeros((self.n, self.legs), dtype=np.int32)
         _check(self.L.shc_engine_get_leg_manipulation_state(self.h, _p(out)), "get_leg_manipulation_state")
         return out
+
+    # -- planner mode (StateController::executePlan)
+    def set_planner_mode(self, on):
+        _check(self.L.shc_engine_set_planner_mode(self.h, int(bool(on))), "set_planner_mode")
+
+    def set_target_configuration(self, configuration, first=0):
+        """targetConfigurationCallback: rows [count][legs][dof]; NaN in a leg's first joint = leg not named."""
+        a = np.ascontiguousarray(configuration, dtype=np.float64).reshape(-1, self.legs * self.dof)
+        _check(self.L.shc_engine_set_target_configuration(self.h, first, a.shape[0], _p(a)), "set_target_configuration")
+
+    def set_target_body_pose(self, pose, first=0):
+        a = np.ascontiguousarray(pose, dtype=np.float64).reshape(-1, 7)
+        _check(self.L.shc_engine_set_target_body_pose(self.h, first, a.shape[0], _p(a)), "set_target_body_pose")
+
+    def execute_plan(self):
+        """One StateController::loop() in planner mode for every instance -> (progress [n], plan_step [n])."""
+        progress, step = np.zeros(self.n, dtype=np.int32), np.zeros(self.n, dtype=np.int32)
+        _check(self.L.shc_engine_execute_plan(self.h, _p(progress), _p(step)), "execute_plan")
+        return progress, step
 
     def pack_legs(self, packed_positions, time_to_pack, unpack=False):
         """One PoseController::packLegs / unpackLegs call; packed_positions [n_pack_steps][legs][dof]."""

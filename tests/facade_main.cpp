@@ -52,15 +52,26 @@ int main(int argc, char **argv) {
       ExternalTarget back = stepper.getExternalTarget();
       printf("external %d %.17g %.17g\n", back.defined_ ? 1 : 0, back.pose_.position_[0], back.swing_clearance_);
     }
-    { // manual leg manipulation: stop, toggle leg 3 to MANUAL (legStateToggle), place its tip with updateManual's pose overload
-      double zero2[2] = {0.0, 0.0};
+    { // planner mode: executePlan stops the robot, waits for plan step 0, runs a body-pose step (transitionStance)
+      engine->setPlannerMode(true);
+      int progress = SHC_PLAN_WALKING, stop_calls = 0, step_calls = 0;
+      while (progress != SHC_PLAN_WAITING && stop_calls < 4000) {
+        progress = engine->executePlan(); // (a robot that is still walking: velocity inputs zeroed, one ordinary cycle)
+        ++stop_calls;
+      }
+      poser->setTargetBodyPose(Pose{{{0.01, -0.005, 0.008}}, {1.0, 0.0, 0.0, 0.0}});
+      while (progress != 100 && step_calls < 4000) {
+        progress = engine->executePlan();
+        ++step_calls;
+      }
+      engine->setPlannerMode(false);
+      Vector3 tip = model->getLegByIDNumber(0).getCurrentTipPosition();
+      printf("plan %d %d %d %.17g %.17g %.17g\n", stop_calls, step_calls, engine->planStep(), tip[0], tip[1], tip[2]);
+    }
+    { // manual leg manipulation: toggle leg 3 to MANUAL (legStateToggle), place its tip with updateManual's pose overload
       int result = -1, calls = 0;
       while (result != 1 && calls < 4000) {
-        result = engine->legStateToggle(3);
-        if (result == -1) { // still walking: zero the velocity inputs and run the normal cycle of this loop (state_controller.cpp:641-645)
-          walker->updateWalk(zero2, 0.0);
-          model->updateModel();
-        }
+        result = engine->legStateToggle(3); // (-1 while the robot still walks: the call zeroes the velocity inputs and runs that loop's cycle)
         ++calls;
       }
       const Pose none{{{0.0, 0.0, 0.0}}, {0.0, 0.0, 0.0, 0.0}};

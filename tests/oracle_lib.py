@@ -86,6 +86,11 @@ def lib():
         L.orc_leg_state_toggle.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_leg_manipulation_state.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_manual_inputs.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.c_int, _dp, _dp]
+        L.orc_set_planner_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_target_configuration.argtypes = [C.c_void_p, _dp]
+        L.orc_set_target_body_pose.argtypes = [C.c_void_p, _dp]
+        L.orc_execute_plan.argtypes = [C.c_void_p]
+        L.orc_get_plan_step.argtypes = [C.c_void_p]
         L.orc_pack_legs.argtypes = [C.c_void_p, _dp, C.c_int, C.c_double]
         L.orc_unpack_legs.argtypes = [C.c_void_p, _dp, C.c_int, C.c_double]
         L.orc_set_external_target.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -328,11 +333,13 @@ class OracleBatch:
 
     # ---- manual leg manipulation
     def toggle_leg_state(self, leg_selection):
-        """One StateController loop with the toggle request pending, per robot (-1 = no request: result -3, nothing runs)."""
+        """One StateController loop per robot, with the toggle request pending (-1 = no request: result -3, an ordinary loop)."""
         out = np.full(self.n, -3, dtype=np.int32)
         for i in range(self.n):
             if leg_selection[i] >= 0:
                 out[i] = self.L.orc_leg_state_toggle(self.L.orc_batch_robot(self.h, i), int(leg_selection[i]))
+            else:
+                self.L.orc_cycle(self.L.orc_batch_robot(self.h, i))
         return out
 
     def set_manual_inputs(self, primary_leg=None, primary_velocity=None, primary_position=None, secondary_leg=None, secondary_velocity=None,
@@ -345,6 +352,26 @@ class OracleBatch:
 
     def leg_manipulation_state(self):
         return np.array([[self.L.orc_get_leg_manipulation_state(self.L.orc_batch_robot(self.h, i), l) for l in range(self.legs)] for i in range(self.n)], dtype=np.int32)
+
+    # ---- planner mode
+    def set_planner_mode(self, on):
+        for i in range(self.n):
+            self.L.orc_set_planner_mode(self.L.orc_batch_robot(self.h, i), int(bool(on)))
+
+    def set_target_configuration(self, configuration, first=0):
+        a = np.ascontiguousarray(configuration, dtype=np.float64).reshape(-1, self.dof)
+        for k in range(a.shape[0]):
+            self.L.orc_set_target_configuration(self.L.orc_batch_robot(self.h, first + k), _ptr(a[k]))
+
+    def set_target_body_pose(self, pose, first=0):
+        a = np.ascontiguousarray(pose, dtype=np.float64).reshape(-1, 7)
+        for k in range(a.shape[0]):
+            self.L.orc_set_target_body_pose(self.L.orc_batch_robot(self.h, first + k), _ptr(a[k]))
+
+    def execute_plan(self):
+        progress = np.array([self.L.orc_execute_plan(self.L.orc_batch_robot(self.h, i)) for i in range(self.n)], dtype=np.int32)
+        step = np.array([self.L.orc_get_plan_step(self.L.orc_batch_robot(self.h, i)) for i in range(self.n)], dtype=np.int32)
+        return progress, step
 
     def pack_legs(self, packed_positions, time_to_pack, unpack=False):
         a = np.ascontiguousarray(packed_positions, dtype=np.float64)
@@ -367,9 +394,15 @@ class OracleBatch:
         legs = self.legs
         assert len(rows) == self.n * legs
         ignored = 0
+        stopped = self.body_state()[2] == 3
         for i in range(self.n):
             for l in range(legs):
-                ignored += 0 if self.L.orc_set_external_target(self.L.orc_batch_robot(self.h, i), which, l, C.byref(rows[i * legs + l])) else 1
+                r = rows[i * legs + l]
+                if which == 0 and r.defined and stopped[i] and self.p.leg_dof[0] <= 3 and any(r.pose[k] != 0.0 for k in range(3, 7)):
+                    ignored += 1   # the engine's documented limit: a planner target with a tip rotation needs the rotation-constrained
+                    continue       # IK, which it runs on legs with more than 3 joints only (the reference's LegPoser would take it)
+                took = self.L.orc_set_external_target(self.L.orc_batch_robot(self.h, i), which, l, C.byref(rows[i * legs + l]))
+                ignored += 0 if took else 1  # 1 a LegStepper took it, 2 the planner-mode LegPoser (robot STOPPED), 0 dropped
         return ignored
 
     def set_external_transform(self, transform, which=0):

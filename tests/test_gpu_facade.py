@@ -85,6 +85,25 @@ def test_facade_sequence_start_up_and_external_target(tmp_path):
     assert np.abs(q_walk - ob.joints()[0][0]).max() <= 1e-6
     tag, defined, x, clearance = out[37].split()     # requested while the robot walks (a STOPPED robot's request goes to the planner)
     assert (tag, defined) == ("external", "1") and float(x) == 0.2 and float(clearance) == 0.03
+    # planner mode through the facade: stop, wait for plan step 0, a body-pose step
+    ob.set_planner_mode(True)
+    stop_calls = step_calls = 0
+    while True:
+        stop_calls += 1
+        if ob.execute_plan()[0][0] == -2:
+            break
+    ob.set_target_body_pose(np.array([[0.01, -0.005, 0.008, 1.0, 0, 0, 0]]))
+    while True:
+        step_calls += 1
+        pr, st = ob.execute_plan()
+        if pr[0] == 100:
+            break
+    ob.set_planner_mode(False)
+    pl = out[38].split()
+    assert pl[0] == "plan" and [int(x) for x in pl[1:4]] == [stop_calls, step_calls, int(st[0])] and int(st[0]) == 1
+    # free-running through ~250 calls of a robot that stands (where the reference's IK step amplifies rounding differences,
+    # tests/test_gpu_planner.py holds every call to 1e-10 teacher-forced); here: same calls, same place
+    assert np.abs(np.array([float(x) for x in pl[4:7]]) - ob.leg_state()["model_tip"][0, 0]).max() <= 5e-3
     # manual leg manipulation through the facade: the same requests on the oracle
     sel = np.array([3], dtype=np.int32)
     while ob.toggle_leg_state(sel)[0] != 1:
@@ -93,6 +112,6 @@ def test_facade_sequence_start_up_and_external_target(tmp_path):
     ob.set_velocity(np.array([[v[0], v[1]]]), np.array([v[2]]))
     ob.set_manual_inputs(sel, None, where, None, None, None)
     ob.step(30, 1)
-    m = out[38].split()
+    m = out[39].split()
     assert m[0] == "manual" and m[1] == "1" and m[6] == "3"                      # toggled, robot STOPPED
-    assert np.abs(np.array([float(x) for x in m[2:5]]) - ob.leg_state()["model_tip"][0, 3]).max() <= 1e-6
+    assert np.abs(np.array([float(x) for x in m[2:5]]) - ob.leg_state()["model_tip"][0, 3]).max() <= 5e-3

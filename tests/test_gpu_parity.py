@@ -1122,7 +1122,10 @@ def test_error_codes(Engine):
     assert L.shc_engine_get_state(eng.h, 11, 2, st) == INVALID and L.shc_engine_get_state(eng.h, -1, 1, st) == INVALID
     assert L.shc_engine_set_state(eng.h, 0, 1, None) == INVALID
     rows = (ExternalTarget * 6)()
-    assert L.shc_engine_set_external_target(eng.h, 0, 0, 1, -1, rows, None) == UNSUPPORTED       # not in rough terrain mode
+    q18 = (C.c_double * (18 * 11))()
+    assert L.shc_engine_set_external_target(eng.h, 1, 0, 1, -1, rows, None) == UNSUPPORTED       # a default pose outside rough terrain mode
+    assert L.shc_engine_set_external_target(eng.h, 3, 0, 1, -1, rows, None) == INVALID           # no such record
+    assert L.shc_engine_set_target_configuration(eng.h, 5, 11, q18) == INVALID and L.shc_engine_set_target_body_pose(eng.h, 0, 1, None) == INVALID
     assert L.shc_engine_execute_sequence(eng.h, 7, None) == INVALID                              # no such sequence
     assert L.shc_engine_execute_sequence(None, 0, None) == INVALID
     pr = C.c_int32(0)

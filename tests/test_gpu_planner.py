@@ -1,0 +1,179 @@
+"""GPU: planner mode - StateController::executePlan (state_controller.cpp:653-698) with PoseController::transitionConfiguration /
+transitionStance (pose_controller.cpp:710-807), the planner callbacks (:1683-1767) and the LegPoser's external target -
+against the oracle."""
+import numpy as np
+import pytest
+
+from oracle_lib import OracleBatch
+from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
+from syropod_highlevel_controller_amd.engine import BatchEngine
+from syropod_highlevel_controller_amd.params import WALK_STOPPED, ExternalTarget
+
+pytestmark = pytest.mark.gpu
+WAITING, WALKING = -2, -1
+
+
+@pytest.mark.parametrize("case", ["hexapod", "hexapod-admittance", "8x4"])
+def test_plan_steps_against_the_oracle(case):
+    """Walk; switch planner mode on: robots still walking are stopped by the call itself (result -1, their loop is the normal
+    cycle) while the ones that stand already wait for plan step 0 (result -2, Model::updateModel only); a joint-configuration step
+    (some legs not named, different per robot), a wait, a tip-target + body-pose step (targets sent through the TargetTipPose path:
+    the robots stand, so the LegPosers take them), a body-pose-only step; planner off and walk again.  The oracle's state is
+    injected before every call (the robots stand still throughout, where the reference's IK step amplifies rounding differences
+    - DESIGN.md section 2.1); progress values, plan steps and request flags are compared exactly."""
+    if case == "8x4":
+        p = synthetic_octopod_params("ripple", 4, 8)
+    else:
+        p = default_hexapod_params("tripod")
+    if "admittance" in case:
+        p.admittance_control = 1
+    n = 8
+    L, D = p.leg_count, p.leg_dof[0]
+    rng = np.random.default_rng(31)
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    lin, ang = rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-0.5, 0.5, n)
+    lin[:2], ang[:2] = 0.0, 0.0                        # robots 0, 1 never walk: they are STOPPED when planner mode starts
+    for o in (eng, ob):
+        o.set_velocity(lin, ang)
+        if p.admittance_control:
+            o.set_tip_force(np.full((n, L, 3), 1.5))
+    worst = 0.0
+
+    def check(tag, rows=slice(None)):
+        nonlocal worst
+        dd = np.abs(eng.joints()[0] - ob.joints()[0])[rows]
+        d = float(dd.max()) if dd.size else 0.0
+        worst = max(worst, d)
+        assert d < 1e-10, (tag, d)
+
+    def forced_cycles(k):
+        for _ in range(k):
+            eng.set_state(ob.get_state())
+            eng.step(1)
+            eng.synchronize()
+            ob.step(1, 1)
+            check("cycle")
+            assert np.array_equal(eng.body_state()[2], ob.body_state()[2])
+
+    def plan_call():
+        eng.set_state(ob.get_state())
+        (pe, se), (po, so) = eng.execute_plan(), ob.execute_plan()
+        assert np.array_equal(pe, po), (pe, po)
+        assert np.array_equal(se, so), (se, so)
+        check("plan")
+        assert np.array_equal(eng.body_state()[2], ob.body_state()[2])
+        return pe, se
+
+    def run_step(expect_step, limit=400):
+        seen, done = set(), np.zeros(n, dtype=bool)   # (robots finish in different calls - e.g. one whose message names no leg - and wait)
+        for _ in range(limit):
+            pr, st = plan_call()
+            seen.update(pr.tolist())
+            assert ((pr == WAITING) == done).all()
+            done |= pr == 100
+            if done.all():
+                break
+        assert done.all() and (st == expect_step).all()
+        return seen
+
+    forced_cycles(60)
+    for o in (eng, ob):
+        o.set_planner_mode(True)
+    seen = set()
+    for _ in range(600):                               # walking robots stop (a step period or two), standing ones wait
+        pr, st = plan_call()
+        seen.update(pr.tolist())
+        if (pr == WAITING).all():
+            break
+    assert seen == {WALKING, WAITING} and (pr == WAITING).all() and (st == 0).all()
+    assert (eng.body_state()[2] == WALK_STOPPED).all()
+    # ---- plan step 0: a joint configuration; robot i leaves leg i % L out of the message, robot 7 names no leg at all
+    q0 = ob.joints()[0].reshape(n, L, D).copy()
+    cfg = q0 + rng.uniform(-0.12, 0.12, q0.shape)
+    for i in range(n):
+        cfg[i, i % L, :] = np.nan
+    cfg[7] = np.nan
+    for o in (eng, ob):
+        o.set_target_configuration(cfg)
+    seen = run_step(1)
+    assert 1 in seen and 50 in seen
+    q1 = eng.joints()[0].reshape(n, L, D)
+    named = ~np.isnan(cfg[:, :, 0])
+    assert np.abs(q1[named] - cfg[named]).max() < 1e-12          # cubic Bezier ends on its last node
+    assert np.array_equal(q1[:7][~named[:7]], q0[:7][~named[:7]])  # a leg the message leaves out stays (robot 7 finished at once and has
+                                                                   # been waiting since: its updateModel keeps stepping the IK)
+    for _ in range(5):                                 # waiting for plan step 1: updateModel pulls towards the (stale) poser tips
+        pr, st = plan_call()
+        assert (pr == WAITING).all() and (st == 1).all()
+    # ---- plan step 1: tip targets for half the legs (with a swing clearance) + a body pose for the even robots
+    tips = ob.leg_state()["model_tip"].reshape(n, L, 3)
+    rows = (ExternalTarget * (n * L))()
+    for i in range(n):
+        for l in range(L):
+            if (i + l) % 2:
+                continue
+            r = rows[i * L + l]
+            r.defined = 1
+            off = rng.normal(size=3)       # 3.5 - 4.5 cm away: a target that the body pose brings within TIP_TOLERANCE of the tip with
+            off *= rng.uniform(0.035, 0.045) / np.linalg.norm(off)   # no lift makes its leg start a call late and the reference never finish
+            r.pose[0:3] = list(tips[i, l] + off)
+            r.pose[3:7] = [0, 0, 0, 0]                 # UNDEFINED_ROTATION
+            r.transform[:] = [0, 0, 0, 1, 0, 0, 0]
+            r.swing_clearance = 0.02 if l % 3 else 0.0
+    assert eng.set_external_target(rows) == 0 and ob.set_external_target(rows) == 0     # every robot stands: the LegPosers take them
+    tr = np.tile(np.array([0.004, -0.003, 0.0, 1, 0, 0, 0.0]), (n, L, 1))              # the tf refresh of a defined planner target
+    tr[:, :, 3:] = [np.cos(0.01), 0, 0, np.sin(0.01)]
+    for o in (eng, ob):
+        o.set_external_transform(tr, which=2)
+    body = np.tile(np.array([0, 0, 0, 1.0, 0, 0, 0]), (n, 1))
+    for i in range(0, n, 2):
+        body[i] = [0.01, -0.008, 0.012, np.cos(0.02), np.sin(0.02), 0, 0]
+    for i in range(0, n, 2):
+        for o in (eng, ob):
+            o.set_target_body_pose(body[i:i + 1], first=i)
+    got = [(r.defined, r.swing_clearance, tuple(r.transform)) for r in eng.get_external_target(which=2)]
+    assert got == [(r.defined, r.swing_clearance, tuple(r.transform)) for r in ob.get_external_target(which=2)]
+    run_step(2)
+    assert not any(r.defined for r in eng.get_external_target(which=2))                # achieved targets are withdrawn (:801-805)
+    assert not any(r.defined for r in ob.get_external_target(which=2))
+    reached = eng.leg_state()["model_tip"].reshape(n, L, 3)
+    for i in (range(1, n, 2) if not p.admittance_control else ()):   # identity body pose: the tips sit on transform * target (IK_TOLERANCE aside)
+        for l in range(L):
+            r = rows[i * L + l]
+            if r.defined:
+                c, s_ = np.cos(0.02), np.sin(0.02)     # yaw by 0.02 rad
+                x, y, z = r.pose[0], r.pose[1], r.pose[2]
+                want = np.array([0.004 + c * x - s_ * y, -0.003 + s_ * x + c * y, z])
+                assert np.abs(reached[i, l] - want).max() < 1.5e-2   # (one DLS step per iteration trails the Bezier; 7 mm on 4-joint legs)
+    # ---- plan step 2: a body pose alone
+    for o in (eng, ob):
+        o.set_target_body_pose(np.tile(np.array([0.0, 0.01, -0.01, 1.0, 0, 0, 0]), (n, 1)))
+    run_step(3)
+    pr, st = plan_call()
+    assert (pr == WAITING).all() and (st == 3).all()
+    # ---- planner off: walk again
+    lin = rng.uniform(-0.4, 0.4, (n, 2))
+    for o in (eng, ob):
+        o.set_planner_mode(False)
+        o.set_velocity(lin, np.full(n, 0.2))
+    forced_cycles(120)
+    assert (eng.body_state()[2] != WALK_STOPPED).all()
+    from conftest import parity_report
+    parity_report(f"[planner {case}] stop / wait / configuration step / tip-target + body-pose step / body-pose step / walk: progress and plan steps "
+                  f"identical, max |dq| = {worst:.2e} rad per call (teacher-forced)")
+
+
+def test_planner_unsupported_configurations():
+    for field in ("imu_posing", "auto_posing", "gravity_aligned_tips"):
+        p = default_hexapod_params("tripod")
+        setattr(p, field, 1)
+        eng = BatchEngine(p, 2)
+        with pytest.raises(RuntimeError):
+            eng.execute_plan()
+    # a planner target with a tip rotation needs the rotation-constrained IK: legs with more than 3 joints only
+    eng = BatchEngine(default_hexapod_params("tripod"), 2)
+    rows = (ExternalTarget * 12)()
+    rows[0].defined = 1
+    rows[0].pose[3] = 1.0
+    with pytest.raises(RuntimeError):
+        eng.set_external_target(rows, which=2)

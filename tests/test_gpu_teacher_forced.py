@@ -410,8 +410,12 @@ def test_rough_terrain_external_targets(Engine, case):
     for key in ("ext_target", "ext_default"):
         ig = sched.ignored[key]
         assert ig[0::2] == ig[1::2], "engine and oracle ignored different requests"     # (engine, oracle) pairs
-        assert sum(ig) > 0                                                                # some robots were STOPPED
-    for which in (0, 1):                 # the records as the steppers hold them now
+        # some robots were STOPPED: their default poses are dropped; their targets go to the planner-mode LegPosers (a target with
+        # a tip rotation cannot on <= 3-DOF legs - planner mode would need the rotation-constrained IK there - and is dropped too)
+        assert sum(ig) > 0 or (key == "ext_target" and rot == "undefined")
+    if rot == "undefined":
+        assert any(r.defined for r in ob.get_external_target(2))
+    for which in (0, 1, 2):              # the records as the steppers / posers hold them now
         a, b = eng.get_external_target(which), ob.get_external_target(which)
         assert bytes(a) == bytes(b)
     assert any(r.defined for r in ob.get_external_target(1))
@@ -425,8 +429,8 @@ def test_external_target_errors(Engine):
     p = default_hexapod_params("tripod")
     eng = Engine(p, 4)
     rows = (ExternalTarget * 24)()
-    with pytest.raises(RuntimeError):                      # read in rough terrain mode only
-        eng.set_external_target(rows)
+    with pytest.raises(RuntimeError):                      # default poses are read in rough terrain mode only
+        eng.set_external_target(rows, which=1)
     p = synthetic_octopod_params("ripple", 4, 6)
     p.rough_terrain_mode = 1
     eng = Engine(p, 4)
@@ -437,7 +441,9 @@ def test_external_target_errors(Engine):
     with pytest.raises(RuntimeError):                      # a tip rotation request on 4-DOF legs
         eng.set_external_target(rows)
     rows[3].pose[3] = 0.0
-    assert eng.set_external_target(rows) == 1              # the robot is STOPPED: the planner-mode LegPoser would take it
+    assert eng.set_external_target(rows) == 0              # the robot is STOPPED: its planner-mode LegPoser takes the target
+    assert [r.defined for r in eng.get_external_target(2)] == [int(k == 3) for k in range(24)]
+    assert not any(r.defined for r in eng.get_external_target(0))
 
 
 def test_rough_terrain_mode_free_running(Engine):

@@ -157,3 +157,67 @@ def test_manual_leg_manipulation_invariants():
     assert (ob.leg_manipulation_state() == 0).all()
     ob.step(150, 1)
     assert ob.body_state()[2][0] == WALK_MOVING
+
+
+def test_planner_mode_invariants():
+    """Planner mode (state_controller.cpp:653-698, pose_controller.cpp:710-807) whatever the implementation: executePlan first
+    stops a walking robot (-1), then waits (-2); a configuration step takes transition_time / time_delta calls, ends exactly on the
+    named legs' target joints and leaves the other legs alone; a tip target handed to a standing robot goes to its LegPoser, is
+    reached within the IK tolerance (with the requested lift on the way) and is withdrawn on completion; a body-pose step moves
+    every tip by the inverse pose; each completed step advances plan_step_."""
+    from oracle_lib import OracleBatch
+    from syropod_highlevel_controller_amd.params import ExternalTarget
+    p = default_hexapod_params("tripod")
+    L, D = p.leg_count, p.leg_dof[0]
+    ob = OracleBatch(p, 1)
+    ob.set_velocity(np.array([[0.3, 0.1]]), np.array([0.1]))
+    ob.step(100, 1)
+    ob.set_planner_mode(True)
+    res = []
+    while not res or res[-1] != -2:
+        res.append(int(ob.execute_plan()[0][0]))
+        assert len(res) < 2000
+    assert set(res) == {-1, -2} and ob.body_state()[2][0] == WALK_STOPPED
+    calls = round(5.0 / p.time_delta)
+    # a joint configuration for legs 0, 2, 4
+    q0 = ob.joints()[0].reshape(L, D).copy()
+    cfg = q0 + 0.1
+    cfg[1::2] = np.nan
+    ob.set_target_configuration(cfg[None])
+    res = []
+    while not res or res[-1] != 100:
+        res.append(int(ob.execute_plan()[0][0]))
+    assert len(res) == calls and res[0] == 1 and sorted(res) == res
+    q1 = ob.joints()[0].reshape(L, D)
+    assert np.abs(q1[0::2] - cfg[0::2]).max() < 1e-12 and np.array_equal(q1[1::2], q0[1::2])
+    assert ob.execute_plan()[1][0] == 1
+    # a tip target for leg 3 (2 cm lift), sent the TargetTipPose way
+    for _ in range(200):        # (let the waiting loop's updateModel settle back on the poser tips)
+        ob.execute_plan()
+    tip0 = ob.leg_state()["model_tip"][0].copy()
+    rows = (ExternalTarget * L)()
+    rows[3].defined = 1
+    target = tip0[3] + np.array([0.03, -0.02, 0.0])
+    rows[3].pose[0:3] = list(target)
+    rows[3].transform[:] = [0, 0, 0, 1, 0, 0, 0]
+    rows[3].swing_clearance = 0.02
+    assert ob.set_external_target(rows) == 0 and ob.get_external_target(2)[3].defined == 1 and not ob.get_external_target(0)[3].defined
+    top, res = -1e9, []
+    while not res or res[-1] != 100:
+        res.append(int(ob.execute_plan()[0][0]))
+        top = max(top, ob.leg_state()["model_tip"][0, 3, 2])
+    assert len(res) == calls
+    tip1 = ob.leg_state()["model_tip"][0]
+    assert np.abs(tip1[3] - target).max() < 5e-3 and top > tip0[3, 2] + 0.012 and not ob.get_external_target(2)[3].defined
+    # (a leg without a target re-latches its own FK tip as the target of every call; the joint-limit cost gradient of the DLS step
+    #  moves it although the tip error is zero, so it creeps - 7 mm over this step - rather than stands)
+    assert np.abs(np.delete(tip1, 3, axis=0) - np.delete(tip0, 3, axis=0)).max() < 1e-2
+    # a body pose: every tip ends on pose^-1 * tip
+    shift = np.array([0.012, -0.01, 0.008])
+    ob.set_target_body_pose(np.array([[*shift, 1.0, 0, 0, 0]]))
+    res = []
+    while not res or res[-1] != 100:
+        res.append(int(ob.execute_plan()[0][0]))
+    assert len(res) == calls
+    assert np.abs(ob.leg_state()["model_tip"][0] - (tip1 - shift)).max() < 5e-3
+    assert ob.execute_plan()[1][0] == 3
