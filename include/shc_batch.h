@@ -533,9 +533,9 @@ enum { SHC_EXTERNAL_TARGET = 0, SHC_EXTERNAL_DEFAULT = 1, SHC_EXTERNAL_PLANNER_T
  * count); rows is a HOST array.  As in the callback (:1734-1757), a LegStepper takes a request only while its robot is not
  * STOPPED; the TARGET of a robot that stands goes to its LegPoser for planner mode (and raises target_tip_pose_acquired_, see
  * shc_engine_execute_plan), a DEFAULT for it is dropped.  Dropped rows are counted in *ignored (may be NULL): defaults for
- * standing robots, stepper requests without rough_terrain_mode (no stepper reads them), and targets with a tip rotation that would
- * go to the LegPoser of a robot with <= 3 joints per leg.  The stepper keeps only the x axis of tip rotations (see
- * shc_leg_snapshot), and legs with <= 3 joints none at all: a defined target rotation on > 3-DOF legs is SHC_ERR_UNSUPPORTED.
+ * standing robots and stepper requests without rough_terrain_mode (no stepper reads them).  The stepper keeps only the x axis of tip rotations (see
+ * shc_leg_snapshot), and legs with <= 3 joints none at all: a defined target rotation on > 3-DOF legs is SHC_ERR_UNSUPPORTED
+ * (it may still reach a LegPoser, which hands it to Leg::applyIK as it is: rotation-constrained solve + unconstrained retry).
  * which = SHC_EXTERNAL_PLANNER_TARGET addresses the LegPoser's record directly (set: whatever the walk state). */
 int shc_engine_set_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, const shc_external_target *rows,
                                    int64_t *ignored);

@@ -1827,7 +1827,7 @@ __host__ __device__ inline ExtAt ext_record(int which) { // 0 LegStepper::extern
   return which == 0 ? ExtAt{ExtFields::T_POSE, ExtFields::T_FLAGS} : which == 1 ? ExtAt{ExtFields::D_POSE, ExtFields::D_FLAGS} : ExtAt{ExtFields::P_POSE, ExtFields::P_FLAGS};
 }
 __global__ void set_external_kernel(DevState st, int L, int64_t first, int64_t count, int leg_sel, int which, const ExtRow *rows, int transform_only,
-                                    unsigned long long *ignored, SeqRobotState *seq, int rough_terrain, int NJ) {
+                                    unsigned long long *ignored, SeqRobotState *seq, int rough_terrain) {
   const int legs = leg_sel < 0 ? L : 1;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= count * legs) return;
@@ -1850,11 +1850,6 @@ __global__ void set_external_kernel(DevState st, int L, int64_t first, int64_t c
   // targetTipPoseCallback (:1734-1757): the LegStepper takes a request only while its robot is not STOPPED; the target of a robot
   // that stands goes to its LegPoser for planner mode (target_tip_pose_acquired_, :1738-1742), a default for it is dropped
   const int walk_state = st.robi[rob_index(rob, RobotFields::I_WORD, 64 / L, RobotFields::I_COUNT)] & 3;
-  const bool rotation_defined = r.pose[3] != 0.0 || r.pose[4] != 0.0 || r.pose[5] != 0.0 || r.pose[6] != 0.0;
-  if (which == 0 && walk_state == WS_STOPPED && NJ <= 3 && rotation_defined) { // (a planner target with a rotation needs the rotation-
-    atomicAdd(ignored, 1ull);                                                  //  constrained IK: legs with more than 3 joints only)
-    return;
-  }
   if (which == 2 || (which == 0 && walk_state == WS_STOPPED)) {
     which = 2;
     base = ext_record(2).base, flags_at = ext_record(2).flags;
@@ -1912,7 +1907,7 @@ static int external_write(shc_engine *e, int which, int64_t first, int64_t count
   hipError_t err = hipMemcpyAsync(d_rows, host.data(), host.size() * sizeof(ExtRow), hipMemcpyHostToDevice, e->stream);
   if (err == hipSuccess) err = hipMemsetAsync(d_ignored, 0, 8, e->stream);
   if (err == hipSuccess) {
-    set_external_kernel<<<dim3((unsigned)((host.size() + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->L, first, count, leg, which, d_rows, transform_only, d_ignored, e->d_seq, e->params.rough_terrain_mode, e->NJ);
+    set_external_kernel<<<dim3((unsigned)((host.size() + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->L, first, count, leg, which, d_rows, transform_only, d_ignored, e->d_seq, e->params.rough_terrain_mode);
     err = hipGetLastError();
   }
   if (err == hipSuccess) err = hipMemcpyAsync(&h_ignored, d_ignored, 8, hipMemcpyDeviceToHost, e->stream);
@@ -1939,10 +1934,6 @@ extern "C" int shc_engine_set_external_target(shc_engine *e, int which, int64_t 
     const bool rotation_defined = t.pose[3] != 0.0 || t.pose[4] != 0.0 || t.pose[5] != 0.0 || t.pose[6] != 0.0;
     if (t.defined && e->NJ > 3 && which == SHC_EXTERNAL_TARGET && rotation_defined)
       return fail(SHC_ERR_UNSUPPORTED, "external target with a defined tip rotation on legs with more than 3 joints");
-    // planner mode hands the target to Leg::applyIK as it is: with a rotation the solve is rotation-constrained, which the engine
-    // runs on legs with more than 3 joints only (the same limit as leg_manipulation_mode joint_control)
-    if (t.defined && e->NJ <= 3 && which == SHC_EXTERNAL_PLANNER_TARGET && rotation_defined)
-      return fail(SHC_ERR_UNSUPPORTED, "planner target with a defined tip rotation on legs with at most 3 joints");
     for (int k = 0; k < 7; ++k) host[i].pose[k] = t.pose[k], host[i].transform[k] = t.transform[k];
     host[i].swing_clearance = t.swing_clearance;
     host[i].flags = double((t.defined ? 1 : 0) | (t.frame_is_odom_ideal ? 2 : 0));

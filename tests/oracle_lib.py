@@ -394,13 +394,8 @@ class OracleBatch:
         legs = self.legs
         assert len(rows) == self.n * legs
         ignored = 0
-        stopped = self.body_state()[2] == 3
         for i in range(self.n):
             for l in range(legs):
-                r = rows[i * legs + l]
-                if which == 0 and r.defined and stopped[i] and self.p.leg_dof[0] <= 3 and any(r.pose[k] != 0.0 for k in range(3, 7)):
-                    ignored += 1   # the engine's documented limit: a planner target with a tip rotation needs the rotation-constrained
-                    continue       # IK, which it runs on legs with more than 3 joints only (the reference's LegPoser would take it)
                 took = self.L.orc_set_external_target(self.L.orc_batch_robot(self.h, i), which, l, C.byref(rows[i * legs + l]))
                 ignored += 0 if took else 1  # 1 a LegStepper took it, 2 the planner-mode LegPoser (robot STOPPED), 0 dropped
         return ignored

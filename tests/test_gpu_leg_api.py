@@ -117,7 +117,7 @@ def test_default_argument_uses_the_poser_tip_and_admittance_delta(Engine):
     np.testing.assert_allclose(eng.joints()[0], ob.joints()[0], atol=1e-10)
 
 
-@pytest.mark.parametrize("dof,legs", [(5, 8), (4, 6)])
+@pytest.mark.parametrize("dof,legs", [(5, 8), (4, 6), (3, 6)])
 def test_rotation_constrained_apply_ik(Engine, dof, legs):
     """A desired tip pose with a defined rotation: position solve, rotation solve on the intermediate joint state, and the
     unconstrained retry when the constrained attempt fails (model.cpp:880-936)."""

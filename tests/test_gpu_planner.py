@@ -108,6 +108,8 @@ def test_plan_steps_against_the_oracle(case):
     # ---- plan step 1: tip targets for half the legs (with a swing clearance) + a body pose for the even robots
     tips = ob.leg_state()["model_tip"].reshape(n, L, 3)
     rows = (ExternalTarget * (n * L))()
+    quat = rng.normal(size=(n, L, 4)) * [0.25, 1.0, 0.25, 0.25] + [0, 0, 0.7, 0]     # tips pointing roughly down and out
+    quat /= np.linalg.norm(quat, axis=2, keepdims=True)
     for i in range(n):
         for l in range(L):
             if (i + l) % 2:
@@ -117,10 +119,15 @@ def test_plan_steps_against_the_oracle(case):
             off = rng.normal(size=3)       # 3.5 - 4.5 cm away: a target that the body pose brings within TIP_TOLERANCE of the tip with
             off *= rng.uniform(0.035, 0.045) / np.linalg.norm(off)   # no lift makes its leg start a call late and the reference never finish
             r.pose[0:3] = list(tips[i, l] + off)
-            r.pose[3:7] = [0, 0, 0, 0]                 # UNDEFINED_ROTATION
+            r.pose[3:7] = [0, 0, 0, 0]                 # UNDEFINED_ROTATION ...
+            if (i + l) % 4 == 0:                       # ... or a requested tip rotation: Leg::applyIK then runs its rotation-constrained
+                r.pose[3:7] = list(quat[i, l])         # solve and, where that fails (3 joints cannot hold a rotation), the unconstrained retry
             r.transform[:] = [0, 0, 0, 1, 0, 0, 0]
             r.swing_clearance = 0.02 if l % 3 else 0.0
-    assert eng.set_external_target(rows) == 0 and ob.set_external_target(rows) == 0     # every robot stands: the LegPosers take them
+    # every robot stands: the LegPosers take what arrives the TargetTipPose way; on > 3-DOF legs a target with a rotation is refused
+    # on that way (a LegStepper could not follow it), so those go to the LegPoser's record directly
+    via = 2 if D > 3 else 0
+    assert eng.set_external_target(rows, which=via) == 0 and ob.set_external_target(rows, which=via) == 0
     tr = np.tile(np.array([0.004, -0.003, 0.0, 1, 0, 0, 0.0]), (n, L, 1))              # the tf refresh of a defined planner target
     tr[:, :, 3:] = [np.cos(0.01), 0, 0, np.sin(0.01)]
     for o in (eng, ob):
@@ -170,10 +177,3 @@ def test_planner_unsupported_configurations():
         eng = BatchEngine(p, 2)
         with pytest.raises(RuntimeError):
             eng.execute_plan()
-    # a planner target with a tip rotation needs the rotation-constrained IK: legs with more than 3 joints only
-    eng = BatchEngine(default_hexapod_params("tripod"), 2)
-    rows = (ExternalTarget * 12)()
-    rows[0].defined = 1
-    rows[0].pose[3] = 1.0
-    with pytest.raises(RuntimeError):
-        eng.set_external_target(rows, which=2)

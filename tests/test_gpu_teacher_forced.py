@@ -410,11 +410,9 @@ def test_rough_terrain_external_targets(Engine, case):
     for key in ("ext_target", "ext_default"):
         ig = sched.ignored[key]
         assert ig[0::2] == ig[1::2], "engine and oracle ignored different requests"     # (engine, oracle) pairs
-        # some robots were STOPPED: their default poses are dropped; their targets go to the planner-mode LegPosers (a target with
-        # a tip rotation cannot on <= 3-DOF legs - planner mode would need the rotation-constrained IK there - and is dropped too)
-        assert sum(ig) > 0 or (key == "ext_target" and rot == "undefined")
-    if rot == "undefined":
-        assert any(r.defined for r in ob.get_external_target(2))
+        # some robots were STOPPED: their default poses are dropped, their targets go to the planner-mode LegPosers
+        assert sum(ig) > 0 or key == "ext_target"
+    assert any(r.defined for r in ob.get_external_target(2))
     for which in (0, 1, 2):              # the records as the steppers / posers hold them now
         a, b = eng.get_external_target(which), ob.get_external_target(which)
         assert bytes(a) == bytes(b)
