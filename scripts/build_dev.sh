@@ -8,3 +8,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value -mll
 /opt/rocm/bin/hipcc $FLAGS -DSHC_TIMING -o $S/libshc_timing.so $S/csrc/shc_engine.hip 2> /tmp/shc_res_timing.txt &
 wait
 python scripts/regs.py /tmp/shc_res.txt
+# stamp the product library with the hash of its sources (engine.build_library() rebuilds a library whose stamp does not match)
+python -c "
+import sys; sys.path.insert(0, '.')
+from syropod_highlevel_controller_amd import engine
+open(engine._SO + '.srchash', 'w').write(engine._source_hash() + '\n')"
