@@ -196,3 +196,54 @@ def test_walk_trajectories(name, meta):
         worst_pose = max(worst_pose, np.abs(q - g["pose"][c]).max())
         assert worst_tip < 1e-9 and worst_pose < 1e-9, (name, c, worst_tip, worst_pose)
     print(f"{name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, max |pose diff| {worst_pose:.2e}")
+
+
+# ------------------------------------------------------------------------------------------------ LegPoser primitives
+SEQ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sequence_golden.npz"))
+
+
+def _standing_hexapod():
+    from oracle_lib import OracleBatch
+    from syropod_highlevel_controller_amd import default_hexapod_params
+    ob = OracleBatch(default_hexapod_params("tripod"), 1)
+    assert np.abs(ob.leg_apply_fk() - SEQ["origin"]).max() < 1e-12       # the data the independent generator started from
+    assert np.abs(ob.joints()[0].reshape(6, 3) - SEQ["q0"]).max() < 1e-12
+    return ob
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[1] for k in SEQ.files if k.startswith("step/")}))
+def test_sequence_trajectories(name):
+    """LegPoser::stepToPosition (pose_controller.cpp:1571-1712) call by call against the independent numpy restatement of
+    tests/golden/make_sequence_golden.py: progress values exact, tip positions and directions to 1e-12."""
+    rows, target, body = SEQ[f"step/{name}/rows"], SEQ[f"step/{name}/target"], SEQ[f"step/{name}/body"]
+    leg, lift, time_to_step = int(SEQ[f"step/{name}/args"][0]), float(SEQ[f"step/{name}/args"][1]), float(SEQ[f"step/{name}/args"][2])
+    ob = _standing_hexapod()
+    targets = None
+    if not np.isnan(target[0]):
+        targets = SEQ["origin"].copy()
+        targets[:, 3:] = 0.0              # the other legs: their own tip, rotation undefined -> nothing to do
+        targets[leg] = target
+    for call, row in enumerate(rows):
+        out, progress = ob.leg_step_to_position(targets, body[None], lift, time_to_step, apply_delta=False)
+        assert progress[leg] == int(row[0]), (call, progress[leg], row[0])
+        assert np.abs(out[leg, :3] - row[1:4]).max() < 1e-12, (call, out[leg, :3], row[1:4])
+        q = out[leg, 3:]
+        if np.isnan(row[4]):
+            assert not q.any()            # UNDEFINED_ROTATION
+        else:                             # x axis of the tip rotation
+            x = np.array([1 - 2 * (q[2] ** 2 + q[3] ** 2), 2 * (q[1] * q[2] + q[0] * q[3]), 2 * (q[1] * q[3] - q[0] * q[2])])
+            assert np.abs(x - row[4:7]).max() < 1e-12, (call, x, row[4:7])
+
+
+@pytest.mark.parametrize("name", sorted({k.split("/")[1] for k in SEQ.files if k.startswith("cfg/")}))
+def test_configuration_transition_trajectories(name):
+    """LegPoser::transitionConfiguration (pose_controller.cpp:1476-1567) against the independent restatement."""
+    rows, target = SEQ[f"cfg/{name}/rows"], SEQ[f"cfg/{name}/target"]
+    leg, transition_time = int(SEQ[f"cfg/{name}/args"][0]), float(SEQ[f"cfg/{name}/args"][1])
+    ob = _standing_hexapod()
+    desired = SEQ["q0"].copy()
+    desired[leg] = target
+    for call, row in enumerate(rows):
+        progress = ob.leg_transition_configuration(desired, transition_time)
+        assert progress[leg] == int(row[0]), (call, progress[leg], row[0])
+        assert np.abs(ob.joints()[0].reshape(6, 3)[leg] - row[1:]).max() < 1e-13
