@@ -11,6 +11,10 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   WalkController::updateWalkPlane          src/walk_controller.cpp:748-779
   LegStepper (iteratePhase, updateStepState, updateStride, updateTipPosition, control nodes, updateDefaultTipPosition)
                                            src/walk_controller.cpp:871-1189, 1238-1329
+    incl. the rough-terrain branches that do not need the kinematic model: default-tip update at every swing / stance
+    start (:1058-1061, :1160-1163), external target / default (:988-990, :1068-1079; struct ExternalTarget,
+    walk_controller.h:38-46; Pose::removePose, pose.h:178; WalkController::calculateOdometry, :783-791), the reactive
+    step-depth target (:1099-1102)
   quarticBezier / quarticBezierDot         include/.../standard_includes.h:402-420
   PoseController::updateWalkPlanePose / updateAutoPose / updateIMUPose   src/pose_controller.cpp:1092-1236
   AutoPoser::updatePose                    src/pose_controller.cpp:1338-1439
@@ -95,6 +99,10 @@ class Pose:
         return [self.p[0], self.p[1], self.p[2], q[3], q[0], q[1], q[2]]
 
 
+def remove_pose(a, b):  # pose.h:178: a.transformVector(-b.position), a.rotation * b.rotation^-1
+    return Pose(a.p + a.r.apply(-b.p), a.r * b.r.inv())
+
+
 def euler_to_rot(e):  # eulerAnglesToQuaternion, extrinsic: Rz(yaw) * Ry(pitch) * Rx(roll)
     return R.from_euler("xyz", [e[0], e[1], e[2]])
 
@@ -133,6 +141,9 @@ class Leg:
         self.completed_first_step = False
         self.swing_progress = -1.0
         self.stance_progress = -1.0
+        self.ext_target = None      # dict(pose=Pose, transform=Pose, clearance=float, odom_ideal=bool) while defined_
+        self.ext_default = None
+        self.touchdown_detection = False
 
 
 class RefWalker:
@@ -235,6 +246,9 @@ class RefWalker:
         leg.swing_clearance = self.P["swing_height"] * leg.walk_plane_normal / np.linalg.norm(leg.walk_plane_normal)
 
     def update_default_tip(self, leg):
+        if leg.ext_default is not None:          # external_default_.pose_.removePose(external_default_.transform_) (:988-990)
+            leg.default = remove_pose(leg.ext_default["pose"], leg.ext_default["transform"]).p
+            return
         ident = self.walk_plane_pose.p + self.walk_plane_pose.r.apply(leg.identity)   # getDefaultBodyPose().transformVector
         leg.default = ident + projection(leg.stance_origin - ident, leg.walk_plane_normal)
 
@@ -256,6 +270,16 @@ class RefWalker:
             first_half = it <= swing_iterations // 2
             if it == 1:
                 leg.swing_origin, leg.swing_origin_velocity = leg.tip.copy(), leg.tip_velocity.copy()
+                if P.get("rough_terrain_mode"):
+                    self.update_default_tip(leg)
+            if P.get("rough_terrain_mode"):
+                if leg.ext_target is not None:   # :1068-1079
+                    leg.target = remove_pose(leg.ext_target["pose"], leg.ext_target["transform"]).p
+                    leg.swing_clearance = leg.swing_clearance / np.linalg.norm(leg.swing_clearance) * leg.ext_target["clearance"]
+                    if leg.ext_target["odom_ideal"]:
+                        leg.target = leg.target - np.array([self.v[0], self.v[1], 0.0]) * ((swing_iterations - it) * dt)
+                elif leg.touchdown_detection:    # no step plane is ever sensed in these scenarios: the reactive branch (:1099-1102)
+                    leg.target = leg.target - np.array([0.0, 0.0, P["step_depth"]])
             mid = (leg.swing_origin + leg.target) / 2.0
             mid[2] = max(leg.swing_origin[2], leg.target[2])
             mid = mid + leg.swing_clearance
@@ -287,6 +311,9 @@ class RefWalker:
             it = (leg.phase + (self.period - mss)) % self.period + 1
             if it == 1:
                 leg.stance_origin = leg.tip.copy()
+                leg.ext_target = None            # "Reset external target after every swing period" (:1159)
+                if P.get("rough_terrain_mode"):
+                    self.update_default_tip(leg)
             scaler = msp / ((self.stance_end - self.stance_start) % self.period)
             sep = -leg.stride * scaler * 0.25
             nodes = [leg.stance_origin + k * sep for k in range(5)]
@@ -466,7 +493,7 @@ def hexapod(gait, **kw):
     from syropod_highlevel_controller_amd import default_hexapod_params
     p = default_hexapod_params(gait)
     P = dict(time_delta=p.time_delta, step_frequency=p.step_frequency, swing_height=p.swing_height, swing_width=p.swing_width,
-             body_clearance=p.body_clearance, force_normal_touchdown=0, velocity_input_mode="throttle",
+             body_clearance=p.body_clearance, force_normal_touchdown=0, velocity_input_mode="throttle", rough_terrain_mode=0, step_depth=0.0,
              stance_position=[[p.stance_position[l][0], p.stance_position[l][1]] for l in range(6)], **GAITS[gait])
     a = AUTO_POSES[gait]
     P.update(n_auto_posers=0, max_rotation=[p.max_rotation[i] for i in range(3)], rotation_pid_gains=[0.2, 0.02, 0.01])
@@ -496,7 +523,33 @@ SCENARIOS = {
     "tripod_force_normal_touchdown": ("tripod", {"force_normal_touchdown": 1, "swing_width": 0.01}, [(0, (0.4, 0.5), -0.3)], 300),
     "tripod_auto_posing": ("tripod", {"auto_posing": 1, "n_auto_posers": None}, [(0, (0.7, 0.0), 0.0), (250, (0, 0), 0.0), (520, (0.0, 0.5), 0.5)], 760),
     "wave_imu_posing": ("wave", {"imu_posing": 1}, [(0, (0.5, 0.2), 0.1)], 400),
+    # rough terrain mode without the kinematic model in the loop: requested targets / default poses, and the reactive step depth
+    "tripod_rough_external_requests": ("tripod", {"rough_terrain_mode": 1}, [(0, (0.5, 0.1), 0.2), (330, (0, 0), 0.0)], 520),
+    "ripple_rough_reactive_step_depth": ("ripple", {"rough_terrain_mode": 1, "step_depth": 0.004}, [(0, (0.3, -0.2), -0.3)], 260),
 }
+
+
+def rough_events(name, P):
+    """TargetTipPose messages / tf refreshes / tip-state messages of the rough-terrain scenarios: (cycle, kind, leg, numbers)."""
+    ev = []
+    if name == "tripod_rough_external_requests":
+        sp = P["stance_position"]
+        for c, leg, dx, dy, dz, clearance, odom in ((70, 0, 0.03, -0.02, 0.01, 0.03, 0), (70, 3, -0.02, 0.02, -0.01, 0.05, 1), (165, 4, 0.02, 0.03, 0.0, 0.02, 1),
+                                                    (240, 1, -0.03, -0.01, 0.015, 0.04, 0)):
+            ev.append((c, "target", leg, [sp[leg][0] + dx, sp[leg][1] + dy, dz, 1, 0, 0, 0, clearance, odom]))
+        for c, leg, dx, dy, dz in ((120, 2, 0.02, 0.01, -0.008), (120, 5, -0.015, 0.02, 0.006), (300, 2, 0.0, 0.0, 0.0)):
+            ev.append((c, "default", leg, [sp[leg][0] + dx, sp[leg][1] + dy, dz, 1, 0, 0, 0, 0.0, 0]))
+        ev.append((310, "withdraw_default", 5, []))
+        for c in range(72, 330, 4):     # generateExternalTargetTransforms: the walk plane frame has moved since the request
+            k = (c - 72) / 4.0
+            yaw = 0.002 * k
+            tr = [0.0006 * k, -0.0004 * k, 0.0002 * k, float(np.cos(yaw / 2)), 0.0, 0.0, float(np.sin(yaw / 2))]
+            for leg in range(6):
+                ev.append((c, "transform_target", leg, tr))
+                ev.append((c, "transform_default", leg, [0.5 * t if i < 3 else t for i, t in enumerate(tr)]))
+    elif name == "ripple_rough_reactive_step_depth":
+        ev.append((0, "zero_tip_force", -1, []))   # tip-state messages arrive (touchdown detection on), no contact is ever sensed
+    return ev
 
 
 def run(name):
@@ -506,12 +559,14 @@ def run(name):
     if "n_auto_posers" in over:
         over["n_auto_posers"] = len(P["pose_phase_starts"])
     P.update(over)
-    prod = {"force_normal_touchdown": P["force_normal_touchdown"], "swing_width": P["swing_width"]}
+    prod = {"force_normal_touchdown": P["force_normal_touchdown"], "swing_width": P["swing_width"], "rough_terrain_mode": P["rough_terrain_mode"],
+            "step_depth": P["step_depth"]}
     limits = limits_from_product(gait, **prod)
     w = RefWalker(P, limits)
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[])
+    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[])
+    events = rough_events(name, P)
     lin, ang = (0.0, 0.0), 0.0
     w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
     for c in range(cycles):
@@ -521,6 +576,25 @@ def run(name):
         if P.get("imu_posing") and c % 25 == 0:  # a new IMU sample every 25 cycles
             e = [rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), 0.0]
             w.imu_q, w.gyro = euler_to_rot(e), rng.normal(0, 0.05, 3)
+        for ec, kind, leg, v in events:          # callbacks arrive between loops; the tf refresh is the first thing a loop does
+            if ec != c:
+                continue
+            mk = lambda a: Pose(a[0:3], R.from_quat([a[4], a[5], a[6], a[3]]))
+            if kind in ("target", "default") and w.walk_state != STOPPED:   # targetTipPoseCallback (state_controller.cpp:1734-1757)
+                rec = dict(pose=mk(v), transform=Pose(), clearance=v[7], odom_ideal=bool(v[8]))
+                if kind == "target":
+                    w.legs[leg].ext_target = rec
+                else:
+                    w.legs[leg].ext_default = rec
+            elif kind == "withdraw_default":
+                w.legs[leg].ext_default = None
+            elif kind == "transform_target" and w.legs[leg].ext_target is not None:
+                w.legs[leg].ext_target["transform"] = mk(v)
+            elif kind == "transform_default" and w.legs[leg].ext_default is not None:
+                w.legs[leg].ext_default["transform"] = mk(v)
+            elif kind == "zero_tip_force":
+                for l_ in w.legs:
+                    l_.touchdown_detection = True
         q = w.imu_q.as_quat()
         out["imu_q"].append([q[3], q[0], q[1], q[2]])
         out["gyro"].append(w.gyro.tolist())
@@ -528,12 +602,14 @@ def run(name):
         out["ang"].append(ang)
         w.cycle(lin, ang)
         out["tips"].append([leg.tip.tolist() for leg in w.legs])
+        out["default"].append([leg.default.tolist() for leg in w.legs])
+        out["target"].append([leg.target.tolist() for leg in w.legs])
         out["phase"].append([leg.phase for leg in w.legs])
         out["state"].append([leg.state for leg in w.legs])
         out["walk_state"].append(w.walk_state)
         out["velocity"].append([w.v[0], w.v[1], w.w])
         out["pose"].append(w.current_pose.as7())
-    meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits,
+    meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events,
                 visited_walk_states=sorted(set(out["walk_state"])))
     return {k: np.array(v) for k, v in out.items()}, meta
 

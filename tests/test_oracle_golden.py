@@ -155,7 +155,9 @@ def test_walk_trajectories(name, meta):
     """Hundreds of cycles of walking from an INDEPENDENT numpy restatement of WalkController::updateWalk / getLimit / LegStepper
     / updateWalkPlane and PoseController's walk-plane, auto and IMU poses (tests/golden/make_walk_golden.py, written from the
     reference sources alone): velocity limiting, every walk-state transition, first-step handling of legs that start mid swing,
-    swing / stance Bezier tips, default-tip updates on stopping, auto-poser latches, the IMU PID.  The oracle must reproduce the
+    swing / stance Bezier tips, default-tip updates on stopping, auto-poser latches, the IMU PID, and rough terrain mode's
+    model-free branches (default-tip update every step, requested targets with clearance / tf transform / odometry lead,
+    requested default poses, the reactive step-depth target, the walk plane fitted through the moving defaults).  The oracle must reproduce the
     walker tips to 1e-9 m, the body pose to 1e-9 and every integer exactly."""
     import os
     from oracle_lib import OracleRobot
@@ -178,7 +180,24 @@ def test_walk_trajectories(name, meta):
     for k, table in meta["limits"].items():  # the fixture's limit tables are the ones this oracle derives too
         np.testing.assert_allclose(list(getattr(t, k)), table, rtol=1e-9)
     worst_tip = worst_pose = 0.0
+    from syropod_highlevel_controller_amd.params import ExternalTarget
+    L = lib()
     for c in range(meta["cycles"]):
+        for ec, kind, leg, v in meta.get("events", []):   # rough-terrain scenarios: TargetTipPose / tf refresh / tip-state messages
+            if ec != c:
+                continue
+            which = 0 if kind.endswith("target") else 1
+            if kind in ("target", "default", "withdraw_default"):
+                row = ExternalTarget()
+                if kind != "withdraw_default":
+                    row.defined, row.swing_clearance, row.frame_is_odom_ideal = 1, v[7], int(v[8])
+                    row.pose[:] = v[:7]
+                    row.transform[:] = [0, 0, 0, 1, 0, 0, 0]
+                L.orc_set_external_target(r.h, which, leg, C.byref(row))
+            elif kind.startswith("transform_"):
+                L.orc_set_external_transform(r.h, which, leg, _ptr(_arr(v)))
+            elif kind == "zero_tip_force":
+                L.orc_set_tip_force(r.h, _ptr(np.zeros(3 * p.leg_count)))
         r.set_velocity(float(g["lin"][c][0]), float(g["lin"][c][1]), float(g["ang"][c]))
         if p.imu_posing:
             r.set_imu(g["imu_q"][c], g["gyro"][c])
