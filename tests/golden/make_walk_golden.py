@@ -19,7 +19,12 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   PoseController::updateWalkPlanePose / updateAutoPose / updateIMUPose   src/pose_controller.cpp:1092-1236
   AutoPoser::updatePose                    src/pose_controller.cpp:1338-1439
   Pose::addPose / interpolate              include/.../pose.h:167-195
-What is NOT restated but fed in as DATA (recorded in the fixture): the velocity / acceleration limit tables, which come out of
+  Model::updateModel for the scenarios that carry joints (`model` in their overrides): PoseController::updateStance
+  (src/pose_controller.cpp:110-141), Leg::setDesiredTipPose (src/model.cpp:653-663), Leg::applyIK -> solveIK + updateJointPositions
+  (:726-857, the reference's 6x6 damped-least-squares form with the joint-limit cost gradient, numpy.linalg.inv for its LU
+  inverse) - the whole control cycle of BASELINE.json config 2, free-running from the recorded start-up joints
+What is NOT restated but fed in as DATA (recorded in the fixture): the joint state the robot has after its direct start-up (q0,
+qd0: thousands of IK steps of the init chain, pinned separately), and the velocity / acceleration limit tables, which come out of
 the IK-based workspace search of the init chain (pinned separately: tests/test_host_tables_and_abi.py, test_oracle_golden.py).
 Rotations use scipy.spatial.transform.Rotation (an independent implementation of the Euler / quaternion conventions).
 
@@ -120,6 +125,57 @@ def from_two_vectors(a, b):
     return R.from_rotvec(ax / s * math.atan2(s, a.dot(b)))
 
 
+# ---- kinematic model of the default.yaml hexapod (config/default.yaml: base / coxa / femur / tibia links, joint limits)
+HEX_BASE_THETA = [-0.523, -1.571, -2.617, 2.617, 1.571, 0.523]
+HEX_LINKS = [(0.0, 0.0, 0.050, 1.571), (0.0, 0.0, 0.050, 0.0), (0.0, -0.100, 0.100, 0.0)]  # d theta r alpha (coxa, femur, tibia)
+HEX_JOINTS = [(-0.55, 0.55, 5.0), (-1.5, 1.5, 5.0), (-2.355, -0.1, 5.0)]                   # min, max, max speed
+DLS_COEFFICIENT, JOINT_LIMIT_COST_WEIGHT = 0.02, 0.1                                       # model.h:19-20
+
+
+def dh(d, th, r, al):
+    c, s_, ca, sa = np.cos(th), np.sin(th), np.cos(al), np.sin(al)
+    return np.array([[c, -s_ * ca, s_ * sa, r * c], [s_, c * ca, -c * sa, r * s_], [0, sa, ca, d], [0, 0, 0, 1]])
+
+
+def apply_ik(leg, q, qd, desired, dt):
+    """Leg::applyIK for a position-only desired tip (robot frame): one DLS step + joint update.  Returns (q, qd) after it."""
+    base = dh(0.0, HEX_BASE_THETA[leg], 0.05, 0.0)
+    ts = [dh(d, th + q[k], r, al) for k, (d, th, r, al) in enumerate(HEX_LINKS)]
+    c1 = ts[0]
+    c2 = c1 @ ts[1]
+    c3 = c2 @ ts[2]
+    pe = c3[:3, 3]
+    z = [np.array([0, 0, 1.0]), c1[:3, 2], c2[:3, 2]]
+    o = [np.zeros(3), c1[:3, 3], c2[:3, 3]]
+    jac = np.zeros((6, 3))                                   # solveIK builds the 6-row Jacobian and zeroes the angular rows (:737-746)
+    for i in range(3):
+        jac[:3, i] = np.cross(z[i], pe - o[i])
+    cur = (base @ c3)[:3, 3]
+    bi = np.linalg.inv(base)
+    delta = np.zeros(6)
+    delta[:3] = (bi @ np.append(desired, 1))[:3] - (bi @ np.append(cur, 1))[:3]        # tip delta in the leg base frame (:866-872)
+    jinv = jac.T @ np.linalg.inv(jac @ jac.T + DLS_COEFFICIENT ** 2 * np.eye(6))
+    w = JOINT_LIMIT_COST_WEIGHT
+    pg, vg, pc, vc = np.zeros(3), np.zeros(3), 0.0, 0.0     # joint-limit avoidance cost gradients (:762-790)
+    for i, (mn, mx, mv) in enumerate(HEX_JOINTS):
+        rg, cen = mx - mn, mn + (mx - mn) / 2
+        pc += (w * (q[i] - cen) / rg) ** 2
+        pg[i] = -w * w * (q[i] - cen) / rg ** 2
+        vc += (w * qd[i] / (2 * mv)) ** 2
+        vg[i] = -w * w * qd[i] / (2 * mv) ** 2
+    pg *= 0 if pc == 0 else 1 / np.sqrt(pc)
+    vg *= 0 if vc == 0 else 1 / np.sqrt(vc)
+    g = 0.25 * pg + 0.75 * vg
+    dq = jinv @ delta + (np.eye(3) - jinv @ jac) @ g
+    qn, vn = np.array(q, dtype=float), np.zeros(3)
+    for i, (mn, mx, mv) in enumerate(HEX_JOINTS):           # updateJointPositions (:799-857), clamp_joint_velocities / positions on
+        v = dq[i] / dt
+        v = min(max(v, -mv), mv)
+        vn[i] = v
+        qn[i] = min(max(q[i] + v * dt, mn), mx)
+    return qn, vn
+
+
 class Leg:
     def __init__(self, stance_xy):
         self.identity = np.array([stance_xy[0], stance_xy[1], 0.0])
@@ -174,6 +230,7 @@ class RefWalker:
         self.imu_q = R.identity()
         self.gyro = np.zeros(3)
         self.current_pose = Pose([0, 0, P["body_clearance"]])
+        self.q = self.qd = None   # joint state [legs][3], for the scenarios that run the kinematic model
 
     def step_cycle(self):  # generateStepCycle + the phase offsets of generateLimits
         P = self.P
@@ -486,6 +543,10 @@ class RefWalker:
         self.current_pose = pose
         self.pose_state = self.auto_posing_state
         self.update_walk(lin, ang)
+        if self.q is not None:   # PoseController::updateStance + Model::updateModel: tips as seen from the posed body, one IK step per leg
+            for i, leg in enumerate(self.legs):
+                poser_tip = pose.r.inv().apply(leg.tip - pose.p)          # Pose::inverseTransformVector (pose_controller.cpp:122-131)
+                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip, self.dt)
 
 
 def hexapod(gait, **kw):
@@ -516,13 +577,13 @@ def limits_from_product(gait, **kw):
 
 SCENARIOS = {
     # name: (gait, parameter overrides, [(first cycle, (vx, vy), omega)], cycles)
-    "tripod_start_walk_stop_restart": ("tripod", {}, [(0, (0.6, -0.3), 0.4), (230, (0, 0), 0.0), (470, (-0.2, 0.7), -0.6)], 700),
+    "tripod_start_walk_stop_restart": ("tripod", {"model": 1}, [(0, (0.6, -0.3), 0.4), (230, (0, 0), 0.0), (470, (-0.2, 0.7), -0.6)], 700),
     "wave_turn_on_the_spot": ("wave", {}, [(0, (0, 0), 1.0), (500, (0, 0), 0.0)], 1000),
     "ripple_overdriven_throttle": ("ripple", {}, [(0, (2.0, 1.5), -0.2), (300, (0.1, 0.0), 1.7)], 620),
     "amble_real_velocity_mode": ("amble", {"velocity_input_mode": "real"}, [(0, (0.05, 0.01), 0.05), (260, (0, 0), 0.0)], 560),
     "tripod_force_normal_touchdown": ("tripod", {"force_normal_touchdown": 1, "swing_width": 0.01}, [(0, (0.4, 0.5), -0.3)], 300),
     "tripod_auto_posing": ("tripod", {"auto_posing": 1, "n_auto_posers": None}, [(0, (0.7, 0.0), 0.0), (250, (0, 0), 0.0), (520, (0.0, 0.5), 0.5)], 760),
-    "wave_imu_posing": ("wave", {"imu_posing": 1}, [(0, (0.5, 0.2), 0.1)], 400),
+    "wave_imu_posing": ("wave", {"imu_posing": 1, "model": 1}, [(0, (0.5, 0.2), 0.1)], 400),
     # rough terrain mode without the kinematic model in the loop: requested targets / default poses, and the reactive step depth
     "tripod_rough_external_requests": ("tripod", {"rough_terrain_mode": 1}, [(0, (0.5, 0.1), 0.2), (330, (0, 0), 0.0)], 520),
     "ripple_rough_reactive_step_depth": ("ripple", {"rough_terrain_mode": 1, "step_depth": 0.004}, [(0, (0.3, -0.2), -0.3)], 260),
@@ -569,6 +630,21 @@ def run(name):
     events = rough_events(name, P)
     lin, ang = (0.0, 0.0), 0.0
     w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
+    start = None
+    if over.get("model"):     # DATA: the joint state of a robot that has gone through its direct start-up and that first loop
+        sys.path.insert(0, os.path.dirname(HERE))
+        from oracle_lib import OracleRobot
+        from syropod_highlevel_controller_amd import default_hexapod_params
+        pp = default_hexapod_params(gait)
+        for k_, v_ in over.items():
+            if k_ in ("imu_posing",):
+                setattr(pp, k_, v_)
+        if pp.imu_posing:
+            pp.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+        q0, qd0 = OracleRobot(pp).joints()
+        w.q, w.qd = q0.reshape(6, 3).copy(), qd0.reshape(6, 3).copy()
+        start = np.stack([w.q, w.qd])
+        out["q"] = []
     for c in range(cycles):
         for first, l, a in schedule:
             if c == first:
@@ -604,6 +680,8 @@ def run(name):
         out["tips"].append([leg.tip.tolist() for leg in w.legs])
         out["default"].append([leg.default.tolist() for leg in w.legs])
         out["target"].append([leg.target.tolist() for leg in w.legs])
+        if w.q is not None:
+            out["q"].append(w.q.copy())
         out["phase"].append([leg.phase for leg in w.legs])
         out["state"].append([leg.state for leg in w.legs])
         out["walk_state"].append(w.walk_state)
@@ -611,7 +689,10 @@ def run(name):
         out["pose"].append(w.current_pose.as7())
     meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events,
                 visited_walk_states=sorted(set(out["walk_state"])))
-    return {k: np.array(v) for k, v in out.items()}, meta
+    arrays = {k: np.array(v) for k, v in out.items()}
+    if start is not None:
+        arrays["joint_start"] = start
+    return arrays, meta
 
 
 if __name__ == "__main__":

@@ -157,7 +157,9 @@ def test_walk_trajectories(name, meta):
     reference sources alone): velocity limiting, every walk-state transition, first-step handling of legs that start mid swing,
     swing / stance Bezier tips, default-tip updates on stopping, auto-poser latches, the IMU PID, and rough terrain mode's
     model-free branches (default-tip update every step, requested targets with clearance / tf transform / odometry lead,
-    requested default poses, the reactive step-depth target, the walk plane fitted through the moving defaults).  The oracle must reproduce the
+    requested default poses, the reactive step-depth target, the walk plane fitted through the moving defaults).  Scenarios
+    with "model" also carry the JOINTS of an independent numpy chain for the whole cycle (updateStance, setDesiredTipPose, the
+    6x6 DLS solveIK with its cost gradient, updateJointPositions), free-running from the recorded start-up state: 1e-6 rad bar.  The oracle must reproduce the
     walker tips to 1e-9 m, the body pose to 1e-9 and every integer exactly."""
     import os
     from oracle_lib import OracleRobot
@@ -169,8 +171,8 @@ def test_walk_trajectories(name, meta):
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k == "n_auto_posers":
-            pass  # (default_hexapod_params already carries auto_pose.yaml)
+        elif k in ("n_auto_posers", "model"):
+            pass  # (default_hexapod_params already carries auto_pose.yaml; "model": the scenario also carries joints)
         else:
             setattr(p, k, v)
     if p.imu_posing:
@@ -179,7 +181,9 @@ def test_walk_trajectories(name, meta):
     t = r.tables()
     for k, table in meta["limits"].items():  # the fixture's limit tables are the ones this oracle derives too
         np.testing.assert_allclose(list(getattr(t, k)), table, rtol=1e-9)
-    worst_tip = worst_pose = 0.0
+    worst_tip = worst_pose = worst_q = 0.0
+    if "joint_start" in g:   # the joint state the independent full-cycle chain started from is this robot's
+        assert np.abs(np.stack(r.joints()).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
     from syropod_highlevel_controller_amd.params import ExternalTarget
     L = lib()
     for c in range(meta["cycles"]):
@@ -214,7 +218,11 @@ def test_walk_trajectories(name, meta):
             q[3:] = -q[3:]
         worst_pose = max(worst_pose, np.abs(q - g["pose"][c]).max())
         assert worst_tip < 1e-9 and worst_pose < 1e-9, (name, c, worst_tip, worst_pose)
-    print(f"{name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, max |pose diff| {worst_pose:.2e}")
+        if "q" in g:   # joints of the whole cycle (updateStance + setDesiredTipPose + applyIK) from the independent numpy chain, free-running
+            worst_q = max(worst_q, np.abs(r.joints()[0].reshape(6, 3) - g["q"][c]).max())
+            assert worst_q < 1e-6, (name, c, worst_q)
+    print(f"{name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, max |pose diff| {worst_pose:.2e}"
+          + (f", max |joint diff| {worst_q:.2e} rad (free-running independent IK chain)" if "q" in g else ""))
 
 
 # ------------------------------------------------------------------------------------------------ LegPoser primitives
