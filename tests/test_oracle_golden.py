@@ -205,6 +205,8 @@ def test_walk_trajectories(name, meta):
         r.set_velocity(float(g["lin"][c][0]), float(g["lin"][c][1]), float(g["ang"][c]))
         if p.imu_posing:
             r.set_imu(g["imu_q"][c], g["gyro"][c])
+        if p.admittance_control:
+            r.set_tip_force(g["force"][c])
         r.cycle(1)
         ls = r.leg_state()
         pose, vel, ws = r.body_state()
