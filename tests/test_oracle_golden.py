@@ -168,10 +168,14 @@ def test_walk_trajectories(name, meta):
     data = np.load(os.path.join(os.path.dirname(__file__), "golden", "walk_golden.npz"))
     g = {k.split("/", 1)[1]: data[k] for k in data.files if k.startswith(name + "/")}
     p = default_hexapod_params(meta["gait"])
+    if meta["overrides"].get("morphology") == "8x5":   # BASELINE.json config 4's synthetic octopod
+        from syropod_highlevel_controller_amd import synthetic_octopod_params
+        p = synthetic_octopod_params(meta["gait"], 5, 8)
+    LD = (p.leg_count, p.leg_dof[0])
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k in ("n_auto_posers", "model"):
+        elif k in ("n_auto_posers", "model", "morphology"):
             pass  # (default_hexapod_params already carries auto_pose.yaml; "model": the scenario also carries joints)
         else:
             setattr(p, k, v)
@@ -183,7 +187,7 @@ def test_walk_trajectories(name, meta):
         np.testing.assert_allclose(list(getattr(t, k)), table, rtol=1e-9)
     worst_tip = worst_pose = worst_q = 0.0
     if "joint_start" in g:   # the joint state the independent full-cycle chain started from is this robot's
-        assert np.abs(np.stack(r.joints()).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
+        assert np.abs(np.stack(r.joints()).reshape(2, *LD) - g["joint_start"]).max() < 1e-12
     from syropod_highlevel_controller_amd.params import ExternalTarget
     L = lib()
     for c in range(meta["cycles"]):
@@ -221,7 +225,7 @@ def test_walk_trajectories(name, meta):
         worst_pose = max(worst_pose, np.abs(q - g["pose"][c]).max())
         assert worst_tip < 1e-9 and worst_pose < 1e-9, (name, c, worst_tip, worst_pose)
         if "q" in g:   # joints of the whole cycle (updateStance + setDesiredTipPose + applyIK) from the independent numpy chain, free-running
-            worst_q = max(worst_q, np.abs(r.joints()[0].reshape(6, 3) - g["q"][c]).max())
+            worst_q = max(worst_q, np.abs(r.joints()[0].reshape(*LD) - g["q"][c]).max())
             assert worst_q < 1e-6, (name, c, worst_q)
     print(f"{name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, max |pose diff| {worst_pose:.2e}"
           + (f", max |joint diff| {worst_q:.2e} rad (free-running independent IK chain)" if "q" in g else ""))
