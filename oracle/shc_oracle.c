@@ -8,9 +8,13 @@
  * updateCurrentPose (walk-plane, manual, inclination, IMU, auto), updateStance, direct start-up;
  * admittance_controller.cpp; call order of state_controller.cpp loop()/runningState().
  * Restated with rough_terrain_mode: the layered workspace, touchdown detection, the step-surface target shift, default tip
- * updates at every swing / stance start (walk_controller.cpp:1058-1107, :1160).
- * Not restated (out of the accelerated path): external targets / defaults of a planner node, manual leg manipulation,
- * start-up/shut-down sequences, tip-align pose (experimental), ROS I/O.
+ * updates at every swing / stance start, external targets / default poses (walk_controller.cpp:984-1107, :1160), the tip-align pose
+ * (pose_controller.cpp:1024-1088).  Widened with the build: per-leg Leg methods, LegPoser::stepToPosition /
+ * transitionConfiguration, directStartup loop by loop, executeSequence (START_UP / SHUT_DOWN), stepToNewStance, packLegs /
+ * unpackLegs, legStateToggle + poseForLegManipulation + updateManual, planner mode (executePlan, transitionConfiguration /
+ * transitionStance), the message callbacks' unit handling, full-state export / import.
+ * Not restated: ROS I/O, tf lookups, parameter server, joint_control's rotation-constrained corner of updateManual on 3-DOF legs
+ * is restated but outside the engine's envelope.
  */
 #include "shc_oracle.h"
 #include "oracle_math.h"

@@ -10,9 +10,13 @@
  * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures for this path
  *  and cannot be compiled in this image (needs ROS-1, Eigen3, Boost.odeint; none
  * installed, no network), so this oracle is pinned only by (1) hand-derived known answers from the
- * reference formulae (tests/test_oracle_kat.py), (2) independent numpy/scipy cross-checks generated in the
- * build container (tests/golden/), (3) the reference's own runtime invariants (FK(IK(x)) within
- * IK_TOLERANCE, C0/C1 continuity of the swing/stance Beziers, finite outputs).
+ * reference formulae (tests/test_oracle_golden.py::test_step_cycle_known_answers), (2) independent numpy/scipy restatements
+ * written from the reference sources alone and committed with their fixtures (tests/golden/): the math primitives
+ * (make_golden.py), the walking loop over hundreds of cycles incl. rough terrain mode's model-free branches and - for the
+ * algorithm paths of BASELINE.json configs 2, 3 and 4 - the whole control cycle with the kinematic model, free-running
+ * (make_walk_golden.py: oracle joints within 3e-10 rad), and the LegPoser primitives behind sequences / leg manipulation /
+ * planner mode (make_sequence_golden.py), (3) the reference's own runtime invariants (FK(IK(x)) within IK_TOLERANCE, C0/C1
+ * continuity of the swing/stance Beziers, sequences and plan steps reaching their goals; tests/test_oracle_invariants.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import, call, link or execute
  * anything under oracle/.  The product (libshc_batch.so) never links this.
