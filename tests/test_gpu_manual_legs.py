@@ -10,7 +10,7 @@ from syropod_highlevel_controller_amd.engine import BatchEngine
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["hexapod-tip-control", "8x4-tip-control", "hexapod-dynamic-stiffness"])
+@pytest.mark.parametrize("case", ["hexapod-tip-control", "8x4-tip-control", "hexapod-dynamic-stiffness", "8x5-gravity-aligned"])
 def test_toggle_manipulate_and_return(case):
     """Walk; request a leg toggle per robot (different legs, two robots none): robots still walking are told to stop first
     (result -1), then the designated leg goes WALKING -> WALKING_TO_MANUAL -> MANUAL while every leg steps to its manipulation
@@ -18,7 +18,10 @@ def test_toggle_manipulate_and_return(case):
     (the other robots keep walking); a second leg joins on some robots, a third is refused; toggled back, everything walks again.
     The oracle's state is injected before every call (the robots stand still for most of this, where the reference's IK step
     amplifies rounding differences - DESIGN.md section 2.1); request results and leg states are compared exactly."""
-    if case.startswith("8x4"):
+    if case.startswith("8x5"):     # gravity-aligned tips: the rotation-constrained IK kernels (F_ROT) with the manual-leg logic
+        p = synthetic_octopod_params("ripple", 5, 8)
+        p.gravity_aligned_tips = 1
+    elif case.startswith("8x4"):
         p = synthetic_octopod_params("ripple", 4, 8)
     else:
         p = default_hexapod_params("tripod")

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 WAITING, WALKING = -2, -1
 
 
-@pytest.mark.parametrize("case", ["hexapod", "hexapod-admittance", "8x4"])
+@pytest.mark.parametrize("case", ["hexapod", "hexapod-admittance", "8x4", "hexapod-rough-terrain"])
 def test_plan_steps_against_the_oracle(case):
     """Walk; switch planner mode on: robots still walking are stopped by the call itself (result -1, their loop is the normal
     cycle) while the ones that stand already wait for plan step 0 (result -2, Model::updateModel only); a joint-configuration step
@@ -27,6 +27,8 @@ def test_plan_steps_against_the_oracle(case):
         p = default_hexapod_params("tripod")
     if "admittance" in case:
         p.admittance_control = 1
+    if "rough" in case:
+        p.rough_terrain_mode = 1
     n = 8
     L, D = p.leg_count, p.leg_dof[0]
     rng = np.random.default_rng(31)
