@@ -9,7 +9,7 @@ from syropod_highlevel_controller_amd.engine import BatchEngine
 
 name = sys.argv[1] if len(sys.argv) > 1 else "config3"
 ks = [int(x) for x in sys.argv[2:]] or [1, 2, 4]
-n = bench.DEFAULT_INSTANCES[name] if name != "config2" else 65536
+n = int(os.environ.get("SPLIT_N", 0)) or (bench.DEFAULT_INSTANCES[name] if name != "config2" else 65536)
 for k in ks:
     part = n // k
     streams = [torch.cuda.Stream() for _ in range(k)]

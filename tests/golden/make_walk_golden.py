@@ -14,7 +14,10 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
     incl. the rough-terrain branches that do not need the kinematic model: default-tip update at every swing / stance
     start (:1058-1061, :1160-1163), external target / default (:988-990, :1068-1079; struct ExternalTarget,
     walk_controller.h:38-46; Pose::removePose, pose.h:178; WalkController::calculateOdometry, :783-791), the reactive
-    step-depth target (:1099-1102)
+    step-depth target (:1099-1102); and, where the scenario runs the kinematic model, the branches that need it: touchdown
+    detection (Leg::touchdownDetection, src/model.cpp:712-722, from tipStatesCallback, src/state_controller.cpp:1618-1648), the
+    proactive target shift onto the sensed step plane (:1082-1096), the stance-like secondary swing nodes on ground contact
+    (:1296-1303)
   quarticBezier / quarticBezierDot         include/.../standard_includes.h:402-420
   PoseController::updateWalkPlanePose / updateAutoPose / updateIMUPose   src/pose_controller.cpp:1092-1236
   AutoPoser::updatePose                    src/pose_controller.cpp:1338-1439
@@ -51,6 +54,7 @@ STARTING, MOVING, STOPPING, STOPPED = 0, 1, 2, 3
 SWING, STANCE, FORCE_STANCE, FORCE_STOP = 0, 1, 2, 3
 POSING, STOP_POSING, POSING_COMPLETE = 0, 1, 2
 TIP_TOLERANCE = 0.01
+TOUCHDOWN_THRESHOLD, LIFTOFF_THRESHOLD = 0.9, 0.1   # default.yaml touchdown_threshold / liftoff_threshold
 UNASSIGNED = 2147483647.0
 
 
@@ -202,6 +206,13 @@ def apply_ik(leg, q, qd, desired, dt):
     return qn, vn
 
 
+def fk_tip(leg, q):
+    t = dh(*MODEL.base[leg])
+    for k, (d, th, r, al) in enumerate(MODEL.links[leg]):
+        t = t @ dh(d, th + q[k], r, al)
+    return t[:3, 3].copy()
+
+
 def tip_axis(leg, q):
     """x axis of the tip frame in the robot frame (Leg::current_tip_pose_.rotation_ * UnitX after applyFK)."""
     t = dh(*MODEL.base[leg])
@@ -258,6 +269,8 @@ class Leg:
         self.ext_target = None      # dict(pose=Pose, transform=Pose, clearance=float, odom_ideal=bool) while defined_
         self.ext_default = None
         self.touchdown_detection = False
+        self.step_plane = None      # Leg::step_plane_pose_.position_ while defined
+        self.model_tip = None       # Leg::current_tip_pose_.position_ (FK of the joints), scenarios with the kinematic model
 
 
 class RefWalker:
@@ -389,14 +402,20 @@ class RefWalker:
                 leg.swing_origin, leg.swing_origin_velocity = leg.tip.copy(), leg.tip_velocity.copy()
                 if P.get("rough_terrain_mode"):
                     self.update_default_tip(leg)
+            ground_contact = False
             if P.get("rough_terrain_mode"):
                 if leg.ext_target is not None:   # :1068-1079
                     leg.target = remove_pose(leg.ext_target["pose"], leg.ext_target["transform"]).p
                     leg.swing_clearance = leg.swing_clearance / np.linalg.norm(leg.swing_clearance) * leg.ext_target["clearance"]
                     if leg.ext_target["odom_ideal"]:
                         leg.target = leg.target - np.array([self.v[0], self.v[1], 0.0]) * ((swing_iterations - it) * dt)
-                elif leg.touchdown_detection:    # no step plane is ever sensed in these scenarios: the reactive branch (:1099-1102)
-                    leg.target = leg.target - np.array([0.0, 0.0, P["step_depth"]])
+                elif leg.touchdown_detection:
+                    if leg.step_plane is not None:   # proactive: shift the target onto the sensed step plane (:1082-1096)
+                        target_tip = leg.tip + (leg.step_plane - leg.model_tip)
+                        leg.target = leg.target + projection(target_tip - leg.target, leg.walk_plane_normal)
+                    else:                            # reactive (:1099-1102)
+                        leg.target = leg.target - np.array([0.0, 0.0, P["step_depth"]])
+                ground_contact = leg.step_plane is not None
             mid = (leg.swing_origin + leg.target) / 2.0
             mid[2] = max(leg.swing_origin[2], leg.target[2])
             mid = mid + leg.swing_clearance
@@ -408,7 +427,9 @@ class RefWalker:
             final_velocity = -leg.stride * (stance_dt / dt)
             sep2 = 0.25 * final_velocity * (dt / swing_dt)
             n2 = [n1[4], n1[4] - (n1[3] - n1[4]), leg.target - 2.0 * sep2, leg.target - sep2, leg.target]
-            if P["force_normal_touchdown"]:
+            if not first_half and ground_contact:     # "Stops further movement of tip position in direction normal to walk plane"
+                n2 = [leg.tip + k * sep2 for k in range(5)]
+            if P["force_normal_touchdown"] and not ground_contact:
                 origin = leg.target - 4.0 * sep2
                 origin[2] = max(leg.swing_origin[2], leg.target[2])
                 origin = origin + leg.swing_clearance
@@ -610,6 +631,7 @@ class RefWalker:
             for i, leg in enumerate(self.legs):
                 poser_tip = pose.r.inv().apply(leg.tip - pose.p)          # Pose::inverseTransformVector (pose_controller.cpp:122-131)
                 self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + adm[i], self.dt)  # setDesiredTipPose(.., apply_delta)
+                leg.model_tip = fk_tip(i, self.q[i])                                                     # applyFK closes applyIK
 
 
 def make_params(gait, morphology=None):
@@ -668,6 +690,9 @@ SCENARIOS = {
     "wave_admittance_imu": ("wave", {"imu_posing": 1, "admittance_control": 1, "model": 1}, [(0, (0.4, -0.2), 0.15)], 400),
     # config 4's path: the synthetic 8 x 5 octopod, ripple gait - redundant chains, the null-space term of the DLS step at work
     "octopod_8x5_ripple": ("ripple", {"model": 1, "morphology": "8x5"}, [(0, (0.5, 0.3), -0.25), (300, (0, 0), 0.0)], 480),
+    # rough terrain mode WITH the kinematic model: tip-state messages from a synthetic terrain (12 mm bumps under legs 0 / 3, 10 mm
+    # hollows under legs 1 / 4) drive touchdown detection, the proactive target shift and the ground-contact swing nodes
+    "tripod_rough_contacts": ("tripod", {"rough_terrain_mode": 1, "step_depth": 0.004, "model": 1, "contacts": 1}, [(0, (0.45, 0.1), 0.15), (420, (0, 0), 0.0)], 600),
     # rough terrain mode without the kinematic model in the loop: requested targets / default poses, and the reactive step depth
     "tripod_rough_external_requests": ("tripod", {"rough_terrain_mode": 1}, [(0, (0.5, 0.1), 0.2), (330, (0, 0), 0.0)], 520),
     "ripple_rough_reactive_step_depth": ("ripple", {"rough_terrain_mode": 1, "step_depth": 0.004}, [(0, (0.3, -0.2), -0.3)], 260),
@@ -711,7 +736,7 @@ def run(name):
     w = RefWalker(P, limits)
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[])
+    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[])
     events = rough_events(name, P)
     lin, ang = (0.0, 0.0), 0.0
     w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
@@ -723,12 +748,14 @@ def run(name):
         pp = make_params(gait, morphology)
         MODEL = Morphology.from_params(pp) if morphology else Morphology.default_hexapod()
         for k_, v_ in over.items():
-            if k_ in ("imu_posing", "admittance_control"):
+            if k_ in ("imu_posing", "admittance_control", "rough_terrain_mode", "step_depth"):
                 setattr(pp, k_, v_)
         if pp.imu_posing:
             pp.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
         q0, qd0 = OracleRobot(pp).joints()
         w.q, w.qd = q0.reshape(pp.leg_count, -1).copy(), qd0.reshape(pp.leg_count, -1).copy()
+        for i_, leg_ in enumerate(w.legs):
+            leg_.model_tip = fk_tip(i_, w.q[i_])
         start = np.stack([w.q, w.qd])
         out["q"] = []
     for c in range(cycles):
@@ -757,6 +784,16 @@ def run(name):
             elif kind == "zero_tip_force":
                 for l_ in w.legs:
                     l_.touchdown_detection = True
+        if over.get("contacts"):     # tipStatesCallback: a wrench per leg from the synthetic terrain, then Leg::touchdownDetection
+            terrain = [0.012, -0.010, 0.0, 0.012, -0.010, 0.0]
+            forces = np.array([[0.0, 0.0, 3.0] if leg.tip[2] <= terrain[i] + 1e-9 else [0.0, 0.0, 0.0] for i, leg in enumerate(w.legs)])
+            out["contact_force"].append(forces)
+            for i, leg in enumerate(w.legs):
+                leg.touchdown_detection = True
+                if np.linalg.norm(forces[i]) > TOUCHDOWN_THRESHOLD and leg.step_plane is None:
+                    leg.step_plane = leg.model_tip.copy()
+                elif np.linalg.norm(forces[i]) < LIFTOFF_THRESHOLD:
+                    leg.step_plane = None
         if P.get("admittance_control") and c % 10 == 0:
             w.tip_force = np.stack([rng.normal(0, 1, w.L), rng.normal(0, 1, w.L), rng.uniform(0, 20, w.L)], axis=1)
         out["force"].append(w.tip_force.copy())
@@ -780,7 +817,7 @@ def run(name):
         over["morphology"] = morphology
     meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events,
                 visited_walk_states=sorted(set(out["walk_state"])))
-    arrays = {k: np.array(v) for k, v in out.items()}
+    arrays = {k: np.array(v) for k, v in out.items() if len(v)}
     if start is not None:
         arrays["joint_start"] = start
     return arrays, meta

@@ -175,7 +175,7 @@ def test_walk_trajectories(name, meta):
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k in ("n_auto_posers", "model", "morphology"):
+        elif k in ("n_auto_posers", "model", "morphology", "contacts"):
             pass  # (default_hexapod_params already carries auto_pose.yaml; "model": the scenario also carries joints)
         else:
             setattr(p, k, v)
@@ -211,6 +211,8 @@ def test_walk_trajectories(name, meta):
             r.set_imu(g["imu_q"][c], g["gyro"][c])
         if p.admittance_control:
             r.set_tip_force(g["force"][c])
+        if "contact_force" in g:       # tip-state messages of the synthetic terrain: touchdown detection runs on arrival
+            r.set_tip_force(g["contact_force"][c])
         r.cycle(1)
         ls = r.leg_state()
         pose, vel, ws = r.body_state()
