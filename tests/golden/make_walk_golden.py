@@ -206,6 +206,27 @@ def apply_ik(leg, q, qd, desired, dt):
     return qn, vn
 
 
+def tip_force_estimate(leg, q, efforts, state, force_gain):
+    """Leg::calculateTipForce (src/model.cpp:667-708): DLS pseudo-inverse of the 6-row Jacobian transposed, applied to the measured
+    joint torques, rotated by the inverse base rotation, low-pass filtered (0.15) with the force gain.  state [3] is updated in place."""
+    n = len(q)
+    chain, t = [], np.eye(4)
+    for k, (d, th, r, al) in enumerate(MODEL.links[leg]):
+        t = t @ dh(d, th + q[k], r, al)
+        chain.append(t)
+    pe = chain[-1][:3, 3]
+    z = [np.array([0, 0, 1.0])] + [c[:3, 2] for c in chain[:-1]]
+    o = [np.zeros(3)] + [c[:3, 3] for c in chain[:-1]]
+    jac = np.zeros((6, n))
+    for i in range(n):
+        jac[:3, i] = np.cross(z[i], pe - o[i])
+        jac[3:, i] = z[i]
+    transformation = jac @ np.linalg.inv(jac.T @ jac + DLS_COEFFICIENT ** 2 * np.eye(n))
+    raw_leg = (transformation @ np.asarray(efforts, dtype=float))[:3]
+    raw = np.linalg.inv(dh(*MODEL.base[leg]))[:3, :3] @ raw_leg      # first_joint->getPoseJointFrame().rotation_
+    state[:] = 0.15 * raw * force_gain + (1 - 0.15) * state
+
+
 def fk_tip(leg, q):
     t = dh(*MODEL.base[leg])
     for k, (d, th, r, al) in enumerate(MODEL.links[leg]):
@@ -304,6 +325,8 @@ class RefWalker:
         self.q = self.qd = None   # joint state [legs][3], for the scenarios that run the kinematic model
         self.adm_state = np.zeros((self.L, 2))
         self.tip_force = np.zeros((self.L, 3))
+        self.tip_force_calc = np.zeros((self.L, 3))   # Leg::tip_force_calculated_
+        self.efforts = None                            # Joint::current_effort_ [legs][dof]
 
     def step_cycle(self):  # generateStepCycle + the phase offsets of generateLimits
         P = self.P
@@ -625,13 +648,15 @@ class RefWalker:
         self.pose_state = self.auto_posing_state
         adm = [np.zeros(3)] * self.L
         if self.P.get("admittance_control") and self.q is not None:      # loop(): the admittance update precedes runningState
-            adm = [admittance_delta(self.adm_state[i], self.tip_force[i], tip_axis(i, self.q[i]), self.P) for i in range(self.L)]
+            src = self.tip_force_calc if self.P.get("use_joint_effort") else self.tip_force      # getTipForceCalculated / Measured (:30-31)
+            adm = [admittance_delta(self.adm_state[i], src[i], tip_axis(i, self.q[i]), self.P) for i in range(self.L)]
         self.update_walk(lin, ang)
         if self.q is not None:   # PoseController::updateStance + Model::updateModel: tips as seen from the posed body, one IK step per leg
             for i, leg in enumerate(self.legs):
                 poser_tip = pose.r.inv().apply(leg.tip - pose.p)          # Pose::inverseTransformVector (pose_controller.cpp:122-131)
                 self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + adm[i], self.dt)  # setDesiredTipPose(.., apply_delta)
                 leg.model_tip = fk_tip(i, self.q[i])                                                     # applyFK closes applyIK
+                tip_force_estimate(i, self.q[i], self.efforts[i], self.tip_force_calc[i], self.P.get("force_gain", 0.1))   # ... and calculateTipForce
 
 
 def make_params(gait, morphology=None):
@@ -662,7 +687,7 @@ def hexapod(gait, morphology=None, **kw):
              roll_amplitudes=a["roll"], pitch_amplitudes=a["pitch"], yaw_amplitudes=a["yaw"], x_amplitudes=a["x"], y_amplitudes=a["y"],
              z_amplitudes=a["z"])
     P.update(virtual_mass=p.virtual_mass, virtual_stiffness=p.virtual_stiffness, virtual_damping_ratio=p.virtual_damping_ratio,
-             integrator_step_time=p.integrator_step_time, force_gain=p.force_gain, admittance_control=0)
+             integrator_step_time=p.integrator_step_time, force_gain=p.force_gain, admittance_control=0, use_joint_effort=0)
     P.update(kw)
     return P
 
@@ -690,6 +715,9 @@ SCENARIOS = {
     "wave_admittance_imu": ("wave", {"imu_posing": 1, "admittance_control": 1, "model": 1}, [(0, (0.4, -0.2), 0.15)], 400),
     # config 4's path: the synthetic 8 x 5 octopod, ripple gait - redundant chains, the null-space term of the DLS step at work
     "octopod_8x5_ripple": ("ripple", {"model": 1, "morphology": "8x5"}, [(0, (0.5, 0.3), -0.25), (300, (0, 0), 0.0)], 480),
+    # the tip-force estimate in the loop: admittance driven by Leg::calculateTipForce from measured joint torques (a new sample every 10 cycles)
+    "tripod_admittance_from_joint_efforts": ("tripod", {"admittance_control": 1, "use_joint_effort": 1, "model": 1, "efforts": 1},
+                                             [(0, (0.5, -0.2), 0.2), (260, (0, 0), 0.0)], 420),
     # rough terrain mode WITH the kinematic model: tip-state messages from a synthetic terrain (12 mm bumps under legs 0 / 3, 10 mm
     # hollows under legs 1 / 4) drive touchdown detection, the proactive target shift and the ground-contact swing nodes
     "tripod_rough_contacts": ("tripod", {"rough_terrain_mode": 1, "step_depth": 0.004, "model": 1, "contacts": 1}, [(0, (0.45, 0.1), 0.15), (420, (0, 0), 0.0)], 600),
@@ -736,7 +764,7 @@ def run(name):
     w = RefWalker(P, limits)
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[])
+    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[])
     events = rough_events(name, P)
     lin, ang = (0.0, 0.0), 0.0
     w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
@@ -748,7 +776,7 @@ def run(name):
         pp = make_params(gait, morphology)
         MODEL = Morphology.from_params(pp) if morphology else Morphology.default_hexapod()
         for k_, v_ in over.items():
-            if k_ in ("imu_posing", "admittance_control", "rough_terrain_mode", "step_depth"):
+            if k_ in ("imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort"):
                 setattr(pp, k_, v_)
         if pp.imu_posing:
             pp.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
@@ -756,6 +784,7 @@ def run(name):
         w.q, w.qd = q0.reshape(pp.leg_count, -1).copy(), qd0.reshape(pp.leg_count, -1).copy()
         for i_, leg_ in enumerate(w.legs):
             leg_.model_tip = fk_tip(i_, w.q[i_])
+        w.efforts = np.zeros_like(w.q)
         start = np.stack([w.q, w.qd])
         out["q"] = []
     for c in range(cycles):
@@ -784,6 +813,10 @@ def run(name):
             elif kind == "zero_tip_force":
                 for l_ in w.legs:
                     l_.touchdown_detection = True
+        if over.get("efforts"):      # jointStatesCallback: measured joint torques
+            if c % 10 == 0:
+                w.efforts = rng.normal(0, 0.5, w.q.shape)
+            out["effort"].append(w.efforts.copy())
         if over.get("contacts"):     # tipStatesCallback: a wrench per leg from the synthetic terrain, then Leg::touchdownDetection
             terrain = [0.012, -0.010, 0.0, 0.012, -0.010, 0.0]
             forces = np.array([[0.0, 0.0, 3.0] if leg.tip[2] <= terrain[i] + 1e-9 else [0.0, 0.0, 0.0] for i, leg in enumerate(w.legs)])
@@ -808,6 +841,7 @@ def run(name):
         out["target"].append([leg.target.tolist() for leg in w.legs])
         if w.q is not None:
             out["q"].append(w.q.copy())
+            out["tip_force_calc"].append(w.tip_force_calc.copy())
         out["phase"].append([leg.phase for leg in w.legs])
         out["state"].append([leg.state for leg in w.legs])
         out["walk_state"].append(w.walk_state)

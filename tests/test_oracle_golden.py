@@ -175,7 +175,7 @@ def test_walk_trajectories(name, meta):
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k in ("n_auto_posers", "model", "morphology", "contacts"):
+        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts"):
             pass  # (default_hexapod_params already carries auto_pose.yaml; "model": the scenario also carries joints)
         else:
             setattr(p, k, v)
@@ -209,8 +209,10 @@ def test_walk_trajectories(name, meta):
         r.set_velocity(float(g["lin"][c][0]), float(g["lin"][c][1]), float(g["ang"][c]))
         if p.imu_posing:
             r.set_imu(g["imu_q"][c], g["gyro"][c])
-        if p.admittance_control:
+        if p.admittance_control and not p.use_joint_effort:
             r.set_tip_force(g["force"][c])
+        if "effort" in g:              # measured joint torques -> Leg::calculateTipForce
+            r.set_joint_effort(g["effort"][c])
         if "contact_force" in g:       # tip-state messages of the synthetic terrain: touchdown detection runs on arrival
             r.set_tip_force(g["contact_force"][c])
         r.cycle(1)
@@ -229,6 +231,8 @@ def test_walk_trajectories(name, meta):
         if "q" in g:   # joints of the whole cycle (updateStance + setDesiredTipPose + applyIK) from the independent numpy chain, free-running
             worst_q = max(worst_q, np.abs(r.joints()[0].reshape(*LD) - g["q"][c]).max())
             assert worst_q < 1e-6, (name, c, worst_q)
+            if "effort" in g:          # the tip-force estimate itself (LegState.tip_force carries it times the force gain, :883-885)
+                assert np.abs(ls["tip_force"] - g["tip_force_calc"][c]).max() < 1e-9, (name, c)
     print(f"{name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, max |pose diff| {worst_pose:.2e}"
           + (f", max |joint diff| {worst_q:.2e} rad (free-running independent IK chain)" if "q" in g else ""))
 
