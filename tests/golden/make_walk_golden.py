@@ -28,7 +28,10 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   inverse) - the whole control cycle of BASELINE.json config 2, free-running from the recorded start-up joints - and, for the
   scenario with admittance_control, AdmittanceController::updateAdmittance (src/admittance_controller.cpp:22-63: 30 RK4 steps per
   axis on the leg's ONE shared state, clamp, deadband) with Leg::setAdmittanceDelta's projection onto the tip axis (model.h:365-368):
-  config 3's path (wave gait + admittance + IMU posing)
+  config 3's path (wave gait + admittance + IMU posing); and for gravity_aligned_tips on > 3-joint legs LegStepper::updateTipRotation
+  (src/walk_controller.cpp:1193-1234, held as tip DIRECTIONS - the only thing any consumer reads) with Leg::applyIK's rotation-constrained
+  pass (src/model.cpp:880-900: simulated position update, rotation delta from the PRE-update tip direction, 6-row solve) and its
+  unconstrained retry (:932-936)
 What is NOT restated but fed in as DATA (recorded in the fixture): the joint state the robot has after its direct start-up (q0,
 qd0: thousands of IK steps of the init chain, pinned separately), and the velocity / acceleration limit tables, which come out of
 the IK-based workspace search of the init chain (pinned separately: tests/test_host_tables_and_abi.py, test_oracle_golden.py).
@@ -165,25 +168,27 @@ class Morphology:
 MODEL = Morphology.default_hexapod()
 
 
-def apply_ik(leg, q, qd, desired, dt):
-    """Leg::applyIK for a position-only desired tip (robot frame): one DLS step + joint update.  Returns (q, qd) after it."""
-    n = len(q)
-    base = dh(*MODEL.base[leg])
-    chain = []                                               # transforms from the leg base to each joint frame / the tip
-    t = np.eye(4)
+def _chain(leg, q):
+    chain, t = [], np.eye(4)
     for k, (d, th, r, al) in enumerate(MODEL.links[leg]):
         t = t @ dh(d, th + q[k], r, al)
         chain.append(t)
+    return chain
+
+
+def solve_ik(leg, q, qd, delta, solve_rotation):
+    """Leg::solveIK (src/model.cpp:726-797): DLS pseudo-inverse of the 6-row Jacobian (angular rows zero unless solve_rotation) applied
+    to delta, plus the joint-limit cost gradient projected into its null space."""
+    n = len(q)
+    chain = _chain(leg, q)
     pe = chain[-1][:3, 3]
     z = [np.array([0, 0, 1.0])] + [c[:3, 2] for c in chain[:-1]]
     o = [np.zeros(3)] + [c[:3, 3] for c in chain[:-1]]
-    jac = np.zeros((6, n))                                   # solveIK builds the 6-row Jacobian and zeroes the angular rows (:737-746)
+    jac = np.zeros((6, n))
     for i in range(n):
         jac[:3, i] = np.cross(z[i], pe - o[i])
-    cur = (base @ chain[-1])[:3, 3]
-    bi = np.linalg.inv(base)
-    delta = np.zeros(6)
-    delta[:3] = (bi @ np.append(desired, 1))[:3] - (bi @ np.append(cur, 1))[:3]        # tip delta in the leg base frame (:866-872)
+        if solve_rotation:
+            jac[3:, i] = z[i]
     jinv = jac.T @ np.linalg.inv(jac @ jac.T + DLS_COEFFICIENT ** 2 * np.eye(6))
     w = JOINT_LIMIT_COST_WEIGHT
     pg, vg, pc, vc = np.zeros(n), np.zeros(n), 0.0, 0.0     # joint-limit avoidance cost gradients (:762-790)
@@ -196,13 +201,48 @@ def apply_ik(leg, q, qd, desired, dt):
     pg *= 0 if pc == 0 else 1 / np.sqrt(pc)
     vg *= 0 if vc == 0 else 1 / np.sqrt(vc)
     g = 0.25 * pg + 0.75 * vg
-    dq = jinv @ delta + (np.eye(n) - jinv @ jac) @ g        # the null-space term matters for the redundant 4- / 5-joint chains
+    return jinv @ delta + (np.eye(n) - jinv @ jac) @ g      # the null-space term matters for the redundant 4- / 5-joint chains
+
+
+def update_joints(leg, q, dq, dt, simulation):
+    """Leg::updateJointPositions (:799-857), clamp_joint_velocities (not in simulation) / clamp_joint_positions on."""
+    n = len(q)
     qn, vn = np.array(q, dtype=float), np.zeros(n)
-    for i, (mn, mx, mv) in enumerate(MODEL.joints[leg]):    # updateJointPositions (:799-857), clamp_joint_velocities / positions on
+    proximity = 1.0                                         # the return value: how close the closest joint is to a limit (0 = on it)
+    for i, (mn, mx, mv) in enumerate(MODEL.joints[leg]):
         v = dq[i] / dt
-        v = min(max(v, -mv), mv)
+        if not simulation:
+            v = min(max(v, -mv), mv)
         vn[i] = v
         qn[i] = min(max(q[i] + v * dt, mn), mx)
+        half = (mx - mn) / 2.0
+        proximity = min(proximity, min(abs(mn - qn[i]), abs(mx - qn[i])) / half if half != 0 else 1.0)
+    return qn, vn, proximity
+
+
+def apply_ik(leg, q, qd, desired, dt, desired_dir=None):
+    """Leg::applyIK (:861-941) towards a desired tip position (robot frame) and, optionally, tip direction.  Returns (q, qd)."""
+    base = dh(*MODEL.base[leg])
+    bi = np.linalg.inv(base)
+    chain = _chain(leg, q)
+    cur = (base @ chain[-1])[:3, 3]
+    cur_dir_leg = chain[-1][:3, 0]                          # leg_frame_current_tip_pose: taken BEFORE any update (:865)
+    delta = np.zeros(6)
+    delta[:3] = (bi @ np.append(desired, 1))[:3] - (bi @ np.append(cur, 1))[:3]        # tip delta in the leg base frame (:863-872)
+    dq = solve_ik(leg, q, qd, delta, False)
+    if desired_dir is not None:                             # rotation_constrained (:880-900)
+        q, qd, _ = update_joints(leg, q, dq, dt, True)
+        des_dir_leg = bi[:3, :3] @ desired_dir
+        rv = from_two_vectors(cur_dir_leg, des_dir_leg).as_rotvec()                   # AngleAxisd(difference): axis * angle
+        delta = np.zeros(6)
+        delta[3:] = rv
+        dq = solve_ik(leg, q, qd, delta, True)
+    qn, vn, ik_success = update_joints(leg, q, dq, dt, False)
+    tip = (base @ _chain(leg, qn)[-1])[:3, 3]
+    if (np.abs(tip - desired) > 0.005).any():               # IK_TOLERANCE (:916-929)
+        ik_success = 0.0
+    if desired_dir is not None and not ik_success:          # a joint ON its limit (proximity 0) counts as failure too: retry unconstrained (:932-936)
+        return apply_ik(leg, qn, vn, desired, dt, None)
     return qn, vn
 
 
@@ -291,6 +331,8 @@ class Leg:
         self.ext_default = None
         self.touchdown_detection = False
         self.step_plane = None      # Leg::step_plane_pose_.position_ while defined
+        self.rot_defined = False    # current_tip_pose_.rotation_ != UNDEFINED_ROTATION (gravity-aligned tips, > 3 joints)
+        self.cur_dir = self.origin_dir = self.model_dir = np.array([0.0, 0.0, -1.0])   # x axes of current / origin tip rotation, of the FK tip frame
         self.model_tip = None       # Leg::current_tip_pose_.position_ (FK of the joints), scenarios with the kinematic model
 
 
@@ -482,6 +524,19 @@ class RefWalker:
             leg.tip = leg.tip + delta
             leg.tip_velocity = delta / dt
 
+    def update_tip_rotation(self, leg):   # LegStepper::updateTipRotation (> 3 joints, target rotation = the gravity-aligned identity tip rotation)
+        target_dir = np.array([0.0, 0.0, -1.0])              # FromTwoVectors(UnitX, -UnitZ) * UnitX (walk_controller.cpp:37-41)
+        if leg.stance_progress >= 0.0 or leg.swing_progress >= 0.5:
+            leg.cur_dir = target_dir
+            if leg.swing_progress >= 0.5:
+                c = smooth_step(min(1.0, 2.0 * (leg.swing_progress - 0.5)))
+                nd = (1.0 - c) * leg.origin_dir + c * target_dir
+                leg.cur_dir = nd / np.linalg.norm(nd)
+            leg.rot_defined = True
+        else:
+            leg.origin_dir = leg.model_dir.copy()             # leg_->getCurrentTipPose().rotation_: the FK tip frame
+            leg.rot_defined = False
+
     def update_walk_plane(self):
         A = np.array([[leg.default[0], leg.default[1], 1.0] for leg in self.legs])
         B = np.array([leg.default[2] for leg in self.legs])
@@ -565,6 +620,8 @@ class RefWalker:
                 leg.state = FORCE_STOP
                 leg.phase = 0
             self.update_tip_position(leg)
+            if P.get("gravity_aligned_tips"):
+                self.update_tip_rotation(leg)
             self.iterate_phase(leg)
         self.update_walk_plane()
 
@@ -654,8 +711,10 @@ class RefWalker:
         if self.q is not None:   # PoseController::updateStance + Model::updateModel: tips as seen from the posed body, one IK step per leg
             for i, leg in enumerate(self.legs):
                 poser_tip = pose.r.inv().apply(leg.tip - pose.p)          # Pose::inverseTransformVector (pose_controller.cpp:122-131)
-                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + adm[i], self.dt)  # setDesiredTipPose(.., apply_delta)
+                ddir = pose.r.inv().apply(leg.cur_dir) if leg.rot_defined else None   # pose.rotation^-1 * walker tip rotation (:129-130)
+                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + adm[i], self.dt, ddir)  # setDesiredTipPose(.., apply_delta)
                 leg.model_tip = fk_tip(i, self.q[i])                                                     # applyFK closes applyIK
+                leg.model_dir = tip_axis(i, self.q[i])
                 tip_force_estimate(i, self.q[i], self.efforts[i], self.tip_force_calc[i], self.P.get("force_gain", 0.1))   # ... and calculateTipForce
 
 
@@ -675,7 +734,9 @@ def hexapod(gait, morphology=None, **kw):
                  stance_position=[[p.stance_position[l][0], p.stance_position[l][1]] for l in range(p.leg_count)],
                  stance_phase=p.stance_phase, swing_phase=p.swing_phase, phase_offset=p.phase_offset,
                  offset_multiplier=[p.offset_multiplier[l] for l in range(p.leg_count)], n_auto_posers=0, admittance_control=0,
-                 max_rotation=[p.max_rotation[i] for i in range(3)], rotation_pid_gains=[0.2, 0.02, 0.01])
+                 max_rotation=[p.max_rotation[i] for i in range(3)], rotation_pid_gains=[0.2, 0.02, 0.01],
+                 virtual_mass=p.virtual_mass, virtual_stiffness=p.virtual_stiffness, virtual_damping_ratio=p.virtual_damping_ratio,
+                 integrator_step_time=p.integrator_step_time, force_gain=p.force_gain, use_joint_effort=0)
         P.update(kw)
         return P
     P = dict(time_delta=p.time_delta, step_frequency=p.step_frequency, swing_height=p.swing_height, swing_width=p.swing_width,
@@ -715,6 +776,11 @@ SCENARIOS = {
     "wave_admittance_imu": ("wave", {"imu_posing": 1, "admittance_control": 1, "model": 1}, [(0, (0.4, -0.2), 0.15)], 400),
     # config 4's path: the synthetic 8 x 5 octopod, ripple gait - redundant chains, the null-space term of the DLS step at work
     "octopod_8x5_ripple": ("ripple", {"model": 1, "morphology": "8x5"}, [(0, (0.5, 0.3), -0.25), (300, (0, 0), 0.0)], 480),
+    # gravity-aligned tips on the 8 x 5 octopod: updateTipRotation + the rotation-constrained IK pass and its retry
+    "octopod_8x5_gravity_aligned_tips": ("ripple", {"model": 1, "morphology": "8x5", "gravity_aligned_tips": 1}, [(0, (0.4, -0.2), 0.2), (260, (0, 0), 0.0)], 420),
+    # ... and with admittance deltas large enough (U(0, 20) N) that the constrained attempt misses IK_TOLERANCE: the unconstrained retry
+    "octopod_8x5_gravity_aligned_admittance": ("ripple", {"model": 1, "morphology": "8x5", "gravity_aligned_tips": 1, "admittance_control": 1},
+                                               [(0, (0.4, 0.3), -0.2)], 300),
     # the tip-force estimate in the loop: admittance driven by Leg::calculateTipForce from measured joint torques (a new sample every 10 cycles)
     "tripod_admittance_from_joint_efforts": ("tripod", {"admittance_control": 1, "use_joint_effort": 1, "model": 1, "efforts": 1},
                                              [(0, (0.5, -0.2), 0.2), (260, (0, 0), 0.0)], 420),
@@ -759,7 +825,7 @@ def run(name):
         over["n_auto_posers"] = len(P["pose_phase_starts"])
     P.update(over)
     prod = {"force_normal_touchdown": P["force_normal_touchdown"], "swing_width": P["swing_width"], "rough_terrain_mode": P["rough_terrain_mode"],
-            "step_depth": P["step_depth"]}
+            "step_depth": P["step_depth"], "gravity_aligned_tips": int(bool(P.get("gravity_aligned_tips")))}
     limits = limits_from_product(gait, morphology, **prod)
     w = RefWalker(P, limits)
     import zlib
@@ -776,7 +842,7 @@ def run(name):
         pp = make_params(gait, morphology)
         MODEL = Morphology.from_params(pp) if morphology else Morphology.default_hexapod()
         for k_, v_ in over.items():
-            if k_ in ("imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort"):
+            if k_ in ("imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort", "gravity_aligned_tips"):
                 setattr(pp, k_, v_)
         if pp.imu_posing:
             pp.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
@@ -784,6 +850,7 @@ def run(name):
         w.q, w.qd = q0.reshape(pp.leg_count, -1).copy(), qd0.reshape(pp.leg_count, -1).copy()
         for i_, leg_ in enumerate(w.legs):
             leg_.model_tip = fk_tip(i_, w.q[i_])
+            leg_.model_dir = tip_axis(i_, w.q[i_])
         w.efforts = np.zeros_like(w.q)
         start = np.stack([w.q, w.qd])
         out["q"] = []
