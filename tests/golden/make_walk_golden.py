@@ -20,6 +20,7 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
     (:1296-1303)
   quarticBezier / quarticBezierDot         include/.../standard_includes.h:402-420
   PoseController::updateWalkPlanePose / updateAutoPose / updateIMUPose   src/pose_controller.cpp:1092-1236
+  PoseController::updateManualPose (velocity inputs, limits, the reset modes) / updateInclinationPose   :863-1003, :1240-1259
   AutoPoser::updatePose                    src/pose_controller.cpp:1338-1439
   Pose::addPose / interpolate              include/.../pose.h:167-195
   Model::updateModel for the scenarios that carry joints (`model` in their overrides): PoseController::updateStance
@@ -365,6 +366,10 @@ class RefWalker:
         self.gyro = np.zeros(3)
         self.current_pose = Pose([0, 0, P["body_clearance"]])
         self.q = self.qd = None   # joint state [legs][3], for the scenarios that run the kinematic model
+        self.manual_pose = Pose()
+        self.tvi, self.rvi = np.zeros(3), np.zeros(3)   # translation / rotation_velocity_input_ (rewritten by the reset modes)
+        self.reset_mode = 0
+        self.prev_auto_r = R.identity()
         self.adm_state = np.zeros((self.L, 2))
         self.tip_force = np.zeros((self.L, 3))
         self.tip_force_calc = np.zeros((self.L, 3))   # Leg::tip_force_calculated_
@@ -680,9 +685,47 @@ class RefWalker:
             self.auto_posing_state = POSING_COMPLETE
         return pose
 
+    def update_manual_pose(self):   # PoseController::updateManualPose (:863-1003); default_pose_ is the identity (calculateDefaultPose is never called)
+        P, dt = self.P, self.dt
+        if self.reset_mode == 5:    # IMMEDIATE_ALL_RESET
+            self.manual_pose = Pose()
+            return
+        reset_t = {1: (0, 0, 1), 2: (1, 1, 0), 3: (0, 0, 0), 4: (1, 1, 1)}.get(self.reset_mode, (0, 0, 0))   # Z_AND_YAW, X_AND_Y, PITCH_AND_ROLL, ALL
+        reset_r = {1: (0, 0, 1), 2: (0, 0, 0), 3: (1, 1, 0), 4: (1, 1, 1)}.get(self.reset_mode, (0, 0, 0))
+        cur_p = self.manual_pose.p.copy()
+        cur_r = self.manual_pose.r.as_euler("XYZ")             # quaternionToEulerAngles(.., intrinsic)
+        new_p, new_r = np.zeros(3), np.zeros(3)
+        for i in range(3):
+            for cur, reset, vin in ((cur_p, reset_t, self.tvi), (cur_r, reset_r, self.rvi)):
+                if reset[i]:
+                    if cur[i] < 0:
+                        vin[i] = 1.0
+                    elif cur[i] > 0:
+                        vin[i] = -1.0
+            for cur, reset, vin, vmax, pmax, out in ((cur_p, reset_t, self.tvi, P["max_translation_velocity"], P["max_translation"], new_p),
+                                                     (cur_r, reset_r, self.rvi, P["max_rotation_velocity"], P["max_rotation"], new_r)):
+                vel = vin[i] * vmax
+                desired = cur[i] + vel * dt
+                limit = sign(vel) * pmax[i]
+                if reset[i] and -pmax[i] < 0.0 < pmax[i]:      # the default pose is the identity
+                    limit = 0.0
+                positive = sign(vel) > 0
+                if (positive and desired > limit) or (not positive and desired < limit):
+                    vel = (limit - cur[i]) / dt
+                out[i] = cur[i] + vel * dt
+        self.manual_pose = Pose(new_p, R.from_euler("XYZ", new_r))   # eulerAnglesToQuaternion(.., intrinsic)
+
+    def inclination_pose(self):     # PoseController::updateInclinationPose (:1240-1259), reads the auto_pose_ of the previous cycle
+        P = self.P
+        combined = self.manual_pose.r * self.prev_auto_r
+        e = rot_to_euler(self.imu_q * combined.inv())
+        lon = min(P["max_translation"][0], max(-P["max_translation"][0], -P["body_clearance"] * math.tan(e[1])))
+        lat = min(P["max_translation"][1], max(-P["max_translation"][1], P["body_clearance"] * math.tan(e[0])))
+        return Pose([lon, lat, 0.0])
+
     def imu_pose(self):
         P = self.P
-        err = rot_to_euler(self.imu_q)  # target rotation = identity manual pose
+        err = rot_to_euler(self.imu_q * self.manual_pose.r.inv())  # target rotation = the manual pose's
         err[2] = 0.0
         self.abs_err = self.abs_err + err * self.dt
         self.vel_err = 0.15 * -self.gyro + (1 - 0.15) * self.vel_err
@@ -690,17 +733,24 @@ class RefWalker:
         corr = -(kd * self.vel_err + kp * err + ki * self.abs_err)
         corr[0] = min(P["max_rotation"][0], max(-P["max_rotation"][0], corr[0]))
         corr[1] = min(P["max_rotation"][1], max(-P["max_rotation"][1], corr[1]))
-        corr[2] = 0.0
+        corr[2] = rot_to_euler(self.manual_pose.r)[2]          # yaw of the target rotation (:1231)
         return Pose(None, euler_to_rot(corr))
 
     def cycle(self, lin, ang):
         """One StateController::loop with robot_state RUNNING (state_controller.cpp:162-193, 429-445)."""
         self.update_walk_plane_pose()
         pose = Pose().add(self.walk_plane_pose)
+        if self.P.get("manual_posing"):
+            self.update_manual_pose()
+            pose = pose.add(self.manual_pose)
+        if self.P.get("inclination_posing"):
+            pose = pose.add(self.inclination_pose())
         if self.P.get("imu_posing"):
             pose = pose.add(self.imu_pose())
         elif self.P.get("auto_posing"):
-            pose = pose.add(self.auto_pose())
+            ap = self.auto_pose()
+            pose = pose.add(ap)
+            self.prev_auto_r = ap.r
         self.current_pose = pose
         self.pose_state = self.auto_posing_state
         adm = [np.zeros(3)] * self.L
@@ -749,6 +799,8 @@ def hexapod(gait, morphology=None, **kw):
              z_amplitudes=a["z"])
     P.update(virtual_mass=p.virtual_mass, virtual_stiffness=p.virtual_stiffness, virtual_damping_ratio=p.virtual_damping_ratio,
              integrator_step_time=p.integrator_step_time, force_gain=p.force_gain, admittance_control=0, use_joint_effort=0)
+    P.update(manual_posing=0, inclination_posing=0, max_translation=[p.max_translation[i] for i in range(3)],
+             max_translation_velocity=p.max_translation_velocity, max_rotation_velocity=p.max_rotation_velocity)
     P.update(kw)
     return P
 
@@ -781,6 +833,9 @@ SCENARIOS = {
     # ... and with admittance deltas large enough (U(0, 20) N) that the constrained attempt misses IK_TOLERANCE: the unconstrained retry
     "octopod_8x5_gravity_aligned_admittance": ("ripple", {"model": 1, "morphology": "8x5", "gravity_aligned_tips": 1, "admittance_control": 1},
                                                [(0, (0.4, 0.3), -0.2)], 300),
+    # joystick body posing with every reset mode, plus inclination posing from IMU samples
+    "tripod_manual_and_inclination_posing": ("tripod", {"manual_posing": 1, "inclination_posing": 1, "model": 1, "pose_inputs": 1},
+                                             [(0, (0.4, 0.2), 0.1), (330, (0, 0), 0.0)], 480),
     # the tip-force estimate in the loop: admittance driven by Leg::calculateTipForce from measured joint torques (a new sample every 10 cycles)
     "tripod_admittance_from_joint_efforts": ("tripod", {"admittance_control": 1, "use_joint_effort": 1, "model": 1, "efforts": 1},
                                              [(0, (0.5, -0.2), 0.2), (260, (0, 0), 0.0)], 420),
@@ -811,6 +866,13 @@ def rough_events(name, P):
             for leg in range(6):
                 ev.append((c, "transform_target", leg, tr))
                 ev.append((c, "transform_default", leg, [0.5 * t if i < 3 else t for i, t in enumerate(tr)]))
+    elif name == "tripod_manual_and_inclination_posing":
+        erng = np.random.default_rng(4242)
+        for c in range(5, 480, 35):      # bodyPoseInputCallback: normalised velocity inputs (some axes idle)
+            v = erng.uniform(-1, 1, 6) * (erng.random(6) < 0.6)
+            ev.append((c, "pose_input", -1, [float(x) for x in v]))
+        for c, mode in ((150, 4), (215, 0), (260, 1), (300, 0), (340, 3), (365, 2), (400, 0), (430, 5), (450, 0)):
+            ev.append((c, "pose_reset_mode", -1, [mode]))   # poseResetCallback: ALL / Z_AND_YAW / PITCH_AND_ROLL / X_AND_Y / IMMEDIATE_ALL / NO_RESET
     elif name == "ripple_rough_reactive_step_depth":
         ev.append((0, "zero_tip_force", -1, []))   # tip-state messages arrive (touchdown detection on), no contact is ever sensed
     return ev
@@ -842,7 +904,7 @@ def run(name):
         pp = make_params(gait, morphology)
         MODEL = Morphology.from_params(pp) if morphology else Morphology.default_hexapod()
         for k_, v_ in over.items():
-            if k_ in ("imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort", "gravity_aligned_tips"):
+            if k_ in ("manual_posing", "inclination_posing", "imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort", "gravity_aligned_tips"):
                 setattr(pp, k_, v_)
         if pp.imu_posing:
             pp.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
@@ -858,7 +920,7 @@ def run(name):
         for first, l, a in schedule:
             if c == first:
                 lin, ang = l, a
-        if P.get("imu_posing") and c % 25 == 0:  # a new IMU sample every 25 cycles
+        if (P.get("imu_posing") or P.get("inclination_posing")) and c % 25 == 0:  # a new IMU sample every 25 cycles
             e = [rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), 0.0]
             w.imu_q, w.gyro = euler_to_rot(e), rng.normal(0, 0.05, 3)
         for ec, kind, leg, v in events:          # callbacks arrive between loops; the tf refresh is the first thing a loop does
@@ -877,6 +939,10 @@ def run(name):
                 w.legs[leg].ext_target["transform"] = mk(v)
             elif kind == "transform_default" and w.legs[leg].ext_default is not None:
                 w.legs[leg].ext_default["transform"] = mk(v)
+            elif kind == "pose_input":
+                w.tvi, w.rvi = np.array(v[:3]), np.array(v[3:])
+            elif kind == "pose_reset_mode":
+                w.reset_mode = int(v[0])
             elif kind == "zero_tip_force":
                 for l_ in w.legs:
                     l_.touchdown_detection = True

@@ -175,7 +175,7 @@ def test_walk_trajectories(name, meta):
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts"):
+        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs"):
             pass  # (default_hexapod_params already carries auto_pose.yaml; "model": the scenario also carries joints)
         else:
             setattr(p, k, v)
@@ -206,8 +206,12 @@ def test_walk_trajectories(name, meta):
                 L.orc_set_external_transform(r.h, which, leg, _ptr(_arr(v)))
             elif kind == "zero_tip_force":
                 L.orc_set_tip_force(r.h, _ptr(np.zeros(3 * p.leg_count)))
+            elif kind == "pose_input":
+                r.set_pose_input(v[:3], v[3:])
+            elif kind == "pose_reset_mode":
+                L.orc_set_pose_reset_mode(r.h, int(v[0]))
         r.set_velocity(float(g["lin"][c][0]), float(g["lin"][c][1]), float(g["ang"][c]))
-        if p.imu_posing:
+        if p.imu_posing or p.inclination_posing:
             r.set_imu(g["imu_q"][c], g["gyro"][c])
         if p.admittance_control and not p.use_joint_effort:
             r.set_tip_force(g["force"][c])
