@@ -327,6 +327,8 @@ static void leg_set_desired_tip_pose(leg_t *leg, orc_pose tip_pose, int apply_de
 {
   int use_poser_tip_pose = orc_pose_eq(orc_pose_undefined(), tip_pose);
   leg->desired_tip_pose = use_poser_tip_pose ? leg->poser.current_tip_pose : tip_pose;
+  /* "Don't apply delta to manually manipulated legs" (:655-656) */
+  apply_delta = apply_delta && !(leg->leg_state == MANUAL || leg->leg_state == WALKING_TO_MANUAL);
   if (apply_delta) leg->desired_tip_pose.p = orc_v3_add(leg->desired_tip_pose.p, leg->admittance_delta);
 }
 
@@ -1986,7 +1988,9 @@ static int leg_poser_step_to_position(orc_robot *r, leg_t *leg, orc_pose target_
     lp->current_tip_pose = lp->origin_tip_pose;
     return PROGRESS_COMPLETE;
   }
-  if (apply_delta) desired_tip_pose.p = orc_v3_add(desired_tip_pose.p, leg->admittance_delta);
+  /* "Apply delta z to target tip position": not to manually manipulated legs (:1610-1614) */
+  int manually_manipulated = (leg->leg_state == MANUAL || leg->leg_state == WALKING_TO_MANUAL);
+  if (apply_delta && !manually_manipulated) desired_tip_pose.p = orc_v3_add(desired_tip_pose.p, leg->admittance_delta);
   lp->master_iteration_count++;
   int num_iterations = orc_round_to_int(time_to_step / r->params.time_delta);
   num_iterations = num_iterations > 1 ? num_iterations : 1;
@@ -2032,8 +2036,11 @@ static int leg_poser_step_to_position(orc_robot *r, leg_t *leg, orc_pose target_
       new_tip_position = orc_quartic_bezier(cs, time_input);
     }
   }
-  lp->current_tip_pose.p = orc_pose_inverse_transform_vector(desired_pose, new_tip_position);
-  lp->current_tip_pose.r = new_tip_rotation;
+  if (leg->leg_state != MANUAL) /* a MANUAL leg keeps the tip pose updateStance gave its LegPoser (:1680-1684) */
+  {
+    lp->current_tip_pose.p = orc_pose_inverse_transform_vector(desired_pose, new_tip_position);
+    lp->current_tip_pose.r = new_tip_rotation;
+  }
   if (lp->master_iteration_count >= num_iterations)
   {
     lp->first_iteration = 1;

@@ -1197,6 +1197,8 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   {
     SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
+    if ((F & F_TERRAIN) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL))
+      desired = out.poser_tip; // "Don't apply delta to manually manipulated legs" (:655-656)
     if ((F & F_TERRAIN) != 0 && mr != nullptr) { // Leg::desired_tip_pose_.position_ is read back by the next updateManual (:692)
       double *dd = const_cast<double *>(legd);
       reinterpret_cast<double2 *>(dd)[(Fields<NJ>::DES_TIP / 2) * ns + slot] = double2{desired.x, desired.y};

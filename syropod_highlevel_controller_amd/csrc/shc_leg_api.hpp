@@ -52,6 +52,9 @@ struct LegIO {
   }
 };
 
+__device__ __forceinline__ int leg_state_of(const DevState &st, int64_t rob, int leg) { // enum LegState; WALKING until a leg has ever been toggled
+  return st.manual ? st.manual[rob].leg_state[leg] : LS_WALKING;
+}
 // Leg::setDesiredTipPose(tip_pose, apply_delta): tip_pose == NULL is the reference's default argument Pose::Undefined(),
 // "use the poser's tip pose" (model.cpp:657-660; POSER_TIP must have been derived, see derive_tips_kernel).
 template <int NJ>
@@ -77,7 +80,9 @@ __device__ __forceinline__ void set_desired_dev(const DevState &st, const LegIO<
       defined = true;
     }
   }
-  if (apply_delta && have_adm) pos = pos + io.get3(FD::ADM_DELTA); // model.cpp:661
+  const int leg_state = leg_state_of(st, rob, int(io.slot & 63) % L);
+  // model.cpp:655-661: the admittance delta is not applied to manually manipulated legs
+  if (apply_delta && have_adm && leg_state != LS_MANUAL && leg_state != LS_WALKING_TO_MANUAL) pos = pos + io.get3(FD::ADM_DELTA);
   io.put3(FD::DES_TIP, pos);
   io.put(FD::DES_TIP + 3, defined ? 1.0 : 0.0);
   io.put3(FD::DES_DIR, dir);
@@ -224,7 +229,8 @@ __global__ void leg_apply_fk_kernel(DevState st, const SharedConsts<L_, NJ> *gc,
 // hand to Leg::setDesiredTipPose + applyIK (stepToNewStance :521, poseForLegManipulation :561, directStartup :463).
 template <int NJ>
 __device__ __forceinline__ int step_to_position_dev(const DevState &st, const LegIO<NJ> &io, const LegConst<NJ> &lc, const double *target7, const Pose &body,
-                                                    double lift_height, double time_to_step, int apply_delta, int have_adm, double dt, Pose &out_pose) {
+                                                    double lift_height, double time_to_step, int apply_delta, int have_adm, double dt, Pose &out_pose,
+                                                    int leg_state = LS_WALKING) {
   using FD = Fields<NJ>;
   V3 origin = io.get3(FD::SEQ_ORG), origin_dir = io.get3(FD::SEQ_DIR);
   int count = int(io.get(FD::SEQ_ORG + 3));
@@ -253,7 +259,8 @@ __device__ __forceinline__ int step_to_position_dev(const DevState &st, const Le
   int progress = 100;
   double running = 0.0;
   if (move || turn || lift_height != 0.0) {
-    if (apply_delta && have_adm) desired = desired + io.get3(FD::ADM_DELTA);
+    // "Apply delta z to target tip position": not to manually manipulated legs (:1610-1614)
+    if (apply_delta && have_adm && leg_state != LS_MANUAL && leg_state != LS_WALKING_TO_MANUAL) desired = desired + io.get3(FD::ADM_DELTA);
     ++count;
     int num = round_to_int(time_to_step / dt);
     num = num > 1 ? num : 1;
@@ -270,6 +277,11 @@ __device__ __forceinline__ int step_to_position_dev(const DevState &st, const Le
     const int sic = (count + (num - 1)) % num + 1;
     const V3 np = sic <= half ? quartic_bezier(prim, sic * delta_t * 2.0) : quartic_bezier(sec, (sic - half) * delta_t * 2.0);
     out.p = inverse_transform_vector(eased, np);
+    if (leg_state == LS_MANUAL) { // a MANUAL leg keeps the tip pose updateStance gave its LegPoser: the stepper's own (:1680-1684, pose_controller.cpp:134-137)
+      out.p = io.get3(FD::TIP);
+      out.r = Quat{0, 0, 0, 0};
+      if (NJ > 3 && (st.legi[io.slot] & LW_ROTDEF)) out.r = from_two_vectors(V3{1, 0, 0}, io.get3(FD::CUR_DIR));
+    }
     if (count >= num) {
       progress = 100; // first_iteration_ = true
     } else {
@@ -297,7 +309,7 @@ __global__ void leg_step_to_position_kernel(DevState st, const SharedConsts<L_, 
   const Pose body{V3{tp[0], tp[1], tp[2]}, Quat{tp[3], tp[4], tp[5], tp[6]}};
   Pose out;
   const int progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target_tip_pose ? target_tip_pose + t * 7 : nullptr, body, lift_height, time_to_step,
-                                                apply_delta, have_adm, dt, out);
+                                                apply_delta, have_adm, dt, out, leg_state_of(st, rob, l));
   double *o = tip_pose_out + t * 7;
   o[0] = out.p.x, o[1] = out.p.y, o[2] = out.p.z, o[3] = out.r.w, o[4] = out.r.x, o[5] = out.r.y, o[6] = out.r.z;
   if (progress_out) progress_out[t] = progress;

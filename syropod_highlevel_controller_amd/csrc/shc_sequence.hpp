@@ -190,7 +190,7 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
         double time_to_step = kHorizontalTransitionTime / P.step_frequency;
         time_to_step *= first ? 2.0 : 1.0;
         Pose tip;
-        progress = step_to_position_dev<NJ>(st, io, gc->leg[l], g.target, identity, step_height, time_to_step, apply_delta, P.have_adm, P.dt, tip);
+        progress = step_to_position_dev<NJ>(st, io, gc->leg[l], g.target, identity, step_height, time_to_step, apply_delta, P.have_adm, P.dt, tip, leg_state_of(st, rob, l));
         put_pose7(g.current, tip);
         set_desired_dev<NJ>(st, io, L, rob, g.current, 1, P.have_adm, P.gravity_aligned);
         const double limit_proximity = apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
@@ -246,7 +246,7 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
       double time_to_step = kVerticalTransitionTime / P.step_frequency;
       time_to_step *= first ? 2.0 : 1.0;
       Pose tip;
-      progress = step_to_position_dev<NJ>(st, io, gc->leg[l], g.target, identity, 0.0, time_to_step, apply_delta, P.have_adm, P.dt, tip);
+      progress = step_to_position_dev<NJ>(st, io, gc->leg[l], g.target, identity, 0.0, time_to_step, apply_delta, P.have_adm, P.dt, tip, leg_state_of(st, rob, l));
       put_pose7(g.current, tip);
       set_desired_dev<NJ>(st, io, L, rob, g.current, 0, P.have_adm, P.gravity_aligned);
       const double limit_proximity = apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
@@ -306,7 +306,7 @@ __global__ void step_to_new_stance_kernel(DevState st, const SharedConsts<L, NJ>
     double target[7];
     put_pose7(target, io.get3(FD::DFLT), target_rotation); // leg_stepper->getDefaultTipPose()
     Pose tip;
-    progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target, current_pose, P.swing_height, 1.0 / P.step_frequency, 1, P.have_adm, P.dt, tip);
+    progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target, current_pose, P.swing_height, 1.0 / P.step_frequency, 1, P.have_adm, P.dt, tip, leg_state_of(st, rob, l));
     put_pose7(s.leg[l].current, tip);
     set_desired_dev<NJ>(st, io, L, rob, s.leg[l].current, 1, P.have_adm, P.gravity_aligned);
     apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
@@ -400,7 +400,7 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
             clearance = xf(X::P_CLEARANCE);
           }
           Pose tip;
-          const int p = step_to_position_dev<NJ>(st, io, gc->leg[l], defined ? target : nullptr, body, clearance, kPlanTransitionTime, 1, P.have_adm, P.dt, tip);
+          const int p = step_to_position_dev<NJ>(st, io, gc->leg[l], defined ? target : nullptr, body, clearance, kPlanTransitionTime, 1, P.have_adm, P.dt, tip, leg_state_of(st, rob, l));
           put_pose7(s.leg[l].current, tip);
           set_desired_dev<NJ>(st, io, L, rob, s.leg[l].current, 1, P.have_adm, 0);
           apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
@@ -521,7 +521,7 @@ __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *
           io.put3(FD::TIP, io.get3(FD::DFLT));                   // leg_stepper->setCurrentTipPose(default tip pose)
         }
         Pose tip;
-        const int progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target, pose_identity(), step_height, step_time, 1, P.have_adm, P.dt, tip);
+        const int progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target, pose_identity(), step_height, step_time, 1, P.have_adm, P.dt, tip, ls);
         min_progress = progress < min_progress ? progress : min_progress;
         if (progress != 100) {
           double cur[7];

@@ -221,3 +221,23 @@ def test_planner_mode_invariants():
     assert len(res) == calls
     assert np.abs(ob.leg_state()["model_tip"][0] - (tip1 - shift)).max() < 5e-3
     assert ob.execute_plan()[1][0] == 3
+
+
+def test_manual_legs_take_no_admittance_delta():
+    """Leg::setDesiredTipPose and LegPoser::stepToPosition leave the admittance delta out for MANUAL / WALKING_TO_MANUAL legs
+    (model.cpp:655-656, pose_controller.cpp:1610-1614): with admittance on and a steady 8 N on every tip (a 2 cm delta along the
+    tip axis for the walking legs) the manual leg's tip still goes exactly where the position input puts it."""
+    from oracle_lib import OracleBatch
+    p = default_hexapod_params("tripod")
+    p.admittance_control = 1
+    ob = OracleBatch(p, 1)
+    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 8.0]), (1, 6, 1)))
+    ob.step(150, 1)
+    delta = ob.leg_state()["admittance"][0]
+    assert np.abs(delta).max() > 0.015                                           # the walking legs do carry a delta
+    while ob.toggle_leg_state(np.array([2], dtype=np.int32))[0] != 1:
+        pass
+    target = np.array([[p.stance_position[2][0] * 0.9, p.stance_position[2][1] * 0.9, -0.07]])
+    ob.set_manual_inputs(np.array([2], dtype=np.int32), None, target, None, None, None)
+    ob.step(60, 1)
+    assert np.abs(ob.leg_state()["model_tip"][0, 2] - target[0]).max() < 5e-3   # IK tolerance, not 2 cm off
