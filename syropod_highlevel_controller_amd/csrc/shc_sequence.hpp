@@ -360,8 +360,11 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
       for (int l = 0; l < L; ++l) { // Model::updateModel: setDesiredTipPose() = the poser's tip pose + admittance delta, applyIK
         const LegIO<NJ> io{st, slot_of(rob, l, L)};
         double tip[7];
-        if (s.poser_tip_from_plan) {
+        const int ls = leg_state_of(st, rob, l);
+        if (s.poser_tip_from_plan && ls != LS_MANUAL) { // (stepToPosition leaves a MANUAL leg's LegPoser tip alone, :1680-1684)
           for (int k = 0; k < 7; ++k) tip[k] = s.leg[l].current[k];
+        } else if (ls == LS_MANUAL || ls == LS_WALKING_TO_MANUAL) {
+          put_pose7(tip, io.get3(FD::TIP), Quat{0, 0, 0, 0}); // updateStance hands manually manipulated legs the stepper's tip as it is (:134-137)
         } else {
           put_pose7(tip, inverse_transform_vector(current_pose, io.get3(FD::TIP)), Quat{0, 0, 0, 0}); // updateStance (pose_controller.cpp:122-131)
         }

@@ -179,3 +179,106 @@ def test_planner_unsupported_configurations():
         eng = BatchEngine(p, 2)
         with pytest.raises(RuntimeError):
             eng.execute_plan()
+
+
+def test_plan_steps_with_manual_legs():
+    """Planner mode on robots that hold a MANUAL leg (admittance on): the manually manipulated leg takes no admittance delta in
+    stepToPosition / setDesiredTipPose and keeps its LegPoser tip (model.cpp:655-656, pose_controller.cpp:1610-1614, :1680-1684),
+    the waiting loop's updateModel uses the stepper's tip for it (updateStance, :134-137).  Teacher-forced against the oracle."""
+    p = default_hexapod_params("tripod")
+    p.admittance_control = 1
+    n, L, D = 6, 6, 3
+    rng = np.random.default_rng(47)
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    lin, ang = rng.uniform(-0.4, 0.4, (n, 2)), rng.uniform(-0.3, 0.3, n)
+    force = np.abs(rng.normal(4.0, 2.0, (n, L, 3)))
+    for o in (eng, ob):
+        o.set_velocity(lin, ang)
+        o.set_tip_force(force)
+    worst = 0.0
+
+    def check(tag):
+        nonlocal worst
+        d = float(np.abs(eng.joints()[0] - ob.joints()[0]).max())
+        worst = max(worst, d)
+        assert d < 1e-10, (tag, d)
+        assert np.array_equal(eng.body_state()[2], ob.body_state()[2]), tag
+
+    def cycles(k):
+        for _ in range(k):
+            eng.set_state(ob.get_state())
+            eng.step(1)
+            eng.synchronize()
+            ob.step(1, 1)
+            check("cycle")
+
+    def toggle(sel):
+        sel = np.array(sel, dtype=np.int32)
+        pending = sel >= 0
+        for _ in range(3000):
+            if not pending.any():
+                return
+            cur = np.where(pending, sel, -1).astype(np.int32)
+            eng.set_state(ob.get_state())
+            re, ro = eng.toggle_leg_state(cur), ob.toggle_leg_state(cur)
+            assert np.array_equal(re, ro)
+            check("toggle")
+            pending &= ~((re == 1) | (re == 2))
+        raise AssertionError("toggle did not finish")
+
+    def plan_until(done_value, limit=700):
+        done = np.zeros(n, dtype=bool)
+        for _ in range(limit):
+            eng.set_state(ob.get_state())
+            (pe, se), (po, so) = eng.execute_plan(), ob.execute_plan()
+            assert np.array_equal(pe, po) and np.array_equal(se, so), (pe, po)
+            check("plan")
+            done |= pe == done_value
+            if done.all():
+                return se
+        raise AssertionError(("plan step did not finish", pe))
+
+    cycles(40)
+    manual = [i % L if i < 4 else -1 for i in range(n)]
+    toggle(manual)                                     # robots 0-3 end up STOPPED with one MANUAL leg, robots 4, 5 keep walking
+    assert np.array_equal(eng.leg_manipulation_state(), ob.leg_manipulation_state())
+    vel = rng.uniform(-1, 1, (n, 3))
+    for o in (eng, ob):
+        o.set_manual_inputs(np.array(manual, dtype=np.int32), vel, None, None, None, None)
+    cycles(20)
+    for o in (eng, ob):
+        o.set_planner_mode(True)
+    plan_until(WAITING)
+    q0 = ob.joints()[0].reshape(n, L, D)
+    cfg = q0 + rng.uniform(-0.1, 0.1, q0.shape)
+    for o in (eng, ob):
+        o.set_target_configuration(cfg)
+    st = plan_until(100)
+    assert (st == 1).all()
+    for _ in range(4):
+        plan_until(WAITING, limit=1)
+    tips = ob.leg_state()["model_tip"].reshape(n, L, 3)
+    rows = (ExternalTarget * (n * L))()
+    for i in range(n):
+        for l in range(L):
+            r = rows[i * L + l]
+            r.defined = 1
+            off = rng.normal(size=3)
+            r.pose[0:3] = list(tips[i, l] + off * 0.04 / np.linalg.norm(off))
+            r.transform[:] = [0, 0, 0, 1, 0, 0, 0]
+            r.swing_clearance = 0.015
+    assert eng.set_external_target(rows) == 0 and ob.set_external_target(rows) == 0
+    body = np.tile(np.array([0.008, 0.0, 0.01, 1.0, 0, 0, 0]), (n, 1))
+    for o in (eng, ob):
+        o.set_target_body_pose(body)
+    st = plan_until(100)
+    assert (st == 2).all()
+    for o in (eng, ob):
+        o.set_planner_mode(False)
+        o.set_manual_inputs(None, None, None, None, None, None)
+    toggle(manual)
+    assert (eng.leg_manipulation_state() == 0).all()
+    cycles(60)
+    from conftest import parity_report
+    parity_report(f"[planner with manual legs] toggle / manipulate / plan steps on robots holding a MANUAL leg / toggle back: max |dq| = {worst:.2e} rad per call "
+                  "(teacher-forced)")
