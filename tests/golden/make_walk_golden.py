@@ -371,6 +371,7 @@ class RefWalker:
         self.reset_mode = 0
         self.prev_auto_r = R.identity()
         self.adm_state = np.zeros((self.L, 2))
+        self.stiffness = [0.0] * self.L   # Leg::virtual_stiffness_: uninitialised in the reference until the first updateStiffness (0 by this build's convention)
         self.tip_force = np.zeros((self.L, 3))
         self.tip_force_calc = np.zeros((self.L, 3))   # Leg::tip_force_calculated_
         self.efforts = None                            # Joint::current_effort_ [legs][dof]
@@ -685,6 +686,20 @@ class RefWalker:
             self.auto_posing_state = POSING_COMPLETE
         return pose
 
+    def update_stiffness(self):     # AdmittanceController::updateStiffness(walker) (src/admittance_controller.cpp:96-134): published per-leg value
+        P, L = self.P, self.L
+        k = P["virtual_stiffness"]
+        self.stiffness = [k] * L
+        for i, leg in enumerate(self.legs):
+            if leg.state == SWING:
+                ref = abs((leg.tip[2] - leg.default[2]) / P["swing_height"])
+                a1, a2 = (i - 1) % L, (i + 1) % L
+                load = k * (ref * (P["load_stiffness_scaler"] - 1))
+                c1, c2 = self.stiffness[a1], self.stiffness[a2]
+                self.stiffness[i] = k * (ref * (P["swing_stiffness_scaler"] - 1) + 1)
+                self.stiffness[a1] = c1 + load
+                self.stiffness[a2] = c2 + load
+
     def update_manual_pose(self):   # PoseController::updateManualPose (:863-1003); default_pose_ is the identity (calculateDefaultPose is never called)
         P, dt = self.P, self.dt
         if self.reset_mode == 5:    # IMMEDIATE_ALL_RESET
@@ -754,6 +769,8 @@ class RefWalker:
         self.current_pose = pose
         self.pose_state = self.auto_posing_state
         adm = [np.zeros(3)] * self.L
+        if self.P.get("admittance_control") and self.P.get("dynamic_stiffness") and self.walk_state != STOPPED:
+            self.update_stiffness()                                        # state_controller.cpp:175: with the walk state BEFORE updateWalk
         if self.P.get("admittance_control") and self.q is not None:      # loop(): the admittance update precedes runningState
             src = self.tip_force_calc if self.P.get("use_joint_effort") else self.tip_force      # getTipForceCalculated / Measured (:30-31)
             adm = [admittance_delta(self.adm_state[i], src[i], tip_axis(i, self.q[i]), self.P) for i in range(self.L)]
@@ -798,7 +815,8 @@ def hexapod(gait, morphology=None, **kw):
              roll_amplitudes=a["roll"], pitch_amplitudes=a["pitch"], yaw_amplitudes=a["yaw"], x_amplitudes=a["x"], y_amplitudes=a["y"],
              z_amplitudes=a["z"])
     P.update(virtual_mass=p.virtual_mass, virtual_stiffness=p.virtual_stiffness, virtual_damping_ratio=p.virtual_damping_ratio,
-             integrator_step_time=p.integrator_step_time, force_gain=p.force_gain, admittance_control=0, use_joint_effort=0)
+             integrator_step_time=p.integrator_step_time, force_gain=p.force_gain, admittance_control=0, use_joint_effort=0,
+             dynamic_stiffness=0, swing_stiffness_scaler=p.swing_stiffness_scaler, load_stiffness_scaler=p.load_stiffness_scaler)
     P.update(manual_posing=0, inclination_posing=0, max_translation=[p.max_translation[i] for i in range(3)],
              max_translation_velocity=p.max_translation_velocity, max_rotation_velocity=p.max_rotation_velocity)
     P.update(kw)
@@ -836,6 +854,8 @@ SCENARIOS = {
     # joystick body posing with every reset mode, plus inclination posing from IMU samples
     "tripod_manual_and_inclination_posing": ("tripod", {"manual_posing": 1, "inclination_posing": 1, "model": 1, "pose_inputs": 1},
                                              [(0, (0.4, 0.2), 0.1), (330, (0, 0), 0.0)], 480),
+    # the published per-leg virtual stiffness of dynamic_stiffness (swing legs soften, their neighbours stiffen)
+    "ripple_dynamic_stiffness": ("ripple", {"admittance_control": 1, "dynamic_stiffness": 1, "model": 1}, [(0, (0.5, 0.1), 0.2), (200, (0, 0), 0.0)], 330),
     # the tip-force estimate in the loop: admittance driven by Leg::calculateTipForce from measured joint torques (a new sample every 10 cycles)
     "tripod_admittance_from_joint_efforts": ("tripod", {"admittance_control": 1, "use_joint_effort": 1, "model": 1, "efforts": 1},
                                              [(0, (0.5, -0.2), 0.2), (260, (0, 0), 0.0)], 420),
@@ -892,7 +912,7 @@ def run(name):
     w = RefWalker(P, limits)
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[])
+    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[])
     events = rough_events(name, P)
     lin, ang = (0.0, 0.0), 0.0
     w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
@@ -904,7 +924,7 @@ def run(name):
         pp = make_params(gait, morphology)
         MODEL = Morphology.from_params(pp) if morphology else Morphology.default_hexapod()
         for k_, v_ in over.items():
-            if k_ in ("manual_posing", "inclination_posing", "imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort", "gravity_aligned_tips"):
+            if k_ in ("dynamic_stiffness", "manual_posing", "inclination_posing", "imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort", "gravity_aligned_tips"):
                 setattr(pp, k_, v_)
         if pp.imu_posing:
             pp.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
@@ -975,6 +995,7 @@ def run(name):
         if w.q is not None:
             out["q"].append(w.q.copy())
             out["tip_force_calc"].append(w.tip_force_calc.copy())
+            out["stiffness"].append(list(w.stiffness))
         out["phase"].append([leg.phase for leg in w.legs])
         out["state"].append([leg.state for leg in w.legs])
         out["walk_state"].append(w.walk_state)

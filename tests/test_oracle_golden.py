@@ -235,6 +235,11 @@ def test_walk_trajectories(name, meta):
         if "q" in g:   # joints of the whole cycle (updateStance + setDesiredTipPose + applyIK) from the independent numpy chain, free-running
             worst_q = max(worst_q, np.abs(r.joints()[0].reshape(*LD) - g["q"][c]).max())
             assert worst_q < 1e-6, (name, c, worst_q)
+            if meta["overrides"].get("dynamic_stiffness"):   # Leg::virtual_stiffness_ as publishLegState reports it (state_controller.cpp:889)
+                from syropod_highlevel_controller_amd.params import LegStateMsg
+                msg = (LegStateMsg * p.leg_count)()
+                L.orc_get_leg_state_msg(r.h, msg)
+                assert np.abs(np.array([m.virtual_stiffness for m in msg]) - g["stiffness"][c]).max() < 1e-12, (name, c)
             if "effort" in g:          # the tip-force estimate itself (LegState.tip_force carries it times the force gain, :883-885)
                 assert np.abs(ls["tip_force"] - g["tip_force_calc"][c]).max() < 1e-9, (name, c)
     print(f"{name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, max |pose diff| {worst_pose:.2e}"
