@@ -21,6 +21,7 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   quarticBezier / quarticBezierDot         include/.../standard_includes.h:402-420
   PoseController::updateWalkPlanePose / updateAutoPose / updateIMUPose   src/pose_controller.cpp:1092-1236
   PoseController::updateManualPose (velocity inputs, limits, the reset modes) / updateInclinationPose   :863-1003, :1240-1259
+  PoseController::updateTipAlignPose (gravity_aligned_tips on <= 3-joint legs; with the kinematic model)   :1024-1088
   AutoPoser::updatePose                    src/pose_controller.cpp:1338-1439
   Pose::addPose / interpolate              include/.../pose.h:167-195
   Model::updateModel for the scenarios that carry joints (`model` in their overrides): PoseController::updateStance
@@ -367,6 +368,7 @@ class RefWalker:
         self.current_pose = Pose([0, 0, P["body_clearance"]])
         self.q = self.qd = None   # joint state [legs][3], for the scenarios that run the kinematic model
         self.manual_pose = Pose()
+        self.tip_align_pose, self.origin_tip_align_pose = Pose(), Pose()
         self.tvi, self.rvi = np.zeros(3), np.zeros(3)   # translation / rotation_velocity_input_ (rewritten by the reset modes)
         self.reset_mode = 0
         self.prev_auto_r = R.identity()
@@ -626,7 +628,7 @@ class RefWalker:
                 leg.state = FORCE_STOP
                 leg.phase = 0
             self.update_tip_position(leg)
-            if P.get("gravity_aligned_tips"):
+            if P.get("gravity_aligned_tips") and self.q is not None and self.q.shape[1] > 3:
                 self.update_tip_rotation(leg)
             self.iterate_phase(leg)
         self.update_walk_plane()
@@ -685,6 +687,33 @@ class RefWalker:
         if complete == len(self.posers):
             self.auto_posing_state = POSING_COMPLETE
         return pose
+
+    def update_tip_align_pose(self):   # PoseController::updateTipAlignPose (:1024-1088): legs in id order, each on the pose the previous one left
+        P = self.P
+        for i, leg in enumerate(self.legs):
+            sp = leg.swing_progress
+            if sp == -1.0:
+                continue
+            normal = leg.walk_plane_normal
+            rot = from_two_vectors(np.array([0.0, 0.0, 1.0]), normal)
+            base = dh(*MODEL.base[i])
+            chain = _chain(i, self.q[i])
+            tip_p, joint_p = (base @ chain[-1])[:3, 3], (base @ chain[-2])[:3, 3]     # the tip and the joint that actuates its link
+            a = rot.apply(joint_p - tip_p)
+            b = np.linalg.norm(tip_p - joint_p) * normal
+            to_alignment = -(a - (a @ b) / (b @ b) * b)
+            a = self.tip_align_pose.p
+            aligned = a - (a @ normal) / (normal @ normal) * normal
+            target = aligned + to_alignment
+            lim = P["max_translation"]
+            target = np.array([max(-lim[k], min(target[k], lim[1])) for k in range(3)])   # clamped(value, limit): the upper bound is limit[1] for every axis (standard_includes.h:134)
+            c = smooth_step(sp)
+            if sp < 0.5:
+                self.tip_align_pose = self.origin_tip_align_pose.interpolate(smooth_step(c * 2.0), Pose())
+            else:
+                self.tip_align_pose = Pose().interpolate(smooth_step((c - 0.5) * 2.0), Pose(target))
+            if sp == 1.0:
+                self.origin_tip_align_pose = self.tip_align_pose
 
     def update_stiffness(self):     # AdmittanceController::updateStiffness(walker) (src/admittance_controller.cpp:96-134): published per-leg value
         P, L = self.P, self.L
@@ -766,6 +795,9 @@ class RefWalker:
             ap = self.auto_pose()
             pose = pose.add(ap)
             self.prev_auto_r = ap.r
+        if self.P.get("gravity_aligned_tips") and self.q is not None and self.q.shape[1] <= 3:   # "TODO EXPERIMENTAL" (:849-855)
+            self.update_tip_align_pose()
+            pose = pose.add(self.tip_align_pose)
         self.current_pose = pose
         self.pose_state = self.auto_posing_state
         adm = [np.zeros(3)] * self.L
@@ -854,6 +886,8 @@ SCENARIOS = {
     # joystick body posing with every reset mode, plus inclination posing from IMU samples
     "tripod_manual_and_inclination_posing": ("tripod", {"manual_posing": 1, "inclination_posing": 1, "model": 1, "pose_inputs": 1},
                                              [(0, (0.4, 0.2), 0.1), (330, (0, 0), 0.0)], 480),
+    # gravity_aligned_tips on 3-joint legs: the experimental tip-align body pose
+    "tripod_tip_align_pose": ("tripod", {"gravity_aligned_tips": 1, "model": 1}, [(0, (0.5, -0.1), 0.15), (280, (0, 0), 0.0)], 420),
     # the published per-leg virtual stiffness of dynamic_stiffness (swing legs soften, their neighbours stiffen)
     "ripple_dynamic_stiffness": ("ripple", {"admittance_control": 1, "dynamic_stiffness": 1, "model": 1}, [(0, (0.5, 0.1), 0.2), (200, (0, 0), 0.0)], 330),
     # the tip-force estimate in the loop: admittance driven by Leg::calculateTipForce from measured joint torques (a new sample every 10 cycles)
