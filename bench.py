@@ -128,6 +128,9 @@ def measured_traffic(workload, n, cps):
         return None
 
 
+_TWO_STREAMS = None
+
+
 def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False, joint_efforts=False):
     """One workload on this rank's GPU: prepare (untimed), time `steps` steps, measure the kernel with HIP events.
     dist_ctx = (world, rank, local_rank) when the RCCL path is active."""
@@ -249,7 +252,10 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     two_streams = None
     if cps == 1 and world == 1 and fused_probe and n >= 32768:
         half = n // 2
-        streams2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+        global _TWO_STREAMS   # one pair for the whole process: streams share a few hardware queues, and two probes' pairs can collide on one
+        if _TWO_STREAMS is None:
+            _TWO_STREAMS = [torch.cuda.Stream(), torch.cuda.Stream()]
+        streams2 = _TWO_STREAMS
         engs = []
         for i, (a, b) in enumerate(((0, half), (half, n))):
             e2 = BatchEngine(p, b - a, device=local_rank, stream=streams2[i].cuda_stream)
