@@ -514,8 +514,8 @@ static double leg_update_joint_positions(orc_robot *r, leg_t *leg, const double 
   return min_limit_proximity;
 }
 
-/* Leg::applyIK (model.cpp:861-941) */
-static double leg_apply_ik(orc_robot *r, leg_t *leg, int simulation)
+/* Leg::applyIK (model.cpp:861-941): one frame of it (the unconstrained retry is a nested frame) */
+static double leg_apply_ik_frame(orc_robot *r, leg_t *leg, int simulation)
 {
   orc_pose leg_frame_desired_tip_pose = joint_pose_joint_frame(leg, 1, leg->desired_tip_pose);
   orc_pose leg_frame_current_tip_pose = joint_pose_joint_frame(leg, 1, leg->current_tip_pose);
@@ -557,11 +557,19 @@ static double leg_apply_ik(orc_robot *r, leg_t *leg, int simulation)
   if (rotation_constrained && !ik_success)
   {
     leg->desired_tip_pose.r = ORC_UNDEFINED_ROTATION;
-    ik_success = leg_apply_ik(r, leg, simulation);
+    ik_success = leg_apply_ik_frame(r, leg, simulation);
   }
 
   leg_calculate_tip_force(r, leg);
   return ik_success;
+}
+
+/* ik_failed is this build's record of the reference's "Inverse kinematics deviation" warning (:921-928): raised by any frame of
+ * the LAST non-simulated applyIK call of the leg. */
+static double leg_apply_ik(orc_robot *r, leg_t *leg, int simulation)
+{
+  if (!simulation) leg->ik_failed = 0;
+  return leg_apply_ik_frame(r, leg, simulation);
 }
 
 /* Model::estimateGravity (model.cpp:156-165) */

@@ -1169,8 +1169,12 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       V3 change = vin * (P.max_translation_velocity * P.dt);
       if (norm(ik_error) >= kIkTolerance) change = (-normalized(ik_error)) * norm(change);
       s.tip = s.tip + change;
+      rot_def = false; // setCurrentTipPose(Pose(new_tip_position, UNDEFINED_ROTATION)) (:704)
     }
-    if (norm(pin) != 0.0) s.tip = pin; // tip-pose overload (:712-744): the requested position, rotation undefined
+    if (norm(pin) != 0.0) { // tip-pose overload (:712-744): the requested position, rotation undefined
+      s.tip = pin;
+      rot_def = false;
+    }
   }
   s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL | LW_ROTDEF)) |
            my_state | (my_acp ? LW_ACP : 0) | (my_cfs ? LW_CFS : 0) | (my_pm << LW_PM_SHIFT) | (my_phase << LW_PHASE_SHIFT) |

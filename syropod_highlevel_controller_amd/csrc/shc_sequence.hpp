@@ -518,10 +518,15 @@ __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *
         double target[7];
         put_pose7(target, inverse_transform_vector(target_pose, io.get3(FD::DFLT)), Quat{0, 0, 0, 0});
         if (ls == LS_WALKING_TO_MANUAL) {
-          io.put3(FD::TIP, V3{target[0], target[1], target[2]}); // leg_stepper->setCurrentTipPose(target_tip_pose)
+          io.put3(FD::TIP, V3{target[0], target[1], target[2]}); // leg_stepper->setCurrentTipPose(target_tip_pose): rotation undefined
+          st.legi[io.slot] &= ~LW_ROTDEF;
           step_height = 0.0;
         } else if (ls == LS_MANUAL_TO_WALKING) {
           io.put3(FD::TIP, io.get3(FD::DFLT));                   // leg_stepper->setCurrentTipPose(default tip pose)
+          // ... whose rotation is undefined once updateDefaultTipPosition has re-derived the pose (every stop does, walk_controller.cpp:1003).
+          // (A robot that has never walked still holds the gravity-aligned identity rotation there; nothing reads the flag before the
+          //  next updateTipRotation recomputes it, so only a snapshot taken in between could tell.)
+          st.legi[io.slot] &= ~LW_ROTDEF;
         }
         Pose tip;
         const int progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target, pose_identity(), step_height, step_time, 1, P.have_adm, P.dt, tip, ls);

@@ -6,6 +6,8 @@ import pytest
 from oracle_lib import OracleBatch
 from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
 from syropod_highlevel_controller_amd.engine import BatchEngine
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT
+from test_gpu_teacher_forced import as_np, compare_records
 
 pytestmark = pytest.mark.gpu
 
@@ -73,6 +75,7 @@ def test_toggle_manipulate_and_return(case):
             d = float(np.abs(eng.joints()[0] - ob.joints()[0]).max())   # every robot ran one loop: toggle, or the ordinary cycle
             worst = max(worst, d)
             assert d < 1e-10, (calls, d)
+            compare_records(p, FEAT_DEFAULT, as_np(eng.get_state()), as_np(ob.get_state()), tol_q=1e-10)   # ... and every other state field
             assert np.array_equal(eng.body_state()[2], ob.body_state()[2])
             pending &= ~((re == 1) | (re == 2))
         assert not pending.any()
@@ -140,3 +143,37 @@ def test_manual_legs_unsupported_configurations():
         eng = BatchEngine(p, 2)
         with pytest.raises(RuntimeError):
             eng.toggle_leg_state(np.array([0, -1], dtype=np.int32))
+
+
+def test_toggle_and_manipulate_free_running():
+    """The same without state injection (what teacher forcing cannot show: state the engine keeps to itself between calls, e.g.
+    the tip-rotation flag of a leg that went MANUAL on gravity-aligned 5-joint legs).  The robots stand for most of this, where
+    the reference's IK step amplifies rounding differences: flags exactly, tips to 5 mm."""
+    p = synthetic_octopod_params("ripple", 5, 8)
+    p.gravity_aligned_tips = 1
+    n, L = 6, 8
+    rng = np.random.default_rng(5)
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    lin, ang = rng.uniform(-0.4, 0.4, (n, 2)), rng.uniform(-0.3, 0.3, n)
+    for o in (eng, ob):
+        o.set_velocity(lin, ang)
+        o.step(50) if o is eng else o.step(50, 1)
+    sel = np.array([i % L for i in range(n)], dtype=np.int32)
+    for _ in range(3000):
+        re, ro = eng.toggle_leg_state(sel), ob.toggle_leg_state(sel)
+        assert np.array_equal(re, ro)
+        if (re == 1).all():
+            break
+        sel = np.where(re == 1, -1, sel).astype(np.int32)
+    assert np.array_equal(eng.leg_manipulation_state(), ob.leg_manipulation_state())
+    vel = rng.uniform(-1, 1, (n, 3))
+    prim = np.array([i % L for i in range(n)], dtype=np.int32)
+    for o in (eng, ob):
+        o.set_manual_inputs(prim, vel, None, None, None, None)
+        o.step(40) if o is eng else o.step(40, 1)
+    eng.synchronize()
+    g, o = as_np(eng.get_state()), as_np(ob.get_state())
+    assert np.array_equal(g["leg"]["tip_rotation_defined"][:, :L], o["leg"]["tip_rotation_defined"][:, :L])
+    assert np.array_equal(g["walk_state"], o["walk_state"])
+    assert np.abs(eng.leg_state()["model_tip"] - ob.leg_state()["model_tip"]).max() < 5e-3
+    assert np.abs(eng.leg_state()["walker_tip"] - ob.leg_state()["walker_tip"]).max() < 5e-3

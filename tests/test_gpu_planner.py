@@ -7,7 +7,8 @@ import pytest
 from oracle_lib import OracleBatch
 from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
 from syropod_highlevel_controller_amd.engine import BatchEngine
-from syropod_highlevel_controller_amd.params import WALK_STOPPED, ExternalTarget
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, WALK_STOPPED, ExternalTarget
+from test_gpu_teacher_forced import as_np, compare_records
 
 pytestmark = pytest.mark.gpu
 WAITING, WALKING = -2, -1
@@ -48,6 +49,8 @@ def test_plan_steps_against_the_oracle(case):
         d = float(dd.max()) if dd.size else 0.0
         worst = max(worst, d)
         assert d < 1e-10, (tag, d)
+        # ... and every other field of the controller state: what the loop-level kernel and the partial cycle launch left behind
+        compare_records(p, FEAT_DEFAULT, as_np(eng.get_state()), as_np(ob.get_state()), tol_q=1e-10)
 
     def forced_cycles(k):
         for _ in range(k):

@@ -76,7 +76,7 @@ def compare_records(p, features, g, o, tol_q=TOL_Q):
         np.testing.assert_allclose(gl["step_plane_position"][d], ol["step_plane_position"][d], atol=TOL_X)
         assert np.array_equal(g["touchdown_detection"], o["touchdown_detection"])
     if p.gravity_aligned_tips and D > 3:
-        assert np.array_equal(gl["tip_rotation_defined"], ol["tip_rotation_defined"])
+        assert np.array_equal(gl["tip_rotation_defined"], ol["tip_rotation_defined"]), ("tip_rotation_defined", gl["tip_rotation_defined"].tolist(), ol["tip_rotation_defined"].tolist())
         d = ol["tip_rotation_defined"] != 0
         np.testing.assert_allclose(gl["walker_tip_direction"][d], ol["walker_tip_direction"][d], atol=1e-12)
         np.testing.assert_allclose(gl["origin_tip_direction"], ol["origin_tip_direction"], atol=1e-12)
