@@ -71,6 +71,22 @@ __device__ __forceinline__ void seq_defaults(SeqRobotState &s) { // member initi
   s.initialised = 1;
 }
 
+// PoseController::updateCurrentPose for a robot none of whose legs swings, with walk-plane + manual posing (what the loop-level
+// kernels support): the walk-plane pose is its origin (no swing progress to interpolate with, pose_controller.cpp:1100-1128) and
+// the manual pose stays as it is without inputs, so Model::current_pose_ = origin_walk_plane_pose_ (+) manual_pose_.  The start-up
+// sequence runs before the first control cycle has ever written the pose.
+template <int L>
+__device__ __forceinline__ void standing_pose_prologue_dev(const DevState &st, int64_t rob) {
+  using R = RobotFields;
+  constexpr int rpw = 64 / L;
+  auto rd = [&](int f) -> double & { return st.robd[rob_index(rob, f, rpw, R::COUNT)]; };
+  const Pose owpp{V3{rd(R::OWPP), rd(R::OWPP + 1), rd(R::OWPP + 2)}, Quat{rd(R::OWPP + 3), rd(R::OWPP + 4), rd(R::OWPP + 5), rd(R::OWPP + 6)}};
+  const Pose manual{V3{rd(R::MPOSE), rd(R::MPOSE + 1), rd(R::MPOSE + 2)}, Quat{rd(R::MPOSE + 3), rd(R::MPOSE + 4), rd(R::MPOSE + 5), rd(R::MPOSE + 6)}};
+  const Pose cp = add_pose(owpp, manual);
+  rd(R::CPOSE) = cp.p.x, rd(R::CPOSE + 1) = cp.p.y, rd(R::CPOSE + 2) = cp.p.z;
+  rd(R::CPOSE + 3) = cp.r.w, rd(R::CPOSE + 4) = cp.r.x, rd(R::CPOSE + 5) = cp.r.y, rd(R::CPOSE + 6) = cp.r.z;
+}
+
 // AdmittanceController::updateAdmittance for one leg (admittance_controller.cpp:22-63) as the posing part of a StateController
 // loop runs it before transitionRobotState / legStateToggle (state_controller.cpp:172-180); the robot is STOPPED on these paths,
 // so the dynamic stiffness update (:175) does not run.  Same arithmetic as the admittance block of the fused cycle.
@@ -114,6 +130,7 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
     return;
   }
   s.completed_sequence = 0;
+  standing_pose_prologue_dev<L>(st, rob);
   for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
   const bool start_up = sequence == 0;
   // Initialise / reset any saved transition sequence (:149-162)

@@ -10,6 +10,9 @@ from oracle_lib import OracleRobot
 from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
 from test_gpu_leg_api import same_pose, walking_pair
 
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT
+from test_gpu_teacher_forced import as_np, compare_records
+
 pytestmark = pytest.mark.gpu
 
 
@@ -186,6 +189,8 @@ def test_execute_sequence_start_up_shut_down_start_up(case, forced):
             d = float(np.abs(eng.joints()[0] - ob.joints()[0]).max())
             worst = max(worst, d)
             assert d < tol, (calls, d)
+            if forced:      # ... and every other field of the controller state record
+                compare_records(p, FEAT_DEFAULT, as_np(eng.get_state()), as_np(ob.get_state()), tol_q=1e-10)
             finished_at[(pe == 100) & (finished_at == 0)] = calls
             if (pe == 100).all():
                 ends.append(d)
