@@ -286,3 +286,56 @@ def test_plan_steps_with_manual_legs():
     from conftest import parity_report
     parity_report(f"[planner with manual legs] toggle / manipulate / plan steps on robots holding a MANUAL leg / toggle back: max |dq| = {worst:.2e} rad per call "
                   "(teacher-forced)")
+
+
+def test_plan_steps_free_running():
+    """The same calls without state injection on the 8 x 4 octopod (state the engine keeps to itself between calls is in play):
+    progress values and plan steps exactly, tips to 5 mm (standing robots: DESIGN.md section 2.1)."""
+    p = synthetic_octopod_params("ripple", 4, 8)
+    n, L, D = 6, 8, 4
+    rng = np.random.default_rng(61)
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    lin, ang = rng.uniform(-0.4, 0.4, (n, 2)), rng.uniform(-0.3, 0.3, n)
+    lin[0], ang[0] = 0.0, 0.0
+    for o in (eng, ob):
+        o.set_velocity(lin, ang)
+        o.step(45) if o is eng else o.step(45, 1)
+        o.set_planner_mode(True)
+
+    def until(value, limit=900):
+        done = np.zeros(n, dtype=bool)
+        for _ in range(limit):
+            (pe, se), (po, so) = eng.execute_plan(), ob.execute_plan()
+            assert np.array_equal(pe, po) and np.array_equal(se, so), (pe, po)
+            done |= pe == value
+            if done.all():
+                return se
+        raise AssertionError(pe)
+
+    until(WAITING)
+    cfg = ob.joints()[0].reshape(n, L, D) + rng.uniform(-0.1, 0.1, (n, L, D))
+    for o in (eng, ob):
+        o.set_target_configuration(cfg)
+    assert (until(100) == 1).all()
+    assert np.abs(eng.joints()[0] - cfg.reshape(n, -1)).max() < 1e-12
+    tips = ob.leg_state()["model_tip"].reshape(n, L, 3)
+    rows = (ExternalTarget * (n * L))()
+    for i in range(n):
+        for l in range(0, L, 2):
+            r = rows[i * L + l]
+            r.defined = 1
+            r.pose[0:3] = list(tips[i, l] + np.array([0.03, -0.02, 0.0]))
+            r.transform[:] = [0, 0, 0, 1, 0, 0, 0]
+            r.swing_clearance = 0.02
+    for o in (eng, ob):
+        assert o.set_external_target(rows) == 0
+        o.set_target_body_pose(np.tile(np.array([0.0, 0.008, 0.01, 1.0, 0, 0, 0]), (n, 1)))
+    assert (until(100) == 2).all()
+    eng.synchronize()
+    assert np.abs(eng.leg_state()["model_tip"] - ob.leg_state()["model_tip"]).max() < 5e-3
+    assert [r.defined for r in eng.get_external_target(which=2)] == [r.defined for r in ob.get_external_target(which=2)]
+    for o in (eng, ob):
+        o.set_planner_mode(False)
+        o.set_velocity(lin, ang + 0.2)
+        o.step(80) if o is eng else o.step(80, 1)
+    assert np.array_equal(eng.body_state()[2], ob.body_state()[2])
