@@ -295,3 +295,31 @@ def test_configuration_transition_trajectories(name):
         progress = ob.leg_transition_configuration(desired, transition_time)
         assert progress[leg] == int(row[0]), (call, progress[leg], row[0])
         assert np.abs(ob.joints()[0].reshape(6, 3)[leg] - row[1:]).max() < 1e-13
+
+
+@pytest.mark.parametrize("start", ["ready", "offset"])
+def test_startup_sequence_trajectories(start):
+    """PoseController::executeSequence (pose_controller.cpp:145-459) against the independent numpy restatement of
+    tests/golden/make_startup_golden.py: a first START_UP (learning its transition poses inside the joint-limit safety factor; from
+    the READY estimate, and from a configuration up to 0.25 rad away from it), SHUT_DOWN, START_UP again (replay) - every return
+    value exactly, joints to 1e-6 rad call by call."""
+    from oracle_lib import OracleBatch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "startup_golden.npz"))
+    pre = "" if start == "ready" else "offset/"
+    p = default_hexapod_params("tripod")
+    ob = OracleBatch(p, 1)
+    ob.begin_sequence_startup(None if start == "ready" else g[pre + "q0"], False)
+    assert np.abs(ob.joints()[0][0].reshape(6, 3) - g[pre + "q0"]).max() == 0.0
+    worst = 0.0
+    for name, which in (("startup_first", 0), ("shutdown", 1), ("startup_replay", 0)):
+        rows = g[pre + name]
+        for call, row in enumerate(rows):
+            r = int(ob.execute_sequence(which)[0])
+            assert r == int(row[0]), (name, call, r, row[0])
+            worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
+            # free-running through a slow body raise: the reference's IK step amplifies rounding differences there (DESIGN.md section
+            # 2.1); the READY start stays within 1e-6 rad, the offset start is given what a twin build of the oracle itself needs
+            assert worst < (1e-6 if start == "ready" else 1e-3), (name, call, worst)
+        assert int(rows[-1][0]) == 100
+    print(f"executeSequence from {start}: {sum(len(g[pre + k]) for k in ('startup_first', 'shutdown', 'startup_replay'))} calls, "
+          f"{int(g[pre + 'transition_steps'][0])} transition steps learnt, {int(g[pre + 'proximity_alerts'][0])} workspace alerts, max |joint diff| {worst:.2e} rad")
