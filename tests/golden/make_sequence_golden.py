@@ -69,7 +69,7 @@ class StepToPosition:
         self.leg_p, self.leg_q = np.array(origin_p, float), np.array(origin_q, float)   # the leg's current tip pose (FK)
         self.count = 0
 
-    def step(self, target_p, target_q, body_p, body_q, lift, time_to_step):
+    def step(self, target_p, target_q, body_p, body_q, lift, time_to_step, delta=None):
         if self.first:                                                # :1574-1579
             self.origin_p, self.origin_q = self.leg_p.copy(), self.leg_q.copy()
             self.count = 0
@@ -89,6 +89,8 @@ class StepToPosition:
         if not moving and not turning and lift == 0.0:                # :1601-1606
             self.first = True
             return 100, self.origin_p.copy(), rot(self.origin_q).apply(x)
+        if delta is not None:                                         # apply_delta and the leg is not manually manipulated (:1609-1614)
+            desired_p = desired_p + np.array(delta, float)
         self.count += 1                                               # :1615
         num = max(1, round_to_int(time_to_step / TIME_DELTA))
         dt = 1.0 / num

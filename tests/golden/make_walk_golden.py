@@ -332,6 +332,8 @@ class Leg:
         self.ext_target = None      # dict(pose=Pose, transform=Pose, clearance=float, odom_ideal=bool) while defined_
         self.ext_default = None
         self.touchdown_detection = False
+        self.leg_state = 0          # enum LegState: 0 WALKING, 1 MANUAL, -1 WALKING_TO_MANUAL, -2 MANUAL_TO_WALKING
+        self.desired_tip = None     # Leg::desired_tip_pose_.position_ of the last setDesiredTipPose
         self.step_plane = None      # Leg::step_plane_pose_.position_ while defined
         self.rot_defined = False    # current_tip_pose_.rotation_ != UNDEFINED_ROTATION (gravity-aligned tips, > 3 joints)
         self.cur_dir = self.origin_dir = self.model_dir = np.array([0.0, 0.0, -1.0])   # x axes of current / origin tip rotation, of the FK tip frame
@@ -368,6 +370,8 @@ class RefWalker:
         self.current_pose = Pose([0, 0, P["body_clearance"]])
         self.q = self.qd = None   # joint state [legs][3], for the scenarios that run the kinematic model
         self.manual_pose = Pose()
+        self.primary_leg = self.secondary_leg = -1
+        self.primary_velocity = self.secondary_velocity = self.primary_position = self.secondary_position = np.zeros(3)
         self.tip_align_pose, self.origin_tip_align_pose = Pose(), Pose()
         self.tvi, self.rvi = np.zeros(3), np.zeros(3)   # translation / rotation_velocity_input_ (rewritten by the reset modes)
         self.reset_mode = 0
@@ -571,6 +575,8 @@ class RefWalker:
         else:
             nv, nw = np.zeros(2), 0.0
         has_command = bool(norm) or bool(ang)
+        if any(leg.leg_state != 0 for leg in self.legs):      # "Check that all legs are in WALKING state" (:491-505): nothing below runs
+            return
         acc = nv - self.v
         if np.linalg.norm(acc) < mla * dt:
             self.v = self.v + acc
@@ -688,6 +694,25 @@ class RefWalker:
             self.auto_posing_state = POSING_COMPLETE
         return pose
 
+    def update_manual(self):   # WalkController::updateManual, tip_control: the velocity overload (:652-708) then the pose overload (:712-744)
+        P = self.P
+        for i, leg in enumerate(self.legs):
+            if leg.leg_state != 1:
+                continue
+            vel, pos = np.zeros(3), np.zeros(3)                # (a MANUAL leg that is neither selection reads an uninitialised vector in the reference)
+            if i == self.primary_leg:
+                vel, pos = self.primary_velocity, self.primary_position
+            elif i == self.secondary_leg:
+                vel, pos = self.secondary_velocity, self.secondary_position
+            if np.linalg.norm(vel) != 0.0:
+                ik_error = leg.desired_tip - leg.model_tip
+                change = vel * P["max_translation_velocity"] * self.dt
+                if np.linalg.norm(ik_error) >= 0.005:
+                    change = np.linalg.norm(change) * -(ik_error / np.linalg.norm(ik_error))
+                leg.tip = leg.tip + change
+            if np.linalg.norm(pos) != 0.0:
+                leg.tip = np.array(pos, dtype=float)
+
     def update_tip_align_pose(self):   # PoseController::updateTipAlignPose (:1024-1088): legs in id order, each on the pose the previous one left
         P = self.P
         for i, leg in enumerate(self.legs):
@@ -780,8 +805,8 @@ class RefWalker:
         corr[2] = rot_to_euler(self.manual_pose.r)[2]          # yaw of the target rotation (:1231)
         return Pose(None, euler_to_rot(corr))
 
-    def cycle(self, lin, ang):
-        """One StateController::loop with robot_state RUNNING (state_controller.cpp:162-193, 429-445)."""
+    def prologue(self):
+        """The posing / admittance part of StateController::loop (state_controller.cpp:165-181): returns (Model::current_pose_, admittance deltas)."""
         self.update_walk_plane_pose()
         pose = Pose().add(self.walk_plane_pose)
         if self.P.get("manual_posing"):
@@ -806,12 +831,23 @@ class RefWalker:
         if self.P.get("admittance_control") and self.q is not None:      # loop(): the admittance update precedes runningState
             src = self.tip_force_calc if self.P.get("use_joint_effort") else self.tip_force      # getTipForceCalculated / Measured (:30-31)
             adm = [admittance_delta(self.adm_state[i], src[i], tip_axis(i, self.q[i]), self.P) for i in range(self.L)]
+        return pose, adm
+
+    def cycle(self, lin, ang):
+        """One StateController::loop with robot_state RUNNING (state_controller.cpp:162-193, 429-445)."""
+        pose, adm = self.prologue()
         self.update_walk(lin, ang)
+        self.update_manual()
         if self.q is not None:   # PoseController::updateStance + Model::updateModel: tips as seen from the posed body, one IK step per leg
             for i, leg in enumerate(self.legs):
                 poser_tip = pose.r.inv().apply(leg.tip - pose.p)          # Pose::inverseTransformVector (pose_controller.cpp:122-131)
                 ddir = pose.r.inv().apply(leg.cur_dir) if leg.rot_defined else None   # pose.rotation^-1 * walker tip rotation (:129-130)
-                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + adm[i], self.dt, ddir)  # setDesiredTipPose(.., apply_delta)
+                delta = adm[i]
+                if leg.leg_state in (1, -1):                              # MANUAL / WALKING_TO_MANUAL: no posing (:134-137), no delta (model.cpp:655-656)
+                    poser_tip, ddir, delta = leg.tip.copy(), None, np.zeros(3)
+                leg.poser_tip = poser_tip
+                leg.desired_tip = poser_tip + delta
+                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + delta, self.dt, ddir)  # setDesiredTipPose(.., apply_delta)
                 leg.model_tip = fk_tip(i, self.q[i])                                                     # applyFK closes applyIK
                 leg.model_dir = tip_axis(i, self.q[i])
                 tip_force_estimate(i, self.q[i], self.efforts[i], self.tip_force_calc[i], self.P.get("force_gain", 0.1))   # ... and calculateTipForce

@@ -323,3 +323,37 @@ def test_startup_sequence_trajectories(start):
         assert int(rows[-1][0]) == 100
     print(f"executeSequence from {start}: {sum(len(g[pre + k]) for k in ('startup_first', 'shutdown', 'startup_replay'))} calls, "
           f"{int(g[pre + 'transition_steps'][0])} transition steps learnt, {int(g[pre + 'proximity_alerts'][0])} workspace alerts, max |joint diff| {worst:.2e} rad")
+
+
+def test_manual_leg_trajectories():
+    """Manual leg manipulation (legStateToggle, poseForLegManipulation, updateManual x 2, the manual-leg cases of updateStance /
+    setDesiredTipPose / stepToPosition) against the independent numpy restatement of tests/golden/make_manual_golden.py, loop by
+    loop: request results exactly; joints to 1e-6 rad while the robot walks, 5e-3 once it stands (free-running: the reference's
+    IK step amplifies rounding differences on a standing robot)."""
+    from oracle_lib import OracleBatch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manual_golden.npz"))
+    p = default_hexapod_params("tripod")
+    p.admittance_control = 1
+    ob = OracleBatch(p, 1)
+    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
+    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
+    worst_walk = worst_stand = 0.0
+    stood = False
+    for k, row in enumerate(g["loops"]):
+        kind, leg, result = int(row[0]), int(row[1]), int(row[2])
+        ob.set_velocity(row[3:5][None], row[5:6])
+        prim, sec = int(row[6]), int(row[13])
+        ob.set_manual_inputs(np.array([prim], dtype=np.int32), row[7:10][None], row[10:13][None], np.array([sec], dtype=np.int32), row[14:17][None], None)
+        if kind == 0:
+            ob.step(1, 1)
+        else:
+            assert int(ob.toggle_leg_state(np.array([leg], dtype=np.int32))[0]) == result, (k, leg, result)
+        d = np.abs(ob.joints()[0][0].reshape(6, 3) - g["joints"][k]).max()
+        stood = stood or ob.body_state()[2][0] == 3
+        if stood:
+            worst_stand = max(worst_stand, d)
+        else:
+            worst_walk = max(worst_walk, d)
+        assert worst_walk < 1e-6 and worst_stand < 5e-3, (k, kind, worst_walk, worst_stand)
+    assert ob.body_state()[2][0] != 3 and (ob.leg_manipulation_state() == 0).all()
+    print(f"manual legs: {len(g['loops'])} loops, max |joint diff| {worst_walk:.2e} rad walking, {worst_stand:.2e} rad after the first stop")
