@@ -15,8 +15,8 @@
  * (make_golden.py), the walking loop over hundreds of cycles incl. rough terrain mode's model-free branches and - for the
  * algorithm paths of BASELINE.json configs 2, 3 and 4 - the whole control cycle with the kinematic model, free-running
  * (make_walk_golden.py: oracle joints within 3e-10 rad), the LegPoser primitives behind sequences / leg manipulation / planner mode
- * (make_sequence_golden.py), the start-up / shut-down choreography (make_startup_golden.py) and manual leg manipulation
- * (make_manual_golden.py), (3) the reference's own runtime invariants (FK(IK(x)) within IK_TOLERANCE, C0/C1
+ * (make_sequence_golden.py), the start-up / shut-down choreography (make_startup_golden.py) manual leg manipulation
+ * (make_manual_golden.py) and planner mode (make_planner_golden.py), (3) the reference's own runtime invariants (FK(IK(x)) within IK_TOLERANCE, C0/C1
  * continuity of the swing/stance Beziers, sequences and plan steps reaching their goals; tests/test_oracle_invariants.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import, call, link or execute
