@@ -26,6 +26,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, os.path.dirname(HERE))
 
 
 def _load(name):
@@ -237,8 +238,49 @@ def run(offset=None):
     return out
 
 
+def run_new_stance():
+    """PoseController::stepToNewStance (src/pose_controller.cpp:521-557) on a robot that stands after its direct start-up: the two
+    leg groups step (with the swing height) onto their default tip poses one after the other, the body pose of stepToPosition
+    easing from the identity to Model::current_pose_."""
+    from oracle_lib import OracleRobot
+    from syropod_highlevel_controller_amd import default_hexapod_params
+    P = mw.hexapod("tripod", manual_posing=1)
+    mw.MODEL = mw.Morphology.default_hexapod()
+    w = mw.RefWalker(P, mw.limits_from_product("tripod"))
+    w.cycle((0.0, 0.0), 0.0)
+    q0, qd0 = OracleRobot(default_hexapod_params("tripod")).joints()      # DATA: the joint state after the direct start-up and the first loop
+    w.q, w.qd = q0.reshape(6, 3).copy(), qd0.reshape(6, 3).copy()
+    for i, leg in enumerate(w.legs):
+        leg.model_tip, leg.model_dir = mw.fk_tip(i, w.q[i]), mw.tip_axis(i, w.q[i])
+    w.efforts = np.zeros_like(w.q)
+    legs_completed, group, rows = 0, 0, []
+    stp = [None] * 6
+    for _ in range(2000):
+        pose, adm = w.prologue()
+        progress = 0
+        for i, leg in enumerate(w.legs):
+            if i % 2 != group:
+                continue
+            if stp[i] is None or stp[i].first:
+                sl = SeqLeg(i, w.q[i], (0.0, 0.0))
+                stp[i] = ms.StepToPosition(sl.tip(), sl.tip_quat())
+            q = pose.r.as_quat()
+            progress, tip, _ = stp[i].step(leg.default, None, pose.p, [q[3], q[0], q[1], q[2]], P["swing_height"], 1.0 / P["step_frequency"], adm[i])
+            w.q[i], w.qd[i] = mw.apply_ik(i, w.q[i], w.qd[i], tip + adm[i], w.dt)
+            legs_completed += int(progress == 100)
+        progress = progress // 2 + group * 50
+        group = legs_completed // 3
+        if legs_completed == 6:
+            legs_completed, group = 0, 0
+        rows.append([progress, *w.q.ravel()])
+        if len(rows) > 1 and progress == 100:
+            break
+    return {"new_stance/rows": np.array(rows), "new_stance/joint_start": np.stack([q0.reshape(6, 3), qd0.reshape(6, 3)])}
+
+
 if __name__ == "__main__":
     out = run()
+    out.update(run_new_stance())
     rng = np.random.default_rng(77)
     off = rng.uniform(-0.25, 0.25, (6, 3))
     for k, v in run(off).items():

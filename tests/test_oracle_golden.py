@@ -418,3 +418,18 @@ def test_planner_trajectories():
             worst_walk = max(worst_walk, d)
         assert worst_walk < 1e-8 and worst_stand < 5e-3, (k, worst_walk, worst_stand)
     print(f"planner: {len(g['rows'])} loops, final plan step {int(g['rows'][-1, 2])}, max |joint diff| {worst_walk:.2e} rad up to the crawl at the end of the first stance step, {worst_stand:.2e} rad after")
+
+
+def test_step_to_new_stance_trajectory():
+    """PoseController::stepToNewStance (pose_controller.cpp:521-557) against the independent restatement in
+    tests/golden/make_startup_golden.py: both leg groups step onto their default tip poses; return values exactly, joints free-running."""
+    from oracle_lib import OracleBatch
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "startup_golden.npz"))
+    ob = OracleBatch(default_hexapod_params("tripod"), 1)
+    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["new_stance/joint_start"]).max() < 1e-12
+    worst = 0.0
+    for call, row in enumerate(g["new_stance/rows"]):
+        assert int(ob.step_to_new_stance()[0]) == int(row[0]), call
+        worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
+        assert worst < 1e-6, (call, worst)
+    print(f"stepToNewStance: {len(g['new_stance/rows'])} calls, max |joint diff| {worst:.2e} rad")
