@@ -9,6 +9,7 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   WalkController::getLimit                 src/walk_controller.cpp:414-436
   WalkController::updateWalk (+ FSM)       src/walk_controller.cpp:440-648
   WalkController::updateWalkPlane          src/walk_controller.cpp:748-779
+  StateController::changeGait              src/state_controller.cpp:513-538   (stop the robot, then a new step cycle + limits)
   LegStepper (iteratePhase, updateStepState, updateStride, updateTipPosition, control nodes, updateDefaultTipPosition)
                                            src/walk_controller.cpp:871-1189, 1238-1329
     incl. the rough-terrain branches that do not need the kinematic model: default-tip update at every swing / stance
@@ -924,6 +925,8 @@ SCENARIOS = {
                                              [(0, (0.4, 0.2), 0.1), (330, (0, 0), 0.0)], 480),
     # gravity_aligned_tips on 3-joint legs: the experimental tip-align body pose
     "tripod_tip_align_pose": ("tripod", {"gravity_aligned_tips": 1, "model": 1}, [(0, (0.5, -0.1), 0.15), (280, (0, 0), 0.0)], 420),
+    # a gait change on the move: the robot is stopped, the step cycle, phase offsets and limit tables are regenerated, it walks on
+    "tripod_to_wave_gait_change": ("tripod", {"model": 1, "gait_change": "wave"}, [(0, (0.5, 0.1), 0.2), (330, (0.3, -0.2), -0.2)], 640),
     # the published per-leg virtual stiffness of dynamic_stiffness (swing legs soften, their neighbours stiffen)
     "ripple_dynamic_stiffness": ("ripple", {"admittance_control": 1, "dynamic_stiffness": 1, "model": 1}, [(0, (0.5, 0.1), 0.2), (200, (0, 0), 0.0)], 330),
     # the tip-force estimate in the loop: admittance driven by Leg::calculateTipForce from measured joint torques (a new sample every 10 cycles)
@@ -982,8 +985,9 @@ def run(name):
     w = RefWalker(P, limits)
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[])
+    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[], gait_request=[])
     events = rough_events(name, P)
+    gait_changed, meta_new_limits = False, {}
     lin, ang = (0.0, 0.0), 0.0
     w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
     start = None
@@ -1013,6 +1017,19 @@ def run(name):
         if (P.get("imu_posing") or P.get("inclination_posing")) and c % 25 == 0:  # a new IMU sample every 25 cycles
             e = [rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), 0.0]
             w.imu_q, w.gyro = euler_to_rot(e), rng.normal(0, 0.05, 3)
+        if over.get("gait_change") and c >= 160 and not gait_changed:   # gaitSelectionCallback at cycle 160; changeGait every loop until done
+            out["gait_request"].append(1)
+            if w.walk_state != STOPPED:
+                lin, ang = (0.0, 0.0), 0.0                                # "Stopping Syropod to change gait" (:531-536)
+            else:
+                from syropod_highlevel_controller_amd.params import GAITS
+                P.update(GAITS[over["gait_change"]])
+                w.limits = limits_from_product(over["gait_change"], morphology, **prod)   # DATA: generateLimits' tables for the new step cycle
+                w.step_cycle()
+                gait_changed = True
+                meta_new_limits.update(w.limits)
+        else:
+            out["gait_request"].append(0)
         for ec, kind, leg, v in events:          # callbacks arrive between loops; the tf refresh is the first thing a loop does
             if ec != c:
                 continue
@@ -1073,7 +1090,7 @@ def run(name):
         out["pose"].append(w.current_pose.as7())
     if morphology:
         over["morphology"] = morphology
-    meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events,
+    meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events, new_limits=meta_new_limits,
                 visited_walk_states=sorted(set(out["walk_state"])))
     arrays = {k: np.array(v) for k, v in out.items() if len(v)}
     if start is not None:

@@ -175,7 +175,7 @@ def test_walk_trajectories(name, meta):
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs"):
+        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs", "gait_change"):
             pass  # (default_hexapod_params already carries auto_pose.yaml; "model": the scenario also carries joints)
         else:
             setattr(p, k, v)
@@ -210,6 +210,9 @@ def test_walk_trajectories(name, meta):
                 r.set_pose_input(v[:3], v[3:])
             elif kind == "pose_reset_mode":
                 L.orc_set_pose_reset_mode(r.h, int(v[0]))
+        if "gait_request" in g and g["gait_request"][c]:   # gait_change_flag_ set: changeGait runs every loop until the robot has stopped
+            L.orc_change_gait.argtypes = [C.c_void_p, C.c_void_p]
+            L.orc_change_gait(r.h, C.byref(default_hexapod_params(meta["overrides"]["gait_change"])))
         r.set_velocity(float(g["lin"][c][0]), float(g["lin"][c][1]), float(g["ang"][c]))
         if p.imu_posing or p.inclination_posing:
             r.set_imu(g["imu_q"][c], g["gyro"][c])
