@@ -19,6 +19,7 @@
 //   Model::updateModel                  src/model.cpp:142  (Leg::setDesiredTipPose :653, Leg::applyIK :861)
 #pragma once
 
+#include "../../include/shc_batch.h"
 #include "shc_leg.hpp"
 
 namespace shc {

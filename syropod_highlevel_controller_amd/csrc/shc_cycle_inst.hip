@@ -1,0 +1,61 @@
+// shc_cycle_inst.hip - the fused cycle kernels of ONE morphology (compile with -DSHC_INST_L=<legs> -DSHC_INST_NJ=<joints>):
+// libshc_batch.so links one object of this file per supported (legs, joints), built in parallel (engine.py build_library).
+#include "shc_cycle_kernel.hpp"
+
+#if !defined(SHC_INST_L) || !defined(SHC_INST_NJ)
+#error "compile with -DSHC_INST_L=<legs> -DSHC_INST_NJ=<joints>"
+#endif
+
+namespace shc {
+
+template <int L, int NJ, unsigned F>
+static void launch_cycle(const CycleLaunch &a) {
+  constexpr int RPW = 64 / L;
+  constexpr size_t wave_bytes = size_t(RobotFields::COUNT * RPW + PK_COUNT * 64 + (RobotFields::I_COUNT * RPW + 1) / 2) * 8;
+  shc_cycle_kernel<L, NJ, F><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, a.n_cycles,
+                                                                                              a.rt_flags);
+}
+
+// Pick the kernel specialisation: the BASELINE.json configurations get feature-exact kernels (dead features cost
+// neither registers nor HBM traffic); every other flag combination runs the generic kernel (F_DYN).
+template <int L, int NJ, bool SPEC>
+static void launch_cycle_feat(const CycleLaunch &a) {
+  const CycleParams &c = *a.cp;
+  unsigned f = (c.manual_posing ? F_MANUAL : 0) | (c.auto_posing ? F_AUTO : 0) | (c.inclination_posing ? F_INCL : 0) |
+               (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0) | (c.odometry ? F_ODOM : 0);
+  // rough terrain mode / the tip-align pose: generic kernels with that logic compiled in (kept out of the plain generic
+  // kernel, which would otherwise spill)
+  const bool terrain = c.rough_terrain || c.tip_align || (a.rt_flags & RT_MANUAL_LEGS) != 0;
+  if constexpr (NJ > 3) {
+    if (c.gravity_aligned) { // gravity-aligned tips: the generic kernel with the tip-rotation logic compiled in
+      if (terrain) launch_cycle<L, NJ, F_DYN | F_ROT | F_TERRAIN>(a);
+      else launch_cycle<L, NJ, F_DYN | F_ROT>(a);
+      return;
+    }
+  }
+  if (terrain) {
+    launch_cycle<L, NJ, F_DYN | F_TERRAIN>(a);
+    return;
+  }
+  if constexpr (SPEC) {
+    constexpr unsigned C2 = F_MANUAL | F_ODOM, C3 = F_MANUAL | F_IMU | F_ADM | F_ODOM; // BASELINE.json configs 2/4 and 3
+    if (!a.generic) switch (f) {
+      case C2 | F_TIPF: launch_cycle<L, NJ, C2 | F_TIPF>(a); return;
+      case C2: launch_cycle<L, NJ, C2>(a); return;
+      case C3 | F_TIPF: launch_cycle<L, NJ, C3 | F_TIPF>(a); return;
+      case C3: launch_cycle<L, NJ, C3>(a); return;
+      default: break;
+    }
+  }
+  launch_cycle<L, NJ, F_DYN>(a);
+}
+
+#define SHC_CAT3(a, b, c) a##b##_##c
+#define SHC_LAUNCHER_NAME(L_, NJ_) SHC_CAT3(shc_launch_cycle_, L_, NJ_)
+void SHC_LAUNCHER_NAME(SHC_INST_L, SHC_INST_NJ)(const CycleLaunch &a) {
+  // feature-exact kernels for the BASELINE.json morphologies: default.yaml hexapods (6 x 3) and the synthetic octopods (8 x 5)
+  constexpr bool spec = (SHC_INST_L == 6 && SHC_INST_NJ == 3) || (SHC_INST_L == 8 && SHC_INST_NJ == 5);
+  launch_cycle_feat<SHC_INST_L, SHC_INST_NJ, spec>(a);
+}
+
+} // namespace shc

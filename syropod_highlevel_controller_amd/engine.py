@@ -51,44 +51,110 @@ class ShcError(RuntimeError):
     pass
 
 
+MORPHOLOGIES = [(3, 3), (4, 3), (4, 4), (4, 5), (5, 3), (6, 3), (6, 4), (6, 5), (7, 3), (8, 3), (8, 4), (8, 5)]  # SHC_FOR_EACH_MORPHOLOGY
+_OBJ = os.path.join(_HERE, "_build")
+
+
 def _sources():
     out = [os.path.join(_SRC, f) for f in sorted(os.listdir(_SRC)) if f.endswith((".hip", ".hpp"))]
     out.append(os.path.join(_INC, "shc_batch.h"))
     return out
 
 
-_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+# -disable-machine-licm: MachineLICM hoists the materialisation of ~100 FP64 literals (polynomial coefficients of
+# sincos / atan2, tolerances) out of the n_cycles loop and pins them in VGPRs for the whole launch (256 VGPRs + scratch
+# spills); re-materialising them at use keeps the hexapod kernel free of scratch.
+# -amdgpu-sched-strategy=max-ilp: at one or two waves per SIMD the cycle is bound by dependent-issue latency (FP64
+# dependent ops issue every 8 clocks, LDS reads return after ~60); the ILP-first scheduler spends the spare VGPRs
+# (the occupancy target of 2 waves/SIMD allows 256) on overlapping independent chains.
+_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
           "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+
+
+def _translation_units():
+    """(object name, source, extra defines): the host side + small kernels, and the fused cycle kernels of each morphology."""
+    tus = [("shc_engine.o", os.path.join(_SRC, "shc_engine.hip"), [])]
+    for l, nj in MORPHOLOGIES:
+        tus.append((f"shc_cycle_{l}_{nj}.o", os.path.join(_SRC, "shc_cycle_inst.hip"), [f"-DSHC_INST_L={l}", f"-DSHC_INST_NJ={nj}"]))
+    return tus
 
 
 def _source_hash() -> str:
     """Content hash of everything the library is built from (sources, ABI header, flags).  A hash, not mtimes: the in-tree
     .so travels to the GPU box in a snapshot that does not keep modification times."""
     import hashlib
-    h = hashlib.sha256(" ".join(_FLAGS).encode())
+    h = hashlib.sha256((" ".join(_FLAGS) + repr(MORPHOLOGIES)).encode())
     for s in _sources():
         with open(s, "rb") as f:
             h.update(f.read())
     return h.hexdigest()
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/shc_engine.hip for gfx950 into libshc_batch.so (in-tree) unless the existing library was built from
-    exactly these sources.  hipcc cross-compiles without a GPU."""
+def _tu_hash(src: str, defines) -> str:
+    """Hash of what one object depends on: its source, every header (a header change rebuilds everything), flags, defines."""
+    import hashlib
+    h = hashlib.sha256((" ".join(_FLAGS + list(defines))).encode())
+    for s in _sources():
+        if s.endswith((".hpp", ".h")) or s == src:
+            with open(s, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def build_library(force: bool = False, verbose: bool = False, jobs: Optional[int] = None, resource_report: Optional[str] = None) -> str:
+    """Compile the library for gfx950 (in-tree libshc_batch.so) unless the existing one was built from exactly these sources:
+    one object per translation unit (host side; the cycle kernels of each morphology) compiled in parallel, objects whose
+    inputs did not change are reused.  hipcc cross-compiles without a GPU.  resource_report: a file that receives hipcc's
+    -Rpass-analysis=kernel-resource-usage remarks (scripts/regs.py reads it)."""
     stamp = _SO + ".srchash"
     want = _source_hash()
-    if not force and os.path.exists(_SO) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+    have_stamp = os.path.exists(stamp) and open(stamp).read().strip() == want
+    if not force and os.path.exists(_SO) and have_stamp:
         return _SO
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -disable-machine-licm: MachineLICM hoists the materialisation of ~100 FP64 literals (polynomial coefficients of
-    # sincos / atan2, tolerances) out of the n_cycles loop and pins them in VGPRs for the whole launch (256 VGPRs + scratch
-    # spills); re-materialising them at use keeps the hexapod kernel free of scratch (DESIGN.md section 4.1).
-    # -amdgpu-sched-strategy=max-ilp: at one or two waves per SIMD the cycle is bound by dependent-issue latency (FP64
-    # dependent ops issue every 8 clocks, LDS reads return after ~60); the ILP-first scheduler spends the spare VGPRs
-    # (the occupancy target of 2 waves/SIMD allows 256) on overlapping independent chains.
-    cmd = [hipcc] + _FLAGS + ["-o", _SO, os.path.join(_SRC, "shc_engine.hip")]
+    import shutil
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        if os.path.exists(_SO):  # a prebuilt library on a host without the compiler: the sizeof checks in lib() guard ABI drift
+            import warnings
+            warnings.warn("libshc_batch.so carries no matching source stamp and hipcc is not available: loading it as it is")
+            return _SO
+        raise FileNotFoundError(f"{_SO} is missing and {hipcc} is not available to build it")
+    os.makedirs(_OBJ, exist_ok=True)
+    from concurrent.futures import ThreadPoolExecutor
+    todo, objs = [], []
+    for name, src, defines in _translation_units():
+        obj = os.path.join(_OBJ, name)
+        objs.append(obj)
+        th = _tu_hash(src, defines)
+        ostamp = obj + ".srchash"
+        if force or resource_report or not (os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == th):
+            todo.append((obj, src, defines, th))
+
+    def compile_one(job):
+        obj, src, defines, th = job
+        cmd = [hipcc] + _FLAGS + list(defines) + ["-c", "-o", obj, src]
+        if resource_report:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd, r.stdout, r.stderr[-4000:])
+        with open(obj + ".srchash", "w") as f:
+            f.write(th + "\n")
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=jobs or min(len(todo) or 1, os.cpu_count() or 1)) as ex:
+        try:
+            reports = list(ex.map(compile_one, todo))
+        except subprocess.CalledProcessError as e:
+            raise RuntimeError(f"hipcc failed: {' '.join(e.cmd)}\n{e.stderr}") from None
+    if resource_report:
+        with open(resource_report, "w") as f:
+            f.write("".join(reports))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", _SO] + objs
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     with open(stamp, "w") as f:
         f.write(want + "\n")
