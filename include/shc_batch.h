@@ -41,9 +41,12 @@ enum {
   SHC_ERR_HIP = 3,
   SHC_ERR_UNSUPPORTED = 4,    /* outside the accelerated path: legs of different DOF in one engine, rough terrain with a stance
                                  span modifier, a requested tip rotation on > 3-DOF legs, sequences with own-clock auto posing */
-  SHC_ERR_UNSTABLE = 5        /* reserved: the reference aborts when the IMU correction's norm exceeds 100 rad
+  SHC_ERR_UNSTABLE = 5,       /* reserved: the reference aborts when the IMU correction's norm exceeds 100 rad
                                  (pose_controller.cpp:1228-1232); after its own clamps (:1222-1226) that needs
                                  max_rotation > 100 rad, so no entry point returns this code today */
+  SHC_ERR_BUSY = 6,           /* the engine is in resident mode (shc_engine_resident_begin): only the shc_engine_resident_*
+                                 calls, shc_engine_instances and shc_engine_get_tables are valid until shc_engine_resident_end */
+  SHC_ERR_TIMEOUT = 7         /* a bounded wait ran out (resident mode: the device loop stopped by itself or did not answer) */
 };
 
 /* parameters_and_states.h:99 */
@@ -236,6 +239,72 @@ int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode, int on_de
  */
 int shc_engine_step(shc_engine *e, int n_cycles);
 int shc_engine_synchronize(shc_engine *e);
+
+/*
+ * Resident mode: the node's control loop kept on the chip.
+ *
+ * The reference runs `while (ros::ok()) { state.loop(); ...publish...; ros::spinOnce(); rate.sleep(); }` (src/main.cpp:106-131):
+ * every iteration takes whatever the callbacks delivered since the last one (velocity :1127, body pose :1142, IMU :1552, joint
+ * states :1566, tip states :1618 of src/state_controller.cpp), runs one control cycle (StateController::loop :162-193) and
+ * publishes the desired joint state (:777-805).  shc_engine_step is one iteration per kernel launch: at batch sizes that fit the
+ * chip once (<= 8 wavefronts per compute unit, e.g. up to ~20 000 hexapods on one MI355X) launch + state load + state store cost
+ * as much as the cycle itself.  In resident mode ONE launch stays on the device for up to `max_cycles` iterations; per-leg state
+ * lives in registers and per-robot state in LDS from one cycle to the next, and every iteration
+ *   - waits for the loop tick: a cycle counter ("doorbell") that shc_engine_resident_publish advances,
+ *   - takes the inputs posted for that cycle (shc_engine_resident_post; groups that were not posted keep their last value,
+ *     exactly like a callback that did not fire), and
+ *   - writes that cycle's desired joint positions and velocities to an output ring (shc_engine_resident_get_joint_state).
+ * Results are bit-identical to the same cycles run through shc_engine_step(e, 1) with the same inputs set in between.
+ *
+ *   shc_engine_resident_begin(e, ring_depth, max_cycles, idle_timeout_ms)
+ *       starts the loop on the engine's stream.  ring_depth (2..255): input sets that may be posted ahead of the cycle that
+ *       consumes them = cycles whose outputs stay readable; max_cycles (1..2^31-2): hard bound of this launch; idle_timeout_ms
+ *       (0 = 2 000): the device loop stops by itself when the doorbell has not moved for this long (a host that went away cannot
+ *       leave the GPU spinning; every device-side wait is bounded).  SHC_ERR_UNSUPPORTED: the batch does not fit the chip once, or
+ *       the configuration runs on a rough-terrain / manual-leg / tip-rotation kernel.  Until shc_engine_resident_end every other
+ *       entry point that touches the engine's state returns SHC_ERR_BUSY.
+ *   shc_engine_resident_post(e, inputs, cycle)
+ *       the inputs "the callbacks delivered" for the next unposted cycle (*cycle receives its index, counted from 0 at begin):
+ *       arrays as for shc_engine_set_velocity / set_imu / set_pose_input / set_pose_reset_mode / set_tip_force /
+ *       set_joint_effort, NULL = not received this iteration.  linear_xy + angular, the two IMU arrays and the two pose arrays are
+ *       posted in pairs.  Joint efforts / pose inputs can only be posted to an engine that was given one (shc_engine_set_joint_effort /
+ *       shc_engine_set_pose_input) before shc_engine_resident_begin - the first one selects the kernels that evaluate them.
+ *       Asynchronous (an internal input stream); blocks only when ring_depth input sets of a group are still waiting to be consumed.
+ *       Posting does not release the cycle: shc_engine_resident_publish does.
+ *   shc_engine_resident_publish(e, n_cycles)
+ *       moves the doorbell: the device may run n_cycles more iterations (cycles nothing was posted for run with the inputs held).
+ *   shc_engine_resident_wait(e, cycles, timeout_ms)
+ *       returns once `cycles` iterations have completed on every instance and their outputs are visible (SHC_ERR_TIMEOUT otherwise).
+ *   shc_engine_resident_get_joint_state(e, cycle, q, qd, on_device)
+ *       desired joint positions / velocities [n][legs][dof] of iteration `cycle` (completed, and at most ring_depth - 1 iterations
+ *       older than the newest published one) - what publishDesiredJointState sends after that loop iteration.
+ *   shc_engine_resident_status(e, published, completed, running)
+ *   shc_engine_resident_end(e, cycles_run)
+ *       stops the loop after the published cycles, waits for it, and leaves the engine exactly as the same cycles through
+ *       shc_engine_step would have (state planes, held inputs).  SHC_ERR_TIMEOUT: the loop had already stopped by itself
+ *       (idle timeout / max_cycles) - the state is that of *cycles_run iterations, consistent across instances.
+ */
+typedef struct shc_cycle_inputs {
+  const double *linear_xy;                  /* [n][2]            velocity command (state_controller.cpp:1127) */
+  const double *angular;                    /* [n]                                                            */
+  const double *imu_orientation_wxyz;       /* [n][4]            sensor_msgs/Imu (:1552), normalised on entry */
+  const double *imu_angular_velocity;       /* [n][3]                                                         */
+  const double *pose_translation_velocity;  /* [n][3]            body pose input (:1142)                      */
+  const double *pose_rotation_velocity;     /* [n][3]                                                         */
+  const int32_t *pose_reset_mode;           /* [n]               SHC_NO_RESET ..                              */
+  const double *tip_force;                  /* [n][legs][3]      tip wrench (:1618)                           */
+  const double *joint_effort;               /* [n][legs][dof]    joint states (:1566)                         */
+  int32_t on_device;                        /* the arrays are device pointers                                 */
+  int32_t reserved;
+} shc_cycle_inputs;
+enum { SHC_RESIDENT_RUNNING = 0, SHC_RESIDENT_STOPPED = 1, SHC_RESIDENT_IDLE_TIMEOUT = 2, SHC_RESIDENT_MAX_CYCLES = 3, SHC_RESIDENT_FAULT = 4 };
+int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t max_cycles, int idle_timeout_ms);
+int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *inputs, int64_t *cycle);
+int shc_engine_resident_publish(shc_engine *e, int64_t n_cycles);
+int shc_engine_resident_wait(shc_engine *e, int64_t cycles, int timeout_ms);
+int shc_engine_resident_get_joint_state(shc_engine *e, int64_t cycle, double *q, double *qd, int on_device);
+int shc_engine_resident_status(shc_engine *e, int64_t *published, int64_t *completed, int32_t *running);
+int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run);
 
 /*
  * Outputs read after the cycle (state_controller.cpp:777-805 publishDesiredJointState).

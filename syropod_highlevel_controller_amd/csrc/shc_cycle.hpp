@@ -341,11 +341,38 @@ __device__ __forceinline__ int bearing_bracket(double y, double x) {
   return xr < 0.0 ? (ay < ax ? 4 : 5) : (ay > ax ? 6 : 7);
 }
 
+// Where a cycle reads its per-leg inputs from (tip_force_measured_, Joint::current_effort_).
+// LegInPlanes: the engine's own state planes - one launch = n cycles with the inputs held (L2-resident across the cycles).
+template <int NJ>
+struct LegInPlanes {
+  const double *legd;
+  int64_t ns;
+  uint32_t slot;
+  __device__ __forceinline__ V3 force() const {
+    const double2 f01 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2) * ns + slot];
+    const double2 f2_ = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2 + 1) * ns + slot];
+    return V3{f01.x, f01.y, f2_.x};
+  }
+  __device__ __forceinline__ void effort(double (&e)[NJ]) const {
+#pragma unroll
+    for (int i = 0; i < NJ; i += 2) {
+      const double2 e2 = reinterpret_cast<const double2 *>(legd)[((Fields<NJ>::EFFORT_IN + i) / 2) * ns + slot];
+      e[i] = e2.x;
+      if (i + 1 < NJ) e[i + 1] = e2.y;
+    }
+  }
+};
+// A hook the resident kernel runs between PoseController::updateStance and Model::updateModel (shc_cycle_kernel.hpp); nothing here.
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+
 // ------------------------------------------------------------------------------------------------- one control cycle
-template <int L, int NJ, unsigned F>
+template <int L, int NJ, unsigned F, typename IN = LegInPlanes<NJ>, typename MID = NoHook>
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                       const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
-                                      const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr) {
+                                      const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
+                                      const MID &mid = MID()) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
@@ -722,10 +749,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       }
       s.stiff = v;
     }
-    // tip_force_measured_ is an input held in HBM (L2-resident across the cycles of one launch)
-    const double2 f01 = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2) * ns + slot];
-    const double2 f2_ = reinterpret_cast<const double2 *>(legd)[(Fields<NJ>::FORCE_IN / 2 + 1) * ns + slot];
-    V3 force_in{f01.x, f01.y, f2_.x};
+    const V3 force_in = in.force(); // tip_force_measured_
     V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
     double fi[3] = {f.x, f.y, f.z}, d[3];
 #pragma unroll
@@ -1198,6 +1222,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
   }
 
   SHC_PHASE_FENCE();
+  mid();
   // =============================================================== Model::updateModel (model.cpp:142-152)
   {
     SHC_TICK(9);
@@ -1274,12 +1299,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) s.word |= LW_IKFAIL; // :916-929
     if (FT::tipf(P)) { // Leg::calculateTipForce (:667-708)
       double effort[NJ];
-#pragma unroll
-      for (int i = 0; i < NJ; i += 2) { // Joint::current_effort_ input
-        const double2 e2 = reinterpret_cast<const double2 *>(legd)[((Fields<NJ>::EFFORT_IN + i) / 2) * ns + slot];
-        effort[i] = e2.x;
-        if (i + 1 < NJ) effort[i + 1] = e2.y;
-      }
+      in.effort(effort); // Joint::current_effort_ input
       V3 raw = tip_force_cols<NJ>(lc, chain, lin, effort);
       s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
       if (rot_on && retried) s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);

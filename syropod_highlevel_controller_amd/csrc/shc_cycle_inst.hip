@@ -12,6 +12,24 @@ template <int L, int NJ, unsigned F>
 static void launch_cycle(const CycleLaunch &a) {
   constexpr int RPW = 64 / L;
   constexpr size_t wave_bytes = size_t(RobotFields::COUNT * RPW + PK_COUNT * 64 + (RobotFields::I_COUNT * RPW + 1) / 2) * 8;
+  if (a.fit || a.resident) {
+    // resident kernels exist for the specialisations without rough terrain / manual legs / tip rotations (those read and
+    // write side records in HBM every cycle and the rotation kernels do not fit two waves per SIMD)
+    if constexpr ((F & (F_TERRAIN | F_ROT)) == 0) {
+      if (a.fit) {
+        a.fit->supported = 1;
+        int blocks = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, shc_resident_kernel<L, NJ, F>, 64, wave_bytes) != hipSuccess) blocks = 0;
+        a.fit->blocks_per_cu = blocks;
+      } else {
+        shc_resident_kernel<L, NJ, F><<<dim3(a.grid), dim3(64), wave_bytes, a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
+      }
+    } else if (a.fit) {
+      a.fit->supported = 0;
+      a.fit->blocks_per_cu = 0;
+    }
+    return;
+  }
   shc_cycle_kernel<L, NJ, F><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, a.n_cycles,
                                                                                               a.rt_flags);
 }

@@ -180,10 +180,277 @@ __device__ __forceinline__ void store_rob_fields(const double *tile, double *gti
   }
 }
 
-// One launch = n_cycles control cycles of every robot; per-leg state stays in registers, per-robot state in LDS.
+// ================================================================================================= resident mode
+// StateController::loop's while-loop (src/main.cpp:106-131: loop(); publish...; spinOnce(); rate.sleep()) kept on the chip.
+// Protocol (shc_cycle_launch.hpp): the relay wave mirrors the host's doorbell / stop words into ResidentCtl::gate and the
+// workers' progress back to the host; a worker runs cycle c while c < min(doorbell, stop), takes what was posted for cycle c
+// (header ring -> fresh input groups in the data rings), writes q / qd of the cycle to the output ring (write-through), and
+// publishes "c cycles done" one half cycle later, when those stores have certainly drained.  Every wait is bounded.
+typedef unsigned long long u64;
+__device__ __forceinline__ u64 ld_agent(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 ld_sys(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void st_sys(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double ld_agent_f64(const double *p) { return __longlong_as_double((long long)ld_agent(reinterpret_cast<const u64 *>(p))); }
+// a value every lane holds alike, moved to SGPRs so that branches on it are scalar branches
+__device__ __forceinline__ u64 uni64(u64 v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(v)), hi = __builtin_amdgcn_readfirstlane(unsigned(v >> 32));
+  return (u64(hi) << 32) | lo;
+}
+
+// per-leg inputs of a resident cycle: the paired planes that currently hold them (a ring position, or the engine's own planes while
+// nothing has been posted), read with agent-scope loads - another agent may have written them while this kernel runs
+template <int NJ>
+struct LegInRing {
+  const double *force_planes, *effort_planes;
+  int64_t ns;
+  uint32_t slot;
+  __device__ __forceinline__ V3 force() const {
+    const double *p = force_planes + int64_t(slot) * 2;
+    return V3{ld_agent_f64(p), ld_agent_f64(p + 1), ld_agent_f64(p + ns * 2)};
+  }
+  __device__ __forceinline__ void effort(double (&e)[NJ]) const {
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) e[i] = ld_agent_f64(effort_planes + (int64_t(i / 2) * ns + slot) * 2 + (i & 1));
+  }
+};
+
+struct ResidentHeld { // what the worker remembers between the loop and the epilogue (all wave-uniform)
+  int src_force = -1, src_effort = -1; // ring position of the per-leg inputs in force; -1: the engine's own planes
+  unsigned seen = 0;                   // input groups that were posted during this run
+  unsigned cycles = 0;
+  bool fault = false;
+};
+
+template <int RPW, int NF>
+__device__ __forceinline__ void ring_to_tile(const double *rec, double *tile_at, int lane) {
+  constexpr int total = NF * RPW;
+#pragma unroll
+  for (int it = 0; it * 64 < total; ++it) {
+    const int i = it * 64 + lane;
+    if (i < total) tile_at[i] = ld_agent_f64(rec + i);
+  }
+}
+
 template <int L, int NJ, unsigned F>
-__global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles,
-                                                                                             unsigned rt_flags) {
+__device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevState &st, LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C,
+                                              const RobTile<64 / L> &rb, const Park &pk, const Group<L> g, const int leg, const uint32_t slot,
+                                              const int lane, const int64_t wave, const bool live, double *tile, int32_t *tile_i, unsigned &dirty,
+                                              const bool manual_live, ResidentHeld &held) {
+  using R = RobotFields;
+  using FD = Fields<NJ>;
+  constexpr int RPW = 64 / L;
+  const int64_t ns = st.n_slots;
+  const unsigned out_slot_bytes = unsigned(NJ * ns * 16); // q, qd = fields [0, 2 NJ) = NJ paired planes
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
+  const u64 emergency_ticks = 4 * A.idle_ticks + 200000000ull; // a worker never waits longer than this for the relay (2 s + 4 idle timeouts)
+  unsigned c = 0, oslot = 0; // cycles completed; output ring position of cycle c
+  u64 gate = uni64(ld_agent(&A.ctl->gate));
+  u64 h0 = 0, h1 = 0;
+  bool hdr_valid = false;
+  for (;;) {
+    unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
+    if (!(c < db && c < sp)) {
+      if (c >= sp) break;
+      const u64 t0 = wall_clock64();
+      for (;;) {
+        __builtin_amdgcn_s_sleep(4);
+        gate = uni64(ld_agent(&A.ctl->gate));
+        db = unsigned(gate), sp = unsigned(gate >> 32);
+        if (c >= sp || c < db) break;
+        if (wall_clock64() - t0 > emergency_ticks) {
+          held.fault = true;
+          break;
+        }
+      }
+      if (held.fault || c >= sp) break;
+      hdr_valid = false;
+    }
+    // what was posted for cycle c
+    if (!hdr_valid) {
+      const u64 *hp = reinterpret_cast<const u64 *>(A.headers + (c & (kResidentHeaders - 1)));
+      h0 = uni64(ld_agent(hp));
+      h1 = uni64(ld_agent(hp + 1));
+    }
+    // prefetch for the next iteration: the gate, and - once the doorbell is known to cover it - the header of cycle c + 1
+    const u64 gate_next_v = ld_agent(&A.ctl->gate);
+    const bool next_valid = db > c + 1;
+    u64 n0v = 0, n1v = 0;
+    if (next_valid) {
+      const u64 *hp = reinterpret_cast<const u64 *>(A.headers + ((c + 1) & (kResidentHeaders - 1)));
+      n0v = ld_agent(hp);
+      n1v = ld_agent(hp + 1);
+    }
+    if (h0 == u64(c) + 1) { // fresh input groups: robot inputs go to the LDS tile, per-leg inputs are read where they lie
+      const unsigned mask = unsigned(h1) & 0xffffu;
+      held.seen |= mask;
+      auto pos = [&](int grp) { return int((h1 >> (16 + 8 * grp)) & 0xff); };
+      if (mask & (1u << RG_VEL))
+        ring_to_tile<RPW, 3>(A.rin + ((int64_t(pos(RG_VEL)) * A.n_waves + wave) * RIN_COUNT + RIN_VEL) * RPW, tile + R::VIN * RPW, lane);
+      if (mask & (1u << RG_IMU)) {
+        const double *rec = A.rin + ((int64_t(pos(RG_IMU)) * A.n_waves + wave) * RIN_COUNT + RIN_IMU) * RPW;
+        ring_to_tile<RPW, 4>(rec, tile + R::IMUQ * RPW, lane);
+        ring_to_tile<RPW, 3>(rec + 4 * RPW, tile + R::GYRO * RPW, lane);
+      }
+      if (mask & (1u << RG_POSE)) {
+        static_assert(R::RVI == R::TVI + 3, "pose inputs are contiguous in the tile");
+        ring_to_tile<RPW, 6>(A.rin + ((int64_t(pos(RG_POSE)) * A.n_waves + wave) * RIN_COUNT + RIN_POSE) * RPW, tile + R::TVI * RPW, lane);
+        dirty |= DIRTY_MANUAL;
+      }
+      if (mask & (1u << RG_RESET)) {
+        if (lane < RPW)
+          tile_i[R::I_RESET_MODE * RPW + lane] = int(unsigned(ld_agent(reinterpret_cast<const u64 *>(A.rini) + ((int64_t(pos(RG_RESET)) * A.n_waves + wave) * RPW + lane))));
+        dirty |= DIRTY_MANUAL;
+      }
+      if (mask & (1u << RG_FORCE)) held.src_force = pos(RG_FORCE);
+      if (mask & (1u << RG_EFFORT)) held.src_effort = pos(RG_EFFORT);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier(); // LDS operations of one wave complete in order: the tile now holds the new inputs
+    }
+    const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
+                           held.src_effort < 0 ? st.legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2,
+                           ns, slot};
+    // half a cycle after the output stores of cycle c - 1 were issued they have drained: publish "c cycles done"
+    const auto publish_previous = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) st_agent(A.progress + wave, u64(c));
+    };
+    cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr, in, publish_previous);
+    { // desired joint state of this cycle -> output ring (write-through 16-byte stores: visible to any agent once drained)
+      typedef unsigned v4u __attribute__((ext_vector_type(4)));
+      double flat[2 * NJ];
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) flat[FD::Q + i] = s.q[i], flat[FD::QD + i] = s.qd[i];
+      const unsigned soff = oslot * out_slot_bytes;
+      if (live) {
+#pragma unroll
+        for (int p = 0; p < NJ; ++p) {
+          const u64 a = u64(__double_as_longlong(flat[2 * p])), b = u64(__double_as_longlong(flat[2 * p + 1]));
+          const v4u w = {unsigned(a), unsigned(a >> 32), unsigned(b), unsigned(b >> 32)};
+          __builtin_amdgcn_raw_buffer_store_b128(w, out_rsrc, unsigned((int64_t(p) * ns + slot) * 16), soff, 16 /* sc1 */);
+        }
+      }
+    }
+    ++c;
+    oslot = oslot + 1 == unsigned(A.depth) ? 0 : oslot + 1;
+    gate = uni64(gate_next_v);
+    hdr_valid = next_valid;
+    if (next_valid) h0 = uni64(n0v), h1 = uni64(n1v);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) st_agent(A.progress + wave, u64(c));
+  held.cycles = c;
+}
+
+// After the loop: the inputs the run received become the engine's held inputs (the next ordinary launch reads them from the
+// state planes), and the wave reports that it has left.
+template <int L, int NJ, unsigned F>
+__device__ __forceinline__ void resident_epilogue(const ResidentArgs &A, const DevState &st, const uint32_t slot, const int lane, const bool live,
+                                                  const double *tile, const int32_t *tile_i, double *gtile, int32_t *gtile_i, const ResidentHeld &held) {
+  using R = RobotFields;
+  using FD = Fields<NJ>;
+  constexpr int RPW = 64 / L;
+  const int64_t ns = st.n_slots;
+  store_rob_fields<RPW, R::VIN, R::CORE_END>(tile, gtile, lane);
+  if (held.seen & (1u << RG_IMU)) {
+    store_rob_fields<RPW, R::GYRO, R::IMU_END>(tile, gtile, lane);
+    store_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(tile, gtile, lane);
+  }
+  if ((held.seen & (1u << RG_RESET)) && lane < RPW) gtile_i[R::I_RESET_MODE * RPW + lane] = tile_i[R::I_RESET_MODE * RPW + lane];
+  if (live) {
+    double2 *planes = reinterpret_cast<double2 *>(st.legd);
+    if (held.src_force >= 0) {
+      const double *src = A.force + int64_t(held.src_force) * 2 * ns * 2;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+        planes[(FD::FORCE_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
+    }
+    if (held.src_effort >= 0) {
+      const double *src = A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2;
+#pragma unroll
+      for (int p = 0; p < FD::NJE / 2; ++p)
+        planes[(FD::EFFORT_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
+    }
+  }
+  if (lane == 0) {
+    if (held.fault) __hip_atomic_fetch_or(&A.ctl->fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&A.ctl->exited, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// The relay: one wave between the host and the workers.  It alone reads / writes the host-mapped words (a handful of PCIe
+// transactions per microsecond instead of one per worker and cycle), it alone writes the gate - so "doorbell" and "stop" change
+// together, atomically, and every worker leaves the loop at the same cycle - and it alone decides to stop: on request, at the
+// launch's cycle bound, or when the doorbell has not moved for idle_ticks (a host that went away cannot leave the GPU spinning).
+__device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
+  const int lane = threadIdx.x;
+  const unsigned max_cycles = A.max_cycles;
+  unsigned db = 0, sp = max_cycles, idle_stop = 0xffffffffu;
+  u64 reason = RESIDENT_EXIT_MAX, last_gate = ~0ull, last_done = 0, iter = 0;
+  u64 t_last = wall_clock64(), t_all_done = 0;
+  for (;;) {
+    const u64 hd = uni64(ld_sys(&A.host->doorbell)), hs = uni64(ld_sys(&A.host->stop));
+    const u64 now = wall_clock64();
+    unsigned want_db = hd > max_cycles ? max_cycles : unsigned(hd);
+    if (want_db < db) want_db = db; // the doorbell only moves forward
+    if (want_db != db) t_last = now;
+    else if (idle_stop == 0xffffffffu && now - t_last > A.idle_ticks) idle_stop = db;
+    unsigned want_sp = max_cycles;
+    u64 why = RESIDENT_EXIT_MAX;
+    if (hs < max_cycles) want_sp = unsigned(hs), why = RESIDENT_EXIT_STOP;
+    if (idle_stop < want_sp) want_sp = idle_stop, why = RESIDENT_EXIT_IDLE;
+    if (want_sp < db) want_sp = db; // cycles already released run
+    if (want_db > want_sp) want_db = want_sp;
+    db = want_db, sp = want_sp, reason = why;
+    const u64 gate = (u64(sp) << 32) | db;
+    if (gate != last_gate) {
+      if (lane == 0) st_agent(&A.ctl->gate, gate);
+      last_gate = gate;
+    }
+    // cycles completed by every worker wave
+    u64 m = ~0ull;
+    for (int64_t w = lane; w < A.n_waves; w += 64) {
+      const u64 v = ld_agent(A.progress + w);
+      m = v < m ? v : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const u64 o = __shfl_xor(m, off, 64);
+      m = o < m ? o : m;
+    }
+    m = uni64(m);
+    if (m != last_done) {
+      if (lane == 0) st_sys(&A.host->done, m);
+      last_done = m;
+    }
+    const u64 exited = uni64(ld_agent(&A.ctl->exited));
+    const u64 fault = uni64(ld_agent(&A.ctl->fault));
+    bool leave = exited == u64(A.n_waves);
+    if (!leave && m >= sp) { // everything that will ever run has run: the workers are on their way out
+      if (t_all_done == 0) t_all_done = now;
+      else if (now - t_all_done > 500000000ull) leave = true, reason = RESIDENT_EXIT_FAULT; // 5 s: give up on them
+    }
+    if (leave) {
+      if (lane == 0) {
+        st_sys(&A.host->fault, fault);
+        st_sys(&A.host->done, m);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_sys(&A.host->exited, fault ? u64(RESIDENT_EXIT_FAULT) : reason);
+      }
+      break;
+    }
+    if ((++iter & 1023) == 0 && lane == 0) st_sys(&A.host->heartbeat, iter);
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// One launch = n_cycles control cycles of every robot; per-leg state stays in registers, per-robot state in LDS.
+// The work of one wavefront: load its robots, run cycles, store them.  RES = false: n_cycles cycles with the inputs held (one
+// ordinary launch).  RES = true: the resident loop (resident_loop below) - cycles run as the doorbell allows, inputs from the
+// rings, outputs to the ring, until the relay says stop.
+template <int L, int NJ, unsigned F, bool RES>
+__device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConsts<L, NJ> *gc, int n_cycles, unsigned rt_flags, const int64_t wave,
+                                           const ResidentArgs *ra) {
   using R = RobotFields;
   using FT = Feat<F>;
   constexpr int RPW = 64 / L; // robots per wavefront
@@ -204,7 +471,6 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   const bool touchdown_detection = (rt_flags & RT_TOUCHDOWN) != 0;
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  const int64_t wave = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
   const int64_t rob0 = wave * RPW;
   const int64_t left = st.n_robots - rob0;
   const int robots_here = left < RPW ? (left < 0 ? 0 : int(left)) : RPW;
@@ -322,9 +588,14 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   double *const ext = ((F & F_TERRAIN) != 0 && (rt_flags & RT_EXTERNAL) != 0) ? st.ext : nullptr; // external targets (rough terrain mode)
   const ManualRobot *const mr = ((F & F_TERRAIN) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0 && any_robot) ? st.manual + (rob0 + grp) : nullptr;
   const bool skip = skip_marked && mr != nullptr && mr->skip_cycle != 0; // (uniform over the lanes of a robot)
-  if (!skip)
+  ResidentHeld held;
+  if constexpr (RES) {
+    resident_loop<L, NJ, F>(*ra, st, s, out, C, rb, pk, g, leg, slot, lane, wave, live, tile, tile_i, dirty, manual_live, held);
+  } else if (!skip) {
     for (int c = 0; c < n_cycles; ++c)
-      cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr);
+      cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
+                      LegInPlanes<NJ>{st.legd, st.n_slots, slot});
+  }
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
@@ -346,7 +617,25 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
   if ((F & F_TERRAIN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
   static_assert((R::I_POSE_PHASE + 1) * RPW <= 64, "the written-back int fields (word, poser latches, pose phase) fit one wave-wide store");
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
+  if constexpr (RES) resident_epilogue<L, NJ, F>(*ra, st, slot, lane, live, tile, tile_i, gtile, gtile_i, held);
   SHC_TICK(14);
+}
+
+template <int L, int NJ, unsigned F>
+__global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles,
+                                                                                             unsigned rt_flags) {
+  cycle_wave<L, NJ, F, false>(st, gc, n_cycles, rt_flags, (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nullptr);
+}
+
+// Resident launch: block 0 is the relay (host <-> device handshake), block 1 + w is worker wave w; 64 threads each, every block
+// co-resident (the host checks the grid against the occupancy of this kernel before launching).
+template <int L, int NJ, unsigned F>
+__global__ void __launch_bounds__(64, SHC_WAVES_PER_SIMD) shc_resident_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
+  if (blockIdx.x == 0) {
+    resident_relay(ra);
+    return;
+  }
+  cycle_wave<L, NJ, F, true>(st, gc, 0, rt_flags, int64_t(blockIdx.x) - 1, &ra);
 }
 
 } // namespace shc

@@ -9,7 +9,55 @@
 
 namespace shc {
 
+// ---- resident mode: StateController::loop's while-loop (src/main.cpp:106-131) kept on the chip.  The cycle kernel stays resident
+//      (one wave per SIMD slot), per-leg state in registers and per-robot state in LDS across cycles; every cycle it waits for the
+//      loop tick (a doorbell the host or a producer advances), takes the inputs the "callbacks" of that iteration delivered from
+//      device-side rings, and writes the desired joint state of that cycle to an output ring.
+enum : int { RG_VEL = 0, RG_IMU = 1, RG_POSE = 2, RG_RESET = 3, RG_FORCE = 4, RG_EFFORT = 5, RG_COUNT = 6 }; // input groups
+// robot-input ring record: fields in this order, [position][wave][field][robots-per-wave]
+enum : int { RIN_VEL = 0, RIN_IMU = 3, RIN_POSE = 10, RIN_COUNT = 16 }; // v(2) w(1) | quat(4) gyro(3) | tvi(3) rvi(3)
+
+struct ResidentCtl { // device memory, polled with agent-scope loads; written by the relay wave only (exited: atomic, workers)
+  unsigned long long gate;      // (stop << 32) | doorbell: run cycle c (counted from resident_begin) while c < min(doorbell, stop)
+  unsigned long long exited;    // worker waves that have left the loop
+  unsigned long long fault;     // != 0: a worker gave up waiting (emergency bound) - state may be inconsistent
+  unsigned long long pad;
+};
+struct ResidentHost { // pinned host memory mapped into the device (fine-grained): the host side of the handshake
+  unsigned long long doorbell;  // host / producer -> device: cycles published since resident_begin
+  unsigned long long stop;      // host -> device: stop after this many cycles (~0ull = keep running)
+  unsigned long long done;      // device -> host: cycles completed by every wave, outputs visible
+  unsigned long long exited;    // device -> host: 0 running | SHC_RESIDENT_* exit reason
+  unsigned long long heartbeat; // device -> host: relay iterations (diagnostic)
+  unsigned long long fault;
+};
+struct ResidentHeader { // one per cycle (ring of kResidentHeaders), written by shc_engine_resident_post before the doorbell moves
+  unsigned long long tag;  // cycle + 1; any other value: nothing was posted for this cycle (inputs held)
+  unsigned short mask;     // bit g: group g is fresh this cycle
+  unsigned char pos[RG_COUNT]; // ring position of each fresh group's data
+};
+static_assert(sizeof(ResidentHeader) == 16, "header is read as two 8-byte words");
+constexpr int kResidentHeaders = 1024;
+enum : unsigned long long { RESIDENT_EXIT_STOP = 1, RESIDENT_EXIT_IDLE = 2, RESIDENT_EXIT_MAX = 3, RESIDENT_EXIT_FAULT = 4 };
+
+struct ResidentArgs {
+  ResidentCtl *ctl;
+  ResidentHost *host;
+  unsigned long long *progress; // [n_waves] cycles completed by wave w (its outputs are visible)
+  const ResidentHeader *headers; // [kResidentHeaders]
+  const double *rin;    // [depth][n_waves][RIN_COUNT][RPW]
+  const int32_t *rini;  // [depth][n_waves][RPW] reset modes
+  const double *force;  // [depth][2 planes][n_slots] double2 (as Fields::FORCE_IN)
+  const double *effort; // [depth][NJE / 2 planes][n_slots] double2 (as Fields::EFFORT_IN)
+  double *out;          // [depth][NJ planes][n_slots] double2: q, qd of every cycle (fields [0, 2 NJ) of the leg state)
+  int depth;
+  unsigned max_cycles;              // hard bound of this launch
+  unsigned long long idle_ticks;    // 100 MHz wall-clock ticks without a new doorbell value before the relay stops the loop
+  int64_t n_waves;
+};
+
 // Everything a launch of the cycle kernel needs from the engine.
+struct ResidentFit;
 struct CycleLaunch {
   DevState st;
   const void *consts;     // SharedConsts<L, NJ> in HBM
@@ -20,6 +68,12 @@ struct CycleLaunch {
   unsigned grid;
   int block;
   int n_cycles;
+  const ResidentArgs *resident; // != nullptr: launch the resident kernel (grid = n_waves + 1 relay block, 64 threads each)
+  struct ResidentFit *fit;      // != nullptr: launch nothing, report whether / how densely the resident kernel of this specialisation fits
+};
+struct ResidentFit {
+  int supported;          // this specialisation has a resident kernel
+  int blocks_per_cu;      // hipOccupancyMaxActiveBlocksPerMultiprocessor of it (64-thread blocks with its per-wave LDS)
 };
 
 // One per (legs, joints); defined by shc_cycle_inst.hip.  Returns false when that morphology has no kernels in this build.

@@ -264,7 +264,17 @@ struct shc_engine {
   int pack_step, executing_transition, transition_calls; // PoseController::pack_step_ / executing_transition_ (pose_controller.h:294, :298)
   bool planner_mode = false;            // StateController::planner_mode_ (state_controller.h:337)
   bool plan_poser_tips_current = false; // no control cycle has run since the last shc_engine_execute_plan (SeqRobotState::poser_tip_from_plan holds)
+  struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
 };
+struct Resident;
+static bool resident_active(const shc_engine *e);
+static void resident_shutdown(shc_engine *e); // stop a running resident loop and free its buffers (shc_engine_destroy)
+// While the resident kernel owns the engine's stream and state, every other entry point that would touch them is refused.
+#define SHC_BUSY_GUARD(e)                                                                                                      \
+  do {                                                                                                                         \
+    if ((e) && resident_active(e))                                                                                             \
+      return fail(SHC_ERR_BUSY, "the engine is in resident mode: only shc_engine_resident_* calls are valid until shc_engine_resident_end"); \
+  } while (0)
 
 template <int L, int NJ>
 static void build_shared_consts(const shc_params &p, const shc_tables &t, const CycleParams &cp, SharedConsts<L, NJ> &c) {
@@ -832,6 +842,7 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
 extern "C" int shc_engine_destroy(shc_engine *e) {
   if (!e) return SHC_OK;
   (void)hipSetDevice(e->device);
+  resident_shutdown(e);
   (void)hipFree(e->st.legd);
   (void)hipFree(e->st.legi);
   (void)hipFree(e->st.robd);
@@ -846,12 +857,14 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
 }
 
 extern "C" int shc_engine_set_stream(shc_engine *e, void *stream) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   e->stream = (hipStream_t)stream;
   return SHC_OK;
 }
 
 extern "C" int shc_engine_set_features(shc_engine *e, uint32_t features) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   e->features = features;
   build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
@@ -935,6 +948,7 @@ static int derive_tips(shc_engine *e);
 #define LEG_FIELD(e, NAME) ((e)->NJ == 3 ? Fields<3>::NAME : ((e)->NJ == 4 ? Fields<4>::NAME : Fields<5>::NAME))
 
 extern "C" int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, const double *angular, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = scatter_rob(e, linear_xy, 2, RobotFields::VIN, on_device);
   if (rc != SHC_OK) return rc;
@@ -942,6 +956,7 @@ extern "C" int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, c
 }
 
 extern "C" int shc_engine_set_imu(shc_engine *e, const double *orientation_wxyz, const double *angular_velocity, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = scatter_rob(e, orientation_wxyz, 4, RobotFields::IMUQ, on_device, 1);
   if (rc != SHC_OK) return rc;
@@ -973,6 +988,7 @@ __global__ void touchdown_detection_kernel(DevState st, const SharedConsts<L, NJ
 }
 
 extern "C" int shc_engine_set_tip_force(shc_engine *e, const double *tip_force, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = scatter_leg(e, tip_force, 3, LEG_FIELD(e, FORCE_IN), on_device);
   if (rc != SHC_OK || !tip_force) return rc;
@@ -998,6 +1014,7 @@ static int effort_live(shc_engine *e) {
 }
 
 extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (joint_effort) { // Leg::calculateTipForce has something to filter from now on
     const int rc = effort_live(e);
@@ -1008,6 +1025,7 @@ extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_ef
 
 extern "C" int shc_engine_set_pose_input(shc_engine *e, const double *translation_velocity, const double *rotation_velocity,
                                          int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (translation_velocity || rotation_velocity) e->rt_flags |= RT_MANUAL_LIVE;
   int rc = scatter_rob(e, translation_velocity, 3, RobotFields::TVI, on_device);
@@ -1016,6 +1034,7 @@ extern "C" int shc_engine_set_pose_input(shc_engine *e, const double *translatio
 }
 
 extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (!mode) return SHC_OK;
   e->rt_flags |= RT_MANUAL_LIVE;
@@ -1033,6 +1052,7 @@ extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode
 }
 
 extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
@@ -1045,7 +1065,7 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   const int block = e->n_waves < 1536 ? 64 : 128;
   const int64_t waves_per_block = block / 64;
   const unsigned grid = (unsigned)((e->n_waves + waves_per_block - 1) / waves_per_block);
-  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, grid, block, n_cycles};
+  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, grid, block, n_cycles, nullptr, nullptr};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
@@ -1054,13 +1074,23 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
 }
 
 extern "C" int shc_engine_synchronize(shc_engine *e) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return SHC_OK;
 }
 
+#include "shc_resident.hpp" // resident mode: the control loop kept on the chip (shc_engine_resident_*)
+static bool resident_active(const shc_engine *e) { return e->res && e->res->active; }
+static void resident_shutdown(shc_engine *e) {
+  if (e->res && e->res->active) (void)shc_engine_resident_end(e, nullptr);
+  resident_free(e->res);
+  e->res = nullptr;
+}
+
 extern "C" int shc_engine_get_joint_state(shc_engine *e, double *q, double *qd, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = gather_leg(e, q, e->NJ, LEG_FIELD(e, Q), on_device);
   if (rc != SHC_OK) return rc;
@@ -1068,6 +1098,7 @@ extern "C" int shc_engine_get_joint_state(shc_engine *e, double *q, double *qd, 
 }
 
 extern "C" int shc_engine_joint_buffer(shc_engine *e, double **device_ptr, int64_t *n_doubles) {
+  SHC_BUSY_GUARD(e);
   if (!e || !device_ptr || !n_doubles) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   *device_ptr = e->st.legd; // fields Q (and, for odd DOF, the first QD) occupy the first ceil(NJ / 2) paired planes of the leg state
   *n_doubles = int64_t((e->NJ + 1) / 2) * e->n_slots * 2;
@@ -1084,6 +1115,7 @@ extern "C" int64_t shc_engine_joint_index(const shc_engine *e, int64_t instance,
 
 extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, double *poser_tip, double *model_tip, double *tip_force,
                                         double *admittance, int32_t *leg_status, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc;
   if ((rc = gather_leg(e, walker_tip, 3, LEG_FIELD(e, TIP), on_device)) != SHC_OK) return rc;
@@ -1107,6 +1139,7 @@ extern "C" int shc_engine_get_leg_state(shc_engine *e, double *walker_tip, doubl
 }
 
 extern "C" int shc_engine_change_gait(shc_engine *e, const shc_params *ng, int64_t *still_walking) {
+  SHC_BUSY_GUARD(e);
   if (!e || !ng) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(e->device));
   const unsigned grid = (unsigned)((e->n + 255) / 256);
@@ -1163,6 +1196,7 @@ extern "C" int shc_engine_change_gait(shc_engine *e, const shc_params *ng, int64
 }
 
 extern "C" int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (!e->cp.odometry) return fail(SHC_ERR_UNSUPPORTED, "SHC_FEAT_ODOMETRY is off");
   if (!pose) return SHC_OK;
@@ -1178,6 +1212,7 @@ extern "C" int shc_engine_get_odometry(shc_engine *e, double *pose, int on_devic
 }
 
 extern "C" int shc_engine_get_virtual_stiffness(shc_engine *e, double *stiffness, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (!e->params.admittance_control) return fail(SHC_ERR_UNSUPPORTED, "admittance_control is off: updateStiffness never runs");
   return gather_leg(e, stiffness, 1, LEG_FIELD(e, ADM_DELTA) + 3, on_device);
@@ -1260,6 +1295,7 @@ static Pose host_fk_tip_pose(const shc_params &p, int leg, const double *q) {
 }
 
 extern "C" int shc_engine_read_leg_state_msg(shc_engine *e, int64_t instance, shc_leg_state_msg *legs) {
+  SHC_BUSY_GUARD(e);
   if (!e || !legs) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   if (instance < 0 || instance >= e->n) return fail(SHC_ERR_INVALID_ARG, "instance out of range");
   int rc = derive_tips(e);
@@ -1398,6 +1434,7 @@ static int upload_offsets(shc_engine *e, const double **d_off) {
 }
 
 extern "C" int shc_engine_set_joint_states_msg(shc_engine *e, const double *position, const double * /*velocity*/, const double *effort, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   HIP_TRY(hipSetDevice(e->device));
   int rc = SHC_OK;
@@ -1416,6 +1453,7 @@ extern "C" int shc_engine_set_joint_states_msg(shc_engine *e, const double *posi
 }
 
 extern "C" int shc_engine_set_tip_states_msg(shc_engine *e, const double *wrench_force, const double *step_plane, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = SHC_OK;
   if (wrench_force && (rc = shc_engine_set_tip_force(e, wrench_force, on_device)) != SHC_OK) return rc;
@@ -1537,6 +1575,7 @@ static int external_write(shc_engine *e, int which, int64_t first, int64_t count
 
 extern "C" int shc_engine_set_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, const shc_external_target *rows,
                                               int64_t *ignored) {
+  SHC_BUSY_GUARD(e);
   int64_t n_rows = 0;
   int rc = external_select(e, which, first, count, leg, &n_rows);
   if (rc != SHC_OK) return rc;
@@ -1560,6 +1599,7 @@ extern "C" int shc_engine_set_external_target(shc_engine *e, int which, int64_t 
 }
 
 extern "C" int shc_engine_set_external_transform(shc_engine *e, int which, int64_t first, int64_t count, int leg, const double *transform) {
+  SHC_BUSY_GUARD(e);
   int64_t n_rows = 0;
   int rc = external_select(e, which, first, count, leg, &n_rows);
   if (rc != SHC_OK) return rc;
@@ -1572,6 +1612,7 @@ extern "C" int shc_engine_set_external_transform(shc_engine *e, int which, int64
 }
 
 extern "C" int shc_engine_get_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, shc_external_target *rows) {
+  SHC_BUSY_GUARD(e);
   int64_t n_rows = 0;
   int rc = external_select(e, which, first, count, leg, &n_rows);
   if (rc != SHC_OK) return rc;
@@ -1596,6 +1637,7 @@ extern "C" int shc_engine_get_external_target(shc_engine *e, int which, int64_t 
 }
 
 extern "C" int shc_engine_get_joint_commands(shc_engine *e, double *position, double *velocity, double *effort, double *position_command, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   HIP_TRY(hipSetDevice(e->device));
   const double *d_off;
@@ -1693,6 +1735,7 @@ static int leg_dispatch(shc_engine *e, Fn &&fn) {
 
 extern "C" int shc_leg_set_desired_tip_pose(shc_engine *e, int64_t first, int64_t count, int leg, const double *tip_pose, int apply_delta,
                                             int on_device) {
+  SHC_BUSY_GUARD(e);
   LegCall c;
   int rc = c.init(e, first, count, leg);
   if (rc != SHC_OK) return rc;
@@ -1705,6 +1748,7 @@ extern "C" int shc_leg_set_desired_tip_pose(shc_engine *e, int64_t first, int64_
 
 extern "C" int shc_leg_solve_ik(shc_engine *e, int64_t first, int64_t count, int leg, const double *delta, int solve_rotation,
                                 double *joint_delta, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!delta || !joint_delta) return fail(SHC_ERR_INVALID_ARG, "delta / joint_delta is NULL");
   LegCall c;
   int rc = c.init(e, first, count, leg);
@@ -1718,6 +1762,7 @@ extern "C" int shc_leg_solve_ik(shc_engine *e, int64_t first, int64_t count, int
 
 extern "C" int shc_leg_update_joint_positions(shc_engine *e, int64_t first, int64_t count, int leg, const double *joint_delta, int simulation,
                                               double *limit_proximity, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!joint_delta) return fail(SHC_ERR_INVALID_ARG, "joint_delta is NULL");
   LegCall c;
   int rc = c.init(e, first, count, leg);
@@ -1732,6 +1777,7 @@ extern "C" int shc_leg_update_joint_positions(shc_engine *e, int64_t first, int6
 }
 
 extern "C" int shc_leg_apply_ik(shc_engine *e, int64_t first, int64_t count, int leg, int simulation, double *ik_result, int on_device) {
+  SHC_BUSY_GUARD(e);
   LegCall c;
   int rc = c.init(e, first, count, leg);
   if (rc != SHC_OK) return rc;
@@ -1745,6 +1791,7 @@ extern "C" int shc_leg_apply_ik(shc_engine *e, int64_t first, int64_t count, int
 
 extern "C" int shc_leg_apply_fk(shc_engine *e, int64_t first, int64_t count, int leg, const double *joint_position, double *tip_pose,
                                 int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!tip_pose) return fail(SHC_ERR_INVALID_ARG, "tip_pose is NULL");
   LegCall c;
   int rc = c.init(e, first, count, leg);
@@ -1759,6 +1806,7 @@ extern "C" int shc_leg_apply_fk(shc_engine *e, int64_t first, int64_t count, int
 // ---- sequences
 extern "C" int shc_leg_step_to_position(shc_engine *e, int64_t first, int64_t count, int leg, const double *target_tip_pose, const double *target_pose,
                                         double lift_height, double time_to_step, int apply_delta, double *tip_pose, int32_t *progress, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!target_pose || !tip_pose) return fail(SHC_ERR_INVALID_ARG, "target_pose / tip_pose is NULL");
   if (!(time_to_step >= 0.0)) return fail(SHC_ERR_INVALID_ARG, "time_to_step must be >= 0");
   LegCall c;
@@ -1787,6 +1835,7 @@ extern "C" int shc_leg_step_to_position(shc_engine *e, int64_t first, int64_t co
 
 extern "C" int shc_leg_transition_configuration(shc_engine *e, int64_t first, int64_t count, int leg, const double *desired_configuration,
                                                 double transition_time, int32_t *progress, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!desired_configuration) return fail(SHC_ERR_INVALID_ARG, "desired_configuration is NULL");
   LegCall c;
   int rc = c.init(e, first, count, leg);
@@ -1832,6 +1881,7 @@ __global__ void restore_joints_kernel(DevState st, const double2 *saved_planes, 
 }
 
 extern "C" int shc_engine_begin_direct_startup(shc_engine *e) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = init_state(e);
   if (rc != SHC_OK) return rc;
@@ -1854,6 +1904,7 @@ extern "C" int shc_engine_begin_direct_startup(shc_engine *e) {
 }
 
 extern "C" int shc_engine_direct_startup(shc_engine *e, int32_t *progress) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (!e->starting_up) return fail(SHC_ERR_INVALID_ARG, "call shc_engine_begin_direct_startup first");
   HIP_TRY(hipSetDevice(e->device));
@@ -1901,6 +1952,7 @@ __global__ void set_joint_positions_kernel(DevState st, const double *q, int per
 }
 
 extern "C" int shc_engine_begin_sequence_startup(shc_engine *e, const double *joint_positions, int per_instance) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (e->params.auto_posing && e->params.pose_frequency != -1.0)
     return fail(SHC_ERR_UNSUPPORTED, "sequences with auto posing on its own clock (the body pose would move during the sequence)");
@@ -1951,6 +2003,7 @@ static SeqParams seq_params(const shc_engine *e) {
 }
 
 static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(START_UP / SHUT_DOWN), 2: stepToNewStance */, int32_t *progress) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = ensure_seq(e);
   if (rc != SHC_OK) return rc;
@@ -1973,6 +2026,7 @@ static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(ST
 }
 
 extern "C" int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t *progress) {
+  SHC_BUSY_GUARD(e);
   if (sequence != SHC_SEQUENCE_START_UP && sequence != SHC_SEQUENCE_SHUT_DOWN) return fail(SHC_ERR_INVALID_ARG, "sequence must be SHC_SEQUENCE_START_UP or SHC_SEQUENCE_SHUT_DOWN");
   return sequence_launch(e, sequence, progress);
 }
@@ -2009,6 +2063,7 @@ static int ensure_manual(shc_engine *e, bool planner = false) {
 }
 
 extern "C" int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_selection, int32_t *result) {
+  SHC_BUSY_GUARD(e);
   int rc = ensure_manual(e);
   if (rc != SHC_OK) return rc;
   if (!leg_selection) return fail(SHC_ERR_INVALID_ARG, "leg_selection is NULL");
@@ -2040,6 +2095,7 @@ extern "C" int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_sel
 
 extern "C" int shc_engine_set_manual_inputs(shc_engine *e, const int32_t *primary_leg, const double *primary_tip_velocity, const double *primary_tip_position,
                                             const int32_t *secondary_leg, const double *secondary_tip_velocity, const double *secondary_tip_position) {
+  SHC_BUSY_GUARD(e);
   int rc = ensure_manual(e);
   if (rc != SHC_OK) return rc;
   // staging layout: [primary leg | secondary leg] ints, then four [n][3] double blocks
@@ -2063,6 +2119,7 @@ extern "C" int shc_engine_set_manual_inputs(shc_engine *e, const int32_t *primar
 }
 
 extern "C" int shc_engine_get_leg_manipulation_state(shc_engine *e, int32_t *states) {
+  SHC_BUSY_GUARD(e);
   if (!e || !states) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(e->device));
   int32_t *d = reinterpret_cast<int32_t *>(e->d_stage);
@@ -2107,21 +2164,25 @@ static int plan_inputs(shc_engine *e, int64_t first, int64_t count, int reset_pl
 }
 
 extern "C" int shc_engine_set_planner_mode(shc_engine *e, int on) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if ((on != 0) == e->planner_mode) return SHC_OK; // plannerModeCallback acts on a change only (state_controller.cpp:1267)
   e->planner_mode = on != 0;
   return on ? plan_inputs(e, 0, e->n, 1, nullptr, nullptr) : SHC_OK; // plan_step_ = 0 (:1273)
 }
 extern "C" int shc_engine_set_target_configuration(shc_engine *e, int64_t first, int64_t count, const double *configuration) {
+  SHC_BUSY_GUARD(e);
   if (!e || !configuration) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   return plan_inputs(e, first, count, 0, configuration, nullptr);
 }
 extern "C" int shc_engine_set_target_body_pose(shc_engine *e, int64_t first, int64_t count, const double *pose) {
+  SHC_BUSY_GUARD(e);
   if (!e || !pose) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   return plan_inputs(e, first, count, 0, nullptr, pose);
 }
 
 extern "C" int shc_engine_execute_plan(shc_engine *e, int32_t *progress, int32_t *plan_step) {
+  SHC_BUSY_GUARD(e);
   int rc = ensure_planner(e);
   if (rc != SHC_OK) return rc;
   int32_t *d_progress = reinterpret_cast<int32_t *>(e->d_stage), *d_step = d_progress + e->n, *d_walking = d_step + e->n;
@@ -2201,10 +2262,12 @@ static int pack_transition(shc_engine *e, const double *packed_positions, int n_
 }
 
 extern "C" int shc_engine_pack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_pack, int32_t *progress) {
+  SHC_BUSY_GUARD(e);
   return pack_transition(e, packed_positions, n_pack_steps, time_to_pack, false, progress);
 }
 
 extern "C" int shc_engine_unpack_legs(shc_engine *e, const double *packed_positions, int n_pack_steps, double time_to_unpack, int32_t *progress) {
+  SHC_BUSY_GUARD(e);
   return pack_transition(e, packed_positions, n_pack_steps, time_to_unpack, true, progress);
 }
 
@@ -2214,6 +2277,7 @@ __global__ void copy_joint_planes_kernel(double2 *dst, const double2 *src, int64
 }
 
 extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   HIP_TRY(hipSetDevice(e->device));
   // Model::updateDefaultConfiguration + generateWorkspaces + generateWalkspace (state_controller.cpp:307-310): the tables of an
@@ -2305,15 +2369,18 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
   return SHC_OK;
 }
 extern "C" int shc_engine_get_state(shc_engine *e, int64_t first, int64_t count, shc_instance_state *states) {
+  SHC_BUSY_GUARD(e);
   if (!states) return fail(SHC_ERR_INVALID_ARG, "states is NULL");
   return state_transfer(e, first, count, states, nullptr);
 }
 extern "C" int shc_engine_set_state(shc_engine *e, int64_t first, int64_t count, const shc_instance_state *states) {
+  SHC_BUSY_GUARD(e);
   if (!states) return fail(SHC_ERR_INVALID_ARG, "states is NULL");
   return state_transfer(e, first, count, nullptr, states);
 }
 
 extern "C" int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int32_t *walk_state, int on_device) {
+  SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc;
   if ((rc = gather_rob(e, pose, 7, RobotFields::CPOSE, on_device)) != SHC_OK) return rc;

@@ -1,0 +1,440 @@
+// shc_resident.hpp - host side of resident mode (include/shc_batch.h: shc_engine_resident_*): the node's control loop
+// (src/main.cpp:106-131 around StateController::loop, src/state_controller.cpp:162-193) kept on the chip.  Included by
+// shc_engine.hip; the device side (worker loop, relay) is in shc_cycle_kernel.hpp, the protocol in shc_cycle_launch.hpp.
+//
+// Buffers (all device memory unless noted):
+//   ResidentHost (pinned host memory, device-mapped)  doorbell / stop / done / exited - the only words that cross PCIe, read and
+//                                                     written on the device by the relay wave alone
+//   ResidentCtl, progress[n_waves], headers[1024]     relay <-> workers
+//   rin / rini / force / effort [ring_depth][...]     input data rings, one position per POSTED set of a group (not per cycle):
+//                                                     a group that is not posted costs nothing and its last data stays where it is
+//   out [ring_depth][dof planes][n_slots]             q, qd of the last ring_depth cycles, in the engine's plane layout
+
+struct Resident {
+  bool active = false;
+  int depth = 0;
+  ResidentArgs args{};
+  ResidentHost *host = nullptr;     // pinned host memory
+  ResidentHost *host_dev = nullptr; // the device's address of it
+  ResidentCtl *ctl = nullptr;
+  unsigned long long *progress = nullptr;
+  ResidentHeader *headers = nullptr;
+  double *rin = nullptr, *force = nullptr, *effort = nullptr, *out = nullptr, *stage = nullptr;
+  int32_t *rini = nullptr;
+  size_t stage_bytes = 0;
+  hipStream_t in_stream = nullptr;
+  unsigned long long published = 0;         // doorbell value
+  unsigned long long posted = 0;            // cycles with a header (the next post is for this cycle)
+  unsigned long long posts[RG_COUNT] = {};  // sets of each group posted so far (ring write positions)
+  std::vector<unsigned long long> post_cycle[RG_COUNT]; // [depth]: the cycle each ring position was posted for
+  unsigned max_cycles = 0;
+  bool stream_doorbell_pending = false;     // a doorbell value travels on in_stream behind the posts it releases
+  unsigned groups_posted = 0;
+};
+
+__global__ void resident_doorbell_kernel(ResidentHost *host, unsigned long long value) {
+  __hip_atomic_store(&host->doorbell, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+struct ResidentPost {
+  const double *lin, *ang, *imu_q, *imu_w, *tvi, *rvi, *force, *effort;
+  const int32_t *reset;
+  int pos[RG_COUNT];
+  unsigned mask;
+  unsigned long long cycle;
+};
+// One posted input set -> the data rings (write-through stores: the resident kernel reads them with agent-scope loads while it
+// runs) + the header of its cycle.  The doorbell moves only after this kernel has completed (stream order).
+__global__ void resident_post_kernel(ResidentPost pp, ResidentArgs A, ResidentHeader *headers, double *rin, int32_t *rini, double *force, double *effort,
+                                     int64_t n, int L, int NJ, int64_t n_slots) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int rpw = 64 / L;
+  auto put = [](double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  if (t < n) {
+    const int64_t w = t / rpw;
+    const int r = int(t - w * rpw);
+    auto rec = [&](int grp, int field) { return rin + ((int64_t(pp.pos[grp]) * A.n_waves + w) * RIN_COUNT + field) * rpw + r; };
+    if (pp.mask & (1u << RG_VEL)) {
+      put(rec(RG_VEL, RIN_VEL), pp.lin[t * 2]);
+      put(rec(RG_VEL, RIN_VEL + 1), pp.lin[t * 2 + 1]);
+      put(rec(RG_VEL, RIN_VEL + 2), pp.ang[t]);
+    }
+    if (pp.mask & (1u << RG_IMU)) { // Model::setImuData input as shc_engine_set_imu stores it: the orientation normalised
+      const Quat qn = normalized(Quat{pp.imu_q[t * 4], pp.imu_q[t * 4 + 1], pp.imu_q[t * 4 + 2], pp.imu_q[t * 4 + 3]}); // as scatter_rob_kernel
+      put(rec(RG_IMU, RIN_IMU + 0), qn.w);
+      put(rec(RG_IMU, RIN_IMU + 1), qn.x);
+      put(rec(RG_IMU, RIN_IMU + 2), qn.y);
+      put(rec(RG_IMU, RIN_IMU + 3), qn.z);
+      for (int k = 0; k < 3; ++k) put(rec(RG_IMU, RIN_IMU + 4 + k), pp.imu_w[t * 3 + k]);
+    }
+    if (pp.mask & (1u << RG_POSE)) {
+      for (int k = 0; k < 3; ++k) put(rec(RG_POSE, RIN_POSE + k), pp.tvi[t * 3 + k]);
+      for (int k = 0; k < 3; ++k) put(rec(RG_POSE, RIN_POSE + 3 + k), pp.rvi[t * 3 + k]);
+    }
+    if (pp.mask & (1u << RG_RESET))
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(rini) + ((int64_t(pp.pos[RG_RESET]) * A.n_waves + w) * rpw + r),
+                         (unsigned long long)(unsigned)pp.reset[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (t < n * L && (pp.mask & ((1u << RG_FORCE) | (1u << RG_EFFORT)))) {
+    const int64_t rob = t / L;
+    const int leg = int(t - rob * L);
+    const int64_t slot = slot_of(rob, leg, L);
+    if (pp.mask & (1u << RG_FORCE)) {
+      double *base = force + int64_t(pp.pos[RG_FORCE]) * 2 * n_slots * 2;
+      for (int k = 0; k < 3; ++k) put(base + leg_field_index(k, slot, n_slots), pp.force[t * 3 + k]);
+    }
+    if (pp.mask & (1u << RG_EFFORT)) {
+      const int nje = (NJ + 1) & ~1;
+      double *base = effort + int64_t(pp.pos[RG_EFFORT]) * (nje / 2) * n_slots * 2;
+      for (int k = 0; k < NJ; ++k) put(base + leg_field_index(k, slot, n_slots), pp.effort[t * NJ + k]);
+    }
+  }
+  if (t == 0) {
+    unsigned long long h1 = pp.mask & 0xffffu;
+    for (int gi = 0; gi < RG_COUNT; ++gi) h1 |= (unsigned long long)(pp.pos[gi] & 0xff) << (16 + 8 * gi);
+    unsigned long long *hp = reinterpret_cast<unsigned long long *>(headers + (pp.cycle & (kResidentHeaders - 1)));
+    __hip_atomic_store(hp + 1, h1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(hp, pp.cycle + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+static void resident_free(Resident *r) {
+  if (!r) return;
+  if (r->host) (void)hipHostFree(r->host);
+  (void)hipFree(r->ctl);
+  (void)hipFree(r->progress);
+  (void)hipFree(r->headers);
+  (void)hipFree(r->rin);
+  (void)hipFree(r->rini);
+  (void)hipFree(r->force);
+  (void)hipFree(r->effort);
+  (void)hipFree(r->out);
+  (void)hipFree(r->stage);
+  if (r->in_stream) (void)hipStreamDestroy(r->in_stream);
+  delete r;
+}
+
+static inline unsigned long long host_load(const unsigned long long *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+static inline void host_store(unsigned long long *p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+static double now_seconds() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return double(ts.tv_sec) + 1e-9 * double(ts.tv_nsec);
+}
+// spin until pred() or the timeout; polite after the first 200 us
+template <typename Pred>
+static bool spin_until(Pred pred, double timeout_s) {
+  const double t0 = now_seconds();
+  for (unsigned it = 0;; ++it) {
+    if (pred()) return true;
+    const double dt = now_seconds() - t0;
+    if (dt > timeout_s) return false;
+    if (dt > 200e-6 && (it & 63) == 0) sched_yield();
+  }
+}
+
+static int resident_require(shc_engine *e, bool active) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (active && !(e->res && e->res->active)) return fail(SHC_ERR_INVALID_ARG, "the engine is not in resident mode (shc_engine_resident_begin)");
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t max_cycles, int idle_timeout_ms) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (e->res && e->res->active) return fail(SHC_ERR_BUSY, "resident mode is already active");
+  if (ring_depth < 2 || ring_depth > 255) return fail(SHC_ERR_INVALID_ARG, "ring_depth must be 2..255");
+  if (max_cycles < 1 || max_cycles > 0x7ffffffe) return fail(SHC_ERR_INVALID_ARG, "max_cycles must be 1..2^31-2");
+  if (idle_timeout_ms < 0 || idle_timeout_ms > 600000) return fail(SHC_ERR_INVALID_ARG, "idle_timeout_ms must be 0..600000");
+  if (e->starting_up) return fail(SHC_ERR_UNSUPPORTED, "resident mode starts from a running engine (finish the start-up first)");
+  HIP_TRY(hipSetDevice(e->device));
+  // does this configuration have a resident kernel, and does the whole batch fit the chip at once (+ the relay block)?
+  ResidentFit fit{0, 0};
+  {
+    CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, 0, 64, 0, nullptr, &fit};
+#define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  }
+  if (!fit.supported)
+    return fail(SHC_ERR_UNSUPPORTED, "resident mode: this configuration runs on a rough-terrain / manual-leg / tip-rotation kernel, which has no resident form");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, e->device));
+  const int64_t capacity = int64_t(fit.blocks_per_cu) * prop.multiProcessorCount;
+  if (e->n_waves + 1 > capacity)
+    return fail(SHC_ERR_UNSUPPORTED, "resident mode: the batch needs " + std::to_string(e->n_waves + 1) + " co-resident wavefronts, this device holds " +
+                                         std::to_string(capacity) + " of this kernel (" + std::to_string(fit.blocks_per_cu) + " per compute unit); use shc_engine_step");
+  const int NJE = (e->NJ + 1) & ~1;
+  const size_t out_slot_bytes = size_t(e->NJ) * e->n_slots * 16;
+  if (out_slot_bytes * size_t(ring_depth) >= (size_t(1) << 31)) return fail(SHC_ERR_INVALID_ARG, "ring_depth x batch: the output ring must stay below 2 GiB");
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->res && e->res->depth != ring_depth) {
+    resident_free(e->res);
+    e->res = nullptr;
+  }
+  if (!e->res) {
+    Resident *r = new Resident();
+    e->res = r;
+    r->depth = ring_depth;
+    const int rpw = 64 / e->L;
+    auto bail = [&](hipError_t err, const char *what) {
+      resident_free(r);
+      e->res = nullptr;
+      return fail(SHC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err));
+    };
+    hipError_t err;
+    if ((err = hipHostMalloc(reinterpret_cast<void **>(&r->host), sizeof(ResidentHost), hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
+      return bail(err, "hipHostMalloc(ResidentHost)");
+    if ((err = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->host_dev), r->host, 0)) != hipSuccess) return bail(err, "hipHostGetDevicePointer");
+    if ((err = hipStreamCreateWithFlags(&r->in_stream, hipStreamNonBlocking)) != hipSuccess) return bail(err, "hipStreamCreate");
+    r->stage_bytes = size_t(e->n) * (16 * 8 + 8) + size_t(e->n) * e->L * (3 + e->NJ) * 8 + 256;
+    const size_t D = size_t(ring_depth);
+    if ((err = hipMalloc(&r->ctl, sizeof(ResidentCtl))) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->progress, size_t(e->n_waves) * 8)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->headers, sizeof(ResidentHeader) * kResidentHeaders)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->rin, D * e->n_waves * RIN_COUNT * rpw * 8)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->rini, D * e->n_waves * rpw * 8)) != hipSuccess) return bail(err, "hipMalloc"); // (one 8-byte word per reset mode)
+    if ((err = hipMalloc(&r->force, D * 2 * e->n_slots * 16)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->effort, D * (NJE / 2) * e->n_slots * 16)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->out, D * out_slot_bytes)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->stage, r->stage_bytes)) != hipSuccess) return bail(err, "hipMalloc");
+    for (int gi = 0; gi < RG_COUNT; ++gi) r->post_cycle[gi].assign(D, 0);
+  }
+  Resident *r = e->res;
+  HIP_TRY(hipMemsetAsync(r->ctl, 0, sizeof(ResidentCtl), e->stream));
+  HIP_TRY(hipMemsetAsync(r->progress, 0, size_t(e->n_waves) * 8, e->stream));
+  HIP_TRY(hipMemsetAsync(r->headers, 0, sizeof(ResidentHeader) * kResidentHeaders, e->stream));
+  memset(r->host, 0, sizeof(ResidentHost));
+  r->host->stop = ~0ull;
+  __sync_synchronize();
+  r->published = r->posted = 0;
+  r->groups_posted = 0;
+  r->stream_doorbell_pending = false;
+  for (int gi = 0; gi < RG_COUNT; ++gi) {
+    r->posts[gi] = 0;
+    std::fill(r->post_cycle[gi].begin(), r->post_cycle[gi].end(), 0ull);
+  }
+  r->max_cycles = unsigned(max_cycles);
+  ResidentArgs &A = r->args;
+  A.ctl = r->ctl;
+  A.host = r->host_dev;
+  A.progress = r->progress;
+  A.headers = r->headers;
+  A.rin = r->rin;
+  A.rini = r->rini;
+  A.force = r->force;
+  A.effort = r->effort;
+  A.out = r->out;
+  A.depth = ring_depth;
+  A.max_cycles = r->max_cycles;
+  A.idle_ticks = (unsigned long long)(idle_timeout_ms ? idle_timeout_ms : 2000) * 100000ull; // wall_clock64(): 100 MHz
+  A.n_waves = e->n_waves;
+  e->plan_poser_tips_current = false;
+  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, unsigned(e->n_waves + 1), 64, 0, &A, nullptr};
+#define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  HIP_TRY(hipGetLastError());
+  r->active = true;
+  return SHC_OK;
+}
+
+// the device loop is still running (it has not stopped by itself)
+static int resident_alive(Resident *r) {
+  if (host_load(&r->host->exited) != 0)
+    return fail(SHC_ERR_TIMEOUT, "resident mode: the device loop has stopped by itself (idle timeout, max_cycles or a fault): call shc_engine_resident_end");
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *in, int64_t *cycle) {
+  int rc = resident_require(e, true);
+  if (rc != SHC_OK) return rc;
+  Resident *r = e->res;
+  if ((rc = resident_alive(r)) != SHC_OK) return rc;
+  if (!in) return fail(SHC_ERR_INVALID_ARG, "inputs is NULL");
+  if ((in->linear_xy == nullptr) != (in->angular == nullptr)) return fail(SHC_ERR_INVALID_ARG, "linear_xy and angular are posted together");
+  if ((in->imu_orientation_wxyz == nullptr) != (in->imu_angular_velocity == nullptr)) return fail(SHC_ERR_INVALID_ARG, "the two IMU arrays are posted together");
+  if ((in->pose_translation_velocity == nullptr) != (in->pose_rotation_velocity == nullptr))
+    return fail(SHC_ERR_INVALID_ARG, "the two pose input arrays are posted together");
+  unsigned mask = 0;
+  if (in->linear_xy) mask |= 1u << RG_VEL;
+  if (in->imu_orientation_wxyz) mask |= 1u << RG_IMU;
+  if (in->pose_translation_velocity) mask |= 1u << RG_POSE;
+  if (in->pose_reset_mode) mask |= 1u << RG_RESET;
+  if (in->tip_force) mask |= 1u << RG_FORCE;
+  if (in->joint_effort) mask |= 1u << RG_EFFORT;
+  if ((mask & ((1u << RG_POSE) | (1u << RG_RESET))) && !(e->rt_flags & RT_MANUAL_LIVE))
+    return fail(SHC_ERR_UNSUPPORTED, "pose inputs: give the engine one (shc_engine_set_pose_input / set_pose_reset_mode) before shc_engine_resident_begin");
+  if ((mask & (1u << RG_EFFORT)) && !(e->rt_flags & RT_EFFORT_LIVE))
+    return fail(SHC_ERR_UNSUPPORTED, "joint efforts: give the engine one (shc_engine_set_joint_effort) before shc_engine_resident_begin");
+  const unsigned long long c = r->posted;
+  if (c < r->published) return fail(SHC_ERR_INVALID_ARG, "resident mode: this cycle has already been published without inputs");
+  if (c >= r->max_cycles) return fail(SHC_ERR_INVALID_ARG, "resident mode: past max_cycles");
+  HIP_TRY(hipSetDevice(e->device));
+  // the header slot of cycle c last served cycle c - 1024; a ring position of group g last served post k - depth, which stays in
+  // force until the cycle post k - depth + 1 was made for has been reached by every wave
+  const double patience = 5.0;
+  if (c >= kResidentHeaders && !spin_until([&] { return host_load(&r->host->done) > c - kResidentHeaders; }, patience))
+    return fail(SHC_ERR_TIMEOUT, "resident mode: 1024 posted cycles are waiting to run");
+  ResidentPost pp{};
+  pp.mask = mask;
+  pp.cycle = c;
+  for (int gi = 0; gi < RG_COUNT; ++gi) {
+    if (!(mask & (1u << gi))) continue;
+    const unsigned long long k = r->posts[gi];
+    pp.pos[gi] = int(k % r->depth);
+    if (k >= (unsigned long long)r->depth) {
+      const unsigned long long successor_cycle = r->post_cycle[gi][(k + 1) % r->depth]; // cycle of post k - depth + 1
+      if (!spin_until([&] { return host_load(&r->host->done) >= successor_cycle || host_load(&r->host->exited) != 0; }, patience))
+        return fail(SHC_ERR_TIMEOUT, "resident mode: ring_depth posted input sets are waiting to be consumed (publish them)");
+    }
+  }
+  // stage host arrays (one staging buffer, consumed in stream order)
+  size_t off = 0;
+  auto dev = [&](const void *src, size_t bytes, const void **out) -> int {
+    if (in->on_device) {
+      *out = src;
+      return SHC_OK;
+    }
+    if (off + bytes > r->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
+    char *d = reinterpret_cast<char *>(r->stage) + off;
+    HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, r->in_stream));
+    *out = d;
+    off += (bytes + 15) & ~size_t(15);
+    return SHC_OK;
+  };
+  const size_t n = size_t(e->n), nl = n * e->L;
+#define STAGE(field, member, bytes)                                                              \
+  if (in->member) {                                                                              \
+    const void *d_;                                                                              \
+    if ((rc = dev(in->member, bytes, &d_)) != SHC_OK) return rc;                                 \
+    pp.field = reinterpret_cast<decltype(pp.field)>(d_);                                         \
+  }
+  STAGE(lin, linear_xy, n * 16)
+  STAGE(ang, angular, n * 8)
+  STAGE(imu_q, imu_orientation_wxyz, n * 32)
+  STAGE(imu_w, imu_angular_velocity, n * 24)
+  STAGE(tvi, pose_translation_velocity, n * 24)
+  STAGE(rvi, pose_rotation_velocity, n * 24)
+  STAGE(reset, pose_reset_mode, n * 4)
+  STAGE(force, tip_force, nl * 24)
+  STAGE(effort, joint_effort, nl * e->NJ * 8)
+#undef STAGE
+  const int64_t threads = (mask & ((1u << RG_FORCE) | (1u << RG_EFFORT))) ? int64_t(nl) : int64_t(n);
+  resident_post_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, r->in_stream>>>(pp, r->args, r->headers, r->rin, r->rini, r->force, r->effort,
+                                                                                              e->n, e->L, e->NJ, e->n_slots);
+  HIP_TRY(hipGetLastError());
+  if (!in->on_device) HIP_TRY(hipStreamSynchronize(r->in_stream)); // the caller's host arrays and the staging buffer are free again
+  for (int gi = 0; gi < RG_COUNT; ++gi)
+    if (mask & (1u << gi)) {
+      r->post_cycle[gi][r->posts[gi] % r->depth] = c;
+      r->posts[gi]++;
+    }
+  r->groups_posted |= mask;
+  r->posted = c + 1;
+  r->stream_doorbell_pending = true; // (a post is in flight on in_stream: the doorbell that releases it must follow it there)
+  if (cycle) *cycle = int64_t(c);
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_resident_publish(shc_engine *e, int64_t n_cycles) {
+  int rc = resident_require(e, true);
+  if (rc != SHC_OK) return rc;
+  Resident *r = e->res;
+  if ((rc = resident_alive(r)) != SHC_OK) return rc;
+  if (n_cycles < 0) return fail(SHC_ERR_INVALID_ARG, "n_cycles < 0");
+  if (n_cycles == 0) return SHC_OK;
+  if (r->published + (unsigned long long)n_cycles > r->max_cycles) return fail(SHC_ERR_INVALID_ARG, "resident mode: past max_cycles");
+  r->published += (unsigned long long)n_cycles;
+  if (r->posted < r->published) r->posted = r->published; // cycles released without a post run with the inputs held
+  if (r->stream_doorbell_pending) {
+    // posts may still be in flight on the input stream: once they have all completed the doorbell is a plain store, until
+    // then it has to queue behind them
+    HIP_TRY(hipSetDevice(e->device));
+    if (hipStreamQuery(r->in_stream) == hipSuccess) {
+      r->stream_doorbell_pending = false;
+    } else {
+      resident_doorbell_kernel<<<dim3(1), dim3(1), 0, r->in_stream>>>(r->host_dev, r->published);
+      HIP_TRY(hipGetLastError());
+      return SHC_OK;
+    }
+  }
+  host_store(&r->host->doorbell, r->published);
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_resident_wait(shc_engine *e, int64_t cycles, int timeout_ms) {
+  int rc = resident_require(e, true);
+  if (rc != SHC_OK) return rc;
+  Resident *r = e->res;
+  if (cycles < 0 || (unsigned long long)cycles > r->published) return fail(SHC_ERR_INVALID_ARG, "resident mode: waiting for cycles that were not published");
+  const unsigned long long want = (unsigned long long)cycles;
+  if (!spin_until([&] { return host_load(&r->host->done) >= want || host_load(&r->host->exited) != 0; }, timeout_ms > 0 ? timeout_ms * 1e-3 : 10.0))
+    return fail(SHC_ERR_TIMEOUT, "resident mode: the published cycles did not complete in time");
+  if (host_load(&r->host->done) < want) return fail(SHC_ERR_TIMEOUT, "resident mode: the device loop stopped before these cycles ran");
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_resident_get_joint_state(shc_engine *e, int64_t cycle, double *q, double *qd, int on_device) {
+  int rc = resident_require(e, true);
+  if (rc != SHC_OK) return rc;
+  Resident *r = e->res;
+  const unsigned long long done = host_load(&r->host->done);
+  if (cycle < 0 || (unsigned long long)cycle >= done) return fail(SHC_ERR_INVALID_ARG, "resident mode: that cycle has not completed (shc_engine_resident_wait)");
+  if (r->published > (unsigned long long)cycle + r->depth) // (cycle + ring_depth shares its ring position and has been released)
+    return fail(SHC_ERR_INVALID_ARG, "resident mode: that cycle's outputs may have been overwritten (ring_depth newer cycles were published)");
+  HIP_TRY(hipSetDevice(e->device));
+  const double *slot = r->out + size_t(cycle % r->depth) * size_t(e->NJ) * e->n_slots * 2;
+  const int64_t threads = e->n * e->L;
+  for (int which = 0; which < 2; ++which) {
+    double *dst = which ? qd : q;
+    if (!dst) continue;
+    double *d = on_device ? dst : r->stage;
+    gather_leg_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, r->in_stream>>>(d, slot, e->n_slots, e->n, e->L, e->NJ,
+                                                                                            which ? LEG_FIELD(e, QD) : LEG_FIELD(e, Q));
+    HIP_TRY(hipGetLastError());
+    if (!on_device) {
+      HIP_TRY(hipMemcpyAsync(dst, d, size_t(threads) * e->NJ * 8, hipMemcpyDeviceToHost, r->in_stream));
+      HIP_TRY(hipStreamSynchronize(r->in_stream));
+    }
+  }
+  r->stream_doorbell_pending = true; // work is queued on in_stream: a doorbell must not overtake a post queued before it
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_resident_status(shc_engine *e, int64_t *published, int64_t *completed, int32_t *running) {
+  int rc = resident_require(e, false);
+  if (rc != SHC_OK) return rc;
+  Resident *r = e->res;
+  const bool active = r && r->active;
+  if (published) *published = active ? int64_t(r->published) : 0;
+  if (completed) *completed = active ? int64_t(host_load(&r->host->done)) : 0;
+  if (running) *running = active && host_load(&r->host->exited) == 0 ? 1 : 0;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
+  int rc = resident_require(e, true);
+  if (rc != SHC_OK) return rc;
+  Resident *r = e->res;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(r->in_stream)); // every post and stream-ordered doorbell has landed
+  host_store(&r->host->doorbell, r->published);
+  host_store(&r->host->stop, r->published);
+  const bool answered = spin_until([&] { return host_load(&r->host->exited) != 0; }, 30.0);
+  hipError_t err = answered ? hipStreamSynchronize(e->stream) : hipErrorNotReady;
+  r->active = false;
+  const unsigned long long reason = host_load(&r->host->exited), done = host_load(&r->host->done);
+  if (cycles_run) *cycles_run = int64_t(done);
+  if (r->groups_posted & (1u << RG_FORCE)) e->rt_flags |= RT_TOUCHDOWN; // as shc_engine_set_tip_force (state_controller.cpp:1642)
+  if (!answered) return fail(SHC_ERR_TIMEOUT, "resident mode: the device loop did not answer the stop request within 30 s");
+  if (err != hipSuccess) return fail(SHC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
+  if (reason == RESIDENT_EXIT_FAULT || host_load(&r->host->fault) != 0)
+    return fail(SHC_ERR_HIP, "resident mode: a wavefront gave up waiting for the relay; restore the engine from a snapshot");
+  if (reason != RESIDENT_EXIT_STOP || done != r->published)
+    return fail(SHC_ERR_TIMEOUT, std::string("resident mode: the device loop had stopped by itself (") +
+                                     (reason == RESIDENT_EXIT_IDLE ? "idle timeout" : reason == RESIDENT_EXIT_MAX ? "max_cycles" : "unknown") + ") after " +
+                                     std::to_string(done) + " of " + std::to_string(r->published) + " published cycles");
+  return SHC_OK;
+}

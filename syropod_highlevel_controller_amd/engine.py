@@ -20,7 +20,7 @@ _SO = os.environ.get("SHC_LIB") or os.path.join(_HERE, "libshc_batch.so")
 _SRC = os.path.join(_HERE, "csrc")
 _INC = os.path.join(os.path.dirname(_HERE), "include")
 
-SHC_OK, SHC_ERR_INVALID_ARG, SHC_ERR_NO_DEVICE, SHC_ERR_HIP, SHC_ERR_UNSUPPORTED, SHC_ERR_UNSTABLE = range(6)
+SHC_OK, SHC_ERR_INVALID_ARG, SHC_ERR_NO_DEVICE, SHC_ERR_HIP, SHC_ERR_UNSUPPORTED, SHC_ERR_UNSTABLE, SHC_ERR_BUSY, SHC_ERR_TIMEOUT = range(8)
 
 EXPORTED_SYMBOLS = [
     "shc_abi_version", "shc_sizeof_params", "shc_sizeof_tables", "shc_device_count", "shc_last_error", "shc_debug_plane_copy", "shc_generate_tables", "shc_engine_create",
@@ -44,7 +44,15 @@ EXPORTED_SYMBOLS = [
     "shc_fleet_part_instances", "shc_fleet_set_velocity", "shc_fleet_set_imu", "shc_fleet_set_pose_input", "shc_fleet_set_tip_force",
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
     "shc_fleet_all_gather_joints",
+    "shc_engine_resident_begin", "shc_engine_resident_post", "shc_engine_resident_publish", "shc_engine_resident_wait",
+    "shc_engine_resident_get_joint_state", "shc_engine_resident_status", "shc_engine_resident_end",
 ]
+
+
+class CycleInputs(C.Structure):
+    """shc_cycle_inputs (include/shc_batch.h): what the callbacks of one loop iteration delivered; NULL = not received."""
+    _fields_ = [(k, C.c_void_p) for k in ("linear_xy", "angular", "imu_orientation_wxyz", "imu_angular_velocity", "pose_translation_velocity",
+                                           "pose_rotation_velocity", "pose_reset_mode", "tip_force", "joint_effort")] + [("on_device", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ShcError(RuntimeError):
@@ -190,6 +198,13 @@ def lib():
                         ("shc_engine_set_joint_effort", 1), ("shc_engine_set_pose_input", 2), ("shc_engine_set_pose_reset_mode", 1)):
             getattr(L, name).argtypes = [C.c_void_p] + [C.c_void_p] * n + [C.c_int]
         L.shc_engine_step.argtypes = [C.c_void_p, C.c_int]
+        L.shc_engine_resident_begin.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int]
+        L.shc_engine_resident_post.argtypes = [C.c_void_p, C.POINTER(CycleInputs), C.POINTER(C.c_int64)]
+        L.shc_engine_resident_publish.argtypes = [C.c_void_p, C.c_int64]
+        L.shc_engine_resident_wait.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        L.shc_engine_resident_get_joint_state.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_resident_status.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.shc_engine_resident_end.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.shc_engine_synchronize.argtypes = [C.c_void_p]
         L.shc_engine_get_joint_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.shc_engine_joint_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
@@ -369,6 +384,60 @@ class BatchEngine:
 
     def synchronize(self):
         _check(self.L.shc_engine_synchronize(self.h), "synchronize")
+
+    # -- resident mode: the control loop kept on the chip (shc_engine_resident_*)
+    def resident_begin(self, ring_depth: int = 16, max_cycles: int = 1 << 24, idle_timeout_ms: int = 0):
+        _check(self.L.shc_engine_resident_begin(self.h, int(ring_depth), int(max_cycles), int(idle_timeout_ms)), "resident_begin")
+
+    def resident_post(self, velocity=None, imu=None, pose_input=None, pose_reset_mode=None, tip_force=None, joint_effort=None, on_device=False) -> int:
+        """Inputs of the next unposted cycle: velocity = (linear_xy, angular), imu = (quat_wxyz, gyro), pose_input = (translation
+        velocity, rotation velocity); host numpy arrays, or integer device pointers with on_device.  Returns the cycle index."""
+        keep = []
+
+        def ptr(a, dtype=np.float64):
+            if a is None:
+                return None
+            if on_device:
+                return int(a)
+            h = _host(a, dtype)
+            keep.append(h)
+            return h.ctypes.data
+
+        ci = CycleInputs()
+        if velocity is not None:
+            ci.linear_xy, ci.angular = ptr(velocity[0]), ptr(velocity[1])
+        if imu is not None:
+            ci.imu_orientation_wxyz, ci.imu_angular_velocity = ptr(imu[0]), ptr(imu[1])
+        if pose_input is not None:
+            ci.pose_translation_velocity, ci.pose_rotation_velocity = ptr(pose_input[0]), ptr(pose_input[1])
+        ci.pose_reset_mode = ptr(pose_reset_mode, np.int32)
+        ci.tip_force, ci.joint_effort = ptr(tip_force), ptr(joint_effort)
+        ci.on_device = 1 if on_device else 0
+        cyc = C.c_int64(-1)
+        _check(self.L.shc_engine_resident_post(self.h, C.byref(ci), C.byref(cyc)), "resident_post")
+        return int(cyc.value)
+
+    def resident_publish(self, n_cycles: int = 1):
+        _check(self.L.shc_engine_resident_publish(self.h, int(n_cycles)), "resident_publish")
+
+    def resident_wait(self, cycles: int, timeout_ms: int = 0):
+        _check(self.L.shc_engine_resident_wait(self.h, int(cycles), int(timeout_ms)), "resident_wait")
+
+    def resident_joints(self, cycle: int):
+        q = np.zeros((self.n, self.legs * self.dof))
+        qd = np.zeros((self.n, self.legs * self.dof))
+        _check(self.L.shc_engine_resident_get_joint_state(self.h, int(cycle), _p(q), _p(qd), 0), "resident_get_joint_state")
+        return q, qd
+
+    def resident_status(self):
+        pub, done, run = C.c_int64(), C.c_int64(), C.c_int32()
+        _check(self.L.shc_engine_resident_status(self.h, C.byref(pub), C.byref(done), C.byref(run)), "resident_status")
+        return int(pub.value), int(done.value), bool(run.value)
+
+    def resident_end(self) -> int:
+        ran = C.c_int64(0)
+        _check(self.L.shc_engine_resident_end(self.h, C.byref(ran)), "resident_end")
+        return int(ran.value)
 
     # -- outputs
     def joints(self):

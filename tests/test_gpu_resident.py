@@ -1,0 +1,215 @@
+"""GPU (-m gpu): resident mode (shc_engine_resident_*) - the control loop kept on the chip (src/main.cpp:106-131 around
+StateController::loop) - against (a) the same cycles through shc_engine_step, byte for byte, and (b) the CPU oracle, with
+inputs that change EVERY cycle (the callbacks of every loop iteration deliver something new).
+"""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from conftest import parity_report
+from oracle_lib import OracleBatch
+from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Engine():
+    from syropod_highlevel_controller_amd import engine
+    if engine.device_count() < 1:
+        pytest.fail("no HIP device: the -m gpu tests must run the native HIP path")
+    return engine.BatchEngine
+
+
+def state_bytes(eng):
+    return bytes(memoryview(eng.get_state()).cast("B"))
+
+
+def velocity_schedule(rng, n, cycles):
+    """A different command every cycle: smooth drift + a few hard steps + a stop / restart in the middle."""
+    base_l, base_a = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
+    out = []
+    for c in range(cycles):
+        k = 0.6 + 0.4 * np.sin(0.05 * c + np.arange(n))
+        lin = base_l * k[:, None] + 0.05 * rng.standard_normal((n, 2))
+        ang = base_a * k[::-1] + 0.05 * rng.standard_normal(n)
+        if cycles // 2 <= c < cycles // 2 + 40:   # a third of the robots stop and restart
+            lin[::3] = 0.0
+            ang[::3] = 0.0
+        out.append((lin, ang))
+    return out
+
+
+def config3_params():
+    p = default_hexapod_params("wave")
+    p.admittance_control, p.imu_posing = 1, 1
+    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    return p
+
+
+def imu_sample(rng, n):
+    from scipy.spatial.transform import Rotation as R
+    e = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-3, 3, n)], axis=1)
+    q = R.from_euler("xyz", e).as_quat()
+    return np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1), rng.normal(0, 0.05, size=(n, 3))
+
+
+def force_sample(rng, n, legs):
+    return np.stack([rng.normal(0, 1, (n, legs)), rng.normal(0, 1, (n, legs)), rng.uniform(0, 20, (n, legs))], axis=2)
+
+
+@pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4"])
+def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case):
+    """Every cycle gets new inputs.  Engine A: set_* + shc_engine_step(1) per cycle.  Engine B: one resident launch, inputs posted per
+    cycle.  q / qd of EVERY cycle (output ring) and the complete state record at the end are equal byte for byte."""
+    rng = np.random.default_rng(11)
+    if case == "config2":
+        p, n = default_hexapod_params("tripod"), 333
+    elif case == "config3":
+        p, n = config3_params(), 250
+    elif case == "octopod":
+        p, n = synthetic_octopod_params("ripple", 5, 8), 203
+    else:
+        p, n = synthetic_octopod_params("amble", 4, 4), 130
+    cycles, depth = 260, 8
+    sched = velocity_schedule(rng, n, cycles)
+    imus = [imu_sample(rng, n) for _ in range(cycles)] if case == "config3" else None
+    forces = [force_sample(rng, n, p.leg_count) if c % 3 == 0 else None for c in range(cycles)] if case == "config3" else None
+    a, b = Engine(p, n), Engine(p, n)
+    for e in (a, b):   # some history before the resident run starts
+        e.set_velocity(*sched[0])
+        e.step(37)
+    qa = []
+    for c in range(cycles):
+        a.set_velocity(*sched[c])
+        if imus:
+            a.set_imu(*imus[c])
+            if forces[c] is not None:
+                a.set_tip_force(forces[c])
+        a.step(1)
+        qa.append(a.joints())
+    a.synchronize()
+    b.resident_begin(ring_depth=depth, max_cycles=cycles + 10)
+    with pytest.raises(Exception, match="resident mode"):
+        b.step(1)          # everything else is refused while the loop owns the engine
+    for c0 in range(0, cycles, depth - 1):   # post up to ring_depth - 1 cycles ahead, release them, read every cycle's output
+        c1 = min(cycles, c0 + depth - 1)
+        for c in range(c0, c1):
+            kw = {"velocity": sched[c]}
+            if imus:
+                kw["imu"] = imus[c]
+                if forces[c] is not None:
+                    kw["tip_force"] = forces[c]
+            assert b.resident_post(**kw) == c
+        b.resident_publish(c1 - c0)
+        b.resident_wait(c1)
+        for c in range(c0, c1):
+            q, qd = b.resident_joints(c)
+            assert np.array_equal(q, qa[c][0]) and np.array_equal(qd, qa[c][1]), f"cycle {c}"
+    assert b.resident_end() == cycles
+    assert state_bytes(a) == state_bytes(b)
+    # ... and the engines go on identically through ordinary launches (held inputs were carried over)
+    for e in (a, b):
+        e.step(25)
+    assert state_bytes(a) == state_bytes(b)
+    qb = b.joints()
+    assert np.array_equal(qb[0], a.joints()[0])
+    a.close()
+    b.close()
+
+
+def test_resident_with_velocities_changing_every_cycle_matches_the_oracle(Engine):
+    """BASELINE.json config 2's path with a new velocity command every cycle, free-running against the oracle: 1e-6 rad."""
+    p, n, cycles = default_hexapod_params("tripod"), 200, 400
+    rng = np.random.default_rng(5)
+    sched = velocity_schedule(rng, n, cycles)
+    eng, ob = Engine(p, n), OracleBatch(p, n)
+    eng.resident_begin(ring_depth=32, max_cycles=cycles)
+    worst = 0.0
+    for c0 in range(0, cycles, 25):
+        for c in range(c0, c0 + 25):
+            eng.resident_post(velocity=sched[c])
+        eng.resident_publish(25)
+        for c in range(c0, c0 + 25):
+            ob.set_velocity(*sched[c])
+            ob.step(1, 4)
+        eng.resident_wait(c0 + 25)
+        q, _ = eng.resident_joints(c0 + 24)
+        worst = max(worst, float(np.abs(q - ob.joints()[0]).max()))
+    assert eng.resident_end() == cycles
+    parity_report(f"resident mode, velocities changing every cycle, {n} hexapods x {cycles} cycles: max |dq| = {worst:.2e} rad")
+    assert worst <= 1e-6
+    _, _, ws = eng.body_state()
+    assert np.array_equal(ws, ob.body_state()[2])
+    eng.close()
+
+
+def test_resident_held_inputs_and_bare_publishes(Engine):
+    """Cycles that nothing was posted for run with the inputs held (a callback that did not fire); a group posted once stays in force."""
+    p, n = config3_params(), 128
+    rng = np.random.default_rng(3)
+    lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
+    f0, f1 = force_sample(rng, n, 6), force_sample(rng, n, 6)
+    a, b = Engine(p, n), Engine(p, n)
+    for e in (a, b):
+        e.set_tip_force(f0)
+    a.set_velocity(lin, ang)
+    a.step(50)
+    a.set_tip_force(f1)
+    a.step(70)
+    a.set_velocity(lin * 0.5, ang)
+    a.step(30)
+    b.resident_begin(ring_depth=4, max_cycles=1000)
+    b.resident_post(velocity=(lin, ang))
+    b.resident_publish(50)           # 1 posted + 49 held
+    b.resident_post(tip_force=f1)
+    b.resident_publish(70)
+    b.resident_post(velocity=(lin * 0.5, ang))
+    b.resident_publish(30)
+    b.resident_wait(150)
+    assert b.resident_status() == (150, 150, True)
+    assert b.resident_end() == 150
+    assert state_bytes(a) == state_bytes(b)
+    a.step(10)
+    b.step(10)                       # the held inputs (velocity, second force set) are the engine's inputs from here on
+    assert state_bytes(a) == state_bytes(b)
+    a.close()
+    b.close()
+
+
+def test_resident_bounds(Engine):
+    """Every device-side wait is bounded: max_cycles, the idle timeout, and batches that do not fit are refused."""
+    from syropod_highlevel_controller_amd.engine import ShcError
+    p = default_hexapod_params("tripod")
+    big = Engine(p, 40000)           # 4 000 waves: more than the chip holds at once
+    with pytest.raises(ShcError, match="co-resident"):
+        big.resident_begin()
+    big.close()
+    e = Engine(p, 64)
+    e.resident_begin(ring_depth=4, max_cycles=20, idle_timeout_ms=300)
+    with pytest.raises(ShcError, match="max_cycles"):
+        e.resident_publish(21)
+    e.resident_publish(20)
+    e.resident_wait(20)
+    time.sleep(0.05)
+    with pytest.raises(ShcError):    # the loop has reached its bound and left by itself
+        e.resident_end()
+    assert e.resident_status()[2] is False
+    e.step(1)                        # ... and the engine is usable again, 20 cycles on
+    ref = Engine(p, 64)
+    ref.step(21)
+    assert state_bytes(ref) == state_bytes(e)
+    # idle timeout: nobody rings the doorbell
+    e.resident_begin(ring_depth=4, max_cycles=1000, idle_timeout_ms=200)
+    e.resident_publish(5)
+    time.sleep(0.6)
+    with pytest.raises(ShcError, match="stopped by itself"):
+        e.resident_publish(1)
+    with pytest.raises(ShcError, match="idle timeout"):
+        e.resident_end()
+    ref.step(5)
+    assert state_bytes(ref) == state_bytes(e)
+    e.close()
+    ref.close()
