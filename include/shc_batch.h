@@ -282,7 +282,8 @@ int shc_engine_synchronize(shc_engine *e);
  *   shc_engine_resident_end(e, cycles_run)
  *       stops the loop after the published cycles, waits for it, and leaves the engine exactly as the same cycles through
  *       shc_engine_step would have (state planes, held inputs).  SHC_ERR_TIMEOUT: the loop had already stopped by itself
- *       (idle timeout / max_cycles) - the state is that of *cycles_run iterations, consistent across instances.
+ *       (idle timeout) before everything published had run - the state is that of *cycles_run iterations, consistent across
+ *       instances, and the engine is usable again.
  */
 typedef struct shc_cycle_inputs {
   const double *linear_xy;                  /* [n][2]            velocity command (state_controller.cpp:1127) */

@@ -252,6 +252,9 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
     unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
     if (!(c < db && c < sp)) {
       if (c >= sp) break;
+      // nothing to run yet: the outputs of cycle c - 1 would otherwise be announced half a cycle into cycle c - announce them now
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) st_agent(A.progress + wave, u64(c));
       const u64 t0 = wall_clock64();
       for (;;) {
         __builtin_amdgcn_s_sleep(4);
@@ -397,7 +400,7 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
     else if (idle_stop == 0xffffffffu && now - t_last > A.idle_ticks) idle_stop = db;
     unsigned want_sp = max_cycles;
     u64 why = RESIDENT_EXIT_MAX;
-    if (hs < max_cycles) want_sp = unsigned(hs), why = RESIDENT_EXIT_STOP;
+    if (hs <= max_cycles) want_sp = unsigned(hs), why = RESIDENT_EXIT_STOP;
     if (idle_stop < want_sp) want_sp = idle_stop, why = RESIDENT_EXIT_IDLE;
     if (want_sp < db) want_sp = db; // cycles already released run
     if (want_db > want_sp) want_db = want_sp;

@@ -202,7 +202,12 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
     for (int gi = 0; gi < RG_COUNT; ++gi) r->post_cycle[gi].assign(D, 0);
   }
   Resident *r = e->res;
-  HIP_TRY(hipMemsetAsync(r->ctl, 0, sizeof(ResidentCtl), e->stream));
+  {
+    ResidentCtl ctl0{};
+    ctl0.gate = (unsigned long long)(unsigned(max_cycles)) << 32; // nothing released yet, stop at the launch's bound (the relay takes over from here)
+    HIP_TRY(hipMemcpyAsync(r->ctl, &ctl0, sizeof ctl0, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   HIP_TRY(hipMemsetAsync(r->progress, 0, size_t(e->n_waves) * 8, e->stream));
   HIP_TRY(hipMemsetAsync(r->headers, 0, sizeof(ResidentHeader) * kResidentHeaders, e->stream));
   memset(r->host, 0, sizeof(ResidentHost));
@@ -228,7 +233,9 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   A.out = r->out;
   A.depth = ring_depth;
   A.max_cycles = r->max_cycles;
-  A.idle_ticks = (unsigned long long)(idle_timeout_ms ? idle_timeout_ms : 2000) * 100000ull; // wall_clock64(): 100 MHz
+  int wall_khz = 0; // wall_clock64() rate (100 MHz on MI300 / MI355X)
+  if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
+  A.idle_ticks = (unsigned long long)(idle_timeout_ms ? idle_timeout_ms : 2000) * (unsigned long long)wall_khz;
   A.n_waves = e->n_waves;
   e->plan_poser_tips_current = false;
   CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, unsigned(e->n_waves + 1), 64, 0, &A, nullptr};
@@ -242,8 +249,10 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
 
 // the device loop is still running (it has not stopped by itself)
 static int resident_alive(Resident *r) {
-  if (host_load(&r->host->exited) != 0)
-    return fail(SHC_ERR_TIMEOUT, "resident mode: the device loop has stopped by itself (idle timeout, max_cycles or a fault): call shc_engine_resident_end");
+  if (const unsigned long long why = host_load(&r->host->exited))
+    return fail(SHC_ERR_TIMEOUT, std::string("resident mode: the device loop has stopped by itself (") +
+                                     (why == RESIDENT_EXIT_IDLE ? "idle timeout" : why == RESIDENT_EXIT_MAX ? "max_cycles" : why == RESIDENT_EXIT_FAULT ? "fault" : "stop") +
+                                     " after " + std::to_string(host_load(&r->host->done)) + " cycles): call shc_engine_resident_end");
   return SHC_OK;
 }
 
@@ -432,7 +441,8 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   if (err != hipSuccess) return fail(SHC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
   if (reason == RESIDENT_EXIT_FAULT || host_load(&r->host->fault) != 0)
     return fail(SHC_ERR_HIP, "resident mode: a wavefront gave up waiting for the relay; restore the engine from a snapshot");
-  if (reason != RESIDENT_EXIT_STOP || done != r->published)
+  // (a loop that reached max_cycles exactly when everything published had run has done what a stop request asks for)
+  if (!((reason == RESIDENT_EXIT_STOP || reason == RESIDENT_EXIT_MAX) && done == r->published))
     return fail(SHC_ERR_TIMEOUT, std::string("resident mode: the device loop had stopped by itself (") +
                                      (reason == RESIDENT_EXIT_IDLE ? "idle timeout" : reason == RESIDENT_EXIT_MAX ? "max_cycles" : "unknown") + ") after " +
                                      std::to_string(done) + " of " + std::to_string(r->published) + " published cycles");

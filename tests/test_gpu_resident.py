@@ -194,8 +194,10 @@ def test_resident_bounds(Engine):
     e.resident_publish(20)
     e.resident_wait(20)
     time.sleep(0.05)
-    with pytest.raises(ShcError):    # the loop has reached its bound and left by itself
-        e.resident_end()
+    assert e.resident_status() == (20, 20, False)   # the loop has reached its bound and left by itself
+    with pytest.raises(ShcError, match="stopped by itself"):
+        e.resident_publish(1)
+    assert e.resident_end() == 20                    # ... having run everything that was published
     assert e.resident_status()[2] is False
     e.step(1)                        # ... and the engine is usable again, 20 cycles on
     ref = Engine(p, 64)
