@@ -155,7 +155,10 @@ enum {
   /* Diagnostic: run the runtime-flag kernel (every feature compiled in, selected per launch) even where a compile-time
    * specialisation for the parameter set exists.  Both produce identical bits (tests/test_gpu_parity.py). */
   SHC_FEAT_GENERIC_KERNEL = 1 << 30,
-  SHC_FEAT_ALL = 0x3fffffff
+  /* Diagnostic: resident mode with ONE wavefront per robot group even where the batch is small enough for the two-wavefront
+   * (walker / model) pipeline.  Both produce identical bits (tests/test_gpu_resident.py). */
+  SHC_FEAT_RESIDENT_ONE_WAVE = 1 << 29,
+  SHC_FEAT_ALL = 0x1fffffff
 };
 
 /*

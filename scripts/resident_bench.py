@@ -27,14 +27,16 @@ for _ in range(steps):
 eng.synchronize()
 dt = time.perf_counter() - t0
 print(f"launch per cycle : {dt / steps * 1e6:7.2f} us/cycle  {n * steps / dt:.3e} cycles/s")
-for mode in ("publish_all", "publish_each", "post_each"):
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE  # noqa: E402
+for mode in ("publish_all", "publish_each", "post_each", "one_wave publish_each"):
+    eng.set_features(FEAT_DEFAULT | (FEAT_RESIDENT_ONE_WAVE if mode.startswith("one_wave") else 0))
     eng.resident_begin(ring_depth=16, max_cycles=steps + 300)
     eng.resident_publish(200)
     eng.resident_wait(200)
     t0 = time.perf_counter()
     if mode == "publish_all":
         eng.resident_publish(steps)
-    elif mode == "publish_each":
+    elif mode.endswith("publish_each"):
         for _ in range(steps):
             eng.resident_publish(1)
     else:

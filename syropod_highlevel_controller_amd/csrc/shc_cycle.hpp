@@ -368,11 +368,41 @@ struct NoHook {
 };
 
 // ------------------------------------------------------------------------------------------------- one control cycle
-template <int L, int NJ, unsigned F, typename IN = LegInPlanes<NJ>, typename MID = NoHook>
-__device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
-                                      const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
-                                      const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
-                                      const MID &mid = MID()) {
+// What the walker / poser half of a cycle hands to the model half (PoseController::updateStance -> Model::updateModel); the
+// positions travel in LegOut (poser_tip, adm_delta).
+struct FrontToBack {
+  V3 desired_dir;   // x axis of the desired tip rotation (body frame) when rot_def
+  bool rot_def;
+  int my_leg_state; // LegState of this leg (manual leg manipulation)
+};
+
+// AdmittanceController::updateAdmittance (admittance_controller.cpp:22-61) + Leg::setAdmittanceDelta (model.h:365-368) of one leg:
+// touches only the admittance state, the tip-force estimate and the tip axis of the last FK - state of the model half.
+template <int NJ, typename IN>
+__device__ __forceinline__ void cycle_admittance(LegRegs<NJ> &s, LegOut &out, const CycleParams &P, const IN &in) {
+  const V3 force_in = in.force(); // tip_force_measured_
+  V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
+  double fi[3] = {f.x, f.y, f.z}, d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double u = fmax(fi[i], 0.0);
+    double x0 = P.adm_m00 * s.adm0 + P.adm_m01 * s.adm1 + P.adm_g0 * u;
+    double x1 = P.adm_m10 * s.adm0 + P.adm_m11 * s.adm1 + P.adm_g1 * u;
+    s.adm0 = x0;
+    s.adm1 = x1;
+    d[i] = clampd(-x0, -0.2, 0.2); // ADMITTANCE_DEADBAND == 0: delta passes through unchanged
+  }
+  // Leg::setAdmittanceDelta (model.h:365-368): projection on the tip's x axis (robot frame) of the current FK
+  out.adm_delta = projection(V3{d[0], d[1], d[2]}, s.tipx);
+}
+
+// The walker / poser half of a cycle: updateCurrentPose, updateStiffness, (ADM_HERE: updateAdmittance,) updateWalk with the
+// LegSteppers, updateStance.  Leaves out.poser_tip (and fb) for the model half.
+template <int L, int NJ, unsigned F, bool ADM_HERE, typename IN>
+__device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
+                                            const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
+                                            const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
+                                            FrontToBack &fb) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
@@ -749,20 +779,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
       }
       s.stiff = v;
     }
-    const V3 force_in = in.force(); // tip_force_measured_
-    V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
-    double fi[3] = {f.x, f.y, f.z}, d[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      double u = fmax(fi[i], 0.0);
-      double x0 = P.adm_m00 * s.adm0 + P.adm_m01 * s.adm1 + P.adm_g0 * u;
-      double x1 = P.adm_m10 * s.adm0 + P.adm_m11 * s.adm1 + P.adm_g1 * u;
-      s.adm0 = x0;
-      s.adm1 = x1;
-      d[i] = clampd(-x0, -0.2, 0.2); // ADMITTANCE_DEADBAND == 0: delta passes through unchanged
-    }
-    // Leg::setAdmittanceDelta (model.h:365-368): projection on the tip's x axis (robot frame) of the current FK
-    out.adm_delta = projection(V3{d[0], d[1], d[2]}, s.tipx);
+    if (ADM_HERE) cycle_admittance<NJ>(s, out, P, in);
   }
 
   SHC_PHASE_FENCE();
@@ -1221,9 +1238,29 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     if (rot_on && rot_def) desired_dir = rotate(inverse(bp.r), s.cur_dir); // pose.rotation^-1 * walker tip rotation (:129-130)
   }
 
+  fb.desired_dir = desired_dir;
+  fb.rot_def = rot_def;
+  fb.my_leg_state = my_leg_state;
   SHC_PHASE_FENCE();
-  mid();
-  // =============================================================== Model::updateModel (model.cpp:142-152)
+}
+
+// The model half of a cycle: Model::updateModel (model.cpp:142-152) - Leg::setDesiredTipPose, applyIK (one DLS step, joint
+// integration and clamps, applyFK, 5 mm check), calculateTipForce.
+template <int L, int NJ, unsigned F, typename IN>
+__device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, int leg, const double *__restrict__ legd, int64_t ns,
+                                           uint32_t slot, const ManualRobot *mr, const IN &in, const FrontToBack &fb) {
+  using FT = Feat<F>;
+  int zero = 0; // (see cycle_front: keeps the loop-invariant LDS loads next to their uses)
+  asm volatile("" : "+v"(zero));
+  const CycleParams &P = (&C.P)[zero];
+  const LegConst<NJ> &lc = C.leg[leg + zero];
+  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
+  const V3 desired_dir = fb.desired_dir;
+  const bool rot_def = fb.rot_def;
+  const int my_leg_state = fb.my_leg_state;
+#ifdef SHC_TIMING
+  const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
+#endif
   {
     SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
@@ -1306,6 +1343,18 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
     }
   }
   SHC_TICK(12);
+}
+
+// One control cycle of this lane's leg (and, redundantly per lane group, of its robot).
+template <int L, int NJ, unsigned F, typename IN = LegInPlanes<NJ>, typename MID = NoHook>
+__device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
+                                      const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
+                                      const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
+                                      const MID &mid = MID()) {
+  FrontToBack fb;
+  cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, legd, ns, slot, dirty, manual_live, touchdown_detection, ext, mr, in, fb);
+  mid();
+  cycle_back<L, NJ, F>(s, out, C, leg, legd, ns, slot, mr, in, fb);
 }
 
 #endif // __HIPCC__

@@ -18,15 +18,20 @@ static void launch_cycle(const CycleLaunch &a) {
     if constexpr ((F & (F_TERRAIN | F_ROT)) == 0) {
       if (a.fit) {
         a.fit->supported = 1;
+        a.fit->two_wave = 1;
         int blocks = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, shc_resident_kernel<L, NJ, F>, 64, wave_bytes) != hipSuccess) blocks = 0;
         a.fit->blocks_per_cu = blocks;
+      } else if (a.block == 256) {
+        shc_resident2_kernel<L, NJ, F><<<dim3(a.grid), dim3(256), 2 * wave_bytes + sizeof(Resident2Lds<L, NJ>), a.stream>>>(
+            a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
       } else {
         shc_resident_kernel<L, NJ, F><<<dim3(a.grid), dim3(64), wave_bytes, a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
       }
     } else if (a.fit) {
       a.fit->supported = 0;
       a.fit->blocks_per_cu = 0;
+      a.fit->two_wave = 0;
     }
     return;
   }

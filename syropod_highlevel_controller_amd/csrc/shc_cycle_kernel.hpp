@@ -41,18 +41,27 @@ struct LegLoad {
   double2 adm, tf0, tf1, stiff, rot0, rot1, rot2;
   int word;
 };
-template <int NJ, unsigned F>
+// ROLE: which half of the per-leg state a wave owns.  ROLE_ALL: the whole leg (one wave runs whole cycles).  The two-wave
+// resident kernel splits it: ROLE_FRONT = the walker / poser half (stepper state: fields [2 NJ, CORE_END), the packed word, the
+// published stiffness and poser tip), ROLE_BACK = the model half (joints: fields [0, 2 NJ) = the first NJ planes, admittance state,
+// tip-force estimate, admittance delta).
+enum : int { ROLE_ALL = 0, ROLE_FRONT = 1, ROLE_BACK = 2 };
+template <int NJ, unsigned F, int ROLE = ROLE_ALL>
 __device__ __forceinline__ void load_leg_issue(LegLoad<NJ> &ll, const DevState &st, const CycleParams &P, uint32_t slot) {
   using FD = Fields<NJ>;
   using FT = Feat<F>;
   const LegPlanes ld{reinterpret_cast<double2 *>(st.legd), st.n_slots, slot};
 #pragma unroll
   for (int p = 0; p < FD::CORE_END / 2; ++p) {
+    if ((ROLE == ROLE_FRONT && p < NJ) || (ROLE == ROLE_BACK && p >= NJ)) {
+      ll.flat[2 * p] = ll.flat[2 * p + 1] = 0.0;
+      continue;
+    }
     double2 v = ld.load(p);
     ll.flat[2 * p] = v.x;
     ll.flat[2 * p + 1] = v.y;
   }
-  ll.word = st.legi[slot];
+  ll.word = ROLE == ROLE_BACK ? 0 : st.legi[slot];
   ll.adm = ll.tf0 = ll.tf1 = ll.stiff = ll.rot0 = ll.rot1 = ll.rot2 = double2{0.0, 0.0};
   if (NJ > 3 && (F & F_ROT)) { // tip directions of the stepper's origin / current tip rotations
     ll.rot0 = ld.load(FD::ORG_DIR / 2);
@@ -60,23 +69,25 @@ __device__ __forceinline__ void load_leg_issue(LegLoad<NJ> &ll, const DevState &
     ll.rot2 = ld.load(FD::ORG_DIR / 2 + 2);
   }
   if (FT::adm(P)) {
-    ll.adm = ld.load(FD::ADM / 2);
-    if (P.dynamic_stiffness) ll.stiff = ld.load(FD::ADM_DELTA / 2 + 1); // virtual_stiffness_ persists while STOPPED
+    if (ROLE != ROLE_FRONT) ll.adm = ld.load(FD::ADM / 2);
+    if (ROLE != ROLE_BACK && P.dynamic_stiffness) ll.stiff = ld.load(FD::ADM_DELTA / 2 + 1); // virtual_stiffness_ persists while STOPPED
   }
-  if (FT::tipf(P)) {
+  if (FT::tipf(P) && ROLE != ROLE_FRONT) {
     ll.tf0 = ld.load(FD::TF / 2);
     ll.tf1 = ld.load(FD::TF / 2 + 1);
   }
 }
-template <int NJ>
+template <int NJ, int ROLE = ROLE_ALL>
 __device__ __forceinline__ void load_leg_finish(LegRegs<NJ> &s, const Park &pk, const LegLoad<NJ> &ll) {
   using FD = Fields<NJ>;
   const double(&flat)[FD::CORE_END] = ll.flat;
   s.word = ll.word;
   // swing origin / velocity, stance origin and default tip go straight to the per-lane LDS strip
   static_assert(FD::SVEL == FD::SORG + 3 && FD::TORG == FD::SORG + 6 && FD::DFLT == FD::SORG + 9, "park layout");
+  if (ROLE != ROLE_BACK) {
 #pragma unroll
-  for (int k = 0; k < PK_COUNT; ++k) pk.d[k * 64 + pk.lane] = flat[FD::SORG + k];
+    for (int k = 0; k < PK_COUNT; ++k) pk.d[k * 64 + pk.lane] = flat[FD::SORG + k];
+  }
   s.tip = V3{flat[FD::TIP + 0], flat[FD::TIP + 1], flat[FD::TIP + 2]};
   s.targ = V3{flat[FD::TARG + 0], flat[FD::TARG + 1], flat[FD::TARG + 2]};
   s.strd = V3{flat[FD::STRD + 0], flat[FD::STRD + 1], flat[FD::STRD + 2]};
@@ -94,7 +105,7 @@ __device__ __forceinline__ void load_leg_finish(LegRegs<NJ> &s, const Park &pk, 
   s.cur_dir = V3{ll.rot1.y, ll.rot2.x, ll.rot2.y};
 }
 
-template <int NJ, unsigned F>
+template <int NJ, unsigned F, int ROLE = ROLE_ALL>
 __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &out, const Park &pk, const DevState &st, const CycleParams &P,
                                           uint32_t slot, unsigned dirty) {
   using FD = Fields<NJ>;
@@ -109,7 +120,7 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   flat[FD::TIP] = s.tip.x, flat[FD::TIP + 1] = s.tip.y, flat[FD::TIP + 2] = s.tip.z;
   flat[FD::TVEL] = s.tvel.x, flat[FD::TVEL + 1] = s.tvel.y, flat[FD::TVEL + 2] = s.tvel.z;
 #pragma unroll
-  for (int k = 0; k < PK_COUNT; ++k) flat[FD::SORG + k] = pk.d[k * 64 + pk.lane];
+  for (int k = 0; k < PK_COUNT; ++k) flat[FD::SORG + k] = ROLE == ROLE_BACK ? 0.0 : pk.d[k * 64 + pk.lane];
   flat[FD::TARG] = s.targ.x, flat[FD::TARG + 1] = s.targ.y, flat[FD::TARG + 2] = s.targ.z;
   flat[FD::STRD] = s.strd.x, flat[FD::STRD + 1] = s.strd.y, flat[FD::STRD + 2] = s.strd.z;
   // swing origin position / velocity and stance origin / default tip change once per step period: their planes are
@@ -120,21 +131,22 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     const bool swing_org = 2 * p >= FD::SORG && 2 * p < FD::TORG, stance_org = 2 * p >= FD::TORG && 2 * p < FD::TARG;
     if (swing_org && !(dirty & DIRTY_SWING_ORG)) continue;
     if (stance_org && !(dirty & DIRTY_STANCE_ORG)) continue;
+    if ((ROLE == ROLE_FRONT && p < NJ) || (ROLE == ROLE_BACK && p >= NJ)) continue;
     ld.store(p, double2{flat[2 * p], flat[2 * p + 1]});
   }
-  if (FT::adm(P)) {
+  if (FT::adm(P) && ROLE != ROLE_FRONT) { // (the two-wave kernel's model half receives s.stiff from the walker half before it stores)
     ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});
     ld.store(FD::ADM_DELTA / 2, double2{out.adm_delta.x, out.adm_delta.y});
     ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, s.stiff});
   }
-  if (FT::tipf(P)) {
+  if (FT::tipf(P) && ROLE != ROLE_FRONT) {
     ld.store(FD::TF / 2, double2{s.tf.x, s.tf.y});
     ld.store(FD::TF / 2 + 1, double2{s.tf.z, 0.0});
   }
   // LegState outputs: the model tip is FK(q) and, without per-leg auto poses, the poser tip is the walker tip seen from
   // Model::current_pose_ - both are derived from the stored state when a getter asks (derive_tips_kernel), not written
   // every launch.  Only the auto-pose path's per-leg pose is not recoverable, so it stores its poser tip.
-  if (FT::autop(P) && !FT::imu(P)) {
+  if (FT::autop(P) && !FT::imu(P) && ROLE != ROLE_BACK) {
     ld.store(FD::POSER_TIP / 2, double2{out.poser_tip.x, out.poser_tip.y});
     ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
   }
@@ -144,7 +156,7 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     ld.store(FD::ORG_DIR / 2 + 1, double2{s.org_dir.z, s.cur_dir.x});
     ld.store(FD::ORG_DIR / 2 + 2, double2{s.cur_dir.y, s.cur_dir.z});
   }
-  st.legi[slot] = s.word;
+  if (ROLE != ROLE_BACK) st.legi[slot] = s.word;
 }
 
 // Robot state lives in HBM as one contiguous tile per wave, [wave][field][RPW] (AoSoA): staging fields [F0, F1) of this
@@ -232,6 +244,43 @@ __device__ __forceinline__ void ring_to_tile(const double *rec, double *tile_at,
   }
 }
 
+// What was posted for cycle c (header words h0, h1; anything but tag c + 1 = nothing posted, inputs held): fresh robot inputs go
+// to the LDS tile (ROBOT), the per-leg inputs are read where they lie - only their ring position is noted (LEG).
+template <int RPW, bool ROBOT, bool LEG>
+__device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, const unsigned c, const u64 h0, const u64 h1, const int64_t wave, const int lane,
+                                                     double *tile, int32_t *tile_i, unsigned &dirty, ResidentHeld &held) {
+  using R = RobotFields;
+  if (h0 != u64(c) + 1) return;
+  const unsigned mask = unsigned(h1) & 0xffffu;
+  held.seen |= mask;
+  auto pos = [&](int grp) { return int((h1 >> (16 + 8 * grp)) & 0xff); };
+  if (ROBOT) {
+    if (mask & (1u << RG_VEL))
+      ring_to_tile<RPW, 3>(A.rin + ((int64_t(pos(RG_VEL)) * A.n_waves + wave) * RIN_COUNT + RIN_VEL) * RPW, tile + R::VIN * RPW, lane);
+    if (mask & (1u << RG_IMU)) {
+      const double *rec = A.rin + ((int64_t(pos(RG_IMU)) * A.n_waves + wave) * RIN_COUNT + RIN_IMU) * RPW;
+      ring_to_tile<RPW, 4>(rec, tile + R::IMUQ * RPW, lane);
+      ring_to_tile<RPW, 3>(rec + 4 * RPW, tile + R::GYRO * RPW, lane);
+    }
+    if (mask & (1u << RG_POSE)) {
+      static_assert(R::RVI == R::TVI + 3, "pose inputs are contiguous in the tile");
+      ring_to_tile<RPW, 6>(A.rin + ((int64_t(pos(RG_POSE)) * A.n_waves + wave) * RIN_COUNT + RIN_POSE) * RPW, tile + R::TVI * RPW, lane);
+      dirty |= DIRTY_MANUAL;
+    }
+    if (mask & (1u << RG_RESET)) {
+      if (lane < RPW)
+        tile_i[R::I_RESET_MODE * RPW + lane] = int(unsigned(ld_agent(reinterpret_cast<const u64 *>(A.rini) + ((int64_t(pos(RG_RESET)) * A.n_waves + wave) * RPW + lane))));
+      dirty |= DIRTY_MANUAL;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier(); // LDS operations of one wave complete in order: the tile now holds the new inputs
+  }
+  if (LEG) {
+    if (mask & (1u << RG_FORCE)) held.src_force = pos(RG_FORCE);
+    if (mask & (1u << RG_EFFORT)) held.src_effort = pos(RG_EFFORT);
+  }
+}
+
 template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevState &st, LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C,
                                               const RobTile<64 / L> &rb, const Park &pk, const Group<L> g, const int leg, const uint32_t slot,
@@ -284,32 +333,7 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
       n0v = ld_agent(hp);
       n1v = ld_agent(hp + 1);
     }
-    if (h0 == u64(c) + 1) { // fresh input groups: robot inputs go to the LDS tile, per-leg inputs are read where they lie
-      const unsigned mask = unsigned(h1) & 0xffffu;
-      held.seen |= mask;
-      auto pos = [&](int grp) { return int((h1 >> (16 + 8 * grp)) & 0xff); };
-      if (mask & (1u << RG_VEL))
-        ring_to_tile<RPW, 3>(A.rin + ((int64_t(pos(RG_VEL)) * A.n_waves + wave) * RIN_COUNT + RIN_VEL) * RPW, tile + R::VIN * RPW, lane);
-      if (mask & (1u << RG_IMU)) {
-        const double *rec = A.rin + ((int64_t(pos(RG_IMU)) * A.n_waves + wave) * RIN_COUNT + RIN_IMU) * RPW;
-        ring_to_tile<RPW, 4>(rec, tile + R::IMUQ * RPW, lane);
-        ring_to_tile<RPW, 3>(rec + 4 * RPW, tile + R::GYRO * RPW, lane);
-      }
-      if (mask & (1u << RG_POSE)) {
-        static_assert(R::RVI == R::TVI + 3, "pose inputs are contiguous in the tile");
-        ring_to_tile<RPW, 6>(A.rin + ((int64_t(pos(RG_POSE)) * A.n_waves + wave) * RIN_COUNT + RIN_POSE) * RPW, tile + R::TVI * RPW, lane);
-        dirty |= DIRTY_MANUAL;
-      }
-      if (mask & (1u << RG_RESET)) {
-        if (lane < RPW)
-          tile_i[R::I_RESET_MODE * RPW + lane] = int(unsigned(ld_agent(reinterpret_cast<const u64 *>(A.rini) + ((int64_t(pos(RG_RESET)) * A.n_waves + wave) * RPW + lane))));
-        dirty |= DIRTY_MANUAL;
-      }
-      if (mask & (1u << RG_FORCE)) held.src_force = pos(RG_FORCE);
-      if (mask & (1u << RG_EFFORT)) held.src_effort = pos(RG_EFFORT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier(); // LDS operations of one wave complete in order: the tile now holds the new inputs
-    }
+    resident_take_inputs<64 / L, true, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held);
     const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
                            held.src_effort < 0 ? st.legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2,
                            ns, slot};
@@ -639,6 +663,271 @@ __global__ void __launch_bounds__(64, SHC_WAVES_PER_SIMD) shc_resident_kernel(De
     return;
   }
   cycle_wave<L, NJ, F, true>(st, gc, 0, rt_flags, int64_t(blockIdx.x) - 1, &ra);
+}
+
+// ================================================================================ resident mode, two wavefronts per robot group
+// At batch sizes where resident mode applies most SIMDs of the chip have nothing to run, and one wavefront's cycle is one long
+// dependent instruction stream (about 2 400 instructions at one 4-clock issue slot each).  This kernel gives every robot group
+// TWO wavefronts on two SIMDs of one compute unit and pipelines the cycle across them:
+//   walker wave  : cycle_front of cycle c + 1 - pose, velocity limiting, walk state machine, Bezier stepper, updateStance
+//   model wave   : cycle_back of cycle c      - admittance, desired tip, DLS IK step, joint integration, FK, tip force, q / qd out
+// The model half needs nothing but the poser tip of its leg (24 bytes per lane, through a double-buffered LDS mailbox) and the
+// walker half needs nothing of the model half (true for every specialisation without rough terrain / tip rotations: the walker
+// integrates its own tip; Leg::applyIK feeds back into the walker only through rough-terrain touchdown and tip-align poses).
+// Same arithmetic, same order per leg: results are bit-identical to one wave running whole cycles.  256-thread workgroups = two
+// robot groups x (walker, model): the four waves of a workgroup always get the four SIMDs of their CU (scripts/ubench/
+// wave_placement.hip), and with at most one such workgroup per CU no SIMD is shared.
+// Control is workgroup-uniform: the leader (wave 0) watches the gate and announces, one iteration ahead, what the next iteration
+// is (REAL: run a cycle, BUBBLE: nothing released yet, EXIT) together with the header of that cycle; one barrier per iteration.
+enum : int { IT_REAL = 1, IT_BUBBLE = 2, IT_EXIT = 3 };
+template <int L, int NJ>
+struct Resident2Lds { // dynamic LDS of one workgroup, after the two walker waves' tiles
+  double mailbox[2][2][3][64]; // [pair][cycle parity][xyz][lane]: PoseController::updateStance -> Leg::setDesiredTipPose
+  double stiff[2][64];         // walker -> model at exit (published virtual stiffness shares a plane with the admittance delta)
+  int ikfail[2][64];           // model -> walker at exit (IK-deviation flag lives in the leg word)
+  unsigned long long ctrl[4][4]; // [iteration & 3]: kind, h0, h1, -
+};
+
+template <int L, int NJ, unsigned F>
+__global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs A, unsigned rt_flags) {
+  using R = RobotFields;
+  using FD = Fields<NJ>;
+  using FT = Feat<F>;
+  constexpr int RPW = 64 / L;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < 64) resident_relay(A);
+    return;
+  }
+  __shared__ SharedConsts<L, NJ> C;
+  extern __shared__ double wave_lds[];
+  constexpr int kWaveDoubles = R::COUNT * RPW + PK_COUNT * 64 + (R::I_COUNT * RPW + 1) / 2;
+  Resident2Lds<L, NJ> &X = *reinterpret_cast<Resident2Lds<L, NJ> *>(wave_lds + 2 * kWaveDoubles);
+  const bool manual_live = (rt_flags & RT_MANUAL_LIVE) != 0;
+  const int lane = threadIdx.x & 63;
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wib & 1;
+  const bool walker = wib < 2, leader = wib == 0;
+  const int64_t wave = (int64_t(blockIdx.x) - 1) * 2 + pair;
+  const bool active = wave < A.n_waves;
+  const int64_t rob0 = wave * RPW;
+  const int64_t left = st.n_robots - rob0;
+  const int robots_here = !active ? 0 : (left < RPW ? (left < 0 ? 0 : int(left)) : RPW);
+  int grp = lane / L;
+  const int leg = lane - grp * L;
+  const bool live = grp < robots_here;
+  if (grp >= robots_here) grp = robots_here > 0 ? robots_here - 1 : 0;
+  const uint32_t slot = uint32_t((active ? wave : 0) * 64 + grp * L + leg);
+  double *const my_lds = wave_lds + pair * kWaveDoubles;
+  Park pk{my_lds + R::COUNT * RPW, lane};
+  double *tile = my_lds;
+  int32_t *tile_i = reinterpret_cast<int32_t *>(my_lds + R::COUNT * RPW + PK_COUNT * 64);
+  double *gtile = st.robd + (active ? wave : 0) * (R::COUNT * RPW);
+  int32_t *gtile_i = st.robi + (active ? wave : 0) * (R::I_COUNT * RPW);
+  const CycleParams &GP = gc->P;
+  LegRegs<NJ> s;
+  // ---- prologue: tables (all four waves), robot tile (walker), the half of the leg state this wave owns
+  {
+    using SC = SharedConsts<L, NJ>;
+    constexpr int n16_all = sizeof(SC) / 16;
+    constexpr int n16_core = (offsetof(SC, P) + offsetof(CycleParams, ap_start)) / 16;
+    const int n16 = FT::autop(GP) ? n16_all : n16_core;
+    const double2 *src = reinterpret_cast<const double2 *>(gc);
+    double2 *dst = reinterpret_cast<double2 *>(&C);
+    for (int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+  }
+  LegLoad<NJ> ll;
+  if (active) {
+    if (walker) {
+      load_leg_issue<NJ, F, ROLE_FRONT>(ll, st, GP, slot);
+      for (int i = lane; i < R::COUNT * RPW; i += 64) tile[i] = gtile[i];
+      for (int i = lane; i < R::I_COUNT * RPW; i += 64) tile_i[i] = gtile_i[i];
+      load_leg_finish<NJ, ROLE_FRONT>(s, pk, ll);
+    } else {
+      load_leg_issue<NJ, F, ROLE_BACK>(ll, st, GP, slot);
+      load_leg_finish<NJ, ROLE_BACK>(s, pk, ll);
+    }
+  }
+  if (leader && lane == 0) { // what iteration 0 is: nothing has been released yet unless the host was quick
+    X.ctrl[0][0] = IT_BUBBLE;
+    X.ctrl[0][1] = X.ctrl[0][2] = 0;
+  }
+  __syncthreads();
+  const CycleParams &P = C.P;
+  Group<L> g{grp * L};
+  RobTile<RPW> rb{tile, tile_i, grp};
+  LegOut out;
+  out.poser_tip = out.model_tip = out.adm_delta = V3{0, 0, 0};
+  s.tipx = V3{1, 0, 0};
+  if (active && !walker) { // Leg::applyFK of the previous cycle, as in cycle_wave
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) sincos_joint(C.leg[leg].link_th[k] + s.q[k], &s.sn[k], &s.cs[k]);
+    if (FT::adm(P) || LegRegs<NJ>::kKeepJacobian) {
+      Chain<NJ> ch;
+      chain_from_sincos<NJ>(C.leg[leg], s.sn, s.cs, ch);
+      if (LegRegs<NJ>::kKeepJacobian) {
+        jacobian_columns<NJ>(ch, s.lin);
+        s.pe = ch.pe;
+      }
+      if (FT::adm(P)) s.tipx = base_rotate(C.leg[leg], ch.xe);
+    }
+    s.word = 0;
+  }
+  unsigned dirty = 0;
+  ResidentHeld held;
+  const int64_t ns = st.n_slots;
+  const unsigned out_slot_bytes = unsigned(NJ * ns * 16);
+  const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
+  const u64 emergency_ticks = 4 * A.idle_ticks + 200000000ull;
+  unsigned k = 0, c_front = 0, c_back = 0, oslot = 0; // iteration; cycles whose walker half has run; cycles completed; output ring position
+  bool prev_real = false;
+  u64 prev_h0 = 0, prev_h1 = 0;
+  u64 gate_pref = leader ? ld_agent(&A.ctl->gate) : 0;
+  u64 bubble_since = 0;
+  FrontToBack fb{V3{1, 0, 0}, false, LS_WALKING};
+  for (;;) {
+    const int kind = __builtin_amdgcn_readfirstlane(int(X.ctrl[k & 3][0]));
+    const u64 h0 = uni64(X.ctrl[k & 3][1]), h1 = uni64(X.ctrl[k & 3][2]);
+    if (walker) {
+      int nk = IT_EXIT;
+      u64 nh0v = 0, nh1v = 0;
+      if (leader && kind != IT_EXIT) { // what will iteration k + 1 be?
+        u64 gate;
+        if (kind == IT_BUBBLE) {
+          __builtin_amdgcn_s_sleep(2);
+          gate = uni64(ld_agent(&A.ctl->gate)); // nothing else to do: look again
+        } else {
+          gate = uni64(gate_pref); // read one iteration ago: at worst the loop learns of a release one iteration late
+        }
+        const unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
+        const unsigned cn = c_front + (kind == IT_REAL ? 1u : 0u); // the cycle iteration k + 1 would start
+        nk = cn >= sp ? IT_EXIT : (cn < db ? IT_REAL : IT_BUBBLE);
+        if (nk == IT_BUBBLE) {
+          const u64 now = wall_clock64();
+          if (bubble_since == 0) bubble_since = now;
+          else if (now - bubble_since > emergency_ticks) nk = IT_EXIT, held.fault = true;
+        } else {
+          bubble_since = 0;
+        }
+        if (nk == IT_REAL) {
+          const u64 *hp = reinterpret_cast<const u64 *>(A.headers + (cn & (kResidentHeaders - 1)));
+          nh0v = ld_agent(hp);
+          nh1v = ld_agent(hp + 1);
+        }
+        gate_pref = ld_agent(&A.ctl->gate);
+      }
+      if (kind == IT_REAL && active) {
+        resident_take_inputs<RPW, true, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
+        cycle_front<L, NJ, F, false>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
+                                     LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb);
+        double *mb = &X.mailbox[pair][c_front & 1][0][lane];
+        mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
+      }
+      if (leader && kind != IT_EXIT && lane == 0) {
+        X.ctrl[(k + 1) & 3][0] = u64(nk);
+        X.ctrl[(k + 1) & 3][1] = nh0v;
+        X.ctrl[(k + 1) & 3][2] = nh1v;
+      }
+    } else if (active) {
+      if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
+        resident_take_inputs<RPW, false, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held);
+        const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
+                               held.src_effort < 0 ? st.legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2,
+                               ns, slot};
+        const double *mb = &X.mailbox[pair][c_back & 1][0][lane];
+        out.poser_tip = V3{mb[0], mb[64], mb[128]};
+        out.adm_delta = V3{0, 0, 0};
+        if (FT::adm(P)) cycle_admittance<NJ>(s, out, P, in);
+        s.word = 0;
+        cycle_back<L, NJ, F>(s, out, C, leg, st.legd, ns, slot, nullptr, in, fb);
+        // the output stores of cycle c_back - 1 were issued one iteration ago: they have drained - announce them, then issue this cycle's
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_agent(A.progress + wave, u64(c_back));
+        {
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          double flat[2 * NJ];
+#pragma unroll
+          for (int i = 0; i < NJ; ++i) flat[FD::Q + i] = s.q[i], flat[FD::QD + i] = s.qd[i];
+          const unsigned soff = oslot * out_slot_bytes;
+          if (live) {
+#pragma unroll
+            for (int p = 0; p < NJ; ++p) {
+              const u64 a = u64(__double_as_longlong(flat[2 * p])), b = u64(__double_as_longlong(flat[2 * p + 1]));
+              const v4u w = {unsigned(a), unsigned(a >> 32), unsigned(b), unsigned(b >> 32)};
+              __builtin_amdgcn_raw_buffer_store_b128(w, out_rsrc, unsigned((int64_t(p) * ns + slot) * 16), soff, 16 /* sc1 */);
+            }
+          }
+        }
+        ++c_back;
+        oslot = oslot + 1 == unsigned(A.depth) ? 0 : oslot + 1;
+      }
+      if (kind != IT_REAL) { // the pipeline runs dry: nothing will follow for a while (or ever) - announce what is done now
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) st_agent(A.progress + wave, u64(c_back));
+      }
+    }
+    if (kind == IT_EXIT) break;
+    if (kind == IT_REAL) ++c_front;
+    prev_real = kind == IT_REAL;
+    prev_h0 = h0, prev_h1 = h1;
+    __syncthreads();
+    ++k;
+  }
+  // ---- epilogue: the halves exchange what the other one stores, then each writes its half of the state back
+  if (active) {
+    if (walker) X.stiff[pair][lane] = s.stiff;
+    else X.ikfail[pair][lane] = s.word & LW_IKFAIL;
+  }
+  __syncthreads();
+  if (!active) return;
+  if (walker) {
+    if (c_front > 0) s.word = (s.word & ~LW_IKFAIL) | X.ikfail[pair][lane];
+    {
+      unsigned d = 0;
+#pragma unroll
+      for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
+        if (__any((dirty & b) != 0)) d |= b;
+      dirty = d;
+    }
+    if (live) store_leg<NJ, F, ROLE_FRONT>(s, out, pk, st, P, slot, dirty);
+    __builtin_amdgcn_wave_barrier();
+    store_rob_fields<RPW, 0, R::PLANE>(tile, gtile, lane);
+    if (dirty & DIRTY_WALK_PLANE) store_rob_fields<RPW, R::PLANE, R::VIN>(tile, gtile, lane);
+    if (FT::manual(P) && manual_live && (dirty & DIRTY_MANUAL)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
+    if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
+    if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
+    store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane);
+    if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::ODOM_END>(tile, gtile, lane);
+    if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
+    // the inputs the run received become the engine's held inputs
+    store_rob_fields<RPW, R::VIN, R::CORE_END>(tile, gtile, lane);
+    if (held.seen & (1u << RG_IMU)) {
+      store_rob_fields<RPW, R::GYRO, R::IMU_END>(tile, gtile, lane);
+      store_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(tile, gtile, lane);
+    }
+    if ((held.seen & (1u << RG_RESET)) && lane < RPW) gtile_i[R::I_RESET_MODE * RPW + lane] = tile_i[R::I_RESET_MODE * RPW + lane];
+    if (lane == 0) {
+      if (held.fault) __hip_atomic_fetch_or(&A.ctl->fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&A.ctl->exited, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else {
+    s.stiff = X.stiff[pair][lane];
+    if (live) {
+      store_leg<NJ, F, ROLE_BACK>(s, out, pk, st, P, slot, 0);
+      double2 *planes = reinterpret_cast<double2 *>(st.legd);
+      if (held.src_force >= 0) {
+        const double *src = A.force + int64_t(held.src_force) * 2 * ns * 2;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          planes[(FD::FORCE_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
+      }
+      if (held.src_effort >= 0) {
+        const double *src = A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2;
+#pragma unroll
+        for (int p = 0; p < FD::NJE / 2; ++p)
+          planes[(FD::EFFORT_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
+      }
+    }
+  }
 }
 
 } // namespace shc

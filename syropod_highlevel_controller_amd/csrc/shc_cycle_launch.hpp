@@ -68,12 +68,14 @@ struct CycleLaunch {
   unsigned grid;
   int block;
   int n_cycles;
-  const ResidentArgs *resident; // != nullptr: launch the resident kernel (grid = n_waves + 1 relay block, 64 threads each)
+  const ResidentArgs *resident; // != nullptr: launch the resident kernel (block = 64: grid = n_waves + 1 relay block of 64 threads, one
+                                // wavefront per robot group; block = 256: the two-wavefront pipeline, grid = ceil(n_waves / 2) + 1)
   struct ResidentFit *fit;      // != nullptr: launch nothing, report whether / how densely the resident kernel of this specialisation fits
 };
 struct ResidentFit {
   int supported;          // this specialisation has a resident kernel
   int blocks_per_cu;      // hipOccupancyMaxActiveBlocksPerMultiprocessor of it (64-thread blocks with its per-wave LDS)
+  int two_wave;           // the two-wavefront pipeline exists for it (256-thread blocks, at most one per compute unit)
 };
 
 // One per (legs, joints); defined by shc_cycle_inst.hip.  Returns false when that morphology has no kernels in this build.

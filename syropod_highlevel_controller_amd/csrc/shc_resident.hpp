@@ -30,6 +30,7 @@ struct Resident {
   unsigned max_cycles = 0;
   bool stream_doorbell_pending = false;     // a doorbell value travels on in_stream behind the posts it releases
   unsigned groups_posted = 0;
+  bool two_wave = false;                    // the two-wavefront (walker / model) pipeline is running
 };
 
 __global__ void resident_doorbell_kernel(ResidentHost *host, unsigned long long value) {
@@ -150,7 +151,7 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   if (e->starting_up) return fail(SHC_ERR_UNSUPPORTED, "resident mode starts from a running engine (finish the start-up first)");
   HIP_TRY(hipSetDevice(e->device));
   // does this configuration have a resident kernel, and does the whole batch fit the chip at once (+ the relay block)?
-  ResidentFit fit{0, 0};
+  ResidentFit fit{0, 0, 0};
   {
     CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, 0, 64, 0, nullptr, &fit};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
@@ -238,7 +239,12 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   A.idle_ticks = (unsigned long long)(idle_timeout_ms ? idle_timeout_ms : 2000) * (unsigned long long)wall_khz;
   A.n_waves = e->n_waves;
   e->plan_poser_tips_current = false;
-  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, unsigned(e->n_waves + 1), 64, 0, &A, nullptr};
+  // Two wavefronts per robot group (walker / model halves of the cycle pipelined over two SIMDs) while every 256-thread workgroup
+  // - two robot groups - and the relay get a compute unit of their own; one wavefront per group above that.
+  const bool two_wave = fit.two_wave && !(e->features & SHC_FEAT_RESIDENT_ONE_WAVE) && (e->n_waves + 1) / 2 + 1 <= prop.multiProcessorCount;
+  r->two_wave = two_wave;
+  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream,
+                two_wave ? unsigned((e->n_waves + 1) / 2 + 1) : unsigned(e->n_waves + 1), two_wave ? 256 : 64, 0, &A, nullptr};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL

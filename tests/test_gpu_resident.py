@@ -60,10 +60,13 @@ def force_sample(rng, n, legs):
     return np.stack([rng.normal(0, 1, (n, legs)), rng.normal(0, 1, (n, legs)), rng.uniform(0, 20, (n, legs))], axis=2)
 
 
+@pytest.mark.parametrize("waves", ["two_waves", "one_wave"])
 @pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4"])
-def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case):
+def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves):
     """Every cycle gets new inputs.  Engine A: set_* + shc_engine_step(1) per cycle.  Engine B: one resident launch, inputs posted per
-    cycle.  q / qd of EVERY cycle (output ring) and the complete state record at the end are equal byte for byte."""
+    cycle.  q / qd of EVERY cycle (output ring) and the complete state record at the end are equal byte for byte - for the
+    two-wavefront (walker / model) pipeline, which these batch sizes get by default, and for one wavefront per robot group."""
+    from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE
     rng = np.random.default_rng(11)
     if case == "config2":
         p, n = default_hexapod_params("tripod"), 333
@@ -78,6 +81,8 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case):
     imus = [imu_sample(rng, n) for _ in range(cycles)] if case == "config3" else None
     forces = [force_sample(rng, n, p.leg_count) if c % 3 == 0 else None for c in range(cycles)] if case == "config3" else None
     a, b = Engine(p, n), Engine(p, n)
+    if waves == "one_wave":
+        b.set_features(FEAT_DEFAULT | FEAT_RESIDENT_ONE_WAVE)
     for e in (a, b):   # some history before the resident run starts
         e.set_velocity(*sched[0])
         e.step(37)
