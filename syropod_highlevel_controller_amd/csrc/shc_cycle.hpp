@@ -189,7 +189,11 @@ struct DevState {
 #define SHC_PHASE_FENCE() do {} while (0)
 #endif
 // Development-only phase timestamps (build with -DSHC_TIMING): wave 0 / lane 0 stores s_memtime at phase boundaries.
-#ifdef SHC_TIMING
+#if defined(SHC_RES2_TIMING)
+// ... of the two-wavefront resident kernel: the leader of workgroup 1 keeps the stamps of its latest iteration in LDS
+__shared__ long long shc_ticks_lds[32];
+#define SHC_TICK(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 1 && threadIdx.x == 0) shc_ticks_lds[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#elif defined(SHC_TIMING)
 __device__ long long *shc_tick_buf = nullptr;
 #define SHC_TICK(i) do { __builtin_amdgcn_sched_barrier(0); if (shc_tick_on) shc_tick_buf[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -1242,6 +1246,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   fb.rot_def = rot_def;
   fb.my_leg_state = my_leg_state;
   SHC_PHASE_FENCE();
+  SHC_TICK(15);
 }
 
 // The model half of a cycle: Model::updateModel (model.cpp:142-152) - Leg::setDesiredTipPose, applyIK (one DLS step, joint

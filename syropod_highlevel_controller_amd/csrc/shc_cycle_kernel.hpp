@@ -784,7 +784,14 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   u64 gate_pref = leader ? ld_agent(&A.ctl->gate) : 0;
   u64 bubble_since = 0;
   FrontToBack fb{V3{1, 0, 0}, false, LS_WALKING};
+#ifdef SHC_RES2_TIMING
+  long long tm_busy = 0, tm_total0 = __builtin_readcyclecounter(), tm_real = 0;
+#endif
   for (;;) {
+#ifdef SHC_RES2_TIMING
+    const long long tm0 = __builtin_readcyclecounter();
+    SHC_TICK(19);
+#endif
     const int kind = __builtin_amdgcn_readfirstlane(int(X.ctrl[k & 3][0]));
     const u64 h0 = uni64(X.ctrl[k & 3][1]), h1 = uni64(X.ctrl[k & 3][2]);
     if (walker) {
@@ -815,18 +822,22 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         }
         gate_pref = ld_agent(&A.ctl->gate);
       }
+      SHC_TICK(20);
       if (kind == IT_REAL && active) {
         resident_take_inputs<RPW, true, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
+        SHC_TICK(21);
         cycle_front<L, NJ, F, false>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
                                      LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
+        SHC_TICK(22);
       }
       if (leader && kind != IT_EXIT && lane == 0) {
         X.ctrl[(k + 1) & 3][0] = u64(nk);
         X.ctrl[(k + 1) & 3][1] = nh0v;
         X.ctrl[(k + 1) & 3][2] = nh1v;
       }
+      SHC_TICK(23);
     } else if (active) {
       if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
         resident_take_inputs<RPW, false, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held);
@@ -866,12 +877,23 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       }
     }
     if (kind == IT_EXIT) break;
+#ifdef SHC_RES2_TIMING
+    if (kind == IT_REAL && prev_real) tm_busy += __builtin_readcyclecounter() - tm0, ++tm_real;
+#endif
     if (kind == IT_REAL) ++c_front;
     prev_real = kind == IT_REAL;
     prev_h0 = h0, prev_h1 = h1;
     __syncthreads();
     ++k;
   }
+#ifdef SHC_RES2_TIMING
+  if (blockIdx.x == 1 && lane == 0 && pair == 0) { // development: clocks from iteration start to the barrier, REAL iterations in steady state
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(A.ctl) + 8 + (walker ? 0 : 4);
+    dbg[0] = tm_busy, dbg[1] = tm_real, dbg[2] = __builtin_readcyclecounter() - tm_total0, dbg[3] = k;
+    if (walker)
+      for (int i = 0; i < 32; ++i) dbg[8 + i] = (unsigned long long)shc_ticks_lds[i];
+  }
+#endif
   // ---- epilogue: the halves exchange what the other one stores, then each writes its half of the state back
   if (active) {
     if (walker) X.stiff[pair][lane] = s.stiff;

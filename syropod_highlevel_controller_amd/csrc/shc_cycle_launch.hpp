@@ -21,7 +21,8 @@ struct ResidentCtl { // device memory, polled with agent-scope loads; written by
   unsigned long long gate;      // (stop << 32) | doorbell: run cycle c (counted from resident_begin) while c < min(doorbell, stop)
   unsigned long long exited;    // worker waves that have left the loop
   unsigned long long fault;     // != 0: a worker gave up waiting (emergency bound) - state may be inconsistent
-  unsigned long long pad;
+  unsigned long long pad[5];
+  unsigned long long dbg[40];   // development builds (-DSHC_RES2_TIMING): phase clocks of workgroup 1
 };
 struct ResidentHost { // pinned host memory mapped into the device (fine-grained): the host side of the handshake
   unsigned long long doorbell;  // host / producer -> device: cycles published since resident_begin

@@ -440,6 +440,19 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   const bool answered = spin_until([&] { return host_load(&r->host->exited) != 0; }, 30.0);
   hipError_t err = answered ? hipStreamSynchronize(e->stream) : hipErrorNotReady;
   r->active = false;
+#ifdef SHC_RES2_TIMING
+  if (answered && err == hipSuccess) {
+    ResidentCtl c;
+    (void)hipMemcpy(&c, r->ctl, sizeof c, hipMemcpyDeviceToHost);
+    for (int w = 0; w < 2; ++w)
+      fprintf(stderr, "[res2 timing] %s: %.0f clocks busy per steady REAL iteration (%llu of them), loop %llu clocks, %llu iterations\n", w ? "model " : "walker",
+              c.dbg[4 * w + 1] ? double(c.dbg[4 * w]) / double(c.dbg[4 * w + 1]) : 0.0, c.dbg[4 * w + 1], c.dbg[4 * w + 2], c.dbg[4 * w + 3]);
+    const int order[] = {19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 15, 22, 23};
+    fprintf(stderr, "[res2 timing] walker leader, last iteration, clocks since its start:");
+    for (int i : order) fprintf(stderr, " t%d=%lld", i, (long long)c.dbg[8 + i] - (long long)c.dbg[8 + 19]);
+    fprintf(stderr, "\n");
+  }
+#endif
   const unsigned long long reason = host_load(&r->host->exited), done = host_load(&r->host->done);
   if (cycles_run) *cycles_run = int64_t(done);
   if (r->groups_posted & (1u << RG_FORCE)) e->rt_flags |= RT_TOUCHDOWN; // as shc_engine_set_tip_force (state_controller.cpp:1642)

@@ -76,7 +76,7 @@ def _sources():
 # dependent ops issue every 8 clocks, LDS reads return after ~60); the ILP-first scheduler spends the spare VGPRs
 # (the occupancy target of 2 waves/SIMD allows 256) on overlapping independent chains.
 _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-          "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+          "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"] + os.environ.get("SHC_EXTRA_FLAGS", "").split()  # (development builds)
 
 
 def _translation_units():
