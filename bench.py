@@ -7,17 +7,24 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 
 * metric / unit: BASELINE.json's ``control-cycles/sec (all legs IK-solved)``.
 * workload (N = 1): BASELINE.json configs[1] — 4 096 default.yaml hexapods (6 legs x 3 DOF), tripod gait, the full
   per-cycle path (velocity limiting + walk FSM + Bezier tip trajectory + body pose + per-leg DLS IK/FK), synthetic
-  seeded velocity commands, every instance MOVING and de-phased before the timed region.  "IK + Bezier tip-traj only":
-  no measured joint torques are supplied, so Leg::calculateTipForce filters zeros into a zero state and the engine runs
-  the kernels without the estimate (identical results); ``--joint-efforts`` supplies torques (estimate evaluated every
-  cycle) and the default run reports that variant under ``config.also``.
-* a "step" = one launch of the fused cycle kernel = ``--cycles-per-step`` control cycles (default 1) of every
-  instance; inputs are resident in HBM (no host traffic inside the timed region).
+  seeded velocity commands, every instance MOVING and de-phased before the timed region.  Measured joint torques are
+  supplied (as jointStatesCallback does on a real node), so Leg::calculateTipForce is evaluated every cycle as in the
+  reference (model.cpp:938); ``--no-joint-efforts`` is the variant without them (the estimate is then identically zero and the
+  engine runs the kernels without it), which the default run reports under ``config.also``.
+* a "step" = one control cycle of every instance (``--cycles-per-step`` 1), inputs resident in HBM (no host traffic inside
+  the timed region).  Batches that fit the chip once (config 2) run in RESIDENT mode (``--mode auto``): one launch of the
+  cycle kernel stays on the device, state in registers / LDS from cycle to cycle, and a step is one tick of the device-side
+  doorbell (shc_engine_resident_publish(1)) - the kernel takes that cycle's inputs from the input rings (posted inputs may
+  differ every cycle: tests/test_gpu_resident.py) and writes its q / qd to the output ring.  ``--mode launch`` (and every batch
+  that does not fit) is one launch of the fused cycle kernel per step; the default run reports both.
 * N > 1: weak scaling — every rank owns ``--instances`` robots of its own (instance ranges are contiguous per rank),
   no data-path collective while stepping; the final joint-state buffer is all-gathered over RCCL inside the timed
   region (every ``--gather-every`` steps if given).
-* ``roofline``: HBM roofline of the cycle kernel — algorithmic bytes per launch (3 008 B per hexapod
-  cycle) / mean kernel duration measured with HIP events on the launch stream.
+* ``roofline``: HBM roofline of the kernel that produced ``value``.  One launch per cycle: algorithmic bytes per launch
+  (3 008 B per hexapod cycle, state streamed in and out) / mean kernel duration, HIP events on the launch
+  stream.  Resident mode: the state never leaves the chip, so per SURVEY.md §8d ("bytes/cycle fall toward the mandatory
+  output - report K and count accordingly") the algorithmic bytes of a cycle are its inputs + the desired joint state it
+  publishes (24 + 2 x legs x dof x 8 B per robot), K = cycles of the launch; duration = HIP events around the launch / K.
 * ``cpu_baseline``: the CPU oracle (a scalar restatement of the reference loop, "port") timed on this box's host
   cores on a bounded sample of the same workload.
 """
@@ -131,7 +138,40 @@ def measured_traffic(workload, n, cps):
 _TWO_STREAMS = None
 
 
-def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False, joint_efforts=False):
+def resident_bytes_per_cycle(p):
+    """SURVEY.md section 8(d), K cycles fused with the state on the chip: per robot and cycle the velocity input (24 B) and the
+    desired joint positions + velocities the cycle publishes."""
+    return 24 + 2 * p.leg_count * p.leg_dof[0] * 8
+
+
+def time_resident(eng, n, steps, warmup, stream, depth=16):
+    """Timed region of resident mode: `steps` ticks of the doorbell, one control cycle each, bracketed by synchronisation.
+    Returns (elapsed seconds for `steps` cycles, seconds per cycle of one long launch from HIP events on the launch stream)."""
+    import torch
+    eng.resident_begin(ring_depth=depth, max_cycles=warmup + steps + 8)
+    eng.resident_publish(max(warmup, 1))
+    eng.resident_wait(max(warmup, 1))
+    torch.cuda.synchronize() if False else None  # (the resident kernel owns the engine's stream: nothing to synchronise on it)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.resident_publish(1)      # one tick = one cycle; the host does not wait for it
+    eng.resident_wait(max(warmup, 1) + steps, 60000)
+    elapsed = time.perf_counter() - t0
+    eng.resident_end()
+    # kernel time per cycle: one launch of m cycles released at once, HIP events on the launch stream around it
+    m = 4000
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    eng.resident_begin(ring_depth=depth, max_cycles=m)
+    eng.resident_publish(m)
+    eng.resident_end()               # stops after the m published cycles, waits for the kernel
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return elapsed, e0.elapsed_time(e1) * 1e-3 / m
+
+
+def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False, joint_efforts=False,
+                 mode="auto"):
     """One workload on this rank's GPU: prepare (untimed), time `steps` steps, measure the kernel with HIP events.
     dist_ctx = (world, rank, local_rank) when the RCCL path is active."""
     import torch
@@ -186,21 +226,54 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             eng.joints_device(qshard.data_ptr(), None)  # SoA planes -> [n][legs][dof] on the engine's stream
             all_gather_joints(qshard, world, out=gathered)  # the helper tests/test_sharding_gloo.py runs over gloo
 
-    for _ in range(warmup):
-        step_once()
+    # resident mode: batches that fit the chip once, one cycle per step, nothing that needs a launch between steps
+    resident = False
+    if mode != "launch" and cps == 1 and not force_sets and not gather_every:
+        try:
+            eng.resident_begin(ring_depth=4, max_cycles=4)
+            eng.resident_end()
+            resident = True
+        except Exception as exc:  # noqa: BLE001
+            if mode == "resident":
+                raise
+            resident = False
+    res_cycle_s = None
+    launch_elapsed = None
     if use_dist:
         gather()
         dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step_once()
-        if gather_every and (i + 1) % gather_every == 0:
-            gather()
-    if not gather_every or steps % gather_every:
+    if resident:   # the launch-per-cycle figure of the same engine first (secondary), then the resident one
+        for _ in range(warmup):
+            step_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_once()
+        torch.cuda.synchronize()
+        launch_elapsed = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # (time_resident's own clock brackets exactly `steps` doorbell ticks; the gather of the final joints follows inside the region)
+        res_elapsed, res_cycle_s = time_resident(eng, n, steps, warmup, stream)
+        t_after = time.perf_counter()
         gather()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0  # this rank's K steps + its part of the gather; the MAX over ranks below is the job's time
+        torch.cuda.synchronize()
+        elapsed = res_elapsed + (time.perf_counter() - t_after)
+    else:
+        for _ in range(warmup):
+            step_once()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step_once()
+            if gather_every and (i + 1) % gather_every == 0:
+                gather()
+        if not gather_every or steps % gather_every:
+            gather()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0  # this rank's K steps + its part of the gather; the MAX over ranks below is the job's time
     if use_dist:
         dist.barrier()  # closing bracket (the all-gather inside the region already needed every rank's shard)
         torch.cuda.synchronize()
@@ -295,17 +368,32 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             two_streams = {"error": str(exc)[:200]}
     alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    launch_roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
+                       "algorithmic_bytes_per_launch": alg_bytes}
+    if resident:
+        rb = resident_bytes_per_cycle(p) * n
+        r_ach = rb / res_cycle_s / 1e9
+        roofline = {"bound": "hbm", "achieved": r_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r_ach / HBM_PEAK_GBS,
+                    "traffic": measured_traffic(name + ":resident", n, cps), "kernel": "shc_resident2_kernel (one launch, K = 4000 cycles; two wavefronts per robot group)",
+                    "kernel_ms": res_cycle_s * 1e3, "kernel_ms_is": "per cycle: HIP events around one launch of K cycles / K",
+                    "algorithmic_bytes_per_launch": rb, "algorithmic_bytes_are": "per cycle, SURVEY.md 8(d) with the state on the chip: velocity input + published q, qd",
+                    "state_streaming_equivalent_frac": ALG_BYTES_PER_CYCLE[key] * n / res_cycle_s / 1e9 / HBM_PEAK_GBS,
+                    "one_launch_per_cycle": launch_roofline}
+    else:
+        roofline = launch_roofline
     res = {
         "value": world * n * steps * cps / elapsed, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": f"BASELINE.json {name}: {n} {desc}", "instances_per_gpu": n, "cycles_per_step": cps,
+                   "mode": ("resident: one launch stays on the chip, a step = one doorbell tick = one control cycle with that cycle's inputs from the "
+                            "device-side rings and its q / qd to the output ring") if resident else "one launch of the fused cycle kernel per step",
+                   "one_launch_per_cycle_value": (world * n * steps * cps / launch_elapsed) if launch_elapsed else None,
                    "legs": p.leg_count, "dof": p.leg_dof[0],
                    "gather": f"all-gather of the joint buffer every {gather_every} steps" if gather_every
                    else "one all-gather of the final joint buffer (N > 1)",
                    "moving_fraction": moving_frac, "finite": finite, "seed": seed, "fused_16_cycles_per_launch_value": fused_value,
                    "two_streams": two_streams},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+        "roofline": roofline,
     }
     if want_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(p, lin, ang, extra)
@@ -378,8 +466,11 @@ def main():
     ap.add_argument("--no-fused-probe", action="store_true", help="skip the secondary 16-cycles-per-launch figure (keeps rocprof stats to one launch shape)")
     ap.add_argument("--no-also", action="store_true", help="skip the config 3 / config 4 measurements reported under config.also")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather path even with one rank")
-    ap.add_argument("--joint-efforts", action="store_true", help="supply measured joint torques: the tip-force estimate (Leg::calculateTipForce) "
-                    "is then evaluated every cycle; without them it is identically zero and the engine runs the kernels without it")
+    ap.add_argument("--joint-efforts", action="store_true", help="(default since round 3) supply measured joint torques: the tip-force estimate "
+                    "(Leg::calculateTipForce) is evaluated every cycle")
+    ap.add_argument("--no-joint-efforts", action="store_true", help="primary line without measured joint torques (Leg::calculateTipForce idle)")
+    ap.add_argument("--mode", choices=("auto", "resident", "launch"), default="auto",
+                    help="auto: resident mode where the batch fits the chip once (config 2), one launch per step otherwise")
     ap.add_argument("--seed", type=int, default=0xC0FFEE)
     args = ap.parse_args()
 
@@ -411,26 +502,28 @@ def main():
                           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                           "config": {k: v for k, v in r.items() if k not in ("value", "roofline", "ms_per_step")}, "roofline": r["roofline"]}), flush=True)
         return
+    # Measured joint torques are part of the primary workload (a node always receives them from jointStatesCallback and the
+    # reference evaluates Leg::calculateTipForce every cycle, model.cpp:938); the variant without them is reported under config.also.
+    primary_efforts = not args.no_joint_efforts
     res = run_workload(args.workload, n, args.steps, args.warmup, args.cycles_per_step, args.seed,
                        dist_ctx=(world, rank, local_rank) if use_dist else None, gather_every=args.gather_every,
                        fused_probe=not args.no_fused_probe, want_cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline),
-                       joint_efforts=args.joint_efforts)
+                       joint_efforts=primary_efforts, mode=args.mode)
     # The other single-GPU BASELINE.json configurations, measured in the same process (N = 1 default run only):
     # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
     also = []
     if world == 1 and not use_dist and args.workload == "config2" and not args.instances and not args.no_also:
-        for name, efforts in (("config3", False), ("config4", False), ("config2", True), ("config4", True)):
-            if efforts == args.joint_efforts and name == "config2":
-                continue
-            k = max(50, min(args.steps, 300))
+        for name, efforts in (("config2", not primary_efforts), ("config3", False), ("config4", False), ("config4", True)):
+            k = max(300, min(args.steps, 1000))   # long enough that first-touch and clock ramp are outside the figure
             try:   # the secondary workloads must never cost the run its primary line
-                r = run_workload(name, DEFAULT_INSTANCES[name], k, max(10, min(args.warmup, 30)), args.cycles_per_step, args.seed,
-                                 fused_probe=not args.no_fused_probe and not efforts, joint_efforts=efforts)
+                r = run_workload(name, DEFAULT_INSTANCES[name], k, max(30, min(args.warmup, 100)), args.cycles_per_step, args.seed,
+                                 fused_probe=not args.no_fused_probe and not efforts, joint_efforts=efforts, mode=args.mode)
             except Exception as exc:  # noqa: BLE001
                 also.append({"workload": name, "error": str(exc)[:200]})
                 continue
             also.append({"workload": r["config"]["workload"], "value": r["value"], "unit": "control-cycles/s", "steps": k,
-                         "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"],
+                         "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"], "mode": r["config"]["mode"],
+                         "one_launch_per_cycle_value": r["config"]["one_launch_per_cycle_value"],
                          "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],
                          "two_streams": r["config"]["two_streams"],
                          "roofline": r["roofline"]})

@@ -405,69 +405,101 @@ __device__ __forceinline__ void resident_epilogue(const ResidentArgs &A, const D
   }
 }
 
-// The relay: one wave between the host and the workers.  It alone reads / writes the host-mapped words (a handful of PCIe
+// The relay: between the host and the workers.  It alone reads / writes the host-mapped words (a handful of PCIe
 // transactions per microsecond instead of one per worker and cycle), it alone writes the gate - so "doorbell" and "stop" change
 // together, atomically, and every worker leaves the loop at the same cycle - and it alone decides to stop: on request, at the
 // launch's cycle bound, or when the doorbell has not moved for idle_ticks (a host that went away cannot leave the GPU spinning).
+// Two directions, PART_GATE (host doorbell / stop -> gate) and PART_DONE (workers' progress -> host, exit report): one wave
+// does both (PART_BOTH), or - where the relay workgroup has waves to spare - one wave each, which halves the latency either way.
+enum : int { PART_BOTH = 0, PART_GATE = 1, PART_DONE = 2 };
+template <int PART>
 __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const unsigned max_cycles = A.max_cycles;
   unsigned db = 0, sp = max_cycles, idle_stop = 0xffffffffu;
-  u64 reason = RESIDENT_EXIT_MAX, last_gate = ~0ull, last_done = 0, iter = 0;
+  u64 reason = RESIDENT_EXIT_MAX, last_reason = 0, last_gate = ~0ull, last_done = 0, iter = 0;
   u64 t_last = wall_clock64(), t_all_done = 0;
   for (;;) {
-    const u64 hd = uni64(ld_sys(&A.host->doorbell)), hs = uni64(ld_sys(&A.host->stop));
     const u64 now = wall_clock64();
-    unsigned want_db = hd > max_cycles ? max_cycles : unsigned(hd);
-    if (want_db < db) want_db = db; // the doorbell only moves forward
-    if (want_db != db) t_last = now;
-    else if (idle_stop == 0xffffffffu && now - t_last > A.idle_ticks) idle_stop = db;
-    unsigned want_sp = max_cycles;
-    u64 why = RESIDENT_EXIT_MAX;
-    if (hs <= max_cycles) want_sp = unsigned(hs), why = RESIDENT_EXIT_STOP;
-    if (idle_stop < want_sp) want_sp = idle_stop, why = RESIDENT_EXIT_IDLE;
-    if (want_sp < db) want_sp = db; // cycles already released run
-    if (want_db > want_sp) want_db = want_sp;
-    db = want_db, sp = want_sp, reason = why;
-    const u64 gate = (u64(sp) << 32) | db;
-    if (gate != last_gate) {
-      if (lane == 0) st_agent(&A.ctl->gate, gate);
-      last_gate = gate;
-    }
-    // cycles completed by every worker wave
-    u64 m = ~0ull;
-    for (int64_t w = lane; w < A.n_waves; w += 64) {
-      const u64 v = ld_agent(A.progress + w);
-      m = v < m ? v : m;
-    }
+    // every load of the iteration is issued before the first one is waited for (each is a trip to memory or across PCIe)
+    const u64 exited_v = ld_agent(&A.ctl->exited);
+    const u64 gate_v = PART == PART_DONE ? ld_agent(&A.ctl->gate) : 0;
+    u64 pv[8];
+    if (PART != PART_GATE) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const u64 o = __shfl_xor(m, off, 64);
-      m = o < m ? o : m;
+      for (int j = 0; j < 8; ++j) pv[j] = j * 64 + lane < A.n_waves ? ld_agent(A.progress + j * 64 + lane) : ~0ull;
     }
-    m = uni64(m);
-    if (m != last_done) {
-      if (lane == 0) st_sys(&A.host->done, m);
-      last_done = m;
-    }
-    const u64 exited = uni64(ld_agent(&A.ctl->exited));
-    const u64 fault = uni64(ld_agent(&A.ctl->fault));
-    bool leave = exited == u64(A.n_waves);
-    if (!leave && m >= sp) { // everything that will ever run has run: the workers are on their way out
-      if (t_all_done == 0) t_all_done = now;
-      else if (now - t_all_done > 500000000ull) leave = true, reason = RESIDENT_EXIT_FAULT; // 5 s: give up on them
-    }
-    if (leave) {
-      if (lane == 0) {
-        st_sys(&A.host->fault, fault);
-        st_sys(&A.host->done, m);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_sys(&A.host->exited, fault ? u64(RESIDENT_EXIT_FAULT) : reason);
+    if (PART != PART_DONE) {
+      const u64 hd_v = ld_sys(&A.host->doorbell), hs_v = ld_sys(&A.host->stop);
+      const u64 hd = uni64(hd_v), hs = uni64(hs_v);
+      unsigned want_db = hd > max_cycles ? max_cycles : unsigned(hd);
+      if (want_db < db) want_db = db; // the doorbell only moves forward
+      if (want_db != db) t_last = now;
+      else if (idle_stop == 0xffffffffu && now - t_last > A.idle_ticks) idle_stop = db;
+      unsigned want_sp = max_cycles;
+      u64 why = RESIDENT_EXIT_MAX;
+      if (hs <= max_cycles) want_sp = unsigned(hs), why = RESIDENT_EXIT_STOP;
+      if (idle_stop < want_sp) want_sp = idle_stop, why = RESIDENT_EXIT_IDLE;
+      if (want_sp < db) want_sp = db; // cycles already released run
+      if (want_db > want_sp) want_db = want_sp;
+      db = want_db, sp = want_sp, reason = why;
+      if (reason != last_reason) { // (the reason is in place before a gate that can end the loop)
+        if (lane == 0) st_agent(&A.ctl->pad[0], reason);
+        last_reason = reason;
       }
-      break;
+      const u64 gate = (u64(sp) << 32) | db;
+      if (gate != last_gate) {
+        if (lane == 0) st_agent(&A.ctl->gate, gate);
+        last_gate = gate;
+      }
     }
-    if ((++iter & 1023) == 0 && lane == 0) st_sys(&A.host->heartbeat, iter);
-    __builtin_amdgcn_s_sleep(2);
+    const u64 exited = uni64(exited_v);
+    bool leave = exited == u64(A.n_waves);
+    if (PART != PART_GATE) {
+      if (PART == PART_DONE) sp = unsigned(uni64(gate_v) >> 32);
+      // cycles completed by every worker wave
+      u64 m = ~0ull;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = pv[j] < m ? pv[j] : m;
+      for (int64_t base = 512; base < A.n_waves; base += 512) { // (more than 512 waves: 8 independent loads per lane in flight at a time)
+        u64 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t w = base + j * 64 + lane;
+          v[j] = w < A.n_waves ? ld_agent(A.progress + w) : ~0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = v[j] < m ? v[j] : m;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = __shfl_xor(m, off, 64);
+        m = o < m ? o : m;
+      }
+      m = uni64(m);
+      if (m != last_done) {
+        if (lane == 0) st_sys(&A.host->done, m);
+        last_done = m;
+      }
+      bool gave_up = false;
+      if (!leave && m >= sp) { // everything that will ever run has run: the workers are on their way out
+        if (t_all_done == 0) t_all_done = now;
+        else if (now - t_all_done > 500000000ull) leave = gave_up = true; // 5 s: give up on them
+      }
+      if (leave) {
+        const u64 fault = uni64(ld_agent(&A.ctl->fault));
+        const u64 why = uni64(ld_agent(&A.ctl->pad[0]));
+        if (lane == 0) {
+          st_sys(&A.host->fault, fault);
+          st_sys(&A.host->done, m);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          st_sys(&A.host->exited, (fault || gave_up) ? u64(RESIDENT_EXIT_FAULT) : why);
+        }
+      }
+      if ((++iter & 1023) == 0 && lane == 0) st_sys(&A.host->heartbeat, iter);
+    }
+    if (leave) break;
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 
@@ -659,7 +691,7 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc
 template <int L, int NJ, unsigned F>
 __global__ void __launch_bounds__(64, SHC_WAVES_PER_SIMD) shc_resident_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
   if (blockIdx.x == 0) {
-    resident_relay(ra);
+    resident_relay<PART_BOTH>(ra);
     return;
   }
   cycle_wave<L, NJ, F, true>(st, gc, 0, rt_flags, int64_t(blockIdx.x) - 1, &ra);
@@ -694,8 +726,9 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   using FD = Fields<NJ>;
   using FT = Feat<F>;
   constexpr int RPW = 64 / L;
-  if (blockIdx.x == 0) {
-    if (threadIdx.x < 64) resident_relay(A);
+  if (blockIdx.x == 0) { // the relay workgroup: one wave per direction
+    if (threadIdx.x < 64) resident_relay<PART_GATE>(A);
+    else if (threadIdx.x < 128) resident_relay<PART_DONE>(A);
     return;
   }
   __shared__ SharedConsts<L, NJ> C;
