@@ -135,9 +135,6 @@ def measured_traffic(workload, n, cps):
         return None
 
 
-_TWO_STREAMS = None
-
-
 def resident_bytes_per_cycle(p):
     """SURVEY.md section 8(d), K cycles fused with the state on the chip: per robot and cycle the velocity input (24 B) and the
     desired joint positions + velocities the cycle publishes."""
@@ -184,6 +181,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     p, lin, ang, extra, key, desc = make_workload(name, n, seed, rank, joint_efforts)
     stream = torch.cuda.current_stream()
     eng = BatchEngine(p, n, device=local_rank, stream=stream.cuda_stream)
+    n_waves = -(-n // (64 // p.leg_count))   # from 4 096 wavefronts on shc_engine_step launches the batch as two halves on two streams
     apply_inputs(eng, lin * 0.0, ang * 0.0, extra)
     # config 3: the measured tip forces are resampled every 10 cycles from sets resident in HBM
     force_sets = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in extra.get("force_sets", [])]
@@ -293,6 +291,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     for a, b in evs:
         a.record(stream)
         eng.step(cps)
+        eng.join()      # (large batches: the second half of the step runs on the engine's internal stream)
         b.record(stream)
     torch.cuda.synchronize()
     per_launch_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
@@ -300,6 +299,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     e0.record(stream)
     for _ in range(m):
         eng.step(cps)
+    eng.join()
     e1.record(stream)
     torch.cuda.synchronize()
     kern_ms = min(per_launch_ms, e0.elapsed_time(e1) / m)
@@ -315,62 +315,32 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             eng.step(fc)
         torch.cuda.synchronize()
         fused_value = n * fc * reps / (time.perf_counter() - tf0)
+    # ---- secondary figure for batches large enough for the engine's two-stream split (shc_engine_step): the same steps as ONE launch
+    #      each on the engine's stream (SHC_FEAT_SINGLE_STREAM), i.e. what round 2 measured as the primary figure
+    single_stream = None
+    if cps == 1 and world == 1 and fused_probe and n_waves >= 4096:
+        from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_SINGLE_STREAM
+        eng.set_features(FEAT_DEFAULT | FEAT_SINGLE_STREAM)
+        for _ in range(20):
+            step_once()
+        torch.cuda.synchronize()
+        reps = max(300, min(steps, 1000))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            step_once()
+        eng.synchronize()
+        dt1 = (time.perf_counter() - t1) / reps
+        single_stream = {"value": n / dt1, "ms_per_step": dt1 * 1e3, "algorithmic_frac": ALG_BYTES_PER_CYCLE[key] * n / dt1 / 1e9 / HBM_PEAK_GBS,
+                         "note": "one launch per step on the engine's stream (SHC_FEAT_SINGLE_STREAM)"}
+        eng.set_features(FEAT_DEFAULT)
     q, _ = eng.joints()
     finite = bool(np.isfinite(q).all())
     eng.close()
-    # ---- secondary figure for batches that fill the machine several times over: the same batch as two engines (contiguous
-    #      halves) on two HIP streams with no join between steps - what shc_fleet_create does when a device id is repeated.
-    #      Step k + 1 of a robot depends on step k of THAT robot only, so the tail of one half's launch (the last, partly filled
-    #      round of waves) and the next launch's ramp-up overlap with the other half's waves.
-    two_streams = None
-    if cps == 1 and world == 1 and fused_probe and n >= 32768:
-        try:   # a secondary figure must never cost the run its primary one
-            half = n // 2
-            global _TWO_STREAMS   # one pair for the whole process: streams share a few hardware queues, and two probes' pairs can collide on one
-            if _TWO_STREAMS is None:
-                _TWO_STREAMS = [torch.cuda.Stream(), torch.cuda.Stream()]
-            streams2 = _TWO_STREAMS
-            engs = []
-            for i, (a, b) in enumerate(((0, half), (half, n))):
-                e2 = BatchEngine(p, b - a, device=local_rank, stream=streams2[i].cuda_stream)
-                apply_inputs(e2, lin[a:b], ang[a:b], {k: (v[a:b] if k != "force_sets" else v) for k, v in extra.items() if k != "force_sets"})
-                engs.append(e2)
-            for gk in range(groups):   # the same de-phasing as the main run (instance i of the whole batch starts i mod groups steps late)
-                for e2, (a, b) in zip(engs, ((0, half), (half, n))):
-                    sel = (np.arange(a, b) % groups) <= gk
-                    e2.set_velocity(lin[a:b] * sel[:, None], ang[a:b] * sel)
-                    for _ in range(max(1, period // groups)):
-                        e2.step(1)
-            for e2, (a, b) in zip(engs, ((0, half), (half, n))):
-                e2.set_velocity(lin[a:b], ang[a:b])
-                for _ in range((2 * period + 64 + 15) // 16):
-                    e2.step(16)
-            for _ in range(10):
-                for e2 in engs:
-                    e2.step(1)
-            torch.cuda.synchronize()
-            reps = max(50, min(steps, 300))
-            bounds = ((0, half), (half, n))
-            t2 = time.perf_counter()
-            for c2 in range(reps):
-                for e2, (a, b) in zip(engs, bounds):
-                    if force_sets and c2 % 10 == 0 and c2 > 0:   # config 3: the same resampling of the measured tip forces
-                        e2.L.shc_engine_set_tip_force(e2.h, force_sets[(c2 // 10) % len(force_sets)][a:b].data_ptr(), 1)
-                    e2.step(1)
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t2) / reps
-            two_streams = {"value": n / dt2, "ms_per_step": dt2 * 1e3, "algorithmic_frac": ALG_BYTES_PER_CYCLE[key] * n / dt2 / 1e9 / HBM_PEAK_GBS,
-                           "note": "two engines (halves of the batch) on two HIP streams, no join between steps (shc_fleet_create with a repeated device id)"}
-            for e2 in engs:
-                e2.close()
-
-        except Exception as exc:  # noqa: BLE001
-            two_streams = {"error": str(exc)[:200]}
     alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     launch_roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel", "kernel_ms": kern_ms,
-                       "algorithmic_bytes_per_launch": alg_bytes}
+                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel" + (" (a step = two launches, the halves of the batch on two streams)" if n_waves >= 4096 else ""),
+                       "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes}
     if resident:
         rb = resident_bytes_per_cycle(p) * n
         r_ach = rb / res_cycle_s / 1e9
@@ -392,7 +362,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                    "gather": f"all-gather of the joint buffer every {gather_every} steps" if gather_every
                    else "one all-gather of the final joint buffer (N > 1)",
                    "moving_fraction": moving_frac, "finite": finite, "seed": seed, "fused_16_cycles_per_launch_value": fused_value,
-                   "two_streams": two_streams},
+                   "two_stream_split": n_waves >= 4096, "single_stream": single_stream},
         "roofline": roofline,
     }
     if want_cpu_baseline:
@@ -525,7 +495,7 @@ def main():
                          "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"], "mode": r["config"]["mode"],
                          "one_launch_per_cycle_value": r["config"]["one_launch_per_cycle_value"],
                          "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],
-                         "two_streams": r["config"]["two_streams"],
+                         "two_stream_split": r["config"]["two_stream_split"], "single_stream": r["config"]["single_stream"],
                          "roofline": r["roofline"]})
         try:
             also.append(run_config5(DEFAULT_INSTANCES["config5"], 100, 10, args.seed))

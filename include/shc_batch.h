@@ -158,7 +158,10 @@ enum {
   /* Diagnostic: resident mode with ONE wavefront per robot group even where the batch is small enough for the two-wavefront
    * (walker / model) pipeline.  Both produce identical bits (tests/test_gpu_resident.py). */
   SHC_FEAT_RESIDENT_ONE_WAVE = 1 << 29,
-  SHC_FEAT_ALL = 0x1fffffff
+  /* Diagnostic: launch every step as ONE kernel on the engine's stream even for batches large enough for the two-stream split
+   * (see shc_engine_step).  Both produce identical bits. */
+  SHC_FEAT_SINGLE_STREAM = 1 << 28,
+  SHC_FEAT_ALL = 0x0fffffff
 };
 
 /*
@@ -242,6 +245,17 @@ int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode, int on_de
  */
 int shc_engine_step(shc_engine *e, int n_cycles);
 int shc_engine_synchronize(shc_engine *e);
+/*
+ * Batches of 4 096 wavefronts and more (40 960 hexapods, 32 768 octopods): shc_engine_step launches the two halves of the batch on
+ * two streams - the engine's and an internal one - and does NOT join them between consecutive steps (a robot's next cycle depends
+ * on its own last cycle only; one half's partly filled last round of wavefronts then overlaps the other half's full rounds:
+ * +20 ... 30 % control cycles per second).  Every other shc_engine_* / shc_leg_* entry point orders the engine's stream after both
+ * halves before it enqueues anything, so getters, setters and shc_engine_synchronize behave as before.  Only a caller that
+ * enqueues ITS OWN work on the engine's stream right after shc_engine_step (a kernel reading shc_engine_joint_buffer, an event,
+ * a graph capture) calls shc_engine_join first: it makes the engine's stream wait for the internal one (no host wait).
+ * SHC_FEAT_SINGLE_STREAM turns the split off.
+ */
+int shc_engine_join(shc_engine *e);
 
 /*
  * Resident mode: the node's control loop kept on the chip.
@@ -583,6 +597,23 @@ typedef struct shc_instance_state {
   int32_t pad_;                       /* explicit: the record has no implicit padding (byte-comparable) */
   shc_leg_snapshot leg[SHC_MAX_LEGS];
 } shc_instance_state;
+
+/*
+ * Auxiliary state: what only the calls AROUND the control cycle keep and shc_instance_state therefore does not carry - the pose
+ * reset mode in force, manual leg manipulation (per-leg LegState, the leg selections and their inputs, Leg::desired_tip_pose_ as
+ * the next WalkController::updateManual reads it back), externally requested targets / default poses / planner targets
+ * (ExternalTarget records with their defined flags), the PoseController / LegPoser members of the start-up, shut-down and planner
+ * sequences (transition steps, learnt transition poses, plan step, target configuration / body pose), the LegPoser origin poses of
+ * stepToPosition / transitionConfiguration, and the measured joint positions of the last joint-state message.
+ * One opaque, versioned blob per instance (its layout is private to the library and tied to the engine's legs x joints;
+ * shc_engine_aux_state_bytes gives the size).  A COMPLETE checkpoint of an engine - restore, or migration into another engine of
+ * the same parameters - is shc_engine_get_state + shc_engine_get_aux_state (+ the engine-wide scalars the host chose itself:
+ * planner mode, pack step); restoring only the first leaves a robot with a MANUAL leg, a pending external target or a half-run
+ * sequence without that state.  Held inputs (velocity, IMU, forces, efforts) are inputs: the caller applies them again.
+ */
+int64_t shc_engine_aux_state_bytes(const shc_engine *e);
+int shc_engine_get_aux_state(shc_engine *e, int64_t first, int64_t count, void *blobs);
+int shc_engine_set_aux_state(shc_engine *e, int64_t first, int64_t count, const void *blobs);
 
 /*
  * Externally requested tip targets / default stance poses of rough terrain mode: struct ExternalTarget (walk_controller.h:38-46)

@@ -36,7 +36,7 @@ static void launch_cycle(const CycleLaunch &a) {
     return;
   }
   shc_cycle_kernel<L, NJ, F><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, a.n_cycles,
-                                                                                              a.rt_flags);
+                                                                                              a.rt_flags, a.wave0);
 }
 
 // Pick the kernel specialisation: the BASELINE.json configurations get feature-exact kernels (dead features cost

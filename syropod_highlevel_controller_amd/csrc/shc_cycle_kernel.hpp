@@ -682,8 +682,8 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
 
 template <int L, int NJ, unsigned F>
 __global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles,
-                                                                                             unsigned rt_flags) {
-  cycle_wave<L, NJ, F, false>(st, gc, n_cycles, rt_flags, (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nullptr);
+                                                                                             unsigned rt_flags, int64_t wave0) {
+  cycle_wave<L, NJ, F, false>(st, gc, n_cycles, rt_flags, wave0 + ((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6), nullptr);
 }
 
 // Resident launch: block 0 is the relay (host <-> device handshake), block 1 + w is worker wave w; 64 threads each, every block

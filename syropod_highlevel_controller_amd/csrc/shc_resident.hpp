@@ -150,10 +150,14 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   if (idle_timeout_ms < 0 || idle_timeout_ms > 600000) return fail(SHC_ERR_INVALID_ARG, "idle_timeout_ms must be 0..600000");
   if (e->starting_up) return fail(SHC_ERR_UNSUPPORTED, "resident mode starts from a running engine (finish the start-up first)");
   HIP_TRY(hipSetDevice(e->device));
+  {
+    const int rc = join_side(e);
+    if (rc != SHC_OK) return rc;
+  }
   // does this configuration have a resident kernel, and does the whole batch fit the chip at once (+ the relay block)?
   ResidentFit fit{0, 0, 0};
   {
-    CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, 0, 64, 0, nullptr, &fit};
+    CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, 0, 64, 0, nullptr, &fit, 0};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
     SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
@@ -244,7 +248,7 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   const bool two_wave = fit.two_wave && !(e->features & SHC_FEAT_RESIDENT_ONE_WAVE) && (e->n_waves + 1) / 2 + 1 <= prop.multiProcessorCount;
   r->two_wave = two_wave;
   CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream,
-                two_wave ? unsigned((e->n_waves + 1) / 2 + 1) : unsigned(e->n_waves + 1), two_wave ? 256 : 64, 0, &A, nullptr};
+                two_wave ? unsigned((e->n_waves + 1) / 2 + 1) : unsigned(e->n_waves + 1), two_wave ? 256 : 64, 0, &A, nullptr, 0};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL

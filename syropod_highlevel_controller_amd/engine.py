@@ -45,7 +45,8 @@ EXPORTED_SYMBOLS = [
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
     "shc_fleet_all_gather_joints",
     "shc_engine_resident_begin", "shc_engine_resident_post", "shc_engine_resident_publish", "shc_engine_resident_wait",
-    "shc_engine_resident_get_joint_state", "shc_engine_resident_status", "shc_engine_resident_end",
+    "shc_engine_resident_get_joint_state", "shc_engine_resident_status", "shc_engine_resident_end", "shc_engine_join",
+    "shc_engine_aux_state_bytes", "shc_engine_get_aux_state", "shc_engine_set_aux_state",
 ]
 
 
@@ -198,6 +199,11 @@ def lib():
                         ("shc_engine_set_joint_effort", 1), ("shc_engine_set_pose_input", 2), ("shc_engine_set_pose_reset_mode", 1)):
             getattr(L, name).argtypes = [C.c_void_p] + [C.c_void_p] * n + [C.c_int]
         L.shc_engine_step.argtypes = [C.c_void_p, C.c_int]
+        L.shc_engine_join.argtypes = [C.c_void_p]
+        L.shc_engine_aux_state_bytes.argtypes = [C.c_void_p]
+        L.shc_engine_aux_state_bytes.restype = C.c_int64
+        L.shc_engine_get_aux_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+        L.shc_engine_set_aux_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.shc_engine_resident_begin.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int]
         L.shc_engine_resident_post.argtypes = [C.c_void_p, C.POINTER(CycleInputs), C.POINTER(C.c_int64)]
         L.shc_engine_resident_publish.argtypes = [C.c_void_p, C.c_int64]
@@ -385,6 +391,10 @@ class BatchEngine:
     def synchronize(self):
         _check(self.L.shc_engine_synchronize(self.h), "synchronize")
 
+    def join(self):
+        """Order the engine's stream after both halves of earlier split steps (large batches; no host wait)."""
+        _check(self.L.shc_engine_join(self.h), "join")
+
     # -- resident mode: the control loop kept on the chip (shc_engine_resident_*)
     def resident_begin(self, ring_depth: int = 16, max_cycles: int = 1 << 24, idle_timeout_ms: int = 0):
         _check(self.L.shc_engine_resident_begin(self.h, int(ring_depth), int(max_cycles), int(idle_timeout_ms)), "resident_begin")
@@ -498,6 +508,18 @@ class BatchEngine:
     def set_state(self, states, first: int = 0):
         """Restore / inject the state of instances [first, first + len(states))."""
         _check(self.L.shc_engine_set_state(self.h, first, len(states), states), "set_state")
+
+    def get_aux_state(self, first: int = 0, count: Optional[int] = None) -> bytes:
+        """The rest of a complete checkpoint (manual legs, external targets, sequence / planner state, ...): opaque blobs."""
+        count = self.n - first if count is None else count
+        buf = C.create_string_buffer(int(self.L.shc_engine_aux_state_bytes(self.h)) * count)
+        _check(self.L.shc_engine_get_aux_state(self.h, first, count, buf), "get_aux_state")
+        return buf.raw
+
+    def set_aux_state(self, blobs: bytes, first: int = 0):
+        per = int(self.L.shc_engine_aux_state_bytes(self.h))
+        assert len(blobs) % per == 0
+        _check(self.L.shc_engine_set_aux_state(self.h, first, len(blobs) // per, C.c_char_p(blobs)), "set_aux_state")
 
     # -- per-leg Leg methods (model.h:448-492), batched: instances [first, first + count), leg = -1 for every leg
     def _rows(self, first, count, leg):

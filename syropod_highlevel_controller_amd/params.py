@@ -26,6 +26,7 @@ VEL_THROTTLE, VEL_REAL = 0, 1
 FEAT_TIP_FORCE = 1
 FEAT_ODOMETRY = 2
 FEAT_GENERIC_KERNEL = 1 << 30  # diagnostic: runtime-flag kernel instead of the compile-time specialisation
+FEAT_SINGLE_STREAM = 1 << 28  # diagnostic: no two-stream split of large batches
 FEAT_RESIDENT_ONE_WAVE = 1 << 29  # diagnostic: resident mode without the two-wavefront (walker / model) pipeline
 FEAT_DEFAULT = FEAT_TIP_FORCE | FEAT_ODOMETRY  # what shc_engine_create enables
 

@@ -177,3 +177,63 @@ def test_toggle_and_manipulate_free_running():
     assert np.array_equal(g["walk_state"], o["walk_state"])
     assert np.abs(eng.leg_state()["model_tip"] - ob.leg_state()["model_tip"]).max() < 5e-3
     assert np.abs(eng.leg_state()["walker_tip"] - ob.leg_state()["walker_tip"]).max() < 5e-3
+
+
+def test_complete_checkpoint_carries_a_manual_leg_into_another_engine():
+    """shc_engine_get_state alone is the control cycle's state; a complete checkpoint adds shc_engine_get_aux_state (manual-leg records,
+    Leg::desired_tip_pose_, reset mode, external / sequence records).  A robot with a MANUAL leg restored into a fresh engine from both
+    goes on byte for byte like the original - and demonstrably not from the first alone."""
+    p = default_hexapod_params("tripod")
+    p.admittance_control = 1
+    n, L = 12, p.leg_count
+    rng = np.random.default_rng(4)
+    a = BatchEngine(p, n)
+    lin, ang = rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-0.5, 0.5, n)
+    force = np.abs(rng.normal(0, 2.0, (n, L, 3))) + 1.0
+    a.set_velocity(lin, ang)
+    a.set_tip_force(force)
+    a.step(150)
+    sel = np.array([i % L if i % 4 else -1 for i in range(n)], dtype=np.int32)   # every fourth robot keeps walking
+    pending = sel >= 0
+    for _ in range(3000):
+        if not pending.any():
+            break
+        res = a.toggle_leg_state(np.where(pending, sel, -1).astype(np.int32))
+        still = res == -1
+        if still.any():
+            lin[still], ang[still] = 0.0, 0.0
+            a.set_velocity(lin, ang)
+        pending &= ~((res == 1) | (res == 2))
+    assert not pending.any()
+    assert (a.leg_manipulation_state()[sel >= 0, sel[sel >= 0]] == 1).all()      # LegState MANUAL
+    vel = rng.uniform(-0.4, 0.4, (n, 3))
+    a.set_manual_inputs(primary_leg=sel, primary_velocity=vel)
+    a.step(7)
+    a.synchronize()
+    state, aux = a.get_state(), a.get_aux_state()
+
+    def go_on(e):
+        e.set_velocity(lin, ang)
+        e.set_tip_force(force)
+        e.set_manual_inputs(primary_leg=sel, primary_velocity=vel)
+        e.step(40)
+        e.set_manual_inputs(primary_leg=sel, primary_velocity=vel * 0.0, primary_position=np.tile([0.25, 0.2, -0.05], (n, 1)))
+        e.step(3)
+        back = e.toggle_leg_state(sel)                                           # ... and hand the legs back
+        e.step(5)
+        e.synchronize()
+        return bytes(memoryview(e.get_state()).cast("B")), e.get_aux_state(), e.leg_manipulation_state(), back
+
+    ref = go_on(a)
+    b = BatchEngine(p, n)
+    b.set_state(state)
+    b.set_aux_state(aux)
+    assert np.array_equal(b.leg_manipulation_state(), np.where(np.arange(L)[None, :] == sel[:, None], 1, 0))
+    got = go_on(b)
+    assert got[0] == ref[0] and got[1] == ref[1]
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    c = BatchEngine(p, n)                                                       # the cycle state alone: the walker unfreezes
+    c.set_state(state)
+    assert (c.leg_manipulation_state() == 0).all()
+    for e in (a, b, c):
+        e.close()
