@@ -72,7 +72,7 @@ struct CycleLaunch {
   const ResidentArgs *resident; // != nullptr: launch the resident kernel (block = 64: grid = n_waves + 1 relay block of 64 threads, one
                                 // wavefront per robot group; block = 256: the two-wavefront pipeline, grid = ceil(n_waves / 2) + 1)
   struct ResidentFit *fit;      // != nullptr: launch nothing, report whether / how densely the resident kernel of this specialisation fits
-  int64_t wave0;                // first wave of this launch (a step of a large batch is two launches: halves on two streams)
+  int64_t wave0;                // first wave of this launch (a step of a large batch is two launches on two streams)
 };
 struct ResidentFit {
   int supported;          // this specialisation has a resident kernel

@@ -64,8 +64,8 @@ __device__ __forceinline__ int64_t slot_of(int64_t rob, int leg, int L) {
 #include "shc_sequence.hpp" // executeSequence / stepToNewStance: per-robot state machines over the per-leg primitives
 
 // AoS [n][L][K] -> leg fields f0..f0+K-1
-__global__ void scatter_leg_kernel(const double *src, double *legd, int64_t n_slots, int64_t n, int L, int K, int f0) {
-  int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+__global__ void scatter_leg_kernel(const double *src, double *legd, int64_t n_slots, int64_t n, int L, int K, int f0, int64_t r0 = 0) {
+  int64_t t = r0 * L + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; // instances [r0, n)
   if (t >= n * L) return;
   int64_t rob = t / L;
   int leg = int(t - rob * L);
@@ -176,9 +176,9 @@ __global__ void gather_leg_status_kernel(int32_t *dst, const int32_t *legi, int6
 }
 // AoS [n][K] -> robot fields
 
-__global__ void scatter_rob_kernel(const double *src, double *robd, int rpw, int64_t n, int K, int f0, int normalize_quat) {
+__global__ void scatter_rob_kernel(const double *src, double *robd, int rpw, int64_t n, int K, int f0, int normalize_quat, int64_t r0 = 0) {
   constexpr int nf = RobotFields::COUNT;
-  int64_t r = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  int64_t r = r0 + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; // instances [r0, n)
   if (r >= n) return;
   if (normalize_quat) { // Model::setImuData normalises the orientation (model.h:150)
     Quat q = normalized(Quat{src[r * 4], src[r * 4 + 1], src[r * 4 + 2], src[r * 4 + 3]});
@@ -266,9 +266,9 @@ struct shc_engine {
   bool plan_poser_tips_current = false; // no control cycle has run since the last shc_engine_execute_plan (SeqRobotState::poser_tip_from_plan holds)
   struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
   // Large batches: a step is launched as two halves on two streams with no join between steps (see shc_engine_step).
-  hipStream_t side = nullptr;           // the second half's stream (created by the first split step)
-  hipEvent_t ev_main = nullptr, ev_side = nullptr;
-  bool side_busy = false;               // launches are outstanding on `side` that the engine's stream has not been ordered after
+  hipStream_t half_stream[2] = {nullptr, nullptr}; // the device's pair of split streams (split_streams()), once this engine has used them
+  hipEvent_t ev_main = nullptr, ev_half[2] = {nullptr, nullptr};
+  bool side_busy = false;               // launches are outstanding on the split streams that the engine's stream has not been ordered after
   bool main_dirty = true;               // work other than steps was enqueued on the engine's stream since the last split step
 };
 struct Resident;
@@ -858,7 +858,9 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   if (!e) return SHC_OK;
   (void)hipSetDevice(e->device);
   resident_shutdown(e);
-  if (e->side) (void)hipStreamSynchronize(e->side); // (the halves of split steps: nothing may still be running on the buffers freed below)
+  for (hipStream_t hs : e->half_stream) // (the halves of split steps: nothing may still be running on the buffers freed below)
+    if (hs) (void)hipStreamSynchronize(hs);
+  (void)hipStreamSynchronize(e->stream);
   (void)hipFree(e->st.legd);
   (void)hipFree(e->st.legi);
   (void)hipFree(e->st.robd);
@@ -868,11 +870,10 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->d_seq);
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
-  if (e->side) {
-    (void)hipStreamSynchronize(e->side);
-    (void)hipStreamDestroy(e->side);
+  if (e->half_stream[0]) { // (the streams belong to the process-wide pair)
     (void)hipEventDestroy(e->ev_main);
-    (void)hipEventDestroy(e->ev_side);
+    (void)hipEventDestroy(e->ev_half[0]);
+    (void)hipEventDestroy(e->ev_half[1]);
   }
   delete e;
   return SHC_OK;
@@ -913,9 +914,37 @@ static int to_device(shc_engine *e, const double *src, size_t count, int on_devi
   return SHC_OK;
 }
 
+// While split steps are in flight (large batches, shc_engine_step) a device-resident input array is scattered by EACH HALF'S OWN
+// stream - ordered after that half's earlier steps and before its later ones by stream order alone, so that new inputs cost no
+// join (a join drains both halves and costs the overlap the split exists for).  The caller's array is ready on the engine's
+// stream: both half streams first wait for that.
+static bool split_inputs(const shc_engine *e, int on_device) { return on_device && e->side_busy; }
+static int split_inputs_begin(shc_engine *e) {
+  HIP_TRY(hipEventRecord(e->ev_main, e->stream));
+  HIP_TRY(hipStreamWaitEvent(e->half_stream[0], e->ev_main, 0));
+  HIP_TRY(hipStreamWaitEvent(e->half_stream[1], e->ev_main, 0));
+  return SHC_OK;
+}
+static int64_t split_first_instance_of_second_half(const shc_engine *e) { // as shc_engine_step cuts the batch
+  const int64_t waves_per_block = e->n_waves < 1536 ? 1 : 2;
+  const int64_t half = ((e->n_waves / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block;
+  const int64_t r = half * (64 / e->L);
+  return r < e->n ? r : e->n;
+}
+
 static int scatter_rob(shc_engine *e, const double *src, int K, int f0, int on_device, int normalize_quat = 0) {
   if (!src) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
+  if (split_inputs(e, on_device)) {
+    const int rc = split_inputs_begin(e);
+    if (rc != SHC_OK) return rc;
+    const int64_t mid = split_first_instance_of_second_half(e);
+    scatter_rob_kernel<<<dim3((unsigned)((mid + 255) / 256)), dim3(256), 0, e->half_stream[0]>>>(src, e->st.robd, 64 / e->L, mid, K, f0, normalize_quat, 0);
+    if (e->n > mid)
+      scatter_rob_kernel<<<dim3((unsigned)((e->n - mid + 255) / 256)), dim3(256), 0, e->half_stream[1]>>>(src, e->st.robd, 64 / e->L, e->n, K, f0, normalize_quat, mid);
+    HIP_TRY(hipGetLastError());
+    return SHC_OK;
+  }
   const double *d;
   int rc = to_device(e, src, size_t(e->n) * K, on_device, &d);
   if (rc != SHC_OK) return rc;
@@ -929,6 +958,16 @@ static int scatter_rob(shc_engine *e, const double *src, int K, int f0, int on_d
 static int scatter_leg(shc_engine *e, const double *src, int K, int f0, int on_device) {
   if (!src) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
+  if (split_inputs(e, on_device)) {
+    const int rc = split_inputs_begin(e);
+    if (rc != SHC_OK) return rc;
+    const int64_t mid = split_first_instance_of_second_half(e);
+    scatter_leg_kernel<<<dim3((unsigned)((mid * e->L + 255) / 256)), dim3(256), 0, e->half_stream[0]>>>(src, e->st.legd, e->n_slots, mid, e->L, K, f0, 0);
+    if (e->n > mid)
+      scatter_leg_kernel<<<dim3((unsigned)(((e->n - mid) * e->L + 255) / 256)), dim3(256), 0, e->half_stream[1]>>>(src, e->st.legd, e->n_slots, e->n, e->L, K, f0, mid);
+    HIP_TRY(hipGetLastError());
+    return SHC_OK;
+  }
   const double *d;
   int rc = to_device(e, src, size_t(e->n) * e->L * K, on_device, &d);
   if (rc != SHC_OK) return rc;
@@ -970,7 +1009,11 @@ static int derive_tips(shc_engine *e);
 #define LEG_FIELD(e, NAME) ((e)->NJ == 3 ? Fields<3>::NAME : ((e)->NJ == 4 ? Fields<4>::NAME : Fields<5>::NAME))
 
 extern "C" int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, const double *angular, int on_device) {
-  SHC_BUSY_GUARD(e);
+  SHC_BUSY_ONLY(e);
+  if (e && !split_inputs(e, on_device)) {
+    const int rc_join_ = join_side(e);
+    if (rc_join_ != SHC_OK) return rc_join_;
+  }
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = scatter_rob(e, linear_xy, 2, RobotFields::VIN, on_device);
   if (rc != SHC_OK) return rc;
@@ -978,7 +1021,11 @@ extern "C" int shc_engine_set_velocity(shc_engine *e, const double *linear_xy, c
 }
 
 extern "C" int shc_engine_set_imu(shc_engine *e, const double *orientation_wxyz, const double *angular_velocity, int on_device) {
-  SHC_BUSY_GUARD(e);
+  SHC_BUSY_ONLY(e);
+  if (e && !split_inputs(e, on_device)) {
+    const int rc_join_ = join_side(e);
+    if (rc_join_ != SHC_OK) return rc_join_;
+  }
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = scatter_rob(e, orientation_wxyz, 4, RobotFields::IMUQ, on_device, 1);
   if (rc != SHC_OK) return rc;
@@ -1010,7 +1057,11 @@ __global__ void touchdown_detection_kernel(DevState st, const SharedConsts<L, NJ
 }
 
 extern "C" int shc_engine_set_tip_force(shc_engine *e, const double *tip_force, int on_device) {
-  SHC_BUSY_GUARD(e);
+  SHC_BUSY_ONLY(e);
+  if (e && !split_inputs(e, on_device && !e->params.rough_terrain_mode)) {
+    const int rc_join_ = join_side(e);
+    if (rc_join_ != SHC_OK) return rc_join_;
+  }
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   int rc = scatter_leg(e, tip_force, 3, LEG_FIELD(e, FORCE_IN), on_device);
   if (rc != SHC_OK || !tip_force) return rc;
@@ -1036,7 +1087,11 @@ static int effort_live(shc_engine *e) {
 }
 
 extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_effort, int on_device) {
-  SHC_BUSY_GUARD(e);
+  SHC_BUSY_ONLY(e);
+  if (e && !split_inputs(e, on_device && (e->rt_flags & RT_EFFORT_LIVE))) {
+    const int rc_join_ = join_side(e);
+    if (rc_join_ != SHC_OK) return rc_join_;
+  }
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (joint_effort) { // Leg::calculateTipForce has something to filter from now on
     const int rc = effort_live(e);
@@ -1047,7 +1102,11 @@ extern "C" int shc_engine_set_joint_effort(shc_engine *e, const double *joint_ef
 
 extern "C" int shc_engine_set_pose_input(shc_engine *e, const double *translation_velocity, const double *rotation_velocity,
                                          int on_device) {
-  SHC_BUSY_GUARD(e);
+  SHC_BUSY_ONLY(e);
+  if (e && !split_inputs(e, on_device)) {
+    const int rc_join_ = join_side(e);
+    if (rc_join_ != SHC_OK) return rc_join_;
+  }
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (translation_velocity || rotation_velocity) e->rt_flags |= RT_MANUAL_LIVE;
   int rc = scatter_rob(e, translation_velocity, 3, RobotFields::TVI, on_device);
@@ -1073,13 +1132,28 @@ extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode
   return SHC_OK;
 }
 
-// Order the engine's stream after everything earlier split steps launched on the side stream (no host wait).
+// The two streams the halves of split steps run on: ONE pair per device for the whole process, created back to back so that they
+// sit on two different hardware queues whatever the caller's own stream is (HIP maps streams to a few hardware queues in
+// creation order; two streams on one queue serialise, and a pair created per engine did land on the caller's queue now and then).
+static int split_streams(int device, hipStream_t out[2]) {
+  static hipStream_t pool[64][2] = {};
+  if (device < 0 || device >= 64) return fail(SHC_ERR_INVALID_ARG, "device index");
+  if (!pool[device][0]) {
+    HIP_TRY(hipStreamCreateWithFlags(&pool[device][0], hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&pool[device][1], hipStreamNonBlocking));
+  }
+  out[0] = pool[device][0], out[1] = pool[device][1];
+  return SHC_OK;
+}
+// Order the engine's stream after everything earlier split steps launched on the split streams (no host wait).
 static int join_side(shc_engine *e) {
   e->main_dirty = true;
   if (!e->side_busy) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(hipEventRecord(e->ev_side, e->side));
-  HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_side, 0));
+  for (int h = 0; h < 2; ++h) {
+    HIP_TRY(hipEventRecord(e->ev_half[h], e->half_stream[h]));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_half[h], 0));
+  }
   e->side_busy = false;
   return SHC_OK;
 }
@@ -1115,31 +1189,51 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
     if (rc != SHC_OK) return rc;
   }
   const int64_t half = split ? ((e->n_waves / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block : e->n_waves;
-  const unsigned grid = (unsigned)((half + waves_per_block - 1) / waves_per_block);
-  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, grid, block, n_cycles, nullptr, nullptr, 0};
-  if (split) {
-    if (!e->side) {
-      HIP_TRY(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&e->ev_side, hipEventDisableTiming));
-    }
-    if (e->main_dirty) { // inputs or state were touched on the engine's stream since the last split step: the side stream follows them
-      HIP_TRY(hipEventRecord(e->ev_main, e->stream));
-      HIP_TRY(hipStreamWaitEvent(e->side, e->ev_main, 0));
-      e->main_dirty = false;
-    }
-  }
+  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream,
+                (unsigned)((half + waves_per_block - 1) / waves_per_block), block, n_cycles, nullptr, nullptr, 0};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
-  SHC_DISPATCH(e->L, e->NJ, CALL);
-  HIP_TRY(hipGetLastError());
-  if (split) {
-    a.stream = e->side;
-    a.wave0 = half;
-    a.grid = (unsigned)((e->n_waves - half + waves_per_block - 1) / waves_per_block);
+  if (!split) {
     SHC_DISPATCH(e->L, e->NJ, CALL);
     HIP_TRY(hipGetLastError());
-    e->side_busy = true;
+    return SHC_OK;
   }
+  if (!e->half_stream[0]) {
+    const int rc = split_streams(e->device, e->half_stream);
+    if (rc != SHC_OK) return rc;
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_half[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_half[1], hipEventDisableTiming));
+  }
+  const bool resync = e->main_dirty; // inputs or state were touched on the engine's stream since the last split step: both halves follow them
+  if (resync) {
+    HIP_TRY(hipEventRecord(e->ev_main, e->stream));
+    HIP_TRY(hipStreamWaitEvent(e->half_stream[0], e->ev_main, 0));
+    HIP_TRY(hipStreamWaitEvent(e->half_stream[1], e->ev_main, 0));
+    e->main_dirty = false;
+  }
+  a.stream = e->half_stream[0];
+  if (resync) {
+    // Two halves that start together end together - their tails and ramp-ups coincide and nothing overlaps (measured: a join
+    // every tenth step costs the whole gain).  After a join the halves are therefore STAGGERED: the first half of this one step
+    // goes out as two launches and the second half starts when the first of them is through, i.e. a quarter of a step late;
+    // both halves take the same time from then on, so the stagger stays until the next join.
+    const int64_t quarter = ((half / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block;
+    a.grid = (unsigned)(quarter / waves_per_block);
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev_half[0], e->half_stream[0]));
+    HIP_TRY(hipStreamWaitEvent(e->half_stream[1], e->ev_half[0], 0));
+    a.wave0 = quarter;
+    a.grid = (unsigned)((half - quarter + waves_per_block - 1) / waves_per_block);
+  }
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+  HIP_TRY(hipGetLastError());
+  a.stream = e->half_stream[1];
+  a.wave0 = half;
+  a.grid = (unsigned)((e->n_waves - half + waves_per_block - 1) / waves_per_block);
+  SHC_DISPATCH(e->L, e->NJ, CALL);
+  HIP_TRY(hipGetLastError());
+  e->side_busy = true;
 #undef CALL
   return SHC_OK;
 }

@@ -48,6 +48,11 @@ static void fleet_free(shc_fleet *f) {
   delete f;
 }
 
+static int f_parts_on_device(const shc_fleet *f, int device) {
+  int k = 0;
+  for (const auto &p : f->parts) k += p.device == device ? 1 : 0;
+  return k;
+}
 extern "C" int shc_fleet_create(const shc_params *params, int n_morphologies, const int32_t *morph_id, int64_t n_instances, const int *device_ids,
                                 int n_devices, shc_fleet **out) {
   if (!params || !out || n_morphologies < 1 || n_instances < 1) return fail(SHC_ERR_INVALID_ARG, "params / out NULL, or no morphology / instance");
@@ -111,6 +116,15 @@ extern "C" int shc_fleet_create(const shc_params *params, int n_morphologies, co
       return rc;
     }
   }
+  // parts that share a device already run concurrently, one stream each: no two-stream split inside such a part (shc_engine_step)
+  for (auto &part : f->parts)
+    if (f_parts_on_device(f, part.device) > 1) {
+      const int rc = shc_engine_set_features(part.engine, part.engine->features | SHC_FEAT_SINGLE_STREAM);
+      if (rc != SHC_OK) {
+        fleet_free(f);
+        return rc;
+      }
+    }
   f->gather.assign(n_devices, nullptr);
   *out = f;
   return SHC_OK;

@@ -4,8 +4,10 @@
 import numpy as np
 import pytest
 
-from syropod_highlevel_controller_amd import default_hexapod_params
-from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_SINGLE_STREAM
+torch = pytest.importorskip("torch")  # (before the engine library: torch bundles its own HIP runtime, which must be the first one loaded)
+
+from syropod_highlevel_controller_amd import default_hexapod_params  # noqa: E402
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_SINGLE_STREAM  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +61,6 @@ def test_split_steps_are_byte_identical_to_single_launches(Engine):
 
 def test_join_orders_the_callers_stream_after_both_halves(Engine):
     """A caller that enqueues its own work on the engine's stream right after shc_engine_step calls shc_engine_join first."""
-    import torch
     p = default_hexapod_params("tripod")
     n = 40960
     rng = np.random.default_rng(2)
