@@ -40,7 +40,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-ALG_BYTES_PER_CYCLE = {("hexapod", 2): 3008, ("hexapod", 3): 3560, ("octopod", 4): 4496}
+ALG_BYTES_PER_CYCLE = {("hexapod", 2): 3008, ("hexapod", 3): 3560, ("octopod", 4): 4496,
+                       # SURVEY.md section 8(f) rank 4 workloads, counted the same way: config 2's state + per leg the measured tip force (24 B read) and
+                       # Leg::step_plane_pose_ (position + defined flag, 32 B read) of rough terrain mode ...
+                       ("hexapod", "rough"): 3008 + 6 * (24 + 32),
+                       # ... config 4's state + per leg the two tip directions the engine keeps for LegStepper's origin / current tip rotations
+                       # (6 doubles read + written; SURVEY counts 3 full quaternions = 1 536 B - the smaller figure is the honest one here)
+                       ("octopod", "gravity"): 4496 + 8 * 2 * 48}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
 
 
@@ -77,6 +83,23 @@ def make_workload(name, n, seed, rank=0, joint_efforts=False):
     elif name == "config4":
         p = synthetic_octopod_params("ripple", 5, 8)
         key, desc = ("octopod", 4), "synthetic octopods (8x5 DOF), ripple gait, IK + Bezier tip trajectory"
+    elif name == "rough":   # the rough-terrain path
+        p = default_hexapod_params("tripod")
+        p.rough_terrain_mode, p.step_depth = 1, 0.012
+        key = ("hexapod", "rough")
+        desc = ("hexapods, tripod gait, rough_terrain_mode: tip-state messages (contact forces that come and go, resampled every 10 cycles from "
+                "device-resident sets) -> touchdown detection, step-plane swing targets, terrain-following default tips, walk-plane refit")
+
+        def contact_forces():
+            f = rng.normal(0, 0.25, (n, 6, 3))
+            f[..., 2] += rng.choice([0.0, 0.05, 0.6, 1.5], size=(n, 6), p=[0.3, 0.2, 0.2, 0.3])
+            return f
+        extra["force"] = contact_forces()
+        extra["force_sets"] = [contact_forces() for _ in range(4)]
+    elif name == "gravity":  # ... and gravity-aligned tips: tip rotations + the rotation-constrained IK on 5-DOF legs
+        p = synthetic_octopod_params("ripple", 5, 8)
+        p.gravity_aligned_tips = 1
+        key, desc = ("octopod", "gravity"), "synthetic octopods (8x5 DOF), ripple gait, gravity_aligned_tips: LegStepper tip rotations + rotation-constrained Leg::applyIK"
     else:
         raise SystemExit(f"unknown workload {name}")
     effort = rng.normal(0, 0.5, size=(n, p.leg_count * p.leg_dof[0]))
@@ -370,7 +393,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     return res
 
 
-DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config5": 1 << 20}
+DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config5": 1 << 20, "rough": 65536, "gravity": 65536}
 CONFIG5_BINS = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"))  # (legs, dof, gait)
 
 
@@ -483,7 +506,7 @@ def main():
     # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
     also = []
     if world == 1 and not use_dist and args.workload == "config2" and not args.instances and not args.no_also:
-        for name, efforts in (("config2", not primary_efforts), ("config3", False), ("config4", False), ("config4", True)):
+        for name, efforts in (("config2", not primary_efforts), ("config3", False), ("config4", False), ("config4", True), ("rough", False), ("gravity", False)):
             k = max(300, min(args.steps, 1000))   # long enough that first-touch and clock ramp are outside the figure
             try:   # the secondary workloads must never cost the run its primary line
                 r = run_workload(name, DEFAULT_INSTANCES[name], k, max(30, min(args.warmup, 100)), args.cycles_per_step, args.seed,

@@ -49,7 +49,11 @@ enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANU
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
                   F_ROT = 1u << 30, // F_ROT (with F_DYN, > 3 DOF): gravity-aligned tips, rotation-constrained IK
-                  F_TERRAIN = 1u << 29 }; // F_TERRAIN (with F_DYN): rough terrain mode and the tip-align pose compiled in
+                  // (with F_DYN) the paths around rough terrain, each compiled in only where a configuration needs it - all three in one kernel spill:
+                  F_ROUGH = 1u << 29,  // rough_terrain_mode: default tips follow the terrain, step-plane targets, external targets / defaults
+                  F_TALIGN = 1u << 28, // gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose
+                  F_MLEGS = 1u << 27,  // manual leg manipulation / planner mode: ManualRobot records, updateManual, RT_SKIP_MARKED
+                  F_TERRAIN = F_ROUGH | F_TALIGN | F_MLEGS };
 
 // Launch-uniform parameters (staged in LDS).
 struct CycleParams {
@@ -450,7 +454,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // state or steppers (walk_controller.cpp:492-505)
   int my_leg_state = LS_WALKING;
   bool frozen = false;
-  if ((F & F_TERRAIN) != 0 && mr != nullptr) {
+  if ((F & F_MLEGS) != 0 && mr != nullptr) {
     my_leg_state = mr->leg_state[leg];
 #pragma unroll
     for (int j = 0; j < L; ++j) frozen = frozen || g.get(my_leg_state, j) != LS_WALKING;
@@ -716,7 +720,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     }
     // ---- updateTipAlignPose (:1024-1088): the legs are visited in id order and each swinging leg overwrites the pose, reading the
     //      translation its predecessor left - re-simulated identically in every lane from L shuffled tip-to-joint vectors
-    if ((F & F_TERRAIN) != 0 && NJ <= 3 && uni(P.tip_align)) {
+    if ((F & F_TALIGN) != 0 && NJ <= 3 && uni(P.tip_align)) {
       Chain<NJ> ch0;
       chain_from_sincos<NJ>(lc, s.sn, s.cs, ch0); // the last applyFK: tip and last joint in the robot frame
       const V3 t2j_own = base_rotate(lc, ch0.p[NJ - 1] - ch0.pe);
@@ -966,7 +970,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     const V3 dflt = pk.get3(PK_DFLT);
     s.targ = dflt + s.strd * 0.5; // uses last cycle's stride (:1044 precedes updateStride)
     bool stepping = my_state != SS_FORCE_STOP;
-    const bool rough = (F & F_TERRAIN) != 0 && uni(P.rough_terrain) != 0; // rough terrain mode runs on the F_TERRAIN kernels
+    const bool rough = (F & F_ROUGH) != 0 && uni(P.rough_terrain) != 0; // rough terrain mode runs on the F_ROUGH kernels
     bool rough_update_default = false;
     V3 model_tip_prev{0, 0, 0};
     if (rough) { // Leg::current_tip_pose_.position_ as the previous cycle's applyFK left it
@@ -1188,7 +1192,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     }
   }
   // =============================================================== WalkController::updateManual x 2 (walk_controller.cpp:652-744)
-  if ((F & F_TERRAIN) != 0 && mr != nullptr && my_leg_state == LS_MANUAL) {
+  if ((F & F_MLEGS) != 0 && mr != nullptr && my_leg_state == LS_MANUAL) {
     const bool primary = leg == mr->primary_leg, secondary = !primary && leg == mr->secondary_leg;
     // (a MANUAL leg that is neither selection reads an uninitialised vector in the reference: its inputs are zero here)
     V3 vin{0, 0, 0}, pin{0, 0, 0};
@@ -1238,7 +1242,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     }
     out.poser_tip = (SHC_DBG(P) & 256) ? s.tip : inverse_transform_vector(bp, s.tip);
     // no posing for manually manipulated legs (:135-139)
-    if ((F & F_TERRAIN) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL)) out.poser_tip = s.tip;
+    if ((F & F_MLEGS) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL)) out.poser_tip = s.tip;
     if (rot_on && rot_def) desired_dir = rotate(inverse(bp.r), s.cur_dir); // pose.rotation^-1 * walker tip rotation (:129-130)
   }
 
@@ -1269,9 +1273,9 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
   {
     SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
-    if ((F & F_TERRAIN) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL))
+    if ((F & F_MLEGS) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL))
       desired = out.poser_tip; // "Don't apply delta to manually manipulated legs" (:655-656)
-    if ((F & F_TERRAIN) != 0 && mr != nullptr) { // Leg::desired_tip_pose_.position_ is read back by the next updateManual (:692)
+    if ((F & F_MLEGS) != 0 && mr != nullptr) { // Leg::desired_tip_pose_.position_ is read back by the next updateManual (:692)
       double *dd = const_cast<double *>(legd);
       reinterpret_cast<double2 *>(dd)[(Fields<NJ>::DES_TIP / 2) * ns + slot] = double2{desired.x, desired.y};
       dd[((Fields<NJ>::DES_TIP / 2 + 1) * ns + slot) * 2] = desired.z;

@@ -46,18 +46,49 @@ static void launch_cycle_feat(const CycleLaunch &a) {
   const CycleParams &c = *a.cp;
   unsigned f = (c.manual_posing ? F_MANUAL : 0) | (c.auto_posing ? F_AUTO : 0) | (c.inclination_posing ? F_INCL : 0) |
                (c.imu_posing ? F_IMU : 0) | (c.admittance_control ? F_ADM : 0) | (c.tip_force ? F_TIPF : 0) | (c.odometry ? F_ODOM : 0);
-  // rough terrain mode / the tip-align pose: generic kernels with that logic compiled in (kept out of the plain generic
-  // kernel, which would otherwise spill)
-  const bool terrain = c.rough_terrain || c.tip_align || (a.rt_flags & RT_MANUAL_LEGS) != 0;
+  // rough terrain mode / the tip-align pose / manual legs: generic kernels with that logic compiled in - one path each where a
+  // configuration needs just one (the usual case), all of them otherwise
+  const bool rough = c.rough_terrain != 0, talign = c.tip_align != 0, mlegs = (a.rt_flags & RT_MANUAL_LEGS) != 0;
+  const bool terrain = rough || talign || mlegs;
   if constexpr (NJ > 3) {
-    if (c.gravity_aligned) { // gravity-aligned tips: the generic kernel with the tip-rotation logic compiled in
+    if (c.gravity_aligned) { // gravity-aligned tips: kernels with the tip-rotation logic compiled in
+      if constexpr (SPEC) {  // default.yaml's posing set: feature-exact
+        constexpr unsigned C2 = F_MANUAL | F_ODOM;
+        if (!a.generic && !terrain && (f & ~F_TIPF) == C2) {
+          if (f & F_TIPF) launch_cycle<L, NJ, C2 | F_TIPF | F_ROT>(a);
+          else launch_cycle<L, NJ, C2 | F_ROT>(a);
+          return;
+        }
+      }
       if (terrain) launch_cycle<L, NJ, F_DYN | F_ROT | F_TERRAIN>(a);
       else launch_cycle<L, NJ, F_DYN | F_ROT>(a);
       return;
     }
   }
   if (terrain) {
-    launch_cycle<L, NJ, F_DYN | F_TERRAIN>(a);
+    if constexpr (SPEC) { // default.yaml's posing set (manual posing + odometry, with / without the tip-force estimate): feature-exact kernels
+      constexpr unsigned C2 = F_MANUAL | F_ODOM;
+      if (!a.generic && (f & ~F_TIPF) == C2) {
+        const bool tf = (f & F_TIPF) != 0;
+        if (rough && !talign && !mlegs) {
+          if (tf) launch_cycle<L, NJ, C2 | F_TIPF | F_ROUGH>(a);
+          else launch_cycle<L, NJ, C2 | F_ROUGH>(a);
+          return;
+        }
+        if constexpr (NJ <= 3) {
+          if (talign && !rough && !mlegs) {
+            if (tf) launch_cycle<L, NJ, C2 | F_TIPF | F_TALIGN>(a);
+            else launch_cycle<L, NJ, C2 | F_TALIGN>(a);
+            return;
+          }
+        }
+      }
+    }
+    if (rough && !talign && !mlegs) launch_cycle<L, NJ, F_DYN | F_ROUGH>(a);
+    else if (mlegs && !rough && !talign) launch_cycle<L, NJ, F_DYN | F_MLEGS>(a);
+    else if (NJ <= 3 && talign && !rough && !mlegs) {
+      if constexpr (NJ <= 3) launch_cycle<L, NJ, F_DYN | F_TALIGN>(a);
+    } else launch_cycle<L, NJ, F_DYN | F_TERRAIN>(a);
     return;
   }
   if constexpr (SPEC) {

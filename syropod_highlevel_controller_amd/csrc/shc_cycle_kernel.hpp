@@ -15,6 +15,12 @@ namespace shc {
 #ifndef SHC_WAVES_PER_SIMD
 #define SHC_WAVES_PER_SIMD 2
 #endif
+#ifndef SHC_ROT_WAVES_PER_SIMD
+#define SHC_ROT_WAVES_PER_SIMD 1
+#endif
+#ifndef SHC_TERRAIN_WAVES_PER_SIMD
+#define SHC_TERRAIN_WAVES_PER_SIMD 2
+#endif
 
 // Paired planes of the per-leg SoA state: plane p = fields (2p, 2p + 1) as one double2 per slot.
 struct LegPlanes {
@@ -582,7 +588,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   // RT_SKIP_MARKED - this launch follows a loop-level kernel (leg toggle, plan execution) that has already run the loop of the robots it
   // marked (ManualRobot::skip_cycle): they are left exactly as they are.  Model::current_pose_ is otherwise output only; here it
   // is loaded too so that the tile write-back is the identity for a skipped robot.
-  const bool skip_marked = (F & F_TERRAIN) != 0 && (rt_flags & RT_SKIP_MARKED) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0;
+  const bool skip_marked = (F & F_MLEGS) != 0 && (rt_flags & RT_SKIP_MARKED) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0;
   constexpr int int_iters = (R::I_COUNT * RPW + 63) / 64; // 3-legged robots: 21 per wave x 4 ints = 84 entries > one wave's width
   int32_t t_int[int_iters];
   if (any_robot) {
@@ -593,7 +599,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
     if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, gtile, lane);
     if (skip_marked) load_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, gtile, lane);
-    if ((F & F_TERRAIN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
+    if ((F & F_TALIGN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
     // Leg::applyFK of the previous cycle: sin / cos of the stored joint angles
@@ -618,7 +624,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
     if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, tile, lane);
     if (skip_marked) put_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, tile, lane);
-    if ((F & F_TERRAIN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
+    if ((F & F_TALIGN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it)
       if (it * 64 + lane < R::I_COUNT * RPW) tile_i[it * 64 + lane] = t_int[it];
@@ -644,8 +650,8 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   LegOut out;
   SHC_TICK(1);
   unsigned dirty = 0;
-  double *const ext = ((F & F_TERRAIN) != 0 && (rt_flags & RT_EXTERNAL) != 0) ? st.ext : nullptr; // external targets (rough terrain mode)
-  const ManualRobot *const mr = ((F & F_TERRAIN) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0 && any_robot) ? st.manual + (rob0 + grp) : nullptr;
+  double *const ext = ((F & F_ROUGH) != 0 && (rt_flags & RT_EXTERNAL) != 0) ? st.ext : nullptr; // external targets (rough terrain mode)
+  const ManualRobot *const mr = ((F & F_MLEGS) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0 && any_robot) ? st.manual + (rob0 + grp) : nullptr;
   const bool skip = skip_marked && mr != nullptr && mr->skip_cycle != 0; // (uniform over the lanes of a robot)
   ResidentHeld held;
   if constexpr (RES) {
@@ -673,7 +679,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
   store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
   if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::ODOM_END>(tile, gtile, lane);
-  if ((F & F_TERRAIN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
+  if ((F & F_TALIGN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
   static_assert((R::I_POSE_PHASE + 1) * RPW <= 64, "the written-back int fields (word, poser latches, pose phase) fit one wave-wide store");
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
   if constexpr (RES) resident_epilogue<L, NJ, F>(*ra, st, slot, lane, live, tile, tile_i, gtile, gtile_i, held);
@@ -681,7 +687,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
 }
 
 template <int L, int NJ, unsigned F>
-__global__ void __launch_bounds__(256, (F & F_ROT) ? 1 : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles,
+__global__ void __launch_bounds__(256, (F & F_ROT) ? SHC_ROT_WAVES_PER_SIMD : ((F & F_DYN) && (F & F_TERRAIN)) ? SHC_TERRAIN_WAVES_PER_SIMD : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles,
                                                                                              unsigned rt_flags, int64_t wave0) {
   cycle_wave<L, NJ, F, false>(st, gc, n_cycles, rt_flags, wave0 + ((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6), nullptr);
 }
