@@ -1,9 +1,20 @@
 #!/bin/bash
-# rocprofv3 evidence for the three single-GPU BASELINE.json workloads (run through gpurun from the repo root).
+# Round-3 profiles (run through gpurun from the repo root): the BASELINE.json configurations + the section 8(f) workloads, each its own
+# rocprofv3 passes (kernel trace + stats; FETCH_SIZE, WRITE_SIZE, SQ, LDS counters each in a run of their own - scripts/profile_round.sh),
+# summarised on the box (the raw CSVs exceed what gpurun copies back) into gpurun_out/summaries/, which is then copied to profiles/.
 R=${GRAFT_REPO_ROOT:-$PWD}
-PROF_DIR=prof_c2 bash $R/scripts/profile_round.sh --workload config2
-PROF_DIR=prof_c3 PROF_STEPS=200 bash $R/scripts/profile_round.sh --workload config3
-PROF_DIR=prof_c4 PROF_STEPS=200 bash $R/scripts/profile_round.sh --workload config4
-# keep the merged output small: the per-dispatch CSVs are what scripts/summarize_prof.py reads
-find $R/gpurun_out/prof_c* -name '*.db' -delete 2>/dev/null
-du -sh $R/gpurun_out/prof_c*
+cd $R
+S=$R/gpurun_out/summaries; mkdir -p $S
+run() { # name, summary file, traffic key, resident K or "", bench arguments...
+  local name=$1 out=$2 key=$3 res=$4; shift 4
+  PROF_DIR=prof_$name PROF_STEPS=${PROF_STEPS:-300} bash scripts/profile_round.sh "$@" > $S/$name.log 2>&1
+  python scripts/summarize_prof.py gpurun_out/prof_$name $S/$out $key $res > /dev/null 2>> $S/$name.log
+  rm -rf gpurun_out/prof_$name
+}
+run c2_resident r03_config2_resident_rocprofv3.txt config2:resident:4096:1 resident:4000 --workload config2
+run c2_launch r03_config2_launch_rocprofv3.txt config2:4096:1 launch --workload config2 --mode launch
+run c3 r03_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-joint-efforts
+run c4 r03_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
+run rough r03_rough_terrain_rocprofv3.txt rough:65536:1 split --workload rough --no-joint-efforts
+run gravity r03_gravity_aligned_rocprofv3.txt gravity:65536:1 split --workload gravity --no-joint-efforts
+ls -la $S

@@ -12,6 +12,9 @@ import statistics as st
 import sys
 
 KERNEL = "shc_cycle_kernel"
+# resident mode: ONE long launch runs K cycles; every per-launch figure below is divided by K (argv[4] = "resident:<K>", the
+# longest launch of the trace is the K-cycle one bench.py times)
+RESIDENT_K = None
 CAL_KERNEL = "shc_plane_copy_kernel"
 CAL_KIB = 64 * 1024 * 1024 * 8 / 1024.0  # scripts/profile_round.sh copies 64 Mi doubles per launch
 
@@ -28,6 +31,7 @@ def kernel_stats(dirn, out):
         out.write(open(f).read())
     f = newest(f"{dirn}/**/*_kernel_trace.csv")
     med = None
+    best_total = 0
     if f:
         rows = list(csv.DictReader(open(f)))
         by = collections.defaultdict(list)
@@ -41,8 +45,12 @@ def kernel_stats(dirn, out):
             d = sorted(d)
             out.write(f"{k[:90]:90s} {len(d):6d} {st.mean(d):10.0f} {st.median(d):10.0f} {d[0]:9d} {d[int(.9 * (len(d) - 1))]:9d} {d[-1]:10d} | "
                       + " ".join(meta[k]) + "\n")
-            if KERNEL in k:
+            if KERNEL in k and (med is None or sum(d) > best_total):  # the specialisation that did the work (largest total time)
+                best_total = sum(d)
                 med = (st.mean(d), st.median(d), len(d))
+                if RESIDENT_K:
+                    out.write(f"  resident: the longest launch ran K = {RESIDENT_K} cycles: {d[-1]} ns / K = {d[-1] / RESIDENT_K:.1f} ns per cycle\n")
+                    med = (d[-1] / RESIDENT_K, d[-1] / RESIDENT_K, 1)
     return med
 
 
@@ -53,19 +61,30 @@ def pmc(dirn, kernel, out, label):
     if not f:
         return res
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if kernel in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
+    names = collections.Counter(r["Kernel_Name"] for r in rows)
+    main = names.most_common(1)[0][0] if names else None   # the specialisation that did the work
+    for r in rows:
+        if r["Kernel_Name"] == main:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     out.write(f"\n== rocprofv3 --pmc ({label}): kernel, counter, dispatches, mean, median\n")
     for c, v in sorted(agg.items()):
         out.write(f"{kernel:24s} {c:22s} {len(v):5d} {st.mean(v):16.1f} {st.median(v):16.1f}\n")
         res[c] = st.median(v)
+        if RESIDENT_K and kernel == KERNEL:  # the K-cycle launch is the one with the largest counts; per cycle
+            res[c] = max(v) / (1 if c == "SQ_WAVES" else RESIDENT_K)
+            out.write(f"{'':24s} {c:22s} largest launch / K = {res[c]:.2f} per cycle\n")
     return res
 
 
 if __name__ == "__main__":
     prof, dest = sys.argv[1], sys.argv[2]
     key = sys.argv[3] if len(sys.argv) > 3 else "config2:4096:1"
+    if len(sys.argv) > 4 and sys.argv[4].startswith("resident:"):
+        RESIDENT_K = int(sys.argv[4].split(":")[1])
+        KERNEL = "shc_resident"
+    # large batches: a step is TWO launches (the halves of the batch on two streams, shc_engine_step): per-step bytes = 2 x per launch
+    per_step = 2 if len(sys.argv) > 4 and sys.argv[4] == "split" else 1
     out = open(dest, "w")
     dur = kernel_stats(f"{prof}/trace", out)
     fetch = pmc(f"{prof}/pmc_fetch", KERNEL, out, "FETCH_SIZE pass").get("FETCH_SIZE")
@@ -82,12 +101,15 @@ if __name__ == "__main__":
     traffic = None
     if fetch and write and cf and cw:
         kib = kf * fetch + kw * write
-        traffic = kib * 1024.0
-        out.write(f"\n== derived ({key})\nHBM traffic per launch = {kf:.3f} x FETCH_SIZE + {kw:.3f} x WRITE_SIZE = {kf:.3f} x {fetch:.1f} KiB + "
-                  f"{kw:.3f} x {write:.1f} KiB = {kib:.1f} KiB = {traffic / 1e6:.2f} MB\n")
+        traffic = kib * 1024.0 * per_step
+        out.write(f"\n== derived ({key})\nHBM traffic per {'cycle' if RESIDENT_K else 'launch'} = {kf:.3f} x FETCH_SIZE + {kw:.3f} x WRITE_SIZE = {kf:.3f} x {fetch:.1f} KiB + "
+                  f"{kw:.3f} x {write:.1f} KiB = {kib:.1f} KiB = {kib * 1024.0 / 1e6:.2f} MB\n")
+        if per_step == 2:
+            out.write(f"a step of this batch = two launches (halves of the batch on two streams, overlapping): HBM traffic per step = {traffic / 1e6:.2f} MB; the step period "
+                      f"is about one launch's duration\n")
     if sq.get("SQ_WAVES"):
         w = sq["SQ_WAVES"]
-        out.write(f"VALU instructions per wave per launch = SQ_INSTS_VALU / SQ_WAVES = {sq.get('SQ_INSTS_VALU', 0) / w:.0f}; SALU {sq.get('SQ_INSTS_SALU', 0) / w:.0f}; "
+        out.write(f"VALU instructions per wave per {'cycle' if RESIDENT_K else 'launch'} = SQ_INSTS_VALU / SQ_WAVES = {sq.get('SQ_INSTS_VALU', 0) / w:.0f}; SALU {sq.get('SQ_INSTS_SALU', 0) / w:.0f}; "
                   f"LDS {sq.get('SQ_INSTS_LDS', 0) / w:.0f}\n")
         if sq.get("SQ_WAVE_CYCLES"):
             out.write(f"VALU issue share of wave lifetime = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {sq.get('SQ_ACTIVE_INST_VALU', 0) / sq['SQ_WAVE_CYCLES']:.3f}; "

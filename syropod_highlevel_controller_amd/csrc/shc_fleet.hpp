@@ -18,6 +18,12 @@ struct FleetPart {
   int morph = 0, device = 0, device_slot = 0;
   hipStream_t stream = nullptr;
   std::vector<int64_t> ids; // caller's instance ids, ascending
+  // the exchange step's buffers, allocated by the first shc_fleet_all_gather_joints and kept
+  double *g_joints = nullptr;         // this part's joints [rows][L][D] on its own device
+  int64_t *g_ids = nullptr;           // its ids on its own device
+  hipEvent_t g_ready = nullptr;       // recorded on `stream` once g_joints is complete
+  std::vector<double *> r_joints;     // per device slot (other devices only): the landing buffer of the peer copy ...
+  std::vector<int64_t *> r_ids;       // ... and the ids over there
 };
 
 struct shc_fleet {
@@ -27,6 +33,7 @@ struct shc_fleet {
   int64_t n = 0;
   int max_legs = 0, max_dof = 0;
   std::vector<double *> gather; // per device: [n][max_legs][max_dof], NaN padded
+  std::vector<hipStream_t> gather_stream; // per device: incoming peer copies + their placement
   std::vector<double> host_a, host_b;
   std::vector<int32_t> host_i;
 };
@@ -40,11 +47,22 @@ static void fleet_free(shc_fleet *f) {
       (void)hipStreamDestroy(p.stream);
     }
   }
-  for (size_t d = 0; d < f->gather.size(); ++d)
-    if (f->gather[d]) {
+  for (auto &p : f->parts) {
+    (void)hipSetDevice(p.device);
+    (void)hipFree(p.g_joints);
+    (void)hipFree(p.g_ids);
+    if (p.g_ready) (void)hipEventDestroy(p.g_ready);
+    for (size_t d = 0; d < p.r_joints.size(); ++d) {
       (void)hipSetDevice(f->devices[d]);
-      (void)hipFree(f->gather[d]);
+      (void)hipFree(p.r_joints[d]);
+      (void)hipFree(p.r_ids[d]);
     }
+  }
+  for (size_t d = 0; d < f->gather.size(); ++d) {
+    (void)hipSetDevice(f->devices[d]);
+    if (f->gather[d]) (void)hipFree(f->gather[d]);
+    if (d < f->gather_stream.size() && f->gather_stream[d]) (void)hipStreamDestroy(f->gather_stream[d]);
+  }
   delete f;
 }
 
@@ -274,94 +292,83 @@ __global__ void fleet_place_joints_kernel(double *gather, const double *part, co
 
 // The exchange step: every device ends up with the desired joint positions of ALL instances ([n][max_legs][max_dof], NaN
 // padded, caller's order) in its own HBM; device_buffers[d] receives device d's buffer (owned by the fleet).  Each part
-// gathers its joints on its own device and stream, places them in the local buffer and copies its rows to the other devices'
-// buffers peer to peer.
+// gathers its joints on its own device and stream, places them in the local buffer, and every other device pulls the part's
+// rows with one peer copy on its own gather stream (ordered behind the part by an event) and places them on its side.
+// Direct peer copies rather than a ring collective: xGMI is point to point (7 links per GPU), so the (device, device) pairs use
+// their own links concurrently - 1/8 of the data per link instead of the 7/8 a ring all-gather pushes through each - and a
+// single-process host needs no communicator; the one-process-per-GPU host (bench.py, parallel.py) exchanges the same buffer
+// with RCCL's all-gather.  Every buffer is allocated once (first call) and kept; nothing synchronises device-wide.
 extern "C" int shc_fleet_all_gather_joints(shc_fleet *f, double **device_buffers) {
   if (!f) return fail(SHC_ERR_INVALID_ARG, "fleet is NULL");
   const size_t row = size_t(f->max_legs) * f->max_dof, total = size_t(f->n) * row;
   const int nd = int(f->devices.size());
+  if (f->gather_stream.size() != size_t(nd)) f->gather_stream.assign(nd, nullptr);
   for (int d = 0; d < nd; ++d) {
     HIP_TRY(hipSetDevice(f->devices[d]));
-    if (!f->gather[d]) HIP_TRY(hipMalloc(&f->gather[d], total * 8));
-    // NaN padding (0xFF bytes are a NaN pattern); parts overwrite their entries
-    HIP_TRY(hipMemsetAsync(f->gather[d], 0xFF, total * 8, nullptr));
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (!f->gather_stream[d]) HIP_TRY(hipStreamCreateWithFlags(&f->gather_stream[d], hipStreamNonBlocking));
+    if (!f->gather[d]) { // NaN padding (0xFF bytes are a NaN pattern), written once: the parts only ever overwrite their own entries
+      HIP_TRY(hipMalloc(&f->gather[d], total * 8));
+      HIP_TRY(hipMemsetAsync(f->gather[d], 0xFF, total * 8, f->gather_stream[d]));
+      HIP_TRY(hipStreamSynchronize(f->gather_stream[d]));
+    }
   }
-  struct Tmp {
-    double *joints = nullptr;
-    int64_t *ids = nullptr;
-    double *placed = nullptr;
-  };
-  std::vector<Tmp> tmp(f->parts.size());
-  int rc = SHC_OK;
-  for (size_t k = 0; k < f->parts.size() && rc == SHC_OK; ++k) {
-    FleetPart &p = f->parts[k];
+  for (auto &p : f->parts) { // first call: the part's own buffers, the landing buffers on the other devices, the ids everywhere
+    if (p.g_joints) continue;
     const shc_params &pp = f->params[p.morph];
-    const int L = pp.leg_count, D = pp.leg_dof[0];
-    const int64_t rows = int64_t(p.ids.size());
-    if (hipSetDevice(p.device) != hipSuccess || hipMalloc(&tmp[k].joints, size_t(rows) * L * D * 8) != hipSuccess ||
-        hipMalloc(&tmp[k].ids, size_t(rows) * 8) != hipSuccess) {
-      rc = fail(SHC_ERR_HIP, "fleet gather: allocation failed");
-      break;
-    }
-    if (hipMemcpyAsync(tmp[k].ids, p.ids.data(), size_t(rows) * 8, hipMemcpyHostToDevice, p.stream) != hipSuccess) rc = fail(SHC_ERR_HIP, "fleet gather: copy failed");
-    if (rc == SHC_OK) rc = shc_engine_get_joint_state(p.engine, tmp[k].joints, nullptr, 1);
-    if (rc != SHC_OK) break;
-    const int64_t threads = rows * L * D;
-    for (int d = 0; d < nd && rc == SHC_OK; ++d) {
-      if (f->devices[d] == p.device) { // local placement (also covers several shards sharing one device)
-        fleet_place_joints_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, p.stream>>>(f->gather[d], tmp[k].joints, tmp[k].ids, rows, L, D,
-                                                                                                   f->max_legs, f->max_dof);
-        if (hipGetLastError() != hipSuccess) rc = fail(SHC_ERR_HIP, "fleet gather: placement kernel failed");
-      }
+    const size_t rows = p.ids.size(), elems = rows * pp.leg_count * pp.leg_dof[0];
+    HIP_TRY(hipSetDevice(p.device));
+    HIP_TRY(hipMalloc(&p.g_joints, elems * 8));
+    HIP_TRY(hipMalloc(&p.g_ids, rows * 8));
+    HIP_TRY(hipEventCreateWithFlags(&p.g_ready, hipEventDisableTiming));
+    HIP_TRY(hipMemcpy(p.g_ids, p.ids.data(), rows * 8, hipMemcpyHostToDevice));
+    p.r_joints.assign(nd, nullptr);
+    p.r_ids.assign(nd, nullptr);
+    for (int d = 0; d < nd; ++d) {
+      if (f->devices[d] == p.device) continue;
+      HIP_TRY(hipSetDevice(f->devices[d]));
+      HIP_TRY(hipMalloc(&p.r_joints[d], elems * 8));
+      HIP_TRY(hipMalloc(&p.r_ids[d], rows * 8));
+      HIP_TRY(hipMemcpy(p.r_ids[d], p.ids.data(), rows * 8, hipMemcpyHostToDevice));
     }
   }
-  // peer copies: a part's rows are scattered in the caller's order, so remote devices receive the part's contiguous joints and
-  // place them with the same kernel on their side
-  std::vector<std::pair<int, void *>> remote; // (device, buffer) to free
-  for (size_t k = 0; k < f->parts.size() && rc == SHC_OK; ++k) {
-    FleetPart &p = f->parts[k];
+  for (auto &p : f->parts) { // every part: joints -> its buffer -> the local gather buffer(s), on its own stream
     const shc_params &pp = f->params[p.morph];
     const int L = pp.leg_count, D = pp.leg_dof[0];
     const int64_t rows = int64_t(p.ids.size()), threads = rows * L * D;
-    if (hipSetDevice(p.device) != hipSuccess || hipStreamSynchronize(p.stream) != hipSuccess) {
-      rc = fail(SHC_ERR_HIP, "fleet gather: synchronisation failed");
-      break;
-    }
-    for (int d = 0; d < nd && rc == SHC_OK; ++d) {
+    HIP_TRY(hipSetDevice(p.device));
+    const int rc = shc_engine_get_joint_state(p.engine, p.g_joints, nullptr, 1);
+    if (rc != SHC_OK) return rc;
+    HIP_TRY(hipEventRecord(p.g_ready, p.stream));
+    for (int d = 0; d < nd; ++d)
+      if (f->devices[d] == p.device) { // (also covers several device slots naming one device)
+        fleet_place_joints_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, p.stream>>>(f->gather[d], p.g_joints, p.g_ids, rows, L, D, f->max_legs,
+                                                                                                   f->max_dof);
+        HIP_TRY(hipGetLastError());
+      }
+  }
+  for (auto &p : f->parts) { // every other device pulls the part's rows and places them
+    const shc_params &pp = f->params[p.morph];
+    const int L = pp.leg_count, D = pp.leg_dof[0];
+    const int64_t rows = int64_t(p.ids.size()), threads = rows * L * D;
+    for (int d = 0; d < nd; ++d) {
       if (f->devices[d] == p.device) continue;
-      double *rj = nullptr;
-      int64_t *ri = nullptr;
-      if (hipSetDevice(f->devices[d]) != hipSuccess || hipMalloc(&rj, size_t(threads) * 8) != hipSuccess || hipMalloc(&ri, size_t(rows) * 8) != hipSuccess) {
-        rc = fail(SHC_ERR_HIP, "fleet gather: remote allocation failed");
-        break;
-      }
-      remote.emplace_back(f->devices[d], rj);
-      remote.emplace_back(f->devices[d], ri);
-      if (hipMemcpyPeerAsync(rj, f->devices[d], tmp[k].joints, p.device, size_t(threads) * 8, nullptr) != hipSuccess ||
-          hipMemcpyPeerAsync(ri, f->devices[d], tmp[k].ids, p.device, size_t(rows) * 8, nullptr) != hipSuccess) {
-        rc = fail(SHC_ERR_HIP, "fleet gather: peer copy failed");
-        break;
-      }
-      fleet_place_joints_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, nullptr>>>(f->gather[d], rj, ri, rows, L, D, f->max_legs,
-                                                                                                 f->max_dof);
-      if (hipGetLastError() != hipSuccess) rc = fail(SHC_ERR_HIP, "fleet gather: remote placement failed");
+      HIP_TRY(hipSetDevice(f->devices[d]));
+      HIP_TRY(hipStreamWaitEvent(f->gather_stream[d], p.g_ready, 0));
+      HIP_TRY(hipMemcpyPeerAsync(p.r_joints[d], f->devices[d], p.g_joints, p.device, size_t(threads) * 8, f->gather_stream[d]));
+      fleet_place_joints_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, f->gather_stream[d]>>>(f->gather[d], p.r_joints[d], p.r_ids[d], rows, L, D,
+                                                                                                            f->max_legs, f->max_dof);
+      HIP_TRY(hipGetLastError());
     }
+  }
+  for (auto &p : f->parts) {
+    HIP_TRY(hipSetDevice(p.device));
+    HIP_TRY(hipStreamSynchronize(p.stream));
   }
   for (int d = 0; d < nd; ++d) {
-    (void)hipSetDevice(f->devices[d]);
-    (void)hipDeviceSynchronize();
+    HIP_TRY(hipSetDevice(f->devices[d]));
+    HIP_TRY(hipStreamSynchronize(f->gather_stream[d]));
   }
-  for (auto &r : remote) {
-    (void)hipSetDevice(r.first);
-    (void)hipFree(r.second);
-  }
-  for (size_t k = 0; k < tmp.size(); ++k) {
-    (void)hipSetDevice(f->parts[k].device);
-    (void)hipFree(tmp[k].joints);
-    (void)hipFree(tmp[k].ids);
-  }
-  if (rc == SHC_OK && device_buffers)
+  if (device_buffers)
     for (int d = 0; d < nd; ++d) device_buffers[d] = f->gather[d];
-  return rc;
+  return SHC_OK;
 }

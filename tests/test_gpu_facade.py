@@ -12,6 +12,10 @@ from oracle_lib import OracleRobot
 from syropod_highlevel_controller_amd import default_hexapod_params, engine
 
 pytestmark = pytest.mark.gpu
+# Free-running through hundreds of loops of a robot that STANDS (planner steps, leg manipulation): the reference's IK step amplifies
+# rounding differences there, so the facade run is held to the oracle as tightly as measured (x10), not to
+# 1e-6; the same loops are held to 1e-10 rad per call teacher-forced in tests/test_gpu_planner.py / test_gpu_manual_legs.py.
+FACADE_FREE_RUNNING_TIP_TOL = 5e-3
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -103,7 +107,8 @@ def test_facade_sequence_start_up_and_external_target(tmp_path):
     assert pl[0] == "plan" and [int(x) for x in pl[1:4]] == [stop_calls, step_calls, int(st[0])] and int(st[0]) == 1
     # free-running through ~250 calls of a robot that stands (where the reference's IK step amplifies rounding differences,
     # tests/test_gpu_planner.py holds every call to 1e-10 teacher-forced); here: same calls, same place
-    assert np.abs(np.array([float(x) for x in pl[4:7]]) - ob.leg_state()["model_tip"][0, 0]).max() <= 5e-3
+    d_plan = np.abs(np.array([float(x) for x in pl[4:7]]) - ob.leg_state()["model_tip"][0, 0]).max()
+    assert d_plan <= FACADE_FREE_RUNNING_TIP_TOL, d_plan
     # manual leg manipulation through the facade: the same requests on the oracle
     sel = np.array([3], dtype=np.int32)
     while ob.toggle_leg_state(sel)[0] != 1:
@@ -114,4 +119,8 @@ def test_facade_sequence_start_up_and_external_target(tmp_path):
     ob.step(30, 1)
     m = out[39].split()
     assert m[0] == "manual" and m[1] == "1" and m[6] == "3"                      # toggled, robot STOPPED
-    assert np.abs(np.array([float(x) for x in m[2:5]]) - ob.leg_state()["model_tip"][0, 3]).max() <= 5e-3
+    d_manual = np.abs(np.array([float(x) for x in m[2:5]]) - ob.leg_state()["model_tip"][0, 3]).max()
+    from conftest import parity_report
+    parity_report(f"[facade, free-running through the planner / manual-leg loops of a standing robot] model tip vs oracle: {d_plan:.2e} m after the plan, "
+                  f"{d_manual:.2e} m after the manual leg moves")
+    assert d_manual <= FACADE_FREE_RUNNING_TIP_TOL, d_manual
