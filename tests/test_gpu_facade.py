@@ -123,4 +123,4 @@ def test_facade_sequence_start_up_and_external_target(tmp_path):
     from conftest import parity_report
     parity_report(f"[facade, free-running through the planner / manual-leg loops of a standing robot] model tip vs oracle: {d_plan:.2e} m after the plan, "
                   f"{d_manual:.2e} m after the manual leg moves")
-    assert d_manual <= FACADE_FREE_RUNNING_TIP_TOL, d_manual
+    assert d_manual <= 1e-9, d_manual                                            # (placed by position input: no drift to speak of)

@@ -24,7 +24,7 @@ TOL_Q = 1e-6  # rad, BASELINE.json north_star
 # Free-running tests with a perturbed twin oracle: the fraction of instances whose REFERENCE trajectory is well-posed over the whole
 # horizon (the twin, inputs perturbed by 1e-13, stays within 1e-9 rad), as measured - asserted, not just reported.  (Every
 # instance, well-posed or not, is held to 1e-12 rad per cycle by the teacher-forced tests.)
-WELL_POSED = {("config3", 20.0): 0.9, ("config3", 2.0): 0.5}
+WELL_POSED = {("config3", 20.0, 100): 0.95, ("config3", 20.0, 300): 0.9, ("config3", 2.0, 300): 0.95}   # measured: 98 %, 95 %, 100 %
 
 
 @pytest.fixture(scope="module")
@@ -101,7 +101,7 @@ def compare(eng, ob, tol_q=TOL_Q, mask=None, ints=True):
     return float(dq.max())
 
 
-def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_posed=0.8, features=FEAT_DEFAULT):
+def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_posed=0.95, features=FEAT_DEFAULT, twin_tol=1e-9):
     # The engine always starts from its OWN init chain.  Parameter sets keep time_to_start / time_delta <= 300 start-up
     # steps: beyond that the reference's start-up iteration is ill-conditioned (two builds of the oracle itself end mrad
     # apart, tests/test_oracle_conditioning.py) and a free-running comparison has no common starting point; such parameter
@@ -131,7 +131,7 @@ def run_pair(Engine, p, n, inp, schedule, tol_q=TOL_Q, twin=False, min_well_pose
             tw.step(k, 8)
             qo, _ = ob.joints()
             qt, _ = tw.joints()
-            well = np.abs(qo - qt).max(axis=1) <= 1e-9
+            well = np.abs(qo - qt).max(axis=1) <= twin_tol
             assert well.mean() >= min_well_posed, f"only {well.mean():.2f} of the reference trajectories are well-posed"
             mask = well
             frac = min(frac, float(well.mean()))
@@ -168,9 +168,14 @@ def test_config3_wave_admittance_imu(Engine, force):
     p.admittance_control, p.imu_posing = 1, 1
     p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
     inp = make_inputs(p, 96, 5, imu=True, force=force)
-    run_pair(Engine, p, 96, inp, [1, 9, 40, 50], twin=False)                 # first 100 cycles: every instance
-    eng, _, _ = run_pair(Engine, p, 96, inp, [100, 100, 100], twin=True, min_well_posed=0.5)
-    assert eng.well_posed_fraction >= WELL_POSED["config3", force], eng.well_posed_fraction
+    if force <= 2.0:
+        run_pair(Engine, p, 96, inp, [1, 9, 40, 50], twin=False)             # first 100 cycles: every instance
+    else:  # (legs pressed into their joint limits: the reference trajectory of some instances is ill-posed from the first stance on)
+        eng, _, _ = run_pair(Engine, p, 96, inp, [1, 9, 40, 50], twin=True, min_well_posed=WELL_POSED["config3", force, 100])
+    # (at 20 N the twin criterion is tightened: an instance counts as well-posed while a 1e-13 input perturbation grows to no more than
+    #  1e-11 rad - the engine's own rounding differences are of that size, not 1e-13, and the map amplifies both alike)
+    eng, _, _ = run_pair(Engine, p, 96, inp, [100, 100, 100], twin=True, min_well_posed=WELL_POSED["config3", force, 300],
+                         twin_tol=1e-9 if force <= 2.0 else 1e-11)
 
 
 def test_config4_octopod_ripple(Engine):
@@ -183,7 +188,7 @@ def test_config5_mixed_morphologies_binned(Engine):
     """configs[4]: mixed morphologies run as one engine per (legs, dof) bin; every bin meets the bar."""
     for legs, dof, gait in ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod")):
         p = synthetic_octopod_params(gait, dof, legs)
-        run_pair(Engine, p, 33, make_inputs(p, 33, legs * 10 + dof), [40, 80, 80], twin=True, min_well_posed=0.5)
+        run_pair(Engine, p, 33, make_inputs(p, 33, legs * 10 + dof), [40, 80, 80], twin=True)
 
 
 @pytest.mark.parametrize("legs,dof,gait", [(3, 3, "wave"), (5, 3, "ripple"), (7, 3, "wave"), (8, 4, "ripple"), (4, 5, "amble"),
@@ -193,8 +198,7 @@ def test_every_other_kernel_instantiation(Engine, legs, dof, gait):
     the oracle (3 - 8 legs x 3 - 5 joints, lanes per group 3 ... 8, 21 ... 8 robots per wavefront)."""
     p = synthetic_octopod_params(gait, dof, legs)
     n = 45
-    run_pair(Engine, p, n, make_inputs(p, n, 500 + legs * 10 + dof, zero_every=8), [1, 1, 58, 120, 120], twin=True,
-             min_well_posed=0.5)
+    run_pair(Engine, p, n, make_inputs(p, n, 500 + legs * 10 + dof, zero_every=8), [1, 1, 58, 120, 120], twin=True)
 
 
 def test_config5_interleaved_fleet(Engine):
@@ -377,7 +381,7 @@ def test_parameter_variants(Engine, kw):
         setattr(p, k, val)
     n = 60
     inp = make_inputs(p, n, 211, force=2.0 if p.admittance_control else None)
-    run_pair(Engine, p, n, inp, [1, 1, 58, 140, 200], twin=True, min_well_posed=0.7)
+    run_pair(Engine, p, n, inp, [1, 1, 58, 140, 200], twin=True)
 
 
 @pytest.mark.parametrize("mode", ["throttle", "real"])
@@ -476,7 +480,7 @@ def test_custom_gait_and_saturating_pose_limits(Engine):
     q = R.from_euler("xyz", e).as_quat()
     inp["imu_q"] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1)
     inp["tv"], inp["rv"] = rng.uniform(-1, 1, size=(n, 3)), rng.uniform(-1, 1, size=(n, 3))
-    run_pair(Engine, p, n, inp, [1, 1, 98, 150, 150], twin=True, min_well_posed=0.5)
+    run_pair(Engine, p, n, inp, [1, 1, 98, 150, 150], twin=True)
 
 
 def test_manual_pose_inputs_and_reset_modes(Engine):
