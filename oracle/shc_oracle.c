@@ -1036,7 +1036,7 @@ static void stepper_update_stride(const orc_robot *r, stepper_t *s)
   s->swing_clearance = orc_v3_scale(orc_v3_normalized(s->walk_plane_normal), r->params.swing_height);
 }
 
-/* LegStepper::calculateStanceSpanChange (walk_controller.cpp:949-980), single-plane workspace */
+/* LegStepper::calculateStanceSpanChange (walk_controller.cpp:949-980): single-plane workspace, or the layered one of rough terrain mode */
 static orc_v3 stepper_calculate_stance_span_change(const orc_robot *r, const leg_t *leg)
 {
   const stepper_t *s = &leg->stepper;
@@ -2828,7 +2828,6 @@ size_t orc_sizeof_robot(void) { return sizeof(orc_robot); }
 orc_robot *orc_create(const shc_params *params)
 {
   if (!params || params->leg_count < 1 || params->leg_count > SHC_MAX_LEGS) return NULL;
-  if (params->rough_terrain_mode && params->stance_span_modifier != 0.0) return NULL; /* (the engine rejects this pair: shc_batch.h) */
   for (int l = 0; l < params->leg_count; ++l)
     if (params->leg_dof[l] < 1 || params->leg_dof[l] > SHC_MAX_JOINTS) return NULL;
   orc_robot *r = (orc_robot *)calloc(1, sizeof(orc_robot));

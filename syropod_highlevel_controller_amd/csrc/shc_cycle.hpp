@@ -180,7 +180,32 @@ struct DevState {
   int64_t n_slots, n_rob_pad, n_robots;
   double *ext; // ExtFields planes, nullptr until the first external request
   ManualRobot *manual; // nullptr until a leg is toggled
+  const double *span;  // rough terrain mode with a stance span modifier: the legs' layered-workspace planes (SpanTable), else nullptr
 };
+
+// LegStepper::calculateStanceSpanChange on the layered workspace of rough terrain mode (walk_controller.cpp:949-980): per leg the
+// plane heights and the plane radii at the one bearing (90 or 270 degrees) the leg's sign of the modifier selects, + the signed modifier.
+struct SpanTable {
+  static constexpr int kPlanes = 14; // WORKSPACE_LAYERS + 4 (hostinit::kMaxWorkspacePlanes)
+  static constexpr int kStride = 2 + 2 * kPlanes; // [0] planes in use, [1] modifier (signed for this leg), then (height, radius) pairs
+};
+SHC_HD double set_precision3(double v) { return round_to_int(v * 1000.0) / 1000.0; } // setPrecision(value, 3) (standard_includes.h:143; pow(10, 3) is exactly 1000)
+SHC_HD double stance_span_change_y(const double *table, int leg, double default_shift_z) {
+  const double *t = table + leg * SpanTable::kStride;
+  const int n = int(t[0]);
+  const double target = set_precision3(default_shift_z);
+  int lower = -1, upper = -1; // workspace.upper_bound(target) and its predecessor
+  for (int k = 0; k < n; ++k) {
+    const double h = t[2 + 2 * k];
+    if (h > target && (upper < 0 || h < t[2 + 2 * upper])) upper = k;
+    if (h <= target && (lower < 0 || h > t[2 + 2 * lower])) lower = k;
+  }
+  if (lower < 0 || upper < 0) return 0.0;
+  const double uh = set_precision3(t[2 + 2 * upper]), lh = set_precision3(t[2 + 2 * lower]);
+  const double i = (target - lh) / (uh - lh);
+  const double radius = t[3 + 2 * lower] * (1.0 - i) + t[3 + 2 * upper] * i;
+  return radius * t[1];
+}
 
 #if defined(__HIPCC__)
 
@@ -192,14 +217,11 @@ struct DevState {
 #else
 #define SHC_PHASE_FENCE() do {} while (0)
 #endif
-// Development-only phase timestamps (build with -DSHC_TIMING): wave 0 / lane 0 stores s_memtime at phase boundaries.
+// Development-only phase timestamps (build with -DSHC_RES2_TIMING) of the two-wavefront resident kernel: the leader of workgroup 1 keeps
+// the s_memtime stamps of its latest iteration in LDS; shc_engine_resident_end prints them.
 #if defined(SHC_RES2_TIMING)
-// ... of the two-wavefront resident kernel: the leader of workgroup 1 keeps the stamps of its latest iteration in LDS
 __shared__ long long shc_ticks_lds[32];
 #define SHC_TICK(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 1 && threadIdx.x == 0) shc_ticks_lds[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#elif defined(SHC_TIMING)
-__device__ long long *shc_tick_buf = nullptr;
-#define SHC_TICK(i) do { __builtin_amdgcn_sched_barrier(0); if (shc_tick_on) shc_tick_buf[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SHC_TICK(i) do {} while (0)
 #endif
@@ -410,7 +432,7 @@ template <int L, int NJ, unsigned F, bool ADM_HERE, typename IN>
 __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                             const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
                                             const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
-                                            FrontToBack &fb) {
+                                            FrontToBack &fb, const double *span = nullptr) {
   using R = RobotFields;
   using FT = Feat<F>;
   // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
@@ -425,9 +447,6 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // its own kernel specialisation (F_ROT), launched when the parameter is set
   constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
   bool rot_def = (s.word & LW_ROTDEF) != 0;
-#ifdef SHC_TIMING
-  const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
-#endif
   SHC_TICK(2);
 
   // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611)
@@ -953,7 +972,9 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     if (__any(my_update_default)) {
       if (my_update_default) {
         Pose wpp = rb.getpose(R::WPP); // leg_->getDefaultBodyPose() == walk_plane_pose_
-        V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y + lc.span_shift, 0.0}); // identity + stance span change
+        // identity + stance span change (single-plane workspace: a constant; layered workspace: from the default tip's current height)
+        const double span_y = ((F & F_ROUGH) != 0 && span != nullptr) ? stance_span_change_y(span, leg, pk.get3(PK_DFLT).z) : lc.span_shift;
+        V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y + span_y, 0.0});
         V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM_PREV));
         pk.put3(PK_DFLT, external_default(ext, ns, slot, idp + proj));
         default_changed = true;
@@ -1107,7 +1128,8 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       if (rough && __any(rough_update_default)) { // LegStepper::updateDefaultTipPosition at the start of a swing / stance period
         if (rough_update_default) { // (the stepper's walk-plane copy was refreshed by updateStride just before: the current plane)
           Pose wpp = rb.getpose(R::WPP);
-          V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y, 0.0}); // (stance span modifier 0 in rough terrain mode)
+          const double span_y = span != nullptr ? stance_span_change_y(span, leg, pk.get3(PK_DFLT).z) : 0.0; // calculateStanceSpanChange (:996-997)
+          V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y + span_y, 0.0});
           V3 proj = projection(pk.get3(PK_TORG) - idp, rb.get3(R::PNORM));
           V3 new_default = external_default(ext, ns, slot, idp + proj);
           pk.put3(PK_DFLT, new_default);
@@ -1267,9 +1289,6 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
   const V3 desired_dir = fb.desired_dir;
   const bool rot_def = fb.rot_def;
   const int my_leg_state = fb.my_leg_state;
-#ifdef SHC_TIMING
-  const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
-#endif
   {
     SHC_TICK(9);
     V3 desired = out.poser_tip + out.adm_delta; // Leg::setDesiredTipPose (:653-663)
@@ -1359,9 +1378,9 @@ template <int L, int NJ, unsigned F, typename IN = LegInPlanes<NJ>, typename MID
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                       const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
                                       const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
-                                      const MID &mid = MID()) {
+                                      const MID &mid = MID(), const double *span = nullptr) {
   FrontToBack fb;
-  cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, legd, ns, slot, dirty, manual_live, touchdown_detection, ext, mr, in, fb);
+  cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, legd, ns, slot, dirty, manual_live, touchdown_detection, ext, mr, in, fb, span);
   mid();
   cycle_back<L, NJ, F>(s, out, C, leg, legd, ns, slot, mr, in, fb);
 }

@@ -524,9 +524,6 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   // workgroup for small batches, 4 for large ones), cycle_lds_bytes_per_wave() each
   extern __shared__ double wave_lds[];
   constexpr int kWaveDoubles = R::COUNT * RPW + PK_COUNT * 64 + (R::I_COUNT * RPW + 1) / 2;
-#ifdef SHC_TIMING
-  const bool shc_tick_on = shc_tick_buf && blockIdx.x == 0 && threadIdx.x == 0;
-#endif
   SHC_TICK(0);
   // Launch-uniform run-time facts the host knows (kernel argument = SGPR from the first instruction on, no load to wait for):
   // RT_MANUAL_LIVE - some pose input / reset mode / injected state has ever been given to this engine.  Until then every
@@ -659,7 +656,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   } else if (!skip) {
     for (int c = 0; c < n_cycles; ++c)
       cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
-                      LegInPlanes<NJ>{st.legd, st.n_slots, slot});
+                      LegInPlanes<NJ>{st.legd, st.n_slots, slot}, NoHook(), (F & F_ROUGH) != 0 ? st.span : nullptr);
   }
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;

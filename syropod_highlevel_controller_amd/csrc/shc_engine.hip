@@ -264,6 +264,8 @@ struct shc_engine {
   int pack_step, executing_transition, transition_calls; // PoseController::pack_step_ / executing_transition_ (pose_controller.h:294, :298)
   bool planner_mode = false;            // StateController::planner_mode_ (state_controller.h:337)
   bool plan_poser_tips_current = false; // no control cycle has run since the last shc_engine_execute_plan (SeqRobotState::poser_tip_from_plan holds)
+  double *d_span = nullptr;             // SpanTable (rough terrain mode with a stance span modifier), rebuilt with the tables
+  bool span_dirty = true;
   struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
   // Large batches: a step is launched as two halves on two streams with no join between steps (see shc_engine_step).
   hipStream_t half_stream[2] = {nullptr, nullptr}; // the device's pair of split streams (split_streams()), once this engine has used them
@@ -432,9 +434,6 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
   for (int l = 0; l < p->leg_count; ++l)
     if (p->leg_dof[l] != nj) return fail(SHC_ERR_UNSUPPORTED, "all legs of one engine must share one DOF (bin mixed morphologies)");
   if (nj < 3 || nj > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
-  if (p->rough_terrain_mode && p->stance_span_modifier != 0.0)
-    return fail(SHC_ERR_UNSUPPORTED, "rough_terrain_mode with a stance span modifier (default tips re-derived from the layered workspace every step) "
-                                     "is outside the accelerated path");
   if (p->rough_terrain_mode && !(p->touchdown_threshold >= p->liftoff_threshold))
     return fail(SHC_ERR_INVALID_ARG, "touchdown_threshold must be >= liftoff_threshold");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
@@ -475,20 +474,6 @@ extern "C" int shc_device_count(void) {
 }
 
 extern "C" const char *shc_last_error(void) { return g_last_error.c_str(); }
-
-#ifdef SHC_TIMING
-extern "C" int shc_debug_ticks(long long *out16) {
-  static long long *d = nullptr;
-  if (!d) {
-    HIP_TRY(hipMalloc(&d, 32 * 8));
-    HIP_TRY(hipMemset(d, 0, 32 * 8));
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(shc_tick_buf), &d, sizeof d));
-  }
-  HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out16, d, 32 * 8, hipMemcpyDeviceToHost));
-  return SHC_OK;
-}
-#endif
 
 extern "C" int shc_debug_plane_copy(int device, int64_t n_doubles, int reps) {
   if (n_doubles < 2 || (n_doubles & 1) || reps < 1) return fail(SHC_ERR_INVALID_ARG, "n_doubles must be even and >= 2, reps >= 1");
@@ -615,7 +600,44 @@ extern "C" int shc_generate_tables_batch(const shc_params *params, int64_t count
     else return fail(SHC_ERR_UNSUPPORTED, "no kernel specialisation for this (legs, dof)"); \
   } while (0)
 
+// rough terrain mode with a stance span modifier: LegStepper::calculateStanceSpanChange interpolates the layered workspace at the
+// default tip's height at every swing / stance start - the planes of every leg's workspace, searched again from the default
+// configuration the tables hold (the init chain itself only keeps the plane at height 0)
+template <int NJ>
+static int build_span_table(shc_engine *e) {
+  e->span_dirty = false;
+  const shc_params &p = e->params;
+  if (!(p.rough_terrain_mode && p.stance_span_modifier != 0.0)) {
+    e->st.span = nullptr;
+    return SHC_OK;
+  }
+  std::vector<double> tab(size_t(e->L) * SpanTable::kStride, 0.0);
+  static_assert(SpanTable::kPlanes >= hostinit::kMaxWorkspacePlanes, "span table holds every plane of the layered workspace");
+  for (int l = 0; l < e->L; ++l) {
+    hostinit::LayeredPlanes planes;
+    shc_tables scratch = e->tables;
+    hostinit::generate_tables_leg<NJ>(p, l, scratch, 1, 8, e->tables.default_joint_position[l], &planes);
+    double m = p.stance_span_modifier;
+    const bool positive_y = p.stance_position[l][1] > 0.0;
+    const int bearing = (positive_y ^ (m > 0.0)) ? 270 : 90;
+    m *= positive_y ? 1.0 : -1.0;
+    double *t = &tab[size_t(l) * SpanTable::kStride];
+    t[0] = planes.n;
+    t[1] = m;
+    for (int k = 0; k < planes.n; ++k) t[2 + 2 * k] = planes.height[k], t[3 + 2 * k] = planes.radius[k][bearing / 45];
+  }
+  if (!e->d_span) HIP_TRY(hipMalloc(&e->d_span, tab.size() * 8));
+  HIP_TRY(hipMemcpyAsync(e->d_span, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->st.span = e->d_span;
+  return SHC_OK;
+}
+
 static int upload_consts(shc_engine *e) {
+  if (e->span_dirty) {
+    const int rc = e->NJ == 3 ? build_span_table<3>(e) : (e->NJ == 4 ? build_span_table<4>(e) : build_span_table<5>(e));
+    if (rc != SHC_OK) return rc;
+  }
 #define CALL(L_, NJ_)                                                                                   \
   {                                                                                                     \
     SharedConsts<L_, NJ_> c;                                                                            \
@@ -802,6 +824,7 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   HIP_TRY(hipSetDevice(device));
   shc_engine *e = new shc_engine();
   memset(static_cast<void *>(e), 0, sizeof *e);
+  e->span_dirty = e->main_dirty = true; // (the memset above also clears the members' default initialisers)
   e->params = *params;
   e->L = L;
   e->NJ = NJ;
@@ -811,6 +834,7 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   e->features = SHC_FEAT_TIP_FORCE | SHC_FEAT_ODOMETRY;
   if (tables) {
     e->tables = *tables;
+    e->span_dirty = true;
   } else {
     rc = shc_generate_tables(params, &e->tables);
     if (rc != SHC_OK) {
@@ -870,6 +894,7 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->d_seq);
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
+  (void)hipFree(e->d_span);
   if (e->half_stream[0]) { // (the streams belong to the process-wide pair)
     (void)hipEventDestroy(e->ev_main);
     (void)hipEventDestroy(e->ev_half[0]);
@@ -1351,6 +1376,7 @@ extern "C" int shc_engine_change_gait(shc_engine *e, const shc_params *ng, int64
   if ((rc = shc_generate_tables(&p, &t)) != SHC_OK) return rc; // generateStepCycle + generateLimits (morphology tables come out unchanged)
   e->params = p;
   e->tables = t;
+  e->span_dirty = true;
   build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   if ((rc = upload_consts(e)) != SHC_OK) return rc;
   if (p.auto_posing) { // setAutoPoseParams builds fresh AutoPosers: their start / end checks are reset (pose_controller.cpp:39-61)
@@ -2121,18 +2147,19 @@ extern "C" int shc_engine_begin_sequence_startup(shc_engine *e, const double *jo
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (e->params.auto_posing && e->params.pose_frequency != -1.0)
     return fail(SHC_ERR_UNSUPPORTED, "sequences with auto posing on its own clock (the body pose would move during the sequence)");
-  int rc = init_state(e); // StateController::init(): fresh walker / poser state
-  if (rc != SHC_OK) return rc;
+  // (arguments first: an INVALID_ARG return leaves the batch as it was)
+  if (per_instance && !joint_positions) return fail(SHC_ERR_INVALID_ARG, "per_instance needs joint_positions");
   const size_t rows = per_instance ? size_t(e->n) * e->L : size_t(e->L);
+  if (rows * e->NJ * 8 > e->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
   std::vector<double> q(rows * e->NJ);
   if (joint_positions) {
     memcpy(q.data(), joint_positions, q.size() * 8);
   } else { // READY: every joint at its `unpacked` position (state_controller.cpp:217, :236)
-    if (per_instance) return fail(SHC_ERR_INVALID_ARG, "per_instance needs joint_positions");
     for (int l = 0; l < e->L; ++l)
       for (int j = 0; j < e->NJ; ++j) q[size_t(l) * e->NJ + j] = e->params.joint[l][j].unpacked;
   }
-  if (q.size() * 8 > e->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
+  int rc = init_state(e); // StateController::init(): fresh walker / poser state
+  if (rc != SHC_OK) return rc;
   HIP_TRY(hipMemcpyAsync(e->d_stage, q.data(), q.size() * 8, hipMemcpyHostToDevice, e->stream));
   const int64_t threads = e->n * e->L;
   set_joint_positions_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(e->st, e->d_stage, per_instance, e->L, e->NJ, LEG_FIELD(e, Q),
@@ -2446,11 +2473,22 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   HIP_TRY(hipSetDevice(e->device));
   // Model::updateDefaultConfiguration + generateWorkspaces + generateWalkspace (state_controller.cpp:307-310): the tables of an
-  // engine belong to its morphology, so the configuration of instance 0 stands for the batch (identical robots that ran the
-  // same sequence end on the same joints)
+  // engine belong to its morphology, so the configuration of instance 0 stands for the batch.  Robots that were started from
+  // different joint positions (shc_engine_begin_sequence_startup per_instance) end their sequences on the same READY stance
+  // only up to the 1 mm / IK tolerance of the last step: the largest difference to instance 0 is checked here - beyond 1e-3 rad
+  // the batch does not share one configuration and the caller has to start such robots in engines of their own.
   std::vector<double> q(size_t(e->n) * e->L * e->NJ);
   int rc = shc_engine_get_joint_state(e, q.data(), nullptr, 0);
   if (rc != SHC_OK) return rc;
+  {
+    const size_t row = size_t(e->L) * e->NJ;
+    double worst = 0.0;
+    for (int64_t i = 1; i < e->n; ++i)
+      for (size_t k = 0; k < row; ++k) worst = fmax(worst, fabs(q[size_t(i) * row + k] - q[k]));
+    if (!(worst <= 1e-3))
+      return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup: the instances ended their start-up sequences on different configurations (max |dq| to instance 0 = " +
+                                           std::to_string(worst) + " rad): one engine has one set of workspace / limit tables");
+  }
   shc_tables t;
   bool ok = false;
   switch (e->NJ) {
@@ -2460,6 +2498,7 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   }
   if (!ok) return fail(SHC_ERR_INVALID_ARG, "init chain failed for the configuration the sequence ended on");
   e->tables = t;
+  e->span_dirty = true;
   build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   if ((rc = upload_consts(e)) != SHC_OK) return rc;
   // walker_->init() (:306): fresh LegSteppers / walk state; the joints stay where the sequence left them

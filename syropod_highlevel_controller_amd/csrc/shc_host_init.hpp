@@ -247,11 +247,21 @@ SHC_HDI void generate_workspace(const shc_params &p, HostLeg<NJ> &leg, V3 identi
 // workspace, each starting from the configuration reached by tracking to that plane's origin.  What the rest of the init
 // chain consumes is Leg::getWorkplane(0) (model.cpp:514-550) - WalkController::generateWalkspace asks for the plane at the
 // default tips' height shift, which is zero right after start-up (walk_controller.cpp:117-121) - written to radius[].
+// The planes of a leg's layered workspace (Leg::workspace_ in rough terrain mode), kept for LegStepper::calculateStanceSpanChange,
+// which interpolates between the planes bounding the default tip's current height (walk_controller.cpp:949-980).
+constexpr int kMaxWorkspacePlanes = kWorkspaceLayers + 4;
+struct LayeredPlanes {
+  int n = 0;
+  double height[kMaxWorkspacePlanes];
+  double radius[kMaxWorkspacePlanes][SHC_N_BEARINGS];
+};
 template <int NJ>
-SHC_HDI void generate_workspace_layered(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS]) {
-  constexpr int kMaxPlanes = kWorkspaceLayers + 4;
+SHC_HDI void generate_workspace_layered(const shc_params &p, HostLeg<NJ> &leg, V3 identity_tip_body, double (&radius)[SHC_N_BEARINGS],
+                                        LayeredPlanes *keep = nullptr) {
+  constexpr int kMaxPlanes = kMaxWorkspacePlanes;
   double height[kMaxPlanes], plane[kMaxPlanes][SHC_N_BEARINGS];
   int planes = 0;
+  if (keep) keep->n = 0;
   for (int b = 0; b < SHC_N_BEARINGS; ++b) radius[b] = 0.0;
   leg.reset_to_default();
   if (norm(identity_tip_body - leg.tip) > kIkTolerance) return; // zero workspace (model.cpp:349-353)
@@ -307,6 +317,13 @@ SHC_HDI void generate_workspace_layered(const shc_params &p, HostLeg<NJ> &leg, V
     h -= delta;
     if (!(h >= min_h)) break;
     cur = add_plane(h, kMaxWorkspaceRadius);
+  }
+  if (keep) {
+    keep->n = planes;
+    for (int k = 0; k < planes; ++k) {
+      keep->height[k] = height[k];
+      for (int b = 0; b < SHC_N_BEARINGS; ++b) keep->radius[k][b] = plane[k][b];
+    }
   }
   // Leg::getWorkplane(0.0): interpolate between the planes bounding height 0 (heights rounded to 3 decimals, :532-533)
   int lower = -1, upper = -1;
@@ -488,7 +505,7 @@ SHC_HDI int startup_loops(const shc_params &p) { return imax(1, round_to_int(p.t
 //  the re-basing prefix, ~350 steps, and searches one bearing, <= 500 steps)
 template <int NJ>
 SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int first_bearing = 1, int last_bearing = 8,
-                                 const double *preset_configuration = nullptr) {
+                                 const double *preset_configuration = nullptr, LayeredPlanes *keep_planes = nullptr) {
   // body pose the start-up solve eases to / the workspace search runs at (identical unless auto posing has its own clock)
   const Pose body = startup_body_pose(p, t, 0), body_ws = startup_body_pose(p, t, startup_loops(p) - 1);
   HostLeg<NJ> leg;
@@ -506,7 +523,7 @@ SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int 
     if (first_bearing == 1) t.default_joint_position[l][j] = leg.q[j];
   }
   if (p.rough_terrain_mode) { // layered workspace: planes are searched one after the other, no split over bearings
-    if (first_bearing == 1) generate_workspace_layered<NJ>(p, leg, inverse_transform_vector(body_ws, default_tip), t.workspace_radius[l]);
+    if (first_bearing == 1) generate_workspace_layered<NJ>(p, leg, inverse_transform_vector(body_ws, default_tip), t.workspace_radius[l], keep_planes);
     return;
   }
   generate_workspace<NJ>(p, leg, inverse_transform_vector(body_ws, default_tip), t.workspace_radius[l], first_bearing, last_bearing);

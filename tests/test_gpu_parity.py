@@ -1162,9 +1162,6 @@ def test_error_codes(Engine):
     bad.leg_dof[3] = 4
     h = C.c_void_p()
     assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED and b"DOF" in L.shc_last_error()
-    bad = default_hexapod_params("tripod")
-    bad.rough_terrain_mode, bad.stance_span_modifier = 1, 0.3   # default tips re-derived from the layered workspace: not accelerated
-    assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED and b"stance span" in L.shc_last_error()
     assert L.shc_engine_create(C.byref(p), 0, 0, None, C.byref(h)) == INVALID
     assert L.shc_engine_create(C.byref(p), 4, 99, None, C.byref(h)) == INVALID       # no such device
     t = engine.Tables()

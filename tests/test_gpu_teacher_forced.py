@@ -302,7 +302,8 @@ def test_gravity_aligned_tips(Engine, dof, legs, gait):
     teacher_forced(Engine, p, n, inp, cycles, stop_go_schedule(p, n, 301, cycles, every=120, pose=True), label=f"gravity-aligned {legs}x{dof}")
 
 
-@pytest.mark.parametrize("case", ["hexapod-tripod", "hexapod-wave-force-normal-touchdown", "6x4-ripple", "no-tip-state-messages"])
+@pytest.mark.parametrize("case", ["hexapod-tripod", "hexapod-wave-force-normal-touchdown", "6x4-ripple", "no-tip-state-messages",
+                                  "hexapod-tripod-wider-stance-span", "hexapod-wave-narrower-stance-span"])
 def test_rough_terrain_mode(Engine, case):
     """rough_terrain_mode (SURVEY.md section 8f rank 4): the layered workspace behind the limits, Leg::touchdownDetection on every
     tip-state message (model.cpp:712-722), default tip positions re-derived at every swing / stance start, swing targets
@@ -314,6 +315,8 @@ def test_rough_terrain_mode(Engine, case):
         p = default_hexapod_params("wave" if "wave" in case else "tripod")
     p.rough_terrain_mode = 1
     p.step_depth = 0.012
+    if "span" in case:   # LegStepper::calculateStanceSpanChange on the layered workspace (walk_controller.cpp:949-980): every new default tip
+        p.stance_span_modifier = 0.3 if "wider" in case else -0.25   # is shifted sideways by a share of the workplane radius at ITS height
     if "normal" in case:
         p.force_normal_touchdown = 1
     n, cycles = 96, 520

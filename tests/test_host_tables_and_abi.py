@@ -115,10 +115,6 @@ def test_struct_layouts_match_the_library():
 
 def test_unsupported_parameters_are_rejected():
     p = default_hexapod_params("tripod")
-    p.rough_terrain_mode, p.stance_span_modifier = 1, 0.2
-    with pytest.raises(engine.ShcError):
-        engine.generate_tables(p)
-    p = default_hexapod_params("tripod")
     p.leg_dof[2] = 4
     with pytest.raises(engine.ShcError):
         engine.generate_tables(p)
