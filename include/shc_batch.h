@@ -39,8 +39,8 @@ enum {
   SHC_ERR_INVALID_ARG = 1,
   SHC_ERR_NO_DEVICE = 2,      /* no HIP device / kernel image: the product path never falls back to CPU */
   SHC_ERR_HIP = 3,
-  SHC_ERR_UNSUPPORTED = 4,    /* outside the accelerated path: legs of different DOF in one engine, rough terrain with a stance
-                                 span modifier, a requested tip rotation on > 3-DOF legs, sequences with own-clock auto posing */
+  SHC_ERR_UNSUPPORTED = 4,    /* outside the accelerated path: legs of different DOF in one engine, sequences with own-clock auto
+                                 posing, joint_control leg manipulation, resident mode for a batch that does not fit the chip */
   SHC_ERR_UNSTABLE = 5,       /* reserved: the reference aborts when the IMU correction's norm exceeds 100 rad
                                  (pose_controller.cpp:1228-1232); after its own clamps (:1222-1226) that needs
                                  max_rotation > 100 rad, so no entry point returns this code today */
@@ -573,6 +573,12 @@ typedef struct shc_leg_snapshot {
   int32_t tip_rotation_defined;            /* current_tip_pose_.rotation_ != UNDEFINED_ROTATION */
   int32_t step_plane_defined;              /* Leg::step_plane_pose_ != Pose::Undefined() (touchdown detection, model.cpp:712-722) */
   double step_plane_position[3];           /* Leg::step_plane_pose_.position_ (robot frame; only its position is read, walk_controller.cpp:1088) */
+  /* LegStepper::target_tip_pose_.rotation_ (> 3 DOF): the identity tip rotation with gravity_aligned_tips, UNDEFINED otherwise - until an
+   * externally requested target (rough terrain mode) assigns its own, which then stays (walk_controller.cpp:1070 assigns the whole
+   * pose, :1044 only the position).  Kept, like the other tip rotations, as the rotated x axis + "defined". */
+  double target_tip_direction[3];
+  int32_t target_rotation_defined;
+  int32_t pad_;
 } shc_leg_snapshot;
 
 typedef struct shc_instance_state {
@@ -638,8 +644,11 @@ enum { SHC_EXTERNAL_TARGET = 0, SHC_EXTERNAL_DEFAULT = 1, SHC_EXTERNAL_PLANNER_T
  * STOPPED; the TARGET of a robot that stands goes to its LegPoser for planner mode (and raises target_tip_pose_acquired_, see
  * shc_engine_execute_plan), a DEFAULT for it is dropped.  Dropped rows are counted in *ignored (may be NULL): defaults for
  * standing robots and stepper requests without rough_terrain_mode (no stepper reads them).  The stepper keeps only the x axis of tip rotations (see
- * shc_leg_snapshot), and legs with <= 3 joints none at all: a defined target rotation on > 3-DOF legs is SHC_ERR_UNSUPPORTED
- * (it may still reach a LegPoser, which hands it to Leg::applyIK as it is: rotation-constrained solve + unconstrained retry).
+ * shc_leg_snapshot), and legs with <= 3 joints none at all.  On > 3-DOF legs a requested target rotation becomes
+ * LegStepper::target_tip_pose_.rotation_ (walk_controller.cpp:1070 assigns the whole pose): updateTipRotation blends the tip towards
+ * it over the back half of the swing, Leg::applyIK solves for it (rotation-constrained pass + unconstrained retry) - and, as in the
+ * reference, it STAYS the leg's target rotation after the request is dropped (:1044 re-assigns only the position), replacing the
+ * identity tip rotation of gravity_aligned_tips; a request with UNDEFINED_ROTATION clears it.
  * which = SHC_EXTERNAL_PLANNER_TARGET addresses the LegPoser's record directly (set: whatever the walk state). */
 int shc_engine_set_external_target(shc_engine *e, int which, int64_t first, int64_t count, int leg, const shc_external_target *rows,
                                    int64_t *ignored);

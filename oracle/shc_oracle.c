@@ -3473,11 +3473,14 @@ void orc_get_state(const orc_robot *r, shc_instance_state *o)
     put3(g->default_tip, s->default_tip_pose.p);
     put3(g->target_tip, s->target_tip_pose.p);
     put3(g->stride_vector, s->stride_vector);
-    if (leg->joint_count > 3 && r->params.gravity_aligned_tips)
-    { /* otherwise the tip rotations are write-only on this path (updateTipRotation's else branch, :1230-1233) */
+    if (leg->joint_count > 3 && (r->params.gravity_aligned_tips || r->params.rough_terrain_mode))
+    { /* otherwise the tip rotations are write-only on this path (updateTipRotation's else branch, :1230-1233): they matter with
+       * gravity-aligned tips and wherever an externally requested target may carry a rotation (rough terrain mode) */
       put3(g->walker_tip_direction, orc_quat_rotate(s->current_tip_pose.r, orc_v3_make(1, 0, 0)));
       put3(g->origin_tip_direction, orc_quat_rotate(s->origin_tip_pose.r, orc_v3_make(1, 0, 0)));
       g->tip_rotation_defined = !orc_quat_is_undefined(s->current_tip_pose.r);
+      g->target_rotation_defined = !orc_quat_is_undefined(s->target_tip_pose.r);
+      if (g->target_rotation_defined) put3(g->target_tip_direction, orc_quat_rotate(s->target_tip_pose.r, orc_v3_make(1, 0, 0)));
     }
     g->admittance_state[0] = leg->admittance_state[0];
     g->admittance_state[1] = leg->admittance_state[1];
@@ -3555,11 +3558,13 @@ void orc_set_state(orc_robot *r, const shc_instance_state *o)
     s->stride_vector = get3(g->stride_vector);
     s->walk_plane = get3(o->stepper_walk_plane);
     s->walk_plane_normal = get3(o->stepper_walk_plane_normal);
-    if (leg->joint_count > 3 && r->params.gravity_aligned_tips)
+    if (leg->joint_count > 3 && (r->params.gravity_aligned_tips || r->params.rough_terrain_mode))
     { /* rotations rebuilt from their x axes the way updateTipRotation builds them (walk_controller.cpp:1224) */
       s->current_tip_pose.r = g->tip_rotation_defined ? orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), get3(g->walker_tip_direction))
                                                       : ORC_UNDEFINED_ROTATION;
       s->origin_tip_pose.r = orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), get3(g->origin_tip_direction));
+      s->target_tip_pose.r = g->target_rotation_defined ? orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), get3(g->target_tip_direction))
+                                                        : ORC_UNDEFINED_ROTATION;
     }
     leg->admittance_state[0] = g->admittance_state[0];
     leg->admittance_state[1] = g->admittance_state[1];

@@ -32,7 +32,8 @@ enum : int { PM_NONE = 0, PM_SWING = 1, PM_STANCE = 2, PM_STOP = 3 };
 
 // packed per-leg word
 constexpr int LW_ACP = 1 << 2, LW_CFS = 1 << 3, LW_PM_SHIFT = 4, LW_NEG = 1 << 6, LW_IKFAIL = 1 << 7, LW_PHASE_SHIFT = 8,
-              LW_PHASE_MASK = 0xFFFFF, LW_ZBV = 1 << 28, LW_ATT = 1 << 29, LW_ROTDEF = 1 << 30; // ROTDEF: walker tip rotation defined
+              LW_PHASE_MASK = 0xFFFFF, LW_ZBV = 1 << 28, LW_ATT = 1 << 29, LW_ROTDEF = 1 << 30, // ROTDEF: walker tip rotation defined
+              LW_TARGROT = int(1u << 31); // LegStepper::target_tip_pose_.rotation_ defined (the direction is in Fields::TARG_DIR)
 // packed per-robot word: walk state [0:1], legs_at_correct_phase [2:5], legs_completed_first_step [6:9],
 // return_to_default_attempted [10], auto_posing_state [11:12]
 constexpr int RW_LACP_SHIFT = 2, RW_LCFS_SHIFT = 6, RW_RTDA = 1 << 10, RW_APS_SHIFT = 11;
@@ -76,9 +77,11 @@ struct CycleParams {
   int32_t tip_force;  // SHC_FEAT_TIP_FORCE
   int32_t debug_skip; // development ablation mask (SHC_DEBUG_SKIP env): 1 pose, 2 limits, 4 stepper, 8 ik, 16 fk
   int32_t odometry;   // SHC_FEAT_ODOMETRY
-  int32_t gravity_aligned;       // gravity_aligned_tips with > 3 DOF legs: rotation-constrained IK (model.cpp:880-900)
+  int32_t gravity_aligned;       // tip rotations are tracked (> 3 DOF legs with gravity_aligned_tips, or in rough terrain mode, where an externally
+                                 // requested target may carry one): LegStepper::updateTipRotation + the rotation-constrained IK (model.cpp:880-900)
   int32_t rough_terrain;         // rough_terrain_mode (generic kernel): default tips follow the terrain, targets meet the step surface
-  int32_t tip_align, pad1;       // gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose (generic kernel)
+  int32_t tip_align;             // gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose (generic kernel)
+  int32_t gravity_target;        // gravity_aligned_tips (> 3 DOF): an UNDEFINED target rotation is re-assigned from Model::estimateGravity (:1197-1205)
   double step_depth;             // walk_controller.h:80
   double target_dir[3];          // x axis of the identity tip rotation FromTwoVectors(x, -z) (walk_controller.cpp:37-41)
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
@@ -120,9 +123,11 @@ struct Fields {
                        POSER_TIP = EFFORT_IN + NJE, MODEL_TIP = POSER_TIP + 4, ADM_DELTA = MODEL_TIP + 4, // outputs
                        // tip directions (x axis of LegStepper::origin_tip_pose_ / current_tip_pose_ rotations), gravity-aligned tips only
                        ORG_DIR = ADM_DELTA + 4, CUR_DIR = ORG_DIR + 3,
+                       // ... and of LegStepper::target_tip_pose_ (the identity tip rotation, or what an externally requested target assigned) + pad
+                       TARG_DIR = CUR_DIR + 3,
                        // Leg::desired_tip_pose_ as the per-leg API holds it between shc_leg_set_desired_tip_pose and shc_leg_apply_ik:
                        // position (3) + "rotation defined" flag, x axis of the rotation (3) + pad.  The fused cycle never touches these.
-                       DES_TIP = CUR_DIR + 3, DES_DIR = DES_TIP + 4,
+                       DES_TIP = TARG_DIR + 4, DES_DIR = DES_TIP + 4,
                        // LegPoser sequence state (pose_controller.h:560-590) for stepToPosition / transitionConfiguration:
                        // origin_tip_pose_ position (3) + master_iteration_count_, x axis of its rotation (3) + "!first_iteration_",
                        // origin_configuration_ (NJ, padded).  Only the sequence entry points touch these.
@@ -308,7 +313,7 @@ struct LegRegs {
   double adm0, adm1;
   double stiff; // Leg::virtual_stiffness_ (published only; admittance feature)
   V3 tf, tipx; // tip x axis (robot frame) of the current FK: Leg::setAdmittanceDelta, origin of the tip-rotation blend
-  V3 org_dir, cur_dir; // tip directions of LegStepper::origin_tip_pose_ / current_tip_pose_ (gravity-aligned tips)
+  V3 org_dir, cur_dir, targ_dir; // tip directions of LegStepper::origin_tip_pose_ / current_tip_pose_ / target_tip_pose_ (tip rotations tracked)
   int word;
 };
 
@@ -447,6 +452,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // its own kernel specialisation (F_ROT), launched when the parameter is set
   constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
   bool rot_def = (s.word & LW_ROTDEF) != 0;
+  bool targ_rot = (s.word & LW_TARGROT) != 0; // LegStepper::target_tip_pose_.rotation_ defined
   SHC_TICK(2);
 
   // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611)
@@ -1048,6 +1054,11 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
               }
               // target_tip_pose_ = pose_.removePose(transform_): position = pose_.transformVector(-transform_.position_) (pose.h:178-184)
               s.targ = V3{v[0], v[1], v[2]} + rotate(Quat{v[3], v[4], v[5], v[6]}, -V3{v[7], v[8], v[9]});
+              if (rot_on) { // ... and its rotation: pose_.rotation_ * transform_.rotation_^-1; a product with UNDEFINED_ROTATION (zeros) stays undefined
+                const Quat tr = Quat{v[3], v[4], v[5], v[6]} * inverse(Quat{v[10], v[11], v[12], v[13]});
+                targ_rot = !(tr.w == 0.0 && tr.x == 0.0 && tr.y == 0.0 && tr.z == 0.0);
+                if (targ_rot) s.targ_dir = rotate(tr, V3{1, 0, 0});
+              }
               clearance = normalized(clearance) * cf.x;
               if (flags & 2) { // "odom_ideal" frame: lead by calculateOdometry(time_to_swing_end).position_ (:1073-1078, :783-791)
                 const double time_to_swing_end = (P.swing_iterations - iteration) * P.dt;
@@ -1144,14 +1155,27 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     if (rot_on) {
       const int pm0 = (s.word >> LW_PM_SHIFT) & 3; // swing / stance progress as the previous iteratePhase left them
       const double sp = swing_progress_of(s.word, P);
-      const V3 target{P.target_dir[0], P.target_dir[1], P.target_dir[2]};
       if (pm0 == PM_STANCE || pm0 == PM_STOP || sp >= 0.5) {
-        s.cur_dir = target; // correctRotation only flips the quaternion's sign
-        if (sp >= 0.5) {
-          const double c = smooth_step(fmin(1.0, 2.0 * (sp - 0.5)));
-          s.cur_dir = normalized(lerp3(s.org_dir, target, c));
+        if (uni(P.gravity_target) && !targ_rot) { // "set target tip rotation to align with gravity if ... currently undefined" (:1197-1205)
+          V3 gv{0, 0, kGravity}; // Model::estimateGravity (model.cpp:156-165); the direction of FromTwoVectors(UnitX, gravity) * UnitX
+          if (FT::imu(P) || FT::incl(P) || FT::autop(P)) {
+            const V3 e = quat_to_euler(rb.getq(R::IMUQ), false);
+            gv = rotate(angle_axis_y(-e.y), gv);
+            gv = rotate(angle_axis_x(-e.x), gv);
+          }
+          s.targ_dir = normalized(gv);
+          targ_rot = true;
         }
-        rot_def = true;
+        if (!targ_rot) { // target undefined: so is the current tip rotation (:1208-1211)
+          rot_def = false;
+        } else {
+          s.cur_dir = s.targ_dir; // correctRotation only flips the quaternion's sign
+          if (sp >= 0.5) {
+            const double c = smooth_step(fmin(1.0, 2.0 * (sp - 0.5)));
+            s.cur_dir = normalized(lerp3(s.org_dir, s.targ_dir, c));
+          }
+          rot_def = true;
+        }
       } else {
         s.org_dir = s.tipx; // leg_->getCurrentTipPose().rotation_: the FK tip rotation of the previous cycle
         rot_def = false;
@@ -1248,9 +1272,9 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       rot_def = false;
     }
   }
-  s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL | LW_ROTDEF)) |
+  s.word = (s.word & ~(3 | LW_ACP | LW_CFS | (3 << LW_PM_SHIFT) | (LW_PHASE_MASK << LW_PHASE_SHIFT) | LW_ZBV | LW_ATT | LW_IKFAIL | LW_ROTDEF | LW_TARGROT)) |
            my_state | (my_acp ? LW_ACP : 0) | (my_cfs ? LW_CFS : 0) | (my_pm << LW_PM_SHIFT) | (my_phase << LW_PHASE_SHIFT) |
-           (rot_def ? LW_ROTDEF : 0);
+           (rot_def ? LW_ROTDEF : 0) | (targ_rot ? LW_TARGROT : 0);
 
   SHC_PHASE_FENCE();
   SHC_TICK(8);

@@ -44,7 +44,7 @@ struct LegPlanes {
 template <int NJ>
 struct LegLoad {
   double flat[Fields<NJ>::CORE_END];
-  double2 adm, tf0, tf1, stiff, rot0, rot1, rot2;
+  double2 adm, tf0, tf1, stiff, rot0, rot1, rot2, rot3, rot4;
   int word;
 };
 // ROLE: which half of the per-leg state a wave owns.  ROLE_ALL: the whole leg (one wave runs whole cycles).  The two-wave
@@ -68,11 +68,13 @@ __device__ __forceinline__ void load_leg_issue(LegLoad<NJ> &ll, const DevState &
     ll.flat[2 * p + 1] = v.y;
   }
   ll.word = ROLE == ROLE_BACK ? 0 : st.legi[slot];
-  ll.adm = ll.tf0 = ll.tf1 = ll.stiff = ll.rot0 = ll.rot1 = ll.rot2 = double2{0.0, 0.0};
-  if (NJ > 3 && (F & F_ROT)) { // tip directions of the stepper's origin / current tip rotations
+  ll.adm = ll.tf0 = ll.tf1 = ll.stiff = ll.rot0 = ll.rot1 = ll.rot2 = ll.rot3 = ll.rot4 = double2{0.0, 0.0};
+  if (NJ > 3 && (F & F_ROT)) { // tip directions of the stepper's origin / current / target tip rotations
     ll.rot0 = ld.load(FD::ORG_DIR / 2);
     ll.rot1 = ld.load(FD::ORG_DIR / 2 + 1);
     ll.rot2 = ld.load(FD::ORG_DIR / 2 + 2);
+    ll.rot3 = ld.load(FD::ORG_DIR / 2 + 3);
+    ll.rot4 = ld.load(FD::ORG_DIR / 2 + 4);
   }
   if (FT::adm(P)) {
     if (ROLE != ROLE_FRONT) ll.adm = ld.load(FD::ADM / 2);
@@ -109,6 +111,7 @@ __device__ __forceinline__ void load_leg_finish(LegRegs<NJ> &s, const Park &pk, 
   s.tf = V3{ll.tf0.x, ll.tf0.y, ll.tf1.x};
   s.org_dir = V3{ll.rot0.x, ll.rot0.y, ll.rot1.x};
   s.cur_dir = V3{ll.rot1.y, ll.rot2.x, ll.rot2.y};
+  s.targ_dir = V3{ll.rot3.x, ll.rot3.y, ll.rot4.x};
 }
 
 template <int NJ, unsigned F, int ROLE = ROLE_ALL>
@@ -157,10 +160,12 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
   }
   if (NJ > 3 && (F & F_ROT)) {
-    static_assert(FD::ORG_DIR % 2 == 0 && FD::CUR_DIR == FD::ORG_DIR + 3, "tip direction planes");
+    static_assert(FD::ORG_DIR % 2 == 0 && FD::CUR_DIR == FD::ORG_DIR + 3 && FD::TARG_DIR == FD::ORG_DIR + 6, "tip direction planes");
     ld.store(FD::ORG_DIR / 2, double2{s.org_dir.x, s.org_dir.y});
     ld.store(FD::ORG_DIR / 2 + 1, double2{s.org_dir.z, s.cur_dir.x});
     ld.store(FD::ORG_DIR / 2 + 2, double2{s.cur_dir.y, s.cur_dir.z});
+    ld.store(FD::ORG_DIR / 2 + 3, double2{s.targ_dir.x, s.targ_dir.y});
+    ld.store(FD::ORG_DIR / 2 + 4, double2{s.targ_dir.z, 0.0});
   }
   if (ROLE != ROLE_BACK) st.legi[slot] = s.word;
 }

@@ -382,7 +382,8 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   // stays it, so the kernels without the estimate run (its planes are neither loaded nor stored).
   c.tip_force = (((features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort) && (rt_flags & RT_EFFORT_LIVE)) ? 1 : 0;
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
-  c.gravity_aligned = hostinit::tips_rotation_constrained(p, p.leg_dof[0]) ? 1 : 0;
+  c.gravity_aligned = hostinit::tips_rotation_tracked(p, p.leg_dof[0]) ? 1 : 0;
+  c.gravity_target = hostinit::tips_rotation_constrained(p, p.leg_dof[0]) ? 1 : 0;
   c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
   c.tip_align = (p.gravity_aligned_tips && p.leg_dof[0] <= 3) ? 1 : 0; // pose_controller.cpp:849
   c.step_depth = p.step_depth;
@@ -688,12 +689,14 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
     t[F::MODEL_TIP + 2] = tip.z;
     // step_state STANCE, phase 0, progress "none" (walk_controller.h:493-501)
     legw[l] = SS_STANCE | (PM_NONE << LW_PM_SHIFT);
-    if (hostinit::tips_rotation_constrained(e->params, NJ)) { // current / origin tip poses start at the identity tip pose (:800-803)
+    if (hostinit::tips_rotation_constrained(e->params, NJ)) { // current / origin / target tip poses start at the identity tip pose (:800-803)
       V3 d = hostinit::gravity_aligned_direction();
-      t[F::ORG_DIR] = t[F::CUR_DIR] = d.x;
-      t[F::ORG_DIR + 1] = t[F::CUR_DIR + 1] = d.y;
-      t[F::ORG_DIR + 2] = t[F::CUR_DIR + 2] = d.z;
-      legw[l] |= LW_ROTDEF;
+      t[F::ORG_DIR] = t[F::CUR_DIR] = t[F::TARG_DIR] = d.x;
+      t[F::ORG_DIR + 1] = t[F::CUR_DIR + 1] = t[F::TARG_DIR + 1] = d.y;
+      t[F::ORG_DIR + 2] = t[F::CUR_DIR + 2] = t[F::TARG_DIR + 2] = d.z;
+      legw[l] |= LW_ROTDEF | LW_TARGROT;
+    } else if (hostinit::tips_rotation_tracked(e->params, NJ)) { // ... at UNDEFINED_ROTATION, whose rotated x axis is x itself
+      t[F::ORG_DIR] = t[F::CUR_DIR] = 1.0;
     }
   }
   robt.assign(R::COUNT, 0.0);
@@ -1776,11 +1779,8 @@ extern "C" int shc_engine_set_external_target(shc_engine *e, int which, int64_t 
   std::vector<ExtRow> host((size_t)n_rows);
   for (int64_t i = 0; i < n_rows; ++i) {
     const shc_external_target &t = rows[i];
-    // LegStepper keeps tip rotations as their x axis, for > 3-DOF legs only; a requested target rotation would have to drive
-    // updateTipRotation / the rotation-constrained IK (walk_controller.cpp:1209-1230), which the engine runs for gravity-aligned tips only
-    const bool rotation_defined = t.pose[3] != 0.0 || t.pose[4] != 0.0 || t.pose[5] != 0.0 || t.pose[6] != 0.0;
-    if (t.defined && e->NJ > 3 && which == SHC_EXTERNAL_TARGET && rotation_defined)
-      return fail(SHC_ERR_UNSUPPORTED, "external target with a defined tip rotation on legs with more than 3 joints");
+    // (a requested target rotation on > 3-DOF legs becomes LegStepper::target_tip_pose_.rotation_: the cycle kernels with the
+    //  tip-rotation logic run for such legs whenever rough terrain mode is on; legs with <= 3 joints never read it)
     for (int k = 0; k < 7; ++k) host[i].pose[k] = t.pose[k], host[i].transform[k] = t.transform[k];
     host[i].swing_clearance = t.swing_clearance;
     host[i].flags = double((t.defined ? 1 : 0) | (t.frame_is_odom_ideal ? 2 : 0));
@@ -2200,7 +2200,7 @@ static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(ST
   int rc = ensure_seq(e);
   if (rc != SHC_OK) return rc;
   SeqParams P = seq_params(e);
-  if (e->cp.gravity_aligned) { // identity tip rotation of gravity-aligned tips (walk_controller.cpp:37-41)
+  if (e->cp.gravity_target) { // identity tip rotation of gravity-aligned tips (walk_controller.cpp:37-41)
     const Quat r = from_two_vectors(V3{1, 0, 0}, V3{e->cp.target_dir[0], e->cp.target_dir[1], e->cp.target_dir[2]});
     P.target_rotation[0] = r.w, P.target_rotation[1] = r.x, P.target_rotation[2] = r.y, P.target_rotation[3] = r.z;
   }
@@ -2475,8 +2475,9 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   // Model::updateDefaultConfiguration + generateWorkspaces + generateWalkspace (state_controller.cpp:307-310): the tables of an
   // engine belong to its morphology, so the configuration of instance 0 stands for the batch.  Robots that were started from
   // different joint positions (shc_engine_begin_sequence_startup per_instance) end their sequences on the same READY stance
-  // only up to the 1 mm / IK tolerance of the last step: the largest difference to instance 0 is checked here - beyond 1e-3 rad
-  // the batch does not share one configuration and the caller has to start such robots in engines of their own.
+  // only up to the tip tolerances of the last steps (a few milliradians): the largest difference to instance 0 is checked here -
+  // beyond 0.02 rad (IK_TOLERANCE, 5 mm, at the end of a 0.25 m leg) the batch does not share one configuration and the caller has to
+  // start such robots in engines of their own.
   std::vector<double> q(size_t(e->n) * e->L * e->NJ);
   int rc = shc_engine_get_joint_state(e, q.data(), nullptr, 0);
   if (rc != SHC_OK) return rc;
@@ -2485,7 +2486,7 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
     double worst = 0.0;
     for (int64_t i = 1; i < e->n; ++i)
       for (size_t k = 0; k < row; ++k) worst = fmax(worst, fabs(q[size_t(i) * row + k] - q[k]));
-    if (!(worst <= 1e-3))
+    if (!(worst <= 0.02))
       return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup: the instances ended their start-up sequences on different configurations (max |dq| to instance 0 = " +
                                            std::to_string(worst) + " rad): one engine has one set of workspace / limit tables");
   }

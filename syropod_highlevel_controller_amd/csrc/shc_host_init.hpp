@@ -174,7 +174,10 @@ struct HostLeg {
 SHC_HDI V3 gravity_aligned_direction() {
   return rotate(correct_rotation(from_two_vectors(V3{1, 0, 0}, V3{-0.0, -0.0, -1.0}), quat_identity()), V3{1, 0, 0});
 }
-SHC_HDI bool tips_rotation_constrained(const shc_params &p, int nj) { return nj > 3 && p.gravity_aligned_tips != 0; }
+SHC_HDI bool tips_rotation_constrained(const shc_params &p, int nj) { return nj > 3 && p.gravity_aligned_tips != 0; } // the identity tip rotation is defined
+// LegStepper::updateTipRotation has something to do: the target tip rotation is defined from the start (gravity-aligned tips) or an
+// externally requested target may define it (rough terrain mode, walk_controller.cpp:1068-1071)
+SHC_HDI bool tips_rotation_tracked(const shc_params &p, int nj) { return nj > 3 && (p.gravity_aligned_tips != 0 || p.rough_terrain_mode != 0); }
 
 template <int NJ>
 SHC_HDI void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip, const Pose &body) {

@@ -117,8 +117,10 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
       for (int k = 0; k < 3; ++k) {
         g.origin_tip_direction[k] = f(FD::ORG_DIR + k);
         g.walker_tip_direction[k] = f(FD::CUR_DIR + k);
+        g.target_tip_direction[k] = (w & LW_TARGROT) ? f(FD::TARG_DIR + k) : 0.0;
       }
       g.tip_rotation_defined = (w & LW_ROTDEF) ? 1 : 0;
+      g.target_rotation_defined = (w & LW_TARGROT) ? 1 : 0;
     }
   }
 }
@@ -200,8 +202,10 @@ __global__ void set_state_kernel(const shc_instance_state *in, DevState st, Cycl
       for (int k = 0; k < 3; ++k) {
         f(FD::ORG_DIR + k, g.origin_tip_direction[k]);
         f(FD::CUR_DIR + k, g.walker_tip_direction[k]);
+        f(FD::TARG_DIR + k, g.target_tip_direction[k]);
       }
       if (g.tip_rotation_defined) w |= LW_ROTDEF;
+      if (g.target_rotation_defined) w |= LW_TARGROT;
     }
     st.legi[slot] = w;
   }

@@ -60,7 +60,8 @@ class LegSnapshot(C.Structure):
                 ("virtual_stiffness", C.c_double), ("tip_force_calculated", C.c_double * 3), ("swing_progress", C.c_double),
                 ("stance_progress", C.c_double), ("step_state", C.c_int32), ("phase", C.c_int32), ("at_correct_phase", C.c_int32),
                 ("completed_first_step", C.c_int32), ("negate_auto_pose", C.c_int32), ("ik_failed", C.c_int32),
-                ("tip_rotation_defined", C.c_int32), ("step_plane_defined", C.c_int32), ("step_plane_position", C.c_double * 3)]
+                ("tip_rotation_defined", C.c_int32), ("step_plane_defined", C.c_int32), ("step_plane_position", C.c_double * 3),
+                ("target_tip_direction", C.c_double * 3), ("target_rotation_defined", C.c_int32), ("pad_", C.c_int32)]
 
 
 class InstanceState(C.Structure):
