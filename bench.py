@@ -278,10 +278,15 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         t0 = time.perf_counter()
         # (time_resident's own clock brackets exactly `steps` doorbell ticks; the gather of the final joints follows inside the region)
         res_elapsed, res_cycle_s = time_resident(eng, n, steps, warmup, stream)
-        t_after = time.perf_counter()
-        gather()
-        torch.cuda.synchronize()
-        elapsed = res_elapsed + (time.perf_counter() - t_after)
+        elapsed = res_elapsed
+        if use_dist:   # N > 1: the all-gather of the final joints belongs to the region (and has its own stream synchronisation)
+            t_after = time.perf_counter()
+            gather()
+            torch.cuda.synchronize()
+            elapsed += time.perf_counter() - t_after
+        # N = 1: the region closes with shc_engine_resident_wait - every wave has completed the K-th cycle and its joint state is
+        # visible (the device-to-host completion handshake).  The loop kernel is still alive at that point, so a stream
+        # synchronisation cannot be the closing bracket here; one issued after resident_end would only time an idle device.
     else:
         for _ in range(warmup):
             step_once()

@@ -409,7 +409,31 @@ struct FrontToBack {
   V3 desired_dir;   // x axis of the desired tip rotation (body frame) when rot_def
   bool rot_def;
   int my_leg_state; // LegState of this leg (manual leg manipulation)
+  V3 odom_vel;      // desired linear (x, y) / angular (z) body velocity of this cycle and whether updateWalk reached its odometry
+  bool odom_run;    //   update (cycle_front<..., ODOM_HERE = false>: the caller runs odometry_step elsewhere)
 };
+
+// odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (walk_controller.cpp:643, :783-791).  Nothing in the
+// cycle reads it back: a pure accumulator over the desired body velocity.
+template <int RPW>
+__device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const CycleParams &P, double vx, double vy, double vw) {
+  using R = RobotFields;
+  // Both poses are pure yaw (rotation (w, 0, 0, z), z translation 0), so Pose::addPose reduces to its w / z and x / y
+  // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
+  double sh, ch;
+  const double ha = 0.5 * (vw * P.dt); // Quaterniond(AngleAxisd(w dt, z^)): half of one cycle's yaw, a few milliradians
+  if (__all(fabs(ha) <= 0.5)) sincos_joint<false>(ha, &sh, &ch);
+  else sincos_joint(ha, &sh, &ch);
+  const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 2), oz = rb.get(R::ODOM + 3);
+  const double a = vx * P.dt, b = vy * P.dt;
+  double ux = -(oz * b), uy = oz * a; // u x v
+  ux = ux + ux;
+  uy = uy + uy;
+  rb.put(R::ODOM, ox + ((a + ux * ow) - oz * uy));
+  rb.put(R::ODOM + 1, oy + ((b + uy * ow) + oz * ux));
+  rb.put(R::ODOM + 2, ow * ch - oz * sh);
+  rb.put(R::ODOM + 3, ow * sh + oz * ch);
+}
 
 // AdmittanceController::updateAdmittance (admittance_controller.cpp:22-61) + Leg::setAdmittanceDelta (model.h:365-368) of one leg:
 // touches only the admittance state, the tip-force estimate and the tip axis of the last FK - state of the model half.
@@ -433,7 +457,7 @@ __device__ __forceinline__ void cycle_admittance(LegRegs<NJ> &s, LegOut &out, co
 
 // The walker / poser half of a cycle: updateCurrentPose, updateStiffness, (ADM_HERE: updateAdmittance,) updateWalk with the
 // LegSteppers, updateStance.  Leaves out.poser_tip (and fb) for the model half.
-template <int L, int NJ, unsigned F, bool ADM_HERE, typename IN>
+template <int L, int NJ, unsigned F, bool ADM_HERE, typename IN, bool ODOM_HERE = true>
 __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                             const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
                                             const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
@@ -453,11 +477,22 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
   bool rot_def = (s.word & LW_ROTDEF) != 0;
   bool targ_rot = (s.word & LW_TARGROT) != 0; // LegStepper::target_tip_pose_.rotation_ defined
+  fb.odom_run = false;
   SHC_TICK(2);
 
-  // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611)
-  if (!(SHC_DBG(P) & 128)) {
-    int w = s.word & ~(LW_ZBV | LW_ATT);
+  int rword = rb.geti(R::I_WORD);
+  int walk_state = rword & 3;
+  // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611).  Their only
+  //      readers are the STOPPING branches (walk FSM :599-619, updateAutoPose :1147-1150), and a robot is STOPPING in this cycle
+  //      only if it already was or if it is MOVING without a command (:533-536): skipped while no robot of the wave can be.
+  bool may_stop = walk_state == WS_STOPPING;
+  if (walk_state == WS_MOVING) { // (a conservative test of "no command": anything that could round to a zero norm counts)
+    const double ax = fabs(rb.get(R::VIN)), ay = fabs(rb.get(R::VIN + 1)), aw = rb.get(R::WIN);
+    may_stop = !(aw != 0.0 || ax > 1e-100 || ay > 1e-100);
+  }
+  s.word &= ~(LW_ZBV | LW_ATT);
+  if (!(SHC_DBG(P) & 128) && __any(may_stop)) {
+    int w = s.word;
     if (dot(s.strd, s.strd) == 0.0) w |= LW_ZBV;
     const V3 pnp = rb.get3(R::PNORM_PREV);
     V3 err = s.tip - s.targ;
@@ -473,8 +508,6 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
 
   SHC_PHASE_FENCE();
   SHC_TICK(3);
-  int rword = rb.geti(R::I_WORD);
-  int walk_state = rword & 3;
   // Manual leg manipulation: while any leg of the robot is not WALKING, updateWalk returns before it touches velocities, walk
   // state or steppers (walk_controller.cpp:492-505)
   int my_leg_state = LS_WALKING;
@@ -1220,21 +1253,9 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     }
     // ---- odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (:643, :783-791)
     if (FT::odom(P) && !(SHC_DBG(P) & 1024)) {
-      // Both poses are pure yaw (rotation (w, 0, 0, z), z translation 0), so Pose::addPose reduces to its w / z and x / y
-      // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
-      double sh, ch;
-      const double ha = 0.5 * (vw * P.dt); // Quaterniond(AngleAxisd(w dt, z^)): half of one cycle's yaw, a few milliradians
-      if (__all(fabs(ha) <= 0.5)) sincos_joint<false>(ha, &sh, &ch);
-      else sincos_joint(ha, &sh, &ch);
-      const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 2), oz = rb.get(R::ODOM + 3);
-      const double a = vx * P.dt, b = vy * P.dt;
-      double ux = -(oz * b), uy = oz * a; // u x v
-      ux = ux + ux;
-      uy = uy + uy;
-      rb.put(R::ODOM, ox + ((a + ux * ow) - oz * uy));
-      rb.put(R::ODOM + 1, oy + ((b + uy * ow) + oz * ux));
-      rb.put(R::ODOM + 2, ow * ch - oz * sh);
-      rb.put(R::ODOM + 3, ow * sh + oz * ch);
+      if (ODOM_HERE) odometry_step(rb, P, vx, vy, vw);
+      fb.odom_vel = V3{vx, vy, vw};
+      fb.odom_run = true;
     }
   }
   // =============================================================== WalkController::updateManual x 2 (walk_controller.cpp:652-744)

@@ -722,7 +722,8 @@ __global__ void __launch_bounds__(64, SHC_WAVES_PER_SIMD) shc_resident_kernel(De
 enum : int { IT_REAL = 1, IT_BUBBLE = 2, IT_EXIT = 3 };
 template <int L, int NJ>
 struct Resident2Lds { // dynamic LDS of one workgroup, after the two walker waves' tiles
-  double mailbox[2][2][3][64]; // [pair][cycle parity][xyz][lane]: PoseController::updateStance -> Leg::setDesiredTipPose
+  double mailbox[2][2][7][64]; // [pair][cycle parity][field][lane]: PoseController::updateStance -> Leg::setDesiredTipPose (xyz), then the
+                               // desired body velocity (x, y, yaw rate) + whether the walker reached its odometry update
   double stiff[2][64];         // walker -> model at exit (published virtual stiffness shares a plane with the admittance delta)
   int ikfail[2][64];           // model -> walker at exit (IK-deviation flag lives in the leg word)
   unsigned long long ctrl[4][4]; // [iteration & 3]: kind, h0, h1, -
@@ -867,10 +868,12 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       if (kind == IT_REAL && active) {
         resident_take_inputs<RPW, true, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
         SHC_TICK(21);
-        cycle_front<L, NJ, F, false>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
-                                     LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb);
+        cycle_front<L, NJ, F, false, LegInRing<NJ>, false>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
+                                                           LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
+        if (FT::odom(P)) // the odometry accumulator is the model wavefront's: it has the time, nothing here reads it back
+          mb[192] = fb.odom_vel.x, mb[256] = fb.odom_vel.y, mb[320] = fb.odom_vel.z, mb[384] = fb.odom_run ? 1.0 : 0.0;
         SHC_TICK(22);
       }
       if (leader && kind != IT_EXIT && lane == 0) {
@@ -887,6 +890,12 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
                                ns, slot};
         const double *mb = &X.mailbox[pair][c_back & 1][0][lane];
         out.poser_tip = V3{mb[0], mb[64], mb[128]};
+        if (FT::odom(P)) {
+          const V3 ov{mb[192], mb[256], mb[320]};
+          if (__any(mb[384] != 0.0)) { // (robots whose updateWalk returned early keep their odometry)
+            if (mb[384] != 0.0) odometry_step(rb, P, ov.x, ov.y, ov.z);
+          }
+        }
         out.adm_delta = V3{0, 0, 0};
         if (FT::adm(P)) cycle_admittance<NJ>(s, out, P, in);
         s.word = 0;
