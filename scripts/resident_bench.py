@@ -4,6 +4,7 @@ import sys
 import time
 
 import numpy as np
+import torch  # (before the engine library: torch brings its own HIP runtime)
 
 sys.path.insert(0, ".")
 from syropod_highlevel_controller_amd import default_hexapod_params  # noqa: E402
@@ -27,8 +28,17 @@ for _ in range(steps):
 eng.synchronize()
 dt = time.perf_counter() - t0
 print(f"launch per cycle : {dt / steps * 1e6:7.2f} us/cycle  {n * steps / dt:.3e} cycles/s")
+t0 = time.perf_counter()
+for _ in range(steps):
+    eng.set_velocity(lin, ang)   # host arrays every cycle (the velocity callback of every loop iteration)
+    eng.step(1)
+eng.synchronize()
+dt = time.perf_counter() - t0
+print(f"launch per cycle, velocities set from host arrays every cycle : {dt / steps * 1e6:7.2f} us/cycle  {n * steps / dt:.3e} cycles/s")
+d_lin, d_ang = torch.from_numpy(lin).cuda(), torch.from_numpy(ang).cuda()
+torch.cuda.synchronize()
 from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE  # noqa: E402
-for mode in ("publish_all", "publish_each", "post_each", "one_wave publish_each"):
+for mode in ("publish_all", "publish_each", "post_each", "post_each_device", "one_wave publish_each"):
     eng.set_features(FEAT_DEFAULT | (FEAT_RESIDENT_ONE_WAVE if mode.startswith("one_wave") else 0))
     eng.resident_begin(ring_depth=16, max_cycles=steps + 300)
     eng.resident_publish(200)
@@ -39,13 +49,17 @@ for mode in ("publish_all", "publish_each", "post_each", "one_wave publish_each"
     elif mode.endswith("publish_each"):
         for _ in range(steps):
             eng.resident_publish(1)
-    else:
+    elif mode == "post_each_device":   # a new velocity set for every cycle, from arrays resident in HBM
+        for i in range(steps):
+            eng.resident_post(velocity=(d_lin.data_ptr(), d_ang.data_ptr()), on_device=True)
+            eng.resident_publish(1)
+    else:                              # ... from host arrays
         for i in range(steps):
             eng.resident_post(velocity=(lin, ang))
             eng.resident_publish(1)
     eng.resident_wait(200 + steps, 60000)
     dt = time.perf_counter() - t0
     ran = eng.resident_end()
-    print(f"resident {mode:13s}: {dt / steps * 1e6:7.2f} us/cycle  {n * steps / dt:.3e} cycles/s  ({ran} cycles)")
+    print(f"resident {mode:21s}: {dt / steps * 1e6:7.2f} us/cycle  {n * steps / dt:.3e} cycles/s  ({ran} cycles)")
 q, _ = eng.joints()
 print("finite", bool(np.isfinite(q).all()))

@@ -464,7 +464,7 @@ static int generate_tables_nj(const shc_params *p, shc_tables *out) {
   return hostinit::generate_tables<NJ>(*p, *out) ? SHC_OK : fail(SHC_ERR_INVALID_ARG, "init chain failed (unreachable stance?)");
 }
 
-extern "C" int shc_abi_version(void) { return 2; }
+extern "C" int shc_abi_version(void) { return 3; } // 3: shc_leg_snapshot carries the stepper target tip direction; resident mode, join, auxiliary state
 extern "C" int64_t shc_sizeof_params(void) { return (int64_t)sizeof(shc_params); }
 extern "C" int64_t shc_sizeof_tables(void) { return (int64_t)sizeof(shc_tables); }
 

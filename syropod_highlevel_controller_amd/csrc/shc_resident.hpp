@@ -22,6 +22,12 @@ struct Resident {
   double *rin = nullptr, *force = nullptr, *effort = nullptr, *out = nullptr, *stage = nullptr;
   int32_t *rini = nullptr;
   size_t stage_bytes = 0;
+  // host arrays handed to shc_engine_resident_post are copied into a ring of pinned, device-mapped staging slots; the post kernel
+  // reads them from there over PCIe, so a post neither copies through a pageable-memory bounce buffer nor synchronises
+  static constexpr int kPinSlots = 4;
+  char *pin = nullptr, *pin_dev = nullptr;
+  hipEvent_t pin_ev[kPinSlots] = {};
+  unsigned long long pin_uses = 0;
   hipStream_t in_stream = nullptr;
   unsigned long long published = 0;         // doorbell value
   unsigned long long posted = 0;            // cycles with a header (the next post is for this cycle)
@@ -113,6 +119,9 @@ static void resident_free(Resident *r) {
   (void)hipFree(r->effort);
   (void)hipFree(r->out);
   (void)hipFree(r->stage);
+  if (r->pin) (void)hipHostFree(r->pin);
+  for (hipEvent_t ev : r->pin_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (r->in_stream) (void)hipStreamDestroy(r->in_stream);
   delete r;
 }
@@ -204,6 +213,11 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
     if ((err = hipMalloc(&r->effort, D * (NJE / 2) * e->n_slots * 16)) != hipSuccess) return bail(err, "hipMalloc");
     if ((err = hipMalloc(&r->out, D * out_slot_bytes)) != hipSuccess) return bail(err, "hipMalloc");
     if ((err = hipMalloc(&r->stage, r->stage_bytes)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipHostMalloc(reinterpret_cast<void **>(&r->pin), r->stage_bytes * Resident::kPinSlots, hipHostMallocMapped)) != hipSuccess)
+      return bail(err, "hipHostMalloc(input staging)");
+    if ((err = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->pin_dev), r->pin, 0)) != hipSuccess) return bail(err, "hipHostGetDevicePointer");
+    for (hipEvent_t &ev : r->pin_ev)
+      if ((err = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(err, "hipEventCreate");
     for (int gi = 0; gi < RG_COUNT; ++gi) r->post_cycle[gi].assign(D, 0);
   }
   Resident *r = e->res;
@@ -309,17 +323,19 @@ extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *i
         return fail(SHC_ERR_TIMEOUT, "resident mode: ring_depth posted input sets are waiting to be consumed (publish them)");
     }
   }
-  // stage host arrays (one staging buffer, consumed in stream order)
+  // host arrays: into the next pinned staging slot (free once the post kernel that read it kPinSlots posts ago has completed)
   size_t off = 0;
+  const int pin_slot = int(r->pin_uses % Resident::kPinSlots);
+  if (!in->on_device && r->pin_uses >= (unsigned long long)Resident::kPinSlots) HIP_TRY(hipEventSynchronize(r->pin_ev[pin_slot]));
   auto dev = [&](const void *src, size_t bytes, const void **out) -> int {
     if (in->on_device) {
       *out = src;
       return SHC_OK;
     }
     if (off + bytes > r->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
-    char *d = reinterpret_cast<char *>(r->stage) + off;
-    HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, r->in_stream));
-    *out = d;
+    const size_t at = size_t(pin_slot) * r->stage_bytes + off;
+    memcpy(r->pin + at, src, bytes);
+    *out = r->pin_dev + at;
     off += (bytes + 15) & ~size_t(15);
     return SHC_OK;
   };
@@ -344,7 +360,10 @@ extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *i
   resident_post_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, r->in_stream>>>(pp, r->args, r->headers, r->rin, r->rini, r->force, r->effort,
                                                                                               e->n, e->L, e->NJ, e->n_slots);
   HIP_TRY(hipGetLastError());
-  if (!in->on_device) HIP_TRY(hipStreamSynchronize(r->in_stream)); // the caller's host arrays and the staging buffer are free again
+  if (!in->on_device) { // (the caller's host arrays were copied: they are free again on return)
+    HIP_TRY(hipEventRecord(r->pin_ev[pin_slot], r->in_stream));
+    r->pin_uses++;
+  }
   for (int gi = 0; gi < RG_COUNT; ++gi)
     if (mask & (1u << gi)) {
       r->post_cycle[gi][r->posts[gi] % r->depth] = c;
