@@ -118,22 +118,10 @@ class Toggler:
 
 def run():
     import zlib
-    from oracle_lib import OracleRobot
-    from syropod_highlevel_controller_amd import default_hexapod_params
     gait = "tripod"
     P = mw.hexapod(gait, admittance_control=1, manual_posing=1)
-    limits = mw.limits_from_product(gait)
-    mw.MODEL = mw.Morphology.default_hexapod()
-    w = mw.RefWalker(P, limits)
-    w.cycle((0.0, 0.0), 0.0)
-    pp = default_hexapod_params(gait)
-    pp.admittance_control = 1
-    q0, qd0 = OracleRobot(pp).joints()           # DATA: the joint state after the direct start-up and the first loop
-    w.q, w.qd = q0.reshape(6, 3).copy(), qd0.reshape(6, 3).copy()
-    for i, leg in enumerate(w.legs):
-        leg.model_tip = mw.fk_tip(i, w.q[i])
-        leg.model_dir = mw.tip_axis(i, w.q[i])
-    w.efforts = np.zeros_like(w.q)
+    w = mw.started_walker(P, gait)               # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
+    q0, qd0 = w.q.copy(), w.qd.copy()
     w.tip_force = np.tile(np.array([0.0, 0.0, 4.0]), (6, 1))
     t = Toggler(w)
     rng = np.random.default_rng(zlib.crc32(b"manual"))

@@ -171,13 +171,22 @@ if __name__ == "__main__":
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     sys.path.insert(0, os.path.dirname(HERE))
-    # the origins: FK tip poses of the default hexapod as it stands after start-up (data for this generator: recorded in the fixture)
-    from oracle_lib import OracleBatch
-    from syropod_highlevel_controller_amd import default_hexapod_params
-    p = default_hexapod_params("tripod")
-    ob = OracleBatch(p, 1)
-    origin = ob.leg_apply_fk()            # [legs][7] (x, y, z, qw, qx, qy, qz)
-    q0 = ob.joints()[0].reshape(p.leg_count, -1)
+    # the origins: FK tip poses of the default hexapod as it stands after start-up - joints from the numpy init chain (make_init_golden.py
+    # through make_walk_golden.started_walker), tip poses from the numpy chain's FK: nothing from oracle/ or the product
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_walk_golden", os.path.join(HERE, "make_walk_golden.py"))
+    mw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mw)
+    w = mw.started_walker(mw.hexapod("tripod"), "tripod")
+    q0 = w.q.copy()
+    origin = []
+    for l in range(6):
+        t = mw.dh(*mw.MODEL.base[l])
+        for k, (d, th, r_, al) in enumerate(mw.MODEL.links[l]):
+            t = t @ mw.dh(d, th + q0[l][k], r_, al)
+        x = R.from_matrix(t[:3, :3]).as_quat()
+        origin.append([*t[:3, 3], x[3], x[0], x[1], x[2]])   # [legs][7] (x, y, z, qw, qx, qy, qz)
+    origin = np.array(origin)
     out = {"origin": origin, "q0": q0}
     for name, sc in STEP_SCENARIOS.items():
         rows, target_p, target_q, body_q = run_step_scenario(sc, origin[sc["leg"], :3], origin[sc["leg"], 3:])

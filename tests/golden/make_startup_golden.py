@@ -242,17 +242,9 @@ def run_new_stance():
     """PoseController::stepToNewStance (src/pose_controller.cpp:521-557) on a robot that stands after its direct start-up: the two
     leg groups step (with the swing height) onto their default tip poses one after the other, the body pose of stepToPosition
     easing from the identity to Model::current_pose_."""
-    from oracle_lib import OracleRobot
-    from syropod_highlevel_controller_amd import default_hexapod_params
     P = mw.hexapod("tripod", manual_posing=1)
-    mw.MODEL = mw.Morphology.default_hexapod()
-    w = mw.RefWalker(P, mw.limits_from_product("tripod"))
-    w.cycle((0.0, 0.0), 0.0)
-    q0, qd0 = OracleRobot(default_hexapod_params("tripod")).joints()      # DATA: the joint state after the direct start-up and the first loop
-    w.q, w.qd = q0.reshape(6, 3).copy(), qd0.reshape(6, 3).copy()
-    for i, leg in enumerate(w.legs):
-        leg.model_tip, leg.model_dir = mw.fk_tip(i, w.q[i]), mw.tip_axis(i, w.q[i])
-    w.efforts = np.zeros_like(w.q)
+    w = mw.started_walker(P, "tripod")           # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
+    q0, qd0 = w.q.copy(), w.qd.copy()
     legs_completed, group, rows = 0, 0, []
     stp = [None] * 6
     for _ in range(2000):

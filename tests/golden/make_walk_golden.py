@@ -35,9 +35,9 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   (src/walk_controller.cpp:1193-1234, held as tip DIRECTIONS - the only thing any consumer reads) with Leg::applyIK's rotation-constrained
   pass (src/model.cpp:880-900: simulated position update, rotation delta from the PRE-update tip direction, 6-row solve) and its
   unconstrained retry (:932-936)
-What is NOT restated but fed in as DATA (recorded in the fixture): the joint state the robot has after its direct start-up (q0,
-qd0: thousands of IK steps of the init chain, pinned separately), and the velocity / acceleration limit tables, which come out of
-the IK-based workspace search of the init chain (pinned separately: tests/test_host_tables_and_abi.py, test_oracle_golden.py).
+Nothing is fed in from oracle/ or the product any more: the joint state the robot has after its direct start-up and the velocity /
+acceleration limit tables (the IK-based workspace search) come from the numpy restatement of the init chain in make_init_golden.py
+(every scenario runs with time_to_start = 2 s: 100 start-up steps, where that iteration is well-posed).
 Rotations use scipy.spatial.transform.Rotation (an independent implementation of the Euler / quaternion conventions).
 
 The fixture cannot lift "parity unpinned" - the reference ships no vectors - but a misreading of the reference shared by the
@@ -223,8 +223,9 @@ def update_joints(leg, q, dq, dt, simulation):
     return qn, vn, proximity
 
 
-def apply_ik(leg, q, qd, desired, dt, desired_dir=None):
-    """Leg::applyIK (:861-941) towards a desired tip position (robot frame) and, optionally, tip direction.  Returns (q, qd)."""
+def apply_ik(leg, q, qd, desired, dt, desired_dir=None, simulation=False):
+    """Leg::applyIK (:861-941) towards a desired tip position (robot frame) and, optionally, tip direction.  Returns (q, qd).
+    simulation: applyIK(true), the joint velocity clamp is off (the init chain's calls)."""
     base = dh(*MODEL.base[leg])
     bi = np.linalg.inv(base)
     chain = _chain(leg, q)
@@ -240,12 +241,12 @@ def apply_ik(leg, q, qd, desired, dt, desired_dir=None):
         delta = np.zeros(6)
         delta[3:] = rv
         dq = solve_ik(leg, q, qd, delta, True)
-    qn, vn, ik_success = update_joints(leg, q, dq, dt, False)
+    qn, vn, ik_success = update_joints(leg, q, dq, dt, simulation)
     tip = (base @ _chain(leg, qn)[-1])[:3, 3]
     if (np.abs(tip - desired) > 0.005).any():               # IK_TOLERANCE (:916-929)
         ik_success = 0.0
     if desired_dir is not None and not ik_success:          # a joint ON its limit (proximity 0) counts as failure too: retry unconstrained (:932-936)
-        return apply_ik(leg, qn, vn, desired, dt, None)
+        return apply_ik(leg, qn, vn, desired, dt, None, simulation)
     return qn, vn
 
 
@@ -892,14 +893,44 @@ def hexapod(gait, morphology=None, **kw):
     return P
 
 
-def limits_from_product(gait, morphology=None, **kw):
-    """The limit tables are DATA here: the init chain's output for default.yaml (recorded in the fixture)."""
-    from syropod_highlevel_controller_amd import engine
-    p = make_params(gait, morphology)
-    for k, v in kw.items():
-        setattr(p, k, v)
-    t = engine.generate_tables(p)
-    return {k: [float(x) for x in getattr(t, k)] for k in ("max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration")}
+START_UP_TIME = 2.0   # time_to_start of every scenario: 100 start-up steps, where the start-up iteration is well-posed for 3- and 5-joint chains alike
+
+
+def init_chain_module():
+    """tests/golden/make_init_golden.py: the independent numpy restatement of the init chain (direct start-up solve, workspace search,
+    walkspace, limits).  Loaded lazily - it builds on this module's kinematic model."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_init_golden", os.path.join(HERE, "make_init_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+_MI = None
+
+
+def init_chain_of(gait, morphology=None, rough=0, gravity=0):
+    """Start-up joint configuration and limit tables of a scenario, from the numpy init chain (nothing from oracle/ or the product)."""
+    global _MI
+    if _MI is None:
+        _MI = init_chain_module()
+    r = _MI.init_chain(gait, morphology, bool(rough), START_UP_TIME, gravity=bool(gravity))
+    return r["q0"], {k: [float(x) for x in v] for k, v in r["limits"].items()}
+
+
+def started_walker(P, gait="tripod"):
+    """A default-hexapod RefWalker as it stands when it has entered RUNNING: joints from the numpy init chain's direct start-up, then the
+    loop that enters RUNNING (one cycle with zero inputs, state_controller.cpp:277-281, :189-192).  For the sibling generators."""
+    global MODEL
+    q_startup, limits = init_chain_of(gait)
+    MODEL = Morphology.default_hexapod()
+    w = RefWalker(P, limits)
+    w.q, w.qd = q_startup.copy(), np.zeros_like(q_startup)
+    for i, leg in enumerate(w.legs):
+        leg.model_tip, leg.model_dir = fk_tip(i, w.q[i]), tip_axis(i, w.q[i])
+    w.efforts = np.zeros_like(w.q)
+    w.cycle((0.0, 0.0), 0.0)
+    return w
 
 
 SCENARIOS = {
@@ -981,7 +1012,7 @@ def run(name):
     P.update(over)
     prod = {"force_normal_touchdown": P["force_normal_touchdown"], "swing_width": P["swing_width"], "rough_terrain_mode": P["rough_terrain_mode"],
             "step_depth": P["step_depth"], "gravity_aligned_tips": int(bool(P.get("gravity_aligned_tips")))}
-    limits = limits_from_product(gait, morphology, **prod)
+    q_startup, limits = init_chain_of(gait, morphology, prod["rough_terrain_mode"], prod["gravity_aligned_tips"])
     w = RefWalker(P, limits)
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
@@ -989,26 +1020,19 @@ def run(name):
     events = rough_events(name, P)
     gait_changed, meta_new_limits = False, {}
     lin, ang = (0.0, 0.0), 0.0
-    w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
     start = None
-    if over.get("model"):     # DATA: the joint state of a robot that has gone through its direct start-up and that first loop
-        sys.path.insert(0, os.path.dirname(HERE))
-        from oracle_lib import OracleRobot
+    if over.get("model"):     # the joint state of a robot that has gone through its direct start-up: the numpy init chain's configuration
         global MODEL
         pp = make_params(gait, morphology)
         MODEL = Morphology.from_params(pp) if morphology else Morphology.default_hexapod()
-        for k_, v_ in over.items():
-            if k_ in ("dynamic_stiffness", "manual_posing", "inclination_posing", "imu_posing", "admittance_control", "rough_terrain_mode", "step_depth", "use_joint_effort", "gravity_aligned_tips"):
-                setattr(pp, k_, v_)
-        if pp.imu_posing:
-            pp.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
-        q0, qd0 = OracleRobot(pp).joints()
-        w.q, w.qd = q0.reshape(pp.leg_count, -1).copy(), qd0.reshape(pp.leg_count, -1).copy()
+        w.q, w.qd = q_startup.copy(), np.zeros_like(q_startup)
         for i_, leg_ in enumerate(w.legs):
             leg_.model_tip = fk_tip(i_, w.q[i_])
             leg_.model_dir = tip_axis(i_, w.q[i_])
         w.efforts = np.zeros_like(w.q)
-        start = np.stack([w.q, w.qd])
+    w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
+    if over.get("model"):
+        start = np.stack([w.q, w.qd])   # ... after that first loop: what the replay's robot must hold when it is handed over
         out["q"] = []
     for c in range(cycles):
         for first, l, a in schedule:
@@ -1024,7 +1048,7 @@ def run(name):
             else:
                 from syropod_highlevel_controller_amd.params import GAITS
                 P.update(GAITS[over["gait_change"]])
-                w.limits = limits_from_product(over["gait_change"], morphology, **prod)   # DATA: generateLimits' tables for the new step cycle
+                w.limits = init_chain_of(over["gait_change"], morphology, prod["rough_terrain_mode"], prod["gravity_aligned_tips"])[1]   # generateLimits for the new step cycle
                 w.step_cycle()
                 gait_changed = True
                 meta_new_limits.update(w.limits)
@@ -1091,6 +1115,7 @@ def run(name):
     if morphology:
         over["morphology"] = morphology
     meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events, new_limits=meta_new_limits,
+                time_to_start=START_UP_TIME,
                 visited_walk_states=sorted(set(out["walk_state"])))
     arrays = {k: np.array(v) for k, v in out.items() if len(v)}
     if start is not None:
