@@ -523,8 +523,9 @@ int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress);
  *       still walking: its velocity inputs are zeroed (:641-645) and its loop is one ordinary control cycle, -3 = no request: one
  *       ordinary control cycle (the call launches the cycle kernel for those two groups only).  While a robot has a leg that is not WALKING its walker
  *       is frozen (updateWalk returns at walk_controller.cpp:503); MANUAL / WALKING_TO_MANUAL legs are not posed (updateStance).
- *       Supported while the body pose is walk-plane pose + manual pose (no IMU / auto / inclination posing, no tip-align pose):
- *       SHC_ERR_UNSUPPORTED otherwise.
+ *       Every posing mode (walk-plane, manual, inclination, IMU, auto) keeps running for the robots that stand during the call - the
+ *       posing part of their loop (state_controller.cpp:165-181) is a pose-only pass of the cycle kernel.  With the experimental
+ *       tip-align pose (gravity_aligned_tips on <= 3-DOF legs) or leg_manipulation_mode joint_control: SHC_ERR_UNSUPPORTED.
  *   shc_engine_set_manual_inputs  primary / secondary leg selection [n] (-1 = LEG_UNDESIGNATED) with their tip velocity inputs
  *       [n][3] (updateManual(.., tip_velocity_input, ..): tip_control moves the tip, joint_control the coxa / tibia joints of
  *       3-DOF legs, params.leg_manipulation_mode) and tip position inputs [n][3] (updateManual(.., Pose, ..); a zero vector

@@ -45,7 +45,7 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // origins of the per-leg planes, which change once per step period).
 enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
-enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8, RT_EFFORT_LIVE = 16, RT_SKIP_MARKED = 32 }; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
+enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8, RT_EFFORT_LIVE = 16, RT_SKIP_MARKED = 32, RT_POSE_MARKED = 64 }; // RT_POSE_MARKED: run only the posing part of the loop (updateCurrentPose, admittance), and only for the robots a loop-level kernel marked; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
 // Feature mask of a kernel specialisation.  F_DYN: every feature is compiled in and selected by the runtime flags.
 enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F_TIPF = 32, F_ODOM = 64, F_DYN = 1u << 31,
@@ -152,7 +152,8 @@ struct RobotFields {
   static constexpr int WPP = 62, WPP_END = 69;                          // walk_plane_pose_ of the current cycle (LDS tile only)
   static constexpr int ODOM = 69, ODOM_END = 73; // WalkController::odometry_ideal_ (odometry feature): x, y, qw, qz (pure yaw)
   // PoseController::tip_align_pose_ / origin_tip_align_pose_ (gravity_aligned_tips with <= 3 DOF legs, generic kernel only)
-  static constexpr int TALIGN = 73, OTALIGN = 80, COUNT = 87;
+  static constexpr int INCL = 73, INCL_END = 75; // output: inclination_pose_.position_ x, y (read by poseForLegManipulation; written by the kernels with manual legs only)
+  static constexpr int TALIGN = 75, OTALIGN = 82, COUNT = 89;
   static constexpr int I_WORD = 0, I_APOSER = 1, I_POSE_PHASE = 2, I_RESET_MODE = 3, I_COUNT = 4;
 };
 
@@ -409,6 +410,7 @@ struct FrontToBack {
   V3 desired_dir;   // x axis of the desired tip rotation (body frame) when rot_def
   bool rot_def;
   int my_leg_state; // LegState of this leg (manual leg manipulation)
+  bool pose_only;   // in: stop after the posing part of the loop (state_controller.cpp:165-181) - a robot that stands while a leg toggle / plan step runs
   V3 odom_vel;      // desired linear (x, y) / angular (z) body velocity of this cycle and whether updateWalk reached its odometry
   bool odom_run;    //   update (cycle_front<..., ODOM_HERE = false>: the caller runs odometry_step elsewhere)
 };
@@ -663,6 +665,10 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       double lon = clampd(-P.body_clearance * tan(e.y), -P.max_translation[0], P.max_translation[0]);
       double lat = clampd(P.body_clearance * tan(e.x), -P.max_translation[1], P.max_translation[1]);
       cp = add_pose(cp, Pose{V3{lon, lat, 0.0}, quat_identity()});
+      if ((F & F_MLEGS) != 0) {
+        rb.put(R::INCL, lon);
+        rb.put(R::INCL + 1, lat);
+      }
     }
     if (FT::imu(P)) { // updateIMUPose (:1191-1236)
       Quat cur = correct_rotation(rb.getq(R::IMUQ), quat_identity());
@@ -846,6 +852,10 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       s.stiff = v;
     }
     if (ADM_HERE) cycle_admittance<NJ>(s, out, P, in);
+  }
+  if ((F & F_MLEGS) != 0 && fb.pose_only) { // the loop of this robot goes on in a loop-level kernel (legStateToggle / executePlan)
+    rb.puti(R::I_WORD, rword);              // walker_->setPoseState(poser_->getAutoPoseState())
+    return;
   }
 
   SHC_PHASE_FENCE();
@@ -1423,9 +1433,11 @@ template <int L, int NJ, unsigned F, typename IN = LegInPlanes<NJ>, typename MID
 __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
                                       const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
                                       const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
-                                      const MID &mid = MID(), const double *span = nullptr) {
+                                      const MID &mid = MID(), const double *span = nullptr, const bool pose_only = false) {
   FrontToBack fb;
+  fb.pose_only = pose_only;
   cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, legd, ns, slot, dirty, manual_live, touchdown_detection, ext, mr, in, fb, span);
+  if ((F & F_MLEGS) != 0 && pose_only) return; // (RT_POSE_MARKED: updateWalk / updateStance / updateModel do not run for this robot in this loop)
   mid();
   cycle_back<L, NJ, F>(s, out, C, leg, legd, ns, slot, mr, in, fb);
 }

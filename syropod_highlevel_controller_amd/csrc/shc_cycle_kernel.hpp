@@ -586,11 +586,15 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   double t_core[(R::CORE_END * RPW + 63) / 64], t_man[((R::MANUAL_END - R::MPOSE) * RPW + 63) / 64],
       t_imu[((R::IMU_END - R::ABSE) * RPW + 63) / 64], t_imuq[((R::IMUQ_END - R::IMUQ) * RPW + 63) / 64],
       t_aprev[((R::APREV_END - R::APREV) * RPW + 63) / 64], t_align[((R::COUNT - R::TALIGN) * RPW + 63) / 64], t_odom[((R::ODOM_END - R::ODOM) * RPW + 63) / 64],
-      t_cpose[((R::CPOSE_END - R::CPOSE) * RPW + 63) / 64];
+      t_cpose[((R::CPOSE_END - R::CPOSE) * RPW + 63) / 64], t_incl[((R::INCL_END - R::INCL) * RPW + 63) / 64];
   // RT_SKIP_MARKED - this launch follows a loop-level kernel (leg toggle, plan execution) that has already run the loop of the robots it
   // marked (ManualRobot::skip_cycle): they are left exactly as they are.  Model::current_pose_ is otherwise output only; here it
   // is loaded too so that the tile write-back is the identity for a skipped robot.
   const bool skip_marked = (F & F_MLEGS) != 0 && (rt_flags & RT_SKIP_MARKED) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0;
+  // RT_POSE_MARKED - the launch that PRECEDES such a loop-level kernel when the body pose has time-dependent parts (IMU / auto / inclination
+  // posing): the marked robots run the posing part of their loop here (PoseController::updateCurrentPose, the admittance update:
+  // state_controller.cpp:165-181) and nothing else; every other robot is left exactly as it is.
+  const bool pose_marked = (F & F_MLEGS) != 0 && (rt_flags & RT_POSE_MARKED) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0;
   constexpr int int_iters = (R::I_COUNT * RPW + 63) / 64; // 3-legged robots: 21 per wave x 4 ints = 84 entries > one wave's width
   int32_t t_int[int_iters];
   if (any_robot) {
@@ -600,7 +604,8 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) load_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, gtile, lane);
     if (FT::incl(GP) && FT::autop(GP)) load_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, gtile, lane);
     if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, gtile, lane);
-    if (skip_marked) load_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, gtile, lane);
+    if (skip_marked || pose_marked) load_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, gtile, lane);
+    if (pose_marked && FT::incl(GP)) load_rob_fields<RPW, R::INCL, R::INCL_END>(t_incl, gtile, lane);
     if ((F & F_TALIGN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
@@ -625,7 +630,8 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     if (FT::imu(GP) || FT::incl(GP) || FT::autop(GP)) put_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(t_imuq, tile, lane);
     if (FT::incl(GP) && FT::autop(GP)) put_rob_fields<RPW, R::APREV, R::APREV_END>(t_aprev, tile, lane);
     if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, tile, lane);
-    if (skip_marked) put_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, tile, lane);
+    if (skip_marked || pose_marked) put_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, tile, lane);
+    if (pose_marked && FT::incl(GP)) put_rob_fields<RPW, R::INCL, R::INCL_END>(t_incl, tile, lane);
     if ((F & F_TALIGN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it)
@@ -654,14 +660,21 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   unsigned dirty = 0;
   double *const ext = ((F & F_ROUGH) != 0 && (rt_flags & RT_EXTERNAL) != 0) ? st.ext : nullptr; // external targets (rough terrain mode)
   const ManualRobot *const mr = ((F & F_MLEGS) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0 && any_robot) ? st.manual + (rob0 + grp) : nullptr;
-  const bool skip = skip_marked && mr != nullptr && mr->skip_cycle != 0; // (uniform over the lanes of a robot)
+  const bool marked = mr != nullptr && mr->skip_cycle != 0;              // (uniform over the lanes of a robot)
+  const bool skip = (skip_marked && marked) || (pose_marked && !marked);
+  const bool pose_only = pose_marked && marked;
   ResidentHeld held;
   if constexpr (RES) {
     resident_loop<L, NJ, F>(*ra, st, s, out, C, rb, pk, g, leg, slot, lane, wave, live, tile, tile_i, dirty, manual_live, held);
   } else if (!skip) {
     for (int c = 0; c < n_cycles; ++c)
       cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
-                      LegInPlanes<NJ>{st.legd, st.n_slots, slot}, NoHook(), (F & F_ROUGH) != 0 ? st.span : nullptr);
+                      LegInPlanes<NJ>{st.legd, st.n_slots, slot}, NoHook(), (F & F_ROUGH) != 0 ? st.span : nullptr, pose_only);
+    if ((F & F_MLEGS) != 0 && pose_only && FT::autop(P) && !FT::imu(P)) { // updateStance did not run: the stored per-leg poser tip stays
+      const double2 *planes = reinterpret_cast<const double2 *>(st.legd);
+      const double2 a = planes[(Fields<NJ>::POSER_TIP / 2) * st.n_slots + slot], b = planes[(Fields<NJ>::POSER_TIP / 2 + 1) * st.n_slots + slot];
+      out.poser_tip = V3{a.x, a.y, b.x};
+    }
   }
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
@@ -679,6 +692,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   if (FT::manual(P) && manual_live && (dirty & DIRTY_MANUAL)) store_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(tile, gtile, lane);
   if (FT::imu(P)) store_rob_fields<RPW, R::ABSE, R::GYRO>(tile, gtile, lane);
   if (FT::incl(P) && FT::autop(P)) store_rob_fields<RPW, R::APREV, R::APREV_END>(tile, gtile, lane);
+  if ((F & F_MLEGS) != 0 && FT::incl(P) && pose_marked) store_rob_fields<RPW, R::INCL, R::INCL_END>(tile, gtile, lane); // for poseForLegManipulation
   store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
   if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::ODOM_END>(tile, gtile, lane);
   if ((F & F_TALIGN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);

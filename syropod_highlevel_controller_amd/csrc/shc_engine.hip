@@ -83,7 +83,7 @@ __global__ void gather_leg_kernel(double *dst, const double *legd, int64_t n_slo
 // LegState tips derived from the stored state (see store_leg): model tip = FK(q) in the robot frame (Leg::applyFK,
 // model.cpp:975), poser tip = Model::current_pose_^-1 * walker tip (PoseController::updateStance, pose_controller.cpp:122-131).
 template <int L, int NJ>
-__global__ void derive_tips_kernel(DevState st, const SharedConsts<L, NJ> *gc, int derive_poser) {
+__global__ void derive_tips_kernel(DevState st, const SharedConsts<L, NJ> *gc, int derive_poser, int keep_marked) {
   using FD = Fields<NJ>;
   using R = RobotFields;
   int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -100,7 +100,9 @@ __global__ void derive_tips_kernel(DevState st, const SharedConsts<L, NJ> *gc, i
   st.legd[leg_field_index(FD::MODEL_TIP, slot, st.n_slots)] = tip.x;
   st.legd[leg_field_index(FD::MODEL_TIP + 1, slot, st.n_slots)] = tip.y;
   st.legd[leg_field_index(FD::MODEL_TIP + 2, slot, st.n_slots)] = tip.z;
-  if (derive_poser) {
+  // keep_marked: the last loop of the marked robots was a plan call under time-dependent posing - their LegPoser tips are state (the
+  // pose has moved on since the updateStance that produced them, see execute_plan_kernel LOOP_MARK)
+  if (derive_poser && !(keep_marked && st.manual != nullptr && st.manual[rob].skip_cycle != 0)) {
     constexpr int rpw = 64 / L;
     double c[7];
     for (int k = 0; k < 7; ++k) c[k] = st.robd[rob_index(rob, R::CPOSE + k, rpw, R::COUNT)];
@@ -1203,7 +1205,7 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
-  if (!(e->rt_flags & RT_SKIP_MARKED)) e->plan_poser_tips_current = false; // PoseController::updateStance rewrites every LegPoser's tip pose
+  if (!(e->rt_flags & (RT_SKIP_MARKED | RT_POSE_MARKED))) e->plan_poser_tips_current = false; // PoseController::updateStance rewrites every LegPoser's tip pose
   // One wave per workgroup while the batch has about as many waves as the chip has SIMDs (1 024): the dispatcher then spreads
   // them one per SIMD (two-wave groups put pairs on the same SIMDs: 12.9 instead of 9.4 us at 768 waves, 12.2 instead of 10.2 at
   // 1 024; equal at 1 536).  Above that, 128-thread groups
@@ -1211,7 +1213,7 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   // fastest or within noise (-2 ... 3 % on 65 536 hexapods).
   const int block = e->n_waves < 1536 ? 64 : 128;
   const int64_t waves_per_block = block / 64;
-  const bool split = e->n_waves >= kSplitWaves && !(e->features & SHC_FEAT_SINGLE_STREAM) && !(e->rt_flags & RT_SKIP_MARKED);
+  const bool split = e->n_waves >= kSplitWaves && !(e->features & SHC_FEAT_SINGLE_STREAM) && !(e->rt_flags & (RT_SKIP_MARKED | RT_POSE_MARKED));
   if (!split) {
     const int rc = join_side(e);
     if (rc != SHC_OK) return rc;
@@ -1416,9 +1418,10 @@ static int derive_tips(shc_engine *e) {
   HIP_TRY(hipSetDevice(e->device));
   const int64_t threads = e->n * e->L;
   const int derive_poser = !(e->cp.auto_posing && !e->cp.imu_posing); // the auto-pose path stores its per-leg poser tip
+  const int keep_marked = e->plan_poser_tips_current && (e->params.imu_posing || e->params.auto_posing || e->params.inclination_posing);
 #define CALL(L_, NJ_)                                                                                             \
   derive_tips_kernel<L_, NJ_><<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(                \
-      e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, derive_poser)
+      e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, derive_poser, keep_marked)
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
   HIP_TRY(hipGetLastError());
@@ -2191,7 +2194,19 @@ static SeqParams seq_params(const shc_engine *e) {
   P.tip_force = e->cp.tip_force;
   P.have_adm = e->params.admittance_control;
   P.gravity_aligned = e->cp.gravity_aligned;
+  P.inclination_posing = e->params.inclination_posing;
+  P.pose_pass = e->params.imu_posing || e->params.auto_posing || e->params.inclination_posing;
+  P.poser_tip_kept = e->params.auto_posing && !e->params.imu_posing;
   return P;
+}
+// The body pose has parts that move while a robot stands (IMU PID, auto-pose latches, inclination): the posing part of a loop-level
+// call then runs in the cycle kernel (RT_POSE_MARKED, see LOOP_MARK in shc_sequence.hpp).
+static bool posing_needs_pose_pass(const shc_engine *e) { return e->params.imu_posing || e->params.auto_posing || e->params.inclination_posing; }
+static int pose_pass(shc_engine *e) { // the marked robots' PoseController::updateCurrentPose + admittance update, everybody else untouched
+  e->rt_flags |= RT_POSE_MARKED;
+  const int rc = shc_engine_step(e, 1);
+  e->rt_flags &= ~RT_POSE_MARKED;
+  return rc;
 }
 
 static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(START_UP / SHUT_DOWN), 2: stepToNewStance */, int32_t *progress) {
@@ -2229,9 +2244,8 @@ extern "C" int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress) {
 static int ensure_manual(shc_engine *e, bool planner = false) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   const shc_params &p = e->params;
-  if (p.imu_posing || p.auto_posing || p.inclination_posing || e->cp.tip_align)
-    return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with IMU / auto / inclination posing or the tip-align pose (the loop-level "
-                                     "kernels run the posing part of a loop for walk-plane + manual posing only)");
+  if (e->cp.tip_align)
+    return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with the tip-align pose (gravity_aligned_tips on <= 3-DOF legs)");
   if (planner) { // (transitionStance would read Model::estimateGravity for the target rotation, pose_controller.cpp:786-790)
     if (p.gravity_aligned_tips) return fail(SHC_ERR_UNSUPPORTED, "planner mode with gravity_aligned_tips");
   } else if (p.leg_manipulation_mode != SHC_MANIPULATION_TIP_CONTROL) {
@@ -2264,10 +2278,18 @@ extern "C" int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_sel
   HIP_TRY(hipMemsetAsync(d_cycle, 0, 4, e->stream));
   const SeqParams P = seq_params(e);
   const dim3 grid((unsigned)((e->n + 63) / 64)), block(64);
+  int phase = LOOP_WHOLE;
 #define CALL(L_, NJ_)                                                                                                                              \
   leg_state_toggle_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, d_sel, P, e->params.virtual_stiffness, \
                                                                   e->params.swing_stiffness_scaler, e->params.load_stiffness_scaler,                \
-                                                                  e->params.admittance_control && e->params.dynamic_stiffness, d_res, d_cycle)
+                                                                  e->params.admittance_control && e->params.dynamic_stiffness, d_res, d_cycle, phase)
+  if (posing_needs_pose_pass(e)) { // mark the robots that stand with a request, run the posing part of their loop in the cycle kernel
+    phase = LOOP_MARK;
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pose_pass(e)) != SHC_OK) return rc;
+    phase = LOOP_AFTER_POSE;
+  }
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
   HIP_TRY(hipGetLastError());
@@ -2382,9 +2404,17 @@ extern "C" int shc_engine_execute_plan(shc_engine *e, int32_t *progress, int32_t
   const SeqParams P = seq_params(e);
   const int reset_poser_tips = e->plan_poser_tips_current ? 0 : 1;
   const dim3 grid((unsigned)((e->n + 63) / 64)), block(64);
+  int phase = LOOP_WHOLE;
 #define CALL(L_, NJ_)                                                                                                                             \
   execute_plan_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, e->d_seq, P, reset_poser_tips, d_progress, \
-                                                              d_step, d_walking)
+                                                              d_step, d_walking, phase)
+  if (posing_needs_pose_pass(e)) { // mark the robots that stand, run the posing part of their loop in the cycle kernel
+    phase = LOOP_MARK;
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pose_pass(e)) != SHC_OK) return rc;
+    phase = LOOP_AFTER_POSE;
+  }
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
   HIP_TRY(hipGetLastError());

@@ -44,8 +44,16 @@ struct SeqParams {
   double step_frequency, swing_height, dt, force_gain;
   double target_rotation[4]; // LegStepper::target_tip_pose_.rotation_ while the robot has not walked: the identity tip rotation
                              // (walk_controller.cpp:37-41), UNDEFINED_ROTATION (zeros) without gravity-aligned tips
-  int clamp_vel, clamp_pos, tip_force, have_adm, gravity_aligned;
+  int clamp_vel, clamp_pos, tip_force, have_adm, gravity_aligned, inclination_posing;
+  int pose_pass;      // the body pose moves while a robot stands (IMU / auto / inclination posing): LOOP_MARK / LOOP_AFTER_POSE below
+  int poser_tip_kept; // the cycle kernels store every LegPoser tip (auto posing without IMU posing: the per-leg auto pose is not re-derivable)
 };
+// One StateController::loop() of the robots that stand while a leg toggle / plan step runs = posing part (:165-181), then legStateToggle /
+// executePlan.  With walk-plane + manual posing only, the loop-level kernel does both (LOOP_WHOLE).  With time-dependent posing (IMU / auto /
+// inclination) the posing part is the cycle kernel's: the loop-level kernel first only marks its robots (LOOP_MARK), the cycle kernel
+// runs PoseController::updateCurrentPose + the admittance update for them (RT_POSE_MARKED), then the loop-level kernel does the rest
+// (LOOP_AFTER_POSE).
+enum : int { LOOP_WHOLE = 0, LOOP_MARK = 1, LOOP_AFTER_POSE = 2 };
 
 template <int NJ>
 __device__ __forceinline__ Pose leg_current_tip_pose(const LegIO<NJ> &io, const LegConst<NJ> &lc) { // Leg::current_tip_pose_ = FK of the joints
@@ -350,17 +358,34 @@ constexpr double kPlanTransitionTime = 5.0;
 
 template <int L, int NJ>
 __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, SeqRobotState *seq, SeqParams P, int reset_poser_tips, int32_t *progress_out,
-                                    int32_t *plan_step_out, int32_t *walking_out) {
+                                    int32_t *plan_step_out, int32_t *walking_out, int phase) {
   using FD = Fields<NJ>;
   using R = RobotFields;
   using X = ExtFields;
   const int64_t rob = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (rob >= st.n_robots) return;
+  constexpr int rpw = 64 / L;
+  const int walk_state = st.robi[rob_index(rob, R::I_WORD, rpw, R::I_COUNT)] & 3;
+  if (phase == LOOP_MARK) { // which robots run their loop here: those that stand (their posing part then runs in the cycle kernel, RT_POSE_MARKED)
+    const bool standing = walk_state == WS_STOPPED;
+    // LegPoser::current_tip_pose_ is what the last PoseController::updateStance left - with a pose that has moved on since.  A robot
+    // whose last loop was a control cycle (this call follows cycles, or the robot was still walking in the previous plan call) gets
+    // it re-derived here from Model::current_pose_ of that cycle, BEFORE the pose pass overwrites it; from then on it is state.
+    if (standing && !P.poser_tip_kept && (reset_poser_tips || st.manual[rob].skip_cycle == 0)) {
+      const Pose pose_of_last_cycle = robot_current_pose<L>(st, rob);
+      for (int l = 0; l < L; ++l) {
+        const LegIO<NJ> io{st, slot_of(rob, l, L)};
+        const int ls = leg_state_of(st, rob, l);
+        const V3 walker_tip = io.get3(FD::TIP);
+        io.put3(FD::POSER_TIP, (ls == LS_MANUAL || ls == LS_WALKING_TO_MANUAL) ? walker_tip : inverse_transform_vector(pose_of_last_cycle, walker_tip));
+      }
+    }
+    st.manual[rob].skip_cycle = standing ? 1 : 0;
+    return;
+  }
   SeqRobotState &s = seq[rob];
   seq_defaults(s);
   if (reset_poser_tips) s.poser_tip_from_plan = 0; // control cycles ran since the last plan call: updateStance rewrote the poser tips
-  constexpr int rpw = 64 / L;
-  const int walk_state = st.robi[rob_index(rob, R::I_WORD, rpw, R::I_COUNT)] & 3;
   int progress;
   if (walk_state != WS_STOPPED) {
     st.robd[rob_index(rob, R::VIN, rpw, R::COUNT)] = 0.0;
@@ -371,7 +396,8 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
     progress = -1;
   } else {
     st.manual[rob].skip_cycle = 1;
-    for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
+    if (phase != LOOP_AFTER_POSE) // (... unless the cycle kernel has just run it)
+      for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
     if (!s.configuration_acquired && !s.tip_pose_acquired && !s.body_pose_acquired) {
       const Pose current_pose = robot_current_pose<L>(st, rob);
       for (int l = 0; l < L; ++l) { // Model::updateModel: setDesiredTipPose() = the poser's tip pose + admittance delta, applyIK
@@ -380,6 +406,8 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
         const int ls = leg_state_of(st, rob, l);
         if (s.poser_tip_from_plan && ls != LS_MANUAL) { // (stepToPosition leaves a MANUAL leg's LegPoser tip alone, :1680-1684)
           for (int k = 0; k < 7; ++k) tip[k] = s.leg[l].current[k];
+        } else if (P.pose_pass) { // the LegPoser's tip of the last updateStance (kept as state: the pose has moved since)
+          put_pose7(tip, io.get3(FD::POSER_TIP), Quat{0, 0, 0, 0});
         } else if (ls == LS_MANUAL || ls == LS_WALKING_TO_MANUAL) {
           put_pose7(tip, io.get3(FD::TIP), Quat{0, 0, 0, 0}); // updateStance hands manually manipulated legs the stepper's tip as it is (:134-137)
         } else {
@@ -476,7 +504,7 @@ constexpr int kMaxManualLegs = 2; // MAX_MANUAL_LEGS (state_controller.h:26)
 template <int L, int NJ>
 __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *gc, const int32_t *leg_selection, SeqParams P, double virtual_stiffness,
                                         double swing_stiffness_scaler, double load_stiffness_scaler, int dynamic_stiffness, int32_t *result_out,
-                                        int32_t *cycle_out) {
+                                        int32_t *cycle_out, int phase) {
   using FD = Fields<NJ>;
   using R = RobotFields;
   const int64_t rob = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -484,14 +512,18 @@ __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *
   const int sel = leg_selection[rob];
   int result = -3;
   st.manual[rob].skip_cycle = 0; // no request, or still walking: this robot's loop is the ordinary control cycle (launched next)
+  if (phase == LOOP_MARK && !(sel >= 0 && sel < L)) return;
   if (sel >= 0 && sel < L) {
     ManualRobot &m = st.manual[rob];
     constexpr int rpw = 64 / L;
     const int walk_state = st.robi[rob_index(rob, R::I_WORD, rpw, R::I_COUNT)] & 3;
     if (walk_state == WS_STOPPED) { // the posing part of this loop (a robot that is still walking runs its whole loop in the cycle kernel)
-      for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P);
       m.skip_cycle = 1;
+      if (phase == LOOP_MARK) return;
+      if (phase != LOOP_AFTER_POSE) // (... unless the cycle kernel has just run it: RT_POSE_MARKED)
+        for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P);
     }
+    if (phase == LOOP_MARK) return;
     if (walk_state != WS_STOPPED) {
       result = -1; // "Stopping Syropod to transition leg state": the velocity inputs are forced to zero (:641-645)
       st.robd[rob_index(rob, R::VIN, rpw, R::COUNT)] = 0.0;
@@ -526,7 +558,11 @@ __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *
         const double step_time = 1.0 / P.step_frequency;
         Pose target_pose;
         if (ls == LS_WALKING_TO_MANUAL) {
-          target_pose = pose_identity(); // (+ inclination_pose_: inclination posing is outside the supported envelope)
+          target_pose = pose_identity();
+          if (P.inclination_posing) { // + inclination_pose_.position_ as this loop's updateInclinationPose left it (the cycle kernel's pose pass)
+            target_pose.p.x += rd(R::INCL);
+            target_pose.p.y += rd(R::INCL + 1);
+          }
           target_pose.p.z -= step_height;
         } else {
           target_pose = current_pose;    // remove the manual pose, add the default pose (identity: calculateDefaultPose is never called)
@@ -565,8 +601,10 @@ __global__ void leg_state_toggle_kernel(DevState st, const SharedConsts<L, NJ> *
         if (m.leg_state[a1] != LS_MANUAL) stiff(a1) = load;
         if (m.leg_state[a2] != LS_MANUAL) stiff(a2) = load;
       }
-      for (int k = 0; k < 7; ++k) rd(R::MPOSE + k) = (k == 3) ? 1.0 : 0.0; // the next pose update: manual_pose_ = default_pose_ ...
-      for (int k = 0; k < 7; ++k) rd(R::CPOSE + k) = rd(R::OWPP + k);      // ... and current_pose_ = the standing walk-plane pose
+      if (phase != LOOP_AFTER_POSE) { // (with time-dependent posing the next loop's pose pass applies the reset itself)
+        for (int k = 0; k < 7; ++k) rd(R::MPOSE + k) = (k == 3) ? 1.0 : 0.0; // the next pose update: manual_pose_ = default_pose_ ...
+        for (int k = 0; k < 7; ++k) rd(R::CPOSE + k) = rd(R::OWPP + k);      // ... and current_pose_ = the standing walk-plane pose
+      }
       st.robi[rob_index(rob, R::I_RESET_MODE, rpw, R::I_COUNT)] = 5; // IMMEDIATE_ALL_RESET while the transition runs
       result = 0;
       if (min_progress == 100) {

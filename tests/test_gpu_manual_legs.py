@@ -12,14 +12,18 @@ from test_gpu_teacher_forced import as_np, compare_records
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("case", ["hexapod-tip-control", "8x4-tip-control", "hexapod-dynamic-stiffness", "8x5-gravity-aligned"])
+@pytest.mark.parametrize("case", ["hexapod-tip-control", "8x4-tip-control", "hexapod-dynamic-stiffness", "8x5-gravity-aligned",
+                                  "hexapod-imu-posing", "hexapod-auto-and-inclination-posing", "hexapod-imu-admittance"])
 def test_toggle_manipulate_and_return(case):
     """Walk; request a leg toggle per robot (different legs, two robots none): robots still walking are told to stop first
     (result -1), then the designated leg goes WALKING -> WALKING_TO_MANUAL -> MANUAL while every leg steps to its manipulation
     stance; MANUAL legs follow tip velocity and tip position inputs with the walker frozen whatever the body velocity command
     (the other robots keep walking); a second leg joins on some robots, a third is refused; toggled back, everything walks again.
     The oracle's state is injected before every call (the robots stand still for most of this, where the reference's IK step
-    amplifies rounding differences - DESIGN.md section 2.1); request results and leg states are compared exactly."""
+    amplifies rounding differences - DESIGN.md section 2.1); request results and leg states are compared exactly.
+    The posing cases: with IMU / auto / inclination posing the body pose keeps moving while a robot stands (PID state, poser latches,
+    the inclination translation poseForLegManipulation adds for the lifted leg): the posing part of those loops runs in the cycle
+    kernel's pose pass (RT_POSE_MARKED), the IMU readings change during the run."""
     if case.startswith("8x5"):     # gravity-aligned tips: the rotation-constrained IK kernels (F_ROT) with the manual-leg logic
         p = synthetic_octopod_params("ripple", 5, 8)
         p.gravity_aligned_tips = 1
@@ -29,6 +33,14 @@ def test_toggle_manipulate_and_return(case):
         p = default_hexapod_params("tripod")
     if "stiffness" in case:
         p.admittance_control, p.dynamic_stiffness = 1, 1
+    if "imu" in case:
+        p.imu_posing = 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    if "auto" in case:
+        p.auto_posing, p.inclination_posing, p.manual_posing = 1, 1, 1
+    if "imu-admittance" in case:
+        p.admittance_control = 1
+    posing = p.imu_posing or p.inclination_posing
     n = 8
     L, D = p.leg_count, p.leg_dof[0]
     rng = np.random.default_rng(23)
@@ -41,10 +53,22 @@ def test_toggle_manipulate_and_return(case):
         if p.admittance_control:
             o.set_tip_force(np.abs(rng.normal(0, 2.0, (n, L, 3))) * 0 + 1.5)
     worst = 0.0
+    calls_made = [0]
+
+    def imu():   # a new IMU reading every 20 loops: the robots stand on a slope that changes under them
+        calls_made[0] += 1
+        if posing and calls_made[0] % 20 == 1:
+            from scipy.spatial.transform import Rotation as R
+            e = np.stack([rng.uniform(-0.12, 0.12, n), rng.uniform(-0.12, 0.12, n), rng.uniform(-1, 1, n)], axis=1)
+            q = R.from_euler("xyz", e).as_quat()
+            quat, gyro = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1), rng.normal(0, 0.03, (n, 3))
+            for o in (eng, ob):
+                o.set_imu(quat, gyro)
 
     def forced_cycles(k):
         nonlocal worst
         for _ in range(k):
+            imu()
             eng.set_state(ob.get_state())
             eng.step(1)
             eng.synchronize()
@@ -64,6 +88,7 @@ def test_toggle_manipulate_and_return(case):
             if not pending.any():
                 break
             cur = np.where(pending, sel, -1).astype(np.int32)
+            imu()
             eng.set_state(ob.get_state())
             re, ro = eng.toggle_leg_state(cur), ob.toggle_leg_state(cur)
             assert np.array_equal(re, ro), (calls, re, ro)
@@ -135,9 +160,9 @@ def test_toggle_manipulate_and_return(case):
 
 
 def test_manual_legs_unsupported_configurations():
-    """Outside the accelerated envelope: other posing modes (the toggle's pose reset assumes walk-plane + manual posing) and
-    joint_control (its FK tip rotation makes the following applyIK rotation-constrained on 3-DOF legs)."""
-    for field in ("imu_posing", "auto_posing", "leg_manipulation_mode"):
+    """Outside the accelerated envelope: joint_control (its FK tip rotation makes the following applyIK rotation-constrained on 3-DOF
+    legs) and the experimental tip-align pose (gravity_aligned_tips on 3-DOF legs)."""
+    for field in ("gravity_aligned_tips", "leg_manipulation_mode"):
         p = default_hexapod_params("tripod")
         setattr(p, field, 1)
         eng = BatchEngine(p, 2)

@@ -14,14 +14,17 @@ pytestmark = pytest.mark.gpu
 WAITING, WALKING = -2, -1
 
 
-@pytest.mark.parametrize("case", ["hexapod", "hexapod-admittance", "8x4", "hexapod-rough-terrain", "hexapod-37-robots"])
+@pytest.mark.parametrize("case", ["hexapod", "hexapod-admittance", "8x4", "hexapod-rough-terrain", "hexapod-37-robots",
+                                  "hexapod-imu-posing-admittance", "hexapod-auto-and-inclination-posing-37-robots"])
 def test_plan_steps_against_the_oracle(case):
     """Walk; switch planner mode on: robots still walking are stopped by the call itself (result -1, their loop is the normal
     cycle) while the ones that stand already wait for plan step 0 (result -2, Model::updateModel only); a joint-configuration step
     (some legs not named, different per robot), a wait, a tip-target + body-pose step (targets sent through the TargetTipPose path:
     the robots stand, so the LegPosers take them), a body-pose-only step; planner off and walk again.  The oracle's state is
     injected before every call (the robots stand still throughout, where the reference's IK step amplifies rounding differences
-    - DESIGN.md section 2.1); progress values, plan steps and request flags are compared exactly."""
+    - DESIGN.md section 2.1); progress values, plan steps and request flags are compared exactly.  The posing cases: with IMU / auto /
+    inclination posing the body pose moves while the robots stand (the posing part of their loops runs in the cycle kernel's pose pass,
+    RT_POSE_MARKED); the IMU reading changes every 15 calls."""
     if case == "8x4":
         p = synthetic_octopod_params("ripple", 4, 8)
     else:
@@ -30,6 +33,12 @@ def test_plan_steps_against_the_oracle(case):
         p.admittance_control = 1
     if "rough" in case:
         p.rough_terrain_mode = 1
+    if "imu" in case:
+        p.imu_posing = 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    if "auto" in case:
+        p.auto_posing, p.inclination_posing, p.manual_posing = 1, 1, 1
+    posing = p.imu_posing or p.inclination_posing
     n = 37 if "37" in case else 8      # 37 hexapods = four waves, the last one partly filled: skip marks and walking robots mix within waves
     L, D = p.leg_count, p.leg_dof[0]
     rng = np.random.default_rng(31)
@@ -42,6 +51,17 @@ def test_plan_steps_against_the_oracle(case):
         if p.admittance_control:
             o.set_tip_force(np.full((n, L, 3), 1.5))
     worst = 0.0
+    calls_made = [0]
+
+    def imu():
+        calls_made[0] += 1
+        if posing and calls_made[0] % 15 == 1:
+            from scipy.spatial.transform import Rotation as R
+            e = np.stack([rng.uniform(-0.12, 0.12, n), rng.uniform(-0.12, 0.12, n), rng.uniform(-1, 1, n)], axis=1)
+            q = R.from_euler("xyz", e).as_quat()
+            quat, gyro = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1), rng.normal(0, 0.03, (n, 3))
+            for o in (eng, ob):
+                o.set_imu(quat, gyro)
 
     def check(tag, rows=slice(None)):
         nonlocal worst
@@ -54,6 +74,7 @@ def test_plan_steps_against_the_oracle(case):
 
     def forced_cycles(k):
         for _ in range(k):
+            imu()
             eng.set_state(ob.get_state())
             eng.step(1)
             eng.synchronize()
@@ -62,6 +83,7 @@ def test_plan_steps_against_the_oracle(case):
             assert np.array_equal(eng.body_state()[2], ob.body_state()[2])
 
     def plan_call():
+        imu()
         eng.set_state(ob.get_state())
         (pe, se), (po, so) = eng.execute_plan(), ob.execute_plan()
         assert np.array_equal(pe, po), (pe, po)
@@ -177,7 +199,7 @@ def test_plan_steps_against_the_oracle(case):
 
 
 def test_planner_unsupported_configurations():
-    for field in ("imu_posing", "auto_posing", "gravity_aligned_tips"):
+    for field in ("gravity_aligned_tips",):   # (on 3-DOF legs: the tip-align pose; on longer legs transitionStance would need Model::estimateGravity)
         p = default_hexapod_params("tripod")
         setattr(p, field, 1)
         eng = BatchEngine(p, 2)
