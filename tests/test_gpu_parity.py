@@ -1022,7 +1022,7 @@ def test_joint_command_and_tip_state_messages(Engine):
 def test_init_chain_on_device_matches_the_oracle():
     """shc_generate_tables_batch (start-up solve + workspace search + walkspace + limits as HIP kernels, one thread per
     (morphology, leg, bearing)) against the ORACLE's init chain for perturbed morphologies.  Integers are exact; workspace
-    radii, walkspace and limits agree to 1e-5.  The start-up joint configuration is the state of the reference's DLS iteration
+    radii, walkspace and limits agree to 1e-12 m / 1e-11 relative for 3-joint legs (the achieved values are in the parity report).  The start-up joint configuration is the state of the reference's DLS iteration
     after time_to_start / time_delta steps, which amplifies rounding differences by ~1.1x per step and, for chains with more
     than three joints, drifts along the null space (tests/test_oracle_conditioning.py): the yardstick for every morphology is
     how far the oracle's own fast-math build ends from the oracle (x20, floor 1e-9 rad) - 1e-14...1e-12 rad for 3-joint legs at
@@ -1053,6 +1053,7 @@ def test_init_chain_on_device_matches_the_oracle():
     assert status[-1] != 0 and (status[:-1] == 0).all()
     from test_oracle_conditioning import dq as dq_of, twin_tables
     err = {200: [], 300: []}
+    derived = {200: [], 300: []}
     worst = 0.0
     for p, t in zip(plist[:-1], tables[:-1]):
         h = OracleRobot(p).tables()
@@ -1071,16 +1072,25 @@ def test_init_chain_on_device_matches_the_oracle():
         # the workspace search is another several hundred DLS steps of the same ill-conditioned iteration (model.cpp:397-460), ending
         # where a step first fails: the device chain's radii (FMA contraction, its own sin / cos) are within a few micrometres of
         # the oracle's (the host chain, plain IEEE arithmetic like the oracle, within 1e-9: tests/test_host_tables_and_abi.py)
-        tol = 1e-5
-        np.testing.assert_allclose(np.array(t.workspace_radius)[:L], np.array(h.workspace_radius)[:L], atol=tol)
-        for name in ("walkspace", "max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration"):
-            np.testing.assert_allclose(np.array(getattr(t, name)), np.array(getattr(h, name)), rtol=tol * 100, atol=tol, err_msg=name)
+        d_ws = float(np.abs(np.array(t.workspace_radius)[:L] - np.array(h.workspace_radius)[:L]).max())
+        d_lim = max(float((np.abs(np.array(getattr(t, name)) - np.array(getattr(h, name))) / np.maximum(np.abs(np.array(getattr(h, name))), 1e-300)).max())
+                    for name in ("walkspace", "max_linear_speed", "max_angular_speed", "max_linear_acceleration", "max_angular_acceleration"))
+        derived[steps].append((d_ws, d_lim, redundant))
+        # 3-joint legs: everything derived from the configuration agrees to rounding (measured 1e-16 m / 4e-15 relative).  Redundant chains
+        # start their workspace search from a configuration that has drifted along its null space (above): micrometres / 4e-5 measured
+        assert d_ws < (1e-5 if redundant else 1e-12) and d_lim < (1e-3 if redundant else 1e-11), (d_ws, d_lim, redundant)
     e200 = np.array([d for d, r in err[200] if not r])
     e300 = np.array([d for d, r in err[300] if not r])
     red = np.array([d for k in err for d, r in err[k] if r])
     from conftest import parity_report
     parity_report(f"device init chain vs oracle, start-up configuration: 200 steps max {e200.max():.2e}, 300 steps median {np.median(e300):.2e} "
           f"max {e300.max():.2e}, 4- / 5-joint chains median {np.median(red):.2e} max {red.max():.2e} rad; worst ratio to the twin-build bound {worst:.2f}")
+    for steps in (200, 300):
+        for red_, label in ((False, "3-joint legs"), (True, "4- / 5-joint chains")):
+            rows = [(a, b) for a, b, r in derived[steps] if r == red_]
+            if rows:
+                parity_report(f"device init chain vs oracle, {steps} start-up steps, {label}: workspace radii max {max(a for a, _ in rows):.2e} m, "
+                              f"walkspace / limit tables max relative {max(b for _, b in rows):.2e} ({len(rows)} morphologies)")
     assert e200.max() < 1e-9                                   # 3-joint legs, 200 steps: well-posed
     assert np.median(e300) < 1e-7 and e300.max() < 1e-5        # default 300 steps
     assert np.median(red) < 1e-5
