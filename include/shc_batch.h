@@ -39,8 +39,8 @@ enum {
   SHC_ERR_INVALID_ARG = 1,
   SHC_ERR_NO_DEVICE = 2,      /* no HIP device / kernel image: the product path never falls back to CPU */
   SHC_ERR_HIP = 3,
-  SHC_ERR_UNSUPPORTED = 4,    /* outside the accelerated path: legs of different DOF in one engine, sequences with own-clock auto
-                                 posing, joint_control leg manipulation, resident mode for a batch that does not fit the chip */
+  SHC_ERR_UNSUPPORTED = 4,    /* outside the accelerated path: gravity_aligned_tips on a robot whose legs differ in DOF, sequences with
+                                 own-clock auto posing, joint_control leg manipulation, resident mode for a batch that does not fit the chip */
   SHC_ERR_UNSTABLE = 5,       /* reserved: the reference aborts when the IMU correction's norm exceeds 100 rad
                                  (pose_controller.cpp:1228-1232); after its own clamps (:1222-1226) that needs
                                  max_rotation > 100 rad, so no entry point returns this code today */
@@ -83,7 +83,8 @@ typedef struct shc_params {
   int32_t manual_posing, auto_posing, rough_terrain_mode, admittance_control, inclination_posing, imu_posing;
   /* model (default.yaml:25-78) */
   int32_t leg_count;
-  int32_t leg_dof[SHC_MAX_LEGS];
+  int32_t leg_dof[SHC_MAX_LEGS];   /* 3..5 per leg; legs may differ: joint arrays of the ABI are then [legs][longest leg's DOF], a shorter leg's
+                                      extra entries read 0 and are ignored on input (the engine pads it behind its tip with locked joints) */
   shc_joint_params joint[SHC_MAX_LEGS][SHC_MAX_JOINTS];
   shc_link_params link[SHC_MAX_LEGS][SHC_MAX_LINKS]; /* link[l][0] = base link */
   int32_t clamp_joint_positions, clamp_joint_velocities;

@@ -62,7 +62,7 @@ class Engine {
 public:
   explicit Engine(const shc_params &params, int64_t n = 1, int device = 0, void *stream = nullptr) : params_(params), n_(n) {
     check(shc_engine_create(&params_, n, device, stream, &e_), "shc_engine_create");
-    measured_q_.assign(size_t(n) * params_.leg_count * params_.leg_dof[0], 0.0);
+    measured_q_.assign(size_t(n) * params_.leg_count * dof(), 0.0);
   }
   ~Engine() { shc_engine_destroy(e_); }
   Engine(const Engine &) = delete;
@@ -72,7 +72,11 @@ public:
   const shc_params &params() const { return params_; }
   int64_t instances() const { return n_; }
   int legs() const { return params_.leg_count; }
-  int dof() const { return params_.leg_dof[0]; }
+  int dof() const { // joint arrays of the C ABI are [legs][DOF of the robot's longest leg]
+    int nj = 0;
+    for (int l = 0; l < params_.leg_count; ++l) nj = params_.leg_dof[l] > nj ? params_.leg_dof[l] : nj;
+    return nj;
+  }
   // One control cycle for the whole batch (asynchronous; the next getter synchronises through its copy).
   void cycle(int n_cycles = 1) {
     check(shc_engine_step(e_, n_cycles), "shc_engine_step");

@@ -337,6 +337,31 @@ static void build_shared_consts(const shc_params &p, const shc_tables &t, const 
   }
 }
 
+// Parameters::leg_DOF is per leg (parameters_and_states.h:298): the engine runs a robot on the kernels of its LONGEST leg; a shorter leg
+// is padded behind its tip with locked zero-length joints (LegConst::jactive, hostinit::fill_leg_const), which leaves every formula of
+// that leg as the reference evaluates it for its own joint count (the padded Jacobian columns are zero, their cost terms too).
+static int max_dof(const shc_params &p) {
+  int nj = 0;
+  for (int l = 0; l < p.leg_count && l < SHC_MAX_LEGS; ++l) nj = p.leg_dof[l] > nj ? p.leg_dof[l] : nj;
+  return nj;
+}
+static bool mixed_dof(const shc_params &p) {
+  for (int l = 1; l < p.leg_count; ++l)
+    if (p.leg_dof[l] != p.leg_dof[0]) return true;
+  return false;
+}
+// ... and the parameter block the engine keeps has neutral entries for the padding (joint arrays of the ABI are [legs][longest leg's DOF]:
+// the padded joints read 0 and ignore what is written to them)
+static shc_params normalised_params(const shc_params &in) {
+  shc_params p = in;
+  const int nj = max_dof(p);
+  for (int l = 0; l < p.leg_count; ++l)
+    for (int j = p.leg_dof[l]; j < nj; ++j) {
+      p.joint[l][j] = shc_joint_params{0.0, 0.0, 0.0, 0.0, 1.0};
+      p.link[l][j + 1] = shc_link_params{0.0, 0.0, 0.0, 0.0};
+    }
+  return p;
+}
 static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_t features, unsigned rt_flags, CycleParams &c) {
   memset(&c, 0, sizeof c);
   const shc_step_cycle &s = t.step;
@@ -384,10 +409,10 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   // stays it, so the kernels without the estimate run (its planes are neither loaded nor stored).
   c.tip_force = (((features & SHC_FEAT_TIP_FORCE) || p.use_joint_effort) && (rt_flags & RT_EFFORT_LIVE)) ? 1 : 0;
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
-  c.gravity_aligned = hostinit::tips_rotation_tracked(p, p.leg_dof[0]) ? 1 : 0;
-  c.gravity_target = hostinit::tips_rotation_constrained(p, p.leg_dof[0]) ? 1 : 0;
+  c.gravity_aligned = hostinit::tips_rotation_tracked(p, max_dof(p)) ? 1 : 0;
+  c.gravity_target = hostinit::tips_rotation_constrained(p, max_dof(p)) ? 1 : 0;
   c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
-  c.tip_align = (p.gravity_aligned_tips && p.leg_dof[0] <= 3) ? 1 : 0; // pose_controller.cpp:849
+  c.tip_align = (p.gravity_aligned_tips && max_dof(p) <= 3) ? 1 : 0; // pose_controller.cpp:849 (leg 0's joint count; mixed DOF + gravity_aligned_tips is rejected)
   c.step_depth = p.step_depth;
   {
     V3 d = hostinit::gravity_aligned_direction();
@@ -433,10 +458,11 @@ static int upload_consts(shc_engine *e);
 static int validate_params(const shc_params *p, int *L, int *NJ) {
   if (!p) return fail(SHC_ERR_INVALID_ARG, "params is NULL");
   if (p->leg_count < 3 || p->leg_count > SHC_MAX_LEGS) return fail(SHC_ERR_INVALID_ARG, "leg_count must be 3..8");
-  int nj = p->leg_dof[0];
+  const int nj = max_dof(*p);
   for (int l = 0; l < p->leg_count; ++l)
-    if (p->leg_dof[l] != nj) return fail(SHC_ERR_UNSUPPORTED, "all legs of one engine must share one DOF (bin mixed morphologies)");
-  if (nj < 3 || nj > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
+    if (p->leg_dof[l] < 3 || p->leg_dof[l] > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
+  if (mixed_dof(*p) && p->gravity_aligned_tips) // (the reference decides per leg: > 3 joints constrain the tip rotation, <= 3 use the tip-align pose)
+    return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips on a robot whose legs differ in DOF");
   if (p->rough_terrain_mode && !(p->touchdown_threshold >= p->liftoff_threshold))
     return fail(SHC_ERR_INVALID_ARG, "touchdown_threshold must be >= liftoff_threshold");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
@@ -513,10 +539,11 @@ extern "C" int shc_generate_tables(const shc_params *params, shc_tables *out) {
   int rc = validate_params(params, &L, &NJ);
   if (rc != SHC_OK) return rc;
   if (!out) return fail(SHC_ERR_INVALID_ARG, "out is NULL");
+  const shc_params np = normalised_params(*params);
   switch (NJ) {
-    case 3: return generate_tables_nj<3>(params, out);
-    case 4: return generate_tables_nj<4>(params, out);
-    case 5: return generate_tables_nj<5>(params, out);
+    case 3: return generate_tables_nj<3>(&np, out);
+    case 4: return generate_tables_nj<4>(&np, out);
+    case 5: return generate_tables_nj<5>(&np, out);
   }
   return fail(SHC_ERR_UNSUPPORTED, "dof");
 }
@@ -553,6 +580,8 @@ extern "C" int shc_generate_tables_batch(const shc_params *params, int64_t count
   for (int64_t i = 0; i < count; ++i) { // parameter screening is host logic (same rules as shc_engine_create)
     int L, NJ;
     st[i] = validate_params(&params[i], &L, &NJ);
+    if (st[i] == SHC_OK && mixed_dof(params[i])) // (the device chain instantiates per DOF; robots whose legs differ go through the host chain)
+      st[i] = fail(SHC_ERR_UNSUPPORTED, "shc_generate_tables_batch: legs of different DOF in one robot (use shc_generate_tables)");
   }
   shc_params *d_p = nullptr;
   shc_tables *d_t = nullptr;
@@ -830,7 +859,7 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   shc_engine *e = new shc_engine();
   memset(static_cast<void *>(e), 0, sizeof *e);
   e->span_dirty = e->main_dirty = true; // (the memset above also clears the members' default initialisers)
-  e->params = *params;
+  e->params = normalised_params(*params); // (legs shorter than the robot's longest: neutral entries for their padded joints)
   e->L = L;
   e->NJ = NJ;
   e->device = device;

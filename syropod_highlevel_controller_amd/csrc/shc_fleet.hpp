@@ -208,7 +208,7 @@ static int fleet_set_leg(shc_fleet *f, const double *src, int max_k, bool per_do
   if (!src) return SHC_OK;
   for (auto &p : f->parts) {
     const shc_params &pp = f->params[p.morph];
-    const int L = pp.leg_count, K = per_dof ? pp.leg_dof[0] : max_k;
+    const int L = pp.leg_count, K = per_dof ? max_dof(pp) : max_k;
     f->host_a.resize(p.ids.size() * size_t(L) * K);
     for (size_t k = 0; k < p.ids.size(); ++k)
       for (int l = 0; l < L; ++l)
@@ -255,7 +255,7 @@ extern "C" int shc_fleet_get_joint_state(shc_fleet *f, double *q, double *qd) {
     if (dst) std::fill(dst, dst + size_t(f->n) * row, std::nan(""));
   for (auto &p : f->parts) {
     const shc_params &pp = f->params[p.morph];
-    const int L = pp.leg_count, D = pp.leg_dof[0];
+    const int L = pp.leg_count, D = max_dof(pp);
     f->host_a.resize(p.ids.size() * size_t(L) * D);
     f->host_b.resize(f->host_a.size());
     const int rc = shc_engine_get_joint_state(p.engine, q ? f->host_a.data() : nullptr, qd ? f->host_b.data() : nullptr, 0);
@@ -315,7 +315,7 @@ extern "C" int shc_fleet_all_gather_joints(shc_fleet *f, double **device_buffers
   for (auto &p : f->parts) { // first call: the part's own buffers, the landing buffers on the other devices, the ids everywhere
     if (p.g_joints) continue;
     const shc_params &pp = f->params[p.morph];
-    const size_t rows = p.ids.size(), elems = rows * pp.leg_count * pp.leg_dof[0];
+    const size_t rows = p.ids.size(), elems = rows * pp.leg_count * max_dof(pp);
     HIP_TRY(hipSetDevice(p.device));
     HIP_TRY(hipMalloc(&p.g_joints, elems * 8));
     HIP_TRY(hipMalloc(&p.g_ids, rows * 8));
@@ -333,7 +333,7 @@ extern "C" int shc_fleet_all_gather_joints(shc_fleet *f, double **device_buffers
   }
   for (auto &p : f->parts) { // every part: joints -> its buffer -> the local gather buffer(s), on its own stream
     const shc_params &pp = f->params[p.morph];
-    const int L = pp.leg_count, D = pp.leg_dof[0];
+    const int L = pp.leg_count, D = max_dof(pp);
     const int64_t rows = int64_t(p.ids.size()), threads = rows * L * D;
     HIP_TRY(hipSetDevice(p.device));
     const int rc = shc_engine_get_joint_state(p.engine, p.g_joints, nullptr, 1);
@@ -348,7 +348,7 @@ extern "C" int shc_fleet_all_gather_joints(shc_fleet *f, double **device_buffers
   }
   for (auto &p : f->parts) { // every other device pulls the part's rows and places them
     const shc_params &pp = f->params[p.morph];
-    const int L = pp.leg_count, D = pp.leg_dof[0];
+    const int L = pp.leg_count, D = max_dof(pp);
     const int64_t rows = int64_t(p.ids.size()), threads = rows * L * D;
     for (int d = 0; d < nd; ++d) {
       if (f->devices[d] == p.device) continue;

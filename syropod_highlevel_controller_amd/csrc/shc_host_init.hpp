@@ -47,6 +47,13 @@ SHC_HDI void fill_leg_const(const shc_params &p, int l, LegConst<NJ> &lc) {
   lc.r1[6] = 0;  lc.r1[7] = sa;       lc.r1[8] = ca;
   lc.p1[0] = b.r * ct; lc.p1[1] = b.r * st; lc.p1[2] = b.d;
   for (int k = 0; k < NJ; ++k) {
+    if (k >= p.leg_dof[l]) { // padding behind the tip of a leg with fewer joints than the robot's longest: an identity transform, locked at 0
+      lc.link_sa[k] = 0.0, lc.link_ca[k] = 1.0;
+      lc.jvmax[k] = 1.0;
+      lc.jw_vrange[k] = kJointLimitCostWeight / 2.0;
+      continue; // (d, r, theta, limits, centre, jw_range, jactive stay 0)
+    }
+    lc.jactive[k] = 1.0;
     const shc_link_params &lk = p.link[l][k + 1];
     lc.link_d[k] = lk.d;
     lc.link_r[k] = lk.r;
@@ -513,7 +520,7 @@ SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int 
   const Pose body = startup_body_pose(p, t, 0), body_ws = startup_body_pose(p, t, startup_loops(p) - 1);
   HostLeg<NJ> leg;
   fill_leg_const<NJ>(p, l, leg.lc);
-  for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, p.joint[l][j].min, p.joint[l][j].max); // model.cpp:1038
+  for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, leg.lc.jmin[j], leg.lc.jmax[j]); // model.cpp:1038
   V3 default_tip{p.stance_position[l][0], p.stance_position[l][1], 0.0};
   if (preset_configuration) { // the default configuration is given (the joints a start-up SEQUENCE ended on, state_controller.cpp:307-310)
     for (int j = 0; j < NJ; ++j) leg.q[j] = preset_configuration[j], leg.qd[j] = 0.0;

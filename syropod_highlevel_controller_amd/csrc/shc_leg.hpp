@@ -28,6 +28,9 @@ struct LegConst {
   double jcentre[NJ];  // min + (max - min) / 2                       (model.cpp:771)
   double jw_range[NJ]; // JOINT_LIMIT_COST_WEIGHT / (max - min), 0 if the range is 0   (model.cpp:772-778)
   double jw_vrange[NJ]; // JOINT_LIMIT_COST_WEIGHT / (2 max_vel)      (model.cpp:781-786)
+  double jactive[NJ];   // 1: a joint of this leg; 0: padding of a leg with fewer joints than the robot's longest (Parameters::leg_DOF is per
+                        // leg): a zero-length link behind the tip with the range [0, 0] - its linear Jacobian column is zero by geometry,
+                        // the angular one (tip-force estimate, rotation-constrained solves) is masked with this
   double stance_x, stance_y; // identity tip position (walk_controller.cpp:34-35)
   double span_shift;         // LegStepper::calculateStanceSpanChange().y for the single-plane workspace (walk_controller.cpp:949-980)
   double neg_ratio;          // negation_transition_ratio
@@ -194,13 +197,16 @@ SHC_HD void ik_step_rotation(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[N
   vs = vcost == 0.0 ? 0.0 : vs;
   const double l2 = kDls * kDls;
   double a[NJ][NJ];
+  V3 z[NJ]; // joint axes = the angular Jacobian columns (padding joints have none)
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) z[i] = c.z[i] * lc.jactive[i];
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
 #pragma unroll
-    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + dot(c.z[i], c.z[j]);
+    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + dot(z[i], z[j]);
     a[i][i] += l2;
     double g = 0.25 * (pg[i] * ps) + 0.75 * (vg[i] * vs);
-    dq[i] = dot(c.z[i], rot_delta) + l2 * g;
+    dq[i] = dot(z[i], rot_delta) + l2 * g;
   }
   spd_solve<NJ, EXACT>(a, dq);
 }
@@ -230,10 +236,10 @@ SHC_HD void solve_ik_delta(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[NJ]
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
 #pragma unroll
-    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + (solve_rotation ? dot(c.z[i], c.z[j]) : 0.0);
+    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + (solve_rotation ? dot(c.z[i] * lc.jactive[i], c.z[j] * lc.jactive[j]) : 0.0);
     a[i][i] += l2;
     double g = 0.25 * (pg[i] * ps) + 0.75 * (vg[i] * vs);
-    dq[i] = dot(lin[i], dp) + (solve_rotation ? dot(c.z[i], dw) : 0.0) + l2 * g;
+    dq[i] = dot(lin[i], dp) + (solve_rotation ? dot(c.z[i] * lc.jactive[i], dw) : 0.0) + l2 * g;
   }
   spd_solve<NJ, EXACT>(a, dq);
 }
@@ -303,10 +309,13 @@ SHC_HD V3 tip_force_raw(const LC &lc, const Chain<NJ> &c, const double (&tau)[NJ
 template <int NJ, class LC>
 SHC_HD V3 tip_force_cols(const LC &lc, const Chain<NJ> &c, const V3 (&lin)[NJ], const double (&tau)[NJ]) {
   double a[NJ][NJ], y[NJ];
+  V3 z[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) z[i] = c.z[i] * lc.jactive[i];
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
 #pragma unroll
-    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + dot(c.z[i], c.z[j]);
+    for (int j = 0; j <= i; ++j) a[i][j] = dot(lin[i], lin[j]) + dot(z[i], z[j]);
     a[i][i] += kDls * kDls;
     y[i] = tau[i];
   }

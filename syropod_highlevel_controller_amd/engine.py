@@ -321,7 +321,7 @@ class BatchEngine:
         if self.L.shc_device_count() < 1:
             raise ShcError("no HIP device visible: the batched engine has no CPU fallback")
         self.params, self.n = params, int(n)
-        self.legs, self.dof = params.leg_count, params.leg_dof[0]
+        self.legs, self.dof = params.leg_count, max(params.leg_dof[l] for l in range(params.leg_count))   # joint arrays are [legs][longest leg's DOF]
         self.features = FEAT_DEFAULT
         h = C.c_void_p()
         if tables is None:

@@ -344,3 +344,19 @@ def synthetic_octopod_params(gait: str = "ripple", dof: int = 5, n_legs: int = 8
     _set_gait(p, gait, n_legs, om)
     _set_auto_pose(p, gait, n_legs)
     return p
+
+
+def synthetic_mixed_dof_params(gait: str = "ripple", dofs=(3, 5, 4, 3, 5, 4)) -> Params:
+    """A SYNTHETIC robot whose legs differ in DOF (``Parameters::leg_DOF`` is per leg, parameters_and_states.h:298; BASELINE.json config 5
+    "3-5 DOF per leg"): leg ``l`` is leg ``l`` of ``synthetic_octopod_params(gait, dofs[l], len(dofs))`` - same hips and stance
+    positions, each leg its own chain."""
+    n_legs = len(dofs)
+    p = synthetic_octopod_params(gait, max(dofs), n_legs)
+    for l, d in enumerate(dofs):
+        src = synthetic_octopod_params(gait, d, n_legs)
+        p.leg_dof[l] = d
+        for j in range(SHC_MAX_JOINTS):
+            p.joint[l][j] = src.joint[l][j]
+        for j in range(SHC_MAX_JOINTS + 1):
+            p.link[l][j] = src.link[l][j]
+    return p

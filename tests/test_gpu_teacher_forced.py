@@ -39,7 +39,7 @@ def as_np(states):
 
 def compare_records(p, features, g, o, tol_q=TOL_Q):
     """g: engine records, o: oracle records (numpy structured arrays).  Returns max |dq|."""
-    L, D = p.leg_count, p.leg_dof[0]
+    L, D = p.leg_count, max(p.leg_dof[l] for l in range(p.leg_count))   # (legs shorter than the longest: their padded joints read 0 on both sides)
     # Teacher forcing equalises the STATE; the launch constants (velocity / acceleration limit tables) still come from each
     # side's own init chain and agree to 1e-9 relative (1e-10 for 3- and 4-joint legs: tests/test_host_tables_and_abi.py), so
     # limited velocities - and the strides / tip targets scaled from them - inherit that relative difference.  The unconstrained
