@@ -460,7 +460,7 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
   if (p->leg_count < 3 || p->leg_count > SHC_MAX_LEGS) return fail(SHC_ERR_INVALID_ARG, "leg_count must be 3..8");
   const int nj = max_dof(*p);
   for (int l = 0; l < p->leg_count; ++l)
-    if (p->leg_dof[l] < 3 || p->leg_dof[l] > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg: 3..5");
+    if (p->leg_dof[l] < 3 || p->leg_dof[l] > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg (leg_dof): 3..5 DOF");
   if (mixed_dof(*p) && p->gravity_aligned_tips) // (the reference decides per leg: > 3 joints constrain the tip rotation, <= 3 use the tip-align pose)
     return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips on a robot whose legs differ in DOF");
   if (p->rough_terrain_mode && !(p->touchdown_threshold >= p->liftoff_threshold))

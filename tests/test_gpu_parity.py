@@ -1169,7 +1169,7 @@ def test_error_codes(Engine):
     assert L.shc_engine_read_leg_state_msg(eng.h, -1, msgs) == INVALID
     assert L.shc_engine_get_virtual_stiffness(eng.h, None, 0) == UNSUPPORTED   # admittance_control is off
     bad = default_hexapod_params("tripod")
-    bad.leg_dof[3] = 4
+    bad.leg_dof[3] = 6
     h = C.c_void_p()
     assert L.shc_engine_create(C.byref(bad), 4, 0, None, C.byref(h)) == UNSUPPORTED and b"DOF" in L.shc_last_error()
     assert L.shc_engine_create(C.byref(p), 0, 0, None, C.byref(h)) == INVALID
