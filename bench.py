@@ -399,19 +399,30 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
 
 
 DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config5": 1 << 20, "rough": 65536, "gravity": 65536}
-CONFIG5_BINS = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"))  # (legs, dof, gait)
+# (legs, dof, gait); a tuple of DOFs = a robot whose legs differ in joint count (BASELINE.json configs[4]: "3-5 DOF per leg")
+CONFIG5_BINS = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"), (6, (3, 5, 4, 3, 5, 4), "ripple"))
+
+
+def config5_morphology(legs, dof, gait):
+    from syropod_highlevel_controller_amd import synthetic_mixed_dof_params, synthetic_octopod_params
+    return synthetic_mixed_dof_params(gait, dof) if isinstance(dof, tuple) else synthetic_octopod_params(gait, dof, legs)
+
+
+def config5_bytes(legs, dof):
+    """SURVEY.md section 8(d) per robot and cycle: per leg 2 x ((2 DOF + 24) doubles + one packed int), per robot 2 x 28 B + the 24 B velocity input."""
+    dofs = dof if isinstance(dof, tuple) else (dof,) * legs
+    return 2 * (sum((2 * d + 24) * 8 + 4 for d in dofs) + 28) + 24
 
 
 def run_config5(n, steps, warmup, seed):
-    """BASELINE.json configs[4]: mixed morphologies (4 / 6 / 8 legs, 3 - 5 joints, all four gaits), instance i has morphology
-    i mod 5 - the worst interleaving for a one-kernel design.  shc_fleet_create bins the instances (one engine + one HIP stream
+    """BASELINE.json configs[4]: mixed morphologies (4 / 6 / 8 legs, 3 - 5 joints - one bin with legs of 3, 5 and 4 joints in the same
+    robot -, all four gaits), instance i has morphology i mod 6 - the worst interleaving for a one-kernel design.  shc_fleet_create bins the instances (one engine + one HIP stream
     per morphology), so the device work is the same whatever the order; the interleaved and the sorted ("binned") order differ
     only in the host-side permutation of the boundary arrays, reported separately."""
     import torch
-    from syropod_highlevel_controller_amd import synthetic_octopod_params
     from syropod_highlevel_controller_amd.fleet import MixedFleet
     from syropod_highlevel_controller_amd.parallel import velocity_inputs
-    morphs = [synthetic_octopod_params(g, d, l) for l, d, g in CONFIG5_BINS]
+    morphs = [config5_morphology(l, d, g) for l, d, g in CONFIG5_BINS]
     lin, ang = velocity_inputs(seed ^ 0x5EED5, 0, n)
     out = {}
     alg = 0
@@ -436,18 +447,18 @@ def run_config5(n, steps, warmup, seed):
         q, _ = fleet.joints()
         t_out = time.perf_counter() - t0
         moving = float((fleet.walk_state() == 1).mean())
-        alg = sum(int((mid == k).sum()) * (2 * (l * ((2 * d + 24) * 8 + 4) + 28) + 24) for k, (l, d, g) in enumerate(CONFIG5_BINS))
+        alg = sum(int((mid == k).sum()) * config5_bytes(l, d) for k, (l, d, g) in enumerate(CONFIG5_BINS))
         out[order] = {"value": n * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "moving_fraction": moving,
                       "finite": bool(np.isfinite(q[~np.isnan(q)]).all()), "host_set_velocity_s": t_in, "host_get_joints_s": t_out}
         fleet.close()
     r = out["interleaved"]
     achieved = alg / (r["ms_per_step"] * 1e-3) / 1e9
-    return {"workload": f"BASELINE.json config5: {n} mixed-morphology robots (legs x dof, gait) = {list(CONFIG5_BINS)}, instance i -> bin i mod 5, "
+    return {"workload": f"BASELINE.json config5: {n} mixed-morphology robots (legs x dof, gait) = {list(CONFIG5_BINS)}, instance i -> bin i mod {len(CONFIG5_BINS)}, "
                         "binned by shc_fleet_create onto one engine + HIP stream per morphology", "value": r["value"], "unit": "control-cycles/s",
             "steps": steps, "ms_per_step": r["ms_per_step"], "moving_fraction": r["moving_fraction"], "finite": r["finite"],
             "interleaved_vs_binned": out,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "shc_cycle_kernel x 5 morphologies on concurrent streams (wall clock per fleet step, not a single launch)",
+                         "kernel": f"shc_cycle_kernel x {len(CONFIG5_BINS)} morphologies on concurrent streams (wall clock per fleet step, not a single launch)",
                          "algorithmic_bytes_per_launch": alg}}
 
 

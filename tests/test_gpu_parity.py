@@ -238,19 +238,22 @@ def test_config5_interleaved_fleet(Engine):
 
 
 def test_config5_full_size_mixed_fleet(Engine):
-    """configs[4] at its full size: 2^20 robots, five morphologies interleaved instance by instance (4 / 6 / 8 legs, 3 - 5 joints, all
-    four gaits), binned by shc_fleet_create.  Size-independent properties (finite, inside the joint limits, padding slots NaN,
-    identical inputs in two places of the batch -> identical bits) + a 64-robot slice of every bin against the oracle."""
+    """configs[4] at its full size: 2^20 robots, six morphologies interleaved instance by instance (4 / 6 / 8 legs, 3 - 5 joints - one bin
+    whose robots have legs of 3, 5 and 4 joints -, all four gaits), binned by shc_fleet_create.  Size-independent properties (finite,
+    inside the joint limits, padding slots NaN, identical inputs in two places of the batch -> identical bits) + a 64-robot slice of
+    every bin against the oracle."""
+    from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
     from syropod_highlevel_controller_amd.fleet import MixedFleet
-    bins = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"))
-    morphs = [synthetic_octopod_params(g, d, l) for l, d, g in bins]
-    n, horizon, m, dup = 1 << 20, 60, 64, 5 * 128
-    mid = np.arange(n) % len(morphs)
+    bins = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"), (6, (3, 5, 4, 3, 5, 4), "ripple"))
+    morphs = [synthetic_mixed_dof_params(g, d) if isinstance(d, tuple) else synthetic_octopod_params(g, d, l) for l, d, g in bins]
+    B = len(morphs)
+    n, horizon, m, dup = 1 << 20, 60, 64, B * 128
+    mid = np.arange(n) % B
     rng = np.random.default_rng(0x5EED5)
     lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
     src = np.arange(dup)                                   # identical inputs in two places of the batch: the first `dup` robots are
-    shift = (mid[n - dup] - mid[0]) % 5                    # copied to the last `dup` slots, each onto a slot of ITS OWN morphology
-    dst = n - dup + ((src + (5 - shift)) % dup)            # (2^20 is not a multiple of 5)
+    shift = (mid[n - dup] - mid[0]) % B                    # copied to the last `dup` slots, each onto a slot of ITS OWN morphology
+    dst = n - dup + ((src + (B - shift)) % dup)            # (2^20 is not a multiple of the number of bins)
     lin[dst], ang[dst] = lin[src], ang[src]
     assert (mid[src] == mid[dst]).all()
     fleet = MixedFleet(morphs, mid)
@@ -261,19 +264,26 @@ def test_config5_full_size_mixed_fleet(Engine):
     ws = fleet.walk_state()
     for k, (legs, dof, gait) in enumerate(bins):
         p = morphs[k]
+        dofs = dof if isinstance(dof, tuple) else (dof,) * legs
+        top = max(dofs)
         idx = np.nonzero(mid == k)[0]
         qk = q[idx]
-        assert np.isfinite(qk[:, :legs, :dof]).all() and np.isfinite(qd[idx][:, :legs, :dof]).all()
-        assert np.isnan(qk[:, legs:, :]).all() and np.isnan(qk[:, :, dof:]).all()
-        jmin = np.array([[p.joint[l][j].min for j in range(dof)] for l in range(legs)])
-        jmax = np.array([[p.joint[l][j].max for j in range(dof)] for l in range(legs)])
-        assert (qk[:, :legs, :dof] >= jmin - 1e-12).all() and (qk[:, :legs, :dof] <= jmax + 1e-12).all()
+        assert np.isfinite(qk[:, :legs, :top]).all() and np.isfinite(qd[idx][:, :legs, :top]).all()
+        assert np.isnan(qk[:, legs:, :]).all() and np.isnan(qk[:, :, top:]).all()
         sl = idx[:m]
         ob = OracleBatch(p, m)
         ob.set_velocity(lin[sl], ang[sl])
         ob.step(horizon, 8)
-        d = np.abs(q[sl][:, :legs, :dof] - ob.joints()[0].reshape(m, legs, dof)).max()
-        assert d <= TOL_Q, (bins[k], d)
+        qo, at, worst = ob.joints()[0], 0, 0.0
+        for l in range(legs):                              # (the oracle packs each leg's own joint count)
+            d_l = dofs[l]
+            jmin = np.array([p.joint[l][j].min for j in range(d_l)])
+            jmax = np.array([p.joint[l][j].max for j in range(d_l)])
+            assert (qk[:, l, :d_l] >= jmin - 1e-12).all() and (qk[:, l, :d_l] <= jmax + 1e-12).all()
+            assert (qk[:, l, d_l:top] == 0.0).all()        # a shorter leg's padded joints
+            worst = max(worst, float(np.abs(q[sl][:, l, :d_l] - qo[:, at:at + d_l]).max()))
+            at += d_l
+        assert worst <= TOL_Q, (bins[k], worst)
         assert np.array_equal(ws[sl], ob.body_state()[2])
     a, b = q[src], q[dst]
     assert np.array_equal(np.nan_to_num(a, nan=-7.0), np.nan_to_num(b, nan=-7.0)) and np.array_equal(ws[src], ws[dst])
