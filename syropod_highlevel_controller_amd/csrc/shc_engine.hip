@@ -2224,6 +2224,7 @@ static SeqParams seq_params(const shc_engine *e) {
   P.have_adm = e->params.admittance_control;
   P.gravity_aligned = e->cp.gravity_aligned;
   P.inclination_posing = e->params.inclination_posing;
+  P.gravity_aligned_tips = e->params.gravity_aligned_tips;
   P.pose_pass = e->params.imu_posing || e->params.auto_posing || e->params.inclination_posing;
   P.poser_tip_kept = e->params.auto_posing && !e->params.imu_posing;
   return P;
@@ -2275,9 +2276,7 @@ static int ensure_manual(shc_engine *e, bool planner = false) {
   const shc_params &p = e->params;
   if (e->cp.tip_align)
     return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with the tip-align pose (gravity_aligned_tips on <= 3-DOF legs)");
-  if (planner) { // (transitionStance would read Model::estimateGravity for the target rotation, pose_controller.cpp:786-790)
-    if (p.gravity_aligned_tips) return fail(SHC_ERR_UNSUPPORTED, "planner mode with gravity_aligned_tips");
-  } else if (p.leg_manipulation_mode != SHC_MANIPULATION_TIP_CONTROL) {
+  if (!planner && p.leg_manipulation_mode != SHC_MANIPULATION_TIP_CONTROL) {
     // joint_control hands the FK tip pose WITH its rotation to the stepper (walk_controller.cpp:688-689), which makes the following
     // applyIK rotation-constrained on 3-DOF legs: outside the accelerated path
     return fail(SHC_ERR_UNSUPPORTED, "leg_manipulation_mode joint_control");

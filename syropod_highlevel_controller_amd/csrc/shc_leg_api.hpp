@@ -227,6 +227,7 @@ __global__ void leg_apply_fk_kernel(DevState st, const SharedConsts<L_, NJ> *gc,
 // Bezier curves from where the leg was when the sequence started (origin_tip_pose_) to the target (with an optional lift)
 // while the body pose eases from the identity to target_pose; the result is LegPoser::current_tip_pose_, which the callers
 // hand to Leg::setDesiredTipPose + applyIK (stepToNewStance :521, poseForLegManipulation :561, directStartup :463).
+constexpr double kUndefinedPosition = 2147483647.0; // UNDEFINED_POSITION = double(INT_MAX) per component (standard_includes.h:57)
 template <int NJ>
 __device__ __forceinline__ int step_to_position_dev(const DevState &st, const LegIO<NJ> &io, const LegConst<NJ> &lc, const double *target7, const Pose &body,
                                                     double lift_height, double time_to_step, int apply_delta, int have_adm, double dt, Pose &out_pose,
@@ -275,7 +276,9 @@ __device__ __forceinline__ int step_to_position_dev(const DevState &st, const Le
     prim[2].z += lift_height, prim[3].z += lift_height, prim[4].z += lift_height;
     sec[0].z += lift_height, sec[1].z += lift_height, sec[2].z += lift_height;
     const int sic = (count + (num - 1)) % num + 1;
-    const V3 np = sic <= half ? quartic_bezier(prim, sic * delta_t * 2.0) : quartic_bezier(sec, (sic - half) * delta_t * 2.0);
+    V3 np = origin; // a target whose position is UNDEFINED_POSITION (transitionStance with gravity-aligned tips and no tip target): stay (:1637-1638)
+    if (desired.x != kUndefinedPosition || desired.y != kUndefinedPosition || desired.z != kUndefinedPosition)
+      np = sic <= half ? quartic_bezier(prim, sic * delta_t * 2.0) : quartic_bezier(sec, (sic - half) * delta_t * 2.0);
     out.p = inverse_transform_vector(eased, np);
     if (leg_state == LS_MANUAL) { // a MANUAL leg keeps the tip pose updateStance gave its LegPoser: the stepper's own (:1680-1684, pose_controller.cpp:134-137)
       out.p = io.get3(FD::TIP);

@@ -45,6 +45,7 @@ struct SeqParams {
   double target_rotation[4]; // LegStepper::target_tip_pose_.rotation_ while the robot has not walked: the identity tip rotation
                              // (walk_controller.cpp:37-41), UNDEFINED_ROTATION (zeros) without gravity-aligned tips
   int clamp_vel, clamp_pos, tip_force, have_adm, gravity_aligned, inclination_posing;
+  int gravity_aligned_tips; // params.gravity_aligned_tips (transitionStance's target rotation)
   int pose_pass;      // the body pose moves while a robot stands (IMU / auto / inclination posing): LOOP_MARK / LOOP_AFTER_POSE below
   int poser_tip_kept; // the cycle kernels store every LegPoser tip (auto posing without IMU posing: the per-leg auto pose is not re-derivable)
 };
@@ -406,12 +407,20 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
         const int ls = leg_state_of(st, rob, l);
         if (s.poser_tip_from_plan && ls != LS_MANUAL) { // (stepToPosition leaves a MANUAL leg's LegPoser tip alone, :1680-1684)
           for (int k = 0; k < 7; ++k) tip[k] = s.leg[l].current[k];
-        } else if (P.pose_pass) { // the LegPoser's tip of the last updateStance (kept as state: the pose has moved since)
-          put_pose7(tip, io.get3(FD::POSER_TIP), Quat{0, 0, 0, 0});
-        } else if (ls == LS_MANUAL || ls == LS_WALKING_TO_MANUAL) {
-          put_pose7(tip, io.get3(FD::TIP), Quat{0, 0, 0, 0}); // updateStance hands manually manipulated legs the stepper's tip as it is (:134-137)
         } else {
-          put_pose7(tip, inverse_transform_vector(current_pose, io.get3(FD::TIP)), Quat{0, 0, 0, 0}); // updateStance (pose_controller.cpp:122-131)
+          const bool manual = ls == LS_MANUAL || ls == LS_WALKING_TO_MANUAL;
+          // ... and its rotation with gravity-aligned tips: pose.rotation^-1 * the walker's tip rotation where that is defined (:129-130)
+          Quat rotation{0, 0, 0, 0};
+          if (P.gravity_aligned && NJ > 3 && (st.legi[io.slot] & LW_ROTDEF)) {
+            const V3 walker_dir = io.get3(FD::CUR_DIR);
+            rotation = from_two_vectors(V3{1, 0, 0}, manual ? walker_dir : rotate(inverse(current_pose.r), walker_dir));
+          }
+          if (P.pose_pass) // the LegPoser's tip of the last updateStance (kept as state: the pose has moved since)
+            put_pose7(tip, io.get3(FD::POSER_TIP), rotation);
+          else if (manual) // updateStance hands manually manipulated legs the stepper's tip as it is (:134-137)
+            put_pose7(tip, io.get3(FD::TIP), rotation);
+          else             // updateStance (pose_controller.cpp:122-131)
+            put_pose7(tip, inverse_transform_vector(current_pose, io.get3(FD::TIP)), rotation);
         }
         set_desired_dev<NJ>(st, io, L, rob, tip, 1, P.have_adm, 0);
         apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);
@@ -439,7 +448,7 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
           const LegIO<NJ> io{st, slot_of(rob, l, L)};
           auto xf = [&](int field) -> double & { return st.ext[leg_field_index(field, io.slot, st.n_slots)]; };
           const bool defined = st.ext != nullptr && (int(xf(X::P_FLAGS)) & 1) != 0;
-          double target[7], clearance = 0.0;
+          double target[7] = {kUndefinedPosition, kUndefinedPosition, kUndefinedPosition, 0.0, 0.0, 0.0, 0.0}, clearance = 0.0; // Pose::Undefined()
           if (defined) { // target.transform_.addPose(target.pose_) (:781)
             const Pose tr{V3{xf(X::P_TRANSFORM), xf(X::P_TRANSFORM + 1), xf(X::P_TRANSFORM + 2)},
                           Quat{xf(X::P_TRANSFORM + 3), xf(X::P_TRANSFORM + 4), xf(X::P_TRANSFORM + 5), xf(X::P_TRANSFORM + 6)}};
@@ -447,8 +456,22 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
             put_pose7(target, transform_vector(tr, V3{xf(X::P_POSE), xf(X::P_POSE + 1), xf(X::P_POSE + 2)}), tr.r * pr);
             clearance = xf(X::P_CLEARANCE);
           }
+          // "Update target rotation if gravity alignment is set" (:786-790): FromTwoVectors(UnitX, Model::estimateGravity())
+          bool gravity_rotation = false;
+          if (P.gravity_aligned_tips && target[3] == 0.0 && target[4] == 0.0 && target[5] == 0.0 && target[6] == 0.0) {
+            constexpr int rpw = 64 / L;
+            const Quat imu{st.robd[rob_index(rob, R::IMUQ, rpw, R::COUNT)], st.robd[rob_index(rob, R::IMUQ + 1, rpw, R::COUNT)],
+                           st.robd[rob_index(rob, R::IMUQ + 2, rpw, R::COUNT)], st.robd[rob_index(rob, R::IMUQ + 3, rpw, R::COUNT)]};
+            const V3 e = quat_to_euler(imu, false); // Model::estimateGravity (model.cpp:156-165)
+            V3 gv{0, 0, kGravity};
+            gv = rotate(angle_axis_y(-e.y), gv);
+            gv = rotate(angle_axis_x(-e.x), gv);
+            const Quat r = from_two_vectors(V3{1, 0, 0}, gv);
+            target[3] = r.w, target[4] = r.x, target[5] = r.y, target[6] = r.z;
+            gravity_rotation = true;
+          }
           Pose tip;
-          const int p = step_to_position_dev<NJ>(st, io, gc->leg[l], defined ? target : nullptr, body, clearance, kPlanTransitionTime, 1, P.have_adm, P.dt, tip, leg_state_of(st, rob, l));
+          const int p = step_to_position_dev<NJ>(st, io, gc->leg[l], (defined || gravity_rotation) ? target : nullptr, body, clearance, kPlanTransitionTime, 1, P.have_adm, P.dt, tip, leg_state_of(st, rob, l));
           put_pose7(s.leg[l].current, tip);
           set_desired_dev<NJ>(st, io, L, rob, s.leg[l].current, 1, P.have_adm, 0);
           apply_ik_dev<NJ>(st, io, gc->leg[l], 0, P.dt, P.clamp_vel, P.clamp_pos, P.tip_force, P.force_gain);

@@ -15,7 +15,7 @@ WAITING, WALKING = -2, -1
 
 
 @pytest.mark.parametrize("case", ["hexapod", "hexapod-admittance", "8x4", "hexapod-rough-terrain", "hexapod-37-robots",
-                                  "hexapod-imu-posing-admittance", "hexapod-auto-and-inclination-posing-37-robots"])
+                                  "hexapod-imu-posing-admittance", "hexapod-auto-and-inclination-posing-37-robots", "8x5-gravity-aligned"])
 def test_plan_steps_against_the_oracle(case):
     """Walk; switch planner mode on: robots still walking are stopped by the call itself (result -1, their loop is the normal
     cycle) while the ones that stand already wait for plan step 0 (result -2, Model::updateModel only); a joint-configuration step
@@ -27,6 +27,9 @@ def test_plan_steps_against_the_oracle(case):
     RT_POSE_MARKED); the IMU reading changes every 15 calls."""
     if case == "8x4":
         p = synthetic_octopod_params("ripple", 4, 8)
+    elif case.startswith("8x5"):   # gravity-aligned tips: transitionStance turns every tip towards Model::estimateGravity (pose_controller.cpp:786-790)
+        p = synthetic_octopod_params("ripple", 5, 8)
+        p.gravity_aligned_tips = 1
     else:
         p = default_hexapod_params("tripod")
     if "admittance" in case:
