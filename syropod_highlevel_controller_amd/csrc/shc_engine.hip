@@ -2647,20 +2647,21 @@ struct AuxHeader {
   uint32_t magic;   // 'SHCA'
   uint16_t version; // layout version of this blob
   uint8_t legs, dof;
-  uint32_t flags;   // 1: manual-leg record live, 2: external target records live, 4: sequence / planner record live
+  uint32_t flags;   // 1: manual-leg record live, 2: external target records live, 4: sequence / planner record live,
+                    // 8: the LegPoser tips are state (plan calls under time-dependent posing since the last control cycle)
   int32_t reset_mode; // PoseController::pose_reset_mode_ (RobotFields::I_RESET_MODE: written by the toggle kernel, read by the cycle)
 };
 constexpr uint32_t kAuxMagic = 0x41434853u;
-constexpr uint16_t kAuxVersion = 1;
-static size_t aux_leg_doubles(int NJ) { // per leg: ExtFields record + leg fields [DES_TIP, COUNT)
+constexpr uint16_t kAuxVersion = 2; // 2: + the LegPoser tip positions (POSER_TIP) and flag 8
+static size_t aux_leg_doubles(int NJ) { // per leg: ExtFields record + leg fields [DES_TIP, COUNT) + the LegPoser tip position
   const int tail = NJ == 3 ? Fields<3>::COUNT - Fields<3>::DES_TIP : (NJ == 4 ? Fields<4>::COUNT - Fields<4>::DES_TIP : Fields<5>::COUNT - Fields<5>::DES_TIP);
-  return size_t(ExtFields::COUNT) + size_t(tail);
+  return size_t(ExtFields::COUNT) + size_t(tail) + 3;
 }
 static size_t aux_bytes(const shc_engine *e) {
   return sizeof(AuxHeader) + sizeof(ManualRobot) + sizeof(SeqRobotState) + size_t(e->L) * aux_leg_doubles(e->NJ) * 8;
 }
 __global__ void aux_state_kernel(unsigned char *blobs, size_t stride, DevState st, SeqRobotState *seq, int L, int NJ, int des_tip_field, int n_leg_fields, int64_t first,
-                                 int64_t count, int to_engine, uint32_t live_flags) {
+                                 int64_t count, int to_engine, uint32_t live_flags, int poser_tip_field) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= count) return;
   const int64_t rob = first + t;
@@ -2670,7 +2671,7 @@ __global__ void aux_state_kernel(unsigned char *blobs, size_t stride, DevState s
   SeqRobotState *q = reinterpret_cast<SeqRobotState *>(b + sizeof(AuxHeader) + sizeof(ManualRobot));
   double *legs = reinterpret_cast<double *>(b + sizeof(AuxHeader) + sizeof(ManualRobot) + sizeof(SeqRobotState));
   const int tail = n_leg_fields - des_tip_field;
-  const int per_leg = ExtFields::COUNT + tail;
+  const int per_leg = ExtFields::COUNT + tail + 3;
   int32_t &reset_mode = st.robi[rob_index(rob, RobotFields::I_RESET_MODE, 64 / L, RobotFields::I_COUNT)];
   if (!to_engine) {
     h->magic = kAuxMagic, h->version = kAuxVersion, h->legs = uint8_t(L), h->dof = uint8_t(NJ), h->flags = live_flags, h->reset_mode = reset_mode;
@@ -2701,6 +2702,11 @@ __global__ void aux_state_kernel(unsigned char *blobs, size_t stride, DevState s
       if (!to_engine) row[ExtFields::COUNT + f] = x;
       else x = row[ExtFields::COUNT + f];
     }
+    for (int f = 0; f < 3; ++f) { // LegPoser::current_tip_pose_.position_ (state while flag 8 holds, an output otherwise)
+      double &x = st.legd[leg_field_index(poser_tip_field + f, slot, st.n_slots)];
+      if (!to_engine) row[ExtFields::COUNT + tail + f] = x;
+      else if (h->flags & 8) x = row[ExtFields::COUNT + tail + f];
+    }
   }
 }
 extern "C" int64_t shc_engine_aux_state_bytes(const shc_engine *e) { return e ? int64_t(aux_bytes(e)) : 0; }
@@ -2729,13 +2735,15 @@ static int aux_state(shc_engine *e, int64_t first, int64_t count, void *blobs, i
     if (rc != SHC_OK) return rc;
     if (want & 1) e->rt_flags |= RT_MANUAL_LEGS | RT_MANUAL_LIVE;
     if (want & 2) e->rt_flags |= RT_EXTERNAL;
+    e->plan_poser_tips_current = (want & 8) != 0; // (engine-wide, like the control cycles that clear it)
   }
   unsigned char *d = nullptr;
   HIP_TRY(hipMalloc(&d, stride * size_t(count)));
   if (to_engine) HIP_TRY_OR(hipMemcpyAsync(d, blobs, stride * size_t(count), hipMemcpyHostToDevice, e->stream), (void)hipFree(d));
-  const uint32_t live = (e->st.manual && (e->rt_flags & RT_MANUAL_LEGS) ? 1u : 0u) | (e->st.ext ? 2u : 0u) | (e->d_seq ? 4u : 0u);
+  const uint32_t live = (e->st.manual && (e->rt_flags & RT_MANUAL_LEGS) ? 1u : 0u) | (e->st.ext ? 2u : 0u) | (e->d_seq ? 4u : 0u) |
+                        (e->plan_poser_tips_current ? 8u : 0u);
   aux_state_kernel<<<dim3((unsigned)((count + 127) / 128)), dim3(128), 0, e->stream>>>(d, stride, e->st, e->d_seq, e->L, e->NJ, LEG_FIELD(e, DES_TIP), e->n_leg_fields,
-                                                                                   first, count, to_engine, live);
+                                                                                   first, count, to_engine, live, LEG_FIELD(e, POSER_TIP));
   HIP_TRY_OR(hipGetLastError(), (void)hipFree(d));
   if (!to_engine) HIP_TRY_OR(hipMemcpyAsync(blobs, d, stride * size_t(count), hipMemcpyDeviceToHost, e->stream), (void)hipFree(d));
   HIP_TRY_OR(hipStreamSynchronize(e->stream), (void)hipFree(d));

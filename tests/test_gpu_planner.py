@@ -364,3 +364,58 @@ def test_plan_steps_free_running():
         o.set_velocity(lin, ang + 0.2)
         o.step(80) if o is eng else o.step(80, 1)
     assert np.array_equal(eng.body_state()[2], ob.body_state()[2])
+
+
+def test_checkpoint_in_the_middle_of_a_plan_under_imu_posing():
+    """Under time-dependent posing the LegPoser tips a waiting robot keeps from its last updateStance are engine state (the pose has
+    moved on since): state record + auxiliary blob taken in the middle of planner mode restore into a fresh engine that goes on byte
+    for byte."""
+    from scipy.spatial.transform import Rotation as R
+    p = default_hexapod_params("tripod")
+    p.imu_posing, p.admittance_control = 1, 1
+    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    n, L = 10, p.leg_count
+    rng = np.random.default_rng(12)
+
+    def imu_reading():
+        e = np.stack([rng.uniform(-0.12, 0.12, n), rng.uniform(-0.12, 0.12, n), rng.uniform(-1, 1, n)], axis=1)
+        q = R.from_euler("xyz", e).as_quat()
+        return np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1), rng.normal(0, 0.03, (n, 3))
+
+    a = BatchEngine(p, n)
+    a.set_velocity(rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-0.5, 0.5, n))
+    a.set_tip_force(np.full((n, L, 3), 1.5))
+    a.set_imu(*imu_reading())
+    a.step(80)
+    a.set_planner_mode(True)
+    for _ in range(600):
+        pr, _ = a.execute_plan()
+        if (pr == WAITING).all():
+            break
+    assert (pr == WAITING).all()
+    a.set_imu(*imu_reading())
+    for _ in range(5):
+        a.execute_plan()
+    state, aux = a.get_state(), a.get_aux_state()
+    readings = [imu_reading() for _ in range(3)]
+    cfg = a.joints()[0].reshape(n, L, -1) + rng.uniform(-0.1, 0.1, (n, L, 3))
+
+    def go_on(e):
+        e.set_tip_force(np.full((n, L, 3), 1.5))
+        out = []
+        for k, rd in enumerate(readings):
+            e.set_imu(*rd)
+            if k == 1:
+                e.set_target_configuration(cfg)
+            for _ in range(12):
+                out.append(e.execute_plan())
+        return bytes(memoryview(e.get_state()).cast("B")), out
+
+    ref = go_on(a)
+    b = BatchEngine(p, n)
+    b.set_planner_mode(True)
+    b.set_state(state)
+    b.set_aux_state(aux)
+    got = go_on(b)
+    assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(ref[1], got[1]))
+    assert ref[0] == got[0]
