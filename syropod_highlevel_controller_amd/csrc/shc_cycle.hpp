@@ -437,94 +437,20 @@ __device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const Cycl
   rb.put(R::ODOM + 3, ow * sh + oz * ch);
 }
 
-// AdmittanceController::updateAdmittance (admittance_controller.cpp:22-61) + Leg::setAdmittanceDelta (model.h:365-368) of one leg:
-// touches only the admittance state, the tip-force estimate and the tip axis of the last FK - state of the model half.
-template <int NJ, typename IN>
-__device__ __forceinline__ void cycle_admittance(LegRegs<NJ> &s, LegOut &out, const CycleParams &P, const IN &in) {
-  const V3 force_in = in.force(); // tip_force_measured_
-  V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
-  double fi[3] = {f.x, f.y, f.z}, d[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    double u = fmax(fi[i], 0.0);
-    double x0 = P.adm_m00 * s.adm0 + P.adm_m01 * s.adm1 + P.adm_g0 * u;
-    double x1 = P.adm_m10 * s.adm0 + P.adm_m11 * s.adm1 + P.adm_g1 * u;
-    s.adm0 = x0;
-    s.adm1 = x1;
-    d[i] = clampd(-x0, -0.2, 0.2); // ADMITTANCE_DEADBAND == 0: delta passes through unchanged
-  }
-  // Leg::setAdmittanceDelta (model.h:365-368): projection on the tip's x axis (robot frame) of the current FK
-  out.adm_delta = projection(V3{d[0], d[1], d[2]}, s.tipx);
-}
-
-// The walker / poser half of a cycle: updateCurrentPose, updateStiffness, (ADM_HERE: updateAdmittance,) updateWalk with the
-// LegSteppers, updateStance.  Leaves out.poser_tip (and fb) for the model half.
-template <int L, int NJ, unsigned F, bool ADM_HERE, typename IN, bool ODOM_HERE = true>
-__device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
-                                            const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
-                                            const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
-                                            FrontToBack &fb, const double *span = nullptr) {
+// PoseController::updateCurrentPose (pose_controller.cpp:811-859): walk-plane pose, manual / inclination / IMU / auto / tip-align pose
+// composed into Model::current_pose_ (returned, and left in the robot tile's CPOSE; the walk-plane pose in WPP).  `lw`: the packed
+// words of the robot's legs as the previous cycle's updateWalk left them.  The kernels call it inside cycle_front; the two-wavefront
+// resident kernel runs it on the model wavefront for the specialisations without auto posing (POSE_HERE = false there).
+template <int L, int NJ, unsigned F>
+__device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L, NJ> &C, const CycleParams &P, const LegConst<NJ> &lc, const RobTile<64 / L> &rb,
+                                           const Group<L> g, const int (&lw)[L], int &rword, const int walk_state, unsigned &dirty, const bool manual_live,
+                                           Pose &auto_pose, Pose &leg_auto, const V3 plane_prev, const V3 pnorm_prev) {
+  // (plane_prev / pnorm_prev: the steppers' copy of the walk plane, RobotFields::PLANE_PREV / PNORM_PREV, as the previous updateWalk left it)
   using R = RobotFields;
   using FT = Feat<F>;
-  // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
-  // every one of their ~90 loads out of the n_cycles loop and pins ~180 VGPRs for the whole launch (measured: 556 B of
-  // scratch per lane, 2x the launch time).  An opaque zero in the address keeps each load next to its use.
-  int zero = 0;
-  asm volatile("" : "+v"(zero));
-  const CycleParams &P = (&C.P)[zero];
-  const LegConst<NJ> &lc = C.leg[leg + zero];
   const V3 UZ{0, 0, 1};
-  // gravity-aligned tips: only legs with more than 3 joints constrain the tip rotation (walk_controller.cpp:37, :1197);
-  // its own kernel specialisation (F_ROT), launched when the parameter is set
-  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
-  bool rot_def = (s.word & LW_ROTDEF) != 0;
-  bool targ_rot = (s.word & LW_TARGROT) != 0; // LegStepper::target_tip_pose_.rotation_ defined
-  fb.odom_run = false;
-  SHC_TICK(2);
-
-  int rword = rb.geti(R::I_WORD);
-  int walk_state = rword & 3;
-  // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611).  Their only
-  //      readers are the STOPPING branches (walk FSM :599-619, updateAutoPose :1147-1150), and a robot is STOPPING in this cycle
-  //      only if it already was or if it is MOVING without a command (:533-536): skipped while no robot of the wave can be.
-  bool may_stop = walk_state == WS_STOPPING;
-  if (walk_state == WS_MOVING) { // (a conservative test of "no command": anything that could round to a zero norm counts)
-    const double ax = fabs(rb.get(R::VIN)), ay = fabs(rb.get(R::VIN + 1)), aw = rb.get(R::WIN);
-    may_stop = !(aw != 0.0 || ax > 1e-100 || ay > 1e-100);
-  }
-  s.word &= ~(LW_ZBV | LW_ATT);
-  if (!(SHC_DBG(P) & 128) && __any(may_stop)) {
-    int w = s.word;
-    if (dot(s.strd, s.strd) == 0.0) w |= LW_ZBV;
-    const V3 pnp = rb.get3(R::PNORM_PREV);
-    V3 err = s.tip - s.targ;
-    // rejection from the exact unit normal (0, 0, 1) is (x, y, z - z): skip the projection's division on flat ground
-    if (__all(pnp.x == 0.0 && pnp.y == 0.0 && pnp.z == 1.0)) err.z = 0.0;
-    else err = rejection(err, pnp);
-    if (dot(err, err) < kTipTolerance * kTipTolerance) w |= LW_ATT;
-    s.word = w;
-  }
-  int lw[L];
-#pragma unroll
-  for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
-
-  SHC_PHASE_FENCE();
-  SHC_TICK(3);
-  // Manual leg manipulation: while any leg of the robot is not WALKING, updateWalk returns before it touches velocities, walk
-  // state or steppers (walk_controller.cpp:492-505)
-  int my_leg_state = LS_WALKING;
-  bool frozen = false;
-  if ((F & F_MLEGS) != 0 && mr != nullptr) {
-    my_leg_state = mr->leg_state[leg];
-#pragma unroll
-    for (int j = 0; j < L; ++j) frozen = frozen || g.get(my_leg_state, j) != LS_WALKING;
-  }
-
-  // =============================================================== PoseController::updateCurrentPose (:811-859)
   Pose cp; // Model::current_pose_
-  Pose auto_pose = pose_identity();
-  Pose leg_auto = pose_identity();
-  if (!(SHC_DBG(P) & 1)) {
+  {
     // ---- updateWalkPlanePose (:1092-1130)
     Pose wpp;
     {
@@ -558,8 +484,8 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
           }
         }
       }
-      V3 wplane = sel ? rb.get3(R::PLANE_PREV) : V3{0, 0, 0};
-      V3 wnorm = sel ? rb.get3(R::PNORM_PREV) : UZ;
+      V3 wplane = sel ? plane_prev : V3{0, 0, 0};
+      V3 wnorm = sel ? pnorm_prev : UZ;
       Pose owpp = rb.getpose(R::OWPP);
       // Flat ground (the walk-plane normal is exactly +z and the body is not tilted): FromTwoVectors(z, z) is exactly the
       // identity and slerp(identity, c, identity) takes Eigen's linear branch, so the result below is bit-identical to the
@@ -789,7 +715,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       chain_from_sincos<NJ>(lc, s.sn, s.cs, ch0); // the last applyFK: tip and last joint in the robot frame
       const V3 t2j_own = base_rotate(lc, ch0.p[NJ - 1] - ch0.pe);
       Pose ta = rb.getpose(R::TALIGN), ota = rb.getpose(R::OTALIGN);
-      const V3 n = rb.get3(R::PNORM_PREV); // leg_stepper->getWalkPlaneNormal(): the copy taken by last cycle's updateStride
+      const V3 n = pnorm_prev; // leg_stepper->getWalkPlaneNormal(): the copy taken by last cycle's updateStride
       const Quat wrot = from_two_vectors(UZ, n);
 #pragma unroll
       for (int j = 0; j < L; ++j) {
@@ -821,7 +747,104 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       cp = add_pose(cp, ta);
     }
     rb.putpose(R::CPOSE, cp);
-  } else {
+  }
+  return cp;
+}
+
+// AdmittanceController::updateAdmittance (admittance_controller.cpp:22-61) + Leg::setAdmittanceDelta (model.h:365-368) of one leg:
+// touches only the admittance state, the tip-force estimate and the tip axis of the last FK - state of the model half.
+template <int NJ, typename IN>
+__device__ __forceinline__ void cycle_admittance(LegRegs<NJ> &s, LegOut &out, const CycleParams &P, const IN &in) {
+  const V3 force_in = in.force(); // tip_force_measured_
+  V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
+  double fi[3] = {f.x, f.y, f.z}, d[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double u = fmax(fi[i], 0.0);
+    double x0 = P.adm_m00 * s.adm0 + P.adm_m01 * s.adm1 + P.adm_g0 * u;
+    double x1 = P.adm_m10 * s.adm0 + P.adm_m11 * s.adm1 + P.adm_g1 * u;
+    s.adm0 = x0;
+    s.adm1 = x1;
+    d[i] = clampd(-x0, -0.2, 0.2); // ADMITTANCE_DEADBAND == 0: delta passes through unchanged
+  }
+  // Leg::setAdmittanceDelta (model.h:365-368): projection on the tip's x axis (robot frame) of the current FK
+  out.adm_delta = projection(V3{d[0], d[1], d[2]}, s.tipx);
+}
+
+// The walker / poser half of a cycle: updateCurrentPose, updateStiffness, (ADM_HERE: updateAdmittance,) updateWalk with the
+// LegSteppers, updateStance.  Leaves out.poser_tip (and fb) for the model half.
+template <int L, int NJ, unsigned F, bool ADM_HERE, typename IN, bool ODOM_HERE = true, bool POSE_HERE = true, typename POSEWAIT = NoHook>
+__device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C, const RobTile<64 / L> &rb, const Park &pk,
+                                            const Group<L> g, int leg, const double *__restrict__ legd, int64_t ns, uint32_t slot, unsigned &dirty,
+                                            const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
+                                            FrontToBack &fb, const double *span = nullptr, const POSEWAIT &pose_wait = POSEWAIT()) {
+  using R = RobotFields;
+  using FT = Feat<F>;
+  // POSE_HERE = false: PoseController::updateCurrentPose of this cycle runs on another wavefront (cycle_pose); pose_wait() returns once
+  // Model::current_pose_ (CPOSE) and the walk-plane pose (WPP) of this cycle are in the robot tile.  Only for specialisations whose
+  // pose does not feed back into updateWalk (no auto posing: its pose state gates the STOPPING -> STOPPED transition).
+  static_assert(POSE_HERE || ((F & F_DYN) == 0 && (F & F_AUTO) == 0 && (F & F_TERRAIN) == 0), "the pose can run elsewhere only without auto posing / terrain paths");
+  // The parameter block and the per-leg records are loop-invariant LDS data: addressed directly, the IR-level LICM hoists
+  // every one of their ~90 loads out of the n_cycles loop and pins ~180 VGPRs for the whole launch (measured: 556 B of
+  // scratch per lane, 2x the launch time).  An opaque zero in the address keeps each load next to its use.
+  int zero = 0;
+  asm volatile("" : "+v"(zero));
+  const CycleParams &P = (&C.P)[zero];
+  const LegConst<NJ> &lc = C.leg[leg + zero];
+  const V3 UZ{0, 0, 1};
+  // gravity-aligned tips: only legs with more than 3 joints constrain the tip rotation (walk_controller.cpp:37, :1197);
+  // its own kernel specialisation (F_ROT), launched when the parameter is set
+  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
+  bool rot_def = (s.word & LW_ROTDEF) != 0;
+  bool targ_rot = (s.word & LW_TARGROT) != 0; // LegStepper::target_tip_pose_.rotation_ defined
+  fb.odom_run = false;
+  SHC_TICK(2);
+
+  int rword = rb.geti(R::I_WORD);
+  int walk_state = rword & 3;
+  // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611).  Their only
+  //      readers are the STOPPING branches (walk FSM :599-619, updateAutoPose :1147-1150), and a robot is STOPPING in this cycle
+  //      only if it already was or if it is MOVING without a command (:533-536): skipped while no robot of the wave can be.
+  bool may_stop = walk_state == WS_STOPPING;
+  if (walk_state == WS_MOVING) { // (a conservative test of "no command": anything that could round to a zero norm counts)
+    const double ax = fabs(rb.get(R::VIN)), ay = fabs(rb.get(R::VIN + 1)), aw = rb.get(R::WIN);
+    may_stop = !(aw != 0.0 || ax > 1e-100 || ay > 1e-100);
+  }
+  s.word &= ~(LW_ZBV | LW_ATT);
+  if (!(SHC_DBG(P) & 128) && __any(may_stop)) {
+    int w = s.word;
+    if (dot(s.strd, s.strd) == 0.0) w |= LW_ZBV;
+    const V3 pnp = rb.get3(R::PNORM_PREV);
+    V3 err = s.tip - s.targ;
+    // rejection from the exact unit normal (0, 0, 1) is (x, y, z - z): skip the projection's division on flat ground
+    if (__all(pnp.x == 0.0 && pnp.y == 0.0 && pnp.z == 1.0)) err.z = 0.0;
+    else err = rejection(err, pnp);
+    if (dot(err, err) < kTipTolerance * kTipTolerance) w |= LW_ATT;
+    s.word = w;
+  }
+  int lw[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
+
+  SHC_PHASE_FENCE();
+  SHC_TICK(3);
+  // Manual leg manipulation: while any leg of the robot is not WALKING, updateWalk returns before it touches velocities, walk
+  // state or steppers (walk_controller.cpp:492-505)
+  int my_leg_state = LS_WALKING;
+  bool frozen = false;
+  if ((F & F_MLEGS) != 0 && mr != nullptr) {
+    my_leg_state = mr->leg_state[leg];
+#pragma unroll
+    for (int j = 0; j < L; ++j) frozen = frozen || g.get(my_leg_state, j) != LS_WALKING;
+  }
+
+  // =============================================================== PoseController::updateCurrentPose (:811-859)
+  Pose cp; // Model::current_pose_
+  Pose auto_pose = pose_identity();
+  Pose leg_auto = pose_identity();
+  if (POSE_HERE && !(SHC_DBG(P) & 1)) {
+    cp = cycle_pose<L, NJ, F>(s, C, P, lc, rb, g, lw, rword, walk_state, dirty, manual_live, auto_pose, leg_auto, rb.get3(R::PLANE_PREV), rb.get3(R::PNORM_PREV));
+  } else if (POSE_HERE) {
     cp = rb.getpose(R::CPOSE);
   }
   SHC_PHASE_FENCE();
@@ -1020,6 +1043,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     // ---- LegStepper::updateDefaultTipPosition (:984-1014) on the STOPPING -> FORCE_STOP edge (rare)
     if (__any(my_update_default)) {
       if (my_update_default) {
+        if (!POSE_HERE) pose_wait();
         Pose wpp = rb.getpose(R::WPP); // leg_->getDefaultBodyPose() == walk_plane_pose_
         // identity + stance span change (single-plane workspace: a constant; layered workspace: from the default tip's current height)
         const double span_y = ((F & F_ROUGH) != 0 && span != nullptr) ? stance_span_change_y(span, leg, pk.get3(PK_DFLT).z) : lc.span_shift;
@@ -1181,6 +1205,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       s.tvel = dpos * P.inv_dt; // delta_pos / time_delta (:1135, :1176)
       if (rough && __any(rough_update_default)) { // LegStepper::updateDefaultTipPosition at the start of a swing / stance period
         if (rough_update_default) { // (the stepper's walk-plane copy was refreshed by updateStride just before: the current plane)
+          if (!POSE_HERE) pose_wait();
           Pose wpp = rb.getpose(R::WPP);
           const double span_y = span != nullptr ? stance_span_change_y(span, leg, pk.get3(PK_DFLT).z) : 0.0; // calculateStanceSpanChange (:996-997)
           V3 idp = transform_vector(wpp, V3{lc.stance_x, lc.stance_y + span_y, 0.0});
@@ -1312,6 +1337,10 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // =============================================================== PoseController::updateStance (:110-141)
   V3 desired_dir{1, 0, 0}; // x axis of the desired tip rotation (body frame) when rot_def
   {
+    if (!POSE_HERE) {
+      pose_wait();
+      cp = rb.getpose(R::CPOSE);
+    }
     Pose bp = cp;
     if (FT::autop(P) && !FT::imu(P)) {
       bp = remove_pose(bp, auto_pose);

@@ -257,7 +257,8 @@ __device__ __forceinline__ void ring_to_tile(const double *rec, double *tile_at,
 
 // What was posted for cycle c (header words h0, h1; anything but tag c + 1 = nothing posted, inputs held): fresh robot inputs go
 // to the LDS tile (ROBOT), the per-leg inputs are read where they lie - only their ring position is noted (LEG).
-template <int RPW, bool ROBOT, bool LEG>
+enum : int { ROBOT_NONE = 0, ROBOT_VEL = 1, ROBOT_POSE = 2, ROBOT_ALL = 3 }; // which per-robot input groups a wave copies into the tile
+template <int RPW, int ROBOT, bool LEG>
 __device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, const unsigned c, const u64 h0, const u64 h1, const int64_t wave, const int lane,
                                                      double *tile, int32_t *tile_i, unsigned &dirty, ResidentHeld &held) {
   using R = RobotFields;
@@ -265,20 +266,20 @@ __device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, cons
   const unsigned mask = unsigned(h1) & 0xffffu;
   held.seen |= mask;
   auto pos = [&](int grp) { return int((h1 >> (16 + 8 * grp)) & 0xff); };
-  if (ROBOT) {
-    if (mask & (1u << RG_VEL))
+  if (ROBOT != ROBOT_NONE) {
+    if ((ROBOT & ROBOT_VEL) && (mask & (1u << RG_VEL)))
       ring_to_tile<RPW, 3>(A.rin + ((int64_t(pos(RG_VEL)) * A.n_waves + wave) * RIN_COUNT + RIN_VEL) * RPW, tile + R::VIN * RPW, lane);
-    if (mask & (1u << RG_IMU)) {
+    if ((ROBOT & ROBOT_POSE) && (mask & (1u << RG_IMU))) {
       const double *rec = A.rin + ((int64_t(pos(RG_IMU)) * A.n_waves + wave) * RIN_COUNT + RIN_IMU) * RPW;
       ring_to_tile<RPW, 4>(rec, tile + R::IMUQ * RPW, lane);
       ring_to_tile<RPW, 3>(rec + 4 * RPW, tile + R::GYRO * RPW, lane);
     }
-    if (mask & (1u << RG_POSE)) {
+    if ((ROBOT & ROBOT_POSE) && (mask & (1u << RG_POSE))) {
       static_assert(R::RVI == R::TVI + 3, "pose inputs are contiguous in the tile");
       ring_to_tile<RPW, 6>(A.rin + ((int64_t(pos(RG_POSE)) * A.n_waves + wave) * RIN_COUNT + RIN_POSE) * RPW, tile + R::TVI * RPW, lane);
       dirty |= DIRTY_MANUAL;
     }
-    if (mask & (1u << RG_RESET)) {
+    if ((ROBOT & ROBOT_POSE) && (mask & (1u << RG_RESET))) {
       if (lane < RPW)
         tile_i[R::I_RESET_MODE * RPW + lane] = int(unsigned(ld_agent(reinterpret_cast<const u64 *>(A.rini) + ((int64_t(pos(RG_RESET)) * A.n_waves + wave) * RPW + lane))));
       dirty |= DIRTY_MANUAL;
@@ -344,7 +345,7 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
       n0v = ld_agent(hp);
       n1v = ld_agent(hp + 1);
     }
-    resident_take_inputs<64 / L, true, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held);
+    resident_take_inputs<64 / L, ROBOT_ALL, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held);
     const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
                            held.src_effort < 0 ? st.legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2,
                            ns, slot};
@@ -736,8 +737,12 @@ __global__ void __launch_bounds__(64, SHC_WAVES_PER_SIMD) shc_resident_kernel(De
 enum : int { IT_REAL = 1, IT_BUBBLE = 2, IT_EXIT = 3 };
 template <int L, int NJ>
 struct Resident2Lds { // dynamic LDS of one workgroup, after the two walker waves' tiles
-  double mailbox[2][2][7][64]; // [pair][cycle parity][field][lane]: PoseController::updateStance -> Leg::setDesiredTipPose (xyz), then the
-                               // desired body velocity (x, y, yaw rate) + whether the walker reached its odometry update
+  double mailbox[2][2][13][64]; // [pair][cycle parity][field][lane]: PoseController::updateStance -> Leg::setDesiredTipPose (xyz), then the
+                                // desired body velocity (x, y, yaw rate) + whether the walker reached its odometry update; 7..12: the steppers'
+                                // walk plane / normal for the NEXT cycle's updateWalkPlanePose (pose on the model wave)
+  int words[2][2][64];          // walker -> model: the packed leg words updateWalk left, for the next cycle's pose
+  unsigned pose_done[2];        // model -> walker: poses completed (current_pose_ / walk-plane pose of that cycle are in the tile)
+  unsigned model_dirty[2], model_seen[2]; // model -> walker at exit: tile groups its pose dirtied, input groups it received
   double stiff[2][64];         // walker -> model at exit (published virtual stiffness shares a plane with the admittance delta)
   int ikfail[2][64];           // model -> walker at exit (IK-deviation flag lives in the leg word)
   unsigned long long ctrl[4][4]; // [iteration & 3]: kind, h0, h1, -
@@ -807,6 +812,12 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
     X.ctrl[0][0] = IT_BUBBLE;
     X.ctrl[0][1] = X.ctrl[0][2] = 0;
   }
+  // PoseController::updateCurrentPose runs on the MODEL wavefront where its result does not feed back into updateWalk (no auto posing): it
+  // reads what the walker left one iteration earlier (leg words, the steppers' walk plane: mailbox) and the pose inputs, and the walker
+  // picks Model::current_pose_ up from the tile when it reaches updateStance - the walker's critical path loses the pose, the model
+  // wavefront's idle half fills up.
+  constexpr bool POSE_SPLIT = (F & (F_DYN | F_AUTO)) == 0;
+  if (POSE_SPLIT && walker && lane == 0) X.pose_done[pair] = 0;
   __syncthreads();
   const CycleParams &P = C.P;
   Group<L> g{grp * L};
@@ -830,6 +841,13 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   }
   unsigned dirty = 0;
   ResidentHeld held;
+  const auto publish_for_pose = [&](unsigned cycle) { // what PoseController::updateCurrentPose of `cycle` reads of the walker's state
+    double *mb = &X.mailbox[pair][cycle & 1][0][lane];
+    const V3 pp = rb.get3(R::PLANE_PREV), pn = rb.get3(R::PNORM_PREV);
+    mb[7 * 64] = pp.x, mb[8 * 64] = pp.y, mb[9 * 64] = pp.z, mb[10 * 64] = pn.x, mb[11 * 64] = pn.y, mb[12 * 64] = pn.z;
+    X.words[pair][cycle & 1][lane] = s.word;
+  };
+  if (POSE_SPLIT && walker && active) publish_for_pose(0); // (iteration 0 is a bubble: its closing barrier comes before any pose)
   const int64_t ns = st.n_slots;
   const unsigned out_slot_bytes = unsigned(NJ * ns * 16);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
@@ -880,10 +898,28 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       }
       SHC_TICK(20);
       if (kind == IT_REAL && active) {
-        resident_take_inputs<RPW, true, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
+        resident_take_inputs<RPW, POSE_SPLIT ? ROBOT_VEL : ROBOT_ALL, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
         SHC_TICK(21);
-        cycle_front<L, NJ, F, false, LegInRing<NJ>, false>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
-                                                           LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb);
+        const auto pose_wait = [&]() { // Model::current_pose_ / walk_plane_pose_ of this cycle are in the tile once the model wavefront says so
+          volatile unsigned *flag = &X.pose_done[pair];
+          unsigned spins = 0;
+          u64 t0 = 0;
+          while (*flag != c_front + 1) { // (bounded like every other device-side wait: 1 s, then the loop reports a fault)
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 4095u) == 0) {
+              const u64 now = wall_clock64();
+              if (t0 == 0) t0 = now;
+              else if (now - t0 > 100000000ull) {
+                held.fault = true;
+                break;
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        cycle_front<L, NJ, F, false, LegInRing<NJ>, false, !POSE_SPLIT>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
+                                                                        LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb, nullptr, pose_wait);
+        if (POSE_SPLIT) publish_for_pose(c_front + 1);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
         if (FT::odom(P)) // the odometry accumulator is the model wavefront's: it has the time, nothing here reads it back
@@ -897,8 +933,23 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       }
       SHC_TICK(23);
     } else if (active) {
+      if (POSE_SPLIT && kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
+        resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
+        const int my_word = X.words[pair][c_front & 1][lane];
+        int lw[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) lw[j] = g.get(my_word, j);
+        const double *mb = &X.mailbox[pair][c_front & 1][0][lane];
+        const V3 plane_prev{mb[7 * 64], mb[8 * 64], mb[9 * 64]}, pnorm_prev{mb[10 * 64], mb[11 * 64], mb[12 * 64]};
+        int rword_unused = 0;
+        Pose ap = pose_identity(), la = pose_identity();
+        (void)cycle_pose<L, NJ, F>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *const_cast<volatile unsigned *>(&X.pose_done[pair]) = c_front + 1;
+      }
       if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
-        resident_take_inputs<RPW, false, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held);
+        resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held);
         const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
                                held.src_effort < 0 ? st.legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2,
                                ns, slot};
@@ -960,12 +1011,23 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #endif
   // ---- epilogue: the halves exchange what the other one stores, then each writes its half of the state back
   if (active) {
-    if (walker) X.stiff[pair][lane] = s.stiff;
-    else X.ikfail[pair][lane] = s.word & LW_IKFAIL;
+    if (walker) {
+      X.stiff[pair][lane] = s.stiff;
+    } else {
+      X.ikfail[pair][lane] = s.word & LW_IKFAIL;
+      if (POSE_SPLIT) { // what the pose on this wavefront dirtied / received is written back by the walker, which owns the tile stores
+        unsigned d = 0;
+#pragma unroll
+        for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
+          if (__any((dirty & b) != 0)) d |= b;
+        if (lane == 0) X.model_dirty[pair] = d, X.model_seen[pair] = held.seen;
+      }
+    }
   }
   __syncthreads();
   if (!active) return;
   if (walker) {
+    if (POSE_SPLIT) dirty |= X.model_dirty[pair], held.seen |= X.model_seen[pair];
     if (c_front > 0) s.word = (s.word & ~LW_IKFAIL) | X.ikfail[pair][lane];
     {
       unsigned d = 0;

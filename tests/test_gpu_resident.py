@@ -61,7 +61,7 @@ def force_sample(rng, n, legs):
 
 
 @pytest.mark.parametrize("waves", ["two_waves", "one_wave"])
-@pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4"])
+@pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4", "config2_body_posing", "config3_body_posing_inclination"])
 def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves):
     """Every cycle gets new inputs.  Engine A: set_* + shc_engine_step(1) per cycle.  Engine B: one resident launch, inputs posted per
     cycle.  q / qd of EVERY cycle (output ring) and the complete state record at the end are equal byte for byte - for the
@@ -70,6 +70,11 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
     rng = np.random.default_rng(11)
     if case == "config2":
         p, n = default_hexapod_params("tripod"), 333
+    elif case == "config2_body_posing":   # joystick body posing: pose inputs and reset modes change while the loop runs (the pose runs on the model wavefront)
+        p, n = default_hexapod_params("tripod"), 171
+    elif case == "config3_body_posing_inclination":
+        p, n = config3_params(), 93
+        p.inclination_posing = 1
     elif case == "config3":
         p, n = config3_params(), 250
     elif case == "octopod":
@@ -78,9 +83,16 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
         p, n = synthetic_octopod_params("amble", 4, 4), 130
     cycles, depth = 260, 8
     sched = velocity_schedule(rng, n, cycles)
-    imus = [imu_sample(rng, n) for _ in range(cycles)] if case == "config3" else None
-    forces = [force_sample(rng, n, p.leg_count) if c % 3 == 0 else None for c in range(cycles)] if case == "config3" else None
+    imus = [imu_sample(rng, n) for _ in range(cycles)] if case.startswith("config3") else None
+    forces = [force_sample(rng, n, p.leg_count) if c % 3 == 0 else None for c in range(cycles)] if case.startswith("config3") else None
+    posing = "body_posing" in case
+    pose_in = [(rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.7), rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.7)) if c % 4 == 0 else None
+               for c in range(cycles)] if posing else None
+    resets = [rng.integers(0, 6, n).astype(np.int32) if c % 37 == 5 else (np.zeros(n, dtype=np.int32) if c % 37 == 11 else None) for c in range(cycles)] if posing else None
     a, b = Engine(p, n), Engine(p, n)
+    if posing:
+        for e in (a, b):   # (the manual-pose group of the state is live from the first pose input on)
+            e.set_pose_input(np.zeros((n, 3)), np.zeros((n, 3)))
     if waves == "one_wave":
         b.set_features(FEAT_DEFAULT | FEAT_RESIDENT_ONE_WAVE)
     for e in (a, b):   # some history before the resident run starts
@@ -93,6 +105,11 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
             a.set_imu(*imus[c])
             if forces[c] is not None:
                 a.set_tip_force(forces[c])
+        if posing:
+            if pose_in[c] is not None:
+                a.set_pose_input(*pose_in[c])
+            if resets[c] is not None:
+                a.set_pose_reset_mode(resets[c])
         a.step(1)
         qa.append(a.joints())
     a.synchronize()
@@ -107,6 +124,11 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
                 kw["imu"] = imus[c]
                 if forces[c] is not None:
                     kw["tip_force"] = forces[c]
+            if posing:
+                if pose_in[c] is not None:
+                    kw["pose_input"] = pose_in[c]
+                if resets[c] is not None:
+                    kw["pose_reset_mode"] = resets[c]
             assert b.resident_post(**kw) == c
         b.resident_publish(c1 - c0)
         b.resident_wait(c1)
