@@ -410,6 +410,7 @@ struct FrontToBack {
   V3 desired_dir;   // x axis of the desired tip rotation (body frame) when rot_def
   bool rot_def;
   int my_leg_state; // LegState of this leg (manual leg manipulation)
+  bool plane_prev_changed; // out: the steppers' walk-plane copy (PLANE_PREV / PNORM_PREV) was rewritten this cycle (wave-uniform)
   bool pose_only;   // in: stop after the posing part of the loop (state_controller.cpp:165-181) - a robot that stands while a leg toggle / plan step runs
   V3 odom_vel;      // desired linear (x, y) / angular (z) body velocity of this cycle and whether updateWalk reached its odometry
   bool odom_run;    //   update (cycle_front<..., ODOM_HERE = false>: the caller runs odometry_step elsewhere)
@@ -798,6 +799,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   bool rot_def = (s.word & LW_ROTDEF) != 0;
   bool targ_rot = (s.word & LW_TARGROT) != 0; // LegStepper::target_tip_pose_.rotation_ defined
   fb.odom_run = false;
+  fb.plane_prev_changed = false;
   SHC_TICK(2);
 
   int rword = rb.geti(R::I_WORD);
@@ -901,7 +903,12 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   SHC_PHASE_FENCE();
   SHC_TICK(5);
   double vx = rb.get(R::VLIN), vy = rb.get(R::VLIN + 1), vw = rb.get(R::VANG);
-  const double lin_norm = sqrt(vin_x * vin_x + vin_y * vin_y);
+  // |linear input|.  Throttle mode only ever asks "> 1" and "!= 0" of it: while no robot of the wave has n2 > 1 (sqrt(n2) <= 1 then, the
+  // correctly rounded square root being monotone with sqrt(1) = 1) a stand-in with the same two answers saves the FP64 square root.
+  const double lin_n2 = vin_x * vin_x + vin_y * vin_y;
+  double lin_norm;
+  if (uni(P.velocity_input_mode) == 0 && __all(lin_n2 <= 1.0)) lin_norm = lin_n2 != 0.0 ? 0.5 : 0.0;
+  else lin_norm = sqrt(lin_n2);
   if (!(SHC_DBG(P) & 32)) {
     double nvx, nvy, nw;
     if (uni(P.velocity_input_mode) == 0) { // throttle (:451-466)
@@ -926,7 +933,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     // acceleration-limited approach (:508-527)
     const double ax = nvx - vx, ay = nvy - vy;
     const double an2 = ax * ax + ay * ay;
-    const double an = sqrt(an2);
+    const double an = __all(an2 == 0.0) ? 0.0 : sqrt(an2); // (every robot already at its target velocity: sqrt(0) = 0)
     const double cap = lim[2] * P.dt;
     if (__all(an < cap)) { // every robot of the wave reaches its target this cycle (the steady state)
       vx += ax;
@@ -1267,6 +1274,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
         rb.put3(R::PLANE_PREV, pl);
         rb.put3(R::PNORM_PREV, pn_);
         dirty |= DIRTY_WALK_PLANE;
+        fb.plane_prev_changed = true;
       }
     }
     if (__any(default_changed)) {

@@ -742,7 +742,7 @@ struct Resident2Lds { // dynamic LDS of one workgroup, after the two walker wave
                                 // walk plane / normal for the NEXT cycle's updateWalkPlanePose (pose on the model wave)
   int words[2][2][64];          // walker -> model: the packed leg words updateWalk left, for the next cycle's pose
   unsigned pose_done[2];        // model -> walker: poses completed (current_pose_ / walk-plane pose of that cycle are in the tile)
-  unsigned model_dirty[2], model_seen[2]; // model -> walker at exit: tile groups its pose dirtied, input groups it received
+  unsigned model_dirty[2], model_seen[2], model_fault[2]; // model -> walker at exit: tile groups its pose dirtied, input groups it received, fault
   double stiff[2][64];         // walker -> model at exit (published virtual stiffness shares a plane with the admittance delta)
   int ikfail[2][64];           // model -> walker at exit (IK-deviation flag lives in the leg word)
   unsigned long long ctrl[4][4]; // [iteration & 3]: kind, h0, h1, -
@@ -767,7 +767,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   const int lane = threadIdx.x & 63;
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = wib & 1;
-  const bool walker = wib < 2, leader = wib == 0;
+  const bool walker = wib < 2, leader = wib == 2; // the model wavefront of pair 0 decides what the next iteration is: it has the time to spare
   const int64_t wave = (int64_t(blockIdx.x) - 1) * 2 + pair;
   const bool active = wave < A.n_waves;
   const int64_t rob0 = wave * RPW;
@@ -841,13 +841,20 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   }
   unsigned dirty = 0;
   ResidentHeld held;
-  const auto publish_for_pose = [&](unsigned cycle) { // what PoseController::updateCurrentPose of `cycle` reads of the walker's state
-    double *mb = &X.mailbox[pair][cycle & 1][0][lane];
-    const V3 pp = rb.get3(R::PLANE_PREV), pn = rb.get3(R::PNORM_PREV);
-    mb[7 * 64] = pp.x, mb[8 * 64] = pp.y, mb[9 * 64] = pp.z, mb[10 * 64] = pn.x, mb[11 * 64] = pn.y, mb[12 * 64] = pn.z;
+  // what PoseController::updateCurrentPose of `cycle` reads of the walker's state: the leg words, and the steppers' walk-plane copy - which
+  // changes on rare events only (a default tip moved), so both parities of its mailbox slots are rewritten then and left alone otherwise
+  const auto publish_for_pose = [&](unsigned cycle, bool planes) {
+    if (planes) {
+      const V3 pp = rb.get3(R::PLANE_PREV), pn = rb.get3(R::PNORM_PREV);
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        double *mb = &X.mailbox[pair][par][0][lane];
+        mb[7 * 64] = pp.x, mb[8 * 64] = pp.y, mb[9 * 64] = pp.z, mb[10 * 64] = pn.x, mb[11 * 64] = pn.y, mb[12 * 64] = pn.z;
+      }
+    }
     X.words[pair][cycle & 1][lane] = s.word;
   };
-  if (POSE_SPLIT && walker && active) publish_for_pose(0); // (iteration 0 is a bubble: its closing barrier comes before any pose)
+  if (POSE_SPLIT && walker && active) publish_for_pose(0, true); // (iteration 0 is a bubble: its closing barrier comes before any pose)
   const int64_t ns = st.n_slots;
   const unsigned out_slot_bytes = unsigned(NJ * ns * 16);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
@@ -868,34 +875,34 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #endif
     const int kind = __builtin_amdgcn_readfirstlane(int(X.ctrl[k & 3][0]));
     const u64 h0 = uni64(X.ctrl[k & 3][1]), h1 = uni64(X.ctrl[k & 3][2]);
-    if (walker) {
-      int nk = IT_EXIT;
-      u64 nh0v = 0, nh1v = 0;
-      if (leader && kind != IT_EXIT) { // what will iteration k + 1 be?
-        u64 gate;
-        if (kind == IT_BUBBLE) {
-          __builtin_amdgcn_s_sleep(2);
-          gate = uni64(ld_agent(&A.ctl->gate)); // nothing else to do: look again
-        } else {
-          gate = uni64(gate_pref); // read one iteration ago: at worst the loop learns of a release one iteration late
-        }
-        const unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
-        const unsigned cn = c_front + (kind == IT_REAL ? 1u : 0u); // the cycle iteration k + 1 would start
-        nk = cn >= sp ? IT_EXIT : (cn < db ? IT_REAL : IT_BUBBLE);
-        if (nk == IT_BUBBLE) {
-          const u64 now = wall_clock64();
-          if (bubble_since == 0) bubble_since = now;
-          else if (now - bubble_since > emergency_ticks) nk = IT_EXIT, held.fault = true;
-        } else {
-          bubble_since = 0;
-        }
-        if (nk == IT_REAL) {
-          const u64 *hp = reinterpret_cast<const u64 *>(A.headers + (cn & (kResidentHeaders - 1)));
-          nh0v = ld_agent(hp);
-          nh1v = ld_agent(hp + 1);
-        }
-        gate_pref = ld_agent(&A.ctl->gate);
+    int nk = IT_EXIT;
+    u64 nh0v = 0, nh1v = 0;
+    if (leader && kind != IT_EXIT) { // what will iteration k + 1 be?
+      u64 gate;
+      if (kind == IT_BUBBLE) {
+        __builtin_amdgcn_s_sleep(2);
+        gate = uni64(ld_agent(&A.ctl->gate)); // nothing else to do: look again
+      } else {
+        gate = uni64(gate_pref); // read one iteration ago: at worst the loop learns of a release one iteration late
       }
+      const unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
+      const unsigned cn = c_front + (kind == IT_REAL ? 1u : 0u); // the cycle iteration k + 1 would start
+      nk = cn >= sp ? IT_EXIT : (cn < db ? IT_REAL : IT_BUBBLE);
+      if (nk == IT_BUBBLE) {
+        const u64 now = wall_clock64();
+        if (bubble_since == 0) bubble_since = now;
+        else if (now - bubble_since > emergency_ticks) nk = IT_EXIT, held.fault = true;
+      } else {
+        bubble_since = 0;
+      }
+      if (nk == IT_REAL) {
+        const u64 *hp = reinterpret_cast<const u64 *>(A.headers + (cn & (kResidentHeaders - 1)));
+        nh0v = ld_agent(hp);
+        nh1v = ld_agent(hp + 1);
+      }
+      gate_pref = ld_agent(&A.ctl->gate);
+    }
+    if (walker) {
       SHC_TICK(20);
       if (kind == IT_REAL && active) {
         resident_take_inputs<RPW, POSE_SPLIT ? ROBOT_VEL : ROBOT_ALL, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
@@ -919,17 +926,12 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         };
         cycle_front<L, NJ, F, false, LegInRing<NJ>, false, !POSE_SPLIT>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
                                                                         LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb, nullptr, pose_wait);
-        if (POSE_SPLIT) publish_for_pose(c_front + 1);
+        if (POSE_SPLIT) publish_for_pose(c_front + 1, fb.plane_prev_changed);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
         if (FT::odom(P)) // the odometry accumulator is the model wavefront's: it has the time, nothing here reads it back
           mb[192] = fb.odom_vel.x, mb[256] = fb.odom_vel.y, mb[320] = fb.odom_vel.z, mb[384] = fb.odom_run ? 1.0 : 0.0;
         SHC_TICK(22);
-      }
-      if (leader && kind != IT_EXIT && lane == 0) {
-        X.ctrl[(k + 1) & 3][0] = u64(nk);
-        X.ctrl[(k + 1) & 3][1] = nh0v;
-        X.ctrl[(k + 1) & 3][2] = nh1v;
       }
       SHC_TICK(23);
     } else if (active) {
@@ -991,6 +993,11 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         if (lane == 0) st_agent(A.progress + wave, u64(c_back));
       }
     }
+    if (leader && kind != IT_EXIT && lane == 0) { // (the header loads issued at the top of the iteration have long arrived)
+      X.ctrl[(k + 1) & 3][0] = u64(nk);
+      X.ctrl[(k + 1) & 3][1] = nh0v;
+      X.ctrl[(k + 1) & 3][2] = nh1v;
+    }
     if (kind == IT_EXIT) break;
 #ifdef SHC_RES2_TIMING
     if (kind == IT_REAL && prev_real) tm_busy += __builtin_readcyclecounter() - tm0, ++tm_real;
@@ -1022,12 +1029,14 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
           if (__any((dirty & b) != 0)) d |= b;
         if (lane == 0) X.model_dirty[pair] = d, X.model_seen[pair] = held.seen;
       }
+      if (lane == 0) X.model_fault[pair] = held.fault ? 1u : 0u; // (the leader's emergency bound)
     }
   }
   __syncthreads();
   if (!active) return;
   if (walker) {
     if (POSE_SPLIT) dirty |= X.model_dirty[pair], held.seen |= X.model_seen[pair];
+    if (X.model_fault[pair]) held.fault = true;
     if (c_front > 0) s.word = (s.word & ~LW_IKFAIL) | X.ikfail[pair][lane];
     {
       unsigned d = 0;
