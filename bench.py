@@ -260,6 +260,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             resident = False
     res_cycle_s = None
     launch_elapsed = None
+    posted_value = None
     if use_dist:
         gather()
         dist.barrier()
@@ -284,6 +285,21 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             gather()
             torch.cuda.synchronize()
             elapsed += time.perf_counter() - t_after
+        # secondary figure: a NEW velocity command for every robot in every cycle, from arrays resident in HBM (post + doorbell in one launch)
+        posted_value = None
+        if not use_dist:
+            d_lin, d_ang = torch.from_numpy(np.ascontiguousarray(lin)).cuda(), torch.from_numpy(np.ascontiguousarray(ang)).cuda()
+            kk = max(steps, 300)
+            eng.resident_begin(ring_depth=16, max_cycles=kk + 16)
+            for _ in range(10):
+                eng.resident_post(velocity=(d_lin.data_ptr(), d_ang.data_ptr()), on_device=True, publish=True)
+            eng.resident_wait(10)
+            tp = time.perf_counter()
+            for _ in range(kk):
+                eng.resident_post(velocity=(d_lin.data_ptr(), d_ang.data_ptr()), on_device=True, publish=True)
+            eng.resident_wait(10 + kk, 60000)
+            posted_value = n * kk / (time.perf_counter() - tp)
+            eng.resident_end()
         # N = 1: the region closes with shc_engine_resident_wait - every wave has completed the K-th cycle and its joint state is
         # visible (the device-to-host completion handshake).  The loop kernel is still alive at that point, so a stream
         # synchronisation cannot be the closing bracket here; one issued after resident_end would only time an idle device.
@@ -386,6 +402,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                    "mode": ("resident: one launch stays on the chip, a step = one doorbell tick = one control cycle with that cycle's inputs from the "
                             "device-side rings and its q / qd to the output ring") if resident else "one launch of the fused cycle kernel per step",
                    "one_launch_per_cycle_value": (world * n * steps * cps / launch_elapsed) if launch_elapsed else None,
+                   "velocities_posted_every_cycle_value": posted_value,   # resident mode, a new velocity set per robot and cycle from device arrays
                    "legs": p.leg_count, "dof": p.leg_dof[0],
                    "gather": f"all-gather of the joint buffer every {gather_every} steps" if gather_every
                    else "one all-gather of the final joint buffer (N > 1)",

@@ -314,7 +314,8 @@ typedef struct shc_cycle_inputs {
   const double *tip_force;                  /* [n][legs][3]      tip wrench (:1618)                           */
   const double *joint_effort;               /* [n][legs][dof]    joint states (:1566)                         */
   int32_t on_device;                        /* the arrays are device pointers                                 */
-  int32_t reserved;
+  int32_t publish;                          /* != 0: release this cycle (and unpublished cycles before it) as soon as its inputs are in
+                                               place - post + shc_engine_resident_publish(…, 1) in one kernel launch */
 } shc_cycle_inputs;
 enum { SHC_RESIDENT_RUNNING = 0, SHC_RESIDENT_STOPPED = 1, SHC_RESIDENT_IDLE_TIMEOUT = 2, SHC_RESIDENT_MAX_CYCLES = 3, SHC_RESIDENT_FAULT = 4 };
 int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t max_cycles, int idle_timeout_ms);

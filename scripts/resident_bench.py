@@ -38,7 +38,7 @@ print(f"launch per cycle, velocities set from host arrays every cycle : {dt / st
 d_lin, d_ang = torch.from_numpy(lin).cuda(), torch.from_numpy(ang).cuda()
 torch.cuda.synchronize()
 from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE  # noqa: E402
-for mode in ("publish_all", "publish_each", "post_each", "post_each_device", "one_wave publish_each"):
+for mode in ("publish_all", "publish_each", "post_each", "post_each_device", "post_and_publish", "post_and_publish_device", "one_wave publish_each"):
     eng.set_features(FEAT_DEFAULT | (FEAT_RESIDENT_ONE_WAVE if mode.startswith("one_wave") else 0))
     eng.resident_begin(ring_depth=16, max_cycles=steps + 300)
     eng.resident_publish(200)
@@ -49,6 +49,12 @@ for mode in ("publish_all", "publish_each", "post_each", "post_each_device", "on
     elif mode.endswith("publish_each"):
         for _ in range(steps):
             eng.resident_publish(1)
+    elif mode == "post_and_publish":   # ... post and doorbell in ONE kernel launch per cycle (shc_cycle_inputs.publish)
+        for i in range(steps):
+            eng.resident_post(velocity=(lin, ang), publish=True)
+    elif mode == "post_and_publish_device":
+        for i in range(steps):
+            eng.resident_post(velocity=(d_lin.data_ptr(), d_ang.data_ptr()), on_device=True, publish=True)
     elif mode == "post_each_device":   # a new velocity set for every cycle, from arrays resident in HBM
         for i in range(steps):
             eng.resident_post(velocity=(d_lin.data_ptr(), d_ang.data_ptr()), on_device=True)
@@ -60,6 +66,6 @@ for mode in ("publish_all", "publish_each", "post_each", "post_each_device", "on
     eng.resident_wait(200 + steps, 60000)
     dt = time.perf_counter() - t0
     ran = eng.resident_end()
-    print(f"resident {mode:21s}: {dt / steps * 1e6:7.2f} us/cycle  {n * steps / dt:.3e} cycles/s  ({ran} cycles)")
+    print(f"resident {mode:24s}: {dt / steps * 1e6:7.2f} us/cycle  {n * steps / dt:.3e} cycles/s  ({ran} cycles)")
 q, _ = eng.joints()
 print("finite", bool(np.isfinite(q).all()))

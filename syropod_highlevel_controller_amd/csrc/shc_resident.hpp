@@ -25,6 +25,7 @@ struct Resident {
   // host arrays handed to shc_engine_resident_post are copied into a ring of pinned, device-mapped staging slots; the post kernel
   // reads them from there over PCIe, so a post neither copies through a pageable-memory bounce buffer nor synchronises
   static constexpr int kPinSlots = 4;
+  unsigned *post_blocks_done = nullptr; // device counter: the last block of a post-and-publish kernel rings the doorbell
   char *pin = nullptr, *pin_dev = nullptr;
   hipEvent_t pin_ev[kPinSlots] = {};
   unsigned long long pin_uses = 0;
@@ -49,6 +50,9 @@ struct ResidentPost {
   int pos[RG_COUNT];
   unsigned mask;
   unsigned long long cycle;
+  unsigned long long doorbell; // != 0: the last block to finish rings the doorbell with this value (post + publish in one launch)
+  ResidentHost *host;
+  unsigned *blocks_done;       // device counter of that election
 };
 // One posted input set -> the data rings (write-through stores: the resident kernel reads them with agent-scope loads while it
 // runs) + the header of its cycle.  The doorbell moves only after this kernel has completed (stream order).
@@ -105,6 +109,21 @@ __global__ void resident_post_kernel(ResidentPost pp, ResidentArgs A, ResidentHe
     __hip_atomic_store(hp + 1, h1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(hp, pp.cycle + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (pp.doorbell != 0) { // release the cycle once every block's stores are out: the last block to arrive rings the doorbell
+    __shared__ unsigned last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence(); // (the write-through stores above have been issued; the fence orders them before the election below)
+      const unsigned arrived = __hip_atomic_fetch_add(pp.blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      last = arrived == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+      __hip_atomic_store(pp.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the next post on this stream starts from zero)
+      __threadfence_system();
+      __hip_atomic_store(&pp.host->doorbell, pp.doorbell, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 static void resident_free(Resident *r) {
@@ -119,6 +138,7 @@ static void resident_free(Resident *r) {
   (void)hipFree(r->effort);
   (void)hipFree(r->out);
   (void)hipFree(r->stage);
+  (void)hipFree(r->post_blocks_done);
   if (r->pin) (void)hipHostFree(r->pin);
   for (hipEvent_t ev : r->pin_ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -213,6 +233,8 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
     if ((err = hipMalloc(&r->effort, D * (NJE / 2) * e->n_slots * 16)) != hipSuccess) return bail(err, "hipMalloc");
     if ((err = hipMalloc(&r->out, D * out_slot_bytes)) != hipSuccess) return bail(err, "hipMalloc");
     if ((err = hipMalloc(&r->stage, r->stage_bytes)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMalloc(&r->post_blocks_done, 64)) != hipSuccess) return bail(err, "hipMalloc");
+    if ((err = hipMemsetAsync(r->post_blocks_done, 0, 64, e->stream)) != hipSuccess) return bail(err, "hipMemset");
     if ((err = hipHostMalloc(reinterpret_cast<void **>(&r->pin), r->stage_bytes * Resident::kPinSlots, hipHostMallocMapped)) != hipSuccess)
       return bail(err, "hipHostMalloc(input staging)");
     if ((err = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->pin_dev), r->pin, 0)) != hipSuccess) return bail(err, "hipHostGetDevicePointer");
@@ -357,6 +379,14 @@ extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *i
   STAGE(effort, joint_effort, nl * e->NJ * 8)
 #undef STAGE
   const int64_t threads = (mask & ((1u << RG_FORCE) | (1u << RG_EFFORT))) ? int64_t(nl) : int64_t(n);
+  // publish: release this cycle (and any cycles before it that were left unpublished) as soon as its inputs are in place - the post
+  // kernel rings the doorbell itself, one launch instead of two per loop iteration
+  const bool publish = in->publish != 0;
+  if (publish) {
+    pp.doorbell = c + 1;
+    pp.host = r->host_dev;
+    pp.blocks_done = r->post_blocks_done;
+  }
   resident_post_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, r->in_stream>>>(pp, r->args, r->headers, r->rin, r->rini, r->force, r->effort,
                                                                                               e->n, e->L, e->NJ, e->n_slots);
   HIP_TRY(hipGetLastError());
@@ -371,6 +401,7 @@ extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *i
     }
   r->groups_posted |= mask;
   r->posted = c + 1;
+  if (publish) r->published = c + 1;
   r->stream_doorbell_pending = true; // (a post is in flight on in_stream: the doorbell that releases it must follow it there)
   if (cycle) *cycle = int64_t(c);
   return SHC_OK;

@@ -53,7 +53,7 @@ EXPORTED_SYMBOLS = [
 class CycleInputs(C.Structure):
     """shc_cycle_inputs (include/shc_batch.h): what the callbacks of one loop iteration delivered; NULL = not received."""
     _fields_ = [(k, C.c_void_p) for k in ("linear_xy", "angular", "imu_orientation_wxyz", "imu_angular_velocity", "pose_translation_velocity",
-                                           "pose_rotation_velocity", "pose_reset_mode", "tip_force", "joint_effort")] + [("on_device", C.c_int32), ("reserved", C.c_int32)]
+                                           "pose_rotation_velocity", "pose_reset_mode", "tip_force", "joint_effort")] + [("on_device", C.c_int32), ("publish", C.c_int32)]
 
 
 class ShcError(RuntimeError):
@@ -399,7 +399,8 @@ class BatchEngine:
     def resident_begin(self, ring_depth: int = 16, max_cycles: int = 1 << 24, idle_timeout_ms: int = 0):
         _check(self.L.shc_engine_resident_begin(self.h, int(ring_depth), int(max_cycles), int(idle_timeout_ms)), "resident_begin")
 
-    def resident_post(self, velocity=None, imu=None, pose_input=None, pose_reset_mode=None, tip_force=None, joint_effort=None, on_device=False) -> int:
+    def resident_post(self, velocity=None, imu=None, pose_input=None, pose_reset_mode=None, tip_force=None, joint_effort=None, on_device=False,
+                      publish=False) -> int:
         """Inputs of the next unposted cycle: velocity = (linear_xy, angular), imu = (quat_wxyz, gyro), pose_input = (translation
         velocity, rotation velocity); host numpy arrays, or integer device pointers with on_device.  Returns the cycle index."""
         keep = []
@@ -423,6 +424,7 @@ class BatchEngine:
         ci.pose_reset_mode = ptr(pose_reset_mode, np.int32)
         ci.tip_force, ci.joint_effort = ptr(tip_force), ptr(joint_effort)
         ci.on_device = 1 if on_device else 0
+        ci.publish = 1 if publish else 0
         cyc = C.c_int64(-1)
         _check(self.L.shc_engine_resident_post(self.h, C.byref(ci), C.byref(cyc)), "resident_post")
         return int(cyc.value)
