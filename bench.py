@@ -287,7 +287,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             elapsed += time.perf_counter() - t_after
         # secondary figure: a NEW velocity command for every robot in every cycle, from arrays resident in HBM (post + doorbell in one launch)
         posted_value = None
-        if not use_dist:
+        if not use_dist and not os.environ.get("SHC_BENCH_NO_POSTED_PROBE"):   # (profiling runs skip it: one K-cycle launch to attribute counters to)
             d_lin, d_ang = torch.from_numpy(np.ascontiguousarray(lin)).cuda(), torch.from_numpy(np.ascontiguousarray(ang)).cuda()
             kk = max(steps, 300)
             eng.resident_begin(ring_depth=16, max_cycles=kk + 16)

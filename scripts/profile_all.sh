@@ -11,7 +11,7 @@ run() { # name, summary file, traffic key, resident K or "", bench arguments...
   python scripts/summarize_prof.py gpurun_out/prof_$name $S/$out $key $res > /dev/null 2>> $S/$name.log
   rm -rf gpurun_out/prof_$name
 }
-run c2_resident r03_config2_resident_rocprofv3.txt config2:resident:4096:1 resident:4000 --workload config2
+SHC_BENCH_NO_POSTED_PROBE=1 run c2_resident r03_config2_resident_rocprofv3.txt config2:resident:4096:1 resident:4000 --workload config2
 run c2_launch r03_config2_launch_rocprofv3.txt config2:4096:1 launch --workload config2 --mode launch
 run c3 r03_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-joint-efforts
 run c4 r03_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
