@@ -275,7 +275,8 @@ int shc_engine_join(shc_engine *e);
  * Results are bit-identical to the same cycles run through shc_engine_step(e, 1) with the same inputs set in between.
  *
  *   shc_engine_resident_begin(e, ring_depth, max_cycles, idle_timeout_ms)
- *       starts the loop on the engine's stream.  ring_depth (2..255): input sets that may be posted ahead of the cycle that
+ *       starts the loop (on a stream of the engine's own, ordered after everything queued on the engine's stream: the kernel does
+ *       not end by itself, so it must not sit on a stream others use - the legacy default stream least of all).  ring_depth (2..255): input sets that may be posted ahead of the cycle that
  *       consumes them = cycles whose outputs stay readable; max_cycles (1..2^31-2): hard bound of this launch; idle_timeout_ms
  *       (0 = 2 000): the device loop stops by itself when the doorbell has not moved for this long (a host that went away cannot
  *       leave the GPU spinning; every device-side wait is bounded).  SHC_ERR_UNSUPPORTED: the batch does not fit the chip once, or

@@ -30,6 +30,10 @@ struct Resident {
   hipEvent_t pin_ev[kPinSlots] = {};
   unsigned long long pin_uses = 0;
   hipStream_t in_stream = nullptr;
+  // The loop kernel runs on a stream of its own (ordered after the engine's stream at begin, synchronised at end): it never ends by
+  // itself, and on the caller's stream - the legacy default stream in particular - it would block whoever else uses that stream.
+  hipStream_t loop_stream = nullptr;
+  hipEvent_t loop_ev = nullptr;
   unsigned long long published = 0;         // doorbell value
   unsigned long long posted = 0;            // cycles with a header (the next post is for this cycle)
   unsigned long long posts[RG_COUNT] = {};  // sets of each group posted so far (ring write positions)
@@ -109,19 +113,17 @@ __global__ void resident_post_kernel(ResidentPost pp, ResidentArgs A, ResidentHe
     __hip_atomic_store(hp + 1, h1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(hp, pp.cycle + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (pp.doorbell != 0) { // release the cycle once every block's stores are out: the last block to arrive rings the doorbell
-    __shared__ unsigned last;
+  if (pp.doorbell != 0) { // release the cycle once every block's stores are out: the last block to arrive rings the doorbell.
+    // (No LDS here: a resident loop that fills the chip leaves none, and a kernel that asks for any would never be scheduled.)
+    __threadfence(); // this thread's write-through stores are visible device-wide before its block is counted
     __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence(); // (the write-through stores above have been issued; the fence orders them before the election below)
       const unsigned arrived = __hip_atomic_fetch_add(pp.blocks_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      last = arrived == gridDim.x - 1 ? 1u : 0u;
-    }
-    __syncthreads();
-    if (last && threadIdx.x == 0) {
-      __hip_atomic_store(pp.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the next post on this stream starts from zero)
-      __threadfence_system();
-      __hip_atomic_store(&pp.host->doorbell, pp.doorbell, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (arrived == gridDim.x - 1) {
+        __hip_atomic_store(pp.blocks_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the next post on this stream starts from zero)
+        __threadfence_system();
+        __hip_atomic_store(&pp.host->doorbell, pp.doorbell, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -143,6 +145,8 @@ static void resident_free(Resident *r) {
   for (hipEvent_t ev : r->pin_ev)
     if (ev) (void)hipEventDestroy(ev);
   if (r->in_stream) (void)hipStreamDestroy(r->in_stream);
+  if (r->loop_stream) (void)hipStreamDestroy(r->loop_stream);
+  if (r->loop_ev) (void)hipEventDestroy(r->loop_ev);
   delete r;
 }
 
@@ -195,7 +199,11 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
     return fail(SHC_ERR_UNSUPPORTED, "resident mode: this configuration runs on a rough-terrain / manual-leg / tip-rotation kernel, which has no resident form");
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, e->device));
-  const int64_t capacity = int64_t(fit.blocks_per_cu) * prop.multiProcessorCount;
+  // ... less one compute unit's worth per XCD (workgroups are dealt round-robin to the 8 XCDs and placed only inside their own): the loop's
+  // wavefronts hold their registers and LDS for as long as it runs, and the kernels that post inputs, ring the doorbell and read the
+  // output ring (64-thread workgroups without LDS) need somewhere to run next to it on EVERY XCD - measured: with 8 free wave slots on
+  // the chip a post kernel is never scheduled, with ~150 it is
+  const int64_t capacity = int64_t(fit.blocks_per_cu) * (prop.multiProcessorCount - 8);
   if (e->n_waves + 1 > capacity)
     return fail(SHC_ERR_UNSUPPORTED, "resident mode: the batch needs " + std::to_string(e->n_waves + 1) + " co-resident wavefronts, this device holds " +
                                          std::to_string(capacity) + " of this kernel (" + std::to_string(fit.blocks_per_cu) + " per compute unit); use shc_engine_step");
@@ -222,6 +230,8 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
       return bail(err, "hipHostMalloc(ResidentHost)");
     if ((err = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->host_dev), r->host, 0)) != hipSuccess) return bail(err, "hipHostGetDevicePointer");
     if ((err = hipStreamCreateWithFlags(&r->in_stream, hipStreamNonBlocking)) != hipSuccess) return bail(err, "hipStreamCreate");
+    if ((err = hipStreamCreateWithFlags(&r->loop_stream, hipStreamNonBlocking)) != hipSuccess) return bail(err, "hipStreamCreate");
+    if ((err = hipEventCreateWithFlags(&r->loop_ev, hipEventDisableTiming)) != hipSuccess) return bail(err, "hipEventCreate");
     r->stage_bytes = size_t(e->n) * (16 * 8 + 8) + size_t(e->n) * e->L * (3 + e->NJ) * 8 + 256;
     const size_t D = size_t(ring_depth);
     if ((err = hipMalloc(&r->ctl, sizeof(ResidentCtl))) != hipSuccess) return bail(err, "hipMalloc");
@@ -283,7 +293,9 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   // - two robot groups - and the relay get a compute unit of their own; one wavefront per group above that.
   const bool two_wave = fit.two_wave && !(e->features & SHC_FEAT_RESIDENT_ONE_WAVE) && (e->n_waves + 1) / 2 + 1 <= prop.multiProcessorCount;
   r->two_wave = two_wave;
-  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream,
+  HIP_TRY(hipEventRecord(r->loop_ev, e->stream)); // everything the engine's stream holds (state, the buffers set up above) comes first
+  HIP_TRY(hipStreamWaitEvent(r->loop_stream, r->loop_ev, 0));
+  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, r->loop_stream,
                 two_wave ? unsigned((e->n_waves + 1) / 2 + 1) : unsigned(e->n_waves + 1), two_wave ? 256 : 64, 0, &A, nullptr, 0};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
   SHC_DISPATCH(e->L, e->NJ, CALL);
@@ -387,7 +399,7 @@ extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *i
     pp.host = r->host_dev;
     pp.blocks_done = r->post_blocks_done;
   }
-  resident_post_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, r->in_stream>>>(pp, r->args, r->headers, r->rin, r->rini, r->force, r->effort,
+  resident_post_kernel<<<dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, r->in_stream>>>(pp, r->args, r->headers, r->rin, r->rini, r->force, r->effort,
                                                                                               e->n, e->L, e->NJ, e->n_slots);
   HIP_TRY(hipGetLastError());
   if (!in->on_device) { // (the caller's host arrays were copied: they are free again on return)
@@ -460,7 +472,7 @@ extern "C" int shc_engine_resident_get_joint_state(shc_engine *e, int64_t cycle,
     double *dst = which ? qd : q;
     if (!dst) continue;
     double *d = on_device ? dst : r->stage;
-    gather_leg_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, r->in_stream>>>(d, slot, e->n_slots, e->n, e->L, e->NJ,
+    gather_leg_kernel<<<dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, r->in_stream>>>(d, slot, e->n_slots, e->n, e->L, e->NJ,
                                                                                             which ? LEG_FIELD(e, QD) : LEG_FIELD(e, Q));
     HIP_TRY(hipGetLastError());
     if (!on_device) {
@@ -492,7 +504,7 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   host_store(&r->host->doorbell, r->published);
   host_store(&r->host->stop, r->published);
   const bool answered = spin_until([&] { return host_load(&r->host->exited) != 0; }, 30.0);
-  hipError_t err = answered ? hipStreamSynchronize(e->stream) : hipErrorNotReady;
+  hipError_t err = answered ? hipStreamSynchronize(r->loop_stream) : hipErrorNotReady; // (the host has waited: whatever follows on the engine's stream is ordered)
   r->active = false;
 #ifdef SHC_RES2_TIMING
   if (answered && err == hipSuccess) {

@@ -245,3 +245,32 @@ def test_resident_bounds(Engine):
     assert state_bytes(ref) == state_bytes(e)
     e.close()
     ref.close()
+
+
+@pytest.mark.parametrize("n", [5100, 5110, 19830])
+def test_resident_at_the_kernel_boundaries(Engine, n):
+    """5 100 hexapods = 510 robot groups = 255 two-wavefront workgroups + the relay: the largest batch the two-wavefront pipeline takes on
+    256 compute units; 5 110 falls to one wavefront per robot group; 19 830 = 1 983 wavefronts + the relay is the largest batch resident mode
+    takes (two per SIMD, less one compute unit's worth per XCD, which stays free for the kernels that post inputs and read the output ring).  Each runs cycles with inputs changing and ends byte-identical to single launches."""
+    p = default_hexapod_params("tripod")
+    rng = np.random.default_rng(n)
+    a, b = Engine(p, n), Engine(p, n)
+    lin, ang = rng.uniform(-0.7, 0.7, (n, 2)), rng.uniform(-1, 1, n)
+    for e in (a, b):
+        e.set_velocity(lin, ang)
+        e.step(20)
+    sched = [(lin * (1.0 - 0.02 * c), ang * (0.5 + 0.01 * c)) for c in range(30)]
+    for v in sched:        # (first: a loop that fills every wave slot of the chip leaves none for another engine's launches)
+        a.set_velocity(*v)
+        a.step(1)
+    a.synchronize()
+    b.resident_begin(ring_depth=4, max_cycles=64)
+    for v in sched:
+        b.resident_post(velocity=v, publish=True)
+    b.resident_wait(30)
+    q, _ = b.resident_joints(29)
+    assert np.array_equal(q, a.joints()[0])
+    assert b.resident_end() == 30
+    assert state_bytes(a) == state_bytes(b)
+    a.close()
+    b.close()
