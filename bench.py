@@ -474,7 +474,8 @@ def run_config5(n, steps, warmup, seed):
                         "binned by shc_fleet_create onto one engine + HIP stream per morphology", "value": r["value"], "unit": "control-cycles/s",
             "steps": steps, "ms_per_step": r["ms_per_step"], "moving_fraction": r["moving_fraction"], "finite": r["finite"],
             "interleaved_vs_binned": out,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("config5", n, 1),
                          "kernel": f"shc_cycle_kernel x {len(CONFIG5_BINS)} morphologies on concurrent streams (wall clock per fleet step, not a single launch)",
                          "algorithmic_bytes_per_launch": alg}}
 

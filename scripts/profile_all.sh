@@ -17,4 +17,5 @@ run c3 r03_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-j
 run c4 r03_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
 run rough r03_rough_terrain_rocprofv3.txt rough:65536:1 split --workload rough --no-joint-efforts
 run gravity r03_gravity_aligned_rocprofv3.txt gravity:65536:1 split --workload gravity --no-joint-efforts
+PROF_STEPS=100 run c5 r03_config5_rocprofv3.txt config5:1048576:1 fleet --workload config5
 ls -la $S

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R
 want=$1
-grep -E "^(SHC_BENCH_NO_POSTED_PROBE=1 )?run $want " scripts/profile_all.sh > /tmp/profile_one_line.sh
+grep -E "^([A-Z_]+=[0-9]+ )?run $want " scripts/profile_all.sh > /tmp/profile_one_line.sh
 sed -n '/^R=/,/^}/p' scripts/profile_all.sh > /tmp/profile_one_head.sh
 cat /tmp/profile_one_head.sh /tmp/profile_one_line.sh > /tmp/profile_one_run.sh
 bash /tmp/profile_one_run.sh

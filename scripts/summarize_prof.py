@@ -54,8 +54,37 @@ def kernel_stats(dirn, out):
     return med
 
 
+FLEET = False  # argv[4] == "fleet": a step = one launch of EACH morphology bin's kernel on concurrent streams; counters are summed over the bins
+
+
+def pmc_fleet(dirn, kernel, out, label):
+    """fleet step: per kernel specialisation (= morphology bin) the median per-dispatch value (a launch moves the same state whether it
+    runs 1 or 16 fused cycles), summed over the specialisations"""
+    f = newest(f"{dirn}/**/*_counter_collection.csv")
+    res = {}
+    if not f:
+        return res
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if kernel in r["Kernel_Name"]:
+            per[r["Counter_Name"]][r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    out.write(f"\n== rocprofv3 --pmc ({label}): counter, kernel specialisation, dispatches, median - and the sum over the specialisations (one fleet step)\n")
+    for c, names in sorted(per.items()):
+        total = 0.0
+        fewest = min(len(v) for v in names.values())
+        for k, v in sorted(names.items()):
+            bins = max(1, round(len(v) / fewest))   # two bins of the same (legs, longest DOF) run the same kernel: twice the dispatches
+            out.write(f"{c:22s} {k[k.find('<'):k.find('>') + 1]:28s} {len(v):6d} {st.median(v):16.1f}" + (f"  x {bins} bins" if bins > 1 else "") + "\n")
+            total += st.median(v) * bins
+        out.write(f"{c:22s} {'sum over the bins':28s} {'':6s} {total:16.1f}\n")
+        res[c] = total
+    return res
+
+
 def pmc(dirn, kernel, out, label):
     """median per-dispatch value of every counter collected for `kernel` in the newest CSV under dirn"""
+    if FLEET and kernel == KERNEL:
+        return pmc_fleet(dirn, kernel, out, label)
     f = newest(f"{dirn}/**/*_counter_collection.csv")
     res = {}
     if not f:
@@ -84,6 +113,7 @@ if __name__ == "__main__":
         RESIDENT_K = int(sys.argv[4].split(":")[1])
         KERNEL = "shc_resident"
     # large batches: a step is TWO launches (the halves of the batch on two streams, shc_engine_step): per-step bytes = 2 x per launch
+    FLEET = len(sys.argv) > 4 and sys.argv[4] == "fleet"   # (bins that share a device run as single launches: SHC_FEAT_SINGLE_STREAM, shc_fleet.hpp)
     per_step = 2 if len(sys.argv) > 4 and sys.argv[4] == "split" else 1
     out = open(dest, "w")
     dur = kernel_stats(f"{prof}/trace", out)
