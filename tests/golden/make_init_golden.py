@@ -310,7 +310,7 @@ def chain(morphology=None, rough=False, gravity=False, time_to_start=TIME_TO_STA
         workspaces.append(generate_workspace(leg, q, defaults[leg] - body_p, not rough, dt))
     workplanes = [get_workplane(ws, 0.0) for ws in workspaces]          # default shift zero: target height 0
     walkspace = generate_walkspace(defaults, workplanes, overlapping)
-    _CHAINS[key] = dict(q0=np.array(q0), startup_calls=calls, workspaces=workspaces, workplanes=workplanes, walkspace=walkspace, defaults=defaults)
+    _CHAINS[key] = dict(q0=q0, startup_calls=calls, workspaces=workspaces, workplanes=workplanes, walkspace=walkspace, defaults=defaults)
     return _CHAINS[key]
 
 
@@ -341,6 +341,8 @@ CASES = {
     # redundant chains drift along their null space: 100 start-up steps keep two correct implementations within 1e-10 rad
     "octopod_8x5_ripple": ("ripple", "8x5", False, False, 2.0),
     "octopod_8x5_gravity_aligned": ("ripple", "8x5", False, True, 2.0),
+    # legs of 3 / 5 / 4 / 3 / 5 / 4 joints in one robot: every leg is its own chain here (the engine pads the shorter legs instead)
+    "hexapod_mixed_dof": ("ripple", "mixed", False, False, 2.0),
 }
 
 
@@ -348,7 +350,8 @@ def main():
     arrays, meta = {}, {}
     for name, (gait, morphology, rough, gravity, tts) in CASES.items():
         r = init_chain(gait, morphology, rough, tts, gravity=gravity)
-        arrays[name + ".q0"] = r["q0"]
+        top = max(len(q) for q in r["q0"])   # (legs may differ in joint count: padded with NaN)
+        arrays[name + ".q0"] = np.array([list(q) + [np.nan] * (top - len(q)) for q in r["q0"]])
         arrays[name + ".workplane"] = np.array([[wp[b] for b in BEARINGS] for wp in r["workplanes"]])
         arrays[name + ".walkspace"] = np.array(r["walkspace"])
         for k, v in r["limits"].items():

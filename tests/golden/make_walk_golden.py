@@ -859,6 +859,9 @@ def make_params(gait, morphology=None):
     from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
     if morphology == "8x5":   # BASELINE.json config 4's synthetic octopod (8 legs x 5 joints)
         return synthetic_octopod_params(gait, 5, 8)
+    if morphology == "mixed": # a hexapod whose legs have 3 / 5 / 4 / 3 / 5 / 4 joints (Parameters::leg_DOF is per leg)
+        from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
+        return synthetic_mixed_dof_params(gait)
     return default_hexapod_params(gait)
 
 
@@ -915,7 +918,7 @@ def init_chain_of(gait, morphology=None, rough=0, gravity=0):
     if _MI is None:
         _MI = init_chain_module()
     r = _MI.init_chain(gait, morphology, bool(rough), START_UP_TIME, gravity=bool(gravity))
-    return r["q0"], {k: [float(x) for x in v] for k, v in r["limits"].items()}
+    return np.array(r["q0"]), {k: [float(x) for x in v] for k, v in r["limits"].items()}
 
 
 def started_walker(P, gait="tripod"):

@@ -465,16 +465,22 @@ def test_init_chain_golden(name, who):
     from syropod_highlevel_controller_amd import default_hexapod_params, engine, synthetic_octopod_params
     m = INIT_META[name]
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "init_golden.npz"))
-    p = synthetic_octopod_params(m["gait"], 5, 8) if m["morphology"] == "8x5" else default_hexapod_params(m["gait"])
+    if m["morphology"] == "mixed":      # legs of 3 / 5 / 4 / 3 / 5 / 4 joints: the numpy chain and the oracle run every leg with its own joint
+        from syropod_highlevel_controller_amd import synthetic_mixed_dof_params   # count, the product pads the shorter legs behind their tips
+        p = synthetic_mixed_dof_params(m["gait"])
+    else:
+        p = synthetic_octopod_params(m["gait"], 5, 8) if m["morphology"] == "8x5" else default_hexapod_params(m["gait"])
     p.time_to_start, p.rough_terrain_mode, p.gravity_aligned_tips = m["time_to_start"], m["rough_terrain_mode"], m["gravity_aligned_tips"]
-    L, NJ = p.leg_count, p.leg_dof[0]
+    L, NJ = p.leg_count, max(p.leg_dof[l] for l in range(p.leg_count))
     t = OracleRobot(p).tables() if who == "oracle" else engine.generate_tables(p)
     assert list(t.phase_offset)[:L] == m["phase_offset"]
     for k in ("period", "swing_start", "swing_end", "stance_period", "swing_period"):
         assert getattr(t.step, k) == m["step"][k]
     assert t.step.frequency == m["step"]["frequency"]
     q = np.array([[t.default_joint_position[l][j] for j in range(NJ)] for l in range(L)])
-    dq = float(np.abs(q - g[name + ".q0"]).max())
+    gq = g[name + ".q0"]
+    dq = float(np.nanmax(np.abs(q - gq)))                    # (NaN in the fixture: a leg with fewer joints than the longest)
+    assert (q[np.isnan(gq)] == 0.0).all()                    # ... whose padded entries the tables leave at 0
     wp = np.array([[t.workspace_radius[l][b] for b in range(9)] for l in range(L)])
     dwp = float(np.abs(wp - g[name + ".workplane"]).max())
     print(f"init chain {name} ({who}): start-up configuration after {m['startup_calls']} steps |dq| = {dq:.2e} rad, workplane {dwp:.2e} m")
