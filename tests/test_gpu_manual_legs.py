@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("case", ["hexapod-tip-control", "8x4-tip-control", "hexapod-dynamic-stiffness", "8x5-gravity-aligned",
-                                  "hexapod-imu-posing", "hexapod-auto-and-inclination-posing", "hexapod-imu-admittance"])
+                                  "hexapod-imu-posing", "hexapod-auto-and-inclination-posing", "hexapod-imu-admittance", "mixed-dof-354354"])
 def test_toggle_manipulate_and_return(case):
     """Walk; request a leg toggle per robot (different legs, two robots none): robots still walking are told to stop first
     (result -1), then the designated leg goes WALKING -> WALKING_TO_MANUAL -> MANUAL while every leg steps to its manipulation
@@ -29,6 +29,9 @@ def test_toggle_manipulate_and_return(case):
         p.gravity_aligned_tips = 1
     elif case.startswith("8x4"):
         p = synthetic_octopod_params("ripple", 4, 8)
+    elif case.startswith("mixed"):   # legs of 3 / 5 / 4 joints in one robot: the loop-level kernels on padded legs (the oracle runs each leg's own chain)
+        from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
+        p = synthetic_mixed_dof_params("ripple")
     else:
         p = default_hexapod_params("tripod")
     if "stiffness" in case:
@@ -42,14 +45,31 @@ def test_toggle_manipulate_and_return(case):
         p.admittance_control = 1
     posing = p.imu_posing or p.inclination_posing
     n = 8
-    L, D = p.leg_count, p.leg_dof[0]
+    L, D = p.leg_count, max(p.leg_dof[l] for l in range(p.leg_count))
+    dofs = [p.leg_dof[l] for l in range(L)]
     rng = np.random.default_rng(23)
     eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    _oj = ob.joints
+
+    def oracle_joints():   # the oracle packs each leg's own joint count; the engine's arrays are [legs][longest DOF]
+        out = []
+        for a in _oj():
+            pad, at = np.zeros((n, L, D)), 0
+            for l, d in enumerate(dofs):
+                pad[:, l, :d] = a[:, at:at + d]
+                at += d
+            out.append(pad.reshape(n, L * D))
+        return tuple(out)
+    ob.joints = oracle_joints
     lin, ang = rng.uniform(-0.5, 0.5, (n, 2)), rng.uniform(-0.5, 0.5, n)
-    effort = rng.normal(0, 0.4, (n, L * D))
+    effort = rng.normal(0, 0.4, (n, L, D))
+    for l, d in enumerate(dofs):
+        effort[:, l, d:] = 0.0
     for o in (eng, ob):
         o.set_velocity(lin, ang)
-        o.set_joint_effort(effort)
+    eng.set_joint_effort(effort.reshape(n, L * D))
+    ob.set_joint_effort(np.concatenate([effort[:, l, :d] for l, d in enumerate(dofs)], axis=1))
+    for o in (eng, ob):
         if p.admittance_control:
             o.set_tip_force(np.abs(rng.normal(0, 2.0, (n, L, 3))) * 0 + 1.5)
     worst = 0.0

@@ -107,3 +107,27 @@ def test_mixed_dof_rejections():
     p.gravity_aligned_tips = 1      # the reference decides per leg there (> 3 joints: tip rotation, <= 3: tip-align pose)
     with pytest.raises(ShcError):
         BatchEngine(p, 4)
+
+
+def test_mixed_dof_robot_in_resident_mode():
+    """... and in resident mode (the generic two-wavefront loop): byte-identical to single launches with inputs changing every cycle."""
+    p = synthetic_mixed_dof_params("ripple", (3, 5, 4, 3, 5, 4))
+    n = 150
+    rng = np.random.default_rng(9)
+    a, b = BatchEngine(p, n), BatchEngine(p, n)
+    lin, ang = rng.uniform(-0.6, 0.6, (n, 2)), rng.uniform(-0.8, 0.8, n)
+    for e in (a, b):
+        e.set_velocity(lin, ang)
+        e.step(30)
+    sched = [(lin * (1.0 - 0.01 * c), ang * np.cos(0.05 * c)) for c in range(120)]
+    for v in sched:
+        a.set_velocity(*v)
+        a.step(1)
+    a.synchronize()
+    b.resident_begin(ring_depth=8, max_cycles=200)
+    for v in sched:
+        b.resident_post(velocity=v, publish=True)
+    b.resident_wait(len(sched))
+    assert np.array_equal(b.resident_joints(len(sched) - 1)[0], a.joints()[0])
+    assert b.resident_end() == len(sched)
+    assert bytes(memoryview(a.get_state()).cast("B")) == bytes(memoryview(b.get_state()).cast("B"))
