@@ -294,9 +294,9 @@ class OracleBatch:
     # ---- start-up / shut-down sequences, one call per robot like the engine's batched entry points
     def begin_sequence_startup(self, joint_positions=None, per_instance=False):
         p = self.p
-        nl, nd = p.leg_count, p.leg_dof[0]
-        if joint_positions is None:
-            q = np.array([[p.joint[l][j].unpacked for j in range(nd)] for l in range(nl)], dtype=np.float64).ravel()
+        nl = p.leg_count
+        if joint_positions is None:   # (packed leg by leg: the legs of a robot may differ in joint count)
+            q = np.array([p.joint[l][j].unpacked for l in range(nl) for j in range(p.leg_dof[l])], dtype=np.float64)
             rows = [q] * self.n
         else:
             a = np.ascontiguousarray(joint_positions, dtype=np.float64)

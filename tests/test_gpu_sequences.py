@@ -139,7 +139,7 @@ def test_transition_configuration(Engine):
 
 
 @pytest.mark.parametrize("forced", [True, False], ids=["teacher-forced", "free-running"])
-@pytest.mark.parametrize("case", ["hexapod-tripod", "6x4-ripple", "8x5-ripple", "hexapod-perturbed-joints"])
+@pytest.mark.parametrize("case", ["hexapod-tripod", "6x4-ripple", "8x5-ripple", "hexapod-perturbed-joints", "mixed-dof-354354"])
 def test_execute_sequence_start_up_shut_down_start_up(case, forced):
     """PoseController::executeSequence (pose_controller.cpp:145-459), every call compared with the oracle: the first START_UP
     from the READY configuration generates the sequence (horizontal / vertical transitions until the default stance is
@@ -161,12 +161,31 @@ def test_execute_sequence_start_up_shut_down_start_up(case, forced):
         p = synthetic_octopod_params("ripple", 4, 6)
     elif case == "8x5-ripple":
         p = synthetic_octopod_params("ripple", 5, 8)
+    elif case.startswith("mixed"):   # legs of 3 / 5 / 4 joints in one robot (the engine pads the shorter legs, the oracle runs each leg's own chain)
+        from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
+        p = synthetic_mixed_dof_params("ripple")
+        if not forced:
+            pytest.skip("redundant chains drift along their null space free-running (covered by 8x5-ripple)")
     else:
         p = default_hexapod_params("tripod")
     n = 6
-    L, D = p.leg_count, p.leg_dof[0]
-    ready = np.array([[p.joint[l][j].unpacked for j in range(D)] for l in range(L)])
+    L, D = p.leg_count, max(p.leg_dof[l] for l in range(p.leg_count))
+    ready = np.array([[p.joint[l][j].unpacked if j < p.leg_dof[l] else 0.0 for j in range(D)] for l in range(L)])
     eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    if case.startswith("mixed"):
+        packed = ob.joints
+
+        def padded_joints():   # the oracle packs each leg's own joint count; the engine's arrays are [legs][longest DOF]
+            out = []
+            for a in packed():
+                pad, at = np.zeros((n, L, D)), 0
+                for l in range(L):
+                    d = p.leg_dof[l]
+                    pad[:, l, :d] = a[:, at:at + d]
+                    at += d
+                out.append(pad.reshape(n, L * D))
+            return tuple(out)
+        ob.joints = padded_joints
     q0, per_instance = None, "perturbed" in case
     if per_instance:
         rng = np.random.default_rng(5)
