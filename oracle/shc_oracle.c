@@ -13,8 +13,7 @@
  * transitionConfiguration, directStartup loop by loop, executeSequence (START_UP / SHUT_DOWN), stepToNewStance, packLegs /
  * unpackLegs, legStateToggle + poseForLegManipulation + updateManual, planner mode (executePlan, transitionConfiguration /
  * transitionStance), the message callbacks' unit handling, full-state export / import.
- * Not restated: ROS I/O, tf lookups, parameter server, joint_control's rotation-constrained corner of updateManual on 3-DOF legs
- * is restated but outside the engine's envelope.
+ * Not restated: ROS I/O, tf lookups, parameter server.
  */
 #include "shc_oracle.h"
 #include "oracle_math.h"
@@ -330,6 +329,16 @@ static void leg_set_desired_tip_pose(leg_t *leg, orc_pose tip_pose, int apply_de
   /* "Don't apply delta to manually manipulated legs" (:655-656) */
   apply_delta = apply_delta && !(leg->leg_state == MANUAL || leg->leg_state == WALKING_TO_MANUAL);
   if (apply_delta) leg->desired_tip_pose.p = orc_v3_add(leg->desired_tip_pose.p, leg->admittance_delta);
+}
+
+/* Whether a leg's stepper tip rotations are part of the exchanged state: legs of more than 3 joints with gravity-aligned tips / in
+ * rough terrain mode (an externally requested target may carry a rotation), and 3-joint legs under joint_control leg manipulation
+ * (updateManual hands the stepper the FK tip pose with its rotation, walk_controller.cpp:688-689).  Elsewhere the rotations are
+ * write-only (updateTipRotation's else branch, :1230-1233). */
+static int tip_rotations_tracked(const orc_robot *r, const leg_t *leg)
+{
+  if (leg->joint_count > 3) return r->params.gravity_aligned_tips || r->params.rough_terrain_mode;
+  return leg->joint_count == 3 && r->params.leg_manipulation_mode == SHC_MANIPULATION_JOINT_CONTROL;
 }
 
 /* Leg::setAdmittanceDelta (model.h:365-368) */
@@ -3473,9 +3482,8 @@ void orc_get_state(const orc_robot *r, shc_instance_state *o)
     put3(g->default_tip, s->default_tip_pose.p);
     put3(g->target_tip, s->target_tip_pose.p);
     put3(g->stride_vector, s->stride_vector);
-    if (leg->joint_count > 3 && (r->params.gravity_aligned_tips || r->params.rough_terrain_mode))
-    { /* otherwise the tip rotations are write-only on this path (updateTipRotation's else branch, :1230-1233): they matter with
-       * gravity-aligned tips and wherever an externally requested target may carry a rotation (rough terrain mode) */
+    if (tip_rotations_tracked(r, leg))
+    {
       put3(g->walker_tip_direction, orc_quat_rotate(s->current_tip_pose.r, orc_v3_make(1, 0, 0)));
       put3(g->origin_tip_direction, orc_quat_rotate(s->origin_tip_pose.r, orc_v3_make(1, 0, 0)));
       g->tip_rotation_defined = !orc_quat_is_undefined(s->current_tip_pose.r);
@@ -3558,7 +3566,7 @@ void orc_set_state(orc_robot *r, const shc_instance_state *o)
     s->stride_vector = get3(g->stride_vector);
     s->walk_plane = get3(o->stepper_walk_plane);
     s->walk_plane_normal = get3(o->stepper_walk_plane_normal);
-    if (leg->joint_count > 3 && (r->params.gravity_aligned_tips || r->params.rough_terrain_mode))
+    if (tip_rotations_tracked(r, leg))
     { /* rotations rebuilt from their x axes the way updateTipRotation builds them (walk_controller.cpp:1224) */
       s->current_tip_pose.r = g->tip_rotation_defined ? orc_quat_from_two_vectors(orc_v3_make(1, 0, 0), get3(g->walker_tip_direction))
                                                       : ORC_UNDEFINED_ROTATION;

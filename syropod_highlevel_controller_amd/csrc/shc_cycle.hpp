@@ -55,6 +55,11 @@ enum : unsigned { F_MANUAL = 1, F_AUTO = 2, F_INCL = 4, F_IMU = 8, F_ADM = 16, F
                   F_TALIGN = 1u << 28, // gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose
                   F_MLEGS = 1u << 27,  // manual leg manipulation / planner mode: ManualRobot records, updateManual, RT_SKIP_MARKED
                   F_TERRAIN = F_ROUGH | F_TALIGN | F_MLEGS };
+// Tip rotations are tracked by a specialisation (stepper rotation planes, rotation-constrained applyIK): legs of more than 3 joints
+// (gravity-aligned tips / externally requested targets), or 3-joint legs a joint_control updateManual hands their FK tip pose to
+// (walk_controller.cpp:677-690) - the latter only exists in the kernels with the manual-leg logic.
+template <int NJ, unsigned F>
+constexpr bool rot_enabled() { return (F & F_ROT) != 0 && (NJ > 3 || (F & F_MLEGS) != 0); }
 
 // Launch-uniform parameters (staged in LDS).
 struct CycleParams {
@@ -82,6 +87,7 @@ struct CycleParams {
   int32_t rough_terrain;         // rough_terrain_mode (generic kernel): default tips follow the terrain, targets meet the step surface
   int32_t tip_align;             // gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose (generic kernel)
   int32_t gravity_target;        // gravity_aligned_tips (> 3 DOF): an UNDEFINED target rotation is re-assigned from Model::estimateGravity (:1197-1205)
+  int32_t joint_control;         // leg_manipulation_mode joint_control: updateManual's velocity inputs move the coxa / tibia joints of 3-joint legs (:677-690)
   double step_depth;             // walk_controller.h:80
   double target_dir[3];          // x axis of the identity tip rotation FromTwoVectors(x, -z) (walk_controller.cpp:37-41)
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
@@ -414,6 +420,10 @@ struct FrontToBack {
   bool pose_only;   // in: stop after the posing part of the loop (state_controller.cpp:165-181) - a robot that stands while a leg toggle / plan step runs
   V3 odom_vel;      // desired linear (x, y) / angular (z) body velocity of this cycle and whether updateWalk reached its odometry
   bool odom_run;    //   update (cycle_front<..., ODOM_HERE = false>: the caller runs odometry_step elsewhere)
+  // joint_control updateManual moved this leg's joints (walk_controller.cpp:677-690): Leg::current_tip_pose_ is still the tip the leg had
+  // before (applyFK(false)) - its position (joint-1 frame) and x axis (body frame), which the following applyIK starts from
+  bool joint_moved;
+  V3 held_pe, held_dir;
 };
 
 // odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (walk_controller.cpp:643, :783-791).  Nothing in the
@@ -795,11 +805,13 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   const V3 UZ{0, 0, 1};
   // gravity-aligned tips: only legs with more than 3 joints constrain the tip rotation (walk_controller.cpp:37, :1197);
   // its own kernel specialisation (F_ROT), launched when the parameter is set
-  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
+  constexpr bool rot_on = rot_enabled<NJ, F>();
+  constexpr bool rot_walk = rot_on && NJ > 3; // LegStepper::updateTipRotation's "more than 3 joints" branch (:1195)
   bool rot_def = (s.word & LW_ROTDEF) != 0;
   bool targ_rot = (s.word & LW_TARGROT) != 0; // LegStepper::target_tip_pose_.rotation_ defined
   fb.odom_run = false;
   fb.plane_prev_changed = false;
+  fb.joint_moved = false;
   SHC_TICK(2);
 
   int rword = rb.geti(R::I_WORD);
@@ -1128,7 +1140,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
               }
               // target_tip_pose_ = pose_.removePose(transform_): position = pose_.transformVector(-transform_.position_) (pose.h:178-184)
               s.targ = V3{v[0], v[1], v[2]} + rotate(Quat{v[3], v[4], v[5], v[6]}, -V3{v[7], v[8], v[9]});
-              if (rot_on) { // ... and its rotation: pose_.rotation_ * transform_.rotation_^-1; a product with UNDEFINED_ROTATION (zeros) stays undefined
+              if (rot_walk) { // ... and its rotation: pose_.rotation_ * transform_.rotation_^-1; a product with UNDEFINED_ROTATION (zeros) stays undefined
                 const Quat tr = Quat{v[3], v[4], v[5], v[6]} * inverse(Quat{v[10], v[11], v[12], v[13]});
                 targ_rot = !(tr.w == 0.0 && tr.x == 0.0 && tr.y == 0.0 && tr.z == 0.0);
                 if (targ_rot) s.targ_dir = rotate(tr, V3{1, 0, 0});
@@ -1230,7 +1242,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     if (rot_on) {
       const int pm0 = (s.word >> LW_PM_SHIFT) & 3; // swing / stance progress as the previous iteratePhase left them
       const double sp = swing_progress_of(s.word, P);
-      if (pm0 == PM_STANCE || pm0 == PM_STOP || sp >= 0.5) {
+      if (rot_walk && (pm0 == PM_STANCE || pm0 == PM_STOP || sp >= 0.5)) {
         if (uni(P.gravity_target) && !targ_rot) { // "set target tip rotation to align with gravity if ... currently undefined" (:1197-1205)
           V3 gv{0, 0, kGravity}; // Model::estimateGravity (model.cpp:156-165); the direction of FromTwoVectors(UnitX, gravity) * UnitX
           if (FT::imu(P) || FT::incl(P) || FT::autop(P)) {
@@ -1313,7 +1325,26 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       vin = V3{mr->secondary_velocity[0], mr->secondary_velocity[1], mr->secondary_velocity[2]};
       pin = V3{mr->secondary_position[0], mr->secondary_position[1], mr->secondary_position[2]};
     }
-    if (norm(vin) != 0.0) { // tip_control (:690-704); joint_control (:677-690) is rejected by the host
+    if (norm(vin) != 0.0 && uni(P.joint_control) != 0) {
+      // joint_control (:677-690, "works only for 3DOF legs"): the x / y inputs step the tibia / coxa joints, unclamped; the stepper's tip
+      // pose becomes the FK tip pose of the moved joints WITH its rotation, so the applyIK that follows is rotation-constrained and
+      // starts from the tip pose the leg had before (Leg::applyFK(false) moves the joint transforms only).  Legs of other joint
+      // counts ignore the input.
+      if constexpr (NJ == 3 && rot_on) {
+        Chain<NJ> ch;
+        chain_from_sincos<NJ>(lc, s.sn, s.cs, ch);
+        fb.joint_moved = true;
+        fb.held_pe = ch.pe;
+        fb.held_dir = s.tipx;
+        s.q[0] += vin.y * P.max_rotation_velocity * P.dt;
+        s.q[2] += vin.x * P.max_rotation_velocity * P.dt;
+        joint_sincos<NJ>(lc, s.q, s.sn, s.cs);
+        chain_from_sincos<NJ>(lc, s.sn, s.cs, ch);
+        s.tip = tip_robot_frame(lc, ch.pe);
+        s.cur_dir = base_rotate(lc, ch.xe);
+        rot_def = true;
+      }
+    } else if (norm(vin) != 0.0) { // tip_control (:690-704)
       // ik_error = desired - current tip of the last updateModel: a leg that could not follow is pushed back towards its tip
       V3 prev_tip;
       if (LegRegs<NJ>::kKeepJacobian) {
@@ -1331,7 +1362,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       s.tip = s.tip + change;
       rot_def = false; // setCurrentTipPose(Pose(new_tip_position, UNDEFINED_ROTATION)) (:704)
     }
-    if (norm(pin) != 0.0) { // tip-pose overload (:712-744): the requested position, rotation undefined
+    if (norm(pin) != 0.0 && uni(P.joint_control) == 0) { // tip-pose overload (:712-744; tip_control only): the requested position, rotation undefined
       s.tip = pin;
       rot_def = false;
     }
@@ -1358,6 +1389,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     // no posing for manually manipulated legs (:135-139)
     if ((F & F_MLEGS) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL)) out.poser_tip = s.tip;
     if (rot_on && rot_def) desired_dir = rotate(inverse(bp.r), s.cur_dir); // pose.rotation^-1 * walker tip rotation (:129-130)
+    if (rot_on && rot_def && (F & F_MLEGS) != 0 && (my_leg_state == LS_MANUAL || my_leg_state == LS_WALKING_TO_MANUAL)) desired_dir = s.cur_dir;
   }
 
   fb.desired_dir = desired_dir;
@@ -1377,7 +1409,7 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
   asm volatile("" : "+v"(zero));
   const CycleParams &P = (&C.P)[zero];
   const LegConst<NJ> &lc = C.leg[leg + zero];
-  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
+  constexpr bool rot_on = rot_enabled<NJ, F>();
   const V3 desired_dir = fb.desired_dir;
   const bool rot_def = fb.rot_def;
   const int my_leg_state = fb.my_leg_state;
@@ -1400,10 +1432,16 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
       // a joint on its limit: proximity 0) retry unconstrained from the state reached.
       const bool cv = uni(P.clamp_joint_velocities) != 0, cp_ = uni(P.clamp_joint_positions) != 0;
       chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
-      const V3 current_dir = chain.xe;
+      V3 current_dir = chain.xe;
       double dq[NJ];
-      ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
       V3 lin[NJ];
+      if ((F & F_MLEGS) != 0 && NJ == 3 && fb.joint_moved) { // the Jacobian of the moved joints, the tip pose of before the move
+        current_dir = base_rotate_inv(lc, fb.held_dir);
+        jacobian_columns<NJ>(chain, lin);
+        ik_step_cols<NJ>(lc, lin, fb.held_pe, s.q, s.qd, desired, dq);
+      } else {
+        ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
+      }
       if (rot_def) {
         update_joints<NJ>(lc, dq, P.dt, P.inv_dt, false, cp_, s.q, s.qd);
         joint_sincos<NJ>(lc, s.q, s.sn, s.cs);

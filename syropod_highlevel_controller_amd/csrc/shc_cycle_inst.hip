@@ -65,6 +65,15 @@ static void launch_cycle_feat(const CycleLaunch &a) {
       return;
     }
   }
+  if constexpr (NJ == 3) {
+    // joint_control leg manipulation (3-joint legs): a MANUAL leg's tip pose carries its FK rotation, the rotation-constrained IK runs on
+    // it (walk_controller.cpp:677-690); only once a leg has been toggled
+    if (mlegs && c.joint_control) {
+      if (rough || talign) launch_cycle<L, NJ, F_DYN | F_ROT | F_TERRAIN>(a);
+      else launch_cycle<L, NJ, F_DYN | F_ROT | F_MLEGS>(a);
+      return;
+    }
+  }
   if (terrain) {
     if constexpr (SPEC) { // default.yaml's posing set (manual posing + odometry, with / without the tip-force estimate): feature-exact kernels
       constexpr unsigned C2 = F_MANUAL | F_ODOM;

@@ -69,7 +69,7 @@ __device__ __forceinline__ void load_leg_issue(LegLoad<NJ> &ll, const DevState &
   }
   ll.word = ROLE == ROLE_BACK ? 0 : st.legi[slot];
   ll.adm = ll.tf0 = ll.tf1 = ll.stiff = ll.rot0 = ll.rot1 = ll.rot2 = ll.rot3 = ll.rot4 = double2{0.0, 0.0};
-  if (NJ > 3 && (F & F_ROT)) { // tip directions of the stepper's origin / current / target tip rotations
+  if (rot_enabled<NJ, F>()) { // tip directions of the stepper's origin / current / target tip rotations
     ll.rot0 = ld.load(FD::ORG_DIR / 2);
     ll.rot1 = ld.load(FD::ORG_DIR / 2 + 1);
     ll.rot2 = ld.load(FD::ORG_DIR / 2 + 2);
@@ -159,7 +159,7 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     ld.store(FD::POSER_TIP / 2, double2{out.poser_tip.x, out.poser_tip.y});
     ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
   }
-  if (NJ > 3 && (F & F_ROT)) {
+  if (rot_enabled<NJ, F>()) {
     static_assert(FD::ORG_DIR % 2 == 0 && FD::CUR_DIR == FD::ORG_DIR + 3 && FD::TARG_DIR == FD::ORG_DIR + 6, "tip direction planes");
     ld.store(FD::ORG_DIR / 2, double2{s.org_dir.x, s.org_dir.y});
     ld.store(FD::ORG_DIR / 2 + 1, double2{s.org_dir.z, s.cur_dir.x});
@@ -646,7 +646,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   Group<L> g{grp * L};
   RobTile<RPW> rb{tile, tile_i, grp};
   s.tipx = V3{1, 0, 0};
-  constexpr bool rot_on = NJ > 3 && (F & F_ROT) != 0;
+  constexpr bool rot_on = rot_enabled<NJ, F>();
   if (FT::adm(P) || LegRegs<NJ>::kKeepJacobian || rot_on) {
     Chain<NJ> ch;
     chain_from_sincos<NJ>(C.leg[leg], s.sn, s.cs, ch);

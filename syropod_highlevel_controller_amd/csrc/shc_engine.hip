@@ -350,6 +350,9 @@ static bool mixed_dof(const shc_params &p) {
     if (p.leg_dof[l] != p.leg_dof[0]) return true;
   return false;
 }
+// Tip rotations are part of the state: legs of more than 3 joints with gravity-aligned tips / in rough terrain mode, or 3-joint legs that
+// joint_control leg manipulation hands their FK tip pose to (walk_controller.cpp:677-690).
+static int rotations_tracked(const shc_engine *e) { return (e->cp.gravity_aligned || (e->cp.joint_control && max_dof(e->params) == 3)) ? 1 : 0; }
 // ... and the parameter block the engine keeps has neutral entries for the padding (joint arrays of the ABI are [legs][longest leg's DOF]:
 // the padded joints read 0 and ignore what is written to them)
 static shc_params normalised_params(const shc_params &in) {
@@ -411,6 +414,7 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
   c.gravity_aligned = hostinit::tips_rotation_tracked(p, max_dof(p)) ? 1 : 0;
   c.gravity_target = hostinit::tips_rotation_constrained(p, max_dof(p)) ? 1 : 0;
+  c.joint_control = p.leg_manipulation_mode == SHC_MANIPULATION_JOINT_CONTROL ? 1 : 0;
   c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
   c.tip_align = (p.gravity_aligned_tips && max_dof(p) <= 3) ? 1 : 0; // pose_controller.cpp:849 (leg 0's joint count; mixed DOF + gravity_aligned_tips is rejected)
   c.step_depth = p.step_depth;
@@ -1965,7 +1969,7 @@ extern "C" int shc_leg_set_desired_tip_pose(shc_engine *e, int64_t first, int64_
   if (!tip_pose && (rc = derive_tips(e)) != SHC_OK) return rc; // Pose::Undefined() = "the poser's tip pose" (model.cpp:657)
   const double *d;
   if ((rc = c.in(tip_pose, 7, on_device, &d)) != SHC_OK) return rc;
-  if ((rc = LEG_KERNEL(leg_set_desired_kernel, d, apply_delta, e->params.admittance_control, e->cp.gravity_aligned)) != SHC_OK) return rc;
+  if ((rc = LEG_KERNEL(leg_set_desired_kernel, d, apply_delta, e->params.admittance_control, rotations_tracked(e))) != SHC_OK) return rc;
   return c.finish(nullptr, nullptr, 0, on_device);
 }
 
@@ -2222,7 +2226,7 @@ static SeqParams seq_params(const shc_engine *e) {
   P.clamp_pos = e->params.clamp_joint_positions;
   P.tip_force = e->cp.tip_force;
   P.have_adm = e->params.admittance_control;
-  P.gravity_aligned = e->cp.gravity_aligned;
+  P.gravity_aligned = rotations_tracked(e);
   P.inclination_posing = e->params.inclination_posing;
   P.gravity_aligned_tips = e->params.gravity_aligned_tips;
   P.pose_pass = e->params.imu_posing || e->params.auto_posing || e->params.inclination_posing;
@@ -2276,10 +2280,10 @@ static int ensure_manual(shc_engine *e, bool planner = false) {
   const shc_params &p = e->params;
   if (e->cp.tip_align)
     return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with the tip-align pose (gravity_aligned_tips on <= 3-DOF legs)");
-  if (!planner && p.leg_manipulation_mode != SHC_MANIPULATION_TIP_CONTROL) {
-    // joint_control hands the FK tip pose WITH its rotation to the stepper (walk_controller.cpp:688-689), which makes the following
-    // applyIK rotation-constrained on 3-DOF legs: outside the accelerated path
-    return fail(SHC_ERR_UNSUPPORTED, "leg_manipulation_mode joint_control");
+  if (!planner && p.leg_manipulation_mode == SHC_MANIPULATION_JOINT_CONTROL && mixed_dof(p)) {
+    // joint_control moves the joints of 3-joint legs only (walk_controller.cpp:677) and hands their FK tip pose WITH its rotation to the
+    // stepper: the kernels track tip rotations per morphology, not per leg
+    return fail(SHC_ERR_UNSUPPORTED, "leg_manipulation_mode joint_control on a robot whose legs differ in DOF");
   }
   HIP_TRY(hipSetDevice(e->device));
   if (!e->st.manual) {

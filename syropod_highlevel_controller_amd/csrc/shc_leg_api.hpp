@@ -72,11 +72,13 @@ __device__ __forceinline__ void set_desired_dev(const DevState &st, const LegIO<
     if (defined) dir = rotate(r, V3{1, 0, 0});
   } else {
     pos = io.get3(FD::POSER_TIP);
-    if (gravity_aligned && NJ > 3 && (st.legi[io.slot] & LW_ROTDEF)) { // pose.rotation^-1 * walker tip rotation (pose_controller.cpp:129-130)
+    if (gravity_aligned && (st.legi[io.slot] & LW_ROTDEF)) { // pose.rotation^-1 * walker tip rotation (pose_controller.cpp:129-130)
       const int rpw = 64 / L;
       const Quat cr{st.robd[rob_index(rob, R::CPOSE + 3, rpw, R::COUNT)], st.robd[rob_index(rob, R::CPOSE + 4, rpw, R::COUNT)],
                     st.robd[rob_index(rob, R::CPOSE + 5, rpw, R::COUNT)], st.robd[rob_index(rob, R::CPOSE + 6, rpw, R::COUNT)]};
-      dir = rotate(inverse(cr), io.get3(FD::CUR_DIR));
+      const int ls = leg_state_of(st, rob, int(io.slot & 63) % L);
+      dir = io.get3(FD::CUR_DIR); // (manually manipulated legs: the stepper's tip pose as it is, :135-139)
+      if (ls != LS_MANUAL && ls != LS_WALKING_TO_MANUAL) dir = rotate(inverse(cr), dir);
       defined = true;
     }
   }
@@ -283,7 +285,7 @@ __device__ __forceinline__ int step_to_position_dev(const DevState &st, const Le
     if (leg_state == LS_MANUAL) { // a MANUAL leg keeps the tip pose updateStance gave its LegPoser: the stepper's own (:1680-1684, pose_controller.cpp:134-137)
       out.p = io.get3(FD::TIP);
       out.r = Quat{0, 0, 0, 0};
-      if (NJ > 3 && (st.legi[io.slot] & LW_ROTDEF)) out.r = from_two_vectors(V3{1, 0, 0}, io.get3(FD::CUR_DIR));
+      if (st.legi[io.slot] & LW_ROTDEF) out.r = from_two_vectors(V3{1, 0, 0}, io.get3(FD::CUR_DIR));
     }
     if (count >= num) {
       progress = 100; // first_iteration_ = true

@@ -411,7 +411,7 @@ __global__ void execute_plan_kernel(DevState st, const SharedConsts<L, NJ> *gc, 
           const bool manual = ls == LS_MANUAL || ls == LS_WALKING_TO_MANUAL;
           // ... and its rotation with gravity-aligned tips: pose.rotation^-1 * the walker's tip rotation where that is defined (:129-130)
           Quat rotation{0, 0, 0, 0};
-          if (P.gravity_aligned && NJ > 3 && (st.legi[io.slot] & LW_ROTDEF)) {
+          if (P.gravity_aligned && (st.legi[io.slot] & LW_ROTDEF)) {
             const V3 walker_dir = io.get3(FD::CUR_DIR);
             rotation = from_two_vectors(V3{1, 0, 0}, manual ? walker_dir : rotate(inverse(current_pose.r), walker_dir));
           }

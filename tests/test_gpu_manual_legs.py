@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("case", ["hexapod-tip-control", "8x4-tip-control", "hexapod-dynamic-stiffness", "8x5-gravity-aligned",
-                                  "hexapod-imu-posing", "hexapod-auto-and-inclination-posing", "hexapod-imu-admittance", "mixed-dof-354354"])
+                                  "hexapod-imu-posing", "hexapod-auto-and-inclination-posing", "hexapod-imu-admittance", "mixed-dof-354354",
+                                  "hexapod-joint-control", "8x4-joint-control"])
 def test_toggle_manipulate_and_return(case):
     """Walk; request a leg toggle per robot (different legs, two robots none): robots still walking are told to stop first
     (result -1), then the designated leg goes WALKING -> WALKING_TO_MANUAL -> MANUAL while every leg steps to its manipulation
@@ -34,6 +35,8 @@ def test_toggle_manipulate_and_return(case):
         p = synthetic_mixed_dof_params("ripple")
     else:
         p = default_hexapod_params("tripod")
+    if "joint-control" in case:   # the velocity inputs move the coxa / tibia joints of 3-joint legs; the tip pose they reach comes WITH its
+        p.leg_manipulation_mode = 1   # rotation: the rotation-constrained IK on 3-joint legs (4-joint legs ignore the inputs)
     if "stiffness" in case:
         p.admittance_control, p.dynamic_stiffness = 1, 1
     if "imu" in case:
@@ -180,23 +183,32 @@ def test_toggle_manipulate_and_return(case):
 
 
 def test_manual_legs_unsupported_configurations():
-    """Outside the accelerated envelope: joint_control (its FK tip rotation makes the following applyIK rotation-constrained on 3-DOF
-    legs) and the experimental tip-align pose (gravity_aligned_tips on 3-DOF legs)."""
-    for field in ("gravity_aligned_tips", "leg_manipulation_mode"):
-        p = default_hexapod_params("tripod")
-        setattr(p, field, 1)
-        eng = BatchEngine(p, 2)
+    """Outside the accelerated envelope: the experimental tip-align pose (gravity_aligned_tips on 3-DOF legs) and joint_control on a robot
+    whose legs differ in DOF (tip rotations are tracked per morphology)."""
+    from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
+    p = default_hexapod_params("tripod")
+    p.gravity_aligned_tips = 1
+    q = synthetic_mixed_dof_params("ripple")
+    q.leg_manipulation_mode = 1
+    for params in (p, q):
+        eng = BatchEngine(params, 2)
         with pytest.raises(RuntimeError):
             eng.toggle_leg_state(np.array([0, -1], dtype=np.int32))
 
 
-def test_toggle_and_manipulate_free_running():
+@pytest.mark.parametrize("case", ["8x5-gravity-aligned", "hexapod-joint-control"])
+def test_toggle_and_manipulate_free_running(case):
     """The same without state injection (what teacher forcing cannot show: state the engine keeps to itself between calls, e.g.
-    the tip-rotation flag of a leg that went MANUAL on gravity-aligned 5-joint legs).  The robots stand for most of this, where
-    the reference's IK step amplifies rounding differences: flags exactly, tips to 5 mm."""
-    p = synthetic_octopod_params("ripple", 5, 8)
-    p.gravity_aligned_tips = 1
-    n, L = 6, 8
+    the tip-rotation flag of a leg that went MANUAL on gravity-aligned 5-joint legs, or the FK tip rotation a joint_control MANUAL leg
+    holds).  The robots stand for most of this, where the reference's IK step amplifies rounding differences:
+    flags exactly, tips to 5 mm."""
+    if case.startswith("8x5"):
+        p = synthetic_octopod_params("ripple", 5, 8)
+        p.gravity_aligned_tips = 1
+    else:
+        p = default_hexapod_params("tripod")
+        p.leg_manipulation_mode = 1
+    n, L = 6, p.leg_count
     rng = np.random.default_rng(5)
     eng, ob = BatchEngine(p, n), OracleBatch(p, n)
     lin, ang = rng.uniform(-0.4, 0.4, (n, 2)), rng.uniform(-0.3, 0.3, n)
@@ -222,6 +234,23 @@ def test_toggle_and_manipulate_free_running():
     assert np.array_equal(g["walk_state"], o["walk_state"])
     assert np.abs(eng.leg_state()["model_tip"] - ob.leg_state()["model_tip"]).max() < 5e-3
     assert np.abs(eng.leg_state()["walker_tip"] - ob.leg_state()["walker_tip"]).max() < 5e-3
+    if "joint-control" in case:   # inputs withdrawn: the legs keep the tip pose (with its rotation) the last FK gave the stepper; then back to walking
+        assert g["leg"]["tip_rotation_defined"][np.arange(n), prim].all()
+        for o in (eng, ob):
+            o.set_manual_inputs(prim, vel * 0.0, None, None, None, None)
+            o.step(30) if o is eng else o.step(30, 1)
+        assert np.abs(eng.joints()[0] - ob.joints()[0]).max() < 2e-2
+        sel = prim.copy()
+        for _ in range(3000):
+            re, ro = eng.toggle_leg_state(sel), ob.toggle_leg_state(sel)
+            assert np.array_equal(re, ro)
+            if (re == 1).all():
+                break
+            sel = np.where(re == 1, -1, sel).astype(np.int32)
+        assert (eng.leg_manipulation_state() == 0).all()
+        g, o = as_np(eng.get_state()), as_np(ob.get_state())
+        assert np.array_equal(g["leg"]["tip_rotation_defined"][:, :L], o["leg"]["tip_rotation_defined"][:, :L])
+        assert np.abs(eng.joints()[0] - ob.joints()[0]).max() < 1e-6
 
 
 def test_complete_checkpoint_carries_a_manual_leg_into_another_engine():
