@@ -164,18 +164,29 @@ def resident_bytes_per_cycle(p):
     return 24 + 2 * p.leg_count * p.leg_dof[0] * 8
 
 
-def time_resident(eng, n, steps, warmup, stream, depth=16):
+def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, host_barrier=None):
     """Timed region of resident mode: `steps` ticks of the doorbell, one control cycle each, bracketed by synchronisation.
+    N > 1 (final_gather): the region ends with the all-gather of the LAST cycle's joints.  It is queued on the engine's stream behind a
+    device-side wait for that cycle (shc_engine_resident_get_joint_state_async) before the first tick, so only its execution - not
+    its launch - follows the last cycle; the closing bracket is the synchronisation of that stream.
     Returns (elapsed seconds for `steps` cycles, seconds per cycle of one long launch from HIP events on the launch stream)."""
     import torch
     eng.resident_begin(ring_depth=depth, max_cycles=warmup + steps + 8)
     eng.resident_publish(max(warmup, 1))
     eng.resident_wait(max(warmup, 1))
-    torch.cuda.synchronize() if False else None  # (the resident kernel owns the engine's stream: nothing to synchronise on it)
+    if final_gather:
+        # launched ahead like a captured graph: the device holds the read (and the collective behind it) until the last cycle of the
+        # region has run - the host calls are outside the region, the gather's execution and the wait for it are inside
+        final_gather(max(warmup, 1) + steps - 1)
+    if host_barrier:
+        host_barrier()               # ranks enter the region together (a host-side barrier: the loop kernel is alive, no device-wide sync)
     t0 = time.perf_counter()
     for _ in range(steps):
         eng.resident_publish(1)      # one tick = one cycle; the host does not wait for it
-    eng.resident_wait(max(warmup, 1) + steps, 60000)
+    if final_gather:
+        stream.synchronize()         # the gathered buffer is complete: every rank's last cycle has run
+    else:
+        eng.resident_wait(max(warmup, 1) + steps, 60000)
     elapsed = time.perf_counter() - t0
     eng.resident_end()
     # kernel time per cycle: one launch of m cycles released at once, HIP events on the launch stream around it
@@ -261,9 +272,16 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     res_cycle_s = None
     launch_elapsed = None
     posted_value = None
+    host_barrier = None
     if use_dist:
         gather()
         dist.barrier()
+        try:    # host-side barriers while a resident loop is alive (no device-wide synchronisation may be issued then)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the loopback interface (the hostname may not resolve)
+            cpu_group = dist.new_group(backend="gloo")
+            host_barrier = lambda: dist.barrier(group=cpu_group)  # noqa: E731
+        except Exception:  # noqa: BLE001 - without one the ranks enter the region as they come (the closing all-gather still joins them)
+            host_barrier = None
     if resident:   # the launch-per-cycle figure of the same engine first (secondary), then the resident one
         for _ in range(warmup):
             step_once()
@@ -278,13 +296,14 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         # (time_resident's own clock brackets exactly `steps` doorbell ticks; the gather of the final joints follows inside the region)
-        res_elapsed, res_cycle_s = time_resident(eng, n, steps, warmup, stream)
+        if use_dist:   # N > 1: the all-gather of the final joints belongs to the region
+            def final_gather(cycle):
+                eng.resident_joints_async(cycle, qshard.data_ptr())
+                all_gather_joints(qshard, world, out=gathered)
+            res_elapsed, res_cycle_s = time_resident(eng, n, steps, warmup, stream, final_gather=final_gather, host_barrier=host_barrier)
+        else:
+            res_elapsed, res_cycle_s = time_resident(eng, n, steps, warmup, stream)
         elapsed = res_elapsed
-        if use_dist:   # N > 1: the all-gather of the final joints belongs to the region (and has its own stream synchronisation)
-            t_after = time.perf_counter()
-            gather()
-            torch.cuda.synchronize()
-            elapsed += time.perf_counter() - t_after
         # secondary figure: a NEW velocity command for every robot in every cycle, from arrays resident in HBM (post + doorbell in one launch)
         posted_value = None
         if not use_dist and not os.environ.get("SHC_BENCH_NO_POSTED_PROBE"):   # (profiling runs skip it: one K-cycle launch to attribute counters to)

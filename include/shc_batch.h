@@ -297,6 +297,12 @@ int shc_engine_join(shc_engine *e);
  *   shc_engine_resident_get_joint_state(e, cycle, q, qd, on_device)
  *       desired joint positions / velocities [n][legs][dof] of iteration `cycle` (completed, and at most ring_depth - 1 iterations
  *       older than the newest published one) - what publishDesiredJointState sends after that loop iteration.
+ *   shc_engine_resident_get_joint_state_async(e, cycle, q, qd, timeout_ms)
+ *       the same into DEVICE buffers, stream-ordered instead of host-ordered: returns at once having queued, on the engine's
+ *       stream, a device-side wait for iteration `cycle` (which may still be unpublished; bounded by timeout_ms, 0 = 5 s) and the copy.
+ *       Work the caller queues on that stream afterwards - the all-gather of the fleet's joint buffer - starts the moment the
+ *       iteration's outputs exist, its launch latency hidden behind the iterations still running.  At most ring_depth - 1 newer
+ *       iterations may be published before the copy has run.  A wait that gave up is reported by shc_engine_resident_end (SHC_ERR_TIMEOUT).
  *   shc_engine_resident_status(e, published, completed, running)
  *   shc_engine_resident_end(e, cycles_run)
  *       stops the loop after the published cycles, waits for it, and leaves the engine exactly as the same cycles through
@@ -324,6 +330,7 @@ int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *inputs, int6
 int shc_engine_resident_publish(shc_engine *e, int64_t n_cycles);
 int shc_engine_resident_wait(shc_engine *e, int64_t cycles, int timeout_ms);
 int shc_engine_resident_get_joint_state(shc_engine *e, int64_t cycle, double *q, double *qd, int on_device);
+int shc_engine_resident_get_joint_state_async(shc_engine *e, int64_t cycle, double *q, double *qd, int timeout_ms);
 int shc_engine_resident_status(shc_engine *e, int64_t *published, int64_t *completed, int32_t *running);
 int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run);
 

@@ -490,7 +490,10 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
       }
       m = uni64(m);
       if (m != last_done) {
-        if (lane == 0) st_sys(&A.host->done, m);
+        if (lane == 0) {
+          st_sys(&A.host->done, m);
+          st_agent(&A.ctl->pad[1], m); // the device's copy: what a stream-ordered read polls (no PCIe traffic next to the doorbell)
+        }
         last_done = m;
       }
       bool gave_up = false;
@@ -504,7 +507,9 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
         if (lane == 0) {
           st_sys(&A.host->fault, fault);
           st_sys(&A.host->done, m);
+          st_agent(&A.ctl->pad[1], m);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          st_agent(&A.ctl->pad[2], 1ull);
           st_sys(&A.host->exited, (fault || gave_up) ? u64(RESIDENT_EXIT_FAULT) : why);
         }
       }

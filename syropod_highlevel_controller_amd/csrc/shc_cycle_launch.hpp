@@ -21,7 +21,7 @@ struct ResidentCtl { // device memory, polled with agent-scope loads; written by
   unsigned long long gate;      // (stop << 32) | doorbell: run cycle c (counted from resident_begin) while c < min(doorbell, stop)
   unsigned long long exited;    // worker waves that have left the loop
   unsigned long long fault;     // != 0: a worker gave up waiting (emergency bound) - state may be inconsistent
-  unsigned long long pad[5];
+  unsigned long long pad[5];    // [0] exit reason, [1] cycles completed by every wave (device copy of ResidentHost::done), [2] the relay has left
   unsigned long long dbg[40];   // development builds (-DSHC_RES2_TIMING): phase clocks of workgroup 1
 };
 struct ResidentHost { // pinned host memory mapped into the device (fine-grained): the host side of the handshake
@@ -31,6 +31,7 @@ struct ResidentHost { // pinned host memory mapped into the device (fine-grained
   unsigned long long exited;    // device -> host: 0 running | SHC_RESIDENT_* exit reason
   unsigned long long heartbeat; // device -> host: relay iterations (diagnostic)
   unsigned long long fault;
+  unsigned long long late_reads; // device -> host: stream-ordered reads that gave up waiting for their cycle
 };
 struct ResidentHeader { // one per cycle (ring of kResidentHeaders), written by shc_engine_resident_post before the doorbell moves
   unsigned long long tag;  // cycle + 1; any other value: nothing was posted for this cycle (inputs held)

@@ -484,6 +484,48 @@ extern "C" int shc_engine_resident_get_joint_state(shc_engine *e, int64_t cycle,
   return SHC_OK;
 }
 
+// Device-side wait for a cycle of the resident loop: one thread watches the relay's count of completed cycles (its device copy),
+// bounded - a loop that stopped or never gets the cycle must not leave a kernel spinning on the caller's stream.
+__global__ void resident_wait_done_kernel(const ResidentCtl *ctl, ResidentHost *host, unsigned long long want, unsigned long long timeout_ticks) {
+  const unsigned long long t0 = wall_clock64();
+  auto done = [&] { return __hip_atomic_load(&ctl->pad[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); };
+  for (;;) {
+    if (done() >= want) return;
+    if (__hip_atomic_load(&ctl->pad[2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0 && done() < want) break; // the loop has ended without it
+    if (wall_clock64() - t0 > timeout_ticks) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  __hip_atomic_fetch_add(&host->late_reads, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Stream-ordered variant of shc_engine_resident_get_joint_state: nothing here waits on the host.  The engine's stream gets a
+// device-side wait for `cycle` followed by the gather into the caller's device buffers, so whatever the caller queues on that
+// stream afterwards (the all-gather of the fleet's joint buffer) runs as soon as the cycle's outputs exist - its launch latency
+// hides behind the cycles still running.  The cycle may be one that has not been published yet.
+extern "C" int shc_engine_resident_get_joint_state_async(shc_engine *e, int64_t cycle, double *q, double *qd, int timeout_ms) {
+  int rc = resident_require(e, true);
+  if (rc != SHC_OK) return rc;
+  Resident *r = e->res;
+  if ((rc = resident_alive(r)) != SHC_OK) return rc;
+  if (cycle < 0 || (unsigned long long)cycle >= r->max_cycles) return fail(SHC_ERR_INVALID_ARG, "resident mode: no such cycle (max_cycles)");
+  if (r->published > (unsigned long long)cycle + r->depth)
+    return fail(SHC_ERR_INVALID_ARG, "resident mode: that cycle's outputs may have been overwritten (ring_depth newer cycles were published)");
+  HIP_TRY(hipSetDevice(e->device));
+  const unsigned long long ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 5000) * 100000ull; // wall_clock64: 100 MHz
+  resident_wait_done_kernel<<<dim3(1), dim3(1), 0, e->stream>>>(r->ctl, r->host_dev, (unsigned long long)cycle + 1, ticks);
+  HIP_TRY(hipGetLastError());
+  const double *slot = r->out + size_t(cycle % r->depth) * size_t(e->NJ) * e->n_slots * 2;
+  const int64_t threads = e->n * e->L;
+  for (int which = 0; which < 2; ++which) {
+    double *dst = which ? qd : q;
+    if (!dst) continue;
+    gather_leg_kernel<<<dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, e->stream>>>(dst, slot, e->n_slots, e->n, e->L, e->NJ,
+                                                                                         which ? LEG_FIELD(e, QD) : LEG_FIELD(e, Q));
+    HIP_TRY(hipGetLastError());
+  }
+  return SHC_OK;
+}
+
 extern "C" int shc_engine_resident_status(shc_engine *e, int64_t *published, int64_t *completed, int32_t *running) {
   int rc = resident_require(e, false);
   if (rc != SHC_OK) return rc;
@@ -526,6 +568,8 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   if (err != hipSuccess) return fail(SHC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
   if (reason == RESIDENT_EXIT_FAULT || host_load(&r->host->fault) != 0)
     return fail(SHC_ERR_HIP, "resident mode: a wavefront gave up waiting for the relay; restore the engine from a snapshot");
+  if (host_load(&r->host->late_reads) != 0)
+    return fail(SHC_ERR_TIMEOUT, "resident mode: a stream-ordered read (shc_engine_resident_get_joint_state_async) gave up waiting for its cycle");
   // (a loop that reached max_cycles exactly when everything published had run has done what a stop request asks for)
   if (!((reason == RESIDENT_EXIT_STOP || reason == RESIDENT_EXIT_MAX) && done == r->published))
     return fail(SHC_ERR_TIMEOUT, std::string("resident mode: the device loop had stopped by itself (") +

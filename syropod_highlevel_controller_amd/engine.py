@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = [
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
     "shc_fleet_all_gather_joints",
     "shc_engine_resident_begin", "shc_engine_resident_post", "shc_engine_resident_publish", "shc_engine_resident_wait",
-    "shc_engine_resident_get_joint_state", "shc_engine_resident_status", "shc_engine_resident_end", "shc_engine_join",
+    "shc_engine_resident_get_joint_state", "shc_engine_resident_get_joint_state_async", "shc_engine_resident_status", "shc_engine_resident_end", "shc_engine_join",
     "shc_engine_aux_state_bytes", "shc_engine_get_aux_state", "shc_engine_set_aux_state",
 ]
 
@@ -209,6 +209,7 @@ def lib():
         L.shc_engine_resident_publish.argtypes = [C.c_void_p, C.c_int64]
         L.shc_engine_resident_wait.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         L.shc_engine_resident_get_joint_state.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.shc_engine_resident_get_joint_state_async.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         L.shc_engine_resident_status.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
         L.shc_engine_resident_end.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         L.shc_engine_synchronize.argtypes = [C.c_void_p]
@@ -440,6 +441,12 @@ class BatchEngine:
         qd = np.zeros((self.n, self.legs * self.dof))
         _check(self.L.shc_engine_resident_get_joint_state(self.h, int(cycle), _p(q), _p(qd), 0), "resident_get_joint_state")
         return q, qd
+
+    def resident_joints_async(self, cycle: int, q_ptr: int, qd_ptr: int = 0, timeout_ms: int = 0):
+        """Stream-ordered read into device buffers (raw pointers, [n][legs][dof]): queued on the engine's stream behind a device-side
+        wait for `cycle`; returns at once."""
+        _check(self.L.shc_engine_resident_get_joint_state_async(self.h, int(cycle), C.c_void_p(q_ptr or None), C.c_void_p(qd_ptr or None), int(timeout_ms)),
+               "resident_get_joint_state_async")
 
     def resident_status(self):
         pub, done, run = C.c_int64(), C.c_int64(), C.c_int32()

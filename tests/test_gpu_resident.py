@@ -209,6 +209,46 @@ def test_resident_held_inputs_and_bare_publishes(Engine):
     b.close()
 
 
+def test_resident_stream_ordered_read_of_a_cycle_still_to_come(Engine):
+    """shc_engine_resident_get_joint_state_async: the copy of a cycle's joints into device buffers is queued on the engine's stream BEFORE
+    the cycle has been published; work queued behind it (here a device-to-device copy, in bench.py the RCCL all-gather) sees the cycle's
+    joints, with no host wait in between.  A read whose cycle never comes gives up and resident_end reports it."""
+    import torch
+    p, n = default_hexapod_params("tripod"), 300
+    rng = np.random.default_rng(8)
+    lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        e = Engine(p, n, stream=stream.cuda_stream)
+        e.set_velocity(lin, ang)
+        e.step(40)
+        e.resident_begin(ring_depth=8, max_cycles=500)
+        q = torch.full((n, 18), float("nan"), dtype=torch.float64, device="cuda")
+        qd = torch.full((n, 18), float("nan"), dtype=torch.float64, device="cuda")
+        e.resident_publish(10)
+        e.resident_joints_async(10 + 24, q.data_ptr(), qd.data_ptr())     # cycle 34: not published yet
+        behind = torch.empty_like(q)
+        behind.copy_(q, non_blocking=True)                                  # queued behind the read on the same stream
+        time.sleep(0.05)
+        assert not stream.query()                                           # the stream is waiting for that cycle on the device
+        for _ in range(25):
+            e.resident_publish(1)
+        stream.synchronize()
+        want_q, want_qd = e.resident_joints(34)
+        assert np.array_equal(behind.cpu().numpy(), want_q) and np.array_equal(qd.cpu().numpy(), want_qd)
+        assert e.resident_end() == 35
+        # ... a read of a cycle that is never published: bounded, reported
+        e.resident_begin(ring_depth=8, max_cycles=100)
+        e.resident_publish(3)
+        e.resident_joints_async(50, q.data_ptr(), 0, timeout_ms=200)
+        stream.synchronize()
+        with pytest.raises(RuntimeError):
+            e.resident_end()
+        e.step(5)                                                           # the engine is usable again
+        e.synchronize()
+        e.close()
+
+
 def test_resident_bounds(Engine):
     """Every device-side wait is bounded: max_cycles, the idle timeout, and batches that do not fit are refused."""
     from syropod_highlevel_controller_amd.engine import ShcError
