@@ -426,7 +426,9 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                    "velocities_posted_every_cycle_value": posted_value,   # resident mode, a new velocity set per robot and cycle from device arrays
                    "legs": p.leg_count, "dof": p.leg_dof[0],
                    "gather": f"all-gather of the joint buffer every {gather_every} steps" if gather_every
-                   else "one all-gather of the final joint buffer (N > 1)",
+                   else ("one all-gather of the final joint buffer, inside the timed region: queued on the engine's stream behind a device-side wait for the "
+                         "region's last cycle before the first tick (stream-ordered, like a captured graph); the region closes when it has completed"
+                         if (use_dist and resident) else "one all-gather of the final joint buffer (N > 1), launched after the last step inside the timed region"),
                    "moving_fraction": moving_frac, "finite": finite, "seed": seed, "fused_16_cycles_per_launch_value": fused_value,
                    "two_stream_split": n_waves >= 4096, "single_stream": single_stream},
         "roofline": roofline,

@@ -11,9 +11,12 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   LegPoser::stepToPosition / Leg::setDesiredTipPose: no admittance delta for manually manipulated legs   :1609-1614, src/model.cpp:655-656
   WalkController::updateManual x 2, updateWalk's "all legs WALKING" gate, PoseController::updateStance for manual legs
                                              (in make_walk_golden.py: src/walk_controller.cpp:491-505, :652-744, src/pose_controller.cpp:134-137)
-One scenario: a default hexapod with admittance control and a steady 4 N on every tip walks, is asked to hand leg 2 over (stops,
-poses, MANUAL), the leg follows tip-velocity and tip-position inputs while body-velocity commands are ignored, a second leg
-follows, a third is refused, both come back, the robot walks again.  Recorded per loop: its kind, the request's result, joints.
+One scenario per leg_manipulation_mode: a default hexapod with admittance control and a steady 4 N on every tip walks, is asked to
+hand leg 2 over (stops, poses, MANUAL), the leg follows tip-velocity and tip-position inputs while body-velocity commands are ignored,
+a second leg follows, a third is refused, both come back, the robot walks again.  Recorded per loop: its kind, the request's result,
+joints.  joint_control (keys jc_*): the velocity inputs step the coxa / tibia joints, the stepper holds the FK tip pose with its
+rotation, every applyIK of the leg is rotation-constrained (walk_controller.cpp:677-690, model.cpp:880-900); the position inputs are
+ignored; inputs withdrawn for a while.
 
 tests/test_oracle_golden.py::test_manual_leg_trajectories replays the loops on the oracle: results exactly, joints to 1e-6 rad
 wherever the robot walks and 5e-3 while it stands (where the reference's IK step amplifies rounding differences).
@@ -68,10 +71,10 @@ class Toggler:
                 tp = pose.p - w.manual_pose.p                                   # current pose, manual pose removed, default pose (identity) added
                 target = pose.r.inv().apply(leg.default - tp)
             if leg.leg_state == W2M:
-                leg.tip = target.copy()
+                leg.tip, leg.rot_defined = target.copy(), False                 # setCurrentTipPose(target_tip_pose): rotation undefined
                 step_height = 0.0
             elif leg.leg_state == M2W:
-                leg.tip = leg.default.copy()
+                leg.tip, leg.rot_defined = leg.default.copy(), False
             if self.stp[i] is None or self.stp[i].first:
                 self.stp[i] = ms.StepToPosition(mw.fk_tip(i, w.q[i]), self.tip_quat(i))
             manually = leg.leg_state in (MANUAL, W2M)
@@ -82,7 +85,9 @@ class Toggler:
             if progress != 100:
                 desired = leg.poser_tip + (np.zeros(3) if manually else adm[i])
                 leg.desired_tip = desired
-                w.q[i], w.qd[i] = mw.apply_ik(i, w.q[i], w.qd[i], desired, w.dt)
+                # a MANUAL leg's LegPoser holds the stepper's tip pose as updateStance left it - with the FK rotation joint_control gave it
+                ddir = leg.cur_dir if (leg.leg_state == MANUAL and leg.rot_defined) else None
+                w.q[i], w.qd[i] = mw.apply_ik(i, w.q[i], w.qd[i], desired, w.dt, ddir)
                 leg.model_tip = mw.fk_tip(i, w.q[i])
         return min_progress
 
@@ -116,10 +121,10 @@ class Toggler:
         return 0, lin, ang
 
 
-def run():
+def run(mode="tip_control"):
     import zlib
     gait = "tripod"
-    P = mw.hexapod(gait, admittance_control=1, manual_posing=1)
+    P = mw.hexapod(gait, admittance_control=1, manual_posing=1, leg_manipulation_mode=mode)
     w = mw.started_walker(P, gait)               # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
     q0, qd0 = w.q.copy(), w.qd.copy()
     w.tip_force = np.tile(np.array([0.0, 0.0, 4.0]), (6, 1))
@@ -163,6 +168,11 @@ def run():
     cycles(20)
     set_inputs(2, pv=rng.uniform(-1, 1, 3))
     cycles(15)
+    if mode == "joint_control":                   # inputs withdrawn: the stepper keeps the last FK tip pose, rotation included
+        set_inputs(2)
+        cycles(20)
+        set_inputs(2, pv=[0.0, 0.0, 0.7])         # a z input moves no joint but still hands the stepper the FK tip pose
+        cycles(10)
     assert toggle(4) == 1
     set_inputs(2, pv=rng.uniform(-1, 1, 3), secondary=4, sv=rng.uniform(-1, 1, 3))
     cycles(25)
@@ -178,6 +188,9 @@ def run():
 
 if __name__ == "__main__":
     out = run()
+    jc = run("joint_control")
+    out.update({"jc_" + k: v for k, v in jc.items()})
     np.savez_compressed(os.path.join(HERE, "manual_golden.npz"), **out)
-    k = out["loops"]
-    print("loops", len(k), "toggle loops", int((k[:, 0] == 1).sum()), "results", sorted(set(k[k[:, 0] == 1][:, 2].astype(int).tolist())))
+    for pre in ("", "jc_"):
+        k = out[pre + "loops"]
+        print(pre or "tip_control", "loops", len(k), "toggle loops", int((k[:, 0] == 1).sum()), "results", sorted(set(k[k[:, 0] == 1][:, 2].astype(int).tolist())))

@@ -223,14 +223,18 @@ def update_joints(leg, q, dq, dt, simulation):
     return qn, vn, proximity
 
 
-def apply_ik(leg, q, qd, desired, dt, desired_dir=None, simulation=False):
+def apply_ik(leg, q, qd, desired, dt, desired_dir=None, simulation=False, held=None):
     """Leg::applyIK (:861-941) towards a desired tip position (robot frame) and, optionally, tip direction.  Returns (q, qd).
-    simulation: applyIK(true), the joint velocity clamp is off (the init chain's calls)."""
+    simulation: applyIK(true), the joint velocity clamp is off (the init chain's calls).
+    held: (tip position, tip x axis) in the robot frame of Leg::current_tip_pose_ where that is NOT the FK of q - joint_control's
+    updateManual moves the joints with applyFK(false), which refreshes the joint transforms (the Jacobian) but not the tip pose."""
     base = dh(*MODEL.base[leg])
     bi = np.linalg.inv(base)
     chain = _chain(leg, q)
     cur = (base @ chain[-1])[:3, 3]
     cur_dir_leg = chain[-1][:3, 0]                          # leg_frame_current_tip_pose: taken BEFORE any update (:865)
+    if held is not None:
+        cur, cur_dir_leg = held[0], bi[:3, :3] @ held[1]
     delta = np.zeros(6)
     delta[:3] = (bi @ np.append(desired, 1))[:3] - (bi @ np.append(cur, 1))[:3]        # tip delta in the leg base frame (:863-872)
     dq = solve_ik(leg, q, qd, delta, False)
@@ -340,6 +344,7 @@ class Leg:
         self.rot_defined = False    # current_tip_pose_.rotation_ != UNDEFINED_ROTATION (gravity-aligned tips, > 3 joints)
         self.cur_dir = self.origin_dir = self.model_dir = np.array([0.0, 0.0, -1.0])   # x axes of current / origin tip rotation, of the FK tip frame
         self.model_tip = None       # Leg::current_tip_pose_.position_ (FK of the joints), scenarios with the kinematic model
+        self.held = None            # Leg::current_tip_pose_ (position, x axis) where joint_control's updateManual has moved the joints under it
 
 
 class RefWalker:
@@ -696,8 +701,9 @@ class RefWalker:
             self.auto_posing_state = POSING_COMPLETE
         return pose
 
-    def update_manual(self):   # WalkController::updateManual, tip_control: the velocity overload (:652-708) then the pose overload (:712-744)
+    def update_manual(self):   # WalkController::updateManual: the velocity overload (:652-708) then the pose overload (:712-744)
         P = self.P
+        joint_control = P.get("leg_manipulation_mode") == "joint_control"
         for i, leg in enumerate(self.legs):
             if leg.leg_state != 1:
                 continue
@@ -706,14 +712,25 @@ class RefWalker:
                 vel, pos = self.primary_velocity, self.primary_position
             elif i == self.secondary_leg:
                 vel, pos = self.secondary_velocity, self.secondary_position
+            if joint_control:
+                # :677-690 ("HACK", 3-joint legs only): y / x inputs step the coxa / tibia joints; applyFK(false) moves the joint transforms and
+                # returns the tip pose they give - the stepper takes it WITH its rotation - while Leg::current_tip_pose_ stays what it was.
+                # The pose overload needs tip_control (:733).
+                if np.linalg.norm(vel) != 0.0 and len(self.q[i]) == 3:
+                    leg.held = (fk_tip(i, self.q[i]), tip_axis(i, self.q[i]))
+                    self.q[i] = self.q[i].copy()
+                    self.q[i][0] += vel[1] * P["max_rotation_velocity"] * self.dt
+                    self.q[i][2] += vel[0] * P["max_rotation_velocity"] * self.dt
+                    leg.tip, leg.cur_dir, leg.rot_defined = fk_tip(i, self.q[i]), tip_axis(i, self.q[i]), True
+                continue
             if np.linalg.norm(vel) != 0.0:
                 ik_error = leg.desired_tip - leg.model_tip
                 change = vel * P["max_translation_velocity"] * self.dt
                 if np.linalg.norm(ik_error) >= 0.005:
                     change = np.linalg.norm(change) * -(ik_error / np.linalg.norm(ik_error))
-                leg.tip = leg.tip + change
+                leg.tip, leg.rot_defined = leg.tip + change, False
             if np.linalg.norm(pos) != 0.0:
-                leg.tip = np.array(pos, dtype=float)
+                leg.tip, leg.rot_defined = np.array(pos, dtype=float), False
 
     def update_tip_align_pose(self):   # PoseController::updateTipAlignPose (:1024-1088): legs in id order, each on the pose the previous one left
         P = self.P
@@ -846,10 +863,11 @@ class RefWalker:
                 ddir = pose.r.inv().apply(leg.cur_dir) if leg.rot_defined else None   # pose.rotation^-1 * walker tip rotation (:129-130)
                 delta = adm[i]
                 if leg.leg_state in (1, -1):                              # MANUAL / WALKING_TO_MANUAL: no posing (:134-137), no delta (model.cpp:655-656)
-                    poser_tip, ddir, delta = leg.tip.copy(), None, np.zeros(3)
+                    poser_tip, ddir, delta = leg.tip.copy(), (leg.cur_dir if leg.rot_defined else None), np.zeros(3)
                 leg.poser_tip = poser_tip
                 leg.desired_tip = poser_tip + delta
-                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + delta, self.dt, ddir)  # setDesiredTipPose(.., apply_delta)
+                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + delta, self.dt, ddir, held=leg.held)  # setDesiredTipPose(.., apply_delta)
+                leg.held = None
                 leg.model_tip = fk_tip(i, self.q[i])                                                     # applyFK closes applyIK
                 leg.model_dir = tip_axis(i, self.q[i])
                 tip_force_estimate(i, self.q[i], self.efforts[i], self.tip_force_calc[i], self.P.get("force_gain", 0.1))   # ... and calculateTipForce

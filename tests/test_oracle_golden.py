@@ -339,15 +339,20 @@ def test_startup_sequence_trajectories(start):
           f"{int(g[pre + 'transition_steps'][0])} transition steps learnt, {int(g[pre + 'proximity_alerts'][0])} workspace alerts, max |joint diff| {worst:.2e} rad")
 
 
-def test_manual_leg_trajectories():
+@pytest.mark.parametrize("mode", ["tip_control", "joint_control"])
+def test_manual_leg_trajectories(mode):
     """Manual leg manipulation (legStateToggle, poseForLegManipulation, updateManual x 2, the manual-leg cases of updateStance /
     setDesiredTipPose / stepToPosition) against the independent numpy restatement of tests/golden/make_manual_golden.py, loop by
     loop: request results exactly; joints to 1e-6 rad while the robot walks, 5e-3 once it stands (free-running: the reference's
-    IK step amplifies rounding differences on a standing robot)."""
+    IK step amplifies rounding differences on a standing robot).  joint_control: the velocity inputs step the
+    coxa / tibia joints and every applyIK of the MANUAL leg is rotation-constrained from the tip pose of before the step."""
     from oracle_lib import OracleBatch
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manual_golden.npz"))
+    if mode == "joint_control":
+        g = {k[3:]: g[k] for k in g.files if k.startswith("jc_")}
     p = _golden_hexapod_params("tripod")
     p.admittance_control = 1
+    p.leg_manipulation_mode = 1 if mode == "joint_control" else 0
     ob = OracleBatch(p, 1)
     assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
     ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
@@ -370,7 +375,7 @@ def test_manual_leg_trajectories():
             worst_walk = max(worst_walk, d)
         assert worst_walk < 1e-6 and worst_stand < 5e-3, (k, kind, worst_walk, worst_stand)
     assert ob.body_state()[2][0] != 3 and (ob.leg_manipulation_state() == 0).all()
-    print(f"manual legs: {len(g['loops'])} loops, max |joint diff| {worst_walk:.2e} rad walking, {worst_stand:.2e} rad after the first stop")
+    print(f"manual legs ({mode}): {len(g['loops'])} loops, max |joint diff| {worst_walk:.2e} rad walking, {worst_stand:.2e} rad after the first stop")
 
 
 def test_planner_trajectories():
