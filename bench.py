@@ -170,9 +170,13 @@ def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, ho
     device-side wait for that cycle (shc_engine_resident_get_joint_state_async) before the first tick, so only its execution - not
     its launch - follows the last cycle; the closing bracket is the synchronisation of that stream.
     Returns (elapsed seconds for `steps` cycles, seconds per cycle of one long launch from HIP events on the launch stream)."""
+    import ctypes
     import torch
     eng.resident_begin(ring_depth=depth, max_cycles=warmup + steps + 8)
-    eng.resident_publish(max(warmup, 1))
+    # the tick as the node's loop would issue it: one C call (bound once - attribute lookups and argument conversion of the Python wrapper
+    # cost as much as a 3 us cycle); return codes are checked after the region
+    tick, handle, one = eng.L.shc_engine_resident_publish, eng.h, ctypes.c_int64(1)
+    rcs = [tick(handle, one) for _ in range(max(warmup, 1))]     # the warm-up steps, tick by tick like the timed ones
     eng.resident_wait(max(warmup, 1))
     if final_gather:
         # launched ahead like a captured graph: the device holds the read (and the collective behind it) until the last cycle of the
@@ -182,12 +186,13 @@ def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, ho
         host_barrier()               # ranks enter the region together (a host-side barrier: the loop kernel is alive, no device-wide sync)
     t0 = time.perf_counter()
     for _ in range(steps):
-        eng.resident_publish(1)      # one tick = one cycle; the host does not wait for it
+        rcs.append(tick(handle, one))   # one tick = one cycle; the host does not wait for it
     if final_gather:
         stream.synchronize()         # the gathered buffer is complete: every rank's last cycle has run
     else:
         eng.resident_wait(max(warmup, 1) + steps, 60000)
     elapsed = time.perf_counter() - t0
+    assert not any(rcs), "shc_engine_resident_publish failed"
     eng.resident_end()
     # kernel time per cycle: one launch of m cycles released at once, HIP events on the launch stream around it
     m = 4000
