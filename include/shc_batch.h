@@ -40,7 +40,7 @@ enum {
   SHC_ERR_NO_DEVICE = 2,      /* no HIP device / kernel image: the product path never falls back to CPU */
   SHC_ERR_HIP = 3,
   SHC_ERR_UNSUPPORTED = 4,    /* outside the accelerated path: gravity_aligned_tips on a robot whose legs differ in DOF, sequences with
-                                 own-clock auto posing, joint_control leg manipulation on such a robot, resident mode for a batch that does not fit the chip */
+                                 own-clock auto posing, resident mode for a batch that does not fit the chip */
   SHC_ERR_UNSTABLE = 5,       /* reserved: the reference aborts when the IMU correction's norm exceeds 100 rad
                                  (pose_controller.cpp:1228-1232); after its own clamps (:1222-1226) that needs
                                  max_rotation > 100 rad, so no entry point returns this code today */
@@ -535,8 +535,7 @@ int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress);
  *       is frozen (updateWalk returns at walk_controller.cpp:503); MANUAL / WALKING_TO_MANUAL legs are not posed (updateStance).
  *       Every posing mode (walk-plane, manual, inclination, IMU, auto) keeps running for the robots that stand during the call - the
  *       posing part of their loop (state_controller.cpp:165-181) is a pose-only pass of the cycle kernel.  With the experimental
- *       tip-align pose (gravity_aligned_tips on <= 3-DOF legs), or leg_manipulation_mode joint_control on a robot whose legs differ in
- *       DOF: SHC_ERR_UNSUPPORTED.
+ *       tip-align pose (gravity_aligned_tips on <= 3-DOF legs): SHC_ERR_UNSUPPORTED.
  *   shc_engine_set_manual_inputs  primary / secondary leg selection [n] (-1 = LEG_UNDESIGNATED) with their tip velocity inputs
  *       [n][3] (updateManual(.., tip_velocity_input, ..): tip_control moves the tip, joint_control the coxa / tibia joints of
  *       3-DOF legs - whose stepper then holds the FK tip pose WITH its rotation, so that applyIK runs rotation-constrained on them

@@ -87,7 +87,8 @@ struct CycleParams {
   int32_t rough_terrain;         // rough_terrain_mode (generic kernel): default tips follow the terrain, targets meet the step surface
   int32_t tip_align;             // gravity_aligned_tips with <= 3 DOF legs: PoseController::updateTipAlignPose (generic kernel)
   int32_t gravity_target;        // gravity_aligned_tips (> 3 DOF): an UNDEFINED target rotation is re-assigned from Model::estimateGravity (:1197-1205)
-  int32_t joint_control;         // leg_manipulation_mode joint_control: updateManual's velocity inputs move the coxa / tibia joints of 3-joint legs (:677-690)
+  int32_t joint_control;         // leg_manipulation_mode joint_control: updateManual's velocity inputs move the coxa / tibia joints of 3-joint legs (:677-690);
+                                 // 2: the robot has such legs (their tip rotations are tracked), 1: it has none (the inputs do nothing)
   double step_depth;             // walk_controller.h:80
   double target_dir[3];          // x axis of the identity tip rotation FromTwoVectors(x, -z) (walk_controller.cpp:37-41)
   double max_translation[3], max_rotation[3], max_translation_velocity, max_rotation_velocity;
@@ -1330,7 +1331,9 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       // pose becomes the FK tip pose of the moved joints WITH its rotation, so the applyIK that follows is rotation-constrained and
       // starts from the tip pose the leg had before (Leg::applyFK(false) moves the joint transforms only).  Legs of other joint
       // counts ignore the input.
-      if constexpr (NJ == 3 && rot_on) {
+      bool three_joints = NJ == 3; // (a robot whose legs differ in DOF: the padded joints of a shorter leg are inactive)
+      if constexpr (NJ > 3) three_joints = lc.jactive[3] == 0.0;
+      if constexpr (rot_on) if (three_joints) {
         Chain<NJ> ch;
         chain_from_sincos<NJ>(lc, s.sn, s.cs, ch);
         fb.joint_moved = true;
@@ -1435,7 +1438,7 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
       V3 current_dir = chain.xe;
       double dq[NJ];
       V3 lin[NJ];
-      if ((F & F_MLEGS) != 0 && NJ == 3 && fb.joint_moved) { // the Jacobian of the moved joints, the tip pose of before the move
+      if ((F & F_MLEGS) != 0 && fb.joint_moved) { // the Jacobian of the moved joints, the tip pose of before the move
         current_dir = base_rotate_inv(lc, fb.held_dir);
         jacobian_columns<NJ>(chain, lin);
         ik_step_cols<NJ>(lc, lin, fb.held_pe, s.q, s.qd, desired, dq);

@@ -51,7 +51,9 @@ static void launch_cycle_feat(const CycleLaunch &a) {
   const bool rough = c.rough_terrain != 0, talign = c.tip_align != 0, mlegs = (a.rt_flags & RT_MANUAL_LEGS) != 0;
   const bool terrain = rough || talign || mlegs;
   if constexpr (NJ > 3) {
-    if (c.gravity_aligned) { // gravity-aligned tips: kernels with the tip-rotation logic compiled in
+    // gravity-aligned tips: kernels with the tip-rotation logic compiled in; also a robot with 3-joint legs next to longer ones under
+    // joint_control leg manipulation (a MANUAL 3-joint leg holds its FK tip rotation), once a leg has been toggled
+    if (c.gravity_aligned || (mlegs && c.joint_control == 2)) {
       if constexpr (SPEC) {  // default.yaml's posing set: feature-exact
         constexpr unsigned C2 = F_MANUAL | F_ODOM;
         if (!a.generic && !terrain && (f & ~F_TIPF) == C2) {
@@ -68,7 +70,7 @@ static void launch_cycle_feat(const CycleLaunch &a) {
   if constexpr (NJ == 3) {
     // joint_control leg manipulation (3-joint legs): a MANUAL leg's tip pose carries its FK rotation, the rotation-constrained IK runs on
     // it (walk_controller.cpp:677-690); only once a leg has been toggled
-    if (mlegs && c.joint_control) {
+    if (mlegs && c.joint_control == 2) {
       if (rough || talign) launch_cycle<L, NJ, F_DYN | F_ROT | F_TERRAIN>(a);
       else launch_cycle<L, NJ, F_DYN | F_ROT | F_MLEGS>(a);
       return;

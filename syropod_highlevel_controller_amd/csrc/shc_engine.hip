@@ -352,7 +352,7 @@ static bool mixed_dof(const shc_params &p) {
 }
 // Tip rotations are part of the state: legs of more than 3 joints with gravity-aligned tips / in rough terrain mode, or 3-joint legs that
 // joint_control leg manipulation hands their FK tip pose to (walk_controller.cpp:677-690).
-static int rotations_tracked(const shc_engine *e) { return (e->cp.gravity_aligned || (e->cp.joint_control && max_dof(e->params) == 3)) ? 1 : 0; }
+static int rotations_tracked(const shc_engine *e) { return (e->cp.gravity_aligned || e->cp.joint_control == 2) ? 1 : 0; }
 // ... and the parameter block the engine keeps has neutral entries for the padding (joint arrays of the ABI are [legs][longest leg's DOF]:
 // the padded joints read 0 and ignore what is written to them)
 static shc_params normalised_params(const shc_params &in) {
@@ -414,7 +414,12 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.odometry = (features & SHC_FEAT_ODOMETRY) ? 1 : 0;
   c.gravity_aligned = hostinit::tips_rotation_tracked(p, max_dof(p)) ? 1 : 0;
   c.gravity_target = hostinit::tips_rotation_constrained(p, max_dof(p)) ? 1 : 0;
-  c.joint_control = p.leg_manipulation_mode == SHC_MANIPULATION_JOINT_CONTROL ? 1 : 0;
+  c.joint_control = 0;
+  if (p.leg_manipulation_mode == SHC_MANIPULATION_JOINT_CONTROL) {
+    c.joint_control = 1;
+    for (int l = 0; l < p.leg_count; ++l)
+      if (p.leg_dof[l] == 3) c.joint_control = 2; // (walk_controller.cpp:677: "works only for 3DOF legs")
+  }
   c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
   c.tip_align = (p.gravity_aligned_tips && max_dof(p) <= 3) ? 1 : 0; // pose_controller.cpp:849 (leg 0's joint count; mixed DOF + gravity_aligned_tips is rejected)
   c.step_depth = p.step_depth;
@@ -2280,11 +2285,6 @@ static int ensure_manual(shc_engine *e, bool planner = false) {
   const shc_params &p = e->params;
   if (e->cp.tip_align)
     return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with the tip-align pose (gravity_aligned_tips on <= 3-DOF legs)");
-  if (!planner && p.leg_manipulation_mode == SHC_MANIPULATION_JOINT_CONTROL && mixed_dof(p)) {
-    // joint_control moves the joints of 3-joint legs only (walk_controller.cpp:677) and hands their FK tip pose WITH its rotation to the
-    // stepper: the kernels track tip rotations per morphology, not per leg
-    return fail(SHC_ERR_UNSUPPORTED, "leg_manipulation_mode joint_control on a robot whose legs differ in DOF");
-  }
   HIP_TRY(hipSetDevice(e->device));
   if (!e->st.manual) {
     HIP_TRY(hipMalloc(&e->st.manual, sizeof(ManualRobot) * size_t(e->n_rob_pad)));

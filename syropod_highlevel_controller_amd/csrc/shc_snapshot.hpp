@@ -113,7 +113,7 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
     } else if (pm == PM_STOP) {
       g.stance_progress = 0.0;
     }
-    if (P.gravity_aligned || P.joint_control) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
+    if (P.gravity_aligned || P.joint_control == 2) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
       for (int k = 0; k < 3; ++k) {
         g.origin_tip_direction[k] = f(FD::ORG_DIR + k);
         g.walker_tip_direction[k] = f(FD::CUR_DIR + k);
@@ -198,7 +198,7 @@ __global__ void set_state_kernel(const shc_instance_state *in, DevState st, Cycl
     else if (g.stance_progress == 0.0) pm = PM_STOP;
     int w = (g.step_state & 3) | (g.at_correct_phase ? LW_ACP : 0) | (g.completed_first_step ? LW_CFS : 0) | (pm << LW_PM_SHIFT) |
             (g.negate_auto_pose ? LW_NEG : 0) | (g.ik_failed ? LW_IKFAIL : 0) | ((g.phase & LW_PHASE_MASK) << LW_PHASE_SHIFT);
-    if (P.gravity_aligned || P.joint_control) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
+    if (P.gravity_aligned || P.joint_control == 2) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
       for (int k = 0; k < 3; ++k) {
         f(FD::ORG_DIR + k, g.origin_tip_direction[k]);
         f(FD::CUR_DIR + k, g.walker_tip_direction[k]);

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("case", ["hexapod-tip-control", "8x4-tip-control", "hexapod-dynamic-stiffness", "8x5-gravity-aligned",
                                   "hexapod-imu-posing", "hexapod-auto-and-inclination-posing", "hexapod-imu-admittance", "mixed-dof-354354",
-                                  "hexapod-joint-control", "8x4-joint-control"])
+                                  "hexapod-joint-control", "8x4-joint-control", "mixed-dof-354354-joint-control"])
 def test_toggle_manipulate_and_return(case):
     """Walk; request a leg toggle per robot (different legs, two robots none): robots still walking are told to stop first
     (result -1), then the designated leg goes WALKING -> WALKING_TO_MANUAL -> MANUAL while every leg steps to its manipulation
@@ -183,17 +183,12 @@ def test_toggle_manipulate_and_return(case):
 
 
 def test_manual_legs_unsupported_configurations():
-    """Outside the accelerated envelope: the experimental tip-align pose (gravity_aligned_tips on 3-DOF legs) and joint_control on a robot
-    whose legs differ in DOF (tip rotations are tracked per morphology)."""
-    from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
+    """Outside the accelerated envelope: the experimental tip-align pose (gravity_aligned_tips on 3-DOF legs)."""
     p = default_hexapod_params("tripod")
     p.gravity_aligned_tips = 1
-    q = synthetic_mixed_dof_params("ripple")
-    q.leg_manipulation_mode = 1
-    for params in (p, q):
-        eng = BatchEngine(params, 2)
-        with pytest.raises(RuntimeError):
-            eng.toggle_leg_state(np.array([0, -1], dtype=np.int32))
+    eng = BatchEngine(p, 2)
+    with pytest.raises(RuntimeError):
+        eng.toggle_leg_state(np.array([0, -1], dtype=np.int32))
 
 
 @pytest.mark.parametrize("case", ["8x5-gravity-aligned", "hexapod-joint-control"])
@@ -253,12 +248,15 @@ def test_toggle_and_manipulate_free_running(case):
         assert np.abs(eng.joints()[0] - ob.joints()[0]).max() < 1e-6
 
 
-def test_complete_checkpoint_carries_a_manual_leg_into_another_engine():
+@pytest.mark.parametrize("mode", ["tip_control", "joint_control"])
+def test_complete_checkpoint_carries_a_manual_leg_into_another_engine(mode):
     """shc_engine_get_state alone is the control cycle's state; a complete checkpoint adds shc_engine_get_aux_state (manual-leg records,
     Leg::desired_tip_pose_, reset mode, external / sequence records).  A robot with a MANUAL leg restored into a fresh engine from both
-    goes on byte for byte like the original - and demonstrably not from the first alone."""
+    goes on byte for byte like the original - and demonstrably not from the first alone.  joint_control: the FK tip rotation the MANUAL
+    leg's stepper holds travels in the state record (tip_rotation_defined + walker_tip_direction)."""
     p = default_hexapod_params("tripod")
     p.admittance_control = 1
+    p.leg_manipulation_mode = 1 if mode == "joint_control" else 0
     n, L = 12, p.leg_count
     rng = np.random.default_rng(4)
     a = BatchEngine(p, n)
