@@ -164,6 +164,39 @@ def resident_bytes_per_cycle(p):
     return 24 + 2 * p.leg_count * p.leg_dof[0] * 8
 
 
+class HostSpinBarrier:
+    """Ranks of one node meet on a page of /dev/shm: every rank publishes its epoch and spins until all have (sub-microsecond skew - a
+    20-step region is 85 us long, a socket barrier's release skew would be a good part of it).  Built around two RCCL barriers, so
+    only while no resident loop is alive; used while one is.  Gives up after 10 s (the ranks then enter the region as they come)."""
+
+    def __init__(self, world, rank):
+        import torch.distributed as dist
+        self.world, self.rank, self.epoch = world, rank, 0
+        self.path = f"/dev/shm/shc_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}"
+        self.slots = None
+        try:
+            if rank == 0:
+                np.memmap(self.path, dtype=np.int64, mode="w+", shape=(world,)).flush()
+            dist.barrier()
+            self.slots = np.asarray(np.memmap(self.path, dtype=np.int64, mode="r+", shape=(world,)))   # (a plain ndarray view: memmap's own operators are slow)
+            dist.barrier()
+            if rank == 0:
+                os.unlink(self.path)    # the mappings keep the page alive; nothing is left behind
+        except OSError:
+            self.slots = None
+
+    def __call__(self):
+        if self.slots is None:
+            return
+        self.epoch += 1
+        self.slots[self.rank] = self.epoch
+        slots, epoch, t_end = self.slots, self.epoch, time.perf_counter() + 10.0
+        while slots.min() < epoch:
+            if time.perf_counter() > t_end:
+                self.slots = None
+                return
+
+
 def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, host_barrier=None):
     """Timed region of resident mode: `steps` ticks of the doorbell, one control cycle each, bracketed by synchronisation.
     N > 1 (final_gather): the region ends with the all-gather of the LAST cycle's joints.  It is queued on the engine's stream behind a
@@ -176,6 +209,8 @@ def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, ho
     # the tick as the node's loop would issue it: one C call (bound once - attribute lookups and argument conversion of the Python wrapper
     # cost as much as a 3 us cycle); return codes are checked after the region
     tick, handle, one = eng.L.shc_engine_resident_publish, eng.h, ctypes.c_int64(1)
+    if host_barrier:
+        host_barrier()               # (a first meeting outside the region: the ranks start their warm-up together, the barrier's own code is warm)
     rcs = [tick(handle, one) for _ in range(max(warmup, 1))]     # the warm-up steps, tick by tick like the timed ones
     eng.resident_wait(max(warmup, 1))
     if final_gather:
@@ -281,12 +316,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     if use_dist:
         gather()
         dist.barrier()
-        try:    # host-side barriers while a resident loop is alive (no device-wide synchronisation may be issued then)
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # one node: the loopback interface (the hostname may not resolve)
-            cpu_group = dist.new_group(backend="gloo")
-            host_barrier = lambda: dist.barrier(group=cpu_group)  # noqa: E731
-        except Exception:  # noqa: BLE001 - without one the ranks enter the region as they come (the closing all-gather still joins them)
-            host_barrier = None
+        host_barrier = HostSpinBarrier(world, rank)   # while a resident loop is alive no device-wide synchronisation may be issued
     if resident:   # the launch-per-cycle figure of the same engine first (secondary), then the resident one
         for _ in range(warmup):
             step_once()
