@@ -73,3 +73,36 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     gathered = np.load(out).reshape(N_TOTAL, -1)
     full = _run_shard(0, N_TOTAL)
     assert np.array_equal(gathered, full)  # same binary, same inputs: bit-identical
+
+
+def _barrier_worker(rank, world, port, out_dir):
+    import sys
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    barrier = bench.HostSpinBarrier(world, rank)
+    assert barrier.slots is not None and not os.path.exists(barrier.path)   # the page lives in the mappings only
+    stamps = []
+    for k in range(6):
+        time.sleep(0.003 * ((rank + k) % world))   # the ranks arrive at different times ...
+        before = time.perf_counter()
+        barrier()
+        stamps.append((before, time.perf_counter()))
+    np.save(os.path.join(out_dir, f"stamps{rank}.npy"), np.array(stamps))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_host_spin_barrier_of_the_resident_region(tmp_path):
+    """bench.py --gpus N lines its ranks up in front of the resident-mode region on a shared /dev/shm page (a resident loop is alive
+    there: no device-wide synchronisation, and a socket barrier's release skew would be a good part of an 85 us region): nobody
+    leaves a meeting before the last rank has arrived, everybody leaves within a fraction of a millisecond of it."""
+    world = 2
+    mp.spawn(_barrier_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    s = np.stack([np.load(str(tmp_path / f"stamps{r}.npy")) for r in range(world)])   # [rank][meeting][arrived, left] (CLOCK_MONOTONIC: one clock for all)
+    last_arrival = s[:, :, 0].max(axis=0)
+    assert (s[:, :, 1] >= last_arrival[None, :]).all()
+    assert (s[:, 1:, 1] - last_arrival[None, 1:]).max() < 1e-3
