@@ -356,6 +356,7 @@ class RefWalker:
         self.legs = [Leg(xy) for xy in P["stance_position"]]
         self.L = len(self.legs)
         self.limits = limits  # dict of four 9-entry tables (bearing 0, 45, .. 360)
+        self.workspaces = None  # per leg {height: {bearing: radius}} (Leg::generateWorkspace), scenarios with a stance span modifier
         self.walk_state = STOPPED
         self.pose_state = POSING_COMPLETE
         self.v = np.zeros(2)
@@ -459,11 +460,35 @@ class RefWalker:
         leg.stride = stride * ((self.stance_period / self.period) / self.frequency)
         leg.swing_clearance = self.P["swing_height"] * leg.walk_plane_normal / np.linalg.norm(leg.walk_plane_normal)
 
+    def stance_span_change(self, leg):
+        """LegStepper::calculateStanceSpanChange (:949-980): the identity tip is shifted sideways by stance_span_modifier times the workspace
+        radius towards / away from the body, at the height the default tip has drifted to (interpolated between the bounding workplanes of
+        a layered workspace; the single plane of a simple one)."""
+        m = self.P.get("stance_span_modifier", 0.0)
+        ws = self.workspaces[self.legs.index(leg)]           # {height: {bearing: radius}}
+        target = round_to_int((leg.default - leg.identity)[2] * 1000.0) / 1000.0       # setPrecision(.., 3)
+        heights = sorted(ws)
+        positive_y = leg.identity[1] > 0.0
+        bearing = 270 if (positive_y ^ (m > 0.0)) else 90
+        m = m * (1.0 if positive_y else -1.0)
+        if len(heights) == 1:
+            radius = ws[0.0][bearing]
+        else:
+            ub = next(k for k, h in enumerate(heights) if h > target)                   # map::upper_bound, then prev()
+            hi, lo = heights[ub], heights[ub - 1]
+            hi3, lo3 = round_to_int(hi * 1000.0) / 1000.0, round_to_int(lo * 1000.0) / 1000.0
+            i = (target - lo3) / (hi3 - lo3)
+            radius = ws[lo][bearing] * (1.0 - i) + ws[hi][bearing] * i
+        return np.array([0.0, radius * m, 0.0])
+
     def update_default_tip(self, leg):
         if leg.ext_default is not None:          # external_default_.pose_.removePose(external_default_.transform_) (:988-990)
             leg.default = remove_pose(leg.ext_default["pose"], leg.ext_default["transform"]).p
             return
-        ident = self.walk_plane_pose.p + self.walk_plane_pose.r.apply(leg.identity)   # getDefaultBodyPose().transformVector
+        identity = leg.identity
+        if self.P.get("stance_span_modifier", 0.0) != 0.0 or self.workspaces is not None:
+            identity = identity + self.stance_span_change(leg)
+        ident = self.walk_plane_pose.p + self.walk_plane_pose.r.apply(identity)   # getDefaultBodyPose().transformVector
         leg.default = ident + projection(leg.stance_origin - ident, leg.walk_plane_normal)
 
     def update_tip_position(self, leg):
@@ -939,6 +964,14 @@ def init_chain_of(gait, morphology=None, rough=0, gravity=0):
     return np.array(r["q0"]), {k: [float(x) for x in v] for k, v in r["limits"].items()}
 
 
+def workspaces_of(gait, morphology=None, rough=0, gravity=0):
+    """Per leg {height: {bearing: radius}}: Leg::generateWorkspace of the numpy init chain (the single plane, or the layered workspace)."""
+    global _MI
+    if _MI is None:
+        _MI = init_chain_module()
+    return _MI.init_chain(gait, morphology, bool(rough), START_UP_TIME, gravity=bool(gravity))["workspaces"]
+
+
 def started_walker(P, gait="tripod"):
     """A default-hexapod RefWalker as it stands when it has entered RUNNING: joints from the numpy init chain's direct start-up, then the
     loop that enters RUNNING (one cycle with zero inputs, state_controller.cpp:277-281, :189-192).  For the sibling generators."""
@@ -988,6 +1021,11 @@ SCENARIOS = {
     # hollows under legs 1 / 4) drive touchdown detection, the proactive target shift and the ground-contact swing nodes
     "tripod_rough_contacts": ("tripod", {"rough_terrain_mode": 1, "step_depth": 0.004, "model": 1, "contacts": 1}, [(0, (0.45, 0.1), 0.15), (420, (0, 0), 0.0)], 600),
     # rough terrain mode without the kinematic model in the loop: requested targets / default poses, and the reactive step depth
+    # stance_span_modifier: updateDefaultTipPosition shifts the identity tips sideways by a share of the workspace radius - at every stop on
+    # the single plane (calculateStanceSpanChange, :949-980), at every swing / stance start on the layered workspace of rough terrain mode
+    "tripod_wider_stance_span": ("tripod", {"stance_span_modifier": 0.3, "model": 1}, [(0, (0.5, 0.1), 0.2), (200, (0, 0), 0.0), (420, (0.3, -0.3), -0.3), (640, (0, 0), 0.0)], 800),
+    "ripple_rough_narrower_stance_span": ("ripple", {"rough_terrain_mode": 1, "step_depth": 0.004, "stance_span_modifier": -0.25, "model": 1},
+                                          [(0, (0.4, -0.1), 0.2), (330, (0, 0), 0.0)], 500),
     "tripod_rough_external_requests": ("tripod", {"rough_terrain_mode": 1}, [(0, (0.5, 0.1), 0.2), (330, (0, 0), 0.0)], 520),
     "ripple_rough_reactive_step_depth": ("ripple", {"rough_terrain_mode": 1, "step_depth": 0.004}, [(0, (0.3, -0.2), -0.3)], 260),
 }
@@ -1035,6 +1073,8 @@ def run(name):
             "step_depth": P["step_depth"], "gravity_aligned_tips": int(bool(P.get("gravity_aligned_tips")))}
     q_startup, limits = init_chain_of(gait, morphology, prod["rough_terrain_mode"], prod["gravity_aligned_tips"])
     w = RefWalker(P, limits)
+    if P.get("stance_span_modifier"):
+        w.workspaces = workspaces_of(gait, morphology, prod["rough_terrain_mode"], prod["gravity_aligned_tips"])
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[], gait_request=[])
