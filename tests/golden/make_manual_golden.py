@@ -16,7 +16,9 @@ hand leg 2 over (stops, poses, MANUAL), the leg follows tip-velocity and tip-pos
 a second leg follows, a third is refused, both come back, the robot walks again.  Recorded per loop: its kind, the request's result,
 joints.  joint_control (keys jc_*): the velocity inputs step the coxa / tibia joints, the stepper holds the FK tip pose with its
 rotation, every applyIK of the leg is rotation-constrained (walk_controller.cpp:677-690, model.cpp:880-900); the position inputs are
-ignored; inputs withdrawn for a while.
+ignored; inputs withdrawn for a while.  IMU + inclination posing (keys imu_*): the tip_control scenario with the body pose moving under
+the standing robot (IMU PID, the inclination translation poseForLegManipulation adds for the lifted leg, :572), a new IMU reading
+every 20 loops (columns 17-23 of a loop row: orientation wxyz, angular velocity).
 
 tests/test_oracle_golden.py::test_manual_leg_trajectories replays the loops on the oracle: results exactly, joints to 1e-6 rad
 wherever the robot walks and 5e-3 while it stands (where the reference's IK step amplifies rounding differences).
@@ -65,7 +67,7 @@ class Toggler:
         for i, leg in enumerate(w.legs):
             step_height, step_time = P["swing_height"], 1.0 / P["step_frequency"]
             if leg.leg_state == W2M:
-                tp, tr = np.array([0.0, 0.0, -step_height]), None             # Identity (+ inclination pose: none here), lowered by the step height
+                tp, tr = w.inclination.p + np.array([0.0, 0.0, -step_height]), None   # Identity + inclination_pose_.position_, lowered by the step height
                 target = leg.default - tp
             else:
                 tp = pose.p - w.manual_pose.p                                   # current pose, manual pose removed, default pose (identity) added
@@ -121,10 +123,12 @@ class Toggler:
         return 0, lin, ang
 
 
-def run(mode="tip_control"):
+def run(mode="tip_control", posing=False):
     import zlib
     gait = "tripod"
     P = mw.hexapod(gait, admittance_control=1, manual_posing=1, leg_manipulation_mode=mode)
+    if posing:                                   # the body pose keeps moving while the robot stands: IMU PID + the inclination translation
+        P.update(imu_posing=1, inclination_posing=1)
     w = mw.started_walker(P, gait)               # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
     q0, qd0 = w.q.copy(), w.qd.copy()
     w.tip_force = np.tile(np.array([0.0, 0.0, 4.0]), (6, 1))
@@ -135,18 +139,31 @@ def run(mode="tip_control"):
     lin, ang = (0.4, 0.15), 0.2
     inputs = dict(primary=-1, pv=np.zeros(3), pp=np.zeros(3), secondary=-1, sv=np.zeros(3))
 
+    imu = dict(q=np.array([1.0, 0, 0, 0]), gyro=np.zeros(3), loops=0)
+
     def record(kind, leg, result):
-        loops.append([kind, leg, result, lin[0], lin[1], ang, inputs["primary"], *inputs["pv"], *inputs["pp"], inputs["secondary"], *inputs["sv"]])
+        loops.append([kind, leg, result, lin[0], lin[1], ang, inputs["primary"], *inputs["pv"], *inputs["pp"], inputs["secondary"], *inputs["sv"],
+                      *imu["q"], *imu["gyro"]])
         joints.append(w.q.copy())
+
+    def imu_sample():                              # a new IMU reading every 20 loops: the slope changes under the standing robot
+        if posing and imu["loops"] % 20 == 0:
+            e = [rng.uniform(-0.12, 0.12), rng.uniform(-0.12, 0.12), 0.0]
+            w.imu_q, w.gyro = mw.euler_to_rot(e), rng.normal(0, 0.03, 3)
+            x = w.imu_q.as_quat()
+            imu["q"], imu["gyro"] = np.array([x[3], x[0], x[1], x[2]]), w.gyro.copy()
+        imu["loops"] += 1
 
     def cycles(k):
         for _ in range(k):
+            imu_sample()
             w.cycle(lin, ang)
             record(0, -1, 0)
 
     def toggle(leg_id):
         nonlocal lin, ang
         for _ in range(4000):
+            imu_sample()
             result, lin, ang = t.loop(leg_id, lin, ang)
             record(1, leg_id, result)
             if result in (1, 2):
@@ -190,7 +207,8 @@ if __name__ == "__main__":
     out = run()
     jc = run("joint_control")
     out.update({"jc_" + k: v for k, v in jc.items()})
+    out.update({"imu_" + k: v for k, v in run(posing=True).items()})
     np.savez_compressed(os.path.join(HERE, "manual_golden.npz"), **out)
-    for pre in ("", "jc_"):
+    for pre in ("", "jc_", "imu_"):
         k = out[pre + "loops"]
         print(pre or "tip_control", "loops", len(k), "toggle loops", int((k[:, 0] == 1).sum()), "results", sorted(set(k[k[:, 0] == 1][:, 2].astype(int).tolist())))

@@ -381,6 +381,7 @@ class RefWalker:
         self.primary_leg = self.secondary_leg = -1
         self.primary_velocity = self.secondary_velocity = self.primary_position = self.secondary_position = np.zeros(3)
         self.tip_align_pose, self.origin_tip_align_pose = Pose(), Pose()
+        self.inclination = Pose()
         self.tvi, self.rvi = np.zeros(3), np.zeros(3)   # translation / rotation_velocity_input_ (rewritten by the reset modes)
         self.reset_mode = 0
         self.prev_auto_r = R.identity()
@@ -857,7 +858,8 @@ class RefWalker:
             self.update_manual_pose()
             pose = pose.add(self.manual_pose)
         if self.P.get("inclination_posing"):
-            pose = pose.add(self.inclination_pose())
+            self.inclination = self.inclination_pose()       # PoseController::inclination_pose_ (poseForLegManipulation reads it, :572)
+            pose = pose.add(self.inclination)
         if self.P.get("imu_posing"):
             pose = pose.add(self.imu_pose())
         elif self.P.get("auto_posing"):

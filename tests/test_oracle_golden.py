@@ -339,7 +339,7 @@ def test_startup_sequence_trajectories(start):
           f"{int(g[pre + 'transition_steps'][0])} transition steps learnt, {int(g[pre + 'proximity_alerts'][0])} workspace alerts, max |joint diff| {worst:.2e} rad")
 
 
-@pytest.mark.parametrize("mode", ["tip_control", "joint_control"])
+@pytest.mark.parametrize("mode", ["tip_control", "joint_control", "imu_and_inclination_posing"])
 def test_manual_leg_trajectories(mode):
     """Manual leg manipulation (legStateToggle, poseForLegManipulation, updateManual x 2, the manual-leg cases of updateStance /
     setDesiredTipPose / stepToPosition) against the independent numpy restatement of tests/golden/make_manual_golden.py, loop by
@@ -348,11 +348,17 @@ def test_manual_leg_trajectories(mode):
     coxa / tibia joints and every applyIK of the MANUAL leg is rotation-constrained from the tip pose of before the step."""
     from oracle_lib import OracleBatch
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manual_golden.npz"))
+    posing = mode == "imu_and_inclination_posing"   # the body pose moves under the standing robot: the posing part of every loop, toggle loops included
     if mode == "joint_control":
         g = {k[3:]: g[k] for k in g.files if k.startswith("jc_")}
+    elif posing:
+        g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
     p = _golden_hexapod_params("tripod")
     p.admittance_control = 1
     p.leg_manipulation_mode = 1 if mode == "joint_control" else 0
+    if posing:
+        p.imu_posing, p.inclination_posing = 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
     ob = OracleBatch(p, 1)
     assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
     ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
@@ -363,6 +369,8 @@ def test_manual_leg_trajectories(mode):
         ob.set_velocity(row[3:5][None], row[5:6])
         prim, sec = int(row[6]), int(row[13])
         ob.set_manual_inputs(np.array([prim], dtype=np.int32), row[7:10][None], row[10:13][None], np.array([sec], dtype=np.int32), row[14:17][None], None)
+        if posing:
+            ob.set_imu(row[17:21][None], row[21:24][None])
         if kind == 0:
             ob.step(1, 1)
         else:
