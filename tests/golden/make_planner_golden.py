@@ -12,7 +12,9 @@ Restated here, from the reference sources only (OpenSHC v0.5.11, paths relative 
   targetConfigurationCallback / targetBodyPoseCallback / targetTipPoseCallback for a robot that stands   src/state_controller.cpp:1683-1767
 One scenario: a default hexapod with admittance control and a steady 4 N on every tip walks, planner mode comes on (the robot is
 stopped, then waits), a joint configuration for four legs, a wait, tip targets for three legs (one with a lift, all through a tf
-transform) together with a body pose, a body pose alone.  Recorded per loop: executePlan's result, plan_step_, joints.
+transform) together with a body pose, a body pose alone.  Recorded per loop: executePlan's result, plan_step_, joints.  A second
+run (keys imu_*) executes the same plan under IMU + inclination posing with a new IMU reading every 20 loops: the pose moves under
+the robot while it stands, waits and transitions (a waiting robot's updateModel keeps the LegPoser tips of the last updateStance).
 
 tests/test_oracle_golden.py::test_planner_trajectories replays the loops on the oracle.
 """
@@ -139,23 +141,39 @@ class Planner:
         return progress
 
 
-def run():
+def run(posing=False):
+    import zlib
     gait = "tripod"
     P = mw.hexapod(gait, admittance_control=1, manual_posing=1)
+    if posing:                                   # the body pose keeps moving while the robot stands and waits: IMU PID + inclination translation
+        P.update(imu_posing=1, inclination_posing=1)
     w = mw.started_walker(P, gait)               # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
     q0, qd0 = w.q.copy(), w.qd.copy()
     w.tip_force = np.tile(np.array([0.0, 0.0, 4.0]), (6, 1))
     rows, joints, events = [], [], []
+    rng = np.random.default_rng(zlib.crc32(b"planner"))
+    imu = dict(q=[1.0, 0.0, 0.0, 0.0], gyro=[0.0, 0.0, 0.0], loops=0)
+
+    def imu_sample():                            # a new IMU reading every 20 loops (columns 3-9 of a row: orientation wxyz, angular velocity)
+        if posing and imu["loops"] % 20 == 0:
+            e = [rng.uniform(-0.12, 0.12), rng.uniform(-0.12, 0.12), 0.0]
+            w.imu_q, w.gyro = mw.euler_to_rot(e), rng.normal(0, 0.03, 3)
+            x = w.imu_q.as_quat()
+            imu["q"], imu["gyro"] = [x[3], x[0], x[1], x[2]], list(w.gyro)
+        imu["loops"] += 1
+
     for _ in range(60):
+        imu_sample()
         w.cycle((0.45, -0.1), 0.15)
-        rows.append([0, 0, 0])
+        rows.append([0, 0, 0, *imu["q"], *imu["gyro"]])
         joints.append(w.q.copy())
     pl = Planner(w)
 
     def loops_until(value, limit=2000):
         for _ in range(limit):
+            imu_sample()
             r = pl.loop()
-            rows.append([1, r, pl.plan_step])
+            rows.append([1, r, pl.plan_step, *imu["q"], *imu["gyro"]])
             joints.append(w.q.copy())
             if r == value:
                 return
@@ -191,7 +209,11 @@ def run():
 if __name__ == "__main__":
     import json
     out, events = run()
+    out2, events2 = run(posing=True)             # the same plan under IMU + inclination posing (keys imu_*)
+    out.update({"imu_" + k: v for k, v in out2.items()})
     np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
     json.dump(events, open(os.path.join(HERE, "planner_golden_events.json"), "w"), indent=1)
-    r = out["rows"]
-    print("loops", len(r), "plan results seen", sorted(set(r[r[:, 0] == 1][:, 1].astype(int).tolist()))[:6], "... final plan step", int(r[-1, 2]))
+    json.dump(events2, open(os.path.join(HERE, "planner_golden_events_imu.json"), "w"), indent=1)
+    for pre in ("", "imu_"):
+        r = out[pre + "rows"]
+        print(pre or "plain", "loops", len(r), "plan results seen", sorted(set(r[r[:, 0] == 1][:, 1].astype(int).tolist()))[:6], "... final plan step", int(r[-1, 2]))

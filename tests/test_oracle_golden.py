@@ -386,18 +386,27 @@ def test_manual_leg_trajectories(mode):
     print(f"manual legs ({mode}): {len(g['loops'])} loops, max |joint diff| {worst_walk:.2e} rad walking, {worst_stand:.2e} rad after the first stop")
 
 
-def test_planner_trajectories():
+@pytest.mark.parametrize("posing", ["walk_plane_posing", "imu_and_inclination_posing"])
+def test_planner_trajectories(posing):
     """Planner mode (executePlan, PoseController::transitionConfiguration / transitionStance, the LegPoser's external target)
     against the independent numpy restatement of tests/golden/make_planner_golden.py, loop by loop: executePlan's result and
-    plan_step_ exactly; joints free-running (tolerances below)."""
+    plan_step_ exactly; joints free-running (tolerances below).  The second run executes the plan under IMU + inclination posing:
+    the body pose moves under the robot while it stands, waits (updateModel on the LegPoser tips of the last updateStance) and
+    transitions."""
     import json
     from oracle_lib import OracleBatch
     from syropod_highlevel_controller_amd.params import ExternalTarget
     here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     g = np.load(os.path.join(here, "planner_golden.npz"))
-    events = {int(e[0]): e for e in json.load(open(os.path.join(here, "planner_golden_events.json")))}
+    imu = posing == "imu_and_inclination_posing"
+    if imu:
+        g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
+    events = {int(e[0]): e for e in json.load(open(os.path.join(here, "planner_golden_events_imu.json" if imu else "planner_golden_events.json")))}
     p = _golden_hexapod_params("tripod")
     p.admittance_control = 1
+    if imu:
+        p.imu_posing, p.inclination_posing = 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
     ob = OracleBatch(p, 1)
     assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
     ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
@@ -405,6 +414,8 @@ def test_planner_trajectories():
     worst_walk = worst_stand = 0.0
     planner_on = seen_crawl = stance_running = False
     for k, row in enumerate(g["rows"]):
+        if imu:
+            ob.set_imu(row[3:7][None], row[7:10][None])
         if k in events:
             _, kind, data = events[k]
             if kind == "configuration":
@@ -444,7 +455,7 @@ def test_planner_trajectories():
         else:
             worst_walk = max(worst_walk, d)
         assert worst_walk < 1e-8 and worst_stand < 5e-3, (k, worst_walk, worst_stand)
-    print(f"planner: {len(g['rows'])} loops, final plan step {int(g['rows'][-1, 2])}, max |joint diff| {worst_walk:.2e} rad up to the crawl at the end of the first stance step, {worst_stand:.2e} rad after")
+    print(f"planner ({posing}): {len(g['rows'])} loops, final plan step {int(g['rows'][-1, 2])}, max |joint diff| {worst_walk:.2e} rad up to the crawl at the end of the first stance step, {worst_stand:.2e} rad after")
 
 
 def test_step_to_new_stance_trajectory():
