@@ -557,6 +557,11 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
             double dpos[3], drot[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
+              // No contraction here: a component that a reset has driven onto its target must land ON it - cur + ((target - cur) / dt) * dt
+              // with separately rounded product and sum, as the reference's x86-64 build computes it - because the reset rewrites the
+              // velocity input from the SIGN of what is left (:905-925): an exact 0 leaves the input alone, a 1e-17 residue of a fused
+              // multiply-add would turn it into +-1, and that input drives the pose once the reset mode is released.
+#pragma clang fp contract(off)
               if (rt[i]) {
                 double diff = cpos[i] - 0.0;
                 if (diff < 0) tvi[i] = 1.0; else if (diff > 0) tvi[i] = -1.0;

@@ -1,0 +1,228 @@
+"""Replays of the committed golden fixtures (tests/golden/*.npz: independent numpy restatements of the reference, see the generators
+there) on anything with the batch interface - the CPU oracle (tests/test_oracle_golden.py) and the HIP engine (tests/test_gpu_golden.py).
+A backend is a function params -> (batch object of ONE instance, step()): OracleBatch and BatchEngine share every other call."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_hexapod_params(gait="tripod"):
+    """default.yaml with the start-up length the generators use (make_walk_golden.py START_UP_TIME: 100 start-up steps)."""
+    from syropod_highlevel_controller_amd import default_hexapod_params
+    p = default_hexapod_params(gait)
+    p.time_to_start = 2.0
+    return p
+
+
+def oracle_backend(p):
+    from oracle_lib import OracleBatch
+    ob = OracleBatch(p, 1)
+    return ob, lambda: ob.step(1, 1)
+
+
+def engine_backend(p):
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+    eng = BatchEngine(p, 1)
+    return eng, lambda: eng.step(1)
+
+
+def replay_manual(backend, mode, start_tol=1e-12):
+    """tests/golden/make_manual_golden.py: request results exactly; joints to 1e-6 rad while the robot walks, 5e-3 once it stands
+    (free-running: the reference's IK step amplifies rounding differences on a standing robot)."""
+    g = np.load(os.path.join(HERE, "manual_golden.npz"))
+    posing = mode == "imu_and_inclination_posing"   # the body pose moves under the standing robot: the posing part of every loop, toggle loops included
+    if mode == "joint_control":
+        g = {k[3:]: g[k] for k in g.files if k.startswith("jc_")}
+    elif posing:
+        g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
+    p = golden_hexapod_params("tripod")
+    p.admittance_control = 1
+    p.leg_manipulation_mode = 1 if mode == "joint_control" else 0
+    if posing:
+        p.imu_posing, p.inclination_posing = 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    ob, step = backend(p)
+    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < start_tol
+    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
+    worst_walk = worst_stand = 0.0
+    stood = False
+    for k, row in enumerate(g["loops"]):
+        kind, leg, result = int(row[0]), int(row[1]), int(row[2])
+        ob.set_velocity(row[3:5][None], row[5:6])
+        prim, sec = int(row[6]), int(row[13])
+        ob.set_manual_inputs(np.array([prim], dtype=np.int32), row[7:10][None], row[10:13][None], np.array([sec], dtype=np.int32), row[14:17][None], None)
+        if posing:
+            ob.set_imu(row[17:21][None], row[21:24][None])
+        if kind == 0:
+            step()
+        else:
+            assert int(ob.toggle_leg_state(np.array([leg], dtype=np.int32))[0]) == result, (k, leg, result)
+        d = np.abs(ob.joints()[0][0].reshape(6, 3) - g["joints"][k]).max()
+        stood = stood or ob.body_state()[2][0] == 3
+        if stood:
+            worst_stand = max(worst_stand, d)
+        else:
+            worst_walk = max(worst_walk, d)
+        assert worst_walk < 1e-6 and worst_stand < 5e-3, (k, kind, worst_walk, worst_stand)
+    assert ob.body_state()[2][0] != 3 and (ob.leg_manipulation_state() == 0).all()
+    return f"manual legs ({mode}): {len(g['loops'])} loops, max |joint diff| {worst_walk:.2e} rad walking, {worst_stand:.2e} rad after the first stop"
+
+
+def replay_planner(backend, posing, start_tol=1e-12):
+    """tests/golden/make_planner_golden.py: executePlan's result and plan_step_ exactly; joints free-running."""
+    from syropod_highlevel_controller_amd.params import ExternalTarget
+    g = np.load(os.path.join(HERE, "planner_golden.npz"))
+    imu = posing == "imu_and_inclination_posing"
+    if imu:
+        g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
+    events = {int(e[0]): e for e in json.load(open(os.path.join(HERE, "planner_golden_events_imu.json" if imu else "planner_golden_events.json")))}
+    p = golden_hexapod_params("tripod")
+    p.admittance_control = 1
+    if imu:
+        p.imu_posing, p.inclination_posing = 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    ob, step = backend(p)
+    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < start_tol
+    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
+    ob.set_velocity(np.array([[0.45, -0.1]]), np.array([0.15]))
+    worst_walk = worst_stand = 0.0
+    planner_on = seen_crawl = stance_running = False
+    for k, row in enumerate(g["rows"]):
+        if imu:
+            ob.set_imu(row[3:7][None], row[7:10][None])
+        if k in events:
+            _, kind, data = events[k]
+            if kind == "configuration":
+                cfg = np.full((6, 3), np.nan)
+                for leg, q in data.items():
+                    cfg[int(leg)] = q
+                ob.set_target_configuration(cfg[None])
+            else:
+                rows = (ExternalTarget * 6)()
+                tr = np.tile(np.array([0, 0, 0, 1.0, 0, 0, 0]), (6, 1))
+                for leg, t in data["targets"].items():
+                    r = rows[int(leg)]
+                    r.defined, r.swing_clearance = 1, t["clearance"]
+                    r.pose[0:3] = t["pose_p"]
+                    r.transform[:] = [0, 0, 0, 1, 0, 0, 0]
+                    tr[int(leg)] = [*t["transform"][0], *t["transform"][1]]
+                if data["targets"]:
+                    assert ob.set_external_target(rows) == 0       # the robot stands: the LegPosers take the targets
+                    ob.set_external_transform(tr[None], which=2)   # generateExternalTargetTransforms
+                ob.set_target_body_pose(np.array([[*data["body"][0], *data["body"][1]]]))
+        if int(row[0]) == 0:
+            step()
+        else:
+            if not planner_on:
+                ob.set_planner_mode(True)
+                planner_on = True
+            pr, st = ob.execute_plan()
+            assert (int(pr[0]), int(st[0])) == (int(row[1]), int(row[2])), (k, pr, st, row)
+        d = np.abs(ob.joints()[0][0].reshape(6, 3) - g["joints"][k]).max()
+        # The two free-running chains agree to 1e-8 through walking, stopping, the waits and the whole configuration step, and through
+        # a stance step until its last few percent: there the tips all but stand still, the regime in which the reference's IK step
+        # amplifies rounding differences by an order of magnitude per loop.  From then on: same place (5 mm).
+        seen_crawl = seen_crawl or (stance_running and int(row[0]) == 1 and 95 <= int(row[1]) <= 100)
+        stance_running = (stance_running or (k in events and events[k][1] == "stance")) and not (int(row[0]) == 1 and int(row[1]) == 100)
+        if seen_crawl:
+            worst_stand = max(worst_stand, d)
+        else:
+            worst_walk = max(worst_walk, d)
+        assert worst_walk < 1e-8 and worst_stand < 5e-3, (k, worst_walk, worst_stand)
+    return (f"planner ({posing}): {len(g['rows'])} loops, final plan step {int(g['rows'][-1, 2])}, max |joint diff| {worst_walk:.2e} rad up to the crawl at the "
+            f"end of the first stance step, {worst_stand:.2e} rad after")
+
+
+def walk_meta():
+    return json.load(open(os.path.join(HERE, "walk_golden_meta.json")))
+
+
+def replay_walk(name, meta, tol_x=1e-9):
+    """tests/golden/make_walk_golden.py on the HIP engine, free-running from the engine's own start-up: walk state, step states and phases
+    exactly; walker tips, body pose and velocities to tol_x; the joints of the scenarios that carry the kinematic model to the
+    north-star bar, 1e-6 rad.  (The oracle's replay of the same fixtures is tests/test_oracle_golden.py::test_walk_trajectories.)"""
+    from syropod_highlevel_controller_amd import default_hexapod_params, synthetic_octopod_params
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+    from syropod_highlevel_controller_amd.params import VEL_REAL, ExternalTarget
+    data = np.load(os.path.join(HERE, "walk_golden.npz"))
+    g = {k.split("/", 1)[1]: data[k] for k in data.files if k.startswith(name + "/")}
+    p = default_hexapod_params(meta["gait"])
+    if meta["overrides"].get("morphology") == "8x5":
+        p = synthetic_octopod_params(meta["gait"], 5, 8)
+    LD = (p.leg_count, p.leg_dof[0])
+    for k, v in meta["overrides"].items():
+        if k == "velocity_input_mode":
+            p.velocity_input_mode = VEL_REAL if v == "real" else 0
+        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs", "gait_change"):
+            pass
+        else:
+            setattr(p, k, v)
+    if p.imu_posing:
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    p.time_to_start = meta["time_to_start"]
+    eng = BatchEngine(p, 1)
+    t = eng.tables()
+    for k, table in meta["limits"].items():   # the product's host init chain against the numpy init chain's limit tables
+        np.testing.assert_allclose(list(getattr(t, k)), table, rtol=1e-8)
+    start_diff = None
+    if "joint_start" in g:
+        start_diff = float(np.abs(np.stack([x[0] for x in eng.joints()]).reshape(2, *LD) - g["joint_start"]).max())
+        assert start_diff < (1e-8 if LD[1] > 3 else 1e-11), (name, start_diff)
+    worst_tip = worst_pose = worst_q = 0.0
+    for c in range(meta["cycles"]):
+        for ec, kind, leg, v in meta.get("events", []):   # rough-terrain scenarios: TargetTipPose / tf refresh / tip-state messages
+            if ec != c:
+                continue
+            which = 0 if kind.endswith("target") else 1
+            if kind in ("target", "default", "withdraw_default"):
+                rows = (ExternalTarget * 1)()
+                if kind != "withdraw_default":
+                    rows[0].defined, rows[0].swing_clearance, rows[0].frame_is_odom_ideal = 1, v[7], int(v[8])
+                    rows[0].pose[:] = v[:7]
+                    rows[0].transform[:] = [0, 0, 0, 1, 0, 0, 0]
+                eng.set_external_target(rows, which=which, leg=leg)
+            elif kind.startswith("transform_"):
+                eng.set_external_transform(np.array(v, dtype=np.float64)[None], which=which, leg=leg)
+            elif kind == "zero_tip_force":
+                eng.set_tip_force(np.zeros((1, p.leg_count, 3)))
+            elif kind == "pose_input":
+                eng.set_pose_input(np.array(v[:3])[None], np.array(v[3:])[None])
+            elif kind == "pose_reset_mode":
+                eng.set_pose_reset_mode(np.array([int(v[0])], dtype=np.int32))
+        if "gait_request" in g and g["gait_request"][c]:   # gait_change_flag_ set: changeGait runs every loop until the robot has stopped
+            eng.change_gait(default_hexapod_params(meta["overrides"]["gait_change"]))
+        eng.set_velocity(np.array(g["lin"][c], dtype=np.float64)[None], np.array([g["ang"][c]], dtype=np.float64))
+        if p.imu_posing or p.inclination_posing:
+            eng.set_imu(np.array(g["imu_q"][c])[None], np.array(g["gyro"][c])[None])
+        if p.admittance_control and not p.use_joint_effort:
+            eng.set_tip_force(np.array(g["force"][c])[None])
+        if "effort" in g:
+            eng.set_joint_effort(np.array(g["effort"][c]).reshape(1, -1))
+        if "contact_force" in g:
+            eng.set_tip_force(np.array(g["contact_force"][c])[None])
+        eng.step(1)
+        ls = eng.leg_state()
+        pose, vel, ws = eng.body_state()
+        assert ws[0] == g["walk_state"][c], (name, c)
+        assert np.array_equal(ls["leg_status"][0] & 3, g["state"][c]), (name, c)
+        assert np.array_equal(ls["leg_status"][0] >> 8, g["phase"][c]), (name, c)
+        np.testing.assert_allclose(vel[0], g["velocity"][c], atol=tol_x, err_msg=f"{name} cycle {c}")
+        worst_tip = max(worst_tip, np.abs(ls["walker_tip"][0] - g["tips"][c]).max())
+        q = np.array(pose[0])
+        if q[3] < 0:
+            q[3:] = -q[3:]
+        worst_pose = max(worst_pose, np.abs(q - g["pose"][c]).max())
+        assert worst_tip < tol_x and worst_pose < tol_x, (name, c, worst_tip, worst_pose)
+        if "q" in g:
+            worst_q = max(worst_q, np.abs(eng.joints()[0][0].reshape(*LD) - g["q"][c]).max())
+            assert worst_q < 1e-6, (name, c, worst_q)
+            if meta["overrides"].get("dynamic_stiffness"):
+                assert np.abs(eng.virtual_stiffness()[0] - g["stiffness"][c]).max() < 1e-9, (name, c)
+            if "effort" in g:
+                assert np.abs(ls["tip_force"][0] - g["tip_force_calc"][c]).max() < 1e-8, (name, c)
+    eng.close()
+    return (f"[HIP engine vs numpy golden] {name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, "
+            f"max |pose diff| {worst_pose:.2e}" + (f", max |joint diff| {worst_q:.2e} rad (free-running; start-up configurations {start_diff:.1e} rad apart)" if "q" in g else ""))

@@ -345,117 +345,21 @@ def test_manual_leg_trajectories(mode):
     setDesiredTipPose / stepToPosition) against the independent numpy restatement of tests/golden/make_manual_golden.py, loop by
     loop: request results exactly; joints to 1e-6 rad while the robot walks, 5e-3 once it stands (free-running: the reference's
     IK step amplifies rounding differences on a standing robot).  joint_control: the velocity inputs step the
-    coxa / tibia joints and every applyIK of the MANUAL leg is rotation-constrained from the tip pose of before the step."""
-    from oracle_lib import OracleBatch
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "manual_golden.npz"))
-    posing = mode == "imu_and_inclination_posing"   # the body pose moves under the standing robot: the posing part of every loop, toggle loops included
-    if mode == "joint_control":
-        g = {k[3:]: g[k] for k in g.files if k.startswith("jc_")}
-    elif posing:
-        g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
-    p = _golden_hexapod_params("tripod")
-    p.admittance_control = 1
-    p.leg_manipulation_mode = 1 if mode == "joint_control" else 0
-    if posing:
-        p.imu_posing, p.inclination_posing = 1, 1
-        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
-    ob = OracleBatch(p, 1)
-    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
-    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
-    worst_walk = worst_stand = 0.0
-    stood = False
-    for k, row in enumerate(g["loops"]):
-        kind, leg, result = int(row[0]), int(row[1]), int(row[2])
-        ob.set_velocity(row[3:5][None], row[5:6])
-        prim, sec = int(row[6]), int(row[13])
-        ob.set_manual_inputs(np.array([prim], dtype=np.int32), row[7:10][None], row[10:13][None], np.array([sec], dtype=np.int32), row[14:17][None], None)
-        if posing:
-            ob.set_imu(row[17:21][None], row[21:24][None])
-        if kind == 0:
-            ob.step(1, 1)
-        else:
-            assert int(ob.toggle_leg_state(np.array([leg], dtype=np.int32))[0]) == result, (k, leg, result)
-        d = np.abs(ob.joints()[0][0].reshape(6, 3) - g["joints"][k]).max()
-        stood = stood or ob.body_state()[2][0] == 3
-        if stood:
-            worst_stand = max(worst_stand, d)
-        else:
-            worst_walk = max(worst_walk, d)
-        assert worst_walk < 1e-6 and worst_stand < 5e-3, (k, kind, worst_walk, worst_stand)
-    assert ob.body_state()[2][0] != 3 and (ob.leg_manipulation_state() == 0).all()
-    print(f"manual legs ({mode}): {len(g['loops'])} loops, max |joint diff| {worst_walk:.2e} rad walking, {worst_stand:.2e} rad after the first stop")
+    coxa / tibia joints and every applyIK of the MANUAL leg is rotation-constrained from the tip pose of before the step.  (The same
+    replay runs on the HIP engine in tests/test_gpu_golden.py.)"""
+    from golden_replay import oracle_backend, replay_manual
+    print(replay_manual(oracle_backend, mode))
 
 
 @pytest.mark.parametrize("posing", ["walk_plane_posing", "imu_and_inclination_posing"])
 def test_planner_trajectories(posing):
     """Planner mode (executePlan, PoseController::transitionConfiguration / transitionStance, the LegPoser's external target)
     against the independent numpy restatement of tests/golden/make_planner_golden.py, loop by loop: executePlan's result and
-    plan_step_ exactly; joints free-running (tolerances below).  The second run executes the plan under IMU + inclination posing:
-    the body pose moves under the robot while it stands, waits (updateModel on the LegPoser tips of the last updateStance) and
-    transitions."""
-    import json
-    from oracle_lib import OracleBatch
-    from syropod_highlevel_controller_amd.params import ExternalTarget
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-    g = np.load(os.path.join(here, "planner_golden.npz"))
-    imu = posing == "imu_and_inclination_posing"
-    if imu:
-        g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
-    events = {int(e[0]): e for e in json.load(open(os.path.join(here, "planner_golden_events_imu.json" if imu else "planner_golden_events.json")))}
-    p = _golden_hexapod_params("tripod")
-    p.admittance_control = 1
-    if imu:
-        p.imu_posing, p.inclination_posing = 1, 1
-        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
-    ob = OracleBatch(p, 1)
-    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < 1e-12
-    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
-    ob.set_velocity(np.array([[0.45, -0.1]]), np.array([0.15]))
-    worst_walk = worst_stand = 0.0
-    planner_on = seen_crawl = stance_running = False
-    for k, row in enumerate(g["rows"]):
-        if imu:
-            ob.set_imu(row[3:7][None], row[7:10][None])
-        if k in events:
-            _, kind, data = events[k]
-            if kind == "configuration":
-                cfg = np.full((6, 3), np.nan)
-                for leg, q in data.items():
-                    cfg[int(leg)] = q
-                ob.set_target_configuration(cfg[None])
-            else:
-                rows = (ExternalTarget * 6)()
-                tr = np.tile(np.array([0, 0, 0, 1.0, 0, 0, 0]), (6, 1))
-                for leg, t in data["targets"].items():
-                    r = rows[int(leg)]
-                    r.defined, r.swing_clearance = 1, t["clearance"]
-                    r.pose[0:3] = t["pose_p"]
-                    r.transform[:] = [0, 0, 0, 1, 0, 0, 0]
-                    tr[int(leg)] = [*t["transform"][0], *t["transform"][1]]
-                if data["targets"]:
-                    assert ob.set_external_target(rows) == 0       # the robot stands: the LegPosers take the targets
-                    ob.set_external_transform(tr[None], which=2)   # generateExternalTargetTransforms
-                ob.set_target_body_pose(np.array([[*data["body"][0], *data["body"][1]]]))
-        if int(row[0]) == 0:
-            ob.step(1, 1)
-        else:
-            if not planner_on:
-                ob.set_planner_mode(True)
-                planner_on = True
-            pr, st = ob.execute_plan()
-            assert (int(pr[0]), int(st[0])) == (int(row[1]), int(row[2])), (k, pr, st, row)
-        d = np.abs(ob.joints()[0][0].reshape(6, 3) - g["joints"][k]).max()
-        # The two free-running chains agree to 1e-8 through walking, stopping, the waits and the whole configuration step, and through
-        # a stance step until its last few percent: there the tips all but stand still, the regime in which the reference's IK step
-        # amplifies rounding differences by an order of magnitude per loop (DESIGN.md section 2.1).  From then on: same place (5 mm).
-        seen_crawl = seen_crawl or (stance_running and int(row[0]) == 1 and 95 <= int(row[1]) <= 100)
-        stance_running = (stance_running or (k in events and events[k][1] == "stance")) and not (int(row[0]) == 1 and int(row[1]) == 100)
-        if seen_crawl:
-            worst_stand = max(worst_stand, d)
-        else:
-            worst_walk = max(worst_walk, d)
-        assert worst_walk < 1e-8 and worst_stand < 5e-3, (k, worst_walk, worst_stand)
-    print(f"planner ({posing}): {len(g['rows'])} loops, final plan step {int(g['rows'][-1, 2])}, max |joint diff| {worst_walk:.2e} rad up to the crawl at the end of the first stance step, {worst_stand:.2e} rad after")
+    plan_step_ exactly; joints free-running (tolerances in golden_replay.py).  The second run executes the plan under IMU + inclination
+    posing: the body pose moves under the robot while it stands, waits (updateModel on the LegPoser tips of the last updateStance) and
+    transitions.  (The same replay runs on the HIP engine in tests/test_gpu_golden.py.)"""
+    from golden_replay import oracle_backend, replay_planner
+    print(replay_planner(oracle_backend, posing))
 
 
 def test_step_to_new_stance_trajectory():
