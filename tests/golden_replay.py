@@ -226,3 +226,92 @@ def replay_walk(name, meta, tol_x=1e-9):
     eng.close()
     return (f"[HIP engine vs numpy golden] {name}: {meta['cycles']} cycles, walk states {meta['visited_walk_states']}, max |tip diff| {worst_tip:.2e} m, "
             f"max |pose diff| {worst_pose:.2e}" + (f", max |joint diff| {worst_q:.2e} rad (free-running; start-up configurations {start_diff:.1e} rad apart)" if "q" in g else ""))
+
+
+# ------------------------------------------------------------------------------------------------ LegPoser primitives, sequences
+def _seq():
+    return np.load(os.path.join(HERE, "sequence_golden.npz"))
+
+
+def _standing_hexapod(backend, tol=1e-12):
+    SEQ = _seq()
+    ob, _ = backend(golden_hexapod_params("tripod"))
+    assert np.abs(ob.leg_apply_fk() - SEQ["origin"]).max() < tol       # the data the independent generator started from
+    assert np.abs(ob.joints()[0].reshape(6, 3) - SEQ["q0"]).max() < tol
+    return ob
+
+
+def replay_step_to_position(backend, name, tol=1e-12):
+    """LegPoser::stepToPosition call by call (tests/golden/make_sequence_golden.py): progress values exact, tip positions and directions to tol."""
+    SEQ = _seq()
+    rows, target, body = SEQ[f"step/{name}/rows"], SEQ[f"step/{name}/target"], SEQ[f"step/{name}/body"]
+    leg, lift, time_to_step = int(SEQ[f"step/{name}/args"][0]), float(SEQ[f"step/{name}/args"][1]), float(SEQ[f"step/{name}/args"][2])
+    ob = _standing_hexapod(backend, max(tol, 1e-12))
+    targets = None
+    if not np.isnan(target[0]):
+        targets = SEQ["origin"].copy()
+        targets[:, 3:] = 0.0              # the other legs: their own tip, rotation undefined -> nothing to do
+        targets[leg] = target
+    for call, row in enumerate(rows):
+        out, progress = ob.leg_step_to_position(targets, body[None], lift, time_to_step, apply_delta=False)
+        assert progress[leg] == int(row[0]), (call, progress[leg], row[0])
+        assert np.abs(out[leg, :3] - row[1:4]).max() < tol, (call, out[leg, :3], row[1:4])
+        q = out[leg, 3:]
+        if np.isnan(row[4]):
+            assert not q.any()            # UNDEFINED_ROTATION
+        else:                             # x axis of the tip rotation
+            x = np.array([1 - 2 * (q[2] ** 2 + q[3] ** 2), 2 * (q[1] * q[2] + q[0] * q[3]), 2 * (q[1] * q[3] - q[0] * q[2])])
+            assert np.abs(x - row[4:7]).max() < tol, (call, x, row[4:7])
+    return len(rows)
+
+
+def replay_configuration_transition(backend, name, tol=1e-13):
+    """LegPoser::transitionConfiguration (pose_controller.cpp:1476-1567) against the independent restatement."""
+    SEQ = _seq()
+    rows, target = SEQ[f"cfg/{name}/rows"], SEQ[f"cfg/{name}/target"]
+    leg, transition_time = int(SEQ[f"cfg/{name}/args"][0]), float(SEQ[f"cfg/{name}/args"][1])
+    ob = _standing_hexapod(backend)
+    desired = SEQ["q0"].copy()
+    desired[leg] = target
+    for call, row in enumerate(rows):
+        progress = ob.leg_transition_configuration(desired, transition_time)
+        assert progress[leg] == int(row[0]), (call, progress[leg], row[0])
+        assert np.abs(ob.joints()[0].reshape(6, 3)[leg] - row[1:]).max() < tol
+    return len(rows)
+
+
+def replay_startup_sequence(backend, start, offset_tol=1e-3):
+    """PoseController::executeSequence (tests/golden/make_startup_golden.py): a first START_UP, SHUT_DOWN, START_UP again (replay) - every return
+    value exactly, joints to 1e-6 rad call by call from the READY estimate."""
+    from syropod_highlevel_controller_amd import default_hexapod_params
+    g = np.load(os.path.join(HERE, "startup_golden.npz"))
+    pre = "" if start == "ready" else "offset/"
+    ob, _ = backend(default_hexapod_params("tripod"))
+    ob.begin_sequence_startup(None if start == "ready" else g[pre + "q0"], False)
+    assert np.abs(ob.joints()[0][0].reshape(6, 3) - g[pre + "q0"]).max() == 0.0
+    worst = 0.0
+    for name, which in (("startup_first", 0), ("shutdown", 1), ("startup_replay", 0)):
+        rows = g[pre + name]
+        for call, row in enumerate(rows):
+            r = int(ob.execute_sequence(which)[0])
+            assert r == int(row[0]), (name, call, r, row[0])
+            worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
+            # free-running through a slow body raise: the reference's IK step amplifies rounding differences there (DESIGN.md section
+            # 2.1); the READY start stays within 1e-6 rad, the offset start is given what a twin build of the oracle itself needs
+            assert worst < (1e-6 if start == "ready" else offset_tol), (name, call, worst)
+        assert int(rows[-1][0]) == 100
+    return (f"executeSequence from {start}: {sum(len(g[pre + k]) for k in ('startup_first', 'shutdown', 'startup_replay'))} calls, "
+            f"{int(g[pre + 'transition_steps'][0])} transition steps learnt, {int(g[pre + 'proximity_alerts'][0])} workspace alerts, max |joint diff| {worst:.2e} rad")
+
+
+def replay_step_to_new_stance(backend, start_tol=1e-12):
+    """PoseController::stepToNewStance (tests/golden/make_startup_golden.py): return values exactly, joints free-running."""
+    g = np.load(os.path.join(HERE, "startup_golden.npz"))
+    ob, _ = backend(golden_hexapod_params("tripod"))
+    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["new_stance/joint_start"]).max() < start_tol
+    worst = 0.0
+    for call, row in enumerate(g["new_stance/rows"]):
+        assert int(ob.step_to_new_stance()[0]) == int(row[0]), call
+        worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
+        assert worst < 1e-6, (call, worst)
+    return f"stepToNewStance: {len(g['new_stance/rows'])} calls, max |joint diff| {worst:.2e} rad"

@@ -264,51 +264,19 @@ def _golden_hexapod_params(gait="tripod"):
 SEQ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sequence_golden.npz"))
 
 
-def _standing_hexapod():
-    from oracle_lib import OracleBatch
-    from syropod_highlevel_controller_amd import default_hexapod_params
-    ob = OracleBatch(_golden_hexapod_params("tripod"), 1)
-    assert np.abs(ob.leg_apply_fk() - SEQ["origin"]).max() < 1e-12       # the data the independent generator started from
-    assert np.abs(ob.joints()[0].reshape(6, 3) - SEQ["q0"]).max() < 1e-12
-    return ob
-
-
 @pytest.mark.parametrize("name", sorted({k.split("/")[1] for k in SEQ.files if k.startswith("step/")}))
 def test_sequence_trajectories(name):
     """LegPoser::stepToPosition (pose_controller.cpp:1571-1712) call by call against the independent numpy restatement of
     tests/golden/make_sequence_golden.py: progress values exact, tip positions and directions to 1e-12."""
-    rows, target, body = SEQ[f"step/{name}/rows"], SEQ[f"step/{name}/target"], SEQ[f"step/{name}/body"]
-    leg, lift, time_to_step = int(SEQ[f"step/{name}/args"][0]), float(SEQ[f"step/{name}/args"][1]), float(SEQ[f"step/{name}/args"][2])
-    ob = _standing_hexapod()
-    targets = None
-    if not np.isnan(target[0]):
-        targets = SEQ["origin"].copy()
-        targets[:, 3:] = 0.0              # the other legs: their own tip, rotation undefined -> nothing to do
-        targets[leg] = target
-    for call, row in enumerate(rows):
-        out, progress = ob.leg_step_to_position(targets, body[None], lift, time_to_step, apply_delta=False)
-        assert progress[leg] == int(row[0]), (call, progress[leg], row[0])
-        assert np.abs(out[leg, :3] - row[1:4]).max() < 1e-12, (call, out[leg, :3], row[1:4])
-        q = out[leg, 3:]
-        if np.isnan(row[4]):
-            assert not q.any()            # UNDEFINED_ROTATION
-        else:                             # x axis of the tip rotation
-            x = np.array([1 - 2 * (q[2] ** 2 + q[3] ** 2), 2 * (q[1] * q[2] + q[0] * q[3]), 2 * (q[1] * q[3] - q[0] * q[2])])
-            assert np.abs(x - row[4:7]).max() < 1e-12, (call, x, row[4:7])
+    from golden_replay import oracle_backend, replay_step_to_position
+    replay_step_to_position(oracle_backend, name)
 
 
 @pytest.mark.parametrize("name", sorted({k.split("/")[1] for k in SEQ.files if k.startswith("cfg/")}))
 def test_configuration_transition_trajectories(name):
     """LegPoser::transitionConfiguration (pose_controller.cpp:1476-1567) against the independent restatement."""
-    rows, target = SEQ[f"cfg/{name}/rows"], SEQ[f"cfg/{name}/target"]
-    leg, transition_time = int(SEQ[f"cfg/{name}/args"][0]), float(SEQ[f"cfg/{name}/args"][1])
-    ob = _standing_hexapod()
-    desired = SEQ["q0"].copy()
-    desired[leg] = target
-    for call, row in enumerate(rows):
-        progress = ob.leg_transition_configuration(desired, transition_time)
-        assert progress[leg] == int(row[0]), (call, progress[leg], row[0])
-        assert np.abs(ob.joints()[0].reshape(6, 3)[leg] - row[1:]).max() < 1e-13
+    from golden_replay import oracle_backend, replay_configuration_transition
+    replay_configuration_transition(oracle_backend, name)
 
 
 @pytest.mark.parametrize("start", ["ready", "offset"])
@@ -317,26 +285,8 @@ def test_startup_sequence_trajectories(start):
     tests/golden/make_startup_golden.py: a first START_UP (learning its transition poses inside the joint-limit safety factor; from
     the READY estimate, and from a configuration up to 0.25 rad away from it), SHUT_DOWN, START_UP again (replay) - every return
     value exactly, joints to 1e-6 rad call by call."""
-    from oracle_lib import OracleBatch
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "startup_golden.npz"))
-    pre = "" if start == "ready" else "offset/"
-    p = default_hexapod_params("tripod")
-    ob = OracleBatch(p, 1)
-    ob.begin_sequence_startup(None if start == "ready" else g[pre + "q0"], False)
-    assert np.abs(ob.joints()[0][0].reshape(6, 3) - g[pre + "q0"]).max() == 0.0
-    worst = 0.0
-    for name, which in (("startup_first", 0), ("shutdown", 1), ("startup_replay", 0)):
-        rows = g[pre + name]
-        for call, row in enumerate(rows):
-            r = int(ob.execute_sequence(which)[0])
-            assert r == int(row[0]), (name, call, r, row[0])
-            worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
-            # free-running through a slow body raise: the reference's IK step amplifies rounding differences there (DESIGN.md section
-            # 2.1); the READY start stays within 1e-6 rad, the offset start is given what a twin build of the oracle itself needs
-            assert worst < (1e-6 if start == "ready" else 1e-3), (name, call, worst)
-        assert int(rows[-1][0]) == 100
-    print(f"executeSequence from {start}: {sum(len(g[pre + k]) for k in ('startup_first', 'shutdown', 'startup_replay'))} calls, "
-          f"{int(g[pre + 'transition_steps'][0])} transition steps learnt, {int(g[pre + 'proximity_alerts'][0])} workspace alerts, max |joint diff| {worst:.2e} rad")
+    from golden_replay import oracle_backend, replay_startup_sequence
+    print(replay_startup_sequence(oracle_backend, start))
 
 
 @pytest.mark.parametrize("mode", ["tip_control", "joint_control", "imu_and_inclination_posing"])
@@ -365,16 +315,8 @@ def test_planner_trajectories(posing):
 def test_step_to_new_stance_trajectory():
     """PoseController::stepToNewStance (pose_controller.cpp:521-557) against the independent restatement in
     tests/golden/make_startup_golden.py: both leg groups step onto their default tip poses; return values exactly, joints free-running."""
-    from oracle_lib import OracleBatch
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "startup_golden.npz"))
-    ob = OracleBatch(_golden_hexapod_params("tripod"), 1)
-    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["new_stance/joint_start"]).max() < 1e-12
-    worst = 0.0
-    for call, row in enumerate(g["new_stance/rows"]):
-        assert int(ob.step_to_new_stance()[0]) == int(row[0]), call
-        worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
-        assert worst < 1e-6, (call, worst)
-    print(f"stepToNewStance: {len(g['new_stance/rows'])} calls, max |joint diff| {worst:.2e} rad")
+    from golden_replay import oracle_backend, replay_step_to_new_stance
+    print(replay_step_to_new_stance(oracle_backend))
 
 
 # ------------------------------------------------------------------------------------------------ the init chain
