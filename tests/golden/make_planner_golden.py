@@ -102,17 +102,23 @@ class Planner:
                 tp, tq = t["transform"]
                 target = np.array(tp, float) + R.from_quat([tq[1], tq[2], tq[3], tq[0]]).apply(np.array(t["pose_p"], float))
                 clearance = t["clearance"]
+            target_q = None
+            if w.P.get("gravity_aligned_tips"):                    # "Update target rotation if gravity alignment is set" (:785-790) - every leg,
+                x = mw.from_two_vectors(np.array([1.0, 0, 0]), w.estimate_gravity()).as_quat()   # whatever its joint count
+                target_q = [x[3], x[0], x[1], x[2]]
             if self.first[i]:
                 self.stp[i] = ms.StepToPosition(mw.fk_tip(i, w.q[i]), tip_quat(i, w.q[i]))
                 self.first[i] = False
             manually = leg.leg_state in (1, -1)
-            progress, tip, _ = self.stp[i].step(target, None, self.body_pose[0], self.body_pose[1], clearance, PLAN_TIME, None if manually else adm[i])
+            progress, tip, direction = self.stp[i].step(target, target_q, self.body_pose[0], self.body_pose[1], clearance, PLAN_TIME, None if manually else adm[i])
             if self.stp[i].first:
                 self.first[i] = True
-            leg.poser_tip = tip
+            if target_q is None:
+                direction = None                                   # (the "nothing to do" return hands back the origin pose; without a target rotation nothing constrains the IK)
+            leg.poser_tip, leg.poser_dir = tip, direction
             desired = tip + (np.zeros(3) if manually else adm[i])
             leg.desired_tip = desired
-            w.q[i], w.qd[i] = mw.apply_ik(i, w.q[i], w.qd[i], desired, w.dt)
+            w.q[i], w.qd[i] = mw.apply_ik(i, w.q[i], w.qd[i], desired, w.dt, direction)
             leg.model_tip = mw.fk_tip(i, w.q[i])
             min_progress = min(min_progress, progress)
             if t is not None and progress == 100:
@@ -130,7 +136,7 @@ class Planner:
             for i, leg in enumerate(w.legs):                       # Model::updateModel: the poser's tip pose + delta, one IK step
                 desired = leg.poser_tip + (np.zeros(3) if leg.leg_state in (1, -1) else adm[i])
                 leg.desired_tip = desired
-                w.q[i], w.qd[i] = mw.apply_ik(i, w.q[i], w.qd[i], desired, w.dt)
+                w.q[i], w.qd[i] = mw.apply_ik(i, w.q[i], w.qd[i], desired, w.dt, leg.poser_dir)   # (the LegPoser's tip pose with its rotation)
                 leg.model_tip = mw.fk_tip(i, w.q[i])
             return -2
         progress = self.transition_configuration() if self.cfg_acquired else self.transition_stance(adm)
@@ -206,6 +212,58 @@ def run(posing=False):
     return {"rows": np.array(rows), "joints": np.array(joints), "joint_start": np.stack([q0.reshape(6, 3), qd0.reshape(6, 3)])}, events
 
 
+def run_gravity():
+    """The synthetic 8 x 5 octopod with gravity-aligned tips: transitionStance turns EVERY tip towards Model::estimateGravity() - a leg
+    without a tip target gets Pose(UNDEFINED_POSITION, that rotation), which is not Pose::Undefined(): its tip stays (:1637) and turns -
+    and a waiting robot's updateModel keeps the LegPoser's tip rotation.  No admittance (a delta added to UNDEFINED_POSITION would send
+    the tip after INT_MAX metres, :1613)."""
+    gait, L = "ripple", 8
+    P = mw.hexapod(gait, "8x5", gravity_aligned_tips=1)
+    w = mw.started_walker(P, gait, "8x5")
+    q0, qd0 = w.q.copy(), w.qd.copy()
+    rows, joints, events = [], [], []
+    for _ in range(70):
+        w.cycle((0.4, -0.2), 0.2)
+        rows.append([0, 0, 0])
+        joints.append(w.q.copy())
+    pl = Planner(w)
+
+    def loops_until(value, limit=2000):
+        for _ in range(limit):
+            r = pl.loop()
+            rows.append([1, r, pl.plan_step])
+            joints.append(w.q.copy())
+            if r == value:
+                return
+        raise AssertionError(value)
+
+    loops_until(-2)
+    for _ in range(3):
+        loops_until(-2, 1)
+    body = ([0.006, -0.004, 0.008], [float(np.cos(0.012)), 0.0, float(np.sin(0.012)), 0.0])
+    events.append((len(rows), "stance", {"targets": {}, "body": body}))          # a body pose alone: every tip stays where it is and turns
+    pl.body_pose, pl.body_acquired = body, True
+    loops_until(100)
+    for _ in range(3):
+        loops_until(-2, 1)
+    cfg = {l: (w.q[l] + np.array([0.05, -0.06, 0.07, -0.04, 0.03]) * (1 if l % 2 else -1)).tolist() for l in (1, 4, 6)}
+    events.append((len(rows), "configuration", {str(k): v for k, v in cfg.items()}))
+    pl.configuration, pl.cfg_acquired = cfg, True
+    loops_until(100)
+    loops_until(-2, 1)
+    tf = ([0.003, -0.002, 0.001], [float(np.cos(0.008)), 0.0, 0.0, float(np.sin(0.008))])
+    targets = {}
+    for l, off, clearance in ((0, [0.02, -0.015, 0.004], 0.0), (3, [-0.02, 0.02, 0.0], 0.015), (7, [0.015, 0.02, -0.003], 0.0)):
+        targets[l] = dict(pose_p=(w.legs[l].model_tip + np.array(off)).tolist(), transform=tf, clearance=clearance)
+    body2 = ([0.0, 0.006, -0.005], [1.0, 0.0, 0.0, 0.0])
+    events.append((len(rows), "stance", {"targets": {str(k): v for k, v in targets.items()}, "body": body2}))
+    pl.targets, pl.tip_acquired = dict(targets), True
+    pl.body_pose, pl.body_acquired = body2, True
+    loops_until(100)
+    loops_until(-2, 1)
+    return {"rows": np.array(rows), "joints": np.array(joints), "joint_start": np.stack([q0.reshape(L, 5), qd0.reshape(L, 5)])}, events
+
+
 if __name__ == "__main__":
     import json
     out, events = run()
@@ -214,6 +272,10 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
     json.dump(events, open(os.path.join(HERE, "planner_golden_events.json"), "w"), indent=1)
     json.dump(events2, open(os.path.join(HERE, "planner_golden_events_imu.json"), "w"), indent=1)
-    for pre in ("", "imu_"):
+    out3, events3 = run_gravity()                # the 8 x 5 octopod with gravity-aligned tips (keys g85_*)
+    out.update({"g85_" + k: v for k, v in out3.items()})
+    json.dump(events3, open(os.path.join(HERE, "planner_golden_events_8x5.json"), "w"), indent=1)
+    np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
+    for pre in ("", "imu_", "g85_"):
         r = out[pre + "rows"]
         print(pre or "plain", "loops", len(r), "plan results seen", sorted(set(r[r[:, 0] == 1][:, 1].astype(int).tolist()))[:6], "... final plan step", int(r[-1, 2]))

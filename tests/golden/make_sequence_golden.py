@@ -61,6 +61,9 @@ def from_two_vectors(a, b):
     return R.from_rotvec(axis / s * np.arctan2(s, c))
 
 
+UNDEFINED_POSITION = np.full(3, 2147483647.0)   # standard_includes.h:57: Vector3d(double(INT_MAX), ..)
+
+
 class StepToPosition:
     """One LegPoser's stepToPosition state: call step() once per control loop; returns (progress, tip position, tip direction or None)."""
 
@@ -74,8 +77,10 @@ class StepToPosition:
             self.origin_p, self.origin_q = self.leg_p.copy(), self.leg_q.copy()
             self.count = 0
             self.first = False
-        if target_p is None:                                          # Pose::Undefined(): stay, rotation undefined (:1581-1586)
+        if target_p is None and target_q is None:                     # Pose::Undefined(): stay, rotation undefined (:1581-1586)
             desired_p, desired_q = self.origin_p.copy(), None
+        elif target_p is None:                                        # UNDEFINED_POSITION with a rotation (transitionStance under gravity-aligned tips):
+            desired_p, desired_q = UNDEFINED_POSITION.copy(), np.array(target_q, float)   # not Pose::Undefined(), so the position goes through as it is
         else:
             desired_p, desired_q = np.array(target_p, float), (None if target_q is None else np.array(target_q, float))
         body = rot(body_q)
@@ -109,7 +114,9 @@ class StepToPosition:
         prim = [self.origin_p, self.origin_p, self.origin_p + lift_v, desired_p + 0.75 * o2t + lift_v, desired_p + 0.5 * o2t + lift_v]
         sec = [desired_p + 0.5 * o2t + lift_v, desired_p + 0.25 * o2t + lift_v, desired_p + lift_v, desired_p, desired_p]
         sic = (self.count + (num - 1)) % num + 1
-        if sic <= half:
+        if not (desired_p != UNDEFINED_POSITION).any():               # "if (desired_tip_pose.position_ != UNDEFINED_POSITION)" (:1637): the tip stays
+            new_p = self.origin_p.copy()
+        elif sic <= half:
             new_p = quartic_bezier(prim, sic * dt * 2.0)
         else:
             new_p = quartic_bezier(sec, (sic - half) * dt * 2.0)

@@ -344,6 +344,7 @@ class Leg:
         self.rot_defined = False    # current_tip_pose_.rotation_ != UNDEFINED_ROTATION (gravity-aligned tips, > 3 joints)
         self.cur_dir = self.origin_dir = self.model_dir = np.array([0.0, 0.0, -1.0])   # x axes of current / origin tip rotation, of the FK tip frame
         self.model_tip = None       # Leg::current_tip_pose_.position_ (FK of the joints), scenarios with the kinematic model
+        self.poser_dir = None       # x axis of LegPoser::current_tip_pose_.rotation_ (None: undefined)
         self.held = None            # Leg::current_tip_pose_ (position, x axis) where joint_control's updateManual has moved the joints under it
 
 
@@ -829,6 +830,12 @@ class RefWalker:
                 out[i] = cur[i] + vel * dt
         self.manual_pose = Pose(new_p, R.from_euler("XYZ", new_r))   # eulerAnglesToQuaternion(.., intrinsic)
 
+    def estimate_gravity(self):     # Model::estimateGravity (src/model.cpp:156-165)
+        e = rot_to_euler(self.imu_q)
+        g = np.array([0.0, 0.0, -9.81])
+        g = R.from_rotvec([0.0, -e[1], 0.0]).apply(g)
+        return R.from_rotvec([-e[0], 0.0, 0.0]).apply(g)
+
     def inclination_pose(self):     # PoseController::updateInclinationPose (:1240-1259), reads the auto_pose_ of the previous cycle
         P = self.P
         combined = self.manual_pose.r * self.prev_auto_r
@@ -891,7 +898,7 @@ class RefWalker:
                 delta = adm[i]
                 if leg.leg_state in (1, -1):                              # MANUAL / WALKING_TO_MANUAL: no posing (:134-137), no delta (model.cpp:655-656)
                     poser_tip, ddir, delta = leg.tip.copy(), (leg.cur_dir if leg.rot_defined else None), np.zeros(3)
-                leg.poser_tip = poser_tip
+                leg.poser_tip, leg.poser_dir = poser_tip, ddir                # LegPoser::current_tip_pose_ (a waiting planner-mode robot's updateModel re-reads it)
                 leg.desired_tip = poser_tip + delta
                 self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + delta, self.dt, ddir, held=leg.held)  # setDesiredTipPose(.., apply_delta)
                 leg.held = None
@@ -974,12 +981,13 @@ def workspaces_of(gait, morphology=None, rough=0, gravity=0):
     return _MI.init_chain(gait, morphology, bool(rough), START_UP_TIME, gravity=bool(gravity))["workspaces"]
 
 
-def started_walker(P, gait="tripod"):
-    """A default-hexapod RefWalker as it stands when it has entered RUNNING: joints from the numpy init chain's direct start-up, then the
-    loop that enters RUNNING (one cycle with zero inputs, state_controller.cpp:277-281, :189-192).  For the sibling generators."""
+def started_walker(P, gait="tripod", morphology=None):
+    """A RefWalker (default hexapod, or the synthetic 8 x 5 octopod) as it stands when it has entered RUNNING: joints from the numpy init
+    chain's direct start-up, then the loop that enters RUNNING (one cycle with zero inputs, state_controller.cpp:277-281, :189-192).
+    For the sibling generators."""
     global MODEL
-    q_startup, limits = init_chain_of(gait)
-    MODEL = Morphology.default_hexapod()
+    q_startup, limits = init_chain_of(gait, morphology, P.get("rough_terrain_mode", 0), int(bool(P.get("gravity_aligned_tips"))))
+    MODEL = Morphology.from_params(make_params(gait, morphology)) if morphology else Morphology.default_hexapod()
     w = RefWalker(P, limits)
     w.q, w.qd = q_startup.copy(), np.zeros_like(q_startup)
     for i, leg in enumerate(w.legs):

@@ -76,18 +76,33 @@ def replay_planner(backend, posing, start_tol=1e-12):
     from syropod_highlevel_controller_amd.params import ExternalTarget
     g = np.load(os.path.join(HERE, "planner_golden.npz"))
     imu = posing == "imu_and_inclination_posing"
+    octopod = posing == "8x5_gravity_aligned_tips"   # transitionStance turns every tip towards gravity; legs without a tip target stay and turn
     if imu:
         g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
-    events = {int(e[0]): e for e in json.load(open(os.path.join(HERE, "planner_golden_events_imu.json" if imu else "planner_golden_events.json")))}
-    p = golden_hexapod_params("tripod")
-    p.admittance_control = 1
+    elif octopod:
+        g = {k[4:]: g[k] for k in g.files if k.startswith("g85_")}
+    events_file = "planner_golden_events_imu.json" if imu else "planner_golden_events_8x5.json" if octopod else "planner_golden_events.json"
+    events = {int(e[0]): e for e in json.load(open(os.path.join(HERE, events_file)))}
+    if octopod:
+        from syropod_highlevel_controller_amd import synthetic_octopod_params
+        p = synthetic_octopod_params("ripple", 5, 8)
+        p.gravity_aligned_tips = 1
+        p.time_to_start = 2.0
+        start_tol = max(start_tol, 1e-8)         # (the redundant chain's start-up configuration: DESIGN.md section 2)
+    else:
+        p = golden_hexapod_params("tripod")
+        p.admittance_control = 1
+    L, D = p.leg_count, p.leg_dof[0]
     if imu:
         p.imu_posing, p.inclination_posing = 1, 1
         p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
     ob, step = backend(p)
-    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < start_tol
-    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
-    ob.set_velocity(np.array([[0.45, -0.1]]), np.array([0.15]))
+    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, L, D) - g["joint_start"]).max() < start_tol
+    if octopod:
+        ob.set_velocity(np.array([[0.4, -0.2]]), np.array([0.2]))
+    else:
+        ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
+        ob.set_velocity(np.array([[0.45, -0.1]]), np.array([0.15]))
     worst_walk = worst_stand = 0.0
     planner_on = seen_crawl = stance_running = False
     for k, row in enumerate(g["rows"]):
@@ -96,13 +111,13 @@ def replay_planner(backend, posing, start_tol=1e-12):
         if k in events:
             _, kind, data = events[k]
             if kind == "configuration":
-                cfg = np.full((6, 3), np.nan)
+                cfg = np.full((L, D), np.nan)
                 for leg, q in data.items():
                     cfg[int(leg)] = q
                 ob.set_target_configuration(cfg[None])
             else:
-                rows = (ExternalTarget * 6)()
-                tr = np.tile(np.array([0, 0, 0, 1.0, 0, 0, 0]), (6, 1))
+                rows = (ExternalTarget * L)()
+                tr = np.tile(np.array([0, 0, 0, 1.0, 0, 0, 0]), (L, 1))
                 for leg, t in data["targets"].items():
                     r = rows[int(leg)]
                     r.defined, r.swing_clearance = 1, t["clearance"]
@@ -121,7 +136,7 @@ def replay_planner(backend, posing, start_tol=1e-12):
                 planner_on = True
             pr, st = ob.execute_plan()
             assert (int(pr[0]), int(st[0])) == (int(row[1]), int(row[2])), (k, pr, st, row)
-        d = np.abs(ob.joints()[0][0].reshape(6, 3) - g["joints"][k]).max()
+        d = np.abs(ob.joints()[0][0].reshape(L, D) - g["joints"][k]).max()
         # The two free-running chains agree to 1e-8 through walking, stopping, the waits and the whole configuration step, and through
         # a stance step until its last few percent: there the tips all but stand still, the regime in which the reference's IK step
         # amplifies rounding differences by an order of magnitude per loop.  From then on: same place (5 mm).
