@@ -900,11 +900,12 @@ class RefWalker:
                     poser_tip, ddir, delta = leg.tip.copy(), (leg.cur_dir if leg.rot_defined else None), np.zeros(3)
                 leg.poser_tip, leg.poser_dir = poser_tip, ddir                # LegPoser::current_tip_pose_ (a waiting planner-mode robot's updateModel re-reads it)
                 leg.desired_tip = poser_tip + delta
-                self.q[i], self.qd[i] = apply_ik(i, self.q[i], self.qd[i], poser_tip + delta, self.dt, ddir, held=leg.held)  # setDesiredTipPose(.., apply_delta)
+                n = len(MODEL.links[i])      # (legs of a robot may differ in joint count: the arrays are [legs][longest], a shorter leg's tail stays 0)
+                self.q[i][:n], self.qd[i][:n] = apply_ik(i, self.q[i][:n], self.qd[i][:n], poser_tip + delta, self.dt, ddir, held=leg.held)  # setDesiredTipPose(.., apply_delta)
                 leg.held = None
                 leg.model_tip = fk_tip(i, self.q[i])                                                     # applyFK closes applyIK
                 leg.model_dir = tip_axis(i, self.q[i])
-                tip_force_estimate(i, self.q[i], self.efforts[i], self.tip_force_calc[i], self.P.get("force_gain", 0.1))   # ... and calculateTipForce
+                tip_force_estimate(i, self.q[i][:n], self.efforts[i][:n], self.tip_force_calc[i], self.P.get("force_gain", 0.1))   # ... and calculateTipForce
 
 
 def make_params(gait, morphology=None):
@@ -970,7 +971,9 @@ def init_chain_of(gait, morphology=None, rough=0, gravity=0):
     if _MI is None:
         _MI = init_chain_module()
     r = _MI.init_chain(gait, morphology, bool(rough), START_UP_TIME, gravity=bool(gravity))
-    return np.array(r["q0"]), {k: [float(x) for x in v] for k, v in r["limits"].items()}
+    top = max(len(q) for q in r["q0"])           # (legs may differ in joint count: [legs][longest], zero tails)
+    q0 = np.array([list(q) + [0.0] * (top - len(q)) for q in r["q0"]])
+    return q0, {k: [float(x) for x in v] for k, v in r["limits"].items()}
 
 
 def workspaces_of(gait, morphology=None, rough=0, gravity=0):
@@ -1011,6 +1014,8 @@ SCENARIOS = {
     # config 4's path: the synthetic 8 x 5 octopod, ripple gait - redundant chains, the null-space term of the DLS step at work
     "octopod_8x5_ripple": ("ripple", {"model": 1, "morphology": "8x5"}, [(0, (0.5, 0.3), -0.25), (300, (0, 0), 0.0)], 480),
     # gravity-aligned tips on the 8 x 5 octopod: updateTipRotation + the rotation-constrained IK pass and its retry
+    # a hexapod whose legs have 3 / 5 / 4 / 3 / 5 / 4 joints (Parameters::leg_DOF is per leg): every leg its own chain here
+    "hexapod_mixed_dof_ripple": ("ripple", {"model": 1, "morphology": "mixed"}, [(0, (0.45, 0.2), -0.2), (300, (0, 0), 0.0)], 460),
     "octopod_8x5_gravity_aligned_tips": ("ripple", {"model": 1, "morphology": "8x5", "gravity_aligned_tips": 1}, [(0, (0.4, -0.2), 0.2), (260, (0, 0), 0.0)], 420),
     # ... and with admittance deltas large enough (U(0, 20) N) that the constrained attempt misses IK_TOLERANCE: the unconstrained retry
     "octopod_8x5_gravity_aligned_admittance": ("ripple", {"model": 1, "morphology": "8x5", "gravity_aligned_tips": 1, "admittance_control": 1},

@@ -167,7 +167,10 @@ def replay_walk(name, meta, tol_x=1e-9):
     p = default_hexapod_params(meta["gait"])
     if meta["overrides"].get("morphology") == "8x5":
         p = synthetic_octopod_params(meta["gait"], 5, 8)
-    LD = (p.leg_count, p.leg_dof[0])
+    if meta["overrides"].get("morphology") == "mixed":   # legs of 3 / 5 / 4 / 3 / 5 / 4 joints: the engine pads the shorter legs, the fixture ran each leg's own chain
+        from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
+        p = synthetic_mixed_dof_params(meta["gait"])
+    LD = (p.leg_count, max(p.leg_dof[l] for l in range(p.leg_count)))
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
