@@ -123,15 +123,20 @@ class Toggler:
         return 0, lin, ang
 
 
-def run(mode="tip_control", posing=False):
+def run(mode="tip_control", posing=False, octopod=False):
     import zlib
-    gait = "tripod"
-    P = mw.hexapod(gait, admittance_control=1, manual_posing=1, leg_manipulation_mode=mode)
+    gait = "ripple" if octopod else "tripod"
+    if octopod:                                  # the synthetic 8 x 5 octopod with gravity-aligned tips: the frozen walker's legs keep their
+        P = mw.hexapod(gait, "8x5", gravity_aligned_tips=1, leg_manipulation_mode=mode,      # rotation-constrained IK, the toggled leg loses its rotation
+                       max_translation_velocity=mw.make_params(gait, "8x5").max_translation_velocity)
+    else:
+        P = mw.hexapod(gait, admittance_control=1, manual_posing=1, leg_manipulation_mode=mode)
     if posing:                                   # the body pose keeps moving while the robot stands: IMU PID + the inclination translation
         P.update(imu_posing=1, inclination_posing=1)
-    w = mw.started_walker(P, gait)               # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
+    w = mw.started_walker(P, gait, "8x5" if octopod else None)   # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
     q0, qd0 = w.q.copy(), w.qd.copy()
-    w.tip_force = np.tile(np.array([0.0, 0.0, 4.0]), (6, 1))
+    if not octopod:
+        w.tip_force = np.tile(np.array([0.0, 0.0, 4.0]), (6, 1))
     t = Toggler(w)
     rng = np.random.default_rng(zlib.crc32(b"manual"))
     loops = []       # (kind, leg, result, lin x, lin y, ang, then the manual inputs in force: primary leg, velocity (3), position (3), secondary leg, velocity (3))
@@ -200,7 +205,7 @@ def run(mode="tip_control", posing=False):
     lin, ang = (0.35, -0.1), -0.15
     cycles(120)
     assert w.walk_state != mw.STOPPED
-    return {"loops": np.array(loops), "joints": np.array(joints), "joint_start": np.stack([q0.reshape(6, 3), qd0.reshape(6, 3)])}
+    return {"loops": np.array(loops), "joints": np.array(joints), "joint_start": np.stack([q0, qd0])}
 
 
 if __name__ == "__main__":
@@ -208,7 +213,8 @@ if __name__ == "__main__":
     jc = run("joint_control")
     out.update({"jc_" + k: v for k, v in jc.items()})
     out.update({"imu_" + k: v for k, v in run(posing=True).items()})
+    out.update({"g85_" + k: v for k, v in run(octopod=True).items()})
     np.savez_compressed(os.path.join(HERE, "manual_golden.npz"), **out)
-    for pre in ("", "jc_", "imu_"):
+    for pre in ("", "jc_", "imu_", "g85_"):
         k = out[pre + "loops"]
         print(pre or "tip_control", "loops", len(k), "toggle loops", int((k[:, 0] == 1).sum()), "results", sorted(set(k[k[:, 0] == 1][:, 2].astype(int).tolist())))

@@ -34,19 +34,31 @@ def replay_manual(backend, mode, start_tol=1e-12):
     (free-running: the reference's IK step amplifies rounding differences on a standing robot)."""
     g = np.load(os.path.join(HERE, "manual_golden.npz"))
     posing = mode == "imu_and_inclination_posing"   # the body pose moves under the standing robot: the posing part of every loop, toggle loops included
+    octopod = mode == "8x5_gravity_aligned_tips"   # the frozen walker's legs keep their rotation-constrained IK, the toggled leg loses its rotation
     if mode == "joint_control":
         g = {k[3:]: g[k] for k in g.files if k.startswith("jc_")}
     elif posing:
         g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
-    p = golden_hexapod_params("tripod")
-    p.admittance_control = 1
+    elif octopod:
+        g = {k[4:]: g[k] for k in g.files if k.startswith("g85_")}
+    if octopod:
+        from syropod_highlevel_controller_amd import synthetic_octopod_params
+        p = synthetic_octopod_params("ripple", 5, 8)
+        p.gravity_aligned_tips = 1
+        p.time_to_start = 2.0
+        start_tol = max(start_tol, 1e-8)         # (the redundant chain's start-up configuration: DESIGN.md section 2)
+    else:
+        p = golden_hexapod_params("tripod")
+        p.admittance_control = 1
+    L, D = p.leg_count, p.leg_dof[0]
     p.leg_manipulation_mode = 1 if mode == "joint_control" else 0
     if posing:
         p.imu_posing, p.inclination_posing = 1, 1
         p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
     ob, step = backend(p)
-    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, 6, 3) - g["joint_start"]).max() < start_tol
-    ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
+    assert np.abs(np.stack([x[0] for x in ob.joints()]).reshape(2, L, D) - g["joint_start"]).max() < start_tol
+    if not octopod:
+        ob.set_tip_force(np.tile(np.array([0.0, 0.0, 4.0]), (1, 6, 1)))
     worst_walk = worst_stand = 0.0
     stood = False
     for k, row in enumerate(g["loops"]):
@@ -60,7 +72,7 @@ def replay_manual(backend, mode, start_tol=1e-12):
             step()
         else:
             assert int(ob.toggle_leg_state(np.array([leg], dtype=np.int32))[0]) == result, (k, leg, result)
-        d = np.abs(ob.joints()[0][0].reshape(6, 3) - g["joints"][k]).max()
+        d = np.abs(ob.joints()[0][0].reshape(L, D) - g["joints"][k]).max()
         stood = stood or ob.body_state()[2][0] == 3
         if stood:
             worst_stand = max(worst_stand, d)
