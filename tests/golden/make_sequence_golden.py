@@ -141,6 +141,60 @@ def transition_configuration(q0, target, transition_time):
     return out
 
 
+class Packer:
+    """PoseController::packLegs / unpackLegs (src/pose_controller.cpp:615-706) over LegPoser::transitionConfiguration (:1476-1567), call by call:
+    every leg runs a cubic-Bezier joint transition to the packed positions of the current pack step; a completed step hands over to the
+    next one (packLegs: pack_step_++ and progress 0 until the last step; unpackLegs: back through the steps, the last one to the unpacked
+    positions)."""
+
+    def __init__(self, q, packed, unpacked):
+        self.q = np.array(q, float)                     # [legs][dof] Joint::desired_position_
+        self.packed, self.unpacked = np.array(packed, float), np.array(unpacked, float)   # [steps][legs][dof], [legs][dof]
+        self.pack_step, self.executing = 0, False
+        self.first, self.count = [True] * len(self.q), [0] * len(self.q)
+        self.origin, self.desired = [None] * len(self.q), [None] * len(self.q)
+
+    def _transition(self, leg, time):
+        if self.first[leg]:
+            self.origin[leg] = self.q[leg].copy()
+            self.first[leg], self.count[leg] = False, 0
+        num = max(1, round_to_int(time / TIME_DELTA))
+        self.count[leg] += 1
+        t = self.count[leg] * (1.0 / num)
+        self.q[leg] = np.array([cubic_bezier([a, a, b, b], t) for a, b in zip(self.origin[leg], self.desired[leg])])
+        progress = min(max(int(((self.count[leg] - 1) / num) * 100), 1), 100)
+        if self.count[leg] >= num:
+            self.first[leg] = True
+            return 100
+        return progress
+
+    def pack(self, time):
+        progress = 0
+        for leg in range(len(self.q)):
+            if not self.executing:
+                self.desired[leg] = self.packed[self.pack_step][leg]
+            progress = self._transition(leg, time)
+        self.executing = progress not in (0, 100)
+        if progress == 100 and self.pack_step < len(self.packed) - 1:
+            self.executing = False
+            self.pack_step += 1
+            progress = 0
+        return progress
+
+    def unpack(self, time):
+        progress = 0
+        for leg in range(len(self.q)):
+            if not self.executing:
+                self.desired[leg] = self.packed[self.pack_step - 1][leg] if self.pack_step > 0 else self.unpacked[leg]
+            progress = self._transition(leg, time)
+        self.executing = progress not in (0, 100)
+        if progress == 100 and self.pack_step != 0:
+            self.executing = False
+            self.pack_step -= 1
+            progress = 0
+        return progress
+
+
 # (target offset from the origin tip, target rotation as a small rotation vector applied to the origin rotation or None,
 #  body pose position, body rotation vector, lift, time) - the origin itself is read from the leg the scenario names at replay
 STEP_SCENARIOS = {
@@ -206,5 +260,21 @@ if __name__ == "__main__":
         out[f"cfg/{name}/rows"] = np.array([[pr, *q] for pr, q in traj])
         out[f"cfg/{name}/target"] = q0[sc["leg"]] + np.array(sc["delta"])
         out[f"cfg/{name}/args"] = np.array([sc["leg"], sc["time"]])
+    # packLegs through two pack steps, unpackLegs back to the unpacked positions (the reference's `packed` / `unpacked` joint parameters;
+    # here: two synthetic pack steps folding the legs in, unpacked = default.yaml's)
+    pp = mw.make_params("tripod")
+    unpacked = np.array([[pp.joint[l][j].unpacked for j in range(3)] for l in range(6)])
+    fold = np.array([0.0, 0.9, -0.4])
+    packed = np.stack([unpacked + 0.5 * fold * np.array([1, 1, 1]), unpacked + fold + np.array([[0.3 * (1 if l < 3 else -1), 0, 0] for l in range(6)])])
+    pk = Packer(q0, packed, unpacked)
+    rows = []
+    for fn, tag in ((pk.pack, 0), (pk.unpack, 1)):
+        for _ in range(2000):
+            pr = fn(0.7)
+            rows.append([tag, pr, *pk.q.reshape(-1)])
+            if pr == 100:
+                break
+        assert pr == 100
+    out["pack/rows"], out["pack/packed"], out["pack/time"] = np.array(rows), packed, np.array([0.7])
     np.savez_compressed(os.path.join(HERE, "sequence_golden.npz"), **out)
     print("wrote", os.path.join(HERE, "sequence_golden.npz"), {k: v.shape for k, v in out.items() if k.endswith("rows")})

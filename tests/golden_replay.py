@@ -345,3 +345,18 @@ def replay_step_to_new_stance(backend, start_tol=1e-12):
         worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
         assert worst < 1e-6, (call, worst)
     return f"stepToNewStance: {len(g['new_stance/rows'])} calls, max |joint diff| {worst:.2e} rad"
+
+
+def replay_pack_unpack(backend, tol=1e-13):
+    """PoseController::packLegs through two pack steps, then unpackLegs back (tests/golden/make_sequence_golden.py, Packer): every return
+    value exactly - the hand-overs between pack steps return 0 -, joints to tol call by call."""
+    SEQ = _seq()
+    ob = _standing_hexapod(backend)
+    rows, packed, time_to_pack = SEQ["pack/rows"], SEQ["pack/packed"], float(SEQ["pack/time"][0])
+    worst = 0.0
+    for call, row in enumerate(rows):
+        progress = ob.pack_legs(packed, time_to_pack, unpack=bool(row[0]))
+        assert int(progress) == int(row[1]), (call, progress, row[1])
+        worst = max(worst, np.abs(ob.joints()[0][0] - row[2:]).max())
+        assert worst < tol, (call, worst)
+    return f"packLegs / unpackLegs: {len(rows)} calls over {len(packed)} pack steps, max |joint diff| {worst:.2e} rad"

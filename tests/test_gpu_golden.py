@@ -30,8 +30,8 @@ import os  # noqa: E402
 
 import numpy as np  # noqa: E402
 
-from golden_replay import (HERE, replay_configuration_transition, replay_startup_sequence, replay_step_to_new_stance,  # noqa: E402
-                           replay_step_to_position)
+from golden_replay import (HERE, replay_configuration_transition, replay_pack_unpack, replay_startup_sequence,  # noqa: E402
+                           replay_step_to_new_stance, replay_step_to_position)
 
 _SEQ = np.load(os.path.join(HERE, "sequence_golden.npz"))
 
@@ -55,3 +55,7 @@ def test_startup_sequence_golden_on_the_engine(start):
 
 def test_step_to_new_stance_golden_on_the_engine():
     parity_report("[HIP engine vs numpy golden] " + replay_step_to_new_stance(engine_backend, start_tol=1e-11))
+
+
+def test_pack_and_unpack_golden_on_the_engine():
+    parity_report("[HIP engine vs numpy golden] " + replay_pack_unpack(engine_backend, tol=1e-12))

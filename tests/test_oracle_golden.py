@@ -290,6 +290,13 @@ def test_configuration_transition_trajectories(name):
     replay_configuration_transition(oracle_backend, name)
 
 
+def test_pack_and_unpack_trajectories():
+    """PoseController::packLegs / unpackLegs (pose_controller.cpp:615-706) against the independent restatement (Packer in
+    tests/golden/make_sequence_golden.py): two pack steps in, back out to the unpacked positions."""
+    from golden_replay import oracle_backend, replay_pack_unpack
+    print(replay_pack_unpack(oracle_backend))
+
+
 @pytest.mark.parametrize("start", ["ready", "offset"])
 def test_startup_sequence_trajectories(start):
     """PoseController::executeSequence (pose_controller.cpp:145-459) against the independent numpy restatement of
