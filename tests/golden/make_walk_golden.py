@@ -344,6 +344,7 @@ class Leg:
         self.rot_defined = False    # current_tip_pose_.rotation_ != UNDEFINED_ROTATION (gravity-aligned tips, > 3 joints)
         self.cur_dir = self.origin_dir = self.model_dir = np.array([0.0, 0.0, -1.0])   # x axes of current / origin tip rotation, of the FK tip frame
         self.model_tip = None       # Leg::current_tip_pose_.position_ (FK of the joints), scenarios with the kinematic model
+        self.target_dir, self.target_dir_set = None, False   # x axis of LegStepper::target_tip_pose_.rotation_ (None: undefined)
         self.poser_dir = None       # x axis of LegPoser::current_tip_pose_.rotation_ (None: undefined)
         self.held = None            # Leg::current_tip_pose_ (position, x axis) where joint_control's updateManual has moved the joints under it
 
@@ -515,8 +516,12 @@ class RefWalker:
                     self.update_default_tip(leg)
             ground_contact = False
             if P.get("rough_terrain_mode"):
-                if leg.ext_target is not None:   # :1068-1079
-                    leg.target = remove_pose(leg.ext_target["pose"], leg.ext_target["transform"]).p
+                if leg.ext_target is not None:   # :1068-1079: target_tip_pose_ = pose_.removePose(transform_) - position AND rotation
+                    tp = remove_pose(leg.ext_target["pose"], leg.ext_target["transform"])
+                    leg.target = tp.p
+                    # (a requested pose without a rotation - the zero quaternion - stays undefined through the product)
+                    leg.target_dir = tp.r.apply(np.array([1.0, 0, 0])) if leg.ext_target.get("rot_defined", True) else None
+                    leg.target_dir_set = True
                     leg.swing_clearance = leg.swing_clearance / np.linalg.norm(leg.swing_clearance) * leg.ext_target["clearance"]
                     if leg.ext_target["odom_ideal"]:
                         leg.target = leg.target - np.array([self.v[0], self.v[1], 0.0]) * ((swing_iterations - it) * dt)
@@ -570,9 +575,18 @@ class RefWalker:
             leg.tip = leg.tip + delta
             leg.tip_velocity = delta / dt
 
-    def update_tip_rotation(self, leg):   # LegStepper::updateTipRotation (> 3 joints, target rotation = the gravity-aligned identity tip rotation)
-        target_dir = np.array([0.0, 0.0, -1.0])              # FromTwoVectors(UnitX, -UnitZ) * UnitX (walk_controller.cpp:37-41)
+    def update_tip_rotation(self, leg):   # LegStepper::updateTipRotation (:1193-1234), legs of more than 3 joints
+        if not leg.target_dir_set:        # target_tip_pose_ starts as the identity tip pose: gravity-aligned with the parameter, else undefined (:37-41)
+            leg.target_dir = np.array([0.0, 0.0, -1.0]) if self.P.get("gravity_aligned_tips") else None   # FromTwoVectors(UnitX, -UnitZ) * UnitX
+            leg.target_dir_set = True
         if leg.stance_progress >= 0.0 or leg.swing_progress >= 0.5:
+            if self.P.get("gravity_aligned_tips") and leg.target_dir is None:   # an undefined target is re-assigned from the gravity estimate (:1197-1205)
+                g = self.estimate_gravity()
+                leg.target_dir = g / np.linalg.norm(g)
+            if leg.target_dir is None:                        # "Target is undefined so set current tip rotation to undefined" (:1208-1211)
+                leg.rot_defined = False
+                return
+            target_dir = leg.target_dir
             leg.cur_dir = target_dir
             if leg.swing_progress >= 0.5:
                 c = smooth_step(min(1.0, 2.0 * (leg.swing_progress - 0.5)))
@@ -668,7 +682,8 @@ class RefWalker:
                 leg.state = FORCE_STOP
                 leg.phase = 0
             self.update_tip_position(leg)
-            if P.get("gravity_aligned_tips") and self.q is not None and self.q.shape[1] > 3:
+            # tip rotations matter on legs of more than 3 joints, with gravity-aligned tips or where a requested target may carry one (rough terrain mode)
+            if (P.get("gravity_aligned_tips") or P.get("rough_terrain_mode")) and self.q is not None and self.q.shape[1] > 3:
                 self.update_tip_rotation(leg)
             self.iterate_phase(leg)
         self.update_walk_plane()
@@ -1041,6 +1056,10 @@ SCENARIOS = {
     "tripod_wider_stance_span": ("tripod", {"stance_span_modifier": 0.3, "model": 1}, [(0, (0.5, 0.1), 0.2), (200, (0, 0), 0.0), (420, (0.3, -0.3), -0.3), (640, (0, 0), 0.0)], 800),
     "ripple_rough_narrower_stance_span": ("ripple", {"rough_terrain_mode": 1, "step_depth": 0.004, "stance_span_modifier": -0.25, "model": 1},
                                           [(0, (0.4, -0.1), 0.2), (330, (0, 0), 0.0)], 500),
+    # requested targets that carry tip rotations, on the 8 x 5 octopod in rough terrain mode WITHOUT gravity-aligned tips: the stepper's target
+    # rotation is whatever the last request left (removePose: pose.rotation * transform.rotation^-1), the tip turns towards it in the second
+    # half of the swing, the stance keeps it (rotation-constrained IK), a request without a rotation makes it undefined again (:1068-1071, :1193-1234)
+    "octopod_8x5_rough_target_rotations": ("ripple", {"rough_terrain_mode": 1, "model": 1, "morphology": "8x5"}, [(0, (0.35, 0.1), 0.15), (330, (0, 0), 0.0)], 440),
     "tripod_rough_external_requests": ("tripod", {"rough_terrain_mode": 1}, [(0, (0.5, 0.1), 0.2), (330, (0, 0), 0.0)], 520),
     "ripple_rough_reactive_step_depth": ("ripple", {"rough_terrain_mode": 1, "step_depth": 0.004}, [(0, (0.3, -0.2), -0.3)], 260),
 }
@@ -1064,6 +1083,20 @@ def rough_events(name, P):
             for leg in range(6):
                 ev.append((c, "transform_target", leg, tr))
                 ev.append((c, "transform_default", leg, [0.5 * t if i < 3 else t for i, t in enumerate(tr)]))
+    elif name == "octopod_8x5_rough_target_rotations":
+        sp = P["stance_position"]
+        tilt = lambda rv: [float(x) for x in (R.from_rotvec(rv) * from_two_vectors(np.array([1.0, 0, 0]), np.array([0, 0, -1.0]))).as_quat()[[3, 0, 1, 2]]]
+        # requested targets WITH tip rotations (the tip tilted off the vertical), one of them later replaced by a request without a rotation
+        for c, leg, dx, dy, dz, clearance, rv in ((60, 0, 0.02, -0.015, 0.0, 0.03, [0.25, 0.0, 0.0]), (60, 5, -0.015, 0.02, 0.004, 0.04, [0.0, -0.3, 0.0]),
+                                                  (150, 2, 0.02, 0.02, 0.0, 0.03, [0.15, 0.2, 0.0]), (230, 0, 0.01, 0.01, 0.0, 0.03, None)):
+            q = tilt(rv) if rv is not None else [0.0, 0.0, 0.0, 0.0]
+            ev.append((c, "target", leg, [sp[leg][0] + dx, sp[leg][1] + dy, dz, *q, clearance, 0]))
+        for c in range(62, 300, 6):     # generateExternalTargetTransforms: a slowly yawing, drifting walk plane frame
+            k = (c - 62) / 6.0
+            yaw = 0.003 * k
+            tr = [0.0005 * k, -0.0003 * k, 0.0, float(np.cos(yaw / 2)), 0.0, 0.0, float(np.sin(yaw / 2))]
+            for leg in range(8):
+                ev.append((c, "transform_target", leg, tr))
     elif name == "tripod_manual_and_inclination_posing":
         erng = np.random.default_rng(4242)
         for c in range(5, 480, 35):      # bodyPoseInputCallback: normalised velocity inputs (some axes idle)
@@ -1133,9 +1166,9 @@ def run(name):
         for ec, kind, leg, v in events:          # callbacks arrive between loops; the tf refresh is the first thing a loop does
             if ec != c:
                 continue
-            mk = lambda a: Pose(a[0:3], R.from_quat([a[4], a[5], a[6], a[3]]))
+            mk = lambda a: Pose(a[0:3], R.from_quat([a[4], a[5], a[6], a[3]]) if any(a[3:7]) else None)   # (a zero quaternion: rotation undefined)
             if kind in ("target", "default") and w.walk_state != STOPPED:   # targetTipPoseCallback (state_controller.cpp:1734-1757)
-                rec = dict(pose=mk(v), transform=Pose(), clearance=v[7], odom_ideal=bool(v[8]))
+                rec = dict(pose=mk(v), transform=Pose(), clearance=v[7], odom_ideal=bool(v[8]), rot_defined=bool(any(v[3:7])))
                 if kind == "target":
                     w.legs[leg].ext_target = rec
                 else:
