@@ -123,7 +123,7 @@ class Toggler:
         return 0, lin, ang
 
 
-def run(mode="tip_control", posing=False, octopod=False):
+def run(mode="tip_control", posing=False, octopod=False, auto=False):
     import zlib
     gait = "ripple" if octopod else "tripod"
     if octopod:                                  # the synthetic 8 x 5 octopod with gravity-aligned tips: the frozen walker's legs keep their
@@ -133,6 +133,8 @@ def run(mode="tip_control", posing=False, octopod=False):
         P = mw.hexapod(gait, admittance_control=1, manual_posing=1, leg_manipulation_mode=mode)
     if posing:                                   # the body pose keeps moving while the robot stands: IMU PID + the inclination translation
         P.update(imu_posing=1, inclination_posing=1)
+    if auto:                                     # cyclic auto posing: the posers' latches and the per-leg negation follow the (frozen) step phases
+        P.update(auto_posing=1, n_auto_posers=len(P["pose_phase_starts"]))
     w = mw.started_walker(P, gait, "8x5" if octopod else None)   # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
     q0, qd0 = w.q.copy(), w.qd.copy()
     if not octopod:
@@ -214,7 +216,8 @@ if __name__ == "__main__":
     out.update({"jc_" + k: v for k, v in jc.items()})
     out.update({"imu_" + k: v for k, v in run(posing=True).items()})
     out.update({"g85_" + k: v for k, v in run(octopod=True).items()})
+    out.update({"auto_" + k: v for k, v in run(auto=True).items()})
     np.savez_compressed(os.path.join(HERE, "manual_golden.npz"), **out)
-    for pre in ("", "jc_", "imu_", "g85_"):
+    for pre in ("", "jc_", "imu_", "g85_", "auto_"):
         k = out[pre + "loops"]
         print(pre or "tip_control", "loops", len(k), "toggle loops", int((k[:, 0] == 1).sum()), "results", sorted(set(k[k[:, 0] == 1][:, 2].astype(int).tolist())))

@@ -344,6 +344,7 @@ class Leg:
         self.rot_defined = False    # current_tip_pose_.rotation_ != UNDEFINED_ROTATION (gravity-aligned tips, > 3 joints)
         self.cur_dir = self.origin_dir = self.model_dir = np.array([0.0, 0.0, -1.0])   # x axes of current / origin tip rotation, of the FK tip frame
         self.model_tip = None       # Leg::current_tip_pose_.position_ (FK of the joints), scenarios with the kinematic model
+        self.negate_auto_pose, self.auto_pose = False, None   # LegPoser::negate_auto_pose_, auto_pose_
         self.target_dir, self.target_dir_set = None, False   # x axis of LegStepper::target_tip_pose_.rotation_ (None: undefined)
         self.poser_dir = None       # x axis of LegPoser::current_tip_pose_.rotation_ (None: undefined)
         self.held = None            # Leg::current_tip_pose_ (position, x axis) where joint_control's updateManual has moved the joints under it
@@ -384,6 +385,7 @@ class RefWalker:
         self.primary_velocity = self.secondary_velocity = self.primary_position = self.secondary_position = np.zeros(3)
         self.tip_align_pose, self.origin_tip_align_pose = Pose(), Pose()
         self.inclination = Pose()
+        self.auto_pose_now = Pose()
         self.tvi, self.rvi = np.zeros(3), np.zeros(3)   # translation / rotation_velocity_input_ (rewritten by the reset modes)
         self.reset_mode = 0
         self.prev_auto_r = R.identity()
@@ -741,6 +743,28 @@ class RefWalker:
                 pose = pose.add(Pose(bezier(nodes_p, t), euler_to_rot(bezier(nodes_r, t))))
         if complete == len(self.posers):
             self.auto_posing_state = POSING_COMPLETE
+        self.auto_pose_now = pose                            # PoseController::auto_pose_
+        for i, leg in enumerate(self.legs):                   # LegPoser::updateAutoPose(master_phase) (:1716-1778): the leg's own auto pose - the
+            sp, ep = P["pose_negation_phase_starts"][i] * self.pose_norm, P["pose_negation_phase_ends"][i] * self.pose_norm   # body's, negated over its window
+            sp = sp if sp != 0 else self.pose_length
+            ep = ep if ep != 0 else self.pose_length
+            phase = master
+            if sp > ep:
+                ep += self.pose_length
+                if phase < sp:
+                    phase += self.pose_length
+            if leg.state not in (FORCE_STANCE, FORCE_STOP) and phase == sp:
+                leg.negate_auto_pose = True
+            if phase < sp or phase > ep:
+                leg.negate_auto_pose = False
+            leg.auto_pose = pose
+            if leg.negate_auto_pose:
+                it, num = phase - sp + 1, ep - sp
+                ratio = P["negation_transition_ratio"][i]
+                c = 1.0
+                if ratio > 0.0:
+                    c = min(1.0, it / (num * ratio)) if it <= num // 2 else min(1.0, (num - it) / (num * ratio))
+                leg.auto_pose = remove_pose(pose, Pose().interpolate(smooth_step(c), pose))
         return pose
 
     def update_manual(self):   # WalkController::updateManual: the velocity overload (:652-708) then the pose overload (:712-744)
@@ -908,8 +932,11 @@ class RefWalker:
         self.update_manual()
         if self.q is not None:   # PoseController::updateStance + Model::updateModel: tips as seen from the posed body, one IK step per leg
             for i, leg in enumerate(self.legs):
-                poser_tip = pose.r.inv().apply(leg.tip - pose.p)          # Pose::inverseTransformVector (pose_controller.cpp:122-131)
-                ddir = pose.r.inv().apply(leg.cur_dir) if leg.rot_defined else None   # pose.rotation^-1 * walker tip rotation (:129-130)
+                lp = pose                                                 # the leg's pose: the body's with auto_pose_ replaced by the leg's own (:118-121)
+                if self.P.get("auto_posing") and not self.P.get("imu_posing"):
+                    lp = remove_pose(pose, self.auto_pose_now).add(leg.auto_pose)
+                poser_tip = lp.r.inv().apply(leg.tip - lp.p)              # Pose::inverseTransformVector (pose_controller.cpp:122-131)
+                ddir = lp.r.inv().apply(leg.cur_dir) if leg.rot_defined else None   # pose.rotation^-1 * walker tip rotation (:129-130)
                 delta = adm[i]
                 if leg.leg_state in (1, -1):                              # MANUAL / WALKING_TO_MANUAL: no posing (:134-137), no delta (model.cpp:655-656)
                     poser_tip, ddir, delta = leg.tip.copy(), (leg.cur_dir if leg.rot_defined else None), np.zeros(3)
@@ -954,7 +981,8 @@ def hexapod(gait, morphology=None, **kw):
     P.update(n_auto_posers=0, max_rotation=[p.max_rotation[i] for i in range(3)], rotation_pid_gains=[0.2, 0.02, 0.01])
     P.update(pose_phase_length=a["pose_phase_length"], pose_phase_starts=a["pose_phase_starts"], pose_phase_ends=a["pose_phase_ends"],
              roll_amplitudes=a["roll"], pitch_amplitudes=a["pitch"], yaw_amplitudes=a["yaw"], x_amplitudes=a["x"], y_amplitudes=a["y"],
-             z_amplitudes=a["z"])
+             z_amplitudes=a["z"], pose_negation_phase_starts=a["pose_negation_phase_starts"], pose_negation_phase_ends=a["pose_negation_phase_ends"],
+             negation_transition_ratio=a["negation_transition_ratio"])
     P.update(virtual_mass=p.virtual_mass, virtual_stiffness=p.virtual_stiffness, virtual_damping_ratio=p.virtual_damping_ratio,
              integrator_step_time=p.integrator_step_time, force_gain=p.force_gain, admittance_control=0, use_joint_effort=0,
              dynamic_stiffness=0, swing_stiffness_scaler=p.swing_stiffness_scaler, load_stiffness_scaler=p.load_stiffness_scaler)
@@ -1023,6 +1051,8 @@ SCENARIOS = {
     "amble_real_velocity_mode": ("amble", {"velocity_input_mode": "real"}, [(0, (0.05, 0.01), 0.05), (260, (0, 0), 0.0)], 560),
     "tripod_force_normal_touchdown": ("tripod", {"force_normal_touchdown": 1, "swing_width": 0.01}, [(0, (0.4, 0.5), -0.3)], 300),
     "tripod_auto_posing": ("tripod", {"auto_posing": 1, "n_auto_posers": None}, [(0, (0.7, 0.0), 0.0), (250, (0, 0), 0.0), (520, (0.0, 0.5), 0.5)], 760),
+    "tripod_auto_posing_model": ("tripod", {"auto_posing": 1, "n_auto_posers": None, "model": 1}, [(0, (0.6, 0.1), 0.1), (250, (0, 0), 0.0), (520, (0.0, 0.5), 0.5)], 700),
+    "wave_auto_posing_model": ("wave", {"auto_posing": 1, "n_auto_posers": None, "model": 1}, [(0, (0.5, -0.1), -0.1)], 500),
     "wave_imu_posing": ("wave", {"imu_posing": 1, "model": 1}, [(0, (0.5, 0.2), 0.1)], 400),
     # config 3's path: wave gait + admittance (tip force z ~ U(0, 20) N, x, y ~ N(0, 1), a new sample every 10 cycles) + IMU posing
     "wave_admittance_imu": ("wave", {"imu_posing": 1, "admittance_control": 1, "model": 1}, [(0, (0.4, -0.2), 0.15)], 400),

@@ -41,6 +41,8 @@ def replay_manual(backend, mode, start_tol=1e-12):
         g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
     elif octopod:
         g = {k[4:]: g[k] for k in g.files if k.startswith("g85_")}
+    elif mode == "auto_posing":
+        g = {k[5:]: g[k] for k in g.files if k.startswith("auto_")}
     if octopod:
         from syropod_highlevel_controller_amd import synthetic_octopod_params
         p = synthetic_octopod_params("ripple", 5, 8)
@@ -52,6 +54,8 @@ def replay_manual(backend, mode, start_tol=1e-12):
         p.admittance_control = 1
     L, D = p.leg_count, p.leg_dof[0]
     p.leg_manipulation_mode = 1 if mode == "joint_control" else 0
+    if mode == "auto_posing":
+        p.auto_posing = 1
     if posing:
         p.imu_posing, p.inclination_posing = 1, 1
         p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]

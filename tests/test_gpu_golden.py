@@ -16,7 +16,7 @@ def test_walk_golden_on_the_engine(name):
     parity_report(replay_walk(name, WALK[name]))
 
 
-@pytest.mark.parametrize("mode", ["tip_control", "joint_control", "imu_and_inclination_posing", "8x5_gravity_aligned_tips"])
+@pytest.mark.parametrize("mode", ["tip_control", "joint_control", "imu_and_inclination_posing", "8x5_gravity_aligned_tips", "auto_posing"])
 def test_manual_leg_golden_on_the_engine(mode):
     parity_report("[HIP engine vs numpy golden] " + replay_manual(engine_backend, mode, start_tol=1e-11))
 

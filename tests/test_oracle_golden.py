@@ -307,7 +307,7 @@ def test_startup_sequence_trajectories(start):
     print(replay_startup_sequence(oracle_backend, start))
 
 
-@pytest.mark.parametrize("mode", ["tip_control", "joint_control", "imu_and_inclination_posing", "8x5_gravity_aligned_tips"])
+@pytest.mark.parametrize("mode", ["tip_control", "joint_control", "imu_and_inclination_posing", "8x5_gravity_aligned_tips", "auto_posing"])
 def test_manual_leg_trajectories(mode):
     """Manual leg manipulation (legStateToggle, poseForLegManipulation, updateManual x 2, the manual-leg cases of updateStance /
     setDesiredTipPose / stepToPosition) against the independent numpy restatement of tests/golden/make_manual_golden.py, loop by
