@@ -3391,15 +3391,14 @@ int64_t orc_batch_change_gait(orc_batch *b, const shc_params *np)
 }
 
 /* WalkController::getOdometryIdeal (walk_controller.h) per robot: position xyz + rotation wxyz */
+void orc_get_odometry(const orc_robot *r, double o[7])
+{
+  o[0] = r->odometry_ideal.p.x; o[1] = r->odometry_ideal.p.y; o[2] = r->odometry_ideal.p.z;
+  o[3] = r->odometry_ideal.r.w; o[4] = r->odometry_ideal.r.x; o[5] = r->odometry_ideal.r.y; o[6] = r->odometry_ideal.r.z;
+}
 void orc_batch_get_odometry(orc_batch *b, double *pose)
 {
-  for (int64_t i = 0; i < b->n; ++i)
-  {
-    const orc_robot *r = &b->robots[i];
-    double *o = pose + 7 * i;
-    o[0] = r->odometry_ideal.p.x; o[1] = r->odometry_ideal.p.y; o[2] = r->odometry_ideal.p.z;
-    o[3] = r->odometry_ideal.r.w; o[4] = r->odometry_ideal.r.x; o[5] = r->odometry_ideal.r.y; o[6] = r->odometry_ideal.r.z;
-  }
+  for (int64_t i = 0; i < b->n; ++i) orc_get_odometry(&b->robots[i], pose + 7 * i);
 }
 
 /* Leg::getVirtualStiffness (model.h:264) per leg; the reference leaves the member uninitialised until the first

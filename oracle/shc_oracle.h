@@ -62,6 +62,7 @@ void orc_get_joint_state(const orc_robot *r, double *q, double *qd);            
 void orc_get_leg_state(const orc_robot *r, double *walker_tip, double *poser_tip, double *model_tip,
                        double *tip_force, double *admittance, int32_t *leg_status);
 void orc_get_body_state(const orc_robot *r, double pose[7], double velocity[3], int32_t *walk_state);
+void orc_get_odometry(const orc_robot *r, double pose[7]); /* WalkController::odometry_ideal_: xyz + wxyz */
 int orc_get_ik_failures(const orc_robot *r);
 
 /*

@@ -386,6 +386,7 @@ class RefWalker:
         self.tip_align_pose, self.origin_tip_align_pose = Pose(), Pose()
         self.inclination = Pose()
         self.auto_pose_now = Pose()
+        self.odometry = Pose()      # WalkController::odometry_ideal_
         self.tvi, self.rvi = np.zeros(3), np.zeros(3)   # translation / rotation_velocity_input_ (rewritten by the reset modes)
         self.reset_mode = 0
         self.prev_auto_r = R.identity()
@@ -689,6 +690,8 @@ class RefWalker:
                 self.update_tip_rotation(leg)
             self.iterate_phase(leg)
         self.update_walk_plane()
+        # odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (:643, :783-791): the desired body velocity integrated
+        self.odometry = self.odometry.add(Pose([self.v[0] * dt, self.v[1] * dt, 0.0], R.from_rotvec([0.0, 0.0, self.w * dt])))
 
     # ---- PoseController
     def update_walk_plane_pose(self):
@@ -1155,7 +1158,7 @@ def run(name):
         w.workspaces = workspaces_of(gait, morphology, prod["rough_terrain_mode"], prod["gravity_aligned_tips"])
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[], gait_request=[])
+    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], odometry=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[], gait_request=[])
     events = rough_events(name, P)
     gait_changed, meta_new_limits = False, {}
     lin, ang = (0.0, 0.0), 0.0
@@ -1251,6 +1254,7 @@ def run(name):
         out["walk_state"].append(w.walk_state)
         out["velocity"].append([w.v[0], w.v[1], w.w])
         out["pose"].append(w.current_pose.as7())
+        out["odometry"].append(w.odometry.as7())
     if morphology:
         over["morphology"] = morphology
     meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events, new_limits=meta_new_limits,

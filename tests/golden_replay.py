@@ -250,6 +250,10 @@ def replay_walk(name, meta, tol_x=1e-9):
             q[3:] = -q[3:]
         worst_pose = max(worst_pose, np.abs(q - g["pose"][c]).max())
         assert worst_tip < tol_x and worst_pose < tol_x, (name, c, worst_tip, worst_pose)
+        odo = eng.odometry()[0]               # WalkController::odometry_ideal_: the desired body velocity integrated (:643, :783-791)
+        if odo[3] < 0:
+            odo[3:] = -odo[3:]
+        assert np.abs(odo - g["odometry"][c]).max() < tol_x, (name, c, odo, g["odometry"][c])
         if "q" in g:
             worst_q = max(worst_q, np.abs(eng.joints()[0][0].reshape(*LD) - g["q"][c]).max())
             assert worst_q < 1e-6, (name, c, worst_q)

@@ -249,6 +249,12 @@ def test_walk_trajectories(name, meta):
             q[3:] = -q[3:]
         worst_pose = max(worst_pose, np.abs(q - g["pose"][c]).max())
         assert worst_tip < 1e-9 and worst_pose < 1e-9, (name, c, worst_tip, worst_pose)
+        odo = np.zeros(7)                     # WalkController::odometry_ideal_: the desired body velocity integrated (:643, :783-791)
+        L.orc_get_odometry.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_odometry(r.h, _ptr(odo))
+        if odo[3] < 0:
+            odo[3:] = -odo[3:]
+        assert np.abs(odo - g["odometry"][c]).max() < 1e-12, (name, c, odo, g["odometry"][c])
         if "q" in g:   # joints of the whole cycle (updateStance + setDesiredTipPose + applyIK) from the independent numpy chain, free-running
             worst_q = max(worst_q, np.abs(padded(r.joints()[0]) - g["q"][c]).max())
             assert worst_q < 1e-6, (name, c, worst_q)
