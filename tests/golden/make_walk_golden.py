@@ -1175,7 +1175,7 @@ def run(name):
     w.cycle(lin, ang)  # the loop that enters RUNNING runs one cycle with zero inputs (state_controller.cpp:277-281, :189-192)
     if over.get("model"):
         start = np.stack([w.q, w.qd])   # ... after that first loop: what the replay's robot must hold when it is handed over
-        out["q"] = []
+        out["q"], out["poser_tip"], out["model_tip"] = [], [], []
     for c in range(cycles):
         for first, l, a in schedule:
             if c == first:
@@ -1247,6 +1247,8 @@ def run(name):
         out["target"].append([leg.target.tolist() for leg in w.legs])
         if w.q is not None:
             out["q"].append(w.q.copy())
+            out["poser_tip"].append([leg.poser_tip for leg in w.legs])   # LegPoser / Leg current tip positions (LegState.msg poser_tip_pose, model_tip_pose)
+            out["model_tip"].append([leg.model_tip for leg in w.legs])
             out["tip_force_calc"].append(w.tip_force_calc.copy())
             out["stiffness"].append(list(w.stiffness))
         out["phase"].append([leg.phase for leg in w.legs])

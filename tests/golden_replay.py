@@ -256,6 +256,8 @@ def replay_walk(name, meta, tol_x=1e-9):
         assert np.abs(odo - g["odometry"][c]).max() < tol_x, (name, c, odo, g["odometry"][c])
         if "q" in g:
             worst_q = max(worst_q, np.abs(eng.joints()[0][0].reshape(*LD) - g["q"][c]).max())
+            for f in ("poser_tip", "model_tip"):   # what publishLegState sends of the LegPoser's and the leg's tip poses
+                assert np.abs(ls[f][0] - g[f][c]).max() < 1e-8, (name, c, f)
             assert worst_q < 1e-6, (name, c, worst_q)
             if meta["overrides"].get("dynamic_stiffness"):
                 assert np.abs(eng.virtual_stiffness()[0] - g["stiffness"][c]).max() < 1e-9, (name, c)

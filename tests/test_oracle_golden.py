@@ -257,6 +257,8 @@ def test_walk_trajectories(name, meta):
         assert np.abs(odo - g["odometry"][c]).max() < 1e-12, (name, c, odo, g["odometry"][c])
         if "q" in g:   # joints of the whole cycle (updateStance + setDesiredTipPose + applyIK) from the independent numpy chain, free-running
             worst_q = max(worst_q, np.abs(padded(r.joints()[0]) - g["q"][c]).max())
+            for f in ("poser_tip", "model_tip"):   # what publishLegState sends of the LegPoser's and the leg's tip poses
+                assert np.abs(ls[f] - g[f][c]).max() < 1e-9, (name, c, f)
             assert worst_q < 1e-6, (name, c, worst_q)
             if meta["overrides"].get("dynamic_stiffness"):   # Leg::virtual_stiffness_ as publishLegState reports it (state_controller.cpp:889)
                 from syropod_highlevel_controller_amd.params import LegStateMsg
