@@ -147,12 +147,14 @@ class Planner:
         return progress
 
 
-def run(posing=False):
+def run(posing=False, auto=False):
     import zlib
     gait = "tripod"
     P = mw.hexapod(gait, admittance_control=1, manual_posing=1)
     if posing:                                   # the body pose keeps moving while the robot stands and waits: IMU PID + inclination translation
         P.update(imu_posing=1, inclination_posing=1)
+    if auto:                                     # cyclic auto posing: the posers wind down after the stop, the legs' negation windows stay where the phases froze
+        P.update(auto_posing=1, n_auto_posers=len(P["pose_phase_starts"]))
     w = mw.started_walker(P, gait)               # joints: the numpy init chain's direct start-up + the first loop (nothing from oracle/ or the product)
     q0, qd0 = w.q.copy(), w.qd.copy()
     w.tip_force = np.tile(np.array([0.0, 0.0, 4.0]), (6, 1))
@@ -272,10 +274,13 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
     json.dump(events, open(os.path.join(HERE, "planner_golden_events.json"), "w"), indent=1)
     json.dump(events2, open(os.path.join(HERE, "planner_golden_events_imu.json"), "w"), indent=1)
+    out4, events4 = run(auto=True)               # the same plan with cyclic auto posing (keys auto_*)
+    out.update({"auto_" + k: v for k, v in out4.items()})
+    json.dump(events4, open(os.path.join(HERE, "planner_golden_events_auto.json"), "w"), indent=1)
     out3, events3 = run_gravity()                # the 8 x 5 octopod with gravity-aligned tips (keys g85_*)
     out.update({"g85_" + k: v for k, v in out3.items()})
     json.dump(events3, open(os.path.join(HERE, "planner_golden_events_8x5.json"), "w"), indent=1)
     np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **out)
-    for pre in ("", "imu_", "g85_"):
+    for pre in ("", "imu_", "g85_", "auto_"):
         r = out[pre + "rows"]
         print(pre or "plain", "loops", len(r), "plan results seen", sorted(set(r[r[:, 0] == 1][:, 1].astype(int).tolist()))[:6], "... final plan step", int(r[-1, 2]))

@@ -97,7 +97,10 @@ def replay_planner(backend, posing, start_tol=1e-12):
         g = {k[4:]: g[k] for k in g.files if k.startswith("imu_")}
     elif octopod:
         g = {k[4:]: g[k] for k in g.files if k.startswith("g85_")}
-    events_file = "planner_golden_events_imu.json" if imu else "planner_golden_events_8x5.json" if octopod else "planner_golden_events.json"
+    elif posing == "auto_posing":
+        g = {k[5:]: g[k] for k in g.files if k.startswith("auto_")}
+    events_file = ("planner_golden_events_imu.json" if imu else "planner_golden_events_8x5.json" if octopod else
+                   "planner_golden_events_auto.json" if posing == "auto_posing" else "planner_golden_events.json")
     events = {int(e[0]): e for e in json.load(open(os.path.join(HERE, events_file)))}
     if octopod:
         from syropod_highlevel_controller_amd import synthetic_octopod_params
@@ -109,6 +112,8 @@ def replay_planner(backend, posing, start_tol=1e-12):
         p = golden_hexapod_params("tripod")
         p.admittance_control = 1
     L, D = p.leg_count, p.leg_dof[0]
+    if posing == "auto_posing":
+        p.auto_posing = 1
     if imu:
         p.imu_posing, p.inclination_posing = 1, 1
         p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]

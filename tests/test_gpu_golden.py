@@ -21,7 +21,7 @@ def test_manual_leg_golden_on_the_engine(mode):
     parity_report("[HIP engine vs numpy golden] " + replay_manual(engine_backend, mode, start_tol=1e-11))
 
 
-@pytest.mark.parametrize("posing", ["walk_plane_posing", "imu_and_inclination_posing", "8x5_gravity_aligned_tips"])
+@pytest.mark.parametrize("posing", ["walk_plane_posing", "imu_and_inclination_posing", "8x5_gravity_aligned_tips", "auto_posing"])
 def test_planner_golden_on_the_engine(posing):
     parity_report("[HIP engine vs numpy golden] " + replay_planner(engine_backend, posing, start_tol=1e-11))
 

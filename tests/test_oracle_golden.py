@@ -327,7 +327,7 @@ def test_manual_leg_trajectories(mode):
     print(replay_manual(oracle_backend, mode))
 
 
-@pytest.mark.parametrize("posing", ["walk_plane_posing", "imu_and_inclination_posing", "8x5_gravity_aligned_tips"])
+@pytest.mark.parametrize("posing", ["walk_plane_posing", "imu_and_inclination_posing", "8x5_gravity_aligned_tips", "auto_posing"])
 def test_planner_trajectories(posing):
     """Planner mode (executePlan, PoseController::transitionConfiguration / transitionStance, the LegPoser's external target)
     against the independent numpy restatement of tests/golden/make_planner_golden.py, loop by loop: executePlan's result and
