@@ -213,15 +213,20 @@ class Sequencer:
         return -1 if self.first_execution else total
 
 
-def run(offset=None):
+def run(offset=None, octopod=False):
     from syropod_highlevel_controller_amd import default_hexapod_params
-    p = default_hexapod_params("tripod")
-    mw.MODEL = mw.Morphology.default_hexapod()
+    if octopod:                 # BASELINE.json config 4's synthetic 8 x 5 octopod: redundant chains through the same choreography
+        p = mw.make_params("ripple", "8x5")
+        mw.MODEL = mw.Morphology.from_params(p)
+    else:
+        p = default_hexapod_params("tripod")
+        mw.MODEL = mw.Morphology.default_hexapod()
+    L, D = p.leg_count, p.leg_dof[0]
     P = dict(time_delta=p.time_delta, body_clearance=p.body_clearance, swing_height=p.swing_height, step_frequency=p.step_frequency)
-    q0 = np.array([[p.joint[l][j].unpacked for j in range(3)] for l in range(6)])
+    q0 = np.array([[p.joint[l][j].unpacked for j in range(D)] for l in range(L)])
     if offset is not None:      # a robot switched on in some other configuration: the first START_UP has to feel its way
         q0 = q0 + offset
-    legs = [SeqLeg(l, q0[l], (p.stance_position[l][0], p.stance_position[l][1])) for l in range(6)]
+    legs = [SeqLeg(l, q0[l], (p.stance_position[l][0], p.stance_position[l][1])) for l in range(L)]
     seq = Sequencer(legs, P)
     out = {"q0": q0}
     for name, which in (("startup_first", START_UP), ("shutdown", SHUT_DOWN), ("startup_replay", START_UP)):
@@ -277,6 +282,8 @@ if __name__ == "__main__":
     off = rng.uniform(-0.25, 0.25, (6, 3))
     for k, v in run(off).items():
         out["offset/" + k] = v
+    for k, v in run(octopod=True).items():
+        out["8x5/" + k] = v
     np.savez_compressed(os.path.join(HERE, "startup_golden.npz"), **out)
     print({k: v.shape for k, v in out.items() if v.ndim == 2}, "transition steps", int(out["transition_steps"][0]), int(out["offset/transition_steps"][0]),
           "workspace alerts", int(out["proximity_alerts"][0]), int(out["offset/proximity_alerts"][0]))

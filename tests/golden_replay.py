@@ -325,15 +325,20 @@ def replay_configuration_transition(backend, name, tol=1e-13):
     return len(rows)
 
 
-def replay_startup_sequence(backend, start, offset_tol=1e-3):
+def replay_startup_sequence(backend, start, offset_tol=1e-3, octopod_tol=2e-2):
     """PoseController::executeSequence (tests/golden/make_startup_golden.py): a first START_UP, SHUT_DOWN, START_UP again (replay) - every return
     value exactly, joints to 1e-6 rad call by call from the READY estimate."""
     from syropod_highlevel_controller_amd import default_hexapod_params
     g = np.load(os.path.join(HERE, "startup_golden.npz"))
-    pre = "" if start == "ready" else "offset/"
-    ob, _ = backend(default_hexapod_params("tripod"))
-    ob.begin_sequence_startup(None if start == "ready" else g[pre + "q0"], False)
-    assert np.abs(ob.joints()[0][0].reshape(6, 3) - g[pre + "q0"]).max() == 0.0
+    pre = {"ready": "", "offset": "offset/", "8x5": "8x5/"}[start]
+    if start == "8x5":           # the synthetic 8 x 5 octopod from its READY estimate: redundant chains through the same choreography
+        from syropod_highlevel_controller_amd import synthetic_octopod_params
+        p = synthetic_octopod_params("ripple", 5, 8)
+    else:
+        p = default_hexapod_params("tripod")
+    ob, _ = backend(p)
+    ob.begin_sequence_startup(g[pre + "q0"] if start == "offset" else None, False)
+    assert np.abs(ob.joints()[0][0].reshape(p.leg_count, p.leg_dof[0]) - g[pre + "q0"]).max() == 0.0
     worst = 0.0
     for name, which in (("startup_first", 0), ("shutdown", 1), ("startup_replay", 0)):
         rows = g[pre + name]
@@ -343,7 +348,11 @@ def replay_startup_sequence(backend, start, offset_tol=1e-3):
             worst = max(worst, np.abs(ob.joints()[0][0] - row[1:]).max())
             # free-running through a slow body raise: the reference's IK step amplifies rounding differences there (DESIGN.md section
             # 2.1); the READY start stays within 1e-6 rad, the offset start is given what a twin build of the oracle itself needs
-            assert worst < (1e-6 if start == "ready" else offset_tol), (name, call, worst)
+            # The octopod's redundant chains: every return value, learnt transition step and workspace alert exactly; its first START_UP
+            # within 1e-6 rad, then the end of the SHUT_DOWN amplifies the difference by 10 per call up to 9 mrad before the replay pulls
+            # the chains together again - same place, not same rounding.
+            tol = 1e-6 if start == "ready" else offset_tol if start == "offset" else (1e-6 if name == "startup_first" else octopod_tol)
+            assert worst < tol, (name, call, worst)
         assert int(rows[-1][0]) == 100
     return (f"executeSequence from {start}: {sum(len(g[pre + k]) for k in ('startup_first', 'shutdown', 'startup_replay'))} calls, "
             f"{int(g[pre + 'transition_steps'][0])} transition steps learnt, {int(g[pre + 'proximity_alerts'][0])} workspace alerts, max |joint diff| {worst:.2e} rad")

@@ -46,7 +46,7 @@ def test_configuration_transition_golden_on_the_engine(name):
     replay_configuration_transition(engine_backend, name, tol=1e-12)
 
 
-@pytest.mark.parametrize("start", ["ready", "offset"])
+@pytest.mark.parametrize("start", ["ready", "offset", "8x5"])
 def test_startup_sequence_golden_on_the_engine(start):
     # (the offset start runs free through a slow body raise, where the reference's IK step amplifies rounding differences - DESIGN.md section
     #  2.1: two builds of the oracle itself end up 1e-3 rad apart there; same place to 5 mm, like every standing-robot bar of this suite)

@@ -305,7 +305,7 @@ def test_pack_and_unpack_trajectories():
     print(replay_pack_unpack(oracle_backend))
 
 
-@pytest.mark.parametrize("start", ["ready", "offset"])
+@pytest.mark.parametrize("start", ["ready", "offset", "8x5"])
 def test_startup_sequence_trajectories(start):
     """PoseController::executeSequence (pose_controller.cpp:145-459) against the independent numpy restatement of
     tests/golden/make_startup_golden.py: a first START_UP (learning its transition poses inside the joint-limit safety factor; from
