@@ -144,6 +144,68 @@ def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
             "single_thread_value": n1 * c1 / t1}
 
 
+PARITY_INSTANCES = 64
+
+
+class ParityWindow:
+    """SURVEY.md section 8(d) "Evidence": max |dq| of the HIP engine against the CPU oracle over the TIMED window.  The first PARITY_INSTANCES
+    instances' complete controller state is taken from the engine right before the window (shc_engine_get_state), the oracle is started from
+    it, given the same inputs (and the same input changes at the same cycles), stepped over the same number of cycles, and its joints are
+    compared with the engine's joints of the window's last cycle.  A twin oracle whose inputs are perturbed by 1e-13 tells which REFERENCE
+    trajectories are well-posed over the window (tests/test_gpu_parity.py header: the reference's one-step DLS with its normalised
+    joint-limit gradient is an expanding map for limit-pinned / redundant legs); the figure over those and over all instances are both reported.
+    Checker only: nothing here is inside a timed region, and the product never calls the oracle."""
+
+    def __init__(self, eng, p, lin, ang, extra, force_now=None):
+        self.p, self.m = p, min(PARITY_INSTANCES, eng.n)
+        m = self.m
+        self.st0 = eng.get_state(0, m)
+        self.inputs = {"lin": lin[:m].copy(), "ang": ang[:m].copy()}
+        for k in ("imu_q", "gyro", "effort"):
+            if k in extra:
+                self.inputs[k] = extra[k][:m].copy()
+        if force_now is not None:
+            self.inputs["force"] = force_now[:m].copy()
+        self.events = []      # (cycle offset inside the window, tip-force set) in order
+
+    def force_changed(self, offset, force):
+        self.events.append((int(offset), force[:self.m].copy()))
+
+    def evaluate(self, n_cycles, q_gpu, threads=None):
+        from oracle_lib import OracleBatch
+        threads = threads or min(os.cpu_count() or 1, 32)
+        m, eps = self.m, 1e-13
+        obs = []
+        for twin in (False, True):
+            ob = OracleBatch(self.p, m)
+            ob.set_state(self.st0)
+            k = 1.0 + (eps if twin else 0.0)
+            ob.set_velocity(self.inputs["lin"] * k, self.inputs["ang"])
+            if "imu_q" in self.inputs:
+                ob.set_imu(self.inputs["imu_q"], self.inputs["gyro"])
+            if "effort" in self.inputs:
+                ob.set_joint_effort(self.inputs["effort"])
+            if "force" in self.inputs:
+                ob.set_tip_force(self.inputs["force"] * k)
+            done = 0
+            for off, force in self.events + [(n_cycles, None)]:
+                off = min(off, n_cycles)
+                if off > done:
+                    ob.step(off - done, threads)
+                    done = off
+                if force is not None and off < n_cycles:
+                    ob.set_tip_force(force * k)
+            obs.append(ob.joints()[0])
+        q_cpu, q_twin = obs
+        dq = np.abs(np.asarray(q_gpu)[:m] - q_cpu).max(axis=1)
+        well = np.abs(q_cpu - q_twin).max(axis=1) <= 1e-9
+        return {"max_abs_dq": float(dq[well].max()) if well.any() else None, "max_abs_dq_all_instances": float(dq.max()), "unit": "rad",
+                "instances": int(m), "cycles": int(n_cycles), "well_posed_fraction": float(well.mean()), "tolerance": 1e-6,
+                "against": "CPU oracle (oracle/shc_oracle.c) started from the engine's state record at the start of the timed window, same inputs, "
+                           "free-running over the window; max_abs_dq over the instances whose reference trajectory is well-posed "
+                           "(a twin oracle with inputs x (1 + 1e-13) stays within 1e-9 rad), max_abs_dq_all_instances over all of them"}
+
+
 def measured_traffic(workload, n, cps):
     """HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel build (profiles/traffic.json, written by
     scripts/summarize_prof.py); null when the committed figure belongs to different kernel sources."""
@@ -197,14 +259,45 @@ class HostSpinBarrier:
                 return
 
 
-def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, host_barrier=None):
+class Watchdog:
+    """N > 1 regions must never hang the driver: if a region is still running after `seconds`, print ONE JSON line with an "error" (what
+    was running, on which rank) and leave the process.  A daemon timer thread: the main thread may be blocked inside a HIP / RCCL call."""
+
+    def __init__(self, seconds, what, rank=0, meta=None):
+        import threading
+        self.t = threading.Timer(seconds, self.fire)
+        self.t.daemon = True
+        self.what, self.rank, self.seconds, self.meta = what, rank, seconds, meta or {}
+
+    def fire(self):
+        line = {"metric": "control-cycles/sec (all legs IK-solved)", "value": None, "unit": "control-cycles/s", "error":
+                f"watchdog: '{self.what}' on rank {self.rank} did not finish within {self.seconds:.0f} s; the process was stopped instead of hanging"}
+        line.update(self.meta)
+        print(json.dumps(line), flush=True)
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.t.cancel()
+        return False
+
+
+def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, host_barrier=None, parity=None, gather_after_end=None):
     """Timed region of resident mode: `steps` ticks of the doorbell, one control cycle each, bracketed by synchronisation.
     N > 1 (final_gather): the region ends with the all-gather of the LAST cycle's joints.  It is queued on the engine's stream behind a
     device-side wait for that cycle (shc_engine_resident_get_joint_state_async) before the first tick, so only its execution - not
     its launch - follows the last cycle; the closing bracket is the synchronisation of that stream.
-    Returns (elapsed seconds for `steps` cycles, seconds per cycle of one long launch from HIP events on the launch stream)."""
+    gather_after_end (N > 1, the default there): the loop is ENDED first (shc_engine_resident_end: state written back, kernel gone), then the
+    joints are gathered - no collective kernel ever has to be scheduled next to a persistent loop; the region contains the ticks, the end
+    of the loop and the gather.
+    parity: a ParityWindow factory; the window is warm-up + timed ticks (the state record is taken before the loop starts).
+    Returns (elapsed seconds for `steps` cycles, seconds per cycle of one long launch from HIP events on the launch stream, parity dict)."""
     import ctypes
     import torch
+    pw = parity() if parity else None
     eng.resident_begin(ring_depth=depth, max_cycles=warmup + steps + 8)
     # the tick as the node's loop would issue it: one C call (bound once - attribute lookups and argument conversion of the Python wrapper
     # cost as much as a 3 us cycle); return codes are checked after the region
@@ -222,13 +315,29 @@ def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, ho
     t0 = time.perf_counter()
     for _ in range(steps):
         rcs.append(tick(handle, one))   # one tick = one cycle; the host does not wait for it
+    ended = False
     if final_gather:
         stream.synchronize()         # the gathered buffer is complete: every rank's last cycle has run
+    elif gather_after_end:
+        eng.resident_wait(max(warmup, 1) + steps, 60000)
+        eng.resident_end()           # the loop leaves the chip, the state is back in the engine's planes
+        ended = True
+        gather_after_end()           # SoA planes -> [n][legs][dof] + all_gather_into_tensor on the engine's stream
+        stream.synchronize()
     else:
         eng.resident_wait(max(warmup, 1) + steps, 60000)
     elapsed = time.perf_counter() - t0
     assert not any(rcs), "shc_engine_resident_publish failed"
-    eng.resident_end()
+    par = None
+    if ended:
+        q_last = eng.joints()[0] if pw else None   # (the state the loop wrote back: q of the window's last cycle)
+    else:
+        if pw:
+            q_last = eng.resident_joints(max(warmup, 1) + steps - 1)[0]   # the output ring still holds the window's last cycle
+        eng.resident_end()
+    if pw:
+        par = pw.evaluate(max(warmup, 1) + steps, q_last)
+        par["window"] = f"{max(warmup, 1)} warm-up + {steps} timed doorbell ticks of the resident loop; the engine's joints are the output ring's slot of the last cycle"
     # kernel time per cycle: one launch of m cycles released at once, HIP events on the launch stream around it
     m = 4000
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -238,11 +347,11 @@ def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, ho
     eng.resident_end()               # stops after the m published cycles, waits for the kernel
     e1.record(stream)
     torch.cuda.synchronize()
-    return elapsed, e0.elapsed_time(e1) * 1e-3 / m
+    return elapsed, e0.elapsed_time(e1) * 1e-3 / m, par
 
 
 def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False, joint_efforts=False,
-                 mode="auto"):
+                 mode="auto", gather_under_loop=False, want_parity=True):
     """One workload on this rank's GPU: prepare (untimed), time `steps` steps, measure the kernel with HIP events.
     dist_ctx = (world, rank, local_rank) when the RCCL path is active."""
     import torch
@@ -259,14 +368,23 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     apply_inputs(eng, lin * 0.0, ang * 0.0, extra)
     # config 3: the measured tip forces are resampled every 10 cycles from sets resident in HBM
     force_sets = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in extra.get("force_sets", [])]
-    state = {"cycle": 0}
+    state = {"cycle": 0, "force": extra.get("force"), "window": None, "window_start": 0}
 
     def step_once():
         if force_sets and state["cycle"] % 10 < cps and state["cycle"] > 0:
-            f = force_sets[(state["cycle"] // 10) % len(force_sets)]
-            eng.L.shc_engine_set_tip_force(eng.h, f.data_ptr(), 1)  # device pointer: a scatter kernel on the engine's stream
+            k = (state["cycle"] // 10) % len(force_sets)
+            eng.L.shc_engine_set_tip_force(eng.h, force_sets[k].data_ptr(), 1)  # device pointer: a scatter kernel on the engine's stream
+            state["force"] = extra["force_sets"][k]
+            if state["window"] is not None:   # (host-side note for the parity replay; no device work)
+                state["window"].force_changed(state["cycle"] - state["window_start"], state["force"])
         eng.step(cps)
         state["cycle"] += cps
+
+    def open_parity_window():   # the engine's state record + the inputs in force, right before a timed window (untimed)
+        eng.synchronize()
+        state["window"] = ParityWindow(eng, p, lin, ang, extra, state["force"])
+        state["window_start"] = state["cycle"]
+        return state["window"]
 
     # ---- untimed preparation: de-phase the instances (instance i receives its command i mod period cycles late),
     #      then walk until every instance is MOVING.
@@ -300,6 +418,8 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
 
     # resident mode: batches that fit the chip once, one cycle per step, nothing that needs a launch between steps
     resident = False
+    if use_dist and mode == "auto":
+        mode = "launch"   # N > 1: launch mode unless resident mode is asked for (north_star states the scaling target on config 4, which does not fit the chip once)
     if mode != "launch" and cps == 1 and not force_sets and not gather_every:
         try:
             eng.resident_begin(ring_depth=4, max_cycles=4)
@@ -313,6 +433,9 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     launch_elapsed = None
     posted_value = None
     host_barrier = None
+    parity = None
+    nogather_elapsed = gather_s = None
+    wd_meta = {"n_gpus": world, "config": {"workload": f"BASELINE.json {name}: {n} per GPU", "mode": mode}}
     if use_dist:
         gather()
         dist.barrier()
@@ -331,13 +454,18 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         # (time_resident's own clock brackets exactly `steps` doorbell ticks; the gather of the final joints follows inside the region)
-        if use_dist:   # N > 1: the all-gather of the final joints belongs to the region
+        pfac = (lambda: ParityWindow(eng, p, lin, ang, extra, state["force"])) if want_parity else None
+        if use_dist and gather_under_loop:   # asked for: the gather is queued behind a device-side wait while the loop is alive
             def final_gather(cycle):
                 eng.resident_joints_async(cycle, qshard.data_ptr())
                 all_gather_joints(qshard, world, out=gathered)
-            res_elapsed, res_cycle_s = time_resident(eng, n, steps, warmup, stream, final_gather=final_gather, host_barrier=host_barrier)
+            with Watchdog(180, "resident region with the all-gather queued under the live loop", rank, wd_meta):
+                res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, final_gather=final_gather, host_barrier=host_barrier, parity=pfac)
+        elif use_dist:   # N > 1 default: end the loop, then gather - no collective kernel next to a persistent loop
+            with Watchdog(180, "resident region, loop ended before the all-gather", rank, wd_meta):
+                res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, gather_after_end=gather, host_barrier=host_barrier, parity=pfac)
         else:
-            res_elapsed, res_cycle_s = time_resident(eng, n, steps, warmup, stream)
+            res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, parity=pfac)
         elapsed = res_elapsed
         # secondary figure: a NEW velocity command for every robot in every cycle, from arrays resident in HBM (post + doorbell in one launch)
         posted_value = None
@@ -360,16 +488,39 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     else:
         for _ in range(warmup):
             step_once()
+        pw = open_parity_window() if want_parity else None
+        if use_dist:
+            dist.barrier()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            step_once()
-            if gather_every and (i + 1) % gather_every == 0:
+        with Watchdog(300, "timed region: steps + all-gather of the final joints" if use_dist else "timed region", rank, wd_meta):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                step_once()
+                if gather_every and (i + 1) % gather_every == 0:
+                    gather()
+            if not gather_every or steps % gather_every:
                 gather()
-        if not gather_every or steps % gather_every:
-            gather()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0  # this rank's K steps + its part of the gather; the MAX over ranks below is the job's time
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0  # this rank's K steps + its part of the gather; the MAX over ranks below is the job's time
+        state["window"] = None
+        if pw:
+            parity = pw.evaluate(steps * cps, eng.joints()[0])
+            parity["window"] = f"the {steps} timed steps ({steps * cps} control cycles, one launch of the fused cycle kernel per step)"
+        if use_dist:   # the same K steps without the gather, and the gather on its own (reported next to `value`, which contains both)
+            with Watchdog(300, "steps without the gather / gather alone", rank, wd_meta):
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(steps):
+                    step_once()
+                torch.cuda.synchronize()
+                nogather_elapsed = time.perf_counter() - t1
+                dist.barrier()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                gather()
+                torch.cuda.synchronize()
+                gather_s = time.perf_counter() - t1
     if use_dist:
         dist.barrier()  # closing bracket (the all-gather inside the region already needed every rank's shard)
         torch.cuda.synchronize()
@@ -377,9 +528,11 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         # the gathered buffer must hold every rank's shard in rank order: check this rank's own slice
         own = gathered[rank * qshard.numel():(rank + 1) * qshard.numel()]
         assert torch.equal(own, qshard), "all-gather returned a different shard for this rank"
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, nogather_elapsed or 0.0, gather_s or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if nogather_elapsed is not None:
+            nogather_elapsed, gather_s = float(t[1].item()), float(t[2].item())
 
     # ---- kernel duration of the cycle kernel, HIP events on the launch stream.  Two upper bounds on the true duration:
     #      (a) one event pair per launch (adds the event-record latency), (b) one pair around m back-to-back launches
@@ -453,7 +606,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     else:
         roofline = launch_roofline
     res = {
-        "value": world * n * steps * cps / elapsed, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3,
+        "value": world * n * steps * cps / elapsed, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "parity": parity,
         "config": {"workload": f"BASELINE.json {name}: {n} {desc}", "instances_per_gpu": n, "cycles_per_step": cps,
                    "mode": ("resident: one launch stays on the chip, a step = one doorbell tick = one control cycle with that cycle's inputs from the "
                             "device-side rings and its q / qd to the output ring") if resident else "one launch of the fused cycle kernel per step",
@@ -463,7 +616,14 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                    "gather": f"all-gather of the joint buffer every {gather_every} steps" if gather_every
                    else ("one all-gather of the final joint buffer, inside the timed region: queued on the engine's stream behind a device-side wait for the "
                          "region's last cycle before the first tick (stream-ordered, like a captured graph); the region closes when it has completed"
-                         if (use_dist and resident) else "one all-gather of the final joint buffer (N > 1), launched after the last step inside the timed region"),
+                         if (use_dist and resident and gather_under_loop) else
+                         ("one all-gather of the final joint buffer inside the timed region, after shc_engine_resident_end (the persistent loop has left the chip before "
+                          "any collective kernel runs)" if (use_dist and resident) else
+                          "one all-gather of the final joint buffer (N > 1), launched after the last step inside the timed region; value_without_gather / gather_ms: "
+                          "the same K steps without it and the gather on its own, measured right after (max over ranks)")),
+                   "value_without_gather": (world * n * steps * cps / nogather_elapsed) if nogather_elapsed else None,
+                   "gather_ms": gather_s * 1e3 if gather_s is not None else None,
+                   "gather_bytes_per_rank": int(qshard.numel() * 8) if use_dist else None,
                    "moving_fraction": moving_frac, "finite": finite, "seed": seed, "fused_16_cycles_per_launch_value": fused_value,
                    "two_stream_split": n_waves >= 4096, "single_stream": single_stream},
         "roofline": roofline,
@@ -543,7 +703,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="config2")
+    ap.add_argument("--workload", default=None, help="default: config2 on one GPU (the configuration the metric is quoted on); N > 1: config4, 131 072 octopods "
+                    "per GPU in launch mode (the 2^20-instance batch north_star states the weak-scaling target on)")
+    ap.add_argument("--gather-under-loop", action="store_true", help="N > 1 with --mode resident: queue the all-gather behind a device-side wait while the "
+                    "persistent loop is still alive (default: the loop is ended first)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity block (max |dq| against the CPU oracle over the timed window)")
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: 4096 for config2)")
     ap.add_argument("--cycles-per-step", type=int, default=1)
     ap.add_argument("--gather-every", type=int, default=0, help="all-gather the joint buffer every G steps (0 = once, at the end)")
@@ -551,8 +715,8 @@ def main():
     ap.add_argument("--no-fused-probe", action="store_true", help="skip the secondary 16-cycles-per-launch figure (keeps rocprof stats to one launch shape)")
     ap.add_argument("--no-also", action="store_true", help="skip the config 3 / config 4 measurements reported under config.also")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather path even with one rank")
-    ap.add_argument("--joint-efforts", action="store_true", help="(default since round 3) supply measured joint torques: the tip-force estimate "
-                    "(Leg::calculateTipForce) is evaluated every cycle")
+    ap.add_argument("--joint-efforts", action="store_true", help="supply measured joint torques: the tip-force estimate (Leg::calculateTipForce) is evaluated "
+                    "every cycle (the default for config2, the headline; the other workloads are BASELINE.json's \"IK + Bezier\" / tip-state-message variants without it)")
     ap.add_argument("--no-joint-efforts", action="store_true", help="primary line without measured joint torques (Leg::calculateTipForce idle)")
     ap.add_argument("--mode", choices=("auto", "resident", "launch"), default="auto",
                     help="auto: resident mode where the batch fits the chip once (config 2), one launch per step otherwise")
@@ -577,6 +741,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.workload is None:
+        args.workload = "config4" if world > 1 else "config2"
     n = args.instances or DEFAULT_INSTANCES[args.workload]
     if args.workload == "config5":
         if world > 1:
@@ -593,7 +759,8 @@ def main():
     res = run_workload(args.workload, n, args.steps, args.warmup, args.cycles_per_step, args.seed,
                        dist_ctx=(world, rank, local_rank) if use_dist else None, gather_every=args.gather_every,
                        fused_probe=not args.no_fused_probe, want_cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline),
-                       joint_efforts=primary_efforts, mode=args.mode)
+                       joint_efforts=primary_efforts and (args.workload == "config2" or args.joint_efforts), mode=args.mode,
+                       gather_under_loop=args.gather_under_loop, want_parity=(rank == 0 and not args.no_parity))
     # The other single-GPU BASELINE.json configurations, measured in the same process (N = 1 default run only):
     # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
     also = []
@@ -611,7 +778,7 @@ def main():
                          "one_launch_per_cycle_value": r["config"]["one_launch_per_cycle_value"],
                          "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],
                          "two_stream_split": r["config"]["two_stream_split"], "single_stream": r["config"]["single_stream"],
-                         "roofline": r["roofline"]})
+                         "roofline": r["roofline"], "parity": r["parity"]})
         try:
             also.append(run_config5(DEFAULT_INSTANCES["config5"], 100, 10, args.seed))
         except Exception as exc:  # noqa: BLE001
@@ -624,7 +791,7 @@ def main():
             "metric": "control-cycles/sec (all legs IK-solved)", "value": res["value"], "unit": "control-cycles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": cfg, "roofline": res["roofline"],
+            "config": cfg, "roofline": res["roofline"], "parity": res["parity"],
         }
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]

@@ -61,23 +61,30 @@ def force_sample(rng, n, legs):
 
 
 @pytest.mark.parametrize("waves", ["two_waves", "one_wave"])
-@pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4", "config2_body_posing", "config3_body_posing_inclination"])
+@pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4", "config2_body_posing", "config3_body_posing_inclination",
+                                  "config2_joint_efforts", "config3_joint_efforts", "config3_joint_efforts_feed_admittance", "octopod_joint_efforts"])
 def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves):
     """Every cycle gets new inputs.  Engine A: set_* + shc_engine_step(1) per cycle.  Engine B: one resident launch, inputs posted per
     cycle.  q / qd of EVERY cycle (output ring) and the complete state record at the end are equal byte for byte - for the
-    two-wavefront (walker / model) pipeline, which these batch sizes get by default, and for one wavefront per robot group."""
+    two-wavefront (walker / model) pipeline, which these batch sizes get by default, and for one wavefront per robot group.
+    *_joint_efforts: measured joint torques are live (shc_engine_set_joint_effort before the loop starts, new torques through the RG_EFFORT
+    ring every few cycles) - the kernels with Leg::calculateTipForce (model.cpp:667-708), i.e. what bench.py's headline number runs on;
+    *_feed_admittance: use_joint_effort, the estimate drives the admittance (admittance_controller.cpp:30-31)."""
     from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE
     rng = np.random.default_rng(11)
-    if case == "config2":
+    efforts_live = "joint_efforts" in case
+    if case in ("config2", "config2_joint_efforts"):
         p, n = default_hexapod_params("tripod"), 333
     elif case == "config2_body_posing":   # joystick body posing: pose inputs and reset modes change while the loop runs (the pose runs on the model wavefront)
         p, n = default_hexapod_params("tripod"), 171
     elif case == "config3_body_posing_inclination":
         p, n = config3_params(), 93
         p.inclination_posing = 1
-    elif case == "config3":
+    elif case in ("config3", "config3_joint_efforts", "config3_joint_efforts_feed_admittance"):
         p, n = config3_params(), 250
-    elif case == "octopod":
+        if case.endswith("feed_admittance"):
+            p.use_joint_effort = 1
+    elif case in ("octopod", "octopod_joint_efforts"):
         p, n = synthetic_octopod_params("ripple", 5, 8), 203
     else:
         p, n = synthetic_octopod_params("amble", 4, 4), 130
@@ -89,10 +96,16 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
     pose_in = [(rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.7), rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.7)) if c % 4 == 0 else None
                for c in range(cycles)] if posing else None
     resets = [rng.integers(0, 6, n).astype(np.int32) if c % 37 == 5 else (np.zeros(n, dtype=np.int32) if c % 37 == 11 else None) for c in range(cycles)] if posing else None
+    nje = p.leg_count * max(p.leg_dof[l] for l in range(p.leg_count))
+    efforts = [rng.normal(0, 0.5, (n, nje)) if (efforts_live and c % 5 == 2) else None for c in range(cycles)]
     a, b = Engine(p, n), Engine(p, n)
     if posing:
         for e in (a, b):   # (the manual-pose group of the state is live from the first pose input on)
             e.set_pose_input(np.zeros((n, 3)), np.zeros((n, 3)))
+    if efforts_live:
+        e0 = rng.normal(0, 0.5, (n, nje))
+        for e in (a, b):   # (the tip-force estimate is live from the first torque on: the kernels with calculateTipForce)
+            e.set_joint_effort(e0)
     if waves == "one_wave":
         b.set_features(FEAT_DEFAULT | FEAT_RESIDENT_ONE_WAVE)
     for e in (a, b):   # some history before the resident run starts
@@ -110,6 +123,8 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
                 a.set_pose_input(*pose_in[c])
             if resets[c] is not None:
                 a.set_pose_reset_mode(resets[c])
+        if efforts[c] is not None:
+            a.set_joint_effort(efforts[c])
         a.step(1)
         qa.append(a.joints())
     a.synchronize()
@@ -129,6 +144,8 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
                     kw["pose_input"] = pose_in[c]
                 if resets[c] is not None:
                     kw["pose_reset_mode"] = resets[c]
+            if efforts[c] is not None:
+                kw["joint_effort"] = efforts[c]
             if case in ("config2", "config3_body_posing_inclination") and c == c1 - 1:
                 kw["publish"] = True     # the last post of the group releases the group: post + doorbell in one kernel launch
             assert b.resident_post(**kw) == c
@@ -140,6 +157,8 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
             assert np.array_equal(q, qa[c][0]) and np.array_equal(qd, qa[c][1]), f"cycle {c}"
     assert b.resident_end() == cycles
     assert state_bytes(a) == state_bytes(b)
+    if efforts_live:   # (the estimate is really being evaluated: a dead filter would be byte-identical too)
+        assert np.abs(a.leg_state()["tip_force"]).max() > 1e-3
     # ... and the engines go on identically through ordinary launches (held inputs were carried over)
     for e in (a, b):
         e.step(25)
@@ -173,6 +192,74 @@ def test_resident_with_velocities_changing_every_cycle_matches_the_oracle(Engine
     assert worst <= 1e-6
     _, _, ws = eng.body_state()
     assert np.array_equal(ws, ob.body_state()[2])
+    eng.close()
+
+
+@pytest.mark.parametrize("case", ["config2", "config3"])
+def test_resident_full_size_with_joint_efforts_matches_the_oracle(Engine, case):
+    """bench.py's headline configuration as it is benchmarked - 4 096 hexapods in resident mode on the two-wavefront kernel with measured
+    joint torques live (shc_resident2_kernel<6, 3, C2 | F_TIPF>; config3: <6, 3, C3 | F_TIPF>) - free-running against the oracle on a
+    128-instance slice spread over the batch (first / middle / last wavefronts): joints within 1e-6 rad, the tip-force estimate within
+    1e-9 N, new torques and a new velocity command every few cycles through the input rings."""
+    n, cycles, burst = 4096, 300, 20
+    p = default_hexapod_params("tripod") if case == "config2" else config3_params()
+    rng = np.random.default_rng(21)
+    sel = np.concatenate([np.arange(0, 48), np.arange(2040, 2080), np.arange(n - 40, n)])
+    lin, ang = rng.uniform(-0.7, 0.7, size=(n, 2)), rng.uniform(-1, 1, size=n)
+    eff0 = rng.normal(0, 0.5, (n, 18))
+    # config 3's U(0, 20) N tip forces press legs into their joint limits, where the reference's one-step DLS map is expanding
+    # (tests/test_gpu_parity.py header): a twin oracle with inputs perturbed by 1e-13 tells which reference trajectories are
+    # well-posed; the bar is evaluated on those and the fraction is asserted and reported.  config 2: every instance.
+    eng, ob = Engine(p, n), OracleBatch(p, len(sel))
+    tw = OracleBatch(p, len(sel)) if case == "config3" else None
+    eng.set_joint_effort(eff0)
+    for o in (ob, tw):
+        if o is not None:
+            o.set_joint_effort(eff0[sel])
+    if case == "config3":
+        imu = imu_sample(rng, n)
+        f0 = force_sample(rng, n, 6)
+        eng.set_imu(*imu)
+        eng.set_tip_force(f0)
+        for o in (ob, tw):
+            o.set_imu(imu[0][sel], imu[1][sel])
+        ob.set_tip_force(f0[sel])
+        tw.set_tip_force(f0[sel] * (1 + 1e-13))
+    eng.resident_begin(ring_depth=8, max_cycles=cycles)
+    worst_q = worst_tf = 0.0
+    well = np.ones(len(sel), dtype=bool)
+    for c0 in range(0, cycles, burst):
+        k = 1.0 - 0.3 * np.sin(0.01 * c0 + np.arange(n))
+        v = (lin * k[:, None], ang * k)
+        eff = rng.normal(0, 0.5, (n, 18))
+        kw = {"velocity": v, "joint_effort": eff}
+        if case == "config3":
+            f = force_sample(rng, n, 6)
+            kw["tip_force"] = f
+            ob.set_tip_force(f[sel])
+            tw.set_tip_force(f[sel] * (1 + 1e-13))
+        assert eng.resident_post(**kw) == c0
+        eng.resident_publish(burst)
+        for o in (ob, tw):
+            if o is not None:
+                o.set_velocity(v[0][sel] * (1 + 1e-13 * (o is tw)), v[1][sel])
+                o.set_joint_effort(eff[sel])
+                o.step(burst, 4)
+        if tw is not None:
+            well &= np.abs(ob.joints()[0] - tw.joints()[0]).max(axis=1) <= 1e-11
+        eng.resident_wait(c0 + burst)
+        q, _ = eng.resident_joints(c0 + burst - 1)
+        worst_q = max(worst_q, float(np.abs(q[sel] - ob.joints()[0])[well].max()))
+    assert eng.resident_end() == cycles
+    tf_gpu, tf_cpu = eng.leg_state()["tip_force"][sel], ob.leg_state()["tip_force"]
+    worst_tf = float(np.abs(tf_gpu - tf_cpu)[well].max())
+    parity_report(f"resident mode at bench size with joint efforts live [{case}], {n} hexapods x {cycles} cycles, {len(sel)} instances against the oracle: "
+                  f"max |dq| = {worst_q:.2e} rad, max |d tip_force_calculated| = {worst_tf:.2e} N (estimate up to {np.abs(tf_cpu).max():.2f} N) over "
+                  f"{'all of them' if tw is None else f'the {well.mean():.0%} whose reference trajectory is well-posed'}")
+    assert np.abs(tf_cpu).max() > 1e-2
+    assert well.mean() >= 0.85
+    assert worst_q <= 1e-6 and worst_tf <= (1e-9 if tw is None else 2e-4)   # (the filter remembers earlier joint differences: ~100 N / rad)
+    assert np.array_equal(eng.body_state()[2][sel][well], ob.body_state()[2][well])
     eng.close()
 
 
