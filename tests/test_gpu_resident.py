@@ -401,3 +401,74 @@ def test_resident_at_the_kernel_boundaries(Engine, n):
     assert state_bytes(a) == state_bytes(b)
     a.close()
     b.close()
+
+
+def test_collective_shaped_kernel_next_to_a_live_loop(Engine, tmp_path):
+    """What `bench.py --gpus N --mode resident --gather-under-loop` relies on and a one-GPU box cannot rehearse with RCCL itself (two ranks
+    on one device are refused): a kernel of the shape of a collective - 32 workgroups x 512 threads, 40 KiB of LDS each, every block
+    spinning on every other block's flags, i.e. all of them must be co-resident - queued on the engine's stream behind
+    shc_engine_resident_get_joint_state_async WHILE the persistent loop of bench.py's headline batch (4 096 hexapods, two-wavefront
+    kernel, joint efforts live) is alive and stepping.  It must be scheduled next to the loop, finish all its rounds, and the loop must
+    keep running; every wait is bounded on the device, so a starved probe is a test failure, not a hung GPU.  (bench.py's default for
+    N > 1 does not depend on this: it ends the loop before the gather.)"""
+    import subprocess
+    import os
+    import ctypes as C
+    from syropod_highlevel_controller_amd import engine
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "collective_shape_probe.hip")
+    so = str(tmp_path / "libcollective_shape_probe.so")
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so, src], cwd=str(tmp_path))
+    P = C.CDLL(so)
+    P.probe_prepare.argtypes = [C.c_int, C.c_int64, C.c_int]
+    P.probe_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    P.probe_stream_wait.argtypes = [C.c_void_p, C.c_int]
+    P.probe_result.argtypes = [C.POINTER(C.c_uint64)]
+    L = engine.lib()
+    stream = C.c_void_p()
+    assert L.shc_stream_create(0, C.byref(stream)) == 0
+    p, n = default_hexapod_params("tripod"), 4096
+    rng = np.random.default_rng(2)
+    eng = Engine(p, n, stream=stream.value)
+    eng.set_velocity(rng.uniform(-0.7, 0.7, (n, 2)), rng.uniform(-1, 1, n))
+    eng.set_joint_effort(rng.normal(0, 0.5, (n, 18)))
+    eng.step(50)
+    eng.synchronize()
+    blocks, threads, lds, rounds, n_doubles = 32, 512, 40 * 1024, 200, 1 << 20
+    import torch   # (device buffers for the stream-ordered read)
+    q = torch.zeros(n * 18, dtype=torch.float64, device="cuda")
+
+    def run_probe(stepping):
+        assert P.probe_prepare(blocks, n_doubles, lds) == 0
+        if stepping:   # (a) the loop is busy stepping for the whole life of the probe: ~1.2 s of cycles released at once
+            total = 400000
+            eng.resident_begin(ring_depth=8, max_cycles=total + 8)
+            eng.resident_publish(total)
+            eng.resident_wait(100)
+        else:          # (b) bench.py's sequence: the read of the region's LAST cycle, the collective behind it; the loop then polls its gate
+            total = 3000
+            eng.resident_begin(ring_depth=8, max_cycles=total + 8)
+            eng.resident_publish(total)
+            eng.resident_joints_async(total - 1, q.data_ptr())
+        assert P.probe_launch(stream, blocks, threads, lds, rounds, 3000) == 0
+        drained = P.probe_stream_wait(stream, 8000)
+        _, done_mid, running = eng.resident_status()
+        ran = eng.resident_end()                   # (stops at the last published cycle)
+        out = (C.c_uint64 * 4)()
+        assert P.probe_result(out) == 0
+        rounds_done, timed_out, _, ticks = [int(x) for x in out]
+        parity_report(f"collective-shaped kernel ({blocks} x {threads} threads, {lds // 1024} KiB LDS, all-to-all flag spins) on the engine's stream next to the live "
+                      f"loop of {n} hexapods ({'stepping' if stepping else 'behind the stream-ordered read of the last cycle, loop polling its gate'}): "
+                      f"{rounds_done}/{rounds} rounds, {timed_out} blocks timed out, {ticks / 100:.0f} us in the kernel; loop alive when it finished: {running} "
+                      f"({done_mid} of {total} cycles done)")
+        assert drained == 1, "the engine's stream did not drain: the probe (or the read before it) was never scheduled next to the loop"
+        assert timed_out == 0 and rounds_done == rounds
+        assert running and ran == total
+        return done_mid, total
+
+    done_mid, total = run_probe(stepping=True)
+    assert 100 < done_mid < total                   # the loop was still stepping when the probe had finished
+    done_mid, total = run_probe(stepping=False)
+    assert done_mid == total
+    assert torch.isfinite(q).all() and float(q.abs().max()) > 0
+    eng.close()
+    L.shc_stream_destroy(0, stream)
