@@ -248,12 +248,16 @@ int shc_engine_step(shc_engine *e, int n_cycles);
 int shc_engine_synchronize(shc_engine *e);
 /*
  * Batches of 4 096 wavefronts and more (40 960 hexapods, 32 768 octopods): shc_engine_step launches the two halves of the batch on
- * two streams - the engine's and an internal one - and does NOT join them between consecutive steps (a robot's next cycle depends
+ * two INTERNAL streams (one pair per device, shared by every engine of the process on that device) and does NOT join them between consecutive steps (a robot's next cycle depends
  * on its own last cycle only; one half's partly filled last round of wavefronts then overlaps the other half's full rounds:
  * +20 ... 30 % control cycles per second).  Every other shc_engine_* / shc_leg_* entry point orders the engine's stream after both
- * halves before it enqueues anything, so getters, setters and shc_engine_synchronize behave as before.  Only a caller that
- * enqueues ITS OWN work on the engine's stream right after shc_engine_step (a kernel reading shc_engine_joint_buffer, an event,
- * a graph capture) calls shc_engine_join first: it makes the engine's stream wait for the internal one (no host wait).
+ * halves before it enqueues anything, so getters, host-array setters and shc_engine_synchronize behave as before.  Setters given
+ * DEVICE arrays (on_device) while split steps are in flight do not join: each half's own stream scatters its share of the array (after
+ * waiting for the engine's stream, where the caller made the array ready), and the engine's stream is then ordered after both reads by
+ * events - so the caller may overwrite or free the array on the engine's stream right after the setter returns, as before, without a
+ * host wait and without draining the steps.  Only a caller that enqueues ITS OWN work on the engine's stream right after shc_engine_step
+ * (a kernel reading shc_engine_joint_buffer, an event, a graph capture) calls shc_engine_join first: it makes the engine's stream wait
+ * for the internal ones (no host wait).
  * SHC_FEAT_SINGLE_STREAM turns the split off.
  */
 int shc_engine_join(shc_engine *e);
@@ -278,8 +282,8 @@ int shc_engine_join(shc_engine *e);
  *       starts the loop (on a stream of the engine's own, ordered after everything queued on the engine's stream: the kernel does
  *       not end by itself, so it must not sit on a stream others use - the legacy default stream least of all).  ring_depth (2..255): input sets that may be posted ahead of the cycle that
  *       consumes them = cycles whose outputs stay readable; max_cycles (1..2^31-2): hard bound of this launch; idle_timeout_ms
- *       (0 = 2 000): the device loop stops by itself when the doorbell has not moved for this long (a host that went away cannot
- *       leave the GPU spinning; every device-side wait is bounded).  SHC_ERR_UNSUPPORTED: the batch does not fit the chip once, or
+ *       (0 = 5 000): the device loop stops by itself when everything released has run and the doorbell has not moved for this long
+ *       (a host that went away cannot leave the GPU spinning; every device-side wait is bounded).  SHC_ERR_UNSUPPORTED: the batch does not fit the chip once, or
  *       the configuration runs on a rough-terrain / manual-leg / tip-rotation kernel.  Until shc_engine_resident_end every other
  *       entry point that touches the engine's state returns SHC_ERR_BUSY.
  *   shc_engine_resident_post(e, inputs, cycle)
@@ -296,7 +300,9 @@ int shc_engine_join(shc_engine *e);
  *       returns once `cycles` iterations have completed on every instance and their outputs are visible (SHC_ERR_TIMEOUT otherwise).
  *   shc_engine_resident_get_joint_state(e, cycle, q, qd, on_device)
  *       desired joint positions / velocities [n][legs][dof] of iteration `cycle` (completed, and at most ring_depth - 1 iterations
- *       older than the newest published one) - what publishDesiredJointState sends after that loop iteration.
+ *       older than the newest published one) - what publishDesiredJointState sends after that loop iteration.  Blocking for host AND
+ *       device buffers: q / qd are complete when the call returns (the copy runs on the engine's private input stream, which a
+ *       caller cannot order anything after; the stream-ordered form is the _async call below).
  *   shc_engine_resident_get_joint_state_async(e, cycle, q, qd, timeout_ms)
  *       the same into DEVICE buffers, stream-ordered instead of host-ordered: returns at once having queued, on the engine's
  *       stream, a device-side wait for iteration `cycle` (which may still be unpublished; bounded by timeout_ms, 0 = 5 s) and the copy.
@@ -308,7 +314,9 @@ int shc_engine_join(shc_engine *e);
  *       stops the loop after the published cycles, waits for it, and leaves the engine exactly as the same cycles through
  *       shc_engine_step would have (state planes, held inputs).  SHC_ERR_TIMEOUT: the loop had already stopped by itself
  *       (idle timeout) before everything published had run - the state is that of *cycles_run iterations, consistent across
- *       instances, and the engine is usable again.
+ *       instances, and the engine is usable again.  If the loop does not ANSWER the stop request in time the call also returns
+ *       SHC_ERR_TIMEOUT, but the engine stays in resident mode (the kernel may still be running: nothing else may touch the state,
+ *       shc_engine_destroy waits for the kernel before it frees anything); call shc_engine_resident_end again.
  */
 typedef struct shc_cycle_inputs {
   const double *linear_xy;                  /* [n][2]            velocity command (state_controller.cpp:1127) */

@@ -304,7 +304,7 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
   const int64_t ns = st.n_slots;
   const unsigned out_slot_bytes = unsigned(NJ * ns * 16); // q, qd = fields [0, 2 NJ) = NJ paired planes
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
-  const u64 emergency_ticks = 4 * A.idle_ticks + 200000000ull; // a worker never waits longer than this for the relay (2 s + 4 idle timeouts)
+  const u64 emergency_ticks = 4 * A.idle_ticks + 2000 * A.ticks_per_ms; // a worker never waits longer than this for the relay (2 s + 4 idle timeouts)
   unsigned c = 0, oslot = 0; // cycles completed; output ring position of cycle c
   u64 gate = uni64(ld_agent(&A.ctl->gate));
   u64 h0 = 0, h1 = 0;
@@ -436,6 +436,7 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
     // every load of the iteration is issued before the first one is waited for (each is a trip to memory or across PCIe)
     const u64 exited_v = ld_agent(&A.ctl->exited);
     const u64 gate_v = PART == PART_DONE ? ld_agent(&A.ctl->gate) : 0;
+    const u64 done_v = PART != PART_DONE ? ld_agent(&A.ctl->pad[1]) : 0; // cycles completed by every wave (the idle clock only runs when nothing is left to run)
     u64 pv[8];
     if (PART != PART_GATE) {
 #pragma unroll
@@ -446,7 +447,9 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
       const u64 hd = uni64(hd_v), hs = uni64(hs_v);
       unsigned want_db = hd > max_cycles ? max_cycles : unsigned(hd);
       if (want_db < db) want_db = db; // the doorbell only moves forward
-      if (want_db != db) t_last = now;
+      // idle = the doorbell has not moved AND everything it released has run: a host that published a long burst is not idle while the
+      // burst is still running (400 000 cycles released at once take 1.2 s)
+      if (want_db != db || uni64(done_v) < u64(db)) t_last = now;
       else if (idle_stop == 0xffffffffu && now - t_last > A.idle_ticks) idle_stop = db;
       unsigned want_sp = max_cycles;
       u64 why = RESIDENT_EXIT_MAX;
@@ -499,7 +502,7 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
       bool gave_up = false;
       if (!leave && m >= sp) { // everything that will ever run has run: the workers are on their way out
         if (t_all_done == 0) t_all_done = now;
-        else if (now - t_all_done > 500000000ull) leave = gave_up = true; // 5 s: give up on them
+        else if (now - t_all_done > 5000 * A.ticks_per_ms) leave = gave_up = true; // 5 s: give up on them
       }
       if (leave) {
         const u64 fault = uni64(ld_agent(&A.ctl->fault));
@@ -863,7 +866,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   const int64_t ns = st.n_slots;
   const unsigned out_slot_bytes = unsigned(NJ * ns * 16);
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
-  const u64 emergency_ticks = 4 * A.idle_ticks + 200000000ull;
+  const u64 emergency_ticks = 4 * A.idle_ticks + 2000 * A.ticks_per_ms;
   unsigned k = 0, c_front = 0, c_back = 0, oslot = 0; // iteration; cycles whose walker half has run; cycles completed; output ring position
   bool prev_real = false;
   u64 prev_h0 = 0, prev_h1 = 0;
@@ -921,7 +924,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
             if ((++spins & 4095u) == 0) {
               const u64 now = wall_clock64();
               if (t0 == 0) t0 = now;
-              else if (now - t0 > 100000000ull) {
+              else if (now - t0 > 1000 * A.ticks_per_ms) {
                 held.fault = true;
                 break;
               }

@@ -54,7 +54,8 @@ struct ResidentArgs {
   double *out;          // [depth][NJ planes][n_slots] double2: q, qd of every cycle (fields [0, 2 NJ) of the leg state)
   int depth;
   unsigned max_cycles;              // hard bound of this launch
-  unsigned long long idle_ticks;    // 100 MHz wall-clock ticks without a new doorbell value before the relay stops the loop
+  unsigned long long idle_ticks;    // wall-clock ticks without a new doorbell value before the relay stops the loop
+  unsigned long long ticks_per_ms;  // wall_clock64() rate of the device (hipDeviceAttributeWallClockRate): every device-side time bound derives from it
   int64_t n_waves;
 };
 

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -272,6 +273,7 @@ struct shc_engine {
   // Large batches: a step is launched as two halves on two streams with no join between steps (see shc_engine_step).
   hipStream_t half_stream[2] = {nullptr, nullptr}; // the device's pair of split streams (split_streams()), once this engine has used them
   hipEvent_t ev_main = nullptr, ev_half[2] = {nullptr, nullptr};
+  hipEvent_t ev_in[2] = {nullptr, nullptr}; // the half streams have read a device-resident input array (the engine's stream is ordered after them)
   bool side_busy = false;               // launches are outstanding on the split streams that the engine's stream has not been ordered after
   bool main_dirty = true;               // work other than steps was enqueued on the engine's stream since the last split step
 };
@@ -942,6 +944,8 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
     (void)hipEventDestroy(e->ev_main);
     (void)hipEventDestroy(e->ev_half[0]);
     (void)hipEventDestroy(e->ev_half[1]);
+    for (hipEvent_t ev : e->ev_in)
+      if (ev) (void)hipEventDestroy(ev);
   }
   delete e;
   return SHC_OK;
@@ -993,6 +997,17 @@ static int split_inputs_begin(shc_engine *e) {
   HIP_TRY(hipStreamWaitEvent(e->half_stream[1], e->ev_main, 0));
   return SHC_OK;
 }
+// ... and once both halves have read the caller's array the engine's stream is ordered after those reads (events, no host wait, no
+// join of the steps): whatever the caller queues on the engine's stream next - a copy_ into the same tensor, a free that the caching
+// allocator turns into a reuse - cannot overtake the scatter kernels, which may sit behind several queued steps of their half.
+static int split_inputs_end(shc_engine *e) {
+  for (int h = 0; h < 2; ++h) {
+    if (!e->ev_in[h]) HIP_TRY(hipEventCreateWithFlags(&e->ev_in[h], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e->ev_in[h], e->half_stream[h]));
+    HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_in[h], 0));
+  }
+  return SHC_OK;
+}
 static int64_t split_first_instance_of_second_half(const shc_engine *e) { // as shc_engine_step cuts the batch
   const int64_t waves_per_block = e->n_waves < 1536 ? 1 : 2;
   const int64_t half = ((e->n_waves / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block;
@@ -1011,7 +1026,7 @@ static int scatter_rob(shc_engine *e, const double *src, int K, int f0, int on_d
     if (e->n > mid)
       scatter_rob_kernel<<<dim3((unsigned)((e->n - mid + 255) / 256)), dim3(256), 0, e->half_stream[1]>>>(src, e->st.robd, 64 / e->L, e->n, K, f0, normalize_quat, mid);
     HIP_TRY(hipGetLastError());
-    return SHC_OK;
+    return split_inputs_end(e);
   }
   const double *d;
   int rc = to_device(e, src, size_t(e->n) * K, on_device, &d);
@@ -1034,7 +1049,7 @@ static int scatter_leg(shc_engine *e, const double *src, int K, int f0, int on_d
     if (e->n > mid)
       scatter_leg_kernel<<<dim3((unsigned)(((e->n - mid) * e->L + 255) / 256)), dim3(256), 0, e->half_stream[1]>>>(src, e->st.legd, e->n_slots, e->n, e->L, K, f0, mid);
     HIP_TRY(hipGetLastError());
-    return SHC_OK;
+    return split_inputs_end(e);
   }
   const double *d;
   int rc = to_device(e, src, size_t(e->n) * e->L * K, on_device, &d);
@@ -1205,7 +1220,9 @@ extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode
 // creation order; two streams on one queue serialise, and a pair created per engine did land on the caller's queue now and then).
 static int split_streams(int device, hipStream_t out[2]) {
   static hipStream_t pool[64][2] = {};
+  static std::mutex pool_mutex; // engines of one process may be created and stepped from different host threads
   if (device < 0 || device >= 64) return fail(SHC_ERR_INVALID_ARG, "device index");
+  std::lock_guard<std::mutex> lock(pool_mutex);
   if (!pool[device][0]) {
     HIP_TRY(hipStreamCreateWithFlags(&pool[device][0], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&pool[device][1], hipStreamNonBlocking));
@@ -1318,6 +1335,11 @@ extern "C" int shc_engine_synchronize(shc_engine *e) {
 static bool resident_active(const shc_engine *e) { return e->res && e->res->active; }
 static void resident_shutdown(shc_engine *e) {
   if (e->res && e->res->active) (void)shc_engine_resident_end(e, nullptr);
+  if (e->res && e->res->active) { // the loop did not answer: its buffers must outlive it - wait for the kernel itself (it is bounded: max_cycles,
+    (void)hipSetDevice(e->device); //  idle timeout, the workers' emergency bound), however long that takes
+    (void)hipStreamSynchronize(e->res->loop_stream);
+    e->res->active = false;
+  }
   resident_free(e->res);
   e->res = nullptr;
 }
@@ -2731,15 +2753,24 @@ static int aux_state(shc_engine *e, int64_t first, int64_t count, void *blobs, i
     int rc = SHC_OK;
     if ((want & 1) && !e->st.manual) rc = ensure_manual(e, false);
     if (rc == SHC_OK && (want & 4) && !e->d_seq) rc = ensure_seq(e);
-    if (rc == SHC_OK && (want & 2) && !e->st.ext) {
+    double *ext_new = nullptr;
+    if (rc == SHC_OK && (want & 2) && !e->st.ext) { // (allocated and cleared completely before the engine sees it: a failure leaves nothing half-grown)
       const size_t bytes = size_t(ExtFields::COUNT) * e->n_slots * 8;
-      HIP_TRY(hipMalloc(&e->st.ext, bytes));
-      HIP_TRY(hipMemsetAsync(e->st.ext, 0, bytes, e->stream));
+      if (hipMalloc(&ext_new, bytes) != hipSuccess) rc = fail(SHC_ERR_HIP, "hipMalloc(external target records)");
+      else if (hipMemsetAsync(ext_new, 0, bytes, e->stream) != hipSuccess) {
+        (void)hipFree(ext_new);
+        rc = fail(SHC_ERR_HIP, "hipMemset(external target records)");
+      }
     }
     if (rc != SHC_OK) return rc;
+    if (ext_new) e->st.ext = ext_new;
     if (want & 1) e->rt_flags |= RT_MANUAL_LEGS | RT_MANUAL_LIVE;
     if (want & 2) e->rt_flags |= RT_EXTERNAL;
-    e->plan_poser_tips_current = (want & 8) != 0; // (engine-wide, like the control cycles that clear it)
+    // "The LegPoser tips of the last plan call are still current" is a fact about the whole engine (any control cycle clears it): a restore
+    // of the whole batch sets it from the blobs; a partial restore / migration of a few instances can only keep it when both sides agree -
+    // it never raises it for the instances it did not touch, and the per-blob flag stays authoritative for the restored ones.
+    if (first == 0 && count == e->n) e->plan_poser_tips_current = (want & 8) != 0;
+    else e->plan_poser_tips_current = e->plan_poser_tips_current && (want & 8) != 0;
   }
   unsigned char *d = nullptr;
   HIP_TRY(hipMalloc(&d, stride * size_t(count)));

@@ -39,6 +39,8 @@ struct Resident {
   unsigned long long posts[RG_COUNT] = {};  // sets of each group posted so far (ring write positions)
   std::vector<unsigned long long> post_cycle[RG_COUNT]; // [depth]: the cycle each ring position was posted for
   unsigned max_cycles = 0;
+  unsigned long long wall_khz = 100000;     // wall_clock64() rate of this device (hipDeviceAttributeWallClockRate; 100 MHz on MI300 / MI355X)
+  bool poisoned = false;                    // the loop did not answer a stop request: the engine stays busy until the kernel is known to have left
   bool stream_doorbell_pending = false;     // a doorbell value travels on in_stream behind the posts it releases
   unsigned groups_posted = 0;
   bool two_wave = false;                    // the two-wavefront (walker / model) pipeline is running
@@ -203,7 +205,8 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   // wavefronts hold their registers and LDS for as long as it runs, and the kernels that post inputs, ring the doorbell and read the
   // output ring (64-thread workgroups without LDS) need somewhere to run next to it on EVERY XCD - measured: with 8 free wave slots on
   // the chip a post kernel is never scheduled, with ~150 it is
-  const int64_t capacity = int64_t(fit.blocks_per_cu) * (prop.multiProcessorCount - 8);
+  constexpr int kXcds = 8; // gfx950 (the only target of this library): 8 XCDs of 32 compute units; HIP has no attribute for it
+  const int64_t capacity = int64_t(fit.blocks_per_cu) * (prop.multiProcessorCount - kXcds);
   if (e->n_waves + 1 > capacity)
     return fail(SHC_ERR_UNSUPPORTED, "resident mode: the batch needs " + std::to_string(e->n_waves + 1) + " co-resident wavefronts, this device holds " +
                                          std::to_string(capacity) + " of this kernel (" + std::to_string(fit.blocks_per_cu) + " per compute unit); use shc_engine_step");
@@ -286,7 +289,9 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   A.max_cycles = r->max_cycles;
   int wall_khz = 0; // wall_clock64() rate (100 MHz on MI300 / MI355X)
   if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, e->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
-  A.idle_ticks = (unsigned long long)(idle_timeout_ms ? idle_timeout_ms : 2000) * (unsigned long long)wall_khz;
+  r->wall_khz = (unsigned long long)wall_khz;
+  A.idle_ticks = (unsigned long long)(idle_timeout_ms ? idle_timeout_ms : 5000) * r->wall_khz;
+  A.ticks_per_ms = r->wall_khz;
   A.n_waves = e->n_waves;
   e->plan_poser_tips_current = false;
   // Two wavefronts per robot group (walker / model halves of the cycle pipelined over two SIMDs) while every 256-thread workgroup
@@ -480,7 +485,10 @@ extern "C" int shc_engine_resident_get_joint_state(shc_engine *e, int64_t cycle,
       HIP_TRY(hipStreamSynchronize(r->in_stream));
     }
   }
-  r->stream_doorbell_pending = true; // work is queued on in_stream: a doorbell must not overtake a post queued before it
+  // Device buffers: the gathers ran on the engine's private input stream, which the caller cannot order anything after - and the ring slot
+  // they read is only protected against newer cycles by the check above, made now.  The call therefore returns when q / qd are complete
+  // (like the host-buffer form); the stream-ordered form is shc_engine_resident_get_joint_state_async.
+  if (on_device) HIP_TRY(hipStreamSynchronize(r->in_stream));
   return SHC_OK;
 }
 
@@ -511,7 +519,7 @@ extern "C" int shc_engine_resident_get_joint_state_async(shc_engine *e, int64_t 
   if (r->published > (unsigned long long)cycle + r->depth)
     return fail(SHC_ERR_INVALID_ARG, "resident mode: that cycle's outputs may have been overwritten (ring_depth newer cycles were published)");
   HIP_TRY(hipSetDevice(e->device));
-  const unsigned long long ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 5000) * 100000ull; // wall_clock64: 100 MHz
+  const unsigned long long ticks = (unsigned long long)(timeout_ms > 0 ? timeout_ms : 5000) * r->wall_khz; // wall_clock64 ticks per millisecond
   resident_wait_done_kernel<<<dim3(1), dim3(1), 0, e->stream>>>(r->ctl, r->host_dev, (unsigned long long)cycle + 1, ticks);
   HIP_TRY(hipGetLastError());
   const double *slot = r->out + size_t(cycle % r->depth) * size_t(e->NJ) * e->n_slots * 2;
@@ -545,11 +553,24 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   HIP_TRY(hipStreamSynchronize(r->in_stream)); // every post and stream-ordered doorbell has landed
   host_store(&r->host->doorbell, r->published);
   host_store(&r->host->stop, r->published);
-  const bool answered = spin_until([&] { return host_load(&r->host->exited) != 0; }, 30.0);
-  hipError_t err = answered ? hipStreamSynchronize(r->loop_stream) : hipErrorNotReady; // (the host has waited: whatever follows on the engine's stream is ordered)
+  // A loop that does not answer keeps the engine: while the kernel may still be running nothing else may touch the state planes, and
+  // shc_engine_destroy must not free the rings under it.  The engine stays in resident mode (every other entry point returns
+  // SHC_ERR_BUSY); a later shc_engine_resident_end tries again - the loop's own bounds (max_cycles, idle timeout, the workers'
+  // emergency bound) end it eventually.
+  const bool answered = spin_until([&] { return host_load(&r->host->exited) != 0; }, r->poisoned ? 5.0 : 30.0);
+  if (!answered) {
+    r->poisoned = true;
+    return fail(SHC_ERR_TIMEOUT, "resident mode: the device loop did not answer the stop request in time; the engine stays in resident mode - call "
+                                 "shc_engine_resident_end again");
+  }
+  hipError_t err = hipStreamSynchronize(r->loop_stream); // (the host has waited: whatever follows on the engine's stream is ordered)
+  // stream-ordered reads queued on the engine's stream are bounded (their own timeout, or the end of the loop): wait for them too before
+  // their verdict (late_reads) is sampled
+  if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
   r->active = false;
+  r->poisoned = false;
 #ifdef SHC_RES2_TIMING
-  if (answered && err == hipSuccess) {
+  if (err == hipSuccess) {
     ResidentCtl c;
     (void)hipMemcpy(&c, r->ctl, sizeof c, hipMemcpyDeviceToHost);
     for (int w = 0; w < 2; ++w)
@@ -564,7 +585,6 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   const unsigned long long reason = host_load(&r->host->exited), done = host_load(&r->host->done);
   if (cycles_run) *cycles_run = int64_t(done);
   if (r->groups_posted & (1u << RG_FORCE)) e->rt_flags |= RT_TOUCHDOWN; // as shc_engine_set_tip_force (state_controller.cpp:1642)
-  if (!answered) return fail(SHC_ERR_TIMEOUT, "resident mode: the device loop did not answer the stop request within 30 s");
   if (err != hipSuccess) return fail(SHC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
   if (reason == RESIDENT_EXIT_FAULT || host_load(&r->host->fault) != 0)
     return fail(SHC_ERR_HIP, "resident mode: a wavefront gave up waiting for the relay; restore the engine from a snapshot");

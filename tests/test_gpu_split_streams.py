@@ -93,3 +93,53 @@ def test_join_orders_the_callers_stream_after_both_halves(Engine):
     assert torch.equal(out, ref_out)
     eng.close()
     ref.close()
+
+
+def test_device_resident_inputs_may_be_reused_right_after_the_setter(Engine):
+    """Setters given device arrays while split steps are in flight scatter them on the two internal streams - behind whatever steps are
+    still queued there - and order the engine's stream after those reads (events, no host wait).  The caller keeps ONE input tensor and
+    refills it on the engine's stream right after each setter, with no synchronisation anywhere: the refill must not overtake the
+    scatter kernels.  Equal byte for byte to host-array setters on a single-stream engine."""
+    p = default_hexapod_params("wave")
+    p.admittance_control = 1
+    n = 41003
+    rng = np.random.default_rng(23)
+    rounds = 12
+    lins = [rng.uniform(-0.7, 0.7, size=(n, 2)) for _ in range(rounds)]
+    angs = [rng.uniform(-1, 1, size=n) for _ in range(rounds)]
+    forces = [np.stack([rng.normal(0, 1, (n, 6)), rng.normal(0, 1, (n, 6)), rng.uniform(0, 5, (n, 6))], axis=2) for _ in range(rounds)]
+    stream = torch.cuda.Stream()
+    eng = Engine(p, n, stream=stream.cuda_stream)
+    ref = Engine(p, n)
+    ref.set_features(FEAT_DEFAULT | FEAT_SINGLE_STREAM)
+    pinned = [(torch.from_numpy(l).pin_memory(), torch.from_numpy(a).pin_memory(), torch.from_numpy(f).pin_memory()) for l, a, f in zip(lins, angs, forces)]
+    with torch.cuda.stream(stream):
+        d_lin = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+        d_ang = torch.empty(n, dtype=torch.float64, device="cuda")
+        d_force = torch.empty((n, 6, 3), dtype=torch.float64, device="cuda")
+        garbage = torch.full_like(d_force, float("nan"))
+        for k in range(rounds):
+            d_lin.copy_(pinned[k][0], non_blocking=True)       # refill the SAME tensors on the engine's stream ...
+            d_ang.copy_(pinned[k][1], non_blocking=True)
+            d_force.copy_(pinned[k][2], non_blocking=True)
+            eng.set_velocity_device(d_lin.data_ptr(), d_ang.data_ptr())
+            assert eng.L.shc_engine_set_tip_force(eng.h, d_force.data_ptr(), 1) == 0
+            d_force.copy_(garbage, non_blocking=True)          # ... and trash one right behind the setter: a scatter that ran late would read NaNs
+            d_lin.mul_(0.0)
+            for _ in range(7):
+                eng.step(1)                                     # several steps stay queued on the half streams: the next scatter sits behind them
+    for k in range(rounds):
+        ref.set_velocity(lins[k], angs[k])
+        ref.set_tip_force(forces[k])
+        for _ in range(7):
+            ref.step(1)
+    eng.synchronize()
+    ref.synchronize()
+    qa, qb = eng.joints(), ref.joints()
+    assert np.isfinite(qa[0]).all()
+    assert np.array_equal(qa[0], qb[0]) and np.array_equal(qa[1], qb[1])
+    la, lb = eng.leg_state(), ref.leg_state()
+    for k in la:
+        assert np.array_equal(la[k], lb[k]), k
+    eng.close()
+    ref.close()

@@ -26,6 +26,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def twin_tables(p):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "twins"])
     L = C.CDLL(os.path.join(ROOT, "oracle", "_twin", "liboracle_fastmath.so"))
+    # the twin differs in code generation only: loading it must not switch the process to flush-to-zero / denormals-are-zero (a library
+    # LINKED with -ffast-math does, through crtfastmath.o) - the reference checker's floating-point environment is the same in every test order
+    tiny = np.float64(5e-324)
+    assert tiny * np.float64(1.0) != 0.0 and np.float64(2.2250738585072014e-308) / np.float64(4.0) != 0.0
     L.orc_create.restype = C.c_void_p
     L.orc_create.argtypes = [C.POINTER(Params)]
     L.orc_startup.argtypes = [C.c_void_p]
