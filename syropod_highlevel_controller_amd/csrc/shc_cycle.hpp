@@ -232,9 +232,10 @@ SHC_HD double stance_span_change_y(const double *table, int leg, double default_
 #endif
 // Development-only phase timestamps (build with -DSHC_RES2_TIMING) of the two-wavefront resident kernel: the leader of workgroup 1 keeps
 // the s_memtime stamps of its latest iteration in LDS; shc_engine_resident_end prints them.
-#if defined(SHC_RES2_TIMING)
-__shared__ long long shc_ticks_lds[32];
-#define SHC_TICK(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 1 && threadIdx.x == 0) shc_ticks_lds[i] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if defined(SHC_RES2_TIMING) && !defined(SHC_RES2_BUSY_ONLY) // (-DSHC_RES2_BUSY_ONLY: only the two stamps per iteration of each role, no phase ticks)
+__shared__ long long shc_ticks_lds[64]; // [0, 32): the walker wavefront of pair 0 (thread 0), [32, 64): its model wavefront (thread 128)
+__shared__ long long shc_acc_lds[64];   // per phase: clocks since the previous stamp, summed over the steady REAL iterations
+#define SHC_TICK(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 1 && (threadIdx.x == 0 || threadIdx.x == 128)) shc_ticks_lds[(threadIdx.x >> 7) * 32 + (i)] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SHC_TICK(i) do {} while (0)
 #endif
@@ -1101,7 +1102,69 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
         model_tip_prev = tip_robot_frame(lc, ch0.pe);
       }
     }
-    if (stepping && !(SHC_DBG(P) & 4)) {
+    // Two forms of the same arithmetic.  On a wave of de-phased robots some leg is in each of the three cases (first / second half of the
+    // swing, stance) in every cycle, so the wave executes all three exec-masked paths anyway - one after the other, each with its own
+    // LDS round trip to the parked origins, and the scheduler cannot interleave across the branches.  The STRAIGHT form evaluates the
+    // swing and stance curves for every lane in one basic block (same operations per lane, results selected at the end): the same
+    // number of instructions, but three independent dependency chains for the scheduler to overlap - what a wavefront that runs alone on
+    // its SIMD (resident mode) is short of.  Rough terrain (ground-contact nodes, step-plane targets, external targets) and
+    // force_normal_touchdown keep the branching form.
+#ifdef SHC_NO_STRAIGHT // (development: the branching form everywhere)
+    const bool straight = false;
+#else
+    const bool straight = (F & F_ROUGH) == 0 && !(SHC_DBG(P) & 4) && uni(P.force_normal_touchdown) == 0;
+#endif
+    if (straight) {
+      const V3 sorg_p = pk.get3(PK_SORG), svel_p = pk.get3(PK_SVEL), torg_p = pk.get3(PK_TORG);
+      const bool swing = my_state == SS_SWING;
+      const bool step_sw = stepping && swing, step_st = stepping && !swing;
+      // updateStride (:921-945)
+      const V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0};
+      const V3 strd_new = scaled(sv, P.stride_scale);
+      s.strd = sel3(stepping, strd_new, s.strd);
+      V3 pn = rb.get3(R::PNORM);
+      const bool flat_n = pn.x == 0.0 && pn.y == 0.0 && pn.z == 1.0;
+      if (!__all(flat_n)) pn = normalized(pn);
+      const V3 clearance = scaled(pn, P.swing_height);
+      // swing (:1110-1157)
+      const int it_sw = my_phase - P.swing_start + 1;
+      const bool first_half = it_sw <= P.swing_iterations / 2;
+      const bool first_sw = step_sw && it_sw == 1;
+      const V3 sorg = sel3(first_sw, s.tip, sorg_p), svel = sel3(first_sw, s.tvel, svel_p);
+      pk.put3(PK_SORG, sorg); // (unchanged unless this is the first iteration of a swing: an unconditional LDS store costs less than the branch)
+      pk.put3(PK_SVEL, svel);
+      dirty |= first_sw ? unsigned(DIRTY_SWING_ORG) : 0u;
+      V3 mid{(sorg.x + s.targ.x) / 2.0, (sorg.y + s.targ.y) / 2.0, fmax(sorg.z, s.targ.z)};
+      mid = mid + clearance;
+      mid.y += (lc.stance_y > 0.0) ? P.swing_width : -P.swing_width;
+      const V3 sep1 = scaled(svel * 0.25, P.dt_over_swing_dt);
+      const V3 n1_0 = sorg, n1_1 = sorg + sep1, n1_2 = sorg + scaled(sep1, 2.0);
+      const V3 n1_3{(mid.x + n1_2.x) / 2.0, (mid.y + n1_2.y) / 2.0, mid.z};
+      const V3 n1_4 = mid;
+      const V3 fv = scaled(-s.strd, stance_dt * P.inv_dt);
+      const V3 sep2 = scaled(fv * 0.25, P.dt_over_swing_dt);
+      const V3 n2_0 = n1_4, n2_1 = n1_4 - (n1_3 - n1_4), n2_2 = s.targ - scaled(sep2, 2.0), n2_3 = s.targ - sep2, n2_4 = s.targ;
+      const double t_sw = first_half ? P.swing_delta_t * it_sw : P.swing_delta_t * (it_sw - P.swing_iterations / 2);
+      const V3 b0 = sel3(first_half, n1_0, n2_0), b1 = sel3(first_half, n1_1, n2_1), b2 = sel3(first_half, n1_2, n2_2), b3 = sel3(first_half, n1_3, n2_3),
+               b4 = sel3(first_half, n1_4, n2_4);
+      const V3 dpos_sw = scaled(quartic_bezier_dot(b0, b1, b2, b3, b4, t_sw), P.swing_delta_t);
+      // stance (:1159-1177)
+      int it_st = my_phase + (P.period - mss); // both terms lie in [0, period]: one conditional subtract is the modulo
+      if (it_st >= P.period) it_st -= P.period;
+      it_st += 1;
+      const bool first_st = step_st && it_st == 1;
+      const V3 torg = sel3(first_st, s.tip, torg_p);
+      pk.put3(PK_TORG, torg);
+      dirty |= first_st ? unsigned(DIRTY_STANCE_ORG) : 0u;
+      const double stride_scaler = standard ? 1.0 : lc.first_stride_scaler; // modified / standard stance period (:1167)
+      const V3 sep = scaled((-s.strd) * stride_scaler, 0.25);
+      const double t_st = it_st * stance_dt;
+      const V3 dpos_st = scaled(quartic_bezier_dot(torg, torg + sep, torg + scaled(sep, 2.0), torg + scaled(sep, 3.0), torg + scaled(sep, 4.0), t_st), stance_dt);
+      const V3 dpos = sel3(swing, dpos_sw, dpos_st);
+      const V3 tip_new = s.tip + dpos, tvel_new = dpos * P.inv_dt; // delta_pos / time_delta (:1135, :1176)
+      s.tip = sel3(stepping, tip_new, s.tip);
+      s.tvel = sel3(stepping, tvel_new, s.tvel);
+    } else if (stepping && !(SHC_DBG(P) & 4)) {
       // updateStride (:921-945)
       V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0}; // v + w z^ x (tip rejected from z^)
       s.strd = scaled(sv, P.stride_scale);

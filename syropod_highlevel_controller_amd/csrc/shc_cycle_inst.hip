@@ -111,6 +111,14 @@ static void launch_cycle_feat(const CycleLaunch &a) {
       case C3: launch_cycle<L, NJ, C3>(a); return;
       default: break;
     }
+  } else {
+    // every other morphology: default.yaml's posing set without the tip-force estimate (what the bins of BASELINE.json configs[4] run on) is
+    // feature-exact too - the runtime-flag kernels of 8 x 3, 6 x 5 and 8 x 5 carry 12 - 36 B of scratch per lane, these carry none
+    constexpr unsigned C2 = F_MANUAL | F_ODOM;
+    if (!a.generic && f == C2) {
+      launch_cycle<L, NJ, C2>(a);
+      return;
+    }
   }
   launch_cycle<L, NJ, F_DYN>(a);
 }

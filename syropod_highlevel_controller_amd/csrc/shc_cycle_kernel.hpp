@@ -875,6 +875,9 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   FrontToBack fb{V3{1, 0, 0}, false, LS_WALKING};
 #ifdef SHC_RES2_TIMING
   long long tm_busy = 0, tm_total0 = __builtin_readcyclecounter(), tm_real = 0;
+#ifndef SHC_RES2_BUSY_ONLY
+  if (threadIdx.x < 64) shc_acc_lds[threadIdx.x] = 0;
+#endif
 #endif
   for (;;) {
 #ifdef SHC_RES2_TIMING
@@ -943,6 +946,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       }
       SHC_TICK(23);
     } else if (active) {
+      SHC_TICK(24);
       if (POSE_SPLIT && kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
         resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
         const int my_word = X.words[pair][c_front & 1][lane];
@@ -958,6 +962,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) *const_cast<volatile unsigned *>(&X.pose_done[pair]) = c_front + 1;
       }
+      SHC_TICK(25);
       if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
         resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held);
         const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
@@ -974,7 +979,9 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         out.adm_delta = V3{0, 0, 0};
         if (FT::adm(P)) cycle_admittance<NJ>(s, out, P, in);
         s.word = 0;
+        SHC_TICK(26);
         cycle_back<L, NJ, F>(s, out, C, leg, st.legd, ns, slot, nullptr, in, fb);
+        SHC_TICK(27);
         // the output stores of cycle c_back - 1 were issued one iteration ago: they have drained - announce them, then issue this cycle's
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) st_agent(A.progress + wave, u64(c_back));
@@ -995,6 +1002,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         }
         ++c_back;
         oslot = oslot + 1 == unsigned(A.depth) ? 0 : oslot + 1;
+        SHC_TICK(28);
       }
       if (kind != IT_REAL) { // the pipeline runs dry: nothing will follow for a while (or ever) - announce what is done now
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1009,6 +1017,14 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
     if (kind == IT_EXIT) break;
 #ifdef SHC_RES2_TIMING
     if (kind == IT_REAL && prev_real) tm_busy += __builtin_readcyclecounter() - tm0, ++tm_real;
+#ifndef SHC_RES2_BUSY_ONLY
+    if (kind == IT_REAL && prev_real && blockIdx.x == 1 && (threadIdx.x == 0 || threadIdx.x == 128)) { // phase clocks of this steady iteration
+      const int base = (threadIdx.x >> 7) * 32;
+      const int worder[] = {19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 15, 22, 23}, morder[] = {24, 25, 26, 9, 10, 11, 12, 27, 28};
+      if (threadIdx.x == 0) for (int i = 1; i < 13; ++i) shc_acc_lds[base + worder[i]] += shc_ticks_lds[base + worder[i]] - shc_ticks_lds[base + worder[i - 1]];
+      else for (int i = 1; i < 9; ++i) shc_acc_lds[base + morder[i]] += shc_ticks_lds[base + morder[i]] - shc_ticks_lds[base + morder[i - 1]];
+    }
+#endif
 #endif
     if (kind == IT_REAL) ++c_front;
     prev_real = kind == IT_REAL;
@@ -1020,8 +1036,15 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   if (blockIdx.x == 1 && lane == 0 && pair == 0) { // development: clocks from iteration start to the barrier, REAL iterations in steady state
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(A.ctl) + 8 + (walker ? 0 : 4);
     dbg[0] = tm_busy, dbg[1] = tm_real, dbg[2] = __builtin_readcyclecounter() - tm_total0, dbg[3] = k;
-    if (walker)
-      for (int i = 0; i < 32; ++i) dbg[8 + i] = (unsigned long long)shc_ticks_lds[i];
+#ifndef SHC_RES2_BUSY_ONLY
+    if (walker) {
+      for (int i = 0; i < 32; ++i) dbg[8 + i] = (unsigned long long)shc_acc_lds[i];
+    } else { // (the model wavefront's stamps share the slots the walker does not use: 9 .. 14, 24 .. 31)
+      __builtin_amdgcn_s_sleep(100);
+      for (int i = 9; i < 15; ++i) dbg[4 + i] = (unsigned long long)shc_acc_lds[32 + i];   // (dbg points 4 words into ResidentCtl::dbg for the model wavefront)
+      for (int i = 24; i < 32; ++i) dbg[4 + i] = (unsigned long long)shc_acc_lds[32 + i];
+    }
+#endif
   }
 #endif
   // ---- epilogue: the halves exchange what the other one stores, then each writes its half of the state back

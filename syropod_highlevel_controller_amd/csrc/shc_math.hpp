@@ -53,6 +53,8 @@ SHC_HD V3 scaled(V3 a, double s) {
   return V3{a.x * s, a.y * s, a.z * s};
 }
 SHC_HD double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// per-component select (a ternary on two V3 lvalues selects between their ADDRESSES and keeps whole structs out of registers)
+SHC_HD V3 sel3(bool c, V3 a, V3 b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 SHC_HD V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 SHC_HD double norm(V3 a) { return sqrt(dot(a, a)); }
 // Eigen 3.3 normalized(): unchanged when the squared norm is 0

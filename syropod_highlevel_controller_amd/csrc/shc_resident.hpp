@@ -576,10 +576,17 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
     for (int w = 0; w < 2; ++w)
       fprintf(stderr, "[res2 timing] %s: %.0f clocks busy per steady REAL iteration (%llu of them), loop %llu clocks, %llu iterations\n", w ? "model " : "walker",
               c.dbg[4 * w + 1] ? double(c.dbg[4 * w]) / double(c.dbg[4 * w + 1]) : 0.0, c.dbg[4 * w + 1], c.dbg[4 * w + 2], c.dbg[4 * w + 3]);
+#ifndef SHC_RES2_BUSY_ONLY
     const int order[] = {19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 15, 22, 23};
-    fprintf(stderr, "[res2 timing] walker leader, last iteration, clocks since its start:");
-    for (int i : order) fprintf(stderr, " t%d=%lld", i, (long long)c.dbg[8 + i] - (long long)c.dbg[8 + 19]);
+    const double its = c.dbg[1] ? double(c.dbg[1]) : 1.0;
+    fprintf(stderr, "[res2 timing] walker of pair 0, mean clocks per phase (up to stamp t):");
+    for (int i : order) fprintf(stderr, " t%d=%.0f", i, double(c.dbg[8 + i]) / its);
     fprintf(stderr, "\n");
+    const int morder[] = {24, 25, 26, 9, 10, 11, 12, 27, 28};
+    fprintf(stderr, "[res2 timing] model wavefront of pair 0 (the leader), mean clocks per phase (up to stamp t):");
+    for (int i : morder) fprintf(stderr, " t%d=%.0f", i, double(c.dbg[8 + i]) / its);
+    fprintf(stderr, "\n");
+#endif
   }
 #endif
   const unsigned long long reason = host_load(&r->host->exited), done = host_load(&r->host->done);
