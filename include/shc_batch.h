@@ -331,9 +331,22 @@ typedef struct shc_cycle_inputs {
   int32_t on_device;                        /* the arrays are device pointers                                 */
   int32_t publish;                          /* != 0: release this cycle (and unpublished cycles before it) as soon as its inputs are in
                                                place - post + shc_engine_resident_publish(…, 1) in one kernel launch */
+  int32_t direct;                           /* k = 1 .. 4: a DIRECT post from bound input set k - 1 (shc_engine_resident_bind_inputs): no kernel
+                                               launch, no copy - the non-NULL members above only say WHICH groups are fresh this cycle (velocity,
+                                               IMU, tip force, joint effort); the device loop reads them from the set's arrays when the cycle
+                                               runs, and the cycle is released at once (publish is implied).  A few host stores per call. */
+  int32_t reserved_;
 } shc_cycle_inputs;
 enum { SHC_RESIDENT_RUNNING = 0, SHC_RESIDENT_STOPPED = 1, SHC_RESIDENT_IDLE_TIMEOUT = 2, SHC_RESIDENT_MAX_CYCLES = 3, SHC_RESIDENT_FAULT = 4 };
 int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t max_cycles, int idle_timeout_ms);
+/* Bind device arrays as input set `set` (0 .. 3) for direct posts; call it while the loop is NOT running (the addresses travel with the launch
+ * of the loop kernel); NULL members = the set does not carry that group; arrays as for the setters ([n][2], [n], [n][4], [n][3],
+ * [n][legs][3], [n][legs][dof]).  Contract of a direct post of set k for cycle c: the arrays hold the cycle's inputs (visible device-wide)
+ * when shc_engine_resident_post is called and stay unchanged until a LATER cycle has completed (shc_engine_resident_wait(c + 2)) - a
+ * host loop alternates between two sets, as the node's callbacks fill one message while the controller reads the other.  Velocity and
+ * IMU samples are taken into the loop's own state when cycle c starts; per-leg inputs (tip force, joint effort) are read from the set's
+ * arrays until another post of that group replaces them, and are carried into the engine's own planes when the loop ends. */
+int shc_engine_resident_bind_inputs(shc_engine *e, int set, const shc_cycle_inputs *arrays);
 int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *inputs, int64_t *cycle);
 int shc_engine_resident_publish(shc_engine *e, int64_t n_cycles);
 int shc_engine_resident_wait(shc_engine *e, int64_t cycles, int timeout_ms);

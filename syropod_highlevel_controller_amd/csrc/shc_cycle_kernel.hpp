@@ -225,21 +225,40 @@ __device__ __forceinline__ u64 uni64(u64 v) {
 // nothing has been posted), read with agent-scope loads - another agent may have written them while this kernel runs
 template <int NJ>
 struct LegInRing {
-  const double *force_planes, *effort_planes;
-  int64_t ns;
-  uint32_t slot;
-  __device__ __forceinline__ V3 force() const {
-    const double *p = force_planes + int64_t(slot) * 2;
-    return V3{ld_agent_f64(p), ld_agent_f64(p + 1), ld_agent_f64(p + ns * 2)};
-  }
+  // this lane's leg: element 2 p + h of its record lies at ptr + p * pair + h - the paired planes of the engine / the input rings
+  // (pair = 2 n_slots) and a caller's instance-major array of a bound input set (pair = 2) alike
+  const double *force_ptr, *effort_ptr;
+  int64_t force_pair, effort_pair;
+  __device__ __forceinline__ V3 force() const { return V3{ld_agent_f64(force_ptr), ld_agent_f64(force_ptr + 1), ld_agent_f64(force_ptr + force_pair)}; }
   __device__ __forceinline__ void effort(double (&e)[NJ]) const {
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) e[i] = ld_agent_f64(effort_planes + (int64_t(i / 2) * ns + slot) * 2 + (i & 1));
+    for (int i = 0; i < NJ; ++i) e[i] = ld_agent_f64(effort_ptr + int64_t(i / 2) * effort_pair + (i & 1));
   }
 };
+// (no dynamic indexing of the kernel-argument struct: that would move it to scratch)
+__device__ __forceinline__ const double *bound_array(const ResidentArgs &A, int set, int which) {
+  const double *const *row = set == 0 ? A.bound[0] : (set == 1 ? A.bound[1] : (set == 2 ? A.bound[2] : A.bound[3]));
+  return which == BND_LIN ? row[BND_LIN] : which == BND_ANG ? row[BND_ANG] : which == BND_IMUQ ? row[BND_IMUQ] : which == BND_IMUW ? row[BND_IMUW]
+       : which == BND_FORCE ? row[BND_FORCE] : row[BND_EFFORT];
+}
+// Where the per-leg inputs in force come from: src >= 0 a ring position, -1 the engine's own planes, <= -2 bound input set -2 - src
+// (the caller's arrays [n][legs][3] / [n][legs][dof]).  All wave-uniform selects.
+template <int L, int NJ>
+__device__ __forceinline__ LegInRing<NJ> leg_inputs_in_force(const ResidentArgs &A, const double *legd, const int src_force, const int src_effort, const int64_t ns,
+                                                             const uint32_t slot, const int64_t robot, const int leg) {
+  using FD = Fields<NJ>;
+  LegInRing<NJ> in;
+  const double *fplanes = src_force < 0 ? legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(src_force) * 2 * ns * 2;
+  const double *eplanes = src_effort < 0 ? legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(src_effort) * (FD::NJE / 2) * ns * 2;
+  in.force_ptr = fplanes + int64_t(slot) * 2, in.force_pair = ns * 2;
+  in.effort_ptr = eplanes + int64_t(slot) * 2, in.effort_pair = ns * 2;
+  if (src_force <= -2) in.force_ptr = bound_array(A, -2 - src_force, BND_FORCE) + (robot * L + leg) * 3, in.force_pair = 2;
+  if (src_effort <= -2) in.effort_ptr = bound_array(A, -2 - src_effort, BND_EFFORT) + (robot * L + leg) * NJ, in.effort_pair = 2;
+  return in;
+}
 
 struct ResidentHeld { // what the worker remembers between the loop and the epilogue (all wave-uniform)
-  int src_force = -1, src_effort = -1; // ring position of the per-leg inputs in force; -1: the engine's own planes
+  int src_force = -1, src_effort = -1; // per-leg inputs in force: ring position; -1: the engine's own planes; <= -2: bound input set -2 - src
   unsigned seen = 0;                   // input groups that were posted during this run
   unsigned cycles = 0;
   bool fault = false;
@@ -260,11 +279,40 @@ __device__ __forceinline__ void ring_to_tile(const double *rec, double *tile_at,
 enum : int { ROBOT_NONE = 0, ROBOT_VEL = 1, ROBOT_POSE = 2, ROBOT_ALL = 3 }; // which per-robot input groups a wave copies into the tile
 template <int RPW, int ROBOT, bool LEG>
 __device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, const unsigned c, const u64 h0, const u64 h1, const int64_t wave, const int lane,
-                                                     double *tile, int32_t *tile_i, unsigned &dirty, ResidentHeld &held) {
+                                                     double *tile, int32_t *tile_i, unsigned &dirty, ResidentHeld &held, const int64_t n_robots) {
   using R = RobotFields;
   if (h0 != u64(c) + 1) return;
-  const unsigned mask = unsigned(h1) & 0xffffu;
+  const unsigned mask = unsigned(h1) & 0x7fffu;
   held.seen |= mask;
+  if (unsigned(h1) & kResidentDirect) { // a direct post: the fresh groups come straight from the caller's arrays of a bound input set
+    const int set = int((h1 >> 16) & 3);
+    if (ROBOT != ROBOT_NONE) {
+      if ((ROBOT & ROBOT_VEL) && (mask & (1u << RG_VEL))) { // [n][2], [n]
+        static_assert(R::WIN == R::VIN + 2, "velocity inputs are contiguous in the tile");
+        const double *lin = bound_array(A, set, BND_LIN), *ang = bound_array(A, set, BND_ANG);
+        const int field = lane / RPW, r = lane - field * RPW;
+        const int64_t rob = wave * RPW + r;
+        if (lane < 3 * RPW && rob < n_robots) tile[(R::VIN + field) * RPW + r] = field < 2 ? ld_agent_f64(lin + rob * 2 + field) : ld_agent_f64(ang + rob);
+      }
+      if ((ROBOT & ROBOT_POSE) && (mask & (1u << RG_IMU))) { // [n][4], [n][3]
+        const int64_t rob = wave * RPW + lane;
+        if (lane < RPW && rob < n_robots) { // Model::setImuData as shc_engine_set_imu stores it: the orientation normalised
+          const double *q = bound_array(A, set, BND_IMUQ) + rob * 4, *w = bound_array(A, set, BND_IMUW) + rob * 3;
+          const Quat qn = normalized(Quat{ld_agent_f64(q), ld_agent_f64(q + 1), ld_agent_f64(q + 2), ld_agent_f64(q + 3)});
+          tile[(R::IMUQ + 0) * RPW + lane] = qn.w, tile[(R::IMUQ + 1) * RPW + lane] = qn.x, tile[(R::IMUQ + 2) * RPW + lane] = qn.y, tile[(R::IMUQ + 3) * RPW + lane] = qn.z;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) tile[(R::GYRO + k) * RPW + lane] = ld_agent_f64(w + k);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (LEG) { // per-leg inputs are read where they lie, from now on in the set's arrays
+      if (mask & (1u << RG_FORCE)) held.src_force = -2 - set;
+      if (mask & (1u << RG_EFFORT)) held.src_effort = -2 - set;
+    }
+    return;
+  }
   auto pos = [&](int grp) { return int((h1 >> (16 + 8 * grp)) & 0xff); };
   if (ROBOT != ROBOT_NONE) {
     if ((ROBOT & ROBOT_VEL) && (mask & (1u << RG_VEL)))
@@ -345,10 +393,8 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
       n0v = ld_agent(hp);
       n1v = ld_agent(hp + 1);
     }
-    resident_take_inputs<64 / L, ROBOT_ALL, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held);
-    const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
-                           held.src_effort < 0 ? st.legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2,
-                           ns, slot};
+    resident_take_inputs<64 / L, ROBOT_ALL, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
+    const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg);
     // half a cycle after the output stores of cycle c - 1 were issued they have drained: publish "c cycles done"
     const auto publish_previous = [&]() {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -381,6 +427,26 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
   held.cycles = c;
 }
 
+// The per-leg inputs in force when the loop ends (a ring position or a bound input set) are carried into the engine's own planes.
+template <int L, int NJ>
+__device__ __forceinline__ void carry_leg_inputs(const ResidentArgs &A, const DevState &st, const ResidentHeld &held, const int64_t ns, const uint32_t slot, const int leg) {
+  using FD = Fields<NJ>;
+  constexpr int RPW = 64 / L;
+  double2 *planes = reinterpret_cast<double2 *>(st.legd);
+  const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg);
+  if (held.src_force != -1) {
+    const V3 f = in.force();
+    planes[(FD::FORCE_IN / 2) * ns + slot] = double2{f.x, f.y};
+    planes[(FD::FORCE_IN / 2 + 1) * ns + slot] = double2{f.z, 0.0};
+  }
+  if (held.src_effort != -1) {
+    double ef[NJ];
+    in.effort(ef);
+#pragma unroll
+    for (int p = 0; p < FD::NJE / 2; ++p) planes[(FD::EFFORT_IN / 2 + p) * ns + slot] = double2{ef[2 * p], 2 * p + 1 < NJ ? ef[2 * p + 1] : 0.0};
+  }
+}
+
 // After the loop: the inputs the run received become the engine's held inputs (the next ordinary launch reads them from the
 // state planes), and the wave reports that it has left.
 template <int L, int NJ, unsigned F>
@@ -396,21 +462,7 @@ __device__ __forceinline__ void resident_epilogue(const ResidentArgs &A, const D
     store_rob_fields<RPW, R::IMUQ, R::IMUQ_END>(tile, gtile, lane);
   }
   if ((held.seen & (1u << RG_RESET)) && lane < RPW) gtile_i[R::I_RESET_MODE * RPW + lane] = tile_i[R::I_RESET_MODE * RPW + lane];
-  if (live) {
-    double2 *planes = reinterpret_cast<double2 *>(st.legd);
-    if (held.src_force >= 0) {
-      const double *src = A.force + int64_t(held.src_force) * 2 * ns * 2;
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-        planes[(FD::FORCE_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
-    }
-    if (held.src_effort >= 0) {
-      const double *src = A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2;
-#pragma unroll
-      for (int p = 0; p < FD::NJE / 2; ++p)
-        planes[(FD::EFFORT_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
-    }
-  }
+  if (live) carry_leg_inputs<L, NJ>(A, st, held, ns, slot, int(slot % 64) % L);
   if (lane == 0) {
     if (held.fault) __hip_atomic_fetch_or(&A.ctl->fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&A.ctl->exited, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -444,9 +496,25 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
     }
     if (PART != PART_DONE) {
       const u64 hd_v = ld_sys(&A.host->doorbell), hs_v = ld_sys(&A.host->stop);
+      // the direct-post record of the next unreleased cycle (two words, lanes 0 and 1), read with the doorbell
+      const u64 rec_v = lane < 2 ? ld_sys(&A.host->records[size_t(db & (kResidentHeaders - 1)) * 2 + lane]) : 0;
       const u64 hd = uni64(hd_v), hs = uni64(hs_v);
       unsigned want_db = hd > max_cycles ? max_cycles : unsigned(hd);
       if (want_db < db) want_db = db; // the doorbell only moves forward
+      if (want_db == db && db < max_cycles) { // nothing released by the doorbell: has cycle db been posted directly?
+        const u64 tag = u64(db) + 1;
+        const bool word_ok = lane == 0 ? rec_v == tag : (lane == 1 ? (rec_v >> 48) == (tag & 0xffffull) : true);
+        if (__all(word_ok)) { // a complete record: it becomes the cycle's header, then the cycle is released
+          const u64 w1 = uni64(__shfl(rec_v, 1, 64));
+          if (lane == 0) {
+            u64 *hp = reinterpret_cast<u64 *>(A.headers + (db & (kResidentHeaders - 1)));
+            st_agent(hp + 1, (w1 & 0x7fffull) | u64(kResidentDirect) | (w1 & 0x30000ull));
+            st_agent(hp, tag);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the header is out before the gate that lets a worker read it
+          want_db = db + 1;
+        }
+      }
       // idle = the doorbell has not moved AND everything it released has run: a host that published a long burst is not idle while the
       // burst is still running (400 000 cycles released at once take 1.2 s)
       if (want_db != db || uni64(done_v) < u64(db)) t_last = now;
@@ -916,7 +984,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
     if (walker) {
       SHC_TICK(20);
       if (kind == IT_REAL && active) {
-        resident_take_inputs<RPW, POSE_SPLIT ? ROBOT_VEL : ROBOT_ALL, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
+        resident_take_inputs<RPW, POSE_SPLIT ? ROBOT_VEL : ROBOT_ALL, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
         SHC_TICK(21);
         const auto pose_wait = [&]() { // Model::current_pose_ / walk_plane_pose_ of this cycle are in the tile once the model wavefront says so
           volatile unsigned *flag = &X.pose_done[pair];
@@ -936,7 +1004,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
         cycle_front<L, NJ, F, false, LegInRing<NJ>, false, !POSE_SPLIT>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
-                                                                        LegInRing<NJ>{nullptr, nullptr, ns, slot}, fb, nullptr, pose_wait);
+                                                                        LegInRing<NJ>{nullptr, nullptr, 0, 0}, fb, nullptr, pose_wait);
         if (POSE_SPLIT) publish_for_pose(c_front + 1, fb.plane_prev_changed);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
@@ -948,7 +1016,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
     } else if (active) {
       SHC_TICK(24);
       if (POSE_SPLIT && kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
-        resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held);
+        resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
         const int my_word = X.words[pair][c_front & 1][lane];
         int lw[L];
 #pragma unroll
@@ -964,10 +1032,8 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       }
       SHC_TICK(25);
       if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
-        resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held);
-        const LegInRing<NJ> in{held.src_force < 0 ? st.legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(held.src_force) * 2 * ns * 2,
-                               held.src_effort < 0 ? st.legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2,
-                               ns, slot};
+        resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
+        const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, wave * RPW + grp, leg);
         const double *mb = &X.mailbox[pair][c_back & 1][0][lane];
         out.poser_tip = V3{mb[0], mb[64], mb[128]};
         if (FT::odom(P)) {
@@ -1101,19 +1167,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
     s.stiff = X.stiff[pair][lane];
     if (live) {
       store_leg<NJ, F, ROLE_BACK>(s, out, pk, st, P, slot, 0);
-      double2 *planes = reinterpret_cast<double2 *>(st.legd);
-      if (held.src_force >= 0) {
-        const double *src = A.force + int64_t(held.src_force) * 2 * ns * 2;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-          planes[(FD::FORCE_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
-      }
-      if (held.src_effort >= 0) {
-        const double *src = A.effort + int64_t(held.src_effort) * (FD::NJE / 2) * ns * 2;
-#pragma unroll
-        for (int p = 0; p < FD::NJE / 2; ++p)
-          planes[(FD::EFFORT_IN / 2 + p) * ns + slot] = double2{ld_agent_f64(src + (int64_t(p) * ns + slot) * 2), ld_agent_f64(src + (int64_t(p) * ns + slot) * 2 + 1)};
-      }
+      carry_leg_inputs<L, NJ>(A, st, held, ns, slot, leg);
     }
   }
 }

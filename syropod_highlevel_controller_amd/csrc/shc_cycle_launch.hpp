@@ -17,6 +17,15 @@ enum : int { RG_VEL = 0, RG_IMU = 1, RG_POSE = 2, RG_RESET = 3, RG_FORCE = 4, RG
 // robot-input ring record: fields in this order, [position][wave][field][robots-per-wave]
 enum : int { RIN_VEL = 0, RIN_IMU = 3, RIN_POSE = 10, RIN_COUNT = 16 }; // v(2) w(1) | quat(4) gyro(3) | tvi(3) rvi(3)
 
+constexpr int kResidentHeaders = 1024; // header ring / direct-record ring entries (cycles that may be posted ahead)
+// DIRECT posts (shc_engine_resident_bind_inputs + shc_cycle_inputs.direct): no kernel launch, no copy.  Up to kBoundSets sets of the caller's
+// device arrays are bound before the loop starts (their addresses travel as kernel arguments); a direct post is then one 16-byte record in
+// pinned, device-mapped memory - the cycle's tag, and { fresh-group mask, set } - which the relay wave, polling the host words anyway,
+// turns into the cycle's header before it releases the cycle; the workers read their robots' inputs straight from the bound arrays.  The
+// second word carries the low 16 bits of the tag in its top 16 bits: a record read while the host was writing it is seen as incomplete.
+constexpr int kBoundSets = 4;
+enum : int { BND_LIN = 0, BND_ANG = 1, BND_IMUQ = 2, BND_IMUW = 3, BND_FORCE = 4, BND_EFFORT = 5, BND_COUNT = 6 };
+constexpr unsigned kResidentDirect = 1u << 15; // header mask bit: the fresh groups of this cycle are read from bound set (header >> 16) & 3
 struct ResidentCtl { // device memory, polled with agent-scope loads; written by the relay wave only (exited: atomic, workers)
   unsigned long long gate;      // (stop << 32) | doorbell: run cycle c (counted from resident_begin) while c < min(doorbell, stop)
   unsigned long long exited;    // worker waves that have left the loop
@@ -32,6 +41,8 @@ struct ResidentHost { // pinned host memory mapped into the device (fine-grained
   unsigned long long heartbeat; // device -> host: relay iterations (diagnostic)
   unsigned long long fault;
   unsigned long long late_reads; // device -> host: stream-ordered reads that gave up waiting for their cycle
+  unsigned long long pad_[1];
+  unsigned long long records[kResidentHeaders * 2]; // host -> device: direct-post records { tag, mask | set << 16 | (tag & 0xffff) << 48 }
 };
 struct ResidentHeader { // one per cycle (ring of kResidentHeaders), written by shc_engine_resident_post before the doorbell moves
   unsigned long long tag;  // cycle + 1; any other value: nothing was posted for this cycle (inputs held)
@@ -39,14 +50,14 @@ struct ResidentHeader { // one per cycle (ring of kResidentHeaders), written by 
   unsigned char pos[RG_COUNT]; // ring position of each fresh group's data
 };
 static_assert(sizeof(ResidentHeader) == 16, "header is read as two 8-byte words");
-constexpr int kResidentHeaders = 1024;
 enum : unsigned long long { RESIDENT_EXIT_STOP = 1, RESIDENT_EXIT_IDLE = 2, RESIDENT_EXIT_MAX = 3, RESIDENT_EXIT_FAULT = 4 };
 
 struct ResidentArgs {
   ResidentCtl *ctl;
   ResidentHost *host;
   unsigned long long *progress; // [n_waves] cycles completed by wave w (its outputs are visible)
-  const ResidentHeader *headers; // [kResidentHeaders]
+  ResidentHeader *headers;       // [kResidentHeaders] (written by the post kernels, and by the relay for direct posts)
+  const double *bound[kBoundSets][BND_COUNT]; // the caller's device arrays of each bound input set (nullptr: not bound), instance-major as the C ABI takes them
   const double *rin;    // [depth][n_waves][RIN_COUNT][RPW]
   const int32_t *rini;  // [depth][n_waves][RPW] reset modes
   const double *force;  // [depth][2 planes][n_slots] double2 (as Fields::FORCE_IN)

@@ -270,6 +270,7 @@ struct shc_engine {
   double *d_span = nullptr;             // SpanTable (rough terrain mode with a stance span modifier), rebuilt with the tables
   bool span_dirty = true;
   struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
+  const double *bound_inputs[kBoundSets][BND_COUNT] = {}; // shc_engine_resident_bind_inputs: the caller's device arrays for direct posts
   // Large batches: a step is launched as two halves on two streams with no join between steps (see shc_engine_step).
   hipStream_t half_stream[2] = {nullptr, nullptr}; // the device's pair of split streams (split_streams()), once this engine has used them
   hipEvent_t ev_main = nullptr, ev_half[2] = {nullptr, nullptr};
@@ -503,7 +504,7 @@ static int generate_tables_nj(const shc_params *p, shc_tables *out) {
   return hostinit::generate_tables<NJ>(*p, *out) ? SHC_OK : fail(SHC_ERR_INVALID_ARG, "init chain failed (unreachable stance?)");
 }
 
-extern "C" int shc_abi_version(void) { return 3; } // 3: shc_leg_snapshot carries the stepper target tip direction; resident mode, join, auxiliary state
+extern "C" int shc_abi_version(void) { return 4; } // 4: shc_cycle_inputs.direct (launch-free posts); 3: shc_leg_snapshot carries the stepper target tip direction; resident mode, join, auxiliary state
 extern "C" int64_t shc_sizeof_params(void) { return (int64_t)sizeof(shc_params); }
 extern "C" int64_t shc_sizeof_tables(void) { return (int64_t)sizeof(shc_tables); }
 

@@ -44,6 +44,7 @@ struct Resident {
   bool stream_doorbell_pending = false;     // a doorbell value travels on in_stream behind the posts it releases
   unsigned groups_posted = 0;
   bool two_wave = false;                    // the two-wavefront (walker / model) pipeline is running
+  long long direct_last = -1;               // cycle of the latest direct post (the doorbell only moves once the relay has released it)
 };
 
 __global__ void resident_doorbell_kernel(ResidentHost *host, unsigned long long value) {
@@ -177,6 +178,23 @@ static int resident_require(shc_engine *e, bool active) {
   return SHC_OK;
 }
 
+extern "C" int shc_engine_resident_bind_inputs(shc_engine *e, int set, const shc_cycle_inputs *arrays) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (e->res && e->res->active) return fail(SHC_ERR_BUSY, "resident mode: input sets are bound while the loop is not running");
+  if (set < 0 || set >= kBoundSets) return fail(SHC_ERR_INVALID_ARG, "input set 0 .. 3");
+  if (arrays && (arrays->linear_xy == nullptr) != (arrays->angular == nullptr)) return fail(SHC_ERR_INVALID_ARG, "linear_xy and angular are bound together");
+  if (arrays && (arrays->imu_orientation_wxyz == nullptr) != (arrays->imu_angular_velocity == nullptr)) return fail(SHC_ERR_INVALID_ARG, "the two IMU arrays are bound together");
+  if (arrays && (arrays->pose_translation_velocity || arrays->pose_rotation_velocity || arrays->pose_reset_mode))
+    return fail(SHC_ERR_INVALID_ARG, "input sets carry velocity, IMU, tip force and joint effort");
+  const double *row[BND_COUNT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (arrays) {
+    row[BND_LIN] = arrays->linear_xy, row[BND_ANG] = arrays->angular, row[BND_IMUQ] = arrays->imu_orientation_wxyz, row[BND_IMUW] = arrays->imu_angular_velocity;
+    row[BND_FORCE] = arrays->tip_force, row[BND_EFFORT] = arrays->joint_effort;
+  }
+  memcpy(e->bound_inputs[set], row, sizeof row);
+  return SHC_OK;
+}
+
 extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t max_cycles, int idle_timeout_ms) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (e->res && e->res->active) return fail(SHC_ERR_BUSY, "resident mode is already active");
@@ -233,7 +251,16 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
       return bail(err, "hipHostMalloc(ResidentHost)");
     if ((err = hipHostGetDevicePointer(reinterpret_cast<void **>(&r->host_dev), r->host, 0)) != hipSuccess) return bail(err, "hipHostGetDevicePointer");
     if ((err = hipStreamCreateWithFlags(&r->in_stream, hipStreamNonBlocking)) != hipSuccess) return bail(err, "hipStreamCreate");
-    if ((err = hipStreamCreateWithFlags(&r->loop_stream, hipStreamNonBlocking)) != hipSuccess) return bail(err, "hipStreamCreate");
+    // The loop's stream sits in a PRIORITY CLASS OF ITS OWN (the lowest).  HIP maps streams onto a few hardware queues per priority class, and
+    // a hardware queue is in-order: a stream that shares the loop's queue would wait for the loop kernel to END - a post kernel, a read of the
+    // output ring, the caller's collective would starve until the idle timeout (seen once in a long test process, when a stream a test had
+    // created landed on the loop's queue).  Streams of normal priority - the caller's, PyTorch's, RCCL's, this engine's input stream - never
+    // share a queue with it.  (The loop is not slowed down: once its wavefronts are resident nothing preempts them; measured equal.)
+    {
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+      if ((err = hipStreamCreateWithPriority(&r->loop_stream, hipStreamNonBlocking, least)) != hipSuccess) return bail(err, "hipStreamCreate");
+    }
     if ((err = hipEventCreateWithFlags(&r->loop_ev, hipEventDisableTiming)) != hipSuccess) return bail(err, "hipEventCreate");
     r->stage_bytes = size_t(e->n) * (16 * 8 + 8) + size_t(e->n) * e->L * (3 + e->NJ) * 8 + 256;
     const size_t D = size_t(ring_depth);
@@ -268,6 +295,7 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   r->host->stop = ~0ull;
   __sync_synchronize();
   r->published = r->posted = 0;
+  r->direct_last = -1;
   r->groups_posted = 0;
   r->stream_doorbell_pending = false;
   for (int gi = 0; gi < RG_COUNT; ++gi) {
@@ -280,6 +308,7 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   A.host = r->host_dev;
   A.progress = r->progress;
   A.headers = r->headers;
+  memcpy(A.bound, e->bound_inputs, sizeof A.bound);
   A.rin = r->rin;
   A.rini = r->rini;
   A.force = r->force;
@@ -349,6 +378,30 @@ extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *i
   const double patience = 5.0;
   if (c >= kResidentHeaders && !spin_until([&] { return host_load(&r->host->done) > c - kResidentHeaders; }, patience))
     return fail(SHC_ERR_TIMEOUT, "resident mode: 1024 posted cycles are waiting to run");
+  if (in->direct) {
+    // Launch-free post: one 16-byte record in the host-mapped ring; the relay turns it into the cycle's header and releases the cycle.
+    const int set = in->direct - 1;
+    if (set < 0 || set >= kBoundSets) return fail(SHC_ERR_INVALID_ARG, "direct: bound input set 1 .. 4");
+    if (mask & ((1u << RG_POSE) | (1u << RG_RESET))) return fail(SHC_ERR_INVALID_ARG, "direct posts carry velocity, IMU, tip force and joint effort; post pose inputs / reset modes the ordinary way");
+    if (mask == 0) return fail(SHC_ERR_INVALID_ARG, "direct post without inputs (use shc_engine_resident_publish)");
+    const int need[RG_COUNT] = {BND_LIN, BND_IMUQ, -1, -1, BND_FORCE, BND_EFFORT};
+    for (int gi = 0; gi < RG_COUNT; ++gi)
+      if ((mask & (1u << gi)) && (need[gi] < 0 || !r->args.bound[set][need[gi]]))
+        return fail(SHC_ERR_INVALID_ARG, "direct post: that group is not part of the bound input set (shc_engine_resident_bind_inputs before shc_engine_resident_begin)");
+    if (r->published < c) { // cycles before this one that are still unpublished are released first, the ordinary way
+      const int rc2 = shc_engine_resident_publish(e, int64_t(c - r->published));
+      if (rc2 != SHC_OK) return rc2;
+    }
+    const unsigned long long tag = c + 1;
+    volatile unsigned long long *rec = r->host->records + size_t(c & (kResidentHeaders - 1)) * 2;
+    rec[1] = (unsigned long long)mask | ((unsigned long long)set << 16) | ((tag & 0xffffull) << 48);
+    host_store(const_cast<unsigned long long *>(&rec[0]), tag); // (release: the word above is in place before the tag)
+    r->groups_posted |= mask;
+    r->posted = r->published = c + 1;
+    r->direct_last = (long long)c;
+    if (cycle) *cycle = int64_t(c);
+    return SHC_OK;
+  }
   ResidentPost pp{};
   pp.mask = mask;
   pp.cycle = c;
@@ -432,6 +485,13 @@ extern "C" int shc_engine_resident_publish(shc_engine *e, int64_t n_cycles) {
   if (n_cycles < 0) return fail(SHC_ERR_INVALID_ARG, "n_cycles < 0");
   if (n_cycles == 0) return SHC_OK;
   if (r->published + (unsigned long long)n_cycles > r->max_cycles) return fail(SHC_ERR_INVALID_ARG, "resident mode: past max_cycles");
+  // (a doorbell value releases everything below it in one go: it may only pass a direct post once the relay has installed that post's record)
+  if (r->direct_last >= 0) {
+    const unsigned long long need = (unsigned long long)r->direct_last + 1;
+    if (!spin_until([&] { return host_load(&r->host->done) >= need || host_load(&r->host->exited) != 0; }, 5.0))
+      return fail(SHC_ERR_TIMEOUT, "resident mode: a direct post is still waiting to run");
+    r->direct_last = -1;
+  }
   r->published += (unsigned long long)n_cycles;
   if (r->posted < r->published) r->posted = r->published; // cycles released without a post run with the inputs held
   if (r->stream_doorbell_pending) {
@@ -551,6 +611,11 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   Resident *r = e->res;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(r->in_stream)); // every post and stream-ordered doorbell has landed
+  if (r->direct_last >= 0) { // (as in publish: the doorbell passes a direct post only after the relay has installed it)
+    const unsigned long long need = (unsigned long long)r->direct_last + 1;
+    (void)spin_until([&] { return host_load(&r->host->done) >= need || host_load(&r->host->exited) != 0; }, 5.0);
+    r->direct_last = -1;
+  }
   host_store(&r->host->doorbell, r->published);
   host_store(&r->host->stop, r->published);
   // A loop that does not answer keeps the engine: while the kernel may still be running nothing else may touch the state planes, and

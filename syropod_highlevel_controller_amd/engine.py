@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = [
     "shc_fleet_part_instances", "shc_fleet_set_velocity", "shc_fleet_set_imu", "shc_fleet_set_pose_input", "shc_fleet_set_tip_force",
     "shc_fleet_set_joint_effort", "shc_fleet_step", "shc_fleet_synchronize", "shc_fleet_get_joint_state", "shc_fleet_get_walk_state",
     "shc_fleet_all_gather_joints",
-    "shc_engine_resident_begin", "shc_engine_resident_post", "shc_engine_resident_publish", "shc_engine_resident_wait",
+    "shc_engine_resident_begin", "shc_engine_resident_bind_inputs", "shc_engine_resident_post", "shc_engine_resident_publish", "shc_engine_resident_wait",
     "shc_engine_resident_get_joint_state", "shc_engine_resident_get_joint_state_async", "shc_engine_resident_status", "shc_engine_resident_end", "shc_engine_join",
     "shc_engine_aux_state_bytes", "shc_engine_get_aux_state", "shc_engine_set_aux_state",
 ]
@@ -53,7 +53,8 @@ EXPORTED_SYMBOLS = [
 class CycleInputs(C.Structure):
     """shc_cycle_inputs (include/shc_batch.h): what the callbacks of one loop iteration delivered; NULL = not received."""
     _fields_ = [(k, C.c_void_p) for k in ("linear_xy", "angular", "imu_orientation_wxyz", "imu_angular_velocity", "pose_translation_velocity",
-                                           "pose_rotation_velocity", "pose_reset_mode", "tip_force", "joint_effort")] + [("on_device", C.c_int32), ("publish", C.c_int32)]
+                                           "pose_rotation_velocity", "pose_reset_mode", "tip_force", "joint_effort")] + [("on_device", C.c_int32), ("publish", C.c_int32),
+                                                                                                                  ("direct", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class ShcError(RuntimeError):
@@ -206,6 +207,7 @@ def lib():
         L.shc_engine_set_aux_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
         L.shc_engine_resident_begin.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int]
         L.shc_engine_resident_post.argtypes = [C.c_void_p, C.POINTER(CycleInputs), C.POINTER(C.c_int64)]
+        L.shc_engine_resident_bind_inputs.argtypes = [C.c_void_p, C.c_int, C.POINTER(CycleInputs)]
         L.shc_engine_resident_publish.argtypes = [C.c_void_p, C.c_int64]
         L.shc_engine_resident_wait.argtypes = [C.c_void_p, C.c_int64, C.c_int]
         L.shc_engine_resident_get_joint_state.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
@@ -400,10 +402,51 @@ class BatchEngine:
     def resident_begin(self, ring_depth: int = 16, max_cycles: int = 1 << 24, idle_timeout_ms: int = 0):
         _check(self.L.shc_engine_resident_begin(self.h, int(ring_depth), int(max_cycles), int(idle_timeout_ms)), "resident_begin")
 
+    def resident_bind_inputs(self, input_set: int, velocity=None, imu=None, tip_force=None, joint_effort=None):
+        """Bind device arrays (integer pointers) as input set 0 .. 3 for direct posts; before resident_begin."""
+        ci = CycleInputs()
+        if velocity is not None:
+            ci.linear_xy, ci.angular = int(velocity[0]), int(velocity[1])
+        if imu is not None:
+            ci.imu_orientation_wxyz, ci.imu_angular_velocity = int(imu[0]), int(imu[1])
+        ci.tip_force = None if tip_force is None else int(tip_force)
+        ci.joint_effort = None if joint_effort is None else int(joint_effort)
+        ci.on_device = 1
+        _check(self.L.shc_engine_resident_bind_inputs(self.h, int(input_set), C.byref(ci)), "resident_bind_inputs")
+
+    def resident_direct_poster(self, input_set: int, velocity=False, imu=False, tip_force=False, joint_effort=False):
+        """A bound C call that posts the named groups of bound input set `input_set` as a DIRECT cycle (no kernel launch, no copy, released
+        at once): the per-iteration call of a host loop without the Python wrapper's per-call marshalling, which costs more than the 3 us
+        cycle.  Returns f() -> return code."""
+        ci = CycleInputs()
+        one = 1  # (any non-NULL value: a direct post only looks at WHICH members are set)
+        if velocity:
+            ci.linear_xy, ci.angular = one, one
+        if imu:
+            ci.imu_orientation_wxyz, ci.imu_angular_velocity = one, one
+        if tip_force:
+            ci.tip_force = one
+        if joint_effort:
+            ci.joint_effort = one
+        ci.on_device, ci.publish, ci.direct = 1, 1, int(input_set) + 1
+        f, h, ref = self.L.shc_engine_resident_post, self.h, C.byref(ci)
+
+        def post(_keep=ci):
+            return f(h, ref, None)
+        return post
+
     def resident_post(self, velocity=None, imu=None, pose_input=None, pose_reset_mode=None, tip_force=None, joint_effort=None, on_device=False,
-                      publish=False) -> int:
+                      publish=False, direct=None) -> int:
         """Inputs of the next unposted cycle: velocity = (linear_xy, angular), imu = (quat_wxyz, gyro), pose_input = (translation
-        velocity, rotation velocity); host numpy arrays, or integer device pointers with on_device.  Returns the cycle index."""
+        velocity, rotation velocity); host numpy arrays, or integer device pointers with on_device.  direct = k: a launch-free post from
+        bound input set k (resident_bind_inputs): the arguments only name the fresh groups (any true value).  Returns the cycle index."""
+        if direct is not None:
+            on_device = True
+            one = 1
+            velocity = None if velocity is None else (one, one)
+            imu = None if imu is None else (one, one)
+            tip_force = None if tip_force is None else one
+            joint_effort = None if joint_effort is None else one
         keep = []
 
         def ptr(a, dtype=np.float64):
@@ -426,6 +469,7 @@ class BatchEngine:
         ci.tip_force, ci.joint_effort = ptr(tip_force), ptr(joint_effort)
         ci.on_device = 1 if on_device else 0
         ci.publish = 1 if publish else 0
+        ci.direct = 0 if direct is None else int(direct) + 1
         cyc = C.c_int64(-1)
         _check(self.L.shc_engine_resident_post(self.h, C.byref(ci), C.byref(cyc)), "resident_post")
         return int(cyc.value)

@@ -472,3 +472,137 @@ def test_collective_shaped_kernel_next_to_a_live_loop(Engine, tmp_path):
     assert torch.isfinite(q).all() and float(q.abs().max()) > 0
     eng.close()
     L.shc_stream_destroy(0, stream)
+
+
+@pytest.mark.parametrize("waves", ["two_waves", "one_wave"])
+@pytest.mark.parametrize("case", ["config2_joint_efforts", "config3_joint_efforts", "octopod", "generic_4x4"])
+def test_resident_direct_posts_are_byte_identical_to_single_cycle_launches(Engine, case, waves):
+    """shc_engine_resident_bind_inputs + shc_cycle_inputs.direct: a cycle's inputs posted and released WITHOUT a kernel launch - one
+    16-byte record in host-mapped memory that the relay wavefront turns into the cycle's header; the workers read their robots'
+    velocity / IMU / tip force / joint efforts straight from the caller's device arrays (bound before the loop starts).  New inputs EVERY cycle from two alternating sets of device arrays (the set of cycle c is rewritten only
+    after cycle c has completed), mixed with ordinary ring posts and bare publishes in between; q / qd of every cycle and the final
+    state record equal the same cycles through set_* + shc_engine_step(1), byte for byte; the inputs of the last direct post stay in
+    force afterwards (per-leg inputs are carried into the engine's own planes)."""
+    import torch
+    from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE
+    rng = np.random.default_rng(31)
+    efforts_live = "joint_efforts" in case
+    if case == "config2_joint_efforts":
+        p, n = default_hexapod_params("tripod"), 333
+    elif case == "config3_joint_efforts":
+        p, n = config3_params(), 250
+    elif case == "octopod":
+        p, n = synthetic_octopod_params("ripple", 5, 8), 203
+    else:
+        p, n = synthetic_octopod_params("amble", 4, 4), 130
+    cycles, depth = 200, 8
+    legs, dof = p.leg_count, p.leg_dof[0]
+    sched = velocity_schedule(rng, n, cycles)
+    with_imu = case.startswith("config3")
+    imus = [imu_sample(rng, n) if c % 2 == 0 else None for c in range(cycles)] if with_imu else [None] * cycles
+    forces = [force_sample(rng, n, legs) if c % 3 == 0 else None for c in range(cycles)] if with_imu else [None] * cycles
+    efforts = [rng.normal(0, 0.5, (n, legs * dof)) if (efforts_live and c % 5 == 1) else None for c in range(cycles)]
+    a, b = Engine(p, n), Engine(p, n)
+    if efforts_live:
+        e0 = rng.normal(0, 0.5, (n, legs * dof))
+        for e in (a, b):
+            e.set_joint_effort(e0)
+    if waves == "one_wave":
+        b.set_features(FEAT_DEFAULT | FEAT_RESIDENT_ONE_WAVE)
+    for e in (a, b):
+        e.set_velocity(*sched[0])
+        e.step(23)
+    # which cycles are posted how: most of them direct, some through the rings, some not at all (inputs held)
+    kind = ["direct"] * cycles
+    for c in range(cycles):
+        if c % 17 == 5:
+            kind[c] = "ring"
+        elif c % 23 == 11:
+            kind[c] = "none"
+    # per-leg arrays of a bound set stay in force until another post of that group replaces them: a direct post may only carry a per-leg
+    # group from the set that is NOT in force (the host loop of a real node alternates sets for exactly that reason)
+    in_force = {"f": None, "e": None}
+    for c in range(cycles):
+        for key, plan in (("f", forces), ("e", efforts)):
+            if plan[c] is None or kind[c] == "none":
+                continue
+            if kind[c] == "ring":
+                in_force[key] = None
+            elif in_force[key] == c % 2:
+                plan[c] = None
+            else:
+                in_force[key] = c % 2
+    qa = []
+    for c in range(cycles):
+        if kind[c] != "none":
+            a.set_velocity(*sched[c])
+            if imus[c] is not None:
+                a.set_imu(*imus[c])
+            if forces[c] is not None:
+                a.set_tip_force(forces[c])
+            if efforts[c] is not None:
+                a.set_joint_effort(efforts[c])
+        a.step(1)
+        qa.append(a.joints())
+    a.synchronize()
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    sets = [{"lin": torch.empty((n, 2), dtype=torch.float64, device="cuda"), "ang": torch.empty(n, dtype=torch.float64, device="cuda"),
+             "q": torch.empty((n, 4), dtype=torch.float64, device="cuda"), "w": torch.empty((n, 3), dtype=torch.float64, device="cuda"),
+             "f": torch.empty((n, legs, 3), dtype=torch.float64, device="cuda"), "e": torch.empty((n, legs * dof), dtype=torch.float64, device="cuda")} for _ in range(2)]
+    for k, s_ in enumerate(sets):
+        b.resident_bind_inputs(k, velocity=(s_["lin"].data_ptr(), s_["ang"].data_ptr()), imu=(s_["q"].data_ptr(), s_["w"].data_ptr()) if with_imu else None,
+                               tip_force=s_["f"].data_ptr() if with_imu else None, joint_effort=s_["e"].data_ptr() if efforts_live else None)
+    b.resident_begin(ring_depth=depth, max_cycles=cycles + 10)
+    checked = 0
+    for c in range(cycles):
+        if kind[c] == "direct":
+            k = c % 2
+            s_ = sets[k]
+            b.resident_wait(c)                  # every earlier cycle has completed: velocity / IMU of this set were taken when ITS cycle started
+            s_["lin"].copy_(dev(sched[c][0]))
+            s_["ang"].copy_(dev(sched[c][1]))
+            kw = {"velocity": True}
+            if imus[c] is not None:
+                s_["q"].copy_(dev(imus[c][0]))
+                s_["w"].copy_(dev(imus[c][1]))
+                kw["imu"] = True
+            if forces[c] is not None:           # (the plan above made sure this set's per-leg arrays are not the ones in force)
+                s_["f"].copy_(dev(forces[c]))
+                kw["tip_force"] = True
+            if efforts[c] is not None:
+                s_["e"].copy_(dev(efforts[c]))
+                kw["joint_effort"] = True
+            torch.cuda.current_stream().synchronize()   # the arrays are complete before the post (the contract of a direct post); a STREAM
+            #                                             synchronisation - a device-wide one would wait for the resident loop itself
+            assert b.resident_post(direct=k, **kw) == c
+        elif kind[c] == "ring":
+            kw = {"velocity": sched[c]}
+            if imus[c] is not None:
+                kw["imu"] = imus[c]
+            if forces[c] is not None:
+                kw["tip_force"] = forces[c]
+            if efforts[c] is not None:
+                kw["joint_effort"] = efforts[c]
+            assert b.resident_post(publish=(c % 2 == 0), **kw) == c
+            if c % 2:
+                b.resident_publish(1)
+        else:
+            b.resident_publish(1)
+        if c % 5 == 4 or c == cycles - 1:
+            b.resident_wait(c + 1)
+            for cc in range(max(checked, c + 1 - (depth - 1)), c + 1):
+                q, qd = b.resident_joints(cc)
+                assert np.array_equal(q, qa[cc][0]) and np.array_equal(qd, qa[cc][1]), f"cycle {cc} ({kind[cc]})"
+            checked = c + 1
+    for s_ in sets:                              # velocity / IMU arrays are only borrowed until their cycle has started; the per-leg arrays in
+        for key in ("lin", "ang", "q", "w"):     # force are read until the loop ends (and carried into the engine's planes then)
+            s_[key].fill_(float("nan"))
+    torch.cuda.current_stream().synchronize()
+    assert b.resident_end() == cycles
+    assert state_bytes(a) == state_bytes(b)
+    for e in (a, b):                             # the inputs of the last posts stay in force through ordinary launches
+        e.step(25)
+    assert state_bytes(a) == state_bytes(b)
+    assert np.isfinite(b.joints()[0]).all()
+    a.close()
+    b.close()
