@@ -431,7 +431,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             resident = False
     res_cycle_s = None
     launch_elapsed = None
-    posted_value = None
+    posted_value = posted_launch_value = None
     host_barrier = None
     parity = None
     nogather_elapsed = gather_s = None
@@ -467,20 +467,36 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         else:
             res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, parity=pfac)
         elapsed = res_elapsed
-        # secondary figure: a NEW velocity command for every robot in every cycle, from arrays resident in HBM (post + doorbell in one launch)
-        posted_value = None
+        # secondary figure: a NEW velocity command for every robot in every cycle, from arrays resident in HBM.  Direct posts (ABI 4): two
+        # bound input sets, alternated as a node's callbacks would fill one message while the controller reads the other; a post is a 16-byte
+        # record in host-mapped memory (no kernel launch) that the relay wavefront turns into the cycle's header, the workers read the arrays.
+        posted_value = posted_launch_value = None
         if not use_dist and not os.environ.get("SHC_BENCH_NO_POSTED_PROBE"):   # (profiling runs skip it: one K-cycle launch to attribute counters to)
-            d_lin, d_ang = torch.from_numpy(np.ascontiguousarray(lin)).cuda(), torch.from_numpy(np.ascontiguousarray(ang)).cuda()
+            d_sets = [(torch.from_numpy(np.ascontiguousarray(lin)).cuda(), torch.from_numpy(np.ascontiguousarray(ang)).cuda()) for _ in range(2)]
+            for k, (dl, da) in enumerate(d_sets):
+                eng.resident_bind_inputs(k, velocity=(dl.data_ptr(), da.data_ptr()))
             kk = max(steps, 300)
             eng.resident_begin(ring_depth=16, max_cycles=kk + 16)
+            posters = [eng.resident_direct_poster(k, velocity=True) for k in range(2)]
+            rcs = [posters[i & 1]() for i in range(10)]
+            eng.resident_wait(10)
+            tp = time.perf_counter()
+            for i in range(kk):
+                rcs.append(posters[i & 1]())
+            eng.resident_wait(10 + kk, 60000)
+            posted_value = n * kk / (time.perf_counter() - tp)
+            assert not any(rcs), "direct post failed"
+            eng.resident_end()
+            # ... and the same through the input rings (one post-and-publish kernel launch per cycle: round 3's form)
+            eng.resident_begin(ring_depth=16, max_cycles=kk + 16)
             for _ in range(10):
-                eng.resident_post(velocity=(d_lin.data_ptr(), d_ang.data_ptr()), on_device=True, publish=True)
+                eng.resident_post(velocity=(d_sets[0][0].data_ptr(), d_sets[0][1].data_ptr()), on_device=True, publish=True)
             eng.resident_wait(10)
             tp = time.perf_counter()
             for _ in range(kk):
-                eng.resident_post(velocity=(d_lin.data_ptr(), d_ang.data_ptr()), on_device=True, publish=True)
+                eng.resident_post(velocity=(d_sets[0][0].data_ptr(), d_sets[0][1].data_ptr()), on_device=True, publish=True)
             eng.resident_wait(10 + kk, 60000)
-            posted_value = n * kk / (time.perf_counter() - tp)
+            posted_launch_value = n * kk / (time.perf_counter() - tp)
             eng.resident_end()
         # N = 1: the region closes with shc_engine_resident_wait - every wave has completed the K-th cycle and its joint state is
         # visible (the device-to-host completion handshake).  The loop kernel is still alive at that point, so a stream
@@ -611,7 +627,8 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                    "mode": ("resident: one launch stays on the chip, a step = one doorbell tick = one control cycle with that cycle's inputs from the "
                             "device-side rings and its q / qd to the output ring") if resident else "one launch of the fused cycle kernel per step",
                    "one_launch_per_cycle_value": (world * n * steps * cps / launch_elapsed) if launch_elapsed else None,
-                   "velocities_posted_every_cycle_value": posted_value,   # resident mode, a new velocity set per robot and cycle from device arrays
+                   "velocities_posted_every_cycle_value": posted_value,   # resident mode, a new velocity set per robot and cycle from device arrays (direct posts)
+                   "velocities_posted_every_cycle_through_the_rings_value": posted_launch_value,   # ... with one post kernel launch per cycle (round 3's form)
                    "legs": p.leg_count, "dof": p.leg_dof[0],
                    "gather": f"all-gather of the joint buffer every {gather_every} steps" if gather_every
                    else ("one all-gather of the final joint buffer, inside the timed region: queued on the engine's stream behind a device-side wait for the "
