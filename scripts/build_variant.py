@@ -19,6 +19,7 @@ morph = (6, 3)
 if "--morph" in args:
     morph = tuple(int(x) for x in args[args.index("--morph") + 1].split(","))
 report = "--report" in args
+drop = [a.split("=", 1)[1] for a in args if a.startswith("--drop-flag=")]   # remove a product flag (and a preceding -mllvm) from the compile line
 with_engine = "--engine" in args   # also recompile the host side (shc_engine.hip) with the extra flags
 engine.build_library()
 out_dir = os.path.join("gpurun_variants", name)
@@ -28,7 +29,12 @@ for oname, src, defines in engine._translation_units():
     obj = os.path.join(engine._OBJ, oname)
     if oname == f"shc_cycle_{morph[0]}_{morph[1]}.o" or (with_engine and oname == "shc_engine.o"):
         obj = os.path.join(out_dir, oname)
-        cmd = ["/opt/rocm/bin/hipcc"] + engine._FLAGS + list(defines) + extra + ["-c", "-o", obj, src]
+        flags = list(engine._FLAGS)
+        for d in drop:
+            if d in flags:
+                i = flags.index(d)
+                del flags[i - 1 if i and flags[i - 1] == "-mllvm" else i:i + 1]
+        cmd = ["/opt/rocm/bin/hipcc"] + flags + list(defines) + extra + ["-c", "-o", obj, src]
         if report:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)

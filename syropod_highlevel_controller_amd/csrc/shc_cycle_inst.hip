@@ -13,18 +13,21 @@ static void launch_cycle(const CycleLaunch &a) {
   constexpr int RPW = 64 / L;
   constexpr size_t wave_bytes = size_t(RobotFields::COUNT * RPW + PK_COUNT * 64 + (RobotFields::I_COUNT * RPW + 1) / 2) * 8;
   if (a.fit || a.resident) {
-    // resident kernels exist for the specialisations without rough terrain / manual legs / tip rotations (those read and
-    // write side records in HBM every cycle and the rotation kernels do not fit two waves per SIMD)
-    if constexpr ((F & (F_TERRAIN | F_ROT)) == 0) {
+    // Resident kernels: every specialisation but the tip-align pose and manual legs (their per-robot records change under loop-level calls).
+    // Rough terrain and tip rotations run as ONE wavefront per robot group (Leg::applyIK feeds back into the stepper there - touchdown
+    // detection, the FK tip rotation - so the walker / model halves cannot be pipelined); everything else also has the two-wavefront form.
+    if constexpr ((F & (F_TALIGN | F_MLEGS)) == 0) {
+      constexpr bool two_wave = (F & (F_TERRAIN | F_ROT)) == 0;
       if (a.fit) {
         a.fit->supported = 1;
-        a.fit->two_wave = 1;
+        a.fit->two_wave = two_wave ? 1 : 0;
         int blocks = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, shc_resident_kernel<L, NJ, F>, 64, wave_bytes) != hipSuccess) blocks = 0;
         a.fit->blocks_per_cu = blocks;
       } else if (a.block == 256) {
-        shc_resident2_kernel<L, NJ, F><<<dim3(a.grid), dim3(256), 2 * wave_bytes + sizeof(Resident2Lds<L, NJ>), a.stream>>>(
-            a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
+        if constexpr (two_wave)
+          shc_resident2_kernel<L, NJ, F><<<dim3(a.grid), dim3(256), 2 * wave_bytes + sizeof(Resident2Lds<L, NJ>), a.stream>>>(
+              a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
       } else {
         shc_resident_kernel<L, NJ, F><<<dim3(a.grid), dim3(64), wave_bytes, a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
       }

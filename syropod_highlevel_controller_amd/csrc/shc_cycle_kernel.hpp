@@ -345,7 +345,7 @@ template <int L, int NJ, unsigned F>
 __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevState &st, LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C,
                                               const RobTile<64 / L> &rb, const Park &pk, const Group<L> g, const int leg, const uint32_t slot,
                                               const int lane, const int64_t wave, const bool live, double *tile, int32_t *tile_i, unsigned &dirty,
-                                              const bool manual_live, ResidentHeld &held) {
+                                              const bool manual_live, ResidentHeld &held, const bool touchdown_at_begin, double *ext) {
   using R = RobotFields;
   using FD = Fields<NJ>;
   constexpr int RPW = 64 / L;
@@ -400,7 +400,29 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) st_agent(A.progress + wave, u64(c));
     };
-    cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr, in, publish_previous);
+    bool touchdown_detection = false;
+    if constexpr ((F & F_ROUGH) != 0) {
+      // tipStatesCallback (state_controller.cpp:1618-1648) delivered a force this iteration: Leg::touchdownDetection (model.cpp:712-722) with the
+      // tip where the last applyFK left it - what shc_engine_set_tip_force runs as a kernel of its own between two launches
+      touchdown_detection = touchdown_at_begin || (held.seen & (1u << RG_FORCE)) != 0; // LegStepper::setTouchdownDetection(true) (:1642)
+      const bool fresh_force = h0 == u64(c) + 1 && (unsigned(h1) & (1u << RG_FORCE)) != 0;
+      if (fresh_force && uni(C.P.rough_terrain) != 0) {
+        double *sp = st.legd + leg_field_index(FD::STEP_PLANE, slot, ns); // fields STEP_PLANE .. + 3 = two paired planes
+        double *sp2 = st.legd + leg_field_index(FD::STEP_PLANE + 2, slot, ns);
+        const double fn = norm(in.force());
+        const double defined = ld_agent_f64(sp2 + 1);
+        if (fn > A.touchdown_threshold && defined == 0.0) {
+          Chain<NJ> ch;
+          fk_chain<NJ>(C.leg[leg], s.q, ch);
+          const V3 tipnow = tip_robot_frame(C.leg[leg], ch.pe); // step_plane_pose_ = current_tip_pose_
+          if (live) sp[0] = tipnow.x, sp[1] = tipnow.y, sp2[0] = tipnow.z, sp2[1] = 1.0;
+        } else if (fn < A.liftoff_threshold) {
+          if (live) sp2[1] = 0.0;
+        }
+      }
+    }
+    cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, touchdown_detection, ext, nullptr, in, publish_previous,
+                    (F & F_ROUGH) != 0 ? st.span : nullptr);
     { // desired joint state of this cycle -> output ring (write-through 16-byte stores: visible to any agent once drained)
       typedef unsigned v4u __attribute__((ext_vector_type(4)));
       double flat[2 * NJ];
@@ -742,7 +764,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   const bool pose_only = pose_marked && marked;
   ResidentHeld held;
   if constexpr (RES) {
-    resident_loop<L, NJ, F>(*ra, st, s, out, C, rb, pk, g, leg, slot, lane, wave, live, tile, tile_i, dirty, manual_live, held);
+    resident_loop<L, NJ, F>(*ra, st, s, out, C, rb, pk, g, leg, slot, lane, wave, live, tile, tile_i, dirty, manual_live, held, touchdown_detection, ext);
   } else if (!skip) {
     for (int c = 0; c < n_cycles; ++c)
       cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
@@ -788,7 +810,9 @@ __global__ void __launch_bounds__(256, (F & F_ROT) ? SHC_ROT_WAVES_PER_SIMD : ((
 // Resident launch: block 0 is the relay (host <-> device handshake), block 1 + w is worker wave w; 64 threads each, every block
 // co-resident (the host checks the grid against the occupancy of this kernel before launching).
 template <int L, int NJ, unsigned F>
-__global__ void __launch_bounds__(64, SHC_WAVES_PER_SIMD) shc_resident_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
+// (rough terrain / tip rotations: one wavefront per SIMD - the resident loop around those cycles does not fit 256 registers without
+//  scratch, and a batch that is resident has SIMDs to spare: up to ~990 wavefronts, 9 900 hexapods / 7 900 octopods)
+__global__ void __launch_bounds__(64, (F & (F_ROT | F_ROUGH)) ? 1 : SHC_WAVES_PER_SIMD) shc_resident_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
   if (blockIdx.x == 0) {
     resident_relay<PART_BOTH>(ra);
     return;

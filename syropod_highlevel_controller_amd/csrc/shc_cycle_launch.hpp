@@ -68,6 +68,7 @@ struct ResidentArgs {
   unsigned long long idle_ticks;    // wall-clock ticks without a new doorbell value before the relay stops the loop
   unsigned long long ticks_per_ms;  // wall_clock64() rate of the device (hipDeviceAttributeWallClockRate): every device-side time bound derives from it
   int64_t n_waves;
+  double touchdown_threshold, liftoff_threshold; // Leg::touchdownDetection (model.cpp:712-722) runs inside the loop when a tip force arrives (rough terrain mode)
 };
 
 // Everything a launch of the cycle kernel needs from the engine.

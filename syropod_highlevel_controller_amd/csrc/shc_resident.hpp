@@ -216,7 +216,7 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
 #undef CALL
   }
   if (!fit.supported)
-    return fail(SHC_ERR_UNSUPPORTED, "resident mode: this configuration runs on a rough-terrain / manual-leg / tip-rotation kernel, which has no resident form");
+    return fail(SHC_ERR_UNSUPPORTED, "resident mode: this configuration runs on a tip-align / manual-leg kernel, which has no resident form");
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, e->device));
   // ... less one compute unit's worth per XCD (workgroups are dealt round-robin to the 8 XCDs and placed only inside their own): the loop's
@@ -322,6 +322,8 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   A.idle_ticks = (unsigned long long)(idle_timeout_ms ? idle_timeout_ms : 5000) * r->wall_khz;
   A.ticks_per_ms = r->wall_khz;
   A.n_waves = e->n_waves;
+  A.touchdown_threshold = e->params.touchdown_threshold;
+  A.liftoff_threshold = e->params.liftoff_threshold;
   e->plan_poser_tips_current = false;
   // Two wavefronts per robot group (walker / model halves of the cycle pipelined over two SIMDs) while every 256-thread workgroup
   // - two robot groups - and the relay get a compute unit of their own; one wavefront per group above that.

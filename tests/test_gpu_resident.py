@@ -62,14 +62,18 @@ def force_sample(rng, n, legs):
 
 @pytest.mark.parametrize("waves", ["two_waves", "one_wave"])
 @pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4", "config2_body_posing", "config3_body_posing_inclination",
-                                  "config2_joint_efforts", "config3_joint_efforts", "config3_joint_efforts_feed_admittance", "octopod_joint_efforts"])
+                                  "config2_joint_efforts", "config3_joint_efforts", "config3_joint_efforts_feed_admittance", "octopod_joint_efforts",
+                                  "rough_terrain", "rough_terrain_joint_efforts", "gravity_aligned_octopod"])
 def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves):
     """Every cycle gets new inputs.  Engine A: set_* + shc_engine_step(1) per cycle.  Engine B: one resident launch, inputs posted per
     cycle.  q / qd of EVERY cycle (output ring) and the complete state record at the end are equal byte for byte - for the
     two-wavefront (walker / model) pipeline, which these batch sizes get by default, and for one wavefront per robot group.
     *_joint_efforts: measured joint torques are live (shc_engine_set_joint_effort before the loop starts, new torques through the RG_EFFORT
     ring every few cycles) - the kernels with Leg::calculateTipForce (model.cpp:667-708), i.e. what bench.py's headline number runs on;
-    *_feed_admittance: use_joint_effort, the estimate drives the admittance (admittance_controller.cpp:30-31)."""
+    *_feed_admittance: use_joint_effort, the estimate drives the admittance (admittance_controller.cpp:30-31).
+    rough_terrain*: rough_terrain_mode with tip forces that come and go (touchdown detection runs inside the loop when a force arrives);
+    gravity_aligned_octopod: tip rotations + the rotation-constrained applyIK - both as one wavefront per robot group (Leg::applyIK feeds
+    back into the stepper there), whatever `waves` asks for."""
     from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE
     rng = np.random.default_rng(11)
     efforts_live = "joint_efforts" in case
@@ -86,12 +90,24 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
             p.use_joint_effort = 1
     elif case in ("octopod", "octopod_joint_efforts"):
         p, n = synthetic_octopod_params("ripple", 5, 8), 203
+    elif case.startswith("rough_terrain"):
+        p, n = default_hexapod_params("tripod"), 287
+        p.rough_terrain_mode, p.step_depth = 1, 0.012
+    elif case == "gravity_aligned_octopod":
+        p, n = synthetic_octopod_params("ripple", 5, 8), 131
+        p.gravity_aligned_tips = 1
     else:
         p, n = synthetic_octopod_params("amble", 4, 4), 130
     cycles, depth = 260, 8
     sched = velocity_schedule(rng, n, cycles)
     imus = [imu_sample(rng, n) for _ in range(cycles)] if case.startswith("config3") else None
     forces = [force_sample(rng, n, p.leg_count) if c % 3 == 0 else None for c in range(cycles)] if case.startswith("config3") else None
+    if case.startswith("rough_terrain"):   # contact forces that come and go around the touchdown / lift-off thresholds
+        def contact():
+            f = rng.normal(0, 0.25, (n, 6, 3))
+            f[..., 2] += rng.choice([0.0, 0.05, 0.6, 1.5], size=(n, 6), p=[0.3, 0.2, 0.2, 0.3])
+            return f
+        forces = [contact() if c % 4 == 1 else None for c in range(cycles)]
     posing = "body_posing" in case
     pose_in = [(rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.7), rng.uniform(-1, 1, (n, 3)) * (rng.random((n, 1)) < 0.7)) if c % 4 == 0 else None
                for c in range(cycles)] if posing else None
@@ -116,8 +132,8 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
         a.set_velocity(*sched[c])
         if imus:
             a.set_imu(*imus[c])
-            if forces[c] is not None:
-                a.set_tip_force(forces[c])
+        if forces and forces[c] is not None:
+            a.set_tip_force(forces[c])
         if posing:
             if pose_in[c] is not None:
                 a.set_pose_input(*pose_in[c])
@@ -137,8 +153,8 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
             kw = {"velocity": sched[c]}
             if imus:
                 kw["imu"] = imus[c]
-                if forces[c] is not None:
-                    kw["tip_force"] = forces[c]
+            if forces and forces[c] is not None:
+                kw["tip_force"] = forces[c]
             if posing:
                 if pose_in[c] is not None:
                     kw["pose_input"] = pose_in[c]
