@@ -728,10 +728,15 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
     }
     // ---- updateTipAlignPose (:1024-1088): the legs are visited in id order and each swinging leg overwrites the pose, reading the
     //      translation its predecessor left - re-simulated identically in every lane from L shuffled tip-to-joint vectors
-    if ((F & F_TALIGN) != 0 && NJ <= 3 && uni(P.tip_align)) {
+    if ((F & F_TALIGN) != 0 && uni(P.tip_align)) { // (leg 0 has at most 3 joints, :849; the other legs may be longer: every leg takes part)
       Chain<NJ> ch0;
       chain_from_sincos<NJ>(lc, s.sn, s.cs, ch0); // the last applyFK: tip and last joint in the robot frame
-      const V3 t2j_own = base_rotate(lc, ch0.p[NJ - 1] - ch0.pe);
+      V3 last_joint = ch0.p[NJ - 1]; // tip->reference_link_->actuating_joint_: the last joint this leg really has (a padded leg's locked joints sit at its tip)
+      if constexpr (NJ > 3) {
+#pragma unroll
+        for (int k = NJ - 2; k >= 2; --k) last_joint = lc.jactive[k + 1] != 0.0 ? last_joint : ch0.p[k];
+      }
+      const V3 t2j_own = base_rotate(lc, last_joint - ch0.pe);
       Pose ta = rb.getpose(R::TALIGN), ota = rb.getpose(R::OTALIGN);
       const V3 n = pnorm_prev; // leg_stepper->getWalkPlaneNormal(): the copy taken by last cycle's updateStride
       const Quat wrot = from_two_vectors(UZ, n);
@@ -1311,7 +1316,9 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     if (rot_on) {
       const int pm0 = (s.word >> LW_PM_SHIFT) & 3; // swing / stance progress as the previous iteratePhase left them
       const double sp = swing_progress_of(s.word, P);
-      if (rot_walk && (pm0 == PM_STANCE || pm0 == PM_STOP || sp >= 0.5)) {
+      bool more_than_3_joints = NJ > 3; // leg_->getJointCount() > 3 (:1195) of THIS leg: a shorter leg padded up to the kernel's NJ has none of it
+      if constexpr (NJ > 3) more_than_3_joints = lc.jactive[3] != 0.0;
+      if (rot_walk && more_than_3_joints && (pm0 == PM_STANCE || pm0 == PM_STOP || sp >= 0.5)) {
         if (uni(P.gravity_target) && !targ_rot) { // "set target tip rotation to align with gravity if ... currently undefined" (:1197-1205)
           V3 gv{0, 0, kGravity}; // Model::estimateGravity (model.cpp:156-165); the direction of FromTwoVectors(UnitX, gravity) * UnitX
           if (FT::imu(P) || FT::incl(P) || FT::autop(P)) {

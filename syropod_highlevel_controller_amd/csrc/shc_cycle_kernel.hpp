@@ -705,7 +705,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     if (FT::odom(GP)) load_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, gtile, lane);
     if (skip_marked || pose_marked) load_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, gtile, lane);
     if (pose_marked && FT::incl(GP)) load_rob_fields<RPW, R::INCL, R::INCL_END>(t_incl, gtile, lane);
-    if ((F & F_TALIGN) != 0 && NJ <= 3 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
+    if ((F & F_TALIGN) != 0 && GP.tip_align) load_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, gtile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
     // Leg::applyFK of the previous cycle: sin / cos of the stored joint angles
@@ -731,7 +731,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     if (FT::odom(GP)) put_rob_fields<RPW, R::ODOM, R::ODOM_END>(t_odom, tile, lane);
     if (skip_marked || pose_marked) put_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(t_cpose, tile, lane);
     if (pose_marked && FT::incl(GP)) put_rob_fields<RPW, R::INCL, R::INCL_END>(t_incl, tile, lane);
-    if ((F & F_TALIGN) != 0 && NJ <= 3 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
+    if ((F & F_TALIGN) != 0 && GP.tip_align) put_rob_fields<RPW, R::TALIGN, R::COUNT>(t_align, tile, lane);
 #pragma unroll
     for (int it = 0; it < int_iters; ++it)
       if (it * 64 + lane < R::I_COUNT * RPW) tile_i[it * 64 + lane] = t_int[it];
@@ -794,7 +794,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   if ((F & F_MLEGS) != 0 && FT::incl(P) && pose_marked) store_rob_fields<RPW, R::INCL, R::INCL_END>(tile, gtile, lane); // for poseForLegManipulation
   store_rob_fields<RPW, R::CPOSE, R::CPOSE_END>(tile, gtile, lane); // (walk_plane_pose_ is recomputed every cycle: LDS only)
   if (FT::odom(P)) store_rob_fields<RPW, R::ODOM, R::ODOM_END>(tile, gtile, lane);
-  if ((F & F_TALIGN) != 0 && NJ <= 3 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
+  if ((F & F_TALIGN) != 0 && P.tip_align) store_rob_fields<RPW, R::TALIGN, R::COUNT>(tile, gtile, lane);
   static_assert((R::I_POSE_PHASE + 1) * RPW <= 64, "the written-back int fields (word, poser latches, pose phase) fit one wave-wide store");
   if (lane < (R::I_POSE_PHASE + 1) * RPW) gtile_i[lane] = tile_i[lane];
   if constexpr (RES) resident_epilogue<L, NJ, F>(*ra, st, slot, lane, live, tile, tile_i, gtile, gtile_i, held);

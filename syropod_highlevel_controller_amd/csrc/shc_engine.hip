@@ -424,7 +424,7 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
       if (p.leg_dof[l] == 3) c.joint_control = 2; // (walk_controller.cpp:677: "works only for 3DOF legs")
   }
   c.rough_terrain = p.rough_terrain_mode ? 1 : 0;
-  c.tip_align = (p.gravity_aligned_tips && max_dof(p) <= 3) ? 1 : 0; // pose_controller.cpp:849 (leg 0's joint count; mixed DOF + gravity_aligned_tips is rejected)
+  c.tip_align = (p.gravity_aligned_tips && p.leg_dof[0] <= 3) ? 1 : 0; // pose_controller.cpp:849: LEG 0's joint count decides for the whole robot
   c.step_depth = p.step_depth;
   {
     V3 d = hostinit::gravity_aligned_direction();
@@ -473,8 +473,9 @@ static int validate_params(const shc_params *p, int *L, int *NJ) {
   const int nj = max_dof(*p);
   for (int l = 0; l < p->leg_count; ++l)
     if (p->leg_dof[l] < 3 || p->leg_dof[l] > 5) return fail(SHC_ERR_UNSUPPORTED, "supported joints per leg (leg_dof): 3..5 DOF");
-  if (mixed_dof(*p) && p->gravity_aligned_tips) // (the reference decides per leg: > 3 joints constrain the tip rotation, <= 3 use the tip-align pose)
-    return fail(SHC_ERR_UNSUPPORTED, "gravity_aligned_tips on a robot whose legs differ in DOF");
+  // (gravity_aligned_tips on a robot whose legs differ in DOF: the reference decides per leg - legs of more than 3 joints constrain their tip
+  //  rotation, walk_controller.cpp:37, :1195, model.cpp:880 - and by LEG 0's joint count whether the tip-align pose runs, over ALL legs,
+  //  pose_controller.cpp:849; both are run-time tests on the padded chains here)
   if (p->rough_terrain_mode && !(p->touchdown_threshold >= p->liftoff_threshold))
     return fail(SHC_ERR_INVALID_ARG, "touchdown_threshold must be >= liftoff_threshold");
   if (p->n_auto_posers < 0 || p->n_auto_posers > kMaxAutoPosers) return fail(SHC_ERR_INVALID_ARG, "n_auto_posers out of range");
@@ -732,13 +733,13 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
     t[F::MODEL_TIP + 2] = tip.z;
     // step_state STANCE, phase 0, progress "none" (walk_controller.h:493-501)
     legw[l] = SS_STANCE | (PM_NONE << LW_PM_SHIFT);
-    if (hostinit::tips_rotation_constrained(e->params, NJ)) { // current / origin / target tip poses start at the identity tip pose (:800-803)
+    if (hostinit::tips_rotation_constrained(e->params, e->params.leg_dof[l])) { // current / origin / target tip poses start at the identity tip pose (:800-803)
       V3 d = hostinit::gravity_aligned_direction();
       t[F::ORG_DIR] = t[F::CUR_DIR] = t[F::TARG_DIR] = d.x;
       t[F::ORG_DIR + 1] = t[F::CUR_DIR + 1] = t[F::TARG_DIR + 1] = d.y;
       t[F::ORG_DIR + 2] = t[F::CUR_DIR + 2] = t[F::TARG_DIR + 2] = d.z;
       legw[l] |= LW_ROTDEF | LW_TARGROT;
-    } else if (hostinit::tips_rotation_tracked(e->params, NJ)) { // ... at UNDEFINED_ROTATION, whose rotated x axis is x itself
+    } else if (hostinit::tips_rotation_tracked(e->params, NJ)) { // ... at UNDEFINED_ROTATION, whose rotated x axis is x itself (also a <= 3-joint leg next to longer ones)
       t[F::ORG_DIR] = t[F::CUR_DIR] = 1.0;
     }
   }
@@ -2631,6 +2632,8 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
     }
   }
   const int touchdown = (e->rt_flags & RT_TOUCHDOWN) ? 1 : 0;
+  unsigned long_legs = 0;
+  for (int l = 0; l < e->L; ++l) long_legs |= e->params.leg_dof[l] > 3 ? 1u << l : 0u;
   HIP_TRY(hipSetDevice(e->device));
   shc_instance_state *d = nullptr;
   const size_t bytes = size_t(count) * sizeof(shc_instance_state);
@@ -2641,13 +2644,13 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
   if (err == hipSuccess) {
     switch (e->NJ) {
       case 3: if (in) set_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
-              else get_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown);
+              else get_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown, long_legs);
               break;
       case 4: if (in) set_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
-              else get_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown);
+              else get_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown, long_legs);
               break;
       default: if (in) set_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
-               else get_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown);
+               else get_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown, long_legs);
                break;
     }
     err = hipGetLastError();

@@ -191,7 +191,9 @@ SHC_HDI void startup_solve(const shc_params &p, HostLeg<NJ> &leg, V3 default_tip
   leg.reset_to_default();
   V3 origin = leg.tip;
   V3 delta = origin - inverse_transform_vector(body, default_tip);
-  const bool rot = tips_rotation_constrained(p, NJ);
+  int joints_of_this_leg = 0; // (a leg padded up to the robot's longest leg decides by ITS OWN joint count, walk_controller.cpp:37)
+  for (int k = 0; k < NJ; ++k) joints_of_this_leg += leg.lc.jactive[k] != 0.0 ? 1 : 0;
+  const bool rot = tips_rotation_constrained(p, joints_of_this_leg);
   const V3 origin_dir = base_rotate(leg.lc, leg.ch.xe), target_dir = gravity_aligned_direction();
   bool transition_rotation = false; // pose_controller.cpp:1594-1601
   if (rot) transition_rotation = norm(angle_axis_vector(from_two_vectors(origin_dir, target_dir))) > kJointTolerance;

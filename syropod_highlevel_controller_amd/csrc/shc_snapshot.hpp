@@ -19,7 +19,9 @@ __device__ inline void snap_put3(double *dst, V3 v) {
 }
 
 template <int NJ>
-__global__ void get_state_kernel(shc_instance_state *out, DevState st, CycleParams P, int L, int64_t first, int64_t count, int touchdown) {
+__global__ void get_state_kernel(shc_instance_state *out, DevState st, CycleParams P, int L, int64_t first, int64_t count, int touchdown, unsigned long_legs) {
+  // long_legs: bit l = leg l has more than 3 joints (its stepper tracks a tip rotation under gravity_aligned_tips / rough terrain mode; a shorter
+  // leg of the same robot, padded up to the kernel's joint count, does not - its record fields stay zero, as for a robot of 3-joint legs)
   using FD = Fields<NJ>;
   using R = RobotFields;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -113,7 +115,7 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
     } else if (pm == PM_STOP) {
       g.stance_progress = 0.0;
     }
-    if (P.gravity_aligned || P.joint_control == 2) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
+    if ((P.gravity_aligned && ((long_legs >> l) & 1u)) || P.joint_control == 2) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
       for (int k = 0; k < 3; ++k) {
         g.origin_tip_direction[k] = f(FD::ORG_DIR + k);
         g.walker_tip_direction[k] = f(FD::CUR_DIR + k);

@@ -102,11 +102,56 @@ def test_mixed_dof_robot_free_running():
     parity_report(f"[mixed DOF free-running] 3 / 5 / 4-joint legs, {n} instances x 360 cycles: median |dq| over instances <= {worst:.2e} rad, >= 90 % within 1e-6")
 
 
-def test_mixed_dof_rejections():
-    p = synthetic_mixed_dof_params("ripple")
-    p.gravity_aligned_tips = 1      # the reference decides per leg there (> 3 joints: tip rotation, <= 3: tip-align pose)
-    with pytest.raises(ShcError):
-        BatchEngine(p, 4)
+@pytest.mark.parametrize("dofs", [(3, 5, 4, 3, 5, 4), (5, 3, 4, 5, 3, 4)])
+def test_mixed_dof_robot_with_gravity_aligned_tips(dofs):
+    """gravity_aligned_tips on a robot whose legs differ in DOF - one bin of BASELINE.json config 5 with the parameter set.  The reference
+    decides per leg: legs of more than 3 joints get the identity tip rotation and the rotation-constrained applyIK (walk_controller.cpp:37,
+    :1195, model.cpp:880-900), and LEG 0's joint count decides whether PoseController::updateTipAlignPose runs - over all legs, each with
+    the vector from its tip to the last joint it really has (pose_controller.cpp:849, :1024-1088).  (3, 5, 4, ...): leg 0 has 3 joints - the
+    tip-align pose AND tip rotations on the four longer legs; (5, 3, 4, ...): rotations only.  Teacher-forced, every field of the record
+    for every instance, then free-running where the reference trajectory is well-posed."""
+    p = synthetic_mixed_dof_params("ripple", dofs)
+    p.gravity_aligned_tips = 1
+    p.time_to_start = 2.0
+    n, L = 36, p.leg_count
+    rng = np.random.default_rng(101)
+    eng, ob = BatchEngine(p, n), OracleBatch(p, n)
+    lin, ang = rng.uniform(-0.6, 0.6, (n, 2)), rng.uniform(-0.8, 0.8, n)
+    worst = 0.0
+    for c in range(240):
+        if c == 150:
+            lin[::2], ang[::2] = 0.0, 0.0
+        for o in (eng, ob):
+            o.set_velocity(lin, ang)
+        eng.set_state(ob.get_state())
+        eng.step(1)
+        eng.synchronize()
+        ob.step(1, 1)
+        d = float(np.abs(eng.joints()[0] - padded(ob.joints()[0], p)).max())
+        worst = max(worst, d)
+        assert d < 1e-11, (c, d)
+        compare_records(p, FEAT_DEFAULT, as_np(eng.get_state()), as_np(ob.get_state()), tol_q=1e-11)
+        assert np.array_equal(eng.body_state()[2], ob.body_state()[2])
+    pose = eng.body_state()[0]
+    if dofs[0] <= 3:   # the tip-align pose has moved the body sideways at some point (it is not the plain walk-plane pose)
+        st = as_np(eng.get_state())
+        assert np.abs(st["tip_align_pose"][:, :3]).max() > 1e-6 or np.abs(st["origin_tip_align_pose"][:, :3]).max() > 1e-6
+    assert np.isfinite(pose).all()
+    # free-running from each side's own init chain
+    eng2, ob2 = BatchEngine(p, n), OracleBatch(p, n)
+    lin2 = rng.uniform(-0.5, 0.5, (n, 2))
+    for o in (eng2, ob2):
+        o.set_velocity(lin2, ang)
+    good = 1.0
+    for _ in range(4):
+        eng2.step(40)
+        ob2.step(40, 8)
+        d = np.abs(eng2.joints()[0] - padded(ob2.joints()[0], p)).max(axis=1)
+        good = min(good, float((d < 1e-6).mean()))
+        assert np.array_equal(eng2.body_state()[2], ob2.body_state()[2])
+    assert good >= 0.85, good
+    parity_report(f"[mixed DOF {dofs} + gravity_aligned_tips] {n} instances x 240 cycles teacher-forced: max |dq| = {worst:.2e} rad; free-running 160 cycles: "
+                  f"{good:.0%} of the instances within 1e-6 rad")
 
 
 def test_mixed_dof_robot_in_resident_mode():
