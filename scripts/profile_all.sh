@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 profiles (run through gpurun from the repo root): the BASELINE.json configurations + the section 8(f) workloads, each its own
+# Round profiles (r04) (run through gpurun from the repo root): the BASELINE.json configurations + the section 8(f) workloads, each its own
 # rocprofv3 passes (kernel trace + stats; FETCH_SIZE, WRITE_SIZE, SQ, LDS counters each in a run of their own - scripts/profile_round.sh),
 # summarised on the box (the raw CSVs exceed what gpurun copies back) into gpurun_out/summaries/, which is then copied to profiles/.
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -11,11 +11,12 @@ run() { # name, summary file, traffic key, resident K or "", bench arguments...
   python scripts/summarize_prof.py gpurun_out/prof_$name $S/$out $key $res > /dev/null 2>> $S/$name.log
   rm -rf gpurun_out/prof_$name
 }
-SHC_BENCH_NO_POSTED_PROBE=1 run c2_resident r03_config2_resident_rocprofv3.txt config2:resident:4096:1 resident:4000 --workload config2
-run c2_launch r03_config2_launch_rocprofv3.txt config2:4096:1 launch --workload config2 --mode launch
-run c3 r03_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-joint-efforts
-run c4 r03_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
-run rough r03_rough_terrain_rocprofv3.txt rough:65536:1 split --workload rough --no-joint-efforts
-run gravity r03_gravity_aligned_rocprofv3.txt gravity:65536:1 split --workload gravity --no-joint-efforts
-PROF_STEPS=100 run c5 r03_config5_rocprofv3.txt config5:1048576:1 fleet --workload config5
+SHC_BENCH_NO_POSTED_PROBE=1 run c2_resident r04_config2_resident_rocprofv3.txt config2:resident:4096:1 resident:4000 --workload config2
+SHC_BENCH_NO_POSTED_PROBE=1 run c4_resident r04_config4_resident_8x5_rocprofv3.txt config4:resident:4000:1 resident:4000 --workload config4 --instances 4000 --no-joint-efforts
+run c2_launch r04_config2_launch_rocprofv3.txt config2:4096:1 launch --workload config2 --mode launch
+run c3 r04_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-joint-efforts
+run c4 r04_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
+run rough r04_rough_terrain_rocprofv3.txt rough:65536:1 split --workload rough --no-joint-efforts
+run gravity r04_gravity_aligned_rocprofv3.txt gravity:65536:1 split --workload gravity --no-joint-efforts
+PROF_STEPS=100 run c5 r04_config5_rocprofv3.txt config5:1048576:1 fleet --workload config5
 ls -la $S

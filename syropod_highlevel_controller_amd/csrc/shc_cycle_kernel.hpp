@@ -229,8 +229,23 @@ struct LegInRing {
   // (pair = 2 n_slots) and a caller's instance-major array of a bound input set (pair = 2) alike
   const double *force_ptr, *effort_ptr;
   int64_t force_pair, effort_pair;
+  // The joint efforts are consumed at the very end of Model::updateModel (Leg::calculateTipForce) but come from memory another agent
+  // may have written (agent-scope loads, ~1 us): a wavefront that runs alone on its SIMD would sit out that latency.  prefetch_effort()
+  // issues the loads where the model half starts; they arrive while the IK step runs.
+  bool effort_prefetched = false;
+  double effort_now[NJ] = {};
+  __device__ __forceinline__ void prefetch_effort() {
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) effort_now[i] = ld_agent_f64(effort_ptr + int64_t(i / 2) * effort_pair + (i & 1));
+    effort_prefetched = true;
+  }
   __device__ __forceinline__ V3 force() const { return V3{ld_agent_f64(force_ptr), ld_agent_f64(force_ptr + 1), ld_agent_f64(force_ptr + force_pair)}; }
   __device__ __forceinline__ void effort(double (&e)[NJ]) const {
+    if (effort_prefetched) {
+#pragma unroll
+      for (int i = 0; i < NJ; ++i) e[i] = effort_now[i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NJ; ++i) e[i] = ld_agent_f64(effort_ptr + int64_t(i / 2) * effort_pair + (i & 1));
   }
@@ -1028,7 +1043,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         };
         cycle_front<L, NJ, F, false, LegInRing<NJ>, false, !POSE_SPLIT>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
-                                                                        LegInRing<NJ>{nullptr, nullptr, 0, 0}, fb, nullptr, pose_wait);
+                                                                        LegInRing<NJ>{nullptr, nullptr, 0, 0, false, {}}, fb, nullptr, pose_wait);
         if (POSE_SPLIT) publish_for_pose(c_front + 1, fb.plane_prev_changed);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
@@ -1057,7 +1072,8 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       SHC_TICK(25);
       if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
         resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
-        const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, wave * RPW + grp, leg);
+        LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, wave * RPW + grp, leg);
+        if (FT::tipf(P)) in.prefetch_effort();
         const double *mb = &X.mailbox[pair][c_back & 1][0][lane];
         out.poser_tip = V3{mb[0], mb[64], mb[128]};
         if (FT::odom(P)) {
