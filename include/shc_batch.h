@@ -169,7 +169,7 @@ enum {
  * Library/device introspection.  shc_device_count() returns the number of visible HIP devices
  * (0 when none; never an error) so a caller can fail loudly before creating an engine.
  */
-int shc_abi_version(void);
+int shc_abi_version(void); /* 4: shc_cycle_inputs.direct + shc_engine_resident_bind_inputs (launch-free posts); 3: resident mode, join, auxiliary state */
 /* sizeof(shc_params) / sizeof(shc_tables) as compiled into the library: lets a foreign-language binding check its layout */
 int64_t shc_sizeof_params(void);
 int64_t shc_sizeof_tables(void);
@@ -284,7 +284,8 @@ int shc_engine_join(shc_engine *e);
  *       consumes them = cycles whose outputs stay readable; max_cycles (1..2^31-2): hard bound of this launch; idle_timeout_ms
  *       (0 = 5 000): the device loop stops by itself when everything released has run and the doorbell has not moved for this long
  *       (a host that went away cannot leave the GPU spinning; every device-side wait is bounded).  SHC_ERR_UNSUPPORTED: the batch does not fit the chip once, or
- *       the configuration runs on a rough-terrain / manual-leg / tip-rotation kernel.  Until shc_engine_resident_end every other
+ *       the configuration runs on a tip-align-pose / manual-leg kernel (rough terrain mode and tip rotations have a resident form: one
+ *       wavefront per robot group, up to ~990 wavefronts).  Until shc_engine_resident_end every other
  *       entry point that touches the engine's state returns SHC_ERR_BUSY.
  *   shc_engine_resident_post(e, inputs, cycle)
  *       the inputs "the callbacks delivered" for the next unposted cycle (*cycle receives its index, counted from 0 at begin):

@@ -5,7 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${PROF_DIR:-prof}; rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps ${PROF_STEPS:-400} --warmup 40 --no-cpu-baseline --no-fused-probe --no-also $*"
+BENCH="python $R/bench.py --steps ${PROF_STEPS:-400} --warmup 40 --no-cpu-baseline --no-fused-probe --no-also --no-parity $*"   # (--no-parity: the parity block reads the output ring while the loop is alive - a kernel launch the PMC passes, which serialise dispatches, would hold back until the loop has idled out)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- $BENCH > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $BENCH > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $BENCH > $O/pmc_write.log 2>&1
