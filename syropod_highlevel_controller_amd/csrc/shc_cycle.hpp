@@ -1570,7 +1570,7 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
     if (FT::adm(P) || rot_on) s.tipx = base_rotate(lc, chain.xe);
     V3 e = out.model_tip - desired;
     if (fabs(e.x) > kIkTolerance || fabs(e.y) > kIkTolerance || fabs(e.z) > kIkTolerance) s.word |= LW_IKFAIL; // :916-929
-    if (FT::tipf(P)) { // Leg::calculateTipForce (:667-708)
+    if (FT::tipf(P) && !(SHC_DBG(P) & 8192)) { // Leg::calculateTipForce (:667-708)
       double effort[NJ];
       in.effort(effort); // Joint::current_effort_ input
       V3 raw = tip_force_cols<NJ>(lc, chain, lin, effort);

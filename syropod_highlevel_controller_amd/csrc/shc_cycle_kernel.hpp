@@ -1064,6 +1064,9 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         const V3 plane_prev{mb[7 * 64], mb[8 * 64], mb[9 * 64]}, pnorm_prev{mb[10 * 64], mb[11 * 64], mb[12 * 64]};
         int rword_unused = 0;
         Pose ap = pose_identity(), la = pose_identity();
+#ifdef SHC_ABLATE
+        if (!(P.debug_skip & 2048))
+#endif
         (void)cycle_pose<L, NJ, F>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -1097,6 +1100,9 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #pragma unroll
           for (int i = 0; i < NJ; ++i) flat[FD::Q + i] = s.q[i], flat[FD::QD + i] = s.qd[i];
           const unsigned soff = oslot * out_slot_bytes;
+#ifdef SHC_ABLATE
+          if (!(P.debug_skip & 4096))
+#endif
           if (live) {
 #pragma unroll
             for (int p = 0; p < NJ; ++p) {
