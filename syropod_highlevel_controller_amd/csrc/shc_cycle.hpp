@@ -411,6 +411,18 @@ struct NoHook {
   __device__ __forceinline__ void operator()() const {}
 };
 
+// Launch-uniform switches of the parameter block as scalars.  Read from the LDS copy one by one where they are used, each costs a wavefront
+// that runs alone on its SIMD an LDS round trip before it can branch; read together once (per cycle() call, or once per launch by the resident
+// loop, which keeps its FrontToBack across cycles) they cost one.
+// (Only the model half's: on the walker half the same grouping cost more - scalar registers are the scarce resource there - than it saved.)
+struct UniFlags {
+  int clamp_joint_velocities, clamp_joint_positions, swing_c_count;
+};
+__device__ __forceinline__ UniFlags load_uni_flags(const CycleParams &P) {
+  const int c = P.clamp_joint_velocities, d = P.clamp_joint_positions, e = P.swing_c_count;
+  return UniFlags{uni(c), uni(d), uni(e)};
+}
+
 // ------------------------------------------------------------------------------------------------- one control cycle
 // What the walker / poser half of a cycle hands to the model half (PoseController::updateStance -> Model::updateModel); the
 // positions travel in LegOut (poser_tip, adm_delta).
@@ -426,19 +438,34 @@ struct FrontToBack {
   // before (applyFK(false)) - its position (joint-1 frame) and x axis (body frame), which the following applyIK starts from
   bool joint_moved;
   V3 held_pe, held_dir;
+  // in / out, kept by a caller that runs many cycles with one FrontToBack (the resident loop): the steppers' walk-plane copies of every
+  // robot of this wave equal the walker's plane, so the per-cycle comparison (12 LDS reads) is skipped until a default tip moves again
+  bool planes_in_sync = false;
+  UniFlags uf; // in: load_uni_flags(C.P)
 };
 
 // odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (walk_controller.cpp:643, :783-791).  Nothing in the
 // cycle reads it back: a pure accumulator over the desired body velocity.
+// (sin, cos) of the half yaw step of the last call: the desired angular velocity of a robot that walks steadily does not change from cycle to
+// cycle, so a caller that keeps this across cycles (the resident loop) re-evaluates the pair only when some robot of the wave turns differently
+struct OdomCache {
+  double ha = 0.0, sh = 0.0, ch = 1.0;
+  bool valid = false;
+};
 template <int RPW>
-__device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const CycleParams &P, double vx, double vy, double vw) {
+__device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const CycleParams &P, double vx, double vy, double vw, OdomCache *cache = nullptr) {
   using R = RobotFields;
   // Both poses are pure yaw (rotation (w, 0, 0, z), z translation 0), so Pose::addPose reduces to its w / z and x / y
   // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
   double sh, ch;
   const double ha = 0.5 * (vw * P.dt); // Quaterniond(AngleAxisd(w dt, z^)): half of one cycle's yaw, a few milliradians
-  if (__all(fabs(ha) <= 0.5)) sincos_joint<false>(ha, &sh, &ch);
-  else sincos_joint(ha, &sh, &ch);
+  if (cache != nullptr && cache->valid && __all(ha == cache->ha)) {
+    sh = cache->sh, ch = cache->ch; // (the same function of the same argument)
+  } else {
+    if (__all(fabs(ha) <= 0.5)) sincos_joint<false>(ha, &sh, &ch);
+    else sincos_joint(ha, &sh, &ch);
+    if (cache != nullptr) cache->ha = ha, cache->sh = sh, cache->ch = ch, cache->valid = true;
+  }
   const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 2), oz = rb.get(R::ODOM + 3);
   const double a = vx * P.dt, b = vy * P.dt;
   double ux = -(oz * b), uy = oz * a; // u x v
@@ -454,10 +481,16 @@ __device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const Cycl
 // composed into Model::current_pose_ (returned, and left in the robot tile's CPOSE; the walk-plane pose in WPP).  `lw`: the packed
 // words of the robot's legs as the previous cycle's updateWalk left them.  The kernels call it inside cycle_front; the two-wavefront
 // resident kernel runs it on the model wavefront for the specialisations without auto posing (POSE_HERE = false there).
-template <int L, int NJ, unsigned F>
+// OWN_WORD: `lw` is not filled in; the leg of the group that drives the walk-plane pose is found from each lane's own packed word
+// (`own_word`) with one ballot and one shuffle instead of L shuffles (specialisations without auto posing / tip-align pose only).
+template <int L, int NJ, unsigned F, bool OWN_WORD = false>
 __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L, NJ> &C, const CycleParams &P, const LegConst<NJ> &lc, const RobTile<64 / L> &rb,
                                            const Group<L> g, const int (&lw)[L], int &rword, const int walk_state, unsigned &dirty, const bool manual_live,
-                                           Pose &auto_pose, Pose &leg_auto, const V3 plane_prev, const V3 pnorm_prev) {
+                                           Pose &auto_pose, Pose &leg_auto, const V3 plane_prev, const V3 pnorm_prev, const int swing_c_count_u,
+                                           const int own_word = 0, Pose *owpp_cache = nullptr) {
+  // swing_c_count_u: UniFlags::swing_c_count; owpp_cache: the origin walk-plane pose (RobotFields::OWPP) kept in registers by a caller that runs
+  // many cycles (it changes at the end of a swing over uneven ground only; the tile copy is kept current)
+  static_assert(!OWN_WORD || ((F & (F_DYN | F_AUTO | F_TALIGN)) == 0), "the other legs' words are needed by auto posing and the tip-align pose");
   // (plane_prev / pnorm_prev: the steppers' copy of the walk plane, RobotFields::PLANE_PREV / PNORM_PREV, as the previous updateWalk left it)
   using R = RobotFields;
   using FT = Feat<F>;
@@ -470,9 +503,18 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
       // control input of the last leg (in id order) whose scaled swing progress lies in [0, 1]
       double c = 0.0;
       bool sel = false;
-      if (uni(P.swing_c_count) > 0) {
+      if (swing_c_count_u > 0) {
         // the legs' words are already in every lane: pick the leg with integer tests, then one table read
         int it_sel = 0;
+        if constexpr (OWN_WORD) { // this lane's leg alone; the LAST leg (in id order) of the group that qualifies is the one the loop below would end on
+          const int it_own = min(max(((own_word >> LW_PHASE_SHIFT) & LW_PHASE_MASK) - P.swing_start, 0), P.swing_c_count - 1);
+          const bool ok_own = ((own_word >> LW_PM_SHIFT) & 3) == PM_SWING && it_own < P.swing_c_valid;
+          const unsigned legs_ok = unsigned((__ballot(ok_own) >> g.base) & ((1ull << L) - 1));
+          sel = legs_ok != 0;
+          const int last = sel ? 31 - __clz(int(legs_ok)) : 0;
+          it_sel = g.get(it_own, last);
+          it_sel = sel ? it_sel : 0;
+        } else {
 #pragma unroll
         for (int j = 0; j < L; ++j) {
           // clamping the iteration is the clamp of the progress to [0, 1] (walk_controller.cpp:880)
@@ -481,11 +523,12 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
           it_sel = ok ? it : it_sel;
           sel = sel || ok;
         }
+        }
         if (__any(sel)) c = sel ? C.swing_c[it_sel] : 0.0;
       } else { // each lane evaluates its own leg once (one division + smoothStep), the group picks the last valid one
         double c_own = -1.0;
         {
-          double sp = swing_progress_of(s.word, P) * P.swing_progress_scaler;
+          double sp = swing_progress_of(OWN_WORD ? own_word : s.word, P) * P.swing_progress_scaler; // (OWN_WORD: the model wavefront of the resident pipeline holds no leg words of its own)
           if (sp >= 0 && sp <= 1.0) c_own = smooth_step(sp);
         }
 #pragma unroll
@@ -499,7 +542,7 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
       }
       V3 wplane = sel ? plane_prev : V3{0, 0, 0};
       V3 wnorm = sel ? pnorm_prev : UZ;
-      Pose owpp = rb.getpose(R::OWPP);
+      Pose owpp = owpp_cache != nullptr ? *owpp_cache : rb.getpose(R::OWPP);
       // Flat ground (the walk-plane normal is exactly +z and the body is not tilted): FromTwoVectors(z, z) is exactly the
       // identity and slerp(identity, c, identity) takes Eigen's linear branch, so the result below is bit-identical to the
       // general path at a fraction of its cost.  The general path only runs after a default tip moved off the plane.
@@ -522,6 +565,7 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
                           wpp.r.y == owpp.r.y && wpp.r.z == owpp.r.z;
         if (__any(!same)) {
           rb.putpose(R::OWPP, wpp);
+          if (owpp_cache != nullptr) *owpp_cache = wpp;
           dirty |= DIRTY_WALK_PLANE;
         }
       }
@@ -831,9 +875,10 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // ---- per-leg predicates the walk FSM needs from the previous cycle's stepper state (walk_controller.cpp:607-611).  Their only
   //      readers are the STOPPING branches (walk FSM :599-619, updateAutoPose :1147-1150), and a robot is STOPPING in this cycle
   //      only if it already was or if it is MOVING without a command (:533-536): skipped while no robot of the wave can be.
+  const double vin_x = rb.get(R::VIN), vin_y = rb.get(R::VIN + 1), win = rb.get(R::WIN); // the velocity command of this cycle (read once)
   bool may_stop = walk_state == WS_STOPPING;
   if (walk_state == WS_MOVING) { // (a conservative test of "no command": anything that could round to a zero norm counts)
-    const double ax = fabs(rb.get(R::VIN)), ay = fabs(rb.get(R::VIN + 1)), aw = rb.get(R::WIN);
+    const double ax = fabs(vin_x), ay = fabs(vin_y), aw = win;
     may_stop = !(aw != 0.0 || ax > 1e-100 || ay > 1e-100);
   }
   s.word &= ~(LW_ZBV | LW_ATT);
@@ -848,9 +893,17 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     if (dot(err, err) < kTipTolerance * kTipTolerance) w |= LW_ATT;
     s.word = w;
   }
+  // The packed words of the robot's legs in every lane (L shuffles): read by the pose (here), the dynamic stiffness and the general walk state
+  // machine.  Where none of them needs it early the steady state (every robot of the wave MOVING) does without: see the state machine below.
   int lw[L];
+  const bool lw_early = POSE_HERE || uni(FT::adm(P) ? 1 : 0) != 0;
+  if (lw_early) {
 #pragma unroll
-  for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
+    for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
+  } else {
+#pragma unroll
+    for (int j = 0; j < L; ++j) lw[j] = 0;
+  }
 
   SHC_PHASE_FENCE();
   SHC_TICK(3);
@@ -869,7 +922,8 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   Pose auto_pose = pose_identity();
   Pose leg_auto = pose_identity();
   if (POSE_HERE && !(SHC_DBG(P) & 1)) {
-    cp = cycle_pose<L, NJ, F>(s, C, P, lc, rb, g, lw, rword, walk_state, dirty, manual_live, auto_pose, leg_auto, rb.get3(R::PLANE_PREV), rb.get3(R::PNORM_PREV));
+    cp = cycle_pose<L, NJ, F>(s, C, P, lc, rb, g, lw, rword, walk_state, dirty, manual_live, auto_pose, leg_auto, rb.get3(R::PLANE_PREV), rb.get3(R::PNORM_PREV),
+                              fb.uf.swing_c_count);
   } else if (POSE_HERE) {
     cp = rb.getpose(R::CPOSE);
   }
@@ -909,7 +963,6 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
 
   SHC_PHASE_FENCE();
   // =============================================================== WalkController::updateWalk (:440-648)
-  const double vin_x = rb.get(R::VIN), vin_y = rb.get(R::VIN + 1), win = rb.get(R::WIN);
   // ---- getLimit x 4 (:414-436): bracket index per leg, min over the robot's legs
   double lim[4] = {0.05, 0.3, 0.02, 0.1};
   if (!(SHC_DBG(P) & 2)) {
@@ -931,11 +984,12 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // correctly rounded square root being monotone with sqrt(1) = 1) a stand-in with the same two answers saves the FP64 square root.
   const double lin_n2 = vin_x * vin_x + vin_y * vin_y;
   double lin_norm;
-  if (uni(P.velocity_input_mode) == 0 && __all(lin_n2 <= 1.0)) lin_norm = lin_n2 != 0.0 ? 0.5 : 0.0;
+  const int velocity_input_mode = uni(P.velocity_input_mode);
+  if (velocity_input_mode == 0 && __all(lin_n2 <= 1.0)) lin_norm = lin_n2 != 0.0 ? 0.5 : 0.0;
   else lin_norm = sqrt(lin_n2);
   if (!(SHC_DBG(P) & 32)) {
     double nvx, nvy, nw;
-    if (uni(P.velocity_input_mode) == 0) { // throttle (:451-466)
+    if (velocity_input_mode == 0) { // throttle (:451-466)
       double k = 1.0; // clamped to the unit disc
       if (__any(lin_norm > 1.0)) k = lin_norm > 1.0 ? 1.0 / lin_norm : 1.0;
       const double cx = lin_norm > 1.0 ? vin_x * k : vin_x, cy = lin_norm > 1.0 ? vin_y * k : vin_y;
@@ -1011,9 +1065,13 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     if (__all(walk_state == WS_MOVING)) {
       // every robot of the wave is MOVING: the loop below reduces to "at_correct_phase = false" (:594-597)
       my_acp = false;
+      // any leg of this robot not in FORCE_STOP: one ballot over the wave, this group's bits
+      any_stepping = ((__ballot((s.word & 3) != SS_FORCE_STOP) >> g.base) & ((1ull << L) - 1)) != 0;
+    } else {
+    if (!lw_early) { // (wave-uniform: the shuffles run with every lane active)
 #pragma unroll
-      for (int j = 0; j < L; ++j) any_stepping = any_stepping || ((lw[j] & 3) != SS_FORCE_STOP);
-    } else
+      for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
+    }
 #pragma unroll
     for (int j = 0; j < L; ++j) {
       int wj = lw[j];
@@ -1060,6 +1118,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
         my_cfs = cfs;
         my_update_default = upd;
       }
+    }
     }
   }
   rword = (rword & ~(3 | (15 << RW_LACP_SHIFT) | (15 << RW_LCFS_SHIFT) | RW_RTDA)) | walk_state | (lacp << RW_LACP_SHIFT) |
@@ -1117,7 +1176,8 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
 #ifdef SHC_NO_STRAIGHT // (development: the branching form everywhere)
     const bool straight = false;
 #else
-    const bool straight = (F & F_ROUGH) == 0 && !(SHC_DBG(P) & 4) && uni(P.force_normal_touchdown) == 0;
+    const int force_normal_touchdown = uni(P.force_normal_touchdown);
+    const bool straight = (F & F_ROUGH) == 0 && !(SHC_DBG(P) & 4) && force_normal_touchdown == 0;
 #endif
     if (straight) {
       const V3 sorg_p = pk.get3(PK_SORG), svel_p = pk.get3(PK_SVEL), torg_p = pk.get3(PK_TORG);
@@ -1252,7 +1312,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
         if (rough && ground_contact && !first_half) { // ground contact in the second half: stance-like nodes from the current tip (:1286-1290)
           n2_0 = s.tip, n2_1 = s.tip + sep2, n2_2 = s.tip + scaled(sep2, 2.0), n2_3 = s.tip + scaled(sep2, 3.0), n2_4 = s.tip + scaled(sep2, 4.0);
         }
-        if (uni(P.force_normal_touchdown) && !(rough && ground_contact)) { // forceNormalTouchdown (:1314-1329), unless in ground contact (:1114)
+        if (force_normal_touchdown && !(rough && ground_contact)) { // forceNormalTouchdown (:1314-1329), unless in ground contact (:1114)
           V3 bo = s.targ - scaled(sep2, 4.0);
           bo.z = fmax(sorg.z, s.targ.z);
           bo = bo + clearance;
@@ -1355,17 +1415,21 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     else if (my_state == SS_FORCE_STOP) my_pm = PM_STOP;
     // ---- updateWalkPlane (:748-779): least-squares plane through the default tip positions.  The fit only changes
     //      when a default tip changed, which is a rare event -> recompute under a wave-uniform guard (bit-identical).
-    if (any_stepping) { // the stepping legs' saved copies (LegStepper::walk_plane_) now hold the pre-update walker plane
+    if (!fb.planes_in_sync) { // (wave-uniform; a caller that keeps fb across cycles skips this while nothing has changed)
       const V3 pl = rb.get3(R::PLANE), pn_ = rb.get3(R::PNORM), plp = rb.get3(R::PLANE_PREV), pnp_ = rb.get3(R::PNORM_PREV);
       const bool same = pl.x == plp.x && pl.y == plp.y && pl.z == plp.z && pn_.x == pnp_.x && pn_.y == pnp_.y && pn_.z == pnp_.z;
-      if (__any(!same)) {
-        rb.put3(R::PLANE_PREV, pl);
-        rb.put3(R::PNORM_PREV, pn_);
-        dirty |= DIRTY_WALK_PLANE;
-        fb.plane_prev_changed = true;
+      if (any_stepping) { // the stepping legs' saved copies (LegStepper::walk_plane_) now hold the pre-update walker plane
+        if (__any(!same)) {
+          rb.put3(R::PLANE_PREV, pl);
+          rb.put3(R::PNORM_PREV, pn_);
+          dirty |= DIRTY_WALK_PLANE;
+          fb.plane_prev_changed = true;
+        }
       }
+      fb.planes_in_sync = __all(same || any_stepping); // robots that are not stepping keep their old copies: the comparison stays
     }
     if (__any(default_changed)) {
+      fb.planes_in_sync = false;
       dirty |= DIRTY_WALK_PLANE;
       const V3 nd = pk.get3(PK_DFLT);
       double x = nd.x, y = nd.y, z = nd.z;
@@ -1508,7 +1572,7 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
       // integrate it without the velocity clamp, FK, solve for the rotation delta between the tip direction the leg had
       // BEFORE this call (:866 is evaluated first) and the desired one; integrate, FK, check; on failure (5 mm deviation or
       // a joint on its limit: proximity 0) retry unconstrained from the state reached.
-      const bool cv = uni(P.clamp_joint_velocities) != 0, cp_ = uni(P.clamp_joint_positions) != 0;
+      const bool cv = fb.uf.clamp_joint_velocities != 0, cp_ = fb.uf.clamp_joint_positions != 0;
       chain_from_sincos<NJ>(lc, s.sn, s.cs, chain);
       V3 current_dir = chain.xe;
       double dq[NJ];
@@ -1551,7 +1615,7 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
         chain_from_sincos<NJ>(lc, s.sn, s.cs, chain); // joint transforms left by the previous applyFK (model.cpp:731,744)
         ik_step<NJ>(lc, chain, s.q, s.qd, desired, dq);
       }
-      update_joints<NJ>(lc, dq, P.dt, P.inv_dt, uni(P.clamp_joint_velocities) != 0, uni(P.clamp_joint_positions) != 0, s.q, s.qd);
+      update_joints<NJ>(lc, dq, P.dt, P.inv_dt, fb.uf.clamp_joint_velocities != 0, fb.uf.clamp_joint_positions != 0, s.q, s.qd);
     }
     SHC_PHASE_FENCE();
     SHC_TICK(10);
@@ -1588,6 +1652,8 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
                                       const bool manual_live, const bool touchdown_detection, double *ext, const ManualRobot *mr, const IN &in,
                                       const MID &mid = MID(), const double *span = nullptr, const bool pose_only = false) {
   FrontToBack fb;
+  fb.planes_in_sync = false;
+  fb.uf = load_uni_flags(C.P);
   fb.pose_only = pose_only;
   cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, legd, ns, slot, dirty, manual_live, touchdown_detection, ext, mr, in, fb, span);
   if ((F & F_MLEGS) != 0 && pose_only) return; // (RT_POSE_MARKED: updateWalk / updateStance / updateModel do not run for this robot in this loop)

@@ -980,6 +980,10 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   u64 gate_pref = leader ? ld_agent(&A.ctl->gate) : 0;
   u64 bubble_since = 0;
   FrontToBack fb{V3{1, 0, 0}, false, LS_WALKING};
+  fb.uf = load_uni_flags(C.P); // (once: the parameter block does not change while the loop runs)
+  OdomCache odom_cache;        // model wavefront: (sin, cos) of the half yaw step while the desired angular velocities stay as they are
+  Pose owpp_cache = pose_identity();
+  if (POSE_SPLIT && active && !walker) owpp_cache = rb.getpose(R::OWPP); // ... and the origin walk-plane pose (the walker wavefront filled the tile before the barrier)
 #ifdef SHC_RES2_TIMING
   long long tm_busy = 0, tm_total0 = __builtin_readcyclecounter(), tm_real = 0;
 #ifndef SHC_RES2_BUSY_ONLY
@@ -1054,12 +1058,10 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       SHC_TICK(23);
     } else if (active) {
       SHC_TICK(24);
-      if (POSE_SPLIT && kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
+      if constexpr (POSE_SPLIT) if (kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
         resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
         const int my_word = X.words[pair][c_front & 1][lane];
-        int lw[L];
-#pragma unroll
-        for (int j = 0; j < L; ++j) lw[j] = g.get(my_word, j);
+        int lw[L] = {}; // (not filled in: the pose finds its leg from each lane's own word, cycle_pose<..., OWN_WORD>)
         const double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         const V3 plane_prev{mb[7 * 64], mb[8 * 64], mb[9 * 64]}, pnorm_prev{mb[10 * 64], mb[11 * 64], mb[12 * 64]};
         int rword_unused = 0;
@@ -1067,7 +1069,8 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #ifdef SHC_ABLATE
         if (!(P.debug_skip & 2048))
 #endif
-        (void)cycle_pose<L, NJ, F>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev);
+        (void)cycle_pose<L, NJ, F, true>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev, fb.uf.swing_c_count, my_word,
+                                         &owpp_cache);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) *const_cast<volatile unsigned *>(&X.pose_done[pair]) = c_front + 1;
@@ -1082,7 +1085,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         if (FT::odom(P)) {
           const V3 ov{mb[192], mb[256], mb[320]};
           if (__any(mb[384] != 0.0)) { // (robots whose updateWalk returned early keep their odometry)
-            if (mb[384] != 0.0) odometry_step(rb, P, ov.x, ov.y, ov.z);
+            if (mb[384] != 0.0) odometry_step(rb, P, ov.x, ov.y, ov.z, &odom_cache);
           }
         }
         out.adm_delta = V3{0, 0, 0};
