@@ -615,8 +615,9 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                     "traffic": measured_traffic(name + ":resident", n, cps), "kernel": "shc_resident2_kernel (one launch, K = 4000 cycles; two wavefronts per robot group)",
                     "kernel_ms": res_cycle_s * 1e3, "kernel_ms_is": "per cycle: HIP events around one launch of K cycles / K",
                     "algorithmic_bytes_per_launch": rb, "algorithmic_bytes_are": "per cycle, SURVEY.md 8(d) with the state on the chip: velocity input + published q, qd",
-                    "bound_note": ("the resident cycle is bound by one wavefront's FP64 issue rate (walker and model wavefront of a robot group both ~6 300-6 600 busy "
-                                   "clocks of the ~6 800-clock cycle, profiles/r03_probe_resident_phase_clocks.txt), not by HBM: frac is small by construction"),
+                    "bound_note": ("the resident cycle is bound by one wavefront's dependent-issue latency, not by HBM (frac is small by construction): 701 VALU + 183 SALU + "
+                                   "62 LDS instructions per wave and cycle in a 6 772-clock wave lifetime, VALU issue share 0.42 (profiles/r04_config2_resident_rocprofv3.txt); "
+                                   "phase ablation in profiles/r04_probe_resident_ablation.txt"),
                     "state_streaming_equivalent_frac": ALG_BYTES_PER_CYCLE[key] * n / res_cycle_s / 1e9 / HBM_PEAK_GBS,
                     "one_launch_per_cycle": launch_roofline}
     else:
