@@ -442,6 +442,11 @@ struct FrontToBack {
   // robot of this wave equal the walker's plane, so the per-cycle comparison (12 LDS reads) is skipped until a default tip moves again
   bool planes_in_sync = false;
   UniFlags uf; // in: load_uni_flags(C.P)
+  // in / out, for a caller that keeps fb across cycles: the bearing bracket of this lane's leg in the previous cycle and the four limits
+  // WalkController::getLimit derived from the robot's legs then - they are a function of the legs' brackets alone, and a bracket changes
+  // when a stride vector crosses a 45-degree sector edge
+  int limit_bracket = -1;
+  double limit_value[4] = {0.0, 0.0, 0.0, 0.0};
 };
 
 // odometry_ideal_ = odometry_ideal_.addPose(calculateOdometry(time_delta_)) (walk_controller.cpp:643, :783-791).  Nothing in the
@@ -477,6 +482,40 @@ __device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const Cycl
   rb.put(R::ODOM + 3, ow * sh + oz * ch);
 }
 
+// The control input of PoseController::updateWalkPlanePose (:1100-1108) from each lane's OWN packed leg word: smoothStep of the scaled swing
+// progress of the last leg (in id order) of the robot whose scaled progress lies in [0, 1]; -1 when no leg qualifies.  One ballot and one
+// shuffle (table path).  The resident pipeline evaluates it on the walker wavefront, which holds the words, for the pose of the next cycle.
+template <int L, int NJ>
+__device__ __forceinline__ double walk_plane_control_input(const int own_word, const SharedConsts<L, NJ> &C, const CycleParams &P, const Group<L> g,
+                                                           const int swing_c_count_u) {
+  double c = 0.0;
+  bool sel = false;
+  if (swing_c_count_u > 0) {
+    // clamping the iteration is the clamp of the progress to [0, 1] (walk_controller.cpp:880)
+    const int it_own = min(max(((own_word >> LW_PHASE_SHIFT) & LW_PHASE_MASK) - P.swing_start, 0), P.swing_c_count - 1);
+    const bool ok_own = ((own_word >> LW_PM_SHIFT) & 3) == PM_SWING && it_own < P.swing_c_valid;
+    const unsigned legs_ok = unsigned((__ballot(ok_own) >> g.base) & ((1ull << L) - 1));
+    sel = legs_ok != 0;
+    const int last = sel ? 31 - __clz(int(legs_ok)) : 0; // the LAST qualifying leg is the one the reference's loop over the legs ends on
+    int it_sel = g.get(it_own, last);
+    it_sel = sel ? it_sel : 0;
+    if (__any(sel)) c = sel ? C.swing_c[it_sel] : 0.0;
+  } else { // swing period too long for the table: each lane evaluates its own leg (one division + smoothStep), the group picks the last valid one
+    double c_own = -1.0;
+    const double sp = swing_progress_of(own_word, P) * P.swing_progress_scaler;
+    if (sp >= 0 && sp <= 1.0) c_own = smooth_step(sp);
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const double cj = g.get(c_own, j);
+      if (cj >= 0.0) {
+        c = cj;
+        sel = true;
+      }
+    }
+  }
+  return sel ? c : -1.0;
+}
+
 // PoseController::updateCurrentPose (pose_controller.cpp:811-859): walk-plane pose, manual / inclination / IMU / auto / tip-align pose
 // composed into Model::current_pose_ (returned, and left in the robot tile's CPOSE; the walk-plane pose in WPP).  `lw`: the packed
 // words of the robot's legs as the previous cycle's updateWalk left them.  The kernels call it inside cycle_front; the two-wavefront
@@ -487,7 +526,7 @@ template <int L, int NJ, unsigned F, bool OWN_WORD = false>
 __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L, NJ> &C, const CycleParams &P, const LegConst<NJ> &lc, const RobTile<64 / L> &rb,
                                            const Group<L> g, const int (&lw)[L], int &rword, const int walk_state, unsigned &dirty, const bool manual_live,
                                            Pose &auto_pose, Pose &leg_auto, const V3 plane_prev, const V3 pnorm_prev, const int swing_c_count_u,
-                                           const int own_word = 0, Pose *owpp_cache = nullptr) {
+                                           const int own_word = 0, Pose *owpp_cache = nullptr, const double *c_given = nullptr) {
   // swing_c_count_u: UniFlags::swing_c_count; owpp_cache: the origin walk-plane pose (RobotFields::OWPP) kept in registers by a caller that runs
   // many cycles (it changes at the end of a swing over uneven ground only; the tile copy is kept current)
   static_assert(!OWN_WORD || ((F & (F_DYN | F_AUTO | F_TALIGN)) == 0), "the other legs' words are needed by auto posing and the tip-align pose");
@@ -503,18 +542,13 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
       // control input of the last leg (in id order) whose scaled swing progress lies in [0, 1]
       double c = 0.0;
       bool sel = false;
-      if (swing_c_count_u > 0) {
+      if constexpr (OWN_WORD) { // from this lane's own word, or handed over ready-made (c_given: walk_plane_control_input's result)
+        const double ce = c_given != nullptr ? *c_given : walk_plane_control_input<L, NJ>(own_word, C, P, g, swing_c_count_u);
+        sel = ce >= 0.0;
+        c = sel ? ce : 0.0;
+      } else if (swing_c_count_u > 0) {
         // the legs' words are already in every lane: pick the leg with integer tests, then one table read
         int it_sel = 0;
-        if constexpr (OWN_WORD) { // this lane's leg alone; the LAST leg (in id order) of the group that qualifies is the one the loop below would end on
-          const int it_own = min(max(((own_word >> LW_PHASE_SHIFT) & LW_PHASE_MASK) - P.swing_start, 0), P.swing_c_count - 1);
-          const bool ok_own = ((own_word >> LW_PM_SHIFT) & 3) == PM_SWING && it_own < P.swing_c_valid;
-          const unsigned legs_ok = unsigned((__ballot(ok_own) >> g.base) & ((1ull << L) - 1));
-          sel = legs_ok != 0;
-          const int last = sel ? 31 - __clz(int(legs_ok)) : 0;
-          it_sel = g.get(it_own, last);
-          it_sel = sel ? it_sel : 0;
-        } else {
 #pragma unroll
         for (int j = 0; j < L; ++j) {
           // clamping the iteration is the clamp of the progress to [0, 1] (walk_controller.cpp:880)
@@ -523,12 +557,11 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
           it_sel = ok ? it : it_sel;
           sel = sel || ok;
         }
-        }
         if (__any(sel)) c = sel ? C.swing_c[it_sel] : 0.0;
       } else { // each lane evaluates its own leg once (one division + smoothStep), the group picks the last valid one
         double c_own = -1.0;
         {
-          double sp = swing_progress_of(OWN_WORD ? own_word : s.word, P) * P.swing_progress_scaler; // (OWN_WORD: the model wavefront of the resident pipeline holds no leg words of its own)
+          double sp = swing_progress_of(s.word, P) * P.swing_progress_scaler;
           if (sp >= 0 && sp <= 1.0) c_own = smooth_step(sp);
         }
 #pragma unroll
@@ -968,13 +1001,21 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   if (!(SHC_DBG(P) & 2)) {
     double sx = vin_x + win * (-s.tip.y), sy = vin_y + win * s.tip.x;
     int idx = bearing_bracket(sy, sx);
+    if (__all(idx == fb.limit_bracket)) { // every leg of every robot of the wave in the bracket it was in: the same minima
 #pragma unroll
-    for (int k = 0; k < 4; ++k) lim[k] = kUnassigned;
+      for (int k = 0; k < 4; ++k) lim[k] = fb.limit_value[k];
+    } else {
 #pragma unroll
-    for (int j = 0; j < L; ++j) {
-      int ij = g.get(idx, j);
+      for (int k = 0; k < 4; ++k) lim[k] = kUnassigned;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) lim[k] = fmin(lim[k], C.limit[ij][k]);
+      for (int j = 0; j < L; ++j) {
+        int ij = g.get(idx, j);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lim[k] = fmin(lim[k], C.limit[ij][k]);
+      }
+      fb.limit_bracket = idx;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fb.limit_value[k] = lim[k];
     }
   }
   SHC_PHASE_FENCE();
@@ -1040,7 +1081,17 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   bool my_acp = (s.word & LW_ACP) != 0, my_cfs = (s.word & LW_CFS) != 0;
   bool my_update_default = false;
   bool any_stepping = false;
-  if (frozen) {
+  // The steady state first, with ONE wave-uniform test: every robot of the wave MOVING with a command.  The general machine below then leaves
+  // the walk state, the shared counters and the robot word as they are and only clears at_correct_phase (:594-597) - but reaches that through
+  // a chain of per-lane conditions that costs a lone wavefront ~700 clocks a cycle.
+  const bool steady = __all(!frozen && walk_state == WS_MOVING && has_cmd) && !(SHC_DBG(P) & 16384);
+  if (steady) {
+    my_acp = false;
+    any_stepping = ((__ballot((s.word & 3) != SS_FORCE_STOP) >> g.base) & ((1ull << L) - 1)) != 0;
+  } else if (SHC_DBG(P) & 16384) { // (development ablation: the state machine's work in the steady state - valid while every robot is MOVING)
+    my_acp = false;
+    any_stepping = true;
+  } else if (frozen) {
     early_return = true; // updateWalk returned at :503
   } else if (walk_state == WS_STOPPED && has_cmd) {
     walk_state = WS_STARTING;
@@ -1121,9 +1172,11 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     }
     }
   }
-  rword = (rword & ~(3 | (15 << RW_LACP_SHIFT) | (15 << RW_LCFS_SHIFT) | RW_RTDA)) | walk_state | (lacp << RW_LACP_SHIFT) |
-          (lcfs << RW_LCFS_SHIFT) | (rtda ? RW_RTDA : 0);
-  rb.puti(R::I_WORD, rword);
+  if (POSE_HERE || !steady) { // (steady: nothing of the robot word changed; with the pose on this wavefront auto posing may have changed its state bits)
+    rword = (rword & ~(3 | (15 << RW_LACP_SHIFT) | (15 << RW_LCFS_SHIFT) | RW_RTDA)) | walk_state | (lacp << RW_LACP_SHIFT) |
+            (lcfs << RW_LCFS_SHIFT) | (rtda ? RW_RTDA : 0);
+    rb.puti(R::I_WORD, rword);
+  }
   SHC_TICK(7);
   int my_pm = (s.word >> LW_PM_SHIFT) & 3;
   SHC_PHASE_FENCE();
@@ -1518,9 +1571,11 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // =============================================================== PoseController::updateStance (:110-141)
   V3 desired_dir{1, 0, 0}; // x axis of the desired tip rotation (body frame) when rot_def
   {
-    if (!POSE_HERE) {
+    if (!POSE_HERE && !(SHC_DBG(P) & 32768)) {
       pose_wait();
       cp = rb.getpose(R::CPOSE);
+    } else if (!POSE_HERE) {
+      cp = pose_identity();
     }
     Pose bp = cp;
     if (FT::autop(P) && !FT::imu(P)) {
@@ -1653,6 +1708,7 @@ __device__ __forceinline__ void cycle(LegRegs<NJ> &s, LegOut &out, const SharedC
                                       const MID &mid = MID(), const double *span = nullptr, const bool pose_only = false) {
   FrontToBack fb;
   fb.planes_in_sync = false;
+  fb.limit_bracket = -1;
   fb.uf = load_uni_flags(C.P);
   fb.pose_only = pose_only;
   cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, legd, ns, slot, dirty, manual_live, touchdown_detection, ext, mr, in, fb, span);

@@ -855,7 +855,7 @@ struct Resident2Lds { // dynamic LDS of one workgroup, after the two walker wave
   double mailbox[2][2][13][64]; // [pair][cycle parity][field][lane]: PoseController::updateStance -> Leg::setDesiredTipPose (xyz), then the
                                 // desired body velocity (x, y, yaw rate) + whether the walker reached its odometry update; 7..12: the steppers'
                                 // walk plane / normal for the NEXT cycle's updateWalkPlanePose (pose on the model wave)
-  int words[2][2][64];          // walker -> model: the packed leg words updateWalk left, for the next cycle's pose
+  double pose_c[2][2][64];      // walker -> model: the control input of the next cycle's walk-plane pose (walk_plane_control_input of the leg words updateWalk left)
   unsigned pose_done[2];        // model -> walker: poses completed (current_pose_ / walk-plane pose of that cycle are in the tile)
   unsigned model_dirty[2], model_seen[2], model_fault[2]; // model -> walker at exit: tile groups its pose dirtied, input groups it received, fault
   double stiff[2][64];         // walker -> model at exit (published virtual stiffness shares a plane with the admittance delta)
@@ -958,6 +958,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   ResidentHeld held;
   // what PoseController::updateCurrentPose of `cycle` reads of the walker's state: the leg words, and the steppers' walk-plane copy - which
   // changes on rare events only (a default tip moved), so both parities of its mailbox slots are rewritten then and left alone otherwise
+  const int swing_c_count_u = uni(P.swing_c_count);
   const auto publish_for_pose = [&](unsigned cycle, bool planes) {
     if (planes) {
       const V3 pp = rb.get3(R::PLANE_PREV), pn = rb.get3(R::PNORM_PREV);
@@ -967,7 +968,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         mb[7 * 64] = pp.x, mb[8 * 64] = pp.y, mb[9 * 64] = pp.z, mb[10 * 64] = pn.x, mb[11 * 64] = pn.y, mb[12 * 64] = pn.z;
       }
     }
-    X.words[pair][cycle & 1][lane] = s.word;
+    X.pose_c[pair][cycle & 1][lane] = walk_plane_control_input<L, NJ>(s.word, C, P, g, swing_c_count_u);
   };
   if (POSE_SPLIT && walker && active) publish_for_pose(0, true); // (iteration 0 is a bubble: its closing barrier comes before any pose)
   const int64_t ns = st.n_slots;
@@ -1048,6 +1049,9 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         };
         cycle_front<L, NJ, F, false, LegInRing<NJ>, false, !POSE_SPLIT>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
                                                                         LegInRing<NJ>{nullptr, nullptr, 0, 0, false, {}}, fb, nullptr, pose_wait);
+#ifdef SHC_ABLATE
+        if (!(P.debug_skip & 65536))
+#endif
         if (POSE_SPLIT) publish_for_pose(c_front + 1, fb.plane_prev_changed);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
@@ -1060,8 +1064,8 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       SHC_TICK(24);
       if constexpr (POSE_SPLIT) if (kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
         resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
-        const int my_word = X.words[pair][c_front & 1][lane];
-        int lw[L] = {}; // (not filled in: the pose finds its leg from each lane's own word, cycle_pose<..., OWN_WORD>)
+        const double pose_c = X.pose_c[pair][c_front & 1][lane];
+        int lw[L] = {}; // (not filled in: the walker wavefront has already reduced the leg words to the pose's control input)
         const double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         const V3 plane_prev{mb[7 * 64], mb[8 * 64], mb[9 * 64]}, pnorm_prev{mb[10 * 64], mb[11 * 64], mb[12 * 64]};
         int rword_unused = 0;
@@ -1069,8 +1073,8 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #ifdef SHC_ABLATE
         if (!(P.debug_skip & 2048))
 #endif
-        (void)cycle_pose<L, NJ, F, true>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev, fb.uf.swing_c_count, my_word,
-                                         &owpp_cache);
+        (void)cycle_pose<L, NJ, F, true>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev, fb.uf.swing_c_count, 0,
+                                         &owpp_cache, &pose_c);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) *const_cast<volatile unsigned *>(&X.pose_done[pair]) = c_front + 1;
