@@ -43,9 +43,7 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // "this group of state fields changed during the launch" bits, kept per lane and OR-reduced over the wave before the
 // write-back: groups nobody changed are not stored (walk plane / manual pose of the robot tile; the parked stepper
 // origins of the per-leg planes, which change once per step period).
-enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8,
-                  DIRTY_TARGET = 16, // the stepper's target tip / stride vector: constant while a robot walks with a constant desired velocity
-                  DIRTY_LAST = DIRTY_TARGET };
+enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
 enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8, RT_EFFORT_LIVE = 16, RT_SKIP_MARKED = 32, RT_POSE_MARKED = 64 }; // RT_POSE_MARKED: run only the posing part of the loop (updateCurrentPose, admittance), and only for the robots a loop-level kernel marked; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
@@ -1207,12 +1205,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     double stance_dt = standard ? P.stance_dt : lc.first_stance_dt; // 1 / stance_iterations (:1041)
     (void)stance_iter;
     const V3 dflt = pk.get3(PK_DFLT);
-    // (the planes of target tip and stride vector are written back only if some lane of the wave changed them: compared where they are assigned -
-    //  rough terrain mode moves the target again further down and compares a copy at the end instead)
-    const V3 targ_before = s.targ, strd_before = s.strd;
     s.targ = dflt + s.strd * 0.5; // uses last cycle's stride (:1044 precedes updateStride)
-    if constexpr ((F & F_ROUGH) == 0)
-      dirty |= (s.targ.x != targ_before.x || s.targ.y != targ_before.y || s.targ.z != targ_before.z) ? unsigned(DIRTY_TARGET) : 0u;
     bool stepping = my_state != SS_FORCE_STOP;
     const bool rough = (F & F_ROUGH) != 0 && uni(P.rough_terrain) != 0; // rough terrain mode runs on the F_ROUGH kernels
     bool rough_update_default = false;
@@ -1246,7 +1239,6 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       // updateStride (:921-945)
       const V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0};
       const V3 strd_new = scaled(sv, P.stride_scale);
-      dirty |= (stepping && (strd_new.x != s.strd.x || strd_new.y != s.strd.y || strd_new.z != s.strd.z)) ? unsigned(DIRTY_TARGET) : 0u;
       s.strd = sel3(stepping, strd_new, s.strd);
       V3 pn = rb.get3(R::PNORM);
       const bool flat_n = pn.x == 0.0 && pn.y == 0.0 && pn.z == 1.0;
@@ -1293,11 +1285,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     } else if (stepping && !(SHC_DBG(P) & 4)) {
       // updateStride (:921-945)
       V3 sv{vx - vw * s.tip.y, vy + vw * s.tip.x, 0.0}; // v + w z^ x (tip rejected from z^)
-      {
-        const V3 strd_new = scaled(sv, P.stride_scale);
-        if constexpr ((F & F_ROUGH) == 0) dirty |= (strd_new.x != s.strd.x || strd_new.y != s.strd.y || strd_new.z != s.strd.z) ? unsigned(DIRTY_TARGET) : 0u;
-        s.strd = strd_new;
-      }
+      s.strd = scaled(sv, P.stride_scale);
       V3 pn = rb.get3(R::PNORM);
       // normalized() of the exact unit vector (0,0,1) is itself: skip the sqrt + 3 divisions on flat ground (bit-identical)
       bool flat_n = pn.x == 0.0 && pn.y == 0.0 && pn.z == 1.0;
@@ -1434,11 +1422,6 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
           dirty |= DIRTY_STANCE_ORG;
         }
       }
-    }
-    if constexpr ((F & F_ROUGH) != 0) {
-      const bool moved = s.targ.x != targ_before.x || s.targ.y != targ_before.y || s.targ.z != targ_before.z || s.strd.x != strd_before.x ||
-                         s.strd.y != strd_before.y || s.strd.z != strd_before.z;
-      dirty |= moved ? unsigned(DIRTY_TARGET) : 0u;
     }
     // ---- updateTipRotation (:1193-1234).  Without gravity-aligned tips every tip rotation stays UNDEFINED.  With them the
     //      target is the constant identity rotation (x axis along -z); only the x axes of the rotations are ever used

@@ -132,15 +132,14 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   for (int k = 0; k < PK_COUNT; ++k) flat[FD::SORG + k] = ROLE == ROLE_BACK ? 0.0 : pk.d[k * 64 + pk.lane];
   flat[FD::TARG] = s.targ.x, flat[FD::TARG + 1] = s.targ.y, flat[FD::TARG + 2] = s.targ.z;
   flat[FD::STRD] = s.strd.x, flat[FD::STRD + 1] = s.strd.y, flat[FD::STRD + 2] = s.strd.z;
-  // swing origin position / velocity and stance origin / default tip change once per step period, target tip and stride vector only
-  // with the desired velocity: their planes are written back only when some lane of the wave changed them during this launch
+  // swing origin position / velocity and stance origin / default tip change once per step period: their planes are
+  // written back only when some lane of the wave changed them during this launch
   static_assert(FD::SORG % 2 == 0 && FD::TORG % 2 == 0 && FD::TARG % 2 == 0, "park groups must cover whole planes");
 #pragma unroll
   for (int p = 0; p < FD::CORE_END / 2; ++p) {
     const bool swing_org = 2 * p >= FD::SORG && 2 * p < FD::TORG, stance_org = 2 * p >= FD::TORG && 2 * p < FD::TARG;
     if (swing_org && !(dirty & DIRTY_SWING_ORG)) continue;
     if (stance_org && !(dirty & DIRTY_STANCE_ORG)) continue;
-    if (2 * p >= FD::TARG && !(dirty & DIRTY_TARGET)) continue; // target tip + stride vector (fields [TARG, CORE_END)): unchanged in steady walking
     if ((ROLE == ROLE_FRONT && p < NJ) || (ROLE == ROLE_BACK && p >= NJ)) continue;
     ld.store(p, double2{flat[2 * p], flat[2 * p + 1]});
   }
@@ -794,7 +793,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
-    for (unsigned b = 1; b <= DIRTY_LAST; b <<= 1)
+    for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
       if (__any((dirty & b) != 0)) d |= b;
     dirty = d;
   }
@@ -1176,7 +1175,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       if (POSE_SPLIT) { // what the pose on this wavefront dirtied / received is written back by the walker, which owns the tile stores
         unsigned d = 0;
 #pragma unroll
-        for (unsigned b = 1; b <= DIRTY_LAST; b <<= 1)
+        for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
           if (__any((dirty & b) != 0)) d |= b;
         if (lane == 0) X.model_dirty[pair] = d, X.model_seen[pair] = held.seen;
       }
@@ -1192,7 +1191,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
     {
       unsigned d = 0;
 #pragma unroll
-      for (unsigned b = 1; b <= DIRTY_LAST; b <<= 1)
+      for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
         if (__any((dirty & b) != 0)) d |= b;
       dirty = d;
     }
