@@ -606,7 +606,8 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     launch_roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": "shc_cycle_kernel" + (" (a step = two launches, the halves of the batch on two streams)" if n_waves >= 4096 else ""),
+                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": ("shc_cycle_half_kernel<walker half> + <model half> (a rotation-constrained cycle is two launches, two wavefronts per SIMD each)" if name == "gravity" and n_waves >= 2048 else "shc_cycle_kernel")
+                                 + (" (a step = that for each half of the batch, the halves on two streams)" if n_waves >= 4096 else ""),
                        "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes}
     if resident:
         rb = resident_bytes_per_cycle(p) * n
@@ -615,8 +616,8 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                     "traffic": measured_traffic(name + ":resident", n, cps), "kernel": "shc_resident2_kernel (one launch, K = 4000 cycles; two wavefronts per robot group)",
                     "kernel_ms": res_cycle_s * 1e3, "kernel_ms_is": "per cycle: HIP events around one launch of K cycles / K",
                     "algorithmic_bytes_per_launch": rb, "algorithmic_bytes_are": "per cycle, SURVEY.md 8(d) with the state on the chip: velocity input + published q, qd",
-                    "bound_note": ("the resident cycle is bound by one wavefront's dependent-issue latency, not by HBM (frac is small by construction): 701 VALU + 183 SALU + "
-                                   "62 LDS instructions per wave and cycle in a 6 772-clock wave lifetime, VALU issue share 0.42 (profiles/r04_config2_resident_rocprofv3.txt); "
+                    "bound_note": ("the resident cycle is bound by one wavefront's dependent-issue latency, not by HBM (frac is small by construction): 663 VALU + 176 SALU + "
+                                   "53 LDS instructions per wave and cycle in a 6 475-clock wave lifetime, VALU issue share 0.42 (profiles/r04_config2_resident_rocprofv3.txt); "
                                    "phase ablation in profiles/r04_probe_resident_ablation.txt"),
                     "state_streaming_equivalent_frac": ALG_BYTES_PER_CYCLE[key] * n / res_cycle_s / 1e9 / HBM_PEAK_GBS,
                     "one_launch_per_cycle": launch_roofline}

@@ -17,6 +17,6 @@ run c2_launch r04_config2_launch_rocprofv3.txt config2:4096:1 launch --workload 
 run c3 r04_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-joint-efforts
 run c4 r04_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
 run rough r04_rough_terrain_rocprofv3.txt rough:65536:1 split --workload rough --no-joint-efforts
-run gravity r04_gravity_aligned_rocprofv3.txt gravity:65536:1 split --workload gravity --no-joint-efforts
+run gravity r04_gravity_aligned_rocprofv3.txt gravity:65536:1 pairs --workload gravity --no-joint-efforts
 PROF_STEPS=100 run c5 r04_config5_rocprofv3.txt config5:1048576:1 fleet --workload config5
 ls -la $S

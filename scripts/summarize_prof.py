@@ -45,7 +45,9 @@ def kernel_stats(dirn, out):
             d = sorted(d)
             out.write(f"{k[:90]:90s} {len(d):6d} {st.mean(d):10.0f} {st.median(d):10.0f} {d[0]:9d} {d[int(.9 * (len(d) - 1))]:9d} {d[-1]:10d} | "
                       + " ".join(meta[k]) + "\n")
-            if KERNEL in k and (med is None or sum(d) > best_total):  # the specialisation that did the work (largest total time)
+            if PAIRS and KERNEL in k:  # the two launches of a cycle follow each other on one stream: their durations add up
+                med = (st.mean(d) + (med[0] if med else 0.0), st.median(d) + (med[1] if med else 0.0), len(d))
+            elif KERNEL in k and (med is None or sum(d) > best_total):  # the specialisation that did the work (largest total time)
                 best_total = sum(d)
                 med = (st.mean(d), st.median(d), len(d))
                 if RESIDENT_K:
@@ -54,6 +56,8 @@ def kernel_stats(dirn, out):
     return med
 
 
+PAIRS = False  # argv[4] == "pairs": a cycle = the walker-half launch + the model-half launch (shc_cycle_half_kernel<..., 1 / 2>), on each of the two
+               # halves of the batch: durations and counters are summed over the two kernels, a step is two such pairs
 FLEET = False  # argv[4] == "fleet": a step = one launch of EACH morphology bin's kernel on concurrent streams; counters are summed over the bins
 
 
@@ -83,7 +87,7 @@ def pmc_fleet(dirn, kernel, out, label):
 
 def pmc(dirn, kernel, out, label):
     """median per-dispatch value of every counter collected for `kernel` in the newest CSV under dirn"""
-    if FLEET and kernel == KERNEL:
+    if (FLEET or PAIRS) and kernel == KERNEL:
         return pmc_fleet(dirn, kernel, out, label)
     f = newest(f"{dirn}/**/*_counter_collection.csv")
     res = {}
@@ -114,7 +118,10 @@ if __name__ == "__main__":
         KERNEL = "shc_resident"
     # large batches: a step is TWO launches (the halves of the batch on two streams, shc_engine_step): per-step bytes = 2 x per launch
     FLEET = len(sys.argv) > 4 and sys.argv[4] == "fleet"   # (bins that share a device run as single launches: SHC_FEAT_SINGLE_STREAM, shc_fleet.hpp)
-    per_step = 2 if len(sys.argv) > 4 and sys.argv[4] == "split" else 1
+    PAIRS = len(sys.argv) > 4 and sys.argv[4] == "pairs"
+    if PAIRS:
+        KERNEL = "shc_cycle_half_kernel"
+    per_step = 2 if len(sys.argv) > 4 and sys.argv[4] in ("split", "pairs") else 1
     out = open(dest, "w")
     dur = kernel_stats(f"{prof}/trace", out)
     fetch = pmc(f"{prof}/pmc_fetch", KERNEL, out, "FETCH_SIZE pass").get("FETCH_SIZE")

@@ -194,6 +194,10 @@ struct DevState {
   double *ext; // ExtFields planes, nullptr until the first external request
   ManualRobot *manual; // nullptr until a leg is toggled
   const double *span;  // rough terrain mode with a stance span modifier: the legs' layered-workspace planes (SpanTable), else nullptr
+  // a step as TWO launches (gravity-aligned tips on legs with more than 3 joints, shc_cycle_half_kernel): what the walker / poser launch hands
+  // to the model launch of the same cycle - 3 double2 planes of n_slots: (poser tip x, y) (poser tip z, desired tip direction x) (y, z).
+  // Scratch, not state: written and consumed within one step.  nullptr: the engine never runs such a step.
+  double *half;
 };
 
 // LegStepper::calculateStanceSpanChange on the layered workspace of rough terrain mode (walk_controller.cpp:949-980): per leg the
@@ -1693,8 +1697,15 @@ __device__ __forceinline__ void cycle_back(LegRegs<NJ> &s, LegOut &out, const Sh
       double effort[NJ];
       in.effort(effort); // Joint::current_effort_ input
       V3 raw = tip_force_cols<NJ>(lc, chain, lin, effort);
-      s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
-      if (rot_on && retried) s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
+      if constexpr (rot_on) {
+        // (the rounding of the filter step is written out: this code is compiled into one-launch cycles and into the model half of
+        //  two-launch cycles, which must agree bit for bit, and the contraction the compiler picks for a * b + c * d depends on its surroundings)
+        const double gk = 0.15 * P.force_gain;
+        s.tf = V3{fma(raw.x, gk, s.tf.x * (1 - 0.15)), fma(raw.y, gk, s.tf.y * (1 - 0.15)), fma(raw.z, gk, s.tf.z * (1 - 0.15))};
+        if (retried) s.tf = V3{fma(raw.x, gk, s.tf.x * (1 - 0.15)), fma(raw.y, gk, s.tf.y * (1 - 0.15)), fma(raw.z, gk, s.tf.z * (1 - 0.15))};
+      } else {
+        s.tf = raw * (0.15 * P.force_gain) + s.tf * (1 - 0.15);
+      }
     }
   }
   SHC_TICK(12);

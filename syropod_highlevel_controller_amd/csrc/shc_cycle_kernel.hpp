@@ -69,7 +69,7 @@ __device__ __forceinline__ void load_leg_issue(LegLoad<NJ> &ll, const DevState &
   }
   ll.word = ROLE == ROLE_BACK ? 0 : st.legi[slot];
   ll.adm = ll.tf0 = ll.tf1 = ll.stiff = ll.rot0 = ll.rot1 = ll.rot2 = ll.rot3 = ll.rot4 = double2{0.0, 0.0};
-  if (rot_enabled<NJ, F>()) { // tip directions of the stepper's origin / current / target tip rotations
+  if (rot_enabled<NJ, F>() && ROLE != ROLE_BACK) { // tip directions of the stepper's origin / current / target tip rotations
     ll.rot0 = ld.load(FD::ORG_DIR / 2);
     ll.rot1 = ld.load(FD::ORG_DIR / 2 + 1);
     ll.rot2 = ld.load(FD::ORG_DIR / 2 + 2);
@@ -159,7 +159,7 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     ld.store(FD::POSER_TIP / 2, double2{out.poser_tip.x, out.poser_tip.y});
     ld.store(FD::POSER_TIP / 2 + 1, double2{out.poser_tip.z, 0.0});
   }
-  if (rot_enabled<NJ, F>()) {
+  if (rot_enabled<NJ, F>() && ROLE != ROLE_BACK) {
     static_assert(FD::ORG_DIR % 2 == 0 && FD::CUR_DIR == FD::ORG_DIR + 3 && FD::TARG_DIR == FD::ORG_DIR + 6, "tip direction planes");
     ld.store(FD::ORG_DIR / 2, double2{s.org_dir.x, s.org_dir.y});
     ld.store(FD::ORG_DIR / 2 + 1, double2{s.org_dir.z, s.cur_dir.x});
@@ -632,9 +632,14 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
 // The work of one wavefront: load its robots, run cycles, store them.  RES = false: n_cycles cycles with the inputs held (one
 // ordinary launch).  RES = true: the resident loop (resident_loop below) - cycles run as the doorbell allows, inputs from the
 // rings, outputs to the ring, until the relay says stop.
-template <int L, int NJ, unsigned F, bool RES>
+// HALF (launch mode only): ROLE_ALL = whole cycles.  ROLE_FRONT / ROLE_BACK = ONE cycle as two launches (shc_cycle_half_kernel): the walker /
+// poser half (cycle_front; owns the stepper planes, the leg word, the tip directions and the robot tile; reads the joint angles for the FK tip
+// rotation Leg::current_tip_pose_ holds) and the model half (cycle_back; owns the joint planes and the tip-force filter, ORs LW_IKFAIL into
+// the word), with PoseController::updateStance's result - poser tip, desired tip direction - in DevState::half between them.
+template <int L, int NJ, unsigned F, bool RES, int HALF = ROLE_ALL>
 __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConsts<L, NJ> *gc, int n_cycles, unsigned rt_flags, const int64_t wave,
                                            const ResidentArgs *ra) {
+  static_assert(HALF == ROLE_ALL || (!RES && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_ADM | F_AUTO)) == 0), "half-step launches: feature-exact kernels without admittance / auto posing / terrain paths");
   using R = RobotFields;
   using FT = Feat<F>;
   constexpr int RPW = 64 / L; // robots per wavefront
@@ -676,10 +681,22 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   double th[NJ]; // DH joint offsets of this lane's leg straight from the table in HBM: the FK of the stored joint state
                  // (sin / cos) then starts as soon as the joint planes arrive, under the latency of the remaining loads
   const bool any_robot = robots_here > 0;
+  double2 hand[3] = {double2{0.0, 0.0}, double2{0.0, 0.0}, double2{0.0, 0.0}}; // (HALF) DevState::half of this slot
+  double2 qpl[(NJ + 1) / 2];                                                      // (ROLE_FRONT) the joint-angle planes
+  int word_back = 0;
   if (any_robot) {
 #pragma unroll
     for (int k = 0; k < NJ; ++k) th[k] = gc->leg[leg].link_th[k];
-    load_leg_issue<NJ, F>(ll, st, GP, slot);
+    load_leg_issue<NJ, F, HALF>(ll, st, GP, slot);
+    if constexpr (HALF == ROLE_FRONT) {
+#pragma unroll
+      for (int p = 0; p < (NJ + 1) / 2; ++p) qpl[p] = reinterpret_cast<const double2 *>(st.legd)[p * st.n_slots + slot];
+    }
+    if constexpr (HALF == ROLE_BACK) {
+      word_back = st.legi[slot];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) hand[p] = reinterpret_cast<const double2 *>(st.half)[p * st.n_slots + slot];
+    }
   }
   using SC = SharedConsts<L, NJ>;
   static_assert(sizeof(SC) % 16 == 0 && (offsetof(SC, P) + offsetof(CycleParams, ap_start)) % 16 == 0, "const block is copied in 16-byte words");
@@ -711,7 +728,13 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   const bool pose_marked = (F & F_MLEGS) != 0 && (rt_flags & RT_POSE_MARKED) != 0 && (rt_flags & RT_MANUAL_LEGS) != 0;
   constexpr int int_iters = (R::I_COUNT * RPW + 63) / 64; // 3-legged robots: 21 per wave x 4 ints = 84 entries > one wave's width
   int32_t t_int[int_iters];
-  if (any_robot) {
+  if (any_robot && HALF == ROLE_BACK) { // the model half reads nothing of the robot tile
+#pragma unroll
+    for (int k = 0; k < NJ; ++k) sincos_joint(th[k] + ll.flat[Fields<NJ>::Q + k], &s.sn[k], &s.cs[k]);
+    load_leg_finish<NJ, HALF>(s, pk, ll);
+    s.word = word_back;
+  }
+  if (any_robot && HALF != ROLE_BACK) {
     load_rob_fields<RPW, 0, R::CORE_END>(t_core, gtile, lane);
     if (FT::manual(GP) && manual_live) load_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, gtile, lane);
     if (FT::imu(GP)) load_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, gtile, lane);
@@ -725,8 +748,12 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     for (int it = 0; it < int_iters; ++it) t_int[it] = it * 64 + lane < R::I_COUNT * RPW ? gtile_i[it * 64 + lane] : 0;
     // Leg::applyFK of the previous cycle: sin / cos of the stored joint angles
 #pragma unroll
-    for (int k = 0; k < NJ; ++k) sincos_joint(th[k] + ll.flat[Fields<NJ>::Q + k], &s.sn[k], &s.cs[k]);
-    load_leg_finish<NJ>(s, pk, ll);
+    for (int k = 0; k < NJ; ++k) {
+      double qk = ll.flat[Fields<NJ>::Q + k];
+      if constexpr (HALF == ROLE_FRONT) qk = (k & 1) ? qpl[k / 2].y : qpl[k / 2].x;
+      sincos_joint(th[k] + qk, &s.sn[k], &s.cs[k]);
+    }
+    load_leg_finish<NJ, HALF>(s, pk, ll);
   }
   {
     double2 *dst = reinterpret_cast<double2 *>(&C);
@@ -737,7 +764,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
       if (i < n16) dst[i] = creg[it];
     }
   }
-  if (any_robot) {
+  if (any_robot && HALF != ROLE_BACK) {
     put_rob_fields<RPW, 0, R::CORE_END>(t_core, tile, lane);
     if (FT::manual(GP) && manual_live) put_rob_fields<RPW, R::MPOSE, R::MANUAL_END>(t_man, tile, lane);
     if (FT::imu(GP)) put_rob_fields<RPW, R::ABSE, R::IMU_END>(t_imu, tile, lane);
@@ -780,6 +807,28 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   ResidentHeld held;
   if constexpr (RES) {
     resident_loop<L, NJ, F>(*ra, st, s, out, C, rb, pk, g, leg, slot, lane, wave, live, tile, tile_i, dirty, manual_live, held, touchdown_detection, ext);
+  } else if constexpr (HALF == ROLE_FRONT) {
+    FrontToBack fb;
+    fb.planes_in_sync = false;
+    fb.limit_bracket = -1;
+    fb.uf = load_uni_flags(C.P);
+    fb.pose_only = false;
+    cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
+                                LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
+    hand[0] = double2{out.poser_tip.x, out.poser_tip.y};
+    hand[1] = double2{out.poser_tip.z, fb.desired_dir.x};
+    hand[2] = double2{fb.desired_dir.y, fb.desired_dir.z};
+  } else if constexpr (HALF == ROLE_BACK) {
+    FrontToBack fb;
+    fb.uf = load_uni_flags(C.P);
+    fb.pose_only = false;
+    fb.joint_moved = false;
+    fb.my_leg_state = 0;
+    fb.rot_def = (s.word & LW_ROTDEF) != 0;
+    fb.desired_dir = V3{hand[1].y, hand[2].x, hand[2].y};
+    out.poser_tip = V3{hand[0].x, hand[0].y, hand[1].x};
+    out.adm_delta = V3{0.0, 0.0, 0.0};
+    cycle_back<L, NJ, F>(s, out, C, leg, st.legd, st.n_slots, slot, mr, LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
   } else if (!skip) {
     for (int c = 0; c < n_cycles; ++c)
       cycle<L, NJ, F>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
@@ -797,7 +846,17 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
       if (__any((dirty & b) != 0)) d |= b;
     dirty = d;
   }
-  if (live && !skip) store_leg<NJ, F>(s, out, pk, st, P, slot, dirty);
+  if (live && !skip) store_leg<NJ, F, HALF>(s, out, pk, st, P, slot, dirty);
+  if constexpr (HALF == ROLE_FRONT) {
+    if (live) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) LegPlanes{reinterpret_cast<double2 *>(st.half), st.n_slots, slot}.store(p, hand[p]);
+    }
+  }
+  if constexpr (HALF == ROLE_BACK) {
+    if (live) st.legi[slot] = s.word; // the walker half's word of this cycle | LW_IKFAIL
+    return;                           // (the robot tile is the walker half's)
+  }
   SHC_TICK(13);
   __builtin_amdgcn_wave_barrier(); // LDS ops of one wave complete in order: the tile now holds the leaders' updates
   // state planes back to this wave's HBM tile (the inputs VIN / WIN / GYRO / IMUQ are not written back)
@@ -820,6 +879,13 @@ template <int L, int NJ, unsigned F>
 __global__ void __launch_bounds__(256, (F & F_ROT) ? SHC_ROT_WAVES_PER_SIMD : ((F & F_DYN) && (F & F_TERRAIN)) ? SHC_TERRAIN_WAVES_PER_SIMD : SHC_WAVES_PER_SIMD) shc_cycle_kernel(DevState st, const SharedConsts<L, NJ> *gc, int n_cycles,
                                                                                              unsigned rt_flags, int64_t wave0) {
   cycle_wave<L, NJ, F, false>(st, gc, n_cycles, rt_flags, wave0 + ((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6), nullptr);
+}
+
+// One half of one cycle per launch (see cycle_wave's HALF): each half fits two wavefronts per SIMD where the whole rotation-constrained
+// cycle needs one (256 VGPRs + 76 - 92 AGPRs).
+template <int L, int NJ, unsigned F, int HALF>
+__global__ void __launch_bounds__(256, 2) shc_cycle_half_kernel(DevState st, const SharedConsts<L, NJ> *gc, unsigned rt_flags, int64_t wave0) {
+  cycle_wave<L, NJ, F, false, HALF>(st, gc, 1, rt_flags, wave0 + ((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6), nullptr);
 }
 
 // Resident launch: block 0 is the relay (host <-> device handshake), block 1 + w is worker wave w; 64 threads each, every block

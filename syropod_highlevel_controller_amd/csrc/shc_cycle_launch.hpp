@@ -87,6 +87,8 @@ struct CycleLaunch {
                                 // wavefront per robot group; block = 256: the two-wavefront pipeline, grid = ceil(n_waves / 2) + 1)
   struct ResidentFit *fit;      // != nullptr: launch nothing, report whether / how densely the resident kernel of this specialisation fits
   int64_t wave0;                // first wave of this launch (a step of a large batch is two launches on two streams)
+  int half_steps;               // gravity-aligned tips, legs of more than 3 joints: 0 = a cycle is two launches (walker half, model half) when
+                                // the launch has wavefronts for two per SIMD, 1 = always, -1 = never (SHC_ROT_SPLIT, read by the engine)
 };
 struct ResidentFit {
   int supported;          // this specialisation has a resident kernel

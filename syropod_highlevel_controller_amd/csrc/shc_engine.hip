@@ -268,6 +268,7 @@ struct shc_engine {
   bool planner_mode = false;            // StateController::planner_mode_ (state_controller.h:337)
   bool plan_poser_tips_current = false; // no control cycle has run since the last shc_engine_execute_plan (SeqRobotState::poser_tip_from_plan holds)
   double *d_span = nullptr;             // SpanTable (rough terrain mode with a stance span modifier), rebuilt with the tables
+  int half_steps = 0;                   // CycleLaunch::half_steps (development switch SHC_ROT_SPLIT = 0 / 1: never / always; unset: by launch size)
   bool span_dirty = true;
   struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
   const double *bound_inputs[kBoundSets][BND_COUNT] = {}; // shc_engine_resident_bind_inputs: the caller's device arrays for direct posts
@@ -879,6 +880,7 @@ static int engine_create(const shc_params *params, const shc_tables *tables, int
   e->stream = (hipStream_t)stream;
   e->n = n_instances;
   e->features = SHC_FEAT_TIP_FORCE | SHC_FEAT_ODOMETRY;
+  if (const char *v = getenv("SHC_ROT_SPLIT")) e->half_steps = atoi(v) > 0 ? 1 : -1;
   if (tables) {
     e->tables = *tables;
     e->span_dirty = true;
@@ -938,6 +940,7 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->st.robi);
   (void)hipFree(e->st.ext);
   (void)hipFree(e->st.manual);
+  (void)hipFree(e->st.half);
   (void)hipFree(e->d_seq);
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
@@ -1276,8 +1279,10 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
     if (rc != SHC_OK) return rc;
   }
   const int64_t half = split ? ((e->n_waves / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block : e->n_waves;
+  if (e->NJ > 3 && e->cp.gravity_aligned && !e->st.half && e->half_steps >= 0) // hand-over planes of two-launch cycles (DevState::half)
+    HIP_TRY(hipMalloc(&e->st.half, size_t(3) * e->n_slots * 16));
   CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream,
-                (unsigned)((half + waves_per_block - 1) / waves_per_block), block, n_cycles, nullptr, nullptr, 0};
+                (unsigned)((half + waves_per_block - 1) / waves_per_block), block, n_cycles, nullptr, nullptr, 0, e->half_steps};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
   if (!split) {
     SHC_DISPATCH(e->L, e->NJ, CALL);

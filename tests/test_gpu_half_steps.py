@@ -1,0 +1,101 @@
+"""GPU (-m gpu): a rotation-constrained cycle as TWO launches (gravity_aligned_tips on legs with more than 3 joints).
+
+The whole cycle of the 8 x 5 feature-exact kernels needs 256 VGPRs + 76 - 92 AGPRs = one wavefront per SIMD; the walker / poser half
+(WalkController::updateWalk + PoseController::updateStance) and the model half (Model::updateModel: Leg::applyIK with the rotation solve,
+model.cpp:861-941) each fit two.  From 2 048 wavefronts per launch on, `shc_engine_step` therefore runs each cycle as
+shc_cycle_half_kernel<ROLE_FRONT> + <ROLE_BACK> with the poser tip and the desired tip direction handed over through scratch planes.
+SHC_ROT_SPLIT (read at shc_engine_create) forces it on (1) or off (0) at any size - that is how the small cases here reach it.
+
+Bar: the two-launch form is byte-identical to the one-launch form (joints and the complete state record), and holds the oracle bar."""
+import numpy as np
+import pytest
+
+from syropod_highlevel_controller_amd import synthetic_octopod_params
+from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_ODOMETRY
+from test_gpu_parity import Engine, make_inputs  # noqa: F401  (Engine: module fixture)
+import test_gpu_parity
+import test_gpu_teacher_forced
+
+pytestmark = pytest.mark.gpu
+
+
+def octopods():
+    p = synthetic_octopod_params("ripple", 5, 8)
+    p.gravity_aligned_tips = 1
+    return p
+
+
+def drive(eng, inp, efforts):
+    """A walk with a direction change, a stop and a restart; returns the joints after every segment and the final state records."""
+    out = []
+    n = len(inp["ang"])
+    eng.set_velocity(inp["lin"], inp["ang"])
+    if efforts:
+        eng.set_joint_effort(inp["effort"])
+    for k in (1, 1, 37, 16, 150):
+        eng.step(k)
+        eng.synchronize()
+        out.append(eng.joints())
+    eng.set_velocity(-inp["lin"], 0.5 * inp["ang"])
+    for k in (1, 90):
+        eng.step(k)
+        eng.synchronize()
+        out.append(eng.joints())
+    eng.set_velocity(np.zeros((n, 2)), np.zeros(n))
+    eng.step(260)
+    eng.set_velocity(inp["lin"], inp["ang"])
+    eng.step(120)
+    eng.synchronize()
+    out.append(eng.joints())
+    return out, eng.get_state()
+
+
+@pytest.mark.parametrize("efforts", [False, True], ids=["no-joint-efforts", "tip-force-estimate"])
+def test_two_launch_cycles_are_byte_identical_to_one_launch(Engine, monkeypatch, efforts):
+    p = octopods()
+    n = 333   # 8 robots per wavefront: the last wavefront is ragged
+    inp = make_inputs(p, n, 77, zero_every=9)
+    runs = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SHC_ROT_SPLIT", mode)
+        eng = Engine(p, n)
+        eng.set_features(FEAT_DEFAULT if efforts else FEAT_ODOMETRY)
+        runs.append(drive(eng, inp, efforts))
+        eng.close()
+    (ja, sa), (jb, sb) = runs
+    for (qa, qda), (qb, qdb) in zip(ja, jb):
+        assert np.isfinite(qa).all() and np.array_equal(qa, qb) and np.array_equal(qda, qdb)
+    assert bytes(memoryview(sa).cast("B")) == bytes(memoryview(sb).cast("B"))
+
+
+def test_two_launch_cycles_chosen_by_size(Engine, monkeypatch):
+    """16 384 octopods = 2 048 wavefronts: the engine picks the two-launch form on its own; 65 536 run it on both halves of a split step."""
+    p = octopods()
+    for n, cycles in ((16384, (1, 16, 40)), (65536, (1, 16, 30))):
+        inp = make_inputs(p, n, 78, zero_every=11)
+        res = []
+        for mode in (None, "0"):
+            if mode is None:
+                monkeypatch.delenv("SHC_ROT_SPLIT", raising=False)
+            else:
+                monkeypatch.setenv("SHC_ROT_SPLIT", mode)
+            eng = Engine(p, n)
+            eng.set_features(FEAT_ODOMETRY)
+            eng.set_velocity(inp["lin"], inp["ang"])
+            for k in cycles:
+                eng.step(k)
+            eng.synchronize()
+            res.append(eng.joints())
+            eng.close()
+        assert np.isfinite(res[0][0]).all()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_two_launch_cycles_free_running_against_the_oracle(Engine, monkeypatch):
+    monkeypatch.setenv("SHC_ROT_SPLIT", "1")
+    test_gpu_parity.test_gravity_aligned_tips_rotation_constrained_ik(Engine, 5, 8, "ripple")
+
+
+def test_two_launch_cycles_teacher_forced_against_the_oracle(Engine, monkeypatch):
+    monkeypatch.setenv("SHC_ROT_SPLIT", "1")
+    test_gpu_teacher_forced.test_gravity_aligned_tips(Engine, 5, 8, "ripple")
