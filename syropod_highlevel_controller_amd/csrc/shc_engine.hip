@@ -1223,6 +1223,42 @@ extern "C" int shc_engine_set_pose_reset_mode(shc_engine *e, const int32_t *mode
 // The two streams the halves of split steps run on: ONE pair per device for the whole process, created back to back so that they
 // sit on two different hardware queues whatever the caller's own stream is (HIP maps streams to a few hardware queues in
 // creation order; two streams on one queue serialise, and a pair created per engine did land on the caller's queue now and then).
+// ... "created back to back" is not enough: the runtime hands a new stream the least-used hardware queue of its priority class, and in
+// a process that has created and destroyed other streams before (engines that came and went) both streams of the pair can be given the
+// same one - the halves then run one after the other and a split step costs what a single launch costs.  The pair is therefore TESTED once: a one-wave kernel on the first
+// stream waits (bounded) for a flag that a kernel launched afterwards on the second stream sets - it sees the flag only if the two run
+// concurrently, i.e. sit on different queues.  A second stream that fails is kept aside (so that the next one is given another queue)
+// and replaced, a few times at most.
+__device__ unsigned long long g_queue_probe[2]; // [0] the flag, [1] what the waiting kernel saw
+__global__ void queue_probe_reset_kernel() {
+  if (threadIdx.x == 0) g_queue_probe[0] = g_queue_probe[1] = 0;
+}
+__global__ void queue_probe_wait_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  unsigned long long seen = 0;
+  while ((seen = __hip_atomic_load(&g_queue_probe[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0 && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  if (threadIdx.x == 0) g_queue_probe[1] = seen;
+}
+__global__ void queue_probe_set_kernel() {
+  if (threadIdx.x == 0) __hip_atomic_store(&g_queue_probe[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (stream-ordered calls only: no allocation, no null-stream copy - another engine of this process may have a resident loop alive)
+static bool streams_run_concurrently(int device, hipStream_t a, hipStream_t b) {
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;
+  void *sym = nullptr;
+  if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_queue_probe)) != hipSuccess) return true; // (cannot tell: keep the pair)
+  unsigned long long h[2] = {0, 1};
+  queue_probe_reset_kernel<<<dim3(1), dim3(64), 0, a>>>();
+  if (hipStreamSynchronize(a) != hipSuccess) return true;
+  queue_probe_wait_kernel<<<dim3(1), dim3(64), 0, a>>>(2ull * (unsigned long long)khz); // 2 ms at most
+  queue_probe_set_kernel<<<dim3(1), dim3(64), 0, b>>>();
+  bool ok = true;
+  if (hipMemcpyAsync(h, sym, 16, hipMemcpyDeviceToHost, a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess) ok = h[1] != 0;
+  (void)hipStreamSynchronize(b);
+  (void)hipGetLastError();
+  return ok;
+}
 static int split_streams(int device, hipStream_t out[2]) {
   static hipStream_t pool[64][2] = {};
   static std::mutex pool_mutex; // engines of one process may be created and stepped from different host threads
@@ -1231,6 +1267,14 @@ static int split_streams(int device, hipStream_t out[2]) {
   if (!pool[device][0]) {
     HIP_TRY(hipStreamCreateWithFlags(&pool[device][0], hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&pool[device][1], hipStreamNonBlocking));
+    hipStream_t aside[6] = {};
+    int n_aside = 0;
+    while (n_aside < 6 && !streams_run_concurrently(device, pool[device][0], pool[device][1])) {
+      aside[n_aside++] = pool[device][1];
+      HIP_TRY(hipStreamCreateWithFlags(&pool[device][1], hipStreamNonBlocking));
+    }
+    if (getenv("SHC_DEBUG_STREAMS")) fprintf(stderr, "shc: split-stream pair of device %d found after %d replacement(s)\n", device, n_aside);
+    for (int k = 0; k < n_aside; ++k) (void)hipStreamDestroy(aside[k]);
   }
   out[0] = pool[device][0], out[1] = pool[device][1];
   return SHC_OK;
@@ -1309,7 +1353,7 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
     // every tenth step costs the whole gain).  After a join the halves are therefore STAGGERED: the first half of this one step
     // goes out as two launches and the second half starts when the first of them is through, i.e. a quarter of a step late;
     // both halves take the same time from then on, so the stagger stays until the next join.
-    const int64_t quarter = ((half / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block;
+    const int64_t quarter = ((half / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block; // (a quarter or three quarters of a half instead: the same step time within 1 %, profiles/r04_probe_build_variants.txt)
     a.grid = (unsigned)(quarter / waves_per_block);
     SHC_DISPATCH(e->L, e->NJ, CALL);
     HIP_TRY(hipGetLastError());
