@@ -435,6 +435,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     host_barrier = None
     parity = None
     nogather_elapsed = gather_s = None
+    enqueue_s = None
     wd_meta = {"n_gpus": world, "config": {"workload": f"BASELINE.json {name}: {n} per GPU", "mode": mode}}
     if use_dist:
         gather()
@@ -516,6 +517,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                     gather()
             if not gather_every or steps % gather_every:
                 gather()
+            enqueue_s = time.perf_counter() - t0   # the host's share: the launches are asynchronous, this is how long issuing them took
             torch.cuda.synchronize()
             elapsed = time.perf_counter() - t0  # this rank's K steps + its part of the gather; the MAX over ranks below is the job's time
         state["window"] = None
@@ -625,6 +627,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         roofline = launch_roofline
     res = {
         "value": world * n * steps * cps / elapsed, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "parity": parity,
+        "host_issue_ms_per_step": (enqueue_s / steps * 1e3) if enqueue_s else None,   # launch mode: the host's time to issue a step's launches (asynchronous)
         "config": {"workload": f"BASELINE.json {name}: {n} {desc}", "instances_per_gpu": n, "cycles_per_step": cps,
                    "mode": ("resident: one launch stays on the chip, a step = one doorbell tick = one control cycle with that cycle's inputs from the "
                             "device-side rings and its q / qd to the output ring") if resident else "one launch of the fused cycle kernel per step",
