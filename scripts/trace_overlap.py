@@ -11,7 +11,13 @@ pat = sys.argv[2] if len(sys.argv) > 2 else "shc_cycle_kernel<8, 5"
 last = int(sys.argv[3]) if len(sys.argv) > 3 else 600
 rows = [r for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-last:]
+if len(sys.argv) > 4 and sys.argv[4] == "region":   # the timed region of bench.run_workload: the `last` launches that follow the last fused (16-cycle, long) launch + its 5 warm-up steps
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    k = max(i for i, d in enumerate(dur) if d > 500000)
+    rows = rows[k + 1 + 12:k + 1 + 12 + last]
+    print("region: launches", k + 13, "...", k + 13 + last, "wall", (int(rows[-1]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e3 / (last / 2), "us per step")
+else:
+    rows = rows[-last:]
 byq = collections.defaultdict(list)
 for r in rows:
     byq[r["Queue_Id"]].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Grid_Size_X"]))
