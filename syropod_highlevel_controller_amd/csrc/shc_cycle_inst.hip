@@ -71,11 +71,16 @@ static void launch_cycle_feat(const CycleLaunch &a) {
     // gravity-aligned tips: kernels with the tip-rotation logic compiled in; also a robot with 3-joint legs next to longer ones under
     // joint_control leg manipulation (a MANUAL 3-joint leg holds its FK tip rotation), once a leg has been toggled
     if (c.gravity_aligned || (mlegs && c.joint_control == 2)) {
-      if constexpr (SPEC) {  // default.yaml's posing set: feature-exact
-        constexpr unsigned C2 = F_MANUAL | F_ODOM;
-        if (!a.generic && !terrain && (f & ~F_TIPF) == C2) {
-          if (f & F_TIPF) launch_cycle<L, NJ, C2 | F_TIPF | F_ROT>(a);
-          else launch_cycle<L, NJ, C2 | F_ROT>(a);
+      // default.yaml's posing set: feature-exact for every morphology (with the tip-force estimate: the BASELINE morphology only), and with that
+      // the two-launch form of the cycle for large launches (launch_cycle)
+      constexpr unsigned C2 = F_MANUAL | F_ODOM;
+      if (!a.generic && !terrain && (f & ~F_TIPF) == C2) {
+        if (!(f & F_TIPF)) {
+          launch_cycle<L, NJ, C2 | F_ROT>(a);
+          return;
+        }
+        if constexpr (SPEC) {
+          launch_cycle<L, NJ, C2 | F_TIPF | F_ROT>(a);
           return;
         }
       }
