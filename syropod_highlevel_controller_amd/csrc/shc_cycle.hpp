@@ -43,7 +43,9 @@ constexpr int kSwingTable = 64;  // entries of the walk-plane-pose control-input
 // "this group of state fields changed during the launch" bits, kept per lane and OR-reduced over the wave before the
 // write-back: groups nobody changed are not stored (walk plane / manual pose of the robot tile; the parked stepper
 // origins of the per-leg planes, which change once per step period).
-enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8 };
+enum : unsigned { DIRTY_WALK_PLANE = 1, DIRTY_MANUAL = 2, DIRTY_SWING_ORG = 4, DIRTY_STANCE_ORG = 8,
+                  DIRTY_TARG_DIR = 16, // the stepper's target tip direction (assigned once per walk, or by an external target): its planes are written back only then
+                  DIRTY_LAST = DIRTY_TARG_DIR };
 // launch-uniform run-time facts passed as a kernel argument (see shc_cycle_kernel)
 enum : unsigned { RT_MANUAL_LIVE = 1, RT_TOUCHDOWN = 2, RT_EXTERNAL = 4, RT_MANUAL_LEGS = 8, RT_EFFORT_LIVE = 16, RT_SKIP_MARKED = 32, RT_POSE_MARKED = 64 }; // RT_POSE_MARKED: run only the posing part of the loop (updateCurrentPose, admittance), and only for the robots a loop-level kernel marked; // RT_MANUAL_LEGS: a leg has been toggled (ManualRobot records exist); // RT_EXTERNAL: external targets / defaults have been requested; // RT_TOUCHDOWN: tip-state (wrench) messages have arrived (walk_controller.h:495)
 
@@ -1334,7 +1336,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
               if (rot_walk) { // ... and its rotation: pose_.rotation_ * transform_.rotation_^-1; a product with UNDEFINED_ROTATION (zeros) stays undefined
                 const Quat tr = Quat{v[3], v[4], v[5], v[6]} * inverse(Quat{v[10], v[11], v[12], v[13]});
                 targ_rot = !(tr.w == 0.0 && tr.x == 0.0 && tr.y == 0.0 && tr.z == 0.0);
-                if (targ_rot) s.targ_dir = rotate(tr, V3{1, 0, 0});
+                if (targ_rot) s.targ_dir = rotate(tr, V3{1, 0, 0}), dirty |= DIRTY_TARG_DIR;
               }
               clearance = normalized(clearance) * cf.x;
               if (flags & 2) { // "odom_ideal" frame: lead by calculateOdometry(time_to_swing_end).position_ (:1073-1078, :783-791)
@@ -1444,6 +1446,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
             gv = rotate(angle_axis_x(-e.x), gv);
           }
           s.targ_dir = normalized(gv);
+          dirty |= DIRTY_TARG_DIR;
           targ_rot = true;
         }
         if (!targ_rot) { // target undefined: so is the current tip rotation (:1208-1211)

@@ -164,8 +164,10 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     ld.store(FD::ORG_DIR / 2, double2{s.org_dir.x, s.org_dir.y});
     ld.store(FD::ORG_DIR / 2 + 1, double2{s.org_dir.z, s.cur_dir.x});
     ld.store(FD::ORG_DIR / 2 + 2, double2{s.cur_dir.y, s.cur_dir.z});
-    ld.store(FD::ORG_DIR / 2 + 3, double2{s.targ_dir.x, s.targ_dir.y});
-    ld.store(FD::ORG_DIR / 2 + 4, double2{s.targ_dir.z, 0.0});
+    if (dirty & DIRTY_TARG_DIR) {
+      ld.store(FD::ORG_DIR / 2 + 3, double2{s.targ_dir.x, s.targ_dir.y});
+      ld.store(FD::ORG_DIR / 2 + 4, double2{s.targ_dir.z, 0.0});
+    }
   }
   if (ROLE != ROLE_BACK) st.legi[slot] = s.word;
 }
@@ -842,7 +844,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   { // OR over the wave (mirror lanes replay a live lane, so their bits are redundant, never wrong)
     unsigned d = 0;
 #pragma unroll
-    for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
+    for (unsigned b = 1; b <= DIRTY_LAST; b <<= 1)
       if (__any((dirty & b) != 0)) d |= b;
     dirty = d;
   }
@@ -1241,7 +1243,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       if (POSE_SPLIT) { // what the pose on this wavefront dirtied / received is written back by the walker, which owns the tile stores
         unsigned d = 0;
 #pragma unroll
-        for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
+        for (unsigned b = 1; b <= DIRTY_LAST; b <<= 1)
           if (__any((dirty & b) != 0)) d |= b;
         if (lane == 0) X.model_dirty[pair] = d, X.model_seen[pair] = held.seen;
       }
@@ -1257,7 +1259,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
     {
       unsigned d = 0;
 #pragma unroll
-      for (unsigned b = 1; b <= DIRTY_STANCE_ORG; b <<= 1)
+      for (unsigned b = 1; b <= DIRTY_LAST; b <<= 1)
         if (__any((dirty & b) != 0)) d |= b;
       dirty = d;
     }
