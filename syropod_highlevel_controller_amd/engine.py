@@ -130,6 +130,20 @@ def build_library(force: bool = False, verbose: bool = False, jobs: Optional[int
             return _SO
         raise FileNotFoundError(f"{_SO} is missing and {hipcc} is not available to build it")
     os.makedirs(_OBJ, exist_ok=True)
+    # several ranks of one node may get here at once (torch.distributed.run): one of them builds, the others wait and find the stamp
+    import fcntl
+    lock = open(_SO + ".lock", "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and os.path.exists(_SO) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            return _SO
+        return _build_locked(force, verbose, jobs, resource_report, hipcc, stamp, want)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(force, verbose, jobs, resource_report, hipcc, stamp, want):
     from concurrent.futures import ThreadPoolExecutor
     todo, objs = [], []
     for name, src, defines in _translation_units():
