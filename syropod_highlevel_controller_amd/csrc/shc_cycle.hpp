@@ -463,9 +463,10 @@ struct OdomCache {
   double ha = 0.0, sh = 0.0, ch = 1.0;
   bool valid = false;
 };
-template <int RPW>
-__device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const CycleParams &P, double vx, double vy, double vw, OdomCache *cache = nullptr) {
-  using R = RobotFields;
+// (the accumulator itself - x, y, qw, qz - by reference: the robot tile's copy, or registers of a caller that runs many cycles and
+//  writes them back once: the two-wavefront resident loop)
+__device__ __forceinline__ void odometry_advance(double &ox, double &oy, double &ow, double &oz, const CycleParams &P, double vx, double vy, double vw,
+                                                 OdomCache *cache = nullptr) {
   // Both poses are pure yaw (rotation (w, 0, 0, z), z translation 0), so Pose::addPose reduces to its w / z and x / y
   // terms; the dropped terms are exact zeros, the kept ones are evaluated in the general formula's order.
   double sh, ch;
@@ -477,15 +478,28 @@ __device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const Cycl
     else sincos_joint(ha, &sh, &ch);
     if (cache != nullptr) cache->ha = ha, cache->sh = sh, cache->ch = ch, cache->valid = true;
   }
-  const double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 2), oz = rb.get(R::ODOM + 3);
-  const double a = vx * P.dt, b = vy * P.dt;
-  double ux = -(oz * b), uy = oz * a; // u x v
-  ux = ux + ux;
-  uy = uy + uy;
-  rb.put(R::ODOM, ox + ((a + ux * ow) - oz * uy));
-  rb.put(R::ODOM + 1, oy + ((b + uy * ow) + oz * ux));
-  rb.put(R::ODOM + 2, ow * ch - oz * sh);
-  rb.put(R::ODOM + 3, ow * sh + oz * ch);
+  // (this code is compiled into kernels that keep the accumulator in LDS and into one that keeps it in registers, which must agree bit for
+  //  bit: contraction is off and the fused multiply-adds are written out)
+  {
+#pragma clang fp contract(off)
+    const double a = vx * P.dt, b = vy * P.dt;
+    double ux = -(oz * b), uy = oz * a; // u x v
+    ux = ux + ux;
+    uy = uy + uy;
+    const double nx = ox + fma(-oz, uy, fma(ux, ow, a)), ny = oy + fma(oz, ux, fma(uy, ow, b));
+    const double nw = fma(ow, ch, -(oz * sh)), nz = fma(ow, sh, oz * ch);
+    ox = nx, oy = ny, ow = nw, oz = nz;
+  }
+}
+template <int RPW>
+__device__ __forceinline__ void odometry_step(const RobTile<RPW> &rb, const CycleParams &P, double vx, double vy, double vw, OdomCache *cache = nullptr) {
+  using R = RobotFields;
+  double ox = rb.get(R::ODOM), oy = rb.get(R::ODOM + 1), ow = rb.get(R::ODOM + 2), oz = rb.get(R::ODOM + 3);
+  odometry_advance(ox, oy, ow, oz, P, vx, vy, vw, cache);
+  rb.put(R::ODOM, ox);
+  rb.put(R::ODOM + 1, oy);
+  rb.put(R::ODOM + 2, ow);
+  rb.put(R::ODOM + 3, oz);
 }
 
 // The control input of PoseController::updateWalkPlanePose (:1100-1108) from each lane's OWN packed leg word: smoothStep of the scaled swing

@@ -1053,6 +1053,13 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   OdomCache odom_cache;        // model wavefront: (sin, cos) of the half yaw step while the desired angular velocities stay as they are
   Pose owpp_cache = pose_identity();
   if (POSE_SPLIT && active && !walker) owpp_cache = rb.getpose(R::OWPP); // ... and the origin walk-plane pose (the walker wavefront filled the tile before the barrier)
+  // ... and WalkController::odometry_ideal_ itself: nothing inside the loop reads it, so the model wavefront accumulates it in registers and
+  // puts it back into the tile when the loop ends (4 LDS reads + 4 writes per cycle less on the longer of the two wavefronts)
+  double odom[4] = {0.0, 0.0, 1.0, 0.0};
+  if (FT::odom(P) && active && !walker) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) odom[i] = rb.get(R::ODOM + i);
+  }
 #ifdef SHC_RES2_TIMING
   long long tm_busy = 0, tm_total0 = __builtin_readcyclecounter(), tm_real = 0;
 #ifndef SHC_RES2_BUSY_ONLY
@@ -1157,7 +1164,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         if (FT::odom(P)) {
           const V3 ov{mb[192], mb[256], mb[320]};
           if (__any(mb[384] != 0.0)) { // (robots whose updateWalk returned early keep their odometry)
-            if (mb[384] != 0.0) odometry_step(rb, P, ov.x, ov.y, ov.z, &odom_cache);
+            if (mb[384] != 0.0) odometry_advance(odom[0], odom[1], odom[2], odom[3], P, ov.x, ov.y, ov.z, &odom_cache);
           }
         }
         out.adm_delta = V3{0, 0, 0};
@@ -1240,6 +1247,10 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       X.stiff[pair][lane] = s.stiff;
     } else {
       X.ikfail[pair][lane] = s.word & LW_IKFAIL;
+      if (FT::odom(P)) { // the odometry accumulated in registers back into the tile the walker wavefront stores
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb.put(R::ODOM + i, odom[i]);
+      }
       if (POSE_SPLIT) { // what the pose on this wavefront dirtied / received is written back by the walker, which owns the tile stores
         unsigned d = 0;
 #pragma unroll
