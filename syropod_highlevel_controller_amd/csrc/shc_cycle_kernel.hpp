@@ -1054,9 +1054,12 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   Pose owpp_cache = pose_identity();
   if (POSE_SPLIT && active && !walker) owpp_cache = rb.getpose(R::OWPP); // ... and the origin walk-plane pose (the walker wavefront filled the tile before the barrier)
   // ... and WalkController::odometry_ideal_ itself: nothing inside the loop reads it, so the model wavefront accumulates it in registers and
-  // puts it back into the tile when the loop ends (4 LDS reads + 4 writes per cycle less on the longer of the two wavefronts)
+  // puts it back into the tile when the loop ends (4 LDS reads + 4 writes per cycle less on the longer of the two wavefronts).  Short chains
+  // only: the 4- and 5-joint model wavefronts already keep part of their state in AGPRs, four more loop-carried doubles cost them more
+  // register moves than the LDS traffic they save (4 000 8 x 5 octopods: 3.47 -> 3.55 us per cycle with it)
+  constexpr bool ODOM_REGS = NJ <= 3;
   double odom[4] = {0.0, 0.0, 1.0, 0.0};
-  if (FT::odom(P) && active && !walker) {
+  if (ODOM_REGS && FT::odom(P) && active && !walker) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) odom[i] = rb.get(R::ODOM + i);
   }
@@ -1164,7 +1167,10 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         if (FT::odom(P)) {
           const V3 ov{mb[192], mb[256], mb[320]};
           if (__any(mb[384] != 0.0)) { // (robots whose updateWalk returned early keep their odometry)
-            if (mb[384] != 0.0) odometry_advance(odom[0], odom[1], odom[2], odom[3], P, ov.x, ov.y, ov.z, &odom_cache);
+            if (mb[384] != 0.0) {
+              if constexpr (ODOM_REGS) odometry_advance(odom[0], odom[1], odom[2], odom[3], P, ov.x, ov.y, ov.z, &odom_cache);
+              else odometry_step(rb, P, ov.x, ov.y, ov.z, &odom_cache);
+            }
           }
         }
         out.adm_delta = V3{0, 0, 0};
@@ -1247,7 +1253,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       X.stiff[pair][lane] = s.stiff;
     } else {
       X.ikfail[pair][lane] = s.word & LW_IKFAIL;
-      if (FT::odom(P)) { // the odometry accumulated in registers back into the tile the walker wavefront stores
+      if (ODOM_REGS && FT::odom(P)) { // the odometry accumulated in registers back into the tile the walker wavefront stores
 #pragma unroll
         for (int i = 0; i < 4; ++i) rb.put(R::ODOM + i, odom[i]);
       }
