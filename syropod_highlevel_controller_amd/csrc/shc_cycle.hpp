@@ -196,10 +196,6 @@ struct DevState {
   double *ext; // ExtFields planes, nullptr until the first external request
   ManualRobot *manual; // nullptr until a leg is toggled
   const double *span;  // rough terrain mode with a stance span modifier: the legs' layered-workspace planes (SpanTable), else nullptr
-  // a step as TWO launches (gravity-aligned tips on legs with more than 3 joints, shc_cycle_half_kernel): what the walker / poser launch hands
-  // to the model launch of the same cycle - 3 double2 planes of n_slots: (poser tip x, y) (poser tip z, desired tip direction x) (y, z).
-  // Scratch, not state: written and consumed within one step.  nullptr: the engine never runs such a step.
-  double *half;
 };
 
 // LegStepper::calculateStanceSpanChange on the layered workspace of rough terrain mode (walk_controller.cpp:949-980): per leg the

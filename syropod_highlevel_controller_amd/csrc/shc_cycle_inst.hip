@@ -42,7 +42,7 @@ static void launch_cycle(const CycleLaunch &a) {
   // each instead of one) once the launch holds at least two wavefronts for every SIMD of the chip; smaller launches stay one kernel.
   if constexpr ((F & F_ROT) != 0 && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_ADM | F_AUTO)) == 0) {
     const int64_t waves = int64_t(a.grid) * (a.block / 64);
-    if (a.st.half != nullptr && a.half_steps >= 0 && (a.half_steps > 0 || waves >= 2048)) {
+    if (a.half_steps >= 0 && (a.half_steps > 0 || waves >= 2048)) {
       for (int c = 0; c < a.n_cycles; ++c) {
         shc_cycle_half_kernel<L, NJ, F, ROLE_FRONT><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(
             a.st, (const SharedConsts<L, NJ> *)a.consts, a.rt_flags, a.wave0);

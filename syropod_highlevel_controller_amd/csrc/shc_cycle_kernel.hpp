@@ -637,7 +637,9 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
 // HALF (launch mode only): ROLE_ALL = whole cycles.  ROLE_FRONT / ROLE_BACK = ONE cycle as two launches (shc_cycle_half_kernel): the walker /
 // poser half (cycle_front; owns the stepper planes, the leg word, the tip directions and the robot tile; reads the joint angles for the FK tip
 // rotation Leg::current_tip_pose_ holds) and the model half (cycle_back; owns the joint planes and the tip-force filter, ORs LW_IKFAIL into
-// the word), with PoseController::updateStance's result - poser tip, desired tip direction - in DevState::half between them.
+// the word).  Nothing is handed over beyond the state itself: the model half redoes PoseController::updateStance's two transforms (poser tip =
+// Model::current_pose_^-1 * walker tip, desired tip direction = pose rotation^-1 * walker tip direction, pose_controller.cpp:122-131) from the walker
+// tip, the walker tip direction and the current pose the walker half has just stored - 64 bytes read per leg instead of 48 written + 48 read.
 template <int L, int NJ, unsigned F, bool RES, int HALF = ROLE_ALL>
 __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConsts<L, NJ> *gc, int n_cycles, unsigned rt_flags, const int64_t wave,
                                            const ResidentArgs *ra) {
@@ -683,7 +685,8 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   double th[NJ]; // DH joint offsets of this lane's leg straight from the table in HBM: the FK of the stored joint state
                  // (sin / cos) then starts as soon as the joint planes arrive, under the latency of the remaining loads
   const bool any_robot = robots_here > 0;
-  double2 hand[3] = {double2{0.0, 0.0}, double2{0.0, 0.0}, double2{0.0, 0.0}}; // (HALF) DevState::half of this slot
+  double2 hand[4] = {double2{0.0, 0.0}, double2{0.0, 0.0}, double2{0.0, 0.0}, double2{0.0, 0.0}}; // (ROLE_BACK) walker tip planes, walker tip direction planes
+  double hpose[7] = {0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0};                                            // (ROLE_BACK) Model::current_pose_ of this lane's robot
   double2 qpl[(NJ + 1) / 2];                                                      // (ROLE_FRONT) the joint-angle planes
   int word_back = 0;
   if (any_robot) {
@@ -696,8 +699,15 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     }
     if constexpr (HALF == ROLE_BACK) {
       word_back = st.legi[slot];
+      using FDh = Fields<NJ>;
+      static_assert(FDh::TIP % 2 == 0 && FDh::CUR_DIR == FDh::ORG_DIR + 3 && FDh::ORG_DIR % 2 == 0, "plane layout of the walker tip / tip direction");
+      const double2 *planes = reinterpret_cast<const double2 *>(st.legd);
+      hand[0] = planes[(FDh::TIP / 2) * st.n_slots + slot];          // tip x, y
+      hand[1] = planes[(FDh::TIP / 2 + 1) * st.n_slots + slot];      // tip z | -
+      hand[2] = planes[(FDh::ORG_DIR / 2 + 1) * st.n_slots + slot];  // - | current direction x
+      hand[3] = planes[(FDh::ORG_DIR / 2 + 2) * st.n_slots + slot];  // current direction y, z
 #pragma unroll
-      for (int p = 0; p < 3; ++p) hand[p] = reinterpret_cast<const double2 *>(st.half)[p * st.n_slots + slot];
+      for (int k = 0; k < 7; ++k) hpose[k] = gtile[(R::CPOSE + k) * RPW + grp];
     }
   }
   using SC = SharedConsts<L, NJ>;
@@ -817,9 +827,6 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     fb.pose_only = false;
     cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
                                 LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
-    hand[0] = double2{out.poser_tip.x, out.poser_tip.y};
-    hand[1] = double2{out.poser_tip.z, fb.desired_dir.x};
-    hand[2] = double2{fb.desired_dir.y, fb.desired_dir.z};
   } else if constexpr (HALF == ROLE_BACK) {
     FrontToBack fb;
     fb.uf = load_uni_flags(C.P);
@@ -827,8 +834,12 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     fb.joint_moved = false;
     fb.my_leg_state = 0;
     fb.rot_def = (s.word & LW_ROTDEF) != 0;
-    fb.desired_dir = V3{hand[1].y, hand[2].x, hand[2].y};
-    out.poser_tip = V3{hand[0].x, hand[0].y, hand[1].x};
+    { // PoseController::updateStance (:122-131) of this cycle, as cycle_front evaluates it (no auto posing in these specialisations: the pose is Model::current_pose_)
+      const Pose bp{V3{hpose[0], hpose[1], hpose[2]}, Quat{hpose[3], hpose[4], hpose[5], hpose[6]}};
+      out.poser_tip = inverse_transform_vector(bp, V3{hand[0].x, hand[0].y, hand[1].x});
+      fb.desired_dir = V3{1, 0, 0};
+      if (fb.rot_def) fb.desired_dir = rotate(inverse(bp.r), V3{hand[2].y, hand[3].x, hand[3].y});
+    }
     out.adm_delta = V3{0.0, 0.0, 0.0};
     cycle_back<L, NJ, F>(s, out, C, leg, st.legd, st.n_slots, slot, mr, LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
   } else if (!skip) {
@@ -849,12 +860,6 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     dirty = d;
   }
   if (live && !skip) store_leg<NJ, F, HALF>(s, out, pk, st, P, slot, dirty);
-  if constexpr (HALF == ROLE_FRONT) {
-    if (live) {
-#pragma unroll
-      for (int p = 0; p < 3; ++p) LegPlanes{reinterpret_cast<double2 *>(st.half), st.n_slots, slot}.store(p, hand[p]);
-    }
-  }
   if constexpr (HALF == ROLE_BACK) {
     if (live) st.legi[slot] = s.word; // the walker half's word of this cycle | LW_IKFAIL
     return;                           // (the robot tile is the walker half's)

@@ -940,7 +940,6 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->st.robi);
   (void)hipFree(e->st.ext);
   (void)hipFree(e->st.manual);
-  (void)hipFree(e->st.half);
   (void)hipFree(e->d_seq);
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
@@ -1323,8 +1322,6 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
     if (rc != SHC_OK) return rc;
   }
   const int64_t half = split ? ((e->n_waves / 2 + waves_per_block - 1) / waves_per_block) * waves_per_block : e->n_waves;
-  if (e->NJ > 3 && e->cp.gravity_aligned && !e->st.half && e->half_steps >= 0) // hand-over planes of two-launch cycles (DevState::half)
-    HIP_TRY(hipMalloc(&e->st.half, size_t(3) * e->n_slots * 16));
   CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream,
                 (unsigned)((half + waves_per_block - 1) / waves_per_block), block, n_cycles, nullptr, nullptr, 0, e->half_steps};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
