@@ -3,7 +3,7 @@
 The whole cycle of the 8 x 5 feature-exact kernels needs 256 VGPRs + 76 - 92 AGPRs = one wavefront per SIMD; the walker / poser half
 (WalkController::updateWalk + PoseController::updateStance) and the model half (Model::updateModel: Leg::applyIK with the rotation solve,
 model.cpp:861-941) each fit two.  From 2 048 wavefronts per launch on, `shc_engine_step` therefore runs each cycle as
-shc_cycle_half_kernel<ROLE_FRONT> + <ROLE_BACK> with the poser tip and the desired tip direction handed over through scratch planes.
+shc_cycle_half_kernel<ROLE_FRONT> + <ROLE_BACK>; the model half redoes PoseController::updateStance's two transforms from the stored walker state.
 SHC_ROT_SPLIT (read at shc_engine_create) forces it on (1) or off (0) at any size - that is how the small cases here reach it.
 
 Bar: the two-launch form is byte-identical to the one-launch form (joints and the complete state record), and holds the oracle bar."""
