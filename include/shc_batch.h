@@ -343,10 +343,15 @@ int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t max_cycles,
 /* Bind device arrays as input set `set` (0 .. 3) for direct posts; call it while the loop is NOT running (the addresses travel with the launch
  * of the loop kernel); NULL members = the set does not carry that group; arrays as for the setters ([n][2], [n], [n][4], [n][3],
  * [n][legs][3], [n][legs][dof]).  Contract of a direct post of set k for cycle c: the arrays hold the cycle's inputs (visible device-wide)
- * when shc_engine_resident_post is called and stay unchanged until a LATER cycle has completed (shc_engine_resident_wait(c + 2)) - a
- * host loop alternates between two sets, as the node's callbacks fill one message while the controller reads the other.  Velocity and
- * IMU samples are taken into the loop's own state when cycle c starts; per-leg inputs (tip force, joint effort) are read from the set's
- * arrays until another post of that group replaces them, and are carried into the engine's own planes when the loop ends. */
+ * when shc_engine_resident_post is called.
+ *  - Velocity and IMU arrays are sampled into the loop's own state when cycle c starts: they may be rewritten once a LATER cycle has
+ *    completed (shc_engine_resident_wait(c + 2)).
+ *  - Per-leg arrays (tip force, joint effort) are NOT copied: the set's arrays are the input IN FORCE - read again in every cycle, and once
+ *    more when the loop ends (carried into the engine's own planes) - until a later post of THAT GROUP (direct from another set, or an
+ *    ordinary post) has replaced them and the cycle it was made for has completed.  Until then they must not be written: a write changes
+ *    the held input of the cycles in between, and a read that races it may be torn.
+ * A host loop therefore alternates between two sets, as the node's callbacks fill one message while the controller reads the other, and
+ * refills a set's per-leg arrays only after the other set's post of the same group has run. */
 int shc_engine_resident_bind_inputs(shc_engine *e, int set, const shc_cycle_inputs *arrays);
 int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *inputs, int64_t *cycle);
 int shc_engine_resident_publish(shc_engine *e, int64_t n_cycles);

@@ -1074,41 +1074,34 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   if (threadIdx.x < 64) shc_acc_lds[threadIdx.x] = 0;
 #endif
 #endif
-  for (;;) {
+  // The two roles run SEPARATE loops - one barrier per iteration each, and the same number of iterations: what an iteration is comes from the
+  // workgroup's control words.  (One loop with the role branch inside kept every loop-carried value of BOTH roles live across the loop header:
+  // phi copies in every iteration and ~100 scalar registers spilled into VGPR lanes, on the walker's and the model's critical path alike.)
 #ifdef SHC_RES2_TIMING
-    const long long tm0 = __builtin_readcyclecounter();
-    SHC_TICK(19);
+#define SHC_R2_ITER_BEGIN() const long long tm0 = __builtin_readcyclecounter(); SHC_TICK(19)
+#ifndef SHC_RES2_BUSY_ONLY
+#define SHC_R2_PHASES(THREAD, ...)                                                                                                  \
+  if (kind == IT_REAL && prev_real && blockIdx.x == 1 && threadIdx.x == (THREAD)) { /* phase clocks of this steady iteration */      \
+    const int base = ((THREAD) >> 7) * 32;                                                                                         \
+    const int order[] = {__VA_ARGS__};                                                                                             \
+    for (int i = 1; i < int(sizeof(order) / sizeof(int)); ++i) shc_acc_lds[base + order[i]] += shc_ticks_lds[base + order[i]] - shc_ticks_lds[base + order[i - 1]]; \
+  }
+#else
+#define SHC_R2_PHASES(THREAD, ...)
 #endif
-    const int kind = __builtin_amdgcn_readfirstlane(int(X.ctrl[k & 3][0]));
-    const u64 h0 = uni64(X.ctrl[k & 3][1]), h1 = uni64(X.ctrl[k & 3][2]);
-    int nk = IT_EXIT;
-    u64 nh0v = 0, nh1v = 0;
-    if (leader && kind != IT_EXIT) { // what will iteration k + 1 be?
-      u64 gate;
-      if (kind == IT_BUBBLE) {
-        __builtin_amdgcn_s_sleep(2);
-        gate = uni64(ld_agent(&A.ctl->gate)); // nothing else to do: look again
-      } else {
-        gate = uni64(gate_pref); // read one iteration ago: at worst the loop learns of a release one iteration late
-      }
-      const unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
-      const unsigned cn = c_front + (kind == IT_REAL ? 1u : 0u); // the cycle iteration k + 1 would start
-      nk = cn >= sp ? IT_EXIT : (cn < db ? IT_REAL : IT_BUBBLE);
-      if (nk == IT_BUBBLE) {
-        const u64 now = wall_clock64();
-        if (bubble_since == 0) bubble_since = now;
-        else if (now - bubble_since > emergency_ticks) nk = IT_EXIT, held.fault = true;
-      } else {
-        bubble_since = 0;
-      }
-      if (nk == IT_REAL) {
-        const u64 *hp = reinterpret_cast<const u64 *>(A.headers + (cn & (kResidentHeaders - 1)));
-        nh0v = ld_agent(hp);
-        nh1v = ld_agent(hp + 1);
-      }
-      gate_pref = ld_agent(&A.ctl->gate);
-    }
-    if (walker) {
+#define SHC_R2_ITER_END(THREAD, ...)                                                         \
+  if (kind == IT_REAL && prev_real) tm_busy += __builtin_readcyclecounter() - tm0, ++tm_real; \
+  SHC_R2_PHASES(THREAD, __VA_ARGS__)
+#else
+#define SHC_R2_ITER_BEGIN() do {} while (0)
+#define SHC_R2_ITER_END(THREAD, ...) do {} while (0)
+#endif
+  if (walker) {
+    // ---------------------------------------------------------------- walker wavefront: cycle_front of cycle c_front
+    for (;;) {
+      SHC_R2_ITER_BEGIN();
+      const int kind = __builtin_amdgcn_readfirstlane(int(X.ctrl[k & 3][0]));
+      const u64 h0 = uni64(X.ctrl[k & 3][1]), h1 = uni64(X.ctrl[k & 3][2]);
       SHC_TICK(20);
       if (kind == IT_REAL && active) {
         resident_take_inputs<RPW, POSE_SPLIT ? ROBOT_VEL : ROBOT_ALL, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
@@ -1143,100 +1136,134 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         SHC_TICK(22);
       }
       SHC_TICK(23);
-    } else if (active) {
-      SHC_TICK(24);
-      if constexpr (POSE_SPLIT) if (kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
-        resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
-        const double pose_c = X.pose_c[pair][c_front & 1][lane];
-        int lw[L] = {}; // (not filled in: the walker wavefront has already reduced the leg words to the pose's control input)
-        const double *mb = &X.mailbox[pair][c_front & 1][0][lane];
-        const V3 plane_prev{mb[7 * 64], mb[8 * 64], mb[9 * 64]}, pnorm_prev{mb[10 * 64], mb[11 * 64], mb[12 * 64]};
-        int rword_unused = 0;
-        Pose ap = pose_identity(), la = pose_identity();
-#ifdef SHC_ABLATE
-        if (!(P.debug_skip & 2048))
-#endif
-        (void)cycle_pose<L, NJ, F, true>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev, fb.uf.swing_c_count, 0,
-                                         &owpp_cache, &pose_c);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) *const_cast<volatile unsigned *>(&X.pose_done[pair]) = c_front + 1;
+      if (kind == IT_EXIT) break;
+      SHC_R2_ITER_END(0, 19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 15, 22, 23);
+      if (kind == IT_REAL) ++c_front;
+      prev_real = kind == IT_REAL;
+      __syncthreads();
+      ++k;
+    }
+  } else {
+    // ---------------------------------------------------------------- model wavefront: the pose of cycle c_front, cycle_back of cycle c_back
+    for (;;) {
+      SHC_R2_ITER_BEGIN();
+      const int kind = __builtin_amdgcn_readfirstlane(int(X.ctrl[k & 3][0]));
+      const u64 h0 = uni64(X.ctrl[k & 3][1]), h1 = uni64(X.ctrl[k & 3][2]);
+      int nk = IT_EXIT;
+      u64 nh0v = 0, nh1v = 0;
+      if (leader && kind != IT_EXIT) { // what will iteration k + 1 be?
+        u64 gate;
+        if (kind == IT_BUBBLE) {
+          __builtin_amdgcn_s_sleep(2);
+          gate = uni64(ld_agent(&A.ctl->gate)); // nothing else to do: look again
+        } else {
+          gate = uni64(gate_pref); // read one iteration ago: at worst the loop learns of a release one iteration late
+        }
+        const unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
+        const unsigned cn = c_front + (kind == IT_REAL ? 1u : 0u); // the cycle iteration k + 1 would start
+        nk = cn >= sp ? IT_EXIT : (cn < db ? IT_REAL : IT_BUBBLE);
+        if (nk == IT_BUBBLE) {
+          const u64 now = wall_clock64();
+          if (bubble_since == 0) bubble_since = now;
+          else if (now - bubble_since > emergency_ticks) nk = IT_EXIT, held.fault = true;
+        } else {
+          bubble_since = 0;
+        }
+        if (nk == IT_REAL) {
+          const u64 *hp = reinterpret_cast<const u64 *>(A.headers + (cn & (kResidentHeaders - 1)));
+          nh0v = ld_agent(hp);
+          nh1v = ld_agent(hp + 1);
+        }
+        gate_pref = ld_agent(&A.ctl->gate);
       }
-      SHC_TICK(25);
-      if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
-        resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
-        LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, wave * RPW + grp, leg);
-        if (FT::tipf(P)) in.prefetch_effort();
-        const double *mb = &X.mailbox[pair][c_back & 1][0][lane];
-        out.poser_tip = V3{mb[0], mb[64], mb[128]};
-        if (FT::odom(P)) {
-          const V3 ov{mb[192], mb[256], mb[320]};
-          if (__any(mb[384] != 0.0)) { // (robots whose updateWalk returned early keep their odometry)
-            if (mb[384] != 0.0) {
-              if constexpr (ODOM_REGS) odometry_advance(odom[0], odom[1], odom[2], odom[3], P, ov.x, ov.y, ov.z, &odom_cache);
-              else odometry_step(rb, P, ov.x, ov.y, ov.z, &odom_cache);
+      if (active) {
+        SHC_TICK(24);
+        if constexpr (POSE_SPLIT) if (kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
+          resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
+          const double pose_c = X.pose_c[pair][c_front & 1][lane];
+          int lw[L] = {}; // (not filled in: the walker wavefront has already reduced the leg words to the pose's control input)
+          const double *mb = &X.mailbox[pair][c_front & 1][0][lane];
+          const V3 plane_prev{mb[7 * 64], mb[8 * 64], mb[9 * 64]}, pnorm_prev{mb[10 * 64], mb[11 * 64], mb[12 * 64]};
+          int rword_unused = 0;
+          Pose ap = pose_identity(), la = pose_identity();
+#ifdef SHC_ABLATE
+          if (!(P.debug_skip & 2048))
+#endif
+          (void)cycle_pose<L, NJ, F, true>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev, fb.uf.swing_c_count, 0,
+                                           &owpp_cache, &pose_c);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) *const_cast<volatile unsigned *>(&X.pose_done[pair]) = c_front + 1;
+        }
+        SHC_TICK(25);
+        if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
+          resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
+          LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, wave * RPW + grp, leg);
+          if (FT::tipf(P)) in.prefetch_effort();
+          const double *mb = &X.mailbox[pair][c_back & 1][0][lane];
+          out.poser_tip = V3{mb[0], mb[64], mb[128]};
+          if (FT::odom(P)) {
+            const V3 ov{mb[192], mb[256], mb[320]};
+            if (__any(mb[384] != 0.0)) { // (robots whose updateWalk returned early keep their odometry)
+              if (mb[384] != 0.0) {
+                if constexpr (ODOM_REGS) odometry_advance(odom[0], odom[1], odom[2], odom[3], P, ov.x, ov.y, ov.z, &odom_cache);
+                else odometry_step(rb, P, ov.x, ov.y, ov.z, &odom_cache);
+              }
             }
           }
-        }
-        out.adm_delta = V3{0, 0, 0};
-        if (FT::adm(P)) cycle_admittance<NJ>(s, out, P, in);
-        s.word = 0;
-        SHC_TICK(26);
-        cycle_back<L, NJ, F>(s, out, C, leg, st.legd, ns, slot, nullptr, in, fb);
-        SHC_TICK(27);
-        // the output stores of cycle c_back - 1 were issued one iteration ago: they have drained - announce them, then issue this cycle's
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_agent(A.progress + wave, u64(c_back));
-        {
-          typedef unsigned v4u __attribute__((ext_vector_type(4)));
-          double flat[2 * NJ];
+          out.adm_delta = V3{0, 0, 0};
+          if (FT::adm(P)) cycle_admittance<NJ>(s, out, P, in);
+          s.word = 0;
+          SHC_TICK(26);
+          cycle_back<L, NJ, F>(s, out, C, leg, st.legd, ns, slot, nullptr, in, fb);
+          SHC_TICK(27);
+          // the output stores of cycle c_back - 1 were issued one iteration ago: they have drained - announce them, then issue this cycle's
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) st_agent(A.progress + wave, u64(c_back));
+          {
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            double flat[2 * NJ];
 #pragma unroll
-          for (int i = 0; i < NJ; ++i) flat[FD::Q + i] = s.q[i], flat[FD::QD + i] = s.qd[i];
-          const unsigned soff = oslot * out_slot_bytes;
+            for (int i = 0; i < NJ; ++i) flat[FD::Q + i] = s.q[i], flat[FD::QD + i] = s.qd[i];
+            const unsigned soff = oslot * out_slot_bytes;
 #ifdef SHC_ABLATE
-          if (!(P.debug_skip & 4096))
+            if (!(P.debug_skip & 4096))
 #endif
-          if (live) {
+            if (live) {
 #pragma unroll
-            for (int p = 0; p < NJ; ++p) {
-              const u64 a = u64(__double_as_longlong(flat[2 * p])), b = u64(__double_as_longlong(flat[2 * p + 1]));
-              const v4u w = {unsigned(a), unsigned(a >> 32), unsigned(b), unsigned(b >> 32)};
-              __builtin_amdgcn_raw_buffer_store_b128(w, out_rsrc, unsigned((int64_t(p) * ns + slot) * 16), soff, 16 /* sc1 */);
+              for (int p = 0; p < NJ; ++p) {
+                const u64 a = u64(__double_as_longlong(flat[2 * p])), b = u64(__double_as_longlong(flat[2 * p + 1]));
+                const v4u w = {unsigned(a), unsigned(a >> 32), unsigned(b), unsigned(b >> 32)};
+                __builtin_amdgcn_raw_buffer_store_b128(w, out_rsrc, unsigned((int64_t(p) * ns + slot) * 16), soff, 16 /* sc1 */);
+              }
             }
           }
+          ++c_back;
+          oslot = oslot + 1 == unsigned(A.depth) ? 0 : oslot + 1;
+          SHC_TICK(28);
         }
-        ++c_back;
-        oslot = oslot + 1 == unsigned(A.depth) ? 0 : oslot + 1;
-        SHC_TICK(28);
+        if (kind != IT_REAL) { // the pipeline runs dry: nothing will follow for a while (or ever) - announce what is done now
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) st_agent(A.progress + wave, u64(c_back));
+        }
       }
-      if (kind != IT_REAL) { // the pipeline runs dry: nothing will follow for a while (or ever) - announce what is done now
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) st_agent(A.progress + wave, u64(c_back));
+      if (leader && kind != IT_EXIT && lane == 0) { // (the header loads issued at the top of the iteration have long arrived)
+        X.ctrl[(k + 1) & 3][0] = u64(nk);
+        X.ctrl[(k + 1) & 3][1] = nh0v;
+        X.ctrl[(k + 1) & 3][2] = nh1v;
       }
+      if (kind == IT_EXIT) break;
+      SHC_R2_ITER_END(128, 24, 25, 26, 9, 10, 11, 12, 27, 28);
+      if (kind == IT_REAL) ++c_front;
+      prev_real = kind == IT_REAL;
+      prev_h0 = h0, prev_h1 = h1;
+      __syncthreads();
+      ++k;
     }
-    if (leader && kind != IT_EXIT && lane == 0) { // (the header loads issued at the top of the iteration have long arrived)
-      X.ctrl[(k + 1) & 3][0] = u64(nk);
-      X.ctrl[(k + 1) & 3][1] = nh0v;
-      X.ctrl[(k + 1) & 3][2] = nh1v;
-    }
-    if (kind == IT_EXIT) break;
-#ifdef SHC_RES2_TIMING
-    if (kind == IT_REAL && prev_real) tm_busy += __builtin_readcyclecounter() - tm0, ++tm_real;
-#ifndef SHC_RES2_BUSY_ONLY
-    if (kind == IT_REAL && prev_real && blockIdx.x == 1 && (threadIdx.x == 0 || threadIdx.x == 128)) { // phase clocks of this steady iteration
-      const int base = (threadIdx.x >> 7) * 32;
-      const int worder[] = {19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 15, 22, 23}, morder[] = {24, 25, 26, 9, 10, 11, 12, 27, 28};
-      if (threadIdx.x == 0) for (int i = 1; i < 13; ++i) shc_acc_lds[base + worder[i]] += shc_ticks_lds[base + worder[i]] - shc_ticks_lds[base + worder[i - 1]];
-      else for (int i = 1; i < 9; ++i) shc_acc_lds[base + morder[i]] += shc_ticks_lds[base + morder[i]] - shc_ticks_lds[base + morder[i - 1]];
-    }
-#endif
-#endif
-    if (kind == IT_REAL) ++c_front;
-    prev_real = kind == IT_REAL;
-    prev_h0 = h0, prev_h1 = h1;
-    __syncthreads();
-    ++k;
   }
+#undef SHC_R2_ITER_BEGIN
+#undef SHC_R2_ITER_END
+#undef SHC_R2_PHASES
 #ifdef SHC_RES2_TIMING
   if (blockIdx.x == 1 && lane == 0 && pair == 0) { // development: clocks from iteration start to the barrier, REAL iterations in steady state
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(A.ctl) + 8 + (walker ? 0 : 4);

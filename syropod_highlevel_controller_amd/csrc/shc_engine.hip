@@ -1264,16 +1264,26 @@ static int split_streams(int device, hipStream_t out[2]) {
   if (device < 0 || device >= 64) return fail(SHC_ERR_INVALID_ARG, "device index");
   std::lock_guard<std::mutex> lock(pool_mutex);
   if (!pool[device][0]) {
-    HIP_TRY(hipStreamCreateWithFlags(&pool[device][0], hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&pool[device][1], hipStreamNonBlocking));
-    hipStream_t aside[6] = {};
+    // The pair is built in locals and published only once both streams exist: a failure on the way destroys what was created (streams set
+    // aside included) and leaves the pool empty, so that a later call starts over instead of handing out a null second stream - which
+    // would be the legacy default stream.
+    hipStream_t a = nullptr, b = nullptr, aside[6] = {};
     int n_aside = 0;
-    while (n_aside < 6 && !streams_run_concurrently(device, pool[device][0], pool[device][1])) {
-      aside[n_aside++] = pool[device][1];
-      HIP_TRY(hipStreamCreateWithFlags(&pool[device][1], hipStreamNonBlocking));
+    hipError_t err = hipStreamCreateWithFlags(&a, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+    while (err == hipSuccess && n_aside < 6 && !streams_run_concurrently(device, a, b)) {
+      aside[n_aside++] = b;
+      b = nullptr;
+      err = hipStreamCreateWithFlags(&b, hipStreamNonBlocking);
+    }
+    for (int k = 0; k < n_aside; ++k) (void)hipStreamDestroy(aside[k]);
+    if (err != hipSuccess) {
+      if (a) (void)hipStreamDestroy(a);
+      if (b) (void)hipStreamDestroy(b);
+      return fail(SHC_ERR_HIP, std::string("split streams: ") + hipGetErrorString(err));
     }
     if (getenv("SHC_DEBUG_STREAMS")) fprintf(stderr, "shc: split-stream pair of device %d found after %d replacement(s)\n", device, n_aside);
-    for (int k = 0; k < n_aside; ++k) (void)hipStreamDestroy(aside[k]);
+    pool[device][0] = a, pool[device][1] = b;
   }
   out[0] = pool[device][0], out[1] = pool[device][1];
   return SHC_OK;
@@ -2689,13 +2699,13 @@ static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_insta
   if (in) err = hipMemcpyAsync(d, in, bytes, hipMemcpyHostToDevice, e->stream);
   if (err == hipSuccess) {
     switch (e->NJ) {
-      case 3: if (in) set_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+      case 3: if (in) set_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, long_legs);
               else get_state_kernel<3><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown, long_legs);
               break;
-      case 4: if (in) set_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+      case 4: if (in) set_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, long_legs);
               else get_state_kernel<4><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown, long_legs);
               break;
-      default: if (in) set_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count);
+      default: if (in) set_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, long_legs);
                else get_state_kernel<5><<<grid, block, 0, e->stream>>>(d, e->st, e->cp, e->L, first, count, touchdown, long_legs);
                break;
     }

@@ -341,6 +341,19 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   return SHC_OK;
 }
 
+// A doorbell value releases every cycle below it in one go, and the relay looks for a direct-post record only while the doorbell has not
+// moved past its cycle: before ANY doorbell value that would pass a direct post is written - by shc_engine_resident_publish, by the post
+// kernel of an ordinary post with publish = 1, by shc_engine_resident_end - the relay must have installed that post's record (seen here as
+// "its cycle has completed").  Bounded; a loop that has stopped by itself ends the wait (the caller reports that).
+static int resident_wait_direct_installed(Resident *r) {
+  if (r->direct_last < 0) return SHC_OK;
+  const unsigned long long need = (unsigned long long)r->direct_last + 1;
+  if (!spin_until([&] { return host_load(&r->host->done) >= need || host_load(&r->host->exited) != 0; }, 5.0))
+    return fail(SHC_ERR_TIMEOUT, "resident mode: a direct post is still waiting to run");
+  r->direct_last = -1;
+  return SHC_OK;
+}
+
 // the device loop is still running (it has not stopped by itself)
 static int resident_alive(Resident *r) {
   if (const unsigned long long why = host_load(&r->host->exited))
@@ -455,6 +468,7 @@ extern "C" int shc_engine_resident_post(shc_engine *e, const shc_cycle_inputs *i
   // kernel rings the doorbell itself, one launch instead of two per loop iteration
   const bool publish = in->publish != 0;
   if (publish) {
+    if ((rc = resident_wait_direct_installed(r)) != SHC_OK) return rc; // (the post kernel rings the doorbell itself: the same rule as in publish)
     pp.doorbell = c + 1;
     pp.host = r->host_dev;
     pp.blocks_done = r->post_blocks_done;
@@ -488,12 +502,7 @@ extern "C" int shc_engine_resident_publish(shc_engine *e, int64_t n_cycles) {
   if (n_cycles == 0) return SHC_OK;
   if (r->published + (unsigned long long)n_cycles > r->max_cycles) return fail(SHC_ERR_INVALID_ARG, "resident mode: past max_cycles");
   // (a doorbell value releases everything below it in one go: it may only pass a direct post once the relay has installed that post's record)
-  if (r->direct_last >= 0) {
-    const unsigned long long need = (unsigned long long)r->direct_last + 1;
-    if (!spin_until([&] { return host_load(&r->host->done) >= need || host_load(&r->host->exited) != 0; }, 5.0))
-      return fail(SHC_ERR_TIMEOUT, "resident mode: a direct post is still waiting to run");
-    r->direct_last = -1;
-  }
+  if ((rc = resident_wait_direct_installed(r)) != SHC_OK) return rc;
   r->published += (unsigned long long)n_cycles;
   if (r->posted < r->published) r->posted = r->published; // cycles released without a post run with the inputs held
   if (r->stream_doorbell_pending) {
@@ -613,13 +622,12 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   Resident *r = e->res;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(r->in_stream)); // every post and stream-ordered doorbell has landed
-  if (r->direct_last >= 0) { // (as in publish: the doorbell passes a direct post only after the relay has installed it)
-    const unsigned long long need = (unsigned long long)r->direct_last + 1;
-    (void)spin_until([&] { return host_load(&r->host->done) >= need || host_load(&r->host->exited) != 0; }, 5.0);
-    r->direct_last = -1;
-  }
-  host_store(&r->host->doorbell, r->published);
-  host_store(&r->host->stop, r->published);
+  // (as in publish: the doorbell passes a direct post only after the relay has installed it.  A direct post that never ran - the loop is wedged -
+  //  is reported, and the stop request below still goes out: with the doorbell left where it is the loop stops at the cycles it has released)
+  const int direct_rc = resident_wait_direct_installed(r);
+  const std::string direct_msg = direct_rc != SHC_OK ? std::string(shc_last_error()) : std::string();
+  if (direct_rc == SHC_OK) host_store(&r->host->doorbell, r->published);
+  host_store(&r->host->stop, direct_rc == SHC_OK ? r->published : 0ull); // (0: the relay stops the loop at the cycles it has already released)
   // A loop that does not answer keeps the engine: while the kernel may still be running nothing else may touch the state planes, and
   // shc_engine_destroy must not free the rings under it.  The engine stays in resident mode (every other entry point returns
   // SHC_ERR_BUSY); a later shc_engine_resident_end tries again - the loop's own bounds (max_cycles, idle timeout, the workers'
@@ -660,6 +668,7 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
   if (cycles_run) *cycles_run = int64_t(done);
   if (r->groups_posted & (1u << RG_FORCE)) e->rt_flags |= RT_TOUCHDOWN; // as shc_engine_set_tip_force (state_controller.cpp:1642)
   if (err != hipSuccess) return fail(SHC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
+  if (direct_rc != SHC_OK) return fail(direct_rc, direct_msg + " (the loop was stopped after " + std::to_string(done) + " cycles)");
   if (reason == RESIDENT_EXIT_FAULT || host_load(&r->host->fault) != 0)
     return fail(SHC_ERR_HIP, "resident mode: a wavefront gave up waiting for the relay; restore the engine from a snapshot");
   if (host_load(&r->host->late_reads) != 0)

@@ -124,6 +124,20 @@ __device__ __forceinline__ void admittance_prologue_dev(const LegIO<NJ> &io, con
   io.put3(FD::ADM_DELTA, projection(V3{d[0], d[1], d[2]}, base_rotate(lc, ch.xe))); // Leg::setAdmittanceDelta (model.h:365-368)
 }
 
+// LegStepper::target_tip_pose_.rotation_ of ONE leg (pose_controller.cpp:238, :377: leg_stepper->getTargetTipPose().rotation_): the identity tip
+// rotation only on legs of more than 3 joints (walk_controller.cpp:37), UNDEFINED (the zero quaternion) on a shorter leg - on a robot whose
+// legs differ in DOF that is a per-leg fact of the padded chain (LegConst::jactive), not of the kernel's NJ.
+template <int NJ>
+__device__ __forceinline__ Quat leg_target_rotation(const LegConst<NJ> &lc, const Quat robot_target_rotation) {
+  if constexpr (NJ > 3) {
+    if (lc.jactive[3] == 0.0) return Quat{0, 0, 0, 0};
+    return robot_target_rotation;
+  } else {
+    (void)lc;
+    return robot_target_rotation; // (SeqParams::target_rotation is only set where the robot's longest leg has more than 3 joints)
+  }
+}
+
 template <int L, int NJ>
 __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *gc, SeqRobotState *seq, int sequence /* 0 START_UP, 1 SHUT_DOWN */,
                                         SeqParams P, int32_t *progress_out) {
@@ -201,7 +215,7 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
         s.leg[l].completed = 0;
         V3 target = transition_target(l, io);
         target.z = leg_current_tip_pose<NJ>(io, gc->leg[l]).p.z; // maintain horizontal position
-        put_pose7(s.leg[l].target, target, target_rotation);
+        put_pose7(s.leg[l].target, target, leg_target_rotation<NJ>(gc->leg[l], target_rotation));
       }
     }
     double height = 0.0; // Model::legsBearingLoad (model.cpp:78-88)
@@ -262,7 +276,7 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
         V3 target = transition_target(l, io);
         const V3 tip = leg_current_tip_pose<NJ>(io, gc->leg[l]).p;
         target.x = tip.x, target.y = tip.y; // maintain horizontal position
-        put_pose7(s.leg[l].target, target, target_rotation);
+        put_pose7(s.leg[l].target, target, leg_target_rotation<NJ>(gc->leg[l], target_rotation));
       }
     }
     bool all_legs_within_workspace = true;
@@ -330,7 +344,7 @@ __global__ void step_to_new_stance_kernel(DevState st, const SharedConsts<L, NJ>
     if ((l % 2) != s.current_group) continue;
     const LegIO<NJ> io{st, slot_of(rob, l, L)};
     double target[7];
-    put_pose7(target, io.get3(FD::DFLT), target_rotation); // leg_stepper->getDefaultTipPose()
+    put_pose7(target, io.get3(FD::DFLT), leg_target_rotation<NJ>(gc->leg[l], target_rotation)); // leg_stepper->getDefaultTipPose()
     Pose tip;
     progress = step_to_position_dev<NJ>(st, io, gc->leg[l], target, current_pose, P.swing_height, 1.0 / P.step_frequency, 1, P.have_adm, P.dt, tip, leg_state_of(st, rob, l));
     put_pose7(s.leg[l].current, tip);

@@ -128,7 +128,9 @@ __global__ void get_state_kernel(shc_instance_state *out, DevState st, CyclePara
 }
 
 template <int NJ>
-__global__ void set_state_kernel(const shc_instance_state *in, DevState st, CycleParams P, int L, int64_t first, int64_t count) {
+__global__ void set_state_kernel(const shc_instance_state *in, DevState st, CycleParams P, int L, int64_t first, int64_t count, unsigned long_legs) {
+  // long_legs: as in get_state_kernel - a shorter leg of a gravity-aligned robot tracks no tip rotation: its direction planes and word bits stay
+  // what the engine holds (the record carries zeros for them), so that get_state -> set_state is the identity on every leg
   using FD = Fields<NJ>;
   using R = RobotFields;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -200,7 +202,7 @@ __global__ void set_state_kernel(const shc_instance_state *in, DevState st, Cycl
     else if (g.stance_progress == 0.0) pm = PM_STOP;
     int w = (g.step_state & 3) | (g.at_correct_phase ? LW_ACP : 0) | (g.completed_first_step ? LW_CFS : 0) | (pm << LW_PM_SHIFT) |
             (g.negate_auto_pose ? LW_NEG : 0) | (g.ik_failed ? LW_IKFAIL : 0) | ((g.phase & LW_PHASE_MASK) << LW_PHASE_SHIFT);
-    if (P.gravity_aligned || P.joint_control == 2) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
+    if ((P.gravity_aligned && ((long_legs >> l) & 1u)) || P.joint_control == 2) { // tip rotations tracked (joint_control: a MANUAL 3-joint leg holds its FK tip rotation)
       for (int k = 0; k < 3; ++k) {
         f(FD::ORG_DIR + k, g.origin_tip_direction[k]);
         f(FD::CUR_DIR + k, g.walker_tip_direction[k]);

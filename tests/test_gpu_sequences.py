@@ -139,7 +139,7 @@ def test_transition_configuration(Engine):
 
 
 @pytest.mark.parametrize("forced", [True, False], ids=["teacher-forced", "free-running"])
-@pytest.mark.parametrize("case", ["hexapod-tripod", "6x4-ripple", "8x5-ripple", "hexapod-perturbed-joints", "mixed-dof-354354"])
+@pytest.mark.parametrize("case", ["hexapod-tripod", "6x4-ripple", "8x5-ripple", "hexapod-perturbed-joints", "mixed-dof-354354", "mixed-dof-354354-gravity-aligned"])
 def test_execute_sequence_start_up_shut_down_start_up(case, forced):
     """PoseController::executeSequence (pose_controller.cpp:145-459), every call compared with the oracle: the first START_UP
     from the READY configuration generates the sequence (horizontal / vertical transitions until the default stance is
@@ -164,6 +164,8 @@ def test_execute_sequence_start_up_shut_down_start_up(case, forced):
     elif case.startswith("mixed"):   # legs of 3 / 5 / 4 joints in one robot (the engine pads the shorter legs, the oracle runs each leg's own chain)
         from syropod_highlevel_controller_amd import synthetic_mixed_dof_params
         p = synthetic_mixed_dof_params("ripple")
+        if "gravity" in case:   # the sequence targets carry the identity tip rotation on the 5- / 4-joint legs only: a 3-joint leg's stays UNDEFINED
+            p.gravity_aligned_tips = 1   # (leg_stepper->getTargetTipPose().rotation_, pose_controller.cpp:238, :377; walk_controller.cpp:37)
         if not forced:
             pytest.skip("redundant chains drift along their null space free-running (covered by 8x5-ripple)")
     else:
