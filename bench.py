@@ -197,13 +197,107 @@ class ParityWindow:
                     ob.set_tip_force(force * k)
             obs.append(ob.joints()[0])
         q_cpu, q_twin = obs
-        dq = np.abs(np.asarray(q_gpu)[:m] - q_cpu).max(axis=1)
+        q_gpu = np.asarray(q_gpu)[:m]
+        if q_cpu.shape != q_gpu.shape:   # a robot whose legs differ in DOF: the oracle packs each leg's own joints, the engine's rows are [legs][longest DOF]
+            L, D = self.p.leg_count, q_gpu.shape[1] // self.p.leg_count
+
+            def padded(a):
+                out, at = np.zeros((m, L, D)), 0
+                for l in range(L):
+                    d = self.p.leg_dof[l]
+                    out[:, l, :d] = a[:, at:at + d]
+                    at += d
+                return out.reshape(m, L * D)
+            q_cpu, q_twin = padded(q_cpu), padded(q_twin)
+        dq = np.abs(q_gpu - q_cpu).max(axis=1)
         well = np.abs(q_cpu - q_twin).max(axis=1) <= 1e-9
         return {"max_abs_dq": float(dq[well].max()) if well.any() else None, "max_abs_dq_all_instances": float(dq.max()), "unit": "rad",
                 "instances": int(m), "cycles": int(n_cycles), "well_posed_fraction": float(well.mean()), "tolerance": 1e-6,
                 "against": "CPU oracle (oracle/shc_oracle.c) started from the engine's state record at the start of the timed window, same inputs, "
                            "free-running over the window; max_abs_dq over the instances whose reference trajectory is well-posed "
                            "(a twin oracle with inputs x (1 + 1e-13) stays within 1e-9 rad), max_abs_dq_all_instances over all of them"}
+
+
+def fused_k_probe(eng, p, n, lin, ang, extra, key, stream, K=16, reps=8, want_parity=True):
+    """Secondary figure for batches that do not fit the chip once: K control cycles per launch, EACH WITH ITS OWN INPUTS (shc_engine_step_k: the
+    node's loop delivers new callbacks' inputs in every iteration, src/main.cpp:106-131) - cycle k reads row k of K-deep device arrays (a new
+    velocity command for every robot, and whatever else the workload feeds: IMU sample, tip force, joint torques) and writes its q / qd to slot
+    k of the output ring; the controller state is loaded once, stays in registers / LDS for the K cycles and is stored once.
+    Bytes per SURVEY.md section 8(d) ("if K cycles are fused per launch ... report K and count accordingly"): the state once per launch + K x
+    (the cycle's inputs + the published q, qd).  Parity: the oracle replays the same K input rows from the engine's state record."""
+    import torch
+    L, D = p.leg_count, p.leg_dof[0]
+    ks = np.arange(K)
+    rows = {"lin": lin[None] * (0.85 + 0.15 * np.cos(0.4 * ks))[:, None, None], "ang": ang[None] * (0.85 + 0.15 * np.sin(0.3 * ks))[:, None]}
+    in_bytes = 24
+    if "imu_q" in extra:
+        rows["imu_q"] = np.repeat(extra["imu_q"][None], K, axis=0)
+        rows["gyro"] = extra["gyro"][None] * (1.0 + 0.05 * ks)[:, None, None]
+        in_bytes += 56
+    if "force_sets" in extra:
+        rows["force"] = np.stack([extra["force_sets"][k % len(extra["force_sets"])] for k in range(K)])
+        in_bytes += L * 24
+    if "effort" in extra:
+        rows["effort"] = extra["effort"][None] * (1.0 + 0.02 * ks)[:, None, None]
+        in_bytes += L * D * 8
+    dev = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in rows.items()}
+    torch.cuda.synchronize()
+    ptr = lambda k: dev[k].data_ptr() if k in dev else None
+
+    def launch():
+        eng.step_k(K, velocity=(ptr("lin"), ptr("ang")), imu=(ptr("imu_q"), ptr("gyro")) if "imu_q" in dev else None, tip_force=ptr("force"), joint_effort=ptr("effort"))
+
+    parity = None
+    if want_parity:
+        from oracle_lib import OracleBatch
+        m, eps, threads = min(PARITY_INSTANCES, n), 1e-13, min(os.cpu_count() or 1, 32)
+        eng.synchronize()
+        st0 = eng.get_state(0, m)
+        launch()
+        q_gpu = eng.step_k_joints(K - 1)[0][:m]
+        obs = []
+        for twin in (False, True):
+            ob = OracleBatch(p, m)
+            ob.set_state(st0)
+            kk = 1.0 + (eps if twin else 0.0)
+            for k in range(K):
+                ob.set_velocity(rows["lin"][k][:m] * kk, rows["ang"][k][:m])
+                if "imu_q" in rows:
+                    ob.set_imu(rows["imu_q"][k][:m], rows["gyro"][k][:m])
+                if "force" in rows:
+                    ob.set_tip_force(rows["force"][k][:m] * kk)
+                if "effort" in rows:
+                    ob.set_joint_effort(rows["effort"][k][:m])
+                ob.step(1, threads)
+            obs.append(ob.joints()[0])
+        dq = np.abs(q_gpu - obs[0]).max(axis=1)
+        well = np.abs(obs[0] - obs[1]).max(axis=1) <= 1e-9
+        parity = {"max_abs_dq": float(dq[well].max()) if well.any() else None, "max_abs_dq_all_instances": float(dq.max()), "unit": "rad", "instances": int(m),
+                  "cycles": K, "well_posed_fraction": float(well.mean()), "tolerance": 1e-6,
+                  "against": "CPU oracle from the engine's state record before one launch, the same K input rows set before each of its cycles; the engine's joints "
+                             "are slot K - 1 of the launch's output ring"}
+    for _ in range(2):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(reps):
+        launch()
+    eng.join()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    launch_ms = e0.elapsed_time(e1) / reps
+    out_bytes = 2 * L * D * 8
+    alg = n * (ALG_BYTES_PER_CYCLE[key] + K * (in_bytes + out_bytes))
+    ach = alg / (launch_ms * 1e-3) / 1e9
+    return {"value": n * K * reps / wall, "K": K, "launches": reps, "ms_per_launch": launch_ms, "ms_per_cycle": launch_ms / K,
+            "inputs_per_cycle": sorted(rows.keys()), "parity": parity,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "shc_resident_kernel, batch form (shc_engine_step_k)", "kernel_ms": launch_ms, "algorithmic_bytes_per_launch": alg,
+                         "algorithmic_bytes_are": f"state once per launch ({ALG_BYTES_PER_CYCLE[key]} B per robot) + K x (inputs {in_bytes} B + published q, qd {out_bytes} B)"},
+            "note": "K cycles per launch with a new input set in every cycle, read from K-deep device arrays; q / qd of every cycle in a K-deep output ring"}
 
 
 def measured_traffic(workload, n, cps):
@@ -218,6 +312,25 @@ def measured_traffic(workload, n, cps):
         return t.get(f"{workload}:{n}:{cps}")
     except Exception:
         return None
+
+
+def measured_valu(workload, n, cps):
+    """Issue-side roofline from the same PMC passes (scripts/summarize_prof.py): the share of the chip's VALU issue slots the kernel used and the
+    share of a wavefront's lifetime its vector ALU was issuing; null when the committed figures belong to different kernel sources."""
+    v = measured_traffic(workload, f"{n}", f"{cps}#valu")
+    return v if isinstance(v, dict) else None
+
+
+def with_issue_side(roofline, valu):
+    """SURVEY.md section 8(d) "report VALUBusy alongside GB/s": adds the VALU-issue fraction and names the bound by the larger of the two fractions."""
+    roofline["valu_issue_frac"] = valu["valu_issue_frac"] if valu else None
+    roofline["valu_issue_share_per_wave"] = valu["valu_issue_share_per_wave"] if valu else None
+    roofline["hbm_frac"] = roofline["frac"]
+    if valu and valu["valu_issue_frac"] > roofline["frac"]:
+        roofline["bound"] = "valu-issue"
+    roofline["bound_is"] = ("the larger of hbm_frac (algorithmic bytes / duration / 8 TB/s) and valu_issue_frac (rocprofv3 SQ_ACTIVE_INST_VALU over the chip's 1 024 SIMD issue "
+                            "slots, profiles/traffic.json, same kernel sources); `frac` stays the HBM fraction the contract defines")
+    return roofline
 
 
 def resident_bytes_per_cycle(p):
@@ -574,6 +687,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     kern_ms = min(per_launch_ms, e0.elapsed_time(e1) / m)
     # ---- secondary figure: 16 control cycles fused per launch (inputs held, state in registers between cycles)
     fused_value = None
+    fused_k = None
     if cps == 1 and world == 1 and fused_probe:
         fc, reps = 16, max(4, steps // 16)
         for _ in range(3):
@@ -584,6 +698,11 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             eng.step(fc)
         torch.cuda.synchronize()
         fused_value = n * fc * reps / (time.perf_counter() - tf0)
+        if not resident:   # ... and the same K with a NEW input set in every cycle (what StateController::loop sees: callbacks every iteration)
+            try:
+                fused_k = fused_k_probe(eng, p, n, lin, ang, extra, key, stream, K=fc, reps=reps, want_parity=want_parity)
+            except Exception as exc:  # noqa: BLE001  (a configuration without a loop-form kernel: reported, not fatal)
+                fused_k = {"error": str(exc)}
     # ---- secondary figure for batches large enough for the engine's two-stream split (shc_engine_step): the same steps as ONE launch
     #      each on the engine's stream (SHC_FEAT_SINGLE_STREAM), i.e. what round 2 measured as the primary figure
     single_stream = None
@@ -611,6 +730,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                        "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": ("shc_cycle_half_kernel<walker half> + <model half> (a rotation-constrained cycle is two launches, two wavefronts per SIMD each)" if name == "gravity" and n_waves >= 2048 else "shc_cycle_kernel")
                                  + (" (a step = that for each half of the batch, the halves on two streams)" if n_waves >= 4096 else ""),
                        "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes}
+    launch_roofline = with_issue_side(launch_roofline, None if joint_efforts else measured_valu(name, n, cps))
     if resident:
         rb = resident_bytes_per_cycle(p) * n
         r_ach = rb / res_cycle_s / 1e9
@@ -623,6 +743,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                                    "phase ablation in profiles/r04_probe_resident_ablation.txt"),
                     "state_streaming_equivalent_frac": ALG_BYTES_PER_CYCLE[key] * n / res_cycle_s / 1e9 / HBM_PEAK_GBS,
                     "one_launch_per_cycle": launch_roofline}
+        roofline = with_issue_side(roofline, measured_valu(name + ":resident", n, cps))
     else:
         roofline = launch_roofline
     res = {
@@ -647,6 +768,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                    "gather_ms": gather_s * 1e3 if gather_s is not None else None,
                    "gather_bytes_per_rank": int(qshard.numel() * 8) if use_dist else None,
                    "moving_fraction": moving_frac, "finite": finite, "seed": seed, "fused_16_cycles_per_launch_value": fused_value,
+                   "fused_K_with_per_cycle_inputs_value": (fused_k or {}).get("value"), "fused_K_with_per_cycle_inputs": fused_k,
                    "two_stream_split": n_waves >= 4096, "single_stream": single_stream},
         "roofline": roofline,
     }
@@ -671,7 +793,7 @@ def config5_bytes(legs, dof):
     return 2 * (sum((2 * d + 24) * 8 + 4 for d in dofs) + 28) + 24
 
 
-def run_config5(n, steps, warmup, seed):
+def run_config5(n, steps, warmup, seed, want_parity=True):
     """BASELINE.json configs[4]: mixed morphologies (4 / 6 / 8 legs, 3 - 5 joints - one bin with legs of 3, 5 and 4 joints in the same
     robot -, all four gaits), instance i has morphology i mod 6 - the worst interleaving for a one-kernel design.  shc_fleet_create bins the instances (one engine + one HIP stream
     per morphology), so the device work is the same whatever the order; the interleaved and the sorted ("binned") order differ
@@ -683,6 +805,7 @@ def run_config5(n, steps, warmup, seed):
     lin, ang = velocity_inputs(seed ^ 0x5EED5, 0, n)
     out = {}
     alg = 0
+    parity = None
     for order in ("interleaved", "binned"):
         mid = np.arange(n) % len(morphs) if order == "interleaved" else np.sort(np.arange(n) % len(morphs))
         fleet = MixedFleet(morphs, mid)
@@ -695,6 +818,12 @@ def run_config5(n, steps, warmup, seed):
             fleet.step(1)
         fleet.synchronize()
         torch.cuda.synchronize()
+        windows = []
+        if want_parity and order == "interleaved":   # the first PARITY_INSTANCES robots of every bin against the oracle over the timed window (untimed set-up)
+            from syropod_highlevel_controller_amd.engine import BatchEngine
+            for handle, mk, _dev, ids in fleet.parts():
+                view = BatchEngine.view(handle, morphs[mk], len(ids))
+                windows.append((mk, view, ParityWindow(view, morphs[mk], lin[ids], ang[ids], {})))
         t0 = time.perf_counter()
         for _ in range(steps):
             fleet.step(1)
@@ -703,6 +832,18 @@ def run_config5(n, steps, warmup, seed):
         t0 = time.perf_counter()
         q, _ = fleet.joints()
         t_out = time.perf_counter() - t0
+        if windows:
+            per_bin = []
+            for mk, view, pw in windows:
+                r = pw.evaluate(steps, view.joints()[0])
+                r["bin"] = list(CONFIG5_BINS[mk]) if not isinstance(CONFIG5_BINS[mk][1], tuple) else [CONFIG5_BINS[mk][0], list(CONFIG5_BINS[mk][1]), CONFIG5_BINS[mk][2]]
+                per_bin.append(r)
+            ok = [r for r in per_bin if r["max_abs_dq"] is not None]
+            parity = {"max_abs_dq": max(r["max_abs_dq"] for r in ok) if ok else None, "max_abs_dq_all_instances": max(r["max_abs_dq_all_instances"] for r in per_bin),
+                      "unit": "rad", "instances": sum(r["instances"] for r in per_bin), "cycles": steps, "tolerance": 1e-6,
+                      "well_posed_fraction": float(np.mean([r["well_posed_fraction"] for r in per_bin])),
+                      "against": per_bin[0]["against"] + "; per morphology bin below", "window": f"the {steps} timed fleet steps", "bins": [
+                          {k: r[k] for k in ("bin", "max_abs_dq", "max_abs_dq_all_instances", "well_posed_fraction", "instances")} for r in per_bin]}
         moving = float((fleet.walk_state() == 1).mean())
         alg = sum(int((mid == k).sum()) * config5_bytes(l, d) for k, (l, d, g) in enumerate(CONFIG5_BINS))
         out[order] = {"value": n * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "moving_fraction": moving,
@@ -712,12 +853,12 @@ def run_config5(n, steps, warmup, seed):
     achieved = alg / (r["ms_per_step"] * 1e-3) / 1e9
     return {"workload": f"BASELINE.json config5: {n} mixed-morphology robots (legs x dof, gait) = {list(CONFIG5_BINS)}, instance i -> bin i mod {len(CONFIG5_BINS)}, "
                         "binned by shc_fleet_create onto one engine + HIP stream per morphology", "value": r["value"], "unit": "control-cycles/s",
-            "steps": steps, "ms_per_step": r["ms_per_step"], "moving_fraction": r["moving_fraction"], "finite": r["finite"],
+            "steps": steps, "ms_per_step": r["ms_per_step"], "moving_fraction": r["moving_fraction"], "finite": r["finite"], "parity": parity,
             "interleaved_vs_binned": out,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("config5", n, 1),
-                         "kernel": f"shc_cycle_kernel x {len(CONFIG5_BINS)} morphologies on concurrent streams (wall clock per fleet step, not a single launch)",
-                         "algorithmic_bytes_per_launch": alg}}
+            "roofline": with_issue_side({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                         "traffic": measured_traffic("config5", n, 1),
+                                         "kernel": f"shc_cycle_kernel x {len(CONFIG5_BINS)} morphologies on concurrent streams (wall clock per fleet step, not a single launch)",
+                                         "algorithmic_bytes_per_launch": alg}, measured_valu("config5", n, 1))}
 
 
 def main():
@@ -769,7 +910,7 @@ def main():
     if args.workload == "config5":
         if world > 1:
             raise SystemExit("config5 is a single-GPU workload here (the fleet shards in-process: shc_fleet_create device_ids)")
-        r = run_config5(n, args.steps, args.warmup, args.seed)
+        r = run_config5(n, args.steps, args.warmup, args.seed, want_parity=not args.no_parity)
         print(json.dumps({"metric": "control-cycles/sec (all legs IK-solved)", "value": r["value"], "unit": "control-cycles/s", "n_gpus": 1,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -802,7 +943,7 @@ def main():
                          "two_stream_split": r["config"]["two_stream_split"], "single_stream": r["config"]["single_stream"],
                          "roofline": r["roofline"], "parity": r["parity"]})
         try:
-            also.append(run_config5(DEFAULT_INSTANCES["config5"], 100, 10, args.seed))
+            also.append(run_config5(DEFAULT_INSTANCES["config5"], 100, 10, args.seed, want_parity=not args.no_parity))
         except Exception as exc:  # noqa: BLE001
             also.append({"workload": "config5", "error": str(exc)[:200]})
     if rank == 0:

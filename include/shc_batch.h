@@ -169,7 +169,7 @@ enum {
  * Library/device introspection.  shc_device_count() returns the number of visible HIP devices
  * (0 when none; never an error) so a caller can fail loudly before creating an engine.
  */
-int shc_abi_version(void); /* 4: shc_cycle_inputs.direct + shc_engine_resident_bind_inputs (launch-free posts); 3: resident mode, join, auxiliary state */
+int shc_abi_version(void); /* 5: shc_engine_step_k / shc_engine_get_step_k_joint_state (K cycles per launch, each with its own inputs); 4: shc_cycle_inputs.direct + shc_engine_resident_bind_inputs (launch-free posts); 3: resident mode, join, auxiliary state */
 /* sizeof(shc_params) / sizeof(shc_tables) as compiled into the library: lets a foreign-language binding check its layout */
 int64_t shc_sizeof_params(void);
 int64_t shc_sizeof_tables(void);
@@ -360,6 +360,26 @@ int shc_engine_resident_get_joint_state(shc_engine *e, int64_t cycle, double *q,
 int shc_engine_resident_get_joint_state_async(shc_engine *e, int64_t cycle, double *q, double *qd, int timeout_ms);
 int shc_engine_resident_status(shc_engine *e, int64_t *published, int64_t *completed, int32_t *running);
 int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run);
+
+/*
+ * K loop iterations in ONE launch, each with its own inputs - for batches of any size (resident mode needs the whole batch on the chip at
+ * once; this does not).  What `for (k = 0; k < K; ++k) { callbacks deliver inputs[k]; StateController::loop(); publish the desired joint state; }`
+ * (src/main.cpp:106-131, src/state_controller.cpp:162-193, :777-805) does, with the state loaded once, kept in registers / LDS for the K cycles and
+ * stored once: per cycle only that cycle's inputs are read and its q / qd written.
+ *   inputs (may be NULL = every input held): DEVICE arrays (on_device = 1) of K rows each - linear_xy [K][n][2] + angular [K][n],
+ *     imu_orientation_wxyz [K][n][4] + imu_angular_velocity [K][n][3], tip_force [K][n][legs][3], joint_effort [K][n][legs][dof]; a NULL member
+ *     is held at what the engine has.  Row k is what shc_engine_set_velocity / set_imu / set_tip_force / set_joint_effort would have been given
+ *     before cycle k (in rough terrain mode Leg::touchdownDetection runs on the fresh tip force inside the loop, model.cpp:712-722).  Pose
+ *     inputs / reset modes are not carried (set them before the call; they are held).  The arrays are read while the launch runs: keep them
+ *     unchanged until the engine's stream has passed it.  After the call the last row is the engine's held input.
+ *   The result is bit-identical to K x { setters with row k; shc_engine_step(e, 1) } - state record and the q / qd of every cycle.
+ *   shc_engine_get_step_k_joint_state(e, k, q, qd, on_device): q / qd [n][legs][dof] of cycle k (0 .. K - 1) of the latest launch
+ *     (stream-ordered; the ring is overwritten by the next shc_engine_step_k).  shc_engine_get_joint_state returns cycle K - 1 as usual.
+ * SHC_ERR_UNSUPPORTED: the configuration runs on a tip-align-pose / manual-leg kernel (use shc_engine_step).  1 <= K <= 4096, and
+ * K x n x legs x dof x 16 B must stay below 2 GiB.
+ */
+int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_inputs *inputs);
+int shc_engine_get_step_k_joint_state(shc_engine *e, int k, double *q, double *qd, int on_device);
 
 /*
  * Outputs read after the cycle (state_controller.cpp:777-805 publishDesiredJointState).

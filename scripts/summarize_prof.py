@@ -56,6 +56,10 @@ def kernel_stats(dirn, out):
     return med
 
 
+def per_step_launches(per_step):
+    return 1.0   # (counters and duration are both per launch; kept as a hook for the forms whose step is several launches)
+
+
 PAIRS = False  # argv[4] == "pairs": a cycle = the walker-half launch + the model-half launch (shc_cycle_half_kernel<..., 1 / 2>), on each of the two
                # halves of the batch: durations and counters are summed over the two kernels, a step is two such pairs
 FLEET = False  # argv[4] == "fleet": a step = one launch of EACH morphology bin's kernel on concurrent streams; counters are summed over the bins
@@ -155,21 +159,33 @@ if __name__ == "__main__":
         out.write(f"LDS bank-conflict share of LDS-active cycles = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = "
                   f"{lds.get('SQ_LDS_BANK_CONFLICT', 0) / lds['SQ_LDS_IDX_ACTIVE']:.3f}; LDS instructions per wave = "
                   f"{lds.get('SQ_INSTS_LDS', 0) / max(lds.get('SQ_WAVES', 1), 1):.0f}\n")
+    valu = None
     if dur:
         out.write(f"kernel duration (kernel_trace): mean {dur[0]:.0f} ns, median {dur[1]:.0f} ns over {dur[2]} launches\n")
+        if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_WAVE_CYCLES"):
+            # the issue-side roofline (SURVEY.md section 8d "report VALUBusy alongside GB/s"): SQ_ACTIVE_INST_VALU counts, in 4-clock units, the time a
+            # SIMD's vector ALU is issuing for some wave; the chip has 1 024 SIMDs (256 CUs x 4), each with one such slot per 4 clocks at 2.4 GHz
+            slots = 1024.0 * dur[0] * 2.4 / 4.0 * per_step_launches(per_step)
+            valu = {"valu_issue_share_per_wave": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], "valu_issue_frac": sq["SQ_ACTIVE_INST_VALU"] * per_step_launches(per_step) / slots,
+                    "valu_insts_per_wave": sq.get("SQ_INSTS_VALU", 0) / max(sq.get("SQ_WAVES", 1), 1)}
+            out.write(f"VALU issue share of the chip = SQ_ACTIVE_INST_VALU / (1 024 SIMDs x kernel duration x 2.4 GHz / 4) = {valu['valu_issue_frac']:.3f} "
+                      f"(per wave: {valu['valu_issue_share_per_wave']:.3f} of its lifetime)\n")
     bl = f"{prof}/bench_line.json"
     if os.path.exists(bl):
         out.write("\n== bench.py line of the traced run (rocprofv3 --kernel-trace --stats -- python bench.py --steps 400 --warmup 40 "
                   "--no-cpu-baseline --no-fused-probe)\n" + open(bl).read())
     out.close()
-    if traffic:
+    if traffic or valu:
         tj = os.path.join(os.path.dirname(dest), "traffic.json")
         d = json.load(open(tj)) if os.path.exists(tj) else {}
-        d[key] = round(traffic)
+        if traffic:
+            d[key] = round(traffic)
+        if valu:
+            d[key + "#valu"] = {k: round(v, 4) for k, v in valu.items()}
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from syropod_highlevel_controller_amd.engine import _source_hash
         if d.get("_kernel_source_hash") != _source_hash():  # figures of an older kernel build are dropped, not mixed in
-            d = {key: round(traffic)}
+            d = {k: v for k, v in d.items() if k in (key, key + "#valu")}
         d["_kernel_source_hash"] = _source_hash()
         d["_note"] = ("HBM bytes per launch of shc_cycle_kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in KiB, each scaled by the "
                       "factor calibrated on shc_debug_plane_copy in the same run); written by scripts/summarize_prof.py from " + os.path.basename(dest))

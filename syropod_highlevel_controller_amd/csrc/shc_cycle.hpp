@@ -416,13 +416,16 @@ struct NoHook {
 // Launch-uniform switches of the parameter block as scalars.  Read from the LDS copy one by one where they are used, each costs a wavefront
 // that runs alone on its SIMD an LDS round trip before it can branch; read together once (per cycle() call, or once per launch by the resident
 // loop, which keeps its FrontToBack across cycles) they cost one.
-// (Only the model half's: on the walker half the same grouping cost more - scalar registers are the scarce resource there - than it saved.)
+// (Round 4 kept only the model half's: on the walker half the grouping cost more scalar registers than it saved.  With the two wavefronts in loops of
+//  their own - half the scalar spills - the walker's two switches belong here too: -2.7 % per resident cycle, profiles/r05_probe_walker_variants.txt.)
 struct UniFlags {
   int clamp_joint_velocities, clamp_joint_positions, swing_c_count;
+  int velocity_input_mode, force_normal_touchdown;
 };
 __device__ __forceinline__ UniFlags load_uni_flags(const CycleParams &P) {
   const int c = P.clamp_joint_velocities, d = P.clamp_joint_positions, e = P.swing_c_count;
-  return UniFlags{uni(c), uni(d), uni(e)};
+  const int f = P.velocity_input_mode, h = P.force_normal_touchdown;
+  return UniFlags{uni(c), uni(d), uni(e), uni(f), uni(h)};
 }
 
 // ------------------------------------------------------------------------------------------------- one control cycle
@@ -530,6 +533,21 @@ __device__ __forceinline__ double walk_plane_control_input(const int own_word, c
     }
   }
   return sel ? c : -1.0;
+}
+
+// The same control input in two steps for the resident pipeline: each lane's OWN candidate (its leg's table value / smoothStep, -1 when its leg
+// does not qualify) - a table read that nothing on the walker wavefront waits for - and the pick of the last qualifying leg of the group, which the
+// model wavefront makes when it reads the candidates.  Same value as walk_plane_control_input (the table holds smoothStep results, >= 0).
+template <int L, int NJ>
+__device__ __forceinline__ double walk_plane_control_candidate(const int own_word, const SharedConsts<L, NJ> &C, const CycleParams &P, const int swing_c_count_u) {
+  if (swing_c_count_u > 0) {
+    const int it_own = min(max(((own_word >> LW_PHASE_SHIFT) & LW_PHASE_MASK) - P.swing_start, 0), P.swing_c_count - 1);
+    const bool ok_own = ((own_word >> LW_PM_SHIFT) & 3) == PM_SWING && it_own < P.swing_c_valid;
+    const double c = C.swing_c[it_own];
+    return ok_own ? c : -1.0;
+  }
+  const double sp = swing_progress_of(own_word, P) * P.swing_progress_scaler;
+  return (sp >= 0 && sp <= 1.0) ? smooth_step(sp) : -1.0;
 }
 
 // PoseController::updateCurrentPose (pose_controller.cpp:811-859): walk-plane pose, manual / inclination / IMU / auto / tip-align pose
@@ -1041,7 +1059,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   // correctly rounded square root being monotone with sqrt(1) = 1) a stand-in with the same two answers saves the FP64 square root.
   const double lin_n2 = vin_x * vin_x + vin_y * vin_y;
   double lin_norm;
-  const int velocity_input_mode = uni(P.velocity_input_mode);
+  const int velocity_input_mode = fb.uf.velocity_input_mode;
   if (velocity_input_mode == 0 && __all(lin_n2 <= 1.0)) lin_norm = lin_n2 != 0.0 ? 0.5 : 0.0;
   else lin_norm = sqrt(lin_n2);
   if (!(SHC_DBG(P) & 32)) {
@@ -1242,7 +1260,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     // number of instructions, but three independent dependency chains for the scheduler to overlap - what a wavefront that runs alone on
     // its SIMD (resident mode) is short of.  Rough terrain (ground-contact nodes, step-plane targets, external targets) and
     // force_normal_touchdown keep the branching form.
-    const int force_normal_touchdown = uni(P.force_normal_touchdown);
+    const int force_normal_touchdown = fb.uf.force_normal_touchdown;
 #ifdef SHC_NO_STRAIGHT // (development: the branching form everywhere)
     const bool straight = false;
 #else

@@ -260,17 +260,18 @@ __device__ __forceinline__ const double *bound_array(const ResidentArgs &A, int 
 }
 // Where the per-leg inputs in force come from: src >= 0 a ring position, -1 the engine's own planes, <= -2 bound input set -2 - src
 // (the caller's arrays [n][legs][3] / [n][legs][dof]).  All wave-uniform selects.
+// row: the cycle's row of K-deep bound arrays (batch form: ResidentArgs::kstride doubles per row; 0 in the doorbell-driven loop)
 template <int L, int NJ>
 __device__ __forceinline__ LegInRing<NJ> leg_inputs_in_force(const ResidentArgs &A, const double *legd, const int src_force, const int src_effort, const int64_t ns,
-                                                             const uint32_t slot, const int64_t robot, const int leg) {
+                                                             const uint32_t slot, const int64_t robot, const int leg, const int64_t row = 0) {
   using FD = Fields<NJ>;
   LegInRing<NJ> in;
   const double *fplanes = src_force < 0 ? legd + int64_t(FD::FORCE_IN / 2) * ns * 2 : A.force + int64_t(src_force) * 2 * ns * 2;
   const double *eplanes = src_effort < 0 ? legd + int64_t(FD::EFFORT_IN / 2) * ns * 2 : A.effort + int64_t(src_effort) * (FD::NJE / 2) * ns * 2;
   in.force_ptr = fplanes + int64_t(slot) * 2, in.force_pair = ns * 2;
   in.effort_ptr = eplanes + int64_t(slot) * 2, in.effort_pair = ns * 2;
-  if (src_force <= -2) in.force_ptr = bound_array(A, -2 - src_force, BND_FORCE) + (robot * L + leg) * 3, in.force_pair = 2;
-  if (src_effort <= -2) in.effort_ptr = bound_array(A, -2 - src_effort, BND_EFFORT) + (robot * L + leg) * NJ, in.effort_pair = 2;
+  if (src_force <= -2) in.force_ptr = bound_array(A, -2 - src_force, BND_FORCE) + row * A.kstride[BND_FORCE] + (robot * L + leg) * 3, in.force_pair = 2;
+  if (src_effort <= -2) in.effort_ptr = bound_array(A, -2 - src_effort, BND_EFFORT) + row * A.kstride[BND_EFFORT] + (robot * L + leg) * NJ, in.effort_pair = 2;
   return in;
 }
 
@@ -296,7 +297,7 @@ __device__ __forceinline__ void ring_to_tile(const double *rec, double *tile_at,
 enum : int { ROBOT_NONE = 0, ROBOT_VEL = 1, ROBOT_POSE = 2, ROBOT_ALL = 3 }; // which per-robot input groups a wave copies into the tile
 template <int RPW, int ROBOT, bool LEG>
 __device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, const unsigned c, const u64 h0, const u64 h1, const int64_t wave, const int lane,
-                                                     double *tile, int32_t *tile_i, unsigned &dirty, ResidentHeld &held, const int64_t n_robots) {
+                                                     double *tile, int32_t *tile_i, unsigned &dirty, ResidentHeld &held, const int64_t n_robots, const int64_t row = 0) {
   using R = RobotFields;
   if (h0 != u64(c) + 1) return;
   const unsigned mask = unsigned(h1) & 0x7fffu;
@@ -306,7 +307,7 @@ __device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, cons
     if (ROBOT != ROBOT_NONE) {
       if ((ROBOT & ROBOT_VEL) && (mask & (1u << RG_VEL))) { // [n][2], [n]
         static_assert(R::WIN == R::VIN + 2, "velocity inputs are contiguous in the tile");
-        const double *lin = bound_array(A, set, BND_LIN), *ang = bound_array(A, set, BND_ANG);
+        const double *lin = bound_array(A, set, BND_LIN) + row * A.kstride[BND_LIN], *ang = bound_array(A, set, BND_ANG) + row * A.kstride[BND_ANG];
         const int field = lane / RPW, r = lane - field * RPW;
         const int64_t rob = wave * RPW + r;
         if (lane < 3 * RPW && rob < n_robots) tile[(R::VIN + field) * RPW + r] = field < 2 ? ld_agent_f64(lin + rob * 2 + field) : ld_agent_f64(ang + rob);
@@ -314,7 +315,7 @@ __device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, cons
       if ((ROBOT & ROBOT_POSE) && (mask & (1u << RG_IMU))) { // [n][4], [n][3]
         const int64_t rob = wave * RPW + lane;
         if (lane < RPW && rob < n_robots) { // Model::setImuData as shc_engine_set_imu stores it: the orientation normalised
-          const double *q = bound_array(A, set, BND_IMUQ) + rob * 4, *w = bound_array(A, set, BND_IMUW) + rob * 3;
+          const double *q = bound_array(A, set, BND_IMUQ) + row * A.kstride[BND_IMUQ] + rob * 4, *w = bound_array(A, set, BND_IMUW) + row * A.kstride[BND_IMUW] + rob * 3;
           const Quat qn = normalized(Quat{ld_agent_f64(q), ld_agent_f64(q + 1), ld_agent_f64(q + 2), ld_agent_f64(q + 3)});
           tile[(R::IMUQ + 0) * RPW + lane] = qn.w, tile[(R::IMUQ + 1) * RPW + lane] = qn.x, tile[(R::IMUQ + 2) * RPW + lane] = qn.y, tile[(R::IMUQ + 3) * RPW + lane] = qn.z;
 #pragma unroll
@@ -371,12 +372,17 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
   const u64 emergency_ticks = 4 * A.idle_ticks + 2000 * A.ticks_per_ms; // a worker never waits longer than this for the relay (2 s + 4 idle timeouts)
   unsigned c = 0, oslot = 0; // cycles completed; output ring position of cycle c
-  u64 gate = uni64(ld_agent(&A.ctl->gate));
+  const bool batch = A.batch_cycles != 0; // (launch-uniform: a kernel argument) K cycles, released from the start, inputs row c of K-deep arrays
+  u64 gate = batch ? ((u64(A.batch_cycles) << 32) | A.batch_cycles) : uni64(ld_agent(&A.ctl->gate));
   u64 h0 = 0, h1 = 0;
   bool hdr_valid = false;
   for (;;) {
     unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
-    if (!(c < db && c < sp)) {
+    if (batch) {
+      if (c >= sp) break;
+      h0 = u64(c) + 1, h1 = u64(A.batch_mask) | kResidentDirect; // what a direct post of set 0 would have left in the header ring
+      hdr_valid = true;
+    } else if (!(c < db && c < sp)) {
       if (c >= sp) break;
       // nothing to run yet: the outputs of cycle c - 1 would otherwise be announced half a cycle into cycle c - announce them now
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -402,18 +408,20 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
       h1 = uni64(ld_agent(hp + 1));
     }
     // prefetch for the next iteration: the gate, and - once the doorbell is known to cover it - the header of cycle c + 1
-    const u64 gate_next_v = ld_agent(&A.ctl->gate);
-    const bool next_valid = db > c + 1;
+    const u64 gate_next_v = batch ? gate : ld_agent(&A.ctl->gate);
+    const bool next_valid = !batch && db > c + 1;
     u64 n0v = 0, n1v = 0;
     if (next_valid) {
       const u64 *hp = reinterpret_cast<const u64 *>(A.headers + ((c + 1) & (kResidentHeaders - 1)));
       n0v = ld_agent(hp);
       n1v = ld_agent(hp + 1);
     }
-    resident_take_inputs<64 / L, ROBOT_ALL, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
-    const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg);
+    const int64_t row = batch ? int64_t(c) : 0;
+    resident_take_inputs<64 / L, ROBOT_ALL, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots, row);
+    const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg, row);
     // half a cycle after the output stores of cycle c - 1 were issued they have drained: publish "c cycles done"
     const auto publish_previous = [&]() {
+      if (batch) return; // (nobody watches the progress of a batch launch: the stream does)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) st_agent(A.progress + wave, u64(c));
     };
@@ -461,8 +469,10 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
     hdr_valid = next_valid;
     if (next_valid) h0 = uni64(n0v), h1 = uni64(n1v);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (lane == 0) st_agent(A.progress + wave, u64(c));
+  if (!batch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) st_agent(A.progress + wave, u64(c));
+  }
   held.cycles = c;
 }
 
@@ -472,7 +482,8 @@ __device__ __forceinline__ void carry_leg_inputs(const ResidentArgs &A, const De
   using FD = Fields<NJ>;
   constexpr int RPW = 64 / L;
   double2 *planes = reinterpret_cast<double2 *>(st.legd);
-  const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg);
+  const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg,
+                                                      A.batch_cycles ? int64_t(A.batch_cycles) - 1 : 0); // (batch form: the last cycle's row stays in force)
   if (held.src_force != -1) {
     const V3 f = in.force();
     planes[(FD::FORCE_IN / 2) * ns + slot] = double2{f.x, f.y};
@@ -502,7 +513,7 @@ __device__ __forceinline__ void resident_epilogue(const ResidentArgs &A, const D
   }
   if ((held.seen & (1u << RG_RESET)) && lane < RPW) gtile_i[R::I_RESET_MODE * RPW + lane] = tile_i[R::I_RESET_MODE * RPW + lane];
   if (live) carry_leg_inputs<L, NJ>(A, st, held, ns, slot, int(slot % 64) % L);
-  if (lane == 0) {
+  if (lane == 0 && A.batch_cycles == 0) {
     if (held.fault) __hip_atomic_fetch_or(&A.ctl->fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(&A.ctl->exited, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -901,6 +912,10 @@ template <int L, int NJ, unsigned F>
 // (rough terrain / tip rotations: one wavefront per SIMD - the resident loop around those cycles does not fit 256 registers without
 //  scratch, and a batch that is resident has SIMDs to spare: up to ~990 wavefronts, 9 900 hexapods / 7 900 octopods)
 __global__ void __launch_bounds__(64, (F & (F_ROT | F_ROUGH)) ? 1 : SHC_WAVES_PER_SIMD) shc_resident_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
+  if (ra.batch_cycles != 0) { // the batch form (shc_engine_step_k): no relay block, every block a worker wavefront
+    cycle_wave<L, NJ, F, true>(st, gc, 0, rt_flags, ra.batch_wave0 + int64_t(blockIdx.x), &ra);
+    return;
+  }
   if (blockIdx.x == 0) {
     resident_relay<PART_BOTH>(ra);
     return;
@@ -923,6 +938,35 @@ __global__ void __launch_bounds__(64, (F & (F_ROT | F_ROUGH)) ? 1 : SHC_WAVES_PE
 // Control is workgroup-uniform: the leader (wave 0) watches the gate and announces, one iteration ahead, what the next iteration
 // is (REAL: run a cycle, BUBBLE: nothing released yet, EXIT) together with the header of that cycle; one barrier per iteration.
 enum : int { IT_REAL = 1, IT_BUBBLE = 2, IT_EXIT = 3 };
+// The walker's wait for Model::current_pose_ / walk_plane_pose_ of its cycle (the model wavefront leaves them in the robot tile and raises
+// `flag` to cycle + 1).  Bounded like every other device-side wait: 1 s, then the loop reports a fault.
+template <int RPW>
+struct PoseWait {
+  unsigned *flag_at;
+  unsigned want;
+  u64 ticks_per_ms;
+  bool *fault;
+  __device__ __forceinline__ bool give_up(unsigned &spins, u64 &t0) const {
+    __builtin_amdgcn_s_sleep(1);
+    if ((++spins & 4095u) == 0) {
+      const u64 now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > 1000 * ticks_per_ms) {
+        *fault = true;
+        return true;
+      }
+    }
+    return false;
+  }
+  __device__ __forceinline__ void operator()() const {
+    volatile unsigned *flag = flag_at;
+    unsigned spins = 0;
+    u64 t0 = 0;
+    while (*flag != want)
+      if (give_up(spins, t0)) break;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+};
 template <int L, int NJ>
 struct Resident2Lds { // dynamic LDS of one workgroup, after the two walker waves' tiles
   double mailbox[2][2][13][64]; // [pair][cycle parity][field][lane]: PoseController::updateStance -> Leg::setDesiredTipPose (xyz), then the
@@ -1041,7 +1085,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         mb[7 * 64] = pp.x, mb[8 * 64] = pp.y, mb[9 * 64] = pp.z, mb[10 * 64] = pn.x, mb[11 * 64] = pn.y, mb[12 * 64] = pn.z;
       }
     }
-    X.pose_c[pair][cycle & 1][lane] = walk_plane_control_input<L, NJ>(s.word, C, P, g, swing_c_count_u);
+    X.pose_c[pair][cycle & 1][lane] = walk_plane_control_candidate<L, NJ>(s.word, C, P, swing_c_count_u); // (the model wavefront picks the group's leg)
   };
   if (POSE_SPLIT && walker && active) publish_for_pose(0, true); // (iteration 0 is a bubble: its closing barrier comes before any pose)
   const int64_t ns = st.n_slots;
@@ -1106,23 +1150,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       if (kind == IT_REAL && active) {
         resident_take_inputs<RPW, POSE_SPLIT ? ROBOT_VEL : ROBOT_ALL, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
         SHC_TICK(21);
-        const auto pose_wait = [&]() { // Model::current_pose_ / walk_plane_pose_ of this cycle are in the tile once the model wavefront says so
-          volatile unsigned *flag = &X.pose_done[pair];
-          unsigned spins = 0;
-          u64 t0 = 0;
-          while (*flag != c_front + 1) { // (bounded like every other device-side wait: 1 s, then the loop reports a fault)
-            __builtin_amdgcn_s_sleep(1);
-            if ((++spins & 4095u) == 0) {
-              const u64 now = wall_clock64();
-              if (t0 == 0) t0 = now;
-              else if (now - t0 > 1000 * A.ticks_per_ms) {
-                held.fault = true;
-                break;
-              }
-            }
-          }
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        };
+        const PoseWait<RPW> pose_wait{&X.pose_done[pair], c_front + 1, A.ticks_per_ms, &held.fault};
         cycle_front<L, NJ, F, false, LegInRing<NJ>, false, !POSE_SPLIT>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
                                                                         LegInRing<NJ>{nullptr, nullptr, 0, 0, false, {}}, fb, nullptr, pose_wait);
 #ifdef SHC_ABLATE
@@ -1174,13 +1202,21 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
           nh0v = ld_agent(hp);
           nh1v = ld_agent(hp + 1);
         }
-        gate_pref = ld_agent(&A.ctl->gate);
+        // (out of a bubble the gate was read just now: the control words below wait for every load of this iteration, and one more trip to
+        //  memory on the way out of a bubble is a microsecond on the latency of every burst)
+        if (kind == IT_BUBBLE) gate_pref = gate;
+        else gate_pref = ld_agent(&A.ctl->gate);
       }
       if (active) {
         SHC_TICK(24);
         if constexpr (POSE_SPLIT) if (kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
           resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
-          const double pose_c = X.pose_c[pair][c_front & 1][lane];
+          double pose_c = -1.0; // the candidate of the LAST leg (in id order) of this lane's robot that has one (pose_controller.cpp:1100-1108)
+#pragma unroll
+          for (int j = 0; j < L; ++j) {
+            const double cj = X.pose_c[pair][c_front & 1][g.base + j];
+            pose_c = cj >= 0.0 ? cj : pose_c;
+          }
           int lw[L] = {}; // (not filled in: the walker wavefront has already reduced the leg words to the pose's control input)
           const double *mb = &X.mailbox[pair][c_front & 1][0][lane];
           const V3 plane_prev{mb[7 * 64], mb[8 * 64], mb[9 * 64]}, pnorm_prev{mb[10 * 64], mb[11 * 64], mb[12 * 64]};

@@ -69,6 +69,13 @@ struct ResidentArgs {
   unsigned long long ticks_per_ms;  // wall_clock64() rate of the device (hipDeviceAttributeWallClockRate): every device-side time bound derives from it
   int64_t n_waves;
   double touchdown_threshold, liftoff_threshold; // Leg::touchdownDetection (model.cpp:712-722) runs inside the loop when a tip force arrives (rough terrain mode)
+  // BATCH form of the same loop (shc_engine_step_k: K cycles per launch, each with its own inputs, for batches of any size).  batch_cycles > 0:
+  // no relay, no doorbell, no header ring, nothing has to be co-resident - every wavefront runs cycles 0 .. batch_cycles - 1 as soon as it is
+  // scheduled and leaves; cycle c takes row c of the K-deep input arrays bound as set 0 (batch_mask: the groups they carry; kstride[which]:
+  // doubles per row) the way a direct post delivers them, and writes its q / qd to slot c of the output ring (depth = batch_cycles).
+  unsigned batch_cycles, batch_mask;
+  int64_t kstride[BND_COUNT];
+  int64_t batch_wave0; // first wave of this launch
 };
 
 // Everything a launch of the cycle kernel needs from the engine.

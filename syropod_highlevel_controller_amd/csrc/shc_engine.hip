@@ -276,6 +276,9 @@ struct shc_engine {
   hipStream_t half_stream[2] = {nullptr, nullptr}; // the device's pair of split streams (split_streams()), once this engine has used them
   hipEvent_t ev_main = nullptr, ev_half[2] = {nullptr, nullptr};
   hipEvent_t ev_in[2] = {nullptr, nullptr}; // the half streams have read a device-resident input array (the engine's stream is ordered after them)
+  double *k_out = nullptr;              // shc_engine_step_k: q / qd of each of the K cycles of the latest launch, [K][dof planes][n_slots] double2
+  size_t k_out_bytes = 0;
+  int k_out_cycles = 0;
   bool side_busy = false;               // launches are outstanding on the split streams that the engine's stream has not been ordered after
   bool main_dirty = true;               // work other than steps was enqueued on the engine's stream since the last split step
 };
@@ -506,7 +509,7 @@ static int generate_tables_nj(const shc_params *p, shc_tables *out) {
   return hostinit::generate_tables<NJ>(*p, *out) ? SHC_OK : fail(SHC_ERR_INVALID_ARG, "init chain failed (unreachable stance?)");
 }
 
-extern "C" int shc_abi_version(void) { return 4; } // 4: shc_cycle_inputs.direct (launch-free posts); 3: shc_leg_snapshot carries the stepper target tip direction; resident mode, join, auxiliary state
+extern "C" int shc_abi_version(void) { return 5; } // 5: shc_engine_step_k (K cycles per launch, each with its own inputs); 4: shc_cycle_inputs.direct (launch-free posts); 3: shc_leg_snapshot carries the stepper target tip direction; resident mode, join, auxiliary state
 extern "C" int64_t shc_sizeof_params(void) { return (int64_t)sizeof(shc_params); }
 extern "C" int64_t shc_sizeof_tables(void) { return (int64_t)sizeof(shc_tables); }
 
@@ -944,6 +947,7 @@ extern "C" int shc_engine_destroy(shc_engine *e) {
   (void)hipFree(e->d_consts);
   (void)hipFree(e->d_stage);
   (void)hipFree(e->d_span);
+  (void)hipFree(e->k_out);
   if (e->half_stream[0]) { // (the streams belong to the process-wide pair)
     (void)hipEventDestroy(e->ev_main);
     (void)hipEventDestroy(e->ev_half[0]);

@@ -680,3 +680,136 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
                                      std::to_string(done) + " of " + std::to_string(r->published) + " published cycles");
   return SHC_OK;
 }
+
+// ================================================================================================ K cycles per launch, each with its own inputs
+// shc_engine_step_k: what the node's loop does K times - callbacks deliver this iteration's inputs, StateController::loop runs one cycle, the
+// desired joint state is published (src/main.cpp:106-131) - as ONE launch for batches of any size: the BATCH form of the resident loop kernel
+// (ResidentArgs::batch_cycles).  State is loaded once, stays in registers / LDS for K cycles and is stored once; cycle k reads row k of the
+// caller's K-deep input arrays where they lie (as a direct post of a bound set would deliver them) and writes its q / qd to slot k of a K-deep
+// output ring.  No relay, no doorbell, nothing has to be co-resident; the launch is ordinary work on the engine's stream.
+static int step_k_out_ring(shc_engine *e, int K) {
+  const size_t need = size_t(K) * size_t(e->NJ) * size_t(e->n_slots) * 16;
+  if (e->k_out && e->k_out_bytes >= need) return SHC_OK;
+  if (e->k_out) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(e->k_out);
+    e->k_out = nullptr, e->k_out_bytes = 0;
+  }
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e->k_out), need));
+  e->k_out_bytes = need;
+  return SHC_OK;
+}
+
+extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_inputs *in) {
+  SHC_BUSY_GUARD(e);
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (n_cycles < 1 || n_cycles > 4096) return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: 1 .. 4096 cycles per launch");
+  if (e->starting_up) return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k starts from a running engine (finish the start-up first)");
+  unsigned mask = 0;
+  if (in) {
+    if (!in->on_device) return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: the K-deep input arrays are device arrays (on_device = 1)");
+    if ((in->linear_xy == nullptr) != (in->angular == nullptr)) return fail(SHC_ERR_INVALID_ARG, "linear_xy and angular are given together");
+    if ((in->imu_orientation_wxyz == nullptr) != (in->imu_angular_velocity == nullptr)) return fail(SHC_ERR_INVALID_ARG, "the two IMU arrays are given together");
+    if (in->pose_translation_velocity || in->pose_rotation_velocity || in->pose_reset_mode)
+      return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k carries velocity, IMU, tip force and joint effort; give pose inputs / reset modes with their setters before the call (held for the K cycles)");
+    if (in->linear_xy) mask |= 1u << RG_VEL;
+    if (in->imu_orientation_wxyz) mask |= 1u << RG_IMU;
+    if (in->tip_force) mask |= 1u << RG_FORCE;
+    if (in->joint_effort) mask |= 1u << RG_EFFORT;
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  if (mask & (1u << RG_EFFORT)) { // Leg::calculateTipForce has something to filter from now on (as shc_engine_set_joint_effort)
+    const int rc = effort_live(e);
+    if (rc != SHC_OK) return rc;
+  }
+  ResidentFit fit{0, 0, 0};
+  {
+    CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, 0, 64, 0, nullptr, &fit, 0};
+#define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+#undef CALL
+  }
+  if (!fit.supported)
+    return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k: this configuration runs on a tip-align / manual-leg kernel, which has no loop form; use shc_engine_step");
+  {
+    const int rc = step_k_out_ring(e, n_cycles);
+    if (rc != SHC_OK) return rc;
+  }
+  if (size_t(e->NJ) * e->n_slots * 16 * size_t(n_cycles) >= (size_t(1) << 31))
+    return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: cycles x batch - the output ring must stay below 2 GiB (fewer cycles per launch)");
+  e->plan_poser_tips_current = false;
+  ResidentArgs A{};
+  if (in) {
+    A.bound[0][BND_LIN] = in->linear_xy, A.bound[0][BND_ANG] = in->angular;
+    A.bound[0][BND_IMUQ] = in->imu_orientation_wxyz, A.bound[0][BND_IMUW] = in->imu_angular_velocity;
+    A.bound[0][BND_FORCE] = in->tip_force, A.bound[0][BND_EFFORT] = in->joint_effort;
+  }
+  A.kstride[BND_LIN] = e->n * 2, A.kstride[BND_ANG] = e->n, A.kstride[BND_IMUQ] = e->n * 4, A.kstride[BND_IMUW] = e->n * 3;
+  A.kstride[BND_FORCE] = e->n * e->L * 3, A.kstride[BND_EFFORT] = e->n * e->L * e->NJ;
+  A.out = e->k_out;
+  A.depth = n_cycles;
+  A.max_cycles = unsigned(n_cycles);
+  A.batch_cycles = unsigned(n_cycles);
+  A.batch_mask = mask;
+  A.n_waves = e->n_waves;
+  A.idle_ticks = 0, A.ticks_per_ms = 100000;
+  A.touchdown_threshold = e->params.touchdown_threshold;
+  A.liftoff_threshold = e->params.liftoff_threshold;
+  // From kSplitWaves waves on the launch goes out as two halves on the two split streams, as the steps of shc_engine_step do (one half's tail
+  // under the other half's full rounds); both are ordered after the engine's stream and the engine's stream after both.
+  const bool split = e->n_waves >= kSplitWaves && !(e->features & SHC_FEAT_SINGLE_STREAM);
+  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, unsigned(e->n_waves), 64, 0, &A, nullptr, 0};
+#define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
+  if (!split) {
+    SHC_DISPATCH(e->L, e->NJ, CALL);
+    HIP_TRY(hipGetLastError());
+  } else {
+    if (!e->half_stream[0]) {
+      const int rc = split_streams(e->device, e->half_stream);
+      if (rc != SHC_OK) return rc;
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_half[0], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_half[1], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(e->ev_main, e->stream));
+    const int64_t half = e->n_waves / 2;
+    for (int h = 0; h < 2; ++h) {
+      HIP_TRY(hipStreamWaitEvent(e->half_stream[h], e->ev_main, 0));
+      A.batch_wave0 = h ? half : 0;
+      a.stream = e->half_stream[h];
+      a.grid = unsigned(h ? e->n_waves - half : half);
+      SHC_DISPATCH(e->L, e->NJ, CALL);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(e->ev_half[h], e->half_stream[h]));
+      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_half[h], 0));
+    }
+    e->main_dirty = true;
+  }
+#undef CALL
+  e->k_out_cycles = n_cycles;
+  if (mask & (1u << RG_FORCE)) e->rt_flags |= RT_TOUCHDOWN; // as shc_engine_set_tip_force (state_controller.cpp:1642)
+  return SHC_OK;
+}
+
+// q / qd of cycle k (0 .. K - 1) of the latest shc_engine_step_k, from its output ring (stream-ordered after the launch).
+extern "C" int shc_engine_get_step_k_joint_state(shc_engine *e, int k, double *q, double *qd, int on_device) {
+  SHC_BUSY_GUARD(e);
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (!e->k_out || k < 0 || k >= e->k_out_cycles) return fail(SHC_ERR_INVALID_ARG, "shc_engine_get_step_k_joint_state: cycle 0 .. K - 1 of the latest shc_engine_step_k");
+  HIP_TRY(hipSetDevice(e->device));
+  const double *slot = e->k_out + size_t(k) * size_t(e->NJ) * e->n_slots * 2;
+  const int64_t threads = e->n * e->L;
+  for (int which = 0; which < 2; ++which) {
+    double *dst = which ? qd : q;
+    if (!dst) continue;
+    double *d = on_device ? dst : e->d_stage;
+    if (!on_device && size_t(threads) * e->NJ * 8 > e->stage_bytes) return fail(SHC_ERR_INVALID_ARG, "staging buffer too small");
+    gather_leg_kernel<<<dim3((unsigned)((threads + 63) / 64)), dim3(64), 0, e->stream>>>(d, slot, e->n_slots, e->n, e->L, e->NJ, which ? LEG_FIELD(e, QD) : LEG_FIELD(e, Q));
+    HIP_TRY(hipGetLastError());
+    if (!on_device) {
+      HIP_TRY(hipMemcpyAsync(dst, d, size_t(threads) * e->NJ * 8, hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+  }
+  return SHC_OK;
+}

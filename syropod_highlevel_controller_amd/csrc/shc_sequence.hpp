@@ -84,14 +84,17 @@ __device__ __forceinline__ void seq_defaults(SeqRobotState &s) { // member initi
 // kernels support): the walk-plane pose is its origin (no swing progress to interpolate with, pose_controller.cpp:1100-1128) and
 // the manual pose stays as it is without inputs, so Model::current_pose_ = origin_walk_plane_pose_ (+) manual_pose_.  The start-up
 // sequence runs before the first control cycle has ever written the pose.
+// With gravity_aligned_tips on a robot whose leg 0 has at most 3 joints the tip-align pose is part of the pose as well: updateTipAlignPose only moves it
+// while a leg swings (pose_controller.cpp:1024-1088), so a robot that stands keeps the pose its last step left - added last, as updateCurrentPose does (:849-856).
 template <int L>
-__device__ __forceinline__ void standing_pose_prologue_dev(const DevState &st, int64_t rob) {
+__device__ __forceinline__ void standing_pose_prologue_dev(const DevState &st, int64_t rob, const bool tip_align = false) {
   using R = RobotFields;
   constexpr int rpw = 64 / L;
   auto rd = [&](int f) -> double & { return st.robd[rob_index(rob, f, rpw, R::COUNT)]; };
   const Pose owpp{V3{rd(R::OWPP), rd(R::OWPP + 1), rd(R::OWPP + 2)}, Quat{rd(R::OWPP + 3), rd(R::OWPP + 4), rd(R::OWPP + 5), rd(R::OWPP + 6)}};
   const Pose manual{V3{rd(R::MPOSE), rd(R::MPOSE + 1), rd(R::MPOSE + 2)}, Quat{rd(R::MPOSE + 3), rd(R::MPOSE + 4), rd(R::MPOSE + 5), rd(R::MPOSE + 6)}};
-  const Pose cp = add_pose(owpp, manual);
+  Pose cp = add_pose(owpp, manual);
+  if (tip_align) cp = add_pose(cp, Pose{V3{rd(R::TALIGN), rd(R::TALIGN + 1), rd(R::TALIGN + 2)}, Quat{rd(R::TALIGN + 3), rd(R::TALIGN + 4), rd(R::TALIGN + 5), rd(R::TALIGN + 6)}});
   rd(R::CPOSE) = cp.p.x, rd(R::CPOSE + 1) = cp.p.y, rd(R::CPOSE + 2) = cp.p.z;
   rd(R::CPOSE + 3) = cp.r.w, rd(R::CPOSE + 4) = cp.r.x, rd(R::CPOSE + 5) = cp.r.y, rd(R::CPOSE + 6) = cp.r.z;
 }
@@ -153,7 +156,7 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
     return;
   }
   s.completed_sequence = 0;
-  standing_pose_prologue_dev<L>(st, rob);
+  standing_pose_prologue_dev<L>(st, rob, gc->P.tip_align != 0);
   for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
   const bool start_up = sequence == 0;
   // Initialise / reset any saved transition sequence (:149-162)

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_resident_begin", "shc_engine_resident_bind_inputs", "shc_engine_resident_post", "shc_engine_resident_publish", "shc_engine_resident_wait",
     "shc_engine_resident_get_joint_state", "shc_engine_resident_get_joint_state_async", "shc_engine_resident_status", "shc_engine_resident_end", "shc_engine_join",
     "shc_engine_aux_state_bytes", "shc_engine_get_aux_state", "shc_engine_set_aux_state",
+    "shc_engine_step_k", "shc_engine_get_step_k_joint_state",
 ]
 
 
@@ -214,6 +215,8 @@ def lib():
                         ("shc_engine_set_joint_effort", 1), ("shc_engine_set_pose_input", 2), ("shc_engine_set_pose_reset_mode", 1)):
             getattr(L, name).argtypes = [C.c_void_p] + [C.c_void_p] * n + [C.c_int]
         L.shc_engine_step.argtypes = [C.c_void_p, C.c_int]
+        L.shc_engine_step_k.argtypes = [C.c_void_p, C.c_int, C.POINTER(CycleInputs)]
+        L.shc_engine_get_step_k_joint_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.shc_engine_join.argtypes = [C.c_void_p]
         L.shc_engine_aux_state_bytes.argtypes = [C.c_void_p]
         L.shc_engine_aux_state_bytes.restype = C.c_int64
@@ -350,8 +353,20 @@ class BatchEngine:
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.shc_engine_destroy(self.h)
+            if getattr(self, "_owned", True):
+                self.L.shc_engine_destroy(self.h)
             self.h = None
+
+    @classmethod
+    def view(cls, handle: int, params: Params, n: int):
+        """A non-owning view of an engine somebody else created (a part of a fleet: shc_fleet_part) - for device-resident I/O and state records
+        through the shc_engine_* calls; closing the view leaves the engine alone."""
+        self = cls.__new__(cls)
+        self.L, self.h, self._owned = lib(), C.c_void_p(handle), False
+        self.params, self.n = params, int(n)
+        self.legs, self.dof = params.leg_count, max(params.leg_dof[l] for l in range(params.leg_count))
+        self.features = FEAT_DEFAULT
+        return self
 
     def __del__(self):
         try:
@@ -405,6 +420,29 @@ class BatchEngine:
     def step(self, n_cycles: int = 1):
         _check(self.L.shc_engine_step(self.h, int(n_cycles)), "step")
 
+    def step_k(self, n_cycles: int, velocity=None, imu=None, tip_force=None, joint_effort=None):
+        """K cycles in one launch, cycle k with row k of the K-deep DEVICE arrays (integer device pointers, e.g. torch.Tensor.data_ptr()):
+        velocity = (linear [K][n][2], angular [K][n]), imu = (quat [K][n][4], gyro [K][n][3]), tip_force [K][n][legs][3],
+        joint_effort [K][n][legs][dof]; None = held (shc_engine_step_k)."""
+        ci = CycleInputs()
+        if velocity is not None:
+            ci.linear_xy, ci.angular = velocity[0] or None, velocity[1] or None
+        if imu is not None:
+            ci.imu_orientation_wxyz, ci.imu_angular_velocity = imu[0] or None, imu[1] or None
+        if tip_force is not None:
+            ci.tip_force = int(tip_force)
+        if joint_effort is not None:
+            ci.joint_effort = int(joint_effort)
+        ci.on_device = 1
+        _check(self.L.shc_engine_step_k(self.h, int(n_cycles), C.byref(ci)), "shc_engine_step_k")
+
+    def step_k_joints(self, k: int):
+        """q, qd [n][legs * dof] of cycle k of the latest step_k (host arrays)."""
+        q = np.empty((self.n, self.legs * self.dof), dtype=np.float64)
+        qd = np.empty_like(q)
+        _check(self.L.shc_engine_get_step_k_joint_state(self.h, int(k), _p(q), _p(qd), 0), "shc_engine_get_step_k_joint_state")
+        return q, qd
+
     def synchronize(self):
         _check(self.L.shc_engine_synchronize(self.h), "synchronize")
 
@@ -420,9 +458,9 @@ class BatchEngine:
         """Bind device arrays (integer pointers) as input set 0 .. 3 for direct posts; before resident_begin."""
         ci = CycleInputs()
         if velocity is not None:
-            ci.linear_xy, ci.angular = int(velocity[0]), int(velocity[1])
+            ci.linear_xy, ci.angular = velocity[0] or None, velocity[1] or None
         if imu is not None:
-            ci.imu_orientation_wxyz, ci.imu_angular_velocity = int(imu[0]), int(imu[1])
+            ci.imu_orientation_wxyz, ci.imu_angular_velocity = imu[0] or None, imu[1] or None
         ci.tip_force = None if tip_force is None else int(tip_force)
         ci.joint_effort = None if joint_effort is None else int(joint_effort)
         ci.on_device = 1
