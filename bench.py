@@ -228,7 +228,9 @@ def fused_k_probe(eng, p, n, lin, ang, extra, key, stream, K=16, reps=8, want_pa
     import torch
     L, D = p.leg_count, p.leg_dof[0]
     ks = np.arange(K)
-    rows = {"lin": lin[None] * (0.85 + 0.15 * np.cos(0.4 * ks))[:, None, None], "ang": ang[None] * (0.85 + 0.15 * np.sin(0.3 * ks))[:, None]}
+    # a new command in every row, moving as a command does between two 20 ms cycles (a few 1e-4 of its size: inside the acceleration limits, so the
+    # robots follow it - a 15 % swing per cycle, tried first, is 3 x the top speed per second and keeps every robot in the acceleration-limited branch)
+    rows = {"lin": lin[None] * (1.0 + 5e-4 * np.cos(0.4 * ks))[:, None, None], "ang": ang[None] * (1.0 + 5e-4 * np.sin(0.3 * ks))[:, None]}
     in_bytes = 24
     if "imu_q" in extra:
         rows["imu_q"] = np.repeat(extra["imu_q"][None], K, axis=0)
@@ -464,7 +466,7 @@ def time_resident(eng, n, steps, warmup, stream, depth=16, final_gather=None, ho
 
 
 def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=0, fused_probe=True, want_cpu_baseline=False, joint_efforts=False,
-                 mode="auto", gather_under_loop=False, want_parity=True):
+                 mode="auto", gather_under_loop=False, want_parity=True, gather_form="rccl"):
     """One workload on this rank's GPU: prepare (untimed), time `steps` steps, measure the kernel with HIP events.
     dist_ctx = (world, rank, local_rank) when the RCCL path is active."""
     import torch
@@ -521,13 +523,28 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     gathered = None
     # joint-state shard of this rank in the C ABI's instance-major layout [n][legs][dof] (device resident)
     qshard = torch.empty(n * p.leg_count * p.leg_dof[0], dtype=torch.float64, device="cuda") if use_dist else None
-    if use_dist:
+    peer = None
+    if use_dist and gather_form == "peer":   # the exchange as peer copies over xGMI (shc_peer_*): one copy per link instead of a ring bound by one link
+        from syropod_highlevel_controller_amd.parallel import PeerAllGather
+        peer = PeerAllGather(qshard.numel(), world, rank, local_rank)
+        gathered = peer.out
+    elif use_dist:
         gathered = torch.empty(world * qshard.numel(), dtype=torch.float64, device="cuda")
 
     def gather():
         if use_dist:
             eng.joints_device(qshard.data_ptr(), None)  # SoA planes -> [n][legs][dof] on the engine's stream
-            all_gather_joints(qshard, world, out=gathered)  # the helper tests/test_sharding_gloo.py runs over gloo
+            if peer:
+                peer.gather(qshard, stream.cuda_stream)     # this rank's shard into every rank's buffer; closed by gather_close() below
+            else:
+                all_gather_joints(qshard, world, out=gathered)  # the helper tests/test_sharding_gloo.py runs over gloo
+
+    def gather_close():   # peer form: this rank's copies have completed (the caller synchronised) - the exchange is complete when every rank's have
+        if peer:
+            if host_barrier.slots is not None:
+                host_barrier()
+            if host_barrier.slots is None:   # (no shared page, or the spin barrier gave up: the collective library's barrier)
+                dist.barrier()
 
     # resident mode: batches that fit the chip once, one cycle per step, nothing that needs a launch between steps
     resident = False
@@ -547,13 +564,16 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     posted_value = posted_launch_value = None
     host_barrier = None
     parity = None
-    nogather_elapsed = gather_s = None
+    nogather_elapsed = gather_s = own_elapsed = None
+    scale_reference = efficiency = None
     enqueue_s = None
     wd_meta = {"n_gpus": world, "config": {"workload": f"BASELINE.json {name}: {n} per GPU", "mode": mode}}
     if use_dist:
-        gather()
-        dist.barrier()
         host_barrier = HostSpinBarrier(world, rank)   # while a resident loop is alive no device-wide synchronisation may be issued
+        gather()
+        torch.cuda.synchronize()
+        gather_close()
+        dist.barrier()   # while a resident loop is alive no device-wide synchronisation may be issued
     if resident:   # the launch-per-cycle figure of the same engine first (secondary), then the resident one
         for _ in range(warmup):
             step_once()
@@ -577,7 +597,12 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                 res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, final_gather=final_gather, host_barrier=host_barrier, parity=pfac)
         elif use_dist:   # N > 1 default: end the loop, then gather - no collective kernel next to a persistent loop
             with Watchdog(180, "resident region, loop ended before the all-gather", rank, wd_meta):
-                res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, gather_after_end=gather, host_barrier=host_barrier, parity=pfac)
+                def gather_and_close():
+                    gather()
+                    if peer:
+                        stream.synchronize()
+                        gather_close()
+                res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, gather_after_end=gather_and_close, host_barrier=host_barrier, parity=pfac)
         else:
             res_elapsed, res_cycle_s, parity = time_resident(eng, n, steps, warmup, stream, parity=pfac)
         elapsed = res_elapsed
@@ -632,6 +657,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                 gather()
             enqueue_s = time.perf_counter() - t0   # the host's share: the launches are asynchronous, this is how long issuing them took
             torch.cuda.synchronize()
+            gather_close()
             elapsed = time.perf_counter() - t0  # this rank's K steps + its part of the gather; the MAX over ranks below is the job's time
         state["window"] = None
         if pw:
@@ -646,11 +672,13 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                     step_once()
                 torch.cuda.synchronize()
                 nogather_elapsed = time.perf_counter() - t1
+                own_elapsed = nogather_elapsed   # this rank's own K steps, before the maximum over the ranks is taken: the same-workload single-GPU reference
                 dist.barrier()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 gather()
                 torch.cuda.synchronize()
+                gather_close()
                 gather_s = time.perf_counter() - t1
     if use_dist:
         dist.barrier()  # closing bracket (the all-gather inside the region already needed every rank's shard)
@@ -664,6 +692,21 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         elapsed = float(t[0].item())
         if nogather_elapsed is not None:
             nogather_elapsed, gather_s = float(t[1].item()), float(t[2].item())
+        if own_elapsed is not None:
+            # One curve from N = 1 to N = 8: the SAME workload on ONE GPU, measured in this run - every rank's own K steps of its shard, no
+            # gather, its own clock (the ranks run side by side, so power and thermals are the job's).  Efficiency = job value / (N x that), with and
+            # without the gather; a driver that divides value(N) by N x value(1) of the default N = 1 line would compare octopod launches with hexapod
+            # doorbell ticks.
+            own = torch.zeros(world, dtype=torch.float64, device="cuda")
+            own[rank] = own_elapsed
+            dist.all_reduce(own, op=dist.ReduceOp.SUM)
+            per_rank = [n * steps * cps / float(x) for x in own.tolist()]
+            ref = float(np.median(per_rank))
+            scale_reference = {"workload": f"BASELINE.json {name}: {n} {desc}, one launch of the fused cycle kernel per step, no gather", "n_gpus": 1,
+                               "value": ref, "ms_per_step": n * cps / ref * 1e3, "value_is": "median over the ranks of each rank's own K steps of its shard (measured in this run, after the timed region)",
+                               "per_rank_values": per_rank}
+            efficiency = {"with_gather": (world * n * steps * cps / elapsed) / (world * ref), "without_gather": (world * n * steps * cps / nogather_elapsed) / (world * ref),
+                          "is": "job value / (n_gpus x scale_reference.value): `value` contains the all-gather of the final joint buffer inside a region of only `steps` steps"}
 
     # ---- kernel duration of the cycle kernel, HIP events on the launch stream.  Two upper bounds on the true duration:
     #      (a) one event pair per launch (adds the event-record latency), (b) one pair around m back-to-back launches
@@ -764,6 +807,9 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                           "any collective kernel runs)" if (use_dist and resident) else
                           "one all-gather of the final joint buffer (N > 1), launched after the last step inside the timed region; value_without_gather / gather_ms: "
                           "the same K steps without it and the gather on its own, measured right after (max over ranks)")),
+                   "gather_form": (("peer copies over xGMI (shc_peer_scatter: this rank's shard into every rank's buffer, one stream per link) + a host barrier" if peer
+                                    else "RCCL all_gather_into_tensor") if use_dist else None),
+                   "scale_reference": scale_reference, "weak_scaling_efficiency": efficiency,
                    "value_without_gather": (world * n * steps * cps / nogather_elapsed) if nogather_elapsed else None,
                    "gather_ms": gather_s * 1e3 if gather_s is not None else None,
                    "gather_bytes_per_rank": int(qshard.numel() * 8) if use_dist else None,
@@ -870,6 +916,8 @@ def main():
                     "per GPU in launch mode (the 2^20-instance batch north_star states the weak-scaling target on)")
     ap.add_argument("--gather-under-loop", action="store_true", help="N > 1 with --mode resident: queue the all-gather behind a device-side wait while the "
                     "persistent loop is still alive (default: the loop is ended first)")
+    ap.add_argument("--gather", choices=("rccl", "peer"), default="rccl", help="N > 1: the exchange of the final joint buffer - RCCL's all-gather (a ring: one xGMI link "
+                    "bounds it), or peer copies (every rank writes its shard into every rank's buffer, one copy per link)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity block (max |dq| against the CPU oracle over the timed window)")
     ap.add_argument("--instances", type=int, default=0, help="instances per GPU (default: 4096 for config2)")
     ap.add_argument("--cycles-per-step", type=int, default=1)
@@ -923,7 +971,7 @@ def main():
                        dist_ctx=(world, rank, local_rank) if use_dist else None, gather_every=args.gather_every,
                        fused_probe=not args.no_fused_probe, want_cpu_baseline=(rank == 0 and world == 1 and not args.no_cpu_baseline),
                        joint_efforts=primary_efforts and (args.workload == "config2" or args.joint_efforts), mode=args.mode,
-                       gather_under_loop=args.gather_under_loop, want_parity=(rank == 0 and not args.no_parity))
+                       gather_under_loop=args.gather_under_loop, want_parity=(rank == 0 and not args.no_parity), gather_form=args.gather)
     # The other single-GPU BASELINE.json configurations, measured in the same process (N = 1 default run only):
     # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
     also = []
@@ -940,6 +988,8 @@ def main():
                          "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"], "mode": r["config"]["mode"],
                          "one_launch_per_cycle_value": r["config"]["one_launch_per_cycle_value"],
                          "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],
+                         "fused_K_with_per_cycle_inputs_value": r["config"]["fused_K_with_per_cycle_inputs_value"],
+                         "fused_K_with_per_cycle_inputs": r["config"]["fused_K_with_per_cycle_inputs"],
                          "two_stream_split": r["config"]["two_stream_split"], "single_stream": r["config"]["single_stream"],
                          "roofline": r["roofline"], "parity": r["parity"]})
         try:

@@ -382,6 +382,20 @@ int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_inputs *input
 int shc_engine_get_step_k_joint_state(shc_engine *e, int k, double *q, double *qd, int on_device);
 
 /*
+ * One process per GPU: the exchange of the final joint buffer as peer copies over xGMI, without a collective library (the alternative to the
+ * RCCL all-gather the one-process-per-GPU host runs; shc_fleet_all_gather_joints is the same exchange inside one process).  Every rank
+ * allocates its gathered buffer with shc_peer_alloc (which also exports it: a 64-byte handle the ranks exchange by whatever means they have),
+ * opens every peer's buffer (shc_peer_open) and, after its last step, writes its shard into every buffer at its own offset:
+ * shc_peer_scatter(device, shard, bytes, destinations, n, stream) - one copy per destination on a stream of its own (the N - 1 links of a GPU
+ * carry N - 1 copies at once), ordered after `stream`, and `stream` ordered after them.  A barrier of the caller's - every rank's copies have
+ * completed - closes the exchange.  shc_peer_close(device, ptr, opened): opened != 0 for a peer's buffer, 0 frees one's own.
+ */
+int shc_peer_alloc(int device, int64_t bytes, void **device_ptr, unsigned char *handle64);
+int shc_peer_open(int device, const unsigned char *handle64, void **device_ptr);
+int shc_peer_close(int device, void *device_ptr, int opened);
+int shc_peer_scatter(int device, const void *src, int64_t bytes, void *const *dst, int n_dst, void *stream);
+
+/*
  * Outputs read after the cycle (state_controller.cpp:777-805 publishDesiredJointState).
  * q/qd: [n][legs][dof] desired joint position / velocity.  Either may be NULL.
  */

@@ -1457,6 +1457,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
         }
       }
     }
+    SHC_TICK(16);
     // ---- updateTipRotation (:1193-1234).  Without gravity-aligned tips every tip rotation stays UNDEFINED.  With them the
     //      target is the constant identity rotation (x axis along -z); only the x axes of the rotations are ever used
     //      downstream (poser, applyIK), so the state is kept as directions + a "defined" bit.
@@ -1608,6 +1609,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   {
     if (!POSE_HERE && !(SHC_DBG(P) & 32768)) {
       pose_wait();
+      SHC_TICK(17);
       cp = rb.getpose(R::CPOSE);
     } else if (!POSE_HERE) {
       cp = pose_identity();

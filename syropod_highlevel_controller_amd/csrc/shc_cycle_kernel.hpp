@@ -229,19 +229,32 @@ template <int NJ>
 struct LegInRing {
   // this lane's leg: element 2 p + h of its record lies at ptr + p * pair + h - the paired planes of the engine / the input rings
   // (pair = 2 n_slots) and a caller's instance-major array of a bound input set (pair = 2) alike
-  const double *force_ptr, *effort_ptr;
-  int64_t force_pair, effort_pair;
+  const double *force_ptr = nullptr, *effort_ptr = nullptr;
+  int64_t force_pair = 0, effort_pair = 0;
   // The joint efforts are consumed at the very end of Model::updateModel (Leg::calculateTipForce) but come from memory another agent
   // may have written (agent-scope loads, ~1 us): a wavefront that runs alone on its SIMD would sit out that latency.  prefetch_effort()
   // issues the loads where the model half starts; they arrive while the IK step runs.
   bool effort_prefetched = false;
   double effort_now[NJ] = {};
+  // The batch form (shc_engine_step_k) reads arrays nobody writes while the launch runs: plain loads (L2 / L1 hits between neighbouring lanes and
+  // loads), and BOTH per-leg groups are issued at the top of the cycle - a thousand clocks before the admittance update consumes the force
+  bool coherent = true; // agent-scope loads (another agent may be writing: the doorbell-driven loop); false: plain loads
+  bool force_prefetched = false;
+  double force_now[3] = {};
+  __device__ __forceinline__ double ld(const double *p) const { return coherent ? ld_agent_f64(p) : *p; }
   __device__ __forceinline__ void prefetch_effort() {
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) effort_now[i] = ld_agent_f64(effort_ptr + int64_t(i / 2) * effort_pair + (i & 1));
+    for (int i = 0; i < NJ; ++i) effort_now[i] = ld(effort_ptr + int64_t(i / 2) * effort_pair + (i & 1));
     effort_prefetched = true;
   }
-  __device__ __forceinline__ V3 force() const { return V3{ld_agent_f64(force_ptr), ld_agent_f64(force_ptr + 1), ld_agent_f64(force_ptr + force_pair)}; }
+  __device__ __forceinline__ void prefetch_force() {
+    force_now[0] = ld(force_ptr), force_now[1] = ld(force_ptr + 1), force_now[2] = ld(force_ptr + force_pair);
+    force_prefetched = true;
+  }
+  __device__ __forceinline__ V3 force() const {
+    if (force_prefetched) return V3{force_now[0], force_now[1], force_now[2]};
+    return V3{ld(force_ptr), ld(force_ptr + 1), ld(force_ptr + force_pair)};
+  }
   __device__ __forceinline__ void effort(double (&e)[NJ]) const {
     if (effort_prefetched) {
 #pragma unroll
@@ -249,7 +262,7 @@ struct LegInRing {
       return;
     }
 #pragma unroll
-    for (int i = 0; i < NJ; ++i) e[i] = ld_agent_f64(effort_ptr + int64_t(i / 2) * effort_pair + (i & 1));
+    for (int i = 0; i < NJ; ++i) e[i] = ld(effort_ptr + int64_t(i / 2) * effort_pair + (i & 1));
   }
 };
 // (no dynamic indexing of the kernel-argument struct: that would move it to scratch)
@@ -359,7 +372,7 @@ __device__ __forceinline__ void resident_take_inputs(const ResidentArgs &A, cons
   }
 }
 
-template <int L, int NJ, unsigned F>
+template <int L, int NJ, unsigned F, bool BATCH = false>
 __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevState &st, LegRegs<NJ> &s, LegOut &out, const SharedConsts<L, NJ> &C,
                                               const RobTile<64 / L> &rb, const Park &pk, const Group<L> g, const int leg, const uint32_t slot,
                                               const int lane, const int64_t wave, const bool live, double *tile, int32_t *tile_i, unsigned &dirty,
@@ -372,17 +385,66 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
   const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.out, 0, int(unsigned(A.depth) * out_slot_bytes), 0x00020000);
   const u64 emergency_ticks = 4 * A.idle_ticks + 2000 * A.ticks_per_ms; // a worker never waits longer than this for the relay (2 s + 4 idle timeouts)
   unsigned c = 0, oslot = 0; // cycles completed; output ring position of cycle c
-  const bool batch = A.batch_cycles != 0; // (launch-uniform: a kernel argument) K cycles, released from the start, inputs row c of K-deep arrays
-  u64 gate = batch ? ((u64(A.batch_cycles) << 32) | A.batch_cycles) : uni64(ld_agent(&A.ctl->gate));
+  constexpr bool batch = BATCH; // the batch form (shc_engine_step_k) is a kernel of its own: K cycles, released from the start, inputs row c of K-deep arrays -
+                                // compiled without the handshake, and the doorbell-driven loop without the batch form's prefetches (scalar registers are scarce in both)
+  u64 gate = 0;
+  if constexpr (batch) gate = (u64(A.batch_cycles) << 32) | A.batch_cycles;
+  else gate = uni64(ld_agent(&A.ctl->gate));
   u64 h0 = 0, h1 = 0;
   bool hdr_valid = false;
+  // Batch form: the per-robot inputs of row `r` - velocity command (3 doubles per robot), IMU sample (gyro 3 + orientation 4) - as one load per lane
+  // and group (lane = field x robots-per-wave + robot), issued a whole cycle before batch_rob_commit() puts them into the LDS tile.
+  static_assert(R::WIN == R::VIN + 2 && R::IMUQ == R::GYRO + 3, "velocity inputs / gyro + orientation are contiguous in the tile");
+  constexpr int NI = (7 * RPW + 63) / 64; // loads per lane that cover the 7 IMU fields of the wave's robots
+  double rob_vel = 0.0, rob_imu[NI] = {};
+  const auto batch_rob_issue = [&](const int64_t r) {
+    const int64_t rob0 = wave * RPW;
+    if (A.batch_mask & (1u << RG_VEL)) { // [K][n][2], [K][n]
+      const int field = lane / RPW, rr = lane - field * RPW;
+      const int64_t rob = rob0 + rr;
+      const double *lin = bound_array(A, 0, BND_LIN) + r * A.kstride[BND_LIN], *ang = bound_array(A, 0, BND_ANG) + r * A.kstride[BND_ANG];
+      if (lane < 3 * RPW && rob < st.n_robots) rob_vel = field < 2 ? lin[rob * 2 + field] : ang[rob];
+    }
+    if (A.batch_mask & (1u << RG_IMU)) { // [K][n][3] gyro -> tile fields GYRO .. + 2, [K][n][4] orientation -> IMUQ .. + 3 (normalised at commit)
+      const double *q = bound_array(A, 0, BND_IMUQ) + r * A.kstride[BND_IMUQ], *w = bound_array(A, 0, BND_IMUW) + r * A.kstride[BND_IMUW];
+#pragma unroll
+      for (int h = 0; h < NI; ++h) {
+        const int idx = lane + 64 * h, field = idx / RPW, rr = idx - field * RPW;
+        const int64_t rob = rob0 + rr;
+        if (field < 7 && rob < st.n_robots) rob_imu[h] = field < 3 ? w[rob * 3 + field] : q[rob * 4 + (field - 3)];
+      }
+    }
+  };
+  const auto batch_rob_commit = [&]() {
+    if (A.batch_mask & (1u << RG_VEL)) {
+      const int field = lane / RPW, rr = lane - field * RPW;
+      if (lane < 3 * RPW && wave * RPW + rr < st.n_robots) tile[(R::VIN + field) * RPW + rr] = rob_vel;
+    }
+    if (A.batch_mask & (1u << RG_IMU)) {
+#pragma unroll
+      for (int h = 0; h < NI; ++h) {
+        const int idx = lane + 64 * h, field = idx / RPW, rr = idx - field * RPW;
+        if (field < 7 && wave * RPW + rr < st.n_robots) tile[(R::GYRO + field) * RPW + rr] = rob_imu[h];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < RPW && wave * RPW + lane < st.n_robots) { // Model::setImuData as shc_engine_set_imu stores it: the orientation normalised
+        const Quat qn = normalized(Quat{tile[(R::IMUQ + 0) * RPW + lane], tile[(R::IMUQ + 1) * RPW + lane], tile[(R::IMUQ + 2) * RPW + lane], tile[(R::IMUQ + 3) * RPW + lane]});
+        tile[(R::IMUQ + 0) * RPW + lane] = qn.w, tile[(R::IMUQ + 1) * RPW + lane] = qn.x, tile[(R::IMUQ + 2) * RPW + lane] = qn.y, tile[(R::IMUQ + 3) * RPW + lane] = qn.z;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
+  if constexpr (batch) batch_rob_issue(0);
   for (;;) {
     unsigned db = unsigned(gate), sp = unsigned(gate >> 32);
-    if (batch) {
+    if constexpr (batch) {
       if (c >= sp) break;
       h0 = u64(c) + 1, h1 = u64(A.batch_mask) | kResidentDirect; // what a direct post of set 0 would have left in the header ring
       hdr_valid = true;
-    } else if (!(c < db && c < sp)) {
+    }
+    if (!batch && !(c < db && c < sp)) {
       if (c >= sp) break;
       // nothing to run yet: the outputs of cycle c - 1 would otherwise be announced half a cycle into cycle c - announce them now
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -408,7 +470,8 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
       h1 = uni64(ld_agent(hp + 1));
     }
     // prefetch for the next iteration: the gate, and - once the doorbell is known to cover it - the header of cycle c + 1
-    const u64 gate_next_v = batch ? gate : ld_agent(&A.ctl->gate);
+    u64 gate_next_v = gate;
+    if constexpr (!batch) gate_next_v = ld_agent(&A.ctl->gate);
     const bool next_valid = !batch && db > c + 1;
     u64 n0v = 0, n1v = 0;
     if (next_valid) {
@@ -417,11 +480,24 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
       n1v = ld_agent(hp + 1);
     }
     const int64_t row = batch ? int64_t(c) : 0;
-    resident_take_inputs<64 / L, ROBOT_ALL, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots, row);
-    const LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg, row);
+    if constexpr (batch) { // row c of the K-deep arrays: the robot inputs were loaded one cycle ahead, the per-leg ones are read where they lie
+      held.seen |= A.batch_mask;
+      if (A.batch_mask & (1u << RG_FORCE)) held.src_force = -2;
+      if (A.batch_mask & (1u << RG_EFFORT)) held.src_effort = -2;
+      batch_rob_commit();
+      if (c + 1 < A.batch_cycles) batch_rob_issue(int64_t(c) + 1); // in flight for the whole of cycle c
+    } else {
+      resident_take_inputs<64 / L, ROBOT_ALL, true>(A, c, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots, row);
+    }
+    LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, int64_t(slot / 64) * RPW + (slot % 64) / L, leg, row);
+    if constexpr (batch) {
+      in.coherent = false;
+      if (Feat<F>::adm(C.P) || (F & F_ROUGH) != 0) in.prefetch_force();
+      if (Feat<F>::tipf(C.P)) in.prefetch_effort();
+    }
     // half a cycle after the output stores of cycle c - 1 were issued they have drained: publish "c cycles done"
     const auto publish_previous = [&]() {
-      if (batch) return; // (nobody watches the progress of a batch launch: the stream does)
+      if constexpr (batch) return; // (nobody watches the progress of a batch launch: the stream does)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) st_agent(A.progress + wave, u64(c));
     };
@@ -469,7 +545,7 @@ __device__ __forceinline__ void resident_loop(const ResidentArgs &A, const DevSt
     hdr_valid = next_valid;
     if (next_valid) h0 = uni64(n0v), h1 = uni64(n1v);
   }
-  if (!batch) {
+  if constexpr (!batch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) st_agent(A.progress + wave, u64(c));
   }
@@ -651,7 +727,7 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
 // the word).  Nothing is handed over beyond the state itself: the model half redoes PoseController::updateStance's two transforms (poser tip =
 // Model::current_pose_^-1 * walker tip, desired tip direction = pose rotation^-1 * walker tip direction, pose_controller.cpp:122-131) from the walker
 // tip, the walker tip direction and the current pose the walker half has just stored - 64 bytes read per leg instead of 48 written + 48 read.
-template <int L, int NJ, unsigned F, bool RES, int HALF = ROLE_ALL>
+template <int L, int NJ, unsigned F, bool RES, int HALF = ROLE_ALL, bool BATCH = false>
 __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConsts<L, NJ> *gc, int n_cycles, unsigned rt_flags, const int64_t wave,
                                            const ResidentArgs *ra) {
   static_assert(HALF == ROLE_ALL || (!RES && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_ADM | F_AUTO)) == 0), "half-step launches: feature-exact kernels without admittance / auto posing / terrain paths");
@@ -829,7 +905,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
   const bool pose_only = pose_marked && marked;
   ResidentHeld held;
   if constexpr (RES) {
-    resident_loop<L, NJ, F>(*ra, st, s, out, C, rb, pk, g, leg, slot, lane, wave, live, tile, tile_i, dirty, manual_live, held, touchdown_detection, ext);
+    resident_loop<L, NJ, F, BATCH>(*ra, st, s, out, C, rb, pk, g, leg, slot, lane, wave, live, tile, tile_i, dirty, manual_live, held, touchdown_detection, ext);
   } else if constexpr (HALF == ROLE_FRONT) {
     FrontToBack fb;
     fb.planes_in_sync = false;
@@ -912,15 +988,18 @@ template <int L, int NJ, unsigned F>
 // (rough terrain / tip rotations: one wavefront per SIMD - the resident loop around those cycles does not fit 256 registers without
 //  scratch, and a batch that is resident has SIMDs to spare: up to ~990 wavefronts, 9 900 hexapods / 7 900 octopods)
 __global__ void __launch_bounds__(64, (F & (F_ROT | F_ROUGH)) ? 1 : SHC_WAVES_PER_SIMD) shc_resident_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
-  if (ra.batch_cycles != 0) { // the batch form (shc_engine_step_k): no relay block, every block a worker wavefront
-    cycle_wave<L, NJ, F, true>(st, gc, 0, rt_flags, ra.batch_wave0 + int64_t(blockIdx.x), &ra);
-    return;
-  }
   if (blockIdx.x == 0) {
     resident_relay<PART_BOTH>(ra);
     return;
   }
   cycle_wave<L, NJ, F, true>(st, gc, 0, rt_flags, int64_t(blockIdx.x) - 1, &ra);
+}
+
+// The batch form of the loop (shc_engine_step_k: K cycles per launch, each with its own inputs, batches of any size): every block a worker wavefront,
+// no relay, no doorbell; two wavefronts per SIMD like the cycle kernels.
+template <int L, int NJ, unsigned F>
+__global__ void __launch_bounds__(64, (F & F_ROT) ? SHC_ROT_WAVES_PER_SIMD : SHC_WAVES_PER_SIMD) shc_batch_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
+  cycle_wave<L, NJ, F, true, ROLE_ALL, true>(st, gc, 0, rt_flags, ra.batch_wave0 + int64_t(blockIdx.x), &ra);
 }
 
 // ================================================================================ resident mode, two wavefronts per robot group
@@ -969,8 +1048,8 @@ struct PoseWait {
 };
 template <int L, int NJ>
 struct Resident2Lds { // dynamic LDS of one workgroup, after the two walker waves' tiles
-  double mailbox[2][2][13][64]; // [pair][cycle parity][field][lane]: PoseController::updateStance -> Leg::setDesiredTipPose (xyz), then the
-                                // desired body velocity (x, y, yaw rate) + whether the walker reached its odometry update; 7..12: the steppers'
+  double mailbox[2][2][13][64]; // [pair][cycle parity][field][lane]: PoseController::updateStance -> Leg::setDesiredTipPose (xyz); 3..6 the desired body
+                                // velocity + whether the walker reached its odometry update (where the model wavefront keeps the odometry); 7..12: the steppers'
                                 // walk plane / normal for the NEXT cycle's updateWalkPlanePose (pose on the model wave)
   double pose_c[2][2][64];      // walker -> model: the control input of the next cycle's walk-plane pose (walk_plane_control_input of the leg words updateWalk left)
   unsigned pose_done[2];        // model -> walker: poses completed (current_pose_ / walk-plane pose of that cycle are in the tile)
@@ -1099,16 +1178,20 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
   u64 bubble_since = 0;
   FrontToBack fb{V3{1, 0, 0}, false, LS_WALKING};
   fb.uf = load_uni_flags(C.P); // (once: the parameter block does not change while the loop runs)
-  OdomCache odom_cache;        // model wavefront: (sin, cos) of the half yaw step while the desired angular velocities stay as they are
+  OdomCache odom_cache;        // walker wavefront: (sin, cos) of the half yaw step while the desired angular velocities stay as they are
   Pose owpp_cache = pose_identity();
   if (POSE_SPLIT && active && !walker) owpp_cache = rb.getpose(R::OWPP); // ... and the origin walk-plane pose (the walker wavefront filled the tile before the barrier)
-  // ... and WalkController::odometry_ideal_ itself: nothing inside the loop reads it, so the model wavefront accumulates it in registers and
+  // ... and WalkController::odometry_ideal_ itself: nothing inside the loop reads it, so the wavefront that advances it (ODOM_WALKER below) accumulates it in registers and
   // puts it back into the tile when the loop ends (4 LDS reads + 4 writes per cycle less on the longer of the two wavefronts).  Short chains
   // only: the 4- and 5-joint model wavefronts already keep part of their state in AGPRs, four more loop-carried doubles cost them more
   // register moves than the LDS traffic they save (4 000 8 x 5 octopods: 3.47 -> 3.55 us per cycle with it)
   constexpr bool ODOM_REGS = NJ <= 3;
+  // ... on whichever wavefront is the shorter one (busy clocks per iteration, profiles/r05_probe_resident_balance.txt): the model wavefront for 3-joint legs
+  // without admittance / IMU posing (its IK step, FK and tip force are short: 5 120 against the walker's 5 330 clocks without the odometry), the walker
+  // wavefront for everything else (admittance, IMU posing, 4- and 5-joint chains make the model wavefront the longer one by 400 - 700 clocks)
+  constexpr bool ODOM_WALKER = NJ > 3 || (F & (F_ADM | F_IMU | F_INCL | F_AUTO | F_DYN)) != 0;
   double odom[4] = {0.0, 0.0, 1.0, 0.0};
-  if (ODOM_REGS && FT::odom(P) && active && !walker) {
+  if (ODOM_REGS && FT::odom(P) && active && walker == ODOM_WALKER) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) odom[i] = rb.get(R::ODOM + i);
   }
@@ -1140,6 +1223,8 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #define SHC_R2_ITER_BEGIN() do {} while (0)
 #define SHC_R2_ITER_END(THREAD, ...) do {} while (0)
 #endif
+  LegInRing<NJ> in_at; // model wavefront: where this lane's per-leg inputs in force lie (recomputed when a post moves them)
+  int in_src_force = -1000, in_src_effort = -1000;
   if (walker) {
     // ---------------------------------------------------------------- walker wavefront: cycle_front of cycle c_front
     for (;;) {
@@ -1152,20 +1237,29 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         SHC_TICK(21);
         const PoseWait<RPW> pose_wait{&X.pose_done[pair], c_front + 1, A.ticks_per_ms, &held.fault};
         cycle_front<L, NJ, F, false, LegInRing<NJ>, false, !POSE_SPLIT>(s, out, C, rb, pk, g, leg, st.legd, ns, slot, dirty, manual_live, false, nullptr, nullptr,
-                                                                        LegInRing<NJ>{nullptr, nullptr, 0, 0, false, {}}, fb, nullptr, pose_wait);
+                                                                        LegInRing<NJ>{}, fb, nullptr, pose_wait);
 #ifdef SHC_ABLATE
         if (!(P.debug_skip & 65536))
 #endif
         if (POSE_SPLIT) publish_for_pose(c_front + 1, fb.plane_prev_changed);
+        SHC_TICK(29);
         double *mb = &X.mailbox[pair][c_front & 1][0][lane];
         mb[0] = out.poser_tip.x, mb[64] = out.poser_tip.y, mb[128] = out.poser_tip.z;
-        if (FT::odom(P)) // the odometry accumulator is the model wavefront's: it has the time, nothing here reads it back
+        if constexpr (ODOM_WALKER) {
+          if (FT::odom(P) && __any(fb.odom_run)) { // odometry_ideal_ (walk_controller.cpp:643; robots whose updateWalk returned early keep theirs)
+            if (fb.odom_run) {
+              if constexpr (ODOM_REGS) odometry_advance(odom[0], odom[1], odom[2], odom[3], P, fb.odom_vel.x, fb.odom_vel.y, fb.odom_vel.z, &odom_cache);
+              else odometry_step(rb, P, fb.odom_vel.x, fb.odom_vel.y, fb.odom_vel.z, &odom_cache);
+            }
+          }
+        } else if (FT::odom(P)) { // the accumulator is the model wavefront's: the desired body velocity travels with the poser tip
           mb[192] = fb.odom_vel.x, mb[256] = fb.odom_vel.y, mb[320] = fb.odom_vel.z, mb[384] = fb.odom_run ? 1.0 : 0.0;
+        }
         SHC_TICK(22);
       }
       SHC_TICK(23);
       if (kind == IT_EXIT) break;
-      SHC_R2_ITER_END(0, 19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 15, 22, 23);
+      SHC_R2_ITER_END(0, 19, 20, 21, 2, 3, 4, 5, 6, 7, 16, 8, 17, 15, 29, 22, 23);
       if (kind == IT_REAL) ++c_front;
       prev_real = kind == IT_REAL;
       __syncthreads();
@@ -1177,6 +1271,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
       SHC_R2_ITER_BEGIN();
       const int kind = __builtin_amdgcn_readfirstlane(int(X.ctrl[k & 3][0]));
       const u64 h0 = uni64(X.ctrl[k & 3][1]), h1 = uni64(X.ctrl[k & 3][2]);
+      SHC_TICK(29);
       int nk = IT_EXIT;
       u64 nh0v = 0, nh1v = 0;
       if (leader && kind != IT_EXIT) { // what will iteration k + 1 be?
@@ -1211,6 +1306,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         SHC_TICK(24);
         if constexpr (POSE_SPLIT) if (kind == IT_REAL) { // PoseController::updateCurrentPose of the cycle the walker is starting: first thing, the walker waits for it
           resident_take_inputs<RPW, ROBOT_POSE, false>(A, c_front, h0, h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
+          SHC_TICK(30);
           double pose_c = -1.0; // the candidate of the LAST leg (in id order) of this lane's robot that has one (pose_controller.cpp:1100-1108)
 #pragma unroll
           for (int j = 0; j < L; ++j) {
@@ -1234,11 +1330,16 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         SHC_TICK(25);
         if (prev_real) { // the model half of the cycle whose walker half ran one iteration ago
           resident_take_inputs<RPW, ROBOT_NONE, true>(A, c_back, prev_h0, prev_h1, wave, lane, tile, tile_i, dirty, held, st.n_robots);
-          LegInRing<NJ> in = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, wave * RPW + grp, leg);
+          if (held.src_force != in_src_force || held.src_effort != in_src_effort) { // (wave-uniform; where the per-leg inputs lie changes with a post of that group only)
+            in_at = leg_inputs_in_force<L, NJ>(A, st.legd, held.src_force, held.src_effort, ns, slot, wave * RPW + grp, leg);
+            in_src_force = held.src_force, in_src_effort = held.src_effort;
+          }
+          LegInRing<NJ> in = in_at;
           if (FT::tipf(P)) in.prefetch_effort();
+          SHC_TICK(31);
           const double *mb = &X.mailbox[pair][c_back & 1][0][lane];
           out.poser_tip = V3{mb[0], mb[64], mb[128]};
-          if (FT::odom(P)) {
+          if constexpr (!ODOM_WALKER) if (FT::odom(P)) {
             const V3 ov{mb[192], mb[256], mb[320]};
             if (__any(mb[384] != 0.0)) { // (robots whose updateWalk returned early keep their odometry)
               if (mb[384] != 0.0) {
@@ -1256,6 +1357,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
           // the output stores of cycle c_back - 1 were issued one iteration ago: they have drained - announce them, then issue this cycle's
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (lane == 0) st_agent(A.progress + wave, u64(c_back));
+          SHC_TICK(13);
           {
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             double flat[2 * NJ];
@@ -1288,8 +1390,9 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
         X.ctrl[(k + 1) & 3][1] = nh0v;
         X.ctrl[(k + 1) & 3][2] = nh1v;
       }
+      SHC_TICK(14);
       if (kind == IT_EXIT) break;
-      SHC_R2_ITER_END(128, 24, 25, 26, 9, 10, 11, 12, 27, 28);
+      SHC_R2_ITER_END(128, 19, 29, 24, 30, 25, 31, 26, 9, 10, 11, 12, 27, 13, 28, 14);
       if (kind == IT_REAL) ++c_front;
       prev_real = kind == IT_REAL;
       prev_h0 = h0, prev_h1 = h1;
@@ -1307,24 +1410,22 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #ifndef SHC_RES2_BUSY_ONLY
     if (walker) {
       for (int i = 0; i < 32; ++i) dbg[8 + i] = (unsigned long long)shc_acc_lds[i];
-    } else { // (the model wavefront's stamps share the slots the walker does not use: 9 .. 14, 24 .. 31)
-      __builtin_amdgcn_s_sleep(100);
-      for (int i = 9; i < 15; ++i) dbg[4 + i] = (unsigned long long)shc_acc_lds[32 + i];   // (dbg points 4 words into ResidentCtl::dbg for the model wavefront)
-      for (int i = 24; i < 32; ++i) dbg[4 + i] = (unsigned long long)shc_acc_lds[32 + i];
+    } else { // (dbg points 4 words into ResidentCtl::dbg for the model wavefront: its phase clocks go to dbg[40 .. 72) of the record)
+      for (int i = 0; i < 32; ++i) dbg[36 + i] = (unsigned long long)shc_acc_lds[32 + i];
     }
 #endif
   }
 #endif
   // ---- epilogue: the halves exchange what the other one stores, then each writes its half of the state back
+  if (active && ODOM_REGS && FT::odom(P) && walker == ODOM_WALKER) { // the odometry accumulated in registers back into the tile the walker wavefront stores
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb.put(R::ODOM + i, odom[i]);
+  }
   if (active) {
     if (walker) {
       X.stiff[pair][lane] = s.stiff;
     } else {
       X.ikfail[pair][lane] = s.word & LW_IKFAIL;
-      if (ODOM_REGS && FT::odom(P)) { // the odometry accumulated in registers back into the tile the walker wavefront stores
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb.put(R::ODOM + i, odom[i]);
-      }
       if (POSE_SPLIT) { // what the pose on this wavefront dirtied / received is written back by the walker, which owns the tile stores
         unsigned d = 0;
 #pragma unroll

@@ -31,7 +31,7 @@ struct ResidentCtl { // device memory, polled with agent-scope loads; written by
   unsigned long long exited;    // worker waves that have left the loop
   unsigned long long fault;     // != 0: a worker gave up waiting (emergency bound) - state may be inconsistent
   unsigned long long pad[5];    // [0] exit reason, [1] cycles completed by every wave (device copy of ResidentHost::done), [2] the relay has left
-  unsigned long long dbg[40];   // development builds (-DSHC_RES2_TIMING): phase clocks of workgroup 1
+  unsigned long long dbg[80];   // development builds (-DSHC_RES2_TIMING): [0, 8) busy clocks, [8, 40) phase clocks of the walker, [40, 72) of the model wavefront of workgroup 1
 };
 struct ResidentHost { // pinned host memory mapped into the device (fine-grained): the host side of the handshake
   unsigned long long doorbell;  // host / producer -> device: cycles published since resident_begin

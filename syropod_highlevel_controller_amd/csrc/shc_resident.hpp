@@ -652,15 +652,21 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
       fprintf(stderr, "[res2 timing] %s: %.0f clocks busy per steady REAL iteration (%llu of them), loop %llu clocks, %llu iterations\n", w ? "model " : "walker",
               c.dbg[4 * w + 1] ? double(c.dbg[4 * w]) / double(c.dbg[4 * w + 1]) : 0.0, c.dbg[4 * w + 1], c.dbg[4 * w + 2], c.dbg[4 * w + 3]);
 #ifndef SHC_RES2_BUSY_ONLY
-    const int order[] = {19, 20, 21, 2, 3, 4, 5, 6, 7, 8, 15, 22, 23};
+    const int order[] = {20, 21, 2, 3, 4, 5, 6, 7, 16, 8, 17, 15, 29, 22, 23};
+    const char *wname[] = {"control words (LDS) read", "inputs of the cycle taken", "cycle_front entry", "robot word / command read, stop predicates", "(pose elsewhere)", "getLimit",
+                           "velocity shaping", "walk state machine", "stepper (stride, Bezier, tip)", "tip rotation / iteratePhase / planes / leg word", "wait for the pose flag",
+                           "pose read + updateStance", "control input for the next pose published", "mailbox written", "to the barrier"};
     const double its = c.dbg[1] ? double(c.dbg[1]) : 1.0;
-    fprintf(stderr, "[res2 timing] walker of pair 0, mean clocks per phase (up to stamp t):");
-    for (int i : order) fprintf(stderr, " t%d=%.0f", i, double(c.dbg[8 + i]) / its);
-    fprintf(stderr, "\n");
-    const int morder[] = {24, 25, 26, 9, 10, 11, 12, 27, 28};
-    fprintf(stderr, "[res2 timing] model wavefront of pair 0 (the leader), mean clocks per phase (up to stamp t):");
-    for (int i : morder) fprintf(stderr, " t%d=%.0f", i, double(c.dbg[8 + i]) / its);
-    fprintf(stderr, "\n");
+    fprintf(stderr, "[res2 timing] walker of pair 0, mean clocks per phase:\n");
+    for (int i = 0; i < int(sizeof(order) / sizeof(int)); ++i) fprintf(stderr, "[res2 timing]   walker t%-2d %-58s %7.0f\n", order[i], wname[i], double(c.dbg[8 + order[i]]) / its);
+    const int morder[] = {29, 24, 30, 25, 31, 26, 9, 10, 11, 12, 27, 13, 28, 14};
+    const char *mname[] = {"control words (LDS) read", "leader: gate, what the next iteration is, header prefetch issued", "pose inputs of the cycle taken",
+                           "updateCurrentPose of the walker's cycle + flag", "leg inputs in force, joint efforts prefetched", "mailbox read, odometry, admittance",
+                           "cycle_back entry (desired tip)", "IK step + joint update", "sin / cos, chain, Jacobian", "model tip, tip force", "cycle_back exit",
+                           "wait for the previous stores + progress word", "output-ring stores issued", "control words written (leader: waits for its loads)"};
+    const double mits = c.dbg[5] ? double(c.dbg[5]) : 1.0;
+    fprintf(stderr, "[res2 timing] model wavefront of pair 0 (the leader), mean clocks per phase:\n");
+    for (int i = 0; i < int(sizeof(morder) / sizeof(int)); ++i) fprintf(stderr, "[res2 timing]   model  t%-2d %-58s %7.0f\n", morder[i], mname[i], double(c.dbg[40 + morder[i]]) / mits);
 #endif
   }
 #endif

@@ -48,6 +48,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_resident_get_joint_state", "shc_engine_resident_get_joint_state_async", "shc_engine_resident_status", "shc_engine_resident_end", "shc_engine_join",
     "shc_engine_aux_state_bytes", "shc_engine_get_aux_state", "shc_engine_set_aux_state",
     "shc_engine_step_k", "shc_engine_get_step_k_joint_state",
+    "shc_peer_alloc", "shc_peer_open", "shc_peer_close", "shc_peer_scatter",
 ]
 
 
@@ -216,6 +217,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p] + [C.c_void_p] * n + [C.c_int]
         L.shc_engine_step.argtypes = [C.c_void_p, C.c_int]
         L.shc_engine_step_k.argtypes = [C.c_void_p, C.c_int, C.POINTER(CycleInputs)]
+        L.shc_peer_alloc.argtypes = [C.c_int, C.c_int64, C.POINTER(C.c_void_p), C.c_char_p]
+        L.shc_peer_open.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.shc_peer_close.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.shc_peer_scatter.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
         L.shc_engine_get_step_k_joint_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
         L.shc_engine_join.argtypes = [C.c_void_p]
         L.shc_engine_aux_state_bytes.argtypes = [C.c_void_p]

@@ -57,3 +57,56 @@ def all_gather_joints(local, world: int, out=None):
         return out
     dist.all_gather_into_tensor(out, local.reshape(-1).contiguous())
     return out
+
+
+class PeerAllGather:
+    """The same exchange as `all_gather_joints`, as peer copies over xGMI instead of a collective (include/shc_batch.h: shc_peer_*): every rank
+    owns a gathered buffer [world][shard], exports it, opens its peers' and, per exchange, writes its shard into every buffer at its own offset -
+    world - 1 copies on world - 1 streams (one per xGMI link) + the local one.  `barrier` (a callable every rank enters, e.g. bench.py's
+    HostSpinBarrier or torch.distributed.barrier) closes an exchange: when it returns on a rank, that rank's buffer holds every shard.
+    torch.distributed (any backend) is only used once, to exchange the 64-byte handles."""
+
+    def __init__(self, shard_numel: int, world: int, rank: int, device: int):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import engine as _engine
+        self.L, self.C, self.world, self.rank, self.device = _engine.lib(), C, world, rank, device
+        self.shard_bytes = int(shard_numel) * 8
+        own, handle = C.c_void_p(), C.create_string_buffer(64)
+        _engine._check(self.L.shc_peer_alloc(device, self.shard_bytes * world, C.byref(own), handle), "shc_peer_alloc")
+        self.own = own.value
+        handles = [None] * world
+        if world > 1 or (dist.is_available() and dist.is_initialized()):
+            dist.all_gather_object(handles, bytes(handle.raw))
+        else:
+            handles[0] = bytes(handle.raw)
+        self.peers = []
+        for r in range(world):
+            if r == rank:
+                self.peers.append(self.own)
+                continue
+            p = C.c_void_p()
+            _engine._check(self.L.shc_peer_open(device, handles[r], C.byref(p)), "shc_peer_open")
+            self.peers.append(p.value)
+        self.dst = (C.c_void_p * world)(*[p + rank * self.shard_bytes for p in self.peers])
+
+        class _View:   # the rank's own gathered buffer as a torch tensor (__cuda_array_interface__: no copy)
+            __cuda_array_interface__ = {"shape": (world * int(shard_numel),), "typestr": "<f8", "data": (self.own, False), "version": 2}
+        self.out = torch.as_tensor(_View(), device=f"cuda:{device}")
+
+    def gather(self, local, stream: int, barrier=None):
+        """local: this rank's shard (contiguous float64 device tensor); the copies are ordered after `stream` and `stream` after them."""
+        from . import engine as _engine
+        _engine._check(self.L.shc_peer_scatter(self.device, self.C.c_void_p(local.data_ptr()), self.shard_bytes, self.dst, self.world, self.C.c_void_p(stream)), "shc_peer_scatter")
+        if barrier is not None:
+            import torch
+            torch.cuda.current_stream().synchronize() if stream == torch.cuda.current_stream().cuda_stream else torch.cuda.synchronize()
+            barrier()
+        return self.out
+
+    def close(self):
+        for r, p in enumerate(self.peers):
+            if p:
+                self.L.shc_peer_close(self.device, self.C.c_void_p(p), 0 if r == self.rank else 1)
+        self.peers = []

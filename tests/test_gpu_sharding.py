@@ -47,13 +47,28 @@ def _run_hip(case, lo, hi, cycles, resident):
     return q
 
 
-def _worker(rank, world, port, case, n_total, cycles, resident, out_path):
+def _worker(rank, world, port, case, n_total, cycles, resident, out_path, peer=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_bounds(n_total, rank, world)
     q = torch.from_numpy(_run_hip(case, lo, hi, cycles, resident))
-    gathered = all_gather_joints(q, world)
+    if peer:   # the exchange as peer copies (shc_peer_*): every rank writes its shard into every rank's buffer - here two processes on device 0
+        from syropod_highlevel_controller_amd.parallel import PeerAllGather
+        qd = q.cuda().reshape(-1).contiguous()
+        pg = PeerAllGather(qd.numel(), world, rank, 0)
+        for _ in range(2):   # (twice: the buffers and streams of the first exchange are reused)
+            pg.gather(qd, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            dist.barrier()
+        gathered = pg.out.cpu()
+        own = gathered[rank * qd.numel():(rank + 1) * qd.numel()]
+        assert torch.equal(own, qd.cpu())
+        dist.barrier()
+        pg.close()
+    else:
+        gathered = all_gather_joints(q, world)
     dist.barrier()
     if rank == 0:
         np.save(out_path, gathered.numpy())
@@ -70,4 +85,17 @@ def test_two_ranks_with_the_hip_engine_match_the_unsharded_run(tmp_path, case, r
     gathered = np.load(out).reshape(n_total, p.leg_count * p.leg_dof[0])
     full = _run_hip(case, 0, n_total, cycles, resident)
     assert np.isfinite(full).all()
+    assert np.array_equal(gathered, full)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_exchange_their_shards_by_peer_copies(tmp_path):
+    """bench.py --gather peer: the final joint buffer exchanged with shc_peer_alloc / open / scatter (IPC handles passed over the process group, one copy
+    per destination on its own stream) instead of the collective library's all-gather; the gathered buffer equals the unsharded run bit for bit."""
+    case, n_total, cycles, world = "octopods", 2000, 120, 2
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(world, _free_port(), case, n_total, cycles, False, out, True), nprocs=world, join=True)
+    p = _params(case)
+    gathered = np.load(out).reshape(n_total, p.leg_count * p.leg_dof[0])
+    full = _run_hip(case, 0, n_total, cycles, False)
     assert np.array_equal(gathered, full)
