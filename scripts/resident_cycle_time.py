@@ -1,6 +1,6 @@
 """Development aid: time per cycle of the resident loop on bench.py's headline configuration (4 096 hexapods, joint efforts live), one
 launch of K cycles released at once, plus a checksum of the final joints (variants of the library must agree byte for byte).
-usage: [SHC_LIB=path] python scripts/resident_cycle_time.py [instances] [cycles] [config2|config3|octopod]"""
+usage: [SHC_LIB=path] python scripts/resident_cycle_time.py [instances] [cycles] [config2|config3|octopod|rough|gravity]"""
 import hashlib
 import sys
 import time
@@ -18,6 +18,12 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 4000
 case = sys.argv[3] if len(sys.argv) > 3 else "config2"
 if case == "octopod":
     p = synthetic_octopod_params("ripple", 5, 8)
+elif case == "gravity":       # gravity-aligned tips on 5-joint legs: tip rotations + the rotation-constrained IK, one wavefront per robot group
+    p = synthetic_octopod_params("ripple", 5, 8)
+    p.gravity_aligned_tips = 1
+elif case == "rough":         # rough terrain mode: touchdown detection inside the loop, step-plane targets (one wavefront per robot group)
+    p = default_hexapod_params("tripod")
+    p.rough_terrain_mode, p.step_depth = 1, 0.012
 else:
     p = default_hexapod_params("tripod" if case == "config2" else "wave")
     if case == "config3":
@@ -26,6 +32,10 @@ else:
 lin, ang = velocity_inputs(0xC0FFEE, 0, n)
 rng = np.random.default_rng(1)
 eng = BatchEngine(p, n)
+if case == "rough":   # contact forces as bench.py's rough workload draws them (held while the loop runs)
+    f = rng.normal(0, 0.25, (n, 6, 3))
+    f[..., 2] += rng.choice([0.0, 0.05, 0.6, 1.5], size=(n, 6), p=[0.3, 0.2, 0.2, 0.3])
+    eng.set_tip_force(f)
 import os  # noqa: E402
 if not os.environ.get("SHC_NO_EFFORTS"):
     eng.set_joint_effort(rng.normal(0, 0.5, (n, p.leg_count * p.leg_dof[0])))

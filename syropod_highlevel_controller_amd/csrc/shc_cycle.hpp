@@ -227,11 +227,19 @@ SHC_HD double stance_span_change_y(const double *table, int leg, double default_
 // Phase fences (-DSHC_FENCE): scheduling barriers between the phases of the cycle.  They bounded live ranges while the
 // kernel was register-starved; with MachineLICM off (see engine.py) the cycle fits without them, and the max-ILP
 // scheduler overlaps the LDS / division latencies of neighbouring phases (-6 % per launch), so they are off by default.
+// Round 5: they are back for the specialisations where the allocator misses 256 registers by ten without them - the feature-exact kernels of 4- and
+// 8-legged robots with 4-joint legs (40 B of scratch per lane otherwise; with the fences 232 / 238 VGPRs, none) and the 8 x 5 kernels with the tip-force estimate.  -DSHC_FENCE: everywhere (development).
+template <int L, int NJ, unsigned F>
+constexpr bool phase_fences() {
 #if defined(SHC_FENCE)
-#define SHC_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+  return true;
 #else
-#define SHC_PHASE_FENCE() do {} while (0)
+  constexpr bool exact = (F & (0x80000000u /* F_DYN */ | 0x40000000u /* F_ROT */)) == 0;
+  constexpr bool octo_tipf = L == 8 && NJ == 5 && (F & 32u /* F_TIPF */) != 0 && (F & 16u /* F_ADM */) == 0; // 8 x 5 with the tip-force estimate (12 B otherwise; the
+  return exact && ((NJ == 4 && (L == 4 || L == 8)) || octo_tipf);                                             // rotation-constrained model half keeps its 20 B: 40 B with fences)
 #endif
+}
+#define SHC_PHASE_FENCE() do { if constexpr (phase_fences<L, NJ, F>()) __builtin_amdgcn_sched_barrier(0); } while (0)
 // Development-only phase timestamps (build with -DSHC_RES2_TIMING) of the two-wavefront resident kernel: the leader of workgroup 1 keeps
 // the s_memtime stamps of its latest iteration in LDS; shc_engine_resident_end prints them.
 #if defined(SHC_RES2_TIMING) && !defined(SHC_RES2_BUSY_ONLY) // (-DSHC_RES2_BUSY_ONLY: only the two stamps per iteration of each role, no phase ticks)

@@ -25,7 +25,7 @@ static void launch_cycle(const CycleLaunch &a) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, shc_resident_kernel<L, NJ, F>, 64, wave_bytes) != hipSuccess) blocks = 0;
         a.fit->blocks_per_cu = blocks;
       } else if (a.resident->batch_cycles != 0) { // shc_engine_step_k: the batch form, a kernel of its own
-        shc_batch_kernel<L, NJ, F><<<dim3(a.grid), dim3(64), wave_bytes, a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
+        shc_batch_kernel<L, NJ, F><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
       } else if (a.block == 256) {
         if constexpr (two_wave)
           shc_resident2_kernel<L, NJ, F><<<dim3(a.grid), dim3(256), 2 * wave_bytes + sizeof(Resident2Lds<L, NJ>), a.stream>>>(

@@ -995,11 +995,11 @@ __global__ void __launch_bounds__(64, (F & (F_ROT | F_ROUGH)) ? 1 : SHC_WAVES_PE
   cycle_wave<L, NJ, F, true>(st, gc, 0, rt_flags, int64_t(blockIdx.x) - 1, &ra);
 }
 
-// The batch form of the loop (shc_engine_step_k: K cycles per launch, each with its own inputs, batches of any size): every block a worker wavefront,
-// no relay, no doorbell; two wavefronts per SIMD like the cycle kernels.
+// The batch form of the loop (shc_engine_step_k: K cycles per launch, each with its own inputs, batches of any size): every wavefront a worker,
+// no relay, no doorbell; workgroups and wavefronts per SIMD like the cycle kernels.
 template <int L, int NJ, unsigned F>
-__global__ void __launch_bounds__(64, (F & F_ROT) ? SHC_ROT_WAVES_PER_SIMD : SHC_WAVES_PER_SIMD) shc_batch_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
-  cycle_wave<L, NJ, F, true, ROLE_ALL, true>(st, gc, 0, rt_flags, ra.batch_wave0 + int64_t(blockIdx.x), &ra);
+__global__ void __launch_bounds__(256, (F & F_ROT) ? SHC_ROT_WAVES_PER_SIMD : SHC_WAVES_PER_SIMD) shc_batch_kernel(DevState st, const SharedConsts<L, NJ> *gc, ResidentArgs ra, unsigned rt_flags) {
+  cycle_wave<L, NJ, F, true, ROLE_ALL, true>(st, gc, 0, rt_flags, ra.batch_wave0 + ((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6), &ra);
 }
 
 // ================================================================================ resident mode, two wavefronts per robot group

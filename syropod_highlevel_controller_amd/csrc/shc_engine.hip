@@ -270,6 +270,7 @@ struct shc_engine {
   double *d_span = nullptr;             // SpanTable (rough terrain mode with a stance span modifier), rebuilt with the tables
   int half_steps = 0;                   // CycleLaunch::half_steps (development switch SHC_ROT_SPLIT = 0 / 1: never / always; unset: by launch size)
   bool span_dirty = true;
+  bool fresh_pose_controller = false;   // init_state for shc_engine_begin_sequence_startup: no direct start-up has run, the auto posers have not been called yet
   struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
   const double *bound_inputs[kBoundSets][BND_COUNT] = {}; // shc_engine_resident_bind_inputs: the caller's device arrays for direct posts
   // Large batches: a step is launched as two halves on two streams with no join between steps (see shc_engine_step).
@@ -574,7 +575,11 @@ __global__ void init_chain_legs_kernel(const shc_params *params, shc_tables *tab
   int l = r / 8, b = r % 8 + 1;
   if (m >= count || status[m] != SHC_OK) return;
   const shc_params &p = params[m];
-  if (p.leg_dof[0] != NJ || l >= p.leg_count) return;
+  // (a robot whose legs differ in DOF runs on the chain of its longest leg: the host has padded the shorter legs - normalised_params - exactly as
+  //  shc_generate_tables does, so Model::generateWorkspaces' per-leg search, model.cpp:309-510, evaluates each leg's own joints)
+  int nj = 0;
+  for (int k = 0; k < p.leg_count && k < SHC_MAX_LEGS; ++k) nj = p.leg_dof[k] > nj ? p.leg_dof[k] : nj;
+  if (nj != NJ || l >= p.leg_count) return;
   hostinit::generate_tables_leg<NJ>(p, l, tables[m], b, b);
 }
 __global__ void init_chain_head_kernel(const shc_params *params, shc_tables *tables, int32_t *status, int64_t count) {
@@ -594,11 +599,11 @@ extern "C" int shc_generate_tables_batch(const shc_params *params, int64_t count
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(SHC_ERR_NO_DEVICE, "no HIP device visible");
   HIP_TRY(hipSetDevice(device));
   std::vector<int32_t> st(count);
+  std::vector<shc_params> np(static_cast<size_t>(count));
   for (int64_t i = 0; i < count; ++i) { // parameter screening is host logic (same rules as shc_engine_create)
     int L, NJ;
     st[i] = validate_params(&params[i], &L, &NJ);
-    if (st[i] == SHC_OK && mixed_dof(params[i])) // (the device chain instantiates per DOF; robots whose legs differ go through the host chain)
-      st[i] = fail(SHC_ERR_UNSUPPORTED, "shc_generate_tables_batch: legs of different DOF in one robot (use shc_generate_tables)");
+    np[size_t(i)] = st[i] == SHC_OK ? normalised_params(params[i]) : params[i]; // (neutral entries for the padded joints of legs shorter than the robot's longest)
   }
   shc_params *d_p = nullptr;
   shc_tables *d_t = nullptr;
@@ -611,7 +616,7 @@ extern "C" int shc_generate_tables_batch(const shc_params *params, int64_t count
   HIP_TRY_OR(hipMalloc(&d_p, size_t(count) * sizeof(shc_params)), release());
   HIP_TRY_OR(hipMalloc(&d_t, size_t(count) * sizeof(shc_tables)), release());
   HIP_TRY_OR(hipMalloc(&d_s, size_t(count) * 4), release());
-  HIP_TRY_OR(hipMemcpy(d_p, params, size_t(count) * sizeof(shc_params), hipMemcpyHostToDevice), release());
+  HIP_TRY_OR(hipMemcpy(d_p, np.data(), size_t(count) * sizeof(shc_params), hipMemcpyHostToDevice), release());
   HIP_TRY_OR(hipMemcpy(d_s, st.data(), size_t(count) * 4, hipMemcpyHostToDevice), release());
   HIP_TRY_OR(hipMemset(d_t, 0, size_t(count) * sizeof(shc_tables)), release());
   const unsigned gm = (unsigned)((count + 63) / 64), gl = (unsigned)((count * SHC_MAX_LEGS * 8 + 63) / 64);
@@ -768,8 +773,8 @@ static void build_templates(const shc_engine *e, std::vector<double> &legt, std:
   // pose_controller.cpp:1476-1567), and every call advances the pose phase counter and lets the posers latch on
   // (start_check is unconditional without step-cycle sync, :1359-1371).  Replay those calls for the flags / counter the
   // first RUNNING cycle starts from; the walk state is STOPPED throughout, hence auto_posing_state STOP_POSING.
-  if (e->params.auto_posing && e->params.pose_frequency != -1.0 && e->tables.pose_phase_length > 0) {
-    int calls = round_to_int(e->params.time_to_start / e->params.time_delta);
+  if (e->params.auto_posing && e->params.pose_frequency != -1.0 && e->tables.pose_phase_length > 0 && !e->fresh_pose_controller) { // (a start-up SEQUENCE begins with a fresh PoseController:
+    int calls = round_to_int(e->params.time_to_start / e->params.time_delta);                                                    //  its loops run the pose themselves, sequence_launch)
     if (calls < 1) calls = 1;
     const int len = e->tables.pose_phase_length, nrm = e->tables.pose_normaliser;
     int phase_counter = 0, flags = 0;
@@ -1851,6 +1856,7 @@ __global__ void get_external_kernel(DevState st, int L, int64_t first, int64_t c
 }
 
 static int ensure_seq(shc_engine *e);
+static int ensure_manual(shc_engine *e, bool planner);
 static int external_select(shc_engine *e, int which, int64_t first, int64_t count, int leg, int64_t *rows_out) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (which != SHC_EXTERNAL_TARGET && which != SHC_EXTERNAL_DEFAULT && which != SHC_EXTERNAL_PLANNER_TARGET)
@@ -2270,8 +2276,6 @@ __global__ void set_joint_positions_kernel(DevState st, const double *q, int per
 extern "C" int shc_engine_begin_sequence_startup(shc_engine *e, const double *joint_positions, int per_instance) {
   SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
-  if (e->params.auto_posing && e->params.pose_frequency != -1.0)
-    return fail(SHC_ERR_UNSUPPORTED, "sequences with auto posing on its own clock (the body pose would move during the sequence)");
   // (arguments first: an INVALID_ARG return leaves the batch as it was)
   if (per_instance && !joint_positions) return fail(SHC_ERR_INVALID_ARG, "per_instance needs joint_positions");
   const size_t rows = per_instance ? size_t(e->n) * e->L : size_t(e->L);
@@ -2283,7 +2287,9 @@ extern "C" int shc_engine_begin_sequence_startup(shc_engine *e, const double *jo
     for (int l = 0; l < e->L; ++l)
       for (int j = 0; j < e->NJ; ++j) q[size_t(l) * e->NJ + j] = e->params.joint[l][j].unpacked;
   }
+  e->fresh_pose_controller = true;
   int rc = init_state(e); // StateController::init(): fresh walker / poser state
+  e->fresh_pose_controller = false;
   if (rc != SHC_OK) return rc;
   HIP_TRY(hipMemcpyAsync(e->d_stage, q.data(), q.size() * 8, hipMemcpyHostToDevice, e->stream));
   const int64_t threads = e->n * e->L;
@@ -2344,12 +2350,26 @@ static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(ST
   }
   int32_t *d_progress = reinterpret_cast<int32_t *>(e->d_stage); // [n] ints fit the staging buffer (>= n * 8 * 8 bytes)
   const dim3 grid((unsigned)((e->n + 63) / 64)), block(64);
+  // Auto posing on its own clock keeps posing through the sequence (pose_controller.cpp:1134-1187 runs in every loop, state_controller.cpp:165-167): the
+  // posing part of this loop runs in the cycle kernel for the robots whose sequence is still running (a pose-only pass, as for leg toggles and plan steps)
+  const bool own_clock = e->params.auto_posing && e->params.pose_frequency != -1.0;
+  if (own_clock) {
+    if ((rc = ensure_manual(e, false)) != SHC_OK) return rc;
+    sequence_mark_kernel<<<grid, block, 0, e->stream>>>(e->st.manual, e->d_seq, e->n, which, 1);
+    HIP_TRY(hipGetLastError());
+    if ((rc = pose_pass(e)) != SHC_OK) return rc;
+    P.posed = 1;
+  }
 #define CALL(L_, NJ_)                                                                                                                        \
   if (which == 2) step_to_new_stance_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, e->d_seq, P, d_progress); \
   else execute_sequence_kernel<L_, NJ_><<<grid, block, 0, e->stream>>>(e->st, (const SharedConsts<L_, NJ_> *)e->d_consts, e->d_seq, which, P, d_progress)
   SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
   HIP_TRY(hipGetLastError());
+  if (own_clock) {
+    sequence_mark_kernel<<<grid, block, 0, e->stream>>>(e->st.manual, e->d_seq, e->n, which, 0);
+    HIP_TRY(hipGetLastError());
+  }
   if (progress) HIP_TRY(hipMemcpyAsync(progress, d_progress, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return SHC_OK;
@@ -2364,7 +2384,7 @@ extern "C" int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t 
 extern "C" int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress) { return sequence_launch(e, 2, progress); }
 
 // ---- manual leg manipulation (shc_sequence.hpp)
-static int ensure_manual(shc_engine *e, bool planner = false) {
+static int ensure_manual(shc_engine *e, bool planner) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   const shc_params &p = e->params;
   if (e->cp.tip_align)
@@ -2386,7 +2406,7 @@ static int ensure_manual(shc_engine *e, bool planner = false) {
 
 extern "C" int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_selection, int32_t *result) {
   SHC_BUSY_GUARD(e);
-  int rc = ensure_manual(e);
+  int rc = ensure_manual(e, false);
   if (rc != SHC_OK) return rc;
   if (!leg_selection) return fail(SHC_ERR_INVALID_ARG, "leg_selection is NULL");
   int32_t *d_sel = reinterpret_cast<int32_t *>(e->d_stage), *d_res = d_sel + e->n, *d_cycle = d_res + e->n;
@@ -2426,7 +2446,7 @@ extern "C" int shc_engine_toggle_leg_state(shc_engine *e, const int32_t *leg_sel
 extern "C" int shc_engine_set_manual_inputs(shc_engine *e, const int32_t *primary_leg, const double *primary_tip_velocity, const double *primary_tip_position,
                                             const int32_t *secondary_leg, const double *secondary_tip_velocity, const double *secondary_tip_position) {
   SHC_BUSY_GUARD(e);
-  int rc = ensure_manual(e);
+  int rc = ensure_manual(e, false);
   if (rc != SHC_OK) return rc;
   // staging layout: [primary leg | secondary leg] ints, then four [n][3] double blocks
   const size_t n = size_t(e->n);
@@ -2618,6 +2638,12 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   HIP_TRY(hipSetDevice(e->device));
+  // Auto posing on its own clock poses the body through the sequence calls (sequence_launch), but what follows a completed START_UP does not carry over yet: the
+  // PoseController's phase counter and poser latches live on through walker_->init() (:306), Leg::generateWorkspace runs at the pose of THAT loop (model.cpp:338)
+  // and the runningState() of the same loop reuses it (:165-167 ran once) - this entry point re-initialises the whole state record and runs a full cycle.
+  if (e->params.auto_posing && e->params.pose_frequency != -1.0)
+    return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup with auto posing on its own clock (the sequence calls themselves are supported; start such robots "
+                                     "with the direct start-up, shc_engine_create)");
   // Model::updateDefaultConfiguration + generateWorkspaces + generateWalkspace (state_controller.cpp:307-310): the tables of an
   // engine belong to its morphology, so the configuration of instance 0 stands for the batch.  Robots that were started from
   // different joint positions (shc_engine_begin_sequence_startup per_instance) end their sequences on the same READY stance

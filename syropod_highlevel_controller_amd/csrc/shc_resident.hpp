@@ -696,7 +696,9 @@ extern "C" int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run) {
 static int step_k_out_ring(shc_engine *e, int K) {
   const size_t need = size_t(K) * size_t(e->NJ) * size_t(e->n_slots) * 16;
   if (e->k_out && e->k_out_bytes >= need) return SHC_OK;
-  if (e->k_out) {
+  if (e->k_out) { // (a launch on the split streams may still be writing the ring that is about to be replaced)
+    const int rc = join_side(e);
+    if (rc != SHC_OK) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     (void)hipFree(e->k_out);
     e->k_out = nullptr, e->k_out_bytes = 0;
@@ -707,7 +709,7 @@ static int step_k_out_ring(shc_engine *e, int K) {
 }
 
 extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_inputs *in) {
-  SHC_BUSY_GUARD(e);
+  SHC_BUSY_ONLY(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1 || n_cycles > 4096) return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: 1 .. 4096 cycles per launch");
   if (e->starting_up) return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k starts from a running engine (finish the start-up first)");
@@ -724,6 +726,11 @@ extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_in
     if (in->joint_effort) mask |= 1u << RG_EFFORT;
   }
   HIP_TRY(hipSetDevice(e->device));
+  const bool split = e->n_waves >= kSplitWaves && !(e->features & SHC_FEAT_SINGLE_STREAM);
+  if (!split || ((mask & (1u << RG_EFFORT)) && !(e->rt_flags & RT_EFFORT_LIVE))) { // (one launch on the engine's stream / the parameter block is about to be re-uploaded)
+    const int rc = join_side(e);
+    if (rc != SHC_OK) return rc;
+  }
   if (mask & (1u << RG_EFFORT)) { // Leg::calculateTipForce has something to filter from now on (as shc_engine_set_joint_effort)
     const int rc = effort_live(e);
     if (rc != SHC_OK) return rc;
@@ -761,10 +768,13 @@ extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_in
   A.idle_ticks = 0, A.ticks_per_ms = 100000;
   A.touchdown_threshold = e->params.touchdown_threshold;
   A.liftoff_threshold = e->params.liftoff_threshold;
-  // From kSplitWaves waves on the launch goes out as two halves on the two split streams, as the steps of shc_engine_step do (one half's tail
-  // under the other half's full rounds); both are ordered after the engine's stream and the engine's stream after both.
-  const bool split = e->n_waves >= kSplitWaves && !(e->features & SHC_FEAT_SINGLE_STREAM);
-  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, unsigned(e->n_waves), 64, 0, &A, nullptr, 0};
+  // Workgroups as shc_engine_step picks them; from kSplitWaves waves on the launch goes out as two halves on the two split streams, and - as there -
+  // the halves are NOT joined between launches (one half's tail runs under the other half's full rounds, launch after launch): each half is ordered
+  // after the engine's stream (where the caller's input rows were written) and after its own previous launch; the engine's stream is ordered after
+  // both at the next call that needs it (join_side: every SHC_BUSY_GUARD entry point, shc_engine_get_step_k_joint_state among them).
+  const int block = e->n_waves < 1536 ? 64 : 128;
+  const int64_t wpb = block / 64;
+  CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, unsigned((e->n_waves + wpb - 1) / wpb), block, 0, &A, nullptr, 0};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
   if (!split) {
     SHC_DISPATCH(e->L, e->NJ, CALL);
@@ -778,18 +788,17 @@ extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_in
       HIP_TRY(hipEventCreateWithFlags(&e->ev_half[1], hipEventDisableTiming));
     }
     HIP_TRY(hipEventRecord(e->ev_main, e->stream));
-    const int64_t half = e->n_waves / 2;
+    const int64_t half = ((e->n_waves / 2 + wpb - 1) / wpb) * wpb;
     for (int h = 0; h < 2; ++h) {
       HIP_TRY(hipStreamWaitEvent(e->half_stream[h], e->ev_main, 0));
       A.batch_wave0 = h ? half : 0;
       a.stream = e->half_stream[h];
-      a.grid = unsigned(h ? e->n_waves - half : half);
+      a.grid = unsigned(((h ? e->n_waves - half : half) + wpb - 1) / wpb);
       SHC_DISPATCH(e->L, e->NJ, CALL);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(e->ev_half[h], e->half_stream[h]));
-      HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_half[h], 0));
     }
-    e->main_dirty = true;
+    e->main_dirty = false;
+    e->side_busy = true;
   }
 #undef CALL
   e->k_out_cycles = n_cycles;

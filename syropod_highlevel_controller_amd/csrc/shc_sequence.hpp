@@ -48,7 +48,18 @@ struct SeqParams {
   int gravity_aligned_tips; // params.gravity_aligned_tips (transitionStance's target rotation)
   int pose_pass;      // the body pose moves while a robot stands (IMU / auto / inclination posing): LOOP_MARK / LOOP_AFTER_POSE below
   int poser_tip_kept; // the cycle kernels store every LegPoser tip (auto posing without IMU posing: the per-leg auto pose is not re-derivable)
+  int posed;          // the posing part of this loop (PoseController::updateCurrentPose + the admittance update, state_controller.cpp:165-181) has already
+                      // run in the cycle kernel for the robots of this call (RT_POSE_MARKED): auto posing on its own clock keeps posing through a sequence
 };
+// executeSequence / stepToNewStance under auto posing on its own clock (pose_frequency != -1: the pose phase counter advances in every loop, the posers latch
+// on without a step cycle, pose_controller.cpp:1134-1187, :1359-1371): the robots whose sequence is still running are marked, the cycle kernel runs the posing
+// part of their loop (pose-only pass), the sequence kernel follows with Model::current_pose_ as that pass left it, and the marks are cleared.
+__global__ void sequence_mark_kernel(ManualRobot *manual, const SeqRobotState *seq, int64_t n, int which, int set) {
+  const int64_t rob = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (rob >= n) return;
+  const bool completed = which < 2 && seq[rob].initialised && seq[rob].completed_sequence == which + 1; // (left alone: its node would have left transitionRobotState)
+  manual[rob].skip_cycle = (set && !completed) ? 1 : 0;
+}
 // One StateController::loop() of the robots that stand while a leg toggle / plan step runs = posing part (:165-181), then legStateToggle /
 // executePlan.  With walk-plane + manual posing only, the loop-level kernel does both (LOOP_WHOLE).  With time-dependent posing (IMU / auto /
 // inclination) the posing part is the cycle kernel's: the loop-level kernel first only marks its robots (LOOP_MARK), the cycle kernel
@@ -156,8 +167,10 @@ __global__ void execute_sequence_kernel(DevState st, const SharedConsts<L, NJ> *
     return;
   }
   s.completed_sequence = 0;
-  standing_pose_prologue_dev<L>(st, rob, gc->P.tip_align != 0);
-  for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
+  if (!P.posed) {
+    standing_pose_prologue_dev<L>(st, rob, gc->P.tip_align != 0);
+    for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
+  }
   const bool start_up = sequence == 0;
   // Initialise / reset any saved transition sequence (:149-162)
   if (s.reset_transition_sequence && start_up) {
@@ -342,7 +355,8 @@ __global__ void step_to_new_stance_kernel(DevState st, const SharedConsts<L, NJ>
   const Pose current_pose = robot_current_pose<L>(st, rob);
   const Quat target_rotation{P.target_rotation[0], P.target_rotation[1], P.target_rotation[2], P.target_rotation[3]};
   int progress = 0;
-  for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
+  if (!P.posed)
+    for (int l = 0; l < L; ++l) admittance_prologue_dev<NJ>(LegIO<NJ>{st, slot_of(rob, l, L)}, gc->leg[l], gc->P); // posing part of the loop
   for (int l = 0; l < L; ++l) {
     if ((l % 2) != s.current_group) continue;
     const LegIO<NJ> io{st, slot_of(rob, l, L)};
