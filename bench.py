@@ -323,12 +323,15 @@ def measured_valu(workload, n, cps):
     return v if isinstance(v, dict) else None
 
 
-def with_issue_side(roofline, valu):
-    """SURVEY.md section 8(d) "report VALUBusy alongside GB/s": adds the VALU-issue fraction and names the bound by the larger of the two fractions."""
-    roofline["valu_issue_frac"] = valu["valu_issue_frac"] if valu else None
+def with_issue_side(roofline, valu, seconds):
+    """SURVEY.md section 8(d) "report VALUBusy alongside GB/s": adds the VALU-issue fraction and names the bound by the larger of the two fractions.
+    valu_issue_frac = the 4-clock VALU issue slots the step's kernels used (rocprofv3 SQ_ACTIVE_INST_VALU, summed over the launches of one step) / the slots the
+    chip's 1 024 SIMDs have in `seconds` at 2.4 GHz - the same duration `achieved` is computed with."""
+    frac = (valu["valu_active_quads_per_step"] / (1024.0 * seconds * 2.4e9 / 4.0)) if (valu and seconds) else None
+    roofline["valu_issue_frac"] = frac
     roofline["valu_issue_share_per_wave"] = valu["valu_issue_share_per_wave"] if valu else None
     roofline["hbm_frac"] = roofline["frac"]
-    if valu and valu["valu_issue_frac"] > roofline["frac"]:
+    if frac is not None and frac > roofline["frac"]:
         roofline["bound"] = "valu-issue"
     roofline["bound_is"] = ("the larger of hbm_frac (algorithmic bytes / duration / 8 TB/s) and valu_issue_frac (rocprofv3 SQ_ACTIVE_INST_VALU over the chip's 1 024 SIMD issue "
                             "slots, profiles/traffic.json, same kernel sources); `frac` stays the HBM fraction the contract defines")
@@ -773,7 +776,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                        "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": ("shc_cycle_half_kernel<walker half> + <model half> (a rotation-constrained cycle is two launches, two wavefronts per SIMD each)" if name == "gravity" and n_waves >= 2048 else "shc_cycle_kernel")
                                  + (" (a step = that for each half of the batch, the halves on two streams)" if n_waves >= 4096 else ""),
                        "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes}
-    launch_roofline = with_issue_side(launch_roofline, None if joint_efforts else measured_valu(name, n, cps))
+    launch_roofline = with_issue_side(launch_roofline, None if joint_efforts else measured_valu(name, n, cps), kern_ms * 1e-3)
     if resident:
         rb = resident_bytes_per_cycle(p) * n
         r_ach = rb / res_cycle_s / 1e9
@@ -786,7 +789,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                                    "phase ablation in profiles/r04_probe_resident_ablation.txt"),
                     "state_streaming_equivalent_frac": ALG_BYTES_PER_CYCLE[key] * n / res_cycle_s / 1e9 / HBM_PEAK_GBS,
                     "one_launch_per_cycle": launch_roofline}
-        roofline = with_issue_side(roofline, measured_valu(name + ":resident", n, cps))
+        roofline = with_issue_side(roofline, measured_valu(name + ":resident", n, cps), res_cycle_s)
     else:
         roofline = launch_roofline
     res = {
@@ -904,7 +907,7 @@ def run_config5(n, steps, warmup, seed, want_parity=True):
             "roofline": with_issue_side({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                          "traffic": measured_traffic("config5", n, 1),
                                          "kernel": f"shc_cycle_kernel x {len(CONFIG5_BINS)} morphologies on concurrent streams (wall clock per fleet step, not a single launch)",
-                                         "algorithmic_bytes_per_launch": alg}, measured_valu("config5", n, 1))}
+                                         "algorithmic_bytes_per_launch": alg}, measured_valu("config5", n, 1), r["ms_per_step"] * 1e-3)}
 
 
 def main():

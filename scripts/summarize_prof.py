@@ -56,10 +56,6 @@ def kernel_stats(dirn, out):
     return med
 
 
-def per_step_launches(per_step):
-    return 1.0   # (counters and duration are both per launch; kept as a hook for the forms whose step is several launches)
-
-
 PAIRS = False  # argv[4] == "pairs": a cycle = the walker-half launch + the model-half launch (shc_cycle_half_kernel<..., 1 / 2>), on each of the two
                # halves of the batch: durations and counters are summed over the two kernels, a step is two such pairs
 FLEET = False  # argv[4] == "fleet": a step = one launch of EACH morphology bin's kernel on concurrent streams; counters are summed over the bins
@@ -165,10 +161,13 @@ if __name__ == "__main__":
         if sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_WAVE_CYCLES"):
             # the issue-side roofline (SURVEY.md section 8d "report VALUBusy alongside GB/s"): SQ_ACTIVE_INST_VALU counts, in 4-clock units, the time a
             # SIMD's vector ALU is issuing for some wave; the chip has 1 024 SIMDs (256 CUs x 4), each with one such slot per 4 clocks at 2.4 GHz
-            slots = 1024.0 * dur[0] * 2.4 / 4.0 * per_step_launches(per_step)
-            valu = {"valu_issue_share_per_wave": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], "valu_issue_frac": sq["SQ_ACTIVE_INST_VALU"] * per_step_launches(per_step) / slots,
-                    "valu_insts_per_wave": sq.get("SQ_INSTS_VALU", 0) / max(sq.get("SQ_WAVES", 1), 1)}
-            out.write(f"VALU issue share of the chip = SQ_ACTIVE_INST_VALU / (1 024 SIMDs x kernel duration x 2.4 GHz / 4) = {valu['valu_issue_frac']:.3f} "
+            # (per STEP: a split step is two such launches side by side, a rotation-constrained step two walker + model pairs, a fleet step one launch per bin -
+            #  the counters are summed accordingly, and the step lasts about as long as one launch / pair / the longest bin; bench.py divides the same sum by its own clock)
+            quads = sq["SQ_ACTIVE_INST_VALU"] * per_step
+            slots = 1024.0 * dur[0] * 2.4 / 4.0
+            valu = {"valu_issue_share_per_wave": sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"], "valu_active_quads_per_step": quads,
+                    "valu_issue_frac_by_kernel_trace": quads / slots, "valu_insts_per_wave": sq.get("SQ_INSTS_VALU", 0) / max(sq.get("SQ_WAVES", 1), 1)}
+            out.write(f"VALU issue share of the chip = {per_step} x SQ_ACTIVE_INST_VALU / (1 024 SIMDs x kernel duration x 2.4 GHz / 4) = {valu['valu_issue_frac_by_kernel_trace']:.3f} "
                       f"(per wave: {valu['valu_issue_share_per_wave']:.3f} of its lifetime)\n")
     bl = f"{prof}/bench_line.json"
     if os.path.exists(bl):
