@@ -46,7 +46,10 @@ ALG_BYTES_PER_CYCLE = {("hexapod", 2): 3008, ("hexapod", 3): 3560, ("octopod", 4
                        ("hexapod", "rough"): 3008 + 6 * (24 + 32),
                        # ... config 4's state + per leg the two tip directions the engine keeps for LegStepper's origin / current tip rotations
                        # (6 doubles read + written; SURVEY counts 3 full quaternions = 1 536 B - the smaller figure is the honest one here)
-                       ("octopod", "gravity"): 4496 + 8 * 2 * 48}
+                       ("octopod", "gravity"): 4496 + 8 * 2 * 48,
+                       # ... and BASELINE config 3's feature set on those octopods: + per leg the admittance state (2 doubles read + written), the admittance
+                       # delta it publishes (32 B written) and the measured tip force (24 B read), per robot the IMU sample (56 B read) and the PID state (6 doubles r + w)
+                       ("octopod", "gravity3"): 4496 + 8 * 2 * 48 + 8 * (32 + 32 + 24) + 56 + 96}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy peak)
 
 
@@ -100,6 +103,21 @@ def make_workload(name, n, seed, rank=0, joint_efforts=False):
         p = synthetic_octopod_params("ripple", 5, 8)
         p.gravity_aligned_tips = 1
         key, desc = ("octopod", "gravity"), "synthetic octopods (8x5 DOF), ripple gait, gravity_aligned_tips: LegStepper tip rotations + rotation-constrained Leg::applyIK"
+    elif name == "gravity3":  # the north-star feature set TOGETHER with the tip rotations: admittance + IMU pose compensation + gravity-aligned tips on 5-DOF legs
+        p = synthetic_octopod_params("ripple", 5, 8)
+        p.gravity_aligned_tips, p.admittance_control, p.imu_posing = 1, 1, 1
+        p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+        key = ("octopod", "gravity3")
+        desc = ("synthetic octopods (8x5 DOF), ripple gait, gravity_aligned_tips + admittance (tip force z ~ U(0, 20) N, resampled every 10 cycles) + IMU pose "
+                "compensation: src/model.cpp:880-903 + src/pose_controller.cpp:1191-1236 + src/admittance_controller.cpp:22-63 in one cycle (two launches per cycle)")
+        from scipy.spatial.transform import Rotation as R
+        e = np.stack([rng.uniform(-0.15, 0.15, n), rng.uniform(-0.15, 0.15, n), rng.uniform(-np.pi, np.pi, n)], axis=1)
+        q = R.from_euler("xyz", e).as_quat()
+        extra["imu_q"] = np.stack([q[:, 3], q[:, 0], q[:, 1], q[:, 2]], axis=1)
+        extra["gyro"] = rng.normal(0, 0.05, size=(n, 3))
+        frng = np.random.default_rng(0xADD2 + rank)
+        extra["force"] = config3_forces(frng, n, 8)
+        extra["force_sets"] = [config3_forces(frng, n, 8) for _ in range(4)]
     else:
         raise SystemExit(f"unknown workload {name}")
     effort = rng.normal(0, 0.5, size=(n, p.leg_count * p.leg_dof[0]))
@@ -773,7 +791,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     launch_roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": ("shc_cycle_half_kernel<walker half> + <model half> (a rotation-constrained cycle is two launches, two wavefronts per SIMD each)" if name == "gravity" and n_waves >= 2048 else "shc_cycle_kernel")
+                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": ("shc_cycle_half_kernel<walker half> + <model half> (a rotation-constrained cycle is two launches, two wavefronts per SIMD each)" if name in ("gravity", "gravity3") and n_waves >= 2048 else "shc_cycle_kernel")
                                  + (" (a step = that for each half of the batch, the halves on two streams)" if n_waves >= 4096 else ""),
                        "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes}
     launch_roofline = with_issue_side(launch_roofline, None if joint_efforts else measured_valu(name, n, cps), kern_ms * 1e-3)
@@ -826,7 +844,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     return res
 
 
-DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config5": 1 << 20, "rough": 65536, "gravity": 65536}
+DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config5": 1 << 20, "rough": 65536, "gravity": 65536, "gravity3": 65536}
 # (legs, dof, gait); a tuple of DOFs = a robot whose legs differ in joint count (BASELINE.json configs[4]: "3-5 DOF per leg")
 CONFIG5_BINS = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"), (6, (3, 5, 4, 3, 5, 4), "ripple"))
 
@@ -979,7 +997,7 @@ def main():
     # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
     also = []
     if world == 1 and not use_dist and args.workload == "config2" and not args.instances and not args.no_also:
-        for name, efforts in (("config2", not primary_efforts), ("config3", False), ("config4", False), ("config4", True), ("rough", False), ("gravity", False)):
+        for name, efforts in (("config2", not primary_efforts), ("config3", False), ("config4", False), ("config4", True), ("rough", False), ("gravity", False), ("gravity3", False)):
             k = max(300, min(args.steps, 1000))   # long enough that first-touch and clock ramp are outside the figure
             try:   # the secondary workloads must never cost the run its primary line
                 r = run_workload(name, DEFAULT_INSTANCES[name], k, max(30, min(args.warmup, 100)), args.cycles_per_step, args.seed,

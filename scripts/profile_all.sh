@@ -18,6 +18,7 @@ run c3 r05_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-j
 run c4 r05_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
 run rough r05_rough_terrain_rocprofv3.txt rough:65536:1 split --workload rough --no-joint-efforts
 run gravity r05_gravity_aligned_rocprofv3.txt gravity:65536:1 pairs --workload gravity --no-joint-efforts
+run gravity3 r05_gravity_aligned_admittance_imu_rocprofv3.txt gravity3:65536:1 pairs --workload gravity3 --no-joint-efforts
 PROF_STEPS=100 run c5 r05_config5_rocprofv3.txt config5:1048576:1 fleet --workload config5
 ls -la $S
 # the driver-shaped default run (every kernel of the bench line incl. the batch form of shc_engine_step_k), kernel trace + stats only

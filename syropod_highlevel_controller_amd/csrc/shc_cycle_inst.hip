@@ -42,7 +42,7 @@ static void launch_cycle(const CycleLaunch &a) {
   }
   // Rotation-constrained cycles of the feature-exact kernels: one cycle = the walker / poser launch + the model launch (two wavefronts per SIMD
   // each instead of one) once the launch holds at least two wavefronts for every SIMD of the chip; smaller launches stay one kernel.
-  if constexpr ((F & F_ROT) != 0 && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_ADM | F_AUTO)) == 0) {
+  if constexpr ((F & F_ROT) != 0 && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_AUTO)) == 0) {
     const int64_t waves = int64_t(a.grid) * (a.block / 64);
     if (a.half_steps >= 0 && (a.half_steps > 0 || waves >= 2048)) {
       for (int c = 0; c < a.n_cycles; ++c) {
@@ -83,6 +83,15 @@ static void launch_cycle_feat(const CycleLaunch &a) {
         }
         if constexpr (SPEC) {
           launch_cycle<L, NJ, C2 | F_TIPF | F_ROT>(a);
+          return;
+        }
+      }
+      // ... and the north-star feature set (admittance + IMU posing, BASELINE config 3's) together with the tip rotations on the BASELINE octopods:
+      // feature-exact, and with that the two-launch form (the runtime-flag kernel below needs one wavefront per SIMD + 122 - 141 AGPRs)
+      if constexpr (SPEC) {
+        constexpr unsigned C3 = F_MANUAL | F_IMU | F_ADM | F_ODOM;
+        if (!a.generic && !terrain && f == C3) {
+          launch_cycle<L, NJ, C3 | F_ROT>(a);
           return;
         }
       }

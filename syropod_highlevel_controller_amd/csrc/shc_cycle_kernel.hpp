@@ -114,7 +114,10 @@ __device__ __forceinline__ void load_leg_finish(LegRegs<NJ> &s, const Park &pk, 
   s.targ_dir = V3{ll.rot3.x, ll.rot3.y, ll.rot4.x};
 }
 
-template <int NJ, unsigned F, int ROLE = ROLE_ALL>
+// SPLIT: the two roles are two LAUNCHES (shc_cycle_half_kernel).  Admittance delta z and the published virtual stiffness share a plane: the walker
+// half stores its 8 bytes of it (the stiffness), the model half the other 8 (in the two-wavefront resident kernel the walker hands the
+// stiffness over at exit and the model wavefront stores the whole plane).
+template <int NJ, unsigned F, int ROLE = ROLE_ALL, bool SPLIT = false>
 __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &out, const Park &pk, const DevState &st, const CycleParams &P,
                                           uint32_t slot, unsigned dirty) {
   using FD = Fields<NJ>;
@@ -146,8 +149,10 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   if (FT::adm(P) && ROLE != ROLE_FRONT) { // (the two-wave kernel's model half receives s.stiff from the walker half before it stores)
     ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});
     ld.store(FD::ADM_DELTA / 2, double2{out.adm_delta.x, out.adm_delta.y});
-    ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, s.stiff});
+    if (SPLIT && ROLE == ROLE_BACK) st.legd[leg_field_index(FD::ADM_DELTA + 2, slot, st.n_slots)] = out.adm_delta.z;
+    else ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, s.stiff});
   }
+  if (SPLIT && ROLE == ROLE_FRONT && FT::adm(P) && P.dynamic_stiffness) st.legd[leg_field_index(FD::ADM_DELTA + 3, slot, st.n_slots)] = s.stiff;
   if (FT::tipf(P) && ROLE != ROLE_FRONT) {
     ld.store(FD::TF / 2, double2{s.tf.x, s.tf.y});
     ld.store(FD::TF / 2 + 1, double2{s.tf.z, 0.0});
@@ -730,7 +735,7 @@ __device__ __forceinline__ void resident_relay(const ResidentArgs &A) {
 template <int L, int NJ, unsigned F, bool RES, int HALF = ROLE_ALL, bool BATCH = false>
 __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConsts<L, NJ> *gc, int n_cycles, unsigned rt_flags, const int64_t wave,
                                            const ResidentArgs *ra) {
-  static_assert(HALF == ROLE_ALL || (!RES && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_ADM | F_AUTO)) == 0), "half-step launches: feature-exact kernels without admittance / auto posing / terrain paths");
+  static_assert(HALF == ROLE_ALL || (!RES && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_AUTO)) == 0), "half-step launches: feature-exact kernels without auto posing / terrain paths");
   using R = RobotFields;
   using FT = Feat<F>;
   constexpr int RPW = 64 / L; // robots per wavefront
@@ -912,8 +917,10 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
     fb.limit_bracket = -1;
     fb.uf = load_uni_flags(C.P);
     fb.pose_only = false;
-    cycle_front<L, NJ, F, true>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
-                                LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
+    // (with admittance the update itself - AdmittanceController::updateAdmittance: admittance state, tip-force estimate, tip axis of the last FK - is the
+    //  model half's, as in the two-wavefront resident kernel; the published dynamic stiffness is this half's)
+    cycle_front<L, NJ, F, (F & F_ADM) == 0>(s, out, C, rb, pk, g, leg, st.legd, st.n_slots, slot, dirty, manual_live, touchdown_detection, ext, mr,
+                                            LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
   } else if constexpr (HALF == ROLE_BACK) {
     FrontToBack fb;
     fb.uf = load_uni_flags(C.P);
@@ -928,6 +935,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
       if (fb.rot_def) fb.desired_dir = rotate(inverse(bp.r), V3{hand[2].y, hand[3].x, hand[3].y});
     }
     out.adm_delta = V3{0.0, 0.0, 0.0};
+    if (FT::adm(P)) cycle_admittance<NJ>(s, out, P, LegInPlanes<NJ>{st.legd, st.n_slots, slot});
     cycle_back<L, NJ, F>(s, out, C, leg, st.legd, st.n_slots, slot, mr, LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
   } else if (!skip) {
     for (int c = 0; c < n_cycles; ++c)
@@ -946,7 +954,7 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
       if (__any((dirty & b) != 0)) d |= b;
     dirty = d;
   }
-  if (live && !skip) store_leg<NJ, F, HALF>(s, out, pk, st, P, slot, dirty);
+  if (live && !skip) store_leg<NJ, F, HALF, HALF != ROLE_ALL>(s, out, pk, st, P, slot, dirty);
   if constexpr (HALF == ROLE_BACK) {
     if (live) st.legi[slot] = s.word; // the walker half's word of this cycle | LW_IKFAIL
     return;                           // (the robot tile is the walker half's)
