@@ -802,9 +802,9 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
                     "traffic": measured_traffic(name + ":resident", n, cps), "kernel": "shc_resident2_kernel (one launch, K = 4000 cycles; two wavefronts per robot group)",
                     "kernel_ms": res_cycle_s * 1e3, "kernel_ms_is": "per cycle: HIP events around one launch of K cycles / K",
                     "algorithmic_bytes_per_launch": rb, "algorithmic_bytes_are": "per cycle, SURVEY.md 8(d) with the state on the chip: velocity input + published q, qd",
-                    "bound_note": ("the resident cycle is bound by one wavefront's dependent-issue latency, not by HBM (frac is small by construction): 677 VALU + 176 SALU + "
-                                   "51 LDS instructions per wave and cycle in a 6 296-clock wave lifetime, VALU issue share 0.44 (profiles/r04_config2_resident_rocprofv3.txt); "
-                                   "phase ablation in profiles/r04_probe_resident_ablation.txt"),
+                    "bound_note": ("the resident cycle is bound by one wavefront's dependent-issue latency, not by HBM (frac is small by construction): 592 VALU + 157 SALU + "
+                                   "50 LDS instructions per wave and cycle in 5 650 wave clocks, VALU issue share 0.43 of the wave's lifetime on 824 of the chip's 1 024 SIMDs "
+                                   "(profiles/r05_config2_resident_rocprofv3.txt); attribution of the loop skeleton in profiles/r05_probe_resident_skeleton.txt"),
                     "state_streaming_equivalent_frac": ALG_BYTES_PER_CYCLE[key] * n / res_cycle_s / 1e9 / HBM_PEAK_GBS,
                     "one_launch_per_cycle": launch_roofline}
         roofline = with_issue_side(roofline, measured_valu(name + ":resident", n, cps), res_cycle_s)

@@ -284,8 +284,8 @@ int shc_engine_join(shc_engine *e);
  *       consumes them = cycles whose outputs stay readable; max_cycles (1..2^31-2): hard bound of this launch; idle_timeout_ms
  *       (0 = 5 000): the device loop stops by itself when everything released has run and the doorbell has not moved for this long
  *       (a host that went away cannot leave the GPU spinning; every device-side wait is bounded).  SHC_ERR_UNSUPPORTED: the batch does not fit the chip once, or
- *       the configuration runs on a tip-align-pose / manual-leg kernel (rough terrain mode and tip rotations have a resident form: one
- *       wavefront per robot group, up to ~990 wavefronts).  Until shc_engine_resident_end every other
+ *       the configuration runs on a manual-leg kernel (a leg toggled, planner mode).  Rough terrain mode, tip rotations and the tip-align
+ *       pose (gravity_aligned_tips on <= 3-DOF legs, since round 5) have a resident form: one wavefront per robot group, up to ~990 wavefronts.  Until shc_engine_resident_end every other
  *       entry point that touches the engine's state returns SHC_ERR_BUSY.
  *   shc_engine_resident_post(e, inputs, cycle)
  *       the inputs "the callbacks delivered" for the next unposted cycle (*cycle receives its index, counted from 0 at begin):
@@ -375,7 +375,7 @@ int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run);
  *   The result is bit-identical to K x { setters with row k; shc_engine_step(e, 1) } - state record and the q / qd of every cycle.
  *   shc_engine_get_step_k_joint_state(e, k, q, qd, on_device): q / qd [n][legs][dof] of cycle k (0 .. K - 1) of the latest launch
  *     (stream-ordered; the ring is overwritten by the next shc_engine_step_k).  shc_engine_get_joint_state returns cycle K - 1 as usual.
- * SHC_ERR_UNSUPPORTED: the configuration runs on a tip-align-pose / manual-leg kernel (use shc_engine_step).  1 <= K <= 4096, and
+ * SHC_ERR_UNSUPPORTED: the configuration runs on a manual-leg kernel - a leg toggled, planner mode (use shc_engine_step).  1 <= K <= 4096, and
  * K x n x legs x dof x 16 B must stay below 2 GiB.
  */
 int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_inputs *inputs);

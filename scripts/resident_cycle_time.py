@@ -21,6 +21,9 @@ if case == "octopod":
 elif case == "gravity":       # gravity-aligned tips on 5-joint legs: tip rotations + the rotation-constrained IK, one wavefront per robot group
     p = synthetic_octopod_params("ripple", 5, 8)
     p.gravity_aligned_tips = 1
+elif case == "tipalign":      # gravity-aligned tips on 3-joint legs: the tip-align pose (one wavefront per robot group)
+    p = default_hexapod_params("tripod")
+    p.gravity_aligned_tips = 1
 elif case == "rough":         # rough terrain mode: touchdown detection inside the loop, step-plane targets (one wavefront per robot group)
     p = default_hexapod_params("tripod")
     p.rough_terrain_mode, p.step_depth = 1, 0.012

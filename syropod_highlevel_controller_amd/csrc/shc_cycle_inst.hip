@@ -13,10 +13,11 @@ static void launch_cycle(const CycleLaunch &a) {
   constexpr int RPW = 64 / L;
   constexpr size_t wave_bytes = size_t(RobotFields::COUNT * RPW + PK_COUNT * 64 + (RobotFields::I_COUNT * RPW + 1) / 2) * 8;
   if (a.fit || a.resident) {
-    // Resident kernels: every specialisation but the tip-align pose and manual legs (their per-robot records change under loop-level calls).
+    // Resident kernels: every specialisation but manual legs (the ManualRobot records change under loop-level calls; the tip-align pose of
+    // gravity_aligned_tips on <= 3-joint legs is per-robot state of the tile like any other and has had a loop form since round 5).
     // Rough terrain and tip rotations run as ONE wavefront per robot group (Leg::applyIK feeds back into the stepper there - touchdown
     // detection, the FK tip rotation - so the walker / model halves cannot be pipelined); everything else also has the two-wavefront form.
-    if constexpr ((F & (F_TALIGN | F_MLEGS)) == 0) {
+    if constexpr ((F & F_MLEGS) == 0) {
       constexpr bool two_wave = (F & (F_TERRAIN | F_ROT)) == 0;
       if (a.fit) {
         a.fit->supported = 1;

@@ -216,7 +216,7 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
 #undef CALL
   }
   if (!fit.supported)
-    return fail(SHC_ERR_UNSUPPORTED, "resident mode: this configuration runs on a tip-align / manual-leg kernel, which has no resident form");
+    return fail(SHC_ERR_UNSUPPORTED, "resident mode: this configuration runs on a manual-leg kernel (a leg has been toggled / planner mode), which has no resident form");
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, e->device));
   // ... less one compute unit's worth per XCD (workgroups are dealt round-robin to the 8 XCDs and placed only inside their own): the loop's
@@ -743,7 +743,7 @@ extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_in
 #undef CALL
   }
   if (!fit.supported)
-    return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k: this configuration runs on a tip-align / manual-leg kernel, which has no loop form; use shc_engine_step");
+    return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k: this configuration runs on a manual-leg kernel (a leg has been toggled / planner mode), which has no loop form; use shc_engine_step");
   {
     const int rc = step_k_out_ring(e, n_cycles);
     if (rc != SHC_OK) return rc;

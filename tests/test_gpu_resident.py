@@ -63,7 +63,8 @@ def force_sample(rng, n, legs):
 @pytest.mark.parametrize("waves", ["two_waves", "one_wave"])
 @pytest.mark.parametrize("case", ["config2", "config3", "octopod", "generic_4x4", "config2_body_posing", "config3_body_posing_inclination",
                                   "config2_joint_efforts", "config3_joint_efforts", "config3_joint_efforts_feed_admittance", "octopod_joint_efforts",
-                                  "rough_terrain", "rough_terrain_joint_efforts", "gravity_aligned_octopod"])
+                                  "rough_terrain", "rough_terrain_joint_efforts", "gravity_aligned_octopod", "tip_align_hexapod",
+                                  "tip_align_hexapod_joint_efforts"])
 def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves):
     """Every cycle gets new inputs.  Engine A: set_* + shc_engine_step(1) per cycle.  Engine B: one resident launch, inputs posted per
     cycle.  q / qd of EVERY cycle (output ring) and the complete state record at the end are equal byte for byte - for the
@@ -73,7 +74,8 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
     *_feed_admittance: use_joint_effort, the estimate drives the admittance (admittance_controller.cpp:30-31).
     rough_terrain*: rough_terrain_mode with tip forces that come and go (touchdown detection runs inside the loop when a force arrives);
     gravity_aligned_octopod: tip rotations + the rotation-constrained applyIK - both as one wavefront per robot group (Leg::applyIK feeds
-    back into the stepper there), whatever `waves` asks for."""
+    back into the stepper there), whatever `waves` asks for; tip_align_hexapod*: gravity_aligned_tips on 3-joint legs - the tip-align pose
+    (PoseController::updateTipAlignPose, pose_controller.cpp:849-905) is state of the loop, one wavefront per robot group as well."""
     from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_RESIDENT_ONE_WAVE
     rng = np.random.default_rng(11)
     efforts_live = "joint_efforts" in case
@@ -93,6 +95,9 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
     elif case.startswith("rough_terrain"):
         p, n = default_hexapod_params("tripod"), 287
         p.rough_terrain_mode, p.step_depth = 1, 0.012
+    elif case.startswith("tip_align_hexapod"):   # gravity_aligned_tips on 3-joint legs: the tip-align pose (PoseController::updateTipAlignPose) is loop state
+        p, n = default_hexapod_params("ripple"), 149
+        p.gravity_aligned_tips = 1
     elif case == "gravity_aligned_octopod":
         p, n = synthetic_octopod_params("ripple", 5, 8), 131
         p.gravity_aligned_tips = 1
@@ -175,6 +180,10 @@ def test_resident_is_byte_identical_to_single_cycle_launches(Engine, case, waves
     assert state_bytes(a) == state_bytes(b)
     if efforts_live:   # (the estimate is really being evaluated: a dead filter would be byte-identical too)
         assert np.abs(a.leg_state()["tip_force"]).max() > 1e-3
+    if case.startswith("tip_align"):   # (and the tip-align pose is moving the body)
+        from syropod_highlevel_controller_amd.params import InstanceState
+        st = np.frombuffer(b.get_state(), dtype=np.dtype(InstanceState))
+        assert max(np.abs(st["tip_align_pose"][:, :3]).max(), np.abs(st["origin_tip_align_pose"][:, :3]).max()) > 1e-4
     # ... and the engines go on identically through ordinary launches (held inputs were carried over)
     for e in (a, b):
         e.step(25)

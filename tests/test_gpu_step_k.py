@@ -32,6 +32,10 @@ def make_case(case):
         p = default_hexapod_params("tripod")
         p.rough_terrain_mode = 1
         return p, 170
+    if case.startswith("tip_align"):   # gravity_aligned_tips on 3-joint legs: the tip-align pose kernels
+        p = default_hexapod_params("ripple")
+        p.gravity_aligned_tips = 1
+        return p, 149
     if case == "split_streams":   # enough wavefronts for the two-stream form of the launch (>= 4 096 waves)
         return default_hexapod_params("ripple"), 41000
     return synthetic_octopod_params("amble", 4, 4), 130   # generic_4x4: the runtime-flag kernels
@@ -64,7 +68,7 @@ def step_k_on_device(eng, rows, K):
 
 
 @pytest.mark.parametrize("case", ["config2", "config2_joint_efforts", "config3", "config3_joint_efforts", "octopod", "octopod_joint_efforts", "rough_terrain",
-                                  "rough_terrain_joint_efforts", "generic_4x4", "split_streams"])
+                                  "rough_terrain_joint_efforts", "generic_4x4", "split_streams", "tip_align", "tip_align_joint_efforts"])
 def test_step_k_is_byte_identical_to_single_cycle_launches(Engine, case):
     """Engine A: setters with row k + shc_engine_step(1), K times.  Engine B: ONE shc_engine_step_k launch over the K-deep device arrays.  q / qd of
     EVERY cycle (the K-deep output ring) and the complete state record at the end are equal byte for byte; the last row stays in force (a further
