@@ -976,6 +976,8 @@ def main():
     if args.workload is None:
         args.workload = "config4" if world > 1 else "config2"
     n = args.instances or DEFAULT_INSTANCES[args.workload]
+    import gc
+    gc.disable()   # no collector pass inside a timed region (a 20-tick region is 65 us long); collected by hand between the workloads
     if args.workload == "config5":
         if world > 1:
             raise SystemExit("config5 is a single-GPU workload here (the fleet shards in-process: shc_fleet_create device_ids)")
@@ -999,6 +1001,7 @@ def main():
     if world == 1 and not use_dist and args.workload == "config2" and not args.instances and not args.no_also:
         for name, efforts in (("config2", not primary_efforts), ("config3", False), ("config4", False), ("config4", True), ("rough", False), ("gravity", False), ("gravity3", False)):
             k = max(300, min(args.steps, 1000))   # long enough that first-touch and clock ramp are outside the figure
+            gc.collect()
             try:   # the secondary workloads must never cost the run its primary line
                 r = run_workload(name, DEFAULT_INSTANCES[name], k, max(30, min(args.warmup, 100)), args.cycles_per_step, args.seed,
                                  fused_probe=not args.no_fused_probe and not efforts, joint_efforts=efforts, mode=args.mode)

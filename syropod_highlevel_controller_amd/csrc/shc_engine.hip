@@ -2357,7 +2357,10 @@ static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(ST
     if ((rc = ensure_manual(e, false)) != SHC_OK) return rc;
     sequence_mark_kernel<<<grid, block, 0, e->stream>>>(e->st.manual, e->d_seq, e->n, which, 1);
     HIP_TRY(hipGetLastError());
-    if ((rc = pose_pass(e)) != SHC_OK) return rc;
+    if ((rc = pose_pass(e)) != SHC_OK) { // (the marks do not outlive the call: a marked robot would sit out every later cycle)
+      sequence_mark_kernel<<<grid, block, 0, e->stream>>>(e->st.manual, e->d_seq, e->n, which, 0);
+      return rc;
+    }
     P.posed = 1;
   }
 #define CALL(L_, NJ_)                                                                                                                        \

@@ -430,7 +430,10 @@ extern "C" int shc_peer_scatter(int device, const void *src, int64_t bytes, void
     hipStream_t s;
     hipEvent_t ev;
     HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (const hipError_t err = hipEventCreateWithFlags(&ev, hipEventDisableTiming); err != hipSuccess) {
+      (void)hipStreamDestroy(s);
+      return fail(SHC_ERR_HIP, std::string("shc_peer_scatter: hipEventCreateWithFlags: ") + hipGetErrorString(err));
+    }
     pool.streams.push_back(s);
     pool.done.push_back(ev);
   }

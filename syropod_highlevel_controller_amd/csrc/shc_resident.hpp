@@ -744,12 +744,12 @@ extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_in
   }
   if (!fit.supported)
     return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k: this configuration runs on a manual-leg kernel (a leg has been toggled / planner mode), which has no loop form; use shc_engine_step");
+  if (size_t(e->NJ) * e->n_slots * 16 * size_t(n_cycles) >= (size_t(1) << 31))
+    return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: cycles x batch - the output ring must stay below 2 GiB (fewer cycles per launch)");
   {
     const int rc = step_k_out_ring(e, n_cycles);
     if (rc != SHC_OK) return rc;
   }
-  if (size_t(e->NJ) * e->n_slots * 16 * size_t(n_cycles) >= (size_t(1) << 31))
-    return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: cycles x batch - the output ring must stay below 2 GiB (fewer cycles per launch)");
   e->plan_poser_tips_current = false;
   ResidentArgs A{};
   if (in) {
