@@ -788,13 +788,16 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     q, _ = eng.joints()
     finite = bool(np.isfinite(q).all())
     eng.close()
-    alg_bytes = ALG_BYTES_PER_CYCLE[key] * n * cps
+    # measured joint torques: per leg the torques themselves (dof x 8 B read) and the filtered tip-force estimate Leg::calculateTipForce keeps (24 B read + 24 B written)
+    effort_bytes = p.leg_count * (p.leg_dof[0] * 8 + 48) if joint_efforts else 0
+    alg_bytes = (ALG_BYTES_PER_CYCLE[key] + effort_bytes) * n * cps
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     launch_roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                       "traffic": None if joint_efforts else measured_traffic(name, n, cps), "kernel": ("shc_cycle_half_kernel<walker half> + <model half> (a rotation-constrained cycle is two launches, two wavefronts per SIMD each)" if name in ("gravity", "gravity3") and n_waves >= 2048 else "shc_cycle_kernel")
+                       "traffic": measured_traffic(name + ("+efforts" if joint_efforts else ""), n, cps), "kernel": ("shc_cycle_half_kernel<walker half> + <model half> (a rotation-constrained cycle is two launches, two wavefronts per SIMD each)" if name in ("gravity", "gravity3") and n_waves >= 2048 else "shc_cycle_kernel")
                                  + (" (a step = that for each half of the batch, the halves on two streams)" if n_waves >= 4096 else ""),
-                       "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes}
-    launch_roofline = with_issue_side(launch_roofline, None if joint_efforts else measured_valu(name, n, cps), kern_ms * 1e-3)
+                       "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                       "algorithmic_bytes_are": f"SURVEY.md 8(d): {ALG_BYTES_PER_CYCLE[key]} B per robot and cycle" + (f" + {effort_bytes} B of joint torques read and tip-force estimate read + written" if effort_bytes else "")}
+    launch_roofline = with_issue_side(launch_roofline, measured_valu(name + ("+efforts" if joint_efforts else ""), n, cps), kern_ms * 1e-3)
     if resident:
         rb = resident_bytes_per_cycle(p) * n
         r_ach = rb / res_cycle_s / 1e9

@@ -7,20 +7,23 @@ cd $R
 S=$R/gpurun_out/summaries; mkdir -p $S
 run() { # name, summary file, traffic key, resident K or "", bench arguments...
   local name=$1 out=$2 key=$3 res=$4; shift 4
+  if [ -n "${ONLY:-}" ] && [[ " $ONLY " != *" $name "* ]]; then return; fi   # ONLY="c2_launch c4e": a subset, merged into the summaries' traffic.json
   PROF_DIR=prof_$name PROF_STEPS=${PROF_STEPS:-300} bash scripts/profile_round.sh "$@" > $S/$name.log 2>&1
   python scripts/summarize_prof.py gpurun_out/prof_$name $S/$out $key $res > /dev/null 2>> $S/$name.log
   rm -rf gpurun_out/prof_$name
 }
 SHC_BENCH_NO_POSTED_PROBE=1 run c2_resident r05_config2_resident_rocprofv3.txt config2:resident:4096:1 resident:4000 --workload config2
 SHC_BENCH_NO_POSTED_PROBE=1 run c4_resident r05_config4_resident_8x5_rocprofv3.txt config4:resident:4000:1 resident:4000 --workload config4 --instances 4000 --no-joint-efforts
-run c2_launch r05_config2_launch_rocprofv3.txt config2:4096:1 launch --workload config2 --mode launch
+run c2_launch r05_config2_launch_rocprofv3.txt config2+efforts:4096:1 launch --workload config2 --mode launch
 run c3 r05_config3_rocprofv3.txt config3:65536:1 split --workload config3 --no-joint-efforts
 run c4 r05_config4_rocprofv3.txt config4:131072:1 split --workload config4 --no-joint-efforts
+run c4e r05_config4_joint_torques_rocprofv3.txt config4+efforts:131072:1 split --workload config4 --joint-efforts
 run rough r05_rough_terrain_rocprofv3.txt rough:65536:1 split --workload rough --no-joint-efforts
 run gravity r05_gravity_aligned_rocprofv3.txt gravity:65536:1 pairs --workload gravity --no-joint-efforts
 run gravity3 r05_gravity_aligned_admittance_imu_rocprofv3.txt gravity3:65536:1 pairs --workload gravity3 --no-joint-efforts
 PROF_STEPS=100 run c5 r05_config5_rocprofv3.txt config5:1048576:1 fleet --workload config5
 ls -la $S
+if [ -n "${ONLY:-}" ]; then exit 0; fi
 # the driver-shaped default run (every kernel of the bench line incl. the batch form of shc_engine_step_k), kernel trace + stats only
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_default -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $S/default.log 2>&1

@@ -115,6 +115,39 @@ def test_step_k_is_byte_identical_to_single_cycle_launches(Engine, case):
     b.close()
 
 
+@pytest.mark.parametrize("n,K", [(1, 1), (7, 257), (11, 1), (64, 2), (10, 4096)])
+def test_step_k_edge_shapes(Engine, n, K):
+    """One robot, one cycle, fewer robots than a wavefront holds, the longest launch the entry point takes (K = 4096): the K-deep rows and the
+    K-deep output ring against K single launches, byte for byte (first, middle and last cycle of the ring; the whole state at the end)."""
+    rng = np.random.default_rng(100 + n + K)
+    p = default_hexapod_params("ripple")
+    a, b = Engine(p, n), Engine(p, n)
+    lin0, ang0 = rng.uniform(-0.7, 0.7, (n, 2)), rng.uniform(-1, 1, n)
+    for e in (a, b):
+        e.set_velocity(lin0, ang0)
+        e.step(23)
+    base_l, base_a = rng.uniform(-0.7, 0.7, (n, 2)), rng.uniform(-1, 1, n)
+    k_ = np.arange(K)[:, None, None]
+    rows = {"lin": base_l[None] * (0.6 + 0.4 * np.sin(0.01 * k_)), "ang": base_a[None] * (0.6 + 0.4 * np.cos(0.013 * k_[:, :, 0])),
+            "imu_q": None, "imu_w": None, "force": None, "effort": None}
+    probe = sorted({0, K // 2, K - 1})
+    qa = {}
+    for k in range(K):
+        a.set_velocity(rows["lin"][k], rows["ang"][k])
+        a.step(1)
+        if k in probe:
+            qa[k] = a.joints()
+    a.synchronize()
+    keep = step_k_on_device(b, rows, K)
+    for k in probe:
+        qb, qdb = b.step_k_joints(k)
+        assert qa[k][0].tobytes() == qb.tobytes() and qa[k][1].tobytes() == qdb.tobytes(), (n, K, k)
+    assert state_bytes(a) == state_bytes(b)
+    del keep
+    a.close()
+    b.close()
+
+
 def test_step_k_with_inputs_held_equals_fused_steps(Engine):
     """inputs = NULL: K cycles with everything held = shc_engine_step(e, K)."""
     p, n = default_hexapod_params("wave"), 500
