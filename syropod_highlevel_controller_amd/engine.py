@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 from typing import Optional
 
 import numpy as np
@@ -192,10 +193,30 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle a HIP runtime of their own.  A process that initialises /opt/rocm's runtime first (libshc_batch.so links against it) and
+    imports torch afterwards ends up with two runtimes, and the second one finds no device ("No HIP GPUs are available", measured on the GPU box).
+    Loaded the other way round both share torch's - the configuration tests/ and bench.py have always run in.  So: when torch is installed but not
+    imported yet, its libamdhip64.so is loaded first (one dlopen, no torch import); the library then binds to it by SONAME and a later
+    `import torch` finds its runtime already in place.  SHC_OWN_HIP_RUNTIME=1 keeps /opt/rocm's (a process that never imports torch)."""
+    if "torch" in sys.modules or os.environ.get("SHC_OWN_HIP_RUNTIME"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 - no torch, or a wheel laid out differently: /opt/rocm's runtime it is
+        pass
+
+
 def lib():
     """Load libshc_batch.so, (re)building it first when it is missing or was built from different sources."""
     global _lib
     if _lib is None:
+        _share_torch_hip_runtime()
         L = C.CDLL(_SO if os.environ.get("SHC_LIB") else build_library())
         L.shc_last_error.restype = C.c_char_p
         L.shc_sizeof_params.restype = C.c_int64

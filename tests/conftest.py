@@ -14,7 +14,8 @@ def pytest_configure(config):
     # Load order: PyTorch bundles its own HIP runtime.  A process that uses both torch's CUDA API (streams, tensors: tests/test_gpu_resident.py,
     # test_gpu_sharding.py) and libshc_batch.so (linked against /opt/rocm's runtime) must load torch FIRST - measured on the GPU box: with the
     # library's runtime initialised first, torch.cuda reports "no ROCm-capable device".  Importing it here makes every subset of the suite
-    # behave like the full run (whose collection imports torch before any engine exists).
+    # behave like the full run (whose collection imports torch before any engine exists).  (Since round 5 engine.lib() loads torch's runtime first by
+    # itself when torch is installed but not imported - scripts/torch_after_engine_probe.py; the import here stays as the belt to those braces.)
     try:
         import torch  # noqa: F401
     except Exception:  # noqa: BLE001
