@@ -156,7 +156,7 @@ def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
     ob1.step(20, 1)
     c1 = int(max(20, min(2000, 3.0 * (rate / cores) / n1)))
     t1 = ob1.step(c1, 1)
-    return {"value": multi, "unit": "control-cycles/s", "cores": cores, "kind": "port",
+    return {"value": multi, "unit": "control-cycles/s", "cores": cores, "kind": "port", "sample_short": f"{n_s} robots x {cycles} cycles, {cores} threads",
             "sample": f"{n_s} instances x {cycles} cycles on {cores} threads (pthreads over instances); "
                       f"single thread: {n1 * c1 / t1:.0f} control-cycles/s ({n1} instances x {c1} cycles)",
             "single_thread_value": n1 * c1 / t1}
@@ -708,7 +708,8 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         # the gathered buffer must hold every rank's shard in rank order: check this rank's own slice
         own = gathered[rank * qshard.numel():(rank + 1) * qshard.numel()]
         assert torch.equal(own, qshard), "all-gather returned a different shard for this rank"
-        t = torch.tensor([elapsed, nogather_elapsed or 0.0, gather_s or 0.0], dtype=torch.float64, device="cuda")
+        red_dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        t = torch.tensor([elapsed, nogather_elapsed or 0.0, gather_s or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
         if nogather_elapsed is not None:
@@ -718,7 +719,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             # gather, its own clock (the ranks run side by side, so power and thermals are the job's).  Efficiency = job value / (N x that), with and
             # without the gather; a driver that divides value(N) by N x value(1) of the default N = 1 line would compare octopod launches with hexapod
             # doorbell ticks.
-            own = torch.zeros(world, dtype=torch.float64, device="cuda")
+            own = torch.zeros(world, dtype=torch.float64, device=red_dev)
             own[rank] = own_elapsed
             dist.all_reduce(own, op=dist.ReduceOp.SUM)
             per_rank = [n * steps * cps / float(x) for x in own.tolist()]
@@ -819,6 +820,9 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
         "config": {"workload": f"BASELINE.json {name}: {n} {desc}", "instances_per_gpu": n, "cycles_per_step": cps,
                    "mode": ("resident: one launch stays on the chip, a step = one doorbell tick = one control cycle with that cycle's inputs from the "
                             "device-side rings and its q / qd to the output ring") if resident else "one launch of the fused cycle kernel per step",
+                   "mode_short": "resident loop: 1 step = 1 doorbell tick = 1 control cycle" if resident else "one launch of the fused cycle kernel per step",
+                   "gather_short": (f"all-gather every {gather_every} steps" if gather_every else ("final joint buffer, in the timed region" if use_dist else "none (N = 1)")),
+                   "gather_form_short": (("peer copies (xGMI)" if peer else "RCCL all_gather") if use_dist else None),
                    "one_launch_per_cycle_value": (world * n * steps * cps / launch_elapsed) if launch_elapsed else None,
                    "velocities_posted_every_cycle_value": posted_value,   # resident mode, a new velocity set per robot and cycle from device arrays (direct posts)
                    "velocities_posted_every_cycle_through_the_rings_value": posted_launch_value,   # ... with one post kernel launch per cycle (round 3's form)
@@ -931,13 +935,268 @@ def run_config5(n, steps, warmup, seed, want_parity=True):
                                          "algorithmic_bytes_per_launch": alg}, measured_valu("config5", n, 1), r["ms_per_step"] * 1e-3)}
 
 
-def main():
+def run_config4_full(steps, warmup, seed, gather_form="rccl", want_parity=True, shards=8):
+    """BASELINE.json configs[3] at its STATED size on ONE MI355X: 2^20 synthetic octopods (8 legs x 5 DOF), ripple gait, as the eight
+    contiguous shards of 131 072 the 8-GPU job would own - one engine + HIP stream per shard (shc_fleet_create with the device id repeated), inputs keyed
+    by the global instance id, nothing exchanged while stepping - followed by the exchange at its TRUE message size: shc_fleet_all_gather_joints fills a
+    gathered [2^20][8][5] buffer (335.5 MB) for every shard slot, device-to-device copies (on one device they run over HBM instead of xGMI).
+    value = the stepping alone (comparable with the config-4 share line); gather_ms and value_with_gather are reported next to it."""
+    import torch
+    from syropod_highlevel_controller_amd import synthetic_octopod_params
+    from syropod_highlevel_controller_amd.engine import BatchEngine
+    from syropod_highlevel_controller_amd.fleet import MixedFleet
+    from syropod_highlevel_controller_amd.parallel import velocity_inputs
+    n = 1 << 20
+    p = synthetic_octopod_params("ripple", 5, 8)
+    lin, ang = velocity_inputs(seed, 0, n)      # the same commands instance for instance as the ranks of the 8-GPU job draw (make_workload)
+    fleet = MixedFleet([p], np.zeros(n, dtype=np.int32), devices=[torch.cuda.current_device()] * shards)
+    period = 0
+    groups = 8
+    parts = fleet.parts()
+    period = BatchEngine.view(parts[0][0], p, len(parts[0][3])).tables().step.period
+    for gk in range(groups):        # de-phase as run_workload does
+        sel = (np.arange(n) % groups) <= gk
+        fleet.set_velocity(lin * sel[:, None], ang * sel)
+        fleet.step(max(1, period // groups))
+    fleet.set_velocity(lin, ang)
+    fleet.step(2 * period + 64)
+    for _ in range(warmup):
+        fleet.step(1)
+    fleet.synchronize()
+    torch.cuda.synchronize()
+    pw = None
+    if want_parity:   # the first PARITY_INSTANCES robots of shard 0 and of the last shard against the oracle over the timed window
+        pw = []
+        for handle, _mk, _dev, ids in (parts[0], parts[-1]):
+            view = BatchEngine.view(handle, p, len(ids))
+            pw.append((view, ParityWindow(view, p, lin[ids], ang[ids], {})))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fleet.step(1)
+    fleet.synchronize()
+    elapsed = time.perf_counter() - t0
+    # the exchange at its true size (untimed first call allocates the gathered buffers)
+    fleet.all_gather_joints()
+    fleet.synchronize()
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bufs = fleet.all_gather_joints()
+        fleet.synchronize()
+    gather_s = (time.perf_counter() - t0) / reps
+    gather_bytes = n * p.leg_count * p.leg_dof[0] * 8
+    parity = None
+    if pw:
+        rs = [w.evaluate(steps, view.joints()[0]) for view, w in pw]
+        ok = [r for r in rs if r["max_abs_dq"] is not None]
+        parity = dict(rs[0], max_abs_dq=max(r["max_abs_dq"] for r in ok) if ok else None, max_abs_dq_all_instances=max(r["max_abs_dq_all_instances"] for r in rs),
+                      instances=sum(r["instances"] for r in rs), well_posed_fraction=float(np.mean([r["well_posed_fraction"] for r in rs])),
+                      window=f"the {steps} timed fleet steps; the first {PARITY_INSTANCES} robots of the first and of the last shard")
+    # the gathered buffer of slot 0 against the joints the getter returns (instance order, all 2^20 robots)
+    q, _ = fleet.joints()
+    import ctypes
+    got = np.empty((n, p.leg_count, p.leg_dof[0]))
+    hip = ctypes.CDLL("libamdhip64.so")
+    rc = hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(bufs[0]), ctypes.c_size_t(got.nbytes), 2)
+    gathered_ok = bool(rc == 0 and np.array_equal(got, q))
+    moving = float((fleet.walk_state() == 1).mean())
+    finite = bool(np.isfinite(q).all())
+    fleet.close()
+    ms = elapsed / steps * 1e3
+    alg = ALG_BYTES_PER_CYCLE[("octopod", 4)] * n
+    ach = alg / (ms * 1e-3) / 1e9
+    cfg = {"workload": f"BASELINE.json config4 at its stated size: {n} synthetic octopods (8x5 DOF), ripple gait, {shards} contiguous shards of {n // shards} on ONE device "
+                       "(shc_fleet_create: one engine + HIP stream per shard), then the exchange of the final joint buffer at full size",
+           "short": SHORT["config4full"], "mode": "one launch of the fused cycle kernel per shard and step (each shard's halves on two streams)", "instances_per_gpu": n,
+           "legs": p.leg_count, "dof": p.leg_dof[0], "seed": seed, "shards": shards, "moving_fraction": moving, "finite": finite,
+           "gather": "shc_fleet_all_gather_joints after the timed steps", "gather_form": "device-to-device copies, one buffer per shard slot (one device: over HBM)",
+           "gather_ms": gather_s * 1e3, "gather_bytes_per_rank": gather_bytes // shards, "gathered_buffer_bytes": gather_bytes, "gathered_buffers": shards,
+           "gathered_buffer_matches_getter": gathered_ok, "value_without_gather": n * steps / elapsed,
+           "value_with_gather": n * steps / (elapsed + gather_s), "steps": steps}
+    roof = with_issue_side({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic("config4full", n, 1),
+                            "kernel": f"shc_cycle_kernel<8,5> x {shards} shards on concurrent streams (wall clock per fleet step)", "kernel_ms": ms,
+                            "algorithmic_bytes_per_launch": alg}, measured_valu("config4full", n, 1), ms * 1e-3)
+    assert gathered_ok, "the gathered buffer differs from the joints the getter returns"
+    return {"workload": cfg["workload"], "value": n * steps / elapsed, "unit": "control-cycles/s", "steps": steps, "ms_per_step": ms, "config": cfg, "roofline": roof,
+            "parity": parity, "gather_ms": gather_s * 1e3}
+
+
+LINE_LIMIT = 4096          # hard limit of the final stdout line (the driver keeps a bounded tail of stdout and parses its last line)
+DETAILS_FILE = "bench_details.json"
+
+
+def _sig(x, digits=5):
+    """Numbers of the compact line carry `digits` significant digits (the full-precision figures are in bench_details.json)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{digits}g}")
+    except (TypeError, ValueError):
+        return None
+
+
+def _short(s, limit):
+    s = str(s)
+    return s if len(s) <= limit else s[:limit - 2] + ".."
+
+
+def _pick_roofline(r, with_kernel=True):
+    if not r:
+        return None
+    out = {"bound": r.get("bound"), "achieved": _sig(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"), "frac": _sig(r.get("frac"), 4),
+           "traffic": r.get("traffic")}
+    if with_kernel:
+        out["kernel"] = _short(r.get("kernel", ""), 72)
+    out.update({"kernel_ms": _sig(r.get("kernel_ms")), "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"),
+                "valu_issue_frac": _sig(r.get("valu_issue_frac"), 3)})
+    return out
+
+
+def _pick_parity(p):
+    if not p:
+        return None
+    return {"max_abs_dq": _sig(p.get("max_abs_dq"), 3), "instances": p.get("instances"), "cycles": p.get("cycles"),
+            "well_posed_fraction": _sig(p.get("well_posed_fraction"), 3), "tolerance": p.get("tolerance")}
+
+
+def _also_entry(a):
+    """One row of the compact `also` list.  Batches that do not fit the chip once report the K-cycles-per-launch form with a new input set in
+    every cycle (shc_engine_step_k) as `value` and the one-launch-per-cycle figure next to it as `launch_value` / `launch_frac`."""
+    if "error" in a:
+        return {"workload": _short(a.get("short", a.get("workload", "?")), 40), "error": _short(a["error"], 80)}
+    roof, par = a.get("roofline") or {}, a.get("parity") or {}
+    traffic, alg = roof.get("traffic"), roof.get("algorithmic_bytes_per_launch")
+    row = {"workload": _short(a.get("short") or a.get("workload", "?"), 40), "value": _sig(a.get("value")), "ms_per_step": _sig(a.get("ms_per_step")),
+           "frac": _sig(roof.get("frac"), 4), "traffic_ratio": _sig(traffic / alg, 3) if (traffic and alg) else None,
+           "valu_issue_frac": _sig(roof.get("valu_issue_frac"), 3), "max_abs_dq": _sig(par.get("max_abs_dq"), 3)}
+    for k in ("form", "launch_value", "launch_frac"):
+        if a.get(k) is not None:
+            row[k] = _sig(a[k], 4) if k != "form" else a[k]
+    return row
+
+
+def compact_line(full):
+    """The ONE line the driver parses: the contract's keys, the headline's roofline / parity / cpu_baseline and one compact `also` list.  Everything
+    else (prose, per-bin parity, the fused-K sub-objects, both rooflines of every secondary workload) is in bench_details.json.  Never longer than
+    LINE_LIMIT bytes: rows are dropped from the end of `also` (and counted in `also_dropped`) should it ever be."""
+    cfg = full.get("config", {})
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    out["value"], out["ms_per_step"] = _sig(out["value"], 7), _sig(out["ms_per_step"], 6)
+    c = {"workload": _short(cfg.get("short") or cfg.get("workload", ""), 100), "mode": _short(cfg.get("mode_short") or cfg.get("mode", ""), 60),
+         "instances_per_gpu": cfg.get("instances_per_gpu"), "legs": cfg.get("legs"), "dof": cfg.get("dof"), "seed": cfg.get("seed"),
+         "gather": _short(cfg.get("gather_short") or cfg.get("gather", ""), 60)}
+    if (full.get("n_gpus") or 1) > 1 or cfg.get("gather_ms") is not None:
+        sr, eff = cfg.get("scale_reference") or {}, cfg.get("weak_scaling_efficiency") or {}
+        c.update({"scale_reference": {"n_gpus": 1, "value": _sig(sr.get("value")), "ms_per_step": _sig(sr.get("ms_per_step"))} if sr else None,
+                  "weak_scaling_efficiency": {"with_gather": _sig(eff.get("with_gather"), 4), "without_gather": _sig(eff.get("without_gather"), 4)} if eff else None,
+                  "value_without_gather": _sig(cfg.get("value_without_gather")), "gather_ms": _sig(cfg.get("gather_ms")),
+                  "gather_bytes_per_rank": cfg.get("gather_bytes_per_rank"), "gather_form": _short(cfg.get("gather_form_short") or cfg.get("gather_form") or "", 24)})
+    for k in ("one_launch_per_cycle_value", "velocities_posted_every_cycle_value"):
+        if cfg.get(k) is not None:
+            c[k] = _sig(cfg[k])
+    out["config"] = c
+    out["roofline"] = _pick_roofline(full.get("roofline"))
+    out["parity"] = _pick_parity(full.get("parity"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _sig(cb.get("value")), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": _short(cb.get("sample_short") or cb.get("sample", ""), 60), "single_thread_value": _sig(cb.get("single_thread_value"))}
+    if full.get("error"):
+        out["error"] = _short(full["error"], 200)
+    rows = [_also_entry(a) for a in (full.get("also") or cfg.get("also") or [])]
+    out["also"] = rows
+    out["details"] = DETAILS_FILE
+    line = json.dumps(out, separators=(",", ":"))
+    dropped = 0
+    while len(line.encode()) >= LINE_LIMIT and out["also"]:
+        out["also"] = out["also"][:-1]
+        dropped += 1
+        out["also_dropped"] = dropped
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line.encode()) < LINE_LIMIT, len(line)
+    return line
+
+
+def emit(full):
+    """Full record -> bench_details.json (next to bench.py, and under gpurun_out/ when that exists) and stderr; compact record -> the LAST stdout line."""
+    text = json.dumps(full)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, DETAILS_FILE), "w") as f:
+                    f.write(text + "\n")
+            except OSError:
+                pass
+    print("bench details (also in " + DETAILS_FILE + "): " + text, file=sys.stderr, flush=True)
+    print(compact_line(full), flush=True)
+
+
+def launcher_argv(args_list, gpus, port=None):
+    """`bench.py --gpus N` started as ONE process: the command line it re-executes itself under (one rank per GPU over RCCL)."""
+    port = port or os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+            os.path.abspath(__file__)] + list(args_list)
+
+
+def resolve_world(args, argv, environ=None):
+    """--gpus N against the environment.  Returns ("run", world, rank, local_rank), or ("exec", argv) when this process has to start the ranks itself,
+    and raises SystemExit (non-zero) when the launcher's world size and --gpus disagree - never a silent single-rank answer."""
+    env = os.environ if environ is None else environ
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+        return ("run", world, int(env.get("RANK", "0")), int(env.get("LOCAL_RANK", "0")))
+    if args.gpus > 1:
+        return ("exec", launcher_argv([a for a in argv if a != "--dry-launch"], args.gpus))
+    return ("run", 1, 0, 0)
+
+
+SHORT = {"config2": "config2 4096 6x3 tripod", "config3": "config3 65536 6x3 wave+adm+imu", "config4": "config4 share 131072 8x5 ripple",
+         "config4full": "config4 FULL 2^20 8x5 ripple, 1 GPU", "rough": "rough terrain 65536 6x3", "gravity": "gravity-aligned tips 65536 8x5",
+         "gravity3": "gravity3 65536 8x5 adm+imu+rot", "config5": "config5 2^20 mixed morphologies"}
+
+
+def also_record(name, r, efforts=False):
+    """A secondary workload's full record (bench_details.json) with the fields the compact row is cut from."""
+    cfg, fk = r["config"], r["config"].get("fused_K_with_per_cycle_inputs") or {}
+    rec = {"workload": cfg["workload"], "short": SHORT.get(name, name) + (" +torques" if efforts else ""), "unit": "control-cycles/s", "steps": r.get("steps"),
+           "moving_fraction": cfg["moving_fraction"], "mode": cfg["mode"], "two_stream_split": cfg["two_stream_split"], "single_stream": cfg["single_stream"],
+           "one_launch_per_cycle_value": cfg["one_launch_per_cycle_value"], "fused_16_cycles_per_launch_value": cfg["fused_16_cycles_per_launch_value"],
+           "fused_K_with_per_cycle_inputs": fk or None, "launch": {"value": r["value"], "ms_per_step": r["ms_per_step"], "roofline": r["roofline"], "parity": r["parity"]}}
+    if fk.get("value") and not fk.get("error"):
+        # batches that do not fit the chip once: K cycles per launch, a new input set in every cycle (shc_engine_step_k), is the form a node would run them in;
+        # the one-launch-per-cycle figure is the secondary one.  traffic / valu_issue_frac come from PMC passes of the one-launch-per-cycle kernels.
+        roof = dict(fk["roofline"])
+        roof["traffic"] = None
+        roof["valu_issue_frac"] = r["roofline"].get("valu_issue_frac")
+        rec.update({"form": f"step_k K={fk['K']}", "value": fk["value"], "ms_per_step": fk["ms_per_cycle"], "roofline": roof, "parity": fk.get("parity") or r["parity"],
+                    "launch_value": r["value"], "launch_frac": r["roofline"]["frac"],
+                    "launch_traffic_ratio": (r["roofline"]["traffic"] / r["roofline"]["algorithmic_bytes_per_launch"]) if r["roofline"].get("traffic") else None})
+    else:
+        rec.update({"form": "resident" if cfg["mode"].startswith("resident") else "launch", "value": r["value"], "ms_per_step": r["ms_per_step"],
+                    "roofline": r["roofline"], "parity": r["parity"]})
+        if cfg.get("one_launch_per_cycle_value"):
+            rec["launch_value"] = cfg["one_launch_per_cycle_value"]
+            rec["launch_frac"] = (r["roofline"].get("one_launch_per_cycle") or {}).get("frac")
+    return rec
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node.  Started as ONE process with N > 1, bench.py re-executes itself under "
+                    "`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, RCCL); under a launcher WORLD_SIZE must equal N")
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default=None, help="default: config2 on one GPU (the configuration the metric is quoted on); N > 1: config4, 131 072 octopods "
                     "per GPU in launch mode (the 2^20-instance batch north_star states the weak-scaling target on)")
+    ap.add_argument("--dry-launch", action="store_true", help="print (as JSON) what --gpus N resolves to - the argv of the launcher it would exec, or the rank it "
+                    "would run as - and exit; needs no GPU")
+    ap.add_argument("--oversubscribe", action="store_true", help="N > 1 on a node with fewer than N GPUs: rank r uses device r mod device_count (tests; never a scaling figure)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="process-group backend of N > 1: nccl = RCCL (the product); gloo only for the launcher test with "
+                    "two ranks on one device (RCCL refuses duplicate devices) together with --gather peer")
     ap.add_argument("--gather-under-loop", action="store_true", help="N > 1 with --mode resident: queue the all-gather behind a device-side wait while the "
                     "persistent loop is still alive (default: the loop is ended first)")
     ap.add_argument("--gather", choices=("rccl", "peer"), default="rccl", help="N > 1: the exchange of the final joint buffer - RCCL's all-gather (a ring: one xGMI link "
@@ -948,7 +1207,7 @@ def main():
     ap.add_argument("--gather-every", type=int, default=0, help="all-gather the joint buffer every G steps (0 = once, at the end)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fused-probe", action="store_true", help="skip the secondary 16-cycles-per-launch figure (keeps rocprof stats to one launch shape)")
-    ap.add_argument("--no-also", action="store_true", help="skip the config 3 / config 4 measurements reported under config.also")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads of the default run (the `also` list)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather path even with one rank")
     ap.add_argument("--joint-efforts", action="store_true", help="supply measured joint torques: the tip-force estimate (Leg::calculateTipForce) is evaluated "
                     "every cycle (the default for config2, the headline; the other workloads are BASELINE.json's \"IK + Bezier\" / tip-state-message variants without it)")
@@ -956,42 +1215,68 @@ def main():
     ap.add_argument("--mode", choices=("auto", "resident", "launch"), default="auto",
                     help="auto: resident mode where the batch fits the chip once (config 2), one launch per step otherwise")
     ap.add_argument("--seed", type=int, default=0xC0FFEE)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    plan = resolve_world(args, argv)
+    if args.dry_launch:
+        print(json.dumps({"action": plan[0], "argv": plan[1]} if plan[0] == "exec" else {"action": "run", "world": plan[1], "rank": plan[2], "local_rank": plan[3]}))
+        return 0
+    if plan[0] == "exec":
+        # one rank per GPU, started by this process: HIP_VISIBLE_DEVICES is left as it is (rank r takes device r)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.stdout.flush()
+        os.execvpe(plan[1][0], plan[1], env)
+    _, world, rank, local_rank = plan
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the batched engine has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not args.oversubscribe:
+            raise SystemExit(f"bench.py: rank {rank} needs device {local_rank} but this node has {ndev} GPU(s); --gpus must not exceed the GPUs of the node "
+                             "(--oversubscribe shares devices between ranks for tests)")
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            if args.gather != "peer":
+                raise SystemExit("bench.py: --backend gloo carries no device collective; use it with --gather peer (launcher tests only)")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     if args.workload is None:
         args.workload = "config4" if world > 1 else "config2"
     n = args.instances or DEFAULT_INSTANCES[args.workload]
+    head = {"metric": "control-cycles/sec (all legs IK-solved)", "unit": "control-cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
     import gc
     gc.disable()   # no collector pass inside a timed region (a 20-tick region is 65 us long); collected by hand between the workloads
     if args.workload == "config5":
         if world > 1:
             raise SystemExit("config5 is a single-GPU workload here (the fleet shards in-process: shc_fleet_create device_ids)")
         r = run_config5(n, args.steps, args.warmup, args.seed, want_parity=not args.no_parity)
-        print(json.dumps({"metric": "control-cycles/sec (all legs IK-solved)", "value": r["value"], "unit": "control-cycles/s", "n_gpus": 1,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                          "config": {k: v for k, v in r.items() if k not in ("value", "roofline", "ms_per_step")}, "roofline": r["roofline"]}), flush=True)
-        return
+        cfg = {k: v for k, v in r.items() if k not in ("value", "roofline", "ms_per_step", "parity")}
+        cfg.update({"short": SHORT["config5"], "mode": "one launch per morphology bin and step, bins on concurrent streams", "instances_per_gpu": n, "seed": args.seed})
+        emit(dict(head, value=r["value"], ms_per_step=r["ms_per_step"], config=cfg, roofline=r["roofline"], parity=r["parity"]))
+        return 0
+    if args.workload == "config4full":   # BASELINE.json configs[3] at its stated size on ONE device: 8 shards of 131 072 octopods + the full-size exchange
+        r = run_config4_full(args.steps, args.warmup, args.seed, gather_form=args.gather, want_parity=not args.no_parity)
+        emit(dict(head, value=r["value"], ms_per_step=r["ms_per_step"], config=r["config"], roofline=r["roofline"], parity=r["parity"]))
+        return 0
     # Measured joint torques are part of the primary workload (a node always receives them from jointStatesCallback and the
-    # reference evaluates Leg::calculateTipForce every cycle, model.cpp:938); the variant without them is reported under config.also.
+    # reference evaluates Leg::calculateTipForce every cycle, model.cpp:938); the variant without them is reported under `also`.
     primary_efforts = not args.no_joint_efforts
     res = run_workload(args.workload, n, args.steps, args.warmup, args.cycles_per_step, args.seed,
                        dist_ctx=(world, rank, local_rank) if use_dist else None, gather_every=args.gather_every,
@@ -999,7 +1284,7 @@ def main():
                        joint_efforts=primary_efforts and (args.workload == "config2" or args.joint_efforts), mode=args.mode,
                        gather_under_loop=args.gather_under_loop, want_parity=(rank == 0 and not args.no_parity), gather_form=args.gather)
     # The other single-GPU BASELINE.json configurations, measured in the same process (N = 1 default run only):
-    # config 3 (65 536 hexapods, all four components of north_star) and one GPU's share of config 4 (131 072 octopods).
+    # config 3 (65 536 hexapods, all four components of north_star), one GPU's share of config 4 (131 072 octopods) and config 4 at its full size.
     also = []
     if world == 1 and not use_dist and args.workload == "config2" and not args.instances and not args.no_also:
         for name, efforts in (("config2", not primary_efforts), ("config3", False), ("config4", False), ("config4", True), ("rough", False), ("gravity", False), ("gravity3", False)):
@@ -1008,38 +1293,33 @@ def main():
             try:   # the secondary workloads must never cost the run its primary line
                 r = run_workload(name, DEFAULT_INSTANCES[name], k, max(30, min(args.warmup, 100)), args.cycles_per_step, args.seed,
                                  fused_probe=not args.no_fused_probe and not efforts, joint_efforts=efforts, mode=args.mode)
+                r["steps"] = k
+                also.append(also_record(name, r, efforts and name != "config2"))
+                if name == "config2" and not efforts:
+                    also[-1]["short"] += " no torques"
             except Exception as exc:  # noqa: BLE001
-                also.append({"workload": name, "error": str(exc)[:200]})
-                continue
-            also.append({"workload": r["config"]["workload"], "value": r["value"], "unit": "control-cycles/s", "steps": k,
-                         "ms_per_step": r["ms_per_step"], "moving_fraction": r["config"]["moving_fraction"], "mode": r["config"]["mode"],
-                         "one_launch_per_cycle_value": r["config"]["one_launch_per_cycle_value"],
-                         "fused_16_cycles_per_launch_value": r["config"]["fused_16_cycles_per_launch_value"],
-                         "fused_K_with_per_cycle_inputs_value": r["config"]["fused_K_with_per_cycle_inputs_value"],
-                         "fused_K_with_per_cycle_inputs": r["config"]["fused_K_with_per_cycle_inputs"],
-                         "two_stream_split": r["config"]["two_stream_split"], "single_stream": r["config"]["single_stream"],
-                         "roofline": r["roofline"], "parity": r["parity"]})
-        try:
-            also.append(run_config5(DEFAULT_INSTANCES["config5"], 100, 10, args.seed, want_parity=not args.no_parity))
-        except Exception as exc:  # noqa: BLE001
-            also.append({"workload": "config5", "error": str(exc)[:200]})
+                also.append({"workload": name, "short": SHORT.get(name, name), "error": str(exc)[:200]})
+        for name, fn in (("config5", lambda: run_config5(DEFAULT_INSTANCES["config5"], 100, 10, args.seed, want_parity=not args.no_parity)),
+                         ("config4full", lambda: run_config4_full(100, 10, args.seed, gather_form="rccl", want_parity=not args.no_parity))):
+            gc.collect()
+            try:
+                r = fn()
+                r["short"], r["form"] = SHORT[name], "launch"
+                also.append(r)
+            except Exception as exc:  # noqa: BLE001
+                also.append({"workload": name, "short": SHORT[name], "error": str(exc)[:200]})
     if rank == 0:
         cfg = res["config"]
-        if also:
-            cfg["also"] = also
-        out = {
-            "metric": "control-cycles/sec (all legs IK-solved)", "value": res["value"], "unit": "control-cycles/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": cfg, "roofline": res["roofline"], "parity": res["parity"],
-        }
+        cfg["short"] = f"BASELINE.json {args.workload}: {n}/GPU {cfg['legs']}x{cfg['dof']}" + (" +joint torques" if "joint-effort" in cfg["workload"] else "")
+        out = dict(head, value=res["value"], ms_per_step=res["ms_per_step"], config=cfg, roofline=res["roofline"], parity=res["parity"], also=also)
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -859,6 +859,42 @@ def test_full_size_config3_and_config4_properties(Engine):
         eng.close()
 
 
+@pytest.mark.timeout(1800)
+def test_full_size_config4_at_its_stated_size(Engine):
+    """BASELINE.json configs[3] at its STATED size on one device: 2^20 synthetic octopods (8 x 5, ripple) in ONE engine (~3 GB of state; the job shards
+    them over eight GPUs, 131 072 each - the sharded form at this size runs in tests/test_gpu_bench_launch.py).  Size-independent properties over 60 cycles:
+    identical inputs in two places of the batch give bit-identical joints wherever they land (first and last 4 096 instances, i.e. other halves of the
+    two-stream split, other XCDs), joints inside their limits, everything finite, every robot MOVING; a 64-instance slice of each end against the oracle."""
+    p = synthetic_octopod_params("ripple", 5, 8)
+    n, horizon, dup, m = 1 << 20, 60, 4096, 64
+    inp = make_inputs(p, n, 61)
+    for k in inp:
+        inp[k][-dup:] = inp[k][:dup]
+    eng = Engine(p, n)
+    apply(eng, inp)
+    eng.step(horizon)
+    eng.synchronize()
+    q, qd = eng.joints()
+    assert q.shape == (n, 40) and np.isfinite(q).all() and np.isfinite(qd).all()
+    assert np.array_equal(q[-dup:], q[:dup]) and np.array_equal(qd[-dup:], qd[:dup])
+    L, D = p.leg_count, p.leg_dof[0]
+    jmin = np.array([[p.joint[l][j].min for j in range(D)] for l in range(L)]).reshape(-1)
+    jmax = np.array([[p.joint[l][j].max for j in range(D)] for l in range(L)]).reshape(-1)
+    assert (q >= jmin - 1e-12).all() and (q <= jmax + 1e-12).all()
+    ws = eng.body_state()[2]
+    assert (ws != WALK_STOPPED).all()
+    for lo in (0, n - dup - m):   # (the slice before the duplicated tail: inputs of its own)
+        ob = OracleBatch(p, m)
+        apply(ob, {k: v[lo:lo + m] for k, v in inp.items()})
+        ob.step(horizon, 8)
+        err = np.abs(ob.joints()[0] - q[lo:lo + m]).max()
+        assert err <= TOL_Q, (lo, err)
+        assert np.array_equal(ob.body_state()[2], ws[lo:lo + m])
+    from conftest import parity_report
+    parity_report(f"[config 4 at its stated size] {n} octopods x {horizon} cycles in one engine: duplicated inputs bit-identical, joints within limits, oracle slices <= {TOL_Q} rad")
+    eng.close()
+
+
 def test_device_pointer_io_with_torch(Engine):
     torch = pytest.importorskip("torch")
     p = default_hexapod_params("tripod")
