@@ -851,7 +851,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     return res
 
 
-DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config5": 1 << 20, "rough": 65536, "gravity": 65536, "gravity3": 65536}
+DEFAULT_INSTANCES = {"config2": 4096, "config3": 65536, "config4": 131072, "config4full": 1 << 20, "config5": 1 << 20, "rough": 65536, "gravity": 65536, "gravity3": 65536}
 # (legs, dof, gait); a tuple of DOFs = a robot whose legs differ in joint count (BASELINE.json configs[4]: "3-5 DOF per leg")
 CONFIG5_BINS = ((4, 3, "tripod"), (4, 4, "amble"), (6, 4, "ripple"), (8, 3, "wave"), (6, 5, "tripod"), (6, (3, 5, 4, 3, 5, 4), "ripple"))
 
