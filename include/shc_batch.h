@@ -371,7 +371,11 @@ int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run);
  *     is held at what the engine has.  Row k is what shc_engine_set_velocity / set_imu / set_tip_force / set_joint_effort would have been given
  *     before cycle k (in rough terrain mode Leg::touchdownDetection runs on the fresh tip force inside the loop, model.cpp:712-722).  Pose
  *     inputs / reset modes are not carried (set them before the call; they are held).  The arrays are read while the launch runs: keep them
- *     unchanged until the engine's stream has passed it.  After the call the last row is the engine's held input.
+ *     valid and unchanged until shc_engine_join (or any synchronising call: shc_engine_synchronize, shc_engine_get_step_k_joint_state, the next
+ *     shc_engine_step / step_k) has been ISSUED after this one and the engine's stream has passed that point.  An event recorded on the engine's
+ *     stream right after shc_engine_step_k is NOT enough for batches of >= 4 096 wavefronts: those launch on the engine's two internal half-streams
+ *     and the engine's own stream is ordered behind them only by the next join (the same holds for a caching allocator that would reuse the
+ *     arrays' memory).  After the call the last row is the engine's held input.
  *   The result is bit-identical to K x { setters with row k; shc_engine_step(e, 1) } - state record and the q / qd of every cycle.
  *   shc_engine_get_step_k_joint_state(e, k, q, qd, on_device): q / qd [n][legs][dof] of cycle k (0 .. K - 1) of the latest launch
  *     (stream-ordered; the ring is overwritten by the next shc_engine_step_k).  shc_engine_get_joint_state returns cycle K - 1 as usual.
@@ -570,6 +574,11 @@ int shc_engine_direct_startup(shc_engine *e, int32_t *progress);
  *   shc_engine_finish_sequence_startup what follows a completed START_UP (:305-313): walker_->init(), the configuration the
  *       sequence ended on becomes the default configuration, workspaces / walkspace / limits are regenerated from it (instance 0
  *       stands for the batch: the tables belong to the engine), robot state RUNNING and the first control cycle of the same loop.
+ *       Auto posing on its own clock (pose_frequency != -1) keeps posing through the sequence; the PoseController's phase counter, poser latches and
+ *       Model::current_pose_ carry over into RUNNING and the workspace is searched at the pose of the completing loop (model.cpp:338) - which every
+ *       instance must share (SHC_ERR_UNSUPPORTED when they completed START_UP in different phases of the auto pose, with IMU posing on top, or on
+ *       tip-align robots).  The sequence calls of such robots run their posing part as a pose-only pass of the manual-leg cycle kernels; that
+ *       leaves no trace: shc_engine_step keeps its kernels, shc_engine_step_k and resident mode stay available afterwards.
  *   shc_engine_step_to_new_stance      ONE call of stepToNewStance per instance (progress as the reference returns it).
  *   shc_engine_pack_legs / unpack_legs PoseController::packLegs / unpackLegs (:615-707), ONE call per loop: every joint follows its
  *       cubic Bezier (LegPoser::transitionConfiguration) to the packed positions of the current pack step / back to the previous

@@ -1857,6 +1857,7 @@ __global__ void get_external_kernel(DevState st, int L, int64_t first, int64_t c
 
 static int ensure_seq(shc_engine *e);
 static int ensure_manual(shc_engine *e, bool planner);
+static int ensure_manual_records(shc_engine *e);
 static int external_select(shc_engine *e, int which, int64_t first, int64_t count, int leg, int64_t *rows_out) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (which != SHC_EXTERNAL_TARGET && which != SHC_EXTERNAL_DEFAULT && which != SHC_EXTERNAL_PLANNER_TARGET)
@@ -2353,12 +2354,21 @@ static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(ST
   // Auto posing on its own clock keeps posing through the sequence (pose_controller.cpp:1134-1187 runs in every loop, state_controller.cpp:165-167): the
   // posing part of this loop runs in the cycle kernel for the robots whose sequence is still running (a pose-only pass, as for leg toggles and plan steps)
   const bool own_clock = e->params.auto_posing && e->params.pose_frequency != -1.0;
+  // The pose-only pass runs on the manual-leg kernels (the marks live in the ManualRobot records), but no leg is toggled by a sequence: RT_MANUAL_LEGS /
+  // RT_MANUAL_LIVE are raised for the duration of this call only - a later shc_engine_step keeps its kernels, shc_engine_step_k / resident mode stay available.
+  const unsigned rt_keep = e->rt_flags;
   if (own_clock) {
-    if ((rc = ensure_manual(e, false)) != SHC_OK) return rc;
+    if (e->cp.tip_align)
+      return fail(SHC_ERR_UNSUPPORTED, "executeSequence / stepToNewStance with auto posing on its own clock on robots that carry the tip-align pose "
+                                       "(gravity_aligned_tips on <= 3-DOF legs): the pose-only pass has no tip-align form");
+    if ((rc = ensure_manual_records(e)) != SHC_OK) return rc;
+    e->rt_flags |= RT_MANUAL_LEGS | RT_MANUAL_LIVE;
     sequence_mark_kernel<<<grid, block, 0, e->stream>>>(e->st.manual, e->d_seq, e->n, which, 1);
-    HIP_TRY(hipGetLastError());
-    if ((rc = pose_pass(e)) != SHC_OK) { // (the marks do not outlive the call: a marked robot would sit out every later cycle)
+    hipError_t herr = hipGetLastError();
+    rc = herr == hipSuccess ? pose_pass(e) : fail(SHC_ERR_HIP, hipGetErrorString(herr));
+    if (rc != SHC_OK) { // (the marks do not outlive the call: a marked robot would sit out every later cycle)
       sequence_mark_kernel<<<grid, block, 0, e->stream>>>(e->st.manual, e->d_seq, e->n, which, 0);
+      e->rt_flags = rt_keep;
       return rc;
     }
     P.posed = 1;
@@ -2371,6 +2381,7 @@ static int sequence_launch(shc_engine *e, int which /* 0 / 1: executeSequence(ST
   HIP_TRY(hipGetLastError());
   if (own_clock) {
     sequence_mark_kernel<<<grid, block, 0, e->stream>>>(e->st.manual, e->d_seq, e->n, which, 0);
+    e->rt_flags = rt_keep;
     HIP_TRY(hipGetLastError());
   }
   if (progress) HIP_TRY(hipMemcpyAsync(progress, d_progress, size_t(e->n) * 4, hipMemcpyDeviceToHost, e->stream));
@@ -2387,11 +2398,7 @@ extern "C" int shc_engine_execute_sequence(shc_engine *e, int sequence, int32_t 
 extern "C" int shc_engine_step_to_new_stance(shc_engine *e, int32_t *progress) { return sequence_launch(e, 2, progress); }
 
 // ---- manual leg manipulation (shc_sequence.hpp)
-static int ensure_manual(shc_engine *e, bool planner) {
-  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
-  const shc_params &p = e->params;
-  if (e->cp.tip_align)
-    return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with the tip-align pose (gravity_aligned_tips on <= 3-DOF legs)");
+static int ensure_manual_records(shc_engine *e) { // the per-robot ManualRobot records (all legs WALKING, no skip marks), on first use; no flag changes
   HIP_TRY(hipSetDevice(e->device));
   if (!e->st.manual) {
     HIP_TRY(hipMalloc(&e->st.manual, sizeof(ManualRobot) * size_t(e->n_rob_pad)));
@@ -2403,6 +2410,14 @@ static int ensure_manual(shc_engine *e, bool planner) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
+  return SHC_OK;
+}
+static int ensure_manual(shc_engine *e, bool planner) {
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (e->cp.tip_align)
+    return fail(SHC_ERR_UNSUPPORTED, "manual leg manipulation / planner mode with the tip-align pose (gravity_aligned_tips on <= 3-DOF legs)");
+  const int rc = ensure_manual_records(e);
+  if (rc != SHC_OK) return rc;
   e->rt_flags |= RT_MANUAL_LEGS | RT_MANUAL_LIVE; // (the toggle resets the manual pose: its group of the robot tile is live from now on)
   return SHC_OK;
 }
@@ -2641,12 +2656,39 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   SHC_BUSY_GUARD(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   HIP_TRY(hipSetDevice(e->device));
-  // Auto posing on its own clock poses the body through the sequence calls (sequence_launch), but what follows a completed START_UP does not carry over yet: the
-  // PoseController's phase counter and poser latches live on through walker_->init() (:306), Leg::generateWorkspace runs at the pose of THAT loop (model.cpp:338)
-  // and the runningState() of the same loop reuses it (:165-167 ran once) - this entry point re-initialises the whole state record and runs a full cycle.
-  if (e->params.auto_posing && e->params.pose_frequency != -1.0)
-    return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup with auto posing on its own clock (the sequence calls themselves are supported; start such robots "
-                                     "with the direct start-up, shc_engine_create)");
+  // Auto posing on its own clock (pose_frequency != -1) poses the body through the sequence calls (sequence_launch), and the PoseController lives on through
+  // walker_->init() (:306): its phase counter, the posers' latches and Model::current_pose_ carry over, Leg::generateWorkspace searches at the pose of THAT loop
+  // (model.cpp:338) and the runningState() of the same loop reuses it (updateCurrentPose, :165-167, ran once, before the sequence call).  Here: the poser part of
+  // every instance's state record is kept across the re-initialisation, the workspace search runs at the kept pose, and the phase counter is set back by one so
+  // that the posing part of the full cycle below recomputes the pose of this loop instead of the next one - exact because that part is idempotent in this
+  // configuration: with its own clock an AutoPoser's latches are OR-latches that are already set (pose_controller.cpp:1359-1371), LegPoser::updateAutoPose
+  // (:1716-1778) is a function of the phase and a latch the same phase sets, the manual pose is checked to be at rest.  IMU posing is the exception
+  // (updateIMUPose needs RUNNING, :836: the loop that completes START_UP poses with the auto pose, the cycle below would pose with the PID) and stays refused.
+  const bool own_clock = e->params.auto_posing && e->params.pose_frequency != -1.0;
+  std::vector<shc_instance_state> kept;
+  Pose ws_pose = pose_identity();
+  if (own_clock) {
+    if (e->params.imu_posing)
+      return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup with auto posing on its own clock AND IMU posing (the loop that completes START_UP still poses with "
+                                       "the auto pose, pose_controller.cpp:836; start such robots with the direct start-up, shc_engine_create)");
+    if (e->cp.tip_align) return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup with auto posing on its own clock on robots that carry the tip-align pose");
+    kept.resize(size_t(e->n));
+    int rck = shc_engine_get_state(e, 0, e->n, kept.data());
+    if (rck != SHC_OK) return rck;
+    const shc_instance_state &k0 = kept[0];
+    for (int64_t i = 0; i < e->n; ++i) {
+      const shc_instance_state &k = kept[size_t(i)];
+      bool same = k.pose_phase == k0.pose_phase && memcmp(k.auto_poser_flags, k0.auto_poser_flags, sizeof(k.auto_poser_flags)) == 0;
+      bool rest = k.manual_pose[0] == 0 && k.manual_pose[1] == 0 && k.manual_pose[2] == 0 && k.manual_pose[4] == 0 && k.manual_pose[5] == 0 && k.manual_pose[6] == 0;
+      for (int a = 0; a < 3; ++a) rest = rest && k.translation_velocity_input[a] == 0 && k.rotation_velocity_input[a] == 0;
+      if (!same)
+        return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup: the instances completed START_UP in different phases of the auto pose (instance " + std::to_string(i) +
+                                             " vs instance 0): the workspace is searched at the body pose of the completing loop and one engine has one set of tables");
+      if (!rest)
+        return fail(SHC_ERR_UNSUPPORTED, "finish_sequence_startup with auto posing on its own clock while the manual body pose is in motion (instance " + std::to_string(i) + ")");
+    }
+    ws_pose = Pose{V3{k0.current_pose[0], k0.current_pose[1], k0.current_pose[2]}, Quat{k0.current_pose[3], k0.current_pose[4], k0.current_pose[5], k0.current_pose[6]}};
+  }
   // Model::updateDefaultConfiguration + generateWorkspaces + generateWalkspace (state_controller.cpp:307-310): the tables of an
   // engine belong to its morphology, so the configuration of instance 0 stands for the batch.  Robots that were started from
   // different joint positions (shc_engine_begin_sequence_startup per_instance) end their sequences on the same READY stance
@@ -2668,9 +2710,9 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   shc_tables t;
   bool ok = false;
   switch (e->NJ) {
-    case 3: ok = hostinit::generate_tables<3>(e->params, t, q.data()); break;
-    case 4: ok = hostinit::generate_tables<4>(e->params, t, q.data()); break;
-    default: ok = hostinit::generate_tables<5>(e->params, t, q.data()); break;
+    case 3: ok = hostinit::generate_tables<3>(e->params, t, q.data(), own_clock ? &ws_pose : nullptr); break;
+    case 4: ok = hostinit::generate_tables<4>(e->params, t, q.data(), own_clock ? &ws_pose : nullptr); break;
+    default: ok = hostinit::generate_tables<5>(e->params, t, q.data(), own_clock ? &ws_pose : nullptr); break;
   }
   if (!ok) return fail(SHC_ERR_INVALID_ARG, "init chain failed for the configuration the sequence ended on");
   e->tables = t;
@@ -2694,6 +2736,25 @@ extern "C" int shc_engine_finish_sequence_startup(shc_engine *e) {
   (void)hipFree(keep);
   if (err != hipSuccess) return fail(SHC_ERR_HIP, hipGetErrorString(err));
   if (rc != SHC_OK) return rc;
+  if (own_clock) { // the PoseController's part of the record carries over, one phase back (see above)
+    std::vector<shc_instance_state> fresh(size_t(e->n));
+    if ((rc = shc_engine_get_state(e, 0, e->n, fresh.data())) != SHC_OK) return rc;
+    const int len = e->tables.pose_phase_length > 0 ? e->tables.pose_phase_length : 1;
+    for (int64_t i = 0; i < e->n; ++i) {
+      shc_instance_state &f = fresh[size_t(i)];
+      const shc_instance_state &k = kept[size_t(i)];
+      f.pose_phase = (k.pose_phase + len - 1) % len;
+      f.auto_posing_state = k.auto_posing_state;
+      memcpy(f.auto_poser_flags, k.auto_poser_flags, sizeof(f.auto_poser_flags));
+      memcpy(f.auto_pose_rotation, k.auto_pose_rotation, sizeof(f.auto_pose_rotation));
+      memcpy(f.current_pose, k.current_pose, sizeof(f.current_pose));
+      for (int l = 0; l < SHC_MAX_LEGS; ++l) f.leg[l].negate_auto_pose = k.leg[l].negate_auto_pose;
+    }
+    const unsigned rt_keep = e->rt_flags; // (the injected manual pose is the identity it was: its group of the robot tile stays as live as it was)
+    rc = shc_engine_set_state(e, 0, e->n, fresh.data());
+    e->rt_flags = rt_keep;
+    if (rc != SHC_OK) return rc;
+  }
   // robot_state_ = RUNNING, and the runningState() of the same loop (:189-192)
   if ((rc = shc_engine_step(e, 1)) != SHC_OK) return rc;
   return shc_engine_synchronize(e);

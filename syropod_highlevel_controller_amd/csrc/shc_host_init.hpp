@@ -517,9 +517,10 @@ SHC_HDI int startup_loops(const shc_params &p) { return imax(1, round_to_int(p.t
 //  the re-basing prefix, ~350 steps, and searches one bearing, <= 500 steps)
 template <int NJ>
 SHC_HDI void generate_tables_leg(const shc_params &p, int l, shc_tables &t, int first_bearing = 1, int last_bearing = 8,
-                                 const double *preset_configuration = nullptr, LayeredPlanes *keep_planes = nullptr) {
-  // body pose the start-up solve eases to / the workspace search runs at (identical unless auto posing has its own clock)
-  const Pose body = startup_body_pose(p, t, 0), body_ws = startup_body_pose(p, t, startup_loops(p) - 1);
+                                 const double *preset_configuration = nullptr, LayeredPlanes *keep_planes = nullptr, const Pose *workspace_pose = nullptr) {
+  // body pose the start-up solve eases to / the workspace search runs at (identical unless auto posing has its own clock); workspace_pose: Model::current_pose_
+  // of the loop that completed a start-up SEQUENCE (Leg::generateWorkspace reads it, model.cpp:338)
+  const Pose body = startup_body_pose(p, t, 0), body_ws = workspace_pose ? *workspace_pose : startup_body_pose(p, t, startup_loops(p) - 1);
   HostLeg<NJ> leg;
   fill_leg_const<NJ>(p, l, leg.lc);
   for (int j = 0; j < NJ; ++j) leg.dflt[j] = clampd(0.0, leg.lc.jmin[j], leg.lc.jmax[j]); // model.cpp:1038
@@ -548,9 +549,10 @@ SHC_HDI void generate_tables_tail(const shc_params &p, shc_tables &t) {
 }
 
 template <int NJ>
-SHC_HDI bool generate_tables(const shc_params &p, shc_tables &t, const double *preset_configuration /* [legs][NJ] or nullptr */ = nullptr) {
+SHC_HDI bool generate_tables(const shc_params &p, shc_tables &t, const double *preset_configuration /* [legs][NJ] or nullptr */ = nullptr,
+                             const Pose *workspace_pose = nullptr) {
   if (!generate_tables_head(p, t)) return false;
-  for (int l = 0; l < p.leg_count; ++l) generate_tables_leg<NJ>(p, l, t, 1, 8, preset_configuration ? preset_configuration + l * NJ : nullptr);
+  for (int l = 0; l < p.leg_count; ++l) generate_tables_leg<NJ>(p, l, t, 1, 8, preset_configuration ? preset_configuration + l * NJ : nullptr, nullptr, workspace_pose);
   generate_tables_tail(p, t);
   return true;
 }

@@ -103,14 +103,29 @@ def _source_hash() -> str:
     return h.hexdigest()
 
 
+def _include_closure(src: str):
+    """The files one translation unit is built from: the source and, transitively, every `#include "..."` it names (system headers are the toolchain's)."""
+    import re
+    seen, todo = [], [os.path.realpath(src)]
+    while todo:
+        f = todo.pop()
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        with open(f, "r", errors="replace") as fh:
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), flags=re.M):
+                todo.append(os.path.realpath(os.path.join(os.path.dirname(f), inc)))
+    return sorted(seen)
+
+
 def _tu_hash(src: str, defines) -> str:
-    """Hash of what one object depends on: its source, every header (a header change rebuilds everything), flags, defines."""
+    """Hash of what one object depends on: its source and the headers it includes (transitively), flags, defines - a change to a header only the
+    host side includes (init chain, sequences, fleets, snapshots) rebuilds shc_engine.o alone, not the cycle kernels of twelve morphologies."""
     import hashlib
     h = hashlib.sha256((" ".join(_FLAGS + list(defines))).encode())
-    for s in _sources():
-        if s.endswith((".hpp", ".h")) or s == src:
-            with open(s, "rb") as f:
-                h.update(f.read())
+    for s in _include_closure(src):
+        with open(s, "rb") as f:
+            h.update(f.read())
     return h.hexdigest()
 
 
