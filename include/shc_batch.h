@@ -169,7 +169,7 @@ enum {
  * Library/device introspection.  shc_device_count() returns the number of visible HIP devices
  * (0 when none; never an error) so a caller can fail loudly before creating an engine.
  */
-int shc_abi_version(void); /* 5: shc_engine_step_k / shc_engine_get_step_k_joint_state (K cycles per launch, each with its own inputs); 4: shc_cycle_inputs.direct + shc_engine_resident_bind_inputs (launch-free posts); 3: resident mode, join, auxiliary state */
+int shc_abi_version(void); /* 6: shc_engine_adjust_parameter (the nine run-time adjustable parameters); 5: shc_engine_step_k / shc_engine_get_step_k_joint_state (K cycles per launch, each with its own inputs); 4: shc_cycle_inputs.direct + shc_engine_resident_bind_inputs (launch-free posts); 3: resident mode, join, auxiliary state */
 /* sizeof(shc_params) / sizeof(shc_tables) as compiled into the library: lets a foreign-language binding check its layout */
 int64_t shc_sizeof_params(void);
 int64_t shc_sizeof_tables(void);
@@ -437,6 +437,32 @@ int shc_engine_get_body_state(shc_engine *e, double *pose, double *velocity, int
  * every loop while gait_change_flag_ is set.  Synchronises the engine's stream.
  */
 int shc_engine_change_gait(shc_engine *e, const shc_params *new_gait, int64_t *still_walking);
+/*
+ * StateController::adjustParameter (state_controller.cpp:451-509), reached from parameterSelectionCallback / parameterAdjustCallback (:1419-1463, the
+ * adjustable_map of :1884-1892) and from dynamicParameterCallback (:1467-1548): one of the nine run-time adjustable parameters takes `value` (the callbacks'
+ * clamping to the parameter's min / max is the caller's - the node's - as are adjust_step and the selection).  `which` numbers them as enum
+ * ParameterSelection does (parameters_and_states.h:165-178).  A batch shares its parameters: the change is for every instance.
+ *   The eight parameters the cycle reads as they are (swing_height, swing_width, step_depth, stance_span_modifier, virtual_mass, virtual_stiffness,
+ *   virtual_damping_ratio, force_gain) are in force from the next control cycle: a new launch-uniform block, no table regenerated, no state touched
+ *   (stance_span_modifier moves the default tips when calculateStanceSpanChange next runs - at a stop, or at swing / stance start in rough terrain).
+ *   step_frequency: as in the reference the new value is stored at once (:454: sequence / transition timings read it from then on) and the maximum-speed maps
+ *   and the legs' phase offsets of the NEW step cycle replace the current ones at once (:458-463, generateLimits' setPhaseOffset walk_controller.cpp:277) -
+ *   the walker slows down to them.  The step cycle itself and all four limit maps are regenerated (generateStepCycle + generateLimits, :491-492) only when the
+ *   desired body velocity is inside what the velocity input maps to under the new limits (:464-489) - here: for EVERY instance; otherwise *pending (may be
+ *   NULL) receives the number of instances still outside and the caller calls again after the next cycle, as runningState retries on every loop while
+ *   parameter_adjust_flag_ is set (:411-414).  On acceptance (*pending = 0) the legs of walking robots are mapped onto the new cycle
+ *   (LegStepper::updatePhase, walk_controller.cpp:862-867) INSIDE the next control cycle, between its posing part and updateWalk, where the reference's
+ *   loop has it; that cycle runs alone in its launch on the runtime-flag kernels.  Until it has run, shc_engine_step_k and resident mode map the phases
+ *   before they start (the one-loop ordering against the posing part is then not kept).  The auto-pose phase tables keep the old step period
+ *   (setAutoPoseParams is not called by adjustParameter).  SHC_ERR_UNSUPPORTED for step_frequency in rough_terrain_mode, with gravity_aligned_tips or with a
+ *   non-zero stance_span_modifier (the posing part / the limit generation read stepper state there that this ordering cannot reproduce); the other eight
+ *   parameters have no such restriction.  Synchronises the engine's stream; SHC_ERR_BUSY in resident mode.
+ */
+enum {
+  SHC_PARAM_STEP_FREQUENCY = 1, SHC_PARAM_SWING_HEIGHT = 2, SHC_PARAM_SWING_WIDTH = 3, SHC_PARAM_STEP_DEPTH = 4, SHC_PARAM_STANCE_SPAN_MODIFIER = 5,
+  SHC_PARAM_VIRTUAL_MASS = 6, SHC_PARAM_VIRTUAL_STIFFNESS = 7, SHC_PARAM_VIRTUAL_DAMPING = 8, SHC_PARAM_FORCE_GAIN = 9
+};
+int shc_engine_adjust_parameter(shc_engine *e, int which, double value, int64_t *pending);
 /* WalkController::getOdometryIdeal() (walk_controller.h:112; integrated at walk_controller.cpp:643 from
  * calculateOdometry :783-791): [n][7] (x,y,z,qw,qx,qy,qz).  Needs SHC_FEAT_ODOMETRY (on by default). */
 int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device);

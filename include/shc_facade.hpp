@@ -131,6 +131,16 @@ public:
     return still == 0;
   }
 
+  // StateController::adjustParameter (state_controller.cpp:451-509), as runningState calls it while parameter_adjust_flag_ is set (:411-414): true once the
+  // new value is set (the flag drops), false while step_frequency waits for the robots to slow down to the new limits (keep cycling and call again).
+  // which = SHC_PARAM_* (enum ParameterSelection); the callbacks' clamping to the parameter's min / max stays with the node.
+  bool adjustParameter(int which, double new_parameter_value) {
+    int64_t pending = 0;
+    check(shc_engine_adjust_parameter(e_, which, new_parameter_value, &pending), "shc_engine_adjust_parameter");
+    invalidate();
+    return pending == 0;
+  }
+
   // ---- cached outputs, one fetch per group and cycle
   const std::vector<double> &q() { return joints_(), q_; }
   const std::vector<double> &qd() { return joints_(), qd_; }

@@ -235,6 +235,10 @@ struct orc_robot
   /* StateController (state_controller.h) */
   int robot_state, new_robot_state, transition_state_flag;
   double linear_velocity_input[2], angular_velocity_input;
+  /* StateController::parameter_adjust_flag_ / dynamic_parameter_ / new_parameter_value_ (state_controller.h) and, for a batch that has decided
+   * together, the parameter whose :491-492 is due in the next loop */
+  int parameter_adjust_flag, dynamic_parameter, adjust_commit_due;
+  double new_parameter_value;
   int unstable;
   int startup_progress; /* last return value of directStartup (orc_startup_step) */
 };
@@ -796,11 +800,12 @@ static void walker_init(orc_robot *r)
   r->step = generate_step_cycle(&r->params);
 }
 
-/* WalkController::generateLimits (walk_controller.cpp:231-361), set_limits path */
-static void walker_generate_limits(orc_robot *r)
+/* WalkController::generateLimits (walk_controller.cpp:231-361) for the given step cycle; a NULL map is not generated (adjustParameter asks for the two
+ * speed maps only, :458-461).  The legs' phase offsets are set from `step` in every case (:277). */
+static void walker_generate_limits_for(orc_robot *r, shc_step_cycle step, double *out_linear_speed, double *out_angular_speed,
+                                       double *out_linear_acceleration, double *out_angular_acceleration)
 {
   const shc_params *p = &r->params;
-  shc_step_cycle step = r->step;
   int base_step_period = p->stance_phase + p->swing_phase;
   int normaliser = step.period / base_step_period;
   int base_step_offset = (int)(p->phase_offset * normaliser);
@@ -858,11 +863,16 @@ static void walker_generate_limits(orc_robot *r)
       max_angular_speed = 0.0;
       max_angular_acceleration = ORC_UNASSIGNED_VALUE;
     }
-    r->max_linear_speed[b] = max_linear_speed;
-    r->max_linear_acceleration[b] = max_linear_acceleration;
-    r->max_angular_speed[b] = max_angular_speed;
-    r->max_angular_acceleration[b] = max_angular_acceleration;
+    if (out_linear_speed) out_linear_speed[b] = max_linear_speed;
+    if (out_linear_acceleration) out_linear_acceleration[b] = max_linear_acceleration;
+    if (out_angular_speed) out_angular_speed[b] = max_angular_speed;
+    if (out_angular_acceleration) out_angular_acceleration[b] = max_angular_acceleration;
   }
+}
+/* ... the set_limits path (no arguments: the walker's own step cycle, all four maps) */
+static void walker_generate_limits(orc_robot *r)
+{
+  walker_generate_limits_for(r, r->step, r->max_linear_speed, r->max_angular_speed, r->max_linear_acceleration, r->max_angular_acceleration);
 }
 
 /* WalkController::generateWalkspace (walk_controller.cpp:57-227) */
@@ -2777,8 +2787,20 @@ static void model_generate_workspaces(orc_robot *r)
 /* StateController::runningState (state_controller.cpp:379-447), no transitions / gait change / manual legs */
 static void walker_update_manual_velocity(orc_robot *r);
 static void walker_update_manual_pose(orc_robot *r);
+int orc_adjust_parameter(orc_robot *r, int which, double value);
+void orc_adjust_parameter_commit(orc_robot *r, int which);
 static void state_running_state(orc_robot *r)
 {
+  /* "Dynamically adjust parameters" (:411-414): after the posing part of this loop, before updateWalk */
+  if (r->adjust_commit_due)
+  {
+    orc_adjust_parameter_commit(r, r->adjust_commit_due);
+    r->adjust_commit_due = 0;
+  }
+  else if (r->parameter_adjust_flag)
+  {
+    if (orc_adjust_parameter(r, r->dynamic_parameter, r->new_parameter_value) != 0) r->parameter_adjust_flag = 0;
+  }
   walker_update_walk(r, r->linear_velocity_input, r->angular_velocity_input);
   walker_update_manual_velocity(r); /* :433-434 */
   walker_update_manual_pose(r);     /* :439-440 */
@@ -2975,6 +2997,89 @@ int orc_change_gait(orc_robot *r, const shc_params *np)
   return 1;
 }
 
+/* StateController::adjustParameter (state_controller.cpp:451-509), as runningState calls it while parameter_adjust_flag_ is set (:411-414).
+ * `which` = enum ParameterSelection (parameters_and_states.h:165-178); the callbacks (:1419-1548) have clamped `value` to the parameter's range.
+ * Eight of the nine parameters are only stored - every reader takes params_.<name>.current_value when it runs.  step_frequency: the value is stored
+ * (:454), the step cycle it gives is generated WITHOUT being set (:458), its two speed maps replace the walker's (:459-463; generateLimits also
+ * sets every LegStepper's phase offset from the new cycle, walk_controller.cpp:277), and only when the desired body velocity is inside what the
+ * velocity input maps to under the new limits (:464-489) are the step cycle and all four maps regenerated (:491-492; a robot that is MOVING maps its
+ * legs' phases onto the new period, LegStepper::updatePhase walk_controller.cpp:402-409, :862-867).  Split in two so that a batch can decide
+ * together (one engine has one set of tables): orc_adjust_parameter_probe does everything up to the decision and returns it, orc_adjust_parameter_commit is
+ * :491-492; orc_adjust_parameter = the reference's function for one robot (state_running_state calls it where runningState does while a request
+ * made with orc_request_parameter_adjust is pending).  A batch (orc_batch_adjust_parameter) probes every robot between two loops - nothing the posing
+ * part of a loop does enters the decision - and, when all agree, has every robot run :491-492 at adjustParameter's place in its next loop. */
+static double *adjustable_field(shc_params *p, int which)
+{
+  switch (which)
+  {
+    case 1: return &p->step_frequency;
+    case 2: return &p->swing_height;
+    case 3: return &p->swing_width;
+    case 4: return &p->step_depth;
+    case 5: return &p->stance_span_modifier;
+    case 6: return &p->virtual_mass;
+    case 7: return &p->virtual_stiffness;
+    case 8: return &p->virtual_damping_ratio;
+    case 9: return &p->force_gain;
+    default: return NULL;
+  }
+}
+int orc_adjust_parameter_probe(orc_robot *r, int which, double value)
+{
+  double *field = adjustable_field(&r->params, which);
+  if (!field) return -1;
+  *field = value; /* p->current_value = new_parameter_value_ */
+  if (which != 1) return 1;
+  shc_step_cycle new_step_cycle = generate_step_cycle(&r->params); /* walker_->generateStepCycle(false) */
+  double max_linear_speed_map[SHC_N_BEARINGS], max_angular_speed_map[SHC_N_BEARINGS];
+  walker_generate_limits_for(r, new_step_cycle, max_linear_speed_map, max_angular_speed_map, NULL, NULL);
+  memcpy(r->max_linear_speed, max_linear_speed_map, sizeof max_linear_speed_map);   /* setLinearSpeedLimitMap */
+  memcpy(r->max_angular_speed, max_angular_speed_map, sizeof max_angular_speed_map); /* setAngularSpeedLimitMap */
+  double max_linear_speed = walker_get_limit(r, r->linear_velocity_input, r->angular_velocity_input, max_linear_speed_map);
+  double max_angular_speed = walker_get_limit(r, r->linear_velocity_input, r->angular_velocity_input, max_angular_speed_map);
+  double target_linear_velocity[2] = { 0.0, 0.0 }, target_angular_velocity = 0.0;
+  const double *in = r->linear_velocity_input;
+  double in_norm = sqrt(in[0] * in[0] + in[1] * in[1]);
+  if (r->params.velocity_input_mode == SHC_VEL_THROTTLE)
+  {
+    double k = in_norm > 1.0 ? 1.0 / in_norm : 1.0; /* clamped(linear_velocity_input_, 1.0) */
+    target_linear_velocity[0] = in[0] * k * max_linear_speed;
+    target_linear_velocity[1] = in[1] * k * max_linear_speed;
+    target_angular_velocity = orc_clamped(r->angular_velocity_input, -1.0, 1.0) * max_angular_speed;
+    target_linear_velocity[0] *= (1.0 - fabs(r->angular_velocity_input));
+    target_linear_velocity[1] *= (1.0 - fabs(r->angular_velocity_input));
+  }
+  else
+  {
+    double k = in_norm > max_linear_speed ? max_linear_speed / in_norm : 1.0; /* clamped(linear_velocity_input_, max_linear_speed) */
+    target_linear_velocity[0] = in[0] * k;
+    target_linear_velocity[1] = in[1] * k;
+    target_angular_velocity = orc_clamped(r->angular_velocity_input, -max_angular_speed, max_angular_speed);
+  }
+  return (r->desired_linear_velocity[0] <= target_linear_velocity[0] && r->desired_linear_velocity[1] <= target_linear_velocity[1] &&
+          fabs(r->desired_angular_velocity) <= fabs(target_angular_velocity)) ? 1 : 0;
+}
+void orc_adjust_parameter_commit(orc_robot *r, int which)
+{
+  if (which != 1) return;
+  r->step = generate_step_cycle(&r->params); /* walker_->generateStepCycle(): set_step_cycle */
+  if (r->walk_state == MOVING)
+  {
+    for (int l = 0; l < r->leg_count; ++l)
+    { /* LegStepper::updatePhase */
+      stepper_t *s = &r->leg[l].stepper;
+      s->phase = (int)(s->step_progress * r->step.period);
+      stepper_update_step_state(r, s);
+    }
+  }
+  walker_generate_limits(r); /* walker_->generateLimits() */
+}
+int orc_adjust_parameter(orc_robot *r, int which, double value)
+{
+  int set_new_parameter = orc_adjust_parameter_probe(r, which, value);
+  if (set_new_parameter == 1) orc_adjust_parameter_commit(r, which);
+  return set_new_parameter;
+}
 void orc_get_tables(const orc_robot *r, shc_tables *out)
 {
   memset(out, 0, sizeof *out);
@@ -3390,6 +3495,30 @@ int64_t orc_batch_change_gait(orc_batch *b, const shc_params *np)
   return 0;
 }
 
+/* the batch's decision: every robot probes (each takes the side effects of a pending change), all commit only when all may */
+int64_t orc_batch_adjust_parameter(orc_batch *b, int which, double value)
+{
+  int64_t waiting = 0;
+  for (int64_t i = 0; i < b->n; ++i)
+  {
+    int ok = orc_adjust_parameter_probe(&b->robots[i], which, value);
+    if (ok < 0) return -1;
+    if (!ok) ++waiting;
+  }
+  if (!waiting) /* :491-492 run where adjustParameter stands in the loop: after the posing part of the next loop, before its updateWalk (state_running_state) */
+    for (int64_t i = 0; i < b->n; ++i) b->robots[i].adjust_commit_due = which;
+  return waiting;
+}
+/* parameterAdjustCallback / dynamicParameterCallback for one robot: the request is served inside its loops (state_running_state) until it is set */
+void orc_request_parameter_adjust(orc_robot *r, int which, double value)
+{
+  r->parameter_adjust_flag = 1;
+  r->dynamic_parameter = which;
+  r->new_parameter_value = value;
+}
+int orc_parameter_adjust_pending(const orc_robot *r) { return r->parameter_adjust_flag; }
+
+
 /* WalkController::getOdometryIdeal (walk_controller.h) per robot: position xyz + rotation wxyz */
 void orc_get_odometry(const orc_robot *r, double o[7])
 {
@@ -3582,6 +3711,7 @@ void orc_set_state(orc_robot *r, const shc_instance_state *o)
     s->stance_progress = g->stance_progress;
     s->step_state = g->step_state;
     s->phase = g->phase;
+    s->step_progress = (double)s->phase / r->step.period; /* (not in the record: what the last iteratePhase left, walk_controller.cpp:878) */
     s->at_correct_phase = g->at_correct_phase;
     s->completed_first_step = g->completed_first_step;
     leg->poser.negate_auto_pose = g->negate_auto_pose;

@@ -89,6 +89,13 @@ void orc_batch_get_body_state(orc_batch *b, double *pose, double *velocity, int3
 void orc_get_leg_state_msg(const orc_robot *r, shc_leg_state_msg *legs /* [leg_count] */);
 int orc_change_gait(orc_robot *r, const shc_params *new_gait);
 int64_t orc_batch_change_gait(orc_batch *b, const shc_params *new_gait);
+/* StateController::adjustParameter (state_controller.cpp:451-509); which = enum ParameterSelection.  1 = set, 0 = step_frequency still waiting, -1 = unknown */
+int orc_adjust_parameter(orc_robot *r, int which, double value);
+int orc_adjust_parameter_probe(orc_robot *r, int which, double value);
+void orc_adjust_parameter_commit(orc_robot *r, int which);
+int64_t orc_batch_adjust_parameter(orc_batch *b, int which, double value); /* instances still waiting; 0 = set for all (committed inside the next loop) */
+void orc_request_parameter_adjust(orc_robot *r, int which, double value); /* one robot: served inside its loops as runningState does */
+int orc_parameter_adjust_pending(const orc_robot *r);
 void orc_batch_get_odometry(orc_batch *b, double *pose /* [n][7]: xyz + wxyz */);
 void orc_batch_get_virtual_stiffness(orc_batch *b, double *stiffness /* [n][legs] */);
 

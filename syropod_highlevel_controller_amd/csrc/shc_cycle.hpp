@@ -67,6 +67,7 @@ constexpr bool rot_enabled() { return (F & F_ROT) != 0 && (NJ > 3 || (F & F_MLEG
 struct CycleParams {
   double dt;
   int32_t period, swing_period, stance_period, stance_end, swing_start, swing_end, stance_start;
+  int32_t remap_old_period;  // != 0 for the ONE cycle that follows an accepted step-frequency change: the period the legs' phases still count in (see cycle_front)
   int32_t swing_iterations;  // walk_controller.cpp:1035-1036
   int32_t stance_iterations; // :1040 with the standard stance period
   double swing_delta_t;      // :1037
@@ -1115,6 +1116,31 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
 
   SHC_PHASE_FENCE();
   SHC_TICK(6);
+  // ---- StateController::adjustParameter("step_frequency") accepted in this loop (state_controller.cpp:491-492, before updateWalk and after the posing
+  //      part): WalkController::generateStepCycle() has installed the new step cycle - the constants of this launch - and, for a robot that is MOVING,
+  //      LegStepper::updatePhase (walk_controller.cpp:862-867) maps every leg's phase onto it: phase_ = int(step_progress_ * period) with
+  //      step_progress_ = phase_ / old period as the last iteratePhase left it (:878), then updateStepState (:901-917).  The posing part above has run
+  //      on the un-mapped words, as in the reference.  shc_engine_adjust_parameter sets P.remap_old_period for exactly one cycle and that cycle runs
+  //      on the runtime-flag kernels (the feature-exact ones carry none of this).
+  if constexpr ((F & F_DYN) != 0) {
+    const int remap_from = uni(P.remap_old_period);
+    if (remap_from > 0) {
+      if (walk_state == WS_MOVING) {
+        int ph = (s.word >> LW_PHASE_SHIFT) & LW_PHASE_MASK, st = s.word & 3;
+        const double step_progress = double(ph) / double(remap_from);
+        ph = int(step_progress * double(P.period));
+        if (st != SS_FORCE_STOP) {
+          if (ph >= P.swing_start && ph < P.swing_end && st != SS_FORCE_STANCE) st = SS_SWING;
+          else if (ph < P.stance_end || ph >= P.stance_start) st = SS_STANCE;
+        }
+        s.word = (s.word & ~(3 | (LW_PHASE_MASK << LW_PHASE_SHIFT))) | st | (ph << LW_PHASE_SHIFT);
+      }
+      if (lw_early) { // the other legs' words as the walk state machine below reads them
+#pragma unroll
+        for (int j = 0; j < L; ++j) lw[j] = g.get(s.word, j);
+      }
+    }
+  }
   // ---- walk state machine (:529-564)
   int lacp = (rword >> RW_LACP_SHIFT) & 15, lcfs = (rword >> RW_LCFS_SHIFT) & 15;
   bool rtda = (rword & RW_RTDA) != 0;
@@ -1311,6 +1337,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       // stance (:1159-1177)
       int it_st = my_phase + (P.period - mss); // both terms lie in [0, period]: one conditional subtract is the modulo
       if (it_st >= P.period) it_st -= P.period;
+      if (it_st < 0 || it_st >= P.period) it_st = mod_i(it_st, P.period); // (... except while a step-frequency change waits: the phase offsets are the NEW cycle's then, see below)
       it_st += 1;
       const bool first_st = step_st && it_st == 1;
       const V3 torg = sel3(first_st, s.tip, torg_p);
@@ -1428,6 +1455,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
       } else { // STANCE / FORCE_STANCE
         int iteration = my_phase + (P.period - mss); // both terms lie in [0, period]: one conditional subtract is the modulo
         if (iteration >= P.period) iteration -= P.period;
+        if (iteration < 0 || iteration >= P.period) iteration = mod_i(iteration, P.period);
         iteration += 1;
         V3 torg;
         if (iteration == 1) {
@@ -1503,6 +1531,10 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     }
     // ---- iteratePhase (:871-897)
     my_phase = my_phase + 1 == P.period ? 0 : my_phase + 1; // (phase + 1) % period with phase in [0, period)
+    // While adjustParameter("step_frequency") waits for the robots to slow down, the legs' phase offsets are already those of the NEW step cycle
+    // (generateLimits' setPhaseOffset, walk_controller.cpp:277) and may exceed the period still in force: a robot that starts to walk then takes such
+    // an offset as its phase (:542) and the reference's modulo brings it back on the first iteratePhase.  A branch no lane takes otherwise.
+    if (my_phase > P.period) my_phase = my_phase % P.period;
     if (my_state != SS_FORCE_STOP) {
       if (my_phase >= P.swing_start && my_phase < P.swing_end && my_state != SS_FORCE_STANCE) my_state = SS_SWING;
       else if (my_phase < P.stance_end || my_phase >= P.stance_start) my_state = SS_STANCE;

@@ -270,6 +270,7 @@ struct shc_engine {
   double *d_span = nullptr;             // SpanTable (rough terrain mode with a stance span modifier), rebuilt with the tables
   int half_steps = 0;                   // CycleLaunch::half_steps (development switch SHC_ROT_SPLIT = 0 / 1: never / always; unset: by launch size)
   bool span_dirty = true;
+  bool step_remap_pending = false;      // an accepted step-frequency change waits for the next cycle (shc_engine_adjust_parameter)
   bool fresh_pose_controller = false;   // init_state for shc_engine_begin_sequence_startup: no direct start-up has run, the auto posers have not been called yet
   struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
   const double *bound_inputs[kBoundSets][BND_COUNT] = {}; // shc_engine_resident_bind_inputs: the caller's device arrays for direct posts
@@ -288,6 +289,7 @@ static bool resident_active(const shc_engine *e);
 static void resident_shutdown(shc_engine *e); // stop a running resident loop and free its buffers (shc_engine_destroy)
 // While the resident kernel owns the engine's stream and state, every other entry point that would touch them is refused.
 static int join_side(shc_engine *e);
+static int flush_step_remap(shc_engine *e); // an accepted step-frequency change no cycle has consumed yet: map the phases now
 #define SHC_BUSY_ONLY(e)                                                                                                       \
   do {                                                                                                                         \
     if ((e) && resident_active(e))                                                                                             \
@@ -510,7 +512,7 @@ static int generate_tables_nj(const shc_params *p, shc_tables *out) {
   return hostinit::generate_tables<NJ>(*p, *out) ? SHC_OK : fail(SHC_ERR_INVALID_ARG, "init chain failed (unreachable stance?)");
 }
 
-extern "C" int shc_abi_version(void) { return 5; } // 5: shc_engine_step_k (K cycles per launch, each with its own inputs); 4: shc_cycle_inputs.direct (launch-free posts); 3: shc_leg_snapshot carries the stepper target tip direction; resident mode, join, auxiliary state
+extern "C" int shc_abi_version(void) { return 6; } // 6: shc_engine_adjust_parameter; 5: shc_engine_step_k (K cycles per launch, each with its own inputs); 4: shc_cycle_inputs.direct (launch-free posts); 3: shc_leg_snapshot carries the stepper target tip direction; resident mode, join, auxiliary state
 extern "C" int64_t shc_sizeof_params(void) { return (int64_t)sizeof(shc_params); }
 extern "C" int64_t shc_sizeof_tables(void) { return (int64_t)sizeof(shc_tables); }
 
@@ -1327,6 +1329,20 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
+  if (e->step_remap_pending && !(e->rt_flags & (RT_SKIP_MARKED | RT_POSE_MARKED))) {
+    // the loop in which adjustParameter accepted a new step frequency: its cycle maps the phases of walking robots onto the new step cycle between the
+    // posing part and updateWalk (cycle_front; the uploaded constants carry remap_old_period) - on the runtime-flag kernels, alone in its launch
+    e->step_remap_pending = false;
+    const uint32_t keep = e->features;
+    e->features |= SHC_FEAT_GENERIC_KERNEL;
+    int rc = shc_engine_step(e, 1);
+    e->features = keep;
+    if (rc == SHC_OK) rc = join_side(e);
+    e->cp.remap_old_period = 0;
+    if (rc == SHC_OK) rc = upload_consts(e); // (ordered behind the cycle above on the engine's stream, and synchronises it)
+    if (rc != SHC_OK || n_cycles == 1) return rc;
+    --n_cycles;
+  }
   if (!(e->rt_flags & (RT_SKIP_MARKED | RT_POSE_MARKED))) e->plan_poser_tips_current = false; // PoseController::updateStance rewrites every LegPoser's tip pose
   // One wave per workgroup while the batch has about as many waves as the chip has SIMDs (1 024): the dispatcher then spreads
   // them one per SIMD (two-wave groups put pairs on the same SIMDs: 12.9 instead of 9.4 us at 768 waves, 12.2 instead of 10.2 at
@@ -1516,6 +1532,164 @@ extern "C" int shc_engine_change_gait(shc_engine *e, const shc_params *ng, int64
     HIP_TRY(hipGetLastError());
   }
   return shc_engine_synchronize(e);
+}
+
+// An accepted step-frequency change that no cycle has consumed yet (the caller went on to something other than shc_engine_step): the phases are mapped
+// here instead, by a kernel of their own - the same arithmetic as in cycle_front, without the reference's ordering against the posing part of that loop.
+__global__ void step_remap_kernel(int32_t *legi, const int32_t *robi, int rpw, int64_t n, int L, int old_period, int period, int swing_start, int swing_end,
+                                  int stance_end, int stance_start) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  const int64_t rob = t / L;
+  const int leg = int(t - rob * L);
+  if ((robi[rob_index(rob, RobotFields::I_WORD, rpw, RobotFields::I_COUNT)] & 3) != WS_MOVING) return;
+  int w = legi[slot_of(rob, leg, L)];
+  int ph = (w >> LW_PHASE_SHIFT) & LW_PHASE_MASK, st = w & 3;
+  const double step_progress = double(ph) / double(old_period);
+  ph = int(step_progress * double(period));
+  if (st != SS_FORCE_STOP) {
+    if (ph >= swing_start && ph < swing_end && st != SS_FORCE_STANCE) st = SS_SWING;
+    else if (ph < stance_end || ph >= stance_start) st = SS_STANCE;
+  }
+  legi[slot_of(rob, leg, L)] = (w & ~(3 | (LW_PHASE_MASK << LW_PHASE_SHIFT))) | st | (ph << LW_PHASE_SHIFT);
+}
+static int flush_step_remap(shc_engine *e) {
+  if (!e->step_remap_pending) return SHC_OK;
+  e->step_remap_pending = false;
+  HIP_TRY(hipSetDevice(e->device));
+  {
+    const int rc = join_side(e);
+    if (rc != SHC_OK) return rc;
+  }
+  const int64_t threads = e->n * e->L;
+  const shc_step_cycle &s = e->tables.step;
+  step_remap_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(e->st.legi, e->st.robi, 64 / e->L, e->n, e->L, e->cp.remap_old_period, s.period,
+                                                                                       s.swing_start, s.swing_end, s.stance_end, s.stance_start);
+  HIP_TRY(hipGetLastError());
+  e->cp.remap_old_period = 0;
+  return upload_consts(e);
+}
+
+// WalkController::getLimit (walk_controller.cpp:414-436) on the host, for the acceptance test of a step-frequency change: per leg the bearing of its
+// stride velocity (linear + angular x the tip's lever arm), rounded to whole degrees, picks the two neighbouring entries of the 45-degree table; the
+// interpolation input is an int / int division in the reference (0 except on a table bearing), the smallest value over the legs is the limit.
+static double host_get_limit(const double *tips /* [L][3] walker tip positions */, int L, double lx, double ly, double ang, const double *limit /* [9] */) {
+  double lowest = kUnassigned;
+  for (int l = 0; l < L; ++l) {
+    const double sx = lx + ang * -tips[l * 3 + 1], sy = ly + ang * tips[l * 3 + 0];
+    int bearing = mod_i(round_to_int(atan2(sy, sx) * (180.0 / M_PI)), 360);
+    int upper = ((bearing + 44) / 45) * 45;
+    const int lower = mod_i(upper - 45, 360);
+    if (bearing < lower) bearing += 360;
+    if (upper < lower) upper += 360;
+    const double c = double((bearing - lower) / (upper - lower));
+    const double lo = limit[lower / 45], hi = limit[mod_i(upper, 360) / 45];
+    lowest = fmin(lowest, lo * (1.0 - c) + hi * c);
+  }
+  return lowest;
+}
+
+static int adjust_step_frequency(shc_engine *e, double value, int64_t *pending) {
+  shc_params &p = e->params;
+  // What the posing part of the accepting loop reads from the legs' steppers must not depend on the step cycle's constants (it runs on the old cycle in the
+  // reference, on the new constants here): the walk-plane blend of rough terrain mode and the tip rotations / tip-align pose of gravity_aligned_tips do.
+  // WalkController::generateLimits takes its stance radius from leg 0's CURRENT default tip (walk_controller.cpp:322-326), which a stance span modifier moves.
+  if (p.rough_terrain_mode || p.gravity_aligned_tips || p.stance_span_modifier != 0.0)
+    return fail(SHC_ERR_UNSUPPORTED, "step_frequency cannot be adjusted at run time in rough_terrain_mode, with gravity_aligned_tips or with a stance span modifier "
+                                     "(the other eight parameters can); change it between runs, shc_engine_create");
+  if (!(value > 0.0)) return fail(SHC_ERR_INVALID_ARG, "step_frequency must be positive");
+  int rc = flush_step_remap(e); // (two changes without a cycle between them)
+  if (rc != SHC_OK) return rc;
+  shc_params np = p;
+  np.step_frequency = value;
+  const shc_step_cycle ns = hostinit::generate_step_cycle(np);
+  if (ns.period <= 0 || ns.period > LW_PHASE_MASK) return fail(SHC_ERR_INVALID_ARG, "step_frequency gives a degenerate step cycle");
+  p.step_frequency = value; // p->current_value = new_parameter_value_ (:454): the sequence / transition timings read it from now on, accepted or not
+  shc_tables tn = e->tables;
+  tn.step = ns;
+  hostinit::generate_limits(p, tn); // the four limit maps + the legs' phase offsets of the new cycle
+  // :462-463 and generateLimits' setPhaseOffset (walk_controller.cpp:277): the speed maps and the phase offsets are the new cycle's from here on, whether the
+  // change is accepted in this loop or not - the walker slows down to them (updateWalk :456-482), which is what makes a later call succeed
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) {
+    e->tables.max_linear_speed[b] = tn.max_linear_speed[b];
+    e->tables.max_angular_speed[b] = tn.max_angular_speed[b];
+  }
+  for (int l = 0; l < e->L; ++l) e->tables.phase_offset[l] = tn.phase_offset[l];
+  // the test of :464-489, for every instance: desired body velocity inside what its velocity input maps to under the new limits
+  std::vector<double> vin(size_t(e->n) * 3), vel(size_t(e->n) * 3), tips(size_t(e->n) * e->L * 3);
+  if ((rc = gather_rob(e, vin.data(), 3, RobotFields::VIN, 0)) != SHC_OK) return rc;
+  if ((rc = gather_rob(e, vel.data(), 3, RobotFields::VLIN, 0)) != SHC_OK) return rc;
+  if ((rc = gather_leg(e, tips.data(), 3, LEG_FIELD(e, TIP), 0)) != SHC_OK) return rc;
+  int64_t waiting = 0;
+  for (int64_t i = 0; i < e->n; ++i) {
+    const double *in = &vin[size_t(i) * 3], *v = &vel[size_t(i) * 3], *tp = &tips[size_t(i) * e->L * 3];
+    const double max_lin = host_get_limit(tp, e->L, in[0], in[1], in[2], tn.max_linear_speed);
+    const double max_ang = host_get_limit(tp, e->L, in[0], in[1], in[2], tn.max_angular_speed);
+    double tx, ty, ta;
+    if (p.velocity_input_mode == SHC_VEL_THROTTLE) {
+      const double nrm = sqrt(in[0] * in[0] + in[1] * in[1]);
+      const double k = nrm > 1.0 ? 1.0 / nrm : 1.0; // clamped(vector, 1.0)
+      tx = in[0] * k * max_lin;
+      ty = in[1] * k * max_lin;
+      ta = clampd(in[2], -1.0, 1.0) * max_ang;
+      tx *= 1.0 - fabs(in[2]);
+      ty *= 1.0 - fabs(in[2]);
+    } else {
+      const double nrm = sqrt(in[0] * in[0] + in[1] * in[1]);
+      const double k = nrm > max_lin ? max_lin / nrm : 1.0;
+      tx = in[0] * k;
+      ty = in[1] * k;
+      ta = clampd(in[2], -max_ang, max_ang);
+    }
+    if (!(v[0] <= tx && v[1] <= ty && fabs(v[2]) <= fabs(ta))) ++waiting; // (signed comparisons of the linear components: as the reference has them)
+  }
+  if (pending) *pending = waiting;
+  if (waiting) return upload_consts(e); // not yet: the new speed maps / phase offsets are in force, the step cycle and the acceleration maps are the old ones
+  // accepted: walker_->generateStepCycle() + generateLimits() (:491-492).  setAutoPoseParams is NOT called (only init / changeGait do): the auto-pose phase
+  // tables keep counting in the old step period, as in the reference.
+  const int old_period = e->tables.step.period;
+  e->tables.step = ns;
+  for (int b = 0; b < SHC_N_BEARINGS; ++b) {
+    e->tables.max_linear_acceleration[b] = tn.max_linear_acceleration[b];
+    e->tables.max_angular_acceleration[b] = tn.max_angular_acceleration[b];
+  }
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
+  e->cp.remap_old_period = old_period; // generateStepCycle's updatePhase for MOVING robots: inside the next cycle (shc_engine_step)
+  e->step_remap_pending = true;
+  return upload_consts(e);
+}
+
+extern "C" int shc_engine_adjust_parameter(shc_engine *e, int which, double value, int64_t *pending) {
+  SHC_BUSY_GUARD(e);
+  if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
+  if (pending) *pending = 0;
+  if (!(value == value) || fabs(value) > 1e300) return fail(SHC_ERR_INVALID_ARG, "parameter value is not finite");
+  HIP_TRY(hipSetDevice(e->device));
+  shc_params &p = e->params;
+  switch (which) {
+    case SHC_PARAM_STEP_FREQUENCY: return adjust_step_frequency(e, value, pending);
+    case SHC_PARAM_SWING_HEIGHT: p.swing_height = value; break;          // LegStepper::updateStride's swing clearance, the dynamic-stiffness reference, sequence step heights
+    case SHC_PARAM_SWING_WIDTH: p.swing_width = value; break;            // generateSecondarySwingControlNodes' lateral shift (walk_controller.cpp:1243)
+    case SHC_PARAM_STEP_DEPTH: p.step_depth = value; break;              // the proactive step-plane target (:1099)
+    case SHC_PARAM_STANCE_SPAN_MODIFIER: p.stance_span_modifier = value; e->span_dirty = true; break; // calculateStanceSpanChange (:966), applied at the next stop / swing start
+    case SHC_PARAM_VIRTUAL_MASS:
+      if (!(value > 0.0)) return fail(SHC_ERR_INVALID_ARG, "virtual_mass must be positive");
+      p.virtual_mass = value;
+      break;
+    case SHC_PARAM_VIRTUAL_STIFFNESS:
+      if (!(value > 0.0)) return fail(SHC_ERR_INVALID_ARG, "virtual_stiffness must be positive");
+      p.virtual_stiffness = value;
+      break;
+    case SHC_PARAM_VIRTUAL_DAMPING: p.virtual_damping_ratio = value; break;
+    case SHC_PARAM_FORCE_GAIN: p.force_gain = value; break;              // admittance input (admittance_controller.cpp:32), tip-force estimate (model.cpp:705), LegState tip force
+    default: return fail(SHC_ERR_INVALID_ARG, "unknown adjustable parameter (SHC_PARAM_*)");
+  }
+  // The eight parameters the control cycle reads as they are (params_.*.current_value): a new launch-uniform block, in force from the next cycle; no table is
+  // regenerated and no state is touched.
+  const int keep_remap = e->cp.remap_old_period;
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
+  e->cp.remap_old_period = keep_remap;
+  return upload_consts(e);
 }
 
 extern "C" int shc_engine_get_odometry(shc_engine *e, double *pose, int on_device) {
@@ -2764,6 +2938,10 @@ extern "C" int64_t shc_sizeof_instance_state(void) { return (int64_t)sizeof(shc_
 
 // Snapshot records travel through a temporary device buffer (checkpoint / injection are not per-cycle operations).
 static int state_transfer(shc_engine *e, int64_t first, int64_t count, shc_instance_state *out, const shc_instance_state *in) {
+  { // (a state record shows / replaces the legs' phases as the accepting loop leaves them)
+    const int rc_remap = flush_step_remap(e);
+    if (rc_remap != SHC_OK) return rc_remap;
+  }
   if (!e || (!out && !in)) return fail(SHC_ERR_INVALID_ARG, "NULL argument");
   if (first < 0 || count < 0 || first + count > e->n) return fail(SHC_ERR_INVALID_ARG, "instance range out of bounds");
   if (count == 0) return SHC_OK;

@@ -202,6 +202,10 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
   if (max_cycles < 1 || max_cycles > 0x7ffffffe) return fail(SHC_ERR_INVALID_ARG, "max_cycles must be 1..2^31-2");
   if (idle_timeout_ms < 0 || idle_timeout_ms > 600000) return fail(SHC_ERR_INVALID_ARG, "idle_timeout_ms must be 0..600000");
   if (e->starting_up) return fail(SHC_ERR_UNSUPPORTED, "resident mode starts from a running engine (finish the start-up first)");
+  {
+    const int rc_remap = flush_step_remap(e);
+    if (rc_remap != SHC_OK) return rc_remap;
+  }
   HIP_TRY(hipSetDevice(e->device));
   {
     const int rc = join_side(e);
@@ -713,6 +717,10 @@ extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_in
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1 || n_cycles > 4096) return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: 1 .. 4096 cycles per launch");
   if (e->starting_up) return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k starts from a running engine (finish the start-up first)");
+  {
+    const int rc_remap = flush_step_remap(e);
+    if (rc_remap != SHC_OK) return rc_remap;
+  }
   unsigned mask = 0;
   if (in) {
     if (!in->on_device) return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: the K-deep input arrays are device arrays (on_device = 1)");

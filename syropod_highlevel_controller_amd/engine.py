@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = [
     "shc_engine_resident_begin", "shc_engine_resident_bind_inputs", "shc_engine_resident_post", "shc_engine_resident_publish", "shc_engine_resident_wait",
     "shc_engine_resident_get_joint_state", "shc_engine_resident_get_joint_state_async", "shc_engine_resident_status", "shc_engine_resident_end", "shc_engine_join",
     "shc_engine_aux_state_bytes", "shc_engine_get_aux_state", "shc_engine_set_aux_state",
-    "shc_engine_step_k", "shc_engine_get_step_k_joint_state",
+    "shc_engine_step_k", "shc_engine_get_step_k_joint_state", "shc_engine_adjust_parameter",
     "shc_peer_alloc", "shc_peer_open", "shc_peer_close", "shc_peer_scatter",
 ]
 
@@ -284,6 +284,7 @@ def lib():
         L.shc_stream_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.shc_stream_destroy.argtypes = [C.c_int, C.c_void_p]
         L.shc_engine_change_gait.argtypes = [C.c_void_p, C.POINTER(Params), C.POINTER(C.c_int64)]
+        L.shc_engine_adjust_parameter.argtypes = [C.c_void_p, C.c_int, C.c_double, C.POINTER(C.c_int64)]
         L.shc_engine_get_virtual_stiffness.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.shc_sizeof_instance_state.restype = C.c_int64
         L.shc_engine_set_joint_states_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -637,6 +638,13 @@ class BatchEngine:
         if still.value == 0:
             self.params = new_gait
         return int(still.value)
+
+    def adjust_parameter(self, which: int, value: float) -> int:
+        """StateController::adjustParameter for the whole batch (which: params.PARAM_*, enum ParameterSelection).  Returns the number of instances
+        whose desired velocity is still outside the new limits (step_frequency only: call again after the next cycle); 0 = the value is set."""
+        pending = C.c_int64(0)
+        _check(self.L.shc_engine_adjust_parameter(self.h, int(which), float(value), C.byref(pending)), "adjust_parameter")
+        return int(pending.value)
 
     def leg_state_msg(self, instance: int):
         """Numeric payload of LegState.msg for every leg of one instance (StateController::publishLegState)."""

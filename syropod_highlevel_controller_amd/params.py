@@ -360,3 +360,11 @@ def synthetic_mixed_dof_params(gait: str = "ripple", dofs=(3, 5, 4, 3, 5, 4)) ->
         for j in range(SHC_MAX_JOINTS + 1):
             p.link[l][j] = src.link[l][j]
     return p
+
+
+# enum ParameterSelection (parameters_and_states.h:165-178) = SHC_PARAM_* of include/shc_batch.h: the run-time adjustable parameters
+(PARAM_STEP_FREQUENCY, PARAM_SWING_HEIGHT, PARAM_SWING_WIDTH, PARAM_STEP_DEPTH, PARAM_STANCE_SPAN_MODIFIER, PARAM_VIRTUAL_MASS, PARAM_VIRTUAL_STIFFNESS,
+ PARAM_VIRTUAL_DAMPING, PARAM_FORCE_GAIN) = range(1, 10)
+PARAM_FIELD = {PARAM_STEP_FREQUENCY: "step_frequency", PARAM_SWING_HEIGHT: "swing_height", PARAM_SWING_WIDTH: "swing_width", PARAM_STEP_DEPTH: "step_depth",
+               PARAM_STANCE_SPAN_MODIFIER: "stance_span_modifier", PARAM_VIRTUAL_MASS: "virtual_mass", PARAM_VIRTUAL_STIFFNESS: "virtual_stiffness",
+               PARAM_VIRTUAL_DAMPING: "virtual_damping_ratio", PARAM_FORCE_GAIN: "force_gain"}

@@ -74,6 +74,9 @@ def lib():
         L.orc_get_leg_state_msg.argtypes = [C.c_void_p, C.POINTER(LegStateMsg)]
         L.orc_batch_change_gait.argtypes = [C.c_void_p, C.POINTER(Params)]
         L.orc_batch_change_gait.restype = C.c_int64
+        L.orc_batch_adjust_parameter.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.orc_batch_adjust_parameter.restype = C.c_int64
+        L.orc_adjust_parameter.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.orc_batch_get_virtual_stiffness.argtypes = [C.c_void_p, _dp]
         L.orc_set_joint_states_msg.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.orc_set_step_plane.argtypes = [C.c_void_p, _dp]
@@ -490,6 +493,20 @@ class OracleBatch:
         if still == 0:
             self.p = new_gait
         return still
+
+    def tables(self):
+        """The step cycle / phase offsets / limit maps robot 0 holds now (every robot of a batch shares them)."""
+        t = Tables()
+        self.L.orc_get_tables(self.L.orc_batch_robot(self.h, 0), C.byref(t))
+        return t
+
+    def adjust_parameter(self, which, value):
+        """StateController::adjustParameter, decided for the batch as a whole (as shc_engine_adjust_parameter does): instances still waiting."""
+        waiting = int(self.L.orc_batch_adjust_parameter(self.h, int(which), float(value)))
+        assert waiting >= 0
+        from syropod_highlevel_controller_amd.params import PARAM_FIELD
+        setattr(self.p, PARAM_FIELD[int(which)], float(value))
+        return waiting
 
     def odometry(self):
         pose = np.zeros((self.n, 7))

@@ -104,7 +104,7 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(engine.build_library())
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.shc_abi_version() == 5
+    assert lib.shc_abi_version() == 6
 
 
 def test_struct_layouts_match_the_library():
