@@ -394,6 +394,9 @@ class RefWalker:
         self.stiffness = [0.0] * self.L   # Leg::virtual_stiffness_: uninitialised in the reference until the first updateStiffness (0 by this build's convention)
         self.tip_force = np.zeros((self.L, 3))
         self.tip_force_calc = np.zeros((self.L, 3))   # Leg::tip_force_calculated_
+        self.adjust = None          # StateController::dynamic_parameter_ / new_parameter_value_ while parameter_adjust_flag_ is set: (name, value)
+        self.adjust_log = []        # cycles (counted by the caller) in which a pending adjustment was set
+        self.walkspace = self.default_tips = None   # what generateLimits needs for a new step cycle (scenarios that adjust step_frequency)
         self.efforts = None                            # Joint::current_effort_ [legs][dof]
 
     def step_cycle(self):  # generateStepCycle + the phase offsets of generateLimits
@@ -928,9 +931,51 @@ class RefWalker:
             adm = [admittance_delta(self.adm_state[i], src[i], tip_axis(i, self.q[i]), self.P) for i in range(self.L)]
         return pose, adm
 
+    def adjust_parameter(self, lin_in, ang_in):
+        """StateController::adjustParameter (state_controller.cpp:451-509).  Every parameter is stored at once; step_frequency additionally installs the
+        two speed maps and the phase offsets of the step cycle it WOULD give (:458-463; generateLimits sets every LegStepper's phase offset,
+        walk_controller.cpp:277) and becomes the walker's step cycle only once the desired body velocity is inside the targets the velocity input maps to
+        under the new limits (:464-497); a MOVING robot's legs are then mapped onto the new period (LegStepper::updatePhase, :402-409, :862-867).
+        setAutoPoseParams is not called: the auto-pose phase tables keep the period they were generated with."""
+        name, value = self.adjust
+        P = self.P
+        P[name] = value                                       # p->current_value = new_parameter_value_
+        if name != "step_frequency":
+            self.adjust = None
+            return
+        probe = RefWalker(P, {})                              # generateStepCycle(false): the cycle the new frequency gives, and generateLimits on it
+        init = init_chain_module()
+        lim = init.generate_limits(P, probe, self.walkspace, self.default_tips)
+        self.limits = dict(self.limits, max_linear_speed=lim["max_linear_speed"], max_angular_speed=lim["max_angular_speed"])   # set*SpeedLimitMap (:462-463)
+        for leg, pl in zip(self.legs, probe.legs):
+            leg.phase_offset = pl.phase_offset                # generateLimits' setPhaseOffset
+        max_lin = self.limit(lin_in, ang_in, lim["max_linear_speed"])
+        max_ang = self.limit(lin_in, ang_in, lim["max_angular_speed"])
+        norm = np.linalg.norm(lin_in)
+        if P["velocity_input_mode"] == "throttle":
+            target = (lin_in / norm if norm > 1.0 else lin_in) * max_lin
+            target_w = min(1.0, max(-1.0, ang_in)) * max_ang
+            target = target * (1.0 - abs(ang_in))
+        else:
+            target = lin_in * (max_lin / norm) if norm > max_lin else lin_in.copy()
+            target_w = min(max_ang, max(-max_ang, ang_in))
+        if not (self.v[0] <= target[0] and self.v[1] <= target[1] and abs(self.w) <= abs(target_w)):
+            return                                            # "Slowing to safe speed before setting new parameter": asked again in the next loop
+        old_period = self.period                              # generateStepCycle(): the walker's step cycle from now on
+        for k in ("period", "frequency", "stance_end", "swing_start", "swing_end", "stance_start", "stance_period", "swing_period"):
+            setattr(self, k, getattr(probe, k))
+        if self.walk_state == MOVING:
+            for leg in self.legs:                             # updatePhase: step_progress_ (= phase / old period, as the last iteratePhase left it) of the new period
+                leg.phase = int((leg.phase / old_period) * self.period)
+                self.update_step_state(leg)
+        self.limits = {k: list(v) for k, v in lim.items()}    # generateLimits(): all four maps
+        self.adjust = None
+
     def cycle(self, lin, ang):
         """One StateController::loop with robot_state RUNNING (state_controller.cpp:162-193, 429-445)."""
         pose, adm = self.prologue()
+        if self.adjust is not None:      # runningState: "Dynamically adjust parameters" (state_controller.cpp:411-414), before updateWalk
+            self.adjust_parameter(np.array(lin, dtype=float), float(ang))
         self.update_walk(lin, ang)
         self.update_manual()
         if self.q is not None:   # PoseController::updateStance + Model::updateModel: tips as seen from the posed body, one IK step per leg
@@ -1075,6 +1120,13 @@ SCENARIOS = {
     "tripod_tip_align_pose": ("tripod", {"gravity_aligned_tips": 1, "model": 1}, [(0, (0.5, -0.1), 0.15), (280, (0, 0), 0.0)], 420),
     # a gait change on the move: the robot is stopped, the step cycle, phase offsets and limit tables are regenerated, it walks on
     "tripod_to_wave_gait_change": ("tripod", {"model": 1, "gait_change": "wave"}, [(0, (0.5, 0.1), 0.2), (330, (0.3, -0.2), -0.2)], 640),
+    # run-time parameter adjustment (StateController::adjustParameter): swing height / width and the virtual spring's constants take effect in the next
+    # loop; a higher step frequency first slows the robot down to the new cycle's speed limits, then replaces the step cycle under the walking legs; a lower
+    # one afterwards (its phase offsets exceed the period still in force while it waits)
+    "tripod_parameters_adjusted_on_the_move": ("tripod", {"model": 1, "admittance_control": 1,
+                                                          "adjust": [[60, "swing_height", 0.035], [90, "swing_width", 0.012], [120, "virtual_stiffness", 15.0],
+                                                                     [150, "force_gain", 0.16], [180, "step_frequency", 1.5], [420, "step_frequency", 0.8]]},
+                                               [(0, (0.7, 0.2), 0.25), (560, (0, 0), 0.0), (620, (0.4, -0.3), -0.2)], 900),
     # the published per-leg virtual stiffness of dynamic_stiffness (swing legs soften, their neighbours stiffen)
     "ripple_dynamic_stiffness": ("ripple", {"admittance_control": 1, "dynamic_stiffness": 1, "model": 1}, [(0, (0.5, 0.1), 0.2), (200, (0, 0), 0.0)], 330),
     # the tip-force estimate in the loop: admittance driven by Leg::calculateTipForce from measured joint torques (a new sample every 10 cycles)
@@ -1158,7 +1210,16 @@ def run(name):
         w.workspaces = workspaces_of(gait, morphology, prod["rough_terrain_mode"], prod["gravity_aligned_tips"])
     import zlib
     rng = np.random.default_rng(zlib.crc32(name.encode()))
-    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], odometry=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[], gait_request=[])
+    out = dict(tips=[], phase=[], state=[], walk_state=[], velocity=[], pose=[], odometry=[], lin=[], ang=[], imu_q=[], gyro=[], default=[], target=[], force=[], contact_force=[], effort=[], tip_force_calc=[], stiffness=[], gait_request=[],
+               adjust_request=[], adjust_value=[], period=[])
+    adjustments = over.pop("adjust", None)
+    P.pop("adjust", None)
+    if adjustments:      # generateLimits for a new step cycle needs the walkspace and the default tips the init chain ended on
+        global _MI
+        if _MI is None:
+            _MI = init_chain_module()
+        ch = _MI.chain(morphology, bool(prod["rough_terrain_mode"]), bool(prod["gravity_aligned_tips"]), START_UP_TIME)
+        w.walkspace, w.default_tips = ch["walkspace"], ch["defaults"]
     events = rough_events(name, P)
     gait_changed, meta_new_limits = False, {}
     lin, ang = (0.0, 0.0), 0.0
@@ -1183,6 +1244,15 @@ def run(name):
         if (P.get("imu_posing") or P.get("inclination_posing")) and c % 25 == 0:  # a new IMU sample every 25 cycles
             e = [rng.uniform(-0.15, 0.15), rng.uniform(-0.15, 0.15), 0.0]
             w.imu_q, w.gyro = euler_to_rot(e), rng.normal(0, 0.05, 3)
+        if adjustments:    # parameterAdjustCallback / dynamicParameterCallback between two loops; runningState asks adjustParameter in every loop until it is set
+            for ac, aname, avalue in adjustments:
+                if ac == c:
+                    assert w.adjust is None
+                    w.adjust = (aname, avalue)
+            from syropod_highlevel_controller_amd.params import PARAM_FIELD
+            ids = {v: k for k, v in PARAM_FIELD.items()}
+            out["adjust_request"].append(ids[w.adjust[0]] if w.adjust else 0)
+            out["adjust_value"].append(w.adjust[1] if w.adjust else 0.0)
         if over.get("gait_change") and c >= 160 and not gait_changed:   # gaitSelectionCallback at cycle 160; changeGait every loop until done
             out["gait_request"].append(1)
             if w.walk_state != STOPPED:
@@ -1254,11 +1324,15 @@ def run(name):
         out["phase"].append([leg.phase for leg in w.legs])
         out["state"].append([leg.state for leg in w.legs])
         out["walk_state"].append(w.walk_state)
+        if adjustments:
+            out["period"].append(w.period)
         out["velocity"].append([w.v[0], w.v[1], w.w])
         out["pose"].append(w.current_pose.as7())
         out["odometry"].append(w.odometry.as7())
     if morphology:
         over["morphology"] = morphology
+    if adjustments:
+        over["adjust"] = adjustments
     meta = dict(gait=gait, overrides={k: v for k, v in over.items()}, schedule=schedule, cycles=cycles, limits=limits, events=events, new_limits=meta_new_limits,
                 time_to_start=START_UP_TIME,
                 visited_walk_states=sorted(set(out["walk_state"])))
@@ -1270,7 +1344,12 @@ def run(name):
 
 if __name__ == "__main__":
     arrays, metas = {}, {}
-    for name in SCENARIOS:
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None
+    if only:            # regenerate the named scenarios only; every other array of the fixture stays byte for byte what it is
+        old = np.load(os.path.join(HERE, "walk_golden.npz"))
+        arrays = {k: old[k] for k in old.files if k.split("/", 1)[0] not in only}
+        metas = {k: v for k, v in json.load(open(os.path.join(HERE, "walk_golden_meta.json"))).items() if k not in only}
+    for name in (only or SCENARIOS):
         a, m = run(name)
         for k, v in a.items():
             arrays[f"{name}/{k}"] = v

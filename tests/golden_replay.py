@@ -195,7 +195,7 @@ def replay_walk(name, meta, tol_x=1e-9):
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs", "gait_change"):
+        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs", "gait_change", "adjust"):
             pass
         else:
             setattr(p, k, v)
@@ -234,6 +234,10 @@ def replay_walk(name, meta, tol_x=1e-9):
         if "gait_request" in g and g["gait_request"][c]:   # gait_change_flag_ set: changeGait runs every loop until the robot has stopped
             eng.change_gait(default_hexapod_params(meta["overrides"]["gait_change"]))
         eng.set_velocity(np.array(g["lin"][c], dtype=np.float64)[None], np.array([g["ang"][c]], dtype=np.float64))
+        if "adjust_request" in g and g["adjust_request"][c]:   # parameter_adjust_flag_ set: adjustParameter runs in every loop until the value is set (its decision reads
+            waiting = eng.adjust_parameter(int(g["adjust_request"][c]), float(g["adjust_value"][c]))   # this loop's velocity input); the fixture asks again exactly while it waits
+            last = c + 1 == meta["cycles"] or g["adjust_request"][c + 1] != g["adjust_request"][c] or g["adjust_value"][c + 1] != g["adjust_value"][c]
+            assert (waiting == 0) == bool(last), (name, c, waiting)
         if p.imu_posing or p.inclination_posing:
             eng.set_imu(np.array(g["imu_q"][c])[None], np.array(g["gyro"][c])[None])
         if p.admittance_control and not p.use_joint_effort:

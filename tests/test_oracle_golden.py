@@ -186,7 +186,7 @@ def test_walk_trajectories(name, meta):
     for k, v in meta["overrides"].items():
         if k == "velocity_input_mode":
             p.velocity_input_mode = VEL_REAL if v == "real" else 0
-        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs", "gait_change"):
+        elif k in ("n_auto_posers", "model", "morphology", "contacts", "efforts", "pose_inputs", "gait_change", "adjust"):
             pass  # (default_hexapod_params already carries auto_pose.yaml; "model": the scenario also carries joints)
         else:
             setattr(p, k, v)
@@ -228,6 +228,13 @@ def test_walk_trajectories(name, meta):
             L.orc_change_gait.argtypes = [C.c_void_p, C.c_void_p]
             L.orc_change_gait(r.h, C.byref(default_hexapod_params(meta["overrides"]["gait_change"])))
         r.set_velocity(float(g["lin"][c][0]), float(g["lin"][c][1]), float(g["ang"][c]))
+        if "adjust_request" in g:   # parameterAdjustCallback sets parameter_adjust_flag_; runningState serves it inside the loops (state_running_state) until it is set
+            L.orc_request_parameter_adjust.argtypes = [C.c_void_p, C.c_int, C.c_double]
+            L.orc_parameter_adjust_pending.argtypes = [C.c_void_p]
+            fresh = g["adjust_request"][c] and (c == 0 or g["adjust_request"][c - 1] != g["adjust_request"][c] or g["adjust_value"][c - 1] != g["adjust_value"][c])
+            if fresh:
+                L.orc_request_parameter_adjust(r.h, int(g["adjust_request"][c]), float(g["adjust_value"][c]))
+            assert bool(L.orc_parameter_adjust_pending(r.h)) == bool(g["adjust_request"][c]), (name, c)   # ... for exactly as many loops as the fixture's robot waited
         if p.imu_posing or p.inclination_posing:
             r.set_imu(g["imu_q"][c], g["gyro"][c])
         if p.admittance_control and not p.use_joint_effort:
