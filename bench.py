@@ -754,7 +754,7 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
     fused_value = None
     fused_k = None
     if cps == 1 and world == 1 and fused_probe:
-        fc, reps = 16, max(4, steps // 16)
+        fc, reps = 16, max(64, steps // 16)   # (64 launches of 16 cycles: 25 - 125 ms per workload - a steady-state figure like the 300+ single launches above)
         for _ in range(3):
             eng.step(fc)
         torch.cuda.synchronize()

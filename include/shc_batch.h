@@ -392,7 +392,10 @@ int shc_engine_get_step_k_joint_state(shc_engine *e, int k, double *q, double *q
  * opens every peer's buffer (shc_peer_open) and, after its last step, writes its shard into every buffer at its own offset:
  * shc_peer_scatter(device, shard, bytes, destinations, n, stream) - one copy per destination on a stream of its own (the N - 1 links of a GPU
  * carry N - 1 copies at once), ordered after `stream`, and `stream` ordered after them.  A barrier of the caller's - every rank's copies have
- * completed - closes the exchange.  shc_peer_close(device, ptr, opened): opened != 0 for a peer's buffer, 0 frees one's own.
+ * completed - closes the exchange.  Nothing orders an exchange after the peers' READS of the previous one: a rank that gathers again while another rank is
+ * still consuming its gathered buffer overwrites a slot under that reader, so a barrier of the caller's belongs BEFORE every exchange as well (or one
+ * gathered buffer per exchange in flight).  shc_peer_close(device, ptr, opened): opened != 0 for a peer's buffer, 0 frees one's own and releases the
+ * copy streams / events shc_peer_scatter keeps for that device.
  */
 int shc_peer_alloc(int device, int64_t bytes, void **device_ptr, unsigned char *handle64);
 int shc_peer_open(int device, const unsigned char *handle64, void **device_ptr);

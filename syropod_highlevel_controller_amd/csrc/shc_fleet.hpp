@@ -411,11 +411,30 @@ extern "C" int shc_peer_open(int device, const unsigned char *handle64, void **d
   HIP_TRY(hipIpcOpenMemHandle(device_ptr, h, hipIpcMemLazyEnablePeerAccess));
   return SHC_OK;
 }
+// the copy streams / events shc_peer_scatter keeps per device: released when the rank frees its own gathered buffer (the exchange's lifetime)
+static void peer_pool_release(int device) {
+  if (device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lock(g_peer_mutex);
+  PeerPool &pool = g_peer_pool[device];
+  for (size_t k = 0; k < pool.streams.size(); ++k) {
+    (void)hipStreamSynchronize(pool.streams[k]);
+    (void)hipEventDestroy(pool.done[k]);
+    (void)hipStreamDestroy(pool.streams[k]);
+  }
+  pool.streams.clear();
+  pool.done.clear();
+  if (pool.start) (void)hipEventDestroy(pool.start);
+  pool.start = nullptr;
+}
 extern "C" int shc_peer_close(int device, void *device_ptr, int opened) {
   if (!device_ptr) return SHC_OK;
   HIP_TRY(hipSetDevice(device));
-  if (opened) HIP_TRY(hipIpcCloseMemHandle(device_ptr));
-  else HIP_TRY(hipFree(device_ptr));
+  if (opened) {
+    HIP_TRY(hipIpcCloseMemHandle(device_ptr));
+  } else {
+    peer_pool_release(device);
+    HIP_TRY(hipFree(device_ptr));
+  }
   return SHC_OK;
 }
 // src (this device) -> dst[k] for k < n_dst, each copy on a stream of its own; ordered after `stream`, and `stream` is ordered after all of them

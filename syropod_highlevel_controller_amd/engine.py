@@ -216,15 +216,40 @@ def _share_torch_hip_runtime():
     `import torch` finds its runtime already in place.  SHC_OWN_HIP_RUNTIME=1 keeps /opt/rocm's (a process that never imports torch)."""
     if "torch" in sys.modules or os.environ.get("SHC_OWN_HIP_RUNTIME"):
         return
+    import warnings
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
-        if spec and spec.submodule_search_locations:
-            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-            if os.path.exists(cand):
-                C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except Exception:  # noqa: BLE001 - no torch, or a wheel laid out differently: /opt/rocm's runtime it is
-        pass
+        if not (spec and spec.submodule_search_locations):
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if not os.path.exists(cand):
+            return
+        # The library is linked against /opt/rocm's runtime by SONAME: only a bundled runtime of the SAME SONAME can stand in for it (a different one would be
+        # loaded next to it - two runtimes after all), and code objects built by one ROCm release are run by the other's runtime only within that ABI.
+        needed, bundled = _elf_soname(_SO, b"libamdhip64.so", needed=True), _elf_soname(cand, b"libamdhip64.so", needed=False)
+        if needed and bundled and needed != bundled:
+            warnings.warn(f"torch bundles HIP runtime {bundled} but libshc_batch.so is linked against {needed}: not pre-loading torch's runtime "
+                          "(import torch BEFORE the engine in a process that needs both, or set SHC_OWN_HIP_RUNTIME=1 to silence this)")
+            return
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        if os.environ.get("SHC_VERBOSE"):
+            print(f"[shc] HIP runtime shared with torch: {cand} ({bundled or 'SONAME unknown'})", file=sys.stderr)
+    except OSError as exc:  # the bundled runtime would not load: /opt/rocm's it is, and a later `import torch` may then find no device - say so
+        warnings.warn(f"could not pre-load torch's bundled HIP runtime ({exc}); import torch before the engine if this process uses both")
+
+
+def _elf_soname(path: str, stem: bytes, needed: bool):
+    """The `stem`.N string an ELF file names - its DT_NEEDED entry (needed=True) or its own DT_SONAME; found by scanning the dynamic string table's bytes
+    (no ELF parser in the image: both are NUL-terminated strings that start with the stem).  None when nothing matches."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    names = sorted(set(m.group(0).decode() for m in re.finditer(re.escape(stem) + rb"(\.\d+)+(?=\x00)", blob)))
+    return names[0] if names else None
 
 
 def lib():

@@ -63,7 +63,9 @@ class PeerAllGather:
     """The same exchange as `all_gather_joints`, as peer copies over xGMI instead of a collective (include/shc_batch.h: shc_peer_*): every rank
     owns a gathered buffer [world][shard], exports it, opens its peers' and, per exchange, writes its shard into every buffer at its own offset -
     world - 1 copies on world - 1 streams (one per xGMI link) + the local one.  `barrier` (a callable every rank enters, e.g. bench.py's
-    HostSpinBarrier or torch.distributed.barrier) closes an exchange: when it returns on a rank, that rank's buffer holds every shard.
+    HostSpinBarrier or torch.distributed.barrier) closes an exchange: when it returns on a rank, that rank's buffer holds every shard.  The same kind of barrier must also PRECEDE
+    every exchange but the first (`pre_barrier`): a rank's copies land in its peers' buffers, and nothing else tells it that the peers have finished reading
+    what the previous exchange left there.
     torch.distributed (any backend) is only used once, to exchange the 64-byte handles."""
 
     def __init__(self, shard_numel: int, world: int, rank: int, device: int):
@@ -95,9 +97,12 @@ class PeerAllGather:
             __cuda_array_interface__ = {"shape": (world * int(shard_numel),), "typestr": "<f8", "data": (self.own, False), "version": 2}
         self.out = torch.as_tensor(_View(), device=f"cuda:{device}")
 
-    def gather(self, local, stream: int, barrier=None):
-        """local: this rank's shard (contiguous float64 device tensor); the copies are ordered after `stream` and `stream` after them."""
+    def gather(self, local, stream: int, barrier=None, pre_barrier=None):
+        """local: this rank's shard (contiguous float64 device tensor); the copies are ordered after `stream` and `stream` after them.
+        pre_barrier: entered first - every rank has finished with the buffers of the previous exchange."""
         from . import engine as _engine
+        if pre_barrier is not None:
+            pre_barrier()
         _engine._check(self.L.shc_peer_scatter(self.device, self.C.c_void_p(local.data_ptr()), self.shard_bytes, self.dst, self.world, self.C.c_void_p(stream)), "shc_peer_scatter")
         if barrier is not None:
             import torch
