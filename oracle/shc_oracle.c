@@ -2789,6 +2789,7 @@ static void walker_update_manual_velocity(orc_robot *r);
 static void walker_update_manual_pose(orc_robot *r);
 int orc_adjust_parameter(orc_robot *r, int which, double value);
 void orc_adjust_parameter_commit(orc_robot *r, int which);
+void orc_request_parameter_adjust(orc_robot *r, int which, double value);
 static void state_running_state(orc_robot *r)
 {
   /* "Dynamically adjust parameters" (:411-414): after the posing part of this loop, before updateWalk */
@@ -3498,6 +3499,13 @@ int64_t orc_batch_change_gait(orc_batch *b, const shc_params *np)
 /* the batch's decision: every robot probes (each takes the side effects of a pending change), all commit only when all may */
 int64_t orc_batch_adjust_parameter(orc_batch *b, int which, double value)
 {
+  if (which != 1)
+  { /* nothing to decide: every robot serves the request inside its next loop, where adjustParameter stands (the posing part of that loop - admittance,
+     * dynamic stiffness - still reads the old value, updateWalk / updateModel the new one) */
+    if (!adjustable_field(&b->robots[0].params, which)) return -1;
+    for (int64_t i = 0; i < b->n; ++i) orc_request_parameter_adjust(&b->robots[i], which, value);
+    return 0;
+  }
   int64_t waiting = 0;
   for (int64_t i = 0; i < b->n; ++i)
   {

@@ -99,6 +99,10 @@ struct CycleParams {
   // admittance: 30 RK4 steps of x'' = -F/m - c/m x' - k/m x collapsed into x <- M x + g F
   double adm_m00, adm_m01, adm_m10, adm_m11, adm_g0, adm_g1;
   double force_gain, virtual_stiffness, swing_stiffness_scaler, load_stiffness_scaler;
+  // The posing part of a loop (updateStiffness / updateAdmittance, state_controller.cpp:170-180) runs BEFORE runningState's adjustParameter: in the loop that
+  // sets a new force gain or swing height it still reads the old one, the rest of that loop the new one.  These two are what the posing part reads (equal to
+  // force_gain / swing_height except in that one cycle; virtual_stiffness and the admittance map above are read by the posing part only).
+  double pose_force_gain, pose_swing_height;
   // auto pose (pose_controller.cpp:44-106)
   int32_t n_auto_posers, pose_phase_length, pose_sync, auto_pose_reference_leg;
   // ---- tail staged to LDS only by kernels with auto posing (16-byte aligned start)
@@ -899,7 +903,7 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
 template <int NJ, typename IN>
 __device__ __forceinline__ void cycle_admittance(LegRegs<NJ> &s, LegOut &out, const CycleParams &P, const IN &in) {
   const V3 force_in = in.force(); // tip_force_measured_
-  V3 f = (P.use_joint_effort ? s.tf : force_in) * P.force_gain;
+  V3 f = (P.use_joint_effort ? s.tf : force_in) * P.pose_force_gain;
   double fi[3] = {f.x, f.y, f.z}, d[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -1018,7 +1022,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
     if (uni(P.dynamic_stiffness) && walk_state != WS_STOPPED) { // state_controller.cpp:175 (walk state before updateWalk)
       const bool swing = (s.word & 3) == SS_SWING;
       const double k = P.virtual_stiffness;
-      const double ref = fabs((s.tip.z - pk.get3(PK_DFLT).z) / P.swing_height);
+      const double ref = fabs((s.tip.z - pk.get3(PK_DFLT).z) / P.pose_swing_height);
       const double load = swing ? k * (ref * (P.load_stiffness_scaler - 1)) : 0.0;
       double v = swing ? k * (ref * (P.swing_stiffness_scaler - 1) + 1) : k;
       const int lo = leg == 0 ? L - 1 : leg - 1, hi = leg == L - 1 ? 0 : leg + 1;

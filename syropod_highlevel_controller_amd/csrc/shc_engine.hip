@@ -271,6 +271,7 @@ struct shc_engine {
   int half_steps = 0;                   // CycleLaunch::half_steps (development switch SHC_ROT_SPLIT = 0 / 1: never / always; unset: by launch size)
   bool span_dirty = true;
   bool step_remap_pending = false;      // an accepted step-frequency change waits for the next cycle (shc_engine_adjust_parameter)
+  bool pose_params_held = false;        // the posing part of the next cycle still runs on the parameter values a just-adjusted parameter had (ditto)
   bool fresh_pose_controller = false;   // init_state for shc_engine_begin_sequence_startup: no direct start-up has run, the auto posers have not been called yet
   struct Resident *res = nullptr;       // resident mode (shc_resident.hpp)
   const double *bound_inputs[kBoundSets][BND_COUNT] = {}; // shc_engine_resident_bind_inputs: the caller's device arrays for direct posts
@@ -452,7 +453,8 @@ static void build_cycle_params(const shc_params &p, const shc_tables &t, uint32_
   c.pid_i = p.rotation_pid_gains[1];
   c.pid_d = p.rotation_pid_gains[2];
   hostinit::admittance_map(p, c.adm_m00, c.adm_m01, c.adm_m10, c.adm_m11, c.adm_g0, c.adm_g1);
-  c.force_gain = p.force_gain;
+  c.force_gain = c.pose_force_gain = p.force_gain;
+  c.pose_swing_height = p.swing_height;
   c.virtual_stiffness = p.virtual_stiffness;
   c.swing_stiffness_scaler = p.swing_stiffness_scaler;
   c.load_stiffness_scaler = p.load_stiffness_scaler;
@@ -1329,16 +1331,19 @@ extern "C" int shc_engine_step(shc_engine *e, int n_cycles) {
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
   if (n_cycles < 1) return SHC_OK;
   HIP_TRY(hipSetDevice(e->device));
-  if (e->step_remap_pending && !(e->rt_flags & (RT_SKIP_MARKED | RT_POSE_MARKED))) {
-    // the loop in which adjustParameter accepted a new step frequency: its cycle maps the phases of walking robots onto the new step cycle between the
-    // posing part and updateWalk (cycle_front; the uploaded constants carry remap_old_period) - on the runtime-flag kernels, alone in its launch
-    e->step_remap_pending = false;
+  if ((e->step_remap_pending || e->pose_params_held) && !(e->rt_flags & (RT_SKIP_MARKED | RT_POSE_MARKED))) {
+    // The loop in which adjustParameter set a new value (state_controller.cpp:411-414, after the posing part of that loop, before updateWalk): its cycle runs
+    // alone in its launch on a parameter block of its own - the posing part still on the old force gain / virtual spring / swing height (pose_params_held),
+    // the phases of walking robots mapped onto a new step cycle between the posing part and updateWalk (step_remap_pending: cycle_front, on the
+    // runtime-flag kernels) - and the plain block of the new values follows it.
+    const bool remap = e->step_remap_pending;
+    e->step_remap_pending = e->pose_params_held = false;
     const uint32_t keep = e->features;
-    e->features |= SHC_FEAT_GENERIC_KERNEL;
+    if (remap) e->features |= SHC_FEAT_GENERIC_KERNEL;
     int rc = shc_engine_step(e, 1);
     e->features = keep;
     if (rc == SHC_OK) rc = join_side(e);
-    e->cp.remap_old_period = 0;
+    build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
     if (rc == SHC_OK) rc = upload_consts(e); // (ordered behind the cycle above on the engine's stream, and synchronises it)
     if (rc != SHC_OK || n_cycles == 1) return rc;
     --n_cycles;
@@ -1554,8 +1559,13 @@ __global__ void step_remap_kernel(int32_t *legi, const int32_t *robi, int rpw, i
   legi[slot_of(rob, leg, L)] = (w & ~(3 | (LW_PHASE_MASK << LW_PHASE_SHIFT))) | st | (ph << LW_PHASE_SHIFT);
 }
 static int flush_step_remap(shc_engine *e) {
-  if (!e->step_remap_pending) return SHC_OK;
-  e->step_remap_pending = false;
+  if (!e->step_remap_pending) {
+    if (!e->pose_params_held) return SHC_OK;
+    e->pose_params_held = false; // (the next cycle is not a shc_engine_step: the new values are in force for all of it)
+    build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
+    return upload_consts(e);
+  }
+  e->step_remap_pending = e->pose_params_held = false;
   HIP_TRY(hipSetDevice(e->device));
   {
     const int rc = join_side(e);
@@ -1566,7 +1576,7 @@ static int flush_step_remap(shc_engine *e) {
   step_remap_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, e->stream>>>(e->st.legi, e->st.robi, 64 / e->L, e->n, e->L, e->cp.remap_old_period, s.period,
                                                                                        s.swing_start, s.swing_end, s.stance_end, s.stance_start);
   HIP_TRY(hipGetLastError());
-  e->cp.remap_old_period = 0;
+  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   return upload_consts(e);
 }
 
@@ -1653,7 +1663,15 @@ static int adjust_step_frequency(shc_engine *e, double value, int64_t *pending) 
     e->tables.max_linear_acceleration[b] = tn.max_linear_acceleration[b];
     e->tables.max_angular_acceleration[b] = tn.max_angular_acceleration[b];
   }
-  build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
+  {
+    const CycleParams before = e->cp;
+    build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
+    if (e->pose_params_held) { // (a direct parameter was adjusted since the last cycle: its old value still belongs to the next cycle's posing part)
+      e->cp.adm_m00 = before.adm_m00, e->cp.adm_m01 = before.adm_m01, e->cp.adm_m10 = before.adm_m10, e->cp.adm_m11 = before.adm_m11;
+      e->cp.adm_g0 = before.adm_g0, e->cp.adm_g1 = before.adm_g1;
+      e->cp.virtual_stiffness = before.virtual_stiffness, e->cp.pose_force_gain = before.pose_force_gain, e->cp.pose_swing_height = before.pose_swing_height;
+    }
+  }
   e->cp.remap_old_period = old_period; // generateStepCycle's updatePhase for MOVING robots: inside the next cycle (shc_engine_step)
   e->step_remap_pending = true;
   return upload_consts(e);
@@ -1686,9 +1704,20 @@ extern "C" int shc_engine_adjust_parameter(shc_engine *e, int which, double valu
   }
   // The eight parameters the control cycle reads as they are (params_.*.current_value): a new launch-uniform block, in force from the next cycle; no table is
   // regenerated and no state is touched.
-  const int keep_remap = e->cp.remap_old_period;
+  // ... except where the POSING part of the loop reads them (updateStiffness / updateAdmittance run before runningState, state_controller.cpp:170-180): the
+  // virtual spring's constants, the force gain as the admittance input scales it and the swing height as the dynamic-stiffness reference divides by it stay
+  // what they were for the posing part of the next cycle (the tip-force estimate and the stepper of that same cycle use the new values), then follow.
+  const CycleParams before = e->cp;
   build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
-  e->cp.remap_old_period = keep_remap;
+  e->cp.remap_old_period = before.remap_old_period;
+  e->cp.adm_m00 = before.adm_m00, e->cp.adm_m01 = before.adm_m01, e->cp.adm_m10 = before.adm_m10, e->cp.adm_m11 = before.adm_m11;
+  e->cp.adm_g0 = before.adm_g0, e->cp.adm_g1 = before.adm_g1;
+  e->cp.virtual_stiffness = before.virtual_stiffness;
+  e->cp.pose_force_gain = before.pose_force_gain;
+  e->cp.pose_swing_height = before.pose_swing_height;
+  if (which == SHC_PARAM_SWING_HEIGHT || which == SHC_PARAM_VIRTUAL_MASS || which == SHC_PARAM_VIRTUAL_STIFFNESS || which == SHC_PARAM_VIRTUAL_DAMPING ||
+      which == SHC_PARAM_FORCE_GAIN)
+    e->pose_params_held = true;
   return upload_consts(e);
 }
 
