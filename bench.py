@@ -567,6 +567,28 @@ def run_workload(name, n, steps, warmup, cps, seed, dist_ctx=None, gather_every=
             if host_barrier.slots is None:   # (no shared page, or the spin barrier gave up: the collective library's barrier)
                 dist.barrier()
 
+    if mode == "step_k":   # K = 16 control cycles per launch, each with its own input row (shc_engine_step_k), as the measured form: a step is still ONE control cycle
+        if use_dist:
+            raise SystemExit("--mode step_k is a single-GPU form here")
+        K = 16
+        for _ in range(warmup):
+            step_once()
+        fk = fused_k_probe(eng, p, n, lin, ang, extra, key, stream, K=K, reps=max(4, steps // K), want_parity=want_parity)
+        q, _ = eng.joints()
+        finite = bool(np.isfinite(q).all())
+        eng.close()
+        nm = name + ("+efforts" if joint_efforts else "") + ":stepk"
+        roof = dict(fk["roofline"], traffic=measured_traffic(nm, n, K))
+        roof = with_issue_side(roof, measured_valu(nm, n, K), fk["ms_per_launch"] * 1e-3)
+        res = {"value": fk["value"], "elapsed": fk["launches"] * K * fk["ms_per_cycle"] * 1e-3, "ms_per_step": fk["ms_per_cycle"], "parity": fk["parity"], "host_issue_ms_per_step": None,
+               "config": {"workload": f"BASELINE.json {name}: {n} {desc}", "instances_per_gpu": n, "cycles_per_step": 1, "legs": p.leg_count, "dof": p.leg_dof[0], "seed": seed,
+                          "mode": f"shc_engine_step_k: {K} control cycles per launch, a new input set in every cycle ({', '.join(fk['inputs_per_cycle'])}); {fk['launches']} launches timed",
+                          "mode_short": f"step_k: {K} cycles per launch, new inputs every cycle", "gather_short": "none (N = 1)", "gather": "none", "moving_fraction": moving_frac,
+                          "finite": finite, "K": K, "launches": fk["launches"], "ms_per_launch": fk["ms_per_launch"], "two_stream_split": n_waves >= 4096},
+               "roofline": roof}
+        if want_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(p, lin, ang, extra)
+        return res
     # resident mode: batches that fit the chip once, one cycle per step, nothing that needs a launch between steps
     resident = False
     if use_dist and mode == "auto":
@@ -1118,8 +1140,20 @@ def compact_line(full):
     return line
 
 
+def flush_c_stdio():
+    """The collective library prints its version banner with C stdio, which a pipe buffers until the process exits - i.e. AFTER anything Python has printed.
+    Flushing the C streams first keeps the JSON line the last line of stdout."""
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001
+        pass
+
+
 def emit(full):
     """Full record -> bench_details.json (next to bench.py, and under gpurun_out/ when that exists) and stderr; compact record -> the LAST stdout line."""
+    flush_c_stdio()
     text = json.dumps(full)
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
@@ -1167,10 +1201,12 @@ def also_record(name, r, efforts=False):
            "fused_K_with_per_cycle_inputs": fk or None, "launch": {"value": r["value"], "ms_per_step": r["ms_per_step"], "roofline": r["roofline"], "parity": r["parity"]}}
     if fk.get("value") and not fk.get("error"):
         # batches that do not fit the chip once: K cycles per launch, a new input set in every cycle (shc_engine_step_k), is the form a node would run them in;
-        # the one-launch-per-cycle figure is the secondary one.  traffic / valu_issue_frac come from PMC passes of the one-launch-per-cycle kernels.
+        # the one-launch-per-cycle figure is the secondary one (launch_value / launch_frac / launch_traffic_ratio).
         roof = dict(fk["roofline"])
-        roof["traffic"] = None
-        roof["valu_issue_frac"] = r["roofline"].get("valu_issue_frac")
+        nm = name + ("+efforts" if efforts else "") + ":stepk"
+        roof["traffic"] = measured_traffic(nm, cfg["instances_per_gpu"], fk["K"])       # PMC passes of the batch kernel itself (profiles/traffic.json), else null
+        roof = with_issue_side(roof, measured_valu(nm, cfg["instances_per_gpu"], fk["K"]), fk["ms_per_launch"] * 1e-3)
+        roof.pop("bound_is", None)
         rec.update({"form": f"step_k K={fk['K']}", "value": fk["value"], "ms_per_step": fk["ms_per_cycle"], "roofline": roof, "parity": fk.get("parity") or r["parity"],
                     "launch_value": r["value"], "launch_frac": r["roofline"]["frac"],
                     "launch_traffic_ratio": (r["roofline"]["traffic"] / r["roofline"]["algorithmic_bytes_per_launch"]) if r["roofline"].get("traffic") else None})
@@ -1212,8 +1248,9 @@ def main(argv=None):
     ap.add_argument("--joint-efforts", action="store_true", help="supply measured joint torques: the tip-force estimate (Leg::calculateTipForce) is evaluated "
                     "every cycle (the default for config2, the headline; the other workloads are BASELINE.json's \"IK + Bezier\" / tip-state-message variants without it)")
     ap.add_argument("--no-joint-efforts", action="store_true", help="primary line without measured joint torques (Leg::calculateTipForce idle)")
-    ap.add_argument("--mode", choices=("auto", "resident", "launch"), default="auto",
-                    help="auto: resident mode where the batch fits the chip once (config 2), one launch per step otherwise")
+    ap.add_argument("--mode", choices=("auto", "resident", "launch", "step_k"), default="auto",
+                    help="auto: resident mode where the batch fits the chip once (config 2), one launch per step otherwise; step_k: 16 cycles per launch with a new "
+                         "input set in every cycle (shc_engine_step_k) as the timed form")
     ap.add_argument("--seed", type=int, default=0xC0FFEE)
     args = ap.parse_args(argv)
 
@@ -1308,6 +1345,11 @@ def main(argv=None):
                 also.append(r)
             except Exception as exc:  # noqa: BLE001
                 also.append({"workload": name, "short": SHORT[name], "error": str(exc)[:200]})
+    if use_dist:   # every rank: whatever the collective library printed goes out now, the process group ends, and only then rank 0 prints - its line stays the last one
+        flush_c_stdio()
+        dist.barrier()
+        dist.destroy_process_group()
+        flush_c_stdio()
     if rank == 0:
         cfg = res["config"]
         cfg["short"] = f"BASELINE.json {args.workload}: {n}/GPU {cfg['legs']}x{cfg['dof']}" + (" +joint torques" if "joint-effort" in cfg["workload"] else "")
@@ -1315,9 +1357,6 @@ def main(argv=None):
         if "cpu_baseline" in res:
             out["cpu_baseline"] = res["cpu_baseline"]
         emit(out)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
     return 0
 
 

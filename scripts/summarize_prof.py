@@ -58,6 +58,7 @@ def kernel_stats(dirn, out):
 
 PAIRS = False  # argv[4] == "pairs": a cycle = the walker-half launch + the model-half launch (shc_cycle_half_kernel<..., 1 / 2>), on each of the two
                # halves of the batch: durations and counters are summed over the two kernels, a step is two such pairs
+SHARDS = 1     # argv[4] == "shards:N": see __main__
 FLEET = False  # argv[4] == "fleet": a step = one launch of EACH morphology bin's kernel on concurrent streams; counters are summed over the bins
 
 
@@ -79,8 +80,8 @@ def pmc_fleet(dirn, kernel, out, label):
         for k, v in sorted(names.items()):
             bins = max(1, round(len(v) / fewest))   # two bins of the same (legs, longest DOF) run the same kernel: twice the dispatches
             out.write(f"{c:22s} {k[k.find('<'):k.find('>') + 1]:28s} {len(v):6d} {st.median(v):16.1f}" + (f"  x {bins} bins" if bins > 1 else "") + "\n")
-            total += st.median(v) * bins
-        out.write(f"{c:22s} {'sum over the bins':28s} {'':6s} {total:16.1f}\n")
+            total += st.median(v) * bins * SHARDS
+        out.write(f"{c:22s} {'sum over the bins' + (f' x {SHARDS} shards' if SHARDS > 1 else ''):28s} {'':6s} {total:16.1f}\n")
         res[c] = total
     return res
 
@@ -117,11 +118,15 @@ if __name__ == "__main__":
         RESIDENT_K = int(sys.argv[4].split(":")[1])
         KERNEL = "shc_resident"
     # large batches: a step is TWO launches (the halves of the batch on two streams, shc_engine_step): per-step bytes = 2 x per launch
-    FLEET = len(sys.argv) > 4 and sys.argv[4] == "fleet"   # (bins that share a device run as single launches: SHC_FEAT_SINGLE_STREAM, shc_fleet.hpp)
+    FLEET = len(sys.argv) > 4 and (sys.argv[4] == "fleet" or sys.argv[4].startswith("shards:"))   # (bins that share a device run as single launches: SHC_FEAT_SINGLE_STREAM, shc_fleet.hpp)
+    if len(sys.argv) > 4 and sys.argv[4].startswith("shards:"):   # N shards of ONE morphology on one device (bench.py --workload config4full): a step = N launches of the same kernel
+        SHARDS = int(sys.argv[4].split(":")[1])
+    if len(sys.argv) > 4 and sys.argv[4] in ("batch", "batch-split"):   # shc_engine_step_k: one launch (or one per half of a large batch) runs K cycles with their own inputs
+        KERNEL = "shc_batch_kernel"
     PAIRS = len(sys.argv) > 4 and sys.argv[4] == "pairs"
     if PAIRS:
         KERNEL = "shc_cycle_half_kernel"
-    per_step = 2 if len(sys.argv) > 4 and sys.argv[4] in ("split", "pairs") else 1
+    per_step = 2 if len(sys.argv) > 4 and sys.argv[4] in ("split", "pairs", "batch-split") else 1
     out = open(dest, "w")
     dur = kernel_stats(f"{prof}/trace", out)
     fetch = pmc(f"{prof}/pmc_fetch", KERNEL, out, "FETCH_SIZE pass").get("FETCH_SIZE")

@@ -45,3 +45,11 @@ def test_config4_at_its_stated_size_on_one_device():
     assert out["parity"]["instances"] == 128 and out["parity"]["max_abs_dq"] <= 1e-6
     det = json.load(open(os.path.join(ROOT, "bench_details.json")))["config"]
     assert det["gathered_buffer_bytes"] == (1 << 20) * 40 * 8 and det["gathered_buffer_matches_getter"] and det["finite"] and det["moving_fraction"] == 1.0
+
+
+@pytest.mark.timeout(1200)
+def test_rccl_path_keeps_the_json_line_last():
+    """One rank with the process group up (--force-dist: RCCL's all-gather in the timed region).  RCCL prints a version banner through C stdio, which a pipe
+    holds back until the process exits; bench.py flushes it before its own line, so the driver's "last line of stdout" is the JSON."""
+    out = run_bench("--gpus", "1", "--force-dist", "--workload", "config4", "--instances", "8192", "--steps", "10", "--warmup", "3", "--no-cpu-baseline")
+    assert out["n_gpus"] == 1 and out["config"]["gather_ms"] > 0 and out["config"]["gather_form"].startswith("RCCL")
