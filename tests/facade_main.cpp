@@ -86,6 +86,29 @@ int main(int argc, char **argv) {
     }
     return 0;
   }
+  if (argc > 6 && std::string(argv[6]) == "adjust") {
+    // StateController::adjustParameter through the facade, as runningState serves it (state_controller.cpp:411-414): a higher step frequency requested at
+    // loop 60 (asked again in every loop until it is set), a new swing height at loop 40; prints the loops the first one waited, then the joints
+    auto model = std::make_shared<Model>(engine);
+    auto walker = std::make_shared<WalkController>(engine);
+    bool parameter_adjust_flag = false;
+    int dynamic_parameter = 0, waited = 0;
+    double new_parameter_value = 0.0;
+    for (int c = 0; c < cycles; ++c) {
+      if (c == 40) parameter_adjust_flag = true, dynamic_parameter = SHC_PARAM_SWING_HEIGHT, new_parameter_value = 0.03;
+      if (c == 60) parameter_adjust_flag = true, dynamic_parameter = SHC_PARAM_STEP_FREQUENCY, new_parameter_value = atof(argv[7]);
+      if (parameter_adjust_flag) {
+        if (engine->adjustParameter(dynamic_parameter, new_parameter_value)) parameter_adjust_flag = false;
+        else ++waited;
+      }
+      walker->updateWalk(v, w);
+      model->updateModel();
+    }
+    printf("waited %d flag %d\n", waited, parameter_adjust_flag ? 1 : 0);
+    for (int l = 0; l < model->getLegCount(); ++l)
+      for (int j = 1; j <= model->getLegByIDNumber(l).getJointCount(); ++j) printf("%.17g\n", model->getLegByIDNumber(l).getJointByIDNumber(j).desired_position_);
+    return 0;
+  }
   auto model = std::make_shared<Model>(engine);
   auto walker = std::make_shared<WalkController>(engine);
   auto poser = std::make_shared<PoseController>(engine);

@@ -124,3 +124,35 @@ def test_facade_sequence_start_up_and_external_target(tmp_path):
     parity_report(f"[facade, free-running through the planner / manual-leg loops of a standing robot] model tip vs oracle: {d_plan:.2e} m after the plan, "
                   f"{d_manual:.2e} m after the manual leg moves")
     assert d_manual <= 1e-9, d_manual                                            # (placed by position input: no drift to speak of)
+
+
+def test_facade_adjust_parameter(tmp_path):
+    """Engine::adjustParameter as a node's runningState would call it: asked in every loop while parameter_adjust_flag_ is set.  The oracle serves the same
+    requests inside its loops (orc_request_parameter_adjust); the step-frequency change waits the same number of loops on both sides."""
+    so = engine.build_library()
+    exe = str(tmp_path / "facade_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "facade_main.cpp"),
+                           so, "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    p = default_hexapod_params("tripod")
+    pfile = str(tmp_path / "params.bin")
+    open(pfile, "wb").write(bytes(p))
+    cycles, v, freq = 260, (0.7, 0.2, 0.25), 0.7
+    out = subprocess.check_output([exe, pfile, str(cycles), *map(str, v), "adjust", str(freq)], text=True).split("\n")
+    waited, flag = int(out[0].split()[1]), int(out[0].split()[3])
+    q_gpu = np.array([float(x) for x in out[1:19]])
+    L = oracle_lib.lib()
+    L.orc_request_parameter_adjust.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.orc_parameter_adjust_pending.argtypes = [C.c_void_p]
+    r = OracleRobot(p)
+    r.set_velocity(*v)
+    waited_ref = 0
+    for c in range(cycles):
+        if c == 40:
+            L.orc_request_parameter_adjust(r.h, 2, 0.03)
+        if c == 60:
+            L.orc_request_parameter_adjust(r.h, 1, freq)
+        r.cycle(1)
+        waited_ref += int(L.orc_parameter_adjust_pending(r.h))
+    assert flag == 0 and waited == waited_ref and waited > 0, (waited, waited_ref, flag)
+    assert np.abs(r.joints()[0] - q_gpu).max() <= 1e-6
+    assert r.tables().step.period != OracleRobot(p).tables().step.period
