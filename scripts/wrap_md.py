@@ -1,6 +1,7 @@
 """Development aid: reflow a markdown file to a column limit (default 120).  Prose paragraphs, list items (hanging indent) and block quotes are re-wrapped;
 headings, code fences and tables whose rows fit stay as they are; a table with rows longer than `--table-limit` (default 360) cannot be wrapped as a table and
-is turned into a list - one item per row, "**first cell** - second cell - ..." with the header row as a legend line - which then wraps like any other list.
+is turned into a list - one item per row, "**first cell** - second cell - ..." with the header row as a legend line - which then wraps like any other list
+(tables of five or more columns are matrices of figures and stay tables whatever their width).
 usage: python scripts/wrap_md.py FILE [--width 120] [--table-limit 360] [--in-place]"""
 import re
 import sys
@@ -34,7 +35,7 @@ def wrap_block(text, width, first, rest):
     return textwrap.fill(" ".join(text.split()), width=width, initial_indent=first, subsequent_indent=rest, break_long_words=False, break_on_hyphens=False)
 
 
-def reflow(src, width=120, table_limit=360):
+def reflow(src, width=120, table_limit=360, matrix_columns=5):
     lines = src.split("\n")
     out, i, fence = [], 0, False
     item = re.compile(r"^(\s*)([*+-]|\d+[.)])\s+")
@@ -54,8 +55,8 @@ def reflow(src, width=120, table_limit=360):
             while j < len(lines) and lines[j].lstrip().startswith("|"):
                 j += 1
             table = lines[i:j]
-            if max(len(r) for r in table) <= table_limit:
-                out.extend(table)
+            if max(len(r) for r in table) <= table_limit or len(split_row(table[0])) >= matrix_columns:
+                out.extend(table)   # (a matrix of figures stays a table whatever its width: as a list it would lose its columns)
             else:
                 indent = re.match(r"^\s*", table[0]).group(0)
                 rows = [split_row(r) for r in table]
