@@ -344,6 +344,7 @@ struct LegRegs {
 // Stepper state that only the swing / stance branch touches is parked in a per-lane LDS strip between uses
 // (swing origin position / velocity, stance origin, default tip): 12 doubles = 24 VGPRs off the persistent set.
 enum : int { PK_SORG = 0, PK_SVEL = 3, PK_TORG = 6, PK_DFLT = 9, PK_COUNT = 12 };
+#ifndef SHC_PARK_REGS
 struct Park {
   double *d; // d[f * 64 + lane]
   int lane;
@@ -353,7 +354,20 @@ struct Park {
     d[(f + 1) * 64 + lane] = v.y;
     d[(f + 2) * 64 + lane] = v.z;
   }
+  __device__ __forceinline__ double at(int k) const { return d[k * 64 + lane]; }
+  __device__ __forceinline__ void set(int k, double v) const { d[k * 64 + lane] = v; }
 };
+#else // development variant (scripts/build_variant.py ... -- -DSHC_PARK_REGS): the strip in registers (AGPR copies at one wave per SIMD) instead of LDS
+struct Park {
+  double *d;
+  int lane;
+  mutable double r[12];
+  __device__ __forceinline__ V3 get3(int f) const { return V3{r[f], r[f + 1], r[f + 2]}; }
+  __device__ __forceinline__ void put3(int f, V3 v) const { r[f] = v.x, r[f + 1] = v.y, r[f + 2] = v.z; }
+  __device__ __forceinline__ double at(int k) const { return r[k]; }
+  __device__ __forceinline__ void set(int k, double v) const { r[k] = v; }
+};
+#endif
 
 // LegStepper::updateDefaultTipPosition with external_default_.defined_ (walk_controller.cpp:988-990): the requested stance pose,
 // moved with the robot since the request (pose_.removePose(transform_), pose.h:178-184), replaces the terrain-following default.

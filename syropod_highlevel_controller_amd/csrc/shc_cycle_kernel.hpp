@@ -94,7 +94,7 @@ __device__ __forceinline__ void load_leg_finish(LegRegs<NJ> &s, const Park &pk, 
   static_assert(FD::SVEL == FD::SORG + 3 && FD::TORG == FD::SORG + 6 && FD::DFLT == FD::SORG + 9, "park layout");
   if (ROLE != ROLE_BACK) {
 #pragma unroll
-    for (int k = 0; k < PK_COUNT; ++k) pk.d[k * 64 + pk.lane] = flat[FD::SORG + k];
+    for (int k = 0; k < PK_COUNT; ++k) pk.set(k, flat[FD::SORG + k]);
   }
   s.tip = V3{flat[FD::TIP + 0], flat[FD::TIP + 1], flat[FD::TIP + 2]};
   s.targ = V3{flat[FD::TARG + 0], flat[FD::TARG + 1], flat[FD::TARG + 2]};
@@ -132,7 +132,7 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
   flat[FD::TIP] = s.tip.x, flat[FD::TIP + 1] = s.tip.y, flat[FD::TIP + 2] = s.tip.z;
   flat[FD::TVEL] = s.tvel.x, flat[FD::TVEL + 1] = s.tvel.y, flat[FD::TVEL + 2] = s.tvel.z;
 #pragma unroll
-  for (int k = 0; k < PK_COUNT; ++k) flat[FD::SORG + k] = ROLE == ROLE_BACK ? 0.0 : pk.d[k * 64 + pk.lane];
+  for (int k = 0; k < PK_COUNT; ++k) flat[FD::SORG + k] = ROLE == ROLE_BACK ? 0.0 : pk.at(k);
   flat[FD::TARG] = s.targ.x, flat[FD::TARG + 1] = s.targ.y, flat[FD::TARG + 2] = s.targ.z;
   flat[FD::STRD] = s.strd.x, flat[FD::STRD + 1] = s.strd.y, flat[FD::STRD + 2] = s.strd.z;
   // swing origin position / velocity and stance origin / default tip change once per step period: their planes are

@@ -1530,6 +1530,7 @@ extern "C" int shc_engine_change_gait(shc_engine *e, const shc_params *ng, int64
   e->params = p;
   e->tables = t;
   e->span_dirty = true;
+  e->step_remap_pending = e->pose_params_held = false; // (every robot is STOPPED: nothing is left of an adjustParameter in flight)
   build_cycle_params(e->params, e->tables, e->features, e->rt_flags, e->cp);
   if ((rc = upload_consts(e)) != SHC_OK) return rc;
   if (p.auto_posing) { // setAutoPoseParams builds fresh AutoPosers: their start / end checks are reset (pose_controller.cpp:39-61)
