@@ -162,7 +162,7 @@ def cpu_baseline(p, lin, ang, extra, target_seconds=12.0):
             "single_thread_value": n1 * c1 / t1}
 
 
-PARITY_INSTANCES = 64
+PARITY_INSTANCES = 256   # robots of the timed batch replayed on the oracle (and its perturbed twin) over the timed window
 
 
 class ParityWindow:

@@ -42,7 +42,7 @@ def test_config4_at_its_stated_size_on_one_device():
     cfg = out["config"]
     assert cfg["instances_per_gpu"] == 1 << 20 and cfg["legs"] == 8 and cfg["dof"] == 5
     assert out["value"] > 1e8 and cfg["gather_ms"] > 0
-    assert out["parity"]["instances"] == 128 and out["parity"]["max_abs_dq"] <= 1e-6
+    assert out["parity"]["instances"] == 512 and out["parity"]["max_abs_dq"] <= 1e-6
     det = json.load(open(os.path.join(ROOT, "bench_details.json")))["config"]
     assert det["gathered_buffer_bytes"] == (1 << 20) * 40 * 8 and det["gathered_buffer_matches_getter"] and det["finite"] and det["moving_fraction"] == 1.0
 

@@ -850,12 +850,19 @@ def test_full_size_config3_and_config4_properties(Engine):
         jmin = np.array([[p.joint[l][j].min for j in range(D)] for l in range(L)]).reshape(-1)
         jmax = np.array([[p.joint[l][j].max for j in range(D)] for l in range(L)]).reshape(-1)
         assert (q >= jmin - 1e-12).all() and (q <= jmax + 1e-12).all()
-        m = 64
-        ob = OracleBatch(p, m)
+        m = 512
+        ob, tw = OracleBatch(p, m), OracleBatch(p, m)
         apply(ob, {k: v[:m] for k, v in inp.items()})
+        apply(tw, {k: (v[:m] * (1 + 1e-13) if k in ("lin", "force") else v[:m]) for k, v in inp.items()})   # the perturbed twin: which REFERENCE trajectories are well-posed
         ob.step(horizon, 8)
-        assert np.abs(ob.joints()[0] - q[:m]).max() <= TOL_Q
+        tw.step(horizon, 8)
+        well = np.abs(ob.joints()[0] - tw.joints()[0]).max(axis=1) <= 1e-9
+        assert well.mean() >= 0.9, (name, well.mean())                    # (config 3's U(0, 20) N forces pin a few legs on their limits: header of this file)
+        assert np.abs(ob.joints()[0] - q[:m])[well].max() <= TOL_Q
         assert np.array_equal(ob.body_state()[2], eng.body_state()[2][:m])
+        from conftest import parity_report
+        parity_report(f"[full size {name}] {n} instances x {horizon} cycles: {m}-instance slice, well-posed {well.mean():.1%}, max |dq| = "
+                      f"{np.abs(ob.joints()[0] - q[:m])[well].max():.2e} rad over them, {np.abs(ob.joints()[0] - q[:m]).max():.2e} over all")
         eng.close()
 
 
@@ -864,9 +871,9 @@ def test_full_size_config4_at_its_stated_size(Engine):
     """BASELINE.json configs[3] at its STATED size on one device: 2^20 synthetic octopods (8 x 5, ripple) in ONE engine (~3 GB of state; the job shards
     them over eight GPUs, 131 072 each - the sharded form at this size runs in tests/test_gpu_bench_launch.py).  Size-independent properties over 60 cycles:
     identical inputs in two places of the batch give bit-identical joints wherever they land (first and last 4 096 instances, i.e. other halves of the
-    two-stream split, other XCDs), joints inside their limits, everything finite, every robot MOVING; a 64-instance slice of each end against the oracle."""
+    two-stream split, other XCDs), joints inside their limits, everything finite, every robot MOVING; a 512-instance slice of each end against the oracle."""
     p = synthetic_octopod_params("ripple", 5, 8)
-    n, horizon, dup, m = 1 << 20, 60, 4096, 64
+    n, horizon, dup, m = 1 << 20, 60, 4096, 512
     inp = make_inputs(p, n, 61)
     for k in inp:
         inp[k][-dup:] = inp[k][:dup]
