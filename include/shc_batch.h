@@ -162,7 +162,11 @@ enum {
   /* Diagnostic: launch every step as ONE kernel on the engine's stream even for batches large enough for the two-stream split
    * (see shc_engine_step).  Both produce identical bits. */
   SHC_FEAT_SINGLE_STREAM = 1 << 28,
-  SHC_FEAT_ALL = 0x0fffffff
+  /* Diagnostic: shc_engine_step_k runs its K cycles as K single launches (row k through the setters, one shc_engine_step, q / qd into slot k of the
+   * output ring) even where the configuration has a batch kernel - the form every configuration WITHOUT one takes (manual-leg kernels; the
+   * runtime-flag families unless the library was built with SHC_GENERIC_LOOP_FORMS=1).  Both produce identical bits (tests/test_gpu_step_k.py). */
+  SHC_FEAT_STEP_K_SERIAL = 1 << 27,
+  SHC_FEAT_ALL = 0x07ffffff
 };
 
 /*
@@ -379,8 +383,10 @@ int shc_engine_resident_end(shc_engine *e, int64_t *cycles_run);
  *   The result is bit-identical to K x { setters with row k; shc_engine_step(e, 1) } - state record and the q / qd of every cycle.
  *   shc_engine_get_step_k_joint_state(e, k, q, qd, on_device): q / qd [n][legs][dof] of cycle k (0 .. K - 1) of the latest launch
  *     (stream-ordered; the ring is overwritten by the next shc_engine_step_k).  shc_engine_get_joint_state returns cycle K - 1 as usual.
- * SHC_ERR_UNSUPPORTED: the configuration runs on a manual-leg kernel - a leg toggled, planner mode (use shc_engine_step).  1 <= K <= 4096, and
- * K x n x legs x dof x 16 B must stay below 2 GiB.
+ * Configurations without a batch kernel - a manual-leg kernel (a leg toggled, planner mode: manual inputs and the plan are held for the K cycles like
+ * the pose inputs) and, unless the library was built with SHC_GENERIC_LOOP_FORMS=1, the runtime-flag kernel families (any posing set other than
+ * default.yaml's / BASELINE config 3's) - run the same K cycles as K single launches inside the call: same results, same output ring, no launch saved.
+ * 1 <= K <= 4096, and K x n x legs x dof x 16 B must stay below 2 GiB.
  */
 int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_inputs *inputs);
 int shc_engine_get_step_k_joint_state(shc_engine *e, int k, double *q, double *qd, int on_device);

@@ -1,51 +1,93 @@
-// shc_cycle_inst.hip - the fused cycle kernels of ONE morphology (compile with -DSHC_INST_L=<legs> -DSHC_INST_NJ=<joints>):
-// libshc_batch.so links one object of this file per supported (legs, joints), built in parallel (engine.py build_library).
+// shc_cycle_inst.hip - the fused cycle kernels of ONE morphology (compile with -DSHC_INST_L=<legs> -DSHC_INST_NJ=<joints> -DSHC_INST_PART=<0|1>):
+// libshc_batch.so links two objects of this file per supported (legs, joints), built in parallel (engine.py build_library) -
+//   part 0: the launch forms (shc_cycle_kernel, the half kernels of rotation-constrained cycles) and the morphology's entry point shc_launch_cycle_L_NJ;
+//   part 1: the loop forms (shc_resident_kernel, shc_resident2_kernel, shc_batch_kernel) behind shc_launch_loop_L_NJ, which part 0 hands loop launches to.
+// Both parts compile the same dispatch (launch_cycle_feat: configuration -> kernel specialisation); each instantiates only its own kernels.
+// -DSHC_GENERIC_LOOP_FORMS=1 (engine.py: SHC_GENERIC_LOOP_FORMS=1 in the environment of the build) adds the loop forms of the runtime-flag (F_DYN) families
+// that the default build leaves out: their batch kernels (shc_engine_step_k then runs such a configuration as K single launches - same results, see
+// shc_resident.hpp) and the resident kernels of F_DYN with rough terrain / tip-align / tip rotations (resident_begin reports SHC_ERR_UNSUPPORTED).
 #include "shc_cycle_kernel.hpp"
 
-#if !defined(SHC_INST_L) || !defined(SHC_INST_NJ)
-#error "compile with -DSHC_INST_L=<legs> -DSHC_INST_NJ=<joints>"
+#if !defined(SHC_INST_L) || !defined(SHC_INST_NJ) || !defined(SHC_INST_PART)
+#error "compile with -DSHC_INST_L=<legs> -DSHC_INST_NJ=<joints> -DSHC_INST_PART=<0|1>"
+#endif
+#ifndef SHC_GENERIC_LOOP_FORMS
+#define SHC_GENERIC_LOOP_FORMS 0
 #endif
 
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <set>
+#include <tuple>
+
 namespace shc {
+
+// Development aid: SHC_KERNEL_LOG=<file> appends one line per kernel specialisation this process launches ("form legs joints features"), the
+// first time it is launched - which of the library's instantiations a test suite / a bench run actually exercises (scripts/kernels_used.py).
+static void note_kernel(const char *form, int legs, int joints, unsigned features) {
+  static const char *path = std::getenv("SHC_KERNEL_LOG");
+  if (!path) return;
+  static std::mutex mu;
+  static std::set<std::tuple<const char *, unsigned>> seen;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!seen.insert({form, features}).second) return;
+  if (FILE *f = std::fopen(path, "a")) {
+    std::fprintf(f, "%s %d %d %u\n", form, legs, joints, features);
+    std::fclose(f);
+  }
+}
+
+// Which loop forms a specialisation has in this build.  Manual legs: none (the ManualRobot records change under loop-level calls).  Runtime-flag
+// families: the plain one keeps its resident kernels; everything else of F_DYN is opt-in (SHC_GENERIC_LOOP_FORMS) - no test, bench line or fleet bin
+// selects them (SHC_KERNEL_LOG over the GPU suite), they are a quarter of the library's kernels and all of them carry scratch.
+template <unsigned F> constexpr bool kHasResident = (F & F_MLEGS) == 0 && (SHC_GENERIC_LOOP_FORMS || (F & F_DYN) == 0 || (F & (F_TERRAIN | F_ROT)) == 0);
+template <unsigned F> constexpr bool kHasBatch = (F & F_MLEGS) == 0 && (SHC_GENERIC_LOOP_FORMS || (F & F_DYN) == 0);
 
 template <int L, int NJ, unsigned F>
 static void launch_cycle(const CycleLaunch &a) {
   constexpr int RPW = 64 / L;
   constexpr size_t wave_bytes = size_t(RobotFields::COUNT * RPW + PK_COUNT * 64 + (RobotFields::I_COUNT * RPW + 1) / 2) * 8;
-  if (a.fit || a.resident) {
-    // Resident kernels: every specialisation but manual legs (the ManualRobot records change under loop-level calls; the tip-align pose of
-    // gravity_aligned_tips on <= 3-joint legs is per-robot state of the tile like any other and has had a loop form since round 5).
-    // Rough terrain and tip rotations run as ONE wavefront per robot group (Leg::applyIK feeds back into the stepper there - touchdown
-    // detection, the FK tip rotation - so the walker / model halves cannot be pipelined); everything else also has the two-wavefront form.
-    if constexpr ((F & F_MLEGS) == 0) {
-      constexpr bool two_wave = (F & (F_TERRAIN | F_ROT)) == 0;
-      if (a.fit) {
-        a.fit->supported = 1;
-        a.fit->two_wave = two_wave ? 1 : 0;
-        int blocks = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, shc_resident_kernel<L, NJ, F>, 64, wave_bytes) != hipSuccess) blocks = 0;
-        a.fit->blocks_per_cu = blocks;
-      } else if (a.resident->batch_cycles != 0) { // shc_engine_step_k: the batch form, a kernel of its own
-        shc_batch_kernel<L, NJ, F><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
-      } else if (a.block == 256) {
-        if constexpr (two_wave)
-          shc_resident2_kernel<L, NJ, F><<<dim3(a.grid), dim3(256), 2 * wave_bytes + sizeof(Resident2Lds<L, NJ>), a.stream>>>(
-              a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
-      } else {
-        shc_resident_kernel<L, NJ, F><<<dim3(a.grid), dim3(64), wave_bytes, a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
-      }
-    } else if (a.fit) {
-      a.fit->supported = 0;
-      a.fit->blocks_per_cu = 0;
-      a.fit->two_wave = 0;
+#if SHC_INST_PART == 1
+  // Resident kernels: every specialisation but manual legs (the tip-align pose of gravity_aligned_tips on <= 3-joint legs is per-robot state of the
+  // tile like any other and has had a loop form since round 5).  Rough terrain and tip rotations run as ONE wavefront per robot group (Leg::applyIK
+  // feeds back into the stepper there - touchdown detection, the FK tip rotation - so the walker / model halves cannot be pipelined); everything else
+  // also has the two-wavefront form.
+  constexpr bool two_wave = (F & (F_TERRAIN | F_ROT)) == 0;
+  if (a.fit) {
+    a.fit->supported = kHasResident<F> ? 1 : 0;
+    a.fit->batch = kHasBatch<F> ? 1 : 0;
+    a.fit->two_wave = kHasResident<F> && two_wave ? 1 : 0;
+    a.fit->blocks_per_cu = 0;
+    if constexpr (kHasResident<F>) {
+      int blocks = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, shc_resident_kernel<L, NJ, F>, 64, wave_bytes) != hipSuccess) blocks = 0;
+      a.fit->blocks_per_cu = blocks;
     }
-    return;
+  } else if (a.resident->batch_cycles != 0) { // shc_engine_step_k: the batch form, a kernel of its own
+    if constexpr (kHasBatch<F>) {
+      note_kernel("batch", L, NJ, F);
+      shc_batch_kernel<L, NJ, F><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
+    }
+  } else if (a.block == 256) {
+    if constexpr (kHasResident<F> && two_wave) {
+      note_kernel("resident2", L, NJ, F);
+      shc_resident2_kernel<L, NJ, F><<<dim3(a.grid), dim3(256), 2 * wave_bytes + sizeof(Resident2Lds<L, NJ>), a.stream>>>(
+          a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
+    }
+  } else {
+    if constexpr (kHasResident<F>) {
+      note_kernel("resident", L, NJ, F);
+      shc_resident_kernel<L, NJ, F><<<dim3(a.grid), dim3(64), wave_bytes, a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, *a.resident, a.rt_flags);
+    }
   }
+#else
   // Rotation-constrained cycles of the feature-exact kernels: one cycle = the walker / poser launch + the model launch (two wavefronts per SIMD
   // each instead of one) once the launch holds at least two wavefronts for every SIMD of the chip; smaller launches stay one kernel.
   if constexpr ((F & F_ROT) != 0 && (F & (F_DYN | F_TERRAIN | F_MLEGS | F_AUTO)) == 0) {
     const int64_t waves = int64_t(a.grid) * (a.block / 64);
     if (a.half_steps >= 0 && (a.half_steps > 0 || waves >= 2048)) {
+      note_kernel("half", L, NJ, F);
       for (int c = 0; c < a.n_cycles; ++c) {
         shc_cycle_half_kernel<L, NJ, F, ROLE_FRONT><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(
             a.st, (const SharedConsts<L, NJ> *)a.consts, a.rt_flags, a.wave0);
@@ -55,8 +97,10 @@ static void launch_cycle(const CycleLaunch &a) {
       return;
     }
   }
+  note_kernel("cycle", L, NJ, F);
   shc_cycle_kernel<L, NJ, F><<<dim3(a.grid), dim3(a.block), wave_bytes * (a.block / 64), a.stream>>>(a.st, (const SharedConsts<L, NJ> *)a.consts, a.n_cycles,
                                                                                               a.rt_flags, a.wave0);
+#endif
 }
 
 // Pick the kernel specialisation: the BASELINE.json configurations get feature-exact kernels (dead features cost
@@ -159,10 +203,20 @@ static void launch_cycle_feat(const CycleLaunch &a) {
 
 #define SHC_CAT3(a, b, c) a##b##_##c
 #define SHC_LAUNCHER_NAME(L_, NJ_) SHC_CAT3(shc_launch_cycle_, L_, NJ_)
+#define SHC_LOOP_LAUNCHER_NAME(L_, NJ_) SHC_CAT3(shc_launch_loop_, L_, NJ_)
+// feature-exact kernels for the BASELINE.json morphologies: default.yaml hexapods (6 x 3) and the synthetic octopods (8 x 5)
+constexpr bool kSpecMorphology = (SHC_INST_L == 6 && SHC_INST_NJ == 3) || (SHC_INST_L == 8 && SHC_INST_NJ == 5);
+#if SHC_INST_PART == 1
+void SHC_LOOP_LAUNCHER_NAME(SHC_INST_L, SHC_INST_NJ)(const CycleLaunch &a) { launch_cycle_feat<SHC_INST_L, SHC_INST_NJ, kSpecMorphology>(a); }
+#else
+void SHC_LOOP_LAUNCHER_NAME(SHC_INST_L, SHC_INST_NJ)(const CycleLaunch &a);
 void SHC_LAUNCHER_NAME(SHC_INST_L, SHC_INST_NJ)(const CycleLaunch &a) {
-  // feature-exact kernels for the BASELINE.json morphologies: default.yaml hexapods (6 x 3) and the synthetic octopods (8 x 5)
-  constexpr bool spec = (SHC_INST_L == 6 && SHC_INST_NJ == 3) || (SHC_INST_L == 8 && SHC_INST_NJ == 5);
-  launch_cycle_feat<SHC_INST_L, SHC_INST_NJ, spec>(a);
+  if (a.fit || a.resident) { // a loop form (or the question whether there is one): the other object of this morphology
+    SHC_LOOP_LAUNCHER_NAME(SHC_INST_L, SHC_INST_NJ)(a);
+    return;
+  }
+  launch_cycle_feat<SHC_INST_L, SHC_INST_NJ, kSpecMorphology>(a);
 }
+#endif
 
 } // namespace shc

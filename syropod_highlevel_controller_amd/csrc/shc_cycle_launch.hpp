@@ -101,6 +101,7 @@ struct ResidentFit {
   int supported;          // this specialisation has a resident kernel
   int blocks_per_cu;      // hipOccupancyMaxActiveBlocksPerMultiprocessor of it (64-thread blocks with its per-wave LDS)
   int two_wave;           // the two-wavefront pipeline exists for it (256-thread blocks, at most one per compute unit)
+  int batch;              // the batch form (shc_engine_step_k's kernel) exists for it; without one step_k runs the K cycles as single launches
 };
 
 // One per (legs, joints); defined by shc_cycle_inst.hip.  Returns false when that morphology has no kernels in this build.

@@ -212,7 +212,7 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
     if (rc != SHC_OK) return rc;
   }
   // does this configuration have a resident kernel, and does the whole batch fit the chip at once (+ the relay block)?
-  ResidentFit fit{0, 0, 0};
+  ResidentFit fit{0, 0, 0, 0};
   {
     CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, 0, 64, 0, nullptr, &fit, 0};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
@@ -220,7 +220,10 @@ extern "C" int shc_engine_resident_begin(shc_engine *e, int ring_depth, int64_t 
 #undef CALL
   }
   if (!fit.supported)
-    return fail(SHC_ERR_UNSUPPORTED, "resident mode: this configuration runs on a manual-leg kernel (a leg has been toggled / planner mode), which has no resident form");
+    return fail(SHC_ERR_UNSUPPORTED, (e->rt_flags & RT_MANUAL_LEGS)
+                                         ? "resident mode: this configuration runs on a manual-leg kernel (a leg has been toggled / planner mode), which has no resident form"
+                                         : "resident mode: this configuration runs on a runtime-flag kernel with rough terrain / tip-align / tip-rotation logic, whose resident "
+                                           "form is not part of this build (SHC_GENERIC_LOOP_FORMS=1 builds it); use shc_engine_step or shc_engine_step_k");
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, e->device));
   // ... less one compute unit's worth per XCD (workgroups are dealt round-robin to the 8 XCDs and placed only inside their own): the loop's
@@ -712,6 +715,30 @@ static int step_k_out_ring(shc_engine *e, int K) {
   return SHC_OK;
 }
 
+// The configurations without a batch kernel - a manual-leg kernel (a leg has been toggled / planner mode: manual inputs and plans are held for the K
+// cycles like the pose inputs), the runtime-flag families in a build without SHC_GENERIC_LOOP_FORMS - run the K cycles as the caller's loop would:
+// row k of each K-deep array through its setter (which is what a direct post is defined against: test_step_k_is_byte_identical_to_single_launches),
+// one shc_engine_step, q / qd into slot k of the output ring.  Same results, K launches instead of one.
+__global__ void copy_joint_planes_kernel(double2 *dst, const double2 *src, int64_t count);
+static int step_k_serial(shc_engine *e, int K, const shc_cycle_inputs *in) {
+  const int64_t n = e->n, slot = int64_t(e->NJ) * e->n_slots; // double2 per ring slot: the planes that hold Q and QD (Fields: Q = 0, QD = NJ)
+  for (int k = 0; k < K; ++k) {
+    int rc = SHC_OK;
+    if (in && in->linear_xy) rc = shc_engine_set_velocity(e, in->linear_xy + k * n * 2, in->angular + k * n, 1);
+    if (rc == SHC_OK && in && in->imu_orientation_wxyz) rc = shc_engine_set_imu(e, in->imu_orientation_wxyz + k * n * 4, in->imu_angular_velocity + k * n * 3, 1);
+    if (rc == SHC_OK && in && in->tip_force) rc = shc_engine_set_tip_force(e, in->tip_force + k * n * e->L * 3, 1);
+    if (rc == SHC_OK && in && in->joint_effort) rc = shc_engine_set_joint_effort(e, in->joint_effort + k * n * e->L * e->NJ, 1);
+    if (rc == SHC_OK) rc = shc_engine_step(e, 1);
+    if (rc == SHC_OK) rc = join_side(e); // (a large batch steps as two halves on the split streams: the copy below is ordered after both)
+    if (rc != SHC_OK) return rc;
+    copy_joint_planes_kernel<<<dim3((unsigned)((slot + 255) / 256)), dim3(256), 0, e->stream>>>(reinterpret_cast<double2 *>(e->k_out) + k * slot,
+                                                                                              reinterpret_cast<const double2 *>(e->st.legd), slot);
+    HIP_TRY(hipGetLastError());
+  }
+  e->k_out_cycles = K;
+  return SHC_OK;
+}
+
 extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_inputs *in) {
   SHC_BUSY_ONLY(e);
   if (!e) return fail(SHC_ERR_INVALID_ARG, "engine is NULL");
@@ -743,21 +770,20 @@ extern "C" int shc_engine_step_k(shc_engine *e, int n_cycles, const shc_cycle_in
     const int rc = effort_live(e);
     if (rc != SHC_OK) return rc;
   }
-  ResidentFit fit{0, 0, 0};
+  ResidentFit fit{0, 0, 0, 0};
   {
     CycleLaunch a{e->st, e->d_consts, &e->cp, e->rt_flags, (e->features & SHC_FEAT_GENERIC_KERNEL) != 0, e->stream, 0, 64, 0, nullptr, &fit, 0};
 #define CALL(L_, NJ_) shc_launch_cycle_##L_##_##NJ_(a)
     SHC_DISPATCH(e->L, e->NJ, CALL);
 #undef CALL
   }
-  if (!fit.supported)
-    return fail(SHC_ERR_UNSUPPORTED, "shc_engine_step_k: this configuration runs on a manual-leg kernel (a leg has been toggled / planner mode), which has no loop form; use shc_engine_step");
   if (size_t(e->NJ) * e->n_slots * 16 * size_t(n_cycles) >= (size_t(1) << 31))
     return fail(SHC_ERR_INVALID_ARG, "shc_engine_step_k: cycles x batch - the output ring must stay below 2 GiB (fewer cycles per launch)");
   {
     const int rc = step_k_out_ring(e, n_cycles);
     if (rc != SHC_OK) return rc;
   }
+  if (!fit.batch || (e->features & SHC_FEAT_STEP_K_SERIAL)) return step_k_serial(e, n_cycles, in);
   e->plan_poser_tips_current = false;
   ResidentArgs A{};
   if (in) {

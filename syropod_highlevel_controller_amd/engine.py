@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 import subprocess
 import sys
 from typing import Optional
@@ -85,10 +86,15 @@ _FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-va
 
 
 def _translation_units():
-    """(object name, source, extra defines): the host side + small kernels, and the fused cycle kernels of each morphology."""
+    """(object name, source, extra defines): the host side + small kernels, and the fused cycle kernels of each morphology - two objects each:
+    the launch forms (part 0) and the loop forms (part 1: resident, batch), so that a build has twice as many units to spread over the cores.
+    SHC_GENERIC_LOOP_FORMS=1 in the environment adds the loop forms of the runtime-flag kernel families (shc_cycle_inst.hip)."""
     tus = [("shc_engine.o", os.path.join(_SRC, "shc_engine.hip"), [])]
+    generic = ["-DSHC_GENERIC_LOOP_FORMS=1"] if os.environ.get("SHC_GENERIC_LOOP_FORMS", "0") not in ("", "0") else []
     for l, nj in MORPHOLOGIES:
-        tus.append((f"shc_cycle_{l}_{nj}.o", os.path.join(_SRC, "shc_cycle_inst.hip"), [f"-DSHC_INST_L={l}", f"-DSHC_INST_NJ={nj}"]))
+        for part, tag in ((0, "launch"), (1, "loop")):
+            tus.append((f"shc_cycle_{l}_{nj}_{tag}.o", os.path.join(_SRC, "shc_cycle_inst.hip"),
+                        [f"-DSHC_INST_L={l}", f"-DSHC_INST_NJ={nj}", f"-DSHC_INST_PART={part}"] + (generic if part == 1 else [])))
     return tus
 
 
@@ -96,7 +102,7 @@ def _source_hash() -> str:
     """Content hash of everything the library is built from (sources, ABI header, flags).  A hash, not mtimes: the in-tree
     .so travels to the GPU box in a snapshot that does not keep modification times."""
     import hashlib
-    h = hashlib.sha256((" ".join(_FLAGS) + repr(MORPHOLOGIES)).encode())
+    h = hashlib.sha256((" ".join(_FLAGS) + repr(MORPHOLOGIES) + repr([(n, d) for n, _, d in _translation_units()])).encode())
     for s in _sources():
         with open(s, "rb") as f:
             h.update(f.read())
@@ -174,7 +180,7 @@ def _build_locked(force, verbose, jobs, resource_report, hipcc, stamp, want):
 
     # longest first: the two BASELINE morphologies carry twice the kernels of the others (feature-exact families, half kernels) and the host side is the
     # third-longest unit; started last they would run alone at the end (measured on 8 cores: 150 s in source order, the longest unit alone 82 s)
-    weight = {"shc_cycle_8_5.o": 0, "shc_cycle_6_3.o": 1, "shc_engine.o": 2}
+    weight = {"shc_cycle_8_5_loop.o": 0, "shc_cycle_8_5_launch.o": 0, "shc_cycle_6_3_loop.o": 1, "shc_cycle_6_3_launch.o": 1, "shc_engine.o": 2}
     todo.sort(key=lambda job: (weight.get(os.path.basename(job[0]), 3), job[0]))
 
     def compile_one(job):
@@ -184,9 +190,12 @@ def _build_locked(force, verbose, jobs, resource_report, hipcc, stamp, want):
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
+        t0 = time.perf_counter()
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         if r.returncode != 0:
             raise subprocess.CalledProcessError(r.returncode, cmd, r.stdout, r.stderr[-4000:])
+        if verbose or os.environ.get("SHC_BUILD_TIMES"):
+            print(f"[shc build] {os.path.basename(obj)} {time.perf_counter() - t0:.1f} s", flush=True)
         with open(obj + ".srchash", "w") as f:
             f.write(th + "\n")
         return r.stderr

@@ -28,6 +28,7 @@ FEAT_ODOMETRY = 2
 FEAT_GENERIC_KERNEL = 1 << 30  # diagnostic: runtime-flag kernel instead of the compile-time specialisation
 FEAT_SINGLE_STREAM = 1 << 28  # diagnostic: no two-stream split of large batches
 FEAT_RESIDENT_ONE_WAVE = 1 << 29  # diagnostic: resident mode without the two-wavefront (walker / model) pipeline
+FEAT_STEP_K_SERIAL = 1 << 27  # diagnostic: shc_engine_step_k as K single launches (the form configurations without a batch kernel take)
 FEAT_DEFAULT = FEAT_TIP_FORCE | FEAT_ODOMETRY  # what shc_engine_create enables
 
 

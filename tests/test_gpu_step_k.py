@@ -38,6 +38,12 @@ def make_case(case):
         return p, 149
     if case == "split_streams":   # enough wavefronts for the two-stream form of the launch (>= 4 096 waves)
         return default_hexapod_params("ripple"), 41000
+    if case.startswith("auto_pose"):   # a runtime-flag (F_DYN) configuration: no batch kernel in the default build - K single launches inside the call
+        p = default_hexapod_params("amble")
+        p.auto_posing = 1
+        return p, 140
+    if case.startswith("serial_"):     # SHC_FEAT_STEP_K_SERIAL on engine B: the serial form where a batch kernel exists
+        return make_case(case[len("serial_"):])
     return synthetic_octopod_params("amble", 4, 4), 130   # generic_4x4: the runtime-flag kernels
 
 
@@ -68,15 +74,20 @@ def step_k_on_device(eng, rows, K):
 
 
 @pytest.mark.parametrize("case", ["config2", "config2_joint_efforts", "config3", "config3_joint_efforts", "octopod", "octopod_joint_efforts", "rough_terrain",
-                                  "rough_terrain_joint_efforts", "generic_4x4", "split_streams", "tip_align", "tip_align_joint_efforts"])
+                                  "rough_terrain_joint_efforts", "generic_4x4", "split_streams", "tip_align", "tip_align_joint_efforts",
+                                  "auto_pose", "auto_pose_joint_efforts", "serial_config3_joint_efforts", "serial_rough_terrain", "serial_split_streams"])
 def test_step_k_is_byte_identical_to_single_cycle_launches(Engine, case):
     """Engine A: setters with row k + shc_engine_step(1), K times.  Engine B: ONE shc_engine_step_k launch over the K-deep device arrays.  q / qd of
     EVERY cycle (the K-deep output ring) and the complete state record at the end are equal byte for byte; the last row stays in force (a further
     plain step on both engines agrees too).  Two launches in a row (the second continues from the first)."""
     rng = np.random.default_rng(77)
     p, n = make_case(case)
-    K = 12 if case != "split_streams" else 5
+    K = 12 if "split_streams" not in case else 5
     a, b = Engine(p, n), Engine(p, n)
+    if case.startswith("serial_"):
+        from syropod_highlevel_controller_amd.params import FEAT_DEFAULT, FEAT_STEP_K_SERIAL
+        b.set_features(FEAT_DEFAULT | FEAT_STEP_K_SERIAL)
+        case = case[len("serial_"):]
     legs, dof = p.leg_count, p.leg_dof[0]
     if "joint_efforts" in case:
         e0 = rng.normal(0, 0.5, (n, legs * dof))
@@ -143,6 +154,47 @@ def test_step_k_edge_shapes(Engine, n, K):
         qb, qdb = b.step_k_joints(k)
         assert qa[k][0].tobytes() == qb.tobytes() and qa[k][1].tobytes() == qdb.tobytes(), (n, K, k)
     assert state_bytes(a) == state_bytes(b)
+    del keep
+    a.close()
+    b.close()
+
+
+def test_step_k_with_a_manual_leg(Engine):
+    """A robot with a MANUAL leg runs on the manual-leg kernels, which have no batch form: shc_engine_step_k serves it as K single launches inside the
+    call - velocity rows per cycle, the manual inputs held like the pose inputs - and lands on the same bytes as the caller's own loop."""
+    p = default_hexapod_params("tripod")
+    n, L, K = 24, p.leg_count, 9
+    rng = np.random.default_rng(11)
+    a, b = Engine(p, n), Engine(p, n)
+    sel = np.array([i % L if i % 3 else -1 for i in range(n)], dtype=np.int32)   # every third robot keeps walking
+    vel = rng.uniform(-0.3, 0.3, (n, 3))
+    for e in (a, b):
+        lin, ang = np.zeros((n, 2)), np.zeros(n)
+        lin[sel < 0], ang[sel < 0] = [0.4, 0.1], 0.3
+        e.set_velocity(lin, ang)
+        e.step(60)
+        pending = sel >= 0
+        for _ in range(2000):
+            if not pending.any():
+                break
+            res = e.toggle_leg_state(np.where(pending, sel, -1).astype(np.int32))
+            pending &= ~((res == 1) | (res == 2))
+        assert not pending.any()
+        e.set_manual_inputs(primary_leg=sel, primary_velocity=vel)
+    rows = input_rows(rng, "config2", p, n, K)
+    rows["lin"][:, sel >= 0], rows["ang"][:, sel >= 0] = 0.0, 0.0
+    qa = []
+    for k in range(K):
+        a.set_velocity(rows["lin"][k], rows["ang"][k])
+        a.step(1)
+        qa.append(a.joints())
+    a.synchronize()
+    keep = step_k_on_device(b, rows, K)
+    for k, (q, qd) in enumerate(qa):
+        qb, qdb = b.step_k_joints(k)
+        assert q.tobytes() == qb.tobytes() and qd.tobytes() == qdb.tobytes(), k
+    assert state_bytes(a) == state_bytes(b)
+    assert np.abs(qa[-1][0] - qa[0][0]).max() > 1e-4   # (the manual legs and the walking robots did move)
     del keep
     a.close()
     b.close()
