@@ -146,11 +146,10 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     if ((ROLE == ROLE_FRONT && p < NJ) || (ROLE == ROLE_BACK && p >= NJ)) continue;
     ld.store(p, double2{flat[2 * p], flat[2 * p + 1]});
   }
-  if (FT::adm(P) && ROLE != ROLE_FRONT) { // (the two-wave kernel's model half receives s.stiff from the walker half before it stores)
-    ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});
+  if (FT::adm(P) && ROLE != ROLE_FRONT && !(SPLIT && ROLE == ROLE_BACK)) { // (the two-wave kernel's model half receives s.stiff from the walker half before it stores;
+    ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});                       //  the model half of a two-LAUNCH cycle stored these right after updateAdmittance: store_admittance_early)
     ld.store(FD::ADM_DELTA / 2, double2{out.adm_delta.x, out.adm_delta.y});
-    if (SPLIT && ROLE == ROLE_BACK) st.legd[leg_field_index(FD::ADM_DELTA + 2, slot, st.n_slots)] = out.adm_delta.z;
-    else ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, s.stiff});
+    ld.store(FD::ADM_DELTA / 2 + 1, double2{out.adm_delta.z, s.stiff});
   }
   if (SPLIT && ROLE == ROLE_FRONT && FT::adm(P) && P.dynamic_stiffness) st.legd[leg_field_index(FD::ADM_DELTA + 3, slot, st.n_slots)] = s.stiff;
   if (FT::tipf(P) && ROLE != ROLE_FRONT) {
@@ -175,6 +174,18 @@ __device__ __forceinline__ void store_leg(const LegRegs<NJ> &s, const LegOut &ou
     }
   }
   if (ROLE != ROLE_BACK) st.legi[slot] = s.word;
+}
+
+// The model half of a two-launch cycle (shc_cycle_half_kernel<..., ROLE_BACK>): admittance state and admittance delta are final once
+// AdmittanceController::updateAdmittance has run, before Model::updateModel - stored there, their ten registers are free during the IK solves (the 8 x 5
+// rotation-constrained model half missed its 256 registers by 21: 84 B of scratch per lane = a fifth of the cycle's algorithmic traffic again).
+template <int NJ>
+__device__ __forceinline__ void store_admittance_early(const LegRegs<NJ> &s, const LegOut &out, const DevState &st, uint32_t slot) {
+  using FD = Fields<NJ>;
+  const LegPlanes ld{reinterpret_cast<double2 *>(st.legd), st.n_slots, slot};
+  ld.store(FD::ADM / 2, double2{s.adm0, s.adm1});
+  ld.store(FD::ADM_DELTA / 2, double2{out.adm_delta.x, out.adm_delta.y});
+  st.legd[leg_field_index(FD::ADM_DELTA + 2, slot, st.n_slots)] = out.adm_delta.z; // (the other 8 bytes of this element: the walker half's published stiffness)
 }
 
 // Robot state lives in HBM as one contiguous tile per wave, [wave][field][RPW] (AoSoA): staging fields [F0, F1) of this
@@ -935,7 +946,10 @@ __device__ __forceinline__ void cycle_wave(const DevState &st, const SharedConst
       if (fb.rot_def) fb.desired_dir = rotate(inverse(bp.r), V3{hand[2].y, hand[3].x, hand[3].y});
     }
     out.adm_delta = V3{0.0, 0.0, 0.0};
-    if (FT::adm(P)) cycle_admittance<NJ>(s, out, P, LegInPlanes<NJ>{st.legd, st.n_slots, slot});
+    if (FT::adm(P)) {
+      cycle_admittance<NJ>(s, out, P, LegInPlanes<NJ>{st.legd, st.n_slots, slot});
+      if (live && !skip) store_admittance_early<NJ>(s, out, st, slot);
+    }
     cycle_back<L, NJ, F>(s, out, C, leg, st.legd, st.n_slots, slot, mr, LegInPlanes<NJ>{st.legd, st.n_slots, slot}, fb);
   } else if (!skip) {
     for (int c = 0; c < n_cycles; ++c)
