@@ -27,7 +27,7 @@ os.makedirs(out_dir, exist_ok=True)
 objs = []
 for oname, src, defines in engine._translation_units():
     obj = os.path.join(engine._OBJ, oname)
-    if oname == f"shc_cycle_{morph[0]}_{morph[1]}.o" or (with_engine and oname == "shc_engine.o"):
+    if oname.startswith(f"shc_cycle_{morph[0]}_{morph[1]}_") or (with_engine and oname == "shc_engine.o"):   # (both objects of the morphology: launch forms, loop forms)
         obj = os.path.join(out_dir, oname)
         flags = list(engine._FLAGS)
         for d in drop:
@@ -41,7 +41,7 @@ for oname, src, defines in engine._translation_units():
         if r.returncode:
             sys.exit(r.stderr[-4000:])
         if report and oname != "shc_engine.o":
-            open(os.path.join(out_dir, "resources.txt"), "w").write(r.stderr)
+            open(os.path.join(out_dir, "resources.txt"), "a").write(r.stderr)
     objs.append(obj)
 so = os.path.join(out_dir, "libshc_batch.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)

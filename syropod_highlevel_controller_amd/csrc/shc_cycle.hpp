@@ -577,6 +577,55 @@ __device__ __forceinline__ double walk_plane_control_candidate(const int own_wor
   return (sp >= 0 && sp <= 1.0) ? smooth_step(sp) : -1.0;
 }
 
+// Robot-level transcendental work with its independent pieces spread over the lanes of the robot's group (every lane of a group computes the
+// same robot-level values from the same bits, so an L-lane group has L - 1 idle copies of every instruction: where a function evaluates the same
+// routine on two or three independent arguments, lanes of different legs take one argument each and the results are shuffled back - the same
+// instructions on the same operands, hence the same bits as the one-lane-does-all form in shc_math.hpp, at a third / two thirds of the issue slots).
+// `leg` is this lane's position in its group (mirror lanes included), L >= 3.
+//
+// quat_to_euler(q, false) - Eigen's eulerAngles(2, 1, 0) + the reference's flip fix-up (standard_includes.h:248-291): r0 = atan2(m10, m00) and
+// r1 = atan2(-m20, +-c2) are independent once the sign of r0 is known, and that is the sign of m10 (atan2(-0, x) is -0 for x >= +0, -pi otherwise);
+// the prediction is checked against the r0 that comes back and the sequential form runs if any lane of the wave disagrees (never observed).
+template <int L>
+__device__ __forceinline__ V3 quat_to_euler_zyx_grouped(Quat q, const Group<L> g, const int leg) {
+  static_assert(L >= 3, "three lanes per robot");
+  double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+  double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  double m00 = 1.0 - (tyy + tzz), m01 = txy - twz, m02 = txz + twy;
+  double m10 = txy + twz, m11 = 1.0 - (txx + tzz), m12 = tyz - twx;
+  double m20 = txz - twy, m21 = tyz + twx, m22 = 1.0 - (txx + tyy);
+  const double c2 = sqrt(m22 * m22 + m21 * m21);
+  const bool neg = m10 < 0.0 || (m10 == 0.0 && __builtin_signbit(m10) && __builtin_signbit(m00));
+  const bool second = leg == 1;
+  const double t = atan2(second ? -m20 : m10, second ? (neg ? -c2 : c2) : m00);
+  double r0 = g.get(t, 0), r1 = g.get(t, 1);
+  if (__builtin_expect(__any((r0 < 0.0) != neg), 0)) r1 = atan2(-m20, r0 < 0.0 ? -c2 : c2);
+  if (r0 < 0.0) r0 += kPi;
+  double s1, c1;
+  sincos_joint(r0, &s1, &c1);
+  double r2 = atan2(s1 * m02 - c1 * m12, c1 * m11 - s1 * m01);
+  if (fabs(r1) > kPi / 2 || fabs(r2) > kPi / 2) {
+    r0 -= kPi;
+    if (r1 > kPi / 2.0) r1 = -r1 + kPi;
+    else if (r1 < kPi / 2.0) r1 = -r1 - kPi;
+    if (r2 > kPi / 2.0) r2 -= kPi;
+    else if (r2 < kPi / 2.0) r2 += kPi;
+  }
+  return V3{r2, r1, r0};
+}
+// euler_to_quat(e, false): the three half-angle sin / cos pairs, one per lane of legs 0 / 1 / 2.
+template <int L>
+__device__ __forceinline__ Quat euler_to_quat_zyx_grouped(V3 e, const Group<L> g, const int leg) {
+  static_assert(L >= 3, "three lanes per robot");
+  double sn, cs;
+  sincos_joint(0.5 * (leg == 0 ? e.x : (leg == 1 ? e.y : e.z)), &sn, &cs);
+  const double sx = g.get(sn, 0), cx = g.get(cs, 0), sy = g.get(sn, 1), cy = g.get(cs, 1), sz = g.get(sn, 2), cz = g.get(cs, 2);
+  Quat qx{cx, sx, 0, 0}, qy{cy, 0, sy, 0}, qz{cz, 0, 0, sz};
+  return (qz * qy) * qx;
+}
+
 // PoseController::updateCurrentPose (pose_controller.cpp:811-859): walk-plane pose, manual / inclination / IMU / auto / tip-align pose
 // composed into Model::current_pose_ (returned, and left in the robot tile's CPOSE; the walk-plane pose in WPP).  `lw`: the packed
 // words of the robot's legs as the previous cycle's updateWalk left them.  The kernels call it inside cycle_front; the two-wavefront
@@ -585,7 +634,7 @@ __device__ __forceinline__ double walk_plane_control_candidate(const int own_wor
 // (`own_word`) with one ballot and one shuffle instead of L shuffles (specialisations without auto posing / tip-align pose only).
 template <int L, int NJ, unsigned F, bool OWN_WORD = false>
 __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L, NJ> &C, const CycleParams &P, const LegConst<NJ> &lc, const RobTile<64 / L> &rb,
-                                           const Group<L> g, const int (&lw)[L], int &rword, const int walk_state, unsigned &dirty, const bool manual_live,
+                                           const Group<L> g, const int leg, const int (&lw)[L], int &rword, const int walk_state, unsigned &dirty, const bool manual_live,
                                            Pose &auto_pose, Pose &leg_auto, const V3 plane_prev, const V3 pnorm_prev, const int swing_c_count_u,
                                            const int own_word = 0, Pose *owpp_cache = nullptr, const double *c_given = nullptr) {
   // swing_c_count_u: UniFlags::swing_c_count; owpp_cache: the origin walk-plane pose (RobotFields::OWPP) kept in registers by a caller that runs
@@ -756,7 +805,11 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
       Quat cur = correct_rotation(rb.getq(R::IMUQ), quat_identity());
       Quat tgt = correct_rotation(manual_r, quat_identity());
       Quat err = normalized(cur * inverse(tgt));
+#ifdef SHC_POSE_R5 // (development A/B: every lane evaluates all three axes)
       V3 pe = quat_to_euler(err, false);
+#else
+      V3 pe = quat_to_euler_zyx_grouped<L>(err, g, leg);
+#endif
       pe.z = 0.0;
       V3 abse = rb.get3(R::ABSE) + pe * P.dt;
       V3 verr = (-rb.get3(R::GYRO)) * 0.15 + rb.get3(R::VERR) * (1 - 0.15);
@@ -771,7 +824,11 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
       if (__any(!tgt_identity)) {
         if (!tgt_identity) corr.z = quat_to_euler(tgt, false).z;
       }
+#ifdef SHC_POSE_R5
       Quat ir = correct_rotation(euler_to_quat(corr, false), tgt);
+#else
+      Quat ir = correct_rotation(euler_to_quat_zyx_grouped<L>(corr, g, leg), tgt);
+#endif
       cp = add_pose(cp, Pose{V3{0, 0, 0}, ir});
     } else if (FT::autop(P)) { // updateAutoPose (:1134-1187)
       int ref = lw[P.auto_pose_reference_leg];
@@ -1016,7 +1073,7 @@ __device__ __forceinline__ void cycle_front(LegRegs<NJ> &s, LegOut &out, const S
   Pose auto_pose = pose_identity();
   Pose leg_auto = pose_identity();
   if (POSE_HERE && !(SHC_DBG(P) & 1)) {
-    cp = cycle_pose<L, NJ, F>(s, C, P, lc, rb, g, lw, rword, walk_state, dirty, manual_live, auto_pose, leg_auto, rb.get3(R::PLANE_PREV), rb.get3(R::PNORM_PREV),
+    cp = cycle_pose<L, NJ, F>(s, C, P, lc, rb, g, leg, lw, rword, walk_state, dirty, manual_live, auto_pose, leg_auto, rb.get3(R::PLANE_PREV), rb.get3(R::PNORM_PREV),
                               fb.uf.swing_c_count);
   } else if (POSE_HERE) {
     cp = rb.getpose(R::CPOSE);

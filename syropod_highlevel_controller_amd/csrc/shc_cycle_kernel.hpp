@@ -1343,7 +1343,7 @@ __global__ void __launch_bounds__(256, 1) shc_resident2_kernel(DevState st, cons
 #ifdef SHC_ABLATE
           if (!(P.debug_skip & 2048))
 #endif
-          (void)cycle_pose<L, NJ, F, true>(s, C, P, C.leg[leg], rb, g, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev, fb.uf.swing_c_count, 0,
+          (void)cycle_pose<L, NJ, F, true>(s, C, P, C.leg[leg], rb, g, leg, lw, rword_unused, 0, dirty, manual_live, ap, la, plane_prev, pnorm_prev, fb.uf.swing_c_count, 0,
                                            &owpp_cache, &pose_c);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();

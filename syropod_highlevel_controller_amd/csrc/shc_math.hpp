@@ -198,7 +198,11 @@ SHC_HD V3 quat_to_euler(Quat q, bool intrinsic) {
       r1 = atan2(-m02, c2);
     }
     double s1, c1;
+#ifdef SHC_POSE_R5 // (development A/B: the round-5 form)
     sincos(r0, &s1, &c1);
+#else
+    sincos_joint(r0, &s1, &c1); // |r0| <= pi: the joint-angle sin / cos (< 1 ulp, a third of ocml's sincos with its large-argument path)
+#endif
     r2 = atan2(s1 * m20 - c1 * m10, c1 * m11 - s1 * m21);
     r0 = -r0;
     r1 = -r1;
@@ -213,7 +217,11 @@ SHC_HD V3 quat_to_euler(Quat q, bool intrinsic) {
       r1 = atan2(-m20, c2);
     }
     double s1, c1;
+#ifdef SHC_POSE_R5 // (development A/B: the round-5 form)
     sincos(r0, &s1, &c1);
+#else
+    sincos_joint(r0, &s1, &c1); // |r0| <= pi: the joint-angle sin / cos (< 1 ulp, a third of ocml's sincos with its large-argument path)
+#endif
     r2 = atan2(s1 * m02 - c1 * m12, c1 * m11 - s1 * m01);
   }
   if (fabs(r1) > kPi / 2 || fabs(r2) > kPi / 2) {
