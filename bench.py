@@ -1092,7 +1092,7 @@ def _also_entry(a):
     row = {"workload": _short(a.get("short") or a.get("workload", "?"), 40), "value": _sig(a.get("value")), "ms_per_step": _sig(a.get("ms_per_step")),
            "frac": _sig(roof.get("frac"), 4), "traffic_ratio": _sig(traffic / alg, 3) if (traffic and alg) else None,
            "valu_issue_frac": _sig(roof.get("valu_issue_frac"), 3), "max_abs_dq": _sig(par.get("max_abs_dq"), 3)}
-    for k in ("form", "launch_value", "launch_frac"):
+    for k in ("form", "launch_value", "launch_frac", "step_k_value"):
         if a.get(k) is not None:
             row[k] = _sig(a[k], 4) if k != "form" else a[k]
     return row
@@ -1199,7 +1199,12 @@ def also_record(name, r, efforts=False):
            "moving_fraction": cfg["moving_fraction"], "mode": cfg["mode"], "two_stream_split": cfg["two_stream_split"], "single_stream": cfg["single_stream"],
            "one_launch_per_cycle_value": cfg["one_launch_per_cycle_value"], "fused_16_cycles_per_launch_value": cfg["fused_16_cycles_per_launch_value"],
            "fused_K_with_per_cycle_inputs": fk or None, "launch": {"value": r["value"], "ms_per_step": r["ms_per_step"], "roofline": r["roofline"], "parity": r["parity"]}}
-    if fk.get("value") and not fk.get("error"):
+    if fk.get("value") and not fk.get("error") and fk["value"] < r["value"]:
+        # the K-cycle form is the slower one here (the 8 x 5 tip-rotation kernel with admittance + IMU posing: its batch kernel runs at one wavefront per
+        # SIMD, the two launches of a cycle at two): the row reports the launch form and carries the step_k figure next to it
+        rec.update({"form": "launch", "value": r["value"], "ms_per_step": r["ms_per_step"], "roofline": r["roofline"], "parity": r["parity"],
+                    "step_k_value": fk["value"]})
+    elif fk.get("value") and not fk.get("error"):
         # batches that do not fit the chip once: K cycles per launch, a new input set in every cycle (shc_engine_step_k), is the form a node would run them in;
         # the one-launch-per-cycle figure is the secondary one (launch_value / launch_frac / launch_traffic_ratio).
         roof = dict(fk["roofline"])
