@@ -265,6 +265,24 @@ def test_config5_bins_and_every_kernel_instantiation(Engine, legs, dof, gait):
                    stop_go_schedule(p, n, legs * 10 + dof, cycles, every=100, pose=True), label=f"{legs}x{dof} {gait}")
 
 
+@pytest.mark.parametrize("legs,dof,gait", [(3, 3, "tripod"), (4, 4, "amble"), (5, 3, "ripple"), (7, 3, "ripple"), (8, 5, "ripple")])
+def test_imu_posing_on_every_group_width(Engine, legs, dof, gait):
+    """PoseController::updateIMUPose spreads its independent atan2 / sin-cos evaluations over the lanes of legs 0, 1, 2 of a robot's group
+    (quat_to_euler_zyx_grouped / euler_to_quat_zyx_grouped, csrc/shc_cycle.hpp): every group width the engine has - three lanes exactly (a tripod: the
+    last lane of the wavefront mirrors leg 0 of the last robot), 4, 5, 7 and 8 - with admittance on top, IMU readings with yaw anywhere in (-pi, pi]
+    (the sign prediction of the yaw's atan2) renewed every 17 cycles, manual pose inputs and resets (a target rotation that is not the identity)."""
+    p = synthetic_octopod_params(gait, dof, legs)
+    p.admittance_control, p.imu_posing = 1, 1
+    p.rotation_pid_gains[:] = [0.2, 0.02, 0.01]
+    n, cycles = 67, 260
+    inp = make_inputs(p, n, 700 + legs, imu=True, force=6.0)
+    sched = stop_go_schedule(p, n, 710 + legs, cycles, every=80, pose=True)
+    for c in range(17, cycles, 17):
+        fresh = make_inputs(p, n, 720 + legs * 100 + c, imu=True)
+        sched.at(c, imu_q=fresh["imu_q"], gyro=fresh["gyro"])
+    teacher_forced(Engine, p, n, inp, cycles, sched, label=f"IMU posing {legs}x{dof} {gait}")
+
+
 # ------------------------------------------------------------------------------------------------ features
 @pytest.mark.parametrize("gait", ["tripod", "wave", "ripple", "amble"])
 def test_manual_pose_resets_stop_and_go(Engine, gait):
