@@ -804,7 +804,14 @@ __device__ __forceinline__ Pose cycle_pose(LegRegs<NJ> &s, const SharedConsts<L,
     if (FT::imu(P)) { // updateIMUPose (:1191-1236)
       Quat cur = correct_rotation(rb.getq(R::IMUQ), quat_identity());
       Quat tgt = correct_rotation(manual_r, quat_identity());
+#ifdef SHC_POSE_R5
       Quat err = normalized(cur * inverse(tgt));
+#else
+      // Quaternion::inverse() = conj / |q|^2.  With |q|^2 == 1.0 exactly - the identity an idle manual pose leaves, above all - every x / 1.0 is x: the four
+      // divisions are skipped while that holds for every robot of the wave (the same bits either way).
+      const double tgt_n2 = dot(tgt, tgt);
+      Quat err = normalized(cur * (__all(tgt_n2 == 1.0) ? conj(tgt) : inverse(tgt)));
+#endif
 #ifdef SHC_POSE_R5 // (development A/B: every lane evaluates all three axes)
       V3 pe = quat_to_euler(err, false);
 #else
